@@ -1,0 +1,68 @@
+"""Input decks for the slice engine (normalised units, explicit Bx/By solver).
+
+Each deck is a plain dict mirroring the keys of the reference's input files that matter to the
+per-slice hot path.  The named decks restate
+
+* ``linear_wake``     -- /root/reference/examples/linear_wake/inputs_normalized
+                         (run as tests/linear_wake.normalized.1Rank.sh:33-36: + ``rho``)
+* ``blowout_wake``    -- /root/reference/examples/blowout_wake/inputs_normalized
+                         (run as tests/blowout_wake_explicit.2Rank.sh:32-35: max_step=1, dt=0)
+* ``beam_in_vacuum``  -- /root/reference/examples/beam_in_vacuum/inputs_normalized
+                         (run as tests/beam_in_vacuum.normalized.Serial.sh:30-34: order 0)
+* ``synthetic(n, nz)``-- the BASELINE.md section 3 benchmark deck (blowout deck scaled to n x n,
+                         ppc 2x2) used by bench.py.
+"""
+import copy
+
+_DEFAULT = dict(
+    nx=64, ny=64, nz=100,
+    lo=(-8.0, -8.0, -6.0), hi=(8.0, 8.0, 6.0),
+    order=2,                 # hipace.depos_order_xy
+    deriv_type=2,            # hipace.depos_derivative_type (Hipace.H:78)
+    plasma_ppc=(1, 1), plasma_density=1.0, plasma_radius=0.0,   # radius 0 -> infinite
+    plasma_charge=-1.0, plasma_mass=1.0,                       # electron, normalised units
+    max_qsa=35.0,            # plasmas.max_qsa_weighting_factor (PlasmaParticleContainer.H:161)
+    n_subcycles=1,
+    beam_profile=0,          # -1 none, 0 gaussian, 1 flattop
+    beam_zmin=-5.9, beam_zmax=5.9, beam_radius=1.2, beam_density=3.0,
+    beam_umean=(0.0, 0.0, 2000.0), beam_pos_mean=(0.0, 0.0, 0.0),
+    beam_pos_std=(0.3, 0.3, 1.41), beam_ppc=(1, 1, 1), beam_charge=-1.0,
+    bc=1,                    # boundary.particle: 0 Reflecting, 1 Periodic, 2 Absorbing
+    mg_tol_rel=1.0e-4,       # hipace.MG_tolerance_rel (Hipace.H:246)
+    mg_tol_abs=2.2250738585072014e-308,   # numeric_limits<double>::min() (Hipace.H:248)
+    deposit_rho=0,
+    n_steps=1,               # max_step + 1; hipace.dt = 0 so the beam never moves
+)
+
+
+def blowout_wake():
+    d = copy.deepcopy(_DEFAULT)
+    d["n_steps"] = 2
+    return d
+
+
+def linear_wake():
+    d = copy.deepcopy(_DEFAULT)
+    d.update(nx=32, ny=32, nz=200, lo=(-10.0, -10.0, -7.5), hi=(10.0, 10.0, 2.0),
+             beam_profile=1, beam_zmin=-1.0, beam_zmax=1.0, beam_radius=3.0, beam_density=0.01,
+             deposit_rho=1)
+    return d
+
+
+def beam_in_vacuum():
+    d = copy.deepcopy(_DEFAULT)
+    d.update(nx=512, ny=768, nz=4, lo=(-200.0, -200.0, -2.0), hi=(200.0, 200.0, 2.0), order=0,
+             plasma_ppc=(0, 0), plasma_density=0.0,
+             beam_profile=1, beam_zmin=-10.0, beam_zmax=10.0, beam_radius=1.0, beam_density=1.0,
+             beam_umean=(0.0, 0.0, 1.0e3), beam_ppc=(2, 2, 1), deposit_rho=1)
+    return d
+
+
+def synthetic(n=1024, nz=1024, ppc=2):
+    """BASELINE.md section 3 / SURVEY 8(d) benchmark deck: blowout deck on n x n x nz, ppc x ppc."""
+    d = copy.deepcopy(_DEFAULT)
+    d.update(nx=n, ny=n, nz=nz, plasma_ppc=(ppc, ppc))
+    return d
+
+
+NAMED = dict(blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum)

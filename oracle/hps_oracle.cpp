@@ -1,0 +1,1225 @@
+// hps_oracle.cpp -- CPU restatement of the HiPACE++ per-zeta-slice hot path.
+//
+// THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg may load this library.  The product path
+// (hipace_amd/csrc + include/hpslice.h) never includes, links or calls anything here.
+//
+// It restates, in plain serial C++ (g++ -O2 -ffp-contract=off), the reference's *serial CPU
+// semantics* of every function on the slice path, citing the reference file:line each routine
+// follows (paths relative to /root/reference/src).  Parity pin: the end-to-end driver at the
+// bottom reproduces the reference's own golden checksums
+//   tests/checksum/benchmarks_json/linear_wake.normalized.1Rank.json
+//   tests/checksum/benchmarks_json/blowout_wake_explicit.2Rank.json
+//   tests/checksum/benchmarks_json/beam_in_vacuum.normalized.Serial.json
+// (copied as data fixtures into tests/golden/), see tests/test_oracle_golden.py.
+// The reference executable itself cannot be built here (AMReX/FFTW are un-vendored
+// network dependencies), so oracle/_ref does not exist; see DESIGN.md.
+//
+// Layout conventions follow the reference: slab components are planes of
+// (nx+2g) x (ny+2g) doubles, x fastest (AMReX Fortran order, utils/GPUUtil.H:99-147).
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <limits>
+#include <vector>
+
+namespace {
+
+using std::size_t;
+typedef double Real;
+
+// ---------------------------------------------------------------------------------------------
+// Shape factors                                  particles/particles_utils/ShapeFactors.H
+// ---------------------------------------------------------------------------------------------
+
+// compute_shape_factor<order>  (ShapeFactors.H:27-108): weights + left-most cell
+int shape_factor (int order, Real* sx, Real xmid)
+{
+    if (order == 0) {
+        const int j = static_cast<int>(std::floor(xmid + 0.5));
+        sx[0] = 1.0;
+        return j;
+    } else if (order == 1) {
+        const int j = static_cast<int>(std::floor(xmid));
+        const Real xint = xmid - j;
+        sx[0] = 1.0 - xint;
+        sx[1] = xint;
+        return j;
+    } else if (order == 2) {
+        const int j = static_cast<int>(std::floor(xmid + 0.5));
+        const Real xint = xmid - j;
+        sx[0] = 0.5*(0.5 - xint)*(0.5 - xint);
+        sx[1] = 0.75 - xint*xint;
+        sx[2] = 0.5*(0.5 + xint)*(0.5 + xint);
+        return j - 1;
+    } else {
+        const int j = static_cast<int>(std::floor(xmid));
+        const Real xint = xmid - j;
+        sx[0] = 1.0/6.0*(1.0 - xint)*(1.0 - xint)*(1.0 - xint);
+        sx[1] = 2.0/3.0 - xint*xint*(1.0 - xint/2.0);
+        sx[2] = 2.0/3.0 - (1.0 - xint)*(1.0 - xint)*(1.0 - 0.5*(1.0 - xint));
+        sx[3] = 1.0/6.0*xint*xint*xint;
+        return j - 1;
+    }
+}
+
+struct DShape { Real s; Real ds; int cell; };
+
+// single_derivative_shape_factor<derivative_type, order>(xmid, ix)  (ShapeFactors.H:211-466)
+// returns {shape, -d(shape)/dx, cell}.  derivative_type: 0 analytic, 1 nodal, 2 centred.
+DShape deriv_shape (int dtype, int order, Real xmid, int ix)
+{
+    Real s = 0, d = 0; int cell = 0;
+    if (dtype == 0) {
+        if (order == 0) {
+            xmid += 0.5; const Real xf = std::floor(xmid);
+            s = 1; d = 0; cell = static_cast<int>(xf);
+        } else if (order == 1) {
+            const Real xf = std::floor(xmid); const Real x = xmid - xf;
+            if (ix == 0) { s = 1 - x; d = -1; } else { s = x; d = 1; }
+            cell = static_cast<int>(xf) + ix;
+        } else if (order == 2) {
+            xmid += 0.5; const Real xf = std::floor(xmid); const Real x = xmid - xf;
+            const Real x2 = x*x;
+            if (ix == 0)      { s = (1.0/2.0)*x2 - 1.0*x + 0.5; d = x - 1.0; }
+            else if (ix == 1) { s = -x2 + 1.0*x + 0.5;          d = 1.0 - 2*x; }
+            else              { s = (1.0/2.0)*x2;               d = x; }
+            cell = static_cast<int>(xf) - 1 + ix;
+        } else {
+            const Real xf = std::floor(xmid); const Real x = xmid - xf;
+            const Real x2 = x*x, x3 = x2*x;
+            if (ix == 0)      { s = -1.0/6.0*x3 + (1.0/2.0)*x2 - 1.0/2.0*x + 1.0/6.0; d = -1.0/2.0*x2 + x - 1.0/2.0; }
+            else if (ix == 1) { s = (1.0/2.0)*x3 - x2 + 2.0/3.0;                      d = (3.0/2.0)*x2 - 2*x; }
+            else if (ix == 2) { s = -1.0/2.0*x3 + (1.0/2.0)*x2 + (1.0/2.0)*x + 1.0/6.0; d = -3.0/2.0*x2 + x + 1.0/2.0; }
+            else              { s = (1.0/6.0)*x3;                                     d = (1.0/2.0)*x2; }
+            cell = static_cast<int>(xf) - 1 + ix;
+        }
+    } else if (dtype == 1) {
+        if (order == 0) {
+            const Real xf = std::floor(xmid); const Real x = xmid - xf;
+            if (ix == 0) { s = (x < 0.5) ? 1 : 0; d = -1; } else { s = (x < 0.5) ? 0 : 1; d = 1; }
+            cell = static_cast<int>(xf) + ix;
+        } else if (order == 1) {
+            xmid += 0.5; const Real xf = std::floor(xmid); const Real x = xmid - xf;
+            if (ix == 0)      { s = (x < 0.5) ? 1.0/2.0 - x : 0;               d = x - 1; }
+            else if (ix == 1) { s = (x < 0.5) ? x + 1.0/2.0 : 3.0/2.0 - x;     d = 1 - 2*x; }
+            else              { s = (x < 0.5) ? 0 : x - 1.0/2.0;               d = x; }
+            cell = static_cast<int>(xf) - 1 + ix;
+        } else if (order == 2) {
+            const Real xf = std::floor(xmid); const Real x = xmid - xf;
+            const Real x2 = x*x;
+            if (ix == 0) {
+                s = (x < 0.5) ? (1.0/2.0)*x2 - 1.0/2.0*x + 1.0/8.0 : 0;
+                d = -1.0/2.0*x2 + x - 1.0/2.0;
+            } else if (ix == 1) {
+                s = (x < 0.5) ? 3.0/4.0 - x2 : (1.0/2.0)*x2 - 3.0/2.0*x + 9.0/8.0;
+                d = (3.0/2.0)*x2 - 2*x;
+            } else if (ix == 2) {
+                s = (x < 0.5) ? (1.0/2.0)*x2 + (1.0/2.0)*x + 1.0/8.0 : -x2 + 2*x - 1.0/4.0;
+                d = -3.0/2.0*x2 + x + 1.0/2.0;
+            } else {
+                s = (x < 0.5) ? 0 : (1.0/2.0)*x2 - 1.0/2.0*x + 1.0/8.0;
+                d = (1.0/2.0)*x2;
+            }
+            cell = static_cast<int>(xf) - 1 + ix;
+        } else {
+            xmid += 0.5; const Real xf = std::floor(xmid); const Real x = xmid - xf;
+            const Real x2 = x*x, x3 = x2*x;
+            if (ix == 0) {
+                s = (x < 0.5) ? -1.0/6.0*x3 + (1.0/4.0)*x2 - 1.0/8.0*x + 1.0/48.0 : 0;
+                d = (1.0/6.0)*x3 - 1.0/2.0*x2 + (1.0/2.0)*x - 1.0/6.0;
+            } else if (ix == 1) {
+                s = (x < 0.5) ? (1.0/2.0)*x3 - 1.0/4.0*x2 - 5.0/8.0*x + 23.0/48.0
+                              : -1.0/6.0*x3 + (3.0/4.0)*x2 - 9.0/8.0*x + 9.0/16.0;
+                d = -2.0/3.0*x3 + (3.0/2.0)*x2 - 1.0/2.0*x - 1.0/2.0;
+            } else if (ix == 2) {
+                s = (x < 0.5) ? -1.0/2.0*x3 - 1.0/4.0*x2 + (5.0/8.0)*x + 23.0/48.0
+                              : (1.0/2.0)*x3 - 7.0/4.0*x2 + (11.0/8.0)*x + 17.0/48.0;
+                d = x3 - 3.0/2.0*x2 - 1.0/2.0*x + 1.0/2.0;
+            } else if (ix == 3) {
+                s = (x < 0.5) ? (1.0/6.0)*x3 + (1.0/4.0)*x2 + (1.0/8.0)*x + 1.0/48.0
+                              : -1.0/2.0*x3 + (5.0/4.0)*x2 - 3.0/8.0*x + 5.0/48.0;
+                d = -2.0/3.0*x3 + (1.0/2.0)*x2 + (1.0/2.0)*x + 1.0/6.0;
+            } else {
+                s = (x < 0.5) ? 0 : (1.0/6.0)*x3 - 1.0/4.0*x2 + (1.0/8.0)*x - 1.0/48.0;
+                d = (1.0/6.0)*x3;
+            }
+            cell = static_cast<int>(xf) - 2 + ix;
+        }
+    } else {
+        if (order == 0) {
+            xmid += 0.5; const Real xf = std::floor(xmid);
+            if (ix == 0)      { s = 0; d = -1.0/2.0; }
+            else if (ix == 1) { s = 1; d = 0; }
+            else              { s = 0; d = 1.0/2.0; }
+            cell = static_cast<int>(xf) - 1 + ix;
+        } else if (order == 1) {
+            const Real xf = std::floor(xmid); const Real x = xmid - xf;
+            if (ix == 0)      { s = 0;     d = (1.0/2.0)*x - 1.0/2.0; }
+            else if (ix == 1) { s = 1 - x; d = -1.0/2.0*x; }
+            else if (ix == 2) { s = x;     d = 1.0/2.0 - 1.0/2.0*x; }
+            else              { s = 0;     d = (1.0/2.0)*x; }
+            cell = static_cast<int>(xf) - 1 + ix;
+        } else if (order == 2) {
+            xmid += 0.5; const Real xf = std::floor(xmid); const Real x = xmid - xf;
+            const Real x2 = x*x;
+            if (ix == 0)      { s = 0;                          d = -1.0/4.0*x2 + (1.0/2.0)*x - 1.0/4.0; }
+            else if (ix == 1) { s = (1.0/2.0)*x2 - x + 1.0/2.0; d = (1.0/2.0)*x2 - 1.0/2.0*x - 1.0/4.0; }
+            else if (ix == 2) { s = -x2 + x + 1.0/2.0;          d = 1.0/4.0 - 1.0/2.0*x; }
+            else if (ix == 3) { s = (1.0/2.0)*x2;               d = -1.0/2.0*x2 + (1.0/2.0)*x + 1.0/4.0; }
+            else              { s = 0;                          d = (1.0/4.0)*x2; }
+            cell = static_cast<int>(xf) - 2 + ix;
+        } else {
+            const Real xf = std::floor(xmid); const Real x = xmid - xf;
+            const Real x2 = x*x, x3 = x2*x;
+            if (ix == 0)      { s = 0; d = (1.0/12.0)*x3 - 1.0/4.0*x2 + (1.0/4.0)*x - 1.0/12.0; }
+            else if (ix == 1) { s = -1.0/6.0*x3 + (1.0/2.0)*x2 - 1.0/2.0*x + 1.0/6.0; d = -1.0/4.0*x3 + (1.0/2.0)*x2 - 1.0/3.0; }
+            else if (ix == 2) { s = (1.0/2.0)*x3 - x2 + 2.0/3.0; d = (1.0/6.0)*x3 - 1.0/2.0*x; }
+            else if (ix == 3) { s = -1.0/2.0*x3 + (1.0/2.0)*x2 + (1.0/2.0)*x + 1.0/6.0; d = (1.0/6.0)*x3 - 1.0/2.0*x2 + 1.0/3.0; }
+            else if (ix == 4) { s = (1.0/6.0)*x3; d = -1.0/4.0*x3 + (1.0/4.0)*x2 + (1.0/4.0)*x + 1.0/12.0; }
+            else              { s = 0; d = (1.0/12.0)*x3; }
+            cell = static_cast<int>(xf) - 2 + ix;
+        }
+    }
+    return {s, -d, cell};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Data views
+// ---------------------------------------------------------------------------------------------
+
+// Array3 view of the field slab (utils/GPUUtil.H:99-147): (i,j,n), i in [-g, nx+g)
+struct Slab {
+    Real* p; int nx, ny, g, ncomp; long js, ns;
+    Real& operator() (int i, int j, int n) const { return p[(i+g) + (long)(j+g)*js + (long)n*ns]; }
+    Real* comp (int n) const { return p + (long)n*ns; }
+};
+
+// Plasma SoA (particles/plasma/PlasmaParticleContainer.H:21-46).  valid = idcpu id sign.
+struct Plasma {
+    Real *x,*y,*w,*ux,*uy,*psi,*x_prev,*y_prev,*ux_half,*uy_half,*psi_half;
+    int32_t* valid; int32_t* ion_lev; long n;
+};
+
+struct Geom {
+    Real dx, dy, dz;          // cell sizes
+    Real xoff, yoff;          // GetPosOffset (fields/Fields.H:71-77)
+    Real c, ep0, mu0, q_e, m_e;
+    Real plo[2], phi[2];      // particle boundary box
+    int bc;                   // 0 Reflecting, 1 Periodic, 2 Absorbing (Hipace.H ParticleBoundary)
+    int normalized;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Plasma current deposition      particles/deposition/PlasmaDepositCurrent.cpp:155-246,
+// serial semantics of            particles/deposition/DepositionUtil.H:256-264
+// comp = {jx, jy, jz, rho, chi, rhomjz}, -1 to skip
+// ---------------------------------------------------------------------------------------------
+long deposit_current (const Slab& f, const Plasma& pl, const Geom& gm, const int* comp,
+                      Real charge, Real mass, int order, Real max_qsa, int can_ionize)
+{
+    const Real dx_inv = 1.0/gm.dx, dy_inv = 1.0/gm.dy, dz_inv = 1.0/gm.dz;
+    const Real invvol = gm.normalized ? gm.dx*gm.dy*dx_inv*dy_inv : dx_inv*dy_inv*dz_inv;
+    const Real clight = gm.c, clightinv = 1.0/gm.c;
+    const Real charge_invvol = charge*invvol;
+    const Real charge_mu0_mass_ratio = charge*gm.mu0/mass;
+    long n_qsa = 0;
+    for (long ip = 0; ip < pl.n; ++ip) {
+        if (!pl.valid[ip]) continue;
+        const Real psi_inv = 1.0/pl.psi[ip];
+        const Real xp = pl.x[ip], yp = pl.y[ip];
+        const Real vx_c = pl.ux[ip]*psi_inv;
+        const Real vy_c = pl.uy[ip]*psi_inv;
+        Real q_invvol = charge_invvol*pl.w[ip];
+        Real q_mu0_mass_ratio = charge_mu0_mass_ratio;
+        if (can_ionize) { q_invvol *= pl.ion_lev[ip]; q_mu0_mass_ratio *= pl.ion_lev[ip]; }
+        const Real xmid = (xp - gm.xoff)*dx_inv;
+        const Real ymid = (yp - gm.yoff)*dy_inv;
+        const Real Aabssqp = 0.0;
+        const Real gamma_psi = 0.5*((1.0 + 0.5*Aabssqp)*psi_inv*psi_inv
+                                    + vx_c*vx_c*clightinv*clightinv
+                                    + vy_c*vy_c*clightinv*clightinv + 1.0);
+        if (gamma_psi < 0.0 || gamma_psi > max_qsa || psi_inv < 0.0) {
+            ++n_qsa; pl.w[ip] = 0.0; pl.valid[ip] = 0; continue;
+        }
+        Real sx[4], sy[4];
+        const int i0 = shape_factor(order, sx, xmid);
+        const int j0 = shape_factor(order, sy, ymid);
+        for (int iy = 0; iy <= order; ++iy) {
+            for (int ix = 0; ix <= order; ++ix) {
+                const int i = i0 + ix, j = j0 + iy;
+                const Real charge_density = q_invvol*sx[ix]*sy[iy];
+                if (comp[0] != -1) {
+                    f(i,j,comp[0]) += charge_density*vx_c;
+                    f(i,j,comp[1]) += charge_density*vy_c;
+                }
+                if (comp[2] != -1) f(i,j,comp[2]) += charge_density*(gamma_psi - 1.0)*clight;
+                if (comp[3] != -1) f(i,j,comp[3]) += charge_density*gamma_psi;
+                if (comp[4] != -1) f(i,j,comp[4]) += charge_density*q_mu0_mass_ratio*psi_inv;
+                if (comp[5] != -1) f(i,j,comp[5]) += charge_density;
+            }
+        }
+    }
+    return n_qsa;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Explicit-solver source deposition     particles/deposition/ExplicitDeposition.cpp:140-261
+// cache = {Bz, Ez, ExmBy, EypBx}; depos = {Sy, Sx}
+// ---------------------------------------------------------------------------------------------
+void explicit_deposit (const Slab& f, const Plasma& pl, const Geom& gm, const int* cache,
+                       const int* depos, Real charge, Real mass, int order, int dtype,
+                       int can_ionize)
+{
+    const Real dx_inv = 1.0/gm.dx, dy_inv = 1.0/gm.dy, dz_inv = 1.0/gm.dz;
+    const Real invvol = gm.normalized ? gm.dx*gm.dy*dx_inv*dy_inv : dx_inv*dy_inv*dz_inv;
+    const Real a_clight = gm.c, clight_inv = 1.0/gm.c;
+    const Real charge_invvol_mu0 = charge*invvol*gm.mu0;
+    const Real charge_mass_ratio = charge/mass;
+    for (long ip = 0; ip < pl.n; ++ip) {
+        if (!pl.valid[ip]) continue;
+        const Real psi_inv = 1.0/pl.psi[ip];
+        const Real xp = pl.x[ip], yp = pl.y[ip];
+        const Real vx = pl.ux[ip]*psi_inv*clight_inv;
+        const Real vy = pl.uy[ip]*psi_inv*clight_inv;
+        Real q_invvol_mu0 = charge_invvol_mu0;
+        Real q_mass_ratio = charge_mass_ratio;
+        if (can_ionize) { q_invvol_mu0 *= pl.ion_lev[ip]; q_mass_ratio *= pl.ion_lev[ip]; }
+        const Real charge_density_mu0 = q_invvol_mu0*pl.w[ip];
+        const Real xmid = (xp - gm.xoff)*dx_inv;
+        const Real ymid = (yp - gm.yoff)*dy_inv;
+        const Real Aabssqp = 0.0;
+        const Real gamma_psi = 0.5*((1.0 + 0.5*Aabssqp)*psi_inv*psi_inv + vx*vx + vy*vy + 1.0);
+        for (int iy = 0; iy <= order + dtype; ++iy) {
+            for (int ix = 0; ix <= order + dtype; ++ix) {
+                if (dtype == 2) {
+                    if ((ix == 0 || ix == order + 2) && (iy == 0 || iy == order + 2)) continue;
+                }
+                const DShape Y = deriv_shape(dtype, order, ymid, iy);
+                const DShape X = deriv_shape(dtype, order, xmid, ix);
+                const int i = X.cell, j = Y.cell;
+                const Real shape_x = X.s, shape_dx = X.ds, shape_y = Y.s, shape_dy = Y.ds;
+                const Real Bz_v = f(i,j,cache[0]);
+                const Real Ez_v = f(i,j,cache[1]);
+                const Real ExmBy_v = f(i,j,cache[2]);
+                const Real EypBx_v = f(i,j,cache[3]);
+                const Real AabssqDxp = 0.0, AabssqDyp = 0.0;
+                f(i,j,depos[0]) += charge_density_mu0*(
+                    - shape_x*shape_y*(
+                        - Bz_v*vx
+                        + ( Ez_v*vy
+                        + ExmBy_v*(          - vx*vy)
+                        + EypBx_v*(gamma_psi - vy*vy) )*clight_inv
+                        - 0.25*AabssqDyp*q_mass_ratio*psi_inv
+                    )*q_mass_ratio*psi_inv
+                    + ( - shape_dx*shape_y*dx_inv*(
+                        - vx*vy
+                    )
+                    - shape_x*shape_dy*dy_inv*(
+                        gamma_psi - vy*vy - 1.0
+                    ))*a_clight);
+                f(i,j,depos[1]) += charge_density_mu0*(
+                    + shape_x*shape_y*(
+                        + Bz_v*vy
+                        + ( Ez_v*vx
+                        + ExmBy_v*(gamma_psi - vx*vx)
+                        + EypBx_v*(          - vx*vy) )*clight_inv
+                        - 0.25*AabssqDxp*q_mass_ratio*psi_inv
+                    )*q_mass_ratio*psi_inv
+                    + ( + shape_dx*shape_y*dx_inv*(
+                        gamma_psi - vx*vx - 1.0
+                    )
+                    + shape_x*shape_dy*dy_inv*(
+                        - vx*vy
+                    ))*a_clight);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Field gather      particles/particles_utils/FieldGather.H:45-96 (doGatherShapeN, nodal
+// derivative of Psi on the fly)
+// ---------------------------------------------------------------------------------------------
+void gather (int order, Real xp, Real yp, Real& ExmByp, Real& EypBxp, Real& Ezp, Real& Bxp,
+             Real& Byp, Real& Bzp, const Slab& f, const int* c, Real dx_inv, Real dy_inv,
+             Real xoff, Real yoff)
+{
+    const Real x = (xp - xoff)*dx_inv;
+    const Real y = (yp - yoff)*dy_inv;
+    const int dtype = 1;
+    for (int iy = 0; iy <= order + dtype; ++iy) {
+        for (int ix = 0; ix <= order + dtype; ++ix) {
+            const DShape Y = deriv_shape(dtype, order, y, iy);
+            const DShape X = deriv_shape(dtype, order, x, ix);
+            const int i = X.cell, j = Y.cell;
+            ExmByp += (X.ds*Y.s)*f(i,j,c[0])*dx_inv;
+            EypBxp += (X.s*Y.ds)*f(i,j,c[0])*dy_inv;
+            Ezp    += (X.s*Y.s)*f(i,j,c[1]);
+            Bxp    += (X.s*Y.s)*f(i,j,c[2]);
+            Byp    += (X.s*Y.s)*f(i,j,c[3]);
+            Bzp    += (X.s*Y.s)*f(i,j,c[4]);
+        }
+    }
+}
+
+// PlasmaMomentumPush<T>  (particles/pusher/PushPlasmaParticles.H:39-75), T = Real or Dual
+struct Dual { Real v, e; };   // utils/DualNumbers.H:13-43
+inline Dual operator+ (Dual a, Dual b) { return {a.v + b.v, a.e + b.e}; }
+inline Dual operator- (Dual a, Dual b) { return {a.v - b.v, a.e - b.e}; }
+inline Dual operator* (Dual a, Dual b) { return {a.v*b.v, a.e*b.v + a.v*b.e}; }
+inline Dual D (Real a) { return {a, 0.0}; }
+
+template <class T> struct Lift;
+template <> struct Lift<Real> { static Real of (Real a) { return a; } };
+template <> struct Lift<Dual> { static Dual of (Real a) { return D(a); } };
+
+template <class T>
+void momentum_push (const T& ux, const T& uy, const T& psi_inv, Real ExmBy, Real EypBx, Real Ez,
+                    Real Bx_c, Real By_c, Real Bz, Real Aabssq, Real ADx, Real ADy,
+                    Real clight_inv, Real qmc, T& dz_ux, T& dz_uy, T& dz_psi)
+{
+    auto L = [] (Real a) { return Lift<T>::of(a); };
+    const T gamma_psi = L(0.5)*psi_inv*psi_inv*(
+                        L(1.0 + Aabssq)
+                        + ux*ux*L(clight_inv*clight_inv)
+                        + uy*uy*L(clight_inv*clight_inv))
+                        + L(0.5);
+    dz_ux = (L(qmc)*(gamma_psi*L(ExmBy) + L(By_c) + (uy*L(Bz))*psi_inv) - L(ADx)*psi_inv);
+    dz_uy = (L(qmc)*(gamma_psi*L(EypBx) - L(Bx_c) - (ux*L(Bz))*psi_inv) - L(ADy)*psi_inv);
+    dz_psi = (L(qmc*clight_inv)*((ux*L(ExmBy) + uy*L(EypBx))*L(clight_inv)*psi_inv - L(Ez)));
+}
+
+// EnforceBC (particles/pusher/GetAndSetPosition.H:29-99); returns true if invalidated
+bool enforce_bc (const Geom& gm, Real& x, Real& y, Real& ux, Real& uy, Real& w, int32_t& valid)
+{
+    if (x < gm.plo[0] || y < gm.plo[1] || x > gm.phi[0] || y > gm.phi[1]) {
+        const Real len_x = gm.phi[0] - gm.plo[0];
+        const Real len_y = gm.phi[1] - gm.plo[1];
+        if (gm.bc == 0) {
+            x = std::fmod(x - gm.plo[0], 2*len_x);
+            if (x < 0) x += 2*len_x;
+            x += gm.plo[0];
+            if (x > gm.phi[0]) { x = 2*gm.phi[0] - x; ux = -ux; }
+            y = std::fmod(y - gm.plo[1], 2*len_y);
+            if (y < 0) y += 2*len_y;
+            y += gm.plo[1];
+            if (y > gm.phi[1]) { y = 2*gm.phi[1] - y; uy = -uy; }
+            return false;
+        } else if (gm.bc == 1) {
+            x = std::fmod(x - gm.plo[0], len_x);
+            if (x < 0) x += len_x;
+            x += gm.plo[0];
+            y = std::fmod(y - gm.plo[1], len_y);
+            if (y < 0) y += len_y;
+            y += gm.plo[1];
+            return false;
+        } else {
+            w = 0.0; valid = 0;
+            return true;
+        }
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// AdvancePlasmaParticles, leapfrog pusher   particles/pusher/PlasmaParticleAdvance.cpp:92-217
+// comp = {Psi, Ez, Bx, By, Bz}
+// ---------------------------------------------------------------------------------------------
+void advance_plasma (const Slab& f, const Plasma& pl, const Geom& gm, const int* comp,
+                     Real charge, Real mass, int order, int temp_slice, int n_subcycles,
+                     int can_ionize)
+{
+    const Real dx_inv = 1.0/gm.dx, dy_inv = 1.0/gm.dy;
+    const Real dz = gm.dz/n_subcycles;
+    const Real clight = gm.c, clight_inv = 1.0/gm.c;
+    const Real charge_mass_clight_ratio = charge/(mass*gm.c);
+    for (long ip = 0; ip < pl.n; ++ip) {
+        if (!pl.valid[ip]) continue;
+        Real ExmByp = 0, EypBxp = 0, Ezp = 0, Bxp = 0, Byp = 0, Bzp = 0;
+        const Real Aabssqp = 0, AabssqDxp = 0, AabssqDyp = 0;
+        Real qmc = charge_mass_clight_ratio;
+        if (can_ionize) qmc *= pl.ion_lev[ip];
+        bool dead = false;
+        for (int isc = 0; isc < n_subcycles && !dead; ++isc) {
+            Real xp = pl.x_prev[ip];
+            Real yp = pl.y_prev[ip];
+            ExmByp = 0; EypBxp = 0; Ezp = 0; Bxp = 0; Byp = 0; Bzp = 0;
+            gather(order, xp, yp, ExmByp, EypBxp, Ezp, Bxp, Byp, Bzp, f, comp,
+                   dx_inv, dy_inv, gm.xoff, gm.yoff);
+            Bxp *= clight;
+            Byp *= clight;
+
+            const int nsub = 4;
+            const Real sdz = dz/nsub;
+            Real ux = pl.ux_half[ip];
+            Real uy = pl.uy_half[ip];
+            Real psi = pl.psi_half[ip];
+
+            auto substep = [&] () {
+                const Real psi_inv = 1.0/psi;
+                Real dz_ux, dz_uy, dz_psi;
+                momentum_push<Real>(ux, uy, psi_inv, ExmByp, EypBxp, Ezp, Bxp, Byp, Bzp,
+                                    Aabssqp, AabssqDxp, AabssqDyp, clight_inv, qmc,
+                                    dz_ux, dz_uy, dz_psi);
+                const Dual ux_d{ux, dz_ux};
+                const Dual uy_d{uy, dz_uy};
+                const Dual psi_inv_d{psi_inv, -psi_inv*psi_inv*dz_psi};
+                Dual ddx, ddy, ddp;
+                momentum_push<Dual>(ux_d, uy_d, psi_inv_d, ExmByp, EypBxp, Ezp, Bxp, Byp, Bzp,
+                                    Aabssqp, AabssqDxp, AabssqDyp, clight_inv, qmc,
+                                    ddx, ddy, ddp);
+                ux += sdz*dz_ux + 0.5*sdz*sdz*ddx.e;
+                uy += sdz*dz_uy + 0.5*sdz*sdz*ddy.e;
+                psi += sdz*dz_psi + 0.5*sdz*sdz*ddp.e;
+            };
+
+            for (int isub = 0; isub < nsub; ++isub) substep();
+
+            xp += dz*clight_inv*(ux*(1.0/psi));
+            yp += dz*clight_inv*(uy*(1.0/psi));
+
+            if (enforce_bc(gm, xp, yp, ux, uy, pl.w[ip], pl.valid[ip])) { dead = true; break; }
+            pl.x[ip] = xp;
+            pl.y[ip] = yp;
+
+            if (!temp_slice) {
+                pl.ux_half[ip] = ux;
+                pl.uy_half[ip] = uy;
+                pl.psi_half[ip] = psi;
+                pl.x_prev[ip] = xp;
+                pl.y_prev[ip] = yp;
+            }
+
+            for (int isub = 0; isub < nsub/2; ++isub) substep();
+
+            pl.ux[ip] = ux;
+            pl.uy[ip] = uy;
+            pl.psi[ip] = psi;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// DST-I Poisson solve  fields/fft_poisson_solver/FFTPoissonSolverDirichletDirect.cpp:51-139
+// (FFTW RODFT00 convention, WrapFFTW.cpp:77-82), here via an own mixed-radix FFT of the odd
+// extension.  Cross-checked against scipy.fft.dstn(type=1) in tests/test_oracle_ops.py.
+// ---------------------------------------------------------------------------------------------
+typedef std::complex<double> cplx;
+
+void fft_rec (int n, int stride, const cplx* in, cplx* out, const std::vector<cplx>& tw, int ntw)
+{
+    // out[k], k<n = sum_m in[m*stride] * W_n^{mk};  tw[k] = exp(-2 pi i k/ntw), ntw % n == 0
+    if (n == 1) { out[0] = in[0]; return; }
+    int p = 2;
+    while (n % p != 0) { ++p; if (p*p > n) { p = n; break; } }
+    if (n % p != 0) p = n;
+    const int m = n/p;
+    if (m == 1) {
+        for (int k = 0; k < n; ++k) {
+            cplx s = 0;
+            for (int r = 0; r < n; ++r) s += in[(long)r*stride]*tw[((long)r*k % n)*(ntw/n)];
+            out[k] = s;
+        }
+        return;
+    }
+    std::vector<cplx> sub((size_t)n);
+    for (int r = 0; r < p; ++r) fft_rec(m, stride*p, in + (long)r*stride, sub.data() + (long)r*m, tw, ntw);
+    for (int k = 0; k < n; ++k) {
+        const int km = k % m;
+        cplx s = 0;
+        for (int r = 0; r < p; ++r) s += sub[(long)r*m + km]*tw[((long)r*k % n)*(ntw/n)];
+        out[k] = s;
+    }
+}
+
+struct DstPlan {
+    int n; int N2; std::vector<cplx> tw; std::vector<cplx> a, b;
+    explicit DstPlan (int n_) : n(n_), N2(2*(n_+1)), tw((size_t)N2), a((size_t)N2), b((size_t)N2) {
+        for (int k = 0; k < N2; ++k) {
+            const double ang = -2.0*M_PI*k/N2;
+            tw[k] = cplx(std::cos(ang), std::sin(ang));
+        }
+    }
+    // in-place RODFT00: X_k = 2 sum_j x_j sin(pi (j+1)(k+1)/(n+1)), strided
+    void apply (double* x, long stride) {
+        a[0] = 0; a[n+1] = 0;
+        for (int j = 0; j < n; ++j) { a[j+1] = x[j*stride]; a[N2-1-j] = -x[j*stride]; }
+        fft_rec(N2, 1, a.data(), b.data(), tw, N2);
+        for (int k = 0; k < n; ++k) x[k*stride] = -b[k+1].imag();
+    }
+};
+
+struct PoissonSolver {
+    int nx, ny; std::vector<double> eig; DstPlan px, py;
+    PoissonSolver (int nx_, int ny_, double dx, double dy)
+        : nx(nx_), ny(ny_), eig((size_t)nx_*ny_), px(nx_), py(ny_)
+    {
+        // eigenvalues incl. normalisation (…DirichletDirect.cpp:58-83)
+        const double dxsq = dx*dx, dysq = dy*dy;
+        const double sxf = M_PI/(2.*(nx + 1)), syf = M_PI/(2.*(ny + 1));
+        const double norm_fac = 0.5/(2*((nx + 1)*(ny + 1)));
+        for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const double sx2 = std::sin((i + 1)*sxf)*std::sin((i + 1)*sxf);
+            const double sy2 = std::sin((j + 1)*syf)*std::sin((j + 1)*syf);
+            eig[(size_t)j*nx + i] = (sx2 != 0 && sy2 != 0)
+                ? norm_fac/(-4.0*(sx2/dxsq + sy2/dysq)) : 0.0;
+        }
+    }
+    // staging (nx*ny, x fastest) is overwritten with the solution
+    void solve (double* st) {
+        bool all_zero = true;   // exact shortcut: a zero source has the zero solution
+        for (size_t k = 0; k < (size_t)nx*ny && all_zero; ++k) all_zero = (st[k] == 0.0);
+        if (all_zero) return;
+        for (int j = 0; j < ny; ++j) px.apply(st + (size_t)j*nx, 1);
+        for (int i = 0; i < nx; ++i) py.apply(st + i, nx);
+        for (size_t k = 0; k < (size_t)nx*ny; ++k) st[k] *= eig[k];
+        for (int j = 0; j < ny; ++j) px.apply(st + (size_t)j*nx, 1);
+        for (int i = 0; i < nx; ++i) py.apply(st + i, nx);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// hpmg::MultiGrid, system type 1            mg_solver/HpMultiGrid.cpp (CPU path)
+//   -acoef*sol + Lap(sol) = rhs, homogeneous Dirichlet, sol/rhs 2 comps, acoef 1 comp
+// gsrb_cached (:595-740) is an exact re-expression of 4 global red-black sweeps (+ residual),
+// so it is restated as global sweeps (gsrb :367-407, gs1 :265-292, residual1 :184-190).
+// ---------------------------------------------------------------------------------------------
+struct MGLevel {
+    int lox, loy, hix, hiy;   // index bounds of the level box (incl. boundary nodes if nodal)
+    int nxb, nyb;             // box lengths
+    std::vector<double> acf, res, cor, rescor;   // acf 1 comp; others 2 comps
+    long idx (int i, int j) const { return (long)(i - lox) + (long)(j - loy)*nxb; }
+    long csz () const { return (long)nxb*nyb; }
+};
+
+struct MG {
+    bool cc; double dx, dy; int nlev; std::vector<MGLevel> L;
+    // external arrays for level 0 (user memory, arbitrary strides, index origin shift)
+    double *sol0, *sol1; const double *rhs0, *rhs1; long ext_js; int ext_shift_i, ext_shift_j;
+
+    MG (int nx, int ny, double dx_, double dy_) : dx(dx_), dy(dy_) {
+        // ctor / level build (HpMultiGrid.cpp:1043-1072)
+        cc = (nx % 2 == 0);
+        int lx = nx, ly = ny;   // cc: number of cells; nodal: box is 0..n+1 => n+2 nodes
+        int hx = cc ? nx - 1 : nx + 1, hy = cc ? ny - 1 : ny + 1;
+        (void)lx; (void)ly;
+        for (int il = 0; il < 31; ++il) {
+            MGLevel lev; lev.lox = 0; lev.loy = 0; lev.hix = hx; lev.hiy = hy;
+            lev.nxb = hx + 1; lev.nyb = hy + 1;
+            lev.acf.assign((size_t)lev.csz(), 0.0);
+            lev.res.assign((size_t)lev.csz()*2, 0.0);
+            lev.cor.assign((size_t)lev.csz()*2, 0.0);
+            lev.rescor.assign((size_t)lev.csz()*2, 0.0);
+            L.push_back(std::move(lev));
+            // coarsenable(2, min_width) (:1065-1072)
+            bool ok;
+            if (cc) {
+                const int nxl = hx + 1, nyl = hy + 1;
+                ok = nxl >= 4 && nyl >= 4 && nxl % 2 == 0 && nyl % 2 == 0;
+                if (ok) { hx = nxl/2 - 1; hy = nyl/2 - 1; }
+            } else {
+                const int nxl = hx + 1, nyl = hy + 1;   // number of nodes
+                ok = nxl >= 8 && nyl >= 8 && hx % 2 == 0 && hy % 2 == 0;
+                if (ok) { hx = hx/2; hy = hy/2; }
+            }
+            if (!ok) break;
+        }
+        nlev = (int)L.size();
+    }
+
+    // valid_domain_box (:20-23)
+    void valid (const MGLevel& l, int& il, int& jl, int& ih, int& jh) const {
+        if (cc) { il = l.lox; jl = l.loy; ih = l.hix; jh = l.hiy; }
+        else    { il = l.lox + 1; jl = l.loy + 1; ih = l.hix - 1; jh = l.hiy - 1; }
+    }
+
+    struct View { double* p; long js; long ns; int oi, oj;   // p(i,j,n)
+        double& operator() (int i, int j, int n) const { return p[(i + oi) + (long)(j + oj)*js + n*ns]; } };
+    struct CView { const double* p; long js; long ns; int oi, oj;
+        const double& operator() (int i, int j, int n) const { return p[(i + oi) + (long)(j + oj)*js + n*ns]; } };
+
+    View lv (MGLevel& l, std::vector<double>& a) const { return {a.data(), l.nxb, l.csz(), 0, 0}; }
+    CView clv (const MGLevel& l, const std::vector<double>& a) const { return {a.data(), l.nxb, l.csz(), 0, 0}; }
+
+    // gs1 (:265-292)
+    inline void gs1 (int i, int j, int n, const MGLevel& l, const View& phi, double rhs,
+                     double acf, double facx, double facy) const {
+        double lap;
+        double c0 = -(acf + 2.0*(facx + facy));
+        if (cc && i == l.lox)      { lap = facx*(4./3.)*phi(i+1,j,n); c0 -= 2.0*facx; }
+        else if (cc && i == l.hix) { lap = facx*(4./3.)*phi(i-1,j,n); c0 -= 2.0*facx; }
+        else                       { lap = facx*(phi(i-1,j,n) + phi(i+1,j,n)); }
+        if (cc && j == l.loy)      { lap += facy*(4./3.)*phi(i,j+1,n); c0 -= 2.0*facy; }
+        else if (cc && j == l.hiy) { lap += facy*(4./3.)*phi(i,j-1,n); c0 -= 2.0*facy; }
+        else                       { lap += facy*(phi(i,j-1,n) + phi(i,j+1,n)); }
+        const double c0_inv = 1.0/c0;
+        phi(i,j,n) = (rhs - lap)*c0_inv;
+    }
+    // laplacian (:162-182) + residual1 (:184-190)
+    inline double residual1 (int i, int j, int n, const MGLevel& l, const View& phi, double rhs,
+                             double acf, double facx, double facy) const {
+        double lap = -2.0*(facx + facy)*phi(i,j,n);
+        if (i == l.lox)      lap += facx*((4./3.)*phi(i+1,j,n) - 2.0*phi(i,j,n));
+        else if (i == l.hix) lap += facx*((4./3.)*phi(i-1,j,n) - 2.0*phi(i,j,n));
+        else                 lap += facx*(phi(i-1,j,n) + phi(i+1,j,n));
+        if (j == l.loy)      lap += facy*((4./3.)*phi(i,j+1,n) - 2.0*phi(i,j,n));
+        else if (j == l.hiy) lap += facy*((4./3.)*phi(i,j-1,n) - 2.0*phi(i,j,n));
+        else                 lap += facy*(phi(i,j-1,n) + phi(i,j+1,n));
+        return rhs + acf*phi(i,j,n) - lap;
+    }
+
+    // gsrb_4_residual<zero_init, do_residual> (:742-848): phi_out = gsrb^4(phi_in or 0); res
+    void gsrb4 (int ilev, bool zero_init, bool do_res, const View& phi_out, const CView& rhs,
+                const View* res, const CView* phi_in, double ldx, double ldy) {
+        MGLevel& l = L[ilev];
+        int il, jl, ih, jh; valid(l, il, jl, ih, jh);
+        const double facx = 1.0/(ldx*ldx), facy = 1.0/(ldy*ldy);
+        const CView acf = clv(l, l.acf);
+        // work on a private zero-padded copy so phi_out's non-valid entries stay untouched
+        const int wx = l.nxb + 2, wy = l.nyb + 2;
+        std::vector<double> wbuf((size_t)wx*wy*2, 0.0);
+        View w{wbuf.data(), wx, (long)wx*wy, 1 - l.lox, 1 - l.loy};
+        if (!zero_init) {
+            for (int n = 0; n < 2; ++n) for (int j = jl; j <= jh; ++j) for (int i = il; i <= ih; ++i)
+                w(i,j,n) = (*phi_in)(i,j,n);
+        }
+        for (int icolor = 0; icolor < 4; ++icolor) {
+            for (int j = jl; j <= jh; ++j) for (int i = il; i <= ih; ++i) {
+                if ((i + j + icolor) % 2 == 0) {
+                    gs1(i, j, 0, l, w, rhs(i,j,0), acf(i,j,0), facx, facy);
+                    gs1(i, j, 1, l, w, rhs(i,j,1), acf(i,j,0), facx, facy);
+                }
+            }
+        }
+        for (int j = jl; j <= jh; ++j) for (int i = il; i <= ih; ++i) {
+            if (do_res) {
+                (*res)(i,j,0) = residual1(i, j, 0, l, w, rhs(i,j,0), acf(i,j,0), facx, facy);
+                (*res)(i,j,1) = residual1(i, j, 1, l, w, rhs(i,j,1), acf(i,j,0), facx, facy);
+            }
+            phi_out(i,j,0) = w(i,j,0);
+            phi_out(i,j,1) = w(i,j,1);
+        }
+    }
+
+    // plain sweep used by the CPU bottom solve (gsrb :367-407)
+    void gsrb_sweep (int ilev, int icolor, const View& phi, const CView& rhs, double ldx, double ldy) {
+        MGLevel& l = L[ilev];
+        int il, jl, ih, jh; valid(l, il, jl, ih, jh);
+        const double facx = 1.0/(ldx*ldx), facy = 1.0/(ldy*ldy);
+        const CView acf = clv(l, l.acf);
+        for (int j = jl; j <= jh; ++j) for (int i = il; i <= ih; ++i) {
+            if ((i + j + icolor) % 2 == 0) {
+                gs1(i, j, 0, l, phi, rhs(i,j,0), acf(i,j,0), facx, facy);
+                gs1(i, j, 1, l, phi, rhs(i,j,1), acf(i,j,0), facx, facy);
+            }
+        }
+    }
+
+    // restriction (:123-138; restrict_cc :29-37, restrict_nd :39-52)
+    void restriction (int ic, std::vector<double>& crse_a, const std::vector<double>& fine_a, int ncomp) {
+        MGLevel& c = L[ic]; const MGLevel& f = L[ic-1];
+        int il, jl, ih, jh; valid(c, il, jl, ih, jh);
+        View crse{crse_a.data(), c.nxb, c.csz(), 0, 0};
+        CView fine{fine_a.data(), f.nxb, f.csz(), 0, 0};
+        for (int n = 0; n < ncomp; ++n) for (int j = jl; j <= jh; ++j) for (int i = il; i <= ih; ++i) {
+            if (cc) {
+                crse(i,j,n) = 0.25*(fine(2*i,2*j,n) + fine(2*i+1,2*j,n) + fine(2*i,2*j+1,n) + fine(2*i+1,2*j+1,n));
+            } else {
+                crse(i,j,n) = (1./16.)*(fine(2*i-1,2*j-1,n) + 2.*fine(2*i,2*j-1,n) + fine(2*i+1,2*j-1,n)
+                                      + 2.*fine(2*i-1,2*j,n) + 4.*fine(2*i,2*j,n) + 2.*fine(2*i+1,2*j,n)
+                                      + fine(2*i-1,2*j+1,n) + 2.*fine(2*i,2*j+1,n) + fine(2*i+1,2*j+1,n));
+            }
+        }
+    }
+
+    static int coarsen2 (int i) { return (i < 0) ? -((-i + 1)/2) : i/2; }
+
+    // interpolation_outofplace (:140-156; interpcpy_cc :88-95, interpcpy_nd :97-121)
+    void interp_copy (int ilev) {
+        MGLevel& f = L[ilev]; MGLevel& c = L[ilev+1];
+        int il, jl, ih, jh; valid(f, il, jl, ih, jh);
+        CView fin = clv(f, f.cor); CView crse = clv(c, c.cor); View fout = lv(f, f.rescor);
+        for (int n = 0; n < 2; ++n) for (int j = jl; j <= jh; ++j) for (int i = il; i <= ih; ++i) {
+            const int ic = coarsen2(i), jc = coarsen2(j);
+            if (cc) {
+                fout(i,j,n) = fin(i,j,n) + crse(ic,jc,n);
+            } else {
+                const bool io = (ic*2 != i), jo = (jc*2 != j);
+                if (io && jo)  fout(i,j,n) = fin(i,j,n) + (crse(ic,jc,n) + crse(ic+1,jc,n) + crse(ic,jc+1,n) + crse(ic+1,jc+1,n))*0.25;
+                else if (io)   fout(i,j,n) = fin(i,j,n) + (crse(ic,jc,n) + crse(ic+1,jc,n))*0.5;
+                else if (jo)   fout(i,j,n) = fin(i,j,n) + (crse(ic,jc,n) + crse(ic,jc+1,n))*0.5;
+                else           fout(i,j,n) = fin(i,j,n) + crse(ic,jc,n);
+            }
+        }
+    }
+
+    View solv () const { return {sol0, ext_js, (long)(sol1 - sol0), ext_shift_i, ext_shift_j}; }
+    CView rhsv () const { return {rhs0, ext_js, (long)(rhs1 - rhs0), ext_shift_i, ext_shift_j}; }
+
+    // vcycle (:1429-1512), CPU: m_single_block_level_begin == m_max_level
+    void vcycle () {
+        const int maxl = nlev - 1;
+        for (int il = 0; il < maxl; ++il) {
+            const double fac = (double)(1 << il);
+            if (il > 0) {
+                View cor = lv(L[il], L[il].cor); View rc = lv(L[il], L[il].rescor);
+                gsrb4(il, true, true, cor, clv(L[il], L[il].res), &rc, nullptr, dx*fac, dy*fac);
+            }
+            restriction(il + 1, L[il+1].res, L[il].rescor, 2);
+        }
+        bottomsolve();
+        for (int il = maxl - 1; il >= 0; --il) {
+            const double fac = (double)(1 << il);
+            interp_copy(il);
+            CView pin = clv(L[il], L[il].rescor);
+            if (il == 0) gsrb4(0, false, false, solv(), rhsv(), nullptr, &pin, dx*fac, dy*fac);
+            else { View cor = lv(L[il], L[il].cor);
+                   gsrb4(il, false, false, cor, clv(L[il], L[il].res), nullptr, &pin, dx*fac, dy*fac); }
+        }
+        View cor0 = lv(L[0], L[0].cor); View rc0 = lv(L[0], L[0].rescor);
+        View s = solv(); CView sin{s.p, s.js, s.ns, s.oi, s.oj};
+        gsrb4(0, false, true, cor0, rhsv(), &rc0, &sin, dx, dy);
+    }
+
+    // bottomsolve, CPU branch (:1583-1593)
+    void bottomsolve () {
+        const int il = nlev - 1;
+        const double fac = (double)(1 << il);
+        std::fill(L[il].cor.begin(), L[il].cor.end(), 0.0);
+        const int nsweeps = 16;
+        const int numsweeps = std::max(nsweeps, (std::max(L[il].nxb, L[il].nyb) + 1)/2*2);
+        View cor = lv(L[il], L[il].cor);
+        for (int is = 0; is < numsweeps; ++is) gsrb_sweep(il, is, cor, clv(L[il], L[il].res), dx*fac, dy*fac);
+    }
+
+    // average_down_acoef (:1640-1700)
+    void average_down_acoef () {
+        for (int il = 1; il < nlev; ++il) restriction(il, L[il].acf, L[il-1].acf, 1);
+    }
+
+    // solve1 (:1169-1190) + solve_doit (:1307-1427).  Arrays are slab components with guards:
+    // p(i,j) = base[(i+g) + (j+g)*js].  Returns number of V-cycles, or -1 on failure.
+    int solve1 (double* sol_c0, double* sol_c1, const double* rhs_c0, const double* rhs_c1,
+                const double* acf_c, long js, int g, double tol_rel, double tol_abs, int maxiter,
+                double* resnorm_out) {
+        // center_box (HpMultiGrid.H:168-175): user cell i -> level index i + sh
+        const int sh = cc ? 0 : 1;
+        sol0 = sol_c0; sol1 = sol_c1; rhs0 = rhs_c0; rhs1 = rhs_c1; ext_js = js;
+        ext_shift_i = g - sh; ext_shift_j = g - sh;
+        MGLevel& l0 = L[0];
+        for (int j = l0.loy; j <= l0.hiy; ++j) for (int i = l0.lox; i <= l0.hix; ++i)
+            l0.acf[l0.idx(i,j)] = acf_c[(i - sh + g) + (long)(j - sh + g)*js];
+        average_down_acoef();
+
+        View cor0 = lv(l0, l0.cor); View rc0 = lv(l0, l0.rescor);
+        View s = solv(); CView sin{s.p, s.js, s.ns, s.oi, s.oj};
+        gsrb4(0, false, true, cor0, rhsv(), &rc0, &sin, dx, dy);
+
+        int il, jl, ih, jh; valid(l0, il, jl, ih, jh);
+        double resnorm0 = 0, rhsnorm0 = 0;
+        { CView r = rhsv();
+          for (int n = 0; n < 2; ++n) for (int j = jl; j <= jh; ++j) for (int i = il; i <= ih; ++i) {
+              resnorm0 = std::max(resnorm0, std::abs(rc0(i,j,n)));
+              rhsnorm0 = std::max(rhsnorm0, std::abs(r(i,j,n)));
+          } }
+        const double max_norm = (rhsnorm0 >= resnorm0) ? rhsnorm0 : resnorm0;
+        const double res_target = std::max(tol_abs, std::max(tol_rel, 1.e-16)*max_norm);
+        int iters = 0;
+        double norminf = resnorm0;
+        if (resnorm0 > res_target) {
+            bool converged = true;
+            for (int iter = 0; iter < maxiter; ++iter) {
+                converged = false;
+                vcycle();
+                ++iters;
+                norminf = 0;
+                for (size_t k = 0; k < l0.rescor.size(); ++k) norminf = std::max(norminf, std::abs(l0.rescor[k]));
+                converged = (norminf <= res_target);
+                if (converged) break;
+                if (norminf > 1.e20*max_norm) return -1;
+            }
+            if (!converged) return -1;
+        }
+        View so = solv();
+        for (int n = 0; n < 2; ++n) for (int j = jl; j <= jh; ++j) for (int i = il; i <= ih; ++i)
+            so(i,j,n) = cor0(i,j,n);
+        if (resnorm_out) *resnorm_out = norminf;
+        return iters;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Slice engine: slab bookkeeping + SolveOneSlice for the explicit solver
+// ---------------------------------------------------------------------------------------------
+
+// Explicit-mode component order (fields/Fields.cpp:70-122), without laser / chi2 / salame
+enum Comp { N_jxb = 0, N_jyb, chi, Sy, Sx, ExmBy, EypBx, Ez, Bx, By, Bz, Psi,
+            jxb, jyb, jzb, jx, jy, rhomjz, P_jxb, P_jyb, Ion_rhomjz, rho /* optional */, NCOMP_MAX };
+
+struct Deck {
+    int nx, ny, nz; double lo[3], hi[3]; int order; int deriv_type;
+    int plasma_ppc[2]; double plasma_density; double plasma_radius;  // radius<=0 -> infinity
+    double plasma_charge, plasma_mass; double max_qsa; int n_subcycles;
+    int beam_profile;           // -1 none, 0 gaussian, 1 flattop
+    double beam_zmin, beam_zmax, beam_radius, beam_density;
+    double beam_umean[3], beam_pos_mean[3], beam_pos_std[3]; int beam_ppc[3];
+    double beam_charge;
+    int bc;                      // particle boundary
+    double mg_tol_rel, mg_tol_abs;
+    int deposit_rho;
+    int n_steps;                 // max_step + 1 (dt = 0: every step identical)
+};
+
+struct Beam { std::vector<double> x, y, z, ux, uy, uz, w; };
+
+struct Engine {
+    Deck d; Geom gm; int g; int ncomp;
+    std::vector<double> slab_data; Slab slab;
+    std::vector<double> pdata; std::vector<int32_t> pvalid, pion; Plasma pl;
+    PoissonSolver* ps; MG* mg; std::vector<double> staging;
+    Beam beam_this, beam_next;
+    std::vector<double> checksum;      // per comp: sum |Q| over all valid cells and slices
+    long total_vcycles; long n_qsa_total;
+    double t_deposit, t_explicit, t_push, t_poisson, t_mg, t_other;
+
+    explicit Engine (const Deck& dk) : d(dk), ps(nullptr), mg(nullptr) {
+        // Fields::AllocData guards (fields/Fields.cpp:63-64)
+        g = (d.order + 1)/2 + 1;
+        ncomp = d.deposit_rho ? 22 : 21;
+        gm.dx = (d.hi[0] - d.lo[0])/d.nx; gm.dy = (d.hi[1] - d.lo[1])/d.ny; gm.dz = (d.hi[2] - d.lo[2])/d.nz;
+        gm.xoff = 0.5*(d.lo[0] + d.hi[0] - gm.dx*(d.nx - 1));
+        gm.yoff = 0.5*(d.lo[1] + d.hi[1] - gm.dy*(d.ny - 1));
+        gm.c = 1; gm.ep0 = 1; gm.mu0 = 1; gm.q_e = 1; gm.m_e = 1;   // make_constants_normalized
+        gm.plo[0] = d.lo[0]; gm.plo[1] = d.lo[1]; gm.phi[0] = d.hi[0]; gm.phi[1] = d.hi[1];
+        gm.bc = d.bc; gm.normalized = 1;
+        const long js = d.nx + 2*g, ns = js*(d.ny + 2*g);
+        slab_data.assign((size_t)ns*ncomp, 0.0);
+        slab = Slab{slab_data.data(), d.nx, d.ny, g, ncomp, js, ns};
+        ps = new PoissonSolver(d.nx, d.ny, gm.dx, gm.dy);
+        mg = new MG(d.nx, d.ny, gm.dx, gm.dy);
+        staging.assign((size_t)d.nx*d.ny, 0.0);
+        checksum.assign((size_t)ncomp, 0.0);
+        total_vcycles = 0; n_qsa_total = 0;
+        t_deposit = t_explicit = t_push = t_poisson = t_mg = t_other = 0;
+        pl.n = 0;
+    }
+    ~Engine () { delete ps; delete mg; }
+
+    void zero_comp (int n) { std::fill(slab.comp(n), slab.comp(n) + slab.ns, 0.0); }
+    void copy_comp (int dst, int src) { std::memcpy(slab.comp(dst), slab.comp(src), sizeof(double)*slab.ns); }
+
+    // PlasmaParticleContainer::InitParticles (plasma/PlasmaParticleContainerInit.cpp:17-378),
+    // fixed ppc, uniform density, no fine patch, u = 0; ppc index outermost (:192)
+    void init_plasma () {
+        const int nppc = d.plasma_ppc[0]*d.plasma_ppc[1];
+        const double scale = nppc <= 0 ? 0. : 1.0/nppc;
+        const double rad = d.plasma_radius > 0 ? d.plasma_radius : std::numeric_limits<double>::infinity();
+        std::vector<double> xs, ys;
+        for (int ip = 0; ip < nppc; ++ip) {
+            const int ixp = ip % d.plasma_ppc[0], iyp = ip / d.plasma_ppc[0];
+            const double r0 = (0.5 + ixp)/d.plasma_ppc[0], r1 = (0.5 + iyp)/d.plasma_ppc[1];
+            for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i) {
+                const double x = d.lo[0] + (i + r0)*gm.dx;
+                const double y = d.lo[1] + (j + r1)*gm.dy;
+                const double rsq = x*x + y*y;
+                if (x >= gm.phi[0] || x < gm.plo[0] || y >= gm.phi[1] || y < gm.plo[1] ||
+                    rsq > rad*rad || d.plasma_density <= 0.0) continue;
+                xs.push_back(x); ys.push_back(y);
+            }
+        }
+        const long n = (long)xs.size();
+        pdata.assign((size_t)n*11, 0.0); pvalid.assign((size_t)n, 1); pion.assign((size_t)n, 0);
+        double* b = pdata.data();
+        pl = Plasma{b, b+n, b+2*n, b+3*n, b+4*n, b+5*n, b+6*n, b+7*n, b+8*n, b+9*n, b+10*n,
+                    pvalid.data(), pion.data(), n};
+        for (long k = 0; k < n; ++k) {
+            pl.x[k] = xs[k]; pl.y[k] = ys[k]; pl.w[k] = d.plasma_density*scale;
+            pl.ux[k] = 0; pl.uy[k] = 0; pl.psi[k] = std::sqrt(1.0) - 0.0;
+            pl.x_prev[k] = xs[k]; pl.y_prev[k] = ys[k];
+            pl.ux_half[k] = 0; pl.uy_half[k] = 0; pl.psi_half[k] = pl.psi[k];
+        }
+    }
+
+    double beam_density (double x, double y, double z) const {
+        // GetInitialDensity (particles/profiles/GetInitialDensity.H:33-51)
+        if (d.beam_profile == 0) {
+            const double ddx = (x - d.beam_pos_mean[0])/d.beam_pos_std[0];
+            const double ddy = (y - d.beam_pos_mean[1])/d.beam_pos_std[1];
+            const double ddz = (z - d.beam_pos_mean[2])/d.beam_pos_std[2];
+            return d.beam_density*std::exp(-0.5*ddx*ddx)*std::exp(-0.5*ddy*ddy)*std::exp(-0.5*ddz*ddz);
+        }
+        return d.beam_density;
+    }
+
+    // InitBeamFixedPPCSlice (beam/BeamParticleContainerInit.cpp:198-346)
+    void init_beam_slice (int islice, Beam& b) const {
+        b = Beam();
+        if (d.beam_profile < 0) return;
+        const int nppc = d.beam_ppc[0]*d.beam_ppc[1]*d.beam_ppc[2];
+        const double scale = 1.0/nppc;
+        const int ny_p = d.beam_ppc[1], nz_p = d.beam_ppc[2];
+        for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i) {
+            for (int ip = 0; ip < nppc; ++ip) {
+                // get_position_unit_cell (particles_utils/ParticleUtil.H:49-63)
+                const int ixp = ip/(ny_p*nz_p), iyp = (ip % (ny_p*nz_p)) % ny_p, izp = (ip % (ny_p*nz_p))/ny_p;
+                const double r0 = (0.5 + ixp)/d.beam_ppc[0], r1 = (0.5 + iyp)/d.beam_ppc[1], r2 = (0.5 + izp)/d.beam_ppc[2];
+                const double x = d.lo[0] + (i + r0)*gm.dx;
+                const double y = d.lo[1] + (j + r1)*gm.dy;
+                const double z = d.lo[2] + (islice + r2)*gm.dz;
+                if (z >= d.beam_zmax || z < d.beam_zmin ||
+                    ((x - d.beam_pos_mean[0])*(x - d.beam_pos_mean[0]) + (y - d.beam_pos_mean[1])*(y - d.beam_pos_mean[1]))
+                        > d.beam_radius*d.beam_radius) continue;
+                const double dens = beam_density(x, y, z);
+                if (dens <= 0.0) continue;
+                b.x.push_back(x); b.y.push_back(y); b.z.push_back(z);
+                b.ux.push_back(d.beam_umean[0]*gm.c); b.uy.push_back(d.beam_umean[1]*gm.c); b.uz.push_back(d.beam_umean[2]*gm.c);
+                b.w.push_back(std::abs(dens*scale));
+            }
+        }
+    }
+
+    // DepositCurrentSlice for beams (deposition/BeamDepositCurrent.cpp:21-195)
+    void deposit_beam (const Beam& b, int cjx, int cjy, int cjz) {
+        const double dxi = 1.0/gm.dx, dyi = 1.0/gm.dy;
+        const double invvol = 1.0;   // normalised, lev 0
+        const double clightsq = 1.0/(gm.c*gm.c);
+        const double q = d.beam_charge;
+        for (size_t ip = 0; ip < b.x.size(); ++ip) {
+            const double ux = b.ux[ip], uy = b.uy[ip], uz = b.uz[ip];
+            const double gaminv = 1.0/std::sqrt(1.0 + ux*ux*clightsq + uy*uy*clightsq + uz*uz*clightsq);
+            const double wq = q*b.w[ip]*invvol;
+            const double vx = ux*gaminv, vy = uy*gaminv, vz = uz*gaminv;
+            const double wqx = wq*vx, wqy = wq*vy, wqz = wq*vz;
+            double sx[4], sy[4];
+            const int i0 = shape_factor(d.order, sx, (b.x[ip] - gm.xoff)*dxi);
+            const int j0 = shape_factor(d.order, sy, (b.y[ip] - gm.yoff)*dyi);
+            for (int iy = 0; iy <= d.order; ++iy) for (int ix = 0; ix <= d.order; ++ix) {
+                if (cjx != -1) { slab(i0+ix, j0+iy, cjx) += sx[ix]*sy[iy]*wqx;
+                                 slab(i0+ix, j0+iy, cjy) += sx[ix]*sy[iy]*wqy; }
+                if (cjz != -1) slab(i0+ix, j0+iy, cjz) += sx[ix]*sy[iy]*wqz;
+            }
+        }
+    }
+
+    // Multiply / LinCombination onto the staging area (fields/Fields.cpp:368-411), valid box only
+    void poisson_to (int dst_comp) {
+        ps->solve(staging.data());
+        for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i)
+            slab(i,j,dst_comp) = staging[(size_t)j*d.nx + i];
+    }
+
+    // SolvePoissonPsiExmByEypBxEzBz (fields/Fields.cpp:840-957)
+    void solve_psi_ez_bz () {
+        const double dxi2 = 0.5*(1.0/gm.dx), dyi2 = 0.5*(1.0/gm.dy);
+        const int nx = d.nx, ny = d.ny;
+        for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i)
+            staging[(size_t)j*nx + i] = (-1.0/gm.ep0)*slab(i,j,rhomjz);
+        poisson_to(Psi);
+        const double fa = 1.0/(gm.ep0*gm.c);
+        for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i)
+            staging[(size_t)j*nx + i] = fa*((slab(i+1,j,jx) - slab(i-1,j,jx))*dxi2)
+                                      + fa*((slab(i,j+1,jy) - slab(i,j-1,jy))*dyi2);
+        poisson_to(Ez);
+        for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i)
+            staging[(size_t)j*nx + i] = gm.mu0*((slab(i,j+1,jx) - slab(i,j-1,jx))*dyi2)
+                                      + (-gm.mu0)*((slab(i+1,j,jy) - slab(i-1,j,jy))*dxi2);
+        poisson_to(Bz);
+        // ExmBy = -d/dx Psi, EypBx = -d/dy Psi on the box grown by (guards-1) (:931-956)
+        const int gg = g - 1;
+        for (int j = -gg; j < ny + gg; ++j) for (int i = -gg; i < nx + gg; ++i) {
+            slab(i,j,ExmBy) = -(slab(i+1,j,Psi) - slab(i-1,j,Psi))*dxi2;
+            slab(i,j,EypBx) = -(slab(i,j+1,Psi) - slab(i,j-1,Psi))*dyi2;
+        }
+    }
+
+    // InitializeSxSyWithBeam (Hipace.cpp:744-790)
+    void init_sxsy_with_beam () {
+        for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i) {
+            const double dx_jzb = (slab(i+1,j,jzb) - slab(i-1,j,jzb))/(2.0*gm.dx);
+            const double dy_jzb = (slab(i,j+1,jzb) - slab(i,j-1,jzb))/(2.0*gm.dy);
+            const double dz_jxb = (slab(i,j,P_jxb) - slab(i,j,N_jxb))/(2.0*gm.dz);
+            const double dz_jyb = (slab(i,j,P_jyb) - slab(i,j,N_jyb))/(2.0*gm.dz);
+            slab(i,j,Sy) =   gm.mu0*(-dy_jzb + dz_jyb);
+            slab(i,j,Sx) = - gm.mu0*(-dx_jzb + dz_jxb);
+        }
+    }
+
+    static double now () {
+        struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9*ts.tv_nsec;
+    }
+
+    // Hipace::SolveOneSlice, explicit branch (Hipace.cpp:556-728)
+    void solve_one_slice (int islice, bool accumulate) {
+        double t0 = now();
+        if (islice == d.nz - 1) init_beam_slice(islice, beam_this);
+        // InitializeSlices (fields/Fields.cpp:535-586)
+        for (int c : {(int)chi, (int)Sy, (int)Sx, (int)ExmBy, (int)EypBx, (int)jzb, (int)rhomjz, (int)N_jxb, (int)N_jyb}) zero_comp(c);
+        if (d.deposit_rho) zero_comp(rho);
+        double t1 = now(); t_other += t1 - t0;
+        // plasma deposit jx jy [rho] chi rhomjz (Hipace.cpp:609-610)
+        { const int comp[6] = {jx, jy, -1, d.deposit_rho ? (int)rho : -1, chi, rhomjz};
+          n_qsa_total += deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0); }
+        double t2 = now(); t_deposit += t2 - t1;
+        deposit_beam(beam_this, -1, -1, jzb);
+        // AddRhoIons (fields/Fields.cpp:606-615)
+        for (long k = 0; k < slab.ns; ++k) slab.comp(rhomjz)[k] += slab.comp(Ion_rhomjz)[k];
+        if (d.deposit_rho) for (long k = 0; k < slab.ns; ++k) slab.comp(rho)[k] += slab.comp(Ion_rhomjz)[k];
+        double t3 = now(); t_other += t3 - t2;
+        solve_psi_ez_bz();
+        double t4 = now(); t_poisson += t4 - t3;
+        if (islice - 1 >= 0) init_beam_slice(islice - 1, beam_next); else beam_next = Beam();
+        deposit_beam(beam_next, N_jxb, N_jyb, -1);
+        init_sxsy_with_beam();
+        double t5 = now(); t_other += t5 - t4;
+        { const int cache[4] = {Bz, Ez, ExmBy, EypBx}; const int depos[2] = {Sy, Sx};
+          explicit_deposit(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0); }
+        double t6 = now(); t_explicit += t6 - t5;
+        // ExplicitMGSolveBxBy (Hipace.cpp:793-933)
+        { const int it = mg->solve1(slab.comp(Bx), slab.comp(By), slab.comp(Sy), slab.comp(Sx), slab.comp(chi),
+                                    slab.js, g, d.mg_tol_rel, d.mg_tol_abs, 200, nullptr);
+          if (it < 0) { std::fprintf(stderr, "oracle: hpmg failed at slice %d\n", islice); std::abort(); }
+          total_vcycles += it; }
+        double t7 = now(); t_mg += t7 - t6;
+        if (accumulate) {
+            for (int n = 0; n < ncomp; ++n) {
+                double s = 0;
+                for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i) s += std::abs(slab(i,j,n));
+                checksum[n] += s;
+            }
+        }
+        double t8 = now(); t_other += t8 - t7;
+        { const int comp[5] = {Psi, Ez, Bx, By, Bz};
+          advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0); }
+        double t9 = now(); t_push += t9 - t8;
+        // ShiftSlices (fields/Fields.cpp:588-604)
+        copy_comp(P_jxb, jxb); copy_comp(P_jyb, jyb);
+        copy_comp(jxb, N_jxb); copy_comp(jyb, N_jyb); copy_comp(jx, N_jxb); copy_comp(jy, N_jyb);
+        beam_this = beam_next;
+        t_other += now() - t9;
+    }
+
+    // start of one time step (Hipace::Evolve, Hipace.cpp:401-471)
+    void begin_step () {
+        std::fill(slab_data.begin(), slab_data.end(), 0.0);     // ResetAllQuantities
+        init_plasma();
+        // DepositNeutralizingBackground (plasma/MultiPlasma.cpp:106-118): rhomjz only, charge -q
+        const int comp[6] = {-1, -1, -1, -1, -1, Ion_rhomjz};
+        deposit_current(slab, pl, gm, comp, -d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0);
+        std::fill(checksum.begin(), checksum.end(), 0.0);
+    }
+
+    void run () {
+        for (int step = 0; step < d.n_steps; ++step) {
+            begin_step();
+            for (int isl = d.nz - 1; isl >= 0; --isl) solve_one_slice(isl, true);
+        }
+    }
+};
+
+} // namespace
+
+// =============================================================================================
+// C ABI for ctypes (tests, smoke, bench cpu_baseline only)
+// =============================================================================================
+extern "C" {
+
+int orc_shape_factor (int order, double xmid, double* s_out) { return shape_factor(order, s_out, xmid); }
+
+int orc_deriv_shape (int dtype, int order, double xmid, int ix, double* s, double* ds) {
+    const DShape r = deriv_shape(dtype, order, xmid, ix); *s = r.s; *ds = r.ds; return r.cell;
+}
+
+struct orc_slab { double* p; int nx, ny, g, ncomp; };
+struct orc_plasma { double *x,*y,*w,*ux,*uy,*psi,*x_prev,*y_prev,*ux_half,*uy_half,*psi_half;
+                    int32_t* valid; int32_t* ion_lev; long n; };
+struct orc_geom { double dx, dy, dz, xoff, yoff, c, ep0, mu0, q_e, m_e; double plo[2], phi[2]; int bc; int normalized; };
+
+static Slab mk_slab (orc_slab s) { const long js = s.nx + 2*s.g; return Slab{s.p, s.nx, s.ny, s.g, s.ncomp, js, js*(s.ny + 2*s.g)}; }
+static Plasma mk_pl (orc_plasma p) { return Plasma{p.x,p.y,p.w,p.ux,p.uy,p.psi,p.x_prev,p.y_prev,p.ux_half,p.uy_half,p.psi_half,p.valid,p.ion_lev,p.n}; }
+static Geom mk_geom (orc_geom g) { Geom r; r.dx=g.dx; r.dy=g.dy; r.dz=g.dz; r.xoff=g.xoff; r.yoff=g.yoff; r.c=g.c; r.ep0=g.ep0; r.mu0=g.mu0; r.q_e=g.q_e; r.m_e=g.m_e;
+    r.plo[0]=g.plo[0]; r.plo[1]=g.plo[1]; r.phi[0]=g.phi[0]; r.phi[1]=g.phi[1]; r.bc=g.bc; r.normalized=g.normalized; return r; }
+
+long orc_deposit_current (orc_slab s, orc_plasma p, orc_geom g, const int* comp, double q, double m, int order, double max_qsa) {
+    return deposit_current(mk_slab(s), mk_pl(p), mk_geom(g), comp, q, m, order, max_qsa, 0);
+}
+void orc_explicit_deposit (orc_slab s, orc_plasma p, orc_geom g, const int* cache, const int* depos, double q, double m, int order, int dtype) {
+    explicit_deposit(mk_slab(s), mk_pl(p), mk_geom(g), cache, depos, q, m, order, dtype, 0);
+}
+void orc_advance_plasma (orc_slab s, orc_plasma p, orc_geom g, const int* comp, double q, double m, int order, int temp_slice, int n_subcycles) {
+    advance_plasma(mk_slab(s), mk_pl(p), mk_geom(g), comp, q, m, order, temp_slice, n_subcycles, 0);
+}
+void orc_gather (orc_slab s, orc_geom g, const int* comp, int order, double xp, double yp, double* out6) {
+    double a=0,b=0,c=0,d=0,e=0,f=0;
+    gather(order, xp, yp, a, b, c, d, e, f, mk_slab(s), comp, 1.0/g.dx, 1.0/g.dy, g.xoff, g.yoff);
+    out6[0]=a; out6[1]=b; out6[2]=c; out6[3]=d; out6[4]=e; out6[5]=f;
+}
+
+void* orc_poisson_create (int nx, int ny, double dx, double dy) { return new PoissonSolver(nx, ny, dx, dy); }
+void orc_poisson_solve (void* h, double* staging) { static_cast<PoissonSolver*>(h)->solve(staging); }
+void orc_poisson_destroy (void* h) { delete static_cast<PoissonSolver*>(h); }
+void orc_dst1 (int n, double* x, long stride) { DstPlan p(n); p.apply(x, stride); }
+
+void* orc_mg_create (int nx, int ny, double dx, double dy) { return new MG(nx, ny, dx, dy); }
+int orc_mg_nlev (void* h) { return static_cast<MG*>(h)->nlev; }
+// sol/rhs: 2 adjacent components each; acf 1 component, all with g guards, row stride nx+2g
+int orc_mg_solve1 (void* h, double* sol2, const double* rhs2, const double* acf, int nx, int ny, int g,
+                   double tol_rel, double tol_abs, int maxiter, double* resnorm) {
+    const long js = nx + 2*g, ns = js*(ny + 2*g);
+    return static_cast<MG*>(h)->solve1(sol2, sol2 + ns, rhs2, rhs2 + ns, acf, js, g, tol_rel, tol_abs, maxiter, resnorm);
+}
+void orc_mg_destroy (void* h) { delete static_cast<MG*>(h); }
+
+struct orc_deck {
+    int nx, ny, nz; double lo[3], hi[3]; int order; int deriv_type;
+    int plasma_ppc[2]; double plasma_density; double plasma_radius;
+    double plasma_charge, plasma_mass; double max_qsa; int n_subcycles;
+    int beam_profile; double beam_zmin, beam_zmax, beam_radius, beam_density;
+    double beam_umean[3], beam_pos_mean[3], beam_pos_std[3]; int beam_ppc[3]; double beam_charge;
+    int bc; double mg_tol_rel, mg_tol_abs; int deposit_rho; int n_steps;
+};
+
+void* orc_engine_create (const orc_deck* k) {
+    Deck d;
+    d.nx=k->nx; d.ny=k->ny; d.nz=k->nz; for (int i=0;i<3;++i){d.lo[i]=k->lo[i]; d.hi[i]=k->hi[i];}
+    d.order=k->order; d.deriv_type=k->deriv_type; d.plasma_ppc[0]=k->plasma_ppc[0]; d.plasma_ppc[1]=k->plasma_ppc[1];
+    d.plasma_density=k->plasma_density; d.plasma_radius=k->plasma_radius; d.plasma_charge=k->plasma_charge; d.plasma_mass=k->plasma_mass;
+    d.max_qsa=k->max_qsa; d.n_subcycles=k->n_subcycles; d.beam_profile=k->beam_profile; d.beam_zmin=k->beam_zmin; d.beam_zmax=k->beam_zmax;
+    d.beam_radius=k->beam_radius; d.beam_density=k->beam_density;
+    for (int i=0;i<3;++i){d.beam_umean[i]=k->beam_umean[i]; d.beam_pos_mean[i]=k->beam_pos_mean[i]; d.beam_pos_std[i]=k->beam_pos_std[i]; d.beam_ppc[i]=k->beam_ppc[i];}
+    d.beam_charge=k->beam_charge; d.bc=k->bc; d.mg_tol_rel=k->mg_tol_rel; d.mg_tol_abs=k->mg_tol_abs; d.deposit_rho=k->deposit_rho; d.n_steps=k->n_steps;
+    return new Engine(d);
+}
+void orc_engine_destroy (void* h) { delete static_cast<Engine*>(h); }
+void orc_engine_run (void* h) { static_cast<Engine*>(h)->run(); }
+void orc_engine_begin_step (void* h) { static_cast<Engine*>(h)->begin_step(); }
+void orc_engine_solve_slice (void* h, int islice) { static_cast<Engine*>(h)->solve_one_slice(islice, true); }
+int orc_engine_ncomp (void* h) { return static_cast<Engine*>(h)->ncomp; }
+int orc_engine_guards (void* h) { return static_cast<Engine*>(h)->g; }
+long orc_engine_nparticles (void* h) { return static_cast<Engine*>(h)->pl.n; }
+double* orc_engine_slab (void* h) { return static_cast<Engine*>(h)->slab_data.data(); }
+double* orc_engine_particles (void* h) { return static_cast<Engine*>(h)->pdata.data(); }
+int32_t* orc_engine_valid (void* h) { return static_cast<Engine*>(h)->pvalid.data(); }
+void orc_engine_checksums (void* h, double* out) { Engine* e = static_cast<Engine*>(h); for (int n = 0; n < e->ncomp; ++n) out[n] = e->checksum[n]; }
+long orc_engine_vcycles (void* h) { return static_cast<Engine*>(h)->total_vcycles; }
+void orc_engine_times (void* h, double* t6) { Engine* e = static_cast<Engine*>(h);
+    t6[0]=e->t_deposit; t6[1]=e->t_explicit; t6[2]=e->t_push; t6[3]=e->t_poisson; t6[4]=e->t_mg; t6[5]=e->t_other; }
+// beam statistics of the whole beam (sum over all slices) for the "beam" block of the JSONs
+void orc_engine_beam_stats (void* h, double* out /* n, sum w, sum|x|, sum|y|, sum|z|, sum|uz| */) {
+    Engine* e = static_cast<Engine*>(h);
+    for (int k = 0; k < 6; ++k) out[k] = 0;
+    Beam b;
+    for (int isl = e->d.nz - 1; isl >= 0; --isl) {
+        e->init_beam_slice(isl, b);
+        out[0] += (double)b.x.size();
+        for (size_t k = 0; k < b.x.size(); ++k) { out[1] += b.w[k]; out[2] += std::abs(b.x[k]); out[3] += std::abs(b.y[k]); out[4] += std::abs(b.z[k]); out[5] += std::abs(b.uz[k]); }
+    }
+}
+
+} // extern "C"

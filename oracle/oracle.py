@@ -1,0 +1,305 @@
+"""ctypes binding of the CPU oracle (oracle/hps_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under hipace_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# component indices of the oracle engine's slab (explicit-solver layout, fields/Fields.cpp:70-122;
+# optional "rho" last)
+COMPS = ["N_jx_beam", "N_jy_beam", "chi", "Sy", "Sx", "ExmBy", "EypBx", "Ez", "Bx", "By", "Bz",
+         "Psi", "jx_beam", "jy_beam", "jz_beam", "jx", "jy", "rhomjz", "P_jx_beam", "P_jy_beam",
+         "Ion_rhomjz", "rho"]
+CIDX = {n: i for i, n in enumerate(COMPS)}
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "hps_oracle.cpp")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+class Slab(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("nx", C.c_int), ("ny", C.c_int), ("g", C.c_int), ("ncomp", C.c_int)]
+
+
+class Plasma(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in
+                ("x", "y", "w", "ux", "uy", "psi", "x_prev", "y_prev", "ux_half", "uy_half", "psi_half",
+                 "valid", "ion_lev")] + [("n", C.c_long)]
+
+
+class Geom(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("dx", "dy", "dz", "xoff", "yoff", "c", "ep0", "mu0", "q_e", "m_e")] + \
+               [("plo", C.c_double * 2), ("phi", C.c_double * 2), ("bc", C.c_int), ("normalized", C.c_int)]
+
+
+class Deck(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+                ("lo", C.c_double * 3), ("hi", C.c_double * 3),
+                ("order", C.c_int), ("deriv_type", C.c_int),
+                ("plasma_ppc", C.c_int * 2), ("plasma_density", C.c_double), ("plasma_radius", C.c_double),
+                ("plasma_charge", C.c_double), ("plasma_mass", C.c_double), ("max_qsa", C.c_double),
+                ("n_subcycles", C.c_int),
+                ("beam_profile", C.c_int), ("beam_zmin", C.c_double), ("beam_zmax", C.c_double),
+                ("beam_radius", C.c_double), ("beam_density", C.c_double),
+                ("beam_umean", C.c_double * 3), ("beam_pos_mean", C.c_double * 3),
+                ("beam_pos_std", C.c_double * 3), ("beam_ppc", C.c_int * 3), ("beam_charge", C.c_double),
+                ("bc", C.c_int), ("mg_tol_rel", C.c_double), ("mg_tol_abs", C.c_double),
+                ("deposit_rho", C.c_int), ("n_steps", C.c_int)]
+
+
+def fill_struct(st, d):
+    """Fill a ctypes Structure from a dict (tuples -> arrays)."""
+    for name, typ in st._fields_:
+        if name not in d:
+            continue
+        v = d[name]
+        if hasattr(typ, "_length_"):
+            setattr(st, name, typ(*v))
+        else:
+            setattr(st, name, v)
+    return st
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_shape_factor.restype = C.c_int
+        L.orc_shape_factor.argtypes = [C.c_int, C.c_double, C.c_void_p]
+        L.orc_deriv_shape.restype = C.c_int
+        L.orc_deriv_shape.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_deposit_current.restype = C.c_long
+        L.orc_deposit_current.argtypes = [Slab, Plasma, Geom, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_double]
+        L.orc_explicit_deposit.restype = None
+        L.orc_explicit_deposit.argtypes = [Slab, Plasma, Geom, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int]
+        L.orc_advance_plasma.restype = None
+        L.orc_advance_plasma.argtypes = [Slab, Plasma, Geom, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
+        L.orc_gather.restype = None
+        L.orc_gather.argtypes = [Slab, Geom, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]
+        L.orc_poisson_create.restype = C.c_void_p
+        L.orc_poisson_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double]
+        L.orc_poisson_solve.restype = None
+        L.orc_poisson_solve.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_poisson_destroy.restype = None
+        L.orc_poisson_destroy.argtypes = [C.c_void_p]
+        L.orc_dst1.restype = None
+        L.orc_dst1.argtypes = [C.c_int, C.c_void_p, C.c_long]
+        L.orc_mg_create.restype = C.c_void_p
+        L.orc_mg_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double]
+        L.orc_mg_nlev.restype = C.c_int
+        L.orc_mg_nlev.argtypes = [C.c_void_p]
+        L.orc_mg_solve1.restype = C.c_int
+        L.orc_mg_solve1.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_double, C.c_double, C.c_int, C.c_void_p]
+        L.orc_mg_destroy.restype = None
+        L.orc_mg_destroy.argtypes = [C.c_void_p]
+        L.orc_engine_create.restype = C.c_void_p
+        L.orc_engine_create.argtypes = [C.c_void_p]
+        for f in ("destroy", "run", "begin_step"):
+            getattr(L, "orc_engine_" + f).restype = None
+            getattr(L, "orc_engine_" + f).argtypes = [C.c_void_p]
+        L.orc_engine_solve_slice.restype = None
+        L.orc_engine_solve_slice.argtypes = [C.c_void_p, C.c_int]
+        L.orc_engine_ncomp.restype = C.c_int
+        L.orc_engine_ncomp.argtypes = [C.c_void_p]
+        L.orc_engine_guards.restype = C.c_int
+        L.orc_engine_guards.argtypes = [C.c_void_p]
+        L.orc_engine_nparticles.restype = C.c_long
+        L.orc_engine_nparticles.argtypes = [C.c_void_p]
+        L.orc_engine_slab.restype = C.c_void_p
+        L.orc_engine_slab.argtypes = [C.c_void_p]
+        L.orc_engine_particles.restype = C.c_void_p
+        L.orc_engine_particles.argtypes = [C.c_void_p]
+        L.orc_engine_valid.restype = C.c_void_p
+        L.orc_engine_valid.argtypes = [C.c_void_p]
+        L.orc_engine_checksums.restype = None
+        L.orc_engine_checksums.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_engine_vcycles.restype = C.c_long
+        L.orc_engine_vcycles.argtypes = [C.c_void_p]
+        L.orc_engine_times.restype = None
+        L.orc_engine_times.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_engine_beam_stats.restype = None
+        L.orc_engine_beam_stats.argtypes = [C.c_void_p, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# --------------------------------------------------------------------------------------------
+# numpy-level helpers used by the tests
+# --------------------------------------------------------------------------------------------
+PL_REAL = ["x", "y", "w", "ux", "uy", "psi", "x_prev", "y_prev", "ux_half", "uy_half", "psi_half"]
+
+
+def make_geom(nx, ny, lo, hi, dz=0.1, bc=1, normalized=1, consts=(1., 1., 1., 1., 1.)):
+    dx = (hi[0] - lo[0]) / nx
+    dy = (hi[1] - lo[1]) / ny
+    g = Geom()
+    g.dx, g.dy, g.dz = dx, dy, dz
+    g.xoff = 0.5 * (lo[0] + hi[0] - dx * (nx - 1))
+    g.yoff = 0.5 * (lo[1] + hi[1] - dy * (ny - 1))
+    g.c, g.ep0, g.mu0, g.q_e, g.m_e = consts
+    g.plo = (C.c_double * 2)(lo[0], lo[1])
+    g.phi = (C.c_double * 2)(hi[0], hi[1])
+    g.bc = bc
+    g.normalized = normalized
+    return g
+
+
+def slab_struct(arr, nx, ny, g):
+    """arr: float64 C-contiguous (ncomp, ny+2g, nx+2g)."""
+    assert arr.dtype == np.float64 and arr.flags.c_contiguous
+    assert arr.shape[1:] == (ny + 2 * g, nx + 2 * g)
+    s = Slab()
+    s.p = arr.ctypes.data
+    s.nx, s.ny, s.g, s.ncomp = nx, ny, g, arr.shape[0]
+    return s
+
+
+def plasma_struct(real, valid, ion):
+    """real: float64 (11, n) C-contiguous; valid/ion: int32 (n,)."""
+    assert real.dtype == np.float64 and real.flags.c_contiguous and real.shape[0] == 11
+    p = Plasma()
+    n = real.shape[1]
+    for k, name in enumerate(PL_REAL):
+        setattr(p, name, real[k].ctypes.data)
+    p.valid = valid.ctypes.data
+    p.ion_lev = ion.ctypes.data
+    p.n = n
+    return p
+
+
+def shape_factor(order, xmid):
+    s = np.zeros(4)
+    cell = lib().orc_shape_factor(order, float(xmid), _ptr(s))
+    return cell, s[:order + 1].copy()
+
+
+def deriv_shape(dtype, order, xmid, ix):
+    s = C.c_double()
+    ds = C.c_double()
+    cell = lib().orc_deriv_shape(dtype, order, float(xmid), ix, C.byref(s), C.byref(ds))
+    return cell, s.value, ds.value
+
+
+def deposit_current(slab, nx, ny, g, real, valid, ion, geom, comp, q, m, order, max_qsa=35.0):
+    c = np.asarray(comp, dtype=np.int32)
+    return lib().orc_deposit_current(slab_struct(slab, nx, ny, g), plasma_struct(real, valid, ion), geom,
+                                     _ptr(c), q, m, order, max_qsa)
+
+
+def explicit_deposit(slab, nx, ny, g, real, valid, ion, geom, cache, depos, q, m, order, dtype=2):
+    c = np.asarray(cache, dtype=np.int32)
+    d = np.asarray(depos, dtype=np.int32)
+    lib().orc_explicit_deposit(slab_struct(slab, nx, ny, g), plasma_struct(real, valid, ion), geom,
+                               _ptr(c), _ptr(d), q, m, order, dtype)
+
+
+def advance_plasma(slab, nx, ny, g, real, valid, ion, geom, comp, q, m, order, temp_slice=0, n_subcycles=1):
+    c = np.asarray(comp, dtype=np.int32)
+    lib().orc_advance_plasma(slab_struct(slab, nx, ny, g), plasma_struct(real, valid, ion), geom,
+                             _ptr(c), q, m, order, temp_slice, n_subcycles)
+
+
+def gather(slab, nx, ny, g, geom, comp, order, xp, yp):
+    c = np.asarray(comp, dtype=np.int32)
+    out = np.zeros(6)
+    lib().orc_gather(slab_struct(slab, nx, ny, g), geom, _ptr(c), order, float(xp), float(yp), _ptr(out))
+    return out
+
+
+def poisson_solve(rhs, dx, dy):
+    """rhs: (ny, nx) float64 -> solution of Lap(F) = rhs, F = 0 one cell outside the box."""
+    ny, nx = rhs.shape
+    h = lib().orc_poisson_create(nx, ny, dx, dy)
+    st = np.ascontiguousarray(rhs, dtype=np.float64).copy()
+    lib().orc_poisson_solve(h, _ptr(st))
+    lib().orc_poisson_destroy(h)
+    return st
+
+
+def dst1(x):
+    y = np.ascontiguousarray(x, dtype=np.float64).copy()
+    lib().orc_dst1(y.size, _ptr(y), 1)
+    return y
+
+
+def mg_solve1(sol2, rhs2, acf, nx, ny, g, dx, dy, tol_rel=1e-4, tol_abs=2.2250738585072014e-308, maxiter=200):
+    """sol2/rhs2: (2, ny+2g, nx+2g); acf: (ny+2g, nx+2g). sol2 updated in place. -> (iters, resnorm)."""
+    assert sol2.flags.c_contiguous and rhs2.flags.c_contiguous and acf.flags.c_contiguous
+    h = lib().orc_mg_create(nx, ny, dx, dy)
+    rn = C.c_double()
+    it = lib().orc_mg_solve1(h, _ptr(sol2), _ptr(rhs2), _ptr(acf), nx, ny, g, tol_rel, tol_abs, maxiter, C.byref(rn))
+    lib().orc_mg_destroy(h)
+    return it, rn.value
+
+
+class Engine:
+    """The oracle's whole-deck driver (Hipace::Evolve + SolveOneSlice, explicit solver)."""
+
+    def __init__(self, deck):
+        self.deck = dict(deck)
+        self._dk = fill_struct(Deck(), deck)
+        self._h = lib().orc_engine_create(C.byref(self._dk))
+        self.ncomp = lib().orc_engine_ncomp(self._h)
+        self.g = lib().orc_engine_guards(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_engine_destroy(self._h)
+            self._h = None
+
+    def run(self):
+        lib().orc_engine_run(self._h)
+
+    def begin_step(self):
+        lib().orc_engine_begin_step(self._h)
+
+    def solve_slice(self, islice):
+        lib().orc_engine_solve_slice(self._h, islice)
+
+    def slab(self):
+        nx, ny, g = self.deck["nx"], self.deck["ny"], self.g
+        n = self.ncomp * (ny + 2 * g) * (nx + 2 * g)
+        buf = (C.c_double * n).from_address(lib().orc_engine_slab(self._h))
+        return np.frombuffer(buf, dtype=np.float64).reshape(self.ncomp, ny + 2 * g, nx + 2 * g)
+
+    def particles(self):
+        n = lib().orc_engine_nparticles(self._h)
+        if n == 0:
+            return np.zeros((11, 0)), np.zeros(0, dtype=np.int32)
+        buf = (C.c_double * (11 * n)).from_address(lib().orc_engine_particles(self._h))
+        vb = (C.c_int32 * n).from_address(lib().orc_engine_valid(self._h))
+        return np.frombuffer(buf, dtype=np.float64).reshape(11, n), np.frombuffer(vb, dtype=np.int32)
+
+    def checksums(self):
+        out = np.zeros(self.ncomp)
+        lib().orc_engine_checksums(self._h, _ptr(out))
+        return {COMPS[i]: out[i] for i in range(self.ncomp)}
+
+    def vcycles(self):
+        return lib().orc_engine_vcycles(self._h)
+
+    def times(self):
+        t = np.zeros(6)
+        lib().orc_engine_times(self._h, _ptr(t))
+        return dict(zip(["deposit", "explicit_deposit", "push", "poisson", "mg", "other"], t))
+
+    def beam_stats(self):
+        t = np.zeros(6)
+        lib().orc_engine_beam_stats(self._h, _ptr(t))
+        return dict(zip(["n", "w", "x", "y", "z", "uz"], t))

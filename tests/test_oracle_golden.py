@@ -1,0 +1,40 @@
+"""Pins the CPU oracle against the reference's own golden checksums.
+
+The JSON files under tests/golden/ are the reference's fixtures
+(/root/reference/tests/checksum/benchmarks_json/*.json, data only).  The checksum definition is
+sum |Q| over all nx*ny*nz valid cells of the last time step
+(/root/reference/tests/checksum/backend/openpmd_backend.py:40-62); the reference's CI compares
+them at rtol 1e-12 on CPU (tests/linear_wake.normalized.1Rank.sh:29).  We demand 1e-11
+(summation order differs from the reference's tiled/OpenMP deposition).
+"""
+import json
+import os
+
+import pytest
+
+from hipace_amd import decks
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = [("linear_wake", "linear_wake.normalized.1Rank"),
+         ("blowout_wake", "blowout_wake_explicit.2Rank"),
+         ("beam_in_vacuum", "beam_in_vacuum.normalized.Serial")]
+
+
+@pytest.mark.parametrize("name,js", CASES)
+def test_oracle_reproduces_reference_checksums(oracle, name, js):
+    gold = json.load(open(os.path.join(GOLD, js + ".json")))
+    eng = oracle.Engine(decks.NAMED[name]())
+    eng.run()
+    cs = eng.checksums()
+    for k, v in gold["lev=0"].items():
+        assert k in cs, k
+        if v == 0.0:
+            assert cs[k] == 0.0, (k, cs[k])
+        else:
+            assert abs(cs[k] - v) <= 1e-11 * abs(v), (k, cs[k], v)
+    # beam block: particle count, sum w, sum |x|, |y|, |z|, |uz|
+    b = eng.beam_stats()
+    gb = gold["beam"]
+    assert b["n"] == gb["charge"]            # |q| = 1 per particle
+    for k in ("w", "x", "y", "z", "uz"):
+        assert abs(b[k] - gb[k]) <= 1e-11 * max(abs(gb[k]), 1e-300), (k, b[k], gb[k])
