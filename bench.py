@@ -1,0 +1,141 @@
+#!/usr/bin/env python
+"""bench.py -- transverse slices/s of the per-zeta-slice hot path on MI355X.
+
+One "step" = one transverse slice (deposit -> Psi/Ez/Bz Poisson solves -> explicit deposit ->
+Bx/By multigrid -> gather+push) of the BASELINE.md section 3 synthetic deck: 1024 x 1024 cells,
+2x2 = 4 plasma particles per cell, order-2 shapes, Gaussian fixed-ppc driver, explicit solver,
+hipace.dt = 0.  The default run times one whole box (1024 slices = one time step, including the
+per-step plasma re-initialisation); slices/s = slices / wall time, particle-pushes/s = 4*1024^2
+times that.  All inputs are generated on the device before the timed region.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  The path shards as the
+reference does, over time steps (rank r runs steps r, r+N, ...: Hipace.cpp:400-401), each rank
+sweeping the whole box; weak scaling, value = total slices of all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(n, ppc2):
+    """SURVEY 8(d) algorithmic traffic per slice of each kernel (fp64), C = n^2 cells, P = ppc2*C."""
+    C = n * n
+    P = ppc2 * C
+    return {
+        "deposit_current": 56 * P + 4 * 8 * C,
+        "explicit_deposit": 56 * P + 4 * 8 * C + 2 * 8 * C,
+        "advance_plasma": (40 + 8) * P + 80 * P + 5 * 8 * C,
+        "poisson": 3 * 4 * 16 * C,
+    }
+
+
+def cpu_baseline(n, ppc, nslices):
+    """Time the CPU oracle (single-thread restatement of the reference's serial path) on the head
+    `nslices` slices of the same deck."""
+    from hipace_amd import decks
+    from oracle import oracle as O
+    deck = decks.synthetic(n, 1024, ppc)
+    eng = O.Engine(deck)
+    eng.begin_step()
+    t0 = time.perf_counter()
+    for k in range(nslices):
+        eng.solve_slice(deck["nz"] - 1 - k)
+    dt = time.perf_counter() - t0
+    return dict(value=nslices / dt, unit="slices/s", cores=1, kind="port",
+                sample=f"oracle (serial C++ restatement, g++ -O2), head {nslices} slices of the same "
+                       f"{n}x{n}x1024 {ppc * ppc}ppc deck, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1024, help="timed slices")
+    ap.add_argument("--warmup", type=int, default=64, help="untimed warm-up slices")
+    ap.add_argument("--n", type=int, default=1024, help="transverse cells per side")
+    ap.add_argument("--ppc", type=int, default=2, help="plasma particles per cell per direction")
+    ap.add_argument("--cpu-slices", type=int, default=4, help="slices of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from hipace_amd import api, decks
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    nz = 1024
+    deck = decks.synthetic(args.n, nz, args.ppc)
+    eng = api.SliceEngine(deck, device=local)
+
+    def run_slices(count, profile=False):
+        done = 0
+        while done < count:
+            eng.begin_step()
+            m = min(nz, count - done)
+            for k in range(m):
+                eng.solve_slice(nz - 1 - k)
+            done += m
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    run_slices(args.warmup)
+    eng.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    run_slices(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    phases, nprof = eng.phase_times()
+    eng.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        total = args.steps * world
+        ab = algorithmic_bytes(args.n, args.ppc * args.ppc)
+        per_kernel = {k: phases[k] / max(nprof, 1) for k in phases}
+        dom = "deposit_current"
+        achieved = ab[dom] / (per_kernel[dom] * 1e-3) / 1e9 if per_kernel[dom] > 0 else 0.0
+        out = {
+            "metric": "transverse slices/s at 1024^2 x 4ppc (explicit solver)",
+            "value": total / dt, "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "particle_pushes_per_s": total / dt * args.ppc * args.ppc * args.n * args.n,
+            "config": {"workload": f"blowout_wake synthetic {args.n}x{args.n}x{nz}, {args.ppc * args.ppc} ppc, "
+                                   "order 2, explicit Bx/By solver, dt=0 (BASELINE.md section 3)",
+                       "parallelism": f"time-step pipeline x{world}"},
+            "phase_ms_per_slice": per_kernel,
+            "vcycles_per_slice": eng.stats()["vcycles"] / max(eng.stats()["slices"], 1),
+            "roofline": {"bound": "hbm", "kernel": "k_deposit_current<2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per_kernel[dom]},
+        }
+        if args.cpu_slices > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.n, args.ppc, args.cpu_slices)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

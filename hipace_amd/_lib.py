@@ -1,0 +1,135 @@
+"""ctypes binding of libhpslice.so (include/hpslice.h).  Fails loudly when the HIP library is
+missing: there is no CPU fallback for any product path."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO = os.path.join(CSRC, "libhpslice.so")
+_LIB = None
+
+
+class Slab(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("nx", C.c_int), ("ny", C.c_int), ("ng", C.c_int), ("ncomp", C.c_int),
+                ("jstride", C.c_long), ("nstride", C.c_long)]
+
+
+PL_REAL = ["x", "y", "w", "ux", "uy", "psi", "x_prev", "y_prev", "ux_half", "uy_half", "psi_half"]
+
+
+class Plasma(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in PL_REAL] + [("idcpu", C.c_void_p), ("ion_lev", C.c_void_p), ("n", C.c_long)]
+
+
+class Geom(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("dx", "dy", "dz", "xoff", "yoff", "c", "ep0", "mu0", "q_e", "m_e")] + \
+               [("plo", C.c_double * 2), ("phi", C.c_double * 2), ("bc", C.c_int), ("normalized", C.c_int)]
+
+
+class Deck(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+                ("lo", C.c_double * 3), ("hi", C.c_double * 3),
+                ("order", C.c_int), ("deriv_type", C.c_int),
+                ("plasma_ppc", C.c_int * 2), ("plasma_density", C.c_double), ("plasma_radius", C.c_double),
+                ("plasma_charge", C.c_double), ("plasma_mass", C.c_double), ("max_qsa", C.c_double),
+                ("n_subcycles", C.c_int),
+                ("beam_profile", C.c_int), ("beam_zmin", C.c_double), ("beam_zmax", C.c_double),
+                ("beam_radius", C.c_double), ("beam_density", C.c_double),
+                ("beam_umean", C.c_double * 3), ("beam_pos_mean", C.c_double * 3),
+                ("beam_pos_std", C.c_double * 3), ("beam_ppc", C.c_int * 3), ("beam_charge", C.c_double),
+                ("bc", C.c_int), ("mg_tol_rel", C.c_double), ("mg_tol_abs", C.c_double),
+                ("deposit_rho", C.c_int), ("n_steps", C.c_int)]
+
+
+# engine component names, index = value of the HPS_C_* enum in include/hpslice.h
+COMPS = ["N_jx_beam", "N_jy_beam", "chi", "Sy", "Sx", "ExmBy", "EypBx", "Ez", "Bx", "By", "Bz",
+         "Psi", "jx_beam", "jy_beam", "jz_beam", "jx", "jy", "rhomjz", "P_jx_beam", "P_jy_beam",
+         "Ion_rhomjz", "rho"]
+CIDX = {n: i for i, n in enumerate(COMPS)}
+ID_VALID = 1 << 63
+
+_SIGS = {
+    "hps_last_error": (C.c_char_p, []),
+    "hps_version": (C.c_char_p, []),
+    "hps_deposit_current": (C.c_int, [Slab, Plasma, Geom, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_double,
+                                      C.c_int, C.c_void_p, C.c_void_p]),
+    "hps_explicit_deposit": (C.c_int, [Slab, Plasma, Geom, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
+                                       C.c_int, C.c_int, C.c_void_p]),
+    "hps_advance_plasma": (C.c_int, [Slab, Plasma, Geom, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_void_p]),
+    "hps_poisson_create": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
+    "hps_poisson_solve": (C.c_int, [C.c_void_p, C.c_void_p, Slab, C.c_int, C.c_void_p]),
+    "hps_poisson_destroy": (C.c_int, [C.c_void_p]),
+    "hps_mg_create": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
+    "hps_mg_solve1": (C.c_int, [C.c_void_p, Slab, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p]),
+    "hps_mg_destroy": (C.c_int, [C.c_void_p]),
+    "hps_engine_create": (C.c_int, [C.POINTER(Deck), C.c_int, C.POINTER(C.c_void_p)]),
+    "hps_engine_destroy": (C.c_int, [C.c_void_p]),
+    "hps_engine_begin_step": (C.c_int, [C.c_void_p]),
+    "hps_engine_solve_slice": (C.c_int, [C.c_void_p, C.c_int]),
+    "hps_engine_run_step": (C.c_int, [C.c_void_p]),
+    "hps_engine_sync": (C.c_int, [C.c_void_p]),
+    "hps_engine_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long)]),
+    "hps_engine_slab": (Slab, [C.c_void_p]),
+    "hps_engine_plasma": (Plasma, [C.c_void_p]),
+    "hps_engine_stream": (C.c_void_p, [C.c_void_p]),
+    "hps_engine_checksums": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hps_engine_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "hps_engine_set_diagnostics": (C.c_int, [C.c_void_p, C.c_int]),
+    "hps_engine_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "hps_engine_phase_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hps_ring_unique_id": (C.c_int, [C.c_void_p]),
+    "hps_ring_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "hps_ring_run": (C.c_int, [C.c_void_p, C.c_int]),
+    "hps_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long]),
+    "hps_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long]),
+    "hps_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+}
+
+
+def build(force=False):
+    """Compile libhpslice.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args + ["libhpslice.so"], stdout=subprocess.DEVNULL)
+    return SO
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO):
+            raise RuntimeError(
+                f"{SO} is missing: the HIP extension was not built (run __graft_entry__.build()); "
+                "hipace_amd has no CPU fallback")
+        L = C.CDLL(SO)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)      # AttributeError here = the library does not export the ABI
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+class HpsError(RuntimeError):
+    pass
+
+
+def check(status):
+    if status != 0:
+        raise HpsError(f"hpslice status {status}: {lib().hps_last_error().decode()}")
+
+
+def fill_struct(st, d):
+    for name, typ in st._fields_:
+        if name not in d:
+            continue
+        v = d[name]
+        if hasattr(typ, "_length_"):
+            setattr(st, name, typ(*v))
+        else:
+            setattr(st, name, v)
+    return st

@@ -1,0 +1,239 @@
+"""Host-side mirror of the reference's operator interface for the slice hot path, on top of the
+C ABI (include/hpslice.h).  Names, argument meaning and error behaviour follow the reference's
+C++ seams:
+
+    DepositCurrent(plasma, fields, ...)          particles/deposition/PlasmaDepositCurrent.H:28-32
+    ExplicitDeposition(plasma, fields, ...)      particles/deposition/ExplicitDeposition.H:20-22
+    AdvancePlasmaParticles(plasma, fields, ...)  particles/pusher/PlasmaParticleAdvance.H:23-26
+    FFTPoissonSolver.SolvePoissonEquation(lhs)   fields/fft_poisson_solver/FFTPoissonSolver.H:26-57
+    MultiGrid.solve1(sol, rhs, acoef, ...)       mg_solver/HpMultiGrid.H:64-66
+    SliceEngine                                  Hipace::Evolve / SolveOneSlice (Hipace.cpp:393-728)
+
+PyTorch is used only to own device memory and streams; all arithmetic happens in libhpslice.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CIDX, COMPS, ID_VALID, PL_REAL, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _iarr(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+class Geometry:
+    """Slice geometry + physical constants + particle boundary (hps_geom)."""
+
+    def __init__(self, nx, ny, lo, hi, dz, bc=1, normalized=True, consts=(1., 1., 1., 1., 1.), ng=None):
+        self.nx, self.ny = nx, ny
+        g = _lib.Geom()
+        g.dx = (hi[0] - lo[0]) / nx
+        g.dy = (hi[1] - lo[1]) / ny
+        g.dz = dz
+        # GetPosOffset (fields/Fields.H:71-77): independent of the number of guard cells
+        g.xoff = 0.5 * (lo[0] + hi[0] - g.dx * (nx - 1))
+        g.yoff = 0.5 * (lo[1] + hi[1] - g.dy * (ny - 1))
+        g.c, g.ep0, g.mu0, g.q_e, g.m_e = consts
+        g.plo = (C.c_double * 2)(lo[0], lo[1])
+        g.phi = (C.c_double * 2)(hi[0], hi[1])
+        g.bc = bc
+        g.normalized = int(normalized)
+        self.c = g
+
+
+class Fields:
+    """The field slab: ncomp planes of (ny+2ng, nx+2ng) doubles in HBM (fields/Fields.H:465)."""
+
+    def __init__(self, nx, ny, ng, ncomp, device="cuda", data=None):
+        self.nx, self.ny, self.ng, self.ncomp = nx, ny, ng, ncomp
+        shape = (ncomp, ny + 2 * ng, nx + 2 * ng)
+        if data is None:
+            self.t = torch.zeros(shape, dtype=torch.float64, device=device)
+        else:
+            self.t = torch.as_tensor(np.ascontiguousarray(data), dtype=torch.float64).reshape(shape).to(device).contiguous()
+
+    def struct(self):
+        s = _lib.Slab()
+        s.p = self.t.data_ptr()
+        s.nx, s.ny, s.ng, s.ncomp = self.nx, self.ny, self.ng, self.ncomp
+        s.jstride = self.nx + 2 * self.ng
+        s.nstride = s.jstride * (self.ny + 2 * self.ng)
+        return s
+
+    def numpy(self):
+        return self.t.cpu().numpy()
+
+
+class PlasmaSheet:
+    """Pure-SoA plasma sheet (particles/plasma/PlasmaParticleContainer.H:21-50)."""
+
+    def __init__(self, real, valid=None, ion_lev=None, device="cuda"):
+        real = np.ascontiguousarray(real, dtype=np.float64)
+        assert real.shape[0] == 11
+        self.n = real.shape[1]
+        self.real = torch.as_tensor(real).to(device).contiguous()
+        if valid is None:
+            valid = np.ones(self.n, dtype=np.int32)
+        idcpu = np.where(np.asarray(valid) != 0, np.uint64(ID_VALID | (1 << 24)), np.uint64(1 << 24)).astype(np.uint64)
+        self.idcpu = torch.as_tensor(idcpu.view(np.int64)).to(device).contiguous()
+        if ion_lev is None:
+            ion_lev = np.zeros(self.n, dtype=np.int32)
+        self.ion_lev = torch.as_tensor(np.asarray(ion_lev, dtype=np.int32)).to(device).contiguous()
+
+    def struct(self):
+        p = _lib.Plasma()
+        base = self.real.data_ptr()
+        for k, name in enumerate(PL_REAL):
+            setattr(p, name, base + 8 * k * self.n)
+        p.idcpu = self.idcpu.data_ptr()
+        p.ion_lev = self.ion_lev.data_ptr()
+        p.n = self.n
+        return p
+
+    def numpy(self):
+        idc = self.idcpu.cpu().numpy().view(np.uint64)
+        return self.real.cpu().numpy(), ((idc >> np.uint64(63)) & np.uint64(1)).astype(np.int32)
+
+
+def DepositCurrent(plasma, fields, geom, charge, mass, depos_order, jx=-1, jy=-1, jz=-1, rho=-1, chi=-1,
+                   rhomjz=-1, max_qsa_weighting_factor=35.0, can_ionize=False, n_qsa=None):
+    comp = _iarr([jx, jy, jz, rho, chi, rhomjz])
+    nq = C.c_void_p(n_qsa.data_ptr()) if n_qsa is not None else None
+    check(_lib.lib().hps_deposit_current(fields.struct(), plasma.struct(), geom.c, comp, charge, mass,
+                                         depos_order, max_qsa_weighting_factor, int(can_ionize), nq, _stream()))
+
+
+def ExplicitDeposition(plasma, fields, geom, charge, mass, depos_order, Bz, Ez, ExmBy, EypBx, Sy, Sx,
+                       derivative_type=2, can_ionize=False):
+    check(_lib.lib().hps_explicit_deposit(fields.struct(), plasma.struct(), geom.c, _iarr([Bz, Ez, ExmBy, EypBx]),
+                                          _iarr([Sy, Sx]), charge, mass, depos_order, derivative_type,
+                                          int(can_ionize), _stream()))
+
+
+def AdvancePlasmaParticles(plasma, fields, geom, charge, mass, depos_order, Psi, Ez, Bx, By, Bz,
+                           temp_slice=False, n_subcycles=1, can_ionize=False):
+    check(_lib.lib().hps_advance_plasma(fields.struct(), plasma.struct(), geom.c, _iarr([Psi, Ez, Bx, By, Bz]),
+                                        charge, mass, depos_order, int(temp_slice), n_subcycles,
+                                        int(can_ionize), _stream()))
+
+
+class FFTPoissonSolver:
+    """Lap(F) = S, F = 0 one cell outside the box; S lives in the staging area."""
+
+    def __init__(self, nx, ny, dx, dy, device="cuda"):
+        self.nx, self.ny = nx, ny
+        self._h = C.c_void_p()
+        check(_lib.lib().hps_poisson_create(nx, ny, dx, dy, C.byref(self._h)))
+        self.staging = torch.zeros((ny, nx), dtype=torch.float64, device=device)
+
+    def StagingArea(self):
+        return self.staging
+
+    def SolvePoissonEquation(self, lhs_fields, comp):
+        check(_lib.lib().hps_poisson_solve(self._h, C.c_void_p(self.staging.data_ptr()), lhs_fields.struct(), comp,
+                                           _stream()))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.lib().hps_poisson_destroy(self._h)
+            self._h = None
+
+
+class MultiGrid:
+    """hpmg::MultiGrid system type 1."""
+
+    def __init__(self, nx, ny, dx, dy):
+        self._h = C.c_void_p()
+        check(_lib.lib().hps_mg_create(nx, ny, dx, dy, C.byref(self._h)))
+
+    def solve1(self, fields, sol_comp, rhs_comp, acoef_comp, tol_rel=1e-4, tol_abs=2.2250738585072014e-308,
+               nummaxiter=200):
+        it = C.c_int()
+        rn = C.c_double()
+        check(_lib.lib().hps_mg_solve1(self._h, fields.struct(), sol_comp, rhs_comp, acoef_comp, tol_rel, tol_abs,
+                                       nummaxiter, C.byref(it), C.byref(rn), _stream()))
+        return it.value, rn.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.lib().hps_mg_destroy(self._h)
+            self._h = None
+
+
+class SliceEngine:
+    """Device-resident slice loop for one deck (see hipace_amd/decks.py)."""
+
+    def __init__(self, deck, device=0):
+        self.deck = dict(deck)
+        self._dk = _lib.fill_struct(_lib.Deck(), deck)
+        self._h = C.c_void_p()
+        check(_lib.lib().hps_engine_create(C.byref(self._dk), device, C.byref(self._h)))
+        nc, ng, npart = C.c_int(), C.c_int(), C.c_long()
+        check(_lib.lib().hps_engine_info(self._h, C.byref(nc), C.byref(ng), C.byref(npart)))
+        self.ncomp, self.ng, self.nparticles = nc.value, ng.value, npart.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.lib().hps_engine_destroy(self._h)
+            self._h = None
+
+    def begin_step(self):
+        check(_lib.lib().hps_engine_begin_step(self._h))
+
+    def solve_slice(self, islice):
+        check(_lib.lib().hps_engine_solve_slice(self._h, islice))
+
+    def run_step(self):
+        check(_lib.lib().hps_engine_run_step(self._h))
+
+    def sync(self):
+        check(_lib.lib().hps_engine_sync(self._h))
+
+    def set_diagnostics(self, on=True):
+        check(_lib.lib().hps_engine_set_diagnostics(self._h, int(on)))
+
+    def set_profiling(self, on=True):
+        check(_lib.lib().hps_engine_set_profiling(self._h, int(on)))
+
+    def phase_times(self):
+        ms = (C.c_double * 6)()
+        n = C.c_long()
+        check(_lib.lib().hps_engine_phase_times(self._h, ms, C.byref(n)))
+        names = ["deposit_current", "poisson", "explicit_deposit", "mg_solve1", "advance_plasma", "other"]
+        return {k: ms[i] for i, k in enumerate(names)}, n.value
+
+    def checksums(self):
+        out = (C.c_double * self.ncomp)()
+        check(_lib.lib().hps_engine_checksums(self._h, out))
+        return {COMPS[i]: out[i] for i in range(self.ncomp)}
+
+    def stats(self):
+        vc, sl = C.c_long(), C.c_long()
+        check(_lib.lib().hps_engine_stats(self._h, C.byref(vc), C.byref(sl)))
+        return dict(vcycles=vc.value, slices=sl.value)
+
+    def slab(self):
+        self.sync()
+        s = _lib.lib().hps_engine_slab(self._h)
+        nx, ny, g = s.nx, s.ny, s.ng
+        out = np.empty((s.ncomp, ny + 2 * g, nx + 2 * g), dtype=np.float64)
+        check(_lib.lib().hps_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(s.p), out.nbytes))
+        return out
+
+    def particles(self):
+        self.sync()
+        p = _lib.lib().hps_engine_plasma(self._h)
+        n = p.n
+        real = np.empty((11, n), dtype=np.float64)
+        idc = np.empty(n, dtype=np.uint64)
+        if n:
+            check(_lib.lib().hps_memcpy_d2h(real.ctypes.data_as(C.c_void_p), C.c_void_p(p.x), real.nbytes))
+            check(_lib.lib().hps_memcpy_d2h(idc.ctypes.data_as(C.c_void_p), C.c_void_p(p.idcpu), idc.nbytes))
+        return real, ((idc >> np.uint64(63)) & np.uint64(1)).astype(np.int32)

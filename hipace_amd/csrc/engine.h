@@ -1,0 +1,46 @@
+// engine.h -- slice-engine state (device resident).
+#ifndef HPS_ENGINE_H_
+#define HPS_ENGINE_H_
+
+#include "common.h"
+#include <vector>
+
+namespace hps {
+
+struct BeamView { double *x, *y, *z, *ux, *uy, *uz, *w; };
+
+struct Engine {
+    hps_deck d{};
+    hps_geom gm{};
+    int g = 0, ncomp = 0;
+    hipStream_t st = nullptr;
+    hps_slab slab{};
+    hps_plasma pl{};
+    double* pl_real = nullptr;
+    long np = 0;
+    void* ps = nullptr;            // Poisson solver handle
+    void* mg = nullptr;            // multigrid handle
+    double* staging = nullptr;
+    // driver beam: slice-major SoA (head slice first), static because hipace.dt = 0
+    double* beam_data = nullptr; BeamView beam{}; long nbeam = 0; std::vector<long> beam_off;
+    int* d_nqsa = nullptr;
+    double* d_checksum = nullptr;
+    bool diagnostics = false;
+    bool profiling = false;
+    std::vector<hipEvent_t> ev; size_t ev_used = 0;      // 10 events per profiled slice
+    void mark ();
+    long total_vcycles = 0, slices_done = 0;
+    // ring pipeline (ring.hip)
+    void* ring = nullptr;
+
+    ~Engine ();
+    int create (const hps_deck& deck, int device);
+    int init_beam ();
+    int begin_step ();
+    int deposit_beam_slice (int islice, int cjx, int cjy, int cjz);
+    int solve_slice (int islice);
+    int run_step ();
+};
+
+} // namespace hps
+#endif

@@ -1,0 +1,477 @@
+// engine.hip -- the slice engine: slab bookkeeping kernels + the per-slice schedule of the explicit
+// solver, i.e. the device-resident equivalent of Hipace::Evolve / Hipace::SolveOneSlice
+// (Hipace.cpp:393-728) restricted to the hot path (one plasma species, fixed-ppc driver beam,
+// Dirichlet fields, normalised units, hipace.dt = 0 so the beam is static).
+#include "common.h"
+#include "engine.h"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace hps {
+
+static thread_local std::string g_err;
+void set_error (const std::string& msg) { g_err = msg; }
+
+// ------------------------------------------------------------------------------------------
+// slab kernels (all over whole planes incl. guards unless noted; x fastest, fully coalesced)
+// ------------------------------------------------------------------------------------------
+struct CompList { int n; int c[12]; };
+
+__global__ __launch_bounds__(256)
+void k_zero_comps (double* p, long ns, long plane, CompList cl)
+{
+    const long s = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (s >= plane) return;
+    for (int k = 0; k < cl.n; ++k) p[cl.c[k]*ns + s] = 0.0;
+}
+
+__global__ __launch_bounds__(256)
+void k_copy_comps (double* p, long ns, long plane, CompList dst, CompList src)
+{
+    const long s = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (s >= plane) return;
+    double v[12];
+    for (int k = 0; k < src.n; ++k) v[k] = p[src.c[k]*ns + s];
+    for (int k = 0; k < dst.n; ++k) p[dst.c[k]*ns + s] = v[k];
+}
+
+// AddRhoIons (fields/Fields.cpp:606-615) fused with the Psi source  -rhomjz/ep0  (:887-888)
+__global__ __launch_bounds__(256)
+void k_add_ions_psi_rhs (SlabView f, int c_rhomjz, int c_ion, int c_rho, double inv_ep0, double* staging)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x - f.ng;
+    const int j = blockIdx.y - f.ng;
+    if (i >= f.nx + f.ng) return;
+    const long o = f.off(i, j);
+    const double ion = f.p[c_ion*f.ns + o];
+    const double r = f.p[c_rhomjz*f.ns + o] + ion;
+    f.p[c_rhomjz*f.ns + o] = r;
+    if (c_rho >= 0) f.p[c_rho*f.ns + o] += ion;
+    if (i >= 0 && i < f.nx && j >= 0 && j < f.ny) staging[(long)j*f.nx + i] = -inv_ep0*r;
+}
+
+// staging = fa * d(A)/d(da) + fb * d(B)/d(db), centred differences (LinCombination + derivative,
+// fields/Fields.cpp:223-249,368-387); dir 0 = x, 1 = y
+__global__ __launch_bounds__(256)
+void k_rhs_lincomb (SlabView f, int cA, int dirA, double fa, int cB, int dirB, double fb, double* staging)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= f.nx) return;
+    const long o = f.off(i, j);
+    const long sa = dirA == 0 ? 1 : f.js, sb = dirB == 0 ? 1 : f.js;
+    const double* A = f.p + cA*f.ns + o;
+    const double* B = f.p + cB*f.ns + o;
+    staging[(long)j*f.nx + i] = fa*(A[sa] - A[-sa]) + fb*(B[sb] - B[-sb]);
+}
+
+// ExmBy = -dPsi/dx, EypBx = -dPsi/dy on the box grown by (guards-1) (fields/Fields.cpp:931-956)
+__global__ __launch_bounds__(256)
+void k_grad_psi (SlabView f, int cPsi, int cExmBy, int cEypBx, double hdx_inv, double hdy_inv)
+{
+    const int gg = f.ng - 1;
+    const int i = blockIdx.x*blockDim.x + threadIdx.x - gg;
+    const int j = blockIdx.y - gg;
+    if (i >= f.nx + gg) return;
+    const long o = f.off(i, j);
+    const double* P = f.p + cPsi*f.ns + o;
+    f.p[cExmBy*f.ns + o] = -(P[1] - P[-1])*hdx_inv;
+    f.p[cEypBx*f.ns + o] = -(P[f.js] - P[-f.js])*hdy_inv;
+}
+
+// beam contribution to the Bx/By sources (Hipace::InitializeSxSyWithBeam, Hipace.cpp:744-790)
+__global__ __launch_bounds__(256)
+void k_sxsy_beam (SlabView f, int cSx, int cSy, int cJzb, int cNx, int cNy, int cPx, int cPy,
+                  double mu0, double dx2, double dy2, double dz2)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= f.nx) return;
+    const long o = f.off(i, j);
+    const double* J = f.p + cJzb*f.ns + o;
+    const double dx_jzb = (J[1] - J[-1])/dx2;
+    const double dy_jzb = (J[f.js] - J[-f.js])/dy2;
+    const double dz_jxb = (f.p[cPx*f.ns + o] - f.p[cNx*f.ns + o])/dz2;
+    const double dz_jyb = (f.p[cPy*f.ns + o] - f.p[cNy*f.ns + o])/dz2;
+    f.p[cSy*f.ns + o] =  mu0*(-dy_jzb + dz_jyb);
+    f.p[cSx*f.ns + o] = -mu0*(-dx_jzb + dz_jxb);
+}
+
+// per-component sum |Q| over the valid cells, accumulated into acc[n]
+__global__ __launch_bounds__(256)
+void k_checksum (SlabView f, int ncomp, double* acc)
+{
+    const int n = blockIdx.y;
+    double s = 0.0;
+    const long cells = (long)f.nx*f.ny;
+    for (long c = (long)blockIdx.x*blockDim.x + threadIdx.x; c < cells; c += (long)gridDim.x*blockDim.x) {
+        const int j = (int)(c / f.nx), i = (int)(c - (long)j*f.nx);
+        s += fabs(f(i, j, n));
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_add_f64(acc + n, part[0] + part[1] + part[2] + part[3]);
+    (void)ncomp;
+}
+
+// plasma sheet on the fixed-ppc lattice, ppc index outermost so that consecutive lanes own
+// consecutive cells (PlasmaParticleContainerInit.cpp:192-313, ParticleUtil.H:72-83)
+__global__ __launch_bounds__(256)
+void k_init_plasma (hps_plasma pl, int nx, int ny, int ppcx, int ppcy, double lox, double loy, double dx, double dy,
+                    double weight)
+{
+    const long k = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (k >= pl.n) return;
+    const long cells = (long)nx*ny;
+    const int ip = (int)(k / cells);
+    const long c = k - (long)ip*cells;
+    const int j = (int)(c / nx), i = (int)(c - (long)j*nx);
+    const int ixp = ip % ppcx, iyp = ip / ppcx;
+    const double x = lox + (i + (0.5 + ixp)/ppcx)*dx;
+    const double y = loy + (j + (0.5 + iyp)/ppcy)*dy;
+    pl.x[k] = x; pl.y[k] = y; pl.w[k] = weight;
+    pl.ux[k] = 0.0; pl.uy[k] = 0.0; pl.psi[k] = 1.0;
+    pl.x_prev[k] = x; pl.y_prev[k] = y;
+    pl.ux_half[k] = 0.0; pl.uy_half[k] = 0.0; pl.psi_half[k] = 1.0;
+    pl.idcpu[k] = HPS_ID_VALID | (1ULL << 24);      // id = 1, cpu (level) = 0
+    pl.ion_lev[k] = 0;
+}
+
+// beam slice deposit (particles/deposition/BeamDepositCurrent.cpp:21-195), depos_order_z = 0
+template <int ORDER>
+__global__ __launch_bounds__(256)
+void k_beam_deposit (SlabView f, BeamView b, long first, long count, int cjx, int cjy, int cjz,
+                     double q_invvol, double clightsq_inv, double dx_inv, double dy_inv, double xoff, double yoff)
+{
+    const long t = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const long ip = first + t;
+    const double ux = b.ux[ip], uy = b.uy[ip], uz = b.uz[ip];
+    const double gaminv = 1.0/sqrt(1.0 + ux*ux*clightsq_inv + uy*uy*clightsq_inv + uz*uz*clightsq_inv);
+    const double wq = q_invvol*b.w[ip];
+    double sx[ORDER + 1], sy[ORDER + 1];
+    const int i0 = shape_weights<ORDER>((b.x[ip] - xoff)*dx_inv, sx);
+    const int j0 = shape_weights<ORDER>((b.y[ip] - yoff)*dy_inv, sy);
+#pragma unroll
+    for (int iy = 0; iy <= ORDER; ++iy) {
+#pragma unroll
+        for (int ix = 0; ix <= ORDER; ++ix) {
+            double* p = f.p + f.off(i0 + ix, j0 + iy);
+            const double s = sx[ix]*sy[iy];
+            if (cjx >= 0) { atomic_add_f64(p + cjx*f.ns, s*(wq*(ux*gaminv))); atomic_add_f64(p + cjy*f.ns, s*(wq*(uy*gaminv))); }
+            if (cjz >= 0) atomic_add_f64(p + cjz*f.ns, s*(wq*(uz*gaminv)));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Engine
+// ------------------------------------------------------------------------------------------
+Engine::~Engine ()
+{
+    if (ps) hps_poisson_destroy(ps);
+    if (mg) hps_mg_destroy(mg);
+    (void)hipFree(slab.p); (void)hipFree(pl_real); (void)hipFree(pl.idcpu); (void)hipFree(pl.ion_lev);
+    (void)hipFree(staging); (void)hipFree(beam_data); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
+    for (auto e : ev) (void)hipEventDestroy(e);
+    if (st) (void)hipStreamDestroy(st);
+}
+
+static double beam_density_at (const hps_deck& d, double x, double y, double z)
+{
+    if (d.beam_profile == 0) {
+        const double a = (x - d.beam_pos_mean[0])/d.beam_pos_std[0];
+        const double b = (y - d.beam_pos_mean[1])/d.beam_pos_std[1];
+        const double c = (z - d.beam_pos_mean[2])/d.beam_pos_std[2];
+        return d.beam_density*std::exp(-0.5*a*a)*std::exp(-0.5*b*b)*std::exp(-0.5*c*c);
+    }
+    return d.beam_density;
+}
+
+// fixed-ppc beam, generated once on the host, stored slice-major (head slice first); restates
+// InitBeamFixedPPCSlice (beam/BeamParticleContainerInit.cpp:198-346)
+int Engine::init_beam ()
+{
+    std::vector<double> h[7];
+    beam_off.assign(d.nz + 1, 0);
+    if (d.beam_profile >= 0) {
+        const int nppc = d.beam_ppc[0]*d.beam_ppc[1]*d.beam_ppc[2];
+        const int nyp = d.beam_ppc[1], nzp = d.beam_ppc[2];
+        for (int isl = d.nz - 1; isl >= 0; --isl) {
+            beam_off[d.nz - 1 - isl] = (long)h[0].size();
+            for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i) for (int ip = 0; ip < nppc; ++ip) {
+                const int ixp = ip/(nyp*nzp), iyp = (ip % (nyp*nzp)) % nyp, izp = (ip % (nyp*nzp))/nyp;
+                const double x = d.lo[0] + (i + (0.5 + ixp)/d.beam_ppc[0])*gm.dx;
+                const double y = d.lo[1] + (j + (0.5 + iyp)/d.beam_ppc[1])*gm.dy;
+                const double z = d.lo[2] + (isl + (0.5 + izp)/d.beam_ppc[2])*gm.dz;
+                const double rx = x - d.beam_pos_mean[0], ry = y - d.beam_pos_mean[1];
+                if (z >= d.beam_zmax || z < d.beam_zmin || (rx*rx + ry*ry) > d.beam_radius*d.beam_radius) continue;
+                const double dens = beam_density_at(d, x, y, z);
+                if (dens <= 0.0) continue;
+                h[0].push_back(x); h[1].push_back(y); h[2].push_back(z);
+                h[3].push_back(d.beam_umean[0]*gm.c); h[4].push_back(d.beam_umean[1]*gm.c); h[5].push_back(d.beam_umean[2]*gm.c);
+                h[6].push_back(std::fabs(dens/nppc));
+            }
+        }
+    }
+    beam_off[d.nz] = (long)h[0].size();
+    nbeam = (long)h[0].size();
+    if (nbeam > 0) {
+        HPS_HIP_CHECK(hipMalloc(&beam_data, 7*nbeam*sizeof(double)));
+        for (int k = 0; k < 7; ++k)
+            HPS_HIP_CHECK(hipMemcpy(beam_data + k*nbeam, h[k].data(), nbeam*sizeof(double), hipMemcpyHostToDevice));
+        beam = BeamView{beam_data, beam_data + nbeam, beam_data + 2*nbeam, beam_data + 3*nbeam, beam_data + 4*nbeam,
+                        beam_data + 5*nbeam, beam_data + 6*nbeam};
+    }
+    return HPS_OK;
+}
+
+int Engine::create (const hps_deck& deck, int device)
+{
+    d = deck;
+    HPS_REQUIRE(d.nx >= 4 && d.ny >= 4 && d.nz >= 1, "hps_engine_create: bad grid");
+    HPS_REQUIRE(d.order >= 0 && d.order <= 3, "hps_engine_create: depos_order must be 0..3");
+    HPS_REQUIRE(d.plasma_radius <= 0.0, "hps_engine_create: finite plasma radius not supported yet");
+    HPS_HIP_CHECK(hipSetDevice(device));
+    HPS_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    g = (d.order + 1)/2 + 1;                       // Fields::AllocData (fields/Fields.cpp:63-64)
+    ncomp = d.deposit_rho ? HPS_C_RHO + 1 : HPS_C_RHO;
+    gm.dx = (d.hi[0] - d.lo[0])/d.nx; gm.dy = (d.hi[1] - d.lo[1])/d.ny; gm.dz = (d.hi[2] - d.lo[2])/d.nz;
+    gm.xoff = 0.5*(d.lo[0] + d.hi[0] - gm.dx*(d.nx - 1));
+    gm.yoff = 0.5*(d.lo[1] + d.hi[1] - gm.dy*(d.ny - 1));
+    gm.c = gm.ep0 = gm.mu0 = gm.q_e = gm.m_e = 1.0;
+    gm.plo[0] = d.lo[0]; gm.plo[1] = d.lo[1]; gm.phi[0] = d.hi[0]; gm.phi[1] = d.hi[1];
+    gm.bc = d.bc; gm.normalized = 1;
+
+    slab.nx = d.nx; slab.ny = d.ny; slab.ng = g; slab.ncomp = ncomp;
+    slab.jstride = d.nx + 2*g; slab.nstride = slab.jstride*(d.ny + 2*g);
+    HPS_HIP_CHECK(hipMalloc(&slab.p, (size_t)slab.nstride*ncomp*sizeof(double)));
+    HPS_HIP_CHECK(hipMemset(slab.p, 0, (size_t)slab.nstride*ncomp*sizeof(double)));
+    HPS_HIP_CHECK(hipMalloc(&staging, (size_t)d.nx*d.ny*sizeof(double)));
+
+    const int nppc = d.plasma_ppc[0]*d.plasma_ppc[1];
+    np = (d.plasma_density > 0.0) ? (long)nppc*d.nx*d.ny : 0;
+    std::memset(&pl, 0, sizeof(pl));
+    pl.n = np;
+    if (np > 0) {
+        HPS_HIP_CHECK(hipMalloc(&pl_real, (size_t)np*11*sizeof(double)));
+        double** arr[11] = {&pl.x, &pl.y, &pl.w, &pl.ux, &pl.uy, &pl.psi, &pl.x_prev, &pl.y_prev, &pl.ux_half, &pl.uy_half, &pl.psi_half};
+        for (int k = 0; k < 11; ++k) *arr[k] = pl_real + (size_t)k*np;
+        HPS_HIP_CHECK(hipMalloc(&pl.idcpu, (size_t)np*sizeof(uint64_t)));
+        HPS_HIP_CHECK(hipMalloc(&pl.ion_lev, (size_t)np*sizeof(int32_t)));
+    }
+    HPS_HIP_CHECK(hipMalloc(&d_nqsa, sizeof(int)));
+    HPS_HIP_CHECK(hipMemset(d_nqsa, 0, sizeof(int)));
+    HPS_HIP_CHECK(hipMalloc(&d_checksum, HPS_NCOMP_MAX*sizeof(double)));
+    HPS_HIP_CHECK(hipMemset(d_checksum, 0, HPS_NCOMP_MAX*sizeof(double)));
+    if (int e = hps_poisson_create(d.nx, d.ny, gm.dx, gm.dy, &ps)) return e;
+    if (int e = hps_mg_create(d.nx, d.ny, gm.dx, gm.dy, &mg)) return e;
+    return init_beam();
+}
+
+int Engine::begin_step ()
+{
+    // ResetAllQuantities (Hipace.cpp:730-742)
+    HPS_HIP_CHECK(hipMemsetAsync(slab.p, 0, (size_t)slab.nstride*ncomp*sizeof(double), st));
+    HPS_HIP_CHECK(hipMemsetAsync(d_checksum, 0, HPS_NCOMP_MAX*sizeof(double), st));
+    if (np > 0) {
+        const int nppc = d.plasma_ppc[0]*d.plasma_ppc[1];
+        hipLaunchKernelGGL(k_init_plasma, dim3(ceil_div(np, 256)), dim3(256), 0, st, pl, d.nx, d.ny,
+                           d.plasma_ppc[0], d.plasma_ppc[1], d.lo[0], d.lo[1], gm.dx, gm.dy, d.plasma_density*(1.0/nppc));
+        // neutralising ion background, deposited once per step with charge -q (MultiPlasma.cpp:106-118)
+        const int comp[6] = {-1, -1, -1, -1, -1, HPS_C_ION_RHOMJZ};
+        if (int e = hps_deposit_current(slab, pl, gm, comp, -d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st)) return e;
+    }
+    HPS_HIP_CHECK(hipGetLastError());
+    return HPS_OK;
+}
+
+int Engine::deposit_beam_slice (int islice, int cjx, int cjy, int cjz)
+{
+    if (nbeam == 0 || islice < 0 || islice >= d.nz) return HPS_OK;
+    const long first = beam_off[d.nz - 1 - islice], count = beam_off[d.nz - islice] - first;
+    if (count <= 0) return HPS_OK;
+    const double q_invvol = d.beam_charge*1.0;      // normalised units, level 0
+    const double csq_inv = 1.0/(gm.c*gm.c);
+    const dim3 grid(ceil_div(count, 256)), block(256);
+    SlabView f(slab);
+    switch (d.order) {
+        case 0: hipLaunchKernelGGL(k_beam_deposit<0>, grid, block, 0, st, f, beam, first, count, cjx, cjy, cjz, q_invvol, csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff); break;
+        case 1: hipLaunchKernelGGL(k_beam_deposit<1>, grid, block, 0, st, f, beam, first, count, cjx, cjy, cjz, q_invvol, csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff); break;
+        case 2: hipLaunchKernelGGL(k_beam_deposit<2>, grid, block, 0, st, f, beam, first, count, cjx, cjy, cjz, q_invvol, csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff); break;
+        default: hipLaunchKernelGGL(k_beam_deposit<3>, grid, block, 0, st, f, beam, first, count, cjx, cjy, cjz, q_invvol, csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff); break;
+    }
+    return HPS_OK;
+}
+
+void Engine::mark ()
+{
+    if (!profiling) return;
+    if (ev_used == ev.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev.push_back(e); }
+    (void)hipEventRecord(ev[ev_used++], st);
+}
+
+int Engine::solve_slice (int islice)
+{
+    SlabView f(slab);
+    const long plane = slab.nstride;
+    const dim3 b256(256);
+    const dim3 gplane(ceil_div(plane, 256));
+    const dim3 gvalid(ceil_div(d.nx, 256), d.ny);
+    int e;
+
+    mark();   // b0
+    // InitializeSlices (fields/Fields.cpp:535-586)
+    {   CompList z{0, {}};
+        for (int c : {HPS_C_CHI, HPS_C_SY, HPS_C_SX, HPS_C_EXMBY, HPS_C_EYPBX, HPS_C_JZB, HPS_C_RHOMJZ, HPS_C_N_JXB, HPS_C_N_JYB}) z.c[z.n++] = c;
+        if (d.deposit_rho) z.c[z.n++] = HPS_C_RHO;
+        hipLaunchKernelGGL(k_zero_comps, gplane, b256, 0, st, slab.p, slab.nstride, plane, z); }
+
+    mark();   // b1
+    // plasma: jx, jy, [rho], chi, rhomjz (Hipace.cpp:609-610); beam: jz_beam on This (:613-614)
+    {   const int comp[6] = {HPS_C_JX, HPS_C_JY, -1, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_CHI, HPS_C_RHOMJZ};
+        if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; }
+    mark();   // b2
+    if ((e = deposit_beam_slice(islice, -1, -1, HPS_C_JZB))) return e;
+
+    // AddRhoIons + Psi, Ez, Bz solves + -grad Psi (fields/Fields.cpp:840-957)
+    hipLaunchKernelGGL(k_add_ions_psi_rhs, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_RHOMJZ,
+                       HPS_C_ION_RHOMJZ, d.deposit_rho ? HPS_C_RHO : -1, 1.0/gm.ep0, staging);
+    if ((e = hps_poisson_solve(ps, staging, slab, HPS_C_PSI, st))) return e;
+    {   const double fa = 1.0/(gm.ep0*gm.c);
+        hipLaunchKernelGGL(k_rhs_lincomb, gvalid, b256, 0, st, f, HPS_C_JX, 0, fa*0.5*(1.0/gm.dx), HPS_C_JY, 1, fa*0.5*(1.0/gm.dy), staging); }
+    if ((e = hps_poisson_solve(ps, staging, slab, HPS_C_EZ, st))) return e;
+    hipLaunchKernelGGL(k_rhs_lincomb, gvalid, b256, 0, st, f, HPS_C_JX, 1, gm.mu0*0.5*(1.0/gm.dy), HPS_C_JY, 0, -gm.mu0*0.5*(1.0/gm.dx), staging);
+    if ((e = hps_poisson_solve(ps, staging, slab, HPS_C_BZ, st))) return e;
+    hipLaunchKernelGGL(k_grad_psi, dim3(ceil_div(d.nx + 2*(g - 1), 256), d.ny + 2*(g - 1)), b256, 0, st, f, HPS_C_PSI,
+                       HPS_C_EXMBY, HPS_C_EYPBX, 0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy));
+
+    mark();   // b3
+    // beam jx, jy of the next slice; beam part of Sx, Sy; plasma part of Sx, Sy (Hipace.cpp:656-663)
+    if ((e = deposit_beam_slice(islice - 1, HPS_C_N_JXB, HPS_C_N_JYB, -1))) return e;
+    hipLaunchKernelGGL(k_sxsy_beam, gvalid, b256, 0, st, f, HPS_C_SX, HPS_C_SY, HPS_C_JZB, HPS_C_N_JXB, HPS_C_N_JYB,
+                       HPS_C_P_JXB, HPS_C_P_JYB, gm.mu0, 2.0*gm.dx, 2.0*gm.dy, 2.0*gm.dz);
+    mark();   // b4
+    {   const int cache[4] = {HPS_C_BZ, HPS_C_EZ, HPS_C_EXMBY, HPS_C_EYPBX};
+        const int depos[2] = {HPS_C_SY, HPS_C_SX};
+        if ((e = hps_explicit_deposit(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, st))) return e; }
+
+    mark();   // b5
+    // Bx, By: Helmholtz multigrid from the previous slice's field (Hipace.cpp:793-933)
+    {   int iters = 0;
+        if ((e = hps_mg_solve1(mg, slab, HPS_C_BX, HPS_C_SY, HPS_C_CHI, d.mg_tol_rel, d.mg_tol_abs, 200, &iters, nullptr, st))) return e;
+        total_vcycles += iters; }
+
+    mark();   // b6
+    if (diagnostics)
+        hipLaunchKernelGGL(k_checksum, dim3(64, ncomp), b256, 0, st, f, ncomp, d_checksum);
+
+    mark();   // b7
+    // gather + push (Hipace.cpp:699-701)
+    {   const int comp[5] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ};
+        if ((e = hps_advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; }
+
+    mark();   // b8
+    // ShiftSlices (fields/Fields.cpp:588-604)
+    {   CompList dst{6, {HPS_C_P_JXB, HPS_C_P_JYB, HPS_C_JXB, HPS_C_JYB, HPS_C_JX, HPS_C_JY}};
+        CompList src{6, {HPS_C_JXB, HPS_C_JYB, HPS_C_N_JXB, HPS_C_N_JYB, HPS_C_N_JXB, HPS_C_N_JYB}};
+        hipLaunchKernelGGL(k_copy_comps, gplane, b256, 0, st, slab.p, slab.nstride, plane, dst, src); }
+    mark();   // b9
+    HPS_HIP_CHECK(hipGetLastError());
+    ++slices_done;
+    return HPS_OK;
+}
+
+int Engine::run_step ()
+{
+    if (int e = begin_step()) return e;
+    for (int isl = d.nz - 1; isl >= 0; --isl)
+        if (int e = solve_slice(isl)) return e;
+    return HPS_OK;
+}
+
+} // namespace hps
+
+using namespace hps;
+
+extern "C" const char* hps_last_error (void) { return g_err.c_str(); }
+extern "C" const char* hps_version (void) { return "hpslice 0.1 (gfx950)"; }
+
+extern "C" int hps_engine_create (const hps_deck* deck, int device, void** handle)
+{
+    HPS_REQUIRE(deck && handle, "hps_engine_create: null argument");
+    Engine* E = new Engine;
+    if (int e = E->create(*deck, device)) { delete E; return e; }
+    *handle = E;
+    return HPS_OK;
+}
+extern "C" int hps_engine_destroy (void* h) { delete static_cast<Engine*>(h); return HPS_OK; }
+extern "C" int hps_engine_begin_step (void* h) { return static_cast<Engine*>(h)->begin_step(); }
+extern "C" int hps_engine_solve_slice (void* h, int islice) { return static_cast<Engine*>(h)->solve_slice(islice); }
+extern "C" int hps_engine_run_step (void* h) { return static_cast<Engine*>(h)->run_step(); }
+extern "C" int hps_engine_sync (void* h) { HPS_HIP_CHECK(hipStreamSynchronize(static_cast<Engine*>(h)->st)); return HPS_OK; }
+extern "C" int hps_engine_info (void* h, int* ncomp, int* ng, long* np)
+{
+    Engine* E = static_cast<Engine*>(h);
+    if (ncomp) *ncomp = E->ncomp;
+    if (ng) *ng = E->g;
+    if (np) *np = E->np;
+    return HPS_OK;
+}
+extern "C" hps_slab hps_engine_slab (void* h) { return static_cast<Engine*>(h)->slab; }
+extern "C" hps_plasma hps_engine_plasma (void* h) { return static_cast<Engine*>(h)->pl; }
+extern "C" hps_stream hps_engine_stream (void* h) { return static_cast<Engine*>(h)->st; }
+extern "C" int hps_engine_checksums (void* h, double* out)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    HPS_HIP_CHECK(hipMemcpy(out, E->d_checksum, E->ncomp*sizeof(double), hipMemcpyDeviceToHost));
+    return HPS_OK;
+}
+extern "C" int hps_engine_stats (void* h, long* vc, long* sl)
+{
+    Engine* E = static_cast<Engine*>(h);
+    if (vc) *vc = E->total_vcycles;
+    if (sl) *sl = E->slices_done;
+    return HPS_OK;
+}
+extern "C" int hps_engine_set_profiling (void* h, int on)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    E->profiling = (on != 0); E->ev_used = 0;
+    return HPS_OK;
+}
+extern "C" int hps_engine_phase_times (void* h, double* ms, long* nsl)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    // interval -> phase: 0 deposit, 1 poisson, 2 explicit, 3 mg, 4 push, 5 other
+    static const int phase_of[9] = {5, 0, 1, 5, 2, 3, 5, 4, 5};
+    for (int k = 0; k < 6; ++k) ms[k] = 0.0;
+    const size_t ns = E->ev_used/10;
+    for (size_t s = 0; s < ns; ++s)
+        for (int k = 0; k < 9; ++k) {
+            float t = 0.f;
+            HPS_HIP_CHECK(hipEventElapsedTime(&t, E->ev[s*10 + k], E->ev[s*10 + k + 1]));
+            ms[phase_of[k]] += t;
+        }
+    if (nsl) *nsl = (long)ns;
+    E->ev_used = 0;
+    return HPS_OK;
+}
+extern "C" int hps_engine_set_diagnostics (void* h, int on) { static_cast<Engine*>(h)->diagnostics = (on != 0); return HPS_OK; }
+
+extern "C" int hps_memcpy_d2h (void* dst, const void* src, long bytes) { HPS_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return HPS_OK; }
+extern "C" int hps_memcpy_h2d (void* dst, const void* src, long bytes) { HPS_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return HPS_OK; }
+extern "C" int hps_device_count (int* n)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    *n = c;
+    return HPS_OK;
+}

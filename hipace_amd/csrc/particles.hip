@@ -1,0 +1,394 @@
+// particles.hip -- plasma-sheet particle kernels for gfx950:
+//   hps_deposit_current   (scatter of jx,jy,jz,rho,chi,rhomjz)
+//   hps_explicit_deposit  (scatter of the explicit-solver sources Sy,Sx)
+//   hps_advance_plasma    (field gather + leapfrog push with dual-number 2nd-order sub-steps)
+// One particle per lane, SoA particle arrays read fully coalesced, 1-D shape factors hoisted out
+// of the stencil loops, native fp64 global atomics (global_atomic_add_f64) for the scatter.
+// Reference semantics: particles/deposition/PlasmaDepositCurrent.cpp:155-246,
+// particles/deposition/ExplicitDeposition.cpp:140-261,
+// particles/pusher/PlasmaParticleAdvance.cpp:92-217.
+#include "common.h"
+
+namespace hps {
+
+struct DepComps { int jx, jy, jz, rho, chi, rhomjz; };
+
+struct PartConsts {
+    double dx_inv, dy_inv, xoff, yoff;
+    double c, c_inv;
+    double a, b;          // kernel-specific prefactors
+    double max_qsa;
+    double plo0, plo1, phi0, phi1;
+    double dz;
+    int bc, can_ionize, temp_slice, n_subcycles;
+};
+
+// ------------------------------------------------------------------------------------------
+// current / charge deposition
+// ------------------------------------------------------------------------------------------
+template <int ORDER>
+__global__ __launch_bounds__(256)
+void k_deposit_current (SlabView f, hps_plasma pl, DepComps cm, PartConsts k, int* n_qsa)
+{
+    const long ip = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (ip >= pl.n) return;
+    const uint64_t id = pl.idcpu[ip];
+    if (!(id & HPS_ID_VALID)) return;
+
+    const double psi_inv = 1.0/pl.psi[ip];
+    const double vx_c = pl.ux[ip]*psi_inv;
+    const double vy_c = pl.uy[ip]*psi_inv;
+    double q_invvol = k.a*pl.w[ip];           // charge * invvol * w
+    double q_mu0_mass = k.b;                  // charge * mu0 / mass
+    if (k.can_ionize) { const double il = (double)pl.ion_lev[ip]; q_invvol *= il; q_mu0_mass *= il; }
+
+    const double gamma_psi = 0.5*(psi_inv*psi_inv + vx_c*vx_c*k.c_inv*k.c_inv
+                                  + vy_c*vy_c*k.c_inv*k.c_inv + 1.0);
+    if (gamma_psi < 0.0 || gamma_psi > k.max_qsa || psi_inv < 0.0) {
+        // particle violates the quasi-static approximation: drop it
+        if (n_qsa) atomicAdd(n_qsa, 1);
+        pl.w[ip] = 0.0;
+        pl.idcpu[ip] = id & ~HPS_ID_VALID;
+        return;
+    }
+
+    double sx[ORDER + 1], sy[ORDER + 1];
+    const int i0 = shape_weights<ORDER>((pl.x[ip] - k.xoff)*k.dx_inv, sx);
+    const int j0 = shape_weights<ORDER>((pl.y[ip] - k.yoff)*k.dy_inv, sy);
+
+    const double wz = (gamma_psi - 1.0)*k.c;
+    const double wchi = q_mu0_mass*psi_inv;
+#pragma unroll
+    for (int iy = 0; iy <= ORDER; ++iy) {
+        const long row = f.off(i0, j0 + iy);
+#pragma unroll
+        for (int ix = 0; ix <= ORDER; ++ix) {
+            const double cd = q_invvol*sx[ix]*sy[iy];
+            double* p = f.p + row + ix;
+            if (cm.jx >= 0) {
+                atomic_add_f64(p + cm.jx*f.ns, cd*vx_c);
+                atomic_add_f64(p + cm.jy*f.ns, cd*vy_c);
+            }
+            if (cm.jz >= 0)     atomic_add_f64(p + cm.jz*f.ns, cd*wz);
+            if (cm.rho >= 0)    atomic_add_f64(p + cm.rho*f.ns, cd*gamma_psi);
+            if (cm.chi >= 0)    atomic_add_f64(p + cm.chi*f.ns, cd*wchi);
+            if (cm.rhomjz >= 0) atomic_add_f64(p + cm.rhomjz*f.ns, cd);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// explicit-solver source deposition (Sy, Sx)
+// ------------------------------------------------------------------------------------------
+template <int ORDER, int DT>
+__global__ __launch_bounds__(256)
+void k_explicit_deposit (SlabView f, hps_plasma pl, int cBz, int cEz, int cExmBy, int cEypBx,
+                         int cSy, int cSx, PartConsts k)
+{
+    const long ip = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (ip >= pl.n) return;
+    if (!(pl.idcpu[ip] & HPS_ID_VALID)) return;
+
+    constexpr int NS = ORDER + DT + 1;
+    const double psi_inv = 1.0/pl.psi[ip];
+    const double vx = pl.ux[ip]*psi_inv*k.c_inv;
+    const double vy = pl.uy[ip]*psi_inv*k.c_inv;
+    double q_invvol_mu0 = k.a;      // charge * invvol * mu0
+    double q_mass = k.b;            // charge / mass
+    if (k.can_ionize) { const double il = (double)pl.ion_lev[ip]; q_invvol_mu0 *= il; q_mass *= il; }
+    const double cdm = q_invvol_mu0*pl.w[ip];
+    const double gp = 0.5*(psi_inv*psi_inv + vx*vx + vy*vy + 1.0);
+
+    double sx[NS], dsx[NS], sy[NS], dsy[NS];
+    int i0, j0;
+    const double xmid = (pl.x[ip] - k.xoff)*k.dx_inv;
+    const double ymid = (pl.y[ip] - k.yoff)*k.dy_inv;
+    if constexpr (DT == 2) { i0 = centred_weights<ORDER>(xmid, sx, dsx); j0 = centred_weights<ORDER>(ymid, sy, dsy); }
+    else                   { i0 = nodal_weights<ORDER>(xmid, sx, dsx);   j0 = nodal_weights<ORDER>(ymid, sy, dsy); }
+
+    const double qp = q_mass*psi_inv;
+    // field-independent coefficient combinations
+    const double vxvy = vx*vy;
+    const double gy = gp - vy*vy;      // multiplies EypBx in Sy
+    const double gx = gp - vx*vx;      // multiplies ExmBy in Sx
+#pragma unroll
+    for (int iy = 0; iy < NS; ++iy) {
+        const long row = f.off(i0, j0 + iy);
+#pragma unroll
+        for (int ix = 0; ix < NS; ++ix) {
+            if (DT == 2 && (ix == 0 || ix == NS - 1) && (iy == 0 || iy == NS - 1)) continue;
+            double* p = f.p + row + ix;
+            const double Bz = p[cBz*f.ns];
+            const double Ez = p[cEz*f.ns];
+            const double ExmBy = p[cExmBy*f.ns];
+            const double EypBx = p[cEypBx*f.ns];
+            const double ss = sx[ix]*sy[iy];
+            const double dxs = dsx[ix]*sy[iy]*k.dx_inv;
+            const double sdy = sx[ix]*dsy[iy]*k.dy_inv;
+            const double sy_add = cdm*(
+                - ss*( -Bz*vx + (Ez*vy + ExmBy*(-vxvy) + EypBx*gy)*k.c_inv )*qp
+                + ( -dxs*(-vxvy) - sdy*(gy - 1.0) )*k.c);
+            const double sx_add = cdm*(
+                + ss*( Bz*vy + (Ez*vx + ExmBy*gx + EypBx*(-vxvy))*k.c_inv )*qp
+                + ( dxs*(gx - 1.0) + sdy*(-vxvy) )*k.c);
+            atomic_add_f64(p + cSy*f.ns, sy_add);
+            atomic_add_f64(p + cSx*f.ns, sx_add);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// gather + push
+// ------------------------------------------------------------------------------------------
+struct D2 { double v, e; };   // dual number (value, first-order part)
+__device__ __forceinline__ D2 operator+ (D2 a, D2 b) { return {a.v + b.v, a.e + b.e}; }
+__device__ __forceinline__ D2 operator- (D2 a, D2 b) { return {a.v - b.v, a.e - b.e}; }
+__device__ __forceinline__ D2 operator* (D2 a, D2 b) { return {a.v*b.v, a.e*b.v + a.v*b.e}; }
+__device__ __forceinline__ D2 operator* (D2 a, double b) { return {a.v*b, a.e*b}; }
+__device__ __forceinline__ D2 operator+ (D2 a, double b) { return {a.v + b, a.e}; }
+__device__ __forceinline__ D2 operator- (D2 a, double b) { return {a.v - b, a.e}; }
+
+struct Fld { double ExmBy, EypBx, Ez, Bxc, Byc, Bz; };
+
+// d/dzeta of (ux, uy, psi) in the quasi-static frame; T = double or D2.
+// gamma/psi = 1/2 psi^-2 (1 + u^2/c^2) + 1/2  (particles/pusher/PushPlasmaParticles.H:59-72)
+template <class T>
+__device__ __forceinline__ void zeta_derivs (const T& ux, const T& uy, const T& psi_inv, const Fld& F,
+                                             double c_inv, double qmc, T& dux, T& duy, T& dpsi)
+{
+    const double ci2 = c_inv*c_inv;
+    const T gamma_psi = (psi_inv*psi_inv)*0.5*( (ux*ux)*ci2 + (uy*uy)*ci2 + 1.0 ) + 0.5;
+    dux = (gamma_psi*F.ExmBy + F.Byc + (uy*F.Bz)*psi_inv)*qmc;
+    duy = (gamma_psi*F.EypBx - F.Bxc - (ux*F.Bz)*psi_inv)*qmc;
+    dpsi = (((ux*F.ExmBy + uy*F.EypBx)*c_inv)*psi_inv - F.Ez)*(qmc*c_inv);
+}
+
+__device__ __forceinline__ void taylor2_substep (double& ux, double& uy, double& psi, const Fld& F,
+                                                 double c_inv, double qmc, double sdz)
+{
+    const double psi_inv = 1.0/psi;
+    double dux, duy, dpsi;
+    zeta_derivs<double>(ux, uy, psi_inv, F, c_inv, qmc, dux, duy, dpsi);
+    const D2 uxd{ux, dux}, uyd{uy, duy}, pid{psi_inv, -psi_inv*psi_inv*dpsi};
+    D2 ddux, dduy, ddpsi;
+    zeta_derivs<D2>(uxd, uyd, pid, F, c_inv, qmc, ddux, dduy, ddpsi);
+    const double h2 = 0.5*sdz*sdz;
+    ux += sdz*dux + h2*ddux.e;
+    uy += sdz*duy + h2*dduy.e;
+    psi += sdz*dpsi + h2*ddpsi.e;
+}
+
+// particle boundary; returns true if the particle was absorbed
+__device__ __forceinline__ bool apply_particle_bc (const PartConsts& k, double& x, double& y,
+                                                   double& ux, double& uy)
+{
+    if (x < k.plo0 || y < k.plo1 || x > k.phi0 || y > k.phi1) {
+        const double lx = k.phi0 - k.plo0, ly = k.phi1 - k.plo1;
+        if (k.bc == HPS_BC_REFLECTING) {
+            x = fmod(x - k.plo0, 2*lx); if (x < 0) x += 2*lx; x += k.plo0;
+            if (x > k.phi0) { x = 2*k.phi0 - x; ux = -ux; }
+            y = fmod(y - k.plo1, 2*ly); if (y < 0) y += 2*ly; y += k.plo1;
+            if (y > k.phi1) { y = 2*k.phi1 - y; uy = -uy; }
+        } else if (k.bc == HPS_BC_PERIODIC) {
+            x = fmod(x - k.plo0, lx); if (x < 0) x += lx; x += k.plo0;
+            y = fmod(y - k.plo1, ly); if (y < 0) y += ly; y += k.plo1;
+        } else {
+            return true;
+        }
+    }
+    return false;
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(256)
+void k_advance_plasma (SlabView f, hps_plasma pl, int cPsi, int cEz, int cBx, int cBy, int cBz,
+                       PartConsts k)
+{
+    const long ip = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (ip >= pl.n) return;
+    const uint64_t id = pl.idcpu[ip];
+    if (!(id & HPS_ID_VALID)) return;
+
+    constexpr int NS = ORDER + 2;
+    double qmc = k.a;    // charge / (mass c)
+    if (k.can_ionize) qmc *= (double)pl.ion_lev[ip];
+
+    for (int isc = 0; isc < k.n_subcycles; ++isc) {
+        double xp = pl.x_prev[ip];
+        double yp = pl.y_prev[ip];
+
+        // gather at (x_prev, y_prev): E-like fields from -grad(Psi) via the nodal-derivative set
+        double sx[NS], dsx[NS], sy[NS], dsy[NS];
+        const int i0 = nodal_weights<ORDER>((xp - k.xoff)*k.dx_inv, sx, dsx);
+        const int j0 = nodal_weights<ORDER>((yp - k.yoff)*k.dy_inv, sy, dsy);
+        Fld F{0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int iy = 0; iy < NS; ++iy) {
+            const long row = f.off(i0, j0 + iy);
+#pragma unroll
+            for (int ix = 0; ix < NS; ++ix) {
+                const double* p = f.p + row + ix;
+                const double psi_c = p[cPsi*f.ns];
+                const double ss = sx[ix]*sy[iy];
+                F.ExmBy += (dsx[ix]*sy[iy])*psi_c*k.dx_inv;
+                F.EypBx += (sx[ix]*dsy[iy])*psi_c*k.dy_inv;
+                F.Ez  += ss*p[cEz*f.ns];
+                F.Bxc += ss*p[cBx*f.ns];
+                F.Byc += ss*p[cBy*f.ns];
+                F.Bz  += ss*p[cBz*f.ns];
+            }
+        }
+        F.Bxc *= k.c;
+        F.Byc *= k.c;
+
+        const double dz = k.dz;
+        const double sdz = dz*0.25;
+        double ux = pl.ux_half[ip], uy = pl.uy_half[ip], psi = pl.psi_half[ip];
+
+        // momenta t-1/2 -> t+1/2 with the fields at t (4 second-order Taylor sub-steps)
+#pragma unroll 1
+        for (int s = 0; s < 4; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
+
+        // positions t -> t+1 with the momenta at t+1/2
+        const double pinv = 1.0/psi;
+        xp += dz*k.c_inv*(ux*pinv);
+        yp += dz*k.c_inv*(uy*pinv);
+
+        if (apply_particle_bc(k, xp, yp, ux, uy)) {
+            pl.w[ip] = 0.0;
+            pl.idcpu[ip] = id & ~HPS_ID_VALID;
+            return;
+        }
+        pl.x[ip] = xp;
+        pl.y[ip] = yp;
+        if (!k.temp_slice) {
+            pl.ux_half[ip] = ux; pl.uy_half[ip] = uy; pl.psi_half[ip] = psi;
+            pl.x_prev[ip] = xp;  pl.y_prev[ip] = yp;
+        }
+
+        // extra half push t+1/2 -> t+1: time-centred state used by the deposition only
+#pragma unroll 1
+        for (int s = 0; s < 2; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
+        pl.ux[ip] = ux; pl.uy[ip] = uy; pl.psi[ip] = psi;
+    }
+}
+
+static PartConsts base_consts (const hps_geom& g)
+{
+    PartConsts k{};
+    k.dx_inv = 1.0/g.dx; k.dy_inv = 1.0/g.dy; k.xoff = g.xoff; k.yoff = g.yoff;
+    k.c = g.c; k.c_inv = 1.0/g.c;
+    k.plo0 = g.plo[0]; k.plo1 = g.plo[1]; k.phi0 = g.phi[0]; k.phi1 = g.phi[1];
+    k.bc = g.bc;
+    return k;
+}
+
+static double invvol_of (const hps_geom& g)
+{
+    // normalised units: 1 on level 0; SI: charge -> charge density (PlasmaDepositCurrent.cpp:71-73)
+    const double dxi = 1.0/g.dx, dyi = 1.0/g.dy, dzi = 1.0/g.dz;
+    return g.normalized ? g.dx*g.dy*dxi*dyi : dxi*dyi*dzi;
+}
+
+static int check_stencil (const hps_slab& s, int need_guards, const char* what)
+{
+    if (s.p == nullptr || s.nx <= 0 || s.ny <= 0 || s.ng < need_guards) {
+        set_error(std::string(what) + ": slab needs at least " + std::to_string(need_guards) + " guard cells");
+        return HPS_ERR_ARG;
+    }
+    return HPS_OK;
+}
+
+} // namespace hps
+
+using namespace hps;
+
+extern "C" int hps_deposit_current (hps_slab slab, hps_plasma pl, hps_geom g, const int comp[6],
+                                    double charge, double mass, int order, double max_qsa,
+                                    int can_ionize, int* n_qsa, hps_stream stream)
+{
+    HPS_REQUIRE(order >= 0 && order <= 3, "hps_deposit_current: depos_order must be 0..3");
+    if (int e = check_stencil(slab, (order + 1)/2, "hps_deposit_current")) return e;
+    for (int c = 0; c < 6; ++c) HPS_REQUIRE(comp[c] >= -1 && comp[c] < slab.ncomp, "hps_deposit_current: bad component");
+    HPS_REQUIRE((comp[0] < 0) == (comp[1] < 0), "hps_deposit_current: jx and jy are deposited together");
+    if (pl.n == 0) return HPS_OK;
+    PartConsts k = base_consts(g);
+    k.a = charge*invvol_of(g);
+    k.b = charge*g.mu0/mass;
+    k.max_qsa = max_qsa; k.can_ionize = can_ionize;
+    DepComps cm{comp[0], comp[1], comp[2], comp[3], comp[4], comp[5]};
+    const dim3 grid(ceil_div(pl.n, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    SlabView f(slab);
+    switch (order) {
+        case 0: hipLaunchKernelGGL(k_deposit_current<0>, grid, block, 0, st, f, pl, cm, k, n_qsa); break;
+        case 1: hipLaunchKernelGGL(k_deposit_current<1>, grid, block, 0, st, f, pl, cm, k, n_qsa); break;
+        case 2: hipLaunchKernelGGL(k_deposit_current<2>, grid, block, 0, st, f, pl, cm, k, n_qsa); break;
+        default: hipLaunchKernelGGL(k_deposit_current<3>, grid, block, 0, st, f, pl, cm, k, n_qsa); break;
+    }
+    HPS_HIP_CHECK(hipGetLastError());
+    return HPS_OK;
+}
+
+template <int DT>
+static void launch_explicit (int order, dim3 grid, dim3 block, hipStream_t st, SlabView f, hps_plasma pl,
+                             const int* ca, const int* de, PartConsts k)
+{
+    switch (order) {
+        case 0: hipLaunchKernelGGL((k_explicit_deposit<0, DT>), grid, block, 0, st, f, pl, ca[0], ca[1], ca[2], ca[3], de[0], de[1], k); break;
+        case 1: hipLaunchKernelGGL((k_explicit_deposit<1, DT>), grid, block, 0, st, f, pl, ca[0], ca[1], ca[2], ca[3], de[0], de[1], k); break;
+        case 2: hipLaunchKernelGGL((k_explicit_deposit<2, DT>), grid, block, 0, st, f, pl, ca[0], ca[1], ca[2], ca[3], de[0], de[1], k); break;
+        default: hipLaunchKernelGGL((k_explicit_deposit<3, DT>), grid, block, 0, st, f, pl, ca[0], ca[1], ca[2], ca[3], de[0], de[1], k); break;
+    }
+}
+
+extern "C" int hps_explicit_deposit (hps_slab slab, hps_plasma pl, hps_geom g, const int cache[4],
+                                     const int depos[2], double charge, double mass, int order,
+                                     int dtype, int can_ionize, hps_stream stream)
+{
+    HPS_REQUIRE(order >= 0 && order <= 3, "hps_explicit_deposit: depos_order must be 0..3");
+    if (dtype != 1 && dtype != 2) {
+        set_error("hps_explicit_deposit: derivative_type 1 (nodal) or 2 (centred) only");
+        return HPS_ERR_UNSUPPORTED;
+    }
+    if (int e = check_stencil(slab, (order + 1)/2 + 1, "hps_explicit_deposit")) return e;
+    for (int c = 0; c < 4; ++c) HPS_REQUIRE(cache[c] >= 0 && cache[c] < slab.ncomp, "hps_explicit_deposit: bad cache component");
+    for (int c = 0; c < 2; ++c) HPS_REQUIRE(depos[c] >= 0 && depos[c] < slab.ncomp, "hps_explicit_deposit: bad depos component");
+    if (pl.n == 0) return HPS_OK;
+    PartConsts k = base_consts(g);
+    k.a = charge*invvol_of(g)*g.mu0;
+    k.b = charge/mass;
+    k.can_ionize = can_ionize;
+    const dim3 grid(ceil_div(pl.n, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 2) launch_explicit<2>(order, grid, block, st, SlabView(slab), pl, cache, depos, k);
+    else            launch_explicit<1>(order, grid, block, st, SlabView(slab), pl, cache, depos, k);
+    HPS_HIP_CHECK(hipGetLastError());
+    return HPS_OK;
+}
+
+extern "C" int hps_advance_plasma (hps_slab slab, hps_plasma pl, hps_geom g, const int comp[5],
+                                   double charge, double mass, int order, int temp_slice,
+                                   int n_subcycles, int can_ionize, hps_stream stream)
+{
+    HPS_REQUIRE(order >= 0 && order <= 3, "hps_advance_plasma: depos_order must be 0..3");
+    HPS_REQUIRE(n_subcycles >= 1, "hps_advance_plasma: n_subcycles must be >= 1");
+    if (int e = check_stencil(slab, (order + 1)/2 + 1, "hps_advance_plasma")) return e;
+    for (int c = 0; c < 5; ++c) HPS_REQUIRE(comp[c] >= 0 && comp[c] < slab.ncomp, "hps_advance_plasma: bad component");
+    if (pl.n == 0) return HPS_OK;
+    PartConsts k = base_consts(g);
+    k.a = charge/(mass*g.c);
+    k.dz = g.dz/n_subcycles;
+    k.temp_slice = temp_slice; k.n_subcycles = n_subcycles; k.can_ionize = can_ionize;
+    const dim3 grid(ceil_div(pl.n, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    SlabView f(slab);
+    switch (order) {
+        case 0: hipLaunchKernelGGL(k_advance_plasma<0>, grid, block, 0, st, f, pl, comp[0], comp[1], comp[2], comp[3], comp[4], k); break;
+        case 1: hipLaunchKernelGGL(k_advance_plasma<1>, grid, block, 0, st, f, pl, comp[0], comp[1], comp[2], comp[3], comp[4], k); break;
+        case 2: hipLaunchKernelGGL(k_advance_plasma<2>, grid, block, 0, st, f, pl, comp[0], comp[1], comp[2], comp[3], comp[4], k); break;
+        default: hipLaunchKernelGGL(k_advance_plasma<3>, grid, block, 0, st, f, pl, comp[0], comp[1], comp[2], comp[3], comp[4], k); break;
+    }
+    HPS_HIP_CHECK(hipGetLastError());
+    return HPS_OK;
+}

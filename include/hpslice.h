@@ -1,0 +1,165 @@
+/* hpslice.h -- C ABI of the MI355X-native quasi-static PIC slice engine (libhpslice.so).
+ *
+ * Drop-in boundary for the per-zeta-slice hot path of HiPACE++ (reference paths relative to
+ * /root/reference/src).  The reference has no FFI layer; each entry point below replaces one of
+ * its C++ operator seams and takes the same data the reference operator touches, as plain
+ * device pointers + sizes:
+ *
+ *   hps_slab    <-> amrex::MultiFab m_slices[lev] viewed as Array3 (utils/GPUUtil.H:99-147,
+ *                   fields/Fields.H:465): ncomp planes of (nx+2ng) x (ny+2ng) doubles, x fastest.
+ *   hps_plasma  <-> PlasmaParticleContainer pure-SoA tile (particles/plasma/
+ *                   PlasmaParticleContainer.H:21-50): 11 real arrays + idcpu + ion_lev.
+ *   hps_geom    <-> amrex::Geometry of the slice + PhysConst (utils/Constants.H:39-81) +
+ *                   particle boundary (particles/pusher/GetAndSetPosition.H:29-99).
+ *
+ * All pointers are DEVICE pointers (HBM) unless a parameter is named *_host.  Every call is
+ * asynchronous on the caller's hipStream_t (passed as void*), returns an int status
+ * (HPS_OK = 0) instead of aborting, and never allocates unless documented.
+ * INTEGRATION.md shows the AMReX-side adaptor for each call.
+ */
+#ifndef HPSLICE_H_
+#define HPSLICE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hps_stream;            /* hipStream_t */
+
+enum { HPS_OK = 0, HPS_ERR_ARG = 1, HPS_ERR_HIP = 2, HPS_ERR_FFT = 3, HPS_ERR_MG_DIVERGED = 4,
+       HPS_ERR_MG_MAXITER = 5, HPS_ERR_COMM = 6, HPS_ERR_UNSUPPORTED = 7 };
+
+/* particle boundary, Hipace.H ParticleBoundary */
+enum { HPS_BC_REFLECTING = 0, HPS_BC_PERIODIC = 1, HPS_BC_ABSORBING = 2 };
+
+/* Field slab view. element (i,j,n), i in [-ng, nx+ng): p[(i+ng) + (j+ng)*jstride + n*nstride] */
+typedef struct {
+    double* p;
+    int nx, ny, ng, ncomp;
+    long jstride, nstride;
+} hps_slab;
+
+/* Plasma sheet, pure SoA.  idcpu follows AMReX's packing: bit 63 set = valid particle
+ * (ParticleIDWrapper::is_valid), low 24 bits = cpu = mesh-refinement level (0 here). */
+typedef struct {
+    double *x, *y, *w, *ux, *uy, *psi, *x_prev, *y_prev, *ux_half, *uy_half, *psi_half;
+    uint64_t* idcpu;
+    int32_t* ion_lev;
+    long n;
+} hps_plasma;
+#define HPS_ID_VALID (1ULL << 63)
+
+typedef struct {
+    double dx, dy, dz;           /* cell sizes of the slice geometry                         */
+    double xoff, yoff;           /* GetPosOffset(0|1, geom, slab box) (fields/Fields.H:71-77) */
+    double c, ep0, mu0, q_e, m_e;/* PhysConst (1 in normalised units)                        */
+    double plo[2], phi[2];       /* particle boundary box (Hipace.cpp:219-222)               */
+    int bc;                      /* HPS_BC_*                                                 */
+    int normalized;              /* hipace.normalized_units                                  */
+} hps_geom;
+
+const char* hps_last_error (void);
+const char* hps_version (void);
+
+/* ---- particle operators ------------------------------------------------------------------ */
+
+/* DepositCurrent (particles/deposition/PlasmaDepositCurrent.H:28-32, .cpp:22-257).
+ * comp = {jx, jy, jz, rho, chi, rhomjz}, -1 = do not deposit.  QSA-violating particles are
+ * invalidated (w = 0, idcpu valid bit cleared) and counted into *n_qsa_violation (device int,
+ * may be NULL).  `charge` is the species charge (pass -charge for WhichSlice::RhomJzIons). */
+int hps_deposit_current (hps_slab slab, hps_plasma plasma, hps_geom geom, const int comp[6],
+                         double charge, double mass, int depos_order, double max_qsa_weighting,
+                         int can_ionize, int* n_qsa_violation, hps_stream stream);
+
+/* ExplicitDeposition (particles/deposition/ExplicitDeposition.H:20-22, .cpp:20-263).
+ * cache = {Bz, Ez, ExmBy, EypBx} (read per cell), depos = {Sy, Sx}. */
+int hps_explicit_deposit (hps_slab slab, hps_plasma plasma, hps_geom geom, const int cache[4],
+                          const int depos[2], double charge, double mass, int depos_order,
+                          int derivative_type, int can_ionize, hps_stream stream);
+
+/* AdvancePlasmaParticles, leapfrog pusher (particles/pusher/PlasmaParticleAdvance.H:23-26,
+ * .cpp:29-305).  comp = {Psi, Ez, Bx, By, Bz}. */
+int hps_advance_plasma (hps_slab slab, hps_plasma plasma, hps_geom geom, const int comp[5],
+                        double charge, double mass, int depos_order, int temp_slice,
+                        int n_subcycles, int can_ionize, hps_stream stream);
+
+/* ---- transverse field solvers ------------------------------------------------------------ */
+
+/* FFTPoissonSolverDirichletFast (fields/fft_poisson_solver/FFTPoissonSolverDirichletFast.H:30-32,
+ * .cpp:195-328): Lap(F) = S on an nx x ny box with F = 0 one cell outside.  `staging` is the
+ * caller-filled nx*ny source (x fastest, no guards; FFTPoissonSolver.H:26-57 StagingArea());
+ * the solution is written into component dst_comp of dst (valid cells only). Creation allocates
+ * device scratch and rocFFT plans. */
+int hps_poisson_create (int nx, int ny, double dx, double dy, void** handle);
+int hps_poisson_solve (void* handle, const double* staging, hps_slab dst, int dst_comp,
+                       hps_stream stream);
+int hps_poisson_destroy (void* handle);
+
+/* hpmg::MultiGrid, system type 1 (mg_solver/HpMultiGrid.H:48,64-66; .cpp:1169-1190,1307-1427):
+ * solves -acoef*sol + Lap(sol) = rhs, homogeneous Dirichlet.  sol (in: initial guess, out:
+ * solution) and rhs are 2 ADJACENT components starting at sol_comp / rhs_comp; acoef is 1
+ * component.  Blocks the host until converged (the stopping rule needs the residual norm);
+ * *iters_host receives the number of V-cycles. */
+int hps_mg_create (int nx, int ny, double dx, double dy, void** handle);
+int hps_mg_solve1 (void* handle, hps_slab slab, int sol_comp, int rhs_comp, int acoef_comp,
+                   double tol_rel, double tol_abs, int max_iters, int* iters_host,
+                   double* resnorm_host, hps_stream stream);
+int hps_mg_destroy (void* handle);
+
+/* ---- slice engine (Hipace::Evolve / SolveOneSlice, explicit solver; Hipace.cpp:393-728) -- */
+
+typedef struct {
+    int nx, ny, nz; double lo[3], hi[3];
+    int order; int deriv_type;
+    int plasma_ppc[2]; double plasma_density; double plasma_radius;
+    double plasma_charge, plasma_mass; double max_qsa; int n_subcycles;
+    int beam_profile;                     /* -1 none, 0 gaussian, 1 flattop */
+    double beam_zmin, beam_zmax, beam_radius, beam_density;
+    double beam_umean[3], beam_pos_mean[3], beam_pos_std[3]; int beam_ppc[3]; double beam_charge;
+    int bc; double mg_tol_rel, mg_tol_abs; int deposit_rho; int n_steps;
+} hps_deck;
+
+/* slab component indices of the engine (explicit-solver layout of fields/Fields.cpp:70-122) */
+enum { HPS_C_N_JXB = 0, HPS_C_N_JYB, HPS_C_CHI, HPS_C_SY, HPS_C_SX, HPS_C_EXMBY, HPS_C_EYPBX,
+       HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ, HPS_C_PSI, HPS_C_JXB, HPS_C_JYB, HPS_C_JZB,
+       HPS_C_JX, HPS_C_JY, HPS_C_RHOMJZ, HPS_C_P_JXB, HPS_C_P_JYB, HPS_C_ION_RHOMJZ, HPS_C_RHO,
+       HPS_NCOMP_MAX };
+
+int hps_engine_create (const hps_deck* deck, int device, void** handle);
+int hps_engine_destroy (void* handle);
+int hps_engine_begin_step (void* handle);                 /* Evolve :401-471: reset, plasma, ions */
+int hps_engine_solve_slice (void* handle, int islice);    /* SolveOneSlice :556-728               */
+int hps_engine_run_step (void* handle);                   /* begin_step + all slices head->tail   */
+int hps_engine_sync (void* handle);
+int hps_engine_info (void* handle, int* ncomp, int* nguards, long* nparticles);
+hps_slab hps_engine_slab (void* handle);
+hps_plasma hps_engine_plasma (void* handle);
+hps_stream hps_engine_stream (void* handle);
+/* sum |Q| per component over valid cells and all slices of the current step (host array[ncomp]) */
+int hps_engine_checksums (void* handle, double* out_host);
+int hps_engine_stats (void* handle, long* total_vcycles, long* slices_done);
+/* accumulate the per-slice checksums (costs one reduction pass per slice; off by default) */
+int hps_engine_set_diagnostics (void* handle, int on);
+/* HIP-event phase timers on the engine's stream.  phase_times sums, over the slices solved since
+ * profiling was switched on (or since the last call), the milliseconds spent in
+ * {deposit_current, poisson x3 (+rhs, grad), explicit_deposit, mg_solve1, advance_plasma, other}
+ * into ms_host[6] and stores the slice count; it synchronises the stream. */
+int hps_engine_set_profiling (void* handle, int on);
+int hps_engine_phase_times (void* handle, double* ms_host, long* nslices_host);
+
+/* ---- ring pipeline over time steps (utils/MultiBuffer.H:21-34; MultiBuffer.cpp:444-609) -- */
+int hps_ring_unique_id (char* id128_host);                /* rank 0: ncclGetUniqueId -> 128 bytes */
+int hps_ring_init (void* engine, const char* id128_host, int rank, int nranks);
+int hps_ring_run (void* engine, int n_steps_total);       /* rank r runs steps r, r+N, ...        */
+
+/* ---- utilities ---------------------------------------------------------------------------- */
+int hps_memcpy_d2h (void* dst_host, const void* src_dev, long bytes);
+int hps_memcpy_h2d (void* dst_dev, const void* src_host, long bytes);
+int hps_device_count (int* n_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPSLICE_H_ */
