@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=64, help="untimed warm-up slices")
     ap.add_argument("--n", type=int, default=1024, help="transverse cells per side")
     ap.add_argument("--ppc", type=int, default=2, help="plasma particles per cell per direction")
+    ap.add_argument("--tile", type=int, default=16, help="particle tile size (0, 16, 32)")
+    ap.add_argument("--sort-period", type=int, default=8, help="slices between particle re-sorts")
     ap.add_argument("--cpu-slices", type=int, default=4, help="slices of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -78,7 +80,7 @@ def main():
 
     nz = 1024
     deck = decks.synthetic(args.n, nz, args.ppc)
-    eng = api.SliceEngine(deck, device=local)
+    eng = api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period)
 
     def run_slices(count, profile=False):
         done = 0

@@ -58,6 +58,16 @@ _SIGS = {
                                        C.c_int, C.c_int, C.c_void_p]),
     "hps_advance_plasma": (C.c_int, [Slab, Plasma, Geom, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_void_p]),
+    "hps_tiling_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_long, C.POINTER(C.c_void_p)]),
+    "hps_reorder_particles": (C.c_int, [C.c_void_p, Plasma, Plasma, Geom, C.c_void_p]),
+    "hps_tiling_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "hps_tiling_destroy": (C.c_int, [C.c_void_p]),
+    "hps_deposit_current_tiled": (C.c_int, [Slab, Plasma, Geom, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_double,
+                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hps_explicit_deposit_tiled": (C.c_int, [Slab, Plasma, Geom, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
+                                             C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hps_advance_plasma_tiled": (C.c_int, [Slab, Plasma, Geom, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hps_poisson_create": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
     "hps_poisson_solve": (C.c_int, [C.c_void_p, C.c_void_p, Slab, C.c_int, C.c_void_p]),
     "hps_poisson_destroy": (C.c_int, [C.c_void_p]),
@@ -78,6 +88,8 @@ _SIGS = {
     "hps_engine_checksums": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "hps_engine_set_diagnostics": (C.c_int, [C.c_void_p, C.c_int]),
+    "hps_engine_set_tiling": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "hps_engine_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
     "hps_engine_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_phase_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hps_ring_unique_id": (C.c_int, [C.c_void_p]),

@@ -102,26 +102,82 @@ class PlasmaSheet:
         return self.real.cpu().numpy(), ((idc >> np.uint64(63)) & np.uint64(1)).astype(np.int32)
 
 
+class Tiling:
+    """Tile binning of a plasma sheet (the reference's ReorderParticles hook)."""
+
+    def __init__(self, nx, ny, tile_size, max_particles):
+        self._h = C.c_void_p()
+        check(_lib.lib().hps_tiling_create(nx, ny, tile_size, max_particles, C.byref(self._h)))
+        self.fallback = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def reorder(self, plasma, geom):
+        """Stable sort of `plasma` by tile; returns the reordered PlasmaSheet (a new SoA buffer)."""
+        out = PlasmaSheet.__new__(PlasmaSheet)
+        out.n = plasma.n
+        out.real = torch.empty_like(plasma.real)
+        out.idcpu = torch.empty_like(plasma.idcpu)
+        out.ion_lev = torch.empty_like(plasma.ion_lev)
+        check(_lib.lib().hps_reorder_particles(self._h, plasma.struct(), out.struct(), geom.c, _stream()))
+        return out
+
+    def info(self):
+        nt, off, perm = C.c_int(), C.c_void_p(), C.c_void_p()
+        check(_lib.lib().hps_tiling_info(self._h, C.byref(nt), C.byref(off), C.byref(perm)))
+        return nt.value, off.value, perm.value
+
+    def offsets_and_perm(self, n):
+        torch.cuda.synchronize()
+        nt, off, perm = self.info()
+        o = np.empty(nt + 2, dtype=np.int32)
+        p = np.empty(n, dtype=np.uint32)
+        check(_lib.lib().hps_memcpy_d2h(o.ctypes.data_as(C.c_void_p), C.c_void_p(off), o.nbytes))
+        if n:
+            check(_lib.lib().hps_memcpy_d2h(p.ctypes.data_as(C.c_void_p), C.c_void_p(perm), p.nbytes))
+        return o, p
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.lib().hps_tiling_destroy(self._h)
+            self._h = None
+
+
 def DepositCurrent(plasma, fields, geom, charge, mass, depos_order, jx=-1, jy=-1, jz=-1, rho=-1, chi=-1,
-                   rhomjz=-1, max_qsa_weighting_factor=35.0, can_ionize=False, n_qsa=None):
+                   rhomjz=-1, max_qsa_weighting_factor=35.0, can_ionize=False, n_qsa=None, tiling=None):
     comp = _iarr([jx, jy, jz, rho, chi, rhomjz])
     nq = C.c_void_p(n_qsa.data_ptr()) if n_qsa is not None else None
-    check(_lib.lib().hps_deposit_current(fields.struct(), plasma.struct(), geom.c, comp, charge, mass,
-                                         depos_order, max_qsa_weighting_factor, int(can_ionize), nq, _stream()))
+    if tiling is None:
+        check(_lib.lib().hps_deposit_current(fields.struct(), plasma.struct(), geom.c, comp, charge, mass,
+                                             depos_order, max_qsa_weighting_factor, int(can_ionize), nq, _stream()))
+    else:
+        check(_lib.lib().hps_deposit_current_tiled(fields.struct(), plasma.struct(), geom.c, comp, charge, mass,
+                                                   depos_order, max_qsa_weighting_factor, int(can_ionize), nq,
+                                                   tiling._h, C.c_void_p(tiling.fallback.data_ptr()), _stream()))
 
 
 def ExplicitDeposition(plasma, fields, geom, charge, mass, depos_order, Bz, Ez, ExmBy, EypBx, Sy, Sx,
-                       derivative_type=2, can_ionize=False):
-    check(_lib.lib().hps_explicit_deposit(fields.struct(), plasma.struct(), geom.c, _iarr([Bz, Ez, ExmBy, EypBx]),
-                                          _iarr([Sy, Sx]), charge, mass, depos_order, derivative_type,
-                                          int(can_ionize), _stream()))
+                       derivative_type=2, can_ionize=False, tiling=None):
+    if tiling is None:
+        check(_lib.lib().hps_explicit_deposit(fields.struct(), plasma.struct(), geom.c, _iarr([Bz, Ez, ExmBy, EypBx]),
+                                              _iarr([Sy, Sx]), charge, mass, depos_order, derivative_type,
+                                              int(can_ionize), _stream()))
+    else:
+        check(_lib.lib().hps_explicit_deposit_tiled(fields.struct(), plasma.struct(), geom.c,
+                                                    _iarr([Bz, Ez, ExmBy, EypBx]), _iarr([Sy, Sx]), charge, mass,
+                                                    depos_order, derivative_type, int(can_ionize), tiling._h,
+                                                    C.c_void_p(tiling.fallback.data_ptr()), _stream()))
 
 
 def AdvancePlasmaParticles(plasma, fields, geom, charge, mass, depos_order, Psi, Ez, Bx, By, Bz,
-                           temp_slice=False, n_subcycles=1, can_ionize=False):
-    check(_lib.lib().hps_advance_plasma(fields.struct(), plasma.struct(), geom.c, _iarr([Psi, Ez, Bx, By, Bz]),
-                                        charge, mass, depos_order, int(temp_slice), n_subcycles,
-                                        int(can_ionize), _stream()))
+                           temp_slice=False, n_subcycles=1, can_ionize=False, tiling=None):
+    if tiling is None:
+        check(_lib.lib().hps_advance_plasma(fields.struct(), plasma.struct(), geom.c, _iarr([Psi, Ez, Bx, By, Bz]),
+                                            charge, mass, depos_order, int(temp_slice), n_subcycles,
+                                            int(can_ionize), _stream()))
+    else:
+        check(_lib.lib().hps_advance_plasma_tiled(fields.struct(), plasma.struct(), geom.c,
+                                                  _iarr([Psi, Ez, Bx, By, Bz]), charge, mass, depos_order,
+                                                  int(temp_slice), n_subcycles, int(can_ionize), tiling._h,
+                                                  C.c_void_p(tiling.fallback.data_ptr()), _stream()))
 
 
 class FFTPoissonSolver:
@@ -141,7 +197,7 @@ class FFTPoissonSolver:
                                            _stream()))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.lib().hps_poisson_destroy(self._h)
             self._h = None
 
@@ -162,7 +218,7 @@ class MultiGrid:
         return it.value, rn.value
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.lib().hps_mg_destroy(self._h)
             self._h = None
 
@@ -170,17 +226,19 @@ class MultiGrid:
 class SliceEngine:
     """Device-resident slice loop for one deck (see hipace_amd/decks.py)."""
 
-    def __init__(self, deck, device=0):
+    def __init__(self, deck, device=0, tile_size=None, sort_period=None):
         self.deck = dict(deck)
         self._dk = _lib.fill_struct(_lib.Deck(), deck)
         self._h = C.c_void_p()
         check(_lib.lib().hps_engine_create(C.byref(self._dk), device, C.byref(self._h)))
+        if tile_size is not None:
+            check(_lib.lib().hps_engine_set_tiling(self._h, tile_size, sort_period or 8))
         nc, ng, npart = C.c_int(), C.c_int(), C.c_long()
         check(_lib.lib().hps_engine_info(self._h, C.byref(nc), C.byref(ng), C.byref(npart)))
         self.ncomp, self.ng, self.nparticles = nc.value, ng.value, npart.value
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _lib is not None:
             _lib.lib().hps_engine_destroy(self._h)
             self._h = None
 
@@ -195,6 +253,14 @@ class SliceEngine:
 
     def sync(self):
         check(_lib.lib().hps_engine_sync(self._h))
+
+    def set_tiling(self, tile_size=16, sort_period=8):
+        check(_lib.lib().hps_engine_set_tiling(self._h, tile_size, sort_period))
+
+    def fallbacks(self):
+        n = C.c_long()
+        check(_lib.lib().hps_engine_fallbacks(self._h, C.byref(n)))
+        return n.value
 
     def set_diagnostics(self, on=True):
         check(_lib.lib().hps_engine_set_diagnostics(self._h, int(on)))

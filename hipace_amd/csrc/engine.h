@@ -4,6 +4,7 @@
 
 #include "common.h"
 #include <vector>
+#include "tiling.h"
 
 namespace hps {
 
@@ -18,6 +19,12 @@ struct Engine {
     hps_plasma pl{};
     double* pl_real = nullptr;
     long np = 0;
+    // tile-sorted sheet (sort.hip): second SoA buffer + tiling state
+    Tiling* tiling = nullptr; int tile_size = 16, sort_period = 8, since_sort = 0;
+    hps_plasma pl_alt{}; double* pl_real_alt = nullptr;
+    int* d_nfallback = nullptr;
+    int setup_tiling ();
+    int resort ();
     void* ps = nullptr;            // Poisson solver handle
     void* mg = nullptr;            // multigrid handle
     double* staging = nullptr;

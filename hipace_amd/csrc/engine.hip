@@ -11,6 +11,16 @@
 
 namespace hps {
 
+int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[6], double charge,
+                           double mass, int order, double max_qsa, int can_ionize, int* n_qsa, Tiling* T, int* n_fallback,
+                           hipStream_t st);
+int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int cache[4], const int depos[2],
+                            double charge, double mass, int order, int dtype, int can_ionize, Tiling* T, int* n_fallback,
+                            hipStream_t st);
+int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], double charge,
+                          double mass, int order, int temp_slice, int n_subcycles, int can_ionize, Tiling* T,
+                          int* n_fallback, hipStream_t st);
+
 static thread_local std::string g_err;
 void set_error (const std::string& msg) { g_err = msg; }
 
@@ -176,6 +186,8 @@ Engine::~Engine ()
     if (ps) hps_poisson_destroy(ps);
     if (mg) hps_mg_destroy(mg);
     (void)hipFree(slab.p); (void)hipFree(pl_real); (void)hipFree(pl.idcpu); (void)hipFree(pl.ion_lev);
+    delete tiling;
+    (void)hipFree(pl_real_alt); (void)hipFree(pl_alt.idcpu); (void)hipFree(pl_alt.ion_lev); (void)hipFree(d_nfallback);
     (void)hipFree(staging); (void)hipFree(beam_data); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
     for (auto e : ev) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
@@ -264,6 +276,8 @@ int Engine::create (const hps_deck& deck, int device)
         HPS_HIP_CHECK(hipMalloc(&pl.idcpu, (size_t)np*sizeof(uint64_t)));
         HPS_HIP_CHECK(hipMalloc(&pl.ion_lev, (size_t)np*sizeof(int32_t)));
     }
+    HPS_HIP_CHECK(hipMalloc(&d_nfallback, sizeof(int)));
+    HPS_HIP_CHECK(hipMemset(d_nfallback, 0, sizeof(int)));
     HPS_HIP_CHECK(hipMalloc(&d_nqsa, sizeof(int)));
     HPS_HIP_CHECK(hipMemset(d_nqsa, 0, sizeof(int)));
     HPS_HIP_CHECK(hipMalloc(&d_checksum, HPS_NCOMP_MAX*sizeof(double)));
@@ -273,8 +287,33 @@ int Engine::create (const hps_deck& deck, int device)
     return init_beam();
 }
 
+int Engine::setup_tiling ()
+{
+    if (tile_size == 0 || np == 0 || tiling) return HPS_OK;
+    if (int e = tiling_create(d.nx, d.ny, tile_size, np, &tiling)) return e;
+    std::memset(&pl_alt, 0, sizeof(pl_alt));
+    pl_alt.n = np;
+    HPS_HIP_CHECK(hipMalloc(&pl_real_alt, (size_t)np*11*sizeof(double)));
+    double** arr[11] = {&pl_alt.x, &pl_alt.y, &pl_alt.w, &pl_alt.ux, &pl_alt.uy, &pl_alt.psi, &pl_alt.x_prev, &pl_alt.y_prev,
+                        &pl_alt.ux_half, &pl_alt.uy_half, &pl_alt.psi_half};
+    for (int k = 0; k < 11; ++k) *arr[k] = pl_real_alt + (size_t)k*np;
+    HPS_HIP_CHECK(hipMalloc(&pl_alt.idcpu, (size_t)np*sizeof(uint64_t)));
+    HPS_HIP_CHECK(hipMalloc(&pl_alt.ion_lev, (size_t)np*sizeof(int32_t)));
+    return HPS_OK;
+}
+
+int Engine::resort ()
+{
+    if (int e = tiling_sort(tiling, pl, pl_alt, gm, st)) return e;
+    std::swap(pl, pl_alt);
+    std::swap(pl_real, pl_real_alt);
+    since_sort = 0;
+    return HPS_OK;
+}
+
 int Engine::begin_step ()
 {
+    if (int e = setup_tiling()) return e;
     // ResetAllQuantities (Hipace.cpp:730-742)
     HPS_HIP_CHECK(hipMemsetAsync(slab.p, 0, (size_t)slab.nstride*ncomp*sizeof(double), st));
     HPS_HIP_CHECK(hipMemsetAsync(d_checksum, 0, HPS_NCOMP_MAX*sizeof(double), st));
@@ -284,7 +323,12 @@ int Engine::begin_step ()
                            d.plasma_ppc[0], d.plasma_ppc[1], d.lo[0], d.lo[1], gm.dx, gm.dy, d.plasma_density*(1.0/nppc));
         // neutralising ion background, deposited once per step with charge -q (MultiPlasma.cpp:106-118)
         const int comp[6] = {-1, -1, -1, -1, -1, HPS_C_ION_RHOMJZ};
-        if (int e = hps_deposit_current(slab, pl, gm, comp, -d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st)) return e;
+        if (tiling) {
+            if (int e = resort()) return e;
+            if (int e = deposit_current_tiled(slab, pl, gm, comp, -d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st)) return e;
+        } else {
+            if (int e = hps_deposit_current(slab, pl, gm, comp, -d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st)) return e;
+        }
     }
     HPS_HIP_CHECK(hipGetLastError());
     return HPS_OK;
@@ -333,8 +377,11 @@ int Engine::solve_slice (int islice)
 
     mark();   // b1
     // plasma: jx, jy, [rho], chi, rhomjz (Hipace.cpp:609-610); beam: jz_beam on This (:613-614)
+    if (tiling && since_sort >= sort_period) { if ((e = resort())) return e; }
+    ++since_sort;
     {   const int comp[6] = {HPS_C_JX, HPS_C_JY, -1, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_CHI, HPS_C_RHOMJZ};
-        if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; }
+        if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st))) return e; }
+        else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
     mark();   // b2
     if ((e = deposit_beam_slice(islice, -1, -1, HPS_C_JZB))) return e;
 
@@ -358,7 +405,8 @@ int Engine::solve_slice (int islice)
     mark();   // b4
     {   const int cache[4] = {HPS_C_BZ, HPS_C_EZ, HPS_C_EXMBY, HPS_C_EYPBX};
         const int depos[2] = {HPS_C_SY, HPS_C_SX};
-        if ((e = hps_explicit_deposit(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, st))) return e; }
+        if (tiling) { if ((e = explicit_deposit_tiled(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, tiling, d_nfallback, st))) return e; }
+        else        { if ((e = hps_explicit_deposit(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, st))) return e; } }
 
     mark();   // b5
     // Bx, By: Helmholtz multigrid from the previous slice's field (Hipace.cpp:793-933)
@@ -373,7 +421,8 @@ int Engine::solve_slice (int islice)
     mark();   // b7
     // gather + push (Hipace.cpp:699-701)
     {   const int comp[5] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ};
-        if ((e = hps_advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; }
+        if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st))) return e; }
+        else        { if ((e = hps_advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; } }
 
     mark();   // b8
     // ShiftSlices (fields/Fields.cpp:588-604)
@@ -462,6 +511,24 @@ extern "C" int hps_engine_phase_times (void* h, double* ms, long* nsl)
         }
     if (nsl) *nsl = (long)ns;
     E->ev_used = 0;
+    return HPS_OK;
+}
+extern "C" int hps_engine_set_tiling (void* h, int tile_size, int sort_period)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(tile_size == 0 || tile_size == 16 || tile_size == 32, "hps_engine_set_tiling: tile_size must be 0, 16 or 32");
+    HPS_REQUIRE(sort_period >= 1, "hps_engine_set_tiling: sort_period must be >= 1");
+    HPS_REQUIRE(E->tiling == nullptr, "hps_engine_set_tiling: call before the first hps_engine_begin_step");
+    E->tile_size = tile_size; E->sort_period = sort_period;
+    return HPS_OK;
+}
+extern "C" int hps_engine_fallbacks (void* h, long* n)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    int v = 0;
+    HPS_HIP_CHECK(hipMemcpy(&v, E->d_nfallback, sizeof(int), hipMemcpyDeviceToHost));
+    *n = v;
     return HPS_OK;
 }
 extern "C" int hps_engine_set_diagnostics (void* h, int on) { static_cast<Engine*>(h)->diagnostics = (on != 0); return HPS_OK; }

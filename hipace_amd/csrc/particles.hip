@@ -8,24 +8,10 @@
 // particles/deposition/ExplicitDeposition.cpp:140-261,
 // particles/pusher/PlasmaParticleAdvance.cpp:92-217.
 #include "common.h"
+#include "particle_math.h"
 
 namespace hps {
 
-struct DepComps { int jx, jy, jz, rho, chi, rhomjz; };
-
-struct PartConsts {
-    double dx_inv, dy_inv, xoff, yoff;
-    double c, c_inv;
-    double a, b;          // kernel-specific prefactors
-    double max_qsa;
-    double plo0, plo1, phi0, phi1;
-    double dz;
-    int bc, can_ionize, temp_slice, n_subcycles;
-};
-
-// ------------------------------------------------------------------------------------------
-// current / charge deposition
-// ------------------------------------------------------------------------------------------
 template <int ORDER>
 __global__ __launch_bounds__(256)
 void k_deposit_current (SlabView f, hps_plasma pl, DepComps cm, PartConsts k, int* n_qsa)
@@ -137,68 +123,6 @@ void k_explicit_deposit (SlabView f, hps_plasma pl, int cBz, int cEz, int cExmBy
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// gather + push
-// ------------------------------------------------------------------------------------------
-struct D2 { double v, e; };   // dual number (value, first-order part)
-__device__ __forceinline__ D2 operator+ (D2 a, D2 b) { return {a.v + b.v, a.e + b.e}; }
-__device__ __forceinline__ D2 operator- (D2 a, D2 b) { return {a.v - b.v, a.e - b.e}; }
-__device__ __forceinline__ D2 operator* (D2 a, D2 b) { return {a.v*b.v, a.e*b.v + a.v*b.e}; }
-__device__ __forceinline__ D2 operator* (D2 a, double b) { return {a.v*b, a.e*b}; }
-__device__ __forceinline__ D2 operator+ (D2 a, double b) { return {a.v + b, a.e}; }
-__device__ __forceinline__ D2 operator- (D2 a, double b) { return {a.v - b, a.e}; }
-
-struct Fld { double ExmBy, EypBx, Ez, Bxc, Byc, Bz; };
-
-// d/dzeta of (ux, uy, psi) in the quasi-static frame; T = double or D2.
-// gamma/psi = 1/2 psi^-2 (1 + u^2/c^2) + 1/2  (particles/pusher/PushPlasmaParticles.H:59-72)
-template <class T>
-__device__ __forceinline__ void zeta_derivs (const T& ux, const T& uy, const T& psi_inv, const Fld& F,
-                                             double c_inv, double qmc, T& dux, T& duy, T& dpsi)
-{
-    const double ci2 = c_inv*c_inv;
-    const T gamma_psi = (psi_inv*psi_inv)*0.5*( (ux*ux)*ci2 + (uy*uy)*ci2 + 1.0 ) + 0.5;
-    dux = (gamma_psi*F.ExmBy + F.Byc + (uy*F.Bz)*psi_inv)*qmc;
-    duy = (gamma_psi*F.EypBx - F.Bxc - (ux*F.Bz)*psi_inv)*qmc;
-    dpsi = (((ux*F.ExmBy + uy*F.EypBx)*c_inv)*psi_inv - F.Ez)*(qmc*c_inv);
-}
-
-__device__ __forceinline__ void taylor2_substep (double& ux, double& uy, double& psi, const Fld& F,
-                                                 double c_inv, double qmc, double sdz)
-{
-    const double psi_inv = 1.0/psi;
-    double dux, duy, dpsi;
-    zeta_derivs<double>(ux, uy, psi_inv, F, c_inv, qmc, dux, duy, dpsi);
-    const D2 uxd{ux, dux}, uyd{uy, duy}, pid{psi_inv, -psi_inv*psi_inv*dpsi};
-    D2 ddux, dduy, ddpsi;
-    zeta_derivs<D2>(uxd, uyd, pid, F, c_inv, qmc, ddux, dduy, ddpsi);
-    const double h2 = 0.5*sdz*sdz;
-    ux += sdz*dux + h2*ddux.e;
-    uy += sdz*duy + h2*dduy.e;
-    psi += sdz*dpsi + h2*ddpsi.e;
-}
-
-// particle boundary; returns true if the particle was absorbed
-__device__ __forceinline__ bool apply_particle_bc (const PartConsts& k, double& x, double& y,
-                                                   double& ux, double& uy)
-{
-    if (x < k.plo0 || y < k.plo1 || x > k.phi0 || y > k.phi1) {
-        const double lx = k.phi0 - k.plo0, ly = k.phi1 - k.plo1;
-        if (k.bc == HPS_BC_REFLECTING) {
-            x = fmod(x - k.plo0, 2*lx); if (x < 0) x += 2*lx; x += k.plo0;
-            if (x > k.phi0) { x = 2*k.phi0 - x; ux = -ux; }
-            y = fmod(y - k.plo1, 2*ly); if (y < 0) y += 2*ly; y += k.plo1;
-            if (y > k.phi1) { y = 2*k.phi1 - y; uy = -uy; }
-        } else if (k.bc == HPS_BC_PERIODIC) {
-            x = fmod(x - k.plo0, lx); if (x < 0) x += lx; x += k.plo0;
-            y = fmod(y - k.plo1, ly); if (y < 0) y += ly; y += k.plo1;
-        } else {
-            return true;
-        }
-    }
-    return false;
-}
-
 template <int ORDER>
 __global__ __launch_bounds__(256)
 void k_advance_plasma (SlabView f, hps_plasma pl, int cPsi, int cEz, int cBx, int cBy, int cBz,
@@ -271,32 +195,6 @@ void k_advance_plasma (SlabView f, hps_plasma pl, int cPsi, int cEz, int cBx, in
         for (int s = 0; s < 2; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
         pl.ux[ip] = ux; pl.uy[ip] = uy; pl.psi[ip] = psi;
     }
-}
-
-static PartConsts base_consts (const hps_geom& g)
-{
-    PartConsts k{};
-    k.dx_inv = 1.0/g.dx; k.dy_inv = 1.0/g.dy; k.xoff = g.xoff; k.yoff = g.yoff;
-    k.c = g.c; k.c_inv = 1.0/g.c;
-    k.plo0 = g.plo[0]; k.plo1 = g.plo[1]; k.phi0 = g.phi[0]; k.phi1 = g.phi[1];
-    k.bc = g.bc;
-    return k;
-}
-
-static double invvol_of (const hps_geom& g)
-{
-    // normalised units: 1 on level 0; SI: charge -> charge density (PlasmaDepositCurrent.cpp:71-73)
-    const double dxi = 1.0/g.dx, dyi = 1.0/g.dy, dzi = 1.0/g.dz;
-    return g.normalized ? g.dx*g.dy*dxi*dyi : dxi*dyi*dzi;
-}
-
-static int check_stencil (const hps_slab& s, int need_guards, const char* what)
-{
-    if (s.p == nullptr || s.nx <= 0 || s.ny <= 0 || s.ng < need_guards) {
-        set_error(std::string(what) + ": slab needs at least " + std::to_string(need_guards) + " guard cells");
-        return HPS_ERR_ARG;
-    }
-    return HPS_OK;
 }
 
 } // namespace hps

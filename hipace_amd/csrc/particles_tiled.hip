@@ -1,0 +1,440 @@
+// particles_tiled.hip -- LDS-tile variants of the particle kernels for a tile-sorted plasma sheet
+// (see sort.hip).  One 256-thread workgroup owns one TS x TS-cell tile: it keeps an LDS image of
+// the tile plus an 8-cell halo (R = TS+16 cells per side), streams the tile's particles (contiguous
+// in the sorted SoA, fully coalesced) and
+//   * deposit:   accumulates all stencil contributions with LDS fp64 atomics (ds_add_f64) and
+//                flushes the non-zero cells once with global atomics (halo cells overlap
+//                neighbouring tiles) -- ~1/10 of the global atomics of the per-particle scatter;
+//   * explicit deposit: additionally serves the 4 per-cell field reads from the LDS image;
+//   * gather+push: serves the 5x16 gathered values per particle from the LDS image.
+// Particles that drifted out of their home tile's halo since the last sort take the global-memory
+// path of the same arithmetic, so results never depend on how stale the sort is.
+// Arithmetic identical to particles.hip (reference file:line cited there).
+#include "common.h"
+#include "particle_math.h"
+#include "tiling.h"
+
+namespace hps {
+
+constexpr int TILE_HALO = 8;
+
+struct CompSlots { int n; int comp[6]; };   // active deposition components, in DepComps order
+
+typedef __attribute__((address_space(3))) double lds_double;
+
+// ds_add_f64: the explicit LDS address space keeps the compiler from emitting a flat atomic
+__device__ __forceinline__ void lds_add (double* p, double v)
+{
+    __hip_atomic_fetch_add((lds_double*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ double lds_get (const double* p)
+{
+    return *(const lds_double*)p;
+}
+
+template <int ORDER, int TS>
+__global__ __launch_bounds__(256)
+void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx, DepComps cm,
+                      PartConsts k, int* n_qsa, int* n_fallback)
+{
+    constexpr int R = TS + 2*TILE_HALO;
+    extern __shared__ __attribute__((aligned(16))) double acc[];     // [6 slots][R*R], unused slots not allocated
+    // slot of each component (compacted)
+    int slot[6]; int na = 0;
+    slot[0] = cm.jx >= 0 ? na++ : -1;  slot[1] = cm.jy >= 0 ? na++ : -1;  slot[2] = cm.jz >= 0 ? na++ : -1;
+    slot[3] = cm.rho >= 0 ? na++ : -1; slot[4] = cm.chi >= 0 ? na++ : -1; slot[5] = cm.rhomjz >= 0 ? na++ : -1;
+    const int gc[6] = {cm.jx, cm.jy, cm.jz, cm.rho, cm.chi, cm.rhomjz};
+
+    const int tile = blockIdx.x;
+    const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
+    const int tid = threadIdx.x;
+    for (int s = tid; s < na*R*R; s += 256) acc[s] = 0.0;
+    __syncthreads();
+
+    const int pend = offsets[tile + 1];
+    int nfb = 0;
+    for (int ip = offsets[tile] + tid; ip < pend; ip += 256) {
+        const uint64_t id = pl.idcpu[ip];
+        if (!(id & HPS_ID_VALID)) continue;
+        const double psi_inv = 1.0/pl.psi[ip];
+        const double vx_c = pl.ux[ip]*psi_inv;
+        const double vy_c = pl.uy[ip]*psi_inv;
+        double q_invvol = k.a*pl.w[ip];
+        double q_mu0_mass = k.b;
+        if (k.can_ionize) { const double il = (double)pl.ion_lev[ip]; q_invvol *= il; q_mu0_mass *= il; }
+        const double gamma_psi = 0.5*(psi_inv*psi_inv + vx_c*vx_c*k.c_inv*k.c_inv + vy_c*vy_c*k.c_inv*k.c_inv + 1.0);
+        if (gamma_psi < 0.0 || gamma_psi > k.max_qsa || psi_inv < 0.0) {
+            if (n_qsa) atomicAdd(n_qsa, 1);
+            pl.w[ip] = 0.0;
+            pl.idcpu[ip] = id & ~HPS_ID_VALID;
+            continue;
+        }
+        double sx[ORDER + 1], sy[ORDER + 1];
+        const int i0 = shape_weights<ORDER>((pl.x[ip] - k.xoff)*k.dx_inv, sx);
+        const int j0 = shape_weights<ORDER>((pl.y[ip] - k.yoff)*k.dy_inv, sy);
+        // per-component weights in DepComps order
+        const double wv[6] = {vx_c, vy_c, (gamma_psi - 1.0)*k.c, gamma_psi, q_mu0_mass*psi_inv, 1.0};
+        const int li = i0 - ox, lj = j0 - oy;
+        if (li >= 0 && li + ORDER < R && lj >= 0 && lj + ORDER < R) {
+#pragma unroll
+            for (int iy = 0; iy <= ORDER; ++iy) {
+#pragma unroll
+                for (int ix = 0; ix <= ORDER; ++ix) {
+                    const double cd = q_invvol*sx[ix]*sy[iy];
+                    double* p = acc + (lj + iy)*R + li + ix;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) if (slot[c] >= 0) lds_add(p + slot[c]*R*R, cd*wv[c]);
+                }
+            }
+        } else {
+            ++nfb;
+#pragma unroll
+            for (int iy = 0; iy <= ORDER; ++iy) {
+#pragma unroll
+                for (int ix = 0; ix <= ORDER; ++ix) {
+                    const double cd = q_invvol*sx[ix]*sy[iy];
+                    double* p = f.p + f.off(i0 + ix, j0 + iy);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) if (slot[c] >= 0) atomic_add_f64(p + gc[c]*f.ns, cd*wv[c]);
+                }
+            }
+        }
+    }
+    if (n_fallback && nfb) atomicAdd(n_fallback, nfb);
+    __syncthreads();
+
+    // flush the touched cells; halo cells are shared with neighbouring tiles -> atomics
+    for (int s = tid; s < R*R; s += 256) {
+        const int lj = s / R, li = s - lj*R;
+        const int i = ox + li, j = oy + lj;
+        if (i < -f.ng || i >= f.nx + f.ng || j < -f.ng || j >= f.ny + f.ng) continue;
+        double* p = f.p + f.off(i, j);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            if (slot[c] >= 0) {
+                const double v = acc[slot[c]*R*R + s];
+                if (v != 0.0) atomic_add_f64(p + gc[c]*f.ns, v);
+            }
+        }
+    }
+}
+
+// image of `nc` slab components over the tile region into LDS (0 outside the slab box)
+template <int R>
+__device__ __forceinline__ void load_region (double* img, const SlabView& f, const int* comps, int nc, int ox, int oy, int tid)
+{
+    for (int s = tid; s < R*R; s += 256) {
+        const int lj = s / R, li = s - lj*R;
+        const int i = ox + li, j = oy + lj;
+        const bool in = (i >= -f.ng && i < f.nx + f.ng && j >= -f.ng && j < f.ny + f.ng);
+        const long o = in ? f.off(i, j) : 0;
+        for (int c = 0; c < nc; ++c) img[c*R*R + s] = in ? f.p[comps[c]*f.ns + o] : 0.0;
+    }
+}
+
+template <int ORDER, int DT, int TS>
+__global__ __launch_bounds__(256)
+void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
+                       int cBz, int cEz, int cExmBy, int cEypBx, int cSy, int cSx, PartConsts k, int* n_fallback)
+{
+    constexpr int R = TS + 2*TILE_HALO;
+    constexpr int NS = ORDER + DT + 1;
+    extern __shared__ __attribute__((aligned(16))) double lds[];     // [4 cached][R*R] + [2 accum][R*R]
+    double* img = lds;
+    double* acc = lds + 4*R*R;
+    const int tile = blockIdx.x;
+    const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
+    const int tid = threadIdx.x;
+    const int cc[4] = {cBz, cEz, cExmBy, cEypBx};
+    load_region<R>(img, f, cc, 4, ox, oy, tid);
+    for (int s = tid; s < 2*R*R; s += 256) acc[s] = 0.0;
+    __syncthreads();
+
+    const int pend = offsets[tile + 1];
+    int nfb = 0;
+    for (int ip = offsets[tile] + tid; ip < pend; ip += 256) {
+        if (!(pl.idcpu[ip] & HPS_ID_VALID)) continue;
+        const double psi_inv = 1.0/pl.psi[ip];
+        const double vx = pl.ux[ip]*psi_inv*k.c_inv;
+        const double vy = pl.uy[ip]*psi_inv*k.c_inv;
+        double q_invvol_mu0 = k.a, q_mass = k.b;
+        if (k.can_ionize) { const double il = (double)pl.ion_lev[ip]; q_invvol_mu0 *= il; q_mass *= il; }
+        const double cdm = q_invvol_mu0*pl.w[ip];
+        const double gp = 0.5*(psi_inv*psi_inv + vx*vx + vy*vy + 1.0);
+        double sx[NS], dsx[NS], sy[NS], dsy[NS];
+        int i0, j0;
+        const double xmid = (pl.x[ip] - k.xoff)*k.dx_inv;
+        const double ymid = (pl.y[ip] - k.yoff)*k.dy_inv;
+        if constexpr (DT == 2) { i0 = centred_weights<ORDER>(xmid, sx, dsx); j0 = centred_weights<ORDER>(ymid, sy, dsy); }
+        else                   { i0 = nodal_weights<ORDER>(xmid, sx, dsx);   j0 = nodal_weights<ORDER>(ymid, sy, dsy); }
+        const double qp = q_mass*psi_inv;
+        const double vxvy = vx*vy, gy = gp - vy*vy, gx = gp - vx*vx;
+        const int li = i0 - ox, lj = j0 - oy;
+        const bool local = (li >= 0 && li + NS <= R && lj >= 0 && lj + NS <= R);
+        if (!local) ++nfb;
+#pragma unroll
+        for (int iy = 0; iy < NS; ++iy) {
+#pragma unroll
+            for (int ix = 0; ix < NS; ++ix) {
+                if (DT == 2 && (ix == 0 || ix == NS - 1) && (iy == 0 || iy == NS - 1)) continue;
+                double Bz, Ez, ExmBy, EypBx;
+                double* gp_ = nullptr; int ls = 0;
+                if (local) {
+                    ls = (lj + iy)*R + li + ix;
+                    Bz = lds_get(img + ls); Ez = lds_get(img + R*R + ls); ExmBy = lds_get(img + 2*R*R + ls); EypBx = lds_get(img + 3*R*R + ls);
+                } else {
+                    gp_ = f.p + f.off(i0 + ix, j0 + iy);
+                    Bz = gp_[cBz*f.ns]; Ez = gp_[cEz*f.ns]; ExmBy = gp_[cExmBy*f.ns]; EypBx = gp_[cEypBx*f.ns];
+                }
+                const double ss = sx[ix]*sy[iy];
+                const double dxs = dsx[ix]*sy[iy]*k.dx_inv;
+                const double sdy = sx[ix]*dsy[iy]*k.dy_inv;
+                const double sy_add = cdm*(
+                    - ss*( -Bz*vx + (Ez*vy + ExmBy*(-vxvy) + EypBx*gy)*k.c_inv )*qp
+                    + ( -dxs*(-vxvy) - sdy*(gy - 1.0) )*k.c);
+                const double sx_add = cdm*(
+                    + ss*( Bz*vy + (Ez*vx + ExmBy*gx + EypBx*(-vxvy))*k.c_inv )*qp
+                    + ( dxs*(gx - 1.0) + sdy*(-vxvy) )*k.c);
+                if (local) { lds_add(acc + ls, sy_add); lds_add(acc + R*R + ls, sx_add); }
+                else       { atomic_add_f64(gp_ + cSy*f.ns, sy_add); atomic_add_f64(gp_ + cSx*f.ns, sx_add); }
+            }
+        }
+    }
+    if (n_fallback && nfb) atomicAdd(n_fallback, nfb);
+    __syncthreads();
+    for (int s = tid; s < R*R; s += 256) {
+        const int lj = s / R, li = s - lj*R;
+        const int i = ox + li, j = oy + lj;
+        if (i < -f.ng || i >= f.nx + f.ng || j < -f.ng || j >= f.ny + f.ng) continue;
+        double* p = f.p + f.off(i, j);
+        const double a = acc[s], b = acc[R*R + s];
+        if (a != 0.0) atomic_add_f64(p + cSy*f.ns, a);
+        if (b != 0.0) atomic_add_f64(p + cSx*f.ns, b);
+    }
+}
+
+template <int ORDER, int TS>
+__global__ __launch_bounds__(256)
+void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
+                      int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, int* n_fallback)
+{
+    constexpr int R = TS + 2*TILE_HALO;
+    constexpr int NS = ORDER + 2;
+    extern __shared__ __attribute__((aligned(16))) double img[];     // [5][R*R]
+    const int tile = blockIdx.x;
+    const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
+    const int tid = threadIdx.x;
+    const int cc[5] = {cPsi, cEz, cBx, cBy, cBz};
+    load_region<R>(img, f, cc, 5, ox, oy, tid);
+    __syncthreads();
+
+    const int pend = offsets[tile + 1];
+    int nfb = 0;
+    for (int ip = offsets[tile] + tid; ip < pend; ip += 256) {
+        const uint64_t id = pl.idcpu[ip];
+        if (!(id & HPS_ID_VALID)) continue;
+        double qmc = k.a;
+        if (k.can_ionize) qmc *= (double)pl.ion_lev[ip];
+        bool dead = false;
+        for (int isc = 0; isc < k.n_subcycles && !dead; ++isc) {
+            double xp = pl.x_prev[ip];
+            double yp = pl.y_prev[ip];
+            double sx[NS], dsx[NS], sy[NS], dsy[NS];
+            const int i0 = nodal_weights<ORDER>((xp - k.xoff)*k.dx_inv, sx, dsx);
+            const int j0 = nodal_weights<ORDER>((yp - k.yoff)*k.dy_inv, sy, dsy);
+            const int li = i0 - ox, lj = j0 - oy;
+            const bool local = (li >= 0 && li + NS <= R && lj >= 0 && lj + NS <= R);
+            if (!local) ++nfb;
+            Fld F{0, 0, 0, 0, 0, 0};
+            if (local) {
+                const double* b = img + lj*R + li;
+#pragma unroll 1
+                for (int iy = 0; iy < NS; ++iy) {
+#pragma unroll
+                    for (int ix = 0; ix < NS; ++ix) {
+                        const int ls = iy*R + ix;
+                        const double psi_c = lds_get(b + ls);
+                        const double ss = sx[ix]*sy[iy];
+                        F.ExmBy += (dsx[ix]*sy[iy])*psi_c*k.dx_inv;
+                        F.EypBx += (sx[ix]*dsy[iy])*psi_c*k.dy_inv;
+                        F.Ez  += ss*lds_get(b + R*R + ls);
+                        F.Bxc += ss*lds_get(b + 2*R*R + ls);
+                        F.Byc += ss*lds_get(b + 3*R*R + ls);
+                        F.Bz  += ss*lds_get(b + 4*R*R + ls);
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int iy = 0; iy < NS; ++iy) {
+#pragma unroll
+                    for (int ix = 0; ix < NS; ++ix) {
+                        const double* p = f.p + f.off(i0 + ix, j0 + iy);
+                        const double psi_c = p[cPsi*f.ns];
+                        const double ss = sx[ix]*sy[iy];
+                        F.ExmBy += (dsx[ix]*sy[iy])*psi_c*k.dx_inv;
+                        F.EypBx += (sx[ix]*dsy[iy])*psi_c*k.dy_inv;
+                        F.Ez  += ss*p[cEz*f.ns];
+                        F.Bxc += ss*p[cBx*f.ns];
+                        F.Byc += ss*p[cBy*f.ns];
+                        F.Bz  += ss*p[cBz*f.ns];
+                    }
+                }
+            }
+            F.Bxc *= k.c;
+            F.Byc *= k.c;
+            const double dz = k.dz, sdz = dz*0.25;
+            double ux = pl.ux_half[ip], uy = pl.uy_half[ip], psi = pl.psi_half[ip];
+#pragma unroll 1
+            for (int s = 0; s < 4; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
+            const double pinv = 1.0/psi;
+            xp += dz*k.c_inv*(ux*pinv);
+            yp += dz*k.c_inv*(uy*pinv);
+            if (apply_particle_bc(k, xp, yp, ux, uy)) {
+                pl.w[ip] = 0.0;
+                pl.idcpu[ip] = id & ~HPS_ID_VALID;
+                dead = true;
+                break;
+            }
+            pl.x[ip] = xp; pl.y[ip] = yp;
+            if (!k.temp_slice) {
+                pl.ux_half[ip] = ux; pl.uy_half[ip] = uy; pl.psi_half[ip] = psi;
+                pl.x_prev[ip] = xp;  pl.y_prev[ip] = yp;
+            }
+#pragma unroll 1
+            for (int s = 0; s < 2; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
+            pl.ux[ip] = ux; pl.uy[ip] = uy; pl.psi[ip] = psi;
+        }
+    }
+    if (n_fallback && nfb) atomicAdd(n_fallback, nfb);
+}
+
+template <class K>
+static int set_lds (K kernel, size_t bytes)
+{
+    if (bytes > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return HPS_OK;
+}
+
+#define HPS_DISPATCH_ORDER_TS(order, ts, CALL)                                   \
+    switch ((order)*100 + (ts)) {                                                \
+        case   16: { CALL(0, 16); } break;  case   32: { CALL(0, 32); } break;    \
+        case  116: { CALL(1, 16); } break;  case  132: { CALL(1, 32); } break;    \
+        case  216: { CALL(2, 16); } break;  case  232: { CALL(2, 32); } break;    \
+        case  316: { CALL(3, 16); } break;  case  332: { CALL(3, 32); } break;    \
+        default: set_error("tiled kernels: unsupported order / tile size"); return HPS_ERR_ARG; }
+
+int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[6], double charge,
+                           double mass, int order, double max_qsa, int can_ionize, int* n_qsa, Tiling* T, int* n_fallback,
+                           hipStream_t st)
+{
+    if (pl.n == 0) return HPS_OK;
+    PartConsts k = base_consts(g);
+    k.a = charge*invvol_of(g); k.b = charge*g.mu0/mass; k.max_qsa = max_qsa; k.can_ionize = can_ionize;
+    DepComps cm{comp[0], comp[1], comp[2], comp[3], comp[4], comp[5]};
+    int na = 0; for (int c = 0; c < 6; ++c) na += comp[c] >= 0;
+    const int R = T->g.ts + 2*TILE_HALO;
+    const size_t lds = (size_t)na*R*R*sizeof(double);
+    SlabView f(slab);
+#define CALL(O, S) { if (int e = set_lds(k_deposit_tiled<O, S>, lds)) return e; \
+        hipLaunchKernelGGL((k_deposit_tiled<O, S>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback); }
+    HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
+#undef CALL
+    HPS_HIP_CHECK(hipGetLastError());
+    return HPS_OK;
+}
+
+int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int cache[4], const int depos[2],
+                            double charge, double mass, int order, int dtype, int can_ionize, Tiling* T, int* n_fallback,
+                            hipStream_t st)
+{
+    if (pl.n == 0) return HPS_OK;
+    PartConsts k = base_consts(g);
+    k.a = charge*invvol_of(g)*g.mu0; k.b = charge/mass; k.can_ionize = can_ionize;
+    const int R = T->g.ts + 2*TILE_HALO;
+    const size_t lds = (size_t)6*R*R*sizeof(double);
+    SlabView f(slab);
+    if (dtype == 2) {
+#define CALL(O, S) { if (int e = set_lds(k_explicit_tiled<O, 2, S>, lds)) return e; \
+        hipLaunchKernelGGL((k_explicit_tiled<O, 2, S>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
+                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback); }
+        HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
+#undef CALL
+    } else {
+#define CALL(O, S) { if (int e = set_lds(k_explicit_tiled<O, 1, S>, lds)) return e; \
+        hipLaunchKernelGGL((k_explicit_tiled<O, 1, S>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
+                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback); }
+        HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
+#undef CALL
+    }
+    HPS_HIP_CHECK(hipGetLastError());
+    return HPS_OK;
+}
+
+int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], double charge,
+                          double mass, int order, int temp_slice, int n_subcycles, int can_ionize, Tiling* T,
+                          int* n_fallback, hipStream_t st)
+{
+    if (pl.n == 0) return HPS_OK;
+    PartConsts k = base_consts(g);
+    k.a = charge/(mass*g.c); k.dz = g.dz/n_subcycles;
+    k.temp_slice = temp_slice; k.n_subcycles = n_subcycles; k.can_ionize = can_ionize;
+    const int R = T->g.ts + 2*TILE_HALO;
+    const size_t lds = (size_t)5*R*R*sizeof(double);
+    SlabView f(slab);
+#define CALL(O, S) { if (int e = set_lds(k_advance_tiled<O, S>, lds)) return e; \
+        hipLaunchKernelGGL((k_advance_tiled<O, S>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
+                           comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback); }
+    HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
+#undef CALL
+    HPS_HIP_CHECK(hipGetLastError());
+    return HPS_OK;
+}
+
+} // namespace hps
+
+using namespace hps;
+
+static int check_tiling (void* tiling, const hps_slab& s, const hps_plasma& pl, const char* what)
+{
+    if (!tiling) { set_error(std::string(what) + ": null tiling"); return HPS_ERR_ARG; }
+    Tiling* T = static_cast<Tiling*>(tiling);
+    if (T->g.nx != s.nx || T->g.ny != s.ny) { set_error(std::string(what) + ": tiling was built for another grid"); return HPS_ERR_ARG; }
+    if (T->sorted_n != pl.n) { set_error(std::string(what) + ": particle count changed since hps_reorder_particles"); return HPS_ERR_ARG; }
+    return HPS_OK;
+}
+
+extern "C" int hps_deposit_current_tiled (hps_slab slab, hps_plasma pl, hps_geom g, const int comp[6], double charge,
+                                          double mass, int order, double max_qsa, int can_ionize, int* n_qsa,
+                                          void* tiling, int* n_fallback, hps_stream stream)
+{
+    HPS_REQUIRE(order >= 0 && order <= 3, "hps_deposit_current_tiled: depos_order must be 0..3");
+    if (int e = check_stencil(slab, (order + 1)/2, "hps_deposit_current_tiled")) return e;
+    if (int e = check_tiling(tiling, slab, pl, "hps_deposit_current_tiled")) return e;
+    for (int c = 0; c < 6; ++c) HPS_REQUIRE(comp[c] >= -1 && comp[c] < slab.ncomp, "hps_deposit_current_tiled: bad component");
+    return deposit_current_tiled(slab, pl, g, comp, charge, mass, order, max_qsa, can_ionize, n_qsa,
+                                 static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream);
+}
+
+extern "C" int hps_explicit_deposit_tiled (hps_slab slab, hps_plasma pl, hps_geom g, const int cache[4], const int depos[2],
+                                           double charge, double mass, int order, int dtype, int can_ionize, void* tiling,
+                                           int* n_fallback, hps_stream stream)
+{
+    HPS_REQUIRE(order >= 0 && order <= 3, "hps_explicit_deposit_tiled: depos_order must be 0..3");
+    if (dtype != 1 && dtype != 2) { set_error("hps_explicit_deposit_tiled: derivative_type 1 or 2 only"); return HPS_ERR_UNSUPPORTED; }
+    if (int e = check_stencil(slab, (order + 1)/2 + 1, "hps_explicit_deposit_tiled")) return e;
+    if (int e = check_tiling(tiling, slab, pl, "hps_explicit_deposit_tiled")) return e;
+    return explicit_deposit_tiled(slab, pl, g, cache, depos, charge, mass, order, dtype, can_ionize,
+                                  static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream);
+}
+
+extern "C" int hps_advance_plasma_tiled (hps_slab slab, hps_plasma pl, hps_geom g, const int comp[5], double charge,
+                                         double mass, int order, int temp_slice, int n_subcycles, int can_ionize,
+                                         void* tiling, int* n_fallback, hps_stream stream)
+{
+    HPS_REQUIRE(order >= 0 && order <= 3, "hps_advance_plasma_tiled: depos_order must be 0..3");
+    HPS_REQUIRE(n_subcycles >= 1, "hps_advance_plasma_tiled: n_subcycles must be >= 1");
+    if (int e = check_stencil(slab, (order + 1)/2 + 1, "hps_advance_plasma_tiled")) return e;
+    if (int e = check_tiling(tiling, slab, pl, "hps_advance_plasma_tiled")) return e;
+    return advance_plasma_tiled(slab, pl, g, comp, charge, mass, order, temp_slice, n_subcycles, can_ionize,
+                                static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream);
+}

@@ -1,0 +1,135 @@
+// sort.hip -- tile binning of the plasma sheet (the "ReorderParticles" seam of the reference,
+// particles/plasma/PlasmaParticleContainer.cpp:196-208, which calls amrex::SortParticlesForDeposition).
+//
+// The sheet is kept physically sorted by TS x TS-cell transverse tiles so that one workgroup can
+// accumulate a whole tile's deposition in LDS and serve its gathers from an LDS copy of the fields.
+// Key = tile of the particle's nearest cell (invalid particles sort to the end); the sort is a
+// STABLE counting/radix sort (rocPRIM radix_sort_pairs), so the permutation is reproducible bit for
+// bit by the CPU restatement (oracle: orc_tile_sort).  All 11 real arrays + idcpu + ion_lev are
+// then gathered through the permutation into a second SoA buffer.
+#include "common.h"
+#include "tiling.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace hps {
+
+__device__ __forceinline__ int tile_key (double x, double y, uint64_t id, const TileGeom& t)
+{
+    if (!(id & HPS_ID_VALID)) return t.ntiles;
+    int ci = (int)floor((x - t.xoff)*t.dx_inv + 0.5);
+    int cj = (int)floor((y - t.yoff)*t.dy_inv + 0.5);
+    ci = min(max(ci, 0), t.nx - 1);
+    cj = min(max(cj, 0), t.ny - 1);
+    return (cj / t.ts)*t.ntx + (ci / t.ts);
+}
+
+__global__ __launch_bounds__(256)
+void k_tile_keys (hps_plasma pl, TileGeom t, unsigned int* keys, unsigned int* idx)
+{
+    const long p = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (p >= pl.n) return;
+    keys[p] = (unsigned int)tile_key(pl.x[p], pl.y[p], pl.idcpu[p], t);
+    idx[p] = (unsigned int)p;
+}
+
+// offsets[t] = first sorted position with key >= t, t = 0 .. ntiles+1
+__global__ __launch_bounds__(256)
+void k_tile_offsets (const unsigned int* keys, long n, int ntiles, int* offsets)
+{
+    const long p = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (p > n) return;
+    const int prev = (p == 0) ? -1 : (int)keys[p - 1];
+    const int cur = (p == n) ? ntiles + 1 : (int)keys[p];
+    for (int t = prev + 1; t <= cur; ++t) offsets[t] = (int)p;
+}
+
+__global__ __launch_bounds__(256)
+void k_permute (hps_plasma src, hps_plasma dst, const unsigned int* perm)
+{
+    const long p = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (p >= src.n) return;
+    const unsigned int q = perm[p];
+    dst.x[p] = src.x[q]; dst.y[p] = src.y[q]; dst.w[p] = src.w[q];
+    dst.ux[p] = src.ux[q]; dst.uy[p] = src.uy[q]; dst.psi[p] = src.psi[q];
+    dst.x_prev[p] = src.x_prev[q]; dst.y_prev[p] = src.y_prev[q];
+    dst.ux_half[p] = src.ux_half[q]; dst.uy_half[p] = src.uy_half[q]; dst.psi_half[p] = src.psi_half[q];
+    dst.idcpu[p] = src.idcpu[q]; dst.ion_lev[p] = src.ion_lev[q];
+}
+
+Tiling::~Tiling ()
+{
+    (void)hipFree(offsets); (void)hipFree(keys_a); (void)hipFree(keys_b); (void)hipFree(idx_a); (void)hipFree(idx_b);
+    (void)hipFree(temp);
+}
+
+int tiling_create (int nx, int ny, int ts, long capacity, Tiling** out)
+{
+    if (ts != 16 && ts != 32) { set_error("hps_tiling_create: tile_size must be 16 or 32"); return HPS_ERR_ARG; }
+    Tiling* T = new Tiling;
+    T->g.nx = nx; T->g.ny = ny; T->g.ts = ts;
+    T->g.ntx = (nx + ts - 1)/ts; T->g.nty = (ny + ts - 1)/ts; T->g.ntiles = T->g.ntx*T->g.nty;
+    T->capacity = capacity;
+    HPS_HIP_CHECK(hipMalloc(&T->offsets, (T->g.ntiles + 2)*sizeof(int)));
+    HPS_HIP_CHECK(hipMemset(T->offsets, 0, (T->g.ntiles + 2)*sizeof(int)));
+    HPS_HIP_CHECK(hipMalloc(&T->keys_a, capacity*sizeof(unsigned int)));
+    HPS_HIP_CHECK(hipMalloc(&T->keys_b, capacity*sizeof(unsigned int)));
+    HPS_HIP_CHECK(hipMalloc(&T->idx_a, capacity*sizeof(unsigned int)));
+    HPS_HIP_CHECK(hipMalloc(&T->idx_b, capacity*sizeof(unsigned int)));
+    int bits = 1; while ((1 << bits) < T->g.ntiles + 1) ++bits;
+    T->key_bits = bits;
+    HPS_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, T->temp_bytes, T->keys_a, T->keys_b, T->idx_a, T->idx_b,
+                                            (size_t)capacity, 0, bits, (hipStream_t)0));
+    HPS_HIP_CHECK(hipMalloc(&T->temp, T->temp_bytes));
+    *out = T;
+    return HPS_OK;
+}
+
+int tiling_sort (Tiling* T, const hps_plasma& src, const hps_plasma& dst, const hps_geom& g, hipStream_t st)
+{
+    if (src.n > T->capacity) { set_error("hps_reorder_particles: more particles than the tiling capacity"); return HPS_ERR_ARG; }
+    T->g.xoff = g.xoff; T->g.yoff = g.yoff; T->g.dx_inv = 1.0/g.dx; T->g.dy_inv = 1.0/g.dy;
+    const long n = src.n;
+    if (n == 0) { HPS_HIP_CHECK(hipMemsetAsync(T->offsets, 0, (T->g.ntiles + 2)*sizeof(int), st)); return HPS_OK; }
+    hipLaunchKernelGGL(k_tile_keys, dim3(ceil_div(n, 256)), dim3(256), 0, st, src, T->g, T->keys_a, T->idx_a);
+    size_t tb = T->temp_bytes;
+    HPS_HIP_CHECK(rocprim::radix_sort_pairs(T->temp, tb, T->keys_a, T->keys_b, T->idx_a, T->idx_b, (size_t)n, 0,
+                                            T->key_bits, st));
+    hipLaunchKernelGGL(k_tile_offsets, dim3(ceil_div(n + 1, 256)), dim3(256), 0, st, T->keys_b, n, T->g.ntiles, T->offsets);
+    hipLaunchKernelGGL(k_permute, dim3(ceil_div(n, 256)), dim3(256), 0, st, src, dst, T->idx_b);
+    HPS_HIP_CHECK(hipGetLastError());
+    T->sorted_n = n;
+    return HPS_OK;
+}
+
+} // namespace hps
+
+using namespace hps;
+
+extern "C" int hps_tiling_create (int nx, int ny, int tile_size, long max_particles, void** handle)
+{
+    HPS_REQUIRE(nx > 0 && ny > 0 && max_particles >= 0 && handle, "hps_tiling_create: bad argument");
+    Tiling* T = nullptr;
+    if (int e = tiling_create(nx, ny, tile_size, std::max(max_particles, 1L), &T)) return e;
+    *handle = T;
+    return HPS_OK;
+}
+
+extern "C" int hps_reorder_particles (void* tiling, hps_plasma src, hps_plasma dst, hps_geom geom, hps_stream stream)
+{
+    HPS_REQUIRE(tiling, "hps_reorder_particles: null tiling");
+    HPS_REQUIRE(dst.n >= src.n || src.n == 0, "hps_reorder_particles: destination too small");
+    return tiling_sort(static_cast<Tiling*>(tiling), src, dst, geom, (hipStream_t)stream);
+}
+
+extern "C" int hps_tiling_info (void* tiling, int* ntiles, const int** offsets_dev, const unsigned int** perm_dev)
+{
+    Tiling* T = static_cast<Tiling*>(tiling);
+    if (ntiles) *ntiles = T->g.ntiles;
+    if (offsets_dev) *offsets_dev = T->offsets;
+    if (perm_dev) *perm_dev = T->idx_b;
+    return HPS_OK;
+}
+
+extern "C" int hps_tiling_destroy (void* tiling) { delete static_cast<Tiling*>(tiling); return HPS_OK; }

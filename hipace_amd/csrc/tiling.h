@@ -1,0 +1,23 @@
+// tiling.h -- tile binning state of the plasma sheet (sort.hip).
+#ifndef HPS_TILING_H_
+#define HPS_TILING_H_
+#include "common.h"
+
+namespace hps {
+
+struct TileGeom { int nx, ny, ts, ntx, nty, ntiles; double xoff, yoff, dx_inv, dy_inv; };
+
+struct Tiling {
+    TileGeom g{};
+    long capacity = 0, sorted_n = 0;
+    int* offsets = nullptr;                       // [ntiles + 2], device
+    unsigned int *keys_a = nullptr, *keys_b = nullptr, *idx_a = nullptr, *idx_b = nullptr;
+    void* temp = nullptr; size_t temp_bytes = 0; int key_bits = 0;
+    ~Tiling ();
+};
+
+int tiling_create (int nx, int ny, int ts, long capacity, Tiling** out);
+int tiling_sort (Tiling* T, const hps_plasma& src, const hps_plasma& dst, const hps_geom& g, hipStream_t st);
+
+} // namespace hps
+#endif

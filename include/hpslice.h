@@ -85,6 +85,36 @@ int hps_advance_plasma (hps_slab slab, hps_plasma plasma, hps_geom geom, const i
                         double charge, double mass, int depos_order, int temp_slice,
                         int n_subcycles, int can_ionize, hps_stream stream);
 
+/* ---- tile-sorted sheet: LDS-tile variants of the three operators -------------------------- */
+
+/* Reorder hook (PlasmaParticleContainer::ReorderParticles, particles/plasma/
+ * PlasmaParticleContainer.cpp:196-208 -> amrex::SortParticlesForDeposition): STABLE sort of the
+ * sheet by tile_size x tile_size-cell tiles of the particle's nearest cell (invalid particles
+ * last).  src is read, dst (a second SoA of >= src.n entries) receives the permuted sheet; the
+ * tiling keeps the per-tile offsets.  tile_size is 16 or 32. */
+int hps_tiling_create (int nx, int ny, int tile_size, long max_particles, void** handle);
+int hps_reorder_particles (void* tiling, hps_plasma src, hps_plasma dst, hps_geom geom,
+                           hps_stream stream);
+int hps_tiling_info (void* tiling, int* ntiles, const int** offsets_dev, const unsigned int** perm_dev);
+int hps_tiling_destroy (void* tiling);
+
+/* Same operators, same arithmetic, for a sheet ordered by hps_reorder_particles: one workgroup
+ * per tile accumulates / gathers through an LDS image of the tile (+8-cell halo).  Particles
+ * that drifted out of the halo since the sort take the global-memory path and are counted into
+ * *n_fallback (device int, may be NULL); results do not depend on how stale the ordering is. */
+int hps_deposit_current_tiled (hps_slab slab, hps_plasma plasma, hps_geom geom, const int comp[6],
+                               double charge, double mass, int depos_order, double max_qsa_weighting,
+                               int can_ionize, int* n_qsa_violation, void* tiling, int* n_fallback,
+                               hps_stream stream);
+int hps_explicit_deposit_tiled (hps_slab slab, hps_plasma plasma, hps_geom geom, const int cache[4],
+                                const int depos[2], double charge, double mass, int depos_order,
+                                int derivative_type, int can_ionize, void* tiling, int* n_fallback,
+                                hps_stream stream);
+int hps_advance_plasma_tiled (hps_slab slab, hps_plasma plasma, hps_geom geom, const int comp[5],
+                              double charge, double mass, int depos_order, int temp_slice,
+                              int n_subcycles, int can_ionize, void* tiling, int* n_fallback,
+                              hps_stream stream);
+
 /* ---- transverse field solvers ------------------------------------------------------------ */
 
 /* FFTPoissonSolverDirichletFast (fields/fft_poisson_solver/FFTPoissonSolverDirichletFast.H:30-32,
@@ -142,6 +172,11 @@ int hps_engine_checksums (void* handle, double* out_host);
 int hps_engine_stats (void* handle, long* total_vcycles, long* slices_done);
 /* accumulate the per-slice checksums (costs one reduction pass per slice; off by default) */
 int hps_engine_set_diagnostics (void* handle, int on);
+/* particle tiling of the engine: tile_size 0 = per-particle global-atomic kernels, 16 | 32 = LDS
+ * tiles with a re-sort every sort_period slices (plasmas.reorder_period of the reference).
+ * Call before hps_engine_begin_step. */
+int hps_engine_set_tiling (void* handle, int tile_size, int sort_period);
+int hps_engine_fallbacks (void* handle, long* n_fallback_host);
 /* HIP-event phase timers on the engine's stream.  phase_times sums, over the slices solved since
  * profiling was switched on (or since the last call), the milliseconds spent in
  * {deposit_current, poisson x3 (+rhs, grad), explicit_deposit, mg_solve1, advance_plasma, other}

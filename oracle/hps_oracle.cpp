@@ -1161,6 +1161,35 @@ void orc_gather (orc_slab s, orc_geom g, const int* comp, int order, double xp, 
     out6[0]=a; out6[1]=b; out6[2]=c; out6[3]=d; out6[4]=e; out6[5]=f;
 }
 
+// Tile binning restated: key = tile of the nearest cell (invalid particles last), STABLE counting
+// sort (the product path: hipace_amd/csrc/sort.hip).  The reference sorts with
+// amrex::SortParticlesForDeposition (not in /root/reference: parity unpinned against the
+// reference; bit-exactness is defined between this restatement and the HIP path).
+void orc_tile_sort (orc_plasma p, orc_geom g, int nx, int ny, int ts, uint32_t* perm, int32_t* offsets)
+{
+    const int ntx = (nx + ts - 1)/ts, nty = (ny + ts - 1)/ts, ntiles = ntx*nty;
+    const double dx_inv = 1.0/g.dx, dy_inv = 1.0/g.dy;
+    std::vector<int> key((size_t)p.n);
+    std::vector<long> count((size_t)ntiles + 2, 0);
+    for (long k = 0; k < p.n; ++k) {
+        int t = ntiles;
+        if (p.valid[k]) {
+            int ci = (int)std::floor((p.x[k] - g.xoff)*dx_inv + 0.5);
+            int cj = (int)std::floor((p.y[k] - g.yoff)*dy_inv + 0.5);
+            ci = std::min(std::max(ci, 0), nx - 1);
+            cj = std::min(std::max(cj, 0), ny - 1);
+            t = (cj/ts)*ntx + (ci/ts);
+        }
+        key[k] = t; ++count[t];
+    }
+    long run = 0;
+    for (int t = 0; t <= ntiles; ++t) { offsets[t] = (int32_t)run; run += count[t]; }
+    offsets[ntiles + 1] = (int32_t)run;
+    std::vector<long> pos((size_t)ntiles + 1);
+    for (int t = 0; t <= ntiles; ++t) pos[t] = offsets[t];
+    for (long k = 0; k < p.n; ++k) perm[pos[key[k]]++] = (uint32_t)k;
+}
+
 void* orc_poisson_create (int nx, int ny, double dx, double dy) { return new PoissonSolver(nx, ny, dx, dy); }
 void orc_poisson_solve (void* h, double* staging) { static_cast<PoissonSolver*>(h)->solve(staging); }
 void orc_poisson_destroy (void* h) { delete static_cast<PoissonSolver*>(h); }

@@ -87,6 +87,8 @@ def lib():
         L.orc_advance_plasma.argtypes = [Slab, Plasma, Geom, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
         L.orc_gather.restype = None
         L.orc_gather.argtypes = [Slab, Geom, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]
+        L.orc_tile_sort.restype = None
+        L.orc_tile_sort.argtypes = [Plasma, Geom, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_poisson_create.restype = C.c_void_p
         L.orc_poisson_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double]
         L.orc_poisson_solve.restype = None
@@ -220,6 +222,15 @@ def gather(slab, nx, ny, g, geom, comp, order, xp, yp):
     out = np.zeros(6)
     lib().orc_gather(slab_struct(slab, nx, ny, g), geom, _ptr(c), order, float(xp), float(yp), _ptr(out))
     return out
+
+
+def tile_sort(real, valid, ion, geom, nx, ny, ts):
+    """-> (perm uint32 (n,), offsets int32 (ntiles+2,)) of the stable tile sort."""
+    ntiles = ((nx + ts - 1) // ts) * ((ny + ts - 1) // ts)
+    perm = np.zeros(real.shape[1], dtype=np.uint32)
+    off = np.zeros(ntiles + 2, dtype=np.int32)
+    lib().orc_tile_sort(plasma_struct(real, valid, ion), geom, nx, ny, ts, _ptr(perm), _ptr(off))
+    return perm, off
 
 
 def poisson_solve(rhs, dx, dy):
