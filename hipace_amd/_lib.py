@@ -70,6 +70,7 @@ _SIGS = {
                                            C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hps_poisson_create": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
     "hps_poisson_solve": (C.c_int, [C.c_void_p, C.c_void_p, Slab, C.c_int, C.c_void_p]),
+    "hps_poisson_solve_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, Slab, C.c_void_p, C.c_void_p]),
     "hps_poisson_destroy": (C.c_int, [C.c_void_p]),
     "hps_mg_create": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
     "hps_mg_solve1": (C.c_int, [C.c_void_p, Slab, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,

@@ -62,6 +62,31 @@ void k_add_ions_psi_rhs (SlabView f, int c_rhomjz, int c_ion, int c_rho, double 
     if (i >= 0 && i < f.nx && j >= 0 && j < f.ny) staging[(long)j*f.nx + i] = -inv_ep0*r;
 }
 
+// AddRhoIons + the three Poisson sources of a slice in one pass (fields/Fields.cpp:606-615,
+// 887-912): st[0] = -rhomjz/ep0 (Psi), st[1] = (d_x jx + d_y jy)/(ep0 c) (Ez),
+// st[2] = mu0 (d_y jx - d_x jy) (Bz); `plane` = nx*ny
+__global__ __launch_bounds__(256)
+void k_rhs_all (SlabView f, int c_rhomjz, int c_ion, int c_rho, int c_jx, int c_jy, double inv_ep0,
+                double fez_x, double fez_y, double fbz_y, double fbz_x, double* staging, long plane)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x - f.ng;
+    const int j = blockIdx.y - f.ng;
+    if (i >= f.nx + f.ng) return;
+    const long o = f.off(i, j);
+    const double ion = f.p[c_ion*f.ns + o];
+    const double r = f.p[c_rhomjz*f.ns + o] + ion;
+    f.p[c_rhomjz*f.ns + o] = r;
+    if (c_rho >= 0) f.p[c_rho*f.ns + o] += ion;
+    if (i >= 0 && i < f.nx && j >= 0 && j < f.ny) {
+        const long so = (long)j*f.nx + i;
+        const double* X = f.p + c_jx*f.ns + o;
+        const double* Y = f.p + c_jy*f.ns + o;
+        staging[so] = -inv_ep0*r;
+        staging[plane + so] = fez_x*(X[1] - X[-1]) + fez_y*(Y[f.js] - Y[-f.js]);
+        staging[2*plane + so] = fbz_y*(X[f.js] - X[-f.js]) + fbz_x*(Y[1] - Y[-1]);
+    }
+}
+
 // staging = fa * d(A)/d(da) + fb * d(B)/d(db), centred differences (LinCombination + derivative,
 // fields/Fields.cpp:223-249,368-387); dir 0 = x, 1 = y
 __global__ __launch_bounds__(256)
@@ -263,7 +288,7 @@ int Engine::create (const hps_deck& deck, int device)
     slab.jstride = d.nx + 2*g; slab.nstride = slab.jstride*(d.ny + 2*g);
     HPS_HIP_CHECK(hipMalloc(&slab.p, (size_t)slab.nstride*ncomp*sizeof(double)));
     HPS_HIP_CHECK(hipMemset(slab.p, 0, (size_t)slab.nstride*ncomp*sizeof(double)));
-    HPS_HIP_CHECK(hipMalloc(&staging, (size_t)d.nx*d.ny*sizeof(double)));
+    HPS_HIP_CHECK(hipMalloc(&staging, (size_t)3*d.nx*d.ny*sizeof(double)));
 
     const int nppc = d.plasma_ppc[0]*d.plasma_ppc[1];
     np = (d.plasma_density > 0.0) ? (long)nppc*d.nx*d.ny : 0;
@@ -386,14 +411,13 @@ int Engine::solve_slice (int islice)
     if ((e = deposit_beam_slice(islice, -1, -1, HPS_C_JZB))) return e;
 
     // AddRhoIons + Psi, Ez, Bz solves + -grad Psi (fields/Fields.cpp:840-957)
-    hipLaunchKernelGGL(k_add_ions_psi_rhs, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_RHOMJZ,
-                       HPS_C_ION_RHOMJZ, d.deposit_rho ? HPS_C_RHO : -1, 1.0/gm.ep0, staging);
-    if ((e = hps_poisson_solve(ps, staging, slab, HPS_C_PSI, st))) return e;
     {   const double fa = 1.0/(gm.ep0*gm.c);
-        hipLaunchKernelGGL(k_rhs_lincomb, gvalid, b256, 0, st, f, HPS_C_JX, 0, fa*0.5*(1.0/gm.dx), HPS_C_JY, 1, fa*0.5*(1.0/gm.dy), staging); }
-    if ((e = hps_poisson_solve(ps, staging, slab, HPS_C_EZ, st))) return e;
-    hipLaunchKernelGGL(k_rhs_lincomb, gvalid, b256, 0, st, f, HPS_C_JX, 1, gm.mu0*0.5*(1.0/gm.dy), HPS_C_JY, 0, -gm.mu0*0.5*(1.0/gm.dx), staging);
-    if ((e = hps_poisson_solve(ps, staging, slab, HPS_C_BZ, st))) return e;
+        hipLaunchKernelGGL(k_rhs_all, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_RHOMJZ,
+                           HPS_C_ION_RHOMJZ, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_JX, HPS_C_JY, 1.0/gm.ep0,
+                           fa*0.5*(1.0/gm.dx), fa*0.5*(1.0/gm.dy), gm.mu0*0.5*(1.0/gm.dy), -gm.mu0*0.5*(1.0/gm.dx),
+                           staging, (long)d.nx*d.ny);
+        const int comps[3] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BZ};
+        if ((e = hps_poisson_solve_batch(ps, 3, staging, slab, comps, st))) return e; }
     hipLaunchKernelGGL(k_grad_psi, dim3(ceil_div(d.nx + 2*(g - 1), 256), d.ny + 2*(g - 1)), b256, 0, st, f, HPS_C_PSI,
                        HPS_C_EXMBY, HPS_C_EYPBX, 0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy));
 

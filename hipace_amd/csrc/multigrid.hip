@@ -3,15 +3,20 @@
 //
 // Numerically a restatement of hpmg::MultiGrid system type 1 (mg_solver/HpMultiGrid.cpp):
 // V-cycle with 4 red-black Gauss-Seidel sweeps per level (colour (i+j+s)%2, s = 0..3), residual
-// fused behind the sweeps, cell-centred 4-average / nodal full-weighting restriction, piecewise
+// behind the sweeps, cell-centred 4-average / nodal full-weighting restriction, piecewise
 // constant / bilinear prolongation, 16 sweeps on the coarsest level, cell-centred wall stencil
 // with the 4/3-2 coefficients (HpMultiGrid.cpp:162-182,265-292), stop rule of solve_doit
 // (:1307-1427).  Because Bx/By are only converged to tol_rel = 1e-4 from the previous slice's
-// field, parity of the slice engine requires this exact arithmetic.
+// field, parity of the slice engine requires this exact per-cell arithmetic.
 //
-// MI355X mapping: the smoother is one LDS-tiled kernel per level doing all 4 sweeps (+ residual,
-// + max-norm) on a 66x34 tile per 256-thread workgroup: phi lives in LDS, the per-cell rhs and
-// coefficient stay in registers across sweeps, every cell is read from HBM once and written once.
+// MI355X mapping (one HBM read + one HBM write of each plane per smoothing step):
+//  * k_smooth: one LDS-tiled kernel per level and direction.  A 256-thread workgroup sweeps a
+//    64x32-cell tile 4 times in LDS (phi in LDS; rhs, coefficient and 1/diagonal in registers),
+//    and fuses what the reference does in separate passes: the prolongation of the coarse
+//    correction into the tile load (up-leg), the residual, its max-norm and -- cell-centred --
+//    its restriction to the next level (down-leg: the fine residual never touches HBM).
+//  * k_lower_v: every level with <= 32x32 unknowns runs inside ONE 1024-thread workgroup with all
+//    its arrays in LDS (whole lower V incl. the 16 bottom sweeps), replacing ~4 launches per level.
 #include "common.h"
 
 #include <vector>
@@ -30,75 +35,113 @@ struct FView {
 struct LevBox { int lox, loy, hix, hiy;      // index bounds of the level box (walls for nodal)
                 int vlx, vly, vhx, vhy; };   // unknowns (valid_domain_box)
 
+enum { SRC_ZERO = 0, SRC_DIRECT = 1, SRC_PROLONG = 2 };
+
 constexpr int GT_X = 64, GT_Y = 32;          // cells swept per tile
 constexpr int GA_X = GT_X + 2, GA_Y = GT_Y + 2;
 constexpr int GPAIRS = GT_X*GT_Y/2/256;      // cell pairs per thread = 4
 
+// diagonal of the operator at (i,j): -(a + 2(fx+fy)) with the wall modification (gs1 :265-292)
 template <bool CC>
-__device__ __forceinline__ void gs_update (double* phi /* LDS plane */, int li, int lj, int i, int j,
-                                           const LevBox& b, double rhs, double acf, double facx, double facy)
+__device__ __forceinline__ double diag_c0 (int i, int j, const LevBox& b, double acf, double facx, double facy)
 {
-    // li, lj: indices into the LDS array (ring included)
-    double lap;
     double c0 = -(acf + 2.0*(facx + facy));
-    const double* c = phi + lj*GA_X + li;
-    if (CC && i == b.lox)      { lap = facx*(4./3.)*c[1];  c0 -= 2.0*facx; }
-    else if (CC && i == b.hix) { lap = facx*(4./3.)*c[-1]; c0 -= 2.0*facx; }
-    else                       { lap = facx*(c[-1] + c[1]); }
-    if (CC && j == b.loy)      { lap += facy*(4./3.)*c[GA_X];  c0 -= 2.0*facy; }
-    else if (CC && j == b.hiy) { lap += facy*(4./3.)*c[-GA_X]; c0 -= 2.0*facy; }
-    else                       { lap += facy*(c[-GA_X] + c[GA_X]); }
-    phi[lj*GA_X + li] = (rhs - lap)*(1.0/c0);
+    if (CC && (i == b.lox || i == b.hix)) c0 -= 2.0*facx;
+    if (CC && (j == b.loy || j == b.hiy)) c0 -= 2.0*facy;
+    return c0;
 }
 
-__device__ __forceinline__ double residual_at (const double* phi, int li, int lj, int i, int j, const LevBox& b,
+// off-diagonal part of the stencil at (i,j); `c` points at the cell, `sy` is the row stride
+template <bool CC, class P>
+__device__ __forceinline__ double offdiag (P c, int sy, int i, int j, const LevBox& b, double facx, double facy)
+{
+    double lap;
+    if (CC && i == b.lox)      lap = facx*(4./3.)*c[1];
+    else if (CC && i == b.hix) lap = facx*(4./3.)*c[-1];
+    else                       lap = facx*(c[-1] + c[1]);
+    if (CC && j == b.loy)      lap += facy*(4./3.)*c[sy];
+    else if (CC && j == b.hiy) lap += facy*(4./3.)*c[-sy];
+    else                       lap += facy*(c[-sy] + c[sy]);
+    return lap;
+}
+
+// residual rhs - L(phi) at (i,j) (laplacian :162-182, residual1 :184-190)
+template <class P>
+__device__ __forceinline__ double residual_at (P c, int sy, int i, int j, const LevBox& b,
                                                double rhs, double acf, double facx, double facy)
 {
-    const double* c = phi + lj*GA_X + li;
     const double p0 = c[0];
     double lap = -2.0*(facx + facy)*p0;
     if (i == b.lox)      lap += facx*((4./3.)*c[1] - 2.0*p0);
     else if (i == b.hix) lap += facx*((4./3.)*c[-1] - 2.0*p0);
     else                 lap += facx*(c[-1] + c[1]);
-    if (j == b.loy)      lap += facy*((4./3.)*c[GA_X] - 2.0*p0);
-    else if (j == b.hiy) lap += facy*((4./3.)*c[-GA_X] - 2.0*p0);
-    else                 lap += facy*(c[-GA_X] + c[GA_X]);
+    if (j == b.loy)      lap += facy*((4./3.)*c[sy] - 2.0*p0);
+    else if (j == b.hiy) lap += facy*((4./3.)*c[-sy] - 2.0*p0);
+    else                 lap += facy*(c[-sy] + c[sy]);
     return rhs + acf*p0 - lap;
 }
 
-__device__ __forceinline__ void atomic_max_abs (unsigned long long* addr, double v)
+// P(coarse) at fine point (i,j): piecewise constant (cell-centred) or bilinear (nodal)
+template <bool CC>
+__device__ __forceinline__ double prolong_at (const FView& crse, int i, int j, int n)
 {
-    // non-negative doubles order like their bit patterns
-    atomicMax(addr, (unsigned long long)__double_as_longlong(fabs(v)));
+    const int ic = i >> 1, jc = j >> 1;      // indices are >= 0
+    if (CC) return crse(ic, jc, n);
+    const bool io = (i & 1), jo = (j & 1);
+    if (io && jo)  return (crse(ic, jc, n) + crse(ic+1, jc, n) + crse(ic, jc+1, n) + crse(ic+1, jc+1, n))*0.25;
+    if (io)        return (crse(ic, jc, n) + crse(ic+1, jc, n))*0.5;
+    if (jo)        return (crse(ic, jc, n) + crse(ic, jc+1, n))*0.5;
+    return crse(ic, jc, n);
 }
 
-// phi_out = GSRB^4(phi_in or 0); optionally res = rhs - L(phi_out), max|res|, max|rhs|
-template <bool CC, bool ZERO_INIT, bool DO_RES>
-__global__ __launch_bounds__(256)
-void k_gsrb4 (LevBox b, FView phi_out, FView rhs, FView acf, FView res, FView phi_in,
-              double facx, double facy, int ntx, unsigned long long* resnorm, unsigned long long* rhsnorm)
+// max-norm accumulation: one atomic per workgroup at most, and only if it would raise the maximum
+// (same-address L2 atomics serialise: 4 per workgroup cost ~60 us on an 817-workgroup launch)
+__device__ __forceinline__ void block_max_to (unsigned long long* addr, double v, double* s_red)
 {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double m = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+        // non-negative doubles order like their bit patterns
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+        if (bits > __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(addr, bits);
+    }
+    __syncthreads();
+}
+
+// phi_out = GSRB^4(start), start = 0 | phi_in | phi_in + P(crse);
+// DO_RES: residual r = rhs - L(phi_out), max|r| (and max|rhs|) -> norms;
+//         FUSE_R (cell-centred): cres = R(r) written straight to the next level; else r -> res_out.
+template <bool CC, int SRC, bool DO_RES, bool FUSE_R>
+__global__ __launch_bounds__(256)
+void k_smooth (LevBox b, FView phi_out, FView rhs, FView acf, FView phi_in, FView crse, FView res_out,
+               FView cres_out, double facx, double facy, int ntx, unsigned long long* resnorm,
+               unsigned long long* rhsnorm)
+{
+    static_assert(!FUSE_R || (CC && DO_RES), "fused restriction is cell-centred only");
     __shared__ double s_phi[2][GA_Y*GA_X];
     constexpr int E = DO_RES ? 4 : 3;                 // rim of the swept tile that is not final
-    constexpr int FX = GT_X - 2*E, FY = GT_Y - 2*E;   // cells a tile finalises
+    constexpr int FX = GT_X - 2*E, FY = GT_Y - 2*E;   // cells a tile finalises (even numbers)
     const int bx = blockIdx.x % ntx, by = blockIdx.x / ntx;
     const int gi0 = b.vlx + bx*FX - E;                // global index of swept cell (0,0)
     const int gj0 = b.vly + by*FY - E;
     const int tid = threadIdx.x;
 
-    // fill LDS (ring included): phi_in inside the unknowns' box, 0 elsewhere
+    // fill LDS (ring included): start value inside the unknowns' box, 0 elsewhere
     for (int s = tid; s < GA_X*GA_Y; s += 256) {
         const int lj = s / GA_X, li = s - lj*GA_X;
         const int i = gi0 - 1 + li, j = gj0 - 1 + lj;
         double v0 = 0.0, v1 = 0.0;
-        if (!ZERO_INIT && i >= b.vlx && i <= b.vhx && j >= b.vly && j <= b.vhy) {
+        if (SRC != SRC_ZERO && i >= b.vlx && i <= b.vhx && j >= b.vly && j <= b.vhy) {
             v0 = phi_in(i, j, 0); v1 = phi_in(i, j, 1);
+            if (SRC == SRC_PROLONG) { v0 += prolong_at<CC>(crse, i, j, 0); v1 += prolong_at<CC>(crse, i, j, 1); }
         }
         s_phi[0][s] = v0; s_phi[1][s] = v1;
     }
 
-    // per-thread cell pairs and their rhs / coefficient registers
-    double r0[GPAIRS][2], r1[GPAIRS][2], ac[GPAIRS][2];
+    // per-thread cell pairs: rhs, coefficient and inverse diagonal stay in registers
+    double r0[GPAIRS][2], r1[GPAIRS][2], ac[GPAIRS][2], ci[GPAIRS][2];
     bool in[GPAIRS][2];
     double rmax = 0.0;
 #pragma unroll
@@ -114,6 +157,7 @@ void k_gsrb4 (LevBox b, FView phi_out, FView rhs, FView acf, FView res, FView ph
             r0[m][h] = ok ? rhs(i, j, 0) : 0.0;
             r1[m][h] = ok ? rhs(i, j, 1) : 0.0;
             ac[m][h] = ok ? acf(i, j, 0) : 0.0;
+            ci[m][h] = 1.0/diag_c0<CC>(i, j, b, ac[m][h], facx, facy);
             if (rhsnorm && ok) rmax = fmax(rmax, fmax(fabs(r0[m][h]), fabs(r1[m][h])));
         }
     }
@@ -129,8 +173,9 @@ void k_gsrb4 (LevBox b, FView phi_out, FView rhs, FView acf, FView res, FView ph
             const int h = (ia + j + icolor) & 1;          // which cell of the pair has this colour
             if (in[m][h]) {
                 const int i = ia + h;
-                gs_update<CC>(s_phi[0], 2*pk + h + 1, jj + 1, i, j, b, r0[m][h], ac[m][h], facx, facy);
-                gs_update<CC>(s_phi[1], 2*pk + h + 1, jj + 1, i, j, b, r1[m][h], ac[m][h], facx, facy);
+                const int o = (jj + 1)*GA_X + 2*pk + h + 1;
+                s_phi[0][o] = (r0[m][h] - offdiag<CC>(&s_phi[0][o], GA_X, i, j, b, facx, facy))*ci[m][h];
+                s_phi[1][o] = (r1[m][h] - offdiag<CC>(&s_phi[1][o], GA_X, i, j, b, facx, facy))*ci[m][h];
             }
         }
         __syncthreads();
@@ -142,33 +187,53 @@ void k_gsrb4 (LevBox b, FView phi_out, FView rhs, FView acf, FView res, FView ph
         const int pi = tid + 256*m;
         const int jj = pi / (GT_X/2), pk = pi - jj*(GT_X/2);
         const int j = gj0 + jj;
-        if (jj < E || jj >= GT_Y - E) continue;
+        const bool rowok = (jj >= E && jj < GT_Y - E);
+        double q0[2] = {0.0, 0.0}, q1[2] = {0.0, 0.0};
+        bool fin[2] = {false, false};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int ii = 2*pk + h;
-            if (ii < E || ii >= GT_X - E || !in[m][h]) continue;
+            fin[h] = rowok && ii >= E && ii < GT_X - E && in[m][h];
+            if (!fin[h]) continue;
             const int i = gi0 + ii;
+            const int o = (jj + 1)*GA_X + ii + 1;
             if (DO_RES) {
-                const double q0 = residual_at(s_phi[0], ii + 1, jj + 1, i, j, b, r0[m][h], ac[m][h], facx, facy);
-                const double q1 = residual_at(s_phi[1], ii + 1, jj + 1, i, j, b, r1[m][h], ac[m][h], facx, facy);
-                res(i, j, 0) = q0; res(i, j, 1) = q1;
-                resmax = fmax(resmax, fmax(fabs(q0), fabs(q1)));
+                q0[h] = residual_at(&s_phi[0][o], GA_X, i, j, b, r0[m][h], ac[m][h], facx, facy);
+                q1[h] = residual_at(&s_phi[1][o], GA_X, i, j, b, r1[m][h], ac[m][h], facx, facy);
+                if (!FUSE_R) { res_out(i, j, 0) = q0[h]; res_out(i, j, 1) = q1[h]; }
+                resmax = fmax(resmax, fmax(fabs(q0[h]), fabs(q1[h])));
             }
-            phi_out(i, j, 0) = s_phi[0][(jj + 1)*GA_X + ii + 1];
-            phi_out(i, j, 1) = s_phi[1][(jj + 1)*GA_X + ii + 1];
+            phi_out(i, j, 0) = s_phi[0][o];
+            phi_out(i, j, 1) = s_phi[1][o];
+        }
+        if (FUSE_R) {
+            // restrict_cc (:29-37): 0.25*(((a+b)+c)+d), a,b this row (even j), c,d the row above.
+            // Tile origins are even, so a pair is one coarse cell's x-extent and lanes l / l+32
+            // of a wave hold rows jj / jj+1.
+            const double c0 = __shfl_down(q0[0], 32), d0 = __shfl_down(q0[1], 32);
+            const double c1 = __shfl_down(q1[0], 32), d1 = __shfl_down(q1[1], 32);
+            if (fin[0] && ((tid & 32) == 0)) {
+                const int ic = (gi0 + 2*pk) >> 1, jc = j >> 1;
+                cres_out(ic, jc, 0) = 0.25*(q0[0] + q0[1] + c0 + d0);
+                cres_out(ic, jc, 1) = 0.25*(q1[0] + q1[1] + c1 + d1);
+            }
         }
     }
-    if (DO_RES && resnorm) {
-        for (int o = 32; o > 0; o >>= 1) resmax = fmax(resmax, __shfl_xor(resmax, o));
-        if ((tid & 63) == 0 && resmax > 0.0) atomic_max_abs(resnorm, resmax);
-    }
-    if (rhsnorm) {
-        for (int o = 32; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o));
-        if ((tid & 63) == 0 && rmax > 0.0) atomic_max_abs(rhsnorm, rmax);
-    }
+    __shared__ double s_red[4];
+    if (DO_RES && resnorm) block_max_to(resnorm, resmax, s_red);
+    if (rhsnorm) block_max_to(rhsnorm, rmax, s_red);
 }
 
 // coarse = R(fine): 4-average (cell-centred) or 9-point full weighting (nodal)
+template <bool CC>
+__device__ __forceinline__ double restrict_at (const FView& fine, int i, int j, int n)
+{
+    if (CC) return 0.25*(fine(2*i, 2*j, n) + fine(2*i+1, 2*j, n) + fine(2*i, 2*j+1, n) + fine(2*i+1, 2*j+1, n));
+    return (1./16.)*(fine(2*i-1, 2*j-1, n) + 2.*fine(2*i, 2*j-1, n) + fine(2*i+1, 2*j-1, n)
+                   + 2.*fine(2*i-1, 2*j, n) + 4.*fine(2*i, 2*j, n) + 2.*fine(2*i+1, 2*j, n)
+                   + fine(2*i-1, 2*j+1, n) + 2.*fine(2*i, 2*j+1, n) + fine(2*i+1, 2*j+1, n));
+}
+
 template <bool CC>
 __global__ __launch_bounds__(256)
 void k_restrict (LevBox cb, FView crse, FView fine, int ncomp)
@@ -176,72 +241,168 @@ void k_restrict (LevBox cb, FView crse, FView fine, int ncomp)
     const int i = cb.vlx + blockIdx.x*blockDim.x + threadIdx.x;
     const int j = cb.vly + blockIdx.y;
     if (i > cb.vhx || j > cb.vhy) return;
-    for (int n = 0; n < ncomp; ++n) {
-        if (CC) {
-            crse(i, j, n) = 0.25*(fine(2*i, 2*j, n) + fine(2*i+1, 2*j, n) + fine(2*i, 2*j+1, n) + fine(2*i+1, 2*j+1, n));
-        } else {
-            crse(i, j, n) = (1./16.)*(fine(2*i-1, 2*j-1, n) + 2.*fine(2*i, 2*j-1, n) + fine(2*i+1, 2*j-1, n)
-                                    + 2.*fine(2*i-1, 2*j, n) + 4.*fine(2*i, 2*j, n) + 2.*fine(2*i+1, 2*j, n)
-                                    + fine(2*i-1, 2*j+1, n) + 2.*fine(2*i, 2*j+1, n) + fine(2*i+1, 2*j+1, n));
-        }
-    }
+    for (int n = 0; n < ncomp; ++n) crse(i, j, n) = restrict_at<CC>(fine, i, j, n);
 }
 
-// fine_out = fine_in + P(coarse)
-template <bool CC>
-__global__ __launch_bounds__(256)
-void k_prolong_add (LevBox fb, FView fin, FView crse, FView fout)
+// ---- all small levels in one workgroup, LDS resident --------------------------------------------
+typedef __attribute__((address_space(3))) double lds_double;
+
+// per small level: box, row length, points, offset (in doubles) of its 7-plane block in LDS:
+// [acf | res0 res1 | cor0 cor1 | rescor0 rescor1]
+struct LowLev { LevBox b; int nxb; int cells; int off; };
+
+struct LView {      // one component plane of a small level in LDS, level index space
+    lds_double* p; int nxb; int lox, loy;
+    __device__ __forceinline__ lds_double& operator() (int i, int j) const { return p[(i - lox) + (j - loy)*nxb]; }
+};
+__device__ __forceinline__ LView lplane (lds_double* base, const LowLev& l, int plane)
 {
-    const int i = fb.vlx + blockIdx.x*blockDim.x + threadIdx.x;
-    const int j = fb.vly + blockIdx.y;
-    if (i > fb.vhx || j > fb.vhy) return;
-    const int ic = i >> 1, jc = j >> 1;      // indices are >= 0
-    for (int n = 0; n < 2; ++n) {
-        double add;
-        if (CC) {
-            add = crse(ic, jc, n);
-        } else {
-            const bool io = (i & 1), jo = (j & 1);
-            if (io && jo)  add = (crse(ic, jc, n) + crse(ic+1, jc, n) + crse(ic, jc+1, n) + crse(ic+1, jc+1, n))*0.25;
-            else if (io)   add = (crse(ic, jc, n) + crse(ic+1, jc, n))*0.5;
-            else if (jo)   add = (crse(ic, jc, n) + crse(ic, jc+1, n))*0.5;
-            else           add = crse(ic, jc, n);
-        }
-        fout(i, j, n) = fin(i, j, n) + add;
-    }
+    return LView{base + l.off + plane*l.cells, l.nxb, l.b.lox, l.b.loy};
 }
 
-// coarsest level: phi = 0, then nsweeps red-black sweeps, one workgroup, data in place
 template <bool CC>
-__global__ __launch_bounds__(256)
-void k_bottom (LevBox b, FView phi, FView rhs, FView acf, double facx, double facy, int nsweeps)
+__device__ __forceinline__ double lrestrict (const LView& f, int i, int j)
 {
-    const int nvx = b.vhx - b.vlx + 1, nvy = b.vhy - b.vly + 1;
-    const int nbx = b.hix - b.lox + 1, nby = b.hiy - b.loy + 1;
-    for (int s = threadIdx.x; s < nbx*nby; s += blockDim.x) {
-        const int jj = s / nbx, ii = s - jj*nbx;
-        phi(b.lox + ii, b.loy + jj, 0) = 0.0; phi(b.lox + ii, b.loy + jj, 1) = 0.0;
-    }
-    __syncthreads();
+    if (CC) return 0.25*(f(2*i, 2*j) + f(2*i+1, 2*j) + f(2*i, 2*j+1) + f(2*i+1, 2*j+1));
+    return (1./16.)*(f(2*i-1, 2*j-1) + 2.*f(2*i, 2*j-1) + f(2*i+1, 2*j-1)
+                   + 2.*f(2*i-1, 2*j) + 4.*f(2*i, 2*j) + 2.*f(2*i+1, 2*j)
+                   + f(2*i-1, 2*j+1) + 2.*f(2*i, 2*j+1) + f(2*i+1, 2*j+1));
+}
+
+template <bool CC>
+__device__ __forceinline__ double lprolong (const LView& c, int i, int j)
+{
+    const int ic = i >> 1, jc = j >> 1;
+    if (CC) return c(ic, jc);
+    const bool io = (i & 1), jo = (j & 1);
+    if (io && jo)  return (c(ic, jc) + c(ic+1, jc) + c(ic, jc+1) + c(ic+1, jc+1))*0.25;
+    if (io)        return (c(ic, jc) + c(ic+1, jc))*0.5;
+    if (jo)        return (c(ic, jc) + c(ic, jc+1))*0.5;
+    return c(ic, jc);
+}
+
+template <bool CC>
+__device__ void low_sweeps (lds_double* base, const LowLev& l, double facx, double facy, int nsweeps)
+{
+    const int nvx = l.b.vhx - l.b.vlx + 1, nvy = l.b.vhy - l.b.vly + 1;
+    const LView acf = lplane(base, l, 0);
     for (int is = 0; is < nsweeps; ++is) {
         for (int s = threadIdx.x; s < nvx*nvy; s += blockDim.x) {
             const int jj = s / nvx, ii = s - jj*nvx;
-            const int i = b.vlx + ii, j = b.vly + jj;
+            const int i = l.b.vlx + ii, j = l.b.vly + jj;
             if (((i + j + is) & 1) == 0) {
-                const double a = acf(i, j, 0);
+                const double cinv = 1.0/diag_c0<CC>(i, j, l.b, acf(i, j), facx, facy);
+#pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    double lap, c0 = -(a + 2.0*(facx + facy));
-                    if (CC && i == b.lox)      { lap = facx*(4./3.)*phi(i+1, j, n); c0 -= 2.0*facx; }
-                    else if (CC && i == b.hix) { lap = facx*(4./3.)*phi(i-1, j, n); c0 -= 2.0*facx; }
-                    else                       { lap = facx*(phi(i-1, j, n) + phi(i+1, j, n)); }
-                    if (CC && j == b.loy)      { lap += facy*(4./3.)*phi(i, j+1, n); c0 -= 2.0*facy; }
-                    else if (CC && j == b.hiy) { lap += facy*(4./3.)*phi(i, j-1, n); c0 -= 2.0*facy; }
-                    else                       { lap += facy*(phi(i, j-1, n) + phi(i, j+1, n)); }
-                    phi(i, j, n) = (rhs(i, j, n) - lap)*(1.0/c0);
+                    const LView rhs = lplane(base, l, 1 + n), phi = lplane(base, l, 3 + n);
+                    phi(i, j) = (rhs(i, j) - offdiag<CC>((const lds_double*)&phi(i, j), l.nxb, i, j, l.b, facx, facy))*cinv;
                 }
             }
         }
         __syncthreads();
+    }
+}
+
+__device__ void low_zero_cor (lds_double* base, const LowLev& l)
+{
+    lds_double* c = base + l.off + 3*l.cells;
+    for (int s = threadIdx.x; s < 2*l.cells; s += blockDim.x) c[s] = 0.0;
+    __syncthreads();
+}
+
+// levels lv[0..nl-1] (finest first): cor[0] = lower-V(res[0]); mirrors the single-block bottom
+// solver of the reference (HpMultiGrid.cpp:854-1033), 16+ sweeps on the last level.  Level 0's
+// coefficient and residual come from HBM (acf_g, res_g), its correction goes back (cor_g); the
+// coefficients of the lower levels are re-derived in LDS (average_down_acoef).
+template <bool CC>
+__global__ __launch_bounds__(1024)
+void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, const double* __restrict__ res_g,
+                double* __restrict__ cor_g, double facx0, double facy0, int nsweeps_bottom)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    lds_double* base = (lds_double*)lds_raw;
+    {
+        const LowLev l = lv[0];
+        for (int s = threadIdx.x; s < l.cells; s += blockDim.x) {
+            base[l.off + s] = acf_g[s];
+            base[l.off + l.cells + s] = res_g[s];
+            base[l.off + 2*l.cells + s] = res_g[l.cells + s];
+        }
+        __syncthreads();
+    }
+    for (int il = 1; il < nl; ++il) {     // coefficient hierarchy
+        const LowLev f = lv[il - 1];
+        const LowLev c = lv[il];
+        const int nvx = c.b.vhx - c.b.vlx + 1, nvy = c.b.vhy - c.b.vly + 1;
+        const LView fine = lplane(base, f, 0), crse = lplane(base, c, 0);
+        for (int s = threadIdx.x; s < c.cells; s += blockDim.x) base[c.off + s] = 0.0;
+        __syncthreads();
+        for (int s = threadIdx.x; s < nvx*nvy; s += blockDim.x) {
+            const int jj = s / nvx, ii = s - jj*nvx;
+            crse(c.b.vlx + ii, c.b.vly + jj) = lrestrict<CC>(fine, c.b.vlx + ii, c.b.vly + jj);
+        }
+        __syncthreads();
+    }
+    double facx = facx0, facy = facy0;
+    for (int il = 0; il < nl - 1; ++il) {
+        const LowLev l = lv[il];
+        const LowLev c = lv[il + 1];
+        low_zero_cor(base, l);
+        low_sweeps<CC>(base, l, facx, facy, 4);
+        {   // residual -> rescor
+            const int nvx = l.b.vhx - l.b.vlx + 1, nvy = l.b.vhy - l.b.vly + 1;
+            const LView acf = lplane(base, l, 0);
+            // walls of rescor must read as 0 for the nodal restriction
+            if (!CC) { lds_double* r = base + l.off + 5*l.cells; for (int s = threadIdx.x; s < 2*l.cells; s += blockDim.x) r[s] = 0.0; __syncthreads(); }
+            for (int s = threadIdx.x; s < nvx*nvy; s += blockDim.x) {
+                const int jj = s / nvx, ii = s - jj*nvx;
+                const int i = l.b.vlx + ii, j = l.b.vly + jj;
+                const double a = acf(i, j);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const LView rhs = lplane(base, l, 1 + n), phi = lplane(base, l, 3 + n), rc = lplane(base, l, 5 + n);
+                    rc(i, j) = residual_at((const lds_double*)&phi(i, j), l.nxb, i, j, l.b, rhs(i, j), a, facx, facy);
+                }
+            }
+            __syncthreads();
+        }
+        {   // restriction -> res of the next level
+            const int nvx = c.b.vhx - c.b.vlx + 1, nvy = c.b.vhy - c.b.vly + 1;
+            for (int s = threadIdx.x; s < nvx*nvy; s += blockDim.x) {
+                const int jj = s / nvx, ii = s - jj*nvx;
+                const int i = c.b.vlx + ii, j = c.b.vly + jj;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) lplane(base, c, 1 + n)(i, j) = lrestrict<CC>(lplane(base, l, 5 + n), i, j);
+            }
+            __syncthreads();
+        }
+        facx *= 0.25; facy *= 0.25;
+    }
+    {
+        const LowLev l = lv[nl - 1];
+        low_zero_cor(base, l);
+        low_sweeps<CC>(base, l, facx, facy, nsweeps_bottom);
+    }
+    for (int il = nl - 2; il >= 0; --il) {
+        const LowLev l = lv[il];
+        const LowLev c = lv[il + 1];
+        facx *= 4.0; facy *= 4.0;
+        const int nvx = l.b.vhx - l.b.vlx + 1, nvy = l.b.vhy - l.b.vly + 1;
+        for (int s = threadIdx.x; s < nvx*nvy; s += blockDim.x) {
+            const int jj = s / nvx, ii = s - jj*nvx;
+            const int i = l.b.vlx + ii, j = l.b.vly + jj;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const LView fine = lplane(base, l, 3 + n);
+                fine(i, j) = fine(i, j) + lprolong<CC>(lplane(base, c, 3 + n), i, j);
+            }
+        }
+        __syncthreads();
+        low_sweeps<CC>(base, l, facx, facy, 4);
+    }
+    {
+        const LowLev l = lv[0];
+        for (int s = threadIdx.x; s < 2*l.cells; s += blockDim.x) cor_g[s] = base[l.off + 3*l.cells + s];
     }
 }
 
@@ -255,17 +416,20 @@ __global__ void k_copy2 (LevBox b, FView dst, FView src)
 
 struct MGLevelDev { LevBox b; long cells; double *acf, *res, *cor, *rescor; };
 
+constexpr long LOWV_MAX_CELLS = 34*34;     // levels with at most ~32x32 unknowns run in k_lower_v (LDS resident)
+
 struct Multigrid {
     bool cc; int nx, ny; double dx, dy;
     std::vector<MGLevelDev> L;
+    int lowv_begin = 1;                         // first level handled by k_lower_v
+    LowLev* d_low = nullptr; size_t low_lds = 0;
     unsigned long long* d_norms = nullptr;      // [0] residual, [1] rhs
     unsigned long long* h_norms = nullptr;      // pinned
-    // level-0 user views (set per solve)
-    FView sol, rhs, acf0;
+    FView sol, rhs, acf0;                       // level-0 user views (set per solve)
 
     ~Multigrid () {
         for (auto& l : L) { (void)hipFree(l.acf); (void)hipFree(l.res); (void)hipFree(l.cor); (void)hipFree(l.rescor); }
-        (void)hipFree(d_norms);
+        (void)hipFree(d_norms); (void)hipFree(d_low);
         if (h_norms) (void)hipHostFree(h_norms);
     }
     FView lv (int il, double* p) const {
@@ -281,6 +445,7 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
     if (nx % 2 != ny % 2) { set_error("hps_mg_create: nx and ny must have the same parity"); return HPS_ERR_ARG; }
     Multigrid* M = new Multigrid;
     M->cc = (nx % 2 == 0); M->nx = nx; M->ny = ny; M->dx = dx; M->dy = dy;
+    // level boxes (ctor, HpMultiGrid.cpp:1043-1072)
     int hx = M->cc ? nx - 1 : nx + 1, hy = M->cc ? ny - 1 : ny + 1;
     for (int il = 0; il < 31; ++il) {
         MGLevelDev l{};
@@ -304,64 +469,90 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
         if (!ok) break;
     }
     if (M->nlev() < 2) { delete M; set_error("hps_mg_create: grid too small to coarsen"); return HPS_ERR_ARG; }
+    const int nl = M->nlev();
+    M->lowv_begin = nl - 1;
+    for (int il = nl - 1; il >= 1; --il) if (M->L[il].cells <= LOWV_MAX_CELLS) M->lowv_begin = il;
+    std::vector<LowLev> low;
+    int off = 0;
+    for (int il = M->lowv_begin; il < nl; ++il) {
+        const MGLevelDev& l = M->L[il];
+        low.push_back(LowLev{l.b, l.b.hix - l.b.lox + 1, (int)l.cells, off});
+        off += 7*(int)l.cells;
+    }
+    M->low_lds = (size_t)off*sizeof(double);
+    if (M->low_lds > 64*1024) {
+        HPS_HIP_CHECK(hipFuncSetAttribute((const void*)k_lower_v<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->low_lds));
+        HPS_HIP_CHECK(hipFuncSetAttribute((const void*)k_lower_v<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->low_lds));
+    }
+    HPS_HIP_CHECK(hipMalloc(&M->d_low, low.size()*sizeof(LowLev)));
+    HPS_HIP_CHECK(hipMemcpy(M->d_low, low.data(), low.size()*sizeof(LowLev), hipMemcpyHostToDevice));
     HPS_HIP_CHECK(hipMalloc(&M->d_norms, 2*sizeof(unsigned long long)));
     HPS_HIP_CHECK(hipHostMalloc(&M->h_norms, 2*sizeof(unsigned long long)));
     *out = M;
     return HPS_OK;
 }
 
-template <bool CC>
-static void launch_gsrb4 (Multigrid* M, int il, bool zero_init, bool do_res, FView phi_out, FView rhs, FView acf,
-                          FView res, FView phi_in, double ldx, double ldy, unsigned long long* resnorm,
-                          unsigned long long* rhsnorm, hipStream_t st)
+template <bool CC, int SRC, bool DO_RES>
+static void launch_smooth (Multigrid* M, int il, FView phi_out, FView rhs, FView acf, FView phi_in, FView crse,
+                           FView res_out, FView cres_out, unsigned long long* resnorm, unsigned long long* rhsnorm,
+                           hipStream_t st)
 {
     const LevBox& b = M->L[il].b;
-    const int E = do_res ? 4 : 3;
-    const int FX = GT_X - 2*E, FY = GT_Y - 2*E;
+    constexpr int E = DO_RES ? 4 : 3;
+    constexpr int FX = GT_X - 2*E, FY = GT_Y - 2*E;
     const int ntx = ceil_div(b.vhx - b.vlx + 1, FX), nty = ceil_div(b.vhy - b.vly + 1, FY);
+    const double fac = (double)(1 << il);
+    const double ldx = M->dx*fac, ldy = M->dy*fac;
     const double facx = 1.0/(ldx*ldx), facy = 1.0/(ldy*ldy);
-    const dim3 grid(ntx*nty), block(256);
-    if (zero_init)      hipLaunchKernelGGL((k_gsrb4<CC, true, true>),  grid, block, 0, st, b, phi_out, rhs, acf, res, phi_in, facx, facy, ntx, resnorm, rhsnorm);
-    else if (do_res)    hipLaunchKernelGGL((k_gsrb4<CC, false, true>), grid, block, 0, st, b, phi_out, rhs, acf, res, phi_in, facx, facy, ntx, resnorm, rhsnorm);
-    else                hipLaunchKernelGGL((k_gsrb4<CC, false, false>), grid, block, 0, st, b, phi_out, rhs, acf, res, phi_in, facx, facy, ntx, resnorm, rhsnorm);
+    constexpr bool FUSE = CC && DO_RES;
+    hipLaunchKernelGGL((k_smooth<CC, SRC, DO_RES, FUSE>), dim3(ntx*nty), dim3(256), 0, st, b, phi_out, rhs, acf, phi_in, crse,
+                       res_out, cres_out, facx, facy, ntx, resnorm, rhsnorm);
 }
 
 template <bool CC>
+static void restrict_residual_if_nodal (Multigrid* M, int il, hipStream_t st)
+{
+    if (CC) return;     // fused into k_smooth
+    const LevBox& cb = M->L[il+1].b;
+    hipLaunchKernelGGL(k_restrict<CC>, dim3(ceil_div(cb.vhx - cb.vlx + 1, 64), cb.vhy - cb.vly + 1), dim3(64), 0, st,
+                       cb, M->lv(il+1, M->L[il+1].res), M->lv(il, M->L[il].rescor), 2);
+}
+
+// one V-cycle (vcycle :1429-1512).  On entry res[1] = R(rhs - L(cor[0])); on exit again, plus
+// sol = smoothed solution, cor[0] = GSRB^4(sol) and the residual norm in d_norms[0].
+template <bool CC>
 static void vcycle (Multigrid* M, hipStream_t st)
 {
-    const int maxl = M->nlev() - 1;
-    for (int il = 0; il < maxl; ++il) {
-        const double fac = (double)(1 << il);
-        if (il > 0) {
-            launch_gsrb4<CC>(M, il, true, true, M->lv(il, M->L[il].cor), M->lv(il, M->L[il].res), M->lv(il, M->L[il].acf),
-                             M->lv(il, M->L[il].rescor), FView{}, M->dx*fac, M->dy*fac, nullptr, nullptr, st);
-        }
-        const LevBox& cb = M->L[il+1].b;
-        hipLaunchKernelGGL(k_restrict<CC>, dim3(ceil_div(cb.vhx - cb.vlx + 1, 64), cb.vhy - cb.vly + 1), dim3(64), 0, st,
-                           cb, M->lv(il+1, M->L[il+1].res), M->lv(il, M->L[il].rescor), 2);
+    const int nl = M->nlev();
+    const int lb = M->lowv_begin;
+    const FView none{};
+    for (int il = 1; il < lb; ++il) {
+        launch_smooth<CC, SRC_ZERO, true>(M, il, M->lv(il, M->L[il].cor), M->lv(il, M->L[il].res), M->lv(il, M->L[il].acf), none, none,
+                                          M->lv(il, M->L[il].rescor), M->lv(il+1, M->L[il+1].res), nullptr, nullptr, st);
+        restrict_residual_if_nodal<CC>(M, il, st);
     }
-    {   // coarsest level (CPU branch of bottomsolve, HpMultiGrid.cpp:1583-1593)
-        const double fac = (double)(1 << maxl);
-        const LevBox& b = M->L[maxl].b;
-        const int nsweeps = std::max(16, (std::max(b.hix - b.lox + 1, b.hiy - b.loy + 1) + 1)/2*2);
+    {
+        const double fac = (double)(1 << lb);
         const double ldx = M->dx*fac, ldy = M->dy*fac;
-        FView rhsb = (maxl == 0) ? M->rhs : M->lv(maxl, M->L[maxl].res);
-        FView acfb = (maxl == 0) ? M->acf0 : M->lv(maxl, M->L[maxl].acf);
-        hipLaunchKernelGGL(k_bottom<CC>, dim3(1), dim3(256), 0, st, b, M->lv(maxl, M->L[maxl].cor), rhsb, acfb,
-                           1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps);
+        const LevBox& bb = M->L[nl-1].b;
+        const int nsweeps = std::max(16, (std::max(bb.hix - bb.lox + 1, bb.hiy - bb.loy + 1) + 1)/2*2);
+        hipLaunchKernelGGL(k_lower_v<CC>, dim3(1), dim3(1024), M->low_lds, st, M->d_low, nl - lb, M->L[lb].acf, M->L[lb].res,
+                           M->L[lb].cor, 1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps);
     }
-    for (int il = maxl - 1; il >= 0; --il) {
-        const double fac = (double)(1 << il);
-        const LevBox& fb = M->L[il].b;
-        hipLaunchKernelGGL(k_prolong_add<CC>, dim3(ceil_div(fb.vhx - fb.vlx + 1, 64), fb.vhy - fb.vly + 1), dim3(64), 0, st,
-                           fb, M->lv(il, M->L[il].cor), M->lv(il+1, M->L[il+1].cor), M->lv(il, M->L[il].rescor));
-        if (il == 0) launch_gsrb4<CC>(M, 0, false, false, M->sol, M->rhs, M->acf0, FView{}, M->lv(0, M->L[0].rescor),
-                                      M->dx, M->dy, nullptr, nullptr, st);
-        else         launch_gsrb4<CC>(M, il, false, false, M->lv(il, M->L[il].cor), M->lv(il, M->L[il].res), M->lv(il, M->L[il].acf),
-                                      FView{}, M->lv(il, M->L[il].rescor), M->dx*fac, M->dy*fac, nullptr, nullptr, st);
+    // up-leg: the smoothed correction of level il lands in rescor[il] (out of place)
+    for (int il = lb - 1; il >= 1; --il) {
+        double* crse = (il + 1 == lb) ? M->L[il+1].cor : M->L[il+1].rescor;
+        launch_smooth<CC, SRC_PROLONG, false>(M, il, M->lv(il, M->L[il].rescor), M->lv(il, M->L[il].res), M->lv(il, M->L[il].acf),
+                                              M->lv(il, M->L[il].cor), M->lv(il+1, crse), none, none, nullptr, nullptr, st);
     }
-    launch_gsrb4<CC>(M, 0, false, true, M->lv(0, M->L[0].cor), M->rhs, M->acf0, M->lv(0, M->L[0].rescor), M->sol,
-                     M->dx, M->dy, M->d_norms, nullptr, st);
+    {
+        double* crse = (1 == lb) ? M->L[1].cor : M->L[1].rescor;
+        launch_smooth<CC, SRC_PROLONG, false>(M, 0, M->sol, M->rhs, M->acf0, M->lv(0, M->L[0].cor), M->lv(1, crse), none, none,
+                                              nullptr, nullptr, st);
+    }
+    launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), M->rhs, M->acf0, M->sol, none, M->lv(0, M->L[0].rescor),
+                                        M->lv(1, M->L[1].res), M->d_norms, nullptr, st);
+    restrict_residual_if_nodal<CC>(M, 0, st);
 }
 
 static inline double norm_value (unsigned long long bits) { double d; memcpy(&d, &bits, 8); return d; }
@@ -370,17 +561,19 @@ template <bool CC>
 static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_iters, int* iters_out, double* resnorm_out,
                         hipStream_t st)
 {
-    const int nl = M->nlev();
+    const int lb = M->lowv_begin;
     // coefficient hierarchy (average_down_acoef, HpMultiGrid.cpp:1640-1700); level 0 reads the slab
-    for (int il = 1; il < nl; ++il) {
+    for (int il = 1; il <= lb; ++il) {
         const LevBox& cb = M->L[il].b;
         FView fine = (il == 1) ? M->acf0 : M->lv(il-1, M->L[il-1].acf);
         hipLaunchKernelGGL(k_restrict<CC>, dim3(ceil_div(cb.vhx - cb.vlx + 1, 64), cb.vhy - cb.vly + 1), dim3(64), 0, st,
                            cb, M->lv(il, M->L[il].acf), fine, 1);
     }
     HPS_HIP_CHECK(hipMemsetAsync(M->d_norms, 0, 2*sizeof(unsigned long long), st));
-    launch_gsrb4<CC>(M, 0, false, true, M->lv(0, M->L[0].cor), M->rhs, M->acf0, M->lv(0, M->L[0].rescor), M->sol,
-                     M->dx, M->dy, M->d_norms, M->d_norms + 1, st);
+    // cor[0] = GSRB^4(sol), residual norm, rhs norm, res[1] = R(residual)  (solve_doit :1319-1346)
+    launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), M->rhs, M->acf0, M->sol, FView{}, M->lv(0, M->L[0].rescor),
+                                        M->lv(1, M->L[1].res), M->d_norms, M->d_norms + 1, st);
+    restrict_residual_if_nodal<CC>(M, 0, st);
     HPS_HIP_CHECK(hipMemcpyAsync(M->h_norms, M->d_norms, 2*sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HPS_HIP_CHECK(hipStreamSynchronize(st));
     const double resnorm0 = norm_value(M->h_norms[0]), rhsnorm0 = norm_value(M->h_norms[1]);

@@ -1,21 +1,25 @@
-// poisson.hip -- transverse Poisson solve Lap(F) = S with homogeneous Dirichlet walls, as a
-// 2-D type-I discrete sine transform (DST-I) built on rocFFT batched 1-D complex-to-real FFTs.
+// poisson.hip -- transverse Poisson solve Lap(F) = S with homogeneous Dirichlet walls as a 2-D type-I
+// discrete sine transform (DST-I).
 //
 // Replaces FFTPoissonSolverDirichletFast (fields/fft_poisson_solver/
 // FFTPoissonSolverDirichletFast.cpp:195-328); eigenvalues / normalisation follow
 // FFTPoissonSolverDirichletDirect.cpp:58-83 (FFTW RODFT00 convention), so CPU goldens apply.
 //
-// DST-I of length n through one real FFT of length N = n+1 (half the odd-extension length):
-// with y the odd 2N-periodic extension of the data (y_m = x_{m-1}, y_0 = y_N = 0) feed the
-// Hermitian spectrum
+// DST-I of length n through one length-N (N = n+1) inverse FFT with Hermitian input: with y the odd
+// 2N-periodic extension of the data (y_m = x_{m-1}, y_0 = y_N = 0) feed
 //        Z_p = (y_{2p+1} - y_{2p-1}) + i y_{2p},      p = 0 .. N/2
-// to an unnormalised C2R transform r = C2R(Z); then for q = 1..n
+// to an unnormalised complex-to-real transform r = C2R(Z); then for q = 1..n
 //        T_{q-1} = 2 sum_m y_m sin(pi m q / N) = (r_{N-q} - r_q)/2 + (r_q + r_{N-q}) / (4 sin(pi q/N)).
-// (Derivation: the even-index samples enter through Im Z, the odd-index samples through the
-// first difference in Re Z, which pulls out the factor 2 sin(pi q/N).)
+// (The even-index samples enter through Im Z, the odd-index samples through the first difference in
+// Re Z, which pulls out the factor 2 sin(pi q/N).)
 //
-// Passes per solve: pre(x) | FFTx | post(x)+transpose+pre(y) | FFTy | post(y)*eig+pre(y) | FFTy |
-// post(y)+transpose+pre(x) | FFTx | post(x) -> slab component.
+// Two back-ends for the length-N transform:
+//  * k_dst_rows<N1,N2>: own LDS-resident FFT for N = N1*N2 with small dense DFT stages.  The
+//    benchmark size nx = 1024 needs N = 1025 = 25*41, which rocFFT only does through Bluestein
+//    (4x slower than a length-1024 transform).  Two real rows are packed into one complex transform
+//    (W = Z_a + i Z_b), pre- and post-processing are fused, so a pass reads and writes each row once.
+//    Pass structure per solve: DSTx | transpose | DSTy * eigenvalues | DSTy | transpose | DSTx.
+//  * rocFFT batched C2R + separate pre/post kernels for every other N.
 #include "common.h"
 
 #include <rocfft/rocfft.h>
@@ -44,7 +48,392 @@ __device__ __forceinline__ double dst_from_r (const double* r, int k, int N, dou
     return 0.5*(b - a) + (a + b)*isin4;
 }
 
-// staging (rows of n reals) -> Z (rows of nh complex)
+// =================================================================================================
+// own transform: N = N1*N2, dense DFT-N1 over the strided index, twiddle, dense DFT-N2
+// =================================================================================================
+constexpr int DST_T = 2;            // complex transforms (= pairs of real rows) per workgroup
+constexpr int DST_MAXPLANES = 4;
+
+struct DstArgs {
+    const double* src[DST_MAXPLANES]; long src_pitch;
+    double* dst[DST_MAXPLANES]; long dst_pitch;
+    const double* scale;            // optional [rows_per_plane][n] factor applied to the output
+    const double2* fa;              // [N1][N1] DFT matrix exp(+2 pi i n1 k1 / N1), row n1
+    const double2* fb;              // [N2][N2] DFT matrix exp(+2 pi i n2 k2 / N2), row n2
+    const double2* tw;              // [N1][N2] twiddles exp(+2 pi i n2 k1 / N), row k1
+    const double* isin4;            // 1/(4 sin(pi (k+1)/N)), k < n
+    int rows_per_plane, nplanes;
+    long long* dbg;                 // optional: shader-clock stamps of workgroup 0 at the phase boundaries
+};
+#define HPS_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+
+typedef __attribute__((address_space(3))) double lds_double;
+
+// complex LDS array access (16-byte aligned pairs -> ds_read_b128 / ds_write_b128)
+__device__ __forceinline__ double2 ldc (const lds_double* c, int i) { return make_double2(c[2*i], c[2*i + 1]); }
+__device__ __forceinline__ void stc (lds_double* c, int i, double re, double im) { c[2*i] = re; c[2*i + 1] = im; }
+
+__device__ __forceinline__ void cmac (double2& acc, const double2 x, const double2 w)
+{
+    acc.x = fma(x.x, w.x, acc.x); acc.x = fma(-x.y, w.y, acc.x);
+    acc.y = fma(x.x, w.y, acc.y); acc.y = fma(x.y, w.x, acc.y);
+}
+
+// coalesced copy of T row pairs into LDS as complex (x_a[j], x_b[j]) at [t][j], j < n = N-1
+template <int T, int N, int NT = 256>
+__device__ __forceinline__ void load_row_pairs (lds_double* cbuf, const DstArgs& a, int row0, int total_rows, int tid)
+{
+    constexpr int n = N - 1;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int ra = row0 + 2*t, rb = ra + 1;
+        const double* pa = nullptr; const double* pb = nullptr;
+        if (ra < total_rows) { const int pl = ra / a.rows_per_plane; pa = a.src[pl] + (long)(ra - pl*a.rows_per_plane)*a.src_pitch; }
+        if (rb < total_rows) { const int pl = rb / a.rows_per_plane; pb = a.src[pl] + (long)(rb - pl*a.rows_per_plane)*a.src_pitch; }
+#pragma unroll 4
+        for (int j = tid; j < n; j += NT) stc(cbuf, t*N + j, pa ? pa[j] : 0.0, pb ? pb[j] : 0.0);
+    }
+}
+
+// Z entries of both rows of a pair -> W[p] and W[N-p] (registers), rows read from LDS
+template <int T, int N, int PP, int NT = 256>
+__device__ __forceinline__ void pre_to_regs (const lds_double* cbuf, int tid, double (&wr)[T][PP], double (&wi)[T][PP],
+                                             double (&vr)[T][PP], double (&vi)[T][PP])
+{
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int m = 0; m < PP; ++m) {
+            const int p = tid + NT*m;
+            wr[t][m] = wi[t][m] = vr[t][m] = vi[t][m] = 0.0;
+            if (p <= N/2) {
+                auto ga = [&] (int j) { return (double)cbuf[2*(t*N + j)]; };
+                auto gb = [&] (int j) { return (double)cbuf[2*(t*N + j) + 1]; };
+                const double are = odd_ext(2*p + 1, N, ga) - odd_ext(2*p - 1, N, ga), aim = odd_ext(2*p, N, ga);
+                const double bre = odd_ext(2*p + 1, N, gb) - odd_ext(2*p - 1, N, gb), bim = odd_ext(2*p, N, gb);
+                wr[t][m] = are - bim; wi[t][m] = aim + bre;      // W[p]
+                vr[t][m] = are + bim; vi[t][m] = bre - aim;      // W[N-p]
+            }
+        }
+    }
+}
+
+// r_a = Re X, r_b = Im X with X[q] stored at [q % N1][q / N1]; T_k from r_{k+1}, r_{N-1-k}; store
+template <int T, int N1, int N2, int NT = 256>
+__device__ __forceinline__ void post_store (const lds_double* cbuf, const DstArgs& a, int row0, int total_rows, int tid)
+{
+    constexpr int N = N1*N2, n = N - 1;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int ra = row0 + 2*t, rb = ra + 1;
+        if (ra >= total_rows) break;
+        const int pla = ra / a.rows_per_plane, plb = rb / a.rows_per_plane;
+        const int ja = ra - pla*a.rows_per_plane, jb = rb - plb*a.rows_per_plane;
+        double* da = a.dst[pla] + (long)ja*a.dst_pitch;
+        double* db = (rb < total_rows) ? a.dst[plb] + (long)jb*a.dst_pitch : nullptr;
+        const double* sa = a.scale ? a.scale + (long)ja*n : nullptr;
+        const double* sb = a.scale ? a.scale + (long)jb*n : nullptr;
+#pragma unroll 2
+        for (int k = tid; k < n; k += NT) {
+            const int q1 = k + 1, q2 = N - 1 - k;
+            const double2 x1 = ldc(cbuf, t*N + (q1 % N1)*N2 + q1/N1);
+            const double2 x2 = ldc(cbuf, t*N + (q2 % N1)*N2 + q2/N1);
+            const double is = a.isin4[k];
+            double ta = 0.5*(x2.x - x1.x) + (x1.x + x2.x)*is;
+            double tb = 0.5*(x2.y - x1.y) + (x1.y + x2.y)*is;
+            if (sa) { ta *= sa[k]; if (db) tb *= sb[k]; }
+            da[k] = ta;
+            if (db) db[k] = tb;
+        }
+    }
+}
+
+template <int N1, int N2>
+__global__ __launch_bounds__(256)
+void k_dst_rows (DstArgs a)
+{
+    constexpr int N = N1*N2, n = N - 1, T = DST_T;
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    lds_double* cbuf = (lds_double*)lds_raw;          // [T][N] complex working set
+    lds_double* fa = cbuf + 2*T*N;                    // [N1][N1] first-stage DFT matrix
+    lds_double* fb = fa + 2*N1*N1;                    // [N2][N2] second-stage DFT matrix
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int total_rows = a.rows_per_plane*a.nplanes;
+    const int row0 = blockIdx.x*2*T;
+
+    HPS_STAMP(0);
+    for (int k = tid; k < N1*N1; k += 256) { const double2 w = a.fa[k]; stc(fa, k, w.x, w.y); }
+    for (int k = tid; k < N2*N2; k += 256) { const double2 w = a.fb[k]; stc(fb, k, w.x, w.y); }
+
+    // ---- pre: W = Z_a + i Z_b with the Hermitian halves unfolded ------------------------------
+    // (1) coalesced copy of the row pairs into LDS as (x_a[j], x_b[j]); (2) every thread forms its
+    // Z entries in registers; (3) W overwrites the rows.
+    load_row_pairs<T, N>(cbuf, a, row0, total_rows, tid);
+    __syncthreads();
+    HPS_STAMP(1);
+    {
+        constexpr int PP = (N/2 + 1 + 255)/256;
+        double wr[T][PP], wi[T][PP], vr[T][PP], vi[T][PP];
+        pre_to_regs<T, N, PP>(cbuf, tid, wr, wi, vr, vi);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int m = 0; m < PP; ++m) {
+                const int p = tid + 256*m;
+                if (p <= N/2) {
+                    stc(cbuf, t*N + p, wr[t][m], wi[t][m]);
+                    if (p > 0 && 2*p != N) stc(cbuf, t*N + N - p, vr[t][m], vi[t][m]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    HPS_STAMP(2);
+    // ---- stage A: for every (t, n2) column the DFT over n1, then the twiddle w_N^(n2 k1) --------
+    {
+        constexpr int ITEMS = T*N2;
+        constexpr int NW = (ITEMS + 63)/64;           // waves that cover all columns once
+        constexpr int NG = (4/NW) > 0 ? (4/NW) : 1;   // groups of waves, each owning a block of k1
+        constexpr int KB = (N1 + NG - 1)/NG;
+        static_assert(NW <= 4, "too many columns for one workgroup");
+        const int g = wave / NW;
+        const int item = (wave % NW)*64 + lane;
+        const bool active = (g < NG) && (item < ITEMS);
+        const int t = item / N2, n2 = item - t*N2;
+        const int k10 = g*KB;
+        double2 acc[KB];
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) acc[kk] = make_double2(0.0, 0.0);
+        if (active) {
+            // the matrix row of n1 is contiguous in k1: constant LDS offsets, no index arithmetic
+            for (int n1 = 0; n1 < N1; ++n1) {
+                const double2 x = ldc(cbuf, t*N + n1*N2 + n2);
+                const lds_double* frow = fa + 2*(n1*N1 + k10);
+#pragma unroll
+                for (int kk = 0; kk < KB; ++kk)
+                    if (k10 + kk < N1) cmac(acc[kk], x, ldc(frow, kk));
+            }
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                const int k1 = k10 + kk;
+                if (k1 < N1) {
+                    const double2 w = a.tw[k1*N2 + n2];
+                    stc(cbuf, t*N + k1*N2 + n2, acc[kk].x*w.x - acc[kk].y*w.y, acc[kk].x*w.y + acc[kk].y*w.x);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    HPS_STAMP(3);
+    // ---- stage B: for every (t, k1) row the DFT over n2; result X[k1 + N1 k2] stays at [k1][k2] ----
+    {
+        constexpr int ITEMS = T*N1;
+        constexpr int NW = (ITEMS + 63)/64;
+        constexpr int NG = (4/NW) > 0 ? (4/NW) : 1;
+        constexpr int KB = (N2 + NG - 1)/NG;
+        static_assert(NW <= 4, "too many rows for one workgroup");
+        const int g = wave / NW;
+        const int item = (wave % NW)*64 + lane;
+        const bool active = (g < NG) && (item < ITEMS);
+        const int t = item / N1, k1 = item - t*N1;
+        const int k20 = g*KB;
+        double2 acc[KB];
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) acc[kk] = make_double2(0.0, 0.0);
+        if (active) {
+            for (int n2 = 0; n2 < N2; ++n2) {
+                const double2 x = ldc(cbuf, t*N + k1*N2 + n2);
+                const lds_double* frow = fb + 2*(n2*N2 + k20);
+#pragma unroll
+                for (int kk = 0; kk < KB; ++kk)
+                    if (k20 + kk < N2) cmac(acc[kk], x, ldc(frow, kk));
+            }
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) if (k20 + kk < N2) stc(cbuf, t*N + k1*N2 + k20 + kk, acc[kk].x, acc[kk].y);
+        }
+        __syncthreads();
+    }
+
+    HPS_STAMP(4);
+    // ---- post: r_a = Re X, r_b = Im X; T_k from r_{k+1} and r_{N-1-k}; optional scaling; store ----
+    post_store<T, N1, N2>(cbuf, a, row0, total_rows, tid);
+    HPS_STAMP(5);
+}
+
+
+// ---- odd factors: conjugate-symmetric small DFTs -------------------------------------------------
+// For odd M and H = (M-1)/2, with s_n = x_n + x_{M-n}, d_n = x_n - x_{M-n}:
+//   X_0 = x_0 + sum_n s_n,   X_k = x_0 + P_k + i Q_k,   X_{M-k} = x_0 + P_k - i Q_k   (k = 1..H)
+//   P_k = sum_{n=1..H} s_n cos(2 pi n k / M),   Q_k = sum_{n=1..H} d_n sin(2 pi n k / M)
+// i.e. M^2 real FMAs per DFT instead of 4 M^2, with one (cos, sin) table read per 4 FMAs.
+constexpr int DSTS_T = 3;
+constexpr int DSTS_NT = 512;        // threads per workgroup of the symmetric kernel
+
+template <int M, int STRIDE, int KSTRIDE, int ITEMS_PER_T, int ITEM_STRIDE, bool TWIDDLE, int T, int NWAVES>
+__device__ __forceinline__ void sym_stage (lds_double* cbuf, const lds_double* cs, const double2* __restrict__ tw, int wave, int lane)
+{
+    // one item = one DFT of size M over elements base + n*STRIDE; results go to base + k*KSTRIDE
+    constexpr int H = (M - 1)/2;
+    constexpr int ITEMS = T*ITEMS_PER_T;
+    constexpr int NW = (ITEMS + 63)/64;
+    constexpr int NG0 = (NWAVES/NW) > 0 ? (NWAVES/NW) : 1;
+    constexpr int NG = NG0 > H ? H : NG0;
+    constexpr int KB = (H + NG - 1)/NG;
+    constexpr int NT = M*ITEMS_PER_T;                 // complex elements per transform
+    static_assert(NW <= NWAVES, "too many items for one workgroup");
+    const int g = wave / NW;
+    const int item = (wave % NW)*64 + lane;
+    const bool active = (g < NG) && (item < ITEMS);
+    const int t = item / ITEMS_PER_T, r = item - t*ITEMS_PER_T;
+    const int base = t*NT + r*ITEM_STRIDE;
+    const int k0 = 1 + g*KB;                          // first k of this group's block
+    double pr[KB], pim[KB], qr[KB], qi[KB];
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) pr[kk] = pim[kk] = qr[kk] = qi[kk] = 0.0;
+    double2 x0 = make_double2(0.0, 0.0), ssum = make_double2(0.0, 0.0);
+    if (active) {
+        x0 = ldc(cbuf, base);
+        for (int n = 1; n <= H; ++n) {
+            const double2 xa = ldc(cbuf, base + n*STRIDE), xb = ldc(cbuf, base + (M - n)*STRIDE);
+            const double sr = xa.x + xb.x, si = xa.y + xb.y, dr = xa.x - xb.x, di = xa.y - xb.y;
+            ssum.x += sr; ssum.y += si;
+            const lds_double* row = cs + 2*((n - 1)*H + (k0 - 1));
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                if (k0 + kk <= H) {
+                    const double2 c = ldc(row, kk);       // (cos, sin)(2 pi n k / M)
+                    pr[kk] = fma(sr, c.x, pr[kk]); pim[kk] = fma(si, c.x, pim[kk]);
+                    qr[kk] = fma(dr, c.y, qr[kk]); qi[kk] = fma(di, c.y, qi[kk]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (active) {
+        auto put = [&] (int k, double re, double im) {
+            if (TWIDDLE) { const double2 w = tw[k*ITEMS_PER_T + r]; const double a = re*w.x - im*w.y; im = re*w.y + im*w.x; re = a; }
+            stc(cbuf, base + k*KSTRIDE, re, im);
+        };
+        if (g == 0) stc(cbuf, base, x0.x + ssum.x, x0.y + ssum.y);      // k = 0, twiddle 1
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+            const int k = k0 + kk;
+            if (k <= H) {
+                const double ar = x0.x + pr[kk], ai = x0.y + pim[kk];
+                put(k, ar - qi[kk], ai + qr[kk]);               // x0 + P + iQ
+                put(M - k, ar + qi[kk], ai - qr[kk]);           // x0 + P - iQ
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int N1, int N2>
+__global__ __launch_bounds__(DSTS_NT)
+void k_dst_rows_sym (DstArgs a)
+{
+    static_assert(N1 % 2 == 1 && N2 % 2 == 1, "symmetric kernel needs odd factors");
+    constexpr int N = N1*N2, T = DSTS_T, NT = DSTS_NT;
+    constexpr int H1 = (N1 - 1)/2, H2 = (N2 - 1)/2;
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    lds_double* cbuf = (lds_double*)lds_raw;          // [T][N] complex working set
+    lds_double* csa = cbuf + 2*T*N;                   // [H1][H1] (cos, sin)(2 pi n k / N1)
+    lds_double* csb = csa + 2*H1*H1;                  // [H2][H2] (cos, sin)(2 pi n k / N2)
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int total_rows = a.rows_per_plane*a.nplanes;
+    const int row0 = blockIdx.x*2*T;
+
+    HPS_STAMP(0);
+    for (int k = tid; k < H1*H1; k += NT) { const double2 w = a.fa[k]; stc(csa, k, w.x, w.y); }
+    for (int k = tid; k < H2*H2; k += NT) { const double2 w = a.fb[k]; stc(csb, k, w.x, w.y); }
+    load_row_pairs<T, N, NT>(cbuf, a, row0, total_rows, tid);
+    __syncthreads();
+    HPS_STAMP(1);
+    {
+        constexpr int PP = (N/2 + NT)/NT;
+        double wr[T][PP], wi[T][PP], vr[T][PP], vi[T][PP];
+        pre_to_regs<T, N, PP, NT>(cbuf, tid, wr, wi, vr, vi);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int m = 0; m < PP; ++m) {
+                const int p = tid + NT*m;
+                if (p <= N/2) {
+                    stc(cbuf, t*N + p, wr[t][m], wi[t][m]);
+                    if (p > 0) stc(cbuf, t*N + N - p, vr[t][m], vi[t][m]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    HPS_STAMP(2);
+    // stage A: DFT-N1 over n1 (stride N2) of column n2, twiddle w_N^(n2 k1), result at [k1][n2]
+    sym_stage<N1, N2, N2, N2, 1, true, T, NT/64>(cbuf, csa, a.tw, wave, lane);
+    HPS_STAMP(3);
+    // stage B: DFT-N2 over n2 (stride 1) of row k1, result X[k1 + N1 k2] at [k1][k2]
+    sym_stage<N2, 1, 1, N1, N2, false, T, NT/64>(cbuf, csb, nullptr, wave, lane);
+    HPS_STAMP(4);
+    post_store<T, N1, N2, NT>(cbuf, a, row0, total_rows, tid);
+    HPS_STAMP(5);
+}
+
+// plane-wise transpose: dst[k][j] = src[j][k], src has `rows` rows of `cols` entries
+__global__ __launch_bounds__(256)
+void k_transpose (const double* __restrict__ src, double* __restrict__ dst, int rows, int cols, long plane_stride)
+{
+    __shared__ double tile[32][33];
+    const double* s = src + blockIdx.z*plane_stride;
+    double* d = dst + blockIdx.z*plane_stride;
+    const int c0 = blockIdx.x*32, r0 = blockIdx.y*32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int rr = ty; rr < 32; rr += 8)
+        if (r0 + rr < rows && c0 + tx < cols) tile[rr][tx] = s[(long)(r0 + rr)*cols + c0 + tx];
+    __syncthreads();
+    for (int cc = ty; cc < 32; cc += 8)
+        if (c0 + cc < cols && r0 + tx < rows) d[(long)(c0 + cc)*rows + r0 + tx] = tile[tx][cc];
+}
+
+typedef void (*dst_kernel_t)(DstArgs);
+struct DstImpl { int N, N1, N2; dst_kernel_t kernel; bool sym; int T; int nt; };
+
+#define HPS_DST_IMPL(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows<N1, N2>, false, DST_T, 256}
+#define HPS_DST_SYM(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows_sym<N1, N2>, true, DSTS_T, DSTS_NT}
+static const DstImpl g_dst_impls[] = {
+    HPS_DST_SYM(25, 41),    // nx = 1024
+    HPS_DST_SYM(19, 27),    // 512
+    HPS_DST_SYM(3, 43),     // 128
+    HPS_DST_SYM(5, 13),     // 64
+    HPS_DST_SYM(3, 11),     // 32
+    HPS_DST_IMPL(32, 32),   // 1023
+    HPS_DST_IMPL(16, 32),   // 511
+    HPS_DST_IMPL(16, 16),   // 255
+    HPS_DST_IMPL(8, 16),    // 127
+    HPS_DST_IMPL(8, 8),     // 63
+    HPS_DST_SYM(9, 11),     // 98
+    HPS_DST_SYM(7, 11),     // 76
+};
+
+static const DstImpl* find_dst_impl (int N)
+{
+    for (const auto& d : g_dst_impls) if (d.N == N) return &d;
+    return nullptr;
+}
+
+// =================================================================================================
+// rocFFT back-end kernels (any N)
+// =================================================================================================
 __global__ __launch_bounds__(256)
 void k_pre_rows (const double* __restrict__ src, long src_pitch, double2* __restrict__ z, int n, int nh, int nrows)
 {
@@ -59,9 +448,6 @@ void k_pre_rows (const double* __restrict__ src, long src_pitch, double2* __rest
     z[(long)row*nh + p] = make_double2(re, im);
 }
 
-// r (rows of N reals, one row per batch entry) -> T^transposed -> Z of the other direction.
-// in : nrows_in rows (index j), each with n_in DST outputs (index k)
-// out: n_in rows (index k), each nh_out complex, transform length N_out = nrows_in + 1
 constexpr int TP_K = 32;      // k-extent of a tile
 constexpr int TP_P = 16;      // p-extent of a tile -> needs 2*TP_P + 2 values of j
 constexpr int TP_J = 2*TP_P + 2;
@@ -76,10 +462,9 @@ void k_post_transpose_pre (const double* __restrict__ r, int n_in, int nrows_in,
     const int k0 = blockIdx.x*TP_K;
     const int p0 = blockIdx.y*TP_P;
     const int j0 = 2*p0 - 2;
-
-    {   // load + post-process: lanes run along k (contiguous in r)
+    {
         const int kk = threadIdx.x % TP_K;
-        const int jr = threadIdx.x / TP_K;          // 0..7
+        const int jr = threadIdx.x / TP_K;
         const int k = k0 + kk;
         for (int jj = jr; jj < TP_J; jj += 256/TP_K) {
             const int j = j0 + jj;
@@ -89,9 +474,9 @@ void k_post_transpose_pre (const double* __restrict__ r, int n_in, int nrows_in,
         }
     }
     __syncthreads();
-    {   // build Z: lanes run along p (contiguous in z)
+    {
         const int pp = threadIdx.x % TP_P;
-        const int kr = threadIdx.x / TP_P;          // 0..15
+        const int kr = threadIdx.x / TP_P;
         const int p = p0 + pp;
         for (int kk = kr; kk < TP_K; kk += 256/TP_P) {
             const int k = k0 + kk;
@@ -105,7 +490,6 @@ void k_post_transpose_pre (const double* __restrict__ r, int n_in, int nrows_in,
     }
 }
 
-// same orientation: T = post(r) * eig, then pre for the inverse transform along the same axis
 __global__ __launch_bounds__(256)
 void k_post_mult_pre (const double* __restrict__ r, int n, int nrows, const double* __restrict__ isin4,
                       const double* __restrict__ eig, double2* __restrict__ z, int nh)
@@ -122,7 +506,6 @@ void k_post_mult_pre (const double* __restrict__ r, int n, int nrows, const doub
     z[(long)row*nh + p] = make_double2(re, im);
 }
 
-// final post-processing straight into the slab component
 __global__ __launch_bounds__(256)
 void k_post_to_slab (const double* __restrict__ r, int n, int nrows, const double* __restrict__ isin4,
                      double* __restrict__ dst, long dst_pitch)
@@ -133,21 +516,33 @@ void k_post_to_slab (const double* __restrict__ r, int n, int nrows, const doubl
     dst[(long)row*dst_pitch + k] = dst_from_r(r + (long)row*(n + 1), k, n + 1, isin4[k]);
 }
 
+// =================================================================================================
 struct Poisson {
     int nx = 0, ny = 0;
+    // own-transform back-end
+    dst_kernel_t kx = nullptr, ky = nullptr;
+    double2 *tab_x = nullptr, *tab_y = nullptr;        // each: [fa | fb | tw] concatenated
+    const double2 *fa_x = nullptr, *fb_x = nullptr, *tw_x = nullptr, *fa_y = nullptr, *fb_y = nullptr, *tw_y = nullptr;
+    double *buf_a = nullptr, *buf_b = nullptr;         // [DST_MAXPLANES][nx*ny] ping-pong
+    long long* dbg = nullptr;
+    size_t lds_x = 0, lds_y = 0; int tx = DST_T, ty = DST_T, ntx = 256, nty = 256;     // LDS bytes, row pairs and threads per workgroup
+    // rocFFT back-end
     rocfft_plan plan_x = nullptr, plan_y = nullptr;
     rocfft_execution_info info = nullptr;
     void* work = nullptr; size_t work_bytes = 0;
     double2* zbuf = nullptr; double* rbuf = nullptr;
-    double* eig = nullptr; double* isin_x = nullptr; double* isin_y = nullptr;
     hipStream_t bound_stream = nullptr; bool stream_bound = false;
+    // shared
+    double* eig = nullptr; double* isin_x = nullptr; double* isin_y = nullptr;
 
+    bool own () const { return kx && ky; }
     ~Poisson () {
         if (plan_x) rocfft_plan_destroy(plan_x);
         if (plan_y) rocfft_plan_destroy(plan_y);
         if (info) rocfft_execution_info_destroy(info);
         (void)hipFree(work); (void)hipFree(zbuf); (void)hipFree(rbuf); (void)hipFree(eig);
-        (void)hipFree(isin_x); (void)hipFree(isin_y);
+        (void)hipFree(isin_x); (void)hipFree(isin_y); (void)hipFree(tab_x); (void)hipFree(tab_y);
+        (void)hipFree(buf_a); (void)hipFree(buf_b);
     }
 };
 
@@ -164,28 +559,68 @@ static int make_plan (rocfft_plan* plan, int N, int batch)
     return HPS_OK;
 }
 
-int poisson_create (int nx, int ny, double dx, double dy, Poisson** out)
+// DFT matrices of both stages and the inter-stage twiddles, concatenated [fa | fb | tw].
+// sym: only the (cos, sin) of n, k = 1..(M-1)/2 are stored.
+static int upload_tables (int N1, int N2, bool sym, double2** out, size_t* na, size_t* nb)
 {
-    if (!g_rocfft_setup) { rocfft_setup(); g_rocfft_setup = true; }
+    const int N = N1*N2;
+    const int a0 = sym ? 1 : 0, a1 = sym ? (N1 - 1)/2 : N1 - 1, b1 = sym ? (N2 - 1)/2 : N2 - 1;
+    *na = (size_t)(a1 - a0 + 1)*(a1 - a0 + 1); *nb = (size_t)(b1 - a0 + 1)*(b1 - a0 + 1);
+    std::vector<double2> h(*na + *nb + N);
+    const long double pi2 = 6.283185307179586476925286766559L;
+    auto root = [&] (long num, long den) { const long double ang = pi2*(num % den)/den;
+                                           return make_double2((double)cosl(ang), (double)sinl(ang)); };
+    size_t o = 0;
+    for (int n1 = a0; n1 <= a1; ++n1) for (int k1 = a0; k1 <= a1; ++k1) h[o++] = root((long)n1*k1, N1);
+    for (int n2 = a0; n2 <= b1; ++n2) for (int k2 = a0; k2 <= b1; ++k2) h[o++] = root((long)n2*k2, N2);
+    for (int k1 = 0; k1 < N1; ++k1) for (int n2 = 0; n2 < N2; ++n2) h[o++] = root((long)n2*k1, N);
+    HPS_HIP_CHECK(hipMalloc(out, h.size()*sizeof(double2)));
+    HPS_HIP_CHECK(hipMemcpy(*out, h.data(), h.size()*sizeof(double2), hipMemcpyHostToDevice));
+    return HPS_OK;
+}
+
+int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisson** out)
+{
     Poisson* P = new Poisson;
     P->nx = nx; P->ny = ny;
     const int Nx = nx + 1, Ny = ny + 1;
-    const int nhx = Nx/2 + 1, nhy = Ny/2 + 1;
-    int e;
-    if ((e = make_plan(&P->plan_x, Nx, ny)) || (e = make_plan(&P->plan_y, Ny, nx))) { delete P; return e; }
-    size_t wx = 0, wy = 0;
-    rocfft_plan_get_work_buffer_size(P->plan_x, &wx);
-    rocfft_plan_get_work_buffer_size(P->plan_y, &wy);
-    P->work_bytes = std::max(wx, wy);
-    rocfft_execution_info_create(&P->info);
-    if (P->work_bytes) {
-        HPS_HIP_CHECK(hipMalloc(&P->work, P->work_bytes));
-        rocfft_execution_info_set_work_buffer(P->info, P->work, P->work_bytes);
+    const DstImpl* ix = allow_own ? find_dst_impl(Nx) : nullptr;
+    const DstImpl* iy = allow_own ? find_dst_impl(Ny) : nullptr;
+    if (ix && iy) {
+        P->kx = ix->kernel; P->ky = iy->kernel;
+        int e;
+        size_t nax, nbx, nay, nby;
+        if ((e = upload_tables(ix->N1, ix->N2, ix->sym, &P->tab_x, &nax, &nbx)) ||
+            (e = upload_tables(iy->N1, iy->N2, iy->sym, &P->tab_y, &nay, &nby))) { delete P; return e; }
+        P->fa_x = P->tab_x; P->fb_x = P->fa_x + nax; P->tw_x = P->fb_x + nbx;
+        P->fa_y = P->tab_y; P->fb_y = P->fa_y + nay; P->tw_y = P->fb_y + nby;
+        P->tx = ix->T; P->ty = iy->T; P->ntx = ix->nt; P->nty = iy->nt;
+        P->lds_x = ((size_t)ix->T*Nx + nax + nbx)*sizeof(double2);
+        P->lds_y = ((size_t)iy->T*Ny + nay + nby)*sizeof(double2);
+        if (P->lds_x > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->kx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_x));
+        if (P->lds_y > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->ky, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_y));
+        HPS_HIP_CHECK(hipMalloc(&P->buf_a, (size_t)DST_MAXPLANES*nx*ny*sizeof(double)));
+        HPS_HIP_CHECK(hipMalloc(&P->buf_b, (size_t)DST_MAXPLANES*nx*ny*sizeof(double)));
+    } else {
+        P->kx = P->ky = nullptr;
+        if (!g_rocfft_setup) { rocfft_setup(); g_rocfft_setup = true; }
+        const int nhx = Nx/2 + 1, nhy = Ny/2 + 1;
+        int e;
+        if ((e = make_plan(&P->plan_x, Nx, ny)) || (e = make_plan(&P->plan_y, Ny, nx))) { delete P; return e; }
+        size_t wx = 0, wy = 0;
+        rocfft_plan_get_work_buffer_size(P->plan_x, &wx);
+        rocfft_plan_get_work_buffer_size(P->plan_y, &wy);
+        P->work_bytes = std::max(wx, wy);
+        rocfft_execution_info_create(&P->info);
+        if (P->work_bytes) {
+            HPS_HIP_CHECK(hipMalloc(&P->work, P->work_bytes));
+            rocfft_execution_info_set_work_buffer(P->info, P->work, P->work_bytes);
+        }
+        const size_t zc = std::max((size_t)nhx*ny, (size_t)nhy*nx);
+        const size_t rc = std::max((size_t)Nx*ny, (size_t)Ny*nx);
+        HPS_HIP_CHECK(hipMalloc(&P->zbuf, zc*sizeof(double2)));
+        HPS_HIP_CHECK(hipMalloc(&P->rbuf, rc*sizeof(double)));
     }
-    const size_t zc = std::max((size_t)nhx*ny, (size_t)nhy*nx);
-    const size_t rc = std::max((size_t)Nx*ny, (size_t)Ny*nx);
-    HPS_HIP_CHECK(hipMalloc(&P->zbuf, zc*sizeof(double2)));
-    HPS_HIP_CHECK(hipMalloc(&P->rbuf, rc*sizeof(double)));
     HPS_HIP_CHECK(hipMalloc(&P->eig, (size_t)nx*ny*sizeof(double)));
     HPS_HIP_CHECK(hipMalloc(&P->isin_x, nx*sizeof(double)));
     HPS_HIP_CHECK(hipMalloc(&P->isin_y, ny*sizeof(double)));
@@ -222,8 +657,7 @@ static int run_fft (Poisson* P, rocfft_plan plan)
     return HPS_OK;
 }
 
-// src: nx*ny source with row pitch src_pitch; dst: pointer to cell (0,0) of the target plane
-int poisson_solve (Poisson* P, const double* src, long src_pitch, double* dst, long dst_pitch, hipStream_t st)
+static int solve_rocfft (Poisson* P, const double* src, long src_pitch, double* dst, long dst_pitch, hipStream_t st)
 {
     const int nx = P->nx, ny = P->ny;
     const int Nx = nx + 1, Ny = ny + 1;
@@ -250,6 +684,48 @@ int poisson_solve (Poisson* P, const double* src, long src_pitch, double* dst, l
     return HPS_OK;
 }
 
+// nb independent solves in one batch: src[b] = nx*ny source with row pitch src_pitch,
+// dst[b] = pointer to cell (0,0) of the target plane with row pitch dst_pitch
+int poisson_solve_batch (Poisson* P, int nb, const double* const* src, long src_pitch, double* const* dst, long dst_pitch,
+                         hipStream_t st)
+{
+    if (!P->own()) {
+        for (int b = 0; b < nb; ++b) if (int e = solve_rocfft(P, src[b], src_pitch, dst[b], dst_pitch, st)) return e;
+        return HPS_OK;
+    }
+    if (nb > DST_MAXPLANES) { set_error("poisson_solve_batch: too many planes"); return HPS_ERR_ARG; }
+    const int nx = P->nx, ny = P->ny;
+    const long plane = (long)nx*ny;
+    auto rows_grid = [] (int rows, int T) { return dim3(ceil_div(rows, 2*T)); };
+    DstArgs a{};
+    a.dbg = P->dbg;
+    // 1: DST along x of the sources -> A
+    for (int b = 0; b < nb; ++b) { a.src[b] = src[b]; a.dst[b] = P->buf_a + b*plane; }
+    a.src_pitch = src_pitch; a.dst_pitch = nx; a.scale = nullptr; a.fa = P->fa_x; a.fb = P->fb_x; a.tw = P->tw_x; a.isin4 = P->isin_x;
+    a.rows_per_plane = ny; a.nplanes = nb;
+    hipLaunchKernelGGL(P->kx, rows_grid(ny*nb, P->tx), dim3(P->ntx), P->lds_x, st, a);
+    // 2: transpose -> B[k][j]
+    hipLaunchKernelGGL(k_transpose, dim3(ceil_div(nx, 32), ceil_div(ny, 32), nb), dim3(256), 0, st, P->buf_a, P->buf_b, ny, nx, plane);
+    // 3: DST along y, times the inverse eigenvalues -> A
+    for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_b + b*plane; a.dst[b] = P->buf_a + b*plane; }
+    a.src_pitch = ny; a.dst_pitch = ny; a.scale = P->eig; a.fa = P->fa_y; a.fb = P->fb_y; a.tw = P->tw_y; a.isin4 = P->isin_y;
+    a.rows_per_plane = nx;
+    hipLaunchKernelGGL(P->ky, rows_grid(nx*nb, P->ty), dim3(P->nty), P->lds_y, st, a);
+    // 4: DST along y again -> B
+    for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_a + b*plane; a.dst[b] = P->buf_b + b*plane; }
+    a.scale = nullptr;
+    hipLaunchKernelGGL(P->ky, rows_grid(nx*nb, P->ty), dim3(P->nty), P->lds_y, st, a);
+    // 5: transpose back -> A[j][k]
+    hipLaunchKernelGGL(k_transpose, dim3(ceil_div(ny, 32), ceil_div(nx, 32), nb), dim3(256), 0, st, P->buf_b, P->buf_a, nx, ny, plane);
+    // 6: DST along x -> destination planes
+    for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_a + b*plane; a.dst[b] = dst[b]; }
+    a.src_pitch = nx; a.dst_pitch = dst_pitch; a.fa = P->fa_x; a.fb = P->fb_x; a.tw = P->tw_x; a.isin4 = P->isin_x;
+    a.rows_per_plane = ny;
+    hipLaunchKernelGGL(P->kx, rows_grid(ny*nb, P->tx), dim3(P->ntx), P->lds_x, st, a);
+    HPS_HIP_CHECK(hipGetLastError());
+    return HPS_OK;
+}
+
 } // namespace hps
 
 using namespace hps;
@@ -258,9 +734,16 @@ extern "C" int hps_poisson_create (int nx, int ny, double dx, double dy, void** 
 {
     HPS_REQUIRE(nx >= 2 && ny >= 2 && handle, "hps_poisson_create: bad size");
     Poisson* P = nullptr;
-    if (int e = poisson_create(nx, ny, dx, dy, &P)) return e;
+    const char* env = getenv("HPS_POISSON_BACKEND");     // "rocfft" forces the library back-end
+    const bool allow_own = !(env && std::string(env) == "rocfft");
+    if (int e = poisson_create(nx, ny, dx, dy, allow_own, &P)) return e;
     *handle = P;
     return HPS_OK;
+}
+
+static double* slab_cell00 (const hps_slab& s, int comp)
+{
+    return s.p + (long)comp*s.nstride + s.ng + (long)s.ng*s.jstride;
 }
 
 extern "C" int hps_poisson_solve (void* handle, const double* staging, hps_slab dst, int dst_comp, hps_stream stream)
@@ -269,8 +752,34 @@ extern "C" int hps_poisson_solve (void* handle, const double* staging, hps_slab 
     Poisson* P = static_cast<Poisson*>(handle);
     HPS_REQUIRE(dst.nx == P->nx && dst.ny == P->ny, "hps_poisson_solve: slab size does not match the solver");
     HPS_REQUIRE(dst_comp >= 0 && dst_comp < dst.ncomp, "hps_poisson_solve: bad component");
-    double* d = dst.p + (long)dst_comp*dst.nstride + dst.ng + (long)dst.ng*dst.jstride;
-    return poisson_solve(P, staging, P->nx, d, dst.jstride, (hipStream_t)stream);
+    const double* s[1] = {staging};
+    double* d[1] = {slab_cell00(dst, dst_comp)};
+    return poisson_solve_batch(P, 1, s, P->nx, d, dst.jstride, (hipStream_t)stream);
+}
+
+extern "C" int hps_poisson_solve_batch (void* handle, int nbatch, const double* staging, hps_slab dst, const int* dst_comps,
+                                        hps_stream stream)
+{
+    HPS_REQUIRE(handle && staging && dst.p && dst_comps, "hps_poisson_solve_batch: null argument");
+    HPS_REQUIRE(nbatch >= 1 && nbatch <= DST_MAXPLANES, "hps_poisson_solve_batch: 1..4 solves per batch");
+    Poisson* P = static_cast<Poisson*>(handle);
+    HPS_REQUIRE(dst.nx == P->nx && dst.ny == P->ny, "hps_poisson_solve_batch: slab size does not match the solver");
+    const double* s[DST_MAXPLANES]; double* d[DST_MAXPLANES];
+    for (int b = 0; b < nbatch; ++b) {
+        HPS_REQUIRE(dst_comps[b] >= 0 && dst_comps[b] < dst.ncomp, "hps_poisson_solve_batch: bad component");
+        s[b] = staging + (long)b*P->nx*P->ny;
+        d[b] = slab_cell00(dst, dst_comps[b]);
+    }
+    return poisson_solve_batch(P, nbatch, s, P->nx, d, dst.jstride, (hipStream_t)stream);
+}
+
+extern "C" int hps_poisson_debug_stamps (void* handle, long long* stamps6_host)
+{
+    Poisson* P = static_cast<Poisson*>(handle);
+    if (!P->dbg) { HPS_HIP_CHECK(hipMalloc(&P->dbg, 8*sizeof(long long))); HPS_HIP_CHECK(hipMemset(P->dbg, 0, 8*sizeof(long long))); return HPS_OK; }
+    HPS_HIP_CHECK(hipDeviceSynchronize());
+    HPS_HIP_CHECK(hipMemcpy(stamps6_host, P->dbg, 6*sizeof(long long), hipMemcpyDeviceToHost));
+    return HPS_OK;
 }
 
 extern "C" int hps_poisson_destroy (void* handle)

@@ -125,6 +125,11 @@ int hps_advance_plasma_tiled (hps_slab slab, hps_plasma plasma, hps_geom geom, c
 int hps_poisson_create (int nx, int ny, double dx, double dy, void** handle);
 int hps_poisson_solve (void* handle, const double* staging, hps_slab dst, int dst_comp,
                        hps_stream stream);
+/* nbatch (<= 4) independent solves in one go: sources stacked in `staging` as nbatch planes of
+ * nx*ny, solutions into components dst_comps[b].  The three solves of a slice (Psi, Ez, Bz) share
+ * their launches this way. */
+int hps_poisson_solve_batch (void* handle, int nbatch, const double* staging, hps_slab dst,
+                             const int* dst_comps, hps_stream stream);
 int hps_poisson_destroy (void* handle);
 
 /* hpmg::MultiGrid, system type 1 (mg_solver/HpMultiGrid.H:48,64-66; .cpp:1169-1190,1307-1427):

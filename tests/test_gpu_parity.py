@@ -112,7 +112,8 @@ def test_advance_plasma(api, oracle, order, bc):
     assert np.array_equal(greal[2][~live], r2[2][~live])
 
 
-@pytest.mark.parametrize("nx,ny", [(64, 64), (32, 48), (63, 63), (127, 65)])
+@pytest.mark.parametrize("nx,ny", [(64, 64), (32, 48), (63, 63), (127, 65), (32, 64), (128, 32), (512, 512),
+                                   (1024, 1024), (1023, 1023)])
 def test_poisson(api, oracle, nx, ny):
     import torch
     rng = np.random.default_rng(nx * 1000 + ny)
@@ -129,6 +130,27 @@ def test_poisson(api, oracle, nx, ny):
     guards = out[1].copy()
     guards[G2:-G2, G2:-G2] = 0
     assert np.all(guards == 0)                          # guard cells are never written
+
+
+def test_poisson_batch(api, oracle):
+    """Three stacked solves (Psi, Ez, Bz of one slice) through the batched entry point."""
+    import ctypes as C
+    import torch
+    from hipace_amd import _lib
+    nx = ny = 64
+    rng = np.random.default_rng(3)
+    rhs = rng.standard_normal((3, ny, nx))
+    dx = dy = 0.25
+    ps = api.FFTPoissonSolver(nx, ny, dx, dy)
+    st = torch.as_tensor(rhs).cuda().contiguous()
+    f = api.Fields(nx, ny, G2, 6)
+    comps = (C.c_int * 3)(4, 1, 2)
+    _lib.check(_lib.lib().hps_poisson_solve_batch(ps._h, 3, C.c_void_p(st.data_ptr()), f.struct(), comps, None))
+    torch.cuda.synchronize()
+    out = f.numpy()
+    for b, c in enumerate((4, 1, 2)):
+        assert rel_err(out[c, G2:-G2, G2:-G2], oracle.poisson_solve(rhs[b], dx, dy)) < 1e-12
+    assert np.all(out[[0, 3, 5]] == 0)
 
 
 @pytest.mark.parametrize("nx,ny", [(64, 64), (32, 32), (96, 48), (63, 63), (31, 63)])
