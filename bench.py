@@ -101,7 +101,17 @@ def main():
     eng.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
-    run_slices(args.steps)
+    if world == 1:
+        run_slices(args.steps)
+    else:
+        # ring pipeline over time steps: every rank sweeps `steps` slices of its own step(s); the beam
+        # slices travel rank -> rank+1 through RCCL (hipace_amd/pipeline.py)
+        from hipace_amd.pipeline import run_pipeline
+        per_step = min(args.steps, nz)
+        steps_per_rank = max(1, args.steps // nz)
+        solved = run_pipeline(eng, rank, world, world * steps_per_rank, torch.device("cuda", local),
+                              slices_per_step=per_step)
+        args.steps = solved
     barrier()
     dt = time.perf_counter() - t0
     phases, nprof = eng.phase_times()
@@ -128,7 +138,7 @@ def main():
                        "parallelism": f"time-step pipeline x{world}"},
             "phase_ms_per_slice": per_kernel,
             "vcycles_per_slice": eng.stats()["vcycles"] / max(eng.stats()["slices"], 1),
-            "roofline": {"bound": "hbm", "kernel": "k_deposit_current<2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_deposit_tiled<2,%d>" % args.tile if args.tile else "k_deposit_current<2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per_kernel[dom]},
         }

@@ -93,9 +93,9 @@ _SIGS = {
     "hps_engine_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
     "hps_engine_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_phase_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    "hps_ring_unique_id": (C.c_int, [C.c_void_p]),
-    "hps_ring_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
-    "hps_ring_run": (C.c_int, [C.c_void_p, C.c_int]),
+    "hps_engine_beam_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.c_void_p]),
+    "hps_engine_set_beam_storage": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hps_engine_initial_beam": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long]),
     "hps_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long]),
     "hps_device_count": (C.c_int, [C.POINTER(C.c_int)]),

@@ -268,11 +268,25 @@ class SliceEngine:
     def set_profiling(self, on=True):
         check(_lib.lib().hps_engine_set_profiling(self._h, int(on)))
 
+    def beam_layout(self):
+        """-> (nbeam, offsets[nz+1]): block p (p-th slice from the head) holds particles offsets[p]:offsets[p+1]."""
+        nb = C.c_long()
+        off = (C.c_long * (self.deck["nz"] + 1))()
+        check(_lib.lib().hps_engine_beam_info(self._h, C.byref(nb), off))
+        return nb.value, np.array(off[:], dtype=np.int64)
+
+    def set_beam_storage(self, tensor):
+        """Use `tensor` (float64, 7*nbeam, on this device) as the engine's beam blocks; None = own."""
+        check(_lib.lib().hps_engine_set_beam_storage(self._h, C.c_void_p(tensor.data_ptr()) if tensor is not None else None))
+
+    def initial_beam_into(self, tensor):
+        check(_lib.lib().hps_engine_initial_beam(self._h, C.c_void_p(tensor.data_ptr())))
+
     def phase_times(self):
-        ms = (C.c_double * 6)()
+        ms = (C.c_double * 7)()
         n = C.c_long()
         check(_lib.lib().hps_engine_phase_times(self._h, ms, C.byref(n)))
-        names = ["deposit_current", "poisson", "explicit_deposit", "mg_solve1", "advance_plasma", "other"]
+        names = ["deposit_current", "poisson", "explicit_deposit", "mg_solve1", "advance_plasma", "other", "sort"]
         return {k: ms[i] for i, k in enumerate(names)}, n.value
 
     def checksums(self):

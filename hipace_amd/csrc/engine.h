@@ -29,16 +29,16 @@ struct Engine {
     void* mg = nullptr;            // multigrid handle
     double* staging = nullptr;
     // driver beam: slice-major SoA (head slice first), static because hipace.dt = 0
-    double* beam_data = nullptr; BeamView beam{}; long nbeam = 0; std::vector<long> beam_off;
+    // blocks [slice p from the head][7][count_p]; beam_cur = storage in use (own or caller's)
+    double* beam_data = nullptr; double* beam_init = nullptr; double* beam_cur = nullptr;
+    long nbeam = 0; std::vector<long> beam_off;
     int* d_nqsa = nullptr;
     double* d_checksum = nullptr;
     bool diagnostics = false;
     bool profiling = false;
-    std::vector<hipEvent_t> ev; size_t ev_used = 0;      // 10 events per profiled slice
+    std::vector<hipEvent_t> ev; size_t ev_used = 0;      // 11 events per profiled slice
     void mark ();
     long total_vcycles = 0, slices_done = 0;
-    // ring pipeline (ring.hip)
-    void* ring = nullptr;
 
     ~Engine ();
     int create (const hps_deck& deck, int device);

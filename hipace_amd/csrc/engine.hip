@@ -213,7 +213,7 @@ Engine::~Engine ()
     (void)hipFree(slab.p); (void)hipFree(pl_real); (void)hipFree(pl.idcpu); (void)hipFree(pl.ion_lev);
     delete tiling;
     (void)hipFree(pl_real_alt); (void)hipFree(pl_alt.idcpu); (void)hipFree(pl_alt.ion_lev); (void)hipFree(d_nfallback);
-    (void)hipFree(staging); (void)hipFree(beam_data); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
+    (void)hipFree(staging); (void)hipFree(beam_data); (void)hipFree(beam_init); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
     for (auto e : ev) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
 }
@@ -258,11 +258,18 @@ int Engine::init_beam ()
     beam_off[d.nz] = (long)h[0].size();
     nbeam = (long)h[0].size();
     if (nbeam > 0) {
+        // slice-major blocks: block p (p-th slice from the head) = [7][count_p] at 7*beam_off[p]
+        std::vector<double> blk((size_t)7*nbeam);
+        for (int p = 0; p < d.nz; ++p) {
+            const long first = beam_off[p], cnt = beam_off[p + 1] - first;
+            for (int k = 0; k < 7; ++k)
+                for (long i = 0; i < cnt; ++i) blk[(size_t)7*first + (size_t)k*cnt + i] = h[k][first + i];
+        }
         HPS_HIP_CHECK(hipMalloc(&beam_data, 7*nbeam*sizeof(double)));
-        for (int k = 0; k < 7; ++k)
-            HPS_HIP_CHECK(hipMemcpy(beam_data + k*nbeam, h[k].data(), nbeam*sizeof(double), hipMemcpyHostToDevice));
-        beam = BeamView{beam_data, beam_data + nbeam, beam_data + 2*nbeam, beam_data + 3*nbeam, beam_data + 4*nbeam,
-                        beam_data + 5*nbeam, beam_data + 6*nbeam};
+        HPS_HIP_CHECK(hipMalloc(&beam_init, 7*nbeam*sizeof(double)));
+        HPS_HIP_CHECK(hipMemcpy(beam_init, blk.data(), 7*nbeam*sizeof(double), hipMemcpyHostToDevice));
+        HPS_HIP_CHECK(hipMemcpy(beam_data, beam_init, 7*nbeam*sizeof(double), hipMemcpyDeviceToDevice));
+        beam_cur = beam_data;
     }
     return HPS_OK;
 }
@@ -362,8 +369,11 @@ int Engine::begin_step ()
 int Engine::deposit_beam_slice (int islice, int cjx, int cjy, int cjz)
 {
     if (nbeam == 0 || islice < 0 || islice >= d.nz) return HPS_OK;
-    const long first = beam_off[d.nz - 1 - islice], count = beam_off[d.nz - islice] - first;
+    const long first0 = beam_off[d.nz - 1 - islice], count = beam_off[d.nz - islice] - first0;
     if (count <= 0) return HPS_OK;
+    double* blk = beam_cur + 7*first0;
+    const BeamView beam{blk, blk + count, blk + 2*count, blk + 3*count, blk + 4*count, blk + 5*count, blk + 6*count};
+    const long first = 0;
     const double q_invvol = d.beam_charge*1.0;      // normalised units, level 0
     const double csq_inv = 1.0/(gm.c*gm.c);
     const dim3 grid(ceil_div(count, 256)), block(256);
@@ -404,6 +414,7 @@ int Engine::solve_slice (int islice)
     // plasma: jx, jy, [rho], chi, rhomjz (Hipace.cpp:609-610); beam: jz_beam on This (:613-614)
     if (tiling && since_sort >= sort_period) { if ((e = resort())) return e; }
     ++since_sort;
+    mark();   // b1b
     {   const int comp[6] = {HPS_C_JX, HPS_C_JY, -1, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_CHI, HPS_C_RHOMJZ};
         if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st))) return e; }
         else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
@@ -524,17 +535,36 @@ extern "C" int hps_engine_phase_times (void* h, double* ms, long* nsl)
     Engine* E = static_cast<Engine*>(h);
     HPS_HIP_CHECK(hipStreamSynchronize(E->st));
     // interval -> phase: 0 deposit, 1 poisson, 2 explicit, 3 mg, 4 push, 5 other
-    static const int phase_of[9] = {5, 0, 1, 5, 2, 3, 5, 4, 5};
-    for (int k = 0; k < 6; ++k) ms[k] = 0.0;
-    const size_t ns = E->ev_used/10;
+    static const int phase_of[10] = {5, 6, 0, 1, 5, 2, 3, 5, 4, 5};
+    for (int k = 0; k < 7; ++k) ms[k] = 0.0;
+    const size_t ns = E->ev_used/11;
     for (size_t s = 0; s < ns; ++s)
-        for (int k = 0; k < 9; ++k) {
+        for (int k = 0; k < 10; ++k) {
             float t = 0.f;
-            HPS_HIP_CHECK(hipEventElapsedTime(&t, E->ev[s*10 + k], E->ev[s*10 + k + 1]));
+            HPS_HIP_CHECK(hipEventElapsedTime(&t, E->ev[s*11 + k], E->ev[s*11 + k + 1]));
             ms[phase_of[k]] += t;
         }
     if (nsl) *nsl = (long)ns;
     E->ev_used = 0;
+    return HPS_OK;
+}
+extern "C" int hps_engine_beam_info (void* h, long* nbeam, long* offsets_host)
+{
+    Engine* E = static_cast<Engine*>(h);
+    if (nbeam) *nbeam = E->nbeam;
+    if (offsets_host) for (int p = 0; p <= E->d.nz; ++p) offsets_host[p] = E->beam_off[p];
+    return HPS_OK;
+}
+extern "C" int hps_engine_set_beam_storage (void* h, double* storage_dev)
+{
+    Engine* E = static_cast<Engine*>(h);
+    E->beam_cur = storage_dev ? storage_dev : E->beam_data;
+    return HPS_OK;
+}
+extern "C" int hps_engine_initial_beam (void* h, double* dst_dev)
+{
+    Engine* E = static_cast<Engine*>(h);
+    if (E->nbeam > 0) HPS_HIP_CHECK(hipMemcpy(dst_dev, E->beam_init, 7*E->nbeam*sizeof(double), hipMemcpyDeviceToDevice));
     return HPS_OK;
 }
 extern "C" int hps_engine_set_tiling (void* h, int tile_size, int sort_period)

@@ -37,6 +37,10 @@ struct LevBox { int lox, loy, hix, hiy;      // index bounds of the level box (w
 
 enum { SRC_ZERO = 0, SRC_DIRECT = 1, SRC_PROLONG = 2 };
 
+// optional shader-clock stamps of workgroup 0 (set through hps_mg_debug_stamps)
+__device__ long long* g_mg_dbg = nullptr;
+#define MG_STAMP(i) do { if (g_mg_dbg && blockIdx.x == 0 && threadIdx.x == 0) g_mg_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+
 constexpr int GT_X = 64, GT_Y = 32;          // cells swept per tile
 constexpr int GA_X = GT_X + 2, GA_Y = GT_Y + 2;
 constexpr int GPAIRS = GT_X*GT_Y/2/256;      // cell pairs per thread = 4
@@ -51,33 +55,38 @@ __device__ __forceinline__ double diag_c0 (int i, int j, const LevBox& b, double
     return c0;
 }
 
-// off-diagonal part of the stencil at (i,j); `c` points at the cell, `sy` is the row stride
-template <bool CC, class P>
+// Off-diagonal part of the stencil at (i,j); `c` points at the cell, `sy` is the row stride.
+// Branch-free: all four neighbours are read unconditionally (the arrays carry a ring / walls), the
+// cell-centred wall variants (gs1 :265-292: facx*(4/3)*phi instead of facx*(phi_w+phi_e)) are picked
+// with selects, so the result is bit-identical to the branching form while the loads of several
+// cells can be in flight together.  INTERIOR = no cell of the tile touches a wall.
+template <bool CC, bool INTERIOR = false, class P>
 __device__ __forceinline__ double offdiag (P c, int sy, int i, int j, const LevBox& b, double facx, double facy)
 {
-    double lap;
-    if (CC && i == b.lox)      lap = facx*(4./3.)*c[1];
-    else if (CC && i == b.hix) lap = facx*(4./3.)*c[-1];
-    else                       lap = facx*(c[-1] + c[1]);
-    if (CC && j == b.loy)      lap += facy*(4./3.)*c[sy];
-    else if (CC && j == b.hiy) lap += facy*(4./3.)*c[-sy];
-    else                       lap += facy*(c[-sy] + c[sy]);
-    return lap;
+    const double w = c[-1], e = c[1], s = c[-sy], n = c[sy];
+    double lx = facx*(w + e), ly = facy*(s + n);
+    if (CC && !INTERIOR) {
+        const double fx43 = facx*(4./3.), fy43 = facy*(4./3.);
+        lx = (i == b.lox) ? fx43*e : ((i == b.hix) ? fx43*w : lx);
+        ly = (j == b.loy) ? fy43*n : ((j == b.hiy) ? fy43*s : ly);
+    }
+    return lx + ly;
 }
 
-// residual rhs - L(phi) at (i,j) (laplacian :162-182, residual1 :184-190)
-template <class P>
+// residual rhs - L(phi) at (i,j) (laplacian :162-182, residual1 :184-190), branch-free as above
+template <bool INTERIOR = false, class P>
 __device__ __forceinline__ double residual_at (P c, int sy, int i, int j, const LevBox& b,
                                                double rhs, double acf, double facx, double facy)
 {
-    const double p0 = c[0];
+    const double p0 = c[0], w = c[-1], e = c[1], s = c[-sy], n = c[sy];
     double lap = -2.0*(facx + facy)*p0;
-    if (i == b.lox)      lap += facx*((4./3.)*c[1] - 2.0*p0);
-    else if (i == b.hix) lap += facx*((4./3.)*c[-1] - 2.0*p0);
-    else                 lap += facx*(c[-1] + c[1]);
-    if (j == b.loy)      lap += facy*((4./3.)*c[sy] - 2.0*p0);
-    else if (j == b.hiy) lap += facy*((4./3.)*c[-sy] - 2.0*p0);
-    else                 lap += facy*(c[-sy] + c[sy]);
+    double tx = facx*(w + e), ty = facy*(s + n);
+    if (!INTERIOR) {
+        tx = (i == b.lox) ? facx*((4./3.)*e - 2.0*p0) : ((i == b.hix) ? facx*((4./3.)*w - 2.0*p0) : tx);
+        ty = (j == b.loy) ? facy*((4./3.)*n - 2.0*p0) : ((j == b.hiy) ? facy*((4./3.)*s - 2.0*p0) : ty);
+    }
+    lap += tx;
+    lap += ty;
     return rhs + acf*p0 - lap;
 }
 
@@ -113,32 +122,42 @@ __device__ __forceinline__ void block_max_to (unsigned long long* addr, double v
 // phi_out = GSRB^4(start), start = 0 | phi_in | phi_in + P(crse);
 // DO_RES: residual r = rhs - L(phi_out), max|r| (and max|rhs|) -> norms;
 //         FUSE_R (cell-centred): cres = R(r) written straight to the next level; else r -> res_out.
-template <bool CC, int SRC, bool DO_RES, bool FUSE_R>
-__global__ __launch_bounds__(256)
-void k_smooth (LevBox b, FView phi_out, FView rhs, FView acf, FView phi_in, FView crse, FView res_out,
-               FView cres_out, double facx, double facy, int ntx, unsigned long long* resnorm,
-               unsigned long long* rhsnorm)
+// INTERIOR tiles (no swept cell on a wall / outside the box) take a path without masks.
+template <bool CC, int SRC, bool DO_RES, bool FUSE_R, bool INTERIOR>
+__device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], double* s_red, const LevBox& b, const FView& phi_out,
+                                             const FView& rhs, const FView& acf, const FView& phi_in, const FView& crse,
+                                             const FView& res_out, const FView& cres_out, double facx, double facy,
+                                             int gi0, int gj0, unsigned long long* resnorm, unsigned long long* rhsnorm)
 {
-    static_assert(!FUSE_R || (CC && DO_RES), "fused restriction is cell-centred only");
-    __shared__ double s_phi[2][GA_Y*GA_X];
     constexpr int E = DO_RES ? 4 : 3;                 // rim of the swept tile that is not final
-    constexpr int FX = GT_X - 2*E, FY = GT_Y - 2*E;   // cells a tile finalises (even numbers)
-    const int bx = blockIdx.x % ntx, by = blockIdx.x / ntx;
-    const int gi0 = b.vlx + bx*FX - E;                // global index of swept cell (0,0)
-    const int gj0 = b.vly + by*FY - E;
     const int tid = threadIdx.x;
-
-    // fill LDS (ring included): start value inside the unknowns' box, 0 elsewhere
-    for (int s = tid; s < GA_X*GA_Y; s += 256) {
-        const int lj = s / GA_X, li = s - lj*GA_X;
-        const int i = gi0 - 1 + li, j = gj0 - 1 + lj;
-        double v0 = 0.0, v1 = 0.0;
-        if (SRC != SRC_ZERO && i >= b.vlx && i <= b.vhx && j >= b.vly && j <= b.vhy) {
-            v0 = phi_in(i, j, 0); v1 = phi_in(i, j, 1);
-            if (SRC == SRC_PROLONG) { v0 += prolong_at<CC>(crse, i, j, 0); v1 += prolong_at<CC>(crse, i, j, 1); }
+    MG_STAMP(0);
+    // fill LDS (ring included): start value inside the unknowns' box, 0 elsewhere.  Loads are
+    // unconditional (clamped address + select) and all issued before the first LDS store.
+    {
+        constexpr int NF = (GA_X*GA_Y + 255)/256;
+        double v0[NF], v1[NF];
+#pragma unroll
+        for (int m = 0; m < NF; ++m) {
+            const int s = min(tid + 256*m, GA_X*GA_Y - 1);
+            const int lj = s / GA_X, li = s - lj*GA_X;
+            const int i = gi0 - 1 + li, j = gj0 - 1 + lj;
+            v0[m] = 0.0; v1[m] = 0.0;
+            if (SRC != SRC_ZERO) {
+                const int ic = INTERIOR ? i : min(max(i, b.vlx), b.vhx), jc = INTERIOR ? j : min(max(j, b.vly), b.vhy);
+                double a0 = phi_in(ic, jc, 0), a1 = phi_in(ic, jc, 1);
+                if (SRC == SRC_PROLONG) { a0 += prolong_at<CC>(crse, ic, jc, 0); a1 += prolong_at<CC>(crse, ic, jc, 1); }
+                const bool inside = INTERIOR || (ic == i && jc == j);
+                v0[m] = inside ? a0 : 0.0; v1[m] = inside ? a1 : 0.0;
+            }
         }
-        s_phi[0][s] = v0; s_phi[1][s] = v1;
+#pragma unroll
+        for (int m = 0; m < NF; ++m) {
+            const int s = tid + 256*m;
+            if (s < GA_X*GA_Y) { s_phi[0][s] = v0[m]; s_phi[1][s] = v1[m]; }
+        }
     }
+    MG_STAMP(1);
 
     // per-thread cell pairs: rhs, coefficient and inverse diagonal stay in registers
     double r0[GPAIRS][2], r1[GPAIRS][2], ac[GPAIRS][2], ci[GPAIRS][2];
@@ -152,16 +171,19 @@ void k_smooth (LevBox b, FView phi_out, FView rhs, FView acf, FView phi_in, FVie
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int i = gi0 + 2*pk + h;
-            const bool ok = (i >= b.vlx && i <= b.vhx && j >= b.vly && j <= b.vhy);
+            const int ic = INTERIOR ? i : min(max(i, b.vlx), b.vhx), jc = INTERIOR ? j : min(max(j, b.vly), b.vhy);
+            const bool ok = INTERIOR || (ic == i && jc == j);
             in[m][h] = ok;
-            r0[m][h] = ok ? rhs(i, j, 0) : 0.0;
-            r1[m][h] = ok ? rhs(i, j, 1) : 0.0;
-            ac[m][h] = ok ? acf(i, j, 0) : 0.0;
+            const double a0 = rhs(ic, jc, 0), a1 = rhs(ic, jc, 1), a2 = acf(ic, jc, 0);
+            r0[m][h] = ok ? a0 : 0.0;
+            r1[m][h] = ok ? a1 : 0.0;
+            ac[m][h] = ok ? a2 : 0.0;
             ci[m][h] = 1.0/diag_c0<CC>(i, j, b, ac[m][h], facx, facy);
-            if (rhsnorm && ok) rmax = fmax(rmax, fmax(fabs(r0[m][h]), fabs(r1[m][h])));
+            if (rhsnorm) rmax = fmax(rmax, fmax(fabs(r0[m][h]), fabs(r1[m][h])));
         }
     }
     __syncthreads();
+    MG_STAMP(2);
 
     for (int icolor = 0; icolor < 4; ++icolor) {
 #pragma unroll
@@ -171,15 +193,17 @@ void k_smooth (LevBox b, FView phi_out, FView rhs, FView acf, FView phi_in, FVie
             const int j = gj0 + jj;
             const int ia = gi0 + 2*pk;
             const int h = (ia + j + icolor) & 1;          // which cell of the pair has this colour
-            if (in[m][h]) {
-                const int i = ia + h;
-                const int o = (jj + 1)*GA_X + 2*pk + h + 1;
-                s_phi[0][o] = (r0[m][h] - offdiag<CC>(&s_phi[0][o], GA_X, i, j, b, facx, facy))*ci[m][h];
-                s_phi[1][o] = (r1[m][h] - offdiag<CC>(&s_phi[1][o], GA_X, i, j, b, facx, facy))*ci[m][h];
-            }
+            const int i = ia + h;
+            const int o = (jj + 1)*GA_X + 2*pk + h + 1;
+            const double rr0 = h ? r0[m][1] : r0[m][0], rr1 = h ? r1[m][1] : r1[m][0], cc = h ? ci[m][1] : ci[m][0];
+            const bool ok = h ? in[m][1] : in[m][0];
+            const double n0 = (rr0 - offdiag<CC, INTERIOR>((const double*)&s_phi[0][o], GA_X, i, j, b, facx, facy))*cc;
+            const double n1 = (rr1 - offdiag<CC, INTERIOR>((const double*)&s_phi[1][o], GA_X, i, j, b, facx, facy))*cc;
+            if (INTERIOR || ok) { s_phi[0][o] = n0; s_phi[1][o] = n1; }
         }
         __syncthreads();
     }
+    MG_STAMP(3);
 
     double resmax = 0.0;
 #pragma unroll
@@ -189,22 +213,24 @@ void k_smooth (LevBox b, FView phi_out, FView rhs, FView acf, FView phi_in, FVie
         const int j = gj0 + jj;
         const bool rowok = (jj >= E && jj < GT_Y - E);
         double q0[2] = {0.0, 0.0}, q1[2] = {0.0, 0.0};
-        bool fin[2] = {false, false};
+        bool fin[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int ii = 2*pk + h;
             fin[h] = rowok && ii >= E && ii < GT_X - E && in[m][h];
-            if (!fin[h]) continue;
             const int i = gi0 + ii;
             const int o = (jj + 1)*GA_X + ii + 1;
             if (DO_RES) {
-                q0[h] = residual_at(&s_phi[0][o], GA_X, i, j, b, r0[m][h], ac[m][h], facx, facy);
-                q1[h] = residual_at(&s_phi[1][o], GA_X, i, j, b, r1[m][h], ac[m][h], facx, facy);
-                if (!FUSE_R) { res_out(i, j, 0) = q0[h]; res_out(i, j, 1) = q1[h]; }
+                const double t0 = residual_at<INTERIOR>((const double*)&s_phi[0][o], GA_X, i, j, b, r0[m][h], ac[m][h], facx, facy);
+                const double t1 = residual_at<INTERIOR>((const double*)&s_phi[1][o], GA_X, i, j, b, r1[m][h], ac[m][h], facx, facy);
+                q0[h] = fin[h] ? t0 : 0.0; q1[h] = fin[h] ? t1 : 0.0;
                 resmax = fmax(resmax, fmax(fabs(q0[h]), fabs(q1[h])));
             }
-            phi_out(i, j, 0) = s_phi[0][o];
-            phi_out(i, j, 1) = s_phi[1][o];
+            if (fin[h]) {
+                if (DO_RES && !FUSE_R) { res_out(i, j, 0) = q0[h]; res_out(i, j, 1) = q1[h]; }
+                phi_out(i, j, 0) = s_phi[0][o];
+                phi_out(i, j, 1) = s_phi[1][o];
+            }
         }
         if (FUSE_R) {
             // restrict_cc (:29-37): 0.25*(((a+b)+c)+d), a,b this row (even j), c,d the row above.
@@ -219,9 +245,33 @@ void k_smooth (LevBox b, FView phi_out, FView rhs, FView acf, FView phi_in, FVie
             }
         }
     }
-    __shared__ double s_red[4];
+    MG_STAMP(4);
     if (DO_RES && resnorm) block_max_to(resnorm, resmax, s_red);
     if (rhsnorm) block_max_to(rhsnorm, rmax, s_red);
+    MG_STAMP(5);
+}
+
+template <bool CC, int SRC, bool DO_RES, bool FUSE_R>
+__global__ __launch_bounds__(256)
+void k_smooth (LevBox b, FView phi_out, FView rhs, FView acf, FView phi_in, FView crse, FView res_out,
+               FView cres_out, double facx, double facy, int ntx, unsigned long long* resnorm,
+               unsigned long long* rhsnorm)
+{
+    static_assert(!FUSE_R || (CC && DO_RES), "fused restriction is cell-centred only");
+    __shared__ double s_phi[2][GA_Y*GA_X];
+    __shared__ double s_red[4];
+    constexpr int E = DO_RES ? 4 : 3;
+    constexpr int FX = GT_X - 2*E, FY = GT_Y - 2*E;   // cells a tile finalises (even numbers)
+    const int bx = blockIdx.x % ntx, by = blockIdx.x / ntx;
+    const int gi0 = b.vlx + bx*FX - E;                // global index of swept cell (0,0)
+    const int gj0 = b.vly + by*FY - E;
+    // every swept cell and its ring strictly inside the unknowns' box and off the walls
+    const bool interior = (gi0 - 1 >= b.vlx) && (gi0 + GT_X <= b.vhx) && (gj0 - 1 >= b.vly) && (gj0 + GT_Y <= b.vhy)
+                       && (gi0 > b.lox) && (gi0 + GT_X - 1 < b.hix) && (gj0 > b.loy) && (gj0 + GT_Y - 1 < b.hiy);
+    if (interior) smooth_tile<CC, SRC, DO_RES, FUSE_R, true>(s_phi, s_red, b, phi_out, rhs, acf, phi_in, crse, res_out, cres_out,
+                                                             facx, facy, gi0, gj0, resnorm, rhsnorm);
+    else          smooth_tile<CC, SRC, DO_RES, FUSE_R, false>(s_phi, s_red, b, phi_out, rhs, acf, phi_in, crse, res_out, cres_out,
+                                                              facx, facy, gi0, gj0, resnorm, rhsnorm);
 }
 
 // coarse = R(fine): 4-average (cell-centred) or 9-point full weighting (nodal)
@@ -247,8 +297,8 @@ void k_restrict (LevBox cb, FView crse, FView fine, int ncomp)
 // ---- all small levels in one workgroup, LDS resident --------------------------------------------
 typedef __attribute__((address_space(3))) double lds_double;
 
-// per small level: box, row length, points, offset (in doubles) of its 7-plane block in LDS:
-// [acf | res0 res1 | cor0 cor1 | rescor0 rescor1]
+// per small level: box, row length, points, offset (in doubles) of its 8-plane block in LDS:
+// [acf | res0 res1 | cor0 cor1 | rescor0 rescor1 | 1/diagonal]
 struct LowLev { LevBox b; int nxb; int cells; int off; };
 
 struct LView {      // one component plane of a small level in LDS, level index space
@@ -281,21 +331,23 @@ __device__ __forceinline__ double lprolong (const LView& c, int i, int j)
     return c(ic, jc);
 }
 
+// 1024 threads as a 32 x 32 patch swept over the level: no integer divisions in the loops
+#define HPS_LOW_FOR_VALID(l, i, j)                                                          \
+    for (int j = (l).b.vly + (int)(threadIdx.x >> 5); j <= (l).b.vhy; j += 32)              \
+        for (int i = (l).b.vlx + (int)(threadIdx.x & 31); i <= (l).b.vhx; i += 32)
+
 template <bool CC>
 __device__ void low_sweeps (lds_double* base, const LowLev& l, double facx, double facy, int nsweeps)
 {
-    const int nvx = l.b.vhx - l.b.vlx + 1, nvy = l.b.vhy - l.b.vly + 1;
-    const LView acf = lplane(base, l, 0);
+    const LView cinv = lplane(base, l, 7);
     for (int is = 0; is < nsweeps; ++is) {
-        for (int s = threadIdx.x; s < nvx*nvy; s += blockDim.x) {
-            const int jj = s / nvx, ii = s - jj*nvx;
-            const int i = l.b.vlx + ii, j = l.b.vly + jj;
+        HPS_LOW_FOR_VALID(l, i, j) {
             if (((i + j + is) & 1) == 0) {
-                const double cinv = 1.0/diag_c0<CC>(i, j, l.b, acf(i, j), facx, facy);
+                const double ci = cinv(i, j);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const LView rhs = lplane(base, l, 1 + n), phi = lplane(base, l, 3 + n);
-                    phi(i, j) = (rhs(i, j) - offdiag<CC>((const lds_double*)&phi(i, j), l.nxb, i, j, l.b, facx, facy))*cinv;
+                    phi(i, j) = (rhs(i, j) - offdiag<CC, false>((const lds_double*)&phi(i, j), l.nxb, i, j, l.b, facx, facy))*ci;
                 }
             }
         }
@@ -321,6 +373,7 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
 {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_double* base = (lds_double*)lds_raw;
+    MG_STAMP(8);
     {
         const LowLev l = lv[0];
         for (int s = threadIdx.x; s < l.cells; s += blockDim.x) {
@@ -333,16 +386,24 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
     for (int il = 1; il < nl; ++il) {     // coefficient hierarchy
         const LowLev f = lv[il - 1];
         const LowLev c = lv[il];
-        const int nvx = c.b.vhx - c.b.vlx + 1, nvy = c.b.vhy - c.b.vly + 1;
         const LView fine = lplane(base, f, 0), crse = lplane(base, c, 0);
         for (int s = threadIdx.x; s < c.cells; s += blockDim.x) base[c.off + s] = 0.0;
         __syncthreads();
-        for (int s = threadIdx.x; s < nvx*nvy; s += blockDim.x) {
-            const int jj = s / nvx, ii = s - jj*nvx;
-            crse(c.b.vlx + ii, c.b.vly + jj) = lrestrict<CC>(fine, c.b.vlx + ii, c.b.vly + jj);
+        HPS_LOW_FOR_VALID(c, i, j) crse(i, j) = lrestrict<CC>(fine, i, j);
+        __syncthreads();
+    }
+    MG_STAMP(9);
+    {   // inverse diagonals of every small level (one division per cell per V-cycle)
+        double fx = facx0, fy = facy0;
+        for (int il = 0; il < nl; ++il) {
+            const LowLev l = lv[il];
+            const LView acf = lplane(base, l, 0), cinv = lplane(base, l, 7);
+            HPS_LOW_FOR_VALID(l, i, j) cinv(i, j) = 1.0/diag_c0<CC>(i, j, l.b, acf(i, j), fx, fy);
+            fx *= 0.25; fy *= 0.25;
         }
         __syncthreads();
     }
+    MG_STAMP(10);
     double facx = facx0, facy = facy0;
     for (int il = 0; il < nl - 1; ++il) {
         const LowLev l = lv[il];
@@ -350,27 +411,21 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
         low_zero_cor(base, l);
         low_sweeps<CC>(base, l, facx, facy, 4);
         {   // residual -> rescor
-            const int nvx = l.b.vhx - l.b.vlx + 1, nvy = l.b.vhy - l.b.vly + 1;
             const LView acf = lplane(base, l, 0);
             // walls of rescor must read as 0 for the nodal restriction
             if (!CC) { lds_double* r = base + l.off + 5*l.cells; for (int s = threadIdx.x; s < 2*l.cells; s += blockDim.x) r[s] = 0.0; __syncthreads(); }
-            for (int s = threadIdx.x; s < nvx*nvy; s += blockDim.x) {
-                const int jj = s / nvx, ii = s - jj*nvx;
-                const int i = l.b.vlx + ii, j = l.b.vly + jj;
+            HPS_LOW_FOR_VALID(l, i, j) {
                 const double a = acf(i, j);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const LView rhs = lplane(base, l, 1 + n), phi = lplane(base, l, 3 + n), rc = lplane(base, l, 5 + n);
-                    rc(i, j) = residual_at((const lds_double*)&phi(i, j), l.nxb, i, j, l.b, rhs(i, j), a, facx, facy);
+                    rc(i, j) = residual_at<false>((const lds_double*)&phi(i, j), l.nxb, i, j, l.b, rhs(i, j), a, facx, facy);
                 }
             }
             __syncthreads();
         }
         {   // restriction -> res of the next level
-            const int nvx = c.b.vhx - c.b.vlx + 1, nvy = c.b.vhy - c.b.vly + 1;
-            for (int s = threadIdx.x; s < nvx*nvy; s += blockDim.x) {
-                const int jj = s / nvx, ii = s - jj*nvx;
-                const int i = c.b.vlx + ii, j = c.b.vly + jj;
+            HPS_LOW_FOR_VALID(c, i, j) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n) lplane(base, c, 1 + n)(i, j) = lrestrict<CC>(lplane(base, l, 5 + n), i, j);
             }
@@ -378,19 +433,18 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
         }
         facx *= 0.25; facy *= 0.25;
     }
+    MG_STAMP(11);
     {
         const LowLev l = lv[nl - 1];
         low_zero_cor(base, l);
         low_sweeps<CC>(base, l, facx, facy, nsweeps_bottom);
     }
+    MG_STAMP(12);
     for (int il = nl - 2; il >= 0; --il) {
         const LowLev l = lv[il];
         const LowLev c = lv[il + 1];
         facx *= 4.0; facy *= 4.0;
-        const int nvx = l.b.vhx - l.b.vlx + 1, nvy = l.b.vhy - l.b.vly + 1;
-        for (int s = threadIdx.x; s < nvx*nvy; s += blockDim.x) {
-            const int jj = s / nvx, ii = s - jj*nvx;
-            const int i = l.b.vlx + ii, j = l.b.vly + jj;
+        HPS_LOW_FOR_VALID(l, i, j) {
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const LView fine = lplane(base, l, 3 + n);
@@ -400,10 +454,12 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
         __syncthreads();
         low_sweeps<CC>(base, l, facx, facy, 4);
     }
+    MG_STAMP(13);
     {
         const LowLev l = lv[0];
         for (int s = threadIdx.x; s < 2*l.cells; s += blockDim.x) cor_g[s] = base[l.off + 3*l.cells + s];
     }
+    MG_STAMP(14);
 }
 
 __global__ void k_copy2 (LevBox b, FView dst, FView src)
@@ -477,7 +533,7 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
     for (int il = M->lowv_begin; il < nl; ++il) {
         const MGLevelDev& l = M->L[il];
         low.push_back(LowLev{l.b, l.b.hix - l.b.lox + 1, (int)l.cells, off});
-        off += 7*(int)l.cells;
+        off += 8*(int)l.cells;
     }
     M->low_lds = (size_t)off*sizeof(double);
     if (M->low_lds > 64*1024) {
@@ -641,6 +697,21 @@ extern "C" int hps_mg_solve1 (void* handle, hps_slab slab, int sol_comp, int rhs
     HPS_REQUIRE(M->cc || slab.ng >= 1, "hps_mg_solve1: node-centred solve needs >= 1 guard cell");
     return mg_solve1(M, slab, sol_comp, rhs_comp, acoef_comp, tol_rel, tol_abs, max_iters, iters_host, resnorm_host,
                      (hipStream_t)stream);
+}
+
+// debug: first call arms the stamps, later calls read the 16 slots back
+extern "C" int hps_mg_debug_stamps (long long* stamps16_host)
+{
+    static long long* d = nullptr;
+    if (!d) {
+        HPS_HIP_CHECK(hipMalloc(&d, 16*sizeof(long long)));
+        HPS_HIP_CHECK(hipMemset(d, 0, 16*sizeof(long long)));
+        HPS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_mg_dbg), &d, sizeof(d)));
+        return HPS_OK;
+    }
+    HPS_HIP_CHECK(hipDeviceSynchronize());
+    HPS_HIP_CHECK(hipMemcpy(stamps16_host, d, 16*sizeof(long long), hipMemcpyDeviceToHost));
+    return HPS_OK;
 }
 
 extern "C" int hps_mg_destroy (void* handle)

@@ -1,0 +1,141 @@
+"""Time-step ring pipeline over the GPUs of one node.
+
+The reference does not decompose a slice or the zeta axis; it pipelines *time steps* over ranks
+(src/Hipace.cpp:400-401: rank r runs steps r, r+N, ...) and hands the freshly pushed beam slice of
+step s to the rank that runs step s+1 (src/utils/MultiBuffer.cpp:444-609; in-process "send to
+myself" when there is one rank, :299-308).  This module is that schedule for `SliceEngine`.
+
+Transport: torch.distributed point-to-point -- backend "nccl" (= RCCL over xGMI) between GPUs,
+"gloo" in the CPU tests.  One message per slice: the slice's beam block, `7*count` doubles
+(x, y, z, ux, uy, uz, w), contiguous in the engine's beam storage (include/hpslice.h,
+hps_engine_beam_info).
+
+Deadlock freedom by construction: all ranks advance through the same global pipeline *ticks*.
+Rank r is 2r ticks behind rank 0 (solving slice k needs the beam of slice k AND of slice k-1, whose
+jx/jy feed the explicit source term: Hipace.cpp:639-657, so a rank trails its predecessor by two
+slices).  In tick t every rank posts, in one batch,
+  * the send of the slice it solved in tick t-1 (if a later step exists), and
+  * the receive of the slice its ring predecessor solved in tick t-1 (if that feeds one of its steps).
+For r > 0 that is slice k-1 while it solves slice k in the same tick; rank 0 receives the slices of
+its next step early (its predecessor, rank N-1, is only 2(N-1) ticks behind; requires nz >= 2N)
+into the other of two beam buffers.  Every posted send therefore has a matching receive posted in
+the same tick on the peer, and a rank only ever waits for messages of earlier-or-equal ticks.
+"""
+import torch
+import torch.distributed as dist
+
+
+def steps_of_rank(rank, world, n_steps):
+    return list(range(rank, n_steps, world))
+
+
+class _Sched:
+    """Who solves what in which tick."""
+
+    def __init__(self, world, n_steps, nz, per_step=None):
+        self.world, self.n_steps, self.nz = world, n_steps, nz
+        self.per_step = per_step or nz        # slices solved per step (head slices first)
+
+    def work(self, rank, tick):
+        """(step, islice, local_step_index) solved by `rank` in `tick`, or None."""
+        loc = tick - 2 * rank
+        if loc < 0:
+            return None
+        m, q = divmod(loc, self.per_step)
+        step = rank + m * self.world
+        if step >= self.n_steps:
+            return None
+        return step, self.nz - 1 - q, m
+
+    def n_ticks(self):
+        last = 0
+        for r in range(self.world):
+            n = len(steps_of_rank(r, self.world, self.n_steps))
+            last = max(last, 2 * r + n * self.per_step)
+        return last + 1      # one more tick to flush the final sends (there are none, but keep symmetric)
+
+
+def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_per_step=None):
+    """Run steps rank, rank+world, ... < n_steps of `engine` with the per-slice ring hand-off.
+
+    engine: SliceEngine-like (begin_step, solve_slice, sync, beam_layout, set_beam_storage,
+    initial_beam_into).  slices_per_step < nz solves only the head slices of every step
+    (benchmark runs shorter than one box).  Returns the number of slices this rank solved.
+    """
+    nz = engine.deck["nz"]
+    per_step = slices_per_step or nz
+    assert per_step >= 2 * world, "the ring pipeline needs at least 2 slices per rank"
+    sched = _Sched(world, n_steps, nz, per_step)
+    nbeam, off = engine.beam_layout()
+    bufs = [torch.zeros(max(7 * nbeam, 1), dtype=torch.float64, device=device) for _ in range(2)]
+    if rank == 0:
+        engine.initial_beam_into(bufs[0])       # only the head rank injects the beam (as the reference)
+    prev, nxt = (rank - 1) % world, (rank + 1) % world
+
+    def block(buf, islice):
+        p = nz - 1 - islice
+        return buf[7 * off[p]:7 * off[p + 1]]
+
+    pending_recv = {}     # (local step index, islice) -> request
+    pending_send = []
+    solved = 0
+    for tick in range(sched.n_ticks()):
+        ops = []
+        # what my predecessor solved in the previous tick feeds my step (its step + 1)
+        pw = sched.work(prev, tick - 1)
+        if pw is not None and pw[0] + 1 < n_steps and (pw[0] + 1) % world == rank:
+            m_target = (pw[0] + 1 - rank) // world
+            t = block(bufs[m_target % 2], pw[1])
+            if t.numel() > 0:
+                if world == 1:
+                    pass                      # in-process hand-off below
+                else:
+                    ops.append(("recv", dist.P2POp(dist.irecv, t, prev), (m_target, pw[1])))
+        # what I solved in the previous tick goes to my successor
+        mw = sched.work(rank, tick - 1)
+        if mw is not None and mw[0] + 1 < n_steps:
+            t = block(bufs[mw[2] % 2], mw[1])
+            if t.numel() > 0:
+                if world == 1:
+                    block(bufs[(mw[2] + 1) % 2], mw[1]).copy_(t)      # MultiBuffer.cpp:299-308
+                else:
+                    ops.append(("send", dist.P2POp(dist.isend, t, nxt), None))
+        # receives and sends go out as separate batches (recv first) so that waiting for this
+        # tick's receive never waits for the successor to pick up this tick's send
+        for kind in ("recv", "send"):
+            sel = [o for o in ops if o[0] == kind]
+            if not sel:
+                continue
+            reqs = dist.batch_isend_irecv([o[1] for o in sel])
+            for i, o in enumerate(sel):
+                rq = reqs[min(i, len(reqs) - 1)]          # coalescing backends return one request per batch
+                if kind == "recv":
+                    pending_recv[o[2]] = rq
+                else:
+                    pending_send.append(rq)
+
+        w = sched.work(rank, tick)
+        if w is None:
+            continue
+        step, islice, m = w
+        if islice == nz - 1:
+            engine.set_beam_storage(bufs[m % 2])
+            engine.begin_step()
+        waited = False
+        for key in ((m, islice), (m, islice - 1)):            # this slice's beam and the next one's (jx/jy source)
+            rq = pending_recv.pop(key, None)
+            if rq is not None:
+                rq.wait()
+                waited = True
+        if waited and str(device) != "cpu":
+            torch.cuda.current_stream().synchronize()         # data landed before the engine's stream reads it
+        engine.solve_slice(islice)
+        engine.sync()                                         # the slice's beam block is final before it is sent
+        solved += 1
+        while len(pending_send) > 4:
+            pending_send.pop(0).wait()
+        if islice == nz - per_step and on_step_end is not None:
+            on_step_end(step)
+    for rq in pending_send:
+        rq.wait()
+    return solved

@@ -184,15 +184,22 @@ int hps_engine_set_tiling (void* handle, int tile_size, int sort_period);
 int hps_engine_fallbacks (void* handle, long* n_fallback_host);
 /* HIP-event phase timers on the engine's stream.  phase_times sums, over the slices solved since
  * profiling was switched on (or since the last call), the milliseconds spent in
- * {deposit_current, poisson x3 (+rhs, grad), explicit_deposit, mg_solve1, advance_plasma, other}
- * into ms_host[6] and stores the slice count; it synchronises the stream. */
+ * {deposit_current, poisson x3 (+rhs, grad), explicit_deposit, mg_solve1, advance_plasma, other,
+ * particle re-sort} into ms_host[7] and stores the slice count; it synchronises the stream. */
 int hps_engine_set_profiling (void* handle, int on);
 int hps_engine_phase_times (void* handle, double* ms_host, long* nslices_host);
 
-/* ---- ring pipeline over time steps (utils/MultiBuffer.H:21-34; MultiBuffer.cpp:444-609) -- */
-int hps_ring_unique_id (char* id128_host);                /* rank 0: ncclGetUniqueId -> 128 bytes */
-int hps_ring_init (void* engine, const char* id128_host, int rank, int nranks);
-int hps_ring_run (void* engine, int n_steps_total);       /* rank r runs steps r, r+N, ...        */
+/* Driver-beam storage of the engine: particles are kept in slice-major blocks, block p (p-th slice
+ * from the head, p = nz-1-islice) = [7][count_p] doubles (x,y,z,ux,uy,uz,w) starting at
+ * 7*offsets[p].  A pipeline driver can point the engine at its own buffer (the receive buffer of
+ * the ring hand-off); hps_engine_initial_beam copies the injected (step 0) beam into one. */
+int hps_engine_beam_info (void* handle, long* nbeam_host, long* offsets_host /* [nz+1] */);
+int hps_engine_set_beam_storage (void* handle, double* storage_dev /* [7*nbeam] or NULL = own */);
+int hps_engine_initial_beam (void* handle, double* dst_dev);
+
+/* ---- ring pipeline over time steps (utils/MultiBuffer.H:21-34; MultiBuffer.cpp:444-609) --------
+ * The hand-off itself is issued by the host driver (hipace_amd/pipeline.py) with RCCL
+ * point-to-point (torch.distributed backend "nccl") on the beam blocks above. */
 
 /* ---- utilities ---------------------------------------------------------------------------- */
 int hps_memcpy_d2h (void* dst_host, const void* src_dev, long bytes);

@@ -885,6 +885,9 @@ struct Engine {
     std::vector<double> pdata; std::vector<int32_t> pvalid, pion; Plasma pl;
     PoissonSolver* ps; MG* mg; std::vector<double> staging;
     Beam beam_this, beam_next;
+    // optional external beam storage in the product's block layout (pipeline tests):
+    // block p (p-th slice from the head) = [7][count_p] at 7*ext_off[p]
+    const double* ext_beam = nullptr; std::vector<long> ext_off;
     std::vector<double> checksum;      // per comp: sum |Q| over all valid cells and slices
     long total_vcycles; long n_qsa_total;
     double t_deposit, t_explicit, t_push, t_poisson, t_mg, t_other;
@@ -958,8 +961,35 @@ struct Engine {
         return d.beam_density;
     }
 
-    // InitBeamFixedPPCSlice (beam/BeamParticleContainerInit.cpp:198-346)
+    void beam_offsets () {
+        ext_off.assign(d.nz + 1, 0);
+        Beam b;
+        for (int p = 0; p < d.nz; ++p) { gen_beam_slice(d.nz - 1 - p, b); ext_off[p + 1] = ext_off[p] + (long)b.x.size(); }
+    }
     void init_beam_slice (int islice, Beam& b) const {
+        if (!ext_beam) { gen_beam_slice(islice, b); return; }
+        b = Beam();
+        const int p = d.nz - 1 - islice;
+        const long first = ext_off[p], cnt = ext_off[p + 1] - first;
+        const double* blk = ext_beam + 7*first;
+        b.x.assign(blk, blk + cnt); b.y.assign(blk + cnt, blk + 2*cnt); b.z.assign(blk + 2*cnt, blk + 3*cnt);
+        b.ux.assign(blk + 3*cnt, blk + 4*cnt); b.uy.assign(blk + 4*cnt, blk + 5*cnt); b.uz.assign(blk + 5*cnt, blk + 6*cnt);
+        b.w.assign(blk + 6*cnt, blk + 7*cnt);
+    }
+    void fill_initial_beam (double* dst) {
+        if (ext_off.empty()) beam_offsets();
+        Beam b;
+        for (int p = 0; p < d.nz; ++p) {
+            gen_beam_slice(d.nz - 1 - p, b);
+            const long cnt = (long)b.x.size();
+            double* blk = dst + 7*ext_off[p];
+            const std::vector<double>* arr[7] = {&b.x, &b.y, &b.z, &b.ux, &b.uy, &b.uz, &b.w};
+            for (int k = 0; k < 7; ++k) std::copy(arr[k]->begin(), arr[k]->end(), blk + k*cnt);
+        }
+    }
+
+    // InitBeamFixedPPCSlice (beam/BeamParticleContainerInit.cpp:198-346)
+    void gen_beam_slice (int islice, Beam& b) const {
         b = Beam();
         if (d.beam_profile < 0) return;
         const int nppc = d.beam_ppc[0]*d.beam_ppc[1]*d.beam_ppc[2];
@@ -1130,6 +1160,11 @@ struct Engine {
 // =============================================================================================
 extern "C" {
 
+// external beam storage in the product's block layout (see include/hpslice.h, hps_engine_beam_info)
+long orc_engine_beam_layout (void* h, long* offsets /* [nz+1] */);
+void orc_engine_set_external_beam (void* h, const double* storage);
+void orc_engine_initial_beam (void* h, double* dst);
+
 int orc_shape_factor (int order, double xmid, double* s_out) { return shape_factor(order, s_out, xmid); }
 
 int orc_deriv_shape (int dtype, int order, double xmid, int ix, double* s, double* ds) {
@@ -1239,13 +1274,26 @@ void orc_engine_checksums (void* h, double* out) { Engine* e = static_cast<Engin
 long orc_engine_vcycles (void* h) { return static_cast<Engine*>(h)->total_vcycles; }
 void orc_engine_times (void* h, double* t6) { Engine* e = static_cast<Engine*>(h);
     t6[0]=e->t_deposit; t6[1]=e->t_explicit; t6[2]=e->t_push; t6[3]=e->t_poisson; t6[4]=e->t_mg; t6[5]=e->t_other; }
+long orc_engine_beam_layout (void* h, long* offsets) {
+    Engine* e = static_cast<Engine*>(h);
+    if (e->ext_off.empty()) e->beam_offsets();
+    for (int p = 0; p <= e->d.nz; ++p) offsets[p] = e->ext_off[p];
+    return e->ext_off[e->d.nz];
+}
+void orc_engine_set_external_beam (void* h, const double* storage) {
+    Engine* e = static_cast<Engine*>(h);
+    if (e->ext_off.empty()) e->beam_offsets();
+    e->ext_beam = storage;
+}
+void orc_engine_initial_beam (void* h, double* dst) { static_cast<Engine*>(h)->fill_initial_beam(dst); }
+
 // beam statistics of the whole beam (sum over all slices) for the "beam" block of the JSONs
 void orc_engine_beam_stats (void* h, double* out /* n, sum w, sum|x|, sum|y|, sum|z|, sum|uz| */) {
     Engine* e = static_cast<Engine*>(h);
     for (int k = 0; k < 6; ++k) out[k] = 0;
     Beam b;
     for (int isl = e->d.nz - 1; isl >= 0; --isl) {
-        e->init_beam_slice(isl, b);
+        e->gen_beam_slice(isl, b);
         out[0] += (double)b.x.size();
         for (size_t k = 0; k < b.x.size(); ++k) { out[1] += b.w[k]; out[2] += std::abs(b.x[k]); out[3] += std::abs(b.y[k]); out[4] += std::abs(b.z[k]); out[5] += std::abs(b.uz[k]); }
     }

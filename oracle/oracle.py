@@ -131,6 +131,12 @@ def lib():
         L.orc_engine_vcycles.argtypes = [C.c_void_p]
         L.orc_engine_times.restype = None
         L.orc_engine_times.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_engine_beam_layout.restype = C.c_long
+        L.orc_engine_beam_layout.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_engine_set_external_beam.restype = None
+        L.orc_engine_set_external_beam.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_engine_initial_beam.restype = None
+        L.orc_engine_initial_beam.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_engine_beam_stats.restype = None
         L.orc_engine_beam_stats.argtypes = [C.c_void_p, C.c_void_p]
         _LIB = L
@@ -296,6 +302,25 @@ class Engine:
         buf = (C.c_double * (11 * n)).from_address(lib().orc_engine_particles(self._h))
         vb = (C.c_int32 * n).from_address(lib().orc_engine_valid(self._h))
         return np.frombuffer(buf, dtype=np.float64).reshape(11, n), np.frombuffer(vb, dtype=np.int32)
+
+    # --- beam blocks, same layout and method names as hipace_amd.api.SliceEngine (pipeline tests) ---
+    def beam_layout(self):
+        off = np.zeros(self.deck["nz"] + 1, dtype=np.int64)
+        n = lib().orc_engine_beam_layout(self._h, _ptr(off))
+        return n, off
+
+    def set_beam_storage(self, tensor):
+        """tensor: CPU float64 torch tensor or numpy array of 7*nbeam doubles (kept alive by the caller)."""
+        self._beam_keep = tensor
+        ptr = tensor.data_ptr() if hasattr(tensor, "data_ptr") else tensor.ctypes.data
+        lib().orc_engine_set_external_beam(self._h, C.c_void_p(ptr) if tensor is not None else None)
+
+    def initial_beam_into(self, tensor):
+        ptr = tensor.data_ptr() if hasattr(tensor, "data_ptr") else tensor.ctypes.data
+        lib().orc_engine_initial_beam(self._h, C.c_void_p(ptr))
+
+    def sync(self):
+        pass
 
     def checksums(self):
         out = np.zeros(self.ncomp)

@@ -357,3 +357,19 @@ def test_engine_checksums_any_tiling(api, tile_size, period):
     for k, v in gold.items():
         if v != 0.0:
             assert abs(cs[k] - v) <= 1e-9 * abs(v), (k, cs[k], v)
+
+
+def test_pipeline_driver_single_rank_on_gpu(api):
+    """The ring driver with world_size 1 (in-process hand-off, MultiBuffer.cpp:299-308) on the GPU:
+    the beam reaches step 1 only through the hand-off buffers."""
+    import torch
+    from hipace_amd.pipeline import run_pipeline
+    gold = json.load(open(os.path.join(GOLD, "blowout_wake_explicit.2Rank.json")))["lev=0"]
+    eng = api.SliceEngine(decks.blowout_wake())
+    eng.set_diagnostics(True)
+    sums = {}
+    solved = run_pipeline(eng, 0, 1, 2, torch.device("cuda", 0), on_step_end=lambda s: sums.__setitem__(s, eng.checksums()))
+    assert solved == 200 and set(sums) == {0, 1}
+    for k, v in gold.items():
+        if v != 0.0:
+            assert abs(sums[1][k] - v) <= 1e-9 * abs(v), (k, sums[1][k], v)

@@ -1,0 +1,78 @@
+"""Ring pipeline over time steps, world_size 2, gloo on CPU.
+
+The product driver (hipace_amd/pipeline.py) is run unchanged; the CPU oracle engine stands in for
+the HIP engine (same beam-block interface), so this checks the message schedule: the head rank
+injects the beam, every other (rank, step) gets it slice by slice through the ring, no deadlock,
+and every step reproduces the single-process checksums (hipace.dt = 0: all steps are identical) --
+the reference's own 2-rank test asserts exactly that (tests/blowout_wake.2Rank.sh: same JSON as 1 rank).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from hipace_amd import decks
+
+
+def _deck():
+    d = decks.blowout_wake()
+    d.update(nx=32, ny=32, nz=24, lo=(-8.0, -8.0, -1.44), hi=(8.0, 8.0, 1.44), n_steps=1,
+             beam_zmin=-1.4, beam_zmax=1.4)
+    return d
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_steps, out):
+    import torch.distributed as dist
+    from hipace_amd.pipeline import run_pipeline
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = O.Engine(_deck())
+    sums = {}
+
+    def on_step_end(step):
+        sums[step] = eng.checksums()
+
+    solved = run_pipeline(eng, rank, world, n_steps, "cpu", on_step_end)
+    out.put((rank, solved, sums))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_steps", [(2, 3), (2, 2), (1, 2)])
+def test_ring_pipeline_matches_single_process(oracle, world, n_steps):
+    ref = oracle.Engine(_deck())
+    ref.run()
+    want = ref.checksums()
+    assert want["jz_beam"] > 0
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_steps, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seen = set()
+    nz = _deck()["nz"]
+    for rank, solved, sums in results:
+        assert solved == nz * len(range(rank, n_steps, world))
+        for step, cs in sums.items():
+            assert step % world == rank
+            seen.add(step)
+            for k, v in want.items():
+                assert abs(cs[k] - v) <= 1e-12 * max(abs(v), 1e-300), (rank, step, k, cs[k], v)
+    assert seen == set(range(n_steps))
