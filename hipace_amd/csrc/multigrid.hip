@@ -43,7 +43,11 @@ __device__ long long* g_mg_dbg = nullptr;
 
 constexpr int GT_X = 64, GT_Y = 32;          // cells swept per tile
 constexpr int GA_X = GT_X + 2, GA_Y = GT_Y + 2;
-constexpr int GPAIRS = GT_X*GT_Y/2/256;      // cell pairs per thread = 4
+#ifndef HPS_MG_NT
+#define HPS_MG_NT 512
+#endif
+constexpr int MG_NT = HPS_MG_NT;             // threads per smoother workgroup
+constexpr int GPAIRS = GT_X*GT_Y/2/MG_NT;    // cell pairs per thread
 
 // diagonal of the operator at (i,j): -(a + 2(fx+fy)) with the wall modification (gs1 :265-292)
 template <bool CC>
@@ -111,7 +115,8 @@ __device__ __forceinline__ void block_max_to (unsigned long long* addr, double v
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double m = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+        double m = 0.0;
+        for (int w = 0; w < MG_NT/64; ++w) m = fmax(m, s_red[w]);
         // non-negative doubles order like their bit patterns
         const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
         if (bits > __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(addr, bits);
@@ -135,11 +140,11 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], doub
     // fill LDS (ring included): start value inside the unknowns' box, 0 elsewhere.  Loads are
     // unconditional (clamped address + select) and all issued before the first LDS store.
     {
-        constexpr int NF = (GA_X*GA_Y + 255)/256;
+        constexpr int NF = (GA_X*GA_Y + MG_NT - 1)/MG_NT;
         double v0[NF], v1[NF];
 #pragma unroll
         for (int m = 0; m < NF; ++m) {
-            const int s = min(tid + 256*m, GA_X*GA_Y - 1);
+            const int s = min(tid + MG_NT*m, GA_X*GA_Y - 1);
             const int lj = s / GA_X, li = s - lj*GA_X;
             const int i = gi0 - 1 + li, j = gj0 - 1 + lj;
             v0[m] = 0.0; v1[m] = 0.0;
@@ -153,53 +158,57 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], doub
         }
 #pragma unroll
         for (int m = 0; m < NF; ++m) {
-            const int s = tid + 256*m;
+            const int s = tid + MG_NT*m;
             if (s < GA_X*GA_Y) { s_phi[0][s] = v0[m]; s_phi[1][s] = v1[m]; }
         }
     }
     MG_STAMP(1);
 
-    // per-thread cell pairs: rhs, coefficient and inverse diagonal stay in registers
+    // per-thread cell pairs: rhs, coefficient and inverse diagonal stay in registers.  Index p is the
+    // sweep parity in which the cell is updated (p = 0: sweeps 0 and 2, p = 1: sweeps 1 and 3), so
+    // that every register array below is indexed by compile-time constants only.
     double r0[GPAIRS][2], r1[GPAIRS][2], ac[GPAIRS][2], ci[GPAIRS][2];
     bool in[GPAIRS][2];
+    int hx[GPAIRS];                                   // x offset (0/1) within the pair of the p = 0 cell
     double rmax = 0.0;
 #pragma unroll
     for (int m = 0; m < GPAIRS; ++m) {
-        const int pi = tid + 256*m;
+        const int pi = tid + MG_NT*m;
         const int jj = pi / (GT_X/2), pk = pi - jj*(GT_X/2);
         const int j = gj0 + jj;
+        hx[m] = (gi0 + 2*pk + j) & 1;                 // colour 0 cell: (i + j) even
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int i = gi0 + 2*pk + h;
+        for (int p = 0; p < 2; ++p) {
+            const int i = gi0 + 2*pk + (hx[m] ^ p);
             const int ic = INTERIOR ? i : min(max(i, b.vlx), b.vhx), jc = INTERIOR ? j : min(max(j, b.vly), b.vhy);
             const bool ok = INTERIOR || (ic == i && jc == j);
-            in[m][h] = ok;
+            in[m][p] = ok;
             const double a0 = rhs(ic, jc, 0), a1 = rhs(ic, jc, 1), a2 = acf(ic, jc, 0);
-            r0[m][h] = ok ? a0 : 0.0;
-            r1[m][h] = ok ? a1 : 0.0;
-            ac[m][h] = ok ? a2 : 0.0;
-            ci[m][h] = 1.0/diag_c0<CC>(i, j, b, ac[m][h], facx, facy);
-            if (rhsnorm) rmax = fmax(rmax, fmax(fabs(r0[m][h]), fabs(r1[m][h])));
+            r0[m][p] = ok ? a0 : 0.0;
+            r1[m][p] = ok ? a1 : 0.0;
+            ac[m][p] = ok ? a2 : 0.0;
+            ci[m][p] = 1.0/diag_c0<CC>(i, j, b, ac[m][p], facx, facy);
+            if (rhsnorm) rmax = fmax(rmax, fmax(fabs(r0[m][p]), fabs(r1[m][p])));
         }
     }
     __syncthreads();
     MG_STAMP(2);
 
+#pragma unroll
     for (int icolor = 0; icolor < 4; ++icolor) {
+        constexpr int dummy = 0; (void)dummy;
+        const int p = icolor & 1;                     // compile-time after unrolling
 #pragma unroll
         for (int m = 0; m < GPAIRS; ++m) {
-            const int pi = tid + 256*m;
+            const int pi = tid + MG_NT*m;
             const int jj = pi / (GT_X/2), pk = pi - jj*(GT_X/2);
             const int j = gj0 + jj;
-            const int ia = gi0 + 2*pk;
-            const int h = (ia + j + icolor) & 1;          // which cell of the pair has this colour
-            const int i = ia + h;
+            const int h = hx[m] ^ p;
+            const int i = gi0 + 2*pk + h;
             const int o = (jj + 1)*GA_X + 2*pk + h + 1;
-            const double rr0 = h ? r0[m][1] : r0[m][0], rr1 = h ? r1[m][1] : r1[m][0], cc = h ? ci[m][1] : ci[m][0];
-            const bool ok = h ? in[m][1] : in[m][0];
-            const double n0 = (rr0 - offdiag<CC, INTERIOR>((const double*)&s_phi[0][o], GA_X, i, j, b, facx, facy))*cc;
-            const double n1 = (rr1 - offdiag<CC, INTERIOR>((const double*)&s_phi[1][o], GA_X, i, j, b, facx, facy))*cc;
-            if (INTERIOR || ok) { s_phi[0][o] = n0; s_phi[1][o] = n1; }
+            const double n0 = (r0[m][p] - offdiag<CC, INTERIOR>((const double*)&s_phi[0][o], GA_X, i, j, b, facx, facy))*ci[m][p];
+            const double n1 = (r1[m][p] - offdiag<CC, INTERIOR>((const double*)&s_phi[1][o], GA_X, i, j, b, facx, facy))*ci[m][p];
+            if (INTERIOR || in[m][p]) { s_phi[0][o] = n0; s_phi[1][o] = n1; }
         }
         __syncthreads();
     }
@@ -208,40 +217,44 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], doub
     double resmax = 0.0;
 #pragma unroll
     for (int m = 0; m < GPAIRS; ++m) {
-        const int pi = tid + 256*m;
+        const int pi = tid + MG_NT*m;
         const int jj = pi / (GT_X/2), pk = pi - jj*(GT_X/2);
         const int j = gj0 + jj;
         const bool rowok = (jj >= E && jj < GT_Y - E);
-        double q0[2] = {0.0, 0.0}, q1[2] = {0.0, 0.0};
+        double q0[2], q1[2];                          // by sweep parity p
         bool fin[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ii = 2*pk + h;
-            fin[h] = rowok && ii >= E && ii < GT_X - E && in[m][h];
+        for (int p = 0; p < 2; ++p) {
+            const int ii = 2*pk + (hx[m] ^ p);
+            fin[p] = rowok && ii >= E && ii < GT_X - E && in[m][p];
             const int i = gi0 + ii;
             const int o = (jj + 1)*GA_X + ii + 1;
+            q0[p] = 0.0; q1[p] = 0.0;
             if (DO_RES) {
-                const double t0 = residual_at<INTERIOR>((const double*)&s_phi[0][o], GA_X, i, j, b, r0[m][h], ac[m][h], facx, facy);
-                const double t1 = residual_at<INTERIOR>((const double*)&s_phi[1][o], GA_X, i, j, b, r1[m][h], ac[m][h], facx, facy);
-                q0[h] = fin[h] ? t0 : 0.0; q1[h] = fin[h] ? t1 : 0.0;
-                resmax = fmax(resmax, fmax(fabs(q0[h]), fabs(q1[h])));
+                const double t0 = residual_at<INTERIOR>((const double*)&s_phi[0][o], GA_X, i, j, b, r0[m][p], ac[m][p], facx, facy);
+                const double t1 = residual_at<INTERIOR>((const double*)&s_phi[1][o], GA_X, i, j, b, r1[m][p], ac[m][p], facx, facy);
+                q0[p] = fin[p] ? t0 : 0.0; q1[p] = fin[p] ? t1 : 0.0;
+                resmax = fmax(resmax, fmax(fabs(q0[p]), fabs(q1[p])));
             }
-            if (fin[h]) {
-                if (DO_RES && !FUSE_R) { res_out(i, j, 0) = q0[h]; res_out(i, j, 1) = q1[h]; }
+            if (fin[p]) {
+                if (DO_RES && !FUSE_R) { res_out(i, j, 0) = q0[p]; res_out(i, j, 1) = q1[p]; }
                 phi_out(i, j, 0) = s_phi[0][o];
                 phi_out(i, j, 1) = s_phi[1][o];
             }
         }
         if (FUSE_R) {
-            // restrict_cc (:29-37): 0.25*(((a+b)+c)+d), a,b this row (even j), c,d the row above.
-            // Tile origins are even, so a pair is one coarse cell's x-extent and lanes l / l+32
-            // of a wave hold rows jj / jj+1.
-            const double c0 = __shfl_down(q0[0], 32), d0 = __shfl_down(q0[1], 32);
-            const double c1 = __shfl_down(q1[0], 32), d1 = __shfl_down(q1[1], 32);
+            // restrict_cc (:29-37): 0.25*(((a+b)+c)+d), a,b = left,right cell of this row (even j),
+            // c,d the row above.  Tile origins are even, so a pair is one coarse cell's x-extent and
+            // lanes l / l+32 of a wave hold rows jj / jj+1.
+            const bool sw = (hx[m] != 0);             // the p = 0 cell is the right one
+            const double la0 = sw ? q0[1] : q0[0], ra0 = sw ? q0[0] : q0[1];
+            const double la1 = sw ? q1[1] : q1[0], ra1 = sw ? q1[0] : q1[1];
+            const double c0 = __shfl_down(la0, 32), d0 = __shfl_down(ra0, 32);
+            const double c1 = __shfl_down(la1, 32), d1 = __shfl_down(ra1, 32);
             if (fin[0] && ((tid & 32) == 0)) {
                 const int ic = (gi0 + 2*pk) >> 1, jc = j >> 1;
-                cres_out(ic, jc, 0) = 0.25*(q0[0] + q0[1] + c0 + d0);
-                cres_out(ic, jc, 1) = 0.25*(q1[0] + q1[1] + c1 + d1);
+                cres_out(ic, jc, 0) = 0.25*(la0 + ra0 + c0 + d0);
+                cres_out(ic, jc, 1) = 0.25*(la1 + ra1 + c1 + d1);
             }
         }
     }
@@ -252,14 +265,14 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], doub
 }
 
 template <bool CC, int SRC, bool DO_RES, bool FUSE_R>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(MG_NT)
 void k_smooth (LevBox b, FView phi_out, FView rhs, FView acf, FView phi_in, FView crse, FView res_out,
                FView cres_out, double facx, double facy, int ntx, unsigned long long* resnorm,
                unsigned long long* rhsnorm)
 {
     static_assert(!FUSE_R || (CC && DO_RES), "fused restriction is cell-centred only");
     __shared__ double s_phi[2][GA_Y*GA_X];
-    __shared__ double s_red[4];
+    __shared__ double s_red[MG_NT/64];
     constexpr int E = DO_RES ? 4 : 3;
     constexpr int FX = GT_X - 2*E, FY = GT_Y - 2*E;   // cells a tile finalises (even numbers)
     const int bx = blockIdx.x % ntx, by = blockIdx.x / ntx;
@@ -561,7 +574,7 @@ static void launch_smooth (Multigrid* M, int il, FView phi_out, FView rhs, FView
     const double ldx = M->dx*fac, ldy = M->dy*fac;
     const double facx = 1.0/(ldx*ldx), facy = 1.0/(ldy*ldy);
     constexpr bool FUSE = CC && DO_RES;
-    hipLaunchKernelGGL((k_smooth<CC, SRC, DO_RES, FUSE>), dim3(ntx*nty), dim3(256), 0, st, b, phi_out, rhs, acf, phi_in, crse,
+    hipLaunchKernelGGL((k_smooth<CC, SRC, DO_RES, FUSE>), dim3(ntx*nty), dim3(MG_NT), 0, st, b, phi_out, rhs, acf, phi_in, crse,
                        res_out, cres_out, facx, facy, ntx, resnorm, rhsnorm);
 }
 
