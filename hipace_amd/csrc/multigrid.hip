@@ -137,33 +137,6 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], doub
     constexpr int E = DO_RES ? 4 : 3;                 // rim of the swept tile that is not final
     const int tid = threadIdx.x;
     MG_STAMP(0);
-    // fill LDS (ring included): start value inside the unknowns' box, 0 elsewhere.  Loads are
-    // unconditional (clamped address + select) and all issued before the first LDS store.
-    {
-        constexpr int NF = (GA_X*GA_Y + MG_NT - 1)/MG_NT;
-        double v0[NF], v1[NF];
-#pragma unroll
-        for (int m = 0; m < NF; ++m) {
-            const int s = min(tid + MG_NT*m, GA_X*GA_Y - 1);
-            const int lj = s / GA_X, li = s - lj*GA_X;
-            const int i = gi0 - 1 + li, j = gj0 - 1 + lj;
-            v0[m] = 0.0; v1[m] = 0.0;
-            if (SRC != SRC_ZERO) {
-                const int ic = INTERIOR ? i : min(max(i, b.vlx), b.vhx), jc = INTERIOR ? j : min(max(j, b.vly), b.vhy);
-                double a0 = phi_in(ic, jc, 0), a1 = phi_in(ic, jc, 1);
-                if (SRC == SRC_PROLONG) { a0 += prolong_at<CC>(crse, ic, jc, 0); a1 += prolong_at<CC>(crse, ic, jc, 1); }
-                const bool inside = INTERIOR || (ic == i && jc == j);
-                v0[m] = inside ? a0 : 0.0; v1[m] = inside ? a1 : 0.0;
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < NF; ++m) {
-            const int s = tid + MG_NT*m;
-            if (s < GA_X*GA_Y) { s_phi[0][s] = v0[m]; s_phi[1][s] = v1[m]; }
-        }
-    }
-    MG_STAMP(1);
-
     // per-thread cell pairs: rhs, coefficient and inverse diagonal stay in registers.  Index p is the
     // sweep parity in which the cell is updated (p = 0: sweeps 0 and 2, p = 1: sweeps 1 and 3), so
     // that every register array below is indexed by compile-time constants only.
@@ -189,6 +162,32 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], doub
             ac[m][p] = ok ? a2 : 0.0;
             ci[m][p] = 1.0/diag_c0<CC>(i, j, b, ac[m][p], facx, facy);
             if (rhsnorm) rmax = fmax(rmax, fmax(fabs(r0[m][p]), fabs(r1[m][p])));
+        }
+    }
+    MG_STAMP(1);
+    // fill LDS (ring included): start value inside the unknowns' box, 0 elsewhere.  Loads are
+    // unconditional (clamped address + select) and all issued before the first LDS store.
+    {
+        constexpr int NF = (GA_X*GA_Y + MG_NT - 1)/MG_NT;
+        double v0[NF], v1[NF];
+#pragma unroll
+        for (int m = 0; m < NF; ++m) {
+            const int s = min(tid + MG_NT*m, GA_X*GA_Y - 1);
+            const int lj = s / GA_X, li = s - lj*GA_X;
+            const int i = gi0 - 1 + li, j = gj0 - 1 + lj;
+            v0[m] = 0.0; v1[m] = 0.0;
+            if (SRC != SRC_ZERO) {
+                const int ic = INTERIOR ? i : min(max(i, b.vlx), b.vhx), jc = INTERIOR ? j : min(max(j, b.vly), b.vhy);
+                double a0 = phi_in(ic, jc, 0), a1 = phi_in(ic, jc, 1);
+                if (SRC == SRC_PROLONG) { a0 += prolong_at<CC>(crse, ic, jc, 0); a1 += prolong_at<CC>(crse, ic, jc, 1); }
+                const bool inside = INTERIOR || (ic == i && jc == j);
+                v0[m] = inside ? a0 : 0.0; v1[m] = inside ? a1 : 0.0;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NF; ++m) {
+            const int s = tid + MG_NT*m;
+            if (s < GA_X*GA_Y) { s_phi[0][s] = v0[m]; s_phi[1][s] = v1[m]; }
         }
     }
     __syncthreads();
@@ -268,9 +267,10 @@ template <bool CC, int SRC, bool DO_RES, bool FUSE_R>
 __global__ __launch_bounds__(MG_NT)
 void k_smooth (LevBox b, FView phi_out, FView rhs, FView acf, FView phi_in, FView crse, FView res_out,
                FView cres_out, double facx, double facy, int ntx, unsigned long long* resnorm,
-               unsigned long long* rhsnorm)
+               unsigned long long* rhsnorm, const int* done)
 {
     static_assert(!FUSE_R || (CC && DO_RES), "fused restriction is cell-centred only");
+    if (done && *done) return;
     __shared__ double s_phi[2][GA_Y*GA_X];
     __shared__ double s_red[MG_NT/64];
     constexpr int E = DO_RES ? 4 : 3;
@@ -299,8 +299,9 @@ __device__ __forceinline__ double restrict_at (const FView& fine, int i, int j, 
 
 template <bool CC>
 __global__ __launch_bounds__(256)
-void k_restrict (LevBox cb, FView crse, FView fine, int ncomp)
+void k_restrict (LevBox cb, FView crse, FView fine, int ncomp, const int* done)
 {
+    if (done && *done) return;
     const int i = cb.vlx + blockIdx.x*blockDim.x + threadIdx.x;
     const int j = cb.vly + blockIdx.y;
     if (i > cb.vhx || j > cb.vhy) return;
@@ -382,8 +383,9 @@ __device__ void low_zero_cor (lds_double* base, const LowLev& l)
 template <bool CC>
 __global__ __launch_bounds__(1024)
 void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, const double* __restrict__ res_g,
-                double* __restrict__ cor_g, double facx0, double facy0, int nsweeps_bottom)
+                double* __restrict__ cor_g, double facx0, double facy0, int nsweeps_bottom, const int* done)
 {
+    if (done && *done) return;
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_double* base = (lds_double*)lds_raw;
     MG_STAMP(8);
@@ -475,6 +477,33 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
     MG_STAMP(14);
 }
 
+// Device-side stopping rule (solve_doit :1352-1398): V-cycles are enqueued speculatively, every
+// kernel of a V-cycle returns at once when `done` is set, and the host reads the block once.
+struct MGCtrl { double target, max_norm, last_norm; int done, iters, diverged, pad; };
+
+__global__ void k_ctrl_init (unsigned long long* norms, MGCtrl* c, double tol_rel, double tol_abs)
+{
+    const double res0 = __longlong_as_double((long long)norms[0]), rhs0 = __longlong_as_double((long long)norms[1]);
+    const double max_norm = (rhs0 >= res0) ? rhs0 : res0;
+    c->max_norm = max_norm;
+    c->target = fmax(tol_abs, fmax(tol_rel, 1.e-16)*max_norm);
+    c->last_norm = res0;
+    c->done = (res0 <= c->target) ? 1 : 0;
+    c->iters = 0; c->diverged = 0;
+    norms[0] = 0ULL;
+}
+
+__global__ void k_ctrl_check (unsigned long long* norms, MGCtrl* c)
+{
+    if (c->done) return;
+    const double n = __longlong_as_double((long long)norms[0]);
+    c->iters += 1;
+    c->last_norm = n;
+    if (n <= c->target) c->done = 1;
+    else if (!(n <= 1.e20*c->max_norm)) { c->done = 1; c->diverged = 1; }
+    norms[0] = 0ULL;
+}
+
 __global__ void k_copy2 (LevBox b, FView dst, FView src)
 {
     const int i = b.vlx + blockIdx.x*blockDim.x + threadIdx.x;
@@ -493,13 +522,14 @@ struct Multigrid {
     int lowv_begin = 1;                         // first level handled by k_lower_v
     LowLev* d_low = nullptr; size_t low_lds = 0;
     unsigned long long* d_norms = nullptr;      // [0] residual, [1] rhs
-    unsigned long long* h_norms = nullptr;      // pinned
+    MGCtrl* d_ctrl = nullptr; MGCtrl* h_ctrl = nullptr;     // device block + pinned host copy
+    int last_iters = 1;                         // V-cycles of the previous solve = speculation depth
     FView sol, rhs, acf0;                       // level-0 user views (set per solve)
 
     ~Multigrid () {
         for (auto& l : L) { (void)hipFree(l.acf); (void)hipFree(l.res); (void)hipFree(l.cor); (void)hipFree(l.rescor); }
-        (void)hipFree(d_norms); (void)hipFree(d_low);
-        if (h_norms) (void)hipHostFree(h_norms);
+        (void)hipFree(d_norms); (void)hipFree(d_low); (void)hipFree(d_ctrl);
+        if (h_ctrl) (void)hipHostFree(h_ctrl);
     }
     FView lv (int il, double* p) const {
         const MGLevelDev& l = L[il];
@@ -556,7 +586,8 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
     HPS_HIP_CHECK(hipMalloc(&M->d_low, low.size()*sizeof(LowLev)));
     HPS_HIP_CHECK(hipMemcpy(M->d_low, low.data(), low.size()*sizeof(LowLev), hipMemcpyHostToDevice));
     HPS_HIP_CHECK(hipMalloc(&M->d_norms, 2*sizeof(unsigned long long)));
-    HPS_HIP_CHECK(hipHostMalloc(&M->h_norms, 2*sizeof(unsigned long long)));
+    HPS_HIP_CHECK(hipMalloc(&M->d_ctrl, sizeof(MGCtrl)));
+    HPS_HIP_CHECK(hipHostMalloc(&M->h_ctrl, sizeof(MGCtrl)));
     *out = M;
     return HPS_OK;
 }
@@ -564,7 +595,7 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
 template <bool CC, int SRC, bool DO_RES>
 static void launch_smooth (Multigrid* M, int il, FView phi_out, FView rhs, FView acf, FView phi_in, FView crse,
                            FView res_out, FView cres_out, unsigned long long* resnorm, unsigned long long* rhsnorm,
-                           hipStream_t st)
+                           const int* done, hipStream_t st)
 {
     const LevBox& b = M->L[il].b;
     constexpr int E = DO_RES ? 4 : 3;
@@ -575,16 +606,16 @@ static void launch_smooth (Multigrid* M, int il, FView phi_out, FView rhs, FView
     const double facx = 1.0/(ldx*ldx), facy = 1.0/(ldy*ldy);
     constexpr bool FUSE = CC && DO_RES;
     hipLaunchKernelGGL((k_smooth<CC, SRC, DO_RES, FUSE>), dim3(ntx*nty), dim3(MG_NT), 0, st, b, phi_out, rhs, acf, phi_in, crse,
-                       res_out, cres_out, facx, facy, ntx, resnorm, rhsnorm);
+                       res_out, cres_out, facx, facy, ntx, resnorm, rhsnorm, done);
 }
 
 template <bool CC>
-static void restrict_residual_if_nodal (Multigrid* M, int il, hipStream_t st)
+static void restrict_residual_if_nodal (Multigrid* M, int il, const int* done, hipStream_t st)
 {
     if (CC) return;     // fused into k_smooth
     const LevBox& cb = M->L[il+1].b;
     hipLaunchKernelGGL(k_restrict<CC>, dim3(ceil_div(cb.vhx - cb.vlx + 1, 64), cb.vhy - cb.vly + 1), dim3(64), 0, st,
-                       cb, M->lv(il+1, M->L[il+1].res), M->lv(il, M->L[il].rescor), 2);
+                       cb, M->lv(il+1, M->L[il+1].res), M->lv(il, M->L[il].rescor), 2, done);
 }
 
 // one V-cycle (vcycle :1429-1512).  On entry res[1] = R(rhs - L(cor[0])); on exit again, plus
@@ -595,10 +626,11 @@ static void vcycle (Multigrid* M, hipStream_t st)
     const int nl = M->nlev();
     const int lb = M->lowv_begin;
     const FView none{};
+    const int* done = &M->d_ctrl->done;
     for (int il = 1; il < lb; ++il) {
         launch_smooth<CC, SRC_ZERO, true>(M, il, M->lv(il, M->L[il].cor), M->lv(il, M->L[il].res), M->lv(il, M->L[il].acf), none, none,
-                                          M->lv(il, M->L[il].rescor), M->lv(il+1, M->L[il+1].res), nullptr, nullptr, st);
-        restrict_residual_if_nodal<CC>(M, il, st);
+                                          M->lv(il, M->L[il].rescor), M->lv(il+1, M->L[il+1].res), nullptr, nullptr, done, st);
+        restrict_residual_if_nodal<CC>(M, il, done, st);
     }
     {
         const double fac = (double)(1 << lb);
@@ -606,25 +638,24 @@ static void vcycle (Multigrid* M, hipStream_t st)
         const LevBox& bb = M->L[nl-1].b;
         const int nsweeps = std::max(16, (std::max(bb.hix - bb.lox + 1, bb.hiy - bb.loy + 1) + 1)/2*2);
         hipLaunchKernelGGL(k_lower_v<CC>, dim3(1), dim3(1024), M->low_lds, st, M->d_low, nl - lb, M->L[lb].acf, M->L[lb].res,
-                           M->L[lb].cor, 1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps);
+                           M->L[lb].cor, 1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, done);
     }
     // up-leg: the smoothed correction of level il lands in rescor[il] (out of place)
     for (int il = lb - 1; il >= 1; --il) {
         double* crse = (il + 1 == lb) ? M->L[il+1].cor : M->L[il+1].rescor;
         launch_smooth<CC, SRC_PROLONG, false>(M, il, M->lv(il, M->L[il].rescor), M->lv(il, M->L[il].res), M->lv(il, M->L[il].acf),
-                                              M->lv(il, M->L[il].cor), M->lv(il+1, crse), none, none, nullptr, nullptr, st);
+                                              M->lv(il, M->L[il].cor), M->lv(il+1, crse), none, none, nullptr, nullptr, done, st);
     }
     {
         double* crse = (1 == lb) ? M->L[1].cor : M->L[1].rescor;
         launch_smooth<CC, SRC_PROLONG, false>(M, 0, M->sol, M->rhs, M->acf0, M->lv(0, M->L[0].cor), M->lv(1, crse), none, none,
-                                              nullptr, nullptr, st);
+                                              nullptr, nullptr, done, st);
     }
     launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), M->rhs, M->acf0, M->sol, none, M->lv(0, M->L[0].rescor),
-                                        M->lv(1, M->L[1].res), M->d_norms, nullptr, st);
-    restrict_residual_if_nodal<CC>(M, 0, st);
+                                        M->lv(1, M->L[1].res), M->d_norms, nullptr, done, st);
+    restrict_residual_if_nodal<CC>(M, 0, done, st);
+    hipLaunchKernelGGL(k_ctrl_check, dim3(1), dim3(1), 0, st, M->d_norms, M->d_ctrl);
 }
-
-static inline double norm_value (unsigned long long bits) { double d; memcpy(&d, &bits, 8); return d; }
 
 template <bool CC>
 static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_iters, int* iters_out, double* resnorm_out,
@@ -636,40 +667,35 @@ static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_it
         const LevBox& cb = M->L[il].b;
         FView fine = (il == 1) ? M->acf0 : M->lv(il-1, M->L[il-1].acf);
         hipLaunchKernelGGL(k_restrict<CC>, dim3(ceil_div(cb.vhx - cb.vlx + 1, 64), cb.vhy - cb.vly + 1), dim3(64), 0, st,
-                           cb, M->lv(il, M->L[il].acf), fine, 1);
+                           cb, M->lv(il, M->L[il].acf), fine, 1, (const int*)nullptr);
     }
     HPS_HIP_CHECK(hipMemsetAsync(M->d_norms, 0, 2*sizeof(unsigned long long), st));
     // cor[0] = GSRB^4(sol), residual norm, rhs norm, res[1] = R(residual)  (solve_doit :1319-1346)
     launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), M->rhs, M->acf0, M->sol, FView{}, M->lv(0, M->L[0].rescor),
-                                        M->lv(1, M->L[1].res), M->d_norms, M->d_norms + 1, st);
-    restrict_residual_if_nodal<CC>(M, 0, st);
-    HPS_HIP_CHECK(hipMemcpyAsync(M->h_norms, M->d_norms, 2*sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    HPS_HIP_CHECK(hipStreamSynchronize(st));
-    const double resnorm0 = norm_value(M->h_norms[0]), rhsnorm0 = norm_value(M->h_norms[1]);
-    const double max_norm = (rhsnorm0 >= resnorm0) ? rhsnorm0 : resnorm0;
-    const double res_target = std::max(tol_abs, std::max(tol_rel, 1.e-16)*max_norm);
-    int iters = 0; double norminf = resnorm0; int status = HPS_OK;
-    if (resnorm0 > res_target) {
-        bool converged = false;
-        for (int iter = 0; iter < max_iters; ++iter) {
-            HPS_HIP_CHECK(hipMemsetAsync(M->d_norms, 0, sizeof(unsigned long long), st));
-            vcycle<CC>(M, st);
-            ++iters;
-            HPS_HIP_CHECK(hipMemcpyAsync(M->h_norms, M->d_norms, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-            HPS_HIP_CHECK(hipStreamSynchronize(st));
-            norminf = norm_value(M->h_norms[0]);
-            if (norminf <= res_target) { converged = true; break; }
-            if (!(norminf <= 1.e20*max_norm)) { set_error("hps_mg_solve1: diverging"); status = HPS_ERR_MG_DIVERGED; break; }
-        }
-        if (!converged && status == HPS_OK) { set_error("hps_mg_solve1: not converged after max_iters V-cycles"); status = HPS_ERR_MG_MAXITER; }
+                                        M->lv(1, M->L[1].res), M->d_norms, M->d_norms + 1, nullptr, st);
+    restrict_residual_if_nodal<CC>(M, 0, nullptr, st);
+    hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, st, M->d_norms, M->d_ctrl, tol_rel, tol_abs);
+    // speculate as many V-cycles as the previous solve needed; each one is a no-op once converged
+    int status = HPS_OK;
+    int nspec = std::min(std::max(M->last_iters, 1), std::max(max_iters, 1));
+    int enq = 0;
+    while (true) {
+        for (int v = 0; v < nspec && enq < max_iters; ++v, ++enq) vcycle<CC>(M, st);
+        HPS_HIP_CHECK(hipMemcpyAsync(M->h_ctrl, M->d_ctrl, sizeof(MGCtrl), hipMemcpyDeviceToHost, st));
+        HPS_HIP_CHECK(hipStreamSynchronize(st));
+        if (M->h_ctrl->done) break;
+        if (enq >= max_iters) { set_error("hps_mg_solve1: not converged after max_iters V-cycles"); status = HPS_ERR_MG_MAXITER; break; }
+        nspec = 1;
     }
+    if (M->h_ctrl->diverged) { set_error("hps_mg_solve1: diverging"); status = HPS_ERR_MG_DIVERGED; }
+    M->last_iters = std::max(1, M->h_ctrl->iters);
     // solution = cor[0] on the unknowns (solve_doit :1419-1426)
     const LevBox& b0 = M->L[0].b;
     hipLaunchKernelGGL(k_copy2, dim3(ceil_div(b0.vhx - b0.vlx + 1, 64), b0.vhy - b0.vly + 1), dim3(64), 0, st,
                        b0, M->sol, M->lv(0, M->L[0].cor));
     HPS_HIP_CHECK(hipGetLastError());
-    if (iters_out) *iters_out = iters;
-    if (resnorm_out) *resnorm_out = norminf;
+    if (iters_out) *iters_out = M->h_ctrl->iters;
+    if (resnorm_out) *resnorm_out = M->h_ctrl->last_norm;
     return status;
 }
 

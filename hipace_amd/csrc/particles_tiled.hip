@@ -18,6 +18,10 @@ namespace hps {
 
 constexpr int TILE_HALO = 8;
 
+// optional shader-clock stamps of one workgroup (hps_particles_debug_stamps)
+__device__ long long* g_pt_dbg = nullptr;
+#define PT_STAMP(i) do { if (g_pt_dbg && blockIdx.x == 2000 && threadIdx.x == 0) g_pt_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+
 struct CompSlots { int n; int comp[6]; };   // active deposition components, in DepComps order
 
 typedef __attribute__((address_space(3))) double lds_double;
@@ -32,36 +36,63 @@ __device__ __forceinline__ double lds_get (const double* p)
     return *(const lds_double*)p;
 }
 
-template <int ORDER, int TS>
+// MASK: compile-time set of deposited components (bit c = DepComps entry c), -1 = decide at run time.
+// With a compile-time set the 9x4 accumulations are straight-line ds_add_f64 with immediate offsets.
+template <int ORDER, int TS, int MASK>
 __global__ __launch_bounds__(256)
 void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx, DepComps cm,
                       PartConsts k, int* n_qsa, int* n_fallback)
 {
     constexpr int R = TS + 2*TILE_HALO;
-    extern __shared__ __attribute__((aligned(16))) double acc[];     // [6 slots][R*R], unused slots not allocated
+    extern __shared__ __attribute__((aligned(16))) double acc[];     // [active comps][R*R]
+    const int gc[6] = {cm.jx, cm.jy, cm.jz, cm.rho, cm.chi, cm.rhomjz};
     // slot of each component (compacted)
     int slot[6]; int na = 0;
-    slot[0] = cm.jx >= 0 ? na++ : -1;  slot[1] = cm.jy >= 0 ? na++ : -1;  slot[2] = cm.jz >= 0 ? na++ : -1;
-    slot[3] = cm.rho >= 0 ? na++ : -1; slot[4] = cm.chi >= 0 ? na++ : -1; slot[5] = cm.rhomjz >= 0 ? na++ : -1;
-    const int gc[6] = {cm.jx, cm.jy, cm.jz, cm.rho, cm.chi, cm.rhomjz};
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const bool on = (MASK >= 0) ? ((MASK >> c) & 1) : (gc[c] >= 0);
+        slot[c] = on ? na++ : -1;
+    }
 
     const int tile = blockIdx.x;
     const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
     const int tid = threadIdx.x;
+    PT_STAMP(0);
     for (int s = tid; s < na*R*R; s += 256) acc[s] = 0.0;
     __syncthreads();
+    PT_STAMP(1);
 
     const int pend = offsets[tile + 1];
     int nfb = 0;
-    for (int ip = offsets[tile] + tid; ip < pend; ip += 256) {
-        const uint64_t id = pl.idcpu[ip];
+    // software pipeline: the loads of the next particle are in flight while this one is deposited
+    struct Rec { double x, y, w, ux, uy, psi; uint64_t id; int ion; };
+    auto fetch = [&] (int ip) {
+        Rec r;
+        r.id = pl.idcpu[ip]; r.x = pl.x[ip]; r.y = pl.y[ip]; r.w = pl.w[ip];
+        r.ux = pl.ux[ip]; r.uy = pl.uy[ip]; r.psi = pl.psi[ip];
+        r.ion = k.can_ionize ? pl.ion_lev[ip] : 1;
+        return r;
+    };
+    // NB particles per thread are fetched back to back (NB*7 loads in flight per lane) before any
+    // of them is processed: the kernel is bound by memory-level parallelism, not by issue slots
+    constexpr int NB = 4;
+    for (int ip0 = offsets[tile] + tid; ip0 < pend; ip0 += 256*NB) {
+      Rec rec[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) { const int q = min(ip0 + 256*u, pend - 1); rec[u] = fetch(q); }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int ip = ip0 + 256*u;
+        if (ip >= pend) break;
+        const Rec cur = rec[u];
+        const uint64_t id = cur.id;
         if (!(id & HPS_ID_VALID)) continue;
-        const double psi_inv = 1.0/pl.psi[ip];
-        const double vx_c = pl.ux[ip]*psi_inv;
-        const double vy_c = pl.uy[ip]*psi_inv;
-        double q_invvol = k.a*pl.w[ip];
+        const double psi_inv = 1.0/cur.psi;
+        const double vx_c = cur.ux*psi_inv;
+        const double vy_c = cur.uy*psi_inv;
+        double q_invvol = k.a*cur.w;
         double q_mu0_mass = k.b;
-        if (k.can_ionize) { const double il = (double)pl.ion_lev[ip]; q_invvol *= il; q_mu0_mass *= il; }
+        if (k.can_ionize) { const double il = (double)cur.ion; q_invvol *= il; q_mu0_mass *= il; }
         const double gamma_psi = 0.5*(psi_inv*psi_inv + vx_c*vx_c*k.c_inv*k.c_inv + vy_c*vy_c*k.c_inv*k.c_inv + 1.0);
         if (gamma_psi < 0.0 || gamma_psi > k.max_qsa || psi_inv < 0.0) {
             if (n_qsa) atomicAdd(n_qsa, 1);
@@ -70,8 +101,8 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             continue;
         }
         double sx[ORDER + 1], sy[ORDER + 1];
-        const int i0 = shape_weights<ORDER>((pl.x[ip] - k.xoff)*k.dx_inv, sx);
-        const int j0 = shape_weights<ORDER>((pl.y[ip] - k.yoff)*k.dy_inv, sy);
+        const int i0 = shape_weights<ORDER>((cur.x - k.xoff)*k.dx_inv, sx);
+        const int j0 = shape_weights<ORDER>((cur.y - k.yoff)*k.dy_inv, sy);
         // per-component weights in DepComps order
         const double wv[6] = {vx_c, vy_c, (gamma_psi - 1.0)*k.c, gamma_psi, q_mu0_mass*psi_inv, 1.0};
         const int li = i0 - ox, lj = j0 - oy;
@@ -99,9 +130,12 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
                 }
             }
         }
+      }
     }
     if (n_fallback && nfb) atomicAdd(n_fallback, nfb);
+    PT_STAMP(2);
     __syncthreads();
+    PT_STAMP(3);
 
     // flush the touched cells; halo cells are shared with neighbouring tiles -> atomics
     for (int s = tid; s < R*R; s += 256) {
@@ -117,6 +151,7 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             }
         }
     }
+    PT_STAMP(4);
 }
 
 // image of `nc` slab components over the tile region into LDS (0 outside the slab box)
@@ -335,10 +370,13 @@ int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
     const int R = T->g.ts + 2*TILE_HALO;
     const size_t lds = (size_t)na*R*R*sizeof(double);
     SlabView f(slab);
-#define CALL(O, S) { if (int e = set_lds(k_deposit_tiled<O, S>, lds)) return e; \
-        hipLaunchKernelGGL((k_deposit_tiled<O, S>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback); }
+    int mask = 0; for (int c = 0; c < 6; ++c) mask |= (comp[c] >= 0) << c;
+#define CALLM(O, S, M) { if (int e = set_lds(k_deposit_tiled<O, S, M>, lds)) return e; \
+        hipLaunchKernelGGL((k_deposit_tiled<O, S, M>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback); }
+#define CALL(O, S) { if (mask == 51) CALLM(O, S, 51) else if (mask == 59) CALLM(O, S, 59) else if (mask == 32) CALLM(O, S, 32) else CALLM(O, S, -1) }
     HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
 #undef CALL
+#undef CALLM
     HPS_HIP_CHECK(hipGetLastError());
     return HPS_OK;
 }
@@ -393,6 +431,20 @@ int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_
 } // namespace hps
 
 using namespace hps;
+
+extern "C" int hps_particles_debug_stamps (long long* stamps8_host)
+{
+    static long long* d = nullptr;
+    if (!d) {
+        HPS_HIP_CHECK(hipMalloc(&d, 8*sizeof(long long)));
+        HPS_HIP_CHECK(hipMemset(d, 0, 8*sizeof(long long)));
+        HPS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_pt_dbg), &d, sizeof(d)));
+        return HPS_OK;
+    }
+    HPS_HIP_CHECK(hipDeviceSynchronize());
+    HPS_HIP_CHECK(hipMemcpy(stamps8_host, d, 8*sizeof(long long), hipMemcpyDeviceToHost));
+    return HPS_OK;
+}
 
 static int check_tiling (void* tiling, const hps_slab& s, const hps_plasma& pl, const char* what)
 {
