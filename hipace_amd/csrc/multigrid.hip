@@ -41,7 +41,10 @@ enum { SRC_ZERO = 0, SRC_DIRECT = 1, SRC_PROLONG = 2 };
 __device__ long long* g_mg_dbg = nullptr;
 #define MG_STAMP(i) do { if (g_mg_dbg && blockIdx.x == 0 && threadIdx.x == 0) g_mg_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
-constexpr int GT_X = 64, GT_Y = 32;          // cells swept per tile
+#ifndef HPS_MG_TY
+#define HPS_MG_TY 32
+#endif
+constexpr int GT_X = 64, GT_Y = HPS_MG_TY;          // cells swept per tile
 constexpr int GA_X = GT_X + 2, GA_Y = GT_Y + 2;
 #ifndef HPS_MG_NT
 #define HPS_MG_NT 512
@@ -77,6 +80,21 @@ __device__ __forceinline__ double offdiag (P c, int sy, int i, int j, const LevB
     return lx + ly;
 }
 
+// The same with per-cell multipliers, for arrays whose cells outside the unknowns' box hold 0:
+// fxm = facx*(4/3) on a cell-centred wall column, facx elsewhere (fym alike), so that
+// fxm*(w + e) is facx*(4/3)*e at the low wall (w = 0 and 0 + e == e), facx*(4/3)*w at the high wall
+// and facx*(w + e) inside -- the values of gs1 :265-292 without a select or a branch per neighbour.
+template <class P>
+__device__ __forceinline__ double offdiag_m (P c, int sy, double fxm, double fym)
+{
+    return fxm*(c[-1] + c[1]) + fym*(c[-sy] + c[sy]);
+}
+template <bool CC>
+__device__ __forceinline__ double wall_mult (int i, int lo, int hi, double fac)
+{
+    return (CC && (i == lo || i == hi)) ? fac*(4./3.) : fac;
+}
+
 // residual rhs - L(phi) at (i,j) (laplacian :162-182, residual1 :184-190), branch-free as above
 template <bool INTERIOR = false, class P>
 __device__ __forceinline__ double residual_at (P c, int sy, int i, int j, const LevBox& b,
@@ -107,6 +125,24 @@ __device__ __forceinline__ double prolong_at (const FView& crse, int i, int j, i
     return crse(ic, jc, n);
 }
 
+// Device-side stopping rule (solve_doit :1352-1398).  norms[0] = initial residual norm, norms[1] =
+// rhs norm, norms[2+k] = residual norm after V-cycle k (all zeroed before a solve).  V-cycles are
+// enqueued speculatively; every kernel of V-cycle k evaluates the rule itself and returns at once
+// if V-cycle k-1 already met the target (an inactive V-cycle leaves its slot at 0, which switches
+// off all later ones).  k < 0: unconditional.
+constexpr int MG_MAX_VCYCLES = 1024;
+struct StopRule { const unsigned long long* norms; int k; double tol_rel, tol_abs; };
+
+__device__ __forceinline__ bool vcycle_active (const StopRule& sr)
+{
+    if (sr.k < 0) return true;
+    const double res0 = __longlong_as_double((long long)sr.norms[0]), rhs0 = __longlong_as_double((long long)sr.norms[1]);
+    const double prev = (sr.k == 0) ? res0 : __longlong_as_double((long long)sr.norms[2 + sr.k - 1]);
+    const double max_norm = (rhs0 >= res0) ? rhs0 : res0;
+    const double target = fmax(sr.tol_abs, fmax(sr.tol_rel, 1.e-16)*max_norm);
+    return prev > target && prev <= 1.e20*max_norm;
+}
+
 // max-norm accumulation: one atomic per workgroup at most, and only if it would raise the maximum
 // (same-address L2 atomics serialise: 4 per workgroup cost ~60 us on an 817-workgroup launch)
 __device__ __forceinline__ void block_max_to (unsigned long long* addr, double v, double* s_red)
@@ -130,7 +166,7 @@ __device__ __forceinline__ void block_max_to (unsigned long long* addr, double v
 // INTERIOR tiles (no swept cell on a wall / outside the box) take a path without masks.
 template <bool CC, int SRC, bool DO_RES, bool FUSE_R, bool INTERIOR>
 __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], double* s_red, const LevBox& b, const FView& phi_out,
-                                             const FView& rhs, const FView& acf, const FView& phi_in, const FView& crse,
+                                             const FView& phi_out2, const FView& rhs, const FView& acf, const FView& phi_in, const FView& crse,
                                              const FView& res_out, const FView& cres_out, double facx, double facy,
                                              int gi0, int gj0, unsigned long long* resnorm, unsigned long long* rhsnorm)
 {
@@ -143,6 +179,7 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], doub
     double r0[GPAIRS][2], r1[GPAIRS][2], ac[GPAIRS][2], ci[GPAIRS][2];
     bool in[GPAIRS][2];
     int hx[GPAIRS];                                   // x offset (0/1) within the pair of the p = 0 cell
+    double fxm[GPAIRS][2], fym[GPAIRS];               // wall multipliers (boundary tiles only)
     double rmax = 0.0;
 #pragma unroll
     for (int m = 0; m < GPAIRS; ++m) {
@@ -150,9 +187,11 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], doub
         const int jj = pi / (GT_X/2), pk = pi - jj*(GT_X/2);
         const int j = gj0 + jj;
         hx[m] = (gi0 + 2*pk + j) & 1;                 // colour 0 cell: (i + j) even
+        fym[m] = INTERIOR ? facy : wall_mult<CC>(j, b.loy, b.hiy, facy);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int i = gi0 + 2*pk + (hx[m] ^ p);
+            fxm[m][p] = INTERIOR ? facx : wall_mult<CC>(i, b.lox, b.hix, facx);
             const int ic = INTERIOR ? i : min(max(i, b.vlx), b.vhx), jc = INTERIOR ? j : min(max(j, b.vly), b.vhy);
             const bool ok = INTERIOR || (ic == i && jc == j);
             in[m][p] = ok;
@@ -205,8 +244,9 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], doub
             const int h = hx[m] ^ p;
             const int i = gi0 + 2*pk + h;
             const int o = (jj + 1)*GA_X + 2*pk + h + 1;
-            const double n0 = (r0[m][p] - offdiag<CC, INTERIOR>((const double*)&s_phi[0][o], GA_X, i, j, b, facx, facy))*ci[m][p];
-            const double n1 = (r1[m][p] - offdiag<CC, INTERIOR>((const double*)&s_phi[1][o], GA_X, i, j, b, facx, facy))*ci[m][p];
+            (void)i; (void)j;
+            const double n0 = (r0[m][p] - offdiag_m((const double*)&s_phi[0][o], GA_X, fxm[m][p], fym[m]))*ci[m][p];
+            const double n1 = (r1[m][p] - offdiag_m((const double*)&s_phi[1][o], GA_X, fxm[m][p], fym[m]))*ci[m][p];
             if (INTERIOR || in[m][p]) { s_phi[0][o] = n0; s_phi[1][o] = n1; }
         }
         __syncthreads();
@@ -237,8 +277,10 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], doub
             }
             if (fin[p]) {
                 if (DO_RES && !FUSE_R) { res_out(i, j, 0) = q0[p]; res_out(i, j, 1) = q1[p]; }
-                phi_out(i, j, 0) = s_phi[0][o];
-                phi_out(i, j, 1) = s_phi[1][o];
+                const double f0 = s_phi[0][o], f1 = s_phi[1][o];
+                phi_out(i, j, 0) = f0;
+                phi_out(i, j, 1) = f1;
+                if (phi_out2.p) { phi_out2(i, j, 0) = f0; phi_out2(i, j, 1) = f1; }
             }
         }
         if (FUSE_R) {
@@ -265,12 +307,12 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], doub
 
 template <bool CC, int SRC, bool DO_RES, bool FUSE_R>
 __global__ __launch_bounds__(MG_NT)
-void k_smooth (LevBox b, FView phi_out, FView rhs, FView acf, FView phi_in, FView crse, FView res_out,
+void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FView phi_in, FView crse, FView res_out,
                FView cres_out, double facx, double facy, int ntx, unsigned long long* resnorm,
-               unsigned long long* rhsnorm, const int* done)
+               unsigned long long* rhsnorm, StopRule sr)
 {
     static_assert(!FUSE_R || (CC && DO_RES), "fused restriction is cell-centred only");
-    if (done && *done) return;
+    if (!vcycle_active(sr)) return;
     __shared__ double s_phi[2][GA_Y*GA_X];
     __shared__ double s_red[MG_NT/64];
     constexpr int E = DO_RES ? 4 : 3;
@@ -281,9 +323,9 @@ void k_smooth (LevBox b, FView phi_out, FView rhs, FView acf, FView phi_in, FVie
     // every swept cell and its ring strictly inside the unknowns' box and off the walls
     const bool interior = (gi0 - 1 >= b.vlx) && (gi0 + GT_X <= b.vhx) && (gj0 - 1 >= b.vly) && (gj0 + GT_Y <= b.vhy)
                        && (gi0 > b.lox) && (gi0 + GT_X - 1 < b.hix) && (gj0 > b.loy) && (gj0 + GT_Y - 1 < b.hiy);
-    if (interior) smooth_tile<CC, SRC, DO_RES, FUSE_R, true>(s_phi, s_red, b, phi_out, rhs, acf, phi_in, crse, res_out, cres_out,
+    if (interior) smooth_tile<CC, SRC, DO_RES, FUSE_R, true>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
                                                              facx, facy, gi0, gj0, resnorm, rhsnorm);
-    else          smooth_tile<CC, SRC, DO_RES, FUSE_R, false>(s_phi, s_red, b, phi_out, rhs, acf, phi_in, crse, res_out, cres_out,
+    else          smooth_tile<CC, SRC, DO_RES, FUSE_R, false>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
                                                               facx, facy, gi0, gj0, resnorm, rhsnorm);
 }
 
@@ -299,9 +341,9 @@ __device__ __forceinline__ double restrict_at (const FView& fine, int i, int j, 
 
 template <bool CC>
 __global__ __launch_bounds__(256)
-void k_restrict (LevBox cb, FView crse, FView fine, int ncomp, const int* done)
+void k_restrict (LevBox cb, FView crse, FView fine, int ncomp, StopRule sr)
 {
-    if (done && *done) return;
+    if (!vcycle_active(sr)) return;
     const int i = cb.vlx + blockIdx.x*blockDim.x + threadIdx.x;
     const int j = cb.vly + blockIdx.y;
     if (i > cb.vhx || j > cb.vhy) return;
@@ -383,9 +425,9 @@ __device__ void low_zero_cor (lds_double* base, const LowLev& l)
 template <bool CC>
 __global__ __launch_bounds__(1024)
 void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, const double* __restrict__ res_g,
-                double* __restrict__ cor_g, double facx0, double facy0, int nsweeps_bottom, const int* done)
+                double* __restrict__ cor_g, double facx0, double facy0, int nsweeps_bottom, StopRule sr)
 {
-    if (done && *done) return;
+    if (!vcycle_active(sr)) return;
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_double* base = (lds_double*)lds_raw;
     MG_STAMP(8);
@@ -477,31 +519,317 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
     MG_STAMP(14);
 }
 
-// Device-side stopping rule (solve_doit :1352-1398): V-cycles are enqueued speculatively, every
-// kernel of a V-cycle returns at once when `done` is set, and the host reads the block once.
-struct MGCtrl { double target, max_norm, last_norm; int done, iters, diverged, pad; };
+// ---------------------------------------------------------------------------------------------
+// Cell-centred lower V, register/LDS resident, from the first level with at most 64 x 64 cells.
+// Level A (index 0 here): 1024 threads x 2 cell pairs, rhs / coefficient / inverse diagonal in
+// registers, the correction in two ringed LDS planes.  Levels below: one thread per cell (thread
+// t <-> cell (t & 31, t >> 5), so a wave always holds two complete rows and the 4-average of the
+// restriction is three lane shuffles), six LDS planes each: cor0 cor1 | res0 res1 | acf | 1/diag.
+// The first sweep of every down-leg level starts from cor = 0, where the update is rhs/diag exactly.
+constexpr int LOW2_MAXLEV = 8;
+struct Low2 { int nl; int total; int nx[LOW2_MAXLEV], ny[LOW2_MAXLEV], off[LOW2_MAXLEV]; };
 
-__global__ void k_ctrl_init (unsigned long long* norms, MGCtrl* c, double tol_rel, double tol_abs)
+__device__ __forceinline__ LevBox cc_box (int nx, int ny) { return LevBox{0, 0, nx - 1, ny - 1, 0, 0, nx - 1, ny - 1}; }
+
+// sweeps s_begin .. s_end-1 of one thread-per-cell level
+__device__ __forceinline__ void tpc_sweeps (lds_double* c0, lds_double* c1, int pitch, int i, int j, bool ok, const LevBox& b,
+                                            double r0, double r1, double ci, double fx, double fy, int s_begin, int s_end)
 {
-    const double res0 = __longlong_as_double((long long)norms[0]), rhs0 = __longlong_as_double((long long)norms[1]);
-    const double max_norm = (rhs0 >= res0) ? rhs0 : res0;
-    c->max_norm = max_norm;
-    c->target = fmax(tol_abs, fmax(tol_rel, 1.e-16)*max_norm);
-    c->last_norm = res0;
-    c->done = (res0 <= c->target) ? 1 : 0;
-    c->iters = 0; c->diverged = 0;
-    norms[0] = 0ULL;
+    const int o = (j + 1)*pitch + i + 1;
+    const double fxm = wall_mult<true>(i, b.lox, b.hix, fx), fym = wall_mult<true>(j, b.loy, b.hiy, fy);
+    for (int s = s_begin; s < s_end; ++s) {
+        if (ok && (((i + j + s) & 1) == 0)) {
+            const double n0 = (r0 - offdiag_m((const lds_double*)(c0 + o), pitch, fxm, fym))*ci;
+            const double n1 = (r1 - offdiag_m((const lds_double*)(c1 + o), pitch, fxm, fym))*ci;
+            c0[o] = n0; c1[o] = n1;
+        }
+        __syncthreads();
+    }
 }
 
-__global__ void k_ctrl_check (unsigned long long* norms, MGCtrl* c)
+__global__ __launch_bounds__(1024)
+void k_lower_v2 (const Low2* __restrict__ dp, const double* __restrict__ acf_g, const double* __restrict__ res_g, double* __restrict__ cor_g,
+                 double facx0, double facy0, int nsweeps_bottom, StopRule sr)
 {
-    if (c->done) return;
-    const double n = __longlong_as_double((long long)norms[0]);
-    c->iters += 1;
-    c->last_norm = n;
-    if (n <= c->target) c->done = 1;
-    else if (!(n <= 1.e20*c->max_norm)) { c->done = 1; c->diverged = 1; }
-    norms[0] = 0ULL;
+    if (!vcycle_active(sr)) return;
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    lds_double* base = (lds_double*)lds_raw;
+    const int t = threadIdx.x;
+    const Low2& d = *dp;          // uniform (scalar) loads; a by-value copy indexed by level would live in scratch
+    MG_STAMP(8);
+    // ---- level A registers
+    const int nxA = d.nx[0], nyA = d.ny[0], pA = nxA + 2, psA = pA*(nyA + 2), cellsA = nxA*nyA;
+    const LevBox bA = cc_box(nxA, nyA);
+    lds_double* const a0p = base + d.off[0];
+    lds_double* const a1p = a0p + psA;
+    double rA0[2][2], rA1[2][2], aA[2][2], cA[2][2], fxA[2][2], fyA[2];
+    bool inA[2][2];
+    int hxA[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int pi = t + 1024*m;
+        const int j = pi >> 5, pk = pi & 31;
+        hxA[m] = (2*pk + j) & 1;
+        fyA[m] = wall_mult<true>(j, 0, nyA - 1, facy0);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int i = 2*pk + (hxA[m] ^ p);
+            fxA[m][p] = wall_mult<true>(i, 0, nxA - 1, facx0);
+            const bool ok = (i < nxA) && (j < nyA);
+            const int idx = min(i, nxA - 1) + min(j, nyA - 1)*nxA;
+            const double v0 = res_g[idx], v1 = res_g[cellsA + idx], v2 = acf_g[idx];
+            inA[m][p] = ok;
+            rA0[m][p] = ok ? v0 : 0.0; rA1[m][p] = ok ? v1 : 0.0; aA[m][p] = ok ? v2 : 0.0;
+            cA[m][p] = 1.0/diag_c0<true>(i, j, bA, aA[m][p], facx0, facy0);
+        }
+    }
+    for (int s = t; s < d.total; s += 1024) base[s] = 0.0;
+    __syncthreads();
+    // ---- coefficient hierarchy (average_down_acoef) and inverse diagonals
+    if (d.nl > 1) {
+        const int p1 = d.nx[1] + 2, ps1 = p1*(d.ny[1] + 2);
+        lds_double* acf1 = base + d.off[1] + 4*ps1;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int pi = t + 1024*m;
+            const int j = pi >> 5, pk = pi & 31;
+            const bool sw = (hxA[m] != 0);
+            const double la = sw ? aA[m][1] : aA[m][0], ra = sw ? aA[m][0] : aA[m][1];
+            const double c = __shfl_down(la, 32), e = __shfl_down(ra, 32);
+            if (((t & 32) == 0) && 2*pk < nxA && j < nyA) acf1[((j >> 1) + 1)*p1 + pk + 1] = 0.25*(la + ra + c + e);
+        }
+        __syncthreads();
+    }
+    const int ti = t & 31, tj = t >> 5;
+    {
+        double fx = facx0, fy = facy0;
+        for (int l = 1; l < d.nl; ++l) {
+            fx *= 0.25; fy *= 0.25;
+            const int nx = d.nx[l], ny = d.ny[l], pl = nx + 2, ps = pl*(ny + 2);
+            lds_double* acf = base + d.off[l] + 4*ps;
+            const bool ok = ti < nx && tj < ny;
+            const double a = ok ? acf[(tj + 1)*pl + ti + 1] : 0.0;
+            if (ok) acf[ps + (tj + 1)*pl + ti + 1] = 1.0/diag_c0<true>(ti, tj, cc_box(nx, ny), a, fx, fy);
+            if (l + 1 < d.nl) {
+                const double b1 = __shfl_down(a, 1), c = __shfl_down(a, 32), e = __shfl_down(a, 33);
+                const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
+                if (ok && !(ti & 1) && !(tj & 1)) base[d.off[l+1] + 4*psn + ((tj >> 1) + 1)*pn + (ti >> 1) + 1] = 0.25*(a + b1 + c + e);
+            }
+            __syncthreads();
+        }
+    }
+    MG_STAMP(9);
+    // ---- level A down-leg
+    const bool bottomA = (d.nl == 1);
+    {
+        // sweep pairs with a compile-time parity: the register arrays must never be indexed by a
+        // run-time value (the compiler would move them to scratch)
+        const int nsw = bottomA ? nsweeps_bottom : 4;       // even
+        for (int s = 0; s < nsw; s += 2) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int pi = t + 1024*m;
+                    const int j = pi >> 5, pk = pi & 31;
+                    const int i = 2*pk + (hxA[m] ^ p);
+                    const int o = (j + 1)*pA + i + 1;
+                    if (inA[m][p]) {
+                        const double n0 = (rA0[m][p] - offdiag_m((const lds_double*)(a0p + o), pA, fxA[m][p], fyA[m]))*cA[m][p];
+                        const double n1 = (rA1[m][p] - offdiag_m((const lds_double*)(a1p + o), pA, fxA[m][p], fyA[m]))*cA[m][p];
+                        a0p[o] = n0; a1p[o] = n1;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (!bottomA) {
+        // residual of level A, restricted straight into the rhs planes of level 1
+        const int p1 = d.nx[1] + 2, ps1 = p1*(d.ny[1] + 2);
+        lds_double* res1 = base + d.off[1] + 2*ps1;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int pi = t + 1024*m;
+            const int j = pi >> 5, pk = pi & 31;
+            double q0[2], q1[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int i = 2*pk + (hxA[m] ^ p);
+                const int o = (min(j, nyA - 1) + 1)*pA + min(i, nxA - 1) + 1;
+                const double u0 = residual_at<false>((const lds_double*)(a0p + o), pA, i, j, bA, rA0[m][p], aA[m][p], facx0, facy0);
+                const double u1 = residual_at<false>((const lds_double*)(a1p + o), pA, i, j, bA, rA1[m][p], aA[m][p], facx0, facy0);
+                q0[p] = inA[m][p] ? u0 : 0.0; q1[p] = inA[m][p] ? u1 : 0.0;
+            }
+            const bool sw = (hxA[m] != 0);
+            const double la0 = sw ? q0[1] : q0[0], ra0 = sw ? q0[0] : q0[1];
+            const double la1 = sw ? q1[1] : q1[0], ra1 = sw ? q1[0] : q1[1];
+            const double c0 = __shfl_down(la0, 32), e0 = __shfl_down(ra0, 32);
+            const double c1 = __shfl_down(la1, 32), e1 = __shfl_down(ra1, 32);
+            if (((t & 32) == 0) && 2*pk < nxA && j < nyA) {
+                const int oc = ((j >> 1) + 1)*p1 + pk + 1;
+                res1[oc] = 0.25*(la0 + ra0 + c0 + e0);
+                res1[ps1 + oc] = 0.25*(la1 + ra1 + c1 + e1);
+            }
+        }
+        __syncthreads();
+    }
+    MG_STAMP(10);
+    // ---- levels 1 .. nl-1 down (the last one is the bottom solve)
+    double fx = facx0, fy = facy0;
+    for (int l = 1; l < d.nl; ++l) {
+        fx *= 0.25; fy *= 0.25;
+        const int nx = d.nx[l], ny = d.ny[l], pl = nx + 2, ps = pl*(ny + 2);
+        lds_double* c0 = base + d.off[l];
+        lds_double* c1 = c0 + ps;
+        const LevBox b = cc_box(nx, ny);
+        const bool ok = ti < nx && tj < ny;
+        const int o = (min(tj, ny - 1) + 1)*pl + min(ti, nx - 1) + 1;
+        const double r0 = c0[2*ps + o], r1 = c0[3*ps + o], a = c0[4*ps + o], ci = c0[5*ps + o];
+        const bool last = (l == d.nl - 1);
+        if (ok && (((ti + tj) & 1) == 0)) { c0[o] = r0*ci; c1[o] = r1*ci; }     // sweep 0 from cor = 0
+        __syncthreads();
+        tpc_sweeps(c0, c1, pl, ti, tj, ok, b, r0, r1, ci, fx, fy, 1, last ? nsweeps_bottom : 4);
+        if (!last) {
+            const double u0 = residual_at<false>((const lds_double*)(c0 + o), pl, ti, tj, b, r0, a, fx, fy);
+            const double u1 = residual_at<false>((const lds_double*)(c1 + o), pl, ti, tj, b, r1, a, fx, fy);
+            const double q0 = ok ? u0 : 0.0, q1 = ok ? u1 : 0.0;
+            const double b0 = __shfl_down(q0, 1), g0 = __shfl_down(q0, 32), e0 = __shfl_down(q0, 33);
+            const double b1 = __shfl_down(q1, 1), g1 = __shfl_down(q1, 32), e1 = __shfl_down(q1, 33);
+            const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
+            if (ok && !(ti & 1) && !(tj & 1)) {
+                lds_double* rn = base + d.off[l+1] + 2*psn + ((tj >> 1) + 1)*pn + (ti >> 1) + 1;
+                rn[0] = 0.25*(q0 + b0 + g0 + e0);
+                rn[psn] = 0.25*(q1 + b1 + g1 + e1);
+            }
+            __syncthreads();
+        }
+    }
+    MG_STAMP(11);
+    // the rhs of level A was dropped from the registers after its residual: fetch it again now, so
+    // that the (L2) latency hides behind the up-leg of the small levels
+    double uA0[2][2], uA1[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int pi = t + 1024*m;
+        const int j = pi >> 5, pk = pi & 31;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int i = 2*pk + (hxA[m] ^ p);
+            const int idx = min(i, nxA - 1) + min(j, nyA - 1)*nxA;
+            uA0[m][p] = __builtin_nontemporal_load(res_g + idx);
+            uA1[m][p] = __builtin_nontemporal_load(res_g + cellsA + idx);
+        }
+    }
+    // ---- up-leg of the thread-per-cell levels
+    for (int l = d.nl - 2; l >= 1; --l) {
+        fx *= 4.0; fy *= 4.0;
+        const int nx = d.nx[l], ny = d.ny[l], pl = nx + 2, ps = pl*(ny + 2);
+        const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
+        lds_double* c0 = base + d.off[l];
+        lds_double* c1 = c0 + ps;
+        const lds_double* k0 = base + d.off[l+1];
+        const bool ok = ti < nx && tj < ny;
+        const int o = (min(tj, ny - 1) + 1)*pl + min(ti, nx - 1) + 1;
+        const double r0 = c0[2*ps + o], r1 = c0[3*ps + o], ci = c0[5*ps + o];
+        if (ok) {
+            const int oc = ((tj >> 1) + 1)*pn + (ti >> 1) + 1;
+            c0[o] = c0[o] + k0[oc];
+            c1[o] = c1[o] + k0[psn + oc];
+        }
+        __syncthreads();
+        tpc_sweeps(c0, c1, pl, ti, tj, ok, cc_box(nx, ny), r0, r1, ci, fx, fy, 0, 4);
+    }
+    MG_STAMP(12);
+    // ---- up-leg of level A and store
+    if (!bottomA) {
+        const int pn = d.nx[1] + 2, psn = pn*(d.ny[1] + 2);
+        const lds_double* k0 = base + d.off[1];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int pi = t + 1024*m;
+            const int j = pi >> 5, pk = pi & 31;
+            const int oc = ((j >> 1) + 1)*pn + pk + 1;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (inA[m][p]) {
+                    const int o = (j + 1)*pA + 2*pk + (hxA[m] ^ p) + 1;
+                    a0p[o] = a0p[o] + k0[oc];
+                    a1p[o] = a1p[o] + k0[psn + oc];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            constexpr int dummy = 0; (void)dummy;
+            const int p = s & 1;                  // compile-time after unrolling
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int pi = t + 1024*m;
+                const int j = pi >> 5, pk = pi & 31;
+                const int i = 2*pk + (hxA[m] ^ p);
+                const int o = (j + 1)*pA + i + 1;
+                if (inA[m][p]) {
+                    const double n0 = (uA0[m][p] - offdiag_m((const lds_double*)(a0p + o), pA, fxA[m][p], fyA[m]))*cA[m][p];
+                    const double n1 = (uA1[m][p] - offdiag_m((const lds_double*)(a1p + o), pA, fxA[m][p], fyA[m]))*cA[m][p];
+                    a0p[o] = n0; a1p[o] = n1;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    MG_STAMP(13);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int pi = t + 1024*m;
+        const int j = pi >> 5, pk = pi & 31;
+        if (j < nyA && 2*pk < nxA) {
+            const int o = (j + 1)*pA + 2*pk + 1;
+            const int idx = 2*pk + j*nxA;
+            cor_g[idx] = a0p[o]; cor_g[cellsA + idx] = a1p[o];
+            if (2*pk + 1 < nxA) { cor_g[idx + 1] = a0p[o + 1]; cor_g[cellsA + idx + 1] = a1p[o + 1]; }
+        }
+    }
+    MG_STAMP(14);
+}
+
+// Coefficient pyramid, cell-centred (average_down_acoef, HpMultiGrid.cpp:1640-1700): one launch
+// derives levels 1..nlev_out from level 0.  A workgroup owns a 32 x 32 block of level-0 cells;
+// thread t holds the level-1 cell (t & 15, t >> 4) of the block and levels 2.. go through LDS.
+// The nested 0.25*(((a+b)+c)+d) order of restrict_cc is kept at every level.
+struct PyrOut { double* p[5]; int nx[5], ny[5]; };      // levels 1..5, row pitch = nx
+
+__global__ __launch_bounds__(256)
+void k_acf_pyramid (FView acf0, int nx0, int ny0, PyrOut out, int nlev_out)
+{
+    __shared__ double s_a[2][16*16];
+    const int t = threadIdx.x;
+    const int bi = blockIdx.x*32, bj = blockIdx.y*32;       // level-0 origin of the block
+    int li = t & 15, lj = t >> 4;
+    double v = 0.0;
+    {
+        const int i = bi + 2*li, j = bj + 2*lj;
+        if (i + 1 < nx0 && j + 1 < ny0) v = 0.25*(acf0(i, j, 0) + acf0(i+1, j, 0) + acf0(i, j+1, 0) + acf0(i+1, j+1, 0));
+        const int ic = (bi >> 1) + li, jc = (bj >> 1) + lj;
+        if (ic < out.nx[0] && jc < out.ny[0]) out.p[0][ic + (long)jc*out.nx[0]] = v;
+        s_a[0][t] = v;
+    }
+    int n = 16, cur = 0;
+    for (int l = 1; l < nlev_out; ++l) {
+        __syncthreads();
+        n >>= 1;
+        if (t < n*n) {
+            li = t % n; lj = t / n;
+            const double* f = s_a[cur];
+            const int w = 2*n;
+            v = 0.25*(f[2*li + 2*lj*w] + f[2*li + 1 + 2*lj*w] + f[2*li + (2*lj + 1)*w] + f[2*li + 1 + (2*lj + 1)*w]);
+            const int ic = (bi >> (l + 1)) + li, jc = (bj >> (l + 1)) + lj;
+            if (ic < out.nx[l] && jc < out.ny[l]) out.p[l][ic + (long)jc*out.nx[l]] = v;
+            s_a[cur ^ 1][t] = v;
+        }
+        cur ^= 1;
+    }
 }
 
 __global__ void k_copy2 (LevBox b, FView dst, FView src)
@@ -522,14 +850,16 @@ struct Multigrid {
     int lowv_begin = 1;                         // first level handled by k_lower_v
     LowLev* d_low = nullptr; size_t low_lds = 0;
     unsigned long long* d_norms = nullptr;      // [0] residual, [1] rhs
-    MGCtrl* d_ctrl = nullptr; MGCtrl* h_ctrl = nullptr;     // device block + pinned host copy
+    unsigned long long* h_norms = nullptr;      // pinned copy of d_norms (2 + MG_MAX_VCYCLES slots)
     int last_iters = 1;                         // V-cycles of the previous solve = speculation depth
+    bool use_low2 = false; Low2 low2{}; Low2* d_low2 = nullptr; size_t low2_lds = 0;   // cell-centred register/LDS lower V
+    double* tmp0 = nullptr;                     // level-0 scratch: smoothed solution before the last GSRB^4
     FView sol, rhs, acf0;                       // level-0 user views (set per solve)
 
     ~Multigrid () {
         for (auto& l : L) { (void)hipFree(l.acf); (void)hipFree(l.res); (void)hipFree(l.cor); (void)hipFree(l.rescor); }
-        (void)hipFree(d_norms); (void)hipFree(d_low); (void)hipFree(d_ctrl);
-        if (h_ctrl) (void)hipHostFree(h_ctrl);
+        (void)hipFree(d_norms); (void)hipFree(d_low); (void)hipFree(tmp0); (void)hipFree(d_low2);
+        if (h_norms) (void)hipHostFree(h_norms);
     }
     FView lv (int il, double* p) const {
         const MGLevelDev& l = L[il];
@@ -571,6 +901,31 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
     const int nl = M->nlev();
     M->lowv_begin = nl - 1;
     for (int il = nl - 1; il >= 1; --il) if (M->L[il].cells <= LOWV_MAX_CELLS) M->lowv_begin = il;
+    if (M->cc && !getenv("HPS_MG_OLD_LOWV")) {
+        // first level with at most 64 x 64 cells whose coarser levels all fit 32 x 32
+        for (int il = 1; il < nl; ++il) {
+            const LevBox& b = M->L[il].b;
+            const bool fits = (b.hix + 1 <= 64) && (b.hiy + 1 <= 64) && (nl - il <= LOW2_MAXLEV)
+                           && (il + 1 >= nl || (M->L[il+1].b.hix + 1 <= 32 && M->L[il+1].b.hiy + 1 <= 32));
+            if (!fits) continue;
+            M->use_low2 = true; M->lowv_begin = il;
+            Low2& d = M->low2;
+            d.nl = nl - il;
+            int off2 = 0;
+            for (int k = 0; k < d.nl; ++k) {
+                const LevBox& bk = M->L[il + k].b;
+                d.nx[k] = bk.hix + 1; d.ny[k] = bk.hiy + 1; d.off[k] = off2;
+                off2 += (k == 0 ? 2 : 6)*(d.nx[k] + 2)*(d.ny[k] + 2);
+            }
+            d.total = off2;
+            M->low2_lds = (size_t)off2*sizeof(double);
+            if (M->low2_lds > 64*1024)
+                HPS_HIP_CHECK(hipFuncSetAttribute((const void*)k_lower_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->low2_lds));
+            HPS_HIP_CHECK(hipMalloc(&M->d_low2, sizeof(Low2)));
+            HPS_HIP_CHECK(hipMemcpy(M->d_low2, &d, sizeof(Low2), hipMemcpyHostToDevice));
+            break;
+        }
+    }
     std::vector<LowLev> low;
     int off = 0;
     for (int il = M->lowv_begin; il < nl; ++il) {
@@ -579,23 +934,24 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
         off += 8*(int)l.cells;
     }
     M->low_lds = (size_t)off*sizeof(double);
-    if (M->low_lds > 64*1024) {
+    if (!M->use_low2 && M->low_lds > 64*1024) {
         HPS_HIP_CHECK(hipFuncSetAttribute((const void*)k_lower_v<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->low_lds));
         HPS_HIP_CHECK(hipFuncSetAttribute((const void*)k_lower_v<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->low_lds));
     }
     HPS_HIP_CHECK(hipMalloc(&M->d_low, low.size()*sizeof(LowLev)));
     HPS_HIP_CHECK(hipMemcpy(M->d_low, low.data(), low.size()*sizeof(LowLev), hipMemcpyHostToDevice));
-    HPS_HIP_CHECK(hipMalloc(&M->d_norms, 2*sizeof(unsigned long long)));
-    HPS_HIP_CHECK(hipMalloc(&M->d_ctrl, sizeof(MGCtrl)));
-    HPS_HIP_CHECK(hipHostMalloc(&M->h_ctrl, sizeof(MGCtrl)));
+    HPS_HIP_CHECK(hipMalloc(&M->d_norms, (2 + MG_MAX_VCYCLES)*sizeof(unsigned long long)));
+    HPS_HIP_CHECK(hipHostMalloc(&M->h_norms, (2 + MG_MAX_VCYCLES)*sizeof(unsigned long long)));
+    HPS_HIP_CHECK(hipMalloc(&M->tmp0, 2*M->L[0].cells*sizeof(double)));
+    HPS_HIP_CHECK(hipMemset(M->tmp0, 0, 2*M->L[0].cells*sizeof(double)));
     *out = M;
     return HPS_OK;
 }
 
 template <bool CC, int SRC, bool DO_RES>
-static void launch_smooth (Multigrid* M, int il, FView phi_out, FView rhs, FView acf, FView phi_in, FView crse,
+static void launch_smooth (Multigrid* M, int il, FView phi_out, FView phi_out2, FView rhs, FView acf, FView phi_in, FView crse,
                            FView res_out, FView cres_out, unsigned long long* resnorm, unsigned long long* rhsnorm,
-                           const int* done, hipStream_t st)
+                           const StopRule& sr, hipStream_t st)
 {
     const LevBox& b = M->L[il].b;
     constexpr int E = DO_RES ? 4 : 3;
@@ -605,56 +961,60 @@ static void launch_smooth (Multigrid* M, int il, FView phi_out, FView rhs, FView
     const double ldx = M->dx*fac, ldy = M->dy*fac;
     const double facx = 1.0/(ldx*ldx), facy = 1.0/(ldy*ldy);
     constexpr bool FUSE = CC && DO_RES;
-    hipLaunchKernelGGL((k_smooth<CC, SRC, DO_RES, FUSE>), dim3(ntx*nty), dim3(MG_NT), 0, st, b, phi_out, rhs, acf, phi_in, crse,
-                       res_out, cres_out, facx, facy, ntx, resnorm, rhsnorm, done);
+    hipLaunchKernelGGL((k_smooth<CC, SRC, DO_RES, FUSE>), dim3(ntx*nty), dim3(MG_NT), 0, st, b, phi_out, phi_out2, rhs, acf, phi_in,
+                       crse, res_out, cres_out, facx, facy, ntx, resnorm, rhsnorm, sr);
 }
 
 template <bool CC>
-static void restrict_residual_if_nodal (Multigrid* M, int il, const int* done, hipStream_t st)
+static void restrict_residual_if_nodal (Multigrid* M, int il, const StopRule& sr, hipStream_t st)
 {
     if (CC) return;     // fused into k_smooth
     const LevBox& cb = M->L[il+1].b;
     hipLaunchKernelGGL(k_restrict<CC>, dim3(ceil_div(cb.vhx - cb.vlx + 1, 64), cb.vhy - cb.vly + 1), dim3(64), 0, st,
-                       cb, M->lv(il+1, M->L[il+1].res), M->lv(il, M->L[il].rescor), 2, done);
+                       cb, M->lv(il+1, M->L[il+1].res), M->lv(il, M->L[il].rescor), 2, sr);
 }
 
-// one V-cycle (vcycle :1429-1512).  On entry res[1] = R(rhs - L(cor[0])); on exit again, plus
-// sol = smoothed solution, cor[0] = GSRB^4(sol) and the residual norm in d_norms[0].
+// V-cycle k (vcycle :1429-1512).  On entry res[1] = R(rhs - L(cor[0])); on exit again, plus
+// tmp0 = smoothed solution, cor[0] = sol = GSRB^4(tmp0) and the residual norm in d_norms[2+k].
 template <bool CC>
-static void vcycle (Multigrid* M, hipStream_t st)
+static void vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStream_t st)
 {
     const int nl = M->nlev();
     const int lb = M->lowv_begin;
     const FView none{};
-    const int* done = &M->d_ctrl->done;
+    const StopRule sr{M->d_norms, k, tol_rel, tol_abs};
     for (int il = 1; il < lb; ++il) {
-        launch_smooth<CC, SRC_ZERO, true>(M, il, M->lv(il, M->L[il].cor), M->lv(il, M->L[il].res), M->lv(il, M->L[il].acf), none, none,
-                                          M->lv(il, M->L[il].rescor), M->lv(il+1, M->L[il+1].res), nullptr, nullptr, done, st);
-        restrict_residual_if_nodal<CC>(M, il, done, st);
+        launch_smooth<CC, SRC_ZERO, true>(M, il, M->lv(il, M->L[il].cor), none, M->lv(il, M->L[il].res), M->lv(il, M->L[il].acf), none,
+                                          none, M->lv(il, M->L[il].rescor), M->lv(il+1, M->L[il+1].res), nullptr, nullptr, sr, st);
+        restrict_residual_if_nodal<CC>(M, il, sr, st);
     }
     {
         const double fac = (double)(1 << lb);
         const double ldx = M->dx*fac, ldy = M->dy*fac;
         const LevBox& bb = M->L[nl-1].b;
         const int nsweeps = std::max(16, (std::max(bb.hix - bb.lox + 1, bb.hiy - bb.loy + 1) + 1)/2*2);
-        hipLaunchKernelGGL(k_lower_v<CC>, dim3(1), dim3(1024), M->low_lds, st, M->d_low, nl - lb, M->L[lb].acf, M->L[lb].res,
-                           M->L[lb].cor, 1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, done);
+        if (M->use_low2)
+            hipLaunchKernelGGL(k_lower_v2, dim3(1), dim3(1024), M->low2_lds, st, M->d_low2, M->L[lb].acf, M->L[lb].res, M->L[lb].cor,
+                               1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr);
+        else
+            hipLaunchKernelGGL(k_lower_v<CC>, dim3(1), dim3(1024), M->low_lds, st, M->d_low, nl - lb, M->L[lb].acf, M->L[lb].res,
+                               M->L[lb].cor, 1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr);
     }
     // up-leg: the smoothed correction of level il lands in rescor[il] (out of place)
     for (int il = lb - 1; il >= 1; --il) {
         double* crse = (il + 1 == lb) ? M->L[il+1].cor : M->L[il+1].rescor;
-        launch_smooth<CC, SRC_PROLONG, false>(M, il, M->lv(il, M->L[il].rescor), M->lv(il, M->L[il].res), M->lv(il, M->L[il].acf),
-                                              M->lv(il, M->L[il].cor), M->lv(il+1, crse), none, none, nullptr, nullptr, done, st);
+        launch_smooth<CC, SRC_PROLONG, false>(M, il, M->lv(il, M->L[il].rescor), none, M->lv(il, M->L[il].res), M->lv(il, M->L[il].acf),
+                                              M->lv(il, M->L[il].cor), M->lv(il+1, crse), none, none, nullptr, nullptr, sr, st);
     }
     {
         double* crse = (1 == lb) ? M->L[1].cor : M->L[1].rescor;
-        launch_smooth<CC, SRC_PROLONG, false>(M, 0, M->sol, M->rhs, M->acf0, M->lv(0, M->L[0].cor), M->lv(1, crse), none, none,
-                                              nullptr, nullptr, done, st);
+        launch_smooth<CC, SRC_PROLONG, false>(M, 0, M->lv(0, M->tmp0), none, M->rhs, M->acf0, M->lv(0, M->L[0].cor), M->lv(1, crse),
+                                              none, none, nullptr, nullptr, sr, st);
     }
-    launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), M->rhs, M->acf0, M->sol, none, M->lv(0, M->L[0].rescor),
-                                        M->lv(1, M->L[1].res), M->d_norms, nullptr, done, st);
-    restrict_residual_if_nodal<CC>(M, 0, done, st);
-    hipLaunchKernelGGL(k_ctrl_check, dim3(1), dim3(1), 0, st, M->d_norms, M->d_ctrl);
+    // the last GSRB^4 of the V-cycle writes the iterate to cor[0] and to the caller's slab
+    launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), M->sol, M->rhs, M->acf0, M->lv(0, M->tmp0), none,
+                                        M->lv(0, M->L[0].rescor), M->lv(1, M->L[1].res), M->d_norms + 2 + k, nullptr, sr, st);
+    restrict_residual_if_nodal<CC>(M, 0, sr, st);
 }
 
 template <bool CC>
@@ -662,40 +1022,73 @@ static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_it
                         hipStream_t st)
 {
     const int lb = M->lowv_begin;
+    max_iters = std::min(max_iters, MG_MAX_VCYCLES);
+    const StopRule always{nullptr, -1, 0.0, 0.0};
     // coefficient hierarchy (average_down_acoef, HpMultiGrid.cpp:1640-1700); level 0 reads the slab
-    for (int il = 1; il <= lb; ++il) {
+    int first = 1;
+    if (CC) {
+        PyrOut po{};
+        const int np = std::min(lb, 5);
+        for (int il = 1; il <= np; ++il) { po.p[il-1] = M->L[il].acf; po.nx[il-1] = M->L[il].b.hix + 1; po.ny[il-1] = M->L[il].b.hiy + 1; }
+        hipLaunchKernelGGL(k_acf_pyramid, dim3(ceil_div(M->nx, 32), ceil_div(M->ny, 32)), dim3(256), 0, st, M->acf0, M->nx, M->ny, po, np);
+        first = np + 1;
+    }
+    for (int il = first; il <= lb; ++il) {
         const LevBox& cb = M->L[il].b;
         FView fine = (il == 1) ? M->acf0 : M->lv(il-1, M->L[il-1].acf);
         hipLaunchKernelGGL(k_restrict<CC>, dim3(ceil_div(cb.vhx - cb.vlx + 1, 64), cb.vhy - cb.vly + 1), dim3(64), 0, st,
-                           cb, M->lv(il, M->L[il].acf), fine, 1, (const int*)nullptr);
+                           cb, M->lv(il, M->L[il].acf), fine, 1, always);
     }
-    HPS_HIP_CHECK(hipMemsetAsync(M->d_norms, 0, 2*sizeof(unsigned long long), st));
-    // cor[0] = GSRB^4(sol), residual norm, rhs norm, res[1] = R(residual)  (solve_doit :1319-1346)
-    launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), M->rhs, M->acf0, M->sol, FView{}, M->lv(0, M->L[0].rescor),
-                                        M->lv(1, M->L[1].res), M->d_norms, M->d_norms + 1, nullptr, st);
-    restrict_residual_if_nodal<CC>(M, 0, nullptr, st);
-    hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, st, M->d_norms, M->d_ctrl, tol_rel, tol_abs);
     // speculate as many V-cycles as the previous solve needed; each one is a no-op once converged
-    int status = HPS_OK;
     int nspec = std::min(std::max(M->last_iters, 1), std::max(max_iters, 1));
-    int enq = 0;
+    HPS_HIP_CHECK(hipMemsetAsync(M->d_norms, 0, (2 + std::min(max_iters, nspec + 8))*sizeof(unsigned long long), st));
+    int nzeroed = std::min(max_iters, nspec + 8);
+    // cor[0] = GSRB^4(sol), residual norm, rhs norm, res[1] = R(residual)  (solve_doit :1319-1346)
+    launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), FView{}, M->rhs, M->acf0, M->sol, FView{}, M->lv(0, M->L[0].rescor),
+                                        M->lv(1, M->L[1].res), M->d_norms, M->d_norms + 1, always, st);
+    restrict_residual_if_nodal<CC>(M, 0, always, st);
+    int status = HPS_OK;
+    int enq = 0, iters = 0;
+    double last_norm = 0.0;
+    bool converged = false, diverged = false;
+    auto as_double = [] (unsigned long long bits) { double dd; memcpy(&dd, &bits, 8); return dd; };
     while (true) {
-        for (int v = 0; v < nspec && enq < max_iters; ++v, ++enq) vcycle<CC>(M, st);
-        HPS_HIP_CHECK(hipMemcpyAsync(M->h_ctrl, M->d_ctrl, sizeof(MGCtrl), hipMemcpyDeviceToHost, st));
+        for (int v = 0; v < nspec && enq < max_iters; ++v, ++enq) {
+            if (enq >= nzeroed) {        // more slots than foreseen: zero the next batch (rare)
+                const int more = std::min(max_iters - nzeroed, 64);
+                HPS_HIP_CHECK(hipMemsetAsync(M->d_norms + 2 + nzeroed, 0, more*sizeof(unsigned long long), st));
+                nzeroed += more;
+            }
+            vcycle<CC>(M, enq, tol_rel, tol_abs, st);
+        }
+        HPS_HIP_CHECK(hipMemcpyAsync(M->h_norms, M->d_norms, (2 + enq)*sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HPS_HIP_CHECK(hipStreamSynchronize(st));
-        if (M->h_ctrl->done) break;
+        // replay the stopping rule on the host (solve_doit :1352-1398)
+        const double res0 = as_double(M->h_norms[0]), rhs0 = as_double(M->h_norms[1]);
+        const double max_norm = (rhs0 >= res0) ? rhs0 : res0;
+        const double target = std::max(tol_abs, std::max(tol_rel, 1.e-16)*max_norm);
+        last_norm = res0; iters = 0;
+        converged = (res0 <= target); diverged = false;
+        for (int k = 0; k < enq && !converged && !diverged; ++k) {
+            last_norm = as_double(M->h_norms[2 + k]); ++iters;
+            if (last_norm <= target) converged = true;
+            else if (!(last_norm <= 1.e20*max_norm)) diverged = true;
+        }
+        if (converged || diverged) break;
         if (enq >= max_iters) { set_error("hps_mg_solve1: not converged after max_iters V-cycles"); status = HPS_ERR_MG_MAXITER; break; }
         nspec = 1;
     }
-    if (M->h_ctrl->diverged) { set_error("hps_mg_solve1: diverging"); status = HPS_ERR_MG_DIVERGED; }
-    M->last_iters = std::max(1, M->h_ctrl->iters);
-    // solution = cor[0] on the unknowns (solve_doit :1419-1426)
-    const LevBox& b0 = M->L[0].b;
-    hipLaunchKernelGGL(k_copy2, dim3(ceil_div(b0.vhx - b0.vlx + 1, 64), b0.vhy - b0.vly + 1), dim3(64), 0, st,
-                       b0, M->sol, M->lv(0, M->L[0].cor));
+    if (diverged) { set_error("hps_mg_solve1: diverging"); status = HPS_ERR_MG_DIVERGED; }
+    M->last_iters = std::max(1, iters);
+    if (iters == 0) {
+        // converged on entry: solution = cor[0] of the initial smoothing (solve_doit :1419-1426)
+        const LevBox& b0 = M->L[0].b;
+        hipLaunchKernelGGL(k_copy2, dim3(ceil_div(b0.vhx - b0.vlx + 1, 64), b0.vhy - b0.vly + 1), dim3(64), 0, st,
+                           b0, M->sol, M->lv(0, M->L[0].cor));
+    }
     HPS_HIP_CHECK(hipGetLastError());
-    if (iters_out) *iters_out = M->h_ctrl->iters;
-    if (resnorm_out) *resnorm_out = M->h_ctrl->last_norm;
+    if (iters_out) *iters_out = iters;
+    if (resnorm_out) *resnorm_out = last_norm;
     return status;
 }
 
