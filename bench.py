@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--n", type=int, default=1024, help="transverse cells per side")
     ap.add_argument("--ppc", type=int, default=2, help="plasma particles per cell per direction")
     ap.add_argument("--tile", type=int, default=16, help="particle tile size (0, 16, 32)")
-    ap.add_argument("--sort-period", type=int, default=8, help="slices between particle re-sorts")
+    ap.add_argument("--sort-period", type=int, default=32, help="max slices between particle re-sorts (adaptive below)")
     ap.add_argument("--cpu-slices", type=int, default=4, help="slices of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -138,6 +138,8 @@ def main():
                        "parallelism": f"time-step pipeline x{world}"},
             "phase_ms_per_slice": per_kernel,
             "vcycles_per_slice": eng.stats()["vcycles"] / max(eng.stats()["slices"], 1),
+            "particle_sorts": eng.sorts() if args.tile else 0,
+            "halo_fallbacks": eng.fallbacks() if args.tile else 0,
             "roofline": {"bound": "hbm", "kernel": "k_deposit_tiled<2,%d>" % args.tile if args.tile else "k_deposit_current<2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per_kernel[dom]},

@@ -262,6 +262,11 @@ class SliceEngine:
         check(_lib.lib().hps_engine_fallbacks(self._h, C.byref(n)))
         return n.value
 
+    def sorts(self):
+        n = C.c_long()
+        check(_lib.lib().hps_engine_sorts(self._h, C.byref(n)))
+        return n.value
+
     def set_diagnostics(self, on=True):
         check(_lib.lib().hps_engine_set_diagnostics(self._h, int(on)))
 

@@ -23,6 +23,8 @@ struct Engine {
     Tiling* tiling = nullptr; int tile_size = 16, sort_period = 8, since_sort = 0;
     hps_plasma pl_alt{}; double* pl_real_alt = nullptr;
     int* d_nfallback = nullptr;
+    int* h_nfallback = nullptr;                 // pinned copy, refreshed every slice ahead of the multigrid sync
+    long fb_at_sort = 0; int n_sorts = 0;       // adaptive re-sort: fallbacks at the last sort, number of sorts
     int setup_tiling ();
     int resort ();
     void* ps = nullptr;            // Poisson solver handle

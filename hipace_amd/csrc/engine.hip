@@ -212,7 +212,7 @@ Engine::~Engine ()
     if (mg) hps_mg_destroy(mg);
     (void)hipFree(slab.p); (void)hipFree(pl_real); (void)hipFree(pl.idcpu); (void)hipFree(pl.ion_lev);
     delete tiling;
-    (void)hipFree(pl_real_alt); (void)hipFree(pl_alt.idcpu); (void)hipFree(pl_alt.ion_lev); (void)hipFree(d_nfallback);
+    (void)hipFree(pl_real_alt); (void)hipFree(pl_alt.idcpu); (void)hipFree(pl_alt.ion_lev); (void)hipFree(d_nfallback); if (h_nfallback) (void)hipHostFree(h_nfallback);
     (void)hipFree(staging); (void)hipFree(beam_data); (void)hipFree(beam_init); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
     for (auto e : ev) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
@@ -310,6 +310,8 @@ int Engine::create (const hps_deck& deck, int device)
     }
     HPS_HIP_CHECK(hipMalloc(&d_nfallback, sizeof(int)));
     HPS_HIP_CHECK(hipMemset(d_nfallback, 0, sizeof(int)));
+    HPS_HIP_CHECK(hipHostMalloc(&h_nfallback, sizeof(int)));
+    *h_nfallback = 0;
     HPS_HIP_CHECK(hipMalloc(&d_nqsa, sizeof(int)));
     HPS_HIP_CHECK(hipMemset(d_nqsa, 0, sizeof(int)));
     HPS_HIP_CHECK(hipMalloc(&d_checksum, HPS_NCOMP_MAX*sizeof(double)));
@@ -339,7 +341,8 @@ int Engine::resort ()
     if (int e = tiling_sort(tiling, pl, pl_alt, gm, st)) return e;
     std::swap(pl, pl_alt);
     std::swap(pl_real, pl_real_alt);
-    since_sort = 0;
+    since_sort = 0; ++n_sorts;
+    fb_at_sort = h_nfallback ? *h_nfallback : 0;
     return HPS_OK;
 }
 
@@ -412,7 +415,9 @@ int Engine::solve_slice (int islice)
 
     mark();   // b1
     // plasma: jx, jy, [rho], chi, rhomjz (Hipace.cpp:609-610); beam: jz_beam on This (:613-614)
-    if (tiling && since_sort >= sort_period) { if ((e = resort())) return e; }
+    // re-sort after sort_period slices at the latest, earlier once more than 1/256 of the sheet has left
+    // the halo of its tile (h_nfallback is as of the previous slice's multigrid sync)
+    if (tiling && (since_sort >= sort_period || (since_sort >= 2 && *h_nfallback - fb_at_sort > np/256))) { if ((e = resort())) return e; }
     ++since_sort;
     mark();   // b1b
     {   const int comp[6] = {HPS_C_JX, HPS_C_JY, -1, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_CHI, HPS_C_RHOMJZ};
@@ -443,6 +448,7 @@ int Engine::solve_slice (int islice)
         if (tiling) { if ((e = explicit_deposit_tiled(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, tiling, d_nfallback, st))) return e; }
         else        { if ((e = hps_explicit_deposit(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, st))) return e; } }
 
+    if (tiling) HPS_HIP_CHECK(hipMemcpyAsync(h_nfallback, d_nfallback, sizeof(int), hipMemcpyDeviceToHost, st));
     mark();   // b5
     // Bx, By: Helmholtz multigrid from the previous slice's field (Hipace.cpp:793-933)
     {   int iters = 0;
@@ -585,6 +591,7 @@ extern "C" int hps_engine_fallbacks (void* h, long* n)
     *n = v;
     return HPS_OK;
 }
+extern "C" int hps_engine_sorts (void* h, long* n) { *n = static_cast<Engine*>(h)->n_sorts; return HPS_OK; }
 extern "C" int hps_engine_set_diagnostics (void* h, int on) { static_cast<Engine*>(h)->diagnostics = (on != 0); return HPS_OK; }
 
 extern "C" int hps_memcpy_d2h (void* dst, const void* src, long bytes) { HPS_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return HPS_OK; }

@@ -131,21 +131,30 @@ __device__ __forceinline__ double prolong_at (const FView& crse, int i, int j, i
 // if V-cycle k-1 already met the target (an inactive V-cycle leaves its slot at 0, which switches
 // off all later ones).  k < 0: unconditional.
 constexpr int MG_MAX_VCYCLES = 1024;
+constexpr int MG_NSUB = 16;       // a norm slot is MG_NSUB words (workgroups spread their atomics: same-address
+                                  // L2 atomics serialise at ~20 ns each); its value is the maximum over them
 struct StopRule { const unsigned long long* norms; int k; double tol_rel, tol_abs; };
+
+__device__ __forceinline__ double norm_slot (const unsigned long long* norms, int slot)
+{
+    unsigned long long m = 0ULL;      // non-negative doubles order like their bit patterns
+#pragma unroll
+    for (int q = 0; q < MG_NSUB; ++q) { const unsigned long long v = norms[slot*MG_NSUB + q]; m = v > m ? v : m; }
+    return __longlong_as_double((long long)m);
+}
 
 __device__ __forceinline__ bool vcycle_active (const StopRule& sr)
 {
     if (sr.k < 0) return true;
-    const double res0 = __longlong_as_double((long long)sr.norms[0]), rhs0 = __longlong_as_double((long long)sr.norms[1]);
-    const double prev = (sr.k == 0) ? res0 : __longlong_as_double((long long)sr.norms[2 + sr.k - 1]);
+    const double res0 = norm_slot(sr.norms, 0), rhs0 = norm_slot(sr.norms, 1);
+    const double prev = (sr.k == 0) ? res0 : norm_slot(sr.norms, 2 + sr.k - 1);
     const double max_norm = (rhs0 >= res0) ? rhs0 : res0;
     const double target = fmax(sr.tol_abs, fmax(sr.tol_rel, 1.e-16)*max_norm);
     return prev > target && prev <= 1.e20*max_norm;
 }
 
-// max-norm accumulation: one atomic per workgroup at most, and only if it would raise the maximum
-// (same-address L2 atomics serialise: 4 per workgroup cost ~60 us on an 817-workgroup launch)
-__device__ __forceinline__ void block_max_to (unsigned long long* addr, double v, double* s_red)
+// max-norm accumulation: one fire-and-forget atomic per workgroup into one of the slot's words
+__device__ __forceinline__ void block_max_to (unsigned long long* slot, double v, double* s_red)
 {
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
@@ -153,9 +162,7 @@ __device__ __forceinline__ void block_max_to (unsigned long long* addr, double v
     if (threadIdx.x == 0) {
         double m = 0.0;
         for (int w = 0; w < MG_NT/64; ++w) m = fmax(m, s_red[w]);
-        // non-negative doubles order like their bit patterns
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
-        if (bits > __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(addr, bits);
+        if (m > 0.0) atomicMax(slot + (blockIdx.x & (MG_NSUB - 1)), (unsigned long long)__double_as_longlong(m));
     }
     __syncthreads();
 }
@@ -317,7 +324,11 @@ void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FV
     __shared__ double s_red[MG_NT/64];
     constexpr int E = DO_RES ? 4 : 3;
     constexpr int FX = GT_X - 2*E, FY = GT_Y - 2*E;   // cells a tile finalises (even numbers)
-    const int bx = blockIdx.x % ntx, by = blockIdx.x / ntx;
+    // workgroups go round-robin to the 8 XCDs: give each XCD a contiguous run of tiles, so that the
+    // rims shared by neighbouring tiles hit in that XCD's L2
+    const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = blockIdx.x & 7;
+    const int tile = xcd*q8 + min(xcd, r8) + (blockIdx.x >> 3);
+    const int bx = tile % ntx, by = tile / ntx;
     const int gi0 = b.vlx + bx*FX - E;                // global index of swept cell (0,0)
     const int gj0 = b.vly + by*FY - E;
     // every swept cell and its ring strictly inside the unknowns' box and off the walls
@@ -940,8 +951,8 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
     }
     HPS_HIP_CHECK(hipMalloc(&M->d_low, low.size()*sizeof(LowLev)));
     HPS_HIP_CHECK(hipMemcpy(M->d_low, low.data(), low.size()*sizeof(LowLev), hipMemcpyHostToDevice));
-    HPS_HIP_CHECK(hipMalloc(&M->d_norms, (2 + MG_MAX_VCYCLES)*sizeof(unsigned long long)));
-    HPS_HIP_CHECK(hipHostMalloc(&M->h_norms, (2 + MG_MAX_VCYCLES)*sizeof(unsigned long long)));
+    HPS_HIP_CHECK(hipMalloc(&M->d_norms, (2 + MG_MAX_VCYCLES)*MG_NSUB*sizeof(unsigned long long)));
+    HPS_HIP_CHECK(hipHostMalloc(&M->h_norms, (2 + MG_MAX_VCYCLES)*MG_NSUB*sizeof(unsigned long long)));
     HPS_HIP_CHECK(hipMalloc(&M->tmp0, 2*M->L[0].cells*sizeof(double)));
     HPS_HIP_CHECK(hipMemset(M->tmp0, 0, 2*M->L[0].cells*sizeof(double)));
     *out = M;
@@ -1013,7 +1024,7 @@ static void vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
     }
     // the last GSRB^4 of the V-cycle writes the iterate to cor[0] and to the caller's slab
     launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), M->sol, M->rhs, M->acf0, M->lv(0, M->tmp0), none,
-                                        M->lv(0, M->L[0].rescor), M->lv(1, M->L[1].res), M->d_norms + 2 + k, nullptr, sr, st);
+                                        M->lv(0, M->L[0].rescor), M->lv(1, M->L[1].res), M->d_norms + (2 + k)*MG_NSUB, nullptr, sr, st);
     restrict_residual_if_nodal<CC>(M, 0, sr, st);
 }
 
@@ -1041,36 +1052,40 @@ static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_it
     }
     // speculate as many V-cycles as the previous solve needed; each one is a no-op once converged
     int nspec = std::min(std::max(M->last_iters, 1), std::max(max_iters, 1));
-    HPS_HIP_CHECK(hipMemsetAsync(M->d_norms, 0, (2 + std::min(max_iters, nspec + 8))*sizeof(unsigned long long), st));
+    HPS_HIP_CHECK(hipMemsetAsync(M->d_norms, 0, (2 + std::min(max_iters, nspec + 8))*MG_NSUB*sizeof(unsigned long long), st));
     int nzeroed = std::min(max_iters, nspec + 8);
     // cor[0] = GSRB^4(sol), residual norm, rhs norm, res[1] = R(residual)  (solve_doit :1319-1346)
     launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), FView{}, M->rhs, M->acf0, M->sol, FView{}, M->lv(0, M->L[0].rescor),
-                                        M->lv(1, M->L[1].res), M->d_norms, M->d_norms + 1, always, st);
+                                        M->lv(1, M->L[1].res), M->d_norms, M->d_norms + MG_NSUB, always, st);
     restrict_residual_if_nodal<CC>(M, 0, always, st);
     int status = HPS_OK;
     int enq = 0, iters = 0;
     double last_norm = 0.0;
     bool converged = false, diverged = false;
-    auto as_double = [] (unsigned long long bits) { double dd; memcpy(&dd, &bits, 8); return dd; };
+    auto slot_value = [M] (int slot) {
+        unsigned long long m = 0ULL;
+        for (int q = 0; q < MG_NSUB; ++q) m = std::max(m, M->h_norms[slot*MG_NSUB + q]);
+        double dd; memcpy(&dd, &m, 8); return dd;
+    };
     while (true) {
         for (int v = 0; v < nspec && enq < max_iters; ++v, ++enq) {
             if (enq >= nzeroed) {        // more slots than foreseen: zero the next batch (rare)
                 const int more = std::min(max_iters - nzeroed, 64);
-                HPS_HIP_CHECK(hipMemsetAsync(M->d_norms + 2 + nzeroed, 0, more*sizeof(unsigned long long), st));
+                HPS_HIP_CHECK(hipMemsetAsync(M->d_norms + (2 + nzeroed)*MG_NSUB, 0, more*MG_NSUB*sizeof(unsigned long long), st));
                 nzeroed += more;
             }
             vcycle<CC>(M, enq, tol_rel, tol_abs, st);
         }
-        HPS_HIP_CHECK(hipMemcpyAsync(M->h_norms, M->d_norms, (2 + enq)*sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HPS_HIP_CHECK(hipMemcpyAsync(M->h_norms, M->d_norms, (2 + enq)*MG_NSUB*sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HPS_HIP_CHECK(hipStreamSynchronize(st));
         // replay the stopping rule on the host (solve_doit :1352-1398)
-        const double res0 = as_double(M->h_norms[0]), rhs0 = as_double(M->h_norms[1]);
+        const double res0 = slot_value(0), rhs0 = slot_value(1);
         const double max_norm = (rhs0 >= res0) ? rhs0 : res0;
         const double target = std::max(tol_abs, std::max(tol_rel, 1.e-16)*max_norm);
         last_norm = res0; iters = 0;
         converged = (res0 <= target); diverged = false;
         for (int k = 0; k < enq && !converged && !diverged; ++k) {
-            last_norm = as_double(M->h_norms[2 + k]); ++iters;
+            last_norm = slot_value(2 + k); ++iters;
             if (last_norm <= target) converged = true;
             else if (!(last_norm <= 1.e20*max_norm)) diverged = true;
         }

@@ -182,6 +182,9 @@ int hps_engine_set_diagnostics (void* handle, int on);
  * Call before hps_engine_begin_step. */
 int hps_engine_set_tiling (void* handle, int tile_size, int sort_period);
 int hps_engine_fallbacks (void* handle, long* n_fallback_host);
+/* number of particle re-sorts so far (periodic + adaptive: the sheet is re-sorted after sort_period slices at the
+   latest, earlier once more than 1/256 of it has left the halo of its tile) */
+int hps_engine_sorts (void* handle, long* n_sorts_host);
 /* HIP-event phase timers on the engine's stream.  phase_times sums, over the slices solved since
  * profiling was switched on (or since the last call), the milliseconds spent in
  * {deposit_current, poisson x3 (+rhs, grad), explicit_deposit, mg_solve1, advance_plasma, other,
