@@ -12,7 +12,8 @@ struct Tiling {
     long capacity = 0, sorted_n = 0;
     int* offsets = nullptr;                       // [ntiles + 2], device
     unsigned int *keys_a = nullptr, *keys_b = nullptr, *idx_a = nullptr, *idx_b = nullptr;
-    void* temp = nullptr; size_t temp_bytes = 0; int key_bits = 0;
+    void* temp = nullptr; size_t temp_bytes = 0; int key_bits = 0, key2_bits = 0;
+    int* cell_first = nullptr;                    // [ntiles*ts*ts + 2] run starts of the cell keys
     ~Tiling ();
 };
 

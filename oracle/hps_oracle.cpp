@@ -1202,27 +1202,47 @@ void orc_gather (orc_slab s, orc_geom g, const int* comp, int order, double xp, 
 // reference; bit-exactness is defined between this restatement and the HIP path).
 void orc_tile_sort (orc_plasma p, orc_geom g, int nx, int ny, int ts, uint32_t* perm, int32_t* offsets)
 {
+    // pass 1: stable order by (tile, cell in tile) of the nearest cell, invalid particles last;
+    // rank = position inside the run of equal keys (capped); pass 2: stable order by
+    // (tile, rank, cell in tile): the particles of a tile interleaved over its cells.
+    const int RANK_CAP = 16;
     const int ntx = (nx + ts - 1)/ts, nty = (ny + ts - 1)/ts, ntiles = ntx*nty;
+    const long ncell = (long)ts*ts;
     const double dx_inv = 1.0/g.dx, dy_inv = 1.0/g.dy;
-    std::vector<int> key((size_t)p.n);
-    std::vector<long> count((size_t)ntiles + 2, 0);
+    std::vector<long> key1((size_t)p.n);
     for (long k = 0; k < p.n; ++k) {
-        int t = ntiles;
+        long c = (long)ntiles*ncell;
         if (p.valid[k]) {
             int ci = (int)std::floor((p.x[k] - g.xoff)*dx_inv + 0.5);
             int cj = (int)std::floor((p.y[k] - g.yoff)*dy_inv + 0.5);
             ci = std::min(std::max(ci, 0), nx - 1);
             cj = std::min(std::max(cj, 0), ny - 1);
-            t = (cj/ts)*ntx + (ci/ts);
+            c = (long)((cj/ts)*ntx + (ci/ts))*ncell + (cj % ts)*ts + (ci % ts);
         }
-        key[k] = t; ++count[t];
+        key1[k] = c;
+    }
+    std::vector<uint32_t> ord((size_t)p.n);
+    for (long k = 0; k < p.n; ++k) ord[k] = (uint32_t)k;
+    std::stable_sort(ord.begin(), ord.end(), [&] (uint32_t a, uint32_t b) { return key1[a] < key1[b]; });
+    std::vector<long> key2((size_t)p.n);      // indexed by position after pass 1
+    long run_start = 0;
+    for (long q = 0; q < p.n; ++q) {
+        if (q > 0 && key1[ord[q]] != key1[ord[q-1]]) run_start = q;
+        const long c = key1[ord[q]], tile = c/ncell, cit = c - tile*ncell;
+        const long rank = std::min<long>(q - run_start, RANK_CAP - 1);
+        key2[q] = (tile*RANK_CAP + rank)*ncell + cit;
+    }
+    std::vector<long> pos((size_t)p.n);
+    for (long q = 0; q < p.n; ++q) pos[q] = q;
+    std::stable_sort(pos.begin(), pos.end(), [&] (long a, long b) { return key2[a] < key2[b]; });
+    std::vector<long> count((size_t)ntiles + 2, 0);
+    for (long q = 0; q < p.n; ++q) {
+        perm[q] = ord[pos[q]];
+        ++count[key2[pos[q]]/(RANK_CAP*ncell)];
     }
     long run = 0;
     for (int t = 0; t <= ntiles; ++t) { offsets[t] = (int32_t)run; run += count[t]; }
     offsets[ntiles + 1] = (int32_t)run;
-    std::vector<long> pos((size_t)ntiles + 1);
-    for (int t = 0; t <= ntiles; ++t) pos[t] = offsets[t];
-    for (long k = 0; k < p.n; ++k) perm[pos[key[k]]++] = (uint32_t)k;
 }
 
 void* orc_poisson_create (int nx, int ny, double dx, double dy) { return new PoissonSolver(nx, ny, dx, dy); }

@@ -112,17 +112,38 @@ def test_oracle_multigrid_residual_and_iteration_count(oracle, n):
     assert rn <= 1e-4 * np.abs(rhs).max()
 
 
-def test_oracle_tile_sort_is_a_stable_permutation(oracle):
-    n = 64
+def test_oracle_tile_sort_is_the_interleaved_stable_order(oracle):
+    """Two stable passes: (tile, cell) -> rank inside the cell run -> (tile, rank, cell); checked against an
+    independent numpy construction of the same definition."""
+    n, ts = 64, 16
     real, valid, ion = thermal_sheet(n, n, LO, HI, ppc=2, seed=4, jitter=20.0)
     valid[::9] = 0
-    perm, off = oracle.tile_sort(real, valid, ion, oracle.make_geom(n, n, LO, HI), n, n, 16)
+    geom = oracle.make_geom(n, n, LO, HI)
+    perm, off = oracle.tile_sort(real, valid, ion, geom, n, n, ts)
     assert sorted(perm.tolist()) == list(range(real.shape[1]))
     assert off[0] == 0 and off[-1] == real.shape[1] and np.all(np.diff(off) >= 0)
     assert off[-1] - off[-2] == (valid == 0).sum()           # invalid particles last
-    for t in range(len(off) - 1):
-        seg = perm[off[t]:off[t + 1]]
-        assert np.all(np.diff(seg.astype(np.int64)) > 0)     # stability = ascending original index
+    dx = (HI[0] - LO[0]) / n
+    xoff = 0.5 * (LO[0] + HI[0] - dx * (n - 1))
+    ci = np.clip(np.floor((real[0] - xoff) / dx + 0.5).astype(np.int64), 0, n - 1)
+    cj = np.clip(np.floor((real[1] - xoff) / dx + 0.5).astype(np.int64), 0, n - 1)
+    ntx = n // ts
+    tile = (cj // ts) * ntx + ci // ts
+    cit = (cj % ts) * ts + ci % ts
+    key1 = np.where(valid != 0, tile * ts * ts + cit, ntx * ntx * ts * ts)
+    o1 = np.argsort(key1, kind="stable")
+    k1s = key1[o1]
+    start = np.r_[0, np.flatnonzero(np.diff(k1s)) + 1]
+    run_id = np.searchsorted(start, np.arange(k1s.size), side="right") - 1
+    rank = np.minimum(np.arange(k1s.size) - start[run_id], 15)
+    key2 = ((k1s // (ts * ts)) * 16 + rank) * ts * ts + k1s % (ts * ts)
+    o2 = np.argsort(key2, kind="stable")
+    assert np.array_equal(perm, o1[o2].astype(np.uint32))
+    # what the order is for: inside a tile, the first min(count, cells) particles hit distinct cells
+    t0 = int(np.argmax(np.diff(off[:-1])))
+    seg = perm[off[t0]:off[t0 + 1]]
+    ncells_hit = len(set(cit[seg].tolist()))
+    assert len(set(cit[seg[:ncells_hit]].tolist())) == ncells_hit
 
 
 def test_deck_definitions_match_reference_inputs():
