@@ -37,6 +37,23 @@ def algorithmic_bytes(n, ppc2):
     }
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of `kernel_prefix` from the committed rocprofv3 --pmc summary (two separate
+    passes, FETCH_SIZE and WRITE_SIZE, scripts/pmc_traffic.py).  Units are KB; on gfx950 FETCH_SIZE reports
+    half of the bytes of a coalesced read (MI355X_MICROARCH.md, HBM section) -- calibrated here on
+    k_copy_comps / k_zero_comps / k_init_plasma, whose byte counts are known: FETCH x2, WRITE x1.
+    Only valid for the default 1024^2 x 4 ppc workload the counters were collected on."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01b_pmc_fetch_write_per_kernel.csv")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["kernel"].startswith(kernel_prefix):
+                return (2.0 * float(r["FETCH_SIZE_raw_per_launch"]) + float(r["WRITE_SIZE_raw_per_launch"])) * 1024.0
+    return None
+
+
 def cpu_baseline(n, ppc, nslices):
     """Time the CPU oracle (single-thread restatement of the reference's serial path) on the head
     `nslices` slices of the same deck."""
@@ -141,7 +158,8 @@ def main():
             "particle_sorts": eng.sorts() if args.tile else 0,
             "halo_fallbacks": eng.fallbacks() if args.tile else 0,
             "roofline": {"bound": "hbm", "kernel": "k_deposit_tiled<2,%d>" % args.tile if args.tile else "k_deposit_current<2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic("void hps::k_deposit_tiled<2, 16, 51>") if (args.tile == 16 and args.n == 1024 and args.ppc == 2) else None,
                          "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per_kernel[dom]},
         }
         if args.cpu_slices > 0 and world == 1:

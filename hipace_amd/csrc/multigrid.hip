@@ -41,16 +41,24 @@ enum { SRC_ZERO = 0, SRC_DIRECT = 1, SRC_PROLONG = 2 };
 __device__ long long* g_mg_dbg = nullptr;
 #define MG_STAMP(i) do { if (g_mg_dbg && blockIdx.x == 0 && threadIdx.x == 0) g_mg_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
-#ifndef HPS_MG_TY
-#define HPS_MG_TY 32
+// Smoother tile shapes: TX x TY cells swept by NT threads (TX*TY/2/NT cell pairs per thread).  A
+// workgroup streams its tile through one CU (~10 B/clk from memory, one instruction stream per
+// SIMD), so the levels with few cells get small tiles -- more workgroups on more CUs -- and the
+// fine levels large ones (less rim re-computation: the 4 sweeps need a rim of 3..4 cells).
+template <int TX_, int TY_, int NT_>
+struct TileShape {
+    static constexpr int TX = TX_, TY = TY_, NT = NT_;
+    static constexpr int AX = TX + 2, AY = TY + 2;          // LDS array with ring
+    static constexpr int PR = TX/2;                          // cell pairs per row
+    static constexpr int GPAIRS = TX*TY/2/NT;                // cell pairs per thread
+    static_assert(TX*TY/2 % NT == 0 && NT % 64 == 0 && 64 % (2*PR) == 0 || PR == 32, "tile shape");
+};
+#ifndef HPS_MG_BIG
+#define HPS_MG_BIG 64, 32, 512
 #endif
-constexpr int GT_X = 64, GT_Y = HPS_MG_TY;          // cells swept per tile
-constexpr int GA_X = GT_X + 2, GA_Y = GT_Y + 2;
-#ifndef HPS_MG_NT
-#define HPS_MG_NT 512
-#endif
-constexpr int MG_NT = HPS_MG_NT;             // threads per smoother workgroup
-constexpr int GPAIRS = GT_X*GT_Y/2/MG_NT;    // cell pairs per thread
+using TileBig = TileShape<HPS_MG_BIG>;
+using TileMid = TileShape<32, 32, 256>;
+using TileSmall = TileShape<32, 16, 256>;
 
 // diagonal of the operator at (i,j): -(a + 2(fx+fy)) with the wall modification (gs1 :265-292)
 template <bool CC>
@@ -154,6 +162,7 @@ __device__ __forceinline__ bool vcycle_active (const StopRule& sr)
 }
 
 // max-norm accumulation: one fire-and-forget atomic per workgroup into one of the slot's words
+template <int NT>
 __device__ __forceinline__ void block_max_to (unsigned long long* slot, double v, double* s_red)
 {
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
@@ -161,7 +170,7 @@ __device__ __forceinline__ void block_max_to (unsigned long long* slot, double v
     __syncthreads();
     if (threadIdx.x == 0) {
         double m = 0.0;
-        for (int w = 0; w < MG_NT/64; ++w) m = fmax(m, s_red[w]);
+        for (int w = 0; w < NT/64; ++w) m = fmax(m, s_red[w]);
         if (m > 0.0) atomicMax(slot + (blockIdx.x & (MG_NSUB - 1)), (unsigned long long)__double_as_longlong(m));
     }
     __syncthreads();
@@ -171,13 +180,14 @@ __device__ __forceinline__ void block_max_to (unsigned long long* slot, double v
 // DO_RES: residual r = rhs - L(phi_out), max|r| (and max|rhs|) -> norms;
 //         FUSE_R (cell-centred): cres = R(r) written straight to the next level; else r -> res_out.
 // INTERIOR tiles (no swept cell on a wall / outside the box) take a path without masks.
-template <bool CC, int SRC, bool DO_RES, bool FUSE_R, bool INTERIOR>
-__device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], double* s_red, const LevBox& b, const FView& phi_out,
+template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, bool INTERIOR>
+__device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], double* s_red, const LevBox& b, const FView& phi_out,
                                              const FView& phi_out2, const FView& rhs, const FView& acf, const FView& phi_in, const FView& crse,
                                              const FView& res_out, const FView& cres_out, double facx, double facy,
                                              int gi0, int gj0, unsigned long long* resnorm, unsigned long long* rhsnorm)
 {
     constexpr int E = DO_RES ? 4 : 3;                 // rim of the swept tile that is not final
+    constexpr int GT_X = TS::TX, GT_Y = TS::TY, GA_X = TS::AX, GA_Y = TS::AY, MG_NT = TS::NT, GPAIRS = TS::GPAIRS, PR = TS::PR;
     const int tid = threadIdx.x;
     MG_STAMP(0);
     // per-thread cell pairs: rhs, coefficient and inverse diagonal stay in registers.  Index p is the
@@ -191,7 +201,7 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], doub
 #pragma unroll
     for (int m = 0; m < GPAIRS; ++m) {
         const int pi = tid + MG_NT*m;
-        const int jj = pi / (GT_X/2), pk = pi - jj*(GT_X/2);
+        const int jj = pi / PR, pk = pi - jj*PR;
         const int j = gj0 + jj;
         hx[m] = (gi0 + 2*pk + j) & 1;                 // colour 0 cell: (i + j) even
         fym[m] = INTERIOR ? facy : wall_mult<CC>(j, b.loy, b.hiy, facy);
@@ -246,7 +256,7 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], doub
 #pragma unroll
         for (int m = 0; m < GPAIRS; ++m) {
             const int pi = tid + MG_NT*m;
-            const int jj = pi / (GT_X/2), pk = pi - jj*(GT_X/2);
+            const int jj = pi / PR, pk = pi - jj*PR;
             const int j = gj0 + jj;
             const int h = hx[m] ^ p;
             const int i = gi0 + 2*pk + h;
@@ -264,7 +274,7 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], doub
 #pragma unroll
     for (int m = 0; m < GPAIRS; ++m) {
         const int pi = tid + MG_NT*m;
-        const int jj = pi / (GT_X/2), pk = pi - jj*(GT_X/2);
+        const int jj = pi / PR, pk = pi - jj*PR;
         const int j = gj0 + jj;
         const bool rowok = (jj >= E && jj < GT_Y - E);
         double q0[2], q1[2];                          // by sweep parity p
@@ -297,9 +307,9 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], doub
             const bool sw = (hx[m] != 0);             // the p = 0 cell is the right one
             const double la0 = sw ? q0[1] : q0[0], ra0 = sw ? q0[0] : q0[1];
             const double la1 = sw ? q1[1] : q1[0], ra1 = sw ? q1[0] : q1[1];
-            const double c0 = __shfl_down(la0, 32), d0 = __shfl_down(ra0, 32);
-            const double c1 = __shfl_down(la1, 32), d1 = __shfl_down(ra1, 32);
-            if (fin[0] && ((tid & 32) == 0)) {
+            const double c0 = __shfl_down(la0, PR), d0 = __shfl_down(ra0, PR);
+            const double c1 = __shfl_down(la1, PR), d1 = __shfl_down(ra1, PR);
+            if (fin[0] && ((tid & PR) == 0)) {
                 const int ic = (gi0 + 2*pk) >> 1, jc = j >> 1;
                 cres_out(ic, jc, 0) = 0.25*(la0 + ra0 + c0 + d0);
                 cres_out(ic, jc, 1) = 0.25*(la1 + ra1 + c1 + d1);
@@ -307,21 +317,22 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][GA_Y*GA_X], doub
         }
     }
     MG_STAMP(4);
-    if (DO_RES && resnorm) block_max_to(resnorm, resmax, s_red);
-    if (rhsnorm) block_max_to(rhsnorm, rmax, s_red);
+    if (DO_RES && resnorm) block_max_to<MG_NT>(resnorm, resmax, s_red);
+    if (rhsnorm) block_max_to<MG_NT>(rhsnorm, rmax, s_red);
     MG_STAMP(5);
 }
 
-template <bool CC, int SRC, bool DO_RES, bool FUSE_R>
-__global__ __launch_bounds__(MG_NT)
+template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R>
+__global__ __launch_bounds__(TS::NT)
 void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FView phi_in, FView crse, FView res_out,
                FView cres_out, double facx, double facy, int ntx, unsigned long long* resnorm,
                unsigned long long* rhsnorm, StopRule sr)
 {
     static_assert(!FUSE_R || (CC && DO_RES), "fused restriction is cell-centred only");
     if (!vcycle_active(sr)) return;
-    __shared__ double s_phi[2][GA_Y*GA_X];
-    __shared__ double s_red[MG_NT/64];
+    constexpr int GT_X = TS::TX, GT_Y = TS::TY;
+    __shared__ double s_phi[2][TS::AY*TS::AX];
+    __shared__ double s_red[TS::NT/64];
     constexpr int E = DO_RES ? 4 : 3;
     constexpr int FX = GT_X - 2*E, FY = GT_Y - 2*E;   // cells a tile finalises (even numbers)
     // workgroups go round-robin to the 8 XCDs: give each XCD a contiguous run of tiles, so that the
@@ -334,9 +345,9 @@ void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FV
     // every swept cell and its ring strictly inside the unknowns' box and off the walls
     const bool interior = (gi0 - 1 >= b.vlx) && (gi0 + GT_X <= b.vhx) && (gj0 - 1 >= b.vly) && (gj0 + GT_Y <= b.vhy)
                        && (gi0 > b.lox) && (gi0 + GT_X - 1 < b.hix) && (gj0 > b.loy) && (gj0 + GT_Y - 1 < b.hiy);
-    if (interior) smooth_tile<CC, SRC, DO_RES, FUSE_R, true>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
+    if (interior) smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, true>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
                                                              facx, facy, gi0, gj0, resnorm, rhsnorm);
-    else          smooth_tile<CC, SRC, DO_RES, FUSE_R, false>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
+    else          smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, false>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
                                                               facx, facy, gi0, gj0, resnorm, rhsnorm);
 }
 
@@ -865,6 +876,8 @@ struct Multigrid {
     int last_iters = 1;                         // V-cycles of the previous solve = speculation depth
     bool use_low2 = false; Low2 low2{}; Low2* d_low2 = nullptr; size_t low2_lds = 0;   // cell-centred register/LDS lower V
     double* tmp0 = nullptr;                     // level-0 scratch: smoothed solution before the last GSRB^4
+    long small_tile_cells = 300L*300L;          // levels up to this many cells use TileSmall
+    long mid_tile_cells = 0;                    // ... up to this many TileMid
     FView sol, rhs, acf0;                       // level-0 user views (set per solve)
 
     ~Multigrid () {
@@ -909,14 +922,17 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
         if (!ok) break;
     }
     if (M->nlev() < 2) { delete M; set_error("hps_mg_create: grid too small to coarsen"); return HPS_ERR_ARG; }
+    if (const char* e = getenv("HPS_MG_SMALL_CELLS")) M->small_tile_cells = atol(e);
+    if (const char* e = getenv("HPS_MG_MID_CELLS")) M->mid_tile_cells = atol(e);
     const int nl = M->nlev();
     M->lowv_begin = nl - 1;
     for (int il = nl - 1; il >= 1; --il) if (M->L[il].cells <= LOWV_MAX_CELLS) M->lowv_begin = il;
     if (M->cc && !getenv("HPS_MG_OLD_LOWV")) {
         // first level with at most 64 x 64 cells whose coarser levels all fit 32 x 32
+        const int amax = getenv("HPS_MG_LOW2_MAX") ? atoi(getenv("HPS_MG_LOW2_MAX")) : 64;
         for (int il = 1; il < nl; ++il) {
             const LevBox& b = M->L[il].b;
-            const bool fits = (b.hix + 1 <= 64) && (b.hiy + 1 <= 64) && (nl - il <= LOW2_MAXLEV)
+            const bool fits = (b.hix + 1 <= amax) && (b.hiy + 1 <= amax) && (nl - il <= LOW2_MAXLEV)
                            && (il + 1 >= nl || (M->L[il+1].b.hix + 1 <= 32 && M->L[il+1].b.hiy + 1 <= 32));
             if (!fits) continue;
             M->use_low2 = true; M->lowv_begin = il;
@@ -959,21 +975,34 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
     return HPS_OK;
 }
 
-template <bool CC, int SRC, bool DO_RES>
-static void launch_smooth (Multigrid* M, int il, FView phi_out, FView phi_out2, FView rhs, FView acf, FView phi_in, FView crse,
-                           FView res_out, FView cres_out, unsigned long long* resnorm, unsigned long long* rhsnorm,
-                           const StopRule& sr, hipStream_t st)
+template <class TS, bool CC, int SRC, bool DO_RES>
+static void launch_smooth_ts (Multigrid* M, int il, FView phi_out, FView phi_out2, FView rhs, FView acf, FView phi_in, FView crse,
+                              FView res_out, FView cres_out, unsigned long long* resnorm, unsigned long long* rhsnorm,
+                              const StopRule& sr, hipStream_t st)
 {
     const LevBox& b = M->L[il].b;
     constexpr int E = DO_RES ? 4 : 3;
-    constexpr int FX = GT_X - 2*E, FY = GT_Y - 2*E;
+    constexpr int FX = TS::TX - 2*E, FY = TS::TY - 2*E;
     const int ntx = ceil_div(b.vhx - b.vlx + 1, FX), nty = ceil_div(b.vhy - b.vly + 1, FY);
     const double fac = (double)(1 << il);
     const double ldx = M->dx*fac, ldy = M->dy*fac;
     const double facx = 1.0/(ldx*ldx), facy = 1.0/(ldy*ldy);
     constexpr bool FUSE = CC && DO_RES;
-    hipLaunchKernelGGL((k_smooth<CC, SRC, DO_RES, FUSE>), dim3(ntx*nty), dim3(MG_NT), 0, st, b, phi_out, phi_out2, rhs, acf, phi_in,
-                       crse, res_out, cres_out, facx, facy, ntx, resnorm, rhsnorm, sr);
+    hipLaunchKernelGGL((k_smooth<TS, CC, SRC, DO_RES, FUSE>), dim3(ntx*nty), dim3(TS::NT), 0, st, b, phi_out, phi_out2, rhs, acf,
+                       phi_in, crse, res_out, cres_out, facx, facy, ntx, resnorm, rhsnorm, sr);
+}
+
+template <bool CC, int SRC, bool DO_RES>
+static void launch_smooth (Multigrid* M, int il, FView phi_out, FView phi_out2, FView rhs, FView acf, FView phi_in, FView crse,
+                           FView res_out, FView cres_out, unsigned long long* resnorm, unsigned long long* rhsnorm,
+                           const StopRule& sr, hipStream_t st)
+{
+    if (M->L[il].cells <= M->small_tile_cells)
+        launch_smooth_ts<TileSmall, CC, SRC, DO_RES>(M, il, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out, resnorm, rhsnorm, sr, st);
+    else if (M->L[il].cells <= M->mid_tile_cells)
+        launch_smooth_ts<TileMid, CC, SRC, DO_RES>(M, il, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out, resnorm, rhsnorm, sr, st);
+    else
+        launch_smooth_ts<TileBig, CC, SRC, DO_RES>(M, il, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out, resnorm, rhsnorm, sr, st);
 }
 
 template <bool CC>
