@@ -104,11 +104,21 @@ __device__ __forceinline__ double wall_mult (int i, int lo, int hi, double fac)
 }
 
 // residual rhs - L(phi) at (i,j) (laplacian :162-182, residual1 :184-190), branch-free as above
+template <bool INTERIOR = false>
+__device__ __forceinline__ double residual_v (double p0, double w, double e, double s, double n, int i, int j, const LevBox& b,
+                                              double rhs, double acf, double facx, double facy);
+
 template <bool INTERIOR = false, class P>
 __device__ __forceinline__ double residual_at (P c, int sy, int i, int j, const LevBox& b,
                                                double rhs, double acf, double facx, double facy)
 {
-    const double p0 = c[0], w = c[-1], e = c[1], s = c[-sy], n = c[sy];
+    return residual_v<INTERIOR>(c[0], c[-1], c[1], c[-sy], c[sy], i, j, b, rhs, acf, facx, facy);
+}
+
+template <bool INTERIOR>
+__device__ __forceinline__ double residual_v (double p0, double w, double e, double s, double n, int i, int j, const LevBox& b,
+                                              double rhs, double acf, double facx, double facy)
+{
     double lap = -2.0*(facx + facy)*p0;
     double tx = facx*(w + e), ty = facy*(s + n);
     if (!INTERIOR) {
@@ -543,29 +553,267 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
 
 // ---------------------------------------------------------------------------------------------
 // Cell-centred lower V, register/LDS resident, from the first level with at most 64 x 64 cells.
-// Level A (index 0 here): 1024 threads x 2 cell pairs, rhs / coefficient / inverse diagonal in
-// registers, the correction in two ringed LDS planes.  Levels below: one thread per cell (thread
-// t <-> cell (t & 31, t >> 5), so a wave always holds two complete rows and the 4-average of the
-// restriction is three lane shuffles), six LDS planes each: cor0 cor1 | res0 res1 | acf | 1/diag.
+// Every level is worked in 2 x 2 cell blocks, one thread per block: the block's correction, rhs and
+// inverse diagonal sit in registers, so a red-black half-sweep updates two cells with two LDS reads
+// each (the other two neighbours are the thread's own cells), the residual's 4-average for the
+// restriction and the piecewise-constant prolongation are thread-local, and the 2 x 2 bottom level is
+// one lane's registers.  LDS: the correction of every level (two ringed planes, for the neighbours);
+// below level A also rhs (2), coefficient and inverse diagonal planes (level A reloads its rhs from
+// HBM for the up-leg).  Levels of at most 64 blocks run in wave 0 alone without workgroup barriers.
 // The first sweep of every down-leg level starts from cor = 0, where the update is rhs/diag exactly.
 constexpr int LOW2_MAXLEV = 8;
 struct Low2 { int nl; int total; int nx[LOW2_MAXLEV], ny[LOW2_MAXLEV], off[LOW2_MAXLEV]; };
 
 __device__ __forceinline__ LevBox cc_box (int nx, int ny) { return LevBox{0, 0, nx - 1, ny - 1, 0, 0, nx - 1, ny - 1}; }
 
-// sweeps s_begin .. s_end-1 of one thread-per-cell level
-__device__ __forceinline__ void tpc_sweeps (lds_double* c0, lds_double* c1, int pitch, int i, int j, bool ok, const LevBox& b,
-                                            double r0, double r1, double ci, double fx, double fy, int s_begin, int s_end)
+template <bool WAVE>
+__device__ __forceinline__ void lvl_sync ()
 {
-    const int o = (j + 1)*pitch + i + 1;
-    const double fxm = wall_mult<true>(i, b.lox, b.hix, fx), fym = wall_mult<true>(j, b.loy, b.hiy, fy);
-    for (int s = s_begin; s < s_end; ++s) {
-        if (ok && (((i + j + s) & 1) == 0)) {
-            const double n0 = (r0 - offdiag_m((const lds_double*)(c0 + o), pitch, fxm, fym))*ci;
-            const double n1 = (r1 - offdiag_m((const lds_double*)(c1 + o), pitch, fxm, fym))*ci;
-            c0[o] = n0; c1[o] = n1;
+    if (WAVE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // one wave: LDS is in order, keep the compiler in order
+    else __syncthreads();
+}
+
+// a thread's 2 x 2 block: cells k = 0:(i,j) 1:(i+1,j) 2:(i,j+1) 3:(i+1,j+1); 0 and 3 have colour 0
+struct Blk {
+    lds_double *c0, *c1;      // the block's cell 0 in the two correction planes
+    int pitch;
+    bool act;                 // this thread has a block on this level
+    bool ok[4];               // cell inside the level (odd sizes)
+    double fxm[2], fym[2];    // wall multipliers of the block's two columns / rows
+    double v0[4], v1[4];      // correction (both components)
+    double r0[4], r1[4], ci[4];
+};
+
+// half-sweep of parity P (0: cells 0 and 3, 1: cells 1 and 2) + publication of the new values
+template <int P, bool WAVE>
+__device__ __forceinline__ void blk_sweep (Blk& B)
+{
+    if (B.act) {
+        const int pt = B.pitch;
+        if (P == 0) {
+            {   const double w0 = B.c0[-1], s0 = B.c0[-pt], w1 = B.c1[-1], s1 = B.c1[-pt];
+                const double n0 = (B.r0[0] - (B.fxm[0]*(w0 + B.v0[1]) + B.fym[0]*(s0 + B.v0[2])))*B.ci[0];
+                const double n1 = (B.r1[0] - (B.fxm[0]*(w1 + B.v1[1]) + B.fym[0]*(s1 + B.v1[2])))*B.ci[0];
+                if (B.ok[0]) { B.v0[0] = n0; B.v1[0] = n1; B.c0[0] = n0; B.c1[0] = n1; } }
+            {   const double e0 = B.c0[pt + 2], t0 = B.c0[2*pt + 1], e1 = B.c1[pt + 2], t1 = B.c1[2*pt + 1];
+                const double n0 = (B.r0[3] - (B.fxm[1]*(B.v0[2] + e0) + B.fym[1]*(B.v0[1] + t0)))*B.ci[3];
+                const double n1 = (B.r1[3] - (B.fxm[1]*(B.v1[2] + e1) + B.fym[1]*(B.v1[1] + t1)))*B.ci[3];
+                if (B.ok[3]) { B.v0[3] = n0; B.v1[3] = n1; B.c0[pt + 1] = n0; B.c1[pt + 1] = n1; } }
+        } else {
+            {   const double e0 = B.c0[2], s0 = B.c0[1 - pt], e1 = B.c1[2], s1 = B.c1[1 - pt];
+                const double n0 = (B.r0[1] - (B.fxm[1]*(B.v0[0] + e0) + B.fym[0]*(s0 + B.v0[3])))*B.ci[1];
+                const double n1 = (B.r1[1] - (B.fxm[1]*(B.v1[0] + e1) + B.fym[0]*(s1 + B.v1[3])))*B.ci[1];
+                if (B.ok[1]) { B.v0[1] = n0; B.v1[1] = n1; B.c0[1] = n0; B.c1[1] = n1; } }
+            {   const double w0 = B.c0[pt - 1], t0 = B.c0[2*pt], w1 = B.c1[pt - 1], t1 = B.c1[2*pt];
+                const double n0 = (B.r0[2] - (B.fxm[0]*(w0 + B.v0[3]) + B.fym[1]*(B.v0[0] + t0)))*B.ci[2];
+                const double n1 = (B.r1[2] - (B.fxm[0]*(w1 + B.v1[3]) + B.fym[1]*(B.v1[0] + t1)))*B.ci[2];
+                if (B.ok[2]) { B.v0[2] = n0; B.v1[2] = n1; B.c0[pt] = n0; B.c1[pt] = n1; } }
         }
-        __syncthreads();
+    }
+    lvl_sync<WAVE>();
+}
+
+// down-leg sweeps from cor = 0: sweep 0 is rhs/diag on the colour-0 cells, then sweeps 1 .. nsw-1 (nsw even)
+template <bool WAVE>
+__device__ __forceinline__ void blk_down_sweeps (Blk& B, int nsw)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { B.v0[k] = 0.0; B.v1[k] = 0.0; }
+    if (B.act) {
+        if (B.ok[0]) { B.v0[0] = B.r0[0]*B.ci[0]; B.v1[0] = B.r1[0]*B.ci[0]; B.c0[0] = B.v0[0]; B.c1[0] = B.v1[0]; }
+        if (B.ok[3]) { B.v0[3] = B.r0[3]*B.ci[3]; B.v1[3] = B.r1[3]*B.ci[3]; B.c0[B.pitch + 1] = B.v0[3]; B.c1[B.pitch + 1] = B.v1[3]; }
+    }
+    lvl_sync<WAVE>();
+    blk_sweep<1, WAVE>(B);
+    for (int s = 2; s < nsw; s += 2) { blk_sweep<0, WAVE>(B); blk_sweep<1, WAVE>(B); }
+}
+
+// The whole level is this one block (2 x 2 cells or fewer): every neighbour outside the block is the
+// zero ring, so all nsw sweeps from cor = 0 run in the lane's registers; published once at the end.
+__device__ __forceinline__ void blk_single_sweeps (Blk& B, int nsw)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { B.v0[k] = 0.0; B.v1[k] = 0.0; }
+    if (B.act) {
+        for (int s = 0; s < nsw; s += 2) {
+            {   const double a0 = (B.r0[0] - (B.fxm[0]*(0.0 + B.v0[1]) + B.fym[0]*(0.0 + B.v0[2])))*B.ci[0];
+                const double a1 = (B.r1[0] - (B.fxm[0]*(0.0 + B.v1[1]) + B.fym[0]*(0.0 + B.v1[2])))*B.ci[0];
+                const double b0 = (B.r0[3] - (B.fxm[1]*(B.v0[2] + 0.0) + B.fym[1]*(B.v0[1] + 0.0)))*B.ci[3];
+                const double b1 = (B.r1[3] - (B.fxm[1]*(B.v1[2] + 0.0) + B.fym[1]*(B.v1[1] + 0.0)))*B.ci[3];
+                if (B.ok[0]) { B.v0[0] = a0; B.v1[0] = a1; }
+                if (B.ok[3]) { B.v0[3] = b0; B.v1[3] = b1; } }
+            {   const double a0 = (B.r0[1] - (B.fxm[1]*(B.v0[0] + 0.0) + B.fym[0]*(0.0 + B.v0[3])))*B.ci[1];
+                const double a1 = (B.r1[1] - (B.fxm[1]*(B.v1[0] + 0.0) + B.fym[0]*(0.0 + B.v1[3])))*B.ci[1];
+                const double b0 = (B.r0[2] - (B.fxm[0]*(0.0 + B.v0[3]) + B.fym[1]*(B.v0[0] + 0.0)))*B.ci[2];
+                const double b1 = (B.r1[2] - (B.fxm[0]*(0.0 + B.v1[3]) + B.fym[1]*(B.v1[0] + 0.0)))*B.ci[2];
+                if (B.ok[1]) { B.v0[1] = a0; B.v1[1] = a1; }
+                if (B.ok[2]) { B.v0[2] = b0; B.v1[2] = b1; } }
+        }
+        const int ok[4] = {0, 1, B.pitch, B.pitch + 1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (B.ok[k]) { B.c0[ok[k]] = B.v0[k]; B.c1[ok[k]] = B.v1[k]; }
+    }
+}
+
+// residuals of the block's four cells (0 for cells outside the level)
+__device__ __forceinline__ void blk_residual (const Blk& B, int i, int j, const LevBox& b, const double (&a)[4],
+                                              double fx, double fy, double (&q0)[4], double (&q1)[4])
+{
+    const int pt = B.pitch;
+    const double w00 = B.c0[-1], s00 = B.c0[-pt], e01 = B.c0[2], s01 = B.c0[1 - pt];
+    const double w02 = B.c0[pt - 1], n02 = B.c0[2*pt], e03 = B.c0[pt + 2], n03 = B.c0[2*pt + 1];
+    const double w10 = B.c1[-1], s10 = B.c1[-pt], e11 = B.c1[2], s11 = B.c1[1 - pt];
+    const double w12 = B.c1[pt - 1], n12 = B.c1[2*pt], e13 = B.c1[pt + 2], n13 = B.c1[2*pt + 1];
+    q0[0] = residual_v<false>(B.v0[0], w00, B.v0[1], s00, B.v0[2], i, j, b, B.r0[0], a[0], fx, fy);
+    q0[1] = residual_v<false>(B.v0[1], B.v0[0], e01, s01, B.v0[3], i + 1, j, b, B.r0[1], a[1], fx, fy);
+    q0[2] = residual_v<false>(B.v0[2], w02, B.v0[3], B.v0[0], n02, i, j + 1, b, B.r0[2], a[2], fx, fy);
+    q0[3] = residual_v<false>(B.v0[3], B.v0[2], e03, B.v0[1], n03, i + 1, j + 1, b, B.r0[3], a[3], fx, fy);
+    q1[0] = residual_v<false>(B.v1[0], w10, B.v1[1], s10, B.v1[2], i, j, b, B.r1[0], a[0], fx, fy);
+    q1[1] = residual_v<false>(B.v1[1], B.v1[0], e11, s11, B.v1[3], i + 1, j, b, B.r1[1], a[1], fx, fy);
+    q1[2] = residual_v<false>(B.v1[2], w12, B.v1[3], B.v1[0], n12, i, j + 1, b, B.r1[2], a[2], fx, fy);
+    q1[3] = residual_v<false>(B.v1[3], B.v1[2], e13, B.v1[1], n13, i + 1, j + 1, b, B.r1[3], a[3], fx, fy);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (!B.ok[k]) { q0[k] = 0.0; q1[k] = 0.0; } }
+}
+
+// geometry of thread t's block on a level of nx x ny cells whose planes start at `lev` (pitch nx + 2)
+__device__ __forceinline__ void blk_geometry (Blk& B, lds_double* lev, int nx, int ny, int t, double fx, double fy, int& i, int& j)
+{
+    const int nbx = (nx + 1) >> 1, nby = (ny + 1) >> 1;
+    int lg = 0; while ((1 << lg) < nbx) ++lg;                  // blocks per row rounded up to a power of two
+    const int bi = t & ((1 << lg) - 1), bj = t >> lg;
+    B.act = (bi < nbx) && (bj < nby);
+    i = 2*bi; j = 2*bj;
+    B.pitch = nx + 2;
+    const int ps = B.pitch*(ny + 2);
+    const int o = B.act ? (j + 1)*B.pitch + i + 1 : B.pitch + 1;
+    B.c0 = lev + o; B.c1 = lev + ps + o;
+    B.ok[0] = B.act; B.ok[1] = B.act && (i + 1 < nx); B.ok[2] = B.act && (j + 1 < ny); B.ok[3] = B.ok[1] && B.ok[2];
+    B.fxm[0] = wall_mult<true>(i, 0, nx - 1, fx); B.fxm[1] = wall_mult<true>(i + 1, 0, nx - 1, fx);
+    B.fym[0] = wall_mult<true>(j, 0, ny - 1, fy); B.fym[1] = wall_mult<true>(j + 1, 0, ny - 1, fy);
+}
+
+__device__ __forceinline__ double lvl_fac (double f0, int l) { for (int k = 0; k < l; ++k) f0 *= 0.25; return f0; }
+
+// levels >= 1 keep six LDS planes: cor0 cor1 | res0 res1 | acf | 1/diag (all ringed, pitch nx + 2)
+
+// down-leg of level l >= 1: cor = GSRB^nsw(0), then (unless last) the restricted residual -> rhs of level l+1
+template <bool WAVE>
+__device__ __forceinline__ void low_down (lds_double* base, const Low2& d, int l, int t, double fx, double fy, int nsw, bool last)
+{
+    const int nx = d.nx[l], ny = d.ny[l];
+    Blk B; int i, j;
+    blk_geometry(B, base + d.off[l], nx, ny, t, fx, fy, i, j);
+    const int ps = B.pitch*(ny + 2);
+    const lds_double* r = B.c0 + 2*ps;
+    const int ok[4] = {0, 1, B.pitch, B.pitch + 1};
+    double a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int o = B.ok[k] ? ok[k] : 0;
+        B.r0[k] = r[o]; B.r1[k] = r[ps + o]; a[k] = r[2*ps + o]; B.ci[k] = r[3*ps + o];
+    }
+    if (last && nx <= 2 && ny <= 2) { blk_single_sweeps(B, nsw); lvl_sync<WAVE>(); }
+    else blk_down_sweeps<WAVE>(B, nsw);
+    if (!last) {
+        double q0[4], q1[4];
+        blk_residual(B, i, j, cc_box(nx, ny), a, fx, fy, q0, q1);
+        if (B.act) {
+            const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
+            lds_double* rn = base + d.off[l+1] + 2*psn + ((j >> 1) + 1)*pn + (i >> 1) + 1;
+            rn[0] = 0.25*(q0[0] + q0[1] + q0[2] + q0[3]);
+            rn[psn] = 0.25*(q1[0] + q1[1] + q1[2] + q1[3]);
+        }
+        lvl_sync<WAVE>();
+    }
+}
+
+// up-leg of level l >= 1: cor += P(cor of level l+1), GSRB^4
+template <bool WAVE>
+__device__ __forceinline__ void low_up (lds_double* base, const Low2& d, int l, int t, double fx, double fy)
+{
+    const int nx = d.nx[l], ny = d.ny[l];
+    Blk B; int i, j;
+    blk_geometry(B, base + d.off[l], nx, ny, t, fx, fy, i, j);
+    const int ps = B.pitch*(ny + 2);
+    const lds_double* r = B.c0 + 2*ps;
+    const int ok[4] = {0, 1, B.pitch, B.pitch + 1};
+    const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
+    const lds_double* kc = base + d.off[l+1] + ((j >> 1) + 1)*pn + (i >> 1) + 1;
+    const double k0 = B.act ? kc[0] : 0.0, k1 = B.act ? kc[psn] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int o = B.ok[k] ? ok[k] : 0;
+        B.r0[k] = r[o]; B.r1[k] = r[ps + o]; B.ci[k] = r[3*ps + o];
+        const double c0 = B.c0[o], c1 = B.c1[o];
+        B.v0[k] = B.ok[k] ? c0 + k0 : 0.0; B.v1[k] = B.ok[k] ? c1 + k1 : 0.0;
+        if (B.ok[k]) { B.c0[o] = B.v0[k]; B.c1[o] = B.v1[k]; }
+    }
+    lvl_sync<WAVE>();
+    blk_sweep<0, WAVE>(B); blk_sweep<1, WAVE>(B); blk_sweep<0, WAVE>(B); blk_sweep<1, WAVE>(B);
+}
+
+// Levels of at most 8 x 8 cells inside wave 0, one lane per cell (lane t <-> cell (t & 7, t >> 3)): a lone
+// wave is bound by its own instruction latencies, and a cell per lane is the shortest stream per sweep.
+__device__ __forceinline__ void tiny_down (lds_double* base, const Low2& d, int l, int t, double fx, double fy)
+{
+    const int nx = d.nx[l], ny = d.ny[l], pitch = nx + 2, ps = pitch*(ny + 2);
+    const int i = t & 7, j = t >> 3;
+    const bool ok = (i < nx) && (j < ny);
+    const int o = ok ? (j + 1)*pitch + i + 1 : pitch + 1;
+    lds_double* c0 = base + d.off[l] + o;
+    lds_double* c1 = c0 + ps;
+    const double r0 = c0[2*ps], r1 = c0[3*ps], a = c0[4*ps], ci = c0[5*ps];
+    const double fxm = wall_mult<true>(i, 0, nx - 1, fx), fym = wall_mult<true>(j, 0, ny - 1, fy);
+    if (ok && (((i + j) & 1) == 0)) { c0[0] = r0*ci; c1[0] = r1*ci; }      // sweep 0 from cor = 0
+    lvl_sync<true>();
+    for (int s = 1; s < 4; ++s) {
+        if (ok && (((i + j + s) & 1) == 0)) {
+            const double n0 = (r0 - offdiag_m((const lds_double*)c0, pitch, fxm, fym))*ci;
+            const double n1 = (r1 - offdiag_m((const lds_double*)c1, pitch, fxm, fym))*ci;
+            c0[0] = n0; c1[0] = n1;
+        }
+        lvl_sync<true>();
+    }
+    const LevBox b = cc_box(nx, ny);
+    const double u0 = residual_at<false>((const lds_double*)c0, pitch, i, j, b, r0, a, fx, fy);
+    const double u1 = residual_at<false>((const lds_double*)c1, pitch, i, j, b, r1, a, fx, fy);
+    const double q0 = ok ? u0 : 0.0, q1 = ok ? u1 : 0.0;
+    const double b0 = __shfl_down(q0, 1), g0 = __shfl_down(q0, 8), e0 = __shfl_down(q0, 9);
+    const double b1 = __shfl_down(q1, 1), g1 = __shfl_down(q1, 8), e1 = __shfl_down(q1, 9);
+    if (ok && !(i & 1) && !(j & 1)) {
+        const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
+        lds_double* rn = base + d.off[l+1] + 2*psn + ((j >> 1) + 1)*pn + (i >> 1) + 1;
+        rn[0] = 0.25*(q0 + b0 + g0 + e0);
+        rn[psn] = 0.25*(q1 + b1 + g1 + e1);
+    }
+    lvl_sync<true>();
+}
+
+__device__ __forceinline__ void tiny_up (lds_double* base, const Low2& d, int l, int t, double fx, double fy)
+{
+    const int nx = d.nx[l], ny = d.ny[l], pitch = nx + 2, ps = pitch*(ny + 2);
+    const int i = t & 7, j = t >> 3;
+    const bool ok = (i < nx) && (j < ny);
+    const int o = ok ? (j + 1)*pitch + i + 1 : pitch + 1;
+    lds_double* c0 = base + d.off[l] + o;
+    lds_double* c1 = c0 + ps;
+    const double r0 = c0[2*ps], r1 = c0[3*ps], ci = c0[5*ps];
+    const double fxm = wall_mult<true>(i, 0, nx - 1, fx), fym = wall_mult<true>(j, 0, ny - 1, fy);
+    if (ok) {
+        const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
+        const lds_double* kc = base + d.off[l+1] + ((j >> 1) + 1)*pn + (i >> 1) + 1;
+        c0[0] = c0[0] + kc[0];
+        c1[0] = c1[0] + kc[psn];
+    }
+    lvl_sync<true>();
+    for (int s = 0; s < 4; ++s) {
+        if (ok && (((i + j + s) & 1) == 0)) {
+            const double n0 = (r0 - offdiag_m((const lds_double*)c0, pitch, fxm, fym))*ci;
+            const double n1 = (r1 - offdiag_m((const lds_double*)c1, pitch, fxm, fym))*ci;
+            c0[0] = n0; c1[0] = n1;
+        }
+        lvl_sync<true>();
     }
 }
 
@@ -578,240 +826,123 @@ void k_lower_v2 (const Low2* __restrict__ dp, const double* __restrict__ acf_g, 
     lds_double* base = (lds_double*)lds_raw;
     const int t = threadIdx.x;
     const Low2& d = *dp;          // uniform (scalar) loads; a by-value copy indexed by level would live in scratch
+    const int nl = d.nl;
     MG_STAMP(8);
-    // ---- level A registers
-    const int nxA = d.nx[0], nyA = d.ny[0], pA = nxA + 2, psA = pA*(nyA + 2), cellsA = nxA*nyA;
+    // ---- level A: rhs and coefficient of the thread's block from HBM, inverse diagonals
+    const int nxA = d.nx[0], nyA = d.ny[0], cellsA = nxA*nyA;
     const LevBox bA = cc_box(nxA, nyA);
-    lds_double* const a0p = base + d.off[0];
-    lds_double* const a1p = a0p + psA;
-    double rA0[2][2], rA1[2][2], aA[2][2], cA[2][2], fxA[2][2], fyA[2];
-    bool inA[2][2];
-    int hxA[2];
+    Blk A; int iA, jA;
+    blk_geometry(A, base + d.off[0], nxA, nyA, t, facx0, facy0, iA, jA);
+    double aA[4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int pi = t + 1024*m;
-        const int j = pi >> 5, pk = pi & 31;
-        hxA[m] = (2*pk + j) & 1;
-        fyA[m] = wall_mult<true>(j, 0, nyA - 1, facy0);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int i = 2*pk + (hxA[m] ^ p);
-            fxA[m][p] = wall_mult<true>(i, 0, nxA - 1, facx0);
-            const bool ok = (i < nxA) && (j < nyA);
-            const int idx = min(i, nxA - 1) + min(j, nyA - 1)*nxA;
-            const double v0 = res_g[idx], v1 = res_g[cellsA + idx], v2 = acf_g[idx];
-            inA[m][p] = ok;
-            rA0[m][p] = ok ? v0 : 0.0; rA1[m][p] = ok ? v1 : 0.0; aA[m][p] = ok ? v2 : 0.0;
-            cA[m][p] = 1.0/diag_c0<true>(i, j, bA, aA[m][p], facx0, facy0);
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int i = iA + (k & 1), j = jA + (k >> 1);
+        const int g = min(i, nxA - 1) + min(j, nyA - 1)*nxA;
+        const double v0 = res_g[g], v1 = res_g[cellsA + g], v2 = acf_g[g];
+        A.r0[k] = A.ok[k] ? v0 : 0.0; A.r1[k] = A.ok[k] ? v1 : 0.0; aA[k] = A.ok[k] ? v2 : 0.0;
+        A.ci[k] = 1.0/diag_c0<true>(i, j, bA, aA[k], facx0, facy0);
     }
     for (int s = t; s < d.total; s += 1024) base[s] = 0.0;
     __syncthreads();
-    // ---- coefficient hierarchy (average_down_acoef) and inverse diagonals
-    if (d.nl > 1) {
+    // ---- coefficient hierarchy (average_down_acoef) and inverse diagonals of the levels below
+    if (nl > 1 && A.act) {
         const int p1 = d.nx[1] + 2, ps1 = p1*(d.ny[1] + 2);
-        lds_double* acf1 = base + d.off[1] + 4*ps1;
+        base[d.off[1] + 4*ps1 + ((jA >> 1) + 1)*p1 + (iA >> 1) + 1] = 0.25*(aA[0] + aA[1] + aA[2] + aA[3]);
+    }
+    __syncthreads();
+    for (int l = 1; l < nl; ++l) {
+        const double fx = lvl_fac(facx0, l), fy = lvl_fac(facy0, l);
+        const int nx = d.nx[l], ny = d.ny[l];
+        Blk B; int i, j;
+        blk_geometry(B, base + d.off[l], nx, ny, t, fx, fy, i, j);
+        const int ps = B.pitch*(ny + 2);
+        lds_double* acf = B.c0 + 4*ps;
+        const int ok[4] = {0, 1, B.pitch, B.pitch + 1};
+        double a[4];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int pi = t + 1024*m;
-            const int j = pi >> 5, pk = pi & 31;
-            const bool sw = (hxA[m] != 0);
-            const double la = sw ? aA[m][1] : aA[m][0], ra = sw ? aA[m][0] : aA[m][1];
-            const double c = __shfl_down(la, 32), e = __shfl_down(ra, 32);
-            if (((t & 32) == 0) && 2*pk < nxA && j < nyA) acf1[((j >> 1) + 1)*p1 + pk + 1] = 0.25*(la + ra + c + e);
+        for (int k = 0; k < 4; ++k) {
+            a[k] = B.ok[k] ? acf[ok[k]] : 0.0;
+            if (B.ok[k]) acf[ps + ok[k]] = 1.0/diag_c0<true>(i + (k & 1), j + (k >> 1), cc_box(nx, ny), a[k], fx, fy);
+        }
+        if (l + 1 < nl && B.act) {
+            const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
+            base[d.off[l+1] + 4*psn + ((j >> 1) + 1)*pn + (i >> 1) + 1] = 0.25*(a[0] + a[1] + a[2] + a[3]);
         }
         __syncthreads();
     }
-    const int ti = t & 31, tj = t >> 5;
-    {
-        double fx = facx0, fy = facy0;
-        for (int l = 1; l < d.nl; ++l) {
-            fx *= 0.25; fy *= 0.25;
-            const int nx = d.nx[l], ny = d.ny[l], pl = nx + 2, ps = pl*(ny + 2);
-            lds_double* acf = base + d.off[l] + 4*ps;
-            const bool ok = ti < nx && tj < ny;
-            const double a = ok ? acf[(tj + 1)*pl + ti + 1] : 0.0;
-            if (ok) acf[ps + (tj + 1)*pl + ti + 1] = 1.0/diag_c0<true>(ti, tj, cc_box(nx, ny), a, fx, fy);
-            if (l + 1 < d.nl) {
-                const double b1 = __shfl_down(a, 1), c = __shfl_down(a, 32), e = __shfl_down(a, 33);
-                const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
-                if (ok && !(ti & 1) && !(tj & 1)) base[d.off[l+1] + 4*psn + ((tj >> 1) + 1)*pn + (ti >> 1) + 1] = 0.25*(a + b1 + c + e);
-            }
-            __syncthreads();
-        }
-    }
     MG_STAMP(9);
     // ---- level A down-leg
-    const bool bottomA = (d.nl == 1);
-    {
-        // sweep pairs with a compile-time parity: the register arrays must never be indexed by a
-        // run-time value (the compiler would move them to scratch)
-        const int nsw = bottomA ? nsweeps_bottom : 4;       // even
-        for (int s = 0; s < nsw; s += 2) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int pi = t + 1024*m;
-                    const int j = pi >> 5, pk = pi & 31;
-                    const int i = 2*pk + (hxA[m] ^ p);
-                    const int o = (j + 1)*pA + i + 1;
-                    if (inA[m][p]) {
-                        const double n0 = (rA0[m][p] - offdiag_m((const lds_double*)(a0p + o), pA, fxA[m][p], fyA[m]))*cA[m][p];
-                        const double n1 = (rA1[m][p] - offdiag_m((const lds_double*)(a1p + o), pA, fxA[m][p], fyA[m]))*cA[m][p];
-                        a0p[o] = n0; a1p[o] = n1;
-                    }
-                }
-                __syncthreads();
-            }
-        }
-    }
+    const bool bottomA = (nl == 1);
+    blk_down_sweeps<false>(A, bottomA ? nsweeps_bottom : 4);
     if (!bottomA) {
-        // residual of level A, restricted straight into the rhs planes of level 1
-        const int p1 = d.nx[1] + 2, ps1 = p1*(d.ny[1] + 2);
-        lds_double* res1 = base + d.off[1] + 2*ps1;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int pi = t + 1024*m;
-            const int j = pi >> 5, pk = pi & 31;
-            double q0[2], q1[2];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int i = 2*pk + (hxA[m] ^ p);
-                const int o = (min(j, nyA - 1) + 1)*pA + min(i, nxA - 1) + 1;
-                const double u0 = residual_at<false>((const lds_double*)(a0p + o), pA, i, j, bA, rA0[m][p], aA[m][p], facx0, facy0);
-                const double u1 = residual_at<false>((const lds_double*)(a1p + o), pA, i, j, bA, rA1[m][p], aA[m][p], facx0, facy0);
-                q0[p] = inA[m][p] ? u0 : 0.0; q1[p] = inA[m][p] ? u1 : 0.0;
-            }
-            const bool sw = (hxA[m] != 0);
-            const double la0 = sw ? q0[1] : q0[0], ra0 = sw ? q0[0] : q0[1];
-            const double la1 = sw ? q1[1] : q1[0], ra1 = sw ? q1[0] : q1[1];
-            const double c0 = __shfl_down(la0, 32), e0 = __shfl_down(ra0, 32);
-            const double c1 = __shfl_down(la1, 32), e1 = __shfl_down(ra1, 32);
-            if (((t & 32) == 0) && 2*pk < nxA && j < nyA) {
-                const int oc = ((j >> 1) + 1)*p1 + pk + 1;
-                res1[oc] = 0.25*(la0 + ra0 + c0 + e0);
-                res1[ps1 + oc] = 0.25*(la1 + ra1 + c1 + e1);
-            }
+        double q0[4], q1[4];
+        blk_residual(A, iA, jA, bA, aA, facx0, facy0, q0, q1);
+        if (A.act) {
+            const int p1 = d.nx[1] + 2, ps1 = p1*(d.ny[1] + 2);
+            lds_double* rn = base + d.off[1] + 2*ps1 + ((jA >> 1) + 1)*p1 + (iA >> 1) + 1;
+            rn[0] = 0.25*(q0[0] + q0[1] + q0[2] + q0[3]);
+            rn[ps1] = 0.25*(q1[0] + q1[1] + q1[2] + q1[3]);
         }
         __syncthreads();
     }
     MG_STAMP(10);
-    // ---- levels 1 .. nl-1 down (the last one is the bottom solve)
-    double fx = facx0, fy = facy0;
-    for (int l = 1; l < d.nl; ++l) {
-        fx *= 0.25; fy *= 0.25;
-        const int nx = d.nx[l], ny = d.ny[l], pl = nx + 2, ps = pl*(ny + 2);
-        lds_double* c0 = base + d.off[l];
-        lds_double* c1 = c0 + ps;
-        const LevBox b = cc_box(nx, ny);
-        const bool ok = ti < nx && tj < ny;
-        const int o = (min(tj, ny - 1) + 1)*pl + min(ti, nx - 1) + 1;
-        const double r0 = c0[2*ps + o], r1 = c0[3*ps + o], a = c0[4*ps + o], ci = c0[5*ps + o];
-        const bool last = (l == d.nl - 1);
-        if (ok && (((ti + tj) & 1) == 0)) { c0[o] = r0*ci; c1[o] = r1*ci; }     // sweep 0 from cor = 0
-        __syncthreads();
-        tpc_sweeps(c0, c1, pl, ti, tj, ok, b, r0, r1, ci, fx, fy, 1, last ? nsweeps_bottom : 4);
-        if (!last) {
-            const double u0 = residual_at<false>((const lds_double*)(c0 + o), pl, ti, tj, b, r0, a, fx, fy);
-            const double u1 = residual_at<false>((const lds_double*)(c1 + o), pl, ti, tj, b, r1, a, fx, fy);
-            const double q0 = ok ? u0 : 0.0, q1 = ok ? u1 : 0.0;
-            const double b0 = __shfl_down(q0, 1), g0 = __shfl_down(q0, 32), e0 = __shfl_down(q0, 33);
-            const double b1 = __shfl_down(q1, 1), g1 = __shfl_down(q1, 32), e1 = __shfl_down(q1, 33);
-            const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
-            if (ok && !(ti & 1) && !(tj & 1)) {
-                lds_double* rn = base + d.off[l+1] + 2*psn + ((tj >> 1) + 1)*pn + (ti >> 1) + 1;
-                rn[0] = 0.25*(q0 + b0 + g0 + e0);
-                rn[psn] = 0.25*(q1 + b1 + g1 + e1);
-            }
-            __syncthreads();
-        }
-    }
-    MG_STAMP(11);
-    // the rhs of level A was dropped from the registers after its residual: fetch it again now, so
-    // that the (L2) latency hides behind the up-leg of the small levels
-    double uA0[2][2], uA1[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int pi = t + 1024*m;
-        const int j = pi >> 5, pk = pi & 31;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int i = 2*pk + (hxA[m] ^ p);
-            const int idx = min(i, nxA - 1) + min(j, nyA - 1)*nxA;
-            uA0[m][p] = __builtin_nontemporal_load(res_g + idx);
-            uA1[m][p] = __builtin_nontemporal_load(res_g + cellsA + idx);
-        }
-    }
-    // ---- up-leg of the thread-per-cell levels
-    for (int l = d.nl - 2; l >= 1; --l) {
-        fx *= 4.0; fy *= 4.0;
-        const int nx = d.nx[l], ny = d.ny[l], pl = nx + 2, ps = pl*(ny + 2);
-        const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
-        lds_double* c0 = base + d.off[l];
-        lds_double* c1 = c0 + ps;
-        const lds_double* k0 = base + d.off[l+1];
-        const bool ok = ti < nx && tj < ny;
-        const int o = (min(tj, ny - 1) + 1)*pl + min(ti, nx - 1) + 1;
-        const double r0 = c0[2*ps + o], r1 = c0[3*ps + o], ci = c0[5*ps + o];
-        if (ok) {
-            const int oc = ((tj >> 1) + 1)*pn + (ti >> 1) + 1;
-            c0[o] = c0[o] + k0[oc];
-            c1[o] = c1[o] + k0[psn + oc];
-        }
-        __syncthreads();
-        tpc_sweeps(c0, c1, pl, ti, tj, ok, cc_box(nx, ny), r0, r1, ci, fx, fy, 0, 4);
-    }
-    MG_STAMP(12);
-    // ---- up-leg of level A and store
     if (!bottomA) {
-        const int pn = d.nx[1] + 2, psn = pn*(d.ny[1] + 2);
-        const lds_double* k0 = base + d.off[1];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int pi = t + 1024*m;
-            const int j = pi >> 5, pk = pi & 31;
-            const int oc = ((j >> 1) + 1)*pn + pk + 1;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                if (inA[m][p]) {
-                    const int o = (j + 1)*pA + 2*pk + (hxA[m] ^ p) + 1;
-                    a0p[o] = a0p[o] + k0[oc];
-                    a1p[o] = a1p[o] + k0[psn + oc];
-                }
-            }
+        // lw = first level whose blocks (and those of every level below it) fit wave 0
+        int lw = 1;
+        for (; lw < nl; ++lw) {
+            const int nbx = (d.nx[lw] + 1) >> 1, nby = (d.ny[lw] + 1) >> 1;
+            int lg = 0; while ((1 << lg) < nbx) ++lg;
+            if ((nby << lg) <= 64) break;
         }
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            constexpr int dummy = 0; (void)dummy;
-            const int p = s & 1;                  // compile-time after unrolling
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int pi = t + 1024*m;
-                const int j = pi >> 5, pk = pi & 31;
-                const int i = 2*pk + (hxA[m] ^ p);
-                const int o = (j + 1)*pA + i + 1;
-                if (inA[m][p]) {
-                    const double n0 = (uA0[m][p] - offdiag_m((const lds_double*)(a0p + o), pA, fxA[m][p], fyA[m]))*cA[m][p];
-                    const double n1 = (uA1[m][p] - offdiag_m((const lds_double*)(a1p + o), pA, fxA[m][p], fyA[m]))*cA[m][p];
-                    a0p[o] = n0; a1p[o] = n1;
+        for (int l = 1; l < lw; ++l)
+            low_down<false>(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l), (l == nl - 1) ? nsweeps_bottom : 4, l == nl - 1);
+        MG_STAMP(11);
+        if (lw < nl) {
+            if (t < 64) {
+                for (int l = lw; l < nl; ++l) {
+                    MG_STAMP(16 + l);
+                    const bool tiny = (d.nx[l] <= 8 && d.ny[l] <= 8 && l < nl - 1);
+                    if (tiny) tiny_down(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l));
+                    else low_down<true>(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l), (l == nl - 1) ? nsweeps_bottom : 4, l == nl - 1);
+                }
+                for (int l = nl - 2; l >= lw; --l) {
+                    MG_STAMP(32 + l);
+                    if (d.nx[l] <= 8 && d.ny[l] <= 8) tiny_up(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l));
+                    else low_up<true>(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l));
                 }
             }
             __syncthreads();
         }
+        MG_STAMP(12);
+        // level A's rhs left the registers after its residual: fetch it again (L2) behind the up-leg below
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int g = min(iA + (k & 1), nxA - 1) + min(jA + (k >> 1), nyA - 1)*nxA;
+            const double v0 = __builtin_nontemporal_load(res_g + g), v1 = __builtin_nontemporal_load(res_g + cellsA + g);
+            A.r0[k] = A.ok[k] ? v0 : 0.0; A.r1[k] = A.ok[k] ? v1 : 0.0;
+        }
+        for (int l = min(lw - 1, nl - 2); l >= 1; --l)
+            low_up<false>(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l));
+        // ---- level A up-leg: correction back from LDS, prolongation, 4 sweeps
+        const int p1 = d.nx[1] + 2, ps1 = p1*(d.ny[1] + 2);
+        const lds_double* kc = base + d.off[1] + ((jA >> 1) + 1)*p1 + (iA >> 1) + 1;
+        const double k0 = A.act ? kc[0] : 0.0, k1 = A.act ? kc[ps1] : 0.0;
+        const int ok[4] = {0, 1, A.pitch, A.pitch + 1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int o = A.ok[k] ? ok[k] : 0;
+            const double c0 = A.c0[o], c1 = A.c1[o];
+            A.v0[k] = A.ok[k] ? c0 + k0 : 0.0; A.v1[k] = A.ok[k] ? c1 + k1 : 0.0;
+            if (A.ok[k]) { A.c0[o] = A.v0[k]; A.c1[o] = A.v1[k]; }
+        }
+        __syncthreads();
+        blk_sweep<0, false>(A); blk_sweep<1, false>(A); blk_sweep<0, false>(A); blk_sweep<1, false>(A);
     }
     MG_STAMP(13);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int pi = t + 1024*m;
-        const int j = pi >> 5, pk = pi & 31;
-        if (j < nyA && 2*pk < nxA) {
-            const int o = (j + 1)*pA + 2*pk + 1;
-            const int idx = 2*pk + j*nxA;
-            cor_g[idx] = a0p[o]; cor_g[cellsA + idx] = a1p[o];
-            if (2*pk + 1 < nxA) { cor_g[idx + 1] = a0p[o + 1]; cor_g[cellsA + idx + 1] = a1p[o + 1]; }
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int g = min(iA + (k & 1), nxA - 1) + min(jA + (k >> 1), nyA - 1)*nxA;
+        if (A.ok[k]) { cor_g[g] = A.v0[k]; cor_g[cellsA + g] = A.v1[k]; }
     }
     MG_STAMP(14);
 }
@@ -1180,13 +1311,13 @@ extern "C" int hps_mg_debug_stamps (long long* stamps16_host)
 {
     static long long* d = nullptr;
     if (!d) {
-        HPS_HIP_CHECK(hipMalloc(&d, 16*sizeof(long long)));
-        HPS_HIP_CHECK(hipMemset(d, 0, 16*sizeof(long long)));
+        HPS_HIP_CHECK(hipMalloc(&d, 48*sizeof(long long)));
+        HPS_HIP_CHECK(hipMemset(d, 0, 48*sizeof(long long)));
         HPS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_mg_dbg), &d, sizeof(d)));
         return HPS_OK;
     }
     HPS_HIP_CHECK(hipDeviceSynchronize());
-    HPS_HIP_CHECK(hipMemcpy(stamps16_host, d, 16*sizeof(long long), hipMemcpyDeviceToHost));
+    HPS_HIP_CHECK(hipMemcpy(stamps16_host, d, 48*sizeof(long long), hipMemcpyDeviceToHost));
     return HPS_OK;
 }
 

@@ -9,7 +9,7 @@ f=api.Fields(n,n,g,5)
 f.t[2:4,g:-g,g:-g]=torch.randn((2,n,n),dtype=torch.float64,device='cuda')
 f.t[4]=0.5+torch.rand((n+2*g,n+2*g),dtype=torch.float64,device='cuda')
 mg=api.MultiGrid(n,n,16/n,16/n)
-st=(C.c_longlong*16)()
+st=(C.c_longlong*48)()
 L.hps_mg_debug_stamps(st)
 it,rn=mg.solve1(f,0,2,4)
 torch.cuda.synchronize()
@@ -23,3 +23,5 @@ v=list(st)
 print('iters',it,'ms/solve',dt*1e3)
 print('k_smooth (last launch, block 0) deltas:', [v[i+1]-v[i] for i in range(5)])
 print('k_lower_v deltas:', [v[i+1]-v[i] for i in range(8,14)])
+print('wave-part down stamps (level: ticks since stamp 11):', {l: v[16+l]-v[11] for l in range(1,9) if v[16+l]})
+print('wave-part up stamps:', {l: v[32+l]-v[11] for l in range(1,9) if v[32+l]}, 'end', v[12]-v[11])
