@@ -1,6 +1,6 @@
 // particles_tiled.hip -- LDS-tile variants of the particle kernels for a tile-sorted plasma sheet
 // (see sort.hip).  One 256-thread workgroup owns one TS x TS-cell tile: it keeps an LDS image of
-// the tile plus an 8-cell halo (R = TS+16 cells per side), streams the tile's particles (contiguous
+// the tile plus a 6-cell halo (R = TS+12 cells per side; 8 cells cost the explicit deposition one workgroup per CU of occupancy), streams the tile's particles (contiguous
 // in the sorted SoA, fully coalesced) and
 //   * deposit:   accumulates all stencil contributions with LDS fp64 atomics (ds_add_f64) and
 //                flushes the non-zero cells once with global atomics (halo cells overlap
@@ -16,7 +16,10 @@
 
 namespace hps {
 
-constexpr int TILE_HALO = 8;
+#ifndef HPS_TILE_HALO
+#define HPS_TILE_HALO 6
+#endif
+constexpr int TILE_HALO = HPS_TILE_HALO;
 
 // optional shader-clock stamps of one workgroup (hps_particles_debug_stamps)
 __device__ long long* g_pt_dbg = nullptr;

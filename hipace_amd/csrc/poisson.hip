@@ -65,7 +65,11 @@ struct DstArgs {
     int rows_per_plane, nplanes;
     long long* dbg;                 // optional: shader-clock stamps of workgroup 0 at the phase boundaries
 };
+#ifdef HPS_POISSON_STAMPS
 #define HPS_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HPS_STAMP(i) do { } while (0)      /* global stores ahead of the table loads would keep them off the scalar path */
+#endif
 
 typedef __attribute__((address_space(3))) double lds_double;
 
@@ -276,11 +280,20 @@ void k_dst_rows (DstArgs a)
 //   X_0 = x_0 + sum_n s_n,   X_k = x_0 + P_k + i Q_k,   X_{M-k} = x_0 + P_k - i Q_k   (k = 1..H)
 //   P_k = sum_{n=1..H} s_n cos(2 pi n k / M),   Q_k = sum_{n=1..H} d_n sin(2 pi n k / M)
 // i.e. M^2 real FMAs per DFT instead of 4 M^2, with one (cos, sin) table read per 4 FMAs.
-constexpr int DSTS_T = 3;
-constexpr int DSTS_NT = 512;        // threads per workgroup of the symmetric kernel
+#ifndef HPS_SYM_UNROLL
+#define HPS_SYM_UNROLL 2
+#endif
+#ifndef HPS_DSTS_T
+#define HPS_DSTS_T 3
+#endif
+#ifndef HPS_DSTS_NT
+#define HPS_DSTS_NT 512
+#endif
+constexpr int DSTS_T = HPS_DSTS_T;
+constexpr int DSTS_NT = HPS_DSTS_NT;        // threads per workgroup of the symmetric kernel
 
 template <int M, int STRIDE, int KSTRIDE, int ITEMS_PER_T, int ITEM_STRIDE, bool TWIDDLE, int T, int NWAVES>
-__device__ __forceinline__ void sym_stage (lds_double* cbuf, const lds_double* cs, const double2* __restrict__ tw, int wave, int lane)
+__device__ __forceinline__ void sym_stage (lds_double* cbuf, const double2* __restrict__ cs, const double2* __restrict__ tw, int wave, int lane)
 {
     // one item = one DFT of size M over elements base + n*STRIDE; results go to base + k*KSTRIDE
     constexpr int H = (M - 1)/2;
@@ -303,15 +316,17 @@ __device__ __forceinline__ void sym_stage (lds_double* cbuf, const lds_double* c
     double2 x0 = make_double2(0.0, 0.0), ssum = make_double2(0.0, 0.0);
     if (active) {
         x0 = ldc(cbuf, base);
+#pragma unroll HPS_SYM_UNROLL
         for (int n = 1; n <= H; ++n) {
             const double2 xa = ldc(cbuf, base + n*STRIDE), xb = ldc(cbuf, base + (M - n)*STRIDE);
             const double sr = xa.x + xb.x, si = xa.y + xb.y, dr = xa.x - xb.x, di = xa.y - xb.y;
             ssum.x += sr; ssum.y += si;
-            const lds_double* row = cs + 2*((n - 1)*H + (k0 - 1));
+            // wave-uniform address: the table is read through the scalar cache, not the LDS pipe
+            const double2* __restrict__ row = cs + ((n - 1)*H + (k0 - 1));
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
                 if (k0 + kk <= H) {
-                    const double2 c = ldc(row, kk);       // (cos, sin)(2 pi n k / M)
+                    const double2 c = row[kk];            // (cos, sin)(2 pi n k / M)
                     pr[kk] = fma(sr, c.x, pr[kk]); pim[kk] = fma(si, c.x, pim[kk]);
                     qr[kk] = fma(dr, c.y, qr[kk]); qi[kk] = fma(di, c.y, qi[kk]);
                 }
@@ -347,16 +362,14 @@ void k_dst_rows_sym (DstArgs a)
     constexpr int H1 = (N1 - 1)/2, H2 = (N2 - 1)/2;
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_double* cbuf = (lds_double*)lds_raw;          // [T][N] complex working set
-    lds_double* csa = cbuf + 2*T*N;                   // [H1][H1] (cos, sin)(2 pi n k / N1)
-    lds_double* csb = csa + 2*H1*H1;                  // [H2][H2] (cos, sin)(2 pi n k / N2)
+    const double2* __restrict__ csa = a.fa;           // [H1][H1] (cos, sin)(2 pi n k / N1)
+    const double2* __restrict__ csb = a.fb;           // [H2][H2] (cos, sin)(2 pi n k / N2)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int total_rows = a.rows_per_plane*a.nplanes;
     const int row0 = blockIdx.x*2*T;
 
     HPS_STAMP(0);
-    for (int k = tid; k < H1*H1; k += NT) { const double2 w = a.fa[k]; stc(csa, k, w.x, w.y); }
-    for (int k = tid; k < H2*H2; k += NT) { const double2 w = a.fb[k]; stc(csb, k, w.x, w.y); }
     load_row_pairs<T, N, NT>(cbuf, a, row0, total_rows, tid);
     __syncthreads();
     HPS_STAMP(1);

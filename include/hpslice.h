@@ -99,7 +99,7 @@ int hps_tiling_info (void* tiling, int* ntiles, const int** offsets_dev, const u
 int hps_tiling_destroy (void* tiling);
 
 /* Same operators, same arithmetic, for a sheet ordered by hps_reorder_particles: one workgroup
- * per tile accumulates / gathers through an LDS image of the tile (+8-cell halo).  Particles
+ * per tile accumulates / gathers through an LDS image of the tile (+6-cell halo).  Particles
  * that drifted out of the halo since the sort take the global-memory path and are counted into
  * *n_fallback (device int, may be NULL); results do not depend on how stale the ordering is. */
 int hps_deposit_current_tiled (hps_slab slab, hps_plasma plasma, hps_geom geom, const int comp[6],
