@@ -58,6 +58,10 @@ struct TileShape {
 #endif
 using TileBig = TileShape<HPS_MG_BIG>;
 using TileMid = TileShape<32, 32, 256>;
+#ifndef HPS_MG_HUGE
+#define HPS_MG_HUGE 64, 48, 512
+#endif
+using TileHuge = TileShape<HPS_MG_HUGE>;      // the fused 8-sweep pass of level 0 (rim 8: 48 x 32 of 64 x 48 final)
 using TileSmall = TileShape<32, 16, 256>;
 
 // diagonal of the operator at (i,j): -(a + 2(fx+fy)) with the wall modification (gs1 :265-292)
@@ -190,13 +194,13 @@ __device__ __forceinline__ void block_max_to (unsigned long long* slot, double v
 // DO_RES: residual r = rhs - L(phi_out), max|r| (and max|rhs|) -> norms;
 //         FUSE_R (cell-centred): cres = R(r) written straight to the next level; else r -> res_out.
 // INTERIOR tiles (no swept cell on a wall / outside the box) take a path without masks.
-template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, bool INTERIOR>
+template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, bool INTERIOR, int NSW>
 __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], double* s_red, const LevBox& b, const FView& phi_out,
                                              const FView& phi_out2, const FView& rhs, const FView& acf, const FView& phi_in, const FView& crse,
                                              const FView& res_out, const FView& cres_out, double facx, double facy,
                                              int gi0, int gj0, unsigned long long* resnorm, unsigned long long* rhsnorm)
 {
-    constexpr int E = DO_RES ? 4 : 3;                 // rim of the swept tile that is not final
+    constexpr int E = DO_RES ? NSW : NSW - 1;         // rim of the swept tile that is not final
     constexpr int GT_X = TS::TX, GT_Y = TS::TY, GA_X = TS::AX, GA_Y = TS::AY, MG_NT = TS::NT, GPAIRS = TS::GPAIRS, PR = TS::PR;
     const int tid = threadIdx.x;
     MG_STAMP(0);
@@ -260,7 +264,7 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
     MG_STAMP(2);
 
 #pragma unroll
-    for (int icolor = 0; icolor < 4; ++icolor) {
+    for (int icolor = 0; icolor < NSW; ++icolor) {
         constexpr int dummy = 0; (void)dummy;
         const int p = icolor & 1;                     // compile-time after unrolling
 #pragma unroll
@@ -332,7 +336,9 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
     MG_STAMP(5);
 }
 
-template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R>
+// NSW red-black half-sweeps per launch: 4 (one GSRB^4 of the reference) or 8 (the two consecutive
+// GSRB^4 that end a V-cycle on level 0, fused: one pass over HBM instead of two)
+template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, int NSW = 4>
 __global__ __launch_bounds__(TS::NT)
 void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FView phi_in, FView crse, FView res_out,
                FView cres_out, double facx, double facy, int ntx, unsigned long long* resnorm,
@@ -343,7 +349,7 @@ void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FV
     constexpr int GT_X = TS::TX, GT_Y = TS::TY;
     __shared__ double s_phi[2][TS::AY*TS::AX];
     __shared__ double s_red[TS::NT/64];
-    constexpr int E = DO_RES ? 4 : 3;
+    constexpr int E = DO_RES ? NSW : NSW - 1;
     constexpr int FX = GT_X - 2*E, FY = GT_Y - 2*E;   // cells a tile finalises (even numbers)
     // workgroups go round-robin to the 8 XCDs: give each XCD a contiguous run of tiles, so that the
     // rims shared by neighbouring tiles hit in that XCD's L2
@@ -355,9 +361,9 @@ void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FV
     // every swept cell and its ring strictly inside the unknowns' box and off the walls
     const bool interior = (gi0 - 1 >= b.vlx) && (gi0 + GT_X <= b.vhx) && (gj0 - 1 >= b.vly) && (gj0 + GT_Y <= b.vhy)
                        && (gi0 > b.lox) && (gi0 + GT_X - 1 < b.hix) && (gj0 > b.loy) && (gj0 + GT_Y - 1 < b.hiy);
-    if (interior) smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, true>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
+    if (interior) smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, true, NSW>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
                                                              facx, facy, gi0, gj0, resnorm, rhsnorm);
-    else          smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, false>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
+    else          smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, false, NSW>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
                                                               facx, facy, gi0, gj0, resnorm, rhsnorm);
 }
 
@@ -1007,6 +1013,7 @@ struct Multigrid {
     int last_iters = 1;                         // V-cycles of the previous solve = speculation depth
     bool use_low2 = false; Low2 low2{}; Low2* d_low2 = nullptr; size_t low2_lds = 0;   // cell-centred register/LDS lower V
     double* tmp0 = nullptr;                     // level-0 scratch: smoothed solution before the last GSRB^4
+    bool fuse_level0 = true, cor_in_tmp = false; // fused 8-sweep end of the V-cycle; which buffer holds cor[0]
     long small_tile_cells = 300L*300L;          // levels up to this many cells use TileSmall
     long mid_tile_cells = 0;                    // ... up to this many TileMid
     FView sol, rhs, acf0;                       // level-0 user views (set per solve)
@@ -1106,20 +1113,20 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
     return HPS_OK;
 }
 
-template <class TS, bool CC, int SRC, bool DO_RES>
+template <class TS, bool CC, int SRC, bool DO_RES, int NSW = 4>
 static void launch_smooth_ts (Multigrid* M, int il, FView phi_out, FView phi_out2, FView rhs, FView acf, FView phi_in, FView crse,
                               FView res_out, FView cres_out, unsigned long long* resnorm, unsigned long long* rhsnorm,
                               const StopRule& sr, hipStream_t st)
 {
     const LevBox& b = M->L[il].b;
-    constexpr int E = DO_RES ? 4 : 3;
+    constexpr int E = DO_RES ? NSW : NSW - 1;
     constexpr int FX = TS::TX - 2*E, FY = TS::TY - 2*E;
     const int ntx = ceil_div(b.vhx - b.vlx + 1, FX), nty = ceil_div(b.vhy - b.vly + 1, FY);
     const double fac = (double)(1 << il);
     const double ldx = M->dx*fac, ldy = M->dy*fac;
     const double facx = 1.0/(ldx*ldx), facy = 1.0/(ldy*ldy);
     constexpr bool FUSE = CC && DO_RES;
-    hipLaunchKernelGGL((k_smooth<TS, CC, SRC, DO_RES, FUSE>), dim3(ntx*nty), dim3(TS::NT), 0, st, b, phi_out, phi_out2, rhs, acf,
+    hipLaunchKernelGGL((k_smooth<TS, CC, SRC, DO_RES, FUSE, NSW>), dim3(ntx*nty), dim3(TS::NT), 0, st, b, phi_out, phi_out2, rhs, acf,
                        phi_in, crse, res_out, cres_out, facx, facy, ntx, resnorm, rhsnorm, sr);
 }
 
@@ -1178,13 +1185,24 @@ static void vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
                                               M->lv(il, M->L[il].cor), M->lv(il+1, crse), none, none, nullptr, nullptr, sr, st);
     }
     {
+        // level 0: cor[0] + P(correction), GSRB^4 (the smoothed solution), GSRB^4 + residual (solve_doit's
+        // iterate) in one pass: out of place between cor[0] and tmp0 (other tiles read the rims), the
+        // iterate also goes to the caller's slab
         double* crse = (1 == lb) ? M->L[1].cor : M->L[1].rescor;
-        launch_smooth<CC, SRC_PROLONG, false>(M, 0, M->lv(0, M->tmp0), none, M->rhs, M->acf0, M->lv(0, M->L[0].cor), M->lv(1, crse),
-                                              none, none, nullptr, nullptr, sr, st);
+        double* in = M->cor_in_tmp ? M->tmp0 : M->L[0].cor;
+        double* out = M->cor_in_tmp ? M->L[0].cor : M->tmp0;
+        if (M->fuse_level0) {
+            launch_smooth_ts<TileHuge, CC, SRC_PROLONG, true, 8>(M, 0, M->lv(0, out), M->sol, M->rhs, M->acf0, M->lv(0, in), M->lv(1, crse),
+                                                                 M->lv(0, M->L[0].rescor), M->lv(1, M->L[1].res), M->d_norms + (2 + k)*MG_NSUB,
+                                                                 nullptr, sr, st);
+            M->cor_in_tmp = !M->cor_in_tmp;
+        } else {
+            launch_smooth<CC, SRC_PROLONG, false>(M, 0, M->lv(0, M->tmp0), none, M->rhs, M->acf0, M->lv(0, M->L[0].cor), M->lv(1, crse),
+                                                  none, none, nullptr, nullptr, sr, st);
+            launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), M->sol, M->rhs, M->acf0, M->lv(0, M->tmp0), none,
+                                                M->lv(0, M->L[0].rescor), M->lv(1, M->L[1].res), M->d_norms + (2 + k)*MG_NSUB, nullptr, sr, st);
+        }
     }
-    // the last GSRB^4 of the V-cycle writes the iterate to cor[0] and to the caller's slab
-    launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), M->sol, M->rhs, M->acf0, M->lv(0, M->tmp0), none,
-                                        M->lv(0, M->L[0].rescor), M->lv(1, M->L[1].res), M->d_norms + (2 + k)*MG_NSUB, nullptr, sr, st);
     restrict_residual_if_nodal<CC>(M, 0, sr, st);
 }
 
@@ -1194,6 +1212,7 @@ static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_it
 {
     const int lb = M->lowv_begin;
     max_iters = std::min(max_iters, MG_MAX_VCYCLES);
+    M->cor_in_tmp = false;
     const StopRule always{nullptr, -1, 0.0, 0.0};
     // coefficient hierarchy (average_down_acoef, HpMultiGrid.cpp:1640-1700); level 0 reads the slab
     int first = 1;
