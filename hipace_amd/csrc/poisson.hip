@@ -66,9 +66,15 @@ struct DstArgs {
     long long* dbg;                 // optional: shader-clock stamps of workgroup 0 at the phase boundaries
 };
 #ifdef HPS_POISSON_STAMPS
-#define HPS_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+// stamps are kept in registers and written by HPS_STAMP_FLUSH at the end of the kernel: a global
+// store ahead of the DFT-table loads would keep those off the scalar path
+#define HPS_STAMP_DECL long long stamp_[6] = {0, 0, 0, 0, 0, 0}
+#define HPS_STAMP(i) do { stamp_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define HPS_STAMP_FLUSH do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) { for (int q_ = 0; q_ < 6; ++q_) a.dbg[q_] = stamp_[q_]; } } while (0)
 #else
-#define HPS_STAMP(i) do { } while (0)      /* global stores ahead of the table loads would keep them off the scalar path */
+#define HPS_STAMP_DECL do { } while (0)
+#define HPS_STAMP(i) do { } while (0)
+#define HPS_STAMP_FLUSH do { } while (0)
 #endif
 
 typedef __attribute__((address_space(3))) double lds_double;
@@ -166,6 +172,7 @@ void k_dst_rows (DstArgs a)
     const int total_rows = a.rows_per_plane*a.nplanes;
     const int row0 = blockIdx.x*2*T;
 
+    HPS_STAMP_DECL;
     HPS_STAMP(0);
     for (int k = tid; k < N1*N1; k += 256) { const double2 w = a.fa[k]; stc(fa, k, w.x, w.y); }
     for (int k = tid; k < N2*N2; k += 256) { const double2 w = a.fb[k]; stc(fb, k, w.x, w.y); }
@@ -272,6 +279,7 @@ void k_dst_rows (DstArgs a)
     // ---- post: r_a = Re X, r_b = Im X; T_k from r_{k+1} and r_{N-1-k}; optional scaling; store ----
     post_store<T, N1, N2>(cbuf, a, row0, total_rows, tid);
     HPS_STAMP(5);
+    HPS_STAMP_FLUSH;
 }
 
 
@@ -316,6 +324,7 @@ __device__ __forceinline__ void sym_stage (lds_double* cbuf, const double2* __re
     double2 x0 = make_double2(0.0, 0.0), ssum = make_double2(0.0, 0.0);
     if (active) {
         x0 = ldc(cbuf, base);
+        // (requesting step n+1's data pair and table row ahead of step n's FMAs by hand was measured slower)
 #pragma unroll HPS_SYM_UNROLL
         for (int n = 1; n <= H; ++n) {
             const double2 xa = ldc(cbuf, base + n*STRIDE), xb = ldc(cbuf, base + (M - n)*STRIDE);
@@ -369,6 +378,7 @@ void k_dst_rows_sym (DstArgs a)
     const int total_rows = a.rows_per_plane*a.nplanes;
     const int row0 = blockIdx.x*2*T;
 
+    HPS_STAMP_DECL;
     HPS_STAMP(0);
     load_row_pairs<T, N, NT>(cbuf, a, row0, total_rows, tid);
     __syncthreads();
@@ -400,6 +410,107 @@ void k_dst_rows_sym (DstArgs a)
     HPS_STAMP(4);
     post_store<T, N1, N2, NT>(cbuf, a, row0, total_rows, tid);
     HPS_STAMP(5);
+    HPS_STAMP_FLUSH;
+}
+
+// ---- y direction on column blocks, in place -----------------------------------------------------
+// One workgroup owns 2*CT adjacent columns of one plane (64-byte row segments for CT = 4): it
+// transforms them along y, multiplies by the inverse eigenvalues and transforms back, all in LDS --
+// the two transposes and one round trip through HBM of the row-wise formulation disappear.
+// a.src/a.dst: planes of `rows_per_plane` rows (y) with pitches src_pitch / dst_pitch; a.scale =
+// [nx][n] inverse eigenvalues (row = column index kx); N = ny + 1 = N1*N2.
+#ifndef HPS_DSTC_T
+#define HPS_DSTC_T 4
+#endif
+constexpr int DSTC_T = HPS_DSTC_T;
+template <int N1, int N2>
+__global__ __launch_bounds__(DSTS_NT)
+void k_dst_cols_sym (DstArgs a, int ncols)
+{
+    static_assert(N1 % 2 == 1 && N2 % 2 == 1, "symmetric kernel needs odd factors");
+    constexpr int N = N1*N2, n = N - 1, T = DSTC_T, NT = DSTS_NT, CB = 2*T;
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    lds_double* cbuf = (lds_double*)lds_raw;          // [T][N] complex: (column 2t, column 2t+1) at row j
+    const double2* __restrict__ csa = a.fa;
+    const double2* __restrict__ csb = a.fb;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nblk = (ncols + CB - 1)/CB;
+    const int plane = blockIdx.x / nblk, c0 = (blockIdx.x - plane*nblk)*CB;
+    const double* __restrict__ src = a.src[plane];
+    double* __restrict__ dst = a.dst[plane];
+
+    // rows j of the column block, CB doubles per row
+    for (int e = tid; e < n*CB; e += NT) {
+        const int j = e / CB, c = e - j*CB;
+        const double v = (c0 + c < ncols) ? src[(long)j*a.src_pitch + c0 + c] : 0.0;
+        cbuf[2*((c >> 1)*N + j) + (c & 1)] = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        {
+            constexpr int PP = (N/2 + NT)/NT;
+            double wr[T][PP], wi[T][PP], vr[T][PP], vi[T][PP];
+            pre_to_regs<T, N, PP, NT>(cbuf, tid, wr, wi, vr, vi);
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int m = 0; m < PP; ++m) {
+                    const int p = tid + NT*m;
+                    if (p <= N/2) {
+                        stc(cbuf, t*N + p, wr[t][m], wi[t][m]);
+                        if (p > 0) stc(cbuf, t*N + N - p, vr[t][m], vi[t][m]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        sym_stage<N1, N2, N2, N2, 1, true, T, NT/64>(cbuf, csa, a.tw, wave, lane);
+        sym_stage<N2, 1, 1, N1, N2, false, T, NT/64>(cbuf, csb, nullptr, wave, lane);
+        {
+            // T_k of both columns of every pair -> registers -> back to [t][k]
+            constexpr int KP = (n + NT - 1)/NT;
+            double ta[T][KP], tb[T][KP];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int m = 0; m < KP; ++m) {
+                    const int k = tid + NT*m;
+                    ta[t][m] = tb[t][m] = 0.0;
+                    if (k < n) {
+                        const int q1 = k + 1, q2 = N - 1 - k;
+                        const double2 x1 = ldc(cbuf, t*N + (q1 % N1)*N2 + q1/N1);
+                        const double2 x2 = ldc(cbuf, t*N + (q2 % N1)*N2 + q2/N1);
+                        const double is = a.isin4[k];
+                        double va = 0.5*(x2.x - x1.x) + (x1.x + x2.x)*is;
+                        double vb = 0.5*(x2.y - x1.y) + (x1.y + x2.y)*is;
+                        if (pass == 0) {
+                            const int ca = min(c0 + 2*t, ncols - 1), cb = min(c0 + 2*t + 1, ncols - 1);
+                            va *= a.scale[(long)ca*n + k];
+                            vb *= a.scale[(long)cb*n + k];
+                        }
+                        ta[t][m] = va; tb[t][m] = vb;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int m = 0; m < KP; ++m) {
+                    const int k = tid + NT*m;
+                    if (k < n) stc(cbuf, t*N + k, ta[t][m], tb[t][m]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < n*CB; e += NT) {
+        const int j = e / CB, c = e - j*CB;
+        if (c0 + c < ncols) dst[(long)j*a.dst_pitch + c0 + c] = cbuf[2*((c >> 1)*N + j) + (c & 1)];
+    }
 }
 
 // plane-wise transpose: dst[k][j] = src[j][k], src has `rows` rows of `cols` entries
@@ -419,10 +530,11 @@ void k_transpose (const double* __restrict__ src, double* __restrict__ dst, int 
 }
 
 typedef void (*dst_kernel_t)(DstArgs);
-struct DstImpl { int N, N1, N2; dst_kernel_t kernel; bool sym; int T; int nt; };
+typedef void (*dst_cols_kernel_t)(DstArgs, int);
+struct DstImpl { int N, N1, N2; dst_kernel_t kernel; bool sym; int T; int nt; dst_cols_kernel_t cols; };
 
-#define HPS_DST_IMPL(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows<N1, N2>, false, DST_T, 256}
-#define HPS_DST_SYM(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows_sym<N1, N2>, true, DSTS_T, DSTS_NT}
+#define HPS_DST_IMPL(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows<N1, N2>, false, DST_T, 256, nullptr}
+#define HPS_DST_SYM(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows_sym<N1, N2>, true, DSTS_T, DSTS_NT, k_dst_cols_sym<N1, N2>}
 static const DstImpl g_dst_impls[] = {
     HPS_DST_SYM(25, 41),    // nx = 1024
     HPS_DST_SYM(19, 27),    // 512
@@ -534,6 +646,7 @@ struct Poisson {
     int nx = 0, ny = 0;
     // own-transform back-end
     dst_kernel_t kx = nullptr, ky = nullptr;
+    dst_cols_kernel_t kcols = nullptr; size_t lds_cols = 0;     // y direction on column blocks (symmetric factorisations)
     double2 *tab_x = nullptr, *tab_y = nullptr;        // each: [fa | fb | tw] concatenated
     const double2 *fa_x = nullptr, *fb_x = nullptr, *tw_x = nullptr, *fa_y = nullptr, *fb_y = nullptr, *tw_y = nullptr;
     double *buf_a = nullptr, *buf_b = nullptr;         // [DST_MAXPLANES][nx*ny] ping-pong
@@ -608,6 +721,11 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
         P->fa_x = P->tab_x; P->fb_x = P->fa_x + nax; P->tw_x = P->fb_x + nbx;
         P->fa_y = P->tab_y; P->fb_y = P->fa_y + nay; P->tw_y = P->fb_y + nby;
         P->tx = ix->T; P->ty = iy->T; P->ntx = ix->nt; P->nty = iy->nt;
+        if (iy->cols && getenv("HPS_POISSON_COLS")) {      // measured no faster than rows + transposes (0.143 ms both): off by default
+            P->kcols = iy->cols;
+            P->lds_cols = (size_t)DSTC_T*Ny*sizeof(double2);
+            if (P->lds_cols > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->kcols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_cols));
+        }
         P->lds_x = ((size_t)ix->T*Nx + nax + nbx)*sizeof(double2);
         P->lds_y = ((size_t)iy->T*Ny + nay + nby)*sizeof(double2);
         if (P->lds_x > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->kx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_x));
@@ -717,19 +835,28 @@ int poisson_solve_batch (Poisson* P, int nb, const double* const* src, long src_
     a.src_pitch = src_pitch; a.dst_pitch = nx; a.scale = nullptr; a.fa = P->fa_x; a.fb = P->fb_x; a.tw = P->tw_x; a.isin4 = P->isin_x;
     a.rows_per_plane = ny; a.nplanes = nb;
     hipLaunchKernelGGL(P->kx, rows_grid(ny*nb, P->tx), dim3(P->ntx), P->lds_x, st, a);
-    // 2: transpose -> B[k][j]
-    hipLaunchKernelGGL(k_transpose, dim3(ceil_div(nx, 32), ceil_div(ny, 32), nb), dim3(256), 0, st, P->buf_a, P->buf_b, ny, nx, plane);
-    // 3: DST along y, times the inverse eigenvalues -> A
-    for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_b + b*plane; a.dst[b] = P->buf_a + b*plane; }
-    a.src_pitch = ny; a.dst_pitch = ny; a.scale = P->eig; a.fa = P->fa_y; a.fb = P->fb_y; a.tw = P->tw_y; a.isin4 = P->isin_y;
-    a.rows_per_plane = nx;
-    hipLaunchKernelGGL(P->ky, rows_grid(nx*nb, P->ty), dim3(P->nty), P->lds_y, st, a);
-    // 4: DST along y again -> B
-    for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_a + b*plane; a.dst[b] = P->buf_b + b*plane; }
-    a.scale = nullptr;
-    hipLaunchKernelGGL(P->ky, rows_grid(nx*nb, P->ty), dim3(P->nty), P->lds_y, st, a);
-    // 5: transpose back -> A[j][k]
-    hipLaunchKernelGGL(k_transpose, dim3(ceil_div(ny, 32), ceil_div(nx, 32), nb), dim3(256), 0, st, P->buf_b, P->buf_a, nx, ny, plane);
+    if (P->kcols) {
+        // 2-5: DST along y, inverse eigenvalues, DST along y -- in place on column blocks of A
+        for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_a + b*plane; a.dst[b] = P->buf_a + b*plane; }
+        a.src_pitch = nx; a.dst_pitch = nx; a.scale = P->eig; a.fa = P->fa_y; a.fb = P->fb_y; a.tw = P->tw_y; a.isin4 = P->isin_y;
+        a.rows_per_plane = ny;
+        hipLaunchKernelGGL(P->kcols, dim3(nb*ceil_div(nx, 2*DSTC_T)), dim3(DSTS_NT), P->lds_cols, st, a, nx);
+        a.scale = nullptr;
+    } else {
+        // 2: transpose -> B[k][j]
+        hipLaunchKernelGGL(k_transpose, dim3(ceil_div(nx, 32), ceil_div(ny, 32), nb), dim3(256), 0, st, P->buf_a, P->buf_b, ny, nx, plane);
+        // 3: DST along y, times the inverse eigenvalues -> A
+        for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_b + b*plane; a.dst[b] = P->buf_a + b*plane; }
+        a.src_pitch = ny; a.dst_pitch = ny; a.scale = P->eig; a.fa = P->fa_y; a.fb = P->fb_y; a.tw = P->tw_y; a.isin4 = P->isin_y;
+        a.rows_per_plane = nx;
+        hipLaunchKernelGGL(P->ky, rows_grid(nx*nb, P->ty), dim3(P->nty), P->lds_y, st, a);
+        // 4: DST along y again -> B
+        for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_a + b*plane; a.dst[b] = P->buf_b + b*plane; }
+        a.scale = nullptr;
+        hipLaunchKernelGGL(P->ky, rows_grid(nx*nb, P->ty), dim3(P->nty), P->lds_y, st, a);
+        // 5: transpose back -> A[j][k]
+        hipLaunchKernelGGL(k_transpose, dim3(ceil_div(ny, 32), ceil_div(nx, 32), nb), dim3(256), 0, st, P->buf_b, P->buf_a, nx, ny, plane);
+    }
     // 6: DST along x -> destination planes
     for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_a + b*plane; a.dst[b] = dst[b]; }
     a.src_pitch = nx; a.dst_pitch = dst_pitch; a.fa = P->fa_x; a.fb = P->fb_x; a.tw = P->tw_x; a.isin4 = P->isin_x;
