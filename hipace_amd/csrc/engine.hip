@@ -121,10 +121,12 @@ __global__ __launch_bounds__(256)
 void k_sxsy_beam (SlabView f, int cSx, int cSy, int cJzb, int cNx, int cNy, int cPx, int cPy,
                   double mu0, double dx2, double dy2, double dz2)
 {
-    const int i = blockIdx.x*blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    if (i >= f.nx) return;
+    // whole plane: the guard cells are set to 0 here (they are not part of InitializeSlices' zero list any more)
+    const int i = blockIdx.x*blockDim.x + threadIdx.x - f.ng;
+    const int j = blockIdx.y - f.ng;
+    if (i >= f.nx + f.ng) return;
     const long o = f.off(i, j);
+    if (i < 0 || i >= f.nx || j < 0 || j >= f.ny) { f.p[cSy*f.ns + o] = 0.0; f.p[cSx*f.ns + o] = 0.0; return; }
     const double* J = f.p + cJzb*f.ns + o;
     const double dx_jzb = (J[1] - J[-1])/dx2;
     const double dy_jzb = (J[f.js] - J[-f.js])/dy2;
@@ -409,7 +411,9 @@ int Engine::solve_slice (int islice)
     mark();   // b0
     // InitializeSlices (fields/Fields.cpp:535-586)
     {   CompList z{0, {}};
-        for (int c : {HPS_C_CHI, HPS_C_SY, HPS_C_SX, HPS_C_EXMBY, HPS_C_EYPBX, HPS_C_JZB, HPS_C_RHOMJZ, HPS_C_N_JXB, HPS_C_N_JYB}) z.c[z.n++] = c;
+        // Sx, Sy are written as whole planes by k_sxsy_beam; ExmBy, EypBx by k_grad_psi up to the outermost
+        // guard ring, which nothing ever writes (it keeps the zeros of begin_step)
+        for (int c : {HPS_C_CHI, HPS_C_JZB, HPS_C_RHOMJZ, HPS_C_N_JXB, HPS_C_N_JYB}) z.c[z.n++] = c;
         if (d.deposit_rho) z.c[z.n++] = HPS_C_RHO;
         hipLaunchKernelGGL(k_zero_comps, gplane, b256, 0, st, slab.p, slab.nstride, plane, z); }
 
@@ -440,7 +444,7 @@ int Engine::solve_slice (int islice)
     mark();   // b3
     // beam jx, jy of the next slice; beam part of Sx, Sy; plasma part of Sx, Sy (Hipace.cpp:656-663)
     if ((e = deposit_beam_slice(islice - 1, HPS_C_N_JXB, HPS_C_N_JYB, -1))) return e;
-    hipLaunchKernelGGL(k_sxsy_beam, gvalid, b256, 0, st, f, HPS_C_SX, HPS_C_SY, HPS_C_JZB, HPS_C_N_JXB, HPS_C_N_JYB,
+    hipLaunchKernelGGL(k_sxsy_beam, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_SX, HPS_C_SY, HPS_C_JZB, HPS_C_N_JXB, HPS_C_N_JYB,
                        HPS_C_P_JXB, HPS_C_P_JYB, gm.mu0, 2.0*gm.dx, 2.0*gm.dy, 2.0*gm.dz);
     mark();   // b4
     {   const int cache[4] = {HPS_C_BZ, HPS_C_EZ, HPS_C_EXMBY, HPS_C_EYPBX};

@@ -960,8 +960,10 @@ void k_lower_v2 (const Low2* __restrict__ dp, const double* __restrict__ acf_g, 
 struct PyrOut { double* p[5]; int nx[5], ny[5]; };      // levels 1..5, row pitch = nx
 
 __global__ __launch_bounds__(256)
-void k_acf_pyramid (FView acf0, int nx0, int ny0, PyrOut out, int nlev_out)
+void k_acf_pyramid (FView acf0, int nx0, int ny0, PyrOut out, int nlev_out, unsigned long long* zero, int nzero)
 {
+    // the first launch of a solve: it also clears the norm slots (saves a memset launch)
+    if (blockIdx.x == 0 && blockIdx.y == 0) for (int q = threadIdx.x; q < nzero; q += 256) zero[q] = 0ULL;
     __shared__ double s_a[2][16*16];
     const int t = threadIdx.x;
     const int bi = blockIdx.x*32, bj = blockIdx.y*32;       // level-0 origin of the block
@@ -1215,13 +1217,20 @@ static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_it
     M->cor_in_tmp = false;
     const StopRule always{nullptr, -1, 0.0, 0.0};
     // coefficient hierarchy (average_down_acoef, HpMultiGrid.cpp:1640-1700); level 0 reads the slab
+    // speculate as many V-cycles as the previous solve needed; each one is a no-op once converged
+    int nspec = std::min(std::max(M->last_iters, 1), std::max(max_iters, 1));
+    int nzeroed = std::min(max_iters, nspec + 8);
+    const int nzero_words = (2 + nzeroed)*MG_NSUB;
     int first = 1;
     if (CC) {
         PyrOut po{};
         const int np = std::min(lb, 5);
         for (int il = 1; il <= np; ++il) { po.p[il-1] = M->L[il].acf; po.nx[il-1] = M->L[il].b.hix + 1; po.ny[il-1] = M->L[il].b.hiy + 1; }
-        hipLaunchKernelGGL(k_acf_pyramid, dim3(ceil_div(M->nx, 32), ceil_div(M->ny, 32)), dim3(256), 0, st, M->acf0, M->nx, M->ny, po, np);
+        hipLaunchKernelGGL(k_acf_pyramid, dim3(ceil_div(M->nx, 32), ceil_div(M->ny, 32)), dim3(256), 0, st, M->acf0, M->nx, M->ny, po, np,
+                           M->d_norms, nzero_words);
         first = np + 1;
+    } else {
+        HPS_HIP_CHECK(hipMemsetAsync(M->d_norms, 0, nzero_words*sizeof(unsigned long long), st));
     }
     for (int il = first; il <= lb; ++il) {
         const LevBox& cb = M->L[il].b;
@@ -1229,10 +1238,6 @@ static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_it
         hipLaunchKernelGGL(k_restrict<CC>, dim3(ceil_div(cb.vhx - cb.vlx + 1, 64), cb.vhy - cb.vly + 1), dim3(64), 0, st,
                            cb, M->lv(il, M->L[il].acf), fine, 1, always);
     }
-    // speculate as many V-cycles as the previous solve needed; each one is a no-op once converged
-    int nspec = std::min(std::max(M->last_iters, 1), std::max(max_iters, 1));
-    HPS_HIP_CHECK(hipMemsetAsync(M->d_norms, 0, (2 + std::min(max_iters, nspec + 8))*MG_NSUB*sizeof(unsigned long long), st));
-    int nzeroed = std::min(max_iters, nspec + 8);
     // cor[0] = GSRB^4(sol), residual norm, rhs norm, res[1] = R(residual)  (solve_doit :1319-1346)
     launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), FView{}, M->rhs, M->acf0, M->sol, FView{}, M->lv(0, M->L[0].rescor),
                                         M->lv(1, M->L[1].res), M->d_norms, M->d_norms + MG_NSUB, always, st);
