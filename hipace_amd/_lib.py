@@ -92,6 +92,7 @@ _SIGS = {
     "hps_engine_set_tiling": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "hps_engine_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
     "hps_engine_sorts": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
+    "hps_engine_assume_initial_beam_support": (C.c_int, [C.c_void_p]),
     "hps_engine_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_phase_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hps_engine_beam_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.c_void_p]),

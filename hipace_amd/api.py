@@ -280,9 +280,13 @@ class SliceEngine:
         check(_lib.lib().hps_engine_beam_info(self._h, C.byref(nb), off))
         return nb.value, np.array(off[:], dtype=np.int64)
 
-    def set_beam_storage(self, tensor):
-        """Use `tensor` (float64, 7*nbeam, on this device) as the engine's beam blocks; None = own."""
+    def set_beam_storage(self, tensor, injected_beam_support=False):
+        """Use `tensor` (float64, 7*nbeam, on this device) as the engine's beam blocks; None = own.
+        injected_beam_support: the blocks are the injected beam handed along the ring (dt = 0), so the slab
+        kernels may keep skipping the beam planes outside its transverse support."""
         check(_lib.lib().hps_engine_set_beam_storage(self._h, C.c_void_p(tensor.data_ptr()) if tensor is not None else None))
+        if tensor is not None and injected_beam_support:
+            check(_lib.lib().hps_engine_assume_initial_beam_support(self._h))
 
     def initial_beam_into(self, tensor):
         check(_lib.lib().hps_engine_initial_beam(self._h, C.c_void_p(tensor.data_ptr())))

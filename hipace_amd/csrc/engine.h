@@ -34,6 +34,10 @@ struct Engine {
     // blocks [slice p from the head][7][count_p]; beam_cur = storage in use (own or caller's)
     double* beam_data = nullptr; double* beam_init = nullptr; double* beam_cur = nullptr;
     long nbeam = 0; std::vector<long> beam_off;
+    // support of the beam currents in padded-array cells (deposit footprint + the centred differences taken of
+    // them); the beam planes are identically zero outside, so the slab kernels skip them there
+    struct Box { int ilo, ihi, jlo, jhi; };
+    Box beam_box{0, -1, 0, -1}, beam_box_init{0, -1, 0, -1}, full_box{0, -1, 0, -1};
     int* d_nqsa = nullptr;
     double* d_checksum = nullptr;
     bool diagnostics = false;

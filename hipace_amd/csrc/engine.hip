@@ -29,12 +29,18 @@ void set_error (const std::string& msg) { g_err = msg; }
 // ------------------------------------------------------------------------------------------
 struct CompList { int n; int c[12]; };
 
+struct CellBox { int ilo, ihi, jlo, jhi; };     // padded-array cell range, inclusive
+
+// zero the components of `full` everywhere and those of `boxed` inside the box
 __global__ __launch_bounds__(256)
-void k_zero_comps (double* p, long ns, long plane, CompList cl)
+void k_zero_comps (double* p, long ns, long plane, int js, CompList full, CompList boxed, CellBox bb)
 {
     const long s = (long)blockIdx.x*blockDim.x + threadIdx.x;
     if (s >= plane) return;
-    for (int k = 0; k < cl.n; ++k) p[cl.c[k]*ns + s] = 0.0;
+    for (int k = 0; k < full.n; ++k) p[full.c[k]*ns + s] = 0.0;
+    const int j = (int)(s / js), i = (int)(s - (long)j*js);
+    if (i >= bb.ilo && i <= bb.ihi && j >= bb.jlo && j <= bb.jhi)
+        for (int k = 0; k < boxed.n; ++k) p[boxed.c[k]*ns + s] = 0.0;
 }
 
 __global__ __launch_bounds__(256)
@@ -45,6 +51,24 @@ void k_copy_comps (double* p, long ns, long plane, CompList dst, CompList src)
     double v[12];
     for (int k = 0; k < src.n; ++k) v[k] = p[src.c[k]*ns + s];
     for (int k = 0; k < dst.n; ++k) p[dst.c[k]*ns + s] = v[k];
+}
+
+// ShiftSlices (fields/Fields.cpp:588-604): Previous <- This <- Next for the beam currents, jx, jy <- Next.
+// The beam planes are zero outside the box: there only jx = jy = 0 is written.
+__global__ __launch_bounds__(256)
+void k_shift_slices (double* p, long ns, long plane, int js, CellBox bb)
+{
+    const long s = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (s >= plane) return;
+    const int j = (int)(s / js), i = (int)(s - (long)j*js);
+    double njx = 0.0, njy = 0.0;
+    if (i >= bb.ilo && i <= bb.ihi && j >= bb.jlo && j <= bb.jhi) {
+        const double tjx = p[HPS_C_JXB*ns + s], tjy = p[HPS_C_JYB*ns + s];
+        njx = p[HPS_C_N_JXB*ns + s]; njy = p[HPS_C_N_JYB*ns + s];
+        p[HPS_C_P_JXB*ns + s] = tjx; p[HPS_C_P_JYB*ns + s] = tjy;
+        p[HPS_C_JXB*ns + s] = njx;   p[HPS_C_JYB*ns + s] = njy;
+    }
+    p[HPS_C_JX*ns + s] = njx; p[HPS_C_JY*ns + s] = njy;
 }
 
 // AddRhoIons (fields/Fields.cpp:606-615) fused with the Psi source  -rhomjz/ep0  (:887-888)
@@ -119,14 +143,18 @@ void k_grad_psi (SlabView f, int cPsi, int cExmBy, int cEypBx, double hdx_inv, d
 // beam contribution to the Bx/By sources (Hipace::InitializeSxSyWithBeam, Hipace.cpp:744-790)
 __global__ __launch_bounds__(256)
 void k_sxsy_beam (SlabView f, int cSx, int cSy, int cJzb, int cNx, int cNy, int cPx, int cPy,
-                  double mu0, double dx2, double dy2, double dz2)
+                  double mu0, double dx2, double dy2, double dz2, CellBox bb)
 {
     // whole plane: the guard cells are set to 0 here (they are not part of InitializeSlices' zero list any more)
     const int i = blockIdx.x*blockDim.x + threadIdx.x - f.ng;
     const int j = blockIdx.y - f.ng;
     if (i >= f.nx + f.ng) return;
     const long o = f.off(i, j);
-    if (i < 0 || i >= f.nx || j < 0 || j >= f.ny) { f.p[cSy*f.ns + o] = 0.0; f.p[cSx*f.ns + o] = 0.0; return; }
+    // no beam current within reach (bb is in padded-array cells): the sources are 0 without a load
+    const int ia = i + f.ng, ja = j + f.ng;
+    if (i < 0 || i >= f.nx || j < 0 || j >= f.ny || ia < bb.ilo || ia > bb.ihi || ja < bb.jlo || ja > bb.jhi) {
+        f.p[cSy*f.ns + o] = 0.0; f.p[cSx*f.ns + o] = 0.0; return;
+    }
     const double* J = f.p + cJzb*f.ns + o;
     const double dx_jzb = (J[1] - J[-1])/dx2;
     const double dy_jzb = (J[f.js] - J[-f.js])/dy2;
@@ -259,6 +287,22 @@ int Engine::init_beam ()
     }
     beam_off[d.nz] = (long)h[0].size();
     nbeam = (long)h[0].size();
+    {
+        const int js = d.nx + 2*g, jn = d.ny + 2*g;
+        full_box = Box{0, js - 1, 0, jn - 1};
+        beam_box_init = Box{0, -1, 0, -1};          // empty
+        if (nbeam > 0) {
+            double xlo = h[0][0], xhi = h[0][0], ylo = h[1][0], yhi = h[1][0];
+            for (long k = 1; k < nbeam; ++k) { xlo = std::min(xlo, h[0][k]); xhi = std::max(xhi, h[0][k]); ylo = std::min(ylo, h[1][k]); yhi = std::max(yhi, h[1][k]); }
+            // nearest cell -+ (deposit footprint 2 + one cell for the centred differences + 1 spare)
+            const int m = 4;
+            beam_box_init.ilo = std::max(0,      (int)std::floor((xlo - gm.xoff)/gm.dx + 0.5) - m + g);
+            beam_box_init.ihi = std::min(js - 1, (int)std::floor((xhi - gm.xoff)/gm.dx + 0.5) + m + g);
+            beam_box_init.jlo = std::max(0,      (int)std::floor((ylo - gm.yoff)/gm.dy + 0.5) - m + g);
+            beam_box_init.jhi = std::min(jn - 1, (int)std::floor((yhi - gm.yoff)/gm.dy + 0.5) + m + g);
+        }
+        beam_box = beam_box_init;
+    }
     if (nbeam > 0) {
         // slice-major blocks: block p (p-th slice from the head) = [7][count_p] at 7*beam_off[p]
         std::vector<double> blk((size_t)7*nbeam);
@@ -410,12 +454,15 @@ int Engine::solve_slice (int islice)
 
     mark();   // b0
     // InitializeSlices (fields/Fields.cpp:535-586)
-    {   CompList z{0, {}};
+    const CellBox bb{beam_box.ilo, beam_box.ihi, beam_box.jlo, beam_box.jhi};
+    {   CompList z{0, {}}, zb{0, {}};
         // Sx, Sy are written as whole planes by k_sxsy_beam; ExmBy, EypBx by k_grad_psi up to the outermost
-        // guard ring, which nothing ever writes (it keeps the zeros of begin_step)
-        for (int c : {HPS_C_CHI, HPS_C_JZB, HPS_C_RHOMJZ, HPS_C_N_JXB, HPS_C_N_JYB}) z.c[z.n++] = c;
+        // guard ring, which nothing ever writes (it keeps the zeros of begin_step); the beam planes only
+        // ever hold values inside the beam's box
+        for (int c : {HPS_C_CHI, HPS_C_RHOMJZ}) z.c[z.n++] = c;
         if (d.deposit_rho) z.c[z.n++] = HPS_C_RHO;
-        hipLaunchKernelGGL(k_zero_comps, gplane, b256, 0, st, slab.p, slab.nstride, plane, z); }
+        for (int c : {HPS_C_JZB, HPS_C_N_JXB, HPS_C_N_JYB}) zb.c[zb.n++] = c;
+        hipLaunchKernelGGL(k_zero_comps, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, z, zb, bb); }
 
     mark();   // b1
     // plasma: jx, jy, [rho], chi, rhomjz (Hipace.cpp:609-610); beam: jz_beam on This (:613-614)
@@ -445,7 +492,7 @@ int Engine::solve_slice (int islice)
     // beam jx, jy of the next slice; beam part of Sx, Sy; plasma part of Sx, Sy (Hipace.cpp:656-663)
     if ((e = deposit_beam_slice(islice - 1, HPS_C_N_JXB, HPS_C_N_JYB, -1))) return e;
     hipLaunchKernelGGL(k_sxsy_beam, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_SX, HPS_C_SY, HPS_C_JZB, HPS_C_N_JXB, HPS_C_N_JYB,
-                       HPS_C_P_JXB, HPS_C_P_JYB, gm.mu0, 2.0*gm.dx, 2.0*gm.dy, 2.0*gm.dz);
+                       HPS_C_P_JXB, HPS_C_P_JYB, gm.mu0, 2.0*gm.dx, 2.0*gm.dy, 2.0*gm.dz, bb);
     mark();   // b4
     {   const int cache[4] = {HPS_C_BZ, HPS_C_EZ, HPS_C_EXMBY, HPS_C_EYPBX};
         const int depos[2] = {HPS_C_SY, HPS_C_SX};
@@ -471,9 +518,7 @@ int Engine::solve_slice (int islice)
 
     mark();   // b8
     // ShiftSlices (fields/Fields.cpp:588-604)
-    {   CompList dst{6, {HPS_C_P_JXB, HPS_C_P_JYB, HPS_C_JXB, HPS_C_JYB, HPS_C_JX, HPS_C_JY}};
-        CompList src{6, {HPS_C_JXB, HPS_C_JYB, HPS_C_N_JXB, HPS_C_N_JYB, HPS_C_N_JXB, HPS_C_N_JYB}};
-        hipLaunchKernelGGL(k_copy_comps, gplane, b256, 0, st, slab.p, slab.nstride, plane, dst, src); }
+    hipLaunchKernelGGL(k_shift_slices, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, bb);
     mark();   // b9
     HPS_HIP_CHECK(hipGetLastError());
     ++slices_done;
@@ -569,6 +614,14 @@ extern "C" int hps_engine_set_beam_storage (void* h, double* storage_dev)
 {
     Engine* E = static_cast<Engine*>(h);
     E->beam_cur = storage_dev ? storage_dev : E->beam_data;
+    // caller-owned particles may sit anywhere: treat the whole plane as beam support until told otherwise
+    E->beam_box = storage_dev ? E->full_box : E->beam_box_init;
+    return HPS_OK;
+}
+extern "C" int hps_engine_assume_initial_beam_support (void* h)
+{
+    Engine* E = static_cast<Engine*>(h);
+    E->beam_box = E->beam_box_init;
     return HPS_OK;
 }
 extern "C" int hps_engine_initial_beam (void* h, double* dst_dev)

@@ -51,7 +51,7 @@ struct TileShape {
     static constexpr int AX = TX + 2, AY = TY + 2;          // LDS array with ring
     static constexpr int PR = TX/2;                          // cell pairs per row
     static constexpr int GPAIRS = TX*TY/2/NT;                // cell pairs per thread
-    static_assert(TX*TY/2 % NT == 0 && NT % 64 == 0 && 64 % (2*PR) == 0 || PR == 32, "tile shape");
+    static_assert(TX*TY/2 % NT == 0 && NT % 64 == 0 && (PR == 16 || PR == 32), "tile shape");
 };
 #ifndef HPS_MG_BIG
 #define HPS_MG_BIG 64, 32, 512

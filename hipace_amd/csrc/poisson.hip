@@ -162,7 +162,7 @@ template <int N1, int N2>
 __global__ __launch_bounds__(256)
 void k_dst_rows (DstArgs a)
 {
-    constexpr int N = N1*N2, n = N - 1, T = DST_T;
+    constexpr int N = N1*N2, T = DST_T;
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_double* cbuf = (lds_double*)lds_raw;          // [T][N] complex working set
     lds_double* fa = cbuf + 2*T*N;                    // [N1][N1] first-stage DFT matrix
@@ -368,7 +368,6 @@ void k_dst_rows_sym (DstArgs a)
 {
     static_assert(N1 % 2 == 1 && N2 % 2 == 1, "symmetric kernel needs odd factors");
     constexpr int N = N1*N2, T = DSTS_T, NT = DSTS_NT;
-    constexpr int H1 = (N1 - 1)/2, H2 = (N2 - 1)/2;
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_double* cbuf = (lds_double*)lds_raw;          // [T][N] complex working set
     const double2* __restrict__ csa = a.fa;           // [H1][H1] (cos, sin)(2 pi n k / N1)

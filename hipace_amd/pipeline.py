@@ -119,7 +119,7 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
             continue
         step, islice, m = w
         if islice == nz - 1:
-            engine.set_beam_storage(bufs[m % 2])
+            engine.set_beam_storage(bufs[m % 2], injected_beam_support=True)     # hipace.dt = 0: the beam never moves
             engine.begin_step()
         waited = False
         for key in ((m, islice), (m, islice - 1)):            # this slice's beam and the next one's (jx/jy source)

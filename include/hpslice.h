@@ -199,6 +199,11 @@ int hps_engine_phase_times (void* handle, double* ms_host, long* nslices_host);
 int hps_engine_beam_info (void* handle, long* nbeam_host, long* offsets_host /* [nz+1] */);
 int hps_engine_set_beam_storage (void* handle, double* storage_dev /* [7*nbeam] or NULL = own */);
 int hps_engine_initial_beam (void* handle, double* dst_dev);
+/* The slab kernels skip the beam-current planes outside the beam's transverse support.  After
+ * hps_engine_set_beam_storage the support is the whole plane (caller-owned particles may sit anywhere); a driver
+ * that knows its blocks are the injected beam handed along the ring (hipace.dt = 0: the beam does not move) calls
+ * this to restore the support box of the injected beam. */
+int hps_engine_assume_initial_beam_support (void* handle);
 
 /* ---- ring pipeline over time steps (utils/MultiBuffer.H:21-34; MultiBuffer.cpp:444-609) --------
  * The hand-off itself is issued by the host driver (hipace_amd/pipeline.py) with RCCL

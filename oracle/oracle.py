@@ -309,7 +309,7 @@ class Engine:
         n = lib().orc_engine_beam_layout(self._h, _ptr(off))
         return n, off
 
-    def set_beam_storage(self, tensor):
+    def set_beam_storage(self, tensor, injected_beam_support=False):
         """tensor: CPU float64 torch tensor or numpy array of 7*nbeam doubles (kept alive by the caller)."""
         self._beam_keep = tensor
         ptr = tensor.data_ptr() if hasattr(tensor, "data_ptr") else tensor.ctypes.data
