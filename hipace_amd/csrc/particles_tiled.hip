@@ -237,6 +237,15 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
         else                   { i0 = nodal_weights<ORDER>(xmid, sx, dsx);   j0 = nodal_weights<ORDER>(ymid, sy, dsy); }
         const double qp = q_mass*psi_inv;
         const double vxvy = vx*vy, gy = gp - vy*vy, gx = gp - vx*vx;
+        // the source terms of ExplicitDeposition.cpp:225-252 are linear in the cached fields and in the
+        // (derivative) shapes: collect the per-particle coefficients once,
+        //   Sy += ss*(a1 Bz + a2 Ez + a3 ExmBy + a4 EypBx) + a5 dxs + a6 sdy,   Sx likewise with b1..b6,
+        // 17 fp64 operations per stencil cell instead of 30
+        const double cq = cdm*qp, cqc = cq*k.c_inv, cc = cdm*k.c;
+        const double a1 = cq*vx, a2 = -cqc*vy, a3 = cqc*vxvy, a4 = -cqc*gy, a5 = cc*vxvy, a6 = -cc*(gy - 1.0);
+        const double b1 = cq*vy, b2 = cqc*vx, b3 = cqc*gx, b4 = -cqc*vxvy, b5 = cc*(gx - 1.0), b6 = -cc*vxvy;
+#pragma unroll
+        for (int m = 0; m < NS; ++m) { dsx[m] *= k.dx_inv; dsy[m] *= k.dy_inv; }
         const int li = i0 - ox, lj = j0 - oy;
         const bool local = (li >= 0 && li + NS <= R && lj >= 0 && lj + NS <= R);
         if (!local) ++nfb;
@@ -255,14 +264,12 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
                     Bz = gp_[cBz*f.ns]; Ez = gp_[cEz*f.ns]; ExmBy = gp_[cExmBy*f.ns]; EypBx = gp_[cEypBx*f.ns];
                 }
                 const double ss = sx[ix]*sy[iy];
-                const double dxs = dsx[ix]*sy[iy]*k.dx_inv;
-                const double sdy = sx[ix]*dsy[iy]*k.dy_inv;
-                const double sy_add = cdm*(
-                    - ss*( -Bz*vx + (Ez*vy + ExmBy*(-vxvy) + EypBx*gy)*k.c_inv )*qp
-                    + ( -dxs*(-vxvy) - sdy*(gy - 1.0) )*k.c);
-                const double sx_add = cdm*(
-                    + ss*( Bz*vy + (Ez*vx + ExmBy*gx + EypBx*(-vxvy))*k.c_inv )*qp
-                    + ( dxs*(gx - 1.0) + sdy*(-vxvy) )*k.c);
+                const double dxs = dsx[ix]*sy[iy];
+                const double sdy = sx[ix]*dsy[iy];
+                const double ty = fma(a1, Bz, fma(a2, Ez, fma(a3, ExmBy, a4*EypBx)));
+                const double tx = fma(b1, Bz, fma(b2, Ez, fma(b3, ExmBy, b4*EypBx)));
+                const double sy_add = fma(ss, ty, fma(a5, dxs, a6*sdy));
+                const double sx_add = fma(ss, tx, fma(b5, dxs, b6*sdy));
                 if (local) { lds_add(acc + ls, sy_add); lds_add(acc + R*R + ls, sx_add); }
                 else       { atomic_add_f64(gp_ + cSy*f.ns, sy_add); atomic_add_f64(gp_ + cSx*f.ns, sx_add); }
             }
