@@ -323,6 +323,7 @@ class SliceEngine:
         real = np.empty((11, n), dtype=np.float64)
         idc = np.empty(n, dtype=np.uint64)
         if n:
-            check(_lib.lib().hps_memcpy_d2h(real.ctypes.data_as(C.c_void_p), C.c_void_p(p.x), real.nbytes))
+            for k, name in enumerate(PL_REAL):       # x_prev / y_prev may alias x / y inside the engine
+                check(_lib.lib().hps_memcpy_d2h(real[k].ctypes.data_as(C.c_void_p), C.c_void_p(getattr(p, name)), real[k].nbytes))
             check(_lib.lib().hps_memcpy_d2h(idc.ctypes.data_as(C.c_void_p), C.c_void_p(p.idcpu), idc.nbytes))
         return real, ((idc >> np.uint64(63)) & np.uint64(1)).astype(np.int32)

@@ -351,6 +351,10 @@ int Engine::create (const hps_deck& deck, int device)
         HPS_HIP_CHECK(hipMalloc(&pl_real, (size_t)np*11*sizeof(double)));
         double** arr[11] = {&pl.x, &pl.y, &pl.w, &pl.ux, &pl.uy, &pl.psi, &pl.x_prev, &pl.y_prev, &pl.ux_half, &pl.uy_half, &pl.psi_half};
         for (int k = 0; k < 11; ++k) *arr[k] = pl_real + (size_t)k*np;
+        // explicit solver: every push commits its state (temp_slice = false), so x_prev == x and y_prev == y at
+        // all times (PlasmaParticleAdvance.cpp:176-188): alias them -- two arrays less to write per push and to
+        // move per re-sort.  The C ABI keeps 11 pointers; the kernels skip the second store when two coincide.
+        pl.x_prev = pl.x; pl.y_prev = pl.y;
         HPS_HIP_CHECK(hipMalloc(&pl.idcpu, (size_t)np*sizeof(uint64_t)));
         HPS_HIP_CHECK(hipMalloc(&pl.ion_lev, (size_t)np*sizeof(int32_t)));
     }
@@ -377,6 +381,7 @@ int Engine::setup_tiling ()
     double** arr[11] = {&pl_alt.x, &pl_alt.y, &pl_alt.w, &pl_alt.ux, &pl_alt.uy, &pl_alt.psi, &pl_alt.x_prev, &pl_alt.y_prev,
                         &pl_alt.ux_half, &pl_alt.uy_half, &pl_alt.psi_half};
     for (int k = 0; k < 11; ++k) *arr[k] = pl_real_alt + (size_t)k*np;
+    pl_alt.x_prev = pl_alt.x; pl_alt.y_prev = pl_alt.y;
     HPS_HIP_CHECK(hipMalloc(&pl_alt.idcpu, (size_t)np*sizeof(uint64_t)));
     HPS_HIP_CHECK(hipMalloc(&pl_alt.ion_lev, (size_t)np*sizeof(int32_t)));
     return HPS_OK;

@@ -324,22 +324,31 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             if (!local) ++nfb;
             Fld F{0, 0, 0, 0, 0, 0};
             if (local) {
+                // tensor-product gather: x sums per stencil row, then one y weight per row and component
                 const double* b = img + lj*R + li;
 #pragma unroll 1
                 for (int iy = 0; iy < NS; ++iy) {
+                    double rp = 0.0, rd = 0.0, rez = 0.0, rbx = 0.0, rby = 0.0, rbz = 0.0;
 #pragma unroll
                     for (int ix = 0; ix < NS; ++ix) {
                         const int ls = iy*R + ix;
                         const double psi_c = lds_get(b + ls);
-                        const double ss = sx[ix]*sy[iy];
-                        F.ExmBy += (dsx[ix]*sy[iy])*psi_c*k.dx_inv;
-                        F.EypBx += (sx[ix]*dsy[iy])*psi_c*k.dy_inv;
-                        F.Ez  += ss*lds_get(b + R*R + ls);
-                        F.Bxc += ss*lds_get(b + 2*R*R + ls);
-                        F.Byc += ss*lds_get(b + 3*R*R + ls);
-                        F.Bz  += ss*lds_get(b + 4*R*R + ls);
+                        rp = fma(sx[ix], psi_c, rp);
+                        rd = fma(dsx[ix], psi_c, rd);
+                        rez = fma(sx[ix], lds_get(b + R*R + ls), rez);
+                        rbx = fma(sx[ix], lds_get(b + 2*R*R + ls), rbx);
+                        rby = fma(sx[ix], lds_get(b + 3*R*R + ls), rby);
+                        rbz = fma(sx[ix], lds_get(b + 4*R*R + ls), rbz);
                     }
+                    F.ExmBy = fma(sy[iy], rd, F.ExmBy);
+                    F.EypBx = fma(dsy[iy], rp, F.EypBx);
+                    F.Ez  = fma(sy[iy], rez, F.Ez);
+                    F.Bxc = fma(sy[iy], rbx, F.Bxc);
+                    F.Byc = fma(sy[iy], rby, F.Byc);
+                    F.Bz  = fma(sy[iy], rbz, F.Bz);
                 }
+                F.ExmBy *= k.dx_inv;
+                F.EypBx *= k.dy_inv;
             } else {
 #pragma unroll 1
                 for (int iy = 0; iy < NS; ++iy) {
@@ -375,7 +384,8 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             pl.x[ip] = xp; pl.y[ip] = yp;
             if (!k.temp_slice) {
                 pl.ux_half[ip] = ux; pl.uy_half[ip] = uy; pl.psi_half[ip] = psi;
-                pl.x_prev[ip] = xp;  pl.y_prev[ip] = yp;
+                if (pl.x_prev != pl.x) pl.x_prev[ip] = xp;      // (aliased by the engine: already stored)
+                if (pl.y_prev != pl.y) pl.y_prev[ip] = yp;
             }
 #pragma unroll 1
             for (int s = 0; s < 2; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);

@@ -88,7 +88,8 @@ void k_permute (hps_plasma src, hps_plasma dst, const unsigned int* perm)
     const unsigned int q = perm[p];
     dst.x[p] = src.x[q]; dst.y[p] = src.y[q]; dst.w[p] = src.w[q];
     dst.ux[p] = src.ux[q]; dst.uy[p] = src.uy[q]; dst.psi[p] = src.psi[q];
-    dst.x_prev[p] = src.x_prev[q]; dst.y_prev[p] = src.y_prev[q];
+    if (dst.x_prev != dst.x) dst.x_prev[p] = src.x_prev[q];     // the engine aliases x_prev/x, y_prev/y
+    if (dst.y_prev != dst.y) dst.y_prev[p] = src.y_prev[q];
     dst.ux_half[p] = src.ux_half[q]; dst.uy_half[p] = src.uy_half[q]; dst.psi_half[p] = src.psi_half[q];
     dst.idcpu[p] = src.idcpu[q]; dst.ion_lev[p] = src.ion_lev[q];
 }
