@@ -13,7 +13,7 @@ hps_engine_beam_info).
 Deadlock freedom by construction: all ranks advance through the same global pipeline *ticks*.
 Rank r is 2r ticks behind rank 0 (solving slice k needs the beam of slice k AND of slice k-1, whose
 jx/jy feed the explicit source term: Hipace.cpp:639-657, so a rank trails its predecessor by two
-slices).  In tick t every rank posts, in one batch,
+slices).  In tick t every rank posts, in one batch (= one RCCL group),
   * the send of the slice it solved in tick t-1 (if a later step exists), and
   * the receive of the slice its ring predecessor solved in tick t-1 (if that feeds one of its steps).
 For r > 0 that is slice k-1 while it solves slice k in the same tick; rank 0 receives the slices of
@@ -100,16 +100,15 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
                     block(bufs[(mw[2] + 1) % 2], mw[1]).copy_(t)      # MultiBuffer.cpp:299-308
                 else:
                     ops.append(("send", dist.P2POp(dist.isend, t, nxt), None))
-        # receives and sends go out as separate batches (recv first) so that waiting for this
-        # tick's receive never waits for the successor to pick up this tick's send
-        for kind in ("recv", "send"):
-            sel = [o for o in ops if o[0] == kind]
-            if not sel:
-                continue
-            reqs = dist.batch_isend_irecv([o[1] for o in sel])
-            for i, o in enumerate(sel):
-                rq = reqs[min(i, len(reqs) - 1)]          # coalescing backends return one request per batch
-                if kind == "recv":
+        # one batch per tick (one RCCL group: the send and the receive of a rank progress together, so a
+        # closed ring -- more steps than ranks -- cannot park every rank in a receive whose matching send is
+        # queued behind another receive).  Every send posted in tick t has its receive posted in tick t of
+        # the successor, and a rank posts its batch before it waits for anything of that tick.
+        if ops:
+            reqs = dist.batch_isend_irecv([o[1] for o in ops])
+            for i, o in enumerate(ops):
+                rq = reqs[i] if len(reqs) == len(ops) else reqs[-1]     # coalescing back-ends: one request per batch
+                if o[0] == "recv":
                     pending_recv[o[2]] = rq
                 else:
                     pending_send.append(rq)
