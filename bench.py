@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--n", type=int, default=1024, help="transverse cells per side")
     ap.add_argument("--ppc", type=int, default=2, help="plasma particles per cell per direction")
     ap.add_argument("--tile", type=int, default=16, help="particle tile size (0, 16, 32)")
-    ap.add_argument("--sort-period", type=int, default=32, help="max slices between particle re-sorts (adaptive below)")
+    ap.add_argument("--sort-period", type=int, default=128, help="max slices between particle re-sorts (adaptive below)")
     ap.add_argument("--cpu-slices", type=int, default=4, help="slices of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 

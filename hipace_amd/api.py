@@ -232,7 +232,7 @@ class SliceEngine:
         self._h = C.c_void_p()
         check(_lib.lib().hps_engine_create(C.byref(self._dk), device, C.byref(self._h)))
         if tile_size is not None:
-            check(_lib.lib().hps_engine_set_tiling(self._h, tile_size, sort_period or 8))
+            check(_lib.lib().hps_engine_set_tiling(self._h, tile_size, sort_period or 128))
         nc, ng, npart = C.c_int(), C.c_int(), C.c_long()
         check(_lib.lib().hps_engine_info(self._h, C.byref(nc), C.byref(ng), C.byref(npart)))
         self.ncomp, self.ng, self.nparticles = nc.value, ng.value, npart.value
@@ -254,7 +254,7 @@ class SliceEngine:
     def sync(self):
         check(_lib.lib().hps_engine_sync(self._h))
 
-    def set_tiling(self, tile_size=16, sort_period=8):
+    def set_tiling(self, tile_size=16, sort_period=128):
         check(_lib.lib().hps_engine_set_tiling(self._h, tile_size, sort_period))
 
     def fallbacks(self):

@@ -20,7 +20,7 @@ struct Engine {
     double* pl_real = nullptr;
     long np = 0;
     // tile-sorted sheet (sort.hip): second SoA buffer + tiling state
-    Tiling* tiling = nullptr; int tile_size = 16, sort_period = 8, since_sort = 0;
+    Tiling* tiling = nullptr; int tile_size = 16, sort_period = 128, since_sort = 0;
     hps_plasma pl_alt{}; double* pl_real_alt = nullptr;
     int* d_nfallback = nullptr;
     int* h_nfallback = nullptr;                 // pinned copy, refreshed every slice ahead of the multigrid sync

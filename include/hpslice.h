@@ -178,7 +178,7 @@ int hps_engine_stats (void* handle, long* total_vcycles, long* slices_done);
 /* accumulate the per-slice checksums (costs one reduction pass per slice; off by default) */
 int hps_engine_set_diagnostics (void* handle, int on);
 /* particle tiling of the engine: tile_size 0 = per-particle global-atomic kernels, 16 | 32 = LDS
- * tiles with a re-sort every sort_period slices (plasmas.reorder_period of the reference).
+ * tiles, re-sorted after sort_period slices at the latest (plasmas.reorder_period of the reference; see hps_engine_sorts).
  * Call before hps_engine_begin_step. */
 int hps_engine_set_tiling (void* handle, int tile_size, int sort_period);
 int hps_engine_fallbacks (void* handle, long* n_fallback_host);
