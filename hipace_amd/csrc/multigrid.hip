@@ -202,7 +202,9 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
 {
     constexpr int E = DO_RES ? NSW : NSW - 1;         // rim of the swept tile that is not final
     constexpr int GT_X = TS::TX, GT_Y = TS::TY, GA_X = TS::AX, GA_Y = TS::AY, MG_NT = TS::NT, GPAIRS = TS::GPAIRS, PR = TS::PR;
+    constexpr int AXH = GA_X/2, CH = GA_Y*AXH;        // entries per row / per plane of one colour
     const int tid = threadIdx.x;
+    const int cpar = (gi0 + gj0) & 1;                 // colour of ringed cell (0, 0) is (gi0 - 1 + gj0 - 1) & 1
     MG_STAMP(0);
     // per-thread cell pairs: rhs, coefficient and inverse diagonal stay in registers.  Index p is the
     // sweep parity in which the cell is updated (p = 0: sweeps 0 and 2, p = 1: sweeps 1 and 3), so
@@ -254,10 +256,17 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
                 v0[m] = inside ? a0 : 0.0; v1[m] = inside ? a1 : 0.0;
             }
         }
+        // LDS layout: the two colours of the red-black ordering in separate planes (cell (li, lj) of the
+        // ringed tile -> plane (i + j) & 1, row lj, entry li >> 1): a half-sweep then reads and writes
+        // consecutive doubles per lane instead of every other one (which is a 2-way bank conflict).
 #pragma unroll
         for (int m = 0; m < NF; ++m) {
             const int s = tid + MG_NT*m;
-            if (s < GA_X*GA_Y) { s_phi[0][s] = v0[m]; s_phi[1][s] = v1[m]; }
+            if (s < GA_X*GA_Y) {
+                const int lj = s / GA_X, li = s - lj*GA_X;
+                const int o = ((cpar + li + lj) & 1)*CH + lj*AXH + (li >> 1);
+                s_phi[0][o] = v0[m]; s_phi[1][o] = v1[m];
+            }
         }
     }
     __syncthreads();
@@ -273,12 +282,14 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
             const int jj = pi / PR, pk = pi - jj*PR;
             const int j = gj0 + jj;
             const int h = hx[m] ^ p;
-            const int i = gi0 + 2*pk + h;
-            const int o = (jj + 1)*GA_X + 2*pk + h + 1;
-            (void)i; (void)j;
-            const double n0 = (r0[m][p] - offdiag_m((const double*)&s_phi[0][o], GA_X, fxm[m][p], fym[m]))*ci[m][p];
-            const double n1 = (r1[m][p] - offdiag_m((const double*)&s_phi[1][o], GA_X, fxm[m][p], fym[m]))*ci[m][p];
-            if (INTERIOR || in[m][p]) { s_phi[0][o] = n0; s_phi[1][o] = n1; }
+            (void)j;
+            // self: plane p, entry pk + h; west / east: plane 1-p, entries pk, pk + 1; south / north: pk + h
+            const int row = (jj + 1)*AXH + pk;
+            const double* nb0 = &s_phi[0][(1 - p)*CH + row];
+            const double* nb1 = &s_phi[1][(1 - p)*CH + row];
+            const double n0 = (r0[m][p] - (fxm[m][p]*(nb0[0] + nb0[1]) + fym[m]*(nb0[h - AXH] + nb0[h + AXH])))*ci[m][p];
+            const double n1 = (r1[m][p] - (fxm[m][p]*(nb1[0] + nb1[1]) + fym[m]*(nb1[h - AXH] + nb1[h + AXH])))*ci[m][p];
+            if (INTERIOR || in[m][p]) { s_phi[0][p*CH + row + h] = n0; s_phi[1][p*CH + row + h] = n1; }
         }
         __syncthreads();
     }
@@ -295,20 +306,23 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
         bool fin[2];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const int ii = 2*pk + (hx[m] ^ p);
+            const int h = hx[m] ^ p;
+            const int ii = 2*pk + h;
             fin[p] = rowok && ii >= E && ii < GT_X - E && in[m][p];
             const int i = gi0 + ii;
-            const int o = (jj + 1)*GA_X + ii + 1;
+            const int row = (jj + 1)*AXH + pk;
+            const double f0 = s_phi[0][p*CH + row + h], f1 = s_phi[1][p*CH + row + h];
             q0[p] = 0.0; q1[p] = 0.0;
             if (DO_RES) {
-                const double t0 = residual_at<INTERIOR>((const double*)&s_phi[0][o], GA_X, i, j, b, r0[m][p], ac[m][p], facx, facy);
-                const double t1 = residual_at<INTERIOR>((const double*)&s_phi[1][o], GA_X, i, j, b, r1[m][p], ac[m][p], facx, facy);
+                const double* nb0 = &s_phi[0][(1 - p)*CH + row];
+                const double* nb1 = &s_phi[1][(1 - p)*CH + row];
+                const double t0 = residual_v<INTERIOR>(f0, nb0[0], nb0[1], nb0[h - AXH], nb0[h + AXH], i, j, b, r0[m][p], ac[m][p], facx, facy);
+                const double t1 = residual_v<INTERIOR>(f1, nb1[0], nb1[1], nb1[h - AXH], nb1[h + AXH], i, j, b, r1[m][p], ac[m][p], facx, facy);
                 q0[p] = fin[p] ? t0 : 0.0; q1[p] = fin[p] ? t1 : 0.0;
                 resmax = fmax(resmax, fmax(fabs(q0[p]), fabs(q1[p])));
             }
             if (fin[p]) {
                 if (DO_RES && !FUSE_R) { res_out(i, j, 0) = q0[p]; res_out(i, j, 1) = q1[p]; }
-                const double f0 = s_phi[0][o], f1 = s_phi[1][o];
                 phi_out(i, j, 0) = f0;
                 phi_out(i, j, 1) = f1;
                 if (phi_out2.p) { phi_out2(i, j, 0) = f0; phi_out2(i, j, 1) = f1; }
