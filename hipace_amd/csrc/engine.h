@@ -6,6 +6,8 @@
 #include <vector>
 #include "tiling.h"
 
+void mg_rider (void* mg_handle, int** dev_words, const int** host_words);     // multigrid.hip
+
 namespace hps {
 
 struct BeamView { double *x, *y, *z, *ux, *uy, *uz, *w; };
@@ -22,8 +24,8 @@ struct Engine {
     // tile-sorted sheet (sort.hip): second SoA buffer + tiling state
     Tiling* tiling = nullptr; int tile_size = 16, sort_period = 128, since_sort = 0;
     hps_plasma pl_alt{}; double* pl_real_alt = nullptr;
-    int* d_nfallback = nullptr;
-    int* h_nfallback = nullptr;                 // pinned copy, refreshed every slice ahead of the multigrid sync
+    int* d_nfallback = nullptr;                 // word 0 of the multigrid norm buffer's header slot (mg_rider)
+    const int* h_nfallback = nullptr;           // its pinned image, refreshed by every multigrid solve
     long fb_at_sort = 0; int n_sorts = 0;       // adaptive re-sort: fallbacks at the last sort, number of sorts
     int setup_tiling ();
     int resort ();

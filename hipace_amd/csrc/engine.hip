@@ -242,7 +242,7 @@ Engine::~Engine ()
     if (mg) hps_mg_destroy(mg);
     (void)hipFree(slab.p); (void)hipFree(pl_real); (void)hipFree(pl.idcpu); (void)hipFree(pl.ion_lev);
     delete tiling;
-    (void)hipFree(pl_real_alt); (void)hipFree(pl_alt.idcpu); (void)hipFree(pl_alt.ion_lev); (void)hipFree(d_nfallback); if (h_nfallback) (void)hipHostFree(h_nfallback);
+    (void)hipFree(pl_real_alt); (void)hipFree(pl_alt.idcpu); (void)hipFree(pl_alt.ion_lev); 
     (void)hipFree(staging); (void)hipFree(beam_data); (void)hipFree(beam_init); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
     for (auto e : ev) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
@@ -358,16 +358,17 @@ int Engine::create (const hps_deck& deck, int device)
         HPS_HIP_CHECK(hipMalloc(&pl.idcpu, (size_t)np*sizeof(uint64_t)));
         HPS_HIP_CHECK(hipMalloc(&pl.ion_lev, (size_t)np*sizeof(int32_t)));
     }
-    HPS_HIP_CHECK(hipMalloc(&d_nfallback, sizeof(int)));
-    HPS_HIP_CHECK(hipMemset(d_nfallback, 0, sizeof(int)));
-    HPS_HIP_CHECK(hipHostMalloc(&h_nfallback, sizeof(int)));
-    *h_nfallback = 0;
     HPS_HIP_CHECK(hipMalloc(&d_nqsa, sizeof(int)));
     HPS_HIP_CHECK(hipMemset(d_nqsa, 0, sizeof(int)));
     HPS_HIP_CHECK(hipMalloc(&d_checksum, HPS_NCOMP_MAX*sizeof(double)));
     HPS_HIP_CHECK(hipMemset(d_checksum, 0, HPS_NCOMP_MAX*sizeof(double)));
     if (int e = hps_poisson_create(d.nx, d.ny, gm.dx, gm.dy, &ps)) return e;
     if (int e = hps_mg_create(d.nx, d.ny, gm.dx, gm.dy, &mg)) return e;
+    // the halo-fallback counter lives in the header slot of the multigrid's norm buffer: it reaches the host
+    // with the read-back every solve does anyway (no copy of its own)
+    {   int* dw = nullptr; const int* hw = nullptr;
+        mg_rider(mg, &dw, &hw);
+        d_nfallback = dw; h_nfallback = hw; }
     return init_beam();
 }
 
@@ -504,7 +505,6 @@ int Engine::solve_slice (int islice)
         if (tiling) { if ((e = explicit_deposit_tiled(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, tiling, d_nfallback, st))) return e; }
         else        { if ((e = hps_explicit_deposit(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, st))) return e; } }
 
-    if (tiling) HPS_HIP_CHECK(hipMemcpyAsync(h_nfallback, d_nfallback, sizeof(int), hipMemcpyDeviceToHost, st));
     mark();   // b5
     // Bx, By: Helmholtz multigrid from the previous slice's field (Hipace.cpp:793-933)
     {   int iters = 0;

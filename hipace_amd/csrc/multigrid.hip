@@ -862,7 +862,13 @@ void k_lower_v2 (const Low2* __restrict__ dp, const double* __restrict__ acf_g, 
         A.r0[k] = A.ok[k] ? v0 : 0.0; A.r1[k] = A.ok[k] ? v1 : 0.0; aA[k] = A.ok[k] ? v2 : 0.0;
         A.ci[k] = 1.0/diag_c0<true>(i, j, bA, aA[k], facx0, facy0);
     }
-    for (int s = t; s < d.total; s += 1024) base[s] = 0.0;
+    // only the correction planes need zeros (ring + the cells of the colour the first half-sweep skips); the
+    // rhs / coefficient / inverse-diagonal planes are written before they are read
+    for (int l = 0; l < nl; ++l) {
+        const int n2 = 2*(d.nx[l] + 2)*(d.ny[l] + 2);
+        lds_double* c = base + d.off[l];
+        for (int s = t; s < n2; s += 1024) c[s] = 0.0;
+    }
     __syncthreads();
     // ---- coefficient hierarchy (average_down_acoef) and inverse diagonals of the levels below
     if (nl > 1 && A.act) {
@@ -1024,6 +1030,9 @@ struct Multigrid {
     std::vector<MGLevelDev> L;
     int lowv_begin = 1;                         // first level handled by k_lower_v
     LowLev* d_low = nullptr; size_t low_lds = 0;
+    // device / pinned buffers: one header slot (MG_NSUB words: a caller's counters ride along with the norm
+    // read-back, see hps_mg_rider) followed by the norm slots; d_norms / h_norms point at slot 0
+    unsigned long long *d_buf = nullptr, *h_buf = nullptr;
     unsigned long long* d_norms = nullptr;      // [0] residual, [1] rhs
     unsigned long long* h_norms = nullptr;      // pinned copy of d_norms (2 + MG_MAX_VCYCLES slots)
     int last_iters = 1;                         // V-cycles of the previous solve = speculation depth
@@ -1036,8 +1045,8 @@ struct Multigrid {
 
     ~Multigrid () {
         for (auto& l : L) { (void)hipFree(l.acf); (void)hipFree(l.res); (void)hipFree(l.cor); (void)hipFree(l.rescor); }
-        (void)hipFree(d_norms); (void)hipFree(d_low); (void)hipFree(tmp0); (void)hipFree(d_low2);
-        if (h_norms) (void)hipHostFree(h_norms);
+        (void)hipFree(d_buf); (void)hipFree(d_low); (void)hipFree(tmp0); (void)hipFree(d_low2);
+        if (h_buf) (void)hipHostFree(h_buf);
     }
     FView lv (int il, double* p) const {
         const MGLevelDev& l = L[il];
@@ -1121,8 +1130,11 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
     }
     HPS_HIP_CHECK(hipMalloc(&M->d_low, low.size()*sizeof(LowLev)));
     HPS_HIP_CHECK(hipMemcpy(M->d_low, low.data(), low.size()*sizeof(LowLev), hipMemcpyHostToDevice));
-    HPS_HIP_CHECK(hipMalloc(&M->d_norms, (2 + MG_MAX_VCYCLES)*MG_NSUB*sizeof(unsigned long long)));
-    HPS_HIP_CHECK(hipHostMalloc(&M->h_norms, (2 + MG_MAX_VCYCLES)*MG_NSUB*sizeof(unsigned long long)));
+    HPS_HIP_CHECK(hipMalloc(&M->d_buf, (3 + MG_MAX_VCYCLES)*MG_NSUB*sizeof(unsigned long long)));
+    HPS_HIP_CHECK(hipHostMalloc(&M->h_buf, (3 + MG_MAX_VCYCLES)*MG_NSUB*sizeof(unsigned long long)));
+    HPS_HIP_CHECK(hipMemset(M->d_buf, 0, (3 + MG_MAX_VCYCLES)*MG_NSUB*sizeof(unsigned long long)));
+    memset(M->h_buf, 0, (3 + MG_MAX_VCYCLES)*MG_NSUB*sizeof(unsigned long long));
+    M->d_norms = M->d_buf + MG_NSUB; M->h_norms = M->h_buf + MG_NSUB;
     HPS_HIP_CHECK(hipMalloc(&M->tmp0, 2*M->L[0].cells*sizeof(double)));
     HPS_HIP_CHECK(hipMemset(M->tmp0, 0, 2*M->L[0].cells*sizeof(double)));
     *out = M;
@@ -1274,7 +1286,7 @@ static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_it
             }
             vcycle<CC>(M, enq, tol_rel, tol_abs, st);
         }
-        HPS_HIP_CHECK(hipMemcpyAsync(M->h_norms, M->d_norms, (2 + enq)*MG_NSUB*sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HPS_HIP_CHECK(hipMemcpyAsync(M->h_buf, M->d_buf, (3 + enq)*MG_NSUB*sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HPS_HIP_CHECK(hipStreamSynchronize(st));
         // replay the stopping rule on the host (solve_doit :1352-1398)
         const double res0 = slot_value(0), rhs0 = slot_value(1);
@@ -1345,6 +1357,15 @@ extern "C" int hps_mg_solve1 (void* handle, hps_slab slab, int sol_comp, int rhs
 }
 
 // debug: first call arms the stamps, later calls read the 16 slots back
+// A header slot of the norm buffer for the caller's own device counters: they reach the host with the read-back
+// every solve does anyway (the engine's halo-fallback counter uses word 0).
+void mg_rider (void* handle, int** dev_words, const int** host_words)
+{
+    Multigrid* M = static_cast<Multigrid*>(handle);
+    *dev_words = reinterpret_cast<int*>(M->d_buf);
+    *host_words = reinterpret_cast<const int*>(M->h_buf);
+}
+
 extern "C" int hps_mg_debug_stamps (long long* stamps16_host)
 {
     static long long* d = nullptr;
