@@ -31,7 +31,11 @@ _DEFAULT = dict(
     mg_tol_rel=1.0e-4,       # hipace.MG_tolerance_rel (Hipace.H:246)
     mg_tol_abs=2.2250738585072014e-308,   # numeric_limits<double>::min() (Hipace.H:248)
     deposit_rho=0,
-    n_steps=1,               # max_step + 1; hipace.dt = 0 so the beam never moves
+    n_steps=1,               # max_step + 1
+    dt=0.0,                  # hipace.dt; 0 in every BASELINE deck: the beam never moves
+    beam_n_subcycles=10,     # beam.n_subcycles (BeamParticleContainer.H:222)
+    beam_mass=1.0,
+    ext_E_slope=(0.0, 0.0),  # beams.external_E(x,y,z,t) = s0*x s1*y 0.
 )
 
 
@@ -65,4 +69,15 @@ def synthetic(n=1024, nz=1024, ppc=2):
     return d
 
 
-NAMED = dict(blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum)
+def beam_evolution():
+    """tests/beam_evolution.1Rank.sh: beam_in_vacuum deck, 32x32x10, 21 steps of dt = 3 in a linear focusing field."""
+    d = copy.deepcopy(_DEFAULT)
+    d.update(nx=32, ny=32, nz=10, lo=(-2.0, -2.0, -2.0), hi=(2.0, 2.0, 2.0), order=2,
+             plasma_ppc=(0, 0), plasma_density=0.0,
+             beam_profile=1, beam_zmin=-10.0, beam_zmax=10.0, beam_radius=1.0, beam_density=1.0e-8,
+             beam_umean=(0.0, 0.0, 1.0e3), beam_ppc=(4, 4, 1), n_steps=21, dt=3.0, ext_E_slope=(0.5, 0.5))
+    return d
+
+
+NAMED = dict(blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
+             beam_evolution=beam_evolution)

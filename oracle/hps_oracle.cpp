@@ -875,9 +875,15 @@ struct Deck {
     double mg_tol_rel, mg_tol_abs;
     int deposit_rho;
     int n_steps;                 // max_step + 1 (dt = 0: every step identical)
+    double dt;                   // hipace.dt: 0 = the beam is never pushed
+    int beam_n_subcycles;        // beam.n_subcycles (BeamParticleContainer.H:222, default 10)
+    double beam_mass;
+    double ext_E_slope[2];       // beams.external_E = (s0*x, s1*y, 0): the only external field form restated
 };
 
-struct Beam { std::vector<double> x, y, z, ux, uy, uz, w; };
+// particles of one beam slice; [0, nreg) were on the slice when the step began ("regular"), the rest slipped in
+// from the slice ahead during this step (BeamParticleContainer.H:175-182)
+struct Beam { std::vector<double> x, y, z, ux, uy, uz, w; std::vector<int> nsub; std::vector<int32_t> valid; long nreg = 0; };
 
 struct Engine {
     Deck d; Geom gm; int g; int ncomp;
@@ -885,6 +891,9 @@ struct Engine {
     std::vector<double> pdata; std::vector<int32_t> pvalid, pion; Plasma pl;
     PoissonSolver* ps; MG* mg; std::vector<double> staging;
     Beam beam_this, beam_next;
+    // dt != 0: the beam lives in per-slice stores across the time steps (index = islice)
+    std::vector<Beam> store; bool store_ready = false; int steps_begun = 0; double phys_time = 0.0;
+    double beam_diag[7] = {0, 0, 0, 0, 0, 0, 0};   // n, sum w, |x|, |y|, |z|, |ux|, |uz| before the push (regular particles)
     // optional external beam storage in the product's block layout (pipeline tests):
     // block p (p-th slice from the head) = [7][count_p] at 7*ext_off[p]
     const double* ext_beam = nullptr; std::vector<long> ext_off;
@@ -1016,12 +1025,14 @@ struct Engine {
     }
 
     // DepositCurrentSlice for beams (deposition/BeamDepositCurrent.cpp:21-195)
-    void deposit_beam (const Beam& b, int cjx, int cjy, int cjz) {
+    void deposit_beam (const Beam& b, int cjx, int cjy, int cjz, long count = -1) {
         const double dxi = 1.0/gm.dx, dyi = 1.0/gm.dy;
         const double invvol = 1.0;   // normalised, lev 0
         const double clightsq = 1.0/(gm.c*gm.c);
         const double q = d.beam_charge;
-        for (size_t ip = 0; ip < b.x.size(); ++ip) {
+        const size_t np = count < 0 ? b.x.size() : (size_t)count;     // getNumParticles: without slipped (:100)
+        for (size_t ip = 0; ip < np; ++ip) {
+            if (!b.valid.empty() && !b.valid[ip]) continue;
             const double ux = b.ux[ip], uy = b.uy[ip], uz = b.uz[ip];
             const double gaminv = 1.0/std::sqrt(1.0 + ux*ux*clightsq + uy*uy*clightsq + uz*uz*clightsq);
             const double wq = q*b.w[ip]*invvol;
@@ -1088,7 +1099,9 @@ struct Engine {
     // Hipace::SolveOneSlice, explicit branch (Hipace.cpp:556-728)
     void solve_one_slice (int islice, bool accumulate) {
         double t0 = now();
-        if (islice == d.nz - 1) init_beam_slice(islice, beam_this);
+        const bool moving = (d.dt != 0.0);
+        if (moving) ensure_store();
+        else if (islice == d.nz - 1) init_beam_slice(islice, beam_this);
         // InitializeSlices (fields/Fields.cpp:535-586)
         for (int c : {(int)chi, (int)Sy, (int)Sx, (int)ExmBy, (int)EypBx, (int)jzb, (int)rhomjz, (int)N_jxb, (int)N_jyb}) zero_comp(c);
         if (d.deposit_rho) zero_comp(rho);
@@ -1097,15 +1110,19 @@ struct Engine {
         { const int comp[6] = {jx, jy, -1, d.deposit_rho ? (int)rho : -1, chi, rhomjz};
           n_qsa_total += deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0); }
         double t2 = now(); t_deposit += t2 - t1;
-        deposit_beam(beam_this, -1, -1, jzb);
+        if (moving) deposit_beam(store[islice], -1, -1, jzb, store[islice].nreg);
+        else deposit_beam(beam_this, -1, -1, jzb);
         // AddRhoIons (fields/Fields.cpp:606-615)
         for (long k = 0; k < slab.ns; ++k) slab.comp(rhomjz)[k] += slab.comp(Ion_rhomjz)[k];
         if (d.deposit_rho) for (long k = 0; k < slab.ns; ++k) slab.comp(rho)[k] += slab.comp(Ion_rhomjz)[k];
         double t3 = now(); t_other += t3 - t2;
         solve_psi_ez_bz();
         double t4 = now(); t_poisson += t4 - t3;
-        if (islice - 1 >= 0) init_beam_slice(islice - 1, beam_next); else beam_next = Beam();
-        deposit_beam(beam_next, N_jxb, N_jyb, -1);
+        if (moving) { if (islice - 1 >= 0) deposit_beam(store[islice - 1], N_jxb, N_jyb, -1, store[islice - 1].nreg); }
+        else {
+            if (islice - 1 >= 0) init_beam_slice(islice - 1, beam_next); else beam_next = Beam();
+            deposit_beam(beam_next, N_jxb, N_jyb, -1);
+        }
         init_sxsy_with_beam();
         double t5 = now(); t_other += t5 - t4;
         { const int cache[4] = {Bz, Ez, ExmBy, EypBx}; const int depos[2] = {Sy, Sx};
@@ -1127,12 +1144,104 @@ struct Engine {
         double t8 = now(); t_other += t8 - t7;
         { const int comp[5] = {Psi, Ez, Bx, By, Bz};
           advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0); }
+        if (moving) {
+            // beam diagnostics before the push (Hipace.cpp:685-686), then push and hand the slipped particles
+            // to the next slice (:704-706)
+            const Beam& b = store[islice];
+            for (long k = 0; k < b.nreg; ++k) {
+                if (!b.valid[k]) continue;
+                beam_diag[0] += 1; beam_diag[1] += std::abs(b.w[k]); beam_diag[2] += std::abs(b.x[k]); beam_diag[3] += std::abs(b.y[k]);
+                beam_diag[4] += std::abs(b.z[k]); beam_diag[5] += std::abs(b.ux[k]); beam_diag[6] += std::abs(b.uz[k]);
+            }
+            advance_beam_slice(islice);
+            shift_slipped(islice);
+        }
         double t9 = now(); t_push += t9 - t8;
         // ShiftSlices (fields/Fields.cpp:588-604)
         copy_comp(P_jxb, jxb); copy_comp(P_jyb, jyb);
         copy_comp(jxb, N_jxb); copy_comp(jyb, N_jyb); copy_comp(jx, N_jxb); copy_comp(jy, N_jyb);
-        beam_this = beam_next;
+        if (!moving) beam_this = beam_next;
         t_other += now() - t9;
+    }
+
+    void ensure_store () {
+        if (store_ready) return;
+        store.assign((size_t)d.nz, Beam());
+        for (int isl = 0; isl < d.nz; ++isl) {
+            Beam& b = store[isl];
+            gen_beam_slice(isl, b);
+            b.nsub.assign(b.x.size(), 0); b.valid.assign(b.x.size(), 1); b.nreg = (long)b.x.size();
+        }
+        store_ready = true;
+    }
+
+    // AdvanceBeamParticlesSlice (particles/pusher/BeamParticleAdvance.cpp:20-336) without radiation reaction,
+    // spin and mesh refinement; external field E = (s0 x, s1 y, 0) (ExternalFields.H:29-56)
+    void advance_beam_slice (int islice) {
+        Beam& b = store[islice];
+        const int nsc = d.beam_n_subcycles;
+        const Real dt = d.dt/nsc;
+        const Real clight = gm.c, inv_c2 = 1.0/(gm.c*gm.c);
+        const Real qm = d.beam_charge/d.beam_mass;
+        const Real min_z = d.lo[2] + islice*gm.dz;
+        const Real dx_inv = 1.0/gm.dx, dy_inv = 1.0/gm.dy;
+        const int comp[5] = {Psi, Ez, Bx, By, Bz};
+        const bool ext = (d.ext_E_slope[0] != 0.0 || d.ext_E_slope[1] != 0.0);
+        for (size_t ip = 0; ip < b.x.size(); ++ip) {          // getNumParticlesIncludingSlipped (:131)
+            if (!b.valid[ip]) continue;
+            Real xp = b.x[ip], yp = b.y[ip], zp = b.z[ip], ux = b.ux[ip], uy = b.uy[ip], uz = b.uz[ip];
+            int i = b.nsub[ip];
+            bool gone = false;
+            for (; i < nsc; ++i) {
+                if (zp < min_z) break;                         // not on this slice any more (:150-153)
+                const Real gammap_inv = 1.0/std::sqrt(1.0 + (ux*ux + uy*uy + uz*uz)*inv_c2);
+                xp += dt*0.5*ux*gammap_inv;
+                yp += dt*0.5*uy*gammap_inv;
+                if (enforce_bc(gm, xp, yp, ux, uy, b.w[ip], b.valid[ip])) { gone = true; break; }
+                Real ExmByp = 0, EypBxp = 0, Ezp = 0, Bxp = 0, Byp = 0, Bzp = 0;
+                gather(d.order, xp, yp, ExmByp, EypBxp, Ezp, Bxp, Byp, Bzp, slab, comp, dx_inv, dy_inv, gm.xoff, gm.yoff);
+                if (ext) {
+                    const Real Ex = d.ext_E_slope[0]*xp, Ey = d.ext_E_slope[1]*yp, Ezx = 0.0, Bx_ = 0.0, By_ = 0.0, Bz_ = 0.0;
+                    ExmByp += Ex - clight*By_; EypBxp += Ey + clight*Bx_; Ezp += Ezx; Bxp += Bx_; Byp += By_; Bzp += Bz_;
+                }
+                const Real ux_next = ux + dt*qm*(ExmByp + (clight - uz*gammap_inv)*Byp + uy*gammap_inv*Bzp);
+                const Real uy_next = uy + dt*qm*(EypBxp + (uz*gammap_inv - clight)*Bxp - ux*gammap_inv*Bzp);
+                const Real ux_i = (ux_next + ux)*0.5, uy_i = (uy_next + uy)*0.5;
+                const Real uz_i = uz + dt*0.5*qm*Ezp;
+                const Real gamma_i_inv = 1.0/std::sqrt(1.0 + (ux_i*ux_i + uy_i*uy_i + uz_i*uz_i)*inv_c2);
+                const Real uz_next = uz + dt*qm*(Ezp + (ux_i*Byp - uy_i*Bxp)*gamma_i_inv);
+                const Real gamma_next_inv = 1.0/std::sqrt(1.0 + (ux_next*ux_next + uy_next*uy_next + uz_next*uz_next)*inv_c2);
+                xp += dt*0.5*ux_next*gamma_next_inv;
+                yp += dt*0.5*uy_next*gamma_next_inv;
+                zp += dt*(uz_next*gamma_next_inv - clight);     // do_z_push (default true)
+                ux = ux_next; uy = uy_next; uz = uz_next;
+            }
+            if (gone) continue;
+            if (enforce_bc(gm, xp, yp, ux, uy, b.w[ip], b.valid[ip])) continue;
+            b.x[ip] = xp; b.y[ip] = yp; b.z[ip] = zp; b.nsub[ip] = i; b.ux[ip] = ux; b.uy[ip] = uy; b.uz[ip] = uz;
+        }
+    }
+
+    // shiftSlippedParticles (particles/sorting/SliceSort.cpp:12-64): drop invalid particles, keep z >= min_z on
+    // this slice (they all count as regular from now on), append the others to the next slice as slipped
+    void shift_slipped (int islice) {
+        Beam& b = store[islice];
+        const Real min_z = d.lo[2] + islice*gm.dz;
+        Beam stay, slip;
+        auto push = [] (Beam& t, const Beam& f, size_t k) {
+            t.x.push_back(f.x[k]); t.y.push_back(f.y[k]); t.z.push_back(f.z[k]); t.ux.push_back(f.ux[k]);
+            t.uy.push_back(f.uy[k]); t.uz.push_back(f.uz[k]); t.w.push_back(f.w[k]); t.nsub.push_back(f.nsub[k]); t.valid.push_back(1);
+        };
+        for (size_t k = 0; k < b.x.size(); ++k) {
+            if (!b.valid[k]) continue;
+            if (b.z[k] >= min_z) push(stay, b, k); else push(slip, b, k);
+        }
+        stay.nreg = (long)stay.x.size();
+        b = stay;
+        if (islice - 1 >= 0) {
+            Beam& nx = store[islice - 1];
+            for (size_t k = 0; k < slip.x.size(); ++k) push(nx, slip, k);      // nreg of the next slice unchanged
+        }
     }
 
     // start of one time step (Hipace::Evolve, Hipace.cpp:401-471)
@@ -1143,6 +1252,17 @@ struct Engine {
         const int comp[6] = {-1, -1, -1, -1, -1, Ion_rhomjz};
         deposit_current(slab, pl, gm, comp, -d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0);
         std::fill(checksum.begin(), checksum.end(), 0.0);
+        for (double& v : beam_diag) v = 0.0;
+        if (d.dt != 0.0) {
+            ensure_store();
+            if (steps_begun > 0) {
+                phys_time += d.dt;
+                // the buffer hand-off between steps does not carry the sub-cycle counters, and whatever sits on a
+                // slice now is regular (BeamParticleContainer.H:35-37, MultiBuffer.cpp:809)
+                for (Beam& b : store) { std::fill(b.nsub.begin(), b.nsub.end(), 0); b.nreg = (long)b.x.size(); }
+            }
+        }
+        ++steps_begun;
     }
 
     void run () {
@@ -1267,6 +1387,7 @@ struct orc_deck {
     int beam_profile; double beam_zmin, beam_zmax, beam_radius, beam_density;
     double beam_umean[3], beam_pos_mean[3], beam_pos_std[3]; int beam_ppc[3]; double beam_charge;
     int bc; double mg_tol_rel, mg_tol_abs; int deposit_rho; int n_steps;
+    double dt; int beam_n_subcycles; double beam_mass; double ext_E_slope[2];
 };
 
 void* orc_engine_create (const orc_deck* k) {
@@ -1278,6 +1399,8 @@ void* orc_engine_create (const orc_deck* k) {
     d.beam_radius=k->beam_radius; d.beam_density=k->beam_density;
     for (int i=0;i<3;++i){d.beam_umean[i]=k->beam_umean[i]; d.beam_pos_mean[i]=k->beam_pos_mean[i]; d.beam_pos_std[i]=k->beam_pos_std[i]; d.beam_ppc[i]=k->beam_ppc[i];}
     d.beam_charge=k->beam_charge; d.bc=k->bc; d.mg_tol_rel=k->mg_tol_rel; d.mg_tol_abs=k->mg_tol_abs; d.deposit_rho=k->deposit_rho; d.n_steps=k->n_steps;
+    d.dt=k->dt; d.beam_n_subcycles=k->beam_n_subcycles > 0 ? k->beam_n_subcycles : 10; d.beam_mass=k->beam_mass != 0.0 ? k->beam_mass : 1.0;
+    d.ext_E_slope[0]=k->ext_E_slope[0]; d.ext_E_slope[1]=k->ext_E_slope[1];
     return new Engine(d);
 }
 void orc_engine_destroy (void* h) { delete static_cast<Engine*>(h); }
@@ -1311,12 +1434,28 @@ void orc_engine_initial_beam (void* h, double* dst) { static_cast<Engine*>(h)->f
 void orc_engine_beam_stats (void* h, double* out /* n, sum w, sum|x|, sum|y|, sum|z|, sum|uz| */) {
     Engine* e = static_cast<Engine*>(h);
     for (int k = 0; k < 6; ++k) out[k] = 0;
+    if (e->d.dt != 0.0) {        // moving beam: what the last step's diagnostics saw (before its pushes)
+        out[0] = e->beam_diag[0]; out[1] = e->beam_diag[1]; out[2] = e->beam_diag[2]; out[3] = e->beam_diag[3];
+        out[4] = e->beam_diag[4]; out[5] = e->beam_diag[6];
+        return;
+    }
     Beam b;
     for (int isl = e->d.nz - 1; isl >= 0; --isl) {
         e->gen_beam_slice(isl, b);
         out[0] += (double)b.x.size();
         for (size_t k = 0; k < b.x.size(); ++k) { out[1] += b.w[k]; out[2] += std::abs(b.x[k]); out[3] += std::abs(b.y[k]); out[4] += std::abs(b.z[k]); out[5] += std::abs(b.uz[k]); }
     }
+}
+
+// moving beam: sum |ux| seen by the last step's diagnostics, and the per-slice store for parity tests
+double orc_engine_beam_sum_abs_ux (void* h) { return static_cast<Engine*>(h)->beam_diag[5]; }
+long orc_engine_beam_slice_count (void* h, int islice) {
+    Engine* e = static_cast<Engine*>(h); e->ensure_store(); return (long)e->store[islice].x.size(); }
+void orc_engine_beam_slice (void* h, int islice, double* out7n) {       // [7][count]: x y z ux uy uz w
+    Engine* e = static_cast<Engine*>(h); e->ensure_store();
+    const Beam& b = e->store[islice]; const size_t n = b.x.size();
+    const std::vector<double>* a[7] = {&b.x, &b.y, &b.z, &b.ux, &b.uy, &b.uz, &b.w};
+    for (int k = 0; k < 7; ++k) for (size_t i = 0; i < n; ++i) out7n[k*n + i] = (*a[k])[i];
 }
 
 } // extern "C"

@@ -55,7 +55,8 @@ class Deck(C.Structure):
                 ("beam_umean", C.c_double * 3), ("beam_pos_mean", C.c_double * 3),
                 ("beam_pos_std", C.c_double * 3), ("beam_ppc", C.c_int * 3), ("beam_charge", C.c_double),
                 ("bc", C.c_int), ("mg_tol_rel", C.c_double), ("mg_tol_abs", C.c_double),
-                ("deposit_rho", C.c_int), ("n_steps", C.c_int)]
+                ("deposit_rho", C.c_int), ("n_steps", C.c_int),
+                ("dt", C.c_double), ("beam_n_subcycles", C.c_int), ("beam_mass", C.c_double), ("ext_E_slope", C.c_double * 2)]
 
 
 def fill_struct(st, d):

@@ -17,7 +17,9 @@ from hipace_amd import decks
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 CASES = [("linear_wake", "linear_wake.normalized.1Rank"),
          ("blowout_wake", "blowout_wake_explicit.2Rank"),
-         ("beam_in_vacuum", "beam_in_vacuum.normalized.Serial")]
+         ("beam_in_vacuum", "beam_in_vacuum.normalized.Serial"),
+         # 21 steps of dt = 3 with the beam pusher in a linear focusing field (tests/beam_evolution.1Rank.sh)
+         ("beam_evolution", "beam_evolution.1Rank")]
 
 
 @pytest.mark.parametrize("name,js", CASES)
