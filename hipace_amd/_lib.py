@@ -39,7 +39,8 @@ class Deck(C.Structure):
                 ("beam_umean", C.c_double * 3), ("beam_pos_mean", C.c_double * 3),
                 ("beam_pos_std", C.c_double * 3), ("beam_ppc", C.c_int * 3), ("beam_charge", C.c_double),
                 ("bc", C.c_int), ("mg_tol_rel", C.c_double), ("mg_tol_abs", C.c_double),
-                ("deposit_rho", C.c_int), ("n_steps", C.c_int)]
+                ("deposit_rho", C.c_int), ("n_steps", C.c_int),
+                ("dt", C.c_double), ("beam_n_subcycles", C.c_int), ("beam_mass", C.c_double), ("ext_E_slope", C.c_double * 2)]
 
 
 # engine component names, index = value of the HPS_C_* enum in include/hpslice.h
@@ -93,6 +94,7 @@ _SIGS = {
     "hps_engine_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
     "hps_engine_sorts": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
     "hps_engine_assume_initial_beam_support": (C.c_int, [C.c_void_p]),
+    "hps_engine_beam_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hps_engine_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_phase_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hps_engine_beam_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.c_void_p]),

@@ -257,6 +257,16 @@ class SliceEngine:
     def set_tiling(self, tile_size=16, sort_period=128):
         check(_lib.lib().hps_engine_set_tiling(self._h, tile_size, sort_period))
 
+    def beam_state(self):
+        """hipace.dt != 0: (boundaries int64 [nz+1], soa float64 [7, nbeam]) of the moving beam; slice p from the head
+        is soa[:, boundaries[p]:boundaries[p+1]] (rows x y z ux uy uz w)."""
+        nbeam, _ = self.beam_layout()
+        nz = self.deck["nz"]
+        bnd = np.zeros(nz + 1, dtype=np.int64)
+        soa = np.zeros((7, max(nbeam, 1)), dtype=np.float64)
+        check(_lib.lib().hps_engine_beam_state(self._h, bnd.ctypes.data_as(C.c_void_p), soa.ctypes.data_as(C.c_void_p) if nbeam else None))
+        return bnd, soa[:, :nbeam].reshape(7, nbeam) if nbeam else soa[:, :0]
+
     def fallbacks(self):
         n = C.c_long()
         check(_lib.lib().hps_engine_fallbacks(self._h, C.byref(n)))

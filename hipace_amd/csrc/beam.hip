@@ -1,0 +1,197 @@
+// beam.hip -- driver-beam slice operators for hipace.dt != 0: the beam slice push
+// (AdvanceBeamParticlesSlice, particles/pusher/BeamParticleAdvance.cpp:20-336), the hand-off of
+// slipped particles to the next slice (shiftSlippedParticles, particles/sorting/SliceSort.cpp:12-64)
+// and the deposit over the part of a slice that has not slipped in during this step
+// (particles/deposition/BeamDepositCurrent.cpp:100).
+//
+// Layout: one global SoA over all beam particles, head slice first.  Slice p (counted from the head)
+// is the index range [B[p], B[p+1]) of DEVICE-resident boundaries: a particle that leaves slice p
+// (z < lower end of the slice) is moved to the end of its range by the partition kernel, and B[p+1]
+// is lowered past it -- it has become the front of slice p+1 without being copied anywhere, and the
+// host never has to learn the counts inside a step (nfront[p+1] = how many such particles lead
+// slice p+1: they are pushed there, to finish their sub-cycles, but not deposited).
+#include "common.h"
+#include "particle_math.h"
+#include "engine.h"
+
+namespace hps {
+
+struct BeamPushConsts {
+    double dt;                 // per sub-cycle
+    double c, inv_c2, qm, min_z;
+    double ex_slope, ey_slope; // beams.external_E = (ex_slope*x, ey_slope*y, 0)
+    int nsc;
+    PartConsts pc;             // geometry, boundary
+};
+
+template <int ORDER>
+__global__ __launch_bounds__(256)
+void k_beam_deposit_dyn (SlabView f, BeamSoA b, const long* __restrict__ B, const int* __restrict__ nfront, int p,
+                         int cjx, int cjy, int cjz, double q_invvol, double clightsq_inv, PartConsts k)
+{
+    const long first = B[p] + nfront[p], count = B[p + 1] - first;
+    const long t = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const long ip = first + t;
+    if (b.nsub[ip] < 0) return;                 // absorbed at the boundary
+    const double ux = b.ux[ip], uy = b.uy[ip], uz = b.uz[ip];
+    const double gaminv = 1.0/sqrt(1.0 + ux*ux*clightsq_inv + uy*uy*clightsq_inv + uz*uz*clightsq_inv);
+    const double wq = q_invvol*b.w[ip];
+    double sx[ORDER + 1], sy[ORDER + 1];
+    const int i0 = shape_weights<ORDER>((b.x[ip] - k.xoff)*k.dx_inv, sx);
+    const int j0 = shape_weights<ORDER>((b.y[ip] - k.yoff)*k.dy_inv, sy);
+#pragma unroll
+    for (int iy = 0; iy <= ORDER; ++iy) {
+#pragma unroll
+        for (int ix = 0; ix <= ORDER; ++ix) {
+            double* q = f.p + f.off(i0 + ix, j0 + iy);
+            const double s = sx[ix]*sy[iy];
+            if (cjx >= 0) { atomic_add_f64(q + cjx*f.ns, s*(wq*(ux*gaminv))); atomic_add_f64(q + cjy*f.ns, s*(wq*(uy*gaminv))); }
+            if (cjz >= 0) atomic_add_f64(q + cjz*f.ns, s*(wq*(uz*gaminv)));
+        }
+    }
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(256)
+void k_beam_push (SlabView f, BeamSoA b, const long* __restrict__ B, int p, int cPsi, int cEz, int cBx, int cBy, int cBz,
+                  BeamPushConsts k)
+{
+    constexpr int NS = ORDER + 2;
+    const long first = B[p], count = B[p + 1] - first;       // slipped-in particles included (:131)
+    const long t = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const long ip = first + t;
+    int i = b.nsub[ip];
+    if (i < 0) return;
+    double xp = b.x[ip], yp = b.y[ip], zp = b.z[ip], ux = b.ux[ip], uy = b.uy[ip], uz = b.uz[ip];
+    for (; i < k.nsc; ++i) {
+        if (zp < k.min_z) break;                              // not on this slice any more (:150-153)
+        const double gi = 1.0/sqrt(1.0 + (ux*ux + uy*uy + uz*uz)*k.inv_c2);
+        xp += k.dt*0.5*ux*gi;
+        yp += k.dt*0.5*uy*gi;
+        if (apply_particle_bc(k.pc, xp, yp, ux, uy)) { b.w[ip] = 0.0; b.nsub[ip] = -1; return; }
+        // doGatherShapeN (particles/particles_utils/FieldGather.H:45-96)
+        double sx[NS], dsx[NS], sy[NS], dsy[NS];
+        const int i0 = nodal_weights<ORDER>((xp - k.pc.xoff)*k.pc.dx_inv, sx, dsx);
+        const int j0 = nodal_weights<ORDER>((yp - k.pc.yoff)*k.pc.dy_inv, sy, dsy);
+        double ExmBy = 0.0, EypBx = 0.0, Ez = 0.0, Bx = 0.0, By = 0.0, Bz = 0.0;
+#pragma unroll
+        for (int iy = 0; iy < NS; ++iy) {
+#pragma unroll
+            for (int ix = 0; ix < NS; ++ix) {
+                const double* q = f.p + f.off(i0 + ix, j0 + iy);
+                const double psi_c = q[cPsi*f.ns];
+                const double ss = sx[ix]*sy[iy];
+                ExmBy += (dsx[ix]*sy[iy])*psi_c*k.pc.dx_inv;
+                EypBx += (sx[ix]*dsy[iy])*psi_c*k.pc.dy_inv;
+                Ez += ss*q[cEz*f.ns];
+                Bx += ss*q[cBx*f.ns];
+                By += ss*q[cBy*f.ns];
+                Bz += ss*q[cBz*f.ns];
+            }
+        }
+        // ApplyExternalField (particles/pusher/ExternalFields.H:29-56), E = (ex_slope x, ey_slope y, 0), B = 0
+        ExmBy += k.ex_slope*xp;
+        EypBx += k.ey_slope*yp;
+        const double ux_next = ux + k.dt*k.qm*(ExmBy + (k.c - uz*gi)*By + uy*gi*Bz);
+        const double uy_next = uy + k.dt*k.qm*(EypBx + (uz*gi - k.c)*Bx - ux*gi*Bz);
+        const double ux_i = (ux_next + ux)*0.5, uy_i = (uy_next + uy)*0.5;
+        const double uz_i = uz + k.dt*0.5*k.qm*Ez;
+        const double gii = 1.0/sqrt(1.0 + (ux_i*ux_i + uy_i*uy_i + uz_i*uz_i)*k.inv_c2);
+        const double uz_next = uz + k.dt*k.qm*(Ez + (ux_i*By - uy_i*Bx)*gii);
+        const double gni = 1.0/sqrt(1.0 + (ux_next*ux_next + uy_next*uy_next + uz_next*uz_next)*k.inv_c2);
+        xp += k.dt*0.5*ux_next*gni;
+        yp += k.dt*0.5*uy_next*gni;
+        zp += k.dt*(uz_next*gni - k.c);                       // do_z_push
+        ux = ux_next; uy = uy_next; uz = uz_next;
+    }
+    if (apply_particle_bc(k.pc, xp, yp, ux, uy)) { b.w[ip] = 0.0; b.nsub[ip] = -1; return; }
+    b.x[ip] = xp; b.y[ip] = yp; b.z[ip] = zp; b.nsub[ip] = i;
+    b.ux[ip] = ux; b.uy[ip] = uy; b.uz[ip] = uz;
+}
+
+// One workgroup: particles of slice p with z < min_z go to the end of the slice's range, the boundary to
+// slice p+1 is lowered past them.  Nothing moves when nothing slipped (the usual case).
+__global__ __launch_bounds__(1024)
+void k_beam_partition (BeamSoA b, BeamSoA scr, long* B, int* nfront, int p, double min_z)
+{
+    __shared__ int s_cnt[2];
+    __shared__ int s_red[16];
+    const long first = B[p], count = B[p + 1] - first;
+    const int t = threadIdx.x;
+    int mine = 0;
+    for (long q = t; q < count; q += 1024) mine += (b.z[first + q] < min_z) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((t & 63) == 0) s_red[t >> 6] = mine;
+    if (t < 2) s_cnt[t] = 0;
+    __syncthreads();
+    int nslip = 0;
+    for (int w = 0; w < 16; ++w) nslip += s_red[w];
+    if (nslip == 0) { if (t == 0) nfront[p + 1] = 0; return; }
+    for (long q = t; q < count; q += 1024) {
+        const long ip = first + q;
+        const bool slip = b.z[ip] < min_z;
+        const long dst = slip ? count - 1 - atomicAdd(&s_cnt[1], 1) : atomicAdd(&s_cnt[0], 1);
+        scr.x[dst] = b.x[ip]; scr.y[dst] = b.y[ip]; scr.z[dst] = b.z[ip]; scr.ux[dst] = b.ux[ip];
+        scr.uy[dst] = b.uy[ip]; scr.uz[dst] = b.uz[ip]; scr.w[dst] = b.w[ip]; scr.nsub[dst] = b.nsub[ip];
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (long q = t; q < count; q += 1024) {
+        const long ip = first + q;
+        b.x[ip] = scr.x[q]; b.y[ip] = scr.y[q]; b.z[ip] = scr.z[q]; b.ux[ip] = scr.ux[q];
+        b.uy[ip] = scr.uy[q]; b.uz[ip] = scr.uz[q]; b.w[ip] = scr.w[q]; b.nsub[ip] = scr.nsub[q];
+    }
+    if (t == 0) { B[p + 1] = first + count - nslip; nfront[p + 1] = nslip; }
+}
+
+static BeamPushConsts push_consts (const Engine& E, int islice)
+{
+    BeamPushConsts k{};
+    const hps_deck& d = E.d;
+    k.nsc = d.beam_n_subcycles > 0 ? d.beam_n_subcycles : 10;
+    k.dt = d.dt/k.nsc;
+    k.c = E.gm.c; k.inv_c2 = 1.0/(E.gm.c*E.gm.c);
+    k.qm = d.beam_charge/(d.beam_mass != 0.0 ? d.beam_mass : 1.0);
+    k.min_z = d.lo[2] + islice*E.gm.dz;
+    k.ex_slope = d.ext_E_slope[0]; k.ey_slope = d.ext_E_slope[1];
+    k.pc = base_consts(E.gm);
+    return k;
+}
+
+#define HPS_BEAM_ORDER(order, CALL) switch (order) { case 0: { CALL(0); } break; case 1: { CALL(1); } break; \
+                                                     case 2: { CALL(2); } break; default: { CALL(3); } break; }
+
+int beam_deposit_moving (Engine& E, int p, int cjx, int cjy, int cjz)
+{
+    if (p < 0 || p >= E.d.nz) return HPS_OK;
+    const long bound = E.beam_bound(p);
+    if (bound <= 0) return HPS_OK;
+    const SlabView f(E.slab);
+    const PartConsts k = base_consts(E.gm);
+    const double q_invvol = E.d.beam_charge*1.0, csq_inv = 1.0/(E.gm.c*E.gm.c);
+    const dim3 grid(ceil_div(bound, 256)), block(256);
+#define CALL(O) hipLaunchKernelGGL(k_beam_deposit_dyn<O>, grid, block, 0, E.st, f, E.bm, E.d_B, E.d_nfront, p, cjx, cjy, cjz, q_invvol, csq_inv, k)
+    HPS_BEAM_ORDER(E.d.order, CALL)
+#undef CALL
+    return HPS_OK;
+}
+
+int beam_push_moving (Engine& E, int islice)
+{
+    const int p = E.d.nz - 1 - islice;
+    const long bound = E.beam_bound(p);
+    if (bound <= 0) return HPS_OK;
+    const SlabView f(E.slab);
+    const BeamPushConsts k = push_consts(E, islice);
+    const dim3 grid(ceil_div(bound, 256)), block(256);
+#define CALL(O) hipLaunchKernelGGL(k_beam_push<O>, grid, block, 0, E.st, f, E.bm, E.d_B, p, HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ, k)
+    HPS_BEAM_ORDER(E.d.order, CALL)
+#undef CALL
+    hipLaunchKernelGGL(k_beam_partition, dim3(1), dim3(1024), 0, E.st, E.bm, E.bm_scr, E.d_B, E.d_nfront, p, k.min_z);
+    HPS_HIP_CHECK(hipGetLastError());
+    return HPS_OK;
+}
+
+} // namespace hps

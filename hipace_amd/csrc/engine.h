@@ -11,6 +11,7 @@ void mg_rider (void* mg_handle, int** dev_words, const int** host_words);     //
 namespace hps {
 
 struct BeamView { double *x, *y, *z, *ux, *uy, *uz, *w; };
+struct BeamSoA { double *x, *y, *z, *ux, *uy, *uz, *w; int* nsub; };     // moving beam (beam.hip); nsub < 0: absorbed
 
 struct Engine {
     hps_deck d{};
@@ -36,6 +37,14 @@ struct Engine {
     // blocks [slice p from the head][7][count_p]; beam_cur = storage in use (own or caller's)
     double* beam_data = nullptr; double* beam_init = nullptr; double* beam_cur = nullptr;
     long nbeam = 0; std::vector<long> beam_off;
+    // hipace.dt != 0 (beam.hip): global SoA + device-resident slice boundaries B[nz+1] and slipped-front counts
+    bool moving = false; int steps_begun = 0;
+    BeamSoA bm{}, bm_scr{}; double* bm_store = nullptr; int* bm_nsub = nullptr; int* bm_nsub_scr = nullptr;
+    long* d_B = nullptr; int* d_nfront = nullptr; std::vector<long> h_B;      // h_B: boundaries as of begin_step
+    long beam_bound (int p) const {      // upper bound of slice p's size during this step: own + what may slip in
+        if (p < 0 || p >= d.nz) return 0;
+        return (h_B[p + 1] - h_B[p]) + (p > 0 ? h_B[p] - h_B[p - 1] : 0);
+    }
     // support of the beam currents in padded-array cells (deposit footprint + the centred differences taken of
     // them); the beam planes are identically zero outside, so the slab kernels skip them there
     struct Box { int ilo, ihi, jlo, jhi; };
@@ -56,6 +65,9 @@ struct Engine {
     int solve_slice (int islice);
     int run_step ();
 };
+
+int beam_deposit_moving (Engine& E, int p, int cjx, int cjy, int cjz);      // beam.hip
+int beam_push_moving (Engine& E, int islice);
 
 } // namespace hps
 #endif

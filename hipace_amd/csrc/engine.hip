@@ -233,6 +233,13 @@ void k_beam_deposit (SlabView f, BeamView b, long first, long count, int cjx, in
     }
 }
 
+__global__ __launch_bounds__(256)
+void k_beam_new_step (int* nsub, long n)
+{
+    const long t = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (t < n && nsub[t] > 0) nsub[t] = 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // Engine
 // ------------------------------------------------------------------------------------------
@@ -243,7 +250,8 @@ Engine::~Engine ()
     (void)hipFree(slab.p); (void)hipFree(pl_real); (void)hipFree(pl.idcpu); (void)hipFree(pl.ion_lev);
     delete tiling;
     (void)hipFree(pl_real_alt); (void)hipFree(pl_alt.idcpu); (void)hipFree(pl_alt.ion_lev); 
-    (void)hipFree(staging); (void)hipFree(beam_data); (void)hipFree(beam_init); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
+    (void)hipFree(staging); (void)hipFree(beam_data); (void)hipFree(beam_init);
+    (void)hipFree(bm_store); (void)hipFree(bm_nsub); (void)hipFree(bm_nsub_scr); (void)hipFree(d_B); (void)hipFree(d_nfront); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
     for (auto e : ev) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
 }
@@ -316,6 +324,27 @@ int Engine::init_beam ()
         HPS_HIP_CHECK(hipMemcpy(beam_init, blk.data(), 7*nbeam*sizeof(double), hipMemcpyHostToDevice));
         HPS_HIP_CHECK(hipMemcpy(beam_data, beam_init, 7*nbeam*sizeof(double), hipMemcpyDeviceToDevice));
         beam_cur = beam_data;
+    }
+    moving = (d.dt != 0.0);
+    if (moving) {
+        // global SoA in head-first order + device boundaries (beam.hip)
+        const long nb = std::max(nbeam, 1L);
+        HPS_HIP_CHECK(hipMalloc(&bm_store, (size_t)14*nb*sizeof(double)));
+        HPS_HIP_CHECK(hipMalloc(&bm_nsub, (size_t)nb*sizeof(int)));
+        HPS_HIP_CHECK(hipMalloc(&bm_nsub_scr, (size_t)nb*sizeof(int)));
+        double* a = bm_store;
+        bm = BeamSoA{a, a + nb, a + 2*nb, a + 3*nb, a + 4*nb, a + 5*nb, a + 6*nb, bm_nsub};
+        a += 7*nb;
+        bm_scr = BeamSoA{a, a + nb, a + 2*nb, a + 3*nb, a + 4*nb, a + 5*nb, a + 6*nb, bm_nsub_scr};
+        for (int k = 0; k < 7 && nbeam > 0; ++k)
+            HPS_HIP_CHECK(hipMemcpy(bm_store + (size_t)k*nb, h[k].data(), nbeam*sizeof(double), hipMemcpyHostToDevice));
+        HPS_HIP_CHECK(hipMemset(bm_nsub, 0, (size_t)nb*sizeof(int)));
+        h_B.assign(beam_off.begin(), beam_off.end());
+        HPS_HIP_CHECK(hipMalloc(&d_B, (size_t)(d.nz + 1)*sizeof(long)));
+        HPS_HIP_CHECK(hipMemcpy(d_B, h_B.data(), (size_t)(d.nz + 1)*sizeof(long), hipMemcpyHostToDevice));
+        HPS_HIP_CHECK(hipMalloc(&d_nfront, (size_t)(d.nz + 2)*sizeof(int)));
+        HPS_HIP_CHECK(hipMemset(d_nfront, 0, (size_t)(d.nz + 2)*sizeof(int)));
+        beam_box = beam_box_init = full_box;          // a moving beam may go anywhere
     }
     return HPS_OK;
 }
@@ -401,6 +430,17 @@ int Engine::resort ()
 int Engine::begin_step ()
 {
     if (int e = setup_tiling()) return e;
+    if (moving) {
+        if (steps_begun > 0) {
+            // the hand-off between steps does not carry the sub-cycle counters (BeamParticleContainer.H:35-37);
+            // whatever sits on a slice now is regular (MultiBuffer.cpp:809).  Absorbed particles keep nsub < 0.
+            hipLaunchKernelGGL(k_beam_new_step, dim3(ceil_div(std::max(nbeam, 1L), 256)), dim3(256), 0, st, bm_nsub, nbeam);
+            HPS_HIP_CHECK(hipMemsetAsync(d_nfront, 0, (size_t)(d.nz + 2)*sizeof(int), st));
+        }
+        HPS_HIP_CHECK(hipMemcpyAsync(h_B.data(), d_B, (size_t)(d.nz + 1)*sizeof(long), hipMemcpyDeviceToHost, st));
+        HPS_HIP_CHECK(hipStreamSynchronize(st));
+        ++steps_begun;
+    }
     // ResetAllQuantities (Hipace.cpp:730-742)
     HPS_HIP_CHECK(hipMemsetAsync(slab.p, 0, (size_t)slab.nstride*ncomp*sizeof(double), st));
     HPS_HIP_CHECK(hipMemsetAsync(d_checksum, 0, HPS_NCOMP_MAX*sizeof(double), st));
@@ -424,6 +464,7 @@ int Engine::begin_step ()
 int Engine::deposit_beam_slice (int islice, int cjx, int cjy, int cjz)
 {
     if (nbeam == 0 || islice < 0 || islice >= d.nz) return HPS_OK;
+    if (moving) return beam_deposit_moving(*this, d.nz - 1 - islice, cjx, cjy, cjz);
     const long first0 = beam_off[d.nz - 1 - islice], count = beam_off[d.nz - islice] - first0;
     if (count <= 0) return HPS_OK;
     double* blk = beam_cur + 7*first0;
@@ -521,6 +562,8 @@ int Engine::solve_slice (int islice)
         if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st))) return e; }
         else        { if ((e = hps_advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; } }
 
+    // beam push and hand-off of the slipped particles (Hipace.cpp:704-706)
+    if (moving && nbeam > 0) { if ((e = beam_push_moving(*this, islice))) return e; }
     mark();   // b8
     // ShiftSlices (fields/Fields.cpp:588-604)
     hipLaunchKernelGGL(k_shift_slices, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, bb);
@@ -618,9 +661,21 @@ extern "C" int hps_engine_beam_info (void* h, long* nbeam, long* offsets_host)
 extern "C" int hps_engine_set_beam_storage (void* h, double* storage_dev)
 {
     Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(!(E->moving && storage_dev), "hps_engine_set_beam_storage: caller-owned beam blocks need hipace.dt = 0 (the moving beam's slice hand-off through the ring is not built yet)");
     E->beam_cur = storage_dev ? storage_dev : E->beam_data;
     // caller-owned particles may sit anywhere: treat the whole plane as beam support until told otherwise
     E->beam_box = storage_dev ? E->full_box : E->beam_box_init;
+    return HPS_OK;
+}
+extern "C" int hps_engine_beam_state (void* h, long* boundaries_host, double* soa_host)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E->moving, "hps_engine_beam_state: the engine's beam is static (hipace.dt = 0)");
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    if (boundaries_host) HPS_HIP_CHECK(hipMemcpy(boundaries_host, E->d_B, (size_t)(E->d.nz + 1)*sizeof(long), hipMemcpyDeviceToHost));
+    if (soa_host && E->nbeam > 0)
+        for (int k = 0; k < 7; ++k)
+            HPS_HIP_CHECK(hipMemcpy(soa_host + (size_t)k*E->nbeam, E->bm_store + (size_t)k*std::max(E->nbeam, 1L), E->nbeam*sizeof(double), hipMemcpyDeviceToHost));
     return HPS_OK;
 }
 extern "C" int hps_engine_assume_initial_beam_support (void* h)

@@ -154,6 +154,10 @@ typedef struct {
     double beam_zmin, beam_zmax, beam_radius, beam_density;
     double beam_umean[3], beam_pos_mean[3], beam_pos_std[3]; int beam_ppc[3]; double beam_charge;
     int bc; double mg_tol_rel, mg_tol_abs; int deposit_rho; int n_steps;
+    /* moving driver beam: hipace.dt (0 = the beam is never pushed, every BASELINE deck),
+     * beam.n_subcycles (0 -> 10, BeamParticleContainer.H:222), beam mass (0 -> 1) and a linear focusing field
+     * beams.external_E(x,y,z,t) = ext_E_slope[0]*x  ext_E_slope[1]*y  0 (ExternalFields.H:29-56) */
+    double dt; int beam_n_subcycles; double beam_mass; double ext_E_slope[2];
 } hps_deck;
 
 /* slab component indices of the engine (explicit-solver layout of fields/Fields.cpp:70-122) */
@@ -199,6 +203,10 @@ int hps_engine_phase_times (void* handle, double* ms_host, long* nslices_host);
 int hps_engine_beam_info (void* handle, long* nbeam_host, long* offsets_host /* [nz+1] */);
 int hps_engine_set_beam_storage (void* handle, double* storage_dev /* [7*nbeam] or NULL = own */);
 int hps_engine_initial_beam (void* handle, double* dst_dev);
+/* hipace.dt != 0: the beam lives in one SoA over all particles (head slice first) whose slice boundaries move when
+ * particles slip (hipace_amd/csrc/beam.hip).  Copies the boundaries [nz+1] and, if soa_host != NULL, the seven
+ * arrays x y z ux uy uz w ([7][nbeam], nbeam = hps_engine_beam_info) to the host; synchronises the stream. */
+int hps_engine_beam_state (void* handle, long* boundaries_host, double* soa_host);
 /* The slab kernels skip the beam-current planes outside the beam's transverse support.  After
  * hps_engine_set_beam_storage the support is the whole plane (caller-owned particles may sit anywhere); a driver
  * that knows its blocks are the injected beam handed along the ring (hipace.dt = 0: the beam does not move) calls

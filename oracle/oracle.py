@@ -310,6 +310,19 @@ class Engine:
         n = lib().orc_engine_beam_layout(self._h, _ptr(off))
         return n, off
 
+    def beam_slice(self, islice):
+        """Moving beam (deck dt != 0): the particles sitting on slice `islice` now, as a (7, count) array x y z ux uy uz w."""
+        L = lib()
+        L.orc_engine_beam_slice_count.restype = C.c_long
+        L.orc_engine_beam_slice_count.argtypes = [C.c_void_p, C.c_int]
+        L.orc_engine_beam_slice.restype = None
+        L.orc_engine_beam_slice.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        n = L.orc_engine_beam_slice_count(self._h, islice)
+        out = np.zeros((7, n), dtype=np.float64)
+        if n:
+            L.orc_engine_beam_slice(self._h, islice, _ptr(out))
+        return out
+
     def set_beam_storage(self, tensor, injected_beam_support=False):
         """tensor: CPU float64 torch tensor or numpy array of 7*nbeam doubles (kept alive by the caller)."""
         self._beam_keep = tensor

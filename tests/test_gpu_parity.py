@@ -373,3 +373,64 @@ def test_pipeline_driver_single_rank_on_gpu(api):
     for k, v in gold.items():
         if v != 0.0:
             assert abs(sums[1][k] - v) <= 1e-9 * abs(v), (k, sums[1][k], v)
+
+
+# ------------------------------------------------------------------------------------------------
+# moving driver beam: beam slice push, slipped-particle hand-off, several time steps
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_beam_evolution_matches_reference_checksums(api, oracle):
+    """tests/beam_evolution.1Rank.sh: 21 steps of dt = 3 in a linear focusing field; field checksums of the last
+    step against the reference's JSON (its CI: rtol 1e-12 on CPU, 2e-6 on GPU), beam state against the oracle."""
+    deck = decks.beam_evolution()
+    gold = json.load(open(os.path.join(GOLD, "beam_evolution.1Rank.json")))["lev=0"]
+    eng = api.SliceEngine(deck, tile_size=0)
+    eng.set_diagnostics(True)
+    for _ in range(deck["n_steps"]):
+        eng.run_step()
+    cs = eng.checksums()
+    for k, v in gold.items():
+        if v == 0.0:
+            assert cs[k] == 0.0, (k, cs[k])
+        else:
+            assert abs(cs[k] - v) <= 1e-9*abs(v), (k, cs[k], v)
+    ref = oracle.Engine(deck)
+    ref.run()
+    bnd, soa = eng.beam_state()
+    nz = deck["nz"]
+    for p in range(nz):
+        want = ref.beam_slice(nz - 1 - p)
+        got = soa[:, bnd[p]:bnd[p + 1]]
+        assert got.shape == want.shape                      # nobody slips in this deck
+        assert np.abs(got - want).max() <= 1e-10*np.abs(want).max()
+
+
+@pytest.mark.gpu
+def test_beam_slipping_matches_oracle(api, oracle):
+    """A slow, hot beam (u_z = 1.2: v_z = 0.77 c) falls back through the slices: the slice populations and every
+    particle's state after 6 steps equal the oracle's (as sets: the device partition is not order preserving)."""
+    deck = decks.beam_evolution()
+    deck.update(nz=12, lo=(-2.0, -2.0, -2.4), hi=(2.0, 2.0, 2.4), beam_zmin=-1.0, beam_zmax=1.6, beam_umean=(0.0, 0.0, 1.2),
+                beam_density=1.0e-3, n_steps=6, dt=0.9, beam_n_subcycles=4, ext_E_slope=(0.3, 0.2))
+    eng = api.SliceEngine(deck, tile_size=0)
+    eng.set_diagnostics(True)
+    for _ in range(deck["n_steps"]):
+        eng.run_step()
+    ref = oracle.Engine(deck)
+    ref.run()
+    bnd, soa = eng.beam_state()
+    nz = deck["nz"]
+    moved = 0
+    n0 = oracle.Engine(deck)
+    for p in range(nz):
+        want = ref.beam_slice(nz - 1 - p)
+        got = soa[:, bnd[p]:bnd[p + 1]]
+        assert got.shape == want.shape, (p, got.shape, want.shape)
+        moved += abs(want.shape[1] - n0.beam_slice(nz - 1 - p).shape[1])
+        if want.shape[1]:
+            ko = np.lexsort((want[1], want[0])); kg = np.lexsort((got[1], got[0]))
+            assert np.abs(got[:, kg] - want[:, ko]).max() <= 1e-10*np.abs(want).max()
+    assert moved > 0                                           # the deck does make particles slip
+    cs, rs = eng.checksums(), ref.checksums()
+    for k in ("jz_beam", "Bx", "By", "Ez", "Sx", "Sy"):
+        assert abs(cs[k] - rs[k]) <= 1e-9*max(abs(rs[k]), 1e-300), (k, cs[k], rs[k])
