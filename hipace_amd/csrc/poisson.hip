@@ -62,6 +62,8 @@ struct DstArgs {
     const double2* fb;              // [N2][N2] DFT matrix exp(+2 pi i n2 k2 / N2), row n2
     const double2* tw;              // [N1][N2] twiddles exp(+2 pi i n2 k1 / N), row k1
     const double* isin4;            // 1/(4 sin(pi (k+1)/N)), k < n
+    const double* ma;               // MFMA operand tables of the two small-DFT stages (k_dst_rows_mfma)
+    const double* mb;
     int rows_per_plane, nplanes;
     long long* dbg;                 // optional: shader-clock stamps of workgroup 0 at the phase boundaries
 };
@@ -412,6 +414,160 @@ void k_dst_rows_sym (DstArgs a)
     HPS_STAMP_FLUSH;
 }
 
+// ---- the small-DFT stages as fp64 MFMA contractions --------------------------------------------
+// The folded DFT of the symmetric kernel is a real matrix product: with s_n = x_n + x_{M-n}, d_n = x_n - x_{M-n},
+//   P[k][col] = sum_n cos(2 pi n k / M) s[n][col]      (row k = 0: all ones -> sum_n s_n)
+//   Q[k][col] = sum_n sin(2 pi n k / M) d[n][col]
+// over k = 0..H, n = 1..H and the columns col = 2*item + (re | im) of all items of the workgroup.  One wave owns a
+// tile of 16 columns (8 items) and both k tiles: v_mfma_f64_16x16x4_f64, the constant matrices as A operands in
+// registers (host tables in the instruction's lane layout: lane l holds A[l % 16][l / 16]), s / d as B operands
+// built from two LDS reads per lane and k step (lane l: n = 1 + 4*ks + l / 16, column l % 16); the accumulator
+// holds D[4 r + l / 16][l % 16] in register r.  No LDS table traffic, no per-step load -> use round trip.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+template <int M> struct MfmaDims { static constexpr int H = (M - 1)/2, MT = (H + 1 + 15)/16, KS = (H + 3)/4; };
+
+// the constant A operands of a stage (requested at kernel start: an L2 / HBM round trip that must not sit at the
+// head of the stage)
+template <int M>
+__device__ __forceinline__ void mfma_load_tables (const double* __restrict__ tab, int lane,
+                                                  double (&ac)[MfmaDims<M>::MT][MfmaDims<M>::KS], double (&as)[MfmaDims<M>::MT][MfmaDims<M>::KS])
+{
+    constexpr int MT = MfmaDims<M>::MT, KS = MfmaDims<M>::KS;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            ac[mt][ks] = tab[(mt*KS + ks)*64 + lane];
+            as[mt][ks] = tab[((MT + mt)*KS + ks)*64 + lane];
+        }
+    }
+}
+
+template <int M, int STRIDE, int ITEMS_PER_T, int ITEM_STRIDE, bool TWIDDLE, int T, int NWAVES>
+__device__ __forceinline__ void mfma_stage (lds_double* cbuf, const double (&ac)[MfmaDims<M>::MT][MfmaDims<M>::KS],
+                                            const double (&as)[MfmaDims<M>::MT][MfmaDims<M>::KS],
+                                            const double2* __restrict__ tw, int wave, int lane)
+{
+    constexpr int H = MfmaDims<M>::H, MT = MfmaDims<M>::MT, KS = MfmaDims<M>::KS;
+    constexpr int ITEMS = T*ITEMS_PER_T, NCOL = 2*ITEMS, NTILES = (NCOL + 15)/16;
+    constexpr int NTE = M*ITEMS_PER_T;                // complex elements per transform
+    const int jl = lane & 15, nq = lane >> 4;
+    for (int nt = wave; nt < NTILES; nt += NWAVES) {
+        const int col = nt*16 + jl;
+        const bool cok = col < NCOL;
+        const int item = min(col, NCOL - 1) >> 1, c = col & 1;
+        const int t = item / ITEMS_PER_T, r = item - t*ITEMS_PER_T;
+        const int base = t*NTE + r*ITEM_STRIDE;
+        mfma_d4 Pa[MT], Qa[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { Pa[mt] = mfma_d4{0.0, 0.0, 0.0, 0.0}; Qa[mt] = mfma_d4{0.0, 0.0, 0.0, 0.0}; }
+        // the twiddles of this lane's outputs are requested now: their (L2) latency hides behind the MFMAs
+        double2 w1[MT][4], w2[MT][4];
+        if (TWIDDLE) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int kc = min(mt*16 + 4*rr + nq, H);
+                    w1[mt][rr] = tw[kc*ITEMS_PER_T + r];
+                    w2[mt][rr] = tw[(M - max(kc, 1))*ITEMS_PER_T + r];
+                }
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int n = 1 + ks*4 + nq;
+            const int nn = min(n, H);
+            const double xa = cbuf[2*(base + nn*STRIDE) + c], xb = cbuf[2*(base + (M - nn)*STRIDE) + c];
+            const bool ok = cok && (n <= H);
+            const double sv = ok ? xa + xb : 0.0, dv = ok ? xa - xb : 0.0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                Pa[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[mt][ks], sv, Pa[mt], 0, 0, 0);
+                Qa[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[mt][ks], dv, Qa[mt], 0, 0, 0);
+            }
+        }
+        const double x0c = cbuf[2*base + c];
+        // X_k = x0 + P_k + i Q_k, X_{M-k} = x0 + P_k - i Q_k: the other component of Q sits in the neighbouring lane
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int k = mt*16 + 4*rr + nq;
+                const double pv = Pa[mt][rr], qv = Qa[mt][rr];
+                const double qo = __shfl_xor(qv, 1);
+                double vk = x0c + pv + (c ? qo : -qo);        // re: P_re - Q_im; im: P_im + Q_re
+                double vm = x0c + pv - (c ? qo : -qo);
+                if (TWIDDLE) {
+                    const double ok_ = __shfl_xor(vk, 1), om_ = __shfl_xor(vm, 1);
+                    const double2 wa = w1[mt][rr], wb = w2[mt][rr];
+                    const double re1 = c ? ok_ : vk, im1 = c ? vk : ok_;
+                    const double re2 = c ? om_ : vm, im2 = c ? vm : om_;
+                    vk = c ? re1*wa.y + im1*wa.x : re1*wa.x - im1*wa.y;
+                    vm = c ? re2*wb.y + im2*wb.x : re2*wb.x - im2*wb.y;
+                }
+                if (cok && k <= H) {
+                    if (k == 0) cbuf[2*base + c] = x0c + pv;                     // twiddle 1
+                    else { cbuf[2*(base + k*STRIDE) + c] = vk; cbuf[2*(base + (M - k)*STRIDE) + c] = vm; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int N1, int N2>
+__global__ __launch_bounds__(DSTS_NT)
+void k_dst_rows_mfma (DstArgs a)
+{
+    static_assert(N1 % 2 == 1 && N2 % 2 == 1, "symmetric kernel needs odd factors");
+    constexpr int N = N1*N2, T = DSTS_T, NT = DSTS_NT;
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    lds_double* cbuf = (lds_double*)lds_raw;          // [T][N] complex working set
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int total_rows = a.rows_per_plane*a.nplanes;
+    const int row0 = blockIdx.x*2*T;
+    HPS_STAMP_DECL;
+    HPS_STAMP(0);
+    double ca[MfmaDims<N1>::MT][MfmaDims<N1>::KS], sa[MfmaDims<N1>::MT][MfmaDims<N1>::KS];
+    double cb[MfmaDims<N2>::MT][MfmaDims<N2>::KS], sb[MfmaDims<N2>::MT][MfmaDims<N2>::KS];
+    mfma_load_tables<N1>(a.ma, lane, ca, sa);
+    mfma_load_tables<N2>(a.mb, lane, cb, sb);
+    load_row_pairs<T, N, NT>(cbuf, a, row0, total_rows, tid);
+    __syncthreads();
+    HPS_STAMP(1);
+    {
+        constexpr int PP = (N/2 + NT)/NT;
+        double wr[T][PP], wi[T][PP], vr[T][PP], vi[T][PP];
+        pre_to_regs<T, N, PP, NT>(cbuf, tid, wr, wi, vr, vi);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int m = 0; m < PP; ++m) {
+                const int p = tid + NT*m;
+                if (p <= N/2) {
+                    stc(cbuf, t*N + p, wr[t][m], wi[t][m]);
+                    if (p > 0) stc(cbuf, t*N + N - p, vr[t][m], vi[t][m]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    HPS_STAMP(2);
+    // stage A: DFT-N1 over n1 (stride N2) of column n2, twiddle w_N^(n2 k1), result at [k1][n2]
+    mfma_stage<N1, N2, N2, 1, true, T, NT/64>(cbuf, ca, sa, a.tw, wave, lane);
+    HPS_STAMP(3);
+    // stage B: DFT-N2 over n2 (stride 1) of row k1, result X[k1 + N1 k2] at [k1][k2]
+    mfma_stage<N2, 1, N1, N2, false, T, NT/64>(cbuf, cb, sb, nullptr, wave, lane);
+    HPS_STAMP(4);
+    post_store<T, N1, N2, NT>(cbuf, a, row0, total_rows, tid);
+    HPS_STAMP(5);
+    HPS_STAMP_FLUSH;
+}
+
 // ---- y direction on column blocks, in place -----------------------------------------------------
 // One workgroup owns 2*CT adjacent columns of one plane (64-byte row segments for CT = 4): it
 // transforms them along y, multiplies by the inverse eigenvalues and transforms back, all in LDS --
@@ -530,10 +686,10 @@ void k_transpose (const double* __restrict__ src, double* __restrict__ dst, int 
 
 typedef void (*dst_kernel_t)(DstArgs);
 typedef void (*dst_cols_kernel_t)(DstArgs, int);
-struct DstImpl { int N, N1, N2; dst_kernel_t kernel; bool sym; int T; int nt; dst_cols_kernel_t cols; };
+struct DstImpl { int N, N1, N2; dst_kernel_t kernel; bool sym; int T; int nt; dst_cols_kernel_t cols; dst_kernel_t mfma; };
 
-#define HPS_DST_IMPL(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows<N1, N2>, false, DST_T, 256, nullptr}
-#define HPS_DST_SYM(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows_sym<N1, N2>, true, DSTS_T, DSTS_NT, k_dst_cols_sym<N1, N2>}
+#define HPS_DST_IMPL(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows<N1, N2>, false, DST_T, 256, nullptr, nullptr}
+#define HPS_DST_SYM(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows_sym<N1, N2>, true, DSTS_T, DSTS_NT, k_dst_cols_sym<N1, N2>, k_dst_rows_mfma<N1, N2>}
 static const DstImpl g_dst_impls[] = {
     HPS_DST_SYM(25, 41),    // nx = 1024
     HPS_DST_SYM(19, 27),    // 512
@@ -647,6 +803,8 @@ struct Poisson {
     dst_kernel_t kx = nullptr, ky = nullptr;
     dst_cols_kernel_t kcols = nullptr; size_t lds_cols = 0;     // y direction on column blocks (symmetric factorisations)
     double2 *tab_x = nullptr, *tab_y = nullptr;        // each: [fa | fb | tw] concatenated
+    double *mtab_x = nullptr, *mtab_y = nullptr;       // MFMA operand tables [stage A | stage B] (k_dst_rows_mfma)
+    const double *ma_x = nullptr, *mb_x = nullptr, *ma_y = nullptr, *mb_y = nullptr;
     const double2 *fa_x = nullptr, *fb_x = nullptr, *tw_x = nullptr, *fa_y = nullptr, *fb_y = nullptr, *tw_y = nullptr;
     double *buf_a = nullptr, *buf_b = nullptr;         // [DST_MAXPLANES][nx*ny] ping-pong
     long long* dbg = nullptr;
@@ -666,7 +824,7 @@ struct Poisson {
         if (plan_y) rocfft_plan_destroy(plan_y);
         if (info) rocfft_execution_info_destroy(info);
         (void)hipFree(work); (void)hipFree(zbuf); (void)hipFree(rbuf); (void)hipFree(eig);
-        (void)hipFree(isin_x); (void)hipFree(isin_y); (void)hipFree(tab_x); (void)hipFree(tab_y);
+        (void)hipFree(isin_x); (void)hipFree(isin_y); (void)hipFree(tab_x); (void)hipFree(tab_y); (void)hipFree(mtab_x); (void)hipFree(mtab_y);
         (void)hipFree(buf_a); (void)hipFree(buf_b);
     }
 };
@@ -704,6 +862,33 @@ static int upload_tables (int N1, int N2, bool sym, double2** out, size_t* na, s
     return HPS_OK;
 }
 
+// A-operand tables of mfma_stage for the two factors: per factor M (H = (M-1)/2, MT k tiles, KS steps of 4 in n)
+// [cos | sin][MT][KS][64 lanes], lane l <-> (k = 16 mt + l % 16, n = 1 + 4 ks + l / 16); zero outside k <= H, n <= H
+static int upload_mfma_tables (int N1, int N2, double** out, size_t* na)
+{
+    std::vector<double> h;
+    const long double pi2 = 6.283185307179586476925286766559L;
+    size_t first = 0;
+    for (int M : {N1, N2}) {
+        const int H = (M - 1)/2, MT = (H + 1 + 15)/16, KS = (H + 3)/4;
+        for (int part = 0; part < 2; ++part)
+            for (int mt = 0; mt < MT; ++mt) for (int ks = 0; ks < KS; ++ks) for (int l = 0; l < 64; ++l) {
+                const int k = 16*mt + l % 16, n = 1 + 4*ks + l/16;
+                double v = 0.0;
+                if (k <= H && n <= H) {
+                    const long double ang = pi2*(((long)n*k) % M)/M;
+                    v = part == 0 ? (double)cosl(ang) : (double)sinl(ang);
+                }
+                h.push_back(v);
+            }
+        if (M == N1 && first == 0) first = h.size();
+    }
+    *na = first;
+    HPS_HIP_CHECK(hipMalloc(out, h.size()*sizeof(double)));
+    HPS_HIP_CHECK(hipMemcpy(*out, h.data(), h.size()*sizeof(double), hipMemcpyHostToDevice));
+    return HPS_OK;
+}
+
 int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisson** out)
 {
     Poisson* P = new Poisson;
@@ -720,6 +905,16 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
         P->fa_x = P->tab_x; P->fb_x = P->fa_x + nax; P->tw_x = P->fb_x + nbx;
         P->fa_y = P->tab_y; P->fb_y = P->fa_y + nay; P->tw_y = P->fb_y + nby;
         P->tx = ix->T; P->ty = iy->T; P->ntx = ix->nt; P->nty = iy->nt;
+        // fp64-MFMA form of the small-DFT stages: parity-tested, but not the default -- v_mfma_f64_16x16x4 runs at the
+        // vector fp64 rate on gfx950 (71 TFLOP/s measured), the padded tiles do 1.5x the flops, and with two workgroups
+        // per CU the MFMA pipes are the bottleneck: 24.5 us per pass against 22 us for the vector kernel (a lone
+        // workgroup per CU is 20 % faster with MFMA)
+        if (ix->mfma && iy->mfma && getenv("HPS_POISSON_MFMA")) {
+            size_t fx = 0, fy = 0;
+            if ((e = upload_mfma_tables(ix->N1, ix->N2, &P->mtab_x, &fx)) || (e = upload_mfma_tables(iy->N1, iy->N2, &P->mtab_y, &fy))) { delete P; return e; }
+            P->ma_x = P->mtab_x; P->mb_x = P->mtab_x + fx; P->ma_y = P->mtab_y; P->mb_y = P->mtab_y + fy;
+            P->kx = ix->mfma; P->ky = iy->mfma;
+        }
         if (iy->cols && getenv("HPS_POISSON_COLS")) {      // measured no faster than rows + transposes (0.143 ms both): off by default
             P->kcols = iy->cols;
             P->lds_cols = (size_t)DSTC_T*Ny*sizeof(double2);
@@ -832,6 +1027,7 @@ int poisson_solve_batch (Poisson* P, int nb, const double* const* src, long src_
     // 1: DST along x of the sources -> A
     for (int b = 0; b < nb; ++b) { a.src[b] = src[b]; a.dst[b] = P->buf_a + b*plane; }
     a.src_pitch = src_pitch; a.dst_pitch = nx; a.scale = nullptr; a.fa = P->fa_x; a.fb = P->fb_x; a.tw = P->tw_x; a.isin4 = P->isin_x;
+    a.ma = P->ma_x; a.mb = P->mb_x;
     a.rows_per_plane = ny; a.nplanes = nb;
     hipLaunchKernelGGL(P->kx, rows_grid(ny*nb, P->tx), dim3(P->ntx), P->lds_x, st, a);
     if (P->kcols) {
@@ -847,6 +1043,7 @@ int poisson_solve_batch (Poisson* P, int nb, const double* const* src, long src_
         // 3: DST along y, times the inverse eigenvalues -> A
         for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_b + b*plane; a.dst[b] = P->buf_a + b*plane; }
         a.src_pitch = ny; a.dst_pitch = ny; a.scale = P->eig; a.fa = P->fa_y; a.fb = P->fb_y; a.tw = P->tw_y; a.isin4 = P->isin_y;
+        a.ma = P->ma_y; a.mb = P->mb_y;
         a.rows_per_plane = nx;
         hipLaunchKernelGGL(P->ky, rows_grid(nx*nb, P->ty), dim3(P->nty), P->lds_y, st, a);
         // 4: DST along y again -> B
@@ -859,6 +1056,7 @@ int poisson_solve_batch (Poisson* P, int nb, const double* const* src, long src_
     // 6: DST along x -> destination planes
     for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_a + b*plane; a.dst[b] = dst[b]; }
     a.src_pitch = nx; a.dst_pitch = dst_pitch; a.fa = P->fa_x; a.fb = P->fb_x; a.tw = P->tw_x; a.isin4 = P->isin_x;
+    a.ma = P->ma_x; a.mb = P->mb_x;
     a.rows_per_plane = ny;
     hipLaunchKernelGGL(P->kx, rows_grid(ny*nb, P->tx), dim3(P->ntx), P->lds_x, st, a);
     HPS_HIP_CHECK(hipGetLastError());
