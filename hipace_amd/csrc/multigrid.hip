@@ -604,52 +604,74 @@ struct Blk {
     double r0[4], r1[4], ci[4];
 };
 
+// TWO = false: the functions below work on ONE component (planes selected by `cmp` in blk_geometry / the callers):
+// the levels that fit a wave are run by two waves, one per component, with no synchronisation between them (the
+// two components only meet in the norm) -- a lone wave is bound by its own instruction latencies, so halving the
+// stream per phase nearly halves the phase.
+
 // half-sweep of parity P (0: cells 0 and 3, 1: cells 1 and 2) + publication of the new values
-template <int P, bool WAVE>
+template <int P, bool WAVE, bool TWO = true>
 __device__ __forceinline__ void blk_sweep (Blk& B)
 {
     if (B.act) {
         const int pt = B.pitch;
         if (P == 0) {
-            {   const double w0 = B.c0[-1], s0 = B.c0[-pt], w1 = B.c1[-1], s1 = B.c1[-pt];
+            {   const double w0 = B.c0[-1], s0 = B.c0[-pt];
                 const double n0 = (B.r0[0] - (B.fxm[0]*(w0 + B.v0[1]) + B.fym[0]*(s0 + B.v0[2])))*B.ci[0];
-                const double n1 = (B.r1[0] - (B.fxm[0]*(w1 + B.v1[1]) + B.fym[0]*(s1 + B.v1[2])))*B.ci[0];
-                if (B.ok[0]) { B.v0[0] = n0; B.v1[0] = n1; B.c0[0] = n0; B.c1[0] = n1; } }
-            {   const double e0 = B.c0[pt + 2], t0 = B.c0[2*pt + 1], e1 = B.c1[pt + 2], t1 = B.c1[2*pt + 1];
+                if (B.ok[0]) { B.v0[0] = n0; B.c0[0] = n0; }
+                if (TWO) {
+                    const double w1 = B.c1[-1], s1 = B.c1[-pt];
+                    const double n1 = (B.r1[0] - (B.fxm[0]*(w1 + B.v1[1]) + B.fym[0]*(s1 + B.v1[2])))*B.ci[0];
+                    if (B.ok[0]) { B.v1[0] = n1; B.c1[0] = n1; }
+                } }
+            {   const double e0 = B.c0[pt + 2], t0 = B.c0[2*pt + 1];
                 const double n0 = (B.r0[3] - (B.fxm[1]*(B.v0[2] + e0) + B.fym[1]*(B.v0[1] + t0)))*B.ci[3];
-                const double n1 = (B.r1[3] - (B.fxm[1]*(B.v1[2] + e1) + B.fym[1]*(B.v1[1] + t1)))*B.ci[3];
-                if (B.ok[3]) { B.v0[3] = n0; B.v1[3] = n1; B.c0[pt + 1] = n0; B.c1[pt + 1] = n1; } }
+                if (B.ok[3]) { B.v0[3] = n0; B.c0[pt + 1] = n0; }
+                if (TWO) {
+                    const double e1 = B.c1[pt + 2], t1 = B.c1[2*pt + 1];
+                    const double n1 = (B.r1[3] - (B.fxm[1]*(B.v1[2] + e1) + B.fym[1]*(B.v1[1] + t1)))*B.ci[3];
+                    if (B.ok[3]) { B.v1[3] = n1; B.c1[pt + 1] = n1; }
+                } }
         } else {
-            {   const double e0 = B.c0[2], s0 = B.c0[1 - pt], e1 = B.c1[2], s1 = B.c1[1 - pt];
+            {   const double e0 = B.c0[2], s0 = B.c0[1 - pt];
                 const double n0 = (B.r0[1] - (B.fxm[1]*(B.v0[0] + e0) + B.fym[0]*(s0 + B.v0[3])))*B.ci[1];
-                const double n1 = (B.r1[1] - (B.fxm[1]*(B.v1[0] + e1) + B.fym[0]*(s1 + B.v1[3])))*B.ci[1];
-                if (B.ok[1]) { B.v0[1] = n0; B.v1[1] = n1; B.c0[1] = n0; B.c1[1] = n1; } }
-            {   const double w0 = B.c0[pt - 1], t0 = B.c0[2*pt], w1 = B.c1[pt - 1], t1 = B.c1[2*pt];
+                if (B.ok[1]) { B.v0[1] = n0; B.c0[1] = n0; }
+                if (TWO) {
+                    const double e1 = B.c1[2], s1 = B.c1[1 - pt];
+                    const double n1 = (B.r1[1] - (B.fxm[1]*(B.v1[0] + e1) + B.fym[0]*(s1 + B.v1[3])))*B.ci[1];
+                    if (B.ok[1]) { B.v1[1] = n1; B.c1[1] = n1; }
+                } }
+            {   const double w0 = B.c0[pt - 1], t0 = B.c0[2*pt];
                 const double n0 = (B.r0[2] - (B.fxm[0]*(w0 + B.v0[3]) + B.fym[1]*(B.v0[0] + t0)))*B.ci[2];
-                const double n1 = (B.r1[2] - (B.fxm[0]*(w1 + B.v1[3]) + B.fym[1]*(B.v1[0] + t1)))*B.ci[2];
-                if (B.ok[2]) { B.v0[2] = n0; B.v1[2] = n1; B.c0[pt] = n0; B.c1[pt] = n1; } }
+                if (B.ok[2]) { B.v0[2] = n0; B.c0[pt] = n0; }
+                if (TWO) {
+                    const double w1 = B.c1[pt - 1], t1 = B.c1[2*pt];
+                    const double n1 = (B.r1[2] - (B.fxm[0]*(w1 + B.v1[3]) + B.fym[1]*(B.v1[0] + t1)))*B.ci[2];
+                    if (B.ok[2]) { B.v1[2] = n1; B.c1[pt] = n1; }
+                } }
         }
     }
     lvl_sync<WAVE>();
 }
 
 // down-leg sweeps from cor = 0: sweep 0 is rhs/diag on the colour-0 cells, then sweeps 1 .. nsw-1 (nsw even)
-template <bool WAVE>
+template <bool WAVE, bool TWO = true>
 __device__ __forceinline__ void blk_down_sweeps (Blk& B, int nsw)
 {
 #pragma unroll
     for (int k = 0; k < 4; ++k) { B.v0[k] = 0.0; B.v1[k] = 0.0; }
     if (B.act) {
-        if (B.ok[0]) { B.v0[0] = B.r0[0]*B.ci[0]; B.v1[0] = B.r1[0]*B.ci[0]; B.c0[0] = B.v0[0]; B.c1[0] = B.v1[0]; }
-        if (B.ok[3]) { B.v0[3] = B.r0[3]*B.ci[3]; B.v1[3] = B.r1[3]*B.ci[3]; B.c0[B.pitch + 1] = B.v0[3]; B.c1[B.pitch + 1] = B.v1[3]; }
+        if (B.ok[0]) { B.v0[0] = B.r0[0]*B.ci[0]; B.c0[0] = B.v0[0]; if (TWO) { B.v1[0] = B.r1[0]*B.ci[0]; B.c1[0] = B.v1[0]; } }
+        if (B.ok[3]) { B.v0[3] = B.r0[3]*B.ci[3]; B.c0[B.pitch + 1] = B.v0[3]; if (TWO) { B.v1[3] = B.r1[3]*B.ci[3]; B.c1[B.pitch + 1] = B.v1[3]; } }
     }
     lvl_sync<WAVE>();
-    blk_sweep<1, WAVE>(B);
-    for (int s = 2; s < nsw; s += 2) { blk_sweep<0, WAVE>(B); blk_sweep<1, WAVE>(B); }
+    blk_sweep<1, WAVE, TWO>(B);
+    for (int s = 2; s < nsw; s += 2) { blk_sweep<0, WAVE, TWO>(B); blk_sweep<1, WAVE, TWO>(B); }
 }
 
 // The whole level is this one block (2 x 2 cells or fewer): every neighbour outside the block is the
 // zero ring, so all nsw sweeps from cor = 0 run in the lane's registers; published once at the end.
+template <bool TWO = true>
 __device__ __forceinline__ void blk_single_sweeps (Blk& B, int nsw)
 {
 #pragma unroll
@@ -657,47 +679,60 @@ __device__ __forceinline__ void blk_single_sweeps (Blk& B, int nsw)
     if (B.act) {
         for (int s = 0; s < nsw; s += 2) {
             {   const double a0 = (B.r0[0] - (B.fxm[0]*(0.0 + B.v0[1]) + B.fym[0]*(0.0 + B.v0[2])))*B.ci[0];
-                const double a1 = (B.r1[0] - (B.fxm[0]*(0.0 + B.v1[1]) + B.fym[0]*(0.0 + B.v1[2])))*B.ci[0];
                 const double b0 = (B.r0[3] - (B.fxm[1]*(B.v0[2] + 0.0) + B.fym[1]*(B.v0[1] + 0.0)))*B.ci[3];
-                const double b1 = (B.r1[3] - (B.fxm[1]*(B.v1[2] + 0.0) + B.fym[1]*(B.v1[1] + 0.0)))*B.ci[3];
-                if (B.ok[0]) { B.v0[0] = a0; B.v1[0] = a1; }
-                if (B.ok[3]) { B.v0[3] = b0; B.v1[3] = b1; } }
+                if (B.ok[0]) B.v0[0] = a0;
+                if (B.ok[3]) B.v0[3] = b0;
+                if (TWO) {
+                    const double a1 = (B.r1[0] - (B.fxm[0]*(0.0 + B.v1[1]) + B.fym[0]*(0.0 + B.v1[2])))*B.ci[0];
+                    const double b1 = (B.r1[3] - (B.fxm[1]*(B.v1[2] + 0.0) + B.fym[1]*(B.v1[1] + 0.0)))*B.ci[3];
+                    if (B.ok[0]) B.v1[0] = a1;
+                    if (B.ok[3]) B.v1[3] = b1;
+                } }
             {   const double a0 = (B.r0[1] - (B.fxm[1]*(B.v0[0] + 0.0) + B.fym[0]*(0.0 + B.v0[3])))*B.ci[1];
-                const double a1 = (B.r1[1] - (B.fxm[1]*(B.v1[0] + 0.0) + B.fym[0]*(0.0 + B.v1[3])))*B.ci[1];
                 const double b0 = (B.r0[2] - (B.fxm[0]*(0.0 + B.v0[3]) + B.fym[1]*(B.v0[0] + 0.0)))*B.ci[2];
-                const double b1 = (B.r1[2] - (B.fxm[0]*(0.0 + B.v1[3]) + B.fym[1]*(B.v1[0] + 0.0)))*B.ci[2];
-                if (B.ok[1]) { B.v0[1] = a0; B.v1[1] = a1; }
-                if (B.ok[2]) { B.v0[2] = b0; B.v1[2] = b1; } }
+                if (B.ok[1]) B.v0[1] = a0;
+                if (B.ok[2]) B.v0[2] = b0;
+                if (TWO) {
+                    const double a1 = (B.r1[1] - (B.fxm[1]*(B.v1[0] + 0.0) + B.fym[0]*(0.0 + B.v1[3])))*B.ci[1];
+                    const double b1 = (B.r1[2] - (B.fxm[0]*(0.0 + B.v1[3]) + B.fym[1]*(B.v1[0] + 0.0)))*B.ci[2];
+                    if (B.ok[1]) B.v1[1] = a1;
+                    if (B.ok[2]) B.v1[2] = b1;
+                } }
         }
         const int ok[4] = {0, 1, B.pitch, B.pitch + 1};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (B.ok[k]) { B.c0[ok[k]] = B.v0[k]; B.c1[ok[k]] = B.v1[k]; }
+        for (int k = 0; k < 4; ++k) if (B.ok[k]) { B.c0[ok[k]] = B.v0[k]; if (TWO) B.c1[ok[k]] = B.v1[k]; }
     }
 }
 
 // residuals of the block's four cells (0 for cells outside the level)
+template <bool TWO = true>
 __device__ __forceinline__ void blk_residual (const Blk& B, int i, int j, const LevBox& b, const double (&a)[4],
                                               double fx, double fy, double (&q0)[4], double (&q1)[4])
 {
     const int pt = B.pitch;
-    const double w00 = B.c0[-1], s00 = B.c0[-pt], e01 = B.c0[2], s01 = B.c0[1 - pt];
-    const double w02 = B.c0[pt - 1], n02 = B.c0[2*pt], e03 = B.c0[pt + 2], n03 = B.c0[2*pt + 1];
-    const double w10 = B.c1[-1], s10 = B.c1[-pt], e11 = B.c1[2], s11 = B.c1[1 - pt];
-    const double w12 = B.c1[pt - 1], n12 = B.c1[2*pt], e13 = B.c1[pt + 2], n13 = B.c1[2*pt + 1];
-    q0[0] = residual_v<false>(B.v0[0], w00, B.v0[1], s00, B.v0[2], i, j, b, B.r0[0], a[0], fx, fy);
-    q0[1] = residual_v<false>(B.v0[1], B.v0[0], e01, s01, B.v0[3], i + 1, j, b, B.r0[1], a[1], fx, fy);
-    q0[2] = residual_v<false>(B.v0[2], w02, B.v0[3], B.v0[0], n02, i, j + 1, b, B.r0[2], a[2], fx, fy);
-    q0[3] = residual_v<false>(B.v0[3], B.v0[2], e03, B.v0[1], n03, i + 1, j + 1, b, B.r0[3], a[3], fx, fy);
-    q1[0] = residual_v<false>(B.v1[0], w10, B.v1[1], s10, B.v1[2], i, j, b, B.r1[0], a[0], fx, fy);
-    q1[1] = residual_v<false>(B.v1[1], B.v1[0], e11, s11, B.v1[3], i + 1, j, b, B.r1[1], a[1], fx, fy);
-    q1[2] = residual_v<false>(B.v1[2], w12, B.v1[3], B.v1[0], n12, i, j + 1, b, B.r1[2], a[2], fx, fy);
-    q1[3] = residual_v<false>(B.v1[3], B.v1[2], e13, B.v1[1], n13, i + 1, j + 1, b, B.r1[3], a[3], fx, fy);
+    {   const double w00 = B.c0[-1], s00 = B.c0[-pt], e01 = B.c0[2], s01 = B.c0[1 - pt];
+        const double w02 = B.c0[pt - 1], n02 = B.c0[2*pt], e03 = B.c0[pt + 2], n03 = B.c0[2*pt + 1];
+        q0[0] = residual_v<false>(B.v0[0], w00, B.v0[1], s00, B.v0[2], i, j, b, B.r0[0], a[0], fx, fy);
+        q0[1] = residual_v<false>(B.v0[1], B.v0[0], e01, s01, B.v0[3], i + 1, j, b, B.r0[1], a[1], fx, fy);
+        q0[2] = residual_v<false>(B.v0[2], w02, B.v0[3], B.v0[0], n02, i, j + 1, b, B.r0[2], a[2], fx, fy);
+        q0[3] = residual_v<false>(B.v0[3], B.v0[2], e03, B.v0[1], n03, i + 1, j + 1, b, B.r0[3], a[3], fx, fy); }
+    if (TWO) {
+        const double w10 = B.c1[-1], s10 = B.c1[-pt], e11 = B.c1[2], s11 = B.c1[1 - pt];
+        const double w12 = B.c1[pt - 1], n12 = B.c1[2*pt], e13 = B.c1[pt + 2], n13 = B.c1[2*pt + 1];
+        q1[0] = residual_v<false>(B.v1[0], w10, B.v1[1], s10, B.v1[2], i, j, b, B.r1[0], a[0], fx, fy);
+        q1[1] = residual_v<false>(B.v1[1], B.v1[0], e11, s11, B.v1[3], i + 1, j, b, B.r1[1], a[1], fx, fy);
+        q1[2] = residual_v<false>(B.v1[2], w12, B.v1[3], B.v1[0], n12, i, j + 1, b, B.r1[2], a[2], fx, fy);
+        q1[3] = residual_v<false>(B.v1[3], B.v1[2], e13, B.v1[1], n13, i + 1, j + 1, b, B.r1[3], a[3], fx, fy);
+    }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { if (!B.ok[k]) { q0[k] = 0.0; q1[k] = 0.0; } }
+    for (int k = 0; k < 4; ++k) { if (!B.ok[k]) { q0[k] = 0.0; q1[k] = 0.0; } else if (!TWO) q1[k] = 0.0; }
 }
 
-// geometry of thread t's block on a level of nx x ny cells whose planes start at `lev` (pitch nx + 2)
-__device__ __forceinline__ void blk_geometry (Blk& B, lds_double* lev, int nx, int ny, int t, double fx, double fy, int& i, int& j)
+// geometry of thread t's block on a level of nx x ny cells whose planes start at `lev` (pitch nx + 2);
+// cmp: the component whose planes become c0 (one-component mode), 0 otherwise
+__device__ __forceinline__ void blk_geometry (Blk& B, lds_double* lev, int nx, int ny, int t, double fx, double fy, int& i, int& j,
+                                              int cmp = 0)
 {
     const int nbx = (nx + 1) >> 1, nby = (ny + 1) >> 1;
     int lg = 0; while ((1 << lg) < nbx) ++lg;                  // blocks per row rounded up to a power of two
@@ -707,7 +742,7 @@ __device__ __forceinline__ void blk_geometry (Blk& B, lds_double* lev, int nx, i
     B.pitch = nx + 2;
     const int ps = B.pitch*(ny + 2);
     const int o = B.act ? (j + 1)*B.pitch + i + 1 : B.pitch + 1;
-    B.c0 = lev + o; B.c1 = lev + ps + o;
+    B.c0 = lev + cmp*ps + o; B.c1 = B.c0 + ps;
     B.ok[0] = B.act; B.ok[1] = B.act && (i + 1 < nx); B.ok[2] = B.act && (j + 1 < ny); B.ok[3] = B.ok[1] && B.ok[2];
     B.fxm[0] = wall_mult<true>(i, 0, nx - 1, fx); B.fxm[1] = wall_mult<true>(i + 1, 0, nx - 1, fx);
     B.fym[0] = wall_mult<true>(j, 0, ny - 1, fy); B.fym[1] = wall_mult<true>(j + 1, 0, ny - 1, fy);
@@ -715,15 +750,17 @@ __device__ __forceinline__ void blk_geometry (Blk& B, lds_double* lev, int nx, i
 
 __device__ __forceinline__ double lvl_fac (double f0, int l) { for (int k = 0; k < l; ++k) f0 *= 0.25; return f0; }
 
-// levels >= 1 keep six LDS planes: cor0 cor1 | res0 res1 | acf | 1/diag (all ringed, pitch nx + 2)
+// levels >= 1 keep six LDS planes: cor0 cor1 | res0 res1 | acf | 1/diag (all ringed, pitch nx + 2).  With c0 = the
+// correction plane of component cmp: rhs of cmp = c0 + 2 ps, coefficient = c0 + (4 - cmp) ps, 1/diag = c0 + (5 - cmp) ps.
 
 // down-leg of level l >= 1: cor = GSRB^nsw(0), then (unless last) the restricted residual -> rhs of level l+1
-template <bool WAVE>
-__device__ __forceinline__ void low_down (lds_double* base, const Low2& d, int l, int t, double fx, double fy, int nsw, bool last)
+template <bool WAVE, bool TWO = true>
+__device__ __forceinline__ void low_down (lds_double* base, const Low2& d, int l, int t, double fx, double fy, int nsw, bool last,
+                                          int cmp = 0)
 {
     const int nx = d.nx[l], ny = d.ny[l];
     Blk B; int i, j;
-    blk_geometry(B, base + d.off[l], nx, ny, t, fx, fy, i, j);
+    blk_geometry(B, base + d.off[l], nx, ny, t, fx, fy, i, j, cmp);
     const int ps = B.pitch*(ny + 2);
     const lds_double* r = B.c0 + 2*ps;
     const int ok[4] = {0, 1, B.pitch, B.pitch + 1};
@@ -731,108 +768,99 @@ __device__ __forceinline__ void low_down (lds_double* base, const Low2& d, int l
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int o = B.ok[k] ? ok[k] : 0;
-        B.r0[k] = r[o]; B.r1[k] = r[ps + o]; a[k] = r[2*ps + o]; B.ci[k] = r[3*ps + o];
+        B.r0[k] = r[o]; B.r1[k] = TWO ? r[ps + o] : 0.0; a[k] = r[(2 - cmp)*ps + o]; B.ci[k] = r[(3 - cmp)*ps + o];
     }
-    if (last && nx <= 2 && ny <= 2) { blk_single_sweeps(B, nsw); lvl_sync<WAVE>(); }
-    else blk_down_sweeps<WAVE>(B, nsw);
+    if (last && nx <= 2 && ny <= 2) { blk_single_sweeps<TWO>(B, nsw); lvl_sync<WAVE>(); }
+    else blk_down_sweeps<WAVE, TWO>(B, nsw);
     if (!last) {
         double q0[4], q1[4];
-        blk_residual(B, i, j, cc_box(nx, ny), a, fx, fy, q0, q1);
+        blk_residual<TWO>(B, i, j, cc_box(nx, ny), a, fx, fy, q0, q1);
         if (B.act) {
             const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
-            lds_double* rn = base + d.off[l+1] + 2*psn + ((j >> 1) + 1)*pn + (i >> 1) + 1;
+            lds_double* rn = base + d.off[l+1] + (2 + cmp)*psn + ((j >> 1) + 1)*pn + (i >> 1) + 1;
             rn[0] = 0.25*(q0[0] + q0[1] + q0[2] + q0[3]);
-            rn[psn] = 0.25*(q1[0] + q1[1] + q1[2] + q1[3]);
+            if (TWO) rn[psn] = 0.25*(q1[0] + q1[1] + q1[2] + q1[3]);
         }
         lvl_sync<WAVE>();
     }
 }
 
 // up-leg of level l >= 1: cor += P(cor of level l+1), GSRB^4
-template <bool WAVE>
-__device__ __forceinline__ void low_up (lds_double* base, const Low2& d, int l, int t, double fx, double fy)
+template <bool WAVE, bool TWO = true>
+__device__ __forceinline__ void low_up (lds_double* base, const Low2& d, int l, int t, double fx, double fy, int cmp = 0)
 {
     const int nx = d.nx[l], ny = d.ny[l];
     Blk B; int i, j;
-    blk_geometry(B, base + d.off[l], nx, ny, t, fx, fy, i, j);
+    blk_geometry(B, base + d.off[l], nx, ny, t, fx, fy, i, j, cmp);
     const int ps = B.pitch*(ny + 2);
     const lds_double* r = B.c0 + 2*ps;
     const int ok[4] = {0, 1, B.pitch, B.pitch + 1};
     const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
-    const lds_double* kc = base + d.off[l+1] + ((j >> 1) + 1)*pn + (i >> 1) + 1;
-    const double k0 = B.act ? kc[0] : 0.0, k1 = B.act ? kc[psn] : 0.0;
+    const lds_double* kc = base + d.off[l+1] + cmp*psn + ((j >> 1) + 1)*pn + (i >> 1) + 1;
+    const double k0 = B.act ? kc[0] : 0.0, k1 = (TWO && B.act) ? kc[psn] : 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int o = B.ok[k] ? ok[k] : 0;
-        B.r0[k] = r[o]; B.r1[k] = r[ps + o]; B.ci[k] = r[3*ps + o];
-        const double c0 = B.c0[o], c1 = B.c1[o];
-        B.v0[k] = B.ok[k] ? c0 + k0 : 0.0; B.v1[k] = B.ok[k] ? c1 + k1 : 0.0;
-        if (B.ok[k]) { B.c0[o] = B.v0[k]; B.c1[o] = B.v1[k]; }
+        B.r0[k] = r[o]; B.r1[k] = TWO ? r[ps + o] : 0.0; B.ci[k] = r[(3 - cmp)*ps + o];
+        const double c0 = B.c0[o];
+        B.v0[k] = B.ok[k] ? c0 + k0 : 0.0;
+        if (B.ok[k]) B.c0[o] = B.v0[k];
+        B.v1[k] = 0.0;
+        if (TWO) {
+            const double c1 = B.c1[o];
+            B.v1[k] = B.ok[k] ? c1 + k1 : 0.0;
+            if (B.ok[k]) B.c1[o] = B.v1[k];
+        }
     }
     lvl_sync<WAVE>();
-    blk_sweep<0, WAVE>(B); blk_sweep<1, WAVE>(B); blk_sweep<0, WAVE>(B); blk_sweep<1, WAVE>(B);
+    blk_sweep<0, WAVE, TWO>(B); blk_sweep<1, WAVE, TWO>(B); blk_sweep<0, WAVE, TWO>(B); blk_sweep<1, WAVE, TWO>(B);
 }
 
-// Levels of at most 8 x 8 cells inside wave 0, one lane per cell (lane t <-> cell (t & 7, t >> 3)): a lone
-// wave is bound by its own instruction latencies, and a cell per lane is the shortest stream per sweep.
-__device__ __forceinline__ void tiny_down (lds_double* base, const Low2& d, int l, int t, double fx, double fy)
+// Levels of at most 8 x 8 cells inside one wave, one lane per cell (lane t <-> cell (t & 7, t >> 3)), one component
+// (cmp) per wave: a lone wave is bound by its own instruction latencies, and a cell per lane is the shortest
+// stream per sweep.
+__device__ __forceinline__ void tiny_down (lds_double* base, const Low2& d, int l, int t, double fx, double fy, int cmp)
 {
     const int nx = d.nx[l], ny = d.ny[l], pitch = nx + 2, ps = pitch*(ny + 2);
     const int i = t & 7, j = t >> 3;
     const bool ok = (i < nx) && (j < ny);
     const int o = ok ? (j + 1)*pitch + i + 1 : pitch + 1;
-    lds_double* c0 = base + d.off[l] + o;
-    lds_double* c1 = c0 + ps;
-    const double r0 = c0[2*ps], r1 = c0[3*ps], a = c0[4*ps], ci = c0[5*ps];
+    lds_double* c0 = base + d.off[l] + cmp*ps + o;
+    const double r0 = c0[2*ps], a = c0[(4 - cmp)*ps], ci = c0[(5 - cmp)*ps];
     const double fxm = wall_mult<true>(i, 0, nx - 1, fx), fym = wall_mult<true>(j, 0, ny - 1, fy);
-    if (ok && (((i + j) & 1) == 0)) { c0[0] = r0*ci; c1[0] = r1*ci; }      // sweep 0 from cor = 0
+    if (ok && (((i + j) & 1) == 0)) c0[0] = r0*ci;                          // sweep 0 from cor = 0
     lvl_sync<true>();
     for (int s = 1; s < 4; ++s) {
-        if (ok && (((i + j + s) & 1) == 0)) {
-            const double n0 = (r0 - offdiag_m((const lds_double*)c0, pitch, fxm, fym))*ci;
-            const double n1 = (r1 - offdiag_m((const lds_double*)c1, pitch, fxm, fym))*ci;
-            c0[0] = n0; c1[0] = n1;
-        }
+        if (ok && (((i + j + s) & 1) == 0)) c0[0] = (r0 - offdiag_m((const lds_double*)c0, pitch, fxm, fym))*ci;
         lvl_sync<true>();
     }
     const LevBox b = cc_box(nx, ny);
     const double u0 = residual_at<false>((const lds_double*)c0, pitch, i, j, b, r0, a, fx, fy);
-    const double u1 = residual_at<false>((const lds_double*)c1, pitch, i, j, b, r1, a, fx, fy);
-    const double q0 = ok ? u0 : 0.0, q1 = ok ? u1 : 0.0;
+    const double q0 = ok ? u0 : 0.0;
     const double b0 = __shfl_down(q0, 1), g0 = __shfl_down(q0, 8), e0 = __shfl_down(q0, 9);
-    const double b1 = __shfl_down(q1, 1), g1 = __shfl_down(q1, 8), e1 = __shfl_down(q1, 9);
     if (ok && !(i & 1) && !(j & 1)) {
         const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
-        lds_double* rn = base + d.off[l+1] + 2*psn + ((j >> 1) + 1)*pn + (i >> 1) + 1;
-        rn[0] = 0.25*(q0 + b0 + g0 + e0);
-        rn[psn] = 0.25*(q1 + b1 + g1 + e1);
+        base[d.off[l+1] + (2 + cmp)*psn + ((j >> 1) + 1)*pn + (i >> 1) + 1] = 0.25*(q0 + b0 + g0 + e0);
     }
     lvl_sync<true>();
 }
 
-__device__ __forceinline__ void tiny_up (lds_double* base, const Low2& d, int l, int t, double fx, double fy)
+__device__ __forceinline__ void tiny_up (lds_double* base, const Low2& d, int l, int t, double fx, double fy, int cmp)
 {
     const int nx = d.nx[l], ny = d.ny[l], pitch = nx + 2, ps = pitch*(ny + 2);
     const int i = t & 7, j = t >> 3;
     const bool ok = (i < nx) && (j < ny);
     const int o = ok ? (j + 1)*pitch + i + 1 : pitch + 1;
-    lds_double* c0 = base + d.off[l] + o;
-    lds_double* c1 = c0 + ps;
-    const double r0 = c0[2*ps], r1 = c0[3*ps], ci = c0[5*ps];
+    lds_double* c0 = base + d.off[l] + cmp*ps + o;
+    const double r0 = c0[2*ps], ci = c0[(5 - cmp)*ps];
     const double fxm = wall_mult<true>(i, 0, nx - 1, fx), fym = wall_mult<true>(j, 0, ny - 1, fy);
     if (ok) {
         const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
-        const lds_double* kc = base + d.off[l+1] + ((j >> 1) + 1)*pn + (i >> 1) + 1;
-        c0[0] = c0[0] + kc[0];
-        c1[0] = c1[0] + kc[psn];
+        c0[0] = c0[0] + base[d.off[l+1] + cmp*psn + ((j >> 1) + 1)*pn + (i >> 1) + 1];
     }
     lvl_sync<true>();
     for (int s = 0; s < 4; ++s) {
-        if (ok && (((i + j + s) & 1) == 0)) {
-            const double n0 = (r0 - offdiag_m((const lds_double*)c0, pitch, fxm, fym))*ci;
-            const double n1 = (r1 - offdiag_m((const lds_double*)c1, pitch, fxm, fym))*ci;
-            c0[0] = n0; c1[0] = n1;
-        }
+        if (ok && (((i + j + s) & 1) == 0)) c0[0] = (r0 - offdiag_m((const lds_double*)c0, pitch, fxm, fym))*ci;
         lvl_sync<true>();
     }
 }
@@ -924,17 +952,19 @@ void k_lower_v2 (const Low2* __restrict__ dp, const double* __restrict__ acf_g, 
             low_down<false>(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l), (l == nl - 1) ? nsweeps_bottom : 4, l == nl - 1);
         MG_STAMP(11);
         if (lw < nl) {
-            if (t < 64) {
+            if (t < 128) {
+                // waves 0 and 1: one component each, no synchronisation between them
+                const int cmp = t >> 6, tl = t & 63;
                 for (int l = lw; l < nl; ++l) {
                     MG_STAMP(16 + l);
                     const bool tiny = (d.nx[l] <= 8 && d.ny[l] <= 8 && l < nl - 1);
-                    if (tiny) tiny_down(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l));
-                    else low_down<true>(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l), (l == nl - 1) ? nsweeps_bottom : 4, l == nl - 1);
+                    if (tiny) tiny_down(base, d, l, tl, lvl_fac(facx0, l), lvl_fac(facy0, l), cmp);
+                    else low_down<true, false>(base, d, l, tl, lvl_fac(facx0, l), lvl_fac(facy0, l), (l == nl - 1) ? nsweeps_bottom : 4, l == nl - 1, cmp);
                 }
                 for (int l = nl - 2; l >= lw; --l) {
                     MG_STAMP(32 + l);
-                    if (d.nx[l] <= 8 && d.ny[l] <= 8) tiny_up(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l));
-                    else low_up<true>(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l));
+                    if (d.nx[l] <= 8 && d.ny[l] <= 8) tiny_up(base, d, l, tl, lvl_fac(facx0, l), lvl_fac(facy0, l), cmp);
+                    else low_up<true, false>(base, d, l, tl, lvl_fac(facx0, l), lvl_fac(facy0, l), cmp);
                 }
             }
             __syncthreads();
