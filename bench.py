@@ -124,7 +124,7 @@ def main():
         # ring pipeline over time steps: every rank sweeps `steps` slices of its own step(s); the beam
         # slices travel rank -> rank+1 through RCCL (hipace_amd/pipeline.py)
         from hipace_amd.pipeline import run_pipeline
-        per_step = min(args.steps, nz)
+        per_step = max(min(args.steps, nz), 2 * world)      # the ring needs 2 slices of skew per rank
         steps_per_rank = max(1, args.steps // nz)
         solved = run_pipeline(eng, rank, world, world * steps_per_rank, torch.device("cuda", local),
                               slices_per_step=per_step)
