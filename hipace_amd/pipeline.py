@@ -65,6 +65,9 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
     nz = engine.deck["nz"]
     per_step = slices_per_step or nz
     assert per_step >= 2 * world, "the ring pipeline needs at least 2 slices per rank"
+    if getattr(engine, "moving", False):
+        assert per_step == nz, "a moving beam (hipace.dt != 0) needs whole steps"
+        return _run_pipeline_moving(engine, rank, world, n_steps, device, on_step_end)
     sched = _Sched(world, n_steps, nz, per_step)
     nbeam, off = engine.beam_layout()
     bufs = [torch.zeros(max(7 * nbeam, 1), dtype=torch.float64, device=device) for _ in range(2)]
@@ -135,6 +138,82 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
             pending_send.pop(0).wait()
         if islice == nz - per_step and on_step_end is not None:
             on_step_end(step)
+    for rq in pending_send:
+        rq.wait()
+    return solved
+
+
+def _run_pipeline_moving(engine, rank, world, n_steps, device, on_step_end):
+    """hipace.dt != 0: what sits on a slice after its push travels as one fixed-size message
+    [count | 7 rows of `cap` doubles] (engine.export_beam_slice) and becomes the next step's slice
+    (engine.import_beam_slice) -- MultiBuffer::put_data / get_data (utils/MultiBuffer.cpp:444-609).  Same tick
+    schedule as the static path; the head rank injects the beam (its first step only)."""
+    nz = engine.deck["nz"]
+    sched = _Sched(world, n_steps, nz, nz)
+    cap = engine.beam_capacity()
+    mlen = 1 + 7 * cap
+    prev, nxt = (rank - 1) % world, (rank + 1) % world
+    # receive slots: two steps' worth (a rank may hold the early slices of its next step); send slots rotate
+    rpool = [[torch.zeros(mlen, dtype=torch.float64, device=device) for _ in range(nz)] for _ in range(2)]
+    spool = [torch.zeros(mlen, dtype=torch.float64, device=device) for _ in range(8)]
+    pending_recv, pending_send, have = {}, [], set()
+    exported = {}          # tick -> send slot holding the slice solved in that tick
+    solved = 0
+    for tick in range(sched.n_ticks()):
+        ops = []
+        pw = sched.work(prev, tick - 1)
+        if world > 1 and pw is not None and pw[0] + 1 < n_steps and (pw[0] + 1) % world == rank:
+            m_target = (pw[0] + 1 - rank) // world
+            ops.append(("recv", dist.P2POp(dist.irecv, rpool[m_target % 2][nz - 1 - pw[1]], prev), (m_target, pw[1])))
+        mw = sched.work(rank, tick - 1)
+        if world > 1 and mw is not None and mw[0] + 1 < n_steps:
+            ops.append(("send", dist.P2POp(dist.isend, exported.pop(tick - 1), nxt), None))
+        if ops:
+            reqs = dist.batch_isend_irecv([o[1] for o in ops])
+            for i, o in enumerate(ops):
+                rq = reqs[i] if len(reqs) == len(ops) else reqs[-1]
+                if o[0] == "recv":
+                    pending_recv[o[2]] = rq
+                else:
+                    pending_send.append(rq)
+
+        w = sched.work(rank, tick)
+        if w is None:
+            continue
+        step, islice, m = w
+        from_ring = step > 0                                    # step 0 is the injected beam of the head rank
+        if islice == nz - 1:
+            engine.set_beam_import(from_ring)
+            engine.begin_step()
+        if from_ring:
+            waited = False
+            for k in (islice, islice - 1):                      # this slice and the next one (jx/jy source)
+                if k < 0 or (m, k) in have:
+                    continue
+                rq = pending_recv.pop((m, k), None)
+                if rq is not None:
+                    rq.wait()
+                    waited = True
+                if waited and str(device) != "cpu":
+                    torch.cuda.current_stream().synchronize()
+                engine.import_beam_slice(k, rpool[m % 2][nz - 1 - k])
+                have.add((m, k))
+        engine.solve_slice(islice)
+        engine.sync()
+        solved += 1
+        if step + 1 < n_steps:
+            if world == 1:
+                engine.export_beam_slice(islice, rpool[(m + 1) % 2][nz - 1 - islice])      # in-process hand-off
+            else:
+                slot = spool[tick % len(spool)]
+                engine.export_beam_slice(islice, slot)
+                exported[tick] = slot
+        while len(pending_send) > 4:
+            pending_send.pop(0).wait()
+        if islice == 0:
+            have = {h for h in have if h[0] != m}
+            if on_step_end is not None:
+                on_step_end(step)
     for rq in pending_send:
         rq.wait()
     return solved

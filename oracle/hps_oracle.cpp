@@ -893,6 +893,7 @@ struct Engine {
     Beam beam_this, beam_next;
     // dt != 0: the beam lives in per-slice stores across the time steps (index = islice)
     std::vector<Beam> store; bool store_ready = false; int steps_begun = 0; double phys_time = 0.0;
+    bool beam_import = false;      // ring pipeline: the slices of the coming step arrive through import_beam_slice
     double beam_diag[7] = {0, 0, 0, 0, 0, 0, 0};   // n, sum w, |x|, |y|, |z|, |ux|, |uz| before the push (regular particles)
     // optional external beam storage in the product's block layout (pipeline tests):
     // block p (p-th slice from the head) = [7][count_p] at 7*ext_off[p]
@@ -1255,7 +1256,9 @@ struct Engine {
         for (double& v : beam_diag) v = 0.0;
         if (d.dt != 0.0) {
             ensure_store();
-            if (steps_begun > 0) {
+            if (beam_import) {
+                for (Beam& b : store) b = Beam();          // filled slice by slice by the ring hand-off
+            } else if (steps_begun > 0) {
                 phys_time += d.dt;
                 // the buffer hand-off between steps does not carry the sub-cycle counters, and whatever sits on a
                 // slice now is regular (BeamParticleContainer.H:35-37, MultiBuffer.cpp:809)
@@ -1447,6 +1450,17 @@ void orc_engine_beam_stats (void* h, double* out /* n, sum w, sum|x|, sum|y|, su
     }
 }
 
+// ring hand-off of a moving beam (MultiBuffer::{put_data,get_data}, utils/MultiBuffer.cpp:444-609): what sits on a
+// slice after its push leaves as one block, and enters the next step's slice as regular particles
+void orc_engine_set_beam_import (void* h, int on) { Engine* e = static_cast<Engine*>(h); e->ensure_store(); e->beam_import = (on != 0); }
+void orc_engine_import_beam_slice (void* h, int islice, long count, const double* in7n) {
+    Engine* e = static_cast<Engine*>(h); e->ensure_store();
+    Beam b; const size_t n = (size_t)count;
+    std::vector<double>* a[7] = {&b.x, &b.y, &b.z, &b.ux, &b.uy, &b.uz, &b.w};
+    for (int k = 0; k < 7; ++k) a[k]->assign(in7n + k*n, in7n + (k + 1)*n);
+    b.nsub.assign(n, 0); b.valid.assign(n, 1); b.nreg = count;
+    e->store[islice] = b;
+}
 // moving beam: sum |ux| seen by the last step's diagnostics, and the per-slice store for parity tests
 double orc_engine_beam_sum_abs_ux (void* h) { return static_cast<Engine*>(h)->beam_diag[5]; }
 long orc_engine_beam_slice_count (void* h, int islice) {

@@ -310,6 +310,44 @@ class Engine:
         n = lib().orc_engine_beam_layout(self._h, _ptr(off))
         return n, off
 
+    # ---- ring hand-off of a moving beam (same interface as hipace_amd.api.SliceEngine) --------------
+    @property
+    def moving(self):
+        return float(self.deck.get("dt", 0.0)) != 0.0
+
+    def beam_capacity(self):
+        """Particles a slice block may hold in the hand-off messages (twice the fullest injected slice)."""
+        return 2 * max(self.beam_slice(i).shape[1] for i in range(self.deck["nz"])) if not getattr(self, "_cap", None) else self._cap
+
+    def set_beam_import(self, on):
+        if not getattr(self, "_cap", None):
+            self._cap = self.beam_capacity()
+        L = lib()
+        L.orc_engine_set_beam_import.restype = None
+        L.orc_engine_set_beam_import.argtypes = [C.c_void_p, C.c_int]
+        L.orc_engine_set_beam_import(self._h, int(on))
+
+    def export_beam_slice(self, islice, msg):
+        """msg: float64 tensor/array of 1 + 7*cap: [count | x.. y.. z.. ux.. uy.. uz.. w.. (row stride cap)]."""
+        cap = (len(msg) - 1) // 7
+        blk = self.beam_slice(islice)
+        n = blk.shape[1]
+        assert n <= cap, "beam slice exceeds the hand-off capacity"
+        m = msg.numpy() if hasattr(msg, "numpy") else msg
+        m[0] = float(n)
+        for k in range(7):
+            m[1 + k * cap:1 + k * cap + n] = blk[k]
+
+    def import_beam_slice(self, islice, msg):
+        cap = (len(msg) - 1) // 7
+        m = msg.numpy() if hasattr(msg, "numpy") else msg
+        n = int(m[0])
+        data = np.ascontiguousarray(np.stack([m[1 + k * cap:1 + k * cap + n] for k in range(7)]), dtype=np.float64)
+        L = lib()
+        L.orc_engine_import_beam_slice.restype = None
+        L.orc_engine_import_beam_slice.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_void_p]
+        L.orc_engine_import_beam_slice(self._h, islice, n, _ptr(data))
+
     def beam_slice(self, islice):
         """Moving beam (deck dt != 0): the particles sitting on slice `islice` now, as a (7, count) array x y z ux uy uz w."""
         L = lib()

@@ -23,6 +23,15 @@ def _deck():
     return d
 
 
+def _moving_deck():
+    """A slow beam (v_z = 0.77 c) in a focusing field: particles fall back through the slices every step, so the
+    hand-off carries blocks of changing size."""
+    d = decks.beam_evolution()
+    d.update(nz=12, lo=(-2.0, -2.0, -2.4), hi=(2.0, 2.0, 2.4), beam_zmin=-1.0, beam_zmax=1.6, beam_umean=(0.0, 0.0, 1.2),
+             beam_density=1.0e-3, n_steps=1, dt=0.9, beam_n_subcycles=4, ext_E_slope=(0.3, 0.2))
+    return d
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -31,14 +40,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_steps, out):
+def _worker(rank, world, port, n_steps, out, moving=False):
     import torch.distributed as dist
     from hipace_amd.pipeline import run_pipeline
     from oracle import oracle as O
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    eng = O.Engine(_deck())
+    eng = O.Engine(_moving_deck() if moving else _deck())
     sums = {}
 
     def on_step_end(step):
@@ -75,4 +84,37 @@ def test_ring_pipeline_matches_single_process(oracle, world, n_steps):
             seen.add(step)
             for k, v in want.items():
                 assert abs(cs[k] - v) <= 1e-12 * max(abs(v), 1e-300), (rank, step, k, cs[k], v)
+    assert seen == set(range(n_steps))
+
+
+@pytest.mark.parametrize("world,n_steps", [(2, 3), (2, 4)])
+def test_ring_pipeline_hands_a_moving_beam_on(oracle, world, n_steps):
+    """hipace.dt != 0: every step's field checksums equal those of one process stepping the same deck (bit for bit:
+    the blocks are moved, not recomputed), with more steps than ranks (closed ring)."""
+    deck = _moving_deck()
+    ref = oracle.Engine(deck)
+    want = {}
+    for s in range(n_steps):
+        ref.begin_step()
+        for k in range(deck["nz"] - 1, -1, -1):
+            ref.solve_slice(k)
+        want[s] = ref.checksums()
+    assert want[n_steps - 1]["jz_beam"] != want[0]["jz_beam"]          # the beam does evolve
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_steps, out, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seen = set()
+    for rank, solved, sums in results:
+        assert solved == deck["nz"] * len(range(rank, n_steps, world))
+        for step, cs in sums.items():
+            seen.add(step)
+            for k, v in want[step].items():
+                assert cs[k] == v, (rank, step, k, cs[k], v)
     assert seen == set(range(n_steps))
