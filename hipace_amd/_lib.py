@@ -95,6 +95,10 @@ _SIGS = {
     "hps_engine_sorts": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
     "hps_engine_assume_initial_beam_support": (C.c_int, [C.c_void_p]),
     "hps_engine_beam_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hps_engine_beam_capacity": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
+    "hps_engine_set_beam_import": (C.c_int, [C.c_void_p, C.c_int]),
+    "hps_engine_export_beam_slice": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "hps_engine_import_beam_slice": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "hps_engine_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_phase_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hps_engine_beam_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.c_void_p]),

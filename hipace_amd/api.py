@@ -257,6 +257,26 @@ class SliceEngine:
     def set_tiling(self, tile_size=16, sort_period=128):
         check(_lib.lib().hps_engine_set_tiling(self._h, tile_size, sort_period))
 
+    # ---- ring hand-off of a moving beam (hipace.dt != 0) ------------------------------------------
+    @property
+    def moving(self):
+        return float(self.deck.get("dt", 0.0)) != 0.0
+
+    def beam_capacity(self):
+        n = C.c_long()
+        check(_lib.lib().hps_engine_beam_capacity(self._h, C.byref(n)))
+        return n.value
+
+    def set_beam_import(self, on):
+        check(_lib.lib().hps_engine_set_beam_import(self._h, int(on)))
+
+    def export_beam_slice(self, islice, msg):
+        """msg: float64 device tensor of 1 + 7*beam_capacity(); filled asynchronously on the engine's stream."""
+        check(_lib.lib().hps_engine_export_beam_slice(self._h, islice, C.c_void_p(msg.data_ptr())))
+
+    def import_beam_slice(self, islice, msg):
+        check(_lib.lib().hps_engine_import_beam_slice(self._h, islice, C.c_void_p(msg.data_ptr())))
+
     def beam_state(self):
         """hipace.dt != 0: (boundaries int64 [nz+1], soa float64 [7, nbeam]) of the moving beam; slice p from the head
         is soa[:, boundaries[p]:boundaries[p+1]] (rows x y z ux uy uz w)."""

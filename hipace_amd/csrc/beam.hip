@@ -146,6 +146,65 @@ void k_beam_partition (BeamSoA b, BeamSoA scr, long* B, int* nfront, int p, doub
     if (t == 0) { B[p + 1] = first + count - nslip; nfront[p + 1] = nslip; }
 }
 
+// ---- ring hand-off (MultiBuffer::put_data / get_data, utils/MultiBuffer.cpp:444-609) ----------------------------
+// message = [count | x[cap] y[cap] z[cap] ux[cap] uy[cap] uz[cap] w[cap]]; everything stays on the device
+__global__ __launch_bounds__(256)
+void k_beam_export (BeamSoA b, const long* __restrict__ B, int p, double* __restrict__ msg, long cap, int* overflow)
+{
+    const long first = B[p], count = B[p + 1] - first;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { msg[0] = (double)min(count, cap); if (count > cap) atomicAdd(overflow, 1); }
+    const double* a[7] = {b.x, b.y, b.z, b.ux, b.uy, b.uz, b.w};
+    for (long q = (long)blockIdx.x*blockDim.x + threadIdx.x; q < min(count, cap); q += (long)gridDim.x*blockDim.x)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) msg[1 + k*cap + q] = a[k][first + q];
+}
+
+// block p of the coming step: placed behind the blocks imported so far (imp[p] = where it starts); every later
+// boundary moves with it, so the slices not imported yet are empty ranges
+__global__ __launch_bounds__(256)
+void k_beam_import (BeamSoA b, long* B, long* imp, int p, int nz, const double* __restrict__ msg, long cap, long capacity, int* overflow)
+{
+    const long start = imp[p];
+    long count = (long)msg[0];
+    if (count > cap) count = cap;
+    if (start + count > capacity) { count = capacity - start; if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(overflow, 1); }
+    double* a[7] = {b.x, b.y, b.z, b.ux, b.uy, b.uz, b.w};
+    for (long q = (long)blockIdx.x*blockDim.x + threadIdx.x; q < count; q += (long)gridDim.x*blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) a[k][start + q] = msg[1 + k*cap + q];
+        b.nsub[start + q] = 0;
+    }
+}
+__global__ void k_beam_import_bounds (long* B, long* imp, int p, int nz, const double* __restrict__ msg, long cap, long capacity)
+{
+    const long start = imp[p];
+    long count = (long)msg[0];
+    if (count > cap) count = cap;
+    if (start + count > capacity) count = capacity - start;
+    if (threadIdx.x == 0) imp[p + 1] = start + count;
+    for (int q = p + 1 + threadIdx.x; q <= nz; q += blockDim.x) B[q] = start + count;
+}
+
+int beam_export_slice (Engine& E, int islice, double* msg_dev, long cap)
+{
+    const int p = E.d.nz - 1 - islice;
+    hipLaunchKernelGGL(k_beam_export, dim3((unsigned)std::max<long>(1, std::min<long>(ceil_div(cap, 256), 256))), dim3(256), 0, E.st,
+                       E.bm, E.d_B, p, msg_dev, cap, E.d_beam_overflow);
+    HPS_HIP_CHECK(hipGetLastError());
+    return HPS_OK;
+}
+
+int beam_import_slice (Engine& E, int islice, const double* msg_dev, long cap)
+{
+    const int p = E.d.nz - 1 - islice;
+    const long capacity = std::max(E.nbeam, 1L);
+    hipLaunchKernelGGL(k_beam_import, dim3((unsigned)std::max<long>(1, std::min<long>(ceil_div(cap, 256), 256))), dim3(256), 0, E.st,
+                       E.bm, E.d_B, E.d_Bimp, p, E.d.nz, msg_dev, cap, capacity, E.d_beam_overflow);
+    hipLaunchKernelGGL(k_beam_import_bounds, dim3(1), dim3(256), 0, E.st, E.d_B, E.d_Bimp, p, E.d.nz, msg_dev, cap, capacity);
+    HPS_HIP_CHECK(hipGetLastError());
+    return HPS_OK;
+}
+
 static BeamPushConsts push_consts (const Engine& E, int islice)
 {
     BeamPushConsts k{};

@@ -41,8 +41,12 @@ struct Engine {
     bool moving = false; int steps_begun = 0;
     BeamSoA bm{}, bm_scr{}; double* bm_store = nullptr; int* bm_nsub = nullptr; int* bm_nsub_scr = nullptr;
     long* d_B = nullptr; int* d_nfront = nullptr; std::vector<long> h_B;      // h_B: boundaries as of begin_step
+    // ring hand-off: import mode (the slices of the coming step arrive as messages), start offsets of the imported
+    // blocks, per-message capacity, overflow counter
+    bool beam_import = false; long* d_Bimp = nullptr; long beam_cap = 0; int* d_beam_overflow = nullptr;
     long beam_bound (int p) const {      // upper bound of slice p's size during this step: own + what may slip in
         if (p < 0 || p >= d.nz) return 0;
+        if (beam_import) return 2*beam_cap;
         return (h_B[p + 1] - h_B[p]) + (p > 0 ? h_B[p] - h_B[p - 1] : 0);
     }
     // support of the beam currents in padded-array cells (deposit footprint + the centred differences taken of
@@ -68,6 +72,8 @@ struct Engine {
 
 int beam_deposit_moving (Engine& E, int p, int cjx, int cjy, int cjz);      // beam.hip
 int beam_push_moving (Engine& E, int islice);
+int beam_export_slice (Engine& E, int islice, double* msg_dev, long cap);
+int beam_import_slice (Engine& E, int islice, const double* msg_dev, long cap);
 
 } // namespace hps
 #endif

@@ -251,7 +251,8 @@ Engine::~Engine ()
     delete tiling;
     (void)hipFree(pl_real_alt); (void)hipFree(pl_alt.idcpu); (void)hipFree(pl_alt.ion_lev); 
     (void)hipFree(staging); (void)hipFree(beam_data); (void)hipFree(beam_init);
-    (void)hipFree(bm_store); (void)hipFree(bm_nsub); (void)hipFree(bm_nsub_scr); (void)hipFree(d_B); (void)hipFree(d_nfront); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
+    (void)hipFree(bm_store); (void)hipFree(bm_nsub); (void)hipFree(bm_nsub_scr); (void)hipFree(d_B); (void)hipFree(d_nfront);
+    (void)hipFree(d_Bimp); (void)hipFree(d_beam_overflow); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
     for (auto e : ev) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
 }
@@ -344,6 +345,13 @@ int Engine::init_beam ()
         HPS_HIP_CHECK(hipMemcpy(d_B, h_B.data(), (size_t)(d.nz + 1)*sizeof(long), hipMemcpyHostToDevice));
         HPS_HIP_CHECK(hipMalloc(&d_nfront, (size_t)(d.nz + 2)*sizeof(int)));
         HPS_HIP_CHECK(hipMemset(d_nfront, 0, (size_t)(d.nz + 2)*sizeof(int)));
+        HPS_HIP_CHECK(hipMalloc(&d_Bimp, (size_t)(d.nz + 1)*sizeof(long)));
+        HPS_HIP_CHECK(hipMemset(d_Bimp, 0, (size_t)(d.nz + 1)*sizeof(long)));
+        HPS_HIP_CHECK(hipMalloc(&d_beam_overflow, sizeof(int)));
+        HPS_HIP_CHECK(hipMemset(d_beam_overflow, 0, sizeof(int)));
+        long mx = 0;
+        for (int p = 0; p < d.nz; ++p) mx = std::max(mx, beam_off[p + 1] - beam_off[p]);
+        beam_cap = std::max(2*mx, 1L);                 // particles a slice may hold in a hand-off message
         beam_box = beam_box_init = full_box;          // a moving beam may go anywhere
     }
     return HPS_OK;
@@ -430,7 +438,13 @@ int Engine::resort ()
 int Engine::begin_step ()
 {
     if (int e = setup_tiling()) return e;
-    if (moving) {
+    if (moving && beam_import) {
+        // the slices of this step arrive through hps_engine_import_beam_slice: every range empty, imports start at 0
+        HPS_HIP_CHECK(hipMemsetAsync(d_B, 0, (size_t)(d.nz + 1)*sizeof(long), st));
+        HPS_HIP_CHECK(hipMemsetAsync(d_Bimp, 0, (size_t)(d.nz + 1)*sizeof(long), st));
+        HPS_HIP_CHECK(hipMemsetAsync(d_nfront, 0, (size_t)(d.nz + 2)*sizeof(int), st));
+        ++steps_begun;
+    } else if (moving) {
         if (steps_begun > 0) {
             // the hand-off between steps does not carry the sub-cycle counters (BeamParticleContainer.H:35-37);
             // whatever sits on a slice now is regular (MultiBuffer.cpp:809).  Absorbed particles keep nsub < 0.
@@ -667,11 +681,40 @@ extern "C" int hps_engine_set_beam_storage (void* h, double* storage_dev)
     E->beam_box = storage_dev ? E->full_box : E->beam_box_init;
     return HPS_OK;
 }
+extern "C" int hps_engine_beam_capacity (void* h, long* cap)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E->moving, "hps_engine_beam_capacity: the engine's beam is static (hipace.dt = 0)");
+    *cap = E->beam_cap;
+    return HPS_OK;
+}
+extern "C" int hps_engine_set_beam_import (void* h, int on)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E->moving, "hps_engine_set_beam_import: the engine's beam is static (hipace.dt = 0)");
+    E->beam_import = (on != 0);
+    return HPS_OK;
+}
+extern "C" int hps_engine_export_beam_slice (void* h, int islice, double* msg_dev)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E->moving && msg_dev && islice >= 0 && islice < E->d.nz, "hps_engine_export_beam_slice: bad argument");
+    return beam_export_slice(*E, islice, msg_dev, E->beam_cap);
+}
+extern "C" int hps_engine_import_beam_slice (void* h, int islice, const double* msg_dev)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E->moving && E->beam_import && msg_dev && islice >= 0 && islice < E->d.nz, "hps_engine_import_beam_slice: bad argument (import mode off?)");
+    return beam_import_slice(*E, islice, msg_dev, E->beam_cap);
+}
 extern "C" int hps_engine_beam_state (void* h, long* boundaries_host, double* soa_host)
 {
     Engine* E = static_cast<Engine*>(h);
     HPS_REQUIRE(E->moving, "hps_engine_beam_state: the engine's beam is static (hipace.dt = 0)");
     HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    {   int ov = 0;
+        HPS_HIP_CHECK(hipMemcpy(&ov, E->d_beam_overflow, sizeof(int), hipMemcpyDeviceToHost));
+        HPS_REQUIRE(ov == 0, "moving beam: a slice outgrew the hand-off capacity (twice the fullest injected slice)"); }
     if (boundaries_host) HPS_HIP_CHECK(hipMemcpy(boundaries_host, E->d_B, (size_t)(E->d.nz + 1)*sizeof(long), hipMemcpyDeviceToHost));
     if (soa_host && E->nbeam > 0)
         for (int k = 0; k < 7; ++k)

@@ -199,8 +199,6 @@ def _run_pipeline_moving(engine, rank, world, n_steps, device, on_step_end):
                 engine.import_beam_slice(k, rpool[m % 2][nz - 1 - k])
                 have.add((m, k))
         engine.solve_slice(islice)
-        engine.sync()
-        solved += 1
         if step + 1 < n_steps:
             if world == 1:
                 engine.export_beam_slice(islice, rpool[(m + 1) % 2][nz - 1 - islice])      # in-process hand-off
@@ -208,6 +206,8 @@ def _run_pipeline_moving(engine, rank, world, n_steps, device, on_step_end):
                 slot = spool[tick % len(spool)]
                 engine.export_beam_slice(islice, slot)
                 exported[tick] = slot
+        engine.sync()                                         # the message is complete before it is sent
+        solved += 1
         while len(pending_send) > 4:
             pending_send.pop(0).wait()
         if islice == 0:

@@ -207,6 +207,15 @@ int hps_engine_initial_beam (void* handle, double* dst_dev);
  * particles slip (hipace_amd/csrc/beam.hip).  Copies the boundaries [nz+1] and, if soa_host != NULL, the seven
  * arrays x y z ux uy uz w ([7][nbeam], nbeam = hps_engine_beam_info) to the host; synchronises the stream. */
 int hps_engine_beam_state (void* handle, long* boundaries_host, double* soa_host);
+/* Ring hand-off of the moving beam (MultiBuffer::put_data / get_data, utils/MultiBuffer.cpp:444-609).  A message is
+ * 1 + 7*cap doubles on the device: [count | x[cap] y[cap] z[cap] ux[cap] uy[cap] uz[cap] w[cap]], cap =
+ * hps_engine_beam_capacity (twice the fullest injected slice).  export: what sits on slice `islice` after its push;
+ * import (import mode on, set before hps_engine_begin_step; slices in head-first order, slice k-1 before slice k is
+ * solved): the regular particles of that slice for the step that has begun.  All asynchronous on the engine's stream. */
+int hps_engine_beam_capacity (void* handle, long* cap_host);
+int hps_engine_set_beam_import (void* handle, int on);
+int hps_engine_export_beam_slice (void* handle, int islice, double* msg_dev);
+int hps_engine_import_beam_slice (void* handle, int islice, const double* msg_dev);
 /* The slab kernels skip the beam-current planes outside the beam's transverse support.  After
  * hps_engine_set_beam_storage the support is the whole plane (caller-owned particles may sit anywhere); a driver
  * that knows its blocks are the injected beam handed along the ring (hipace.dt = 0: the beam does not move) calls

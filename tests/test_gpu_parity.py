@@ -434,3 +434,30 @@ def test_beam_slipping_matches_oracle(api, oracle):
     cs, rs = eng.checksums(), ref.checksums()
     for k in ("jz_beam", "Bx", "By", "Ez", "Sx", "Sy"):
         assert abs(cs[k] - rs[k]) <= 1e-9*max(abs(rs[k]), 1e-300), (k, cs[k], rs[k])
+
+
+@pytest.mark.gpu
+def test_moving_beam_through_the_ring_hand_off(api, oracle):
+    """world = 1 pipeline (in-process hand-off through export / import messages on the device) of a beam that slips
+    every step: per-step checksums equal those of the oracle stepping the same deck."""
+    import torch
+    from hipace_amd.pipeline import run_pipeline
+    deck = decks.beam_evolution()
+    deck.update(nz=12, lo=(-2.0, -2.0, -2.4), hi=(2.0, 2.0, 2.4), beam_zmin=-1.0, beam_zmax=1.6, beam_umean=(0.0, 0.0, 1.2),
+                beam_density=1.0e-3, n_steps=4, dt=0.9, beam_n_subcycles=4, ext_E_slope=(0.3, 0.2))
+    ref = oracle.Engine(deck)
+    want = {}
+    for s in range(deck["n_steps"]):
+        ref.begin_step()
+        for k in range(deck["nz"] - 1, -1, -1):
+            ref.solve_slice(k)
+        want[s] = ref.checksums()
+    eng = api.SliceEngine(deck, tile_size=0)
+    eng.set_diagnostics(True)
+    got = {}
+    solved = run_pipeline(eng, 0, 1, deck["n_steps"], torch.device("cuda", 0), on_step_end=lambda s: got.__setitem__(s, eng.checksums()))
+    assert solved == deck["n_steps"]*deck["nz"]
+    for s in want:
+        for k in ("jz_beam", "jx_beam", "Bx", "By", "Ez", "Sx", "Sy"):
+            assert abs(got[s][k] - want[s][k]) <= 1e-9*max(abs(want[s][k]), 1e-300), (s, k, got[s][k], want[s][k])
+    eng.beam_state()            # raises if a slice outgrew the message capacity
