@@ -40,7 +40,9 @@ class Deck(C.Structure):
                 ("beam_pos_std", C.c_double * 3), ("beam_ppc", C.c_int * 3), ("beam_charge", C.c_double),
                 ("bc", C.c_int), ("mg_tol_rel", C.c_double), ("mg_tol_abs", C.c_double),
                 ("deposit_rho", C.c_int), ("n_steps", C.c_int),
-                ("dt", C.c_double), ("beam_n_subcycles", C.c_int), ("beam_mass", C.c_double), ("ext_E_slope", C.c_double * 2)]
+                ("dt", C.c_double), ("beam_n_subcycles", C.c_int), ("beam_mass", C.c_double), ("ext_E_slope", C.c_double * 2),
+                ("bxby_solver", C.c_int), ("predcorr_tol", C.c_double), ("predcorr_max_iter", C.c_int),
+                ("predcorr_mix", C.c_double), ("field_bc", C.c_int)]
 
 
 # engine component names, index = value of the HPS_C_* enum in include/hpslice.h
@@ -48,6 +50,10 @@ COMPS = ["N_jx_beam", "N_jy_beam", "chi", "Sy", "Sx", "ExmBy", "EypBx", "Ez", "B
          "Psi", "jx_beam", "jy_beam", "jz_beam", "jx", "jy", "rhomjz", "P_jx_beam", "P_jy_beam",
          "Ion_rhomjz", "rho"]
 CIDX = {n: i for i, n in enumerate(COMPS)}
+# predictor-corrector layout, index = value of the HPS_PC_* enum
+COMPS_PC = ["N_jx", "N_jy", "ExmBy", "EypBx", "Ez", "Bx", "By", "Bz", "Psi", "jx", "jy", "jz", "rhomjz",
+            "P_Bx", "P_By", "P_jx", "P_jy", "Ion_rhomjz", "It_Bx", "It_By", "PIt_Bx", "PIt_By", "rho"]
+CIDX_PC = {n: i for i, n in enumerate(COMPS_PC)}
 ID_VALID = 1 << 63
 
 _SIGS = {
@@ -89,6 +95,7 @@ _SIGS = {
     "hps_engine_stream": (C.c_void_p, [C.c_void_p]),
     "hps_engine_checksums": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "hps_engine_pc_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_double)]),
     "hps_engine_set_diagnostics": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_set_tiling": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "hps_engine_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),

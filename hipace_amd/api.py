@@ -331,7 +331,14 @@ class SliceEngine:
     def checksums(self):
         out = (C.c_double * self.ncomp)()
         check(_lib.lib().hps_engine_checksums(self._h, out))
-        return {COMPS[i]: out[i] for i in range(self.ncomp)}
+        names = _lib.COMPS_PC if self.deck.get("bxby_solver", 0) else COMPS
+        return {names[i]: out[i] for i in range(self.ncomp)}
+
+    def pc_stats(self):
+        """(predictor-corrector iterations so far, sum over slices of the final relative B-field error)."""
+        its, err = C.c_long(), C.c_double()
+        check(_lib.lib().hps_engine_pc_stats(self._h, C.byref(its), C.byref(err)))
+        return its.value, err.value
 
     def stats(self):
         vc, sl = C.c_long(), C.c_long()

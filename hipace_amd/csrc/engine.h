@@ -60,6 +60,11 @@ struct Engine {
     std::vector<hipEvent_t> ev; size_t ev_used = 0;      // 11 events per profiled slice
     void mark ();
     long total_vcycles = 0, slices_done = 0;
+    // predictor-corrector Bx/By (hipace.bxby_solver = predictor-corrector): d_pc = {sum |B|, sum |B - B_iter|, halo
+    // fallback counter (int), spare}, h_pc its pinned image read back once per iteration
+    bool pc = false; double* d_pc = nullptr; double* h_pc = nullptr; long pc_iterations = 0; double pc_err_sum = 0.0;
+    double pc_tol = 4e-2, pc_mix = 0.05; int pc_max_iter = 30;
+    int solve_slice_pc (int islice);
 
     ~Engine ();
     int create (const hps_deck& deck, int device);

@@ -253,6 +253,7 @@ Engine::~Engine ()
     (void)hipFree(staging); (void)hipFree(beam_data); (void)hipFree(beam_init);
     (void)hipFree(bm_store); (void)hipFree(bm_nsub); (void)hipFree(bm_nsub_scr); (void)hipFree(d_B); (void)hipFree(d_nfront);
     (void)hipFree(d_Bimp); (void)hipFree(d_beam_overflow); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
+    (void)hipFree(d_pc); if (h_pc) (void)hipHostFree(h_pc);
     for (auto e : ev) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
 }
@@ -363,10 +364,15 @@ int Engine::create (const hps_deck& deck, int device)
     HPS_REQUIRE(d.nx >= 4 && d.ny >= 4 && d.nz >= 1, "hps_engine_create: bad grid");
     HPS_REQUIRE(d.order >= 0 && d.order <= 3, "hps_engine_create: depos_order must be 0..3");
     HPS_REQUIRE(d.plasma_radius <= 0.0, "hps_engine_create: finite plasma radius not supported yet");
+    if (d.field_bc != 0) { set_error("hps_engine_create: only boundary.field = Dirichlet is built"); return HPS_ERR_UNSUPPORTED; }
+    pc = (d.bxby_solver != 0);
+    if (d.predcorr_tol > 0.0) pc_tol = d.predcorr_tol;
+    if (d.predcorr_max_iter > 0) pc_max_iter = d.predcorr_max_iter;
+    if (d.predcorr_mix > 0.0) pc_mix = d.predcorr_mix;
     HPS_HIP_CHECK(hipSetDevice(device));
     HPS_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     g = (d.order + 1)/2 + 1;                       // Fields::AllocData (fields/Fields.cpp:63-64)
-    ncomp = d.deposit_rho ? HPS_C_RHO + 1 : HPS_C_RHO;
+    ncomp = pc ? (d.deposit_rho ? HPS_PC_RHO + 1 : HPS_PC_RHO) : (d.deposit_rho ? HPS_C_RHO + 1 : HPS_C_RHO);
     gm.dx = (d.hi[0] - d.lo[0])/d.nx; gm.dy = (d.hi[1] - d.lo[1])/d.ny; gm.dz = (d.hi[2] - d.lo[2])/d.nz;
     gm.xoff = 0.5*(d.lo[0] + d.hi[0] - gm.dx*(d.nx - 1));
     gm.yoff = 0.5*(d.lo[1] + d.hi[1] - gm.dy*(d.ny - 1));
@@ -391,7 +397,8 @@ int Engine::create (const hps_deck& deck, int device)
         // explicit solver: every push commits its state (temp_slice = false), so x_prev == x and y_prev == y at
         // all times (PlasmaParticleAdvance.cpp:176-188): alias them -- two arrays less to write per push and to
         // move per re-sort.  The C ABI keeps 11 pointers; the kernels skip the second store when two coincide.
-        pl.x_prev = pl.x; pl.y_prev = pl.y;
+        // (the predictor-corrector pushes to temporary slices from x_prev: separate arrays there)
+        if (!pc) { pl.x_prev = pl.x; pl.y_prev = pl.y; }
         HPS_HIP_CHECK(hipMalloc(&pl.idcpu, (size_t)np*sizeof(uint64_t)));
         HPS_HIP_CHECK(hipMalloc(&pl.ion_lev, (size_t)np*sizeof(int32_t)));
     }
@@ -406,6 +413,14 @@ int Engine::create (const hps_deck& deck, int device)
     {   int* dw = nullptr; const int* hw = nullptr;
         mg_rider(mg, &dw, &hw);
         d_nfallback = dw; h_nfallback = hw; }
+    if (pc) {
+        // no multigrid solves in this mode: the counter travels with the per-iteration read-back of the B error
+        HPS_HIP_CHECK(hipMalloc(&d_pc, 4*sizeof(double)));
+        HPS_HIP_CHECK(hipMemset(d_pc, 0, 4*sizeof(double)));
+        HPS_HIP_CHECK(hipHostMalloc(&h_pc, 4*sizeof(double)));
+        std::memset(h_pc, 0, 4*sizeof(double));
+        d_nfallback = reinterpret_cast<int*>(d_pc + 2); h_nfallback = reinterpret_cast<const int*>(h_pc + 2);
+    }
     return init_beam();
 }
 
@@ -419,7 +434,7 @@ int Engine::setup_tiling ()
     double** arr[11] = {&pl_alt.x, &pl_alt.y, &pl_alt.w, &pl_alt.ux, &pl_alt.uy, &pl_alt.psi, &pl_alt.x_prev, &pl_alt.y_prev,
                         &pl_alt.ux_half, &pl_alt.uy_half, &pl_alt.psi_half};
     for (int k = 0; k < 11; ++k) *arr[k] = pl_real_alt + (size_t)k*np;
-    pl_alt.x_prev = pl_alt.x; pl_alt.y_prev = pl_alt.y;
+    if (!pc) { pl_alt.x_prev = pl_alt.x; pl_alt.y_prev = pl_alt.y; }
     HPS_HIP_CHECK(hipMalloc(&pl_alt.idcpu, (size_t)np*sizeof(uint64_t)));
     HPS_HIP_CHECK(hipMalloc(&pl_alt.ion_lev, (size_t)np*sizeof(int32_t)));
     return HPS_OK;
@@ -463,7 +478,7 @@ int Engine::begin_step ()
         hipLaunchKernelGGL(k_init_plasma, dim3(ceil_div(np, 256)), dim3(256), 0, st, pl, d.nx, d.ny,
                            d.plasma_ppc[0], d.plasma_ppc[1], d.lo[0], d.lo[1], gm.dx, gm.dy, d.plasma_density*(1.0/nppc));
         // neutralising ion background, deposited once per step with charge -q (MultiPlasma.cpp:106-118)
-        const int comp[6] = {-1, -1, -1, -1, -1, HPS_C_ION_RHOMJZ};
+        const int comp[6] = {-1, -1, -1, -1, -1, pc ? (int)HPS_PC_ION_RHOMJZ : (int)HPS_C_ION_RHOMJZ};
         if (tiling) {
             if (int e = resort()) return e;
             if (int e = deposit_current_tiled(slab, pl, gm, comp, -d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st)) return e;
@@ -504,8 +519,175 @@ void Engine::mark ()
     (void)hipEventRecord(ev[ev_used++], st);
 }
 
+// ---- predictor-corrector Bx/By (Hipace::PredictorCorrectorLoopToSolveBxBy, Hipace.cpp:935-1031) ----------------
+
+// Fields::ComputeRelBFieldError (fields/Fields.cpp:1233-1286): out[0] += sum |B|, out[1] += sum |B - B_iter| over
+// the valid cells
+__global__ __launch_bounds__(256)
+void k_rel_b_error (SlabView f, int cB, int cBit, double* out)
+{
+    double sb = 0.0, sd = 0.0;
+    const long cells = (long)f.nx*f.ny;
+    for (long c = (long)blockIdx.x*blockDim.x + threadIdx.x; c < cells; c += (long)gridDim.x*blockDim.x) {
+        const int j = (int)(c / f.nx), i = (int)(c - (long)j*f.nx);
+        const long o = f.off(i, j);
+        const double bx = f.p[cB*f.ns + o], by = f.p[(cB + 1)*f.ns + o];
+        const double ex = bx - f.p[cBit*f.ns + o], ey = by - f.p[(cBit + 1)*f.ns + o];
+        sb += sqrt(bx*bx + by*by);
+        sd += sqrt(ex*ex + ey*ey);
+    }
+    for (int o = 32; o > 0; o >>= 1) { sb += __shfl_xor(sb, o); sd += __shfl_xor(sd, o); }
+    __shared__ double part[8];
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = sb; part[4 + (threadIdx.x >> 6)] = sd; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomic_add_f64(out, part[0] + part[1] + part[2] + part[3]);
+        atomic_add_f64(out + 1, part[4] + part[5] + part[6] + part[7]);
+    }
+}
+
+// InitialBfieldGuess (fields/Fields.cpp:1151-1173) + the set-up of the loop (Hipace.cpp:950-954): This = (1+m) Previous
+// - m PCPrevIter with m = exp(-0.5 (err/(2.5 tol))^2), err = sums[1]/sums[0] of (Previous, PCPrevIter);
+// PCIter = 0; PCPrevIter = This.  Whole planes incl. guards, both components.
+__global__ __launch_bounds__(256)
+void k_pc_guess (double* p, long ns, long plane, const double* sums, double tol)
+{
+    const long s = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (s >= plane) return;
+    const double err = sums[0] > 0.0 ? sums[1]/sums[0] : 0.0;
+    const double q = err/(2.5*tol);
+    const double m = exp(-0.5*(q*q));
+    for (int c = 0; c < 2; ++c) {
+        const double b = (1.0 + m)*p[(HPS_PC_P_BX + c)*ns + s] + (-m)*p[(HPS_PC_PIT_BX + c)*ns + s];
+        p[(HPS_PC_BX + c)*ns + s] = b;
+        p[(HPS_PC_IT_BX + c)*ns + s] = 0.0;
+        p[(HPS_PC_PIT_BX + c)*ns + s] = b;
+    }
+}
+
+// sources of Fields::SolvePoissonBxBy (fields/Fields.cpp:1043-1064): st[0] = mu0 (-d_y jz + d_z jy),
+// st[1] = mu0 (d_x jz - d_z jx), d_z = (Previous - Next)/(2 dz)
+__global__ __launch_bounds__(256)
+void k_rhs_bxby (SlabView f, double mu0, double hdx_inv, double hdy_inv, double hdz_inv, double* staging, long plane)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= f.nx) return;
+    const long o = f.off(i, j), so = (long)j*f.nx + i;
+    const double* Z = f.p + HPS_PC_JZ*f.ns + o;
+    staging[so] = (-mu0)*((Z[f.js] - Z[-f.js])*hdy_inv) + mu0*((f.p[HPS_PC_P_JY*f.ns + o] - f.p[HPS_PC_N_JY*f.ns + o])*hdz_inv);
+    staging[plane + so] = mu0*((Z[1] - Z[-1])*hdx_inv) + (-mu0)*((f.p[HPS_PC_P_JX*f.ns + o] - f.p[HPS_PC_N_JX*f.ns + o])*hdz_inv);
+}
+
+// MixAndShiftBfields (fields/Fields.cpp:1175-1231) + the reset of the temporary currents (Hipace.cpp:1000-1003)
+__global__ __launch_bounds__(256)
+void k_pc_mix (double* p, long ns, long plane, double w_it, double w_prev, double mix)
+{
+    const long s = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (s >= plane) return;
+    for (int c = 0; c < 2; ++c) {
+        const double it = p[(HPS_PC_IT_BX + c)*ns + s];
+        const double mixed = w_it*it + w_prev*p[(HPS_PC_PIT_BX + c)*ns + s];
+        p[(HPS_PC_BX + c)*ns + s] = (1.0 - mix)*p[(HPS_PC_BX + c)*ns + s] + mix*mixed;
+        p[(HPS_PC_PIT_BX + c)*ns + s] = it;
+    }
+    p[HPS_PC_N_JX*ns + s] = 0.0; p[HPS_PC_N_JY*ns + s] = 0.0;
+}
+
+// SolveOneSlice with hipace.bxby_solver = predictor-corrector (Hipace.cpp:556-728; the explicit branch is
+// Engine::solve_slice below).  Event marks keep the 10 intervals of the explicit schedule: the loop is booked under
+// the Bx/By-solve interval.
+int Engine::solve_slice_pc (int islice)
+{
+    SlabView f(slab);
+    const long plane = slab.nstride;
+    const dim3 b256(256);
+    const dim3 gplane(ceil_div(plane, 256));
+    const long nval = (long)d.nx*d.ny;
+    int e;
+
+    mark();   // b0
+    // InitializeSlices (fields/Fields.cpp:565-570); ExmBy, EypBx are rewritten by k_grad_psi up to the outermost
+    // guard ring, which stays zero from begin_step
+    {   CompList z{0, {}}, zb{0, {}};
+        for (int c : {HPS_PC_JX, HPS_PC_JY, HPS_PC_JZ, HPS_PC_RHOMJZ}) z.c[z.n++] = c;
+        if (d.deposit_rho) z.c[z.n++] = HPS_PC_RHO;
+        hipLaunchKernelGGL(k_zero_comps, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, z, zb, CellBox{0, -1, 0, -1}); }
+    mark();   // b1
+    if (tiling && (since_sort >= sort_period || (since_sort >= 2 && *h_nfallback - fb_at_sort > np/256))) { if ((e = resort())) return e; }
+    ++since_sort;
+    mark();   // b1b
+    // plasma: jx jy jz [rho] rhomjz (Hipace.cpp:616-618); beams deposit into the same jx jy jz (:620-623)
+    {   const int comp[6] = {HPS_PC_JX, HPS_PC_JY, HPS_PC_JZ, d.deposit_rho ? HPS_PC_RHO : -1, -1, HPS_PC_RHOMJZ};
+        if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st))) return e; }
+        else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
+    mark();   // b2
+    if ((e = deposit_beam_slice(islice, HPS_PC_JX, HPS_PC_JY, HPS_PC_JZ))) return e;
+    {   const double fa = 1.0/(gm.ep0*gm.c);
+        hipLaunchKernelGGL(k_rhs_all, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_PC_RHOMJZ,
+                           HPS_PC_ION_RHOMJZ, d.deposit_rho ? HPS_PC_RHO : -1, HPS_PC_JX, HPS_PC_JY, 1.0/gm.ep0,
+                           fa*0.5*(1.0/gm.dx), fa*0.5*(1.0/gm.dy), gm.mu0*0.5*(1.0/gm.dy), -gm.mu0*0.5*(1.0/gm.dx),
+                           staging, nval);
+        const int comps[3] = {HPS_PC_PSI, HPS_PC_EZ, HPS_PC_BZ};
+        if ((e = hps_poisson_solve_batch(ps, 3, staging, slab, comps, st))) return e; }
+    hipLaunchKernelGGL(k_grad_psi, dim3(ceil_div(d.nx + 2*(g - 1), 256), d.ny + 2*(g - 1)), b256, 0, st, f, HPS_PC_PSI,
+                       HPS_PC_EXMBY, HPS_PC_EYPBX, 0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy));
+    mark();   // b3
+    mark();   // b4
+    mark();   // b5
+    // the loop (Hipace.cpp:935-1031)
+    HPS_HIP_CHECK(hipMemsetAsync(d_pc, 0, 2*sizeof(double), st));
+    hipLaunchKernelGGL(k_rel_b_error, dim3(128), b256, 0, st, f, HPS_PC_P_BX, HPS_PC_PIT_BX, d_pc);
+    hipLaunchKernelGGL(k_pc_guess, gplane, b256, 0, st, slab.p, slab.nstride, plane, d_pc, pc_tol);
+    double err = 1.0, err_prev = 1.0;
+    int it = 0;
+    const int comp_push[5] = {HPS_PC_PSI, HPS_PC_EZ, HPS_PC_BX, HPS_PC_BY, HPS_PC_BZ};
+    while (err > pc_tol && it < pc_max_iter) {
+        ++it; ++pc_iterations;
+        // plasma to the temporary next slice, its jx jy (+ the beam's) there
+        if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 1, d.n_subcycles, 0, tiling, d_nfallback, st))) return e; }
+        else        { if ((e = hps_advance_plasma(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 1, d.n_subcycles, 0, st))) return e; }
+        {   const int comp[6] = {HPS_PC_N_JX, HPS_PC_N_JY, -1, -1, -1, -1};
+            if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st))) return e; }
+            else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
+        if ((e = deposit_beam_slice(islice - 1, HPS_PC_N_JX, HPS_PC_N_JY, -1))) return e;
+        hipLaunchKernelGGL(k_rhs_bxby, dim3(ceil_div(d.nx, 256), d.ny), b256, 0, st, f, gm.mu0, 0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy),
+                           0.5*(1.0/gm.dz), staging, nval);
+        {   const int comps[2] = {HPS_PC_IT_BX, HPS_PC_IT_BY};
+            if ((e = hps_poisson_solve_batch(ps, 2, staging, slab, comps, st))) return e; }
+        HPS_HIP_CHECK(hipMemsetAsync(d_pc, 0, 2*sizeof(double), st));
+        hipLaunchKernelGGL(k_rel_b_error, dim3(128), b256, 0, st, f, HPS_PC_BX, HPS_PC_IT_BX, d_pc);
+        HPS_HIP_CHECK(hipMemcpyAsync(h_pc, d_pc, 4*sizeof(double), hipMemcpyDeviceToHost, st));
+        HPS_HIP_CHECK(hipStreamSynchronize(st));
+        err = h_pc[0] > 0.0 ? h_pc[1]/h_pc[0] : 0.0;
+        if (it == 1) err_prev = err;
+        double w_it = 0.5, w_prev = 0.5;
+        if (err != 0.0 || err_prev != 0.0) { w_it = err_prev/(err + err_prev); w_prev = err/(err + err_prev); }
+        hipLaunchKernelGGL(k_pc_mix, gplane, b256, 0, st, slab.p, slab.nstride, plane, w_it, w_prev, pc_mix);
+        err_prev = err;
+    }
+    pc_err_sum += err;
+    mark();   // b6
+    if (diagnostics)
+        hipLaunchKernelGGL(k_checksum, dim3(64, ncomp), b256, 0, st, f, ncomp, d_checksum);
+    mark();   // b7
+    if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st))) return e; }
+    else        { if ((e = hps_advance_plasma(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; }
+    if (moving && nbeam > 0) { if ((e = beam_push_moving(*this, islice))) return e; }
+    mark();   // b8
+    // ShiftSlices (fields/Fields.cpp:600-603): PCPrevIter <- Previous <- This for Bx By, Previous <- This for jx jy
+    {   CompList dst{6, {HPS_PC_PIT_BX, HPS_PC_PIT_BY, HPS_PC_P_BX, HPS_PC_P_BY, HPS_PC_P_JX, HPS_PC_P_JY}};
+        CompList src{6, {HPS_PC_P_BX, HPS_PC_P_BY, HPS_PC_BX, HPS_PC_BY, HPS_PC_JX, HPS_PC_JY}};
+        hipLaunchKernelGGL(k_copy_comps, gplane, b256, 0, st, slab.p, slab.nstride, plane, dst, src); }
+    mark();   // b9
+    HPS_HIP_CHECK(hipGetLastError());
+    ++slices_done;
+    return HPS_OK;
+}
+
 int Engine::solve_slice (int islice)
 {
+    if (pc) return solve_slice_pc(islice);
     SlabView f(slab);
     const long plane = slab.nstride;
     const dim3 b256(256);
@@ -638,6 +820,13 @@ extern "C" int hps_engine_stats (void* h, long* vc, long* sl)
     Engine* E = static_cast<Engine*>(h);
     if (vc) *vc = E->total_vcycles;
     if (sl) *sl = E->slices_done;
+    return HPS_OK;
+}
+extern "C" int hps_engine_pc_stats (void* h, long* its, double* err_sum)
+{
+    Engine* E = static_cast<Engine*>(h);
+    if (its) *its = E->pc_iterations;
+    if (err_sum) *err_sum = E->pc_err_sum;
     return HPS_OK;
 }
 extern "C" int hps_engine_set_profiling (void* h, int on)

@@ -9,6 +9,8 @@ per-slice hot path.  The named decks restate
                          (run as tests/blowout_wake_explicit.2Rank.sh:32-35: max_step=1, dt=0)
 * ``beam_in_vacuum``  -- /root/reference/examples/beam_in_vacuum/inputs_normalized
                          (run as tests/beam_in_vacuum.normalized.Serial.sh:30-34: order 0)
+* ``beam_in_vacuum_open_boundary`` -- the same deck as run by tests/beam_in_vacuum_open_boundary.normalized.1Rank.sh
+                         (predictor-corrector Bx/By; oracle only)
 * ``synthetic(n, nz)``-- the BASELINE.md section 3 benchmark deck (blowout deck scaled to n x n,
                          ppc 2x2) used by bench.py.
 """
@@ -36,6 +38,11 @@ _DEFAULT = dict(
     beam_n_subcycles=10,     # beam.n_subcycles (BeamParticleContainer.H:222)
     beam_mass=1.0,
     ext_E_slope=(0.0, 0.0),  # beams.external_E(x,y,z,t) = s0*x s1*y 0.
+    bxby_solver=0,           # hipace.bxby_solver: 0 explicit (Hipace.H:244), 1 predictor-corrector
+    predcorr_tol=4.0e-2,     # hipace.predcorr_B_error_tolerance (Hipace.H:210)
+    predcorr_max_iter=30,    # hipace.predcorr_max_iterations (Hipace.H:213)
+    predcorr_mix=0.05,       # hipace.predcorr_B_mixing_factor (Hipace.H:222)
+    field_bc=0,              # boundary.field: 0 Dirichlet; 1 Open exists in the CPU oracle only (the engine refuses it)
 )
 
 
@@ -50,6 +57,15 @@ def linear_wake():
     d.update(nx=32, ny=32, nz=200, lo=(-10.0, -10.0, -7.5), hi=(10.0, 10.0, 2.0),
              beam_profile=1, beam_zmin=-1.0, beam_zmax=1.0, beam_radius=3.0, beam_density=0.01,
              deposit_rho=1)
+    return d
+
+
+def linear_wake_gaussian():
+    """linear_wake grid and plasma with a Gaussian driver (smooth in zeta) -- the deck of the predictor-corrector
+    tests; the reference's own such test (tests/ion_motion.SI.1Rank.sh) also drives with a Gaussian beam."""
+    d = linear_wake()
+    d.update(beam_profile=0, beam_pos_std=(1.5, 1.5, 0.7), beam_pos_mean=(0.0, 0.0, 0.0), beam_zmin=-7.4, beam_zmax=1.9,
+             beam_radius=6.0, beam_density=0.05)
     return d
 
 
@@ -79,5 +95,22 @@ def beam_evolution():
     return d
 
 
-NAMED = dict(blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
-             beam_evolution=beam_evolution)
+def beam_in_vacuum_open_boundary():
+    """tests/beam_in_vacuum_open_boundary.normalized.1Rank.sh:31-43 -- the reference's only checksum fixture of the
+    predictor-corrector Bx/By solver: beam_in_vacuum deck, order 0, off-centre beam, boundary.field = Open."""
+    d = beam_in_vacuum()
+    d.update(lo=(-4.0, -4.0, -2.0), hi=(4.0, 4.0, 2.0), beam_pos_mean=(2.0, -1.0, 0.0), bc=2, deposit_rho=1,
+             bxby_solver=1, predcorr_mix=0.95, predcorr_max_iter=5, predcorr_tol=4.0e-2, field_bc=1)
+    return d
+
+
+def predictor_corrector(base, tol=1.0e-4, max_iter=7, mix=0.0635):
+    """`base` with hipace.bxby_solver = predictor-corrector; the defaults are the settings of the reference's own
+    predictor-corrector-vs-explicit test (tests/ion_motion.SI.1Rank.sh:30-34)."""
+    d = copy.deepcopy(base)
+    d.update(bxby_solver=1, predcorr_tol=tol, predcorr_max_iter=max_iter, predcorr_mix=mix)
+    return d
+
+
+NAMED = dict(linear_wake_gaussian=linear_wake_gaussian, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
+             beam_evolution=beam_evolution, beam_in_vacuum_open_boundary=beam_in_vacuum_open_boundary)

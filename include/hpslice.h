@@ -158,6 +158,10 @@ typedef struct {
      * beam.n_subcycles (0 -> 10, BeamParticleContainer.H:222), beam mass (0 -> 1) and a linear focusing field
      * beams.external_E(x,y,z,t) = ext_E_slope[0]*x  ext_E_slope[1]*y  0 (ExternalFields.H:29-56) */
     double dt; int beam_n_subcycles; double beam_mass; double ext_E_slope[2];
+    /* hipace.bxby_solver: 0 explicit (Hipace.H:244), 1 predictor-corrector (Hipace.cpp:935-1031) with
+     * hipace.predcorr_B_error_tolerance (0 -> 4e-2), predcorr_max_iterations (0 -> 30), predcorr_B_mixing_factor
+     * (0 -> 0.05) (Hipace.H:210-222).  field_bc: boundary.field, 0 Dirichlet; anything else is refused. */
+    int bxby_solver; double predcorr_tol; int predcorr_max_iter; double predcorr_mix; int field_bc;
 } hps_deck;
 
 /* slab component indices of the engine (explicit-solver layout of fields/Fields.cpp:70-122) */
@@ -165,6 +169,13 @@ enum { HPS_C_N_JXB = 0, HPS_C_N_JYB, HPS_C_CHI, HPS_C_SY, HPS_C_SX, HPS_C_EXMBY,
        HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ, HPS_C_PSI, HPS_C_JXB, HPS_C_JYB, HPS_C_JZB,
        HPS_C_JX, HPS_C_JY, HPS_C_RHOMJZ, HPS_C_P_JXB, HPS_C_P_JYB, HPS_C_ION_RHOMJZ, HPS_C_RHO,
        HPS_NCOMP_MAX };
+
+/* slab component indices with bxby_solver = 1 (predictor-corrector layout of fields/Fields.cpp:128-164: beams and
+ * plasma share jx jy jz; Previous keeps Bx By jx jy; PCIter / PCPrevIter hold the iterated Bx By) */
+enum { HPS_PC_N_JX = 0, HPS_PC_N_JY, HPS_PC_EXMBY, HPS_PC_EYPBX, HPS_PC_EZ, HPS_PC_BX, HPS_PC_BY, HPS_PC_BZ,
+       HPS_PC_PSI, HPS_PC_JX, HPS_PC_JY, HPS_PC_JZ, HPS_PC_RHOMJZ, HPS_PC_P_BX, HPS_PC_P_BY, HPS_PC_P_JX,
+       HPS_PC_P_JY, HPS_PC_ION_RHOMJZ, HPS_PC_IT_BX, HPS_PC_IT_BY, HPS_PC_PIT_BX, HPS_PC_PIT_BY, HPS_PC_RHO,
+       HPS_PC_NCOMP_MAX };
 
 int hps_engine_create (const hps_deck* deck, int device, void** handle);
 int hps_engine_destroy (void* handle);
@@ -179,6 +190,9 @@ hps_stream hps_engine_stream (void* handle);
 /* sum |Q| per component over valid cells and all slices of the current step (host array[ncomp]) */
 int hps_engine_checksums (void* handle, double* out_host);
 int hps_engine_stats (void* handle, long* total_vcycles, long* slices_done);
+/* predictor-corrector: iterations so far and the sum over slices of the final relative B-field error
+ * (m_predcorr_avg_iterations / m_predcorr_avg_B_error of Hipace.cpp:964,1028 before the division by nz) */
+int hps_engine_pc_stats (void* handle, long* iterations, double* error_sum);
 /* accumulate the per-slice checksums (costs one reduction pass per slice; off by default) */
 int hps_engine_set_diagnostics (void* handle, int on);
 /* particle tiling of the engine: tile_size 0 = per-particle global-atomic kernels, 16 | 32 = LDS

@@ -863,6 +863,11 @@ struct MG {
 enum Comp { N_jxb = 0, N_jyb, chi, Sy, Sx, ExmBy, EypBx, Ez, Bx, By, Bz, Psi,
             jxb, jyb, jzb, jx, jy, rhomjz, P_jxb, P_jyb, Ion_rhomjz, rho /* optional */, NCOMP_MAX };
 
+// Predictor-corrector component order (fields/Fields.cpp:128-164): Next{jx,jy}, This{ExmBy,EypBx,Ez,Bx,By,Bz,Psi,
+// jx,jy,jz,rhomjz}, Previous{Bx,By,jx,jy}, RhomJzIons{rhomjz}, PCIter{Bx,By}, PCPrevIter{Bx,By}; optional rho last
+enum PcComp { pN_jx = 0, pN_jy, pExmBy, pEypBx, pEz, pBx, pBy, pBz, pPsi, pjx, pjy, pjz, prhomjz,
+              pP_Bx, pP_By, pP_jx, pP_jy, pIon_rhomjz, pIt_Bx, pIt_By, pPIt_Bx, pPIt_By, prho /* optional */, PC_NCOMP_MAX };
+
 struct Deck {
     int nx, ny, nz; double lo[3], hi[3]; int order; int deriv_type;
     int plasma_ppc[2]; double plasma_density; double plasma_radius;  // radius<=0 -> infinity
@@ -879,6 +884,12 @@ struct Deck {
     int beam_n_subcycles;        // beam.n_subcycles (BeamParticleContainer.H:222, default 10)
     double beam_mass;
     double ext_E_slope[2];       // beams.external_E = (s0*x, s1*y, 0): the only external field form restated
+    int bxby_solver;             // 0 explicit (Hipace.H:244 default), 1 predictor-corrector
+    double predcorr_tol;         // hipace.predcorr_B_error_tolerance (Hipace.H:210, 4e-2)
+    int predcorr_max_iter;       // hipace.predcorr_max_iterations (Hipace.H:213, 30)
+    double predcorr_mix;         // hipace.predcorr_B_mixing_factor (Hipace.H:222, 0.05)
+    int field_bc;                // boundary.field: 0 Dirichlet, 1 Open (oracle only: pins the predictor-corrector
+                                 // path on beam_in_vacuum_open_boundary.normalized.1Rank.json)
 };
 
 // particles of one beam slice; [0, nreg) were on the slice when the step began ("regular"), the rest slipped in
@@ -900,12 +911,13 @@ struct Engine {
     const double* ext_beam = nullptr; std::vector<long> ext_off;
     std::vector<double> checksum;      // per comp: sum |Q| over all valid cells and slices
     long total_vcycles; long n_qsa_total;
+    long pc_iterations = 0; double pc_err_sum = 0.0;     // Hipace.cpp:964,1028 (m_predcorr_avg_*)
     double t_deposit, t_explicit, t_push, t_poisson, t_mg, t_other;
 
     explicit Engine (const Deck& dk) : d(dk), ps(nullptr), mg(nullptr) {
         // Fields::AllocData guards (fields/Fields.cpp:63-64)
         g = (d.order + 1)/2 + 1;
-        ncomp = d.deposit_rho ? 22 : 21;
+        ncomp = d.bxby_solver ? (d.deposit_rho ? 23 : 22) : (d.deposit_rho ? 22 : 21);
         gm.dx = (d.hi[0] - d.lo[0])/d.nx; gm.dy = (d.hi[1] - d.lo[1])/d.ny; gm.dz = (d.hi[2] - d.lo[2])/d.nz;
         gm.xoff = 0.5*(d.lo[0] + d.hi[0] - gm.dx*(d.nx - 1));
         gm.yoff = 0.5*(d.lo[1] + d.hi[1] - gm.dy*(d.ny - 1));
@@ -916,7 +928,7 @@ struct Engine {
         slab_data.assign((size_t)ns*ncomp, 0.0);
         slab = Slab{slab_data.data(), d.nx, d.ny, g, ncomp, js, ns};
         ps = new PoissonSolver(d.nx, d.ny, gm.dx, gm.dy);
-        mg = new MG(d.nx, d.ny, gm.dx, gm.dy);
+        mg = d.bxby_solver ? nullptr : new MG(d.nx, d.ny, gm.dx, gm.dy);
         staging.assign((size_t)d.nx*d.ny, 0.0);
         checksum.assign((size_t)ncomp, 0.0);
         total_vcycles = 0; n_qsa_total = 0;
@@ -1051,14 +1063,61 @@ struct Engine {
     }
 
     // Multiply / LinCombination onto the staging area (fields/Fields.cpp:368-411), valid box only
-    void poisson_to (int dst_comp) {
+    // Fields::SetBoundaryCondition, level 0, boundary.field = Open (fields/Fields.cpp:672-735) followed by
+    // SetDirichletBoundaries (:627-669) with BoundaryOffset = BoundaryFactor = 1.  The reference expands the free-space
+    // Green's function G = ln|r - r'|^2 / (4 pi) to order 18 about the origin with 37 real moments
+    // (fields/OpenBoundary.H); the same expansion in complex form, z = x + i y:
+    //     ln|z - z'|^2 = ln|z|^2 - sum_{n>=1} (2/n) Re( (z'/z)^n ),
+    // so with M_n = sum_src s z'^n the boundary potential is  dx dy/(4 pi) [ M_0 ln|z|^2 - sum_n (2/n) Re(M_n z^-n) ].
+    // Coordinates are scaled by 3/|diagonal| as in the reference (only the monopole's logarithm sees the scale);
+    // sources further than 95 % of the distance to the nearest wall are ignored; Ez and Bz have no monopole.
+    void open_boundary (bool no_monopole) {
+        const int nx = d.nx, ny = d.ny;
+        const double Lx = d.hi[0] - d.lo[0], Ly = d.hi[1] - d.lo[1];
+        const double scale = 3.0/std::sqrt(Lx*Lx + Ly*Ly);
+        const double radius = std::min(std::min(std::abs(d.lo[0]), std::abs(d.hi[0])), std::min(std::abs(d.lo[1]), std::abs(d.hi[1])));
+        const double cutoff_sq = (0.95*radius*scale)*(0.95*radius*scale);
+        constexpr int NO = 18;
+        cplx M[NO + 1];
+        for (int n = 0; n <= NO; ++n) M[n] = cplx(0.0, 0.0);
+        for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const double x = (i*gm.dx + gm.xoff)*scale, y = (j*gm.dy + gm.yoff)*scale;
+            if (x*x + y*y > cutoff_sq) continue;
+            const double sv = staging[(size_t)j*nx + i];
+            const cplx z(x, y); cplx zn(1.0, 0.0);
+            for (int n = 0; n <= NO; ++n) { M[n] += sv*zn; zn *= z; }
+        }
+        if (no_monopole) M[0] = cplx(0.0, 0.0);
+        const double pref = gm.dx*gm.dy/(4.0*M_PI);
+        auto potential = [&] (double xd, double yd) {
+            const cplx z(xd*scale, yd*scale);
+            const cplx zi = 1.0/z; cplx zin = zi;
+            double v = M[0].real()*std::log(std::norm(z));
+            for (int n = 1; n <= NO; ++n) { v -= (2.0/n)*(M[n]*zin).real(); zin *= zi; }
+            return pref*v;
+        };
+        // outermost rows/columns of the source get -phi(one cell outside)/h^2; corners get both
+        for (int i = 0; i < nx; ++i) {
+            const double x = i*gm.dx + gm.xoff;
+            staging[(size_t)0*nx + i]        -= potential(x, (-1)*gm.dy + gm.yoff)/(gm.dy*gm.dy);
+            staging[(size_t)(ny - 1)*nx + i] -= potential(x, ny*gm.dy + gm.yoff)/(gm.dy*gm.dy);
+        }
+        for (int j = 0; j < ny; ++j) {
+            const double y = j*gm.dy + gm.yoff;
+            staging[(size_t)j*nx + 0]        -= potential((-1)*gm.dx + gm.xoff, y)/(gm.dx*gm.dx);
+            staging[(size_t)j*nx + (nx - 1)] -= potential(nx*gm.dx + gm.xoff, y)/(gm.dx*gm.dx);
+        }
+    }
+
+    void poisson_to (int dst_comp, bool no_monopole = false) {
+        if (d.field_bc == 1) open_boundary(no_monopole);
         ps->solve(staging.data());
         for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i)
             slab(i,j,dst_comp) = staging[(size_t)j*d.nx + i];
     }
 
     // SolvePoissonPsiExmByEypBxEzBz (fields/Fields.cpp:840-957)
-    void solve_psi_ez_bz () {
+    void solve_psi_ez_bz (int rhomjz, int jx, int jy, int Psi, int Ez, int Bz, int ExmBy, int EypBx) {
         const double dxi2 = 0.5*(1.0/gm.dx), dyi2 = 0.5*(1.0/gm.dy);
         const int nx = d.nx, ny = d.ny;
         for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i)
@@ -1068,11 +1127,11 @@ struct Engine {
         for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i)
             staging[(size_t)j*nx + i] = fa*((slab(i+1,j,jx) - slab(i-1,j,jx))*dxi2)
                                       + fa*((slab(i,j+1,jy) - slab(i,j-1,jy))*dyi2);
-        poisson_to(Ez);
+        poisson_to(Ez, true);
         for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i)
             staging[(size_t)j*nx + i] = gm.mu0*((slab(i,j+1,jx) - slab(i,j-1,jx))*dyi2)
                                       + (-gm.mu0)*((slab(i+1,j,jy) - slab(i-1,j,jy))*dxi2);
-        poisson_to(Bz);
+        poisson_to(Bz, true);
         // ExmBy = -d/dx Psi, EypBx = -d/dy Psi on the box grown by (guards-1) (:931-956)
         const int gg = g - 1;
         for (int j = -gg; j < ny + gg; ++j) for (int i = -gg; i < nx + gg; ++i) {
@@ -1097,8 +1156,130 @@ struct Engine {
         struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9*ts.tv_nsec;
     }
 
+    // Fields::ComputeRelBFieldError (fields/Fields.cpp:1233-1286), level 0: sums over the valid box
+    double rel_b_error (int cBx, int cBy, int cBxI, int cByI) const {
+        double nB = 0.0, nD = 0.0;
+        for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i) {
+            const double bx = slab(i,j,cBx), by = slab(i,j,cBy), ex = bx - slab(i,j,cBxI), ey = by - slab(i,j,cByI);
+            nB += std::sqrt(bx*bx + by*by);
+            nD += std::sqrt(ex*ex + ey*ey);
+        }
+        return nB > 0.0 ? nD/nB : 0.0;
+    }
+    // amrex::MultiFab::LinComb over the grown box: dst = a*x + b*y (dst may alias x or y)
+    void lincomb (int dst, double a, int x, double b, int y) {
+        double* pd = slab.comp(dst); const double* px = slab.comp(x); const double* py = slab.comp(y);
+        for (long k = 0; k < slab.ns; ++k) pd[k] = a*px[k] + b*py[k];
+    }
+    // Fields::SolvePoissonBxBy (fields/Fields.cpp:1008-1075), level 0, Dirichlet
+    void solve_bxby_poisson (int dstBx, int dstBy) {
+        const double dxi2 = 0.5*(1.0/gm.dx), dyi2 = 0.5*(1.0/gm.dy), dzi2 = 0.5*(1.0/gm.dz);
+        const int nx = d.nx, ny = d.ny;
+        for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i)
+            staging[(size_t)j*nx + i] = (-gm.mu0)*((slab(i,j+1,pjz) - slab(i,j-1,pjz))*dyi2)
+                                      + gm.mu0*((slab(i,j,pP_jy) - slab(i,j,pN_jy))*dzi2);
+        poisson_to(dstBx);
+        for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i)
+            staging[(size_t)j*nx + i] = gm.mu0*((slab(i+1,j,pjz) - slab(i-1,j,pjz))*dxi2)
+                                      + (-gm.mu0)*((slab(i,j,pP_jx) - slab(i,j,pN_jx))*dzi2);
+        poisson_to(dstBy);
+    }
+
+    // Hipace::SolveOneSlice, predictor-corrector branch (Hipace.cpp:556-728, 935-1031)
+    void solve_one_slice_pc (int islice, bool accumulate) {
+        double t0 = now();
+        const bool moving = (d.dt != 0.0);
+        if (moving) ensure_store();
+        else if (islice == d.nz - 1) init_beam_slice(islice, beam_this);
+        // InitializeSlices (fields/Fields.cpp:565-570)
+        for (int c : {(int)pExmBy, (int)pEypBx, (int)pjx, (int)pjy, (int)pjz, (int)prhomjz}) zero_comp(c);
+        if (d.deposit_rho) zero_comp(prho);
+        double t1 = now(); t_other += t1 - t0;
+        // plasma deposit jx jy jz [rho] rhomjz (Hipace.cpp:616-618; chi only with a laser)
+        { const int comp[6] = {pjx, pjy, pjz, d.deposit_rho ? (int)prho : -1, -1, prhomjz};
+          n_qsa_total += deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0); }
+        double t2 = now(); t_deposit += t2 - t1;
+        // beam jx jy jz on This, into the shared components (Hipace.cpp:620-623, BeamDepositCurrent.cpp:56-60)
+        if (moving) deposit_beam(store[islice], pjx, pjy, pjz, store[islice].nreg);
+        else deposit_beam(beam_this, pjx, pjy, pjz);
+        for (long k = 0; k < slab.ns; ++k) slab.comp(prhomjz)[k] += slab.comp(pIon_rhomjz)[k];
+        if (d.deposit_rho) for (long k = 0; k < slab.ns; ++k) slab.comp(prho)[k] += slab.comp(pIon_rhomjz)[k];
+        double t3 = now(); t_other += t3 - t2;
+        solve_psi_ez_bz(prhomjz, pjx, pjy, pPsi, pEz, pBz, pExmBy, pEypBx);
+        double t4 = now(); t_poisson += t4 - t3;
+        if (!moving) { if (islice - 1 >= 0) init_beam_slice(islice - 1, beam_next); else beam_next = Beam(); }
+
+        // PredictorCorrectorLoopToSolveBxBy (Hipace.cpp:935-1031)
+        double err_prev = 1.0;
+        double err = rel_b_error(pP_Bx, pP_By, pPIt_Bx, pPIt_By);
+        {   // InitialBfieldGuess (fields/Fields.cpp:1151-1173)
+            const double mix0 = std::exp(-0.5*std::pow(err/(2.5*d.predcorr_tol), 2));
+            lincomb(pBx, 1.0 + mix0, pP_Bx, -mix0, pPIt_Bx);
+            lincomb(pBy, 1.0 + mix0, pP_By, -mix0, pPIt_By); }
+        zero_comp(pIt_Bx); zero_comp(pIt_By);
+        copy_comp(pPIt_Bx, pBx); copy_comp(pPIt_By, pBy);
+        int it = 0;
+        err = 1.0;
+        while (err > d.predcorr_tol && it < d.predcorr_max_iter) {
+            ++it; ++pc_iterations;
+            double ta = now();
+            { const int comp[5] = {pPsi, pEz, pBx, pBy, pBz};
+              advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 1, d.n_subcycles, 0); }
+            double tb = now(); t_push += tb - ta;
+            { const int comp[6] = {pN_jx, pN_jy, -1, -1, -1, -1};
+              n_qsa_total += deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0); }
+            double tc = now(); t_deposit += tc - tb;
+            if (moving) { if (islice - 1 >= 0) deposit_beam(store[islice - 1], pN_jx, pN_jy, -1, store[islice - 1].nreg); }
+            else deposit_beam(beam_next, pN_jx, pN_jy, -1);
+            solve_bxby_poisson(pIt_Bx, pIt_By);
+            err = rel_b_error(pBx, pBy, pIt_Bx, pIt_By);
+            if (it == 1) err_prev = err;
+            {   // MixAndShiftBfields (fields/Fields.cpp:1175-1231)
+                double w_it, w_prev;
+                if (err != 0.0 || err_prev != 0.0) { w_it = err_prev/(err + err_prev); w_prev = err/(err + err_prev); }
+                else { w_it = 0.5; w_prev = 0.5; }
+                lincomb(pPIt_Bx, w_it, pIt_Bx, w_prev, pPIt_Bx);
+                lincomb(pPIt_By, w_it, pIt_By, w_prev, pPIt_By);
+                lincomb(pBx, 1.0 - d.predcorr_mix, pBx, d.predcorr_mix, pPIt_Bx);
+                lincomb(pBy, 1.0 - d.predcorr_mix, pBy, d.predcorr_mix, pPIt_By);
+                copy_comp(pPIt_Bx, pIt_Bx); copy_comp(pPIt_By, pIt_By); }
+            zero_comp(pN_jx); zero_comp(pN_jy);
+            err_prev = err;
+            t_poisson += now() - tc;
+        }
+        pc_err_sum += err;
+        double t7 = now();
+        if (accumulate) {
+            for (int n = 0; n < ncomp; ++n) {
+                double s = 0;
+                for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i) s += std::abs(slab(i,j,n));
+                checksum[n] += s;
+            }
+        }
+        double t8 = now(); t_other += t8 - t7;
+        { const int comp[5] = {pPsi, pEz, pBx, pBy, pBz};
+          advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0); }
+        if (moving) {
+            const Beam& b = store[islice];
+            for (long k = 0; k < b.nreg; ++k) {
+                if (!b.valid[k]) continue;
+                beam_diag[0] += 1; beam_diag[1] += std::abs(b.w[k]); beam_diag[2] += std::abs(b.x[k]); beam_diag[3] += std::abs(b.y[k]);
+                beam_diag[4] += std::abs(b.z[k]); beam_diag[5] += std::abs(b.ux[k]); beam_diag[6] += std::abs(b.uz[k]);
+            }
+            advance_beam_slice(islice);
+            shift_slipped(islice);
+        }
+        double t9 = now(); t_push += t9 - t8;
+        // ShiftSlices (fields/Fields.cpp:600-603)
+        copy_comp(pPIt_Bx, pP_Bx); copy_comp(pPIt_By, pP_By);
+        copy_comp(pP_Bx, pBx); copy_comp(pP_By, pBy); copy_comp(pP_jx, pjx); copy_comp(pP_jy, pjy);
+        if (!moving) beam_this = beam_next;
+        t_other += now() - t9;
+    }
+
     // Hipace::SolveOneSlice, explicit branch (Hipace.cpp:556-728)
     void solve_one_slice (int islice, bool accumulate) {
+        if (d.bxby_solver) { solve_one_slice_pc(islice, accumulate); return; }
         double t0 = now();
         const bool moving = (d.dt != 0.0);
         if (moving) ensure_store();
@@ -1117,7 +1298,7 @@ struct Engine {
         for (long k = 0; k < slab.ns; ++k) slab.comp(rhomjz)[k] += slab.comp(Ion_rhomjz)[k];
         if (d.deposit_rho) for (long k = 0; k < slab.ns; ++k) slab.comp(rho)[k] += slab.comp(Ion_rhomjz)[k];
         double t3 = now(); t_other += t3 - t2;
-        solve_psi_ez_bz();
+        solve_psi_ez_bz(rhomjz, jx, jy, Psi, Ez, Bz, ExmBy, EypBx);
         double t4 = now(); t_poisson += t4 - t3;
         if (moving) { if (islice - 1 >= 0) deposit_beam(store[islice - 1], N_jxb, N_jyb, -1, store[islice - 1].nreg); }
         else {
@@ -1250,7 +1431,7 @@ struct Engine {
         std::fill(slab_data.begin(), slab_data.end(), 0.0);     // ResetAllQuantities
         init_plasma();
         // DepositNeutralizingBackground (plasma/MultiPlasma.cpp:106-118): rhomjz only, charge -q
-        const int comp[6] = {-1, -1, -1, -1, -1, Ion_rhomjz};
+        const int comp[6] = {-1, -1, -1, -1, -1, d.bxby_solver ? (int)pIon_rhomjz : (int)Ion_rhomjz};
         deposit_current(slab, pl, gm, comp, -d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0);
         std::fill(checksum.begin(), checksum.end(), 0.0);
         for (double& v : beam_diag) v = 0.0;
@@ -1391,6 +1572,7 @@ struct orc_deck {
     double beam_umean[3], beam_pos_mean[3], beam_pos_std[3]; int beam_ppc[3]; double beam_charge;
     int bc; double mg_tol_rel, mg_tol_abs; int deposit_rho; int n_steps;
     double dt; int beam_n_subcycles; double beam_mass; double ext_E_slope[2];
+    int bxby_solver; double predcorr_tol; int predcorr_max_iter; double predcorr_mix; int field_bc;
 };
 
 void* orc_engine_create (const orc_deck* k) {
@@ -1404,6 +1586,9 @@ void* orc_engine_create (const orc_deck* k) {
     d.beam_charge=k->beam_charge; d.bc=k->bc; d.mg_tol_rel=k->mg_tol_rel; d.mg_tol_abs=k->mg_tol_abs; d.deposit_rho=k->deposit_rho; d.n_steps=k->n_steps;
     d.dt=k->dt; d.beam_n_subcycles=k->beam_n_subcycles > 0 ? k->beam_n_subcycles : 10; d.beam_mass=k->beam_mass != 0.0 ? k->beam_mass : 1.0;
     d.ext_E_slope[0]=k->ext_E_slope[0]; d.ext_E_slope[1]=k->ext_E_slope[1];
+    d.bxby_solver=k->bxby_solver; d.predcorr_tol=k->predcorr_tol > 0.0 ? k->predcorr_tol : 4e-2;
+    d.predcorr_max_iter=k->predcorr_max_iter > 0 ? k->predcorr_max_iter : 30; d.predcorr_mix=k->predcorr_mix > 0.0 ? k->predcorr_mix : 0.05;
+    d.field_bc=k->field_bc;
     return new Engine(d);
 }
 void orc_engine_destroy (void* h) { delete static_cast<Engine*>(h); }
@@ -1418,6 +1603,8 @@ double* orc_engine_particles (void* h) { return static_cast<Engine*>(h)->pdata.d
 int32_t* orc_engine_valid (void* h) { return static_cast<Engine*>(h)->pvalid.data(); }
 void orc_engine_checksums (void* h, double* out) { Engine* e = static_cast<Engine*>(h); for (int n = 0; n < e->ncomp; ++n) out[n] = e->checksum[n]; }
 long orc_engine_vcycles (void* h) { return static_cast<Engine*>(h)->total_vcycles; }
+long orc_engine_pc_iterations (void* h) { return static_cast<Engine*>(h)->pc_iterations; }
+double orc_engine_pc_error_sum (void* h) { return static_cast<Engine*>(h)->pc_err_sum; }
 void orc_engine_times (void* h, double* t6) { Engine* e = static_cast<Engine*>(h);
     t6[0]=e->t_deposit; t6[1]=e->t_explicit; t6[2]=e->t_push; t6[3]=e->t_poisson; t6[4]=e->t_mg; t6[5]=e->t_other; }
 long orc_engine_beam_layout (void* h, long* offsets) {

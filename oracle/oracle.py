@@ -18,6 +18,10 @@ COMPS = ["N_jx_beam", "N_jy_beam", "chi", "Sy", "Sx", "ExmBy", "EypBx", "Ez", "B
          "Psi", "jx_beam", "jy_beam", "jz_beam", "jx", "jy", "rhomjz", "P_jx_beam", "P_jy_beam",
          "Ion_rhomjz", "rho"]
 CIDX = {n: i for i, n in enumerate(COMPS)}
+# predictor-corrector layout (fields/Fields.cpp:128-164; optional "rho" last)
+COMPS_PC = ["N_jx", "N_jy", "ExmBy", "EypBx", "Ez", "Bx", "By", "Bz", "Psi", "jx", "jy", "jz", "rhomjz",
+            "P_Bx", "P_By", "P_jx", "P_jy", "Ion_rhomjz", "It_Bx", "It_By", "PIt_Bx", "PIt_By", "rho"]
+CIDX_PC = {n: i for i, n in enumerate(COMPS_PC)}
 
 
 def build(force=False):
@@ -56,7 +60,9 @@ class Deck(C.Structure):
                 ("beam_pos_std", C.c_double * 3), ("beam_ppc", C.c_int * 3), ("beam_charge", C.c_double),
                 ("bc", C.c_int), ("mg_tol_rel", C.c_double), ("mg_tol_abs", C.c_double),
                 ("deposit_rho", C.c_int), ("n_steps", C.c_int),
-                ("dt", C.c_double), ("beam_n_subcycles", C.c_int), ("beam_mass", C.c_double), ("ext_E_slope", C.c_double * 2)]
+                ("dt", C.c_double), ("beam_n_subcycles", C.c_int), ("beam_mass", C.c_double), ("ext_E_slope", C.c_double * 2),
+                ("bxby_solver", C.c_int), ("predcorr_tol", C.c_double), ("predcorr_max_iter", C.c_int),
+                ("predcorr_mix", C.c_double), ("field_bc", C.c_int)]
 
 
 def fill_struct(st, d):
@@ -377,10 +383,20 @@ class Engine:
     def checksums(self):
         out = np.zeros(self.ncomp)
         lib().orc_engine_checksums(self._h, _ptr(out))
-        return {COMPS[i]: out[i] for i in range(self.ncomp)}
+        names = COMPS_PC if self.deck.get("bxby_solver", 0) else COMPS
+        return {names[i]: out[i] for i in range(self.ncomp)}
 
     def vcycles(self):
         return lib().orc_engine_vcycles(self._h)
+
+    def pc_stats(self):
+        """(predictor-corrector iterations so far, sum over slices of the final relative B error)."""
+        L = lib()
+        L.orc_engine_pc_iterations.restype = C.c_long
+        L.orc_engine_pc_iterations.argtypes = [C.c_void_p]
+        L.orc_engine_pc_error_sum.restype = C.c_double
+        L.orc_engine_pc_error_sum.argtypes = [C.c_void_p]
+        return L.orc_engine_pc_iterations(self._h), L.orc_engine_pc_error_sum(self._h)
 
     def times(self):
         t = np.zeros(6)

@@ -461,3 +461,73 @@ def test_moving_beam_through_the_ring_hand_off(api, oracle):
         for k in ("jz_beam", "jx_beam", "Bx", "By", "Ez", "Sx", "Sy"):
             assert abs(got[s][k] - want[s][k]) <= 1e-9*max(abs(want[s][k]), 1e-300), (s, k, got[s][k], want[s][k])
     eng.beam_state()            # raises if a slice outgrew the message capacity
+
+
+# ---- predictor-corrector Bx/By (BASELINE config 2 runs this solver) -------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile_size", [0, 16])
+@pytest.mark.parametrize("settings", [(1.0e-4, 7, 0.0635), (4.0e-2, 30, 0.05)])
+def test_predictor_corrector_slice_by_slice_vs_oracle(api, oracle, tile_size, settings):
+    """hipace.bxby_solver = predictor-corrector (Hipace.cpp:935-1031) against the oracle, whose loop is pinned on the
+    reference's beam_in_vacuum_open_boundary checksums: every slab component and the particle sheet, slice by slice,
+    with the loop settings of the reference's own test (ion_motion.SI.1Rank.sh) and with the code defaults."""
+    from hipace_amd._lib import COMPS_PC
+    base = decks.linear_wake_gaussian()
+    base.update(nz=60, lo=(-10.0, -10.0, -4.0), hi=(10.0, 10.0, 2.0), beam_zmin=-3.9)
+    deck = decks.predictor_corrector(base, *settings)
+    ge = api.SliceEngine(deck, tile_size=tile_size, sort_period=5)
+    oe = oracle.Engine(deck)
+    ge.begin_step()
+    oe.begin_step()
+    for isl in range(deck["nz"] - 1, -1, -1):
+        ge.solve_slice(isl)
+        oe.solve_slice(isl)
+        if isl % 7 == 0:
+            gs, os_ = ge.slab(), oe.slab()
+            for c in range(ge.ncomp):
+                assert rel_err(gs[c], os_[c]) < 1e-9, (isl, COMPS_PC[c], rel_err(gs[c], os_[c]))
+    assert ge.pc_stats()[0] == oe.pc_stats()[0]                 # same number of iterations on every slice
+    assert abs(ge.pc_stats()[1] - oe.pc_stats()[1]) <= 1e-9 * oe.pc_stats()[1]
+    greal, gvalid = ge.particles()
+    oreal, ovalid = oe.particles()
+    if tile_size:
+        gk = np.lexsort((np.round(greal[0], 7), np.round(greal[1], 7)))
+        ok = np.lexsort((np.round(oreal[0], 7), np.round(oreal[1], 7)))
+        greal, gvalid, oreal, ovalid = greal[:, gk], gvalid[gk], oreal[:, ok], ovalid[ok]
+    assert np.array_equal(gvalid, ovalid)
+    for k in range(11):
+        assert rel_err(greal[k], oreal[k]) < 1e-9, k
+
+
+@pytest.mark.gpu
+def test_predictor_corrector_config2_head_slices(api, oracle):
+    """BASELINE config 2: linear_wake.normalized on 256 x 256 x 512 at 4 ppc with the predictor-corrector solver --
+    the first slices through the beam against the oracle (checksums over those slices, 1e-9)."""
+    deck = decks.predictor_corrector(decks.linear_wake(), 4.0e-2, 30, 0.05)
+    deck.update(nx=256, ny=256, nz=512, plasma_ppc=(2, 2))
+    ge = api.SliceEngine(deck, tile_size=16, sort_period=16)
+    ge.set_diagnostics(True)
+    oe = oracle.Engine(deck)
+    ge.begin_step()
+    oe.begin_step()
+    # the slices ahead of the beam head (z = 1) are field-free: start just before it (the static beam blocks are
+    # addressed by slice, so both engines may start anywhere).  Three slices only: the oracle's DST of length 257
+    # (prime) costs about a second per loop iteration.
+    first = 512 - int((2.0 - 1.0) / (9.5 / 512)) - 1
+    for isl in range(first, first - 3, -1):
+        ge.solve_slice(isl)
+        oe.solve_slice(isl)
+    gc, oc = ge.checksums(), oe.checksums()
+    for k, v in oc.items():
+        if v == 0.0:
+            assert gc[k] == 0.0, k
+        else:
+            assert abs(gc[k] - v) <= 1e-9 * abs(v), (k, gc[k], v)
+    assert ge.pc_stats()[0] == oe.pc_stats()[0]
+
+
+@pytest.mark.gpu
+def test_open_field_boundary_is_refused(api):
+    deck = decks.beam_in_vacuum_open_boundary()
+    with pytest.raises(RuntimeError):
+        api.SliceEngine(deck)

@@ -19,7 +19,10 @@ CASES = [("linear_wake", "linear_wake.normalized.1Rank"),
          ("blowout_wake", "blowout_wake_explicit.2Rank"),
          ("beam_in_vacuum", "beam_in_vacuum.normalized.Serial"),
          # 21 steps of dt = 3 with the beam pusher in a linear focusing field (tests/beam_evolution.1Rank.sh)
-         ("beam_evolution", "beam_evolution.1Rank")]
+         ("beam_evolution", "beam_evolution.1Rank"),
+         # predictor-corrector Bx/By loop (Hipace.cpp:935-1031) with boundary.field = Open: the reference's only
+         # checksum fixture of that solver (tests/beam_in_vacuum_open_boundary.normalized.1Rank.sh)
+         ("beam_in_vacuum_open_boundary", "beam_in_vacuum_open_boundary.normalized.1Rank")]
 
 
 @pytest.mark.parametrize("name,js", CASES)
@@ -40,3 +43,31 @@ def test_oracle_reproduces_reference_checksums(oracle, name, js):
     assert b["n"] == gb["charge"]            # |q| = 1 per particle
     for k in ("w", "x", "y", "z", "uz"):
         assert abs(b[k] - gb[k]) <= 1e-11 * max(abs(gb[k]), 1e-300), (k, b[k], gb[k])
+
+
+def test_predictor_corrector_agrees_with_explicit_solver(oracle):
+    """The reference's own check of the predictor-corrector loop on a plasma (tests/ion_motion.SI.1Rank.sh:30-42 ->
+    examples/linear_wake/analysis_equal.py:39-46): sum (F_pc - F_expl)^2 / sum F_expl^2 < 0.006 over the box for
+    Bx, By, Ez, ExmBy, EypBx, with that test's loop settings (tolerance 1e-4, 7 iterations, mixing 0.0635).  Deck:
+    linear_wake with a Gaussian driver (the loop's extrapolated first guess needs a beam that is smooth in zeta, as
+    the reference test's is)."""
+    base = decks.linear_wake_gaussian()
+    ee = oracle.Engine(base)
+    ep = oracle.Engine(decks.predictor_corrector(base))
+    ee.begin_step()
+    ep.begin_step()
+    names = ["Bx", "By", "Ez", "ExmBy", "EypBx"]
+    num = dict.fromkeys(names, 0.0)
+    den = dict.fromkeys(names, 0.0)
+    g = ee.g
+    for isl in range(base["nz"] - 1, -1, -1):
+        ee.solve_slice(isl)
+        ep.solve_slice(isl)
+        se, sp = ee.slab(), ep.slab()
+        for k in names:
+            a = se[oracle.CIDX[k]][g:-g, g:-g]
+            b = sp[oracle.CIDX_PC[k]][g:-g, g:-g]
+            num[k] += float(((b - a) ** 2).sum())
+            den[k] += float((a ** 2).sum())
+    for k in names:
+        assert num[k] / den[k] < 0.006, (k, num[k] / den[k])
