@@ -404,8 +404,8 @@ int Engine::create (const hps_deck& deck, int device)
     }
     HPS_HIP_CHECK(hipMalloc(&d_nqsa, sizeof(int)));
     HPS_HIP_CHECK(hipMemset(d_nqsa, 0, sizeof(int)));
-    HPS_HIP_CHECK(hipMalloc(&d_checksum, HPS_NCOMP_MAX*sizeof(double)));
-    HPS_HIP_CHECK(hipMemset(d_checksum, 0, HPS_NCOMP_MAX*sizeof(double)));
+    HPS_HIP_CHECK(hipMalloc(&d_checksum, HPS_PC_NCOMP_MAX*sizeof(double)));
+    HPS_HIP_CHECK(hipMemset(d_checksum, 0, HPS_PC_NCOMP_MAX*sizeof(double)));
     if (int e = hps_poisson_create(d.nx, d.ny, gm.dx, gm.dy, &ps)) return e;
     if (int e = hps_mg_create(d.nx, d.ny, gm.dx, gm.dy, &mg)) return e;
     // the halo-fallback counter lives in the header slot of the multigrid's norm buffer: it reaches the host
@@ -472,7 +472,7 @@ int Engine::begin_step ()
     }
     // ResetAllQuantities (Hipace.cpp:730-742)
     HPS_HIP_CHECK(hipMemsetAsync(slab.p, 0, (size_t)slab.nstride*ncomp*sizeof(double), st));
-    HPS_HIP_CHECK(hipMemsetAsync(d_checksum, 0, HPS_NCOMP_MAX*sizeof(double), st));
+    HPS_HIP_CHECK(hipMemsetAsync(d_checksum, 0, HPS_PC_NCOMP_MAX*sizeof(double), st));
     if (np > 0) {
         const int nppc = d.plasma_ppc[0]*d.plasma_ppc[1];
         hipLaunchKernelGGL(k_init_plasma, dim3(ceil_div(np, 256)), dim3(256), 0, st, pl, d.nx, d.ny,

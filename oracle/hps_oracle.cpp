@@ -901,7 +901,7 @@ struct Engine {
     std::vector<double> slab_data; Slab slab;
     std::vector<double> pdata; std::vector<int32_t> pvalid, pion; Plasma pl;
     PoissonSolver* ps; MG* mg; std::vector<double> staging;
-    Beam beam_this, beam_next;
+    Beam beam_this, beam_next; int beam_this_slice = -2;      // slice whose particles beam_this holds
     // dt != 0: the beam lives in per-slice stores across the time steps (index = islice)
     std::vector<Beam> store; bool store_ready = false; int steps_begun = 0; double phys_time = 0.0;
     bool beam_import = false;      // ring pipeline: the slices of the coming step arrive through import_beam_slice
@@ -1190,7 +1190,7 @@ struct Engine {
         double t0 = now();
         const bool moving = (d.dt != 0.0);
         if (moving) ensure_store();
-        else if (islice == d.nz - 1) init_beam_slice(islice, beam_this);
+        else if (islice != beam_this_slice) init_beam_slice(islice, beam_this);
         // InitializeSlices (fields/Fields.cpp:565-570)
         for (int c : {(int)pExmBy, (int)pEypBx, (int)pjx, (int)pjy, (int)pjz, (int)prhomjz}) zero_comp(c);
         if (d.deposit_rho) zero_comp(prho);
@@ -1273,7 +1273,7 @@ struct Engine {
         // ShiftSlices (fields/Fields.cpp:600-603)
         copy_comp(pPIt_Bx, pP_Bx); copy_comp(pPIt_By, pP_By);
         copy_comp(pP_Bx, pBx); copy_comp(pP_By, pBy); copy_comp(pP_jx, pjx); copy_comp(pP_jy, pjy);
-        if (!moving) beam_this = beam_next;
+        if (!moving) { beam_this = beam_next; beam_this_slice = islice - 1; }
         t_other += now() - t9;
     }
 
@@ -1283,7 +1283,7 @@ struct Engine {
         double t0 = now();
         const bool moving = (d.dt != 0.0);
         if (moving) ensure_store();
-        else if (islice == d.nz - 1) init_beam_slice(islice, beam_this);
+        else if (islice != beam_this_slice) init_beam_slice(islice, beam_this);
         // InitializeSlices (fields/Fields.cpp:535-586)
         for (int c : {(int)chi, (int)Sy, (int)Sx, (int)ExmBy, (int)EypBx, (int)jzb, (int)rhomjz, (int)N_jxb, (int)N_jyb}) zero_comp(c);
         if (d.deposit_rho) zero_comp(rho);
@@ -1342,7 +1342,7 @@ struct Engine {
         // ShiftSlices (fields/Fields.cpp:588-604)
         copy_comp(P_jxb, jxb); copy_comp(P_jyb, jyb);
         copy_comp(jxb, N_jxb); copy_comp(jyb, N_jyb); copy_comp(jx, N_jxb); copy_comp(jy, N_jyb);
-        if (!moving) beam_this = beam_next;
+        if (!moving) { beam_this = beam_next; beam_this_slice = islice - 1; }
         t_other += now() - t9;
     }
 
@@ -1429,6 +1429,7 @@ struct Engine {
     // start of one time step (Hipace::Evolve, Hipace.cpp:401-471)
     void begin_step () {
         std::fill(slab_data.begin(), slab_data.end(), 0.0);     // ResetAllQuantities
+        beam_this_slice = -2;
         init_plasma();
         // DepositNeutralizingBackground (plasma/MultiPlasma.cpp:106-118): rhomjz only, charge -q
         const int comp[6] = {-1, -1, -1, -1, -1, d.bxby_solver ? (int)pIon_rhomjz : (int)Ion_rhomjz};
