@@ -684,6 +684,73 @@ void k_transpose (const double* __restrict__ src, double* __restrict__ dst, int 
         if (c0 + cc < cols && r0 + tx < rows) d[(long)(c0 + cc)*rows + r0 + tx] = tile[tx][cc];
 }
 
+// =================================================================================================
+// dense back-end: n + 1 without a built factorisation (prime 257 of the 256^2 decks, ...), n <= 512.
+// DST-I as a matrix product with S[j][k] = 2 sin(pi (j+1)(k+1)/(n+1)) (FFTW's RODFT00 scaling, as the row kernels):
+// x direction X.S_x, y direction S_y.X -- four products per solve, no transposes.  One workgroup per 32 x 32 tile of
+// the product, operands staged through LDS in 32-deep slabs, four waves on fp64 MFMA (a real contraction: 2 n^3 flops per
+// product; a VALU version with 2 x 2 outputs per lane was LDS-bandwidth bound at 14 us per product).
+// =================================================================================================
+struct GemmArgs {
+    const double* A[DST_MAXPLANES]; long lda;
+    const double* B[DST_MAXPLANES]; long ldb;
+    double* C[DST_MAXPLANES]; long ldc;
+    int M, N, K;
+    const double* scale; long scale_r, scale_c;      // optional factor scale[r*scale_r + c*scale_c] on the output
+};
+
+__global__ __launch_bounds__(256)
+void k_dense_product (GemmArgs g)
+{
+    // pitches chosen so that the 32 lanes of one LDS pass hit 32 different 8-byte slots: A rows 34 apart, B rows 48
+    __shared__ double As[32][34];
+    __shared__ double Bs[32][48];
+    const int pl = blockIdx.z;
+    const double* __restrict__ A = g.A[pl];
+    const double* __restrict__ B = g.B[pl];
+    const int r0 = blockIdx.y*32, c0 = blockIdx.x*32;
+    // four waves, one 16 x 16 block of the tile each, on v_mfma_f64_16x16x4_f64: lane l feeds A[l%16][l/16] and
+    // B[l/16][l%16] of the 4-deep step and holds D[4r + l/16][l%16], r = 0..3
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wr = (wave >> 1)*16, wc = (wave & 1)*16;
+    const int lm = lane & 15, lk = lane >> 4;
+    mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    // the next slab's operands are fetched into registers while this one is multiplied out of LDS
+    double ra[4], rb[4];
+    auto fetch = [&] (int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = threadIdx.x + 256*q, r = e >> 5, k = e & 31;
+            ra[q] = (r0 + r < g.M && k0 + k < g.K) ? A[(long)(r0 + r)*g.lda + k0 + k] : 0.0;
+            rb[q] = (k0 + r < g.K && c0 + k < g.N) ? B[(long)(k0 + r)*g.ldb + c0 + k] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < g.K; k0 += 32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = threadIdx.x + 256*q, r = e >> 5, k = e & 31;
+            As[r][k] = ra[q]; Bs[r][k] = rb[q];
+        }
+        __syncthreads();
+        if (k0 + 32 < g.K) fetch(k0 + 32);
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[wr + lm][kk + lk], Bs[kk + lk][wc + lm], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    double* __restrict__ C = g.C[pl];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = r0 + wr + 4*q + lk, c = c0 + wc + lm;
+        if (r < g.M && c < g.N) {
+            double v = acc[q];
+            if (g.scale) v *= g.scale[(long)r*g.scale_r + (long)c*g.scale_c];
+            C[(long)r*g.ldc + c] = v;
+        }
+    }
+}
+
 typedef void (*dst_kernel_t)(DstArgs);
 typedef void (*dst_cols_kernel_t)(DstArgs, int);
 struct DstImpl { int N, N1, N2; dst_kernel_t kernel; bool sym; int T; int nt; dst_cols_kernel_t cols; dst_kernel_t mfma; };
@@ -807,6 +874,7 @@ struct Poisson {
     const double *ma_x = nullptr, *mb_x = nullptr, *ma_y = nullptr, *mb_y = nullptr;
     const double2 *fa_x = nullptr, *fb_x = nullptr, *tw_x = nullptr, *fa_y = nullptr, *fb_y = nullptr, *tw_y = nullptr;
     double *buf_a = nullptr, *buf_b = nullptr;         // [DST_MAXPLANES][nx*ny] ping-pong
+    double *S_x = nullptr, *S_y = nullptr;             // dense back-end: [n][n] sine matrices (S_y = S_x if nx == ny)
     long long* dbg = nullptr;
     size_t lds_x = 0, lds_y = 0; int tx = DST_T, ty = DST_T, ntx = 256, nty = 256;     // LDS bytes, row pairs and threads per workgroup
     // rocFFT back-end
@@ -819,6 +887,7 @@ struct Poisson {
     double* eig = nullptr; double* isin_x = nullptr; double* isin_y = nullptr;
 
     bool own () const { return kx && ky; }
+    bool dense () const { return S_x != nullptr; }
     ~Poisson () {
         if (plan_x) rocfft_plan_destroy(plan_x);
         if (plan_y) rocfft_plan_destroy(plan_y);
@@ -826,6 +895,8 @@ struct Poisson {
         (void)hipFree(work); (void)hipFree(zbuf); (void)hipFree(rbuf); (void)hipFree(eig);
         (void)hipFree(isin_x); (void)hipFree(isin_y); (void)hipFree(tab_x); (void)hipFree(tab_y); (void)hipFree(mtab_x); (void)hipFree(mtab_y);
         (void)hipFree(buf_a); (void)hipFree(buf_b);
+        if (S_y != S_x) (void)hipFree(S_y);
+        (void)hipFree(S_x);
     }
 };
 
@@ -926,6 +997,21 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
         if (P->lds_y > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->ky, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_y));
         HPS_HIP_CHECK(hipMalloc(&P->buf_a, (size_t)DST_MAXPLANES*nx*ny*sizeof(double)));
         HPS_HIP_CHECK(hipMalloc(&P->buf_b, (size_t)DST_MAXPLANES*nx*ny*sizeof(double)));
+    } else if (allow_own && nx <= 512 && ny <= 512) {
+        P->kx = P->ky = nullptr;
+        auto sines = [] (int n, double** out) -> int {
+            std::vector<double> h((size_t)n*n);
+            for (int j = 0; j < n; ++j) for (int k = 0; k < n; ++k)
+                h[(size_t)j*n + k] = (double)(2.0L*sinl(3.14159265358979323846264338327950288L*(long double)((j + 1.0L)*(k + 1.0L))/(long double)(n + 1)));
+            HPS_HIP_CHECK(hipMalloc(out, h.size()*sizeof(double)));
+            HPS_HIP_CHECK(hipMemcpy(*out, h.data(), h.size()*sizeof(double), hipMemcpyHostToDevice));
+            return (int)HPS_OK;
+        };
+        if (int e = sines(nx, &P->S_x)) { delete P; return e; }
+        if (ny == nx) P->S_y = P->S_x;
+        else if (int e = sines(ny, &P->S_y)) { delete P; return e; }
+        HPS_HIP_CHECK(hipMalloc(&P->buf_a, (size_t)DST_MAXPLANES*nx*ny*sizeof(double)));
+        HPS_HIP_CHECK(hipMalloc(&P->buf_b, (size_t)DST_MAXPLANES*nx*ny*sizeof(double)));
     } else {
         P->kx = P->ky = nullptr;
         if (!g_rocfft_setup) { rocfft_setup(); g_rocfft_setup = true; }
@@ -1014,11 +1100,36 @@ static int solve_rocfft (Poisson* P, const double* src, long src_pitch, double* 
 int poisson_solve_batch (Poisson* P, int nb, const double* const* src, long src_pitch, double* const* dst, long dst_pitch,
                          hipStream_t st)
 {
+    if (nb > DST_MAXPLANES) { set_error("poisson_solve_batch: too many planes"); return HPS_ERR_ARG; }
+    if (P->dense()) {
+        const int nx = P->nx, ny = P->ny;
+        const long plane = (long)nx*ny;
+        const dim3 grid(ceil_div(nx, 32), ceil_div(ny, 32), nb), block(256);
+        GemmArgs g{};
+        g.M = ny; g.N = nx;
+        // 1: A = src . S_x
+        for (int b = 0; b < nb; ++b) { g.A[b] = src[b]; g.B[b] = P->S_x; g.C[b] = P->buf_a + b*plane; }
+        g.lda = src_pitch; g.ldb = nx; g.ldc = nx; g.K = nx; g.scale = nullptr;
+        hipLaunchKernelGGL(k_dense_product, grid, block, 0, st, g);
+        // 2: B = (S_y . A) * inverse eigenvalues (stored x-frequency major)
+        for (int b = 0; b < nb; ++b) { g.A[b] = P->S_y; g.B[b] = P->buf_a + b*plane; g.C[b] = P->buf_b + b*plane; }
+        g.lda = ny; g.ldb = nx; g.ldc = nx; g.K = ny; g.scale = P->eig; g.scale_r = 1; g.scale_c = ny;
+        hipLaunchKernelGGL(k_dense_product, grid, block, 0, st, g);
+        // 3: A = S_y . B
+        for (int b = 0; b < nb; ++b) { g.A[b] = P->S_y; g.B[b] = P->buf_b + b*plane; g.C[b] = P->buf_a + b*plane; }
+        g.scale = nullptr;
+        hipLaunchKernelGGL(k_dense_product, grid, block, 0, st, g);
+        // 4: dst = A . S_x
+        for (int b = 0; b < nb; ++b) { g.A[b] = P->buf_a + b*plane; g.B[b] = P->S_x; g.C[b] = dst[b]; }
+        g.lda = nx; g.ldb = nx; g.ldc = dst_pitch; g.K = nx;
+        hipLaunchKernelGGL(k_dense_product, grid, block, 0, st, g);
+        HPS_HIP_CHECK(hipGetLastError());
+        return HPS_OK;
+    }
     if (!P->own()) {
         for (int b = 0; b < nb; ++b) if (int e = solve_rocfft(P, src[b], src_pitch, dst[b], dst_pitch, st)) return e;
         return HPS_OK;
     }
-    if (nb > DST_MAXPLANES) { set_error("poisson_solve_batch: too many planes"); return HPS_ERR_ARG; }
     const int nx = P->nx, ny = P->ny;
     const long plane = (long)nx*ny;
     auto rows_grid = [] (int rows, int T) { return dim3(ceil_div(rows, 2*T)); };

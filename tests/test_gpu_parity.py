@@ -113,7 +113,7 @@ def test_advance_plasma(api, oracle, order, bc):
 
 
 @pytest.mark.parametrize("nx,ny", [(64, 64), (32, 48), (63, 63), (127, 65), (32, 64), (128, 32), (512, 512),
-                                   (1024, 1024), (1023, 1023)])
+                                   (1024, 1024), (1023, 1023), (256, 256), (256, 100), (48, 500), (600, 520)])
 def test_poisson(api, oracle, nx, ny):
     import torch
     rng = np.random.default_rng(nx * 1000 + ny)
