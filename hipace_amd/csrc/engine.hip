@@ -417,8 +417,9 @@ int Engine::create (const hps_deck& deck, int device)
         // no multigrid solves in this mode: the counter travels with the per-iteration read-back of the B error
         HPS_HIP_CHECK(hipMalloc(&d_pc, 4*sizeof(double)));
         HPS_HIP_CHECK(hipMemset(d_pc, 0, 4*sizeof(double)));
-        HPS_HIP_CHECK(hipHostMalloc(&h_pc, 4*sizeof(double)));
+        HPS_HIP_CHECK(hipHostMalloc(&h_pc, 4*sizeof(double), hipHostMallocMapped));
         std::memset(h_pc, 0, 4*sizeof(double));
+        HPS_HIP_CHECK(hipHostGetDevicePointer((void**)&h_pc_dev, h_pc, 0));
         d_nfallback = reinterpret_cast<int*>(d_pc + 2); h_nfallback = reinterpret_cast<const int*>(h_pc + 2);
     }
     return init_beam();
@@ -523,8 +524,10 @@ void Engine::mark ()
 
 // Fields::ComputeRelBFieldError (fields/Fields.cpp:1233-1286): out[0] += sum |B|, out[1] += sum |B - B_iter| over
 // the valid cells
+// With `host` (mapped pinned memory) the last workgroup to finish posts {sum |B|, sum |B - B_iter|, fallback counter,
+// seq} there, seq last behind a system-scope fence: the host polls seq instead of a copy + stream synchronise.
 __global__ __launch_bounds__(256)
-void k_rel_b_error (SlabView f, int cB, int cBit, double* out)
+void k_rel_b_error (SlabView f, int cB, int cBit, double* out, volatile double* host, double seq)
 {
     double sb = 0.0, sd = 0.0;
     const long cells = (long)f.nx*f.ny;
@@ -543,6 +546,19 @@ void k_rel_b_error (SlabView f, int cB, int cBit, double* out)
     if (threadIdx.x == 0) {
         atomic_add_f64(out, part[0] + part[1] + part[2] + part[3]);
         atomic_add_f64(out + 1, part[4] + part[5] + part[6] + part[7]);
+        if (host) {
+            __threadfence();
+            unsigned int* done = reinterpret_cast<unsigned int*>(out + 3);
+            if (atomicAdd(done, 1u) == gridDim.x - 1) {
+                *done = 0u;
+                __threadfence();
+                host[0] = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                host[1] = __hip_atomic_load(out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                host[2] = __hip_atomic_load(out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+                host[3] = seq;
+            }
+        }
     }
 }
 
@@ -568,10 +584,12 @@ void k_pc_guess (double* p, long ns, long plane, const double* sums, double tol)
 // sources of Fields::SolvePoissonBxBy (fields/Fields.cpp:1043-1064): st[0] = mu0 (-d_y jz + d_z jy),
 // st[1] = mu0 (d_x jz - d_z jx), d_z = (Previous - Next)/(2 dz)
 __global__ __launch_bounds__(256)
-void k_rhs_bxby (SlabView f, double mu0, double hdx_inv, double hdy_inv, double hdz_inv, double* staging, long plane)
+void k_rhs_bxby (SlabView f, double mu0, double hdx_inv, double hdy_inv, double hdz_inv, double* staging, long plane,
+                 double* sums)
 {
     const int i = blockIdx.x*blockDim.x + threadIdx.x;
     const int j = blockIdx.y;
+    if (i == 0 && j == 0) { sums[0] = 0.0; sums[1] = 0.0; }      // for the k_rel_b_error of this pass
     if (i >= f.nx) return;
     const long o = f.off(i, j), so = (long)j*f.nx + i;
     const double* Z = f.p + HPS_PC_JZ*f.ns + o;
@@ -637,7 +655,7 @@ int Engine::solve_slice_pc (int islice)
     mark();   // b5
     // the loop (Hipace.cpp:935-1031)
     HPS_HIP_CHECK(hipMemsetAsync(d_pc, 0, 2*sizeof(double), st));
-    hipLaunchKernelGGL(k_rel_b_error, dim3(128), b256, 0, st, f, HPS_PC_P_BX, HPS_PC_PIT_BX, d_pc);
+    hipLaunchKernelGGL(k_rel_b_error, dim3(128), b256, 0, st, f, HPS_PC_P_BX, HPS_PC_PIT_BX, d_pc, (volatile double*)nullptr, 0.0);
     hipLaunchKernelGGL(k_pc_guess, gplane, b256, 0, st, slab.p, slab.nstride, plane, d_pc, pc_tol);
     double err = 1.0, err_prev = 1.0;
     int it = 0;
@@ -652,13 +670,22 @@ int Engine::solve_slice_pc (int islice)
             else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
         if ((e = deposit_beam_slice(islice - 1, HPS_PC_N_JX, HPS_PC_N_JY, -1))) return e;
         hipLaunchKernelGGL(k_rhs_bxby, dim3(ceil_div(d.nx, 256), d.ny), b256, 0, st, f, gm.mu0, 0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy),
-                           0.5*(1.0/gm.dz), staging, nval);
+                           0.5*(1.0/gm.dz), staging, nval, d_pc);
         {   const int comps[2] = {HPS_PC_IT_BX, HPS_PC_IT_BY};
             if ((e = hps_poisson_solve_batch(ps, 2, staging, slab, comps, st))) return e; }
-        HPS_HIP_CHECK(hipMemsetAsync(d_pc, 0, 2*sizeof(double), st));
-        hipLaunchKernelGGL(k_rel_b_error, dim3(128), b256, 0, st, f, HPS_PC_BX, HPS_PC_IT_BX, d_pc);
-        HPS_HIP_CHECK(hipMemcpyAsync(h_pc, d_pc, 4*sizeof(double), hipMemcpyDeviceToHost, st));
-        HPS_HIP_CHECK(hipStreamSynchronize(st));
+        pc_seq += 1.0;
+        hipLaunchKernelGGL(k_rel_b_error, dim3(128), b256, 0, st, f, HPS_PC_BX, HPS_PC_IT_BX, d_pc, (volatile double*)h_pc_dev, pc_seq);
+        {   // wait for the post; fall back to the stream's status every so often so that a failed launch cannot hang us
+            volatile double* hp = h_pc;
+            long spins = 0;
+            while (hp[3] != pc_seq) {
+                if ((++spins & 0xfffff) == 0 && hipStreamQuery(st) != hipErrorNotReady) {
+                    if (hp[3] == pc_seq) break;
+                    HPS_HIP_CHECK(hipStreamSynchronize(st));
+                    if (hp[3] != pc_seq) { set_error("predictor-corrector: the error read-back never arrived"); return HPS_ERR_HIP; }
+                }
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE); }
         err = h_pc[0] > 0.0 ? h_pc[1]/h_pc[0] : 0.0;
         if (it == 1) err_prev = err;
         double w_it = 0.5, w_prev = 0.5;

@@ -429,7 +429,8 @@ int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
     int mask = 0; for (int c = 0; c < 6; ++c) mask |= (comp[c] >= 0) << c;
 #define CALLM(O, S, M) { if (int e = set_lds(k_deposit_tiled<O, S, M>, lds)) return e; \
         hipLaunchKernelGGL((k_deposit_tiled<O, S, M>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback); }
-#define CALL(O, S) { if (mask == 51) CALLM(O, S, 51) else if (mask == 59) CALLM(O, S, 59) else if (mask == 32) CALLM(O, S, 32) else CALLM(O, S, -1) }
+#define CALL(O, S) { if (mask == 51) CALLM(O, S, 51) else if (mask == 59) CALLM(O, S, 59) else if (mask == 32) CALLM(O, S, 32) \
+                     else if (mask == 3) CALLM(O, S, 3) else if (mask == 39) CALLM(O, S, 39) else if (mask == 47) CALLM(O, S, 47) else CALLM(O, S, -1) }
     HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
 #undef CALL
 #undef CALLM
