@@ -16,10 +16,12 @@ import torch.multiprocessing as mp
 from hipace_amd import decks
 
 
-def _deck():
+def _deck(pc=False):
     d = decks.blowout_wake()
     d.update(nx=32, ny=32, nz=24, lo=(-8.0, -8.0, -1.44), hi=(8.0, 8.0, 1.44), n_steps=1,
              beam_zmin=-1.4, beam_zmax=1.4)
+    if pc:      # the same hand-off under the predictor-corrector Bx/By solver (beams deposit into the shared jx jy jz)
+        d = decks.predictor_corrector(d, 1.0e-3, 5, 0.1)
     return d
 
 
@@ -40,14 +42,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_steps, out, moving=False):
+def _worker(rank, world, port, n_steps, out, moving=False, pc=False):
     import torch.distributed as dist
     from hipace_amd.pipeline import run_pipeline
     from oracle import oracle as O
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    eng = O.Engine(_moving_deck() if moving else _deck())
+    eng = O.Engine(_moving_deck() if moving else _deck(pc))
     sums = {}
 
     def on_step_end(step):
@@ -59,16 +61,16 @@ def _worker(rank, world, port, n_steps, out, moving=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_steps", [(2, 3), (2, 2), (1, 2)])
-def test_ring_pipeline_matches_single_process(oracle, world, n_steps):
-    ref = oracle.Engine(_deck())
+@pytest.mark.parametrize("world,n_steps,pc", [(2, 3, False), (2, 2, False), (1, 2, False), (2, 2, True)])
+def test_ring_pipeline_matches_single_process(oracle, world, n_steps, pc):
+    ref = oracle.Engine(_deck(pc))
     ref.run()
     want = ref.checksums()
-    assert want["jz_beam"] > 0
+    assert want["jz" if pc else "jz_beam"] > 0
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_steps, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_steps, out, False, pc)) for r in range(world)]
     for p in procs:
         p.start()
     results = [out.get(timeout=240) for _ in range(world)]
