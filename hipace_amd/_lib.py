@@ -94,6 +94,8 @@ _SIGS = {
     "hps_engine_plasma": (Plasma, [C.c_void_p]),
     "hps_engine_stream": (C.c_void_p, [C.c_void_p]),
     "hps_engine_checksums": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hps_beam_sort_by_box": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
     "hps_engine_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "hps_engine_pc_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_double)]),
     "hps_engine_set_diagnostics": (C.c_int, [C.c_void_p, C.c_int]),

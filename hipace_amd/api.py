@@ -102,6 +102,27 @@ class PlasmaSheet:
         return self.real.cpu().numpy(), ((idc >> np.uint64(63)) & np.uint64(1)).astype(np.int32)
 
 
+class BoxSorter:
+    """BoxSorter::sortParticlesByBox (particles/sorting/BoxSort.H:18-48): beam particles -> longitudinal boxes."""
+
+    def sortParticlesByBox(self, z, plo_z, dz, num_boxes):
+        """z: float64 device tensor.  Fills boxCounts / boxOffsets (num_boxes + 1 each) and boxPermutations
+        (perm[new] = old) as numpy uint64 arrays."""
+        z = z.contiguous()
+        n = z.numel()
+        counts = torch.zeros(num_boxes + 1, dtype=torch.int64, device=z.device)
+        offsets = torch.zeros(num_boxes + 1, dtype=torch.int64, device=z.device)
+        perm = torch.zeros(max(n, 1), dtype=torch.int64, device=z.device)
+        check(_lib.lib().hps_beam_sort_by_box(C.c_void_p(z.data_ptr() if n else 0), n, float(plo_z), float(dz), num_boxes,
+                                              C.c_void_p(counts.data_ptr()), C.c_void_p(offsets.data_ptr()),
+                                              C.c_void_p(perm.data_ptr()), _stream()))
+        torch.cuda.synchronize()
+        self.boxCounts = counts.cpu().numpy().astype(np.uint64)
+        self.boxOffsets = offsets.cpu().numpy().astype(np.uint64)
+        self.boxPermutations = perm[:n].cpu().numpy().astype(np.uint64)
+        return self
+
+
 class Tiling:
     """Tile binning of a plasma sheet (the reference's ReorderParticles hook)."""
 

@@ -154,9 +154,76 @@ int tiling_sort (Tiling* T, const hps_plasma& src, const hps_plasma& dst, const 
     return HPS_OK;
 }
 
+// ---- beam particles -> longitudinal boxes (BoxSorter::sortParticlesByBox, particles/sorting/BoxSort.cpp:14-78) ------
+// box = int((z - plo_z) * dzi), truncated toward zero as the reference's static_cast; outside [0, num_boxes] -> the
+// extra last box num_boxes (:40-43)
+__global__ __launch_bounds__(256)
+void k_box_keys (const double* __restrict__ z, long n, double plo_z, double dzi, int num_boxes, unsigned int* keys, unsigned int* idx)
+{
+    const long i = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int b = static_cast<int>((z[i] - plo_z)*dzi);
+    if (b < 0 || b > num_boxes) b = num_boxes;
+    keys[i] = (unsigned int)b; idx[i] = (unsigned int)i;
+}
+
+// offsets[b] = first sorted position with key >= b (the exclusive scan of the counts, :47), counts[b] = run length
+__global__ __launch_bounds__(256)
+void k_box_offsets (const unsigned int* keys, long n, int num_boxes, unsigned long long* counts, unsigned long long* offsets)
+{
+    const long p = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (p > n) return;
+    const int prev = (p == 0) ? -1 : (int)keys[p - 1];
+    const int cur = (p == n) ? num_boxes + 1 : (int)keys[p];
+    for (int k = prev + 1; k <= cur && k <= num_boxes; ++k) offsets[k] = (unsigned long long)p;
+    (void)counts;
+}
+__global__ __launch_bounds__(256)
+void k_box_counts (long n, int num_boxes, const unsigned int* idx, unsigned long long* counts, const unsigned long long* offsets,
+                   unsigned long long* perm)
+{
+    const long p = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (p < n) perm[p] = idx[p];
+    if (p <= num_boxes) counts[p] = (p == num_boxes ? (unsigned long long)n : offsets[p + 1]) - offsets[p];
+}
+
 } // namespace hps
 
 using namespace hps;
+
+extern "C" int hps_beam_sort_by_box (const double* z_dev, long n, double plo_z, double dz, int num_boxes,
+                                     unsigned long long* counts_dev, unsigned long long* offsets_dev,
+                                     unsigned long long* perm_dev, hps_stream stream)
+{
+    HPS_REQUIRE(n >= 0 && num_boxes >= 1 && counts_dev && offsets_dev && (perm_dev || n == 0) && (z_dev || n == 0),
+                "hps_beam_sort_by_box: bad argument");
+    HPS_REQUIRE(n < (1L << 32), "hps_beam_sort_by_box: more than 2^32 particles");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nb1 = (size_t)num_boxes + 1;
+    if (n == 0) {
+        HPS_HIP_CHECK(hipMemsetAsync(counts_dev, 0, nb1*sizeof(unsigned long long), st));
+        HPS_HIP_CHECK(hipMemsetAsync(offsets_dev, 0, nb1*sizeof(unsigned long long), st));
+        return HPS_OK;
+    }
+    unsigned int *ka = nullptr, *kb = nullptr, *ia = nullptr, *ib = nullptr; void* temp = nullptr; size_t tb = 0;
+    int bits = 1; while ((1L << bits) < (long)nb1) ++bits;
+    HPS_HIP_CHECK(hipMalloc(&ka, 4*(size_t)n*sizeof(unsigned int)));
+    kb = ka + n; ia = kb + n; ib = ia + n;
+    HPS_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, ka, kb, ia, ib, (size_t)n, 0, bits, st));
+    HPS_HIP_CHECK(hipMalloc(&temp, tb));
+    const dim3 b256(256);
+    // the reference takes 1/dz from the geometry (InvCellSize)
+    hipLaunchKernelGGL(k_box_keys, dim3(ceil_div(n, 256)), b256, 0, st, z_dev, n, plo_z, 1.0/dz, num_boxes, ka, ia);
+    // stable: particles keep their order inside a box, which is what the reference's serial CPU build produces
+    HPS_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, ka, kb, ia, ib, (size_t)n, 0, bits, st));
+    const long span = std::max<long>(n + 1, (long)nb1);
+    hipLaunchKernelGGL(k_box_offsets, dim3(ceil_div(n + 1, 256)), b256, 0, st, kb, n, num_boxes, counts_dev, offsets_dev);
+    hipLaunchKernelGGL(k_box_counts, dim3(ceil_div(span, 256)), b256, 0, st, n, num_boxes, ib, counts_dev, offsets_dev, perm_dev);
+    HPS_HIP_CHECK(hipGetLastError());
+    HPS_HIP_CHECK(hipStreamSynchronize(st));        // the reference synchronises too (:66-69); frees the scratch
+    (void)hipFree(ka); (void)hipFree(temp);
+    return HPS_OK;
+}
 
 extern "C" int hps_tiling_create (int nx, int ny, int tile_size, long max_particles, void** handle)
 {

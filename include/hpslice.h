@@ -98,6 +98,15 @@ int hps_reorder_particles (void* tiling, hps_plasma src, hps_plasma dst, hps_geo
 int hps_tiling_info (void* tiling, int* ntiles, const int** offsets_dev, const unsigned int** perm_dev);
 int hps_tiling_destroy (void* tiling);
 
+/* BoxSorter::sortParticlesByBox (particles/sorting/BoxSort.cpp:14-78; index_type = unsigned long long, BoxSort.H:21):
+ * beam particles -> longitudinal boxes (slices).  box = (int)((z - plo_z)/dz), out of range -> the extra box
+ * num_boxes; counts and offsets have num_boxes + 1 entries (offsets = exclusive scan of counts), perm[new] = old,
+ * particles keep their order inside a box (the serial CPU result of the reference).  Allocates scratch and
+ * synchronises the stream, like the reference; an initialisation-time operator. */
+int hps_beam_sort_by_box (const double* z_dev, long n, double plo_z, double dz, int num_boxes,
+                          unsigned long long* counts_dev, unsigned long long* offsets_dev,
+                          unsigned long long* perm_dev, hps_stream stream);
+
 /* Same operators, same arithmetic, for a sheet ordered by hps_reorder_particles: one workgroup
  * per tile accumulates / gathers through an LDS image of the tile (+6-cell halo).  Particles
  * that drifted out of the halo since the sort take the global-memory path and are counted into

@@ -272,6 +272,21 @@ def mg_solve1(sol2, rhs2, acf, nx, ny, g, dx, dy, tol_rel=1e-4, tol_abs=2.225073
     return it, rn.value
 
 
+def beam_sort_by_box(z, plo_z, dz, num_boxes):
+    """BoxSorter::sortParticlesByBox (particles/sorting/BoxSort.cpp:14-78), serial CPU semantics: box =
+    static_cast<int>((z - plo_z) * dzi) (truncation toward zero), out of [0, num_boxes] -> num_boxes; counts,
+    offsets = exclusive scan of the counts (both num_boxes + 1 long), perm[offset[box] + k] = k-th particle of the box
+    in input order.  -> (counts, offsets, perm) as uint64."""
+    z = np.asarray(z, dtype=np.float64)
+    dzi = 1.0 / dz
+    box = np.trunc((z - plo_z) * dzi)
+    box = np.where((box < 0) | (box > num_boxes) | ~np.isfinite(box), num_boxes, box).astype(np.int64)
+    counts = np.bincount(box, minlength=num_boxes + 1).astype(np.uint64)
+    offsets = np.concatenate(([0], np.cumsum(counts)[:-1])).astype(np.uint64)
+    perm = np.argsort(box, kind="stable").astype(np.uint64)
+    return counts, offsets, perm
+
+
 class Engine:
     """The oracle's whole-deck driver (Hipace::Evolve + SolveOneSlice, explicit solver)."""
 

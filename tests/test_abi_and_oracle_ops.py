@@ -154,3 +154,35 @@ def test_deck_definitions_match_reference_inputs():
     assert (lw["nx"], lw["ny"], lw["nz"]) == (32, 32, 200) and lw["deposit_rho"] == 1 and lw["beam_profile"] == 1
     s = decks.synthetic(1024, 1024, 2)
     assert s["plasma_ppc"] == (2, 2) and s["nx"] == 1024
+
+
+def test_oracle_beam_box_sort_against_a_serial_loop(oracle):
+    """The vectorised restatement of BoxSorter::sortParticlesByBox equals the reference's two serial passes
+    (count, exclusive scan, place; particles/sorting/BoxSort.cpp:36-61) written out as a plain loop."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for n, nb in [(0, 3), (1, 1), (200, 7), (999, 64)]:
+        plo, dz = -3.0, 6.0 / nb
+        z = rng.uniform(-3.6, 3.6, n)
+        if n > 20:
+            z[:10] = plo + dz * rng.integers(0, nb + 1, 10)
+            z[10:14] = plo - 0.5 * dz
+        c, o, p = oracle.beam_sort_by_box(z, plo, dz, nb)
+        dzi = 1.0 / dz
+        cnt, box = [0] * (nb + 1), []
+        for v in z:
+            b = int((v - plo) * dzi)
+            if b < 0 or b > nb:
+                b = nb
+            box.append(b)
+            cnt[b] += 1
+        off = [0] * (nb + 1)
+        for b in range(1, nb + 1):
+            off[b] = off[b - 1] + cnt[b - 1]
+        perm, fill = [0] * n, [0] * (nb + 1)
+        for i, b in enumerate(box):
+            perm[off[b] + fill[b]] = i
+            fill[b] += 1
+        assert np.array_equal(c, np.array(cnt, dtype=np.uint64))
+        assert np.array_equal(o, np.array(off, dtype=np.uint64))
+        assert np.array_equal(p, np.array(perm, dtype=np.uint64))

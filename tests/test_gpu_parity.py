@@ -538,3 +538,26 @@ def test_open_field_boundary_is_refused(api):
     deck = decks.beam_in_vacuum_open_boundary()
     with pytest.raises(RuntimeError):
         api.SliceEngine(deck)
+
+
+# ---- beam particles -> slices (integer work: bit-exact) ---------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,num_boxes", [(0, 8), (1, 1), (1000, 7), (200000, 1024), (65537, 100)])
+def test_beam_sort_by_box_bit_exact(api, oracle, n, num_boxes):
+    """BoxSorter::sortParticlesByBox against the oracle's restatement of the serial CPU result: counts, offsets and
+    permutation equal bit for bit, including particles below / above the box (-> the extra last box), particles
+    exactly on box edges, an empty beam and a single box."""
+    import torch
+    rng = np.random.default_rng(n + num_boxes)
+    plo, dz = -3.0, 6.0 / num_boxes
+    z = rng.uniform(-3.6, 3.6, n)
+    if n >= 1000:
+        z[:50] = plo + dz * rng.integers(0, num_boxes + 1, 50)      # exactly on edges
+        z[50:60] = plo - 0.3 * dz                                   # truncation toward zero keeps these in box 0
+        z[60:70] = plo - 1.0 * dz
+    want = oracle.beam_sort_by_box(z, plo, dz, num_boxes)
+    got = api.BoxSorter().sortParticlesByBox(torch.as_tensor(z, device="cuda"), plo, dz, num_boxes)
+    assert np.array_equal(got.boxCounts, want[0])
+    assert np.array_equal(got.boxOffsets, want[1])
+    assert np.array_equal(got.boxPermutations, want[2])
+    assert int(got.boxCounts.sum()) == n
