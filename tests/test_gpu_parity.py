@@ -263,6 +263,29 @@ def test_full_size_properties(api):
     assert res.abs().max().item() <= 1e-8 * R.abs().max().item() * 1.0001
 
 
+@pytest.mark.parametrize("n,nsl", [(512, 6), (1024, 3)])
+def test_baseline_blowout_configs_head_slices(api, oracle, n, nsl):
+    """BASELINE configs 3 and 4 at their full transverse size (blowout_wake n x n x 1024, 4 ppc, explicit solver):
+    a few slices through the driver against the oracle -- every slab component and the V-cycle count.  Both engines
+    start on a slice one sigma ahead of the beam centre (the static beam blocks are addressed by slice), where the
+    fields are strong from the first slice on.  (The whole box would take the oracle 20 min to 1 h; the decks'
+    whole-box checksums are covered at 64^2 by the golden fixtures.)"""
+    from hipace_amd._lib import COMPS
+    deck = decks.synthetic(n, 1024, 2)
+    ge = api.SliceEngine(deck, tile_size=16, sort_period=128)
+    oe = oracle.Engine(deck)
+    ge.begin_step()
+    oe.begin_step()
+    for isl in range(640, 640 - nsl, -1):
+        ge.solve_slice(isl)
+        oe.solve_slice(isl)
+    gs, os_ = ge.slab(), oe.slab()
+    assert np.abs(os_[COMPS.index("Bx")]).max() > 1e-2 and np.abs(os_[COMPS.index("Ez")]).max() > 1e-4
+    for c in range(ge.ncomp):
+        assert rel_err(gs[c], os_[c]) < 1e-8, (COMPS[c], rel_err(gs[c], os_[c]))
+    assert ge.stats()["vcycles"] == oe.vcycles()
+
+
 # ------------------------------------------------------------------------------------------------
 # tile-sorted sheet: sort is bit-exact against the CPU restatement; LDS-tile kernels agree with
 # the oracle both for a fresh sort and for a stale one (particles far outside their home tile)
