@@ -342,6 +342,24 @@ class SliceEngine:
     def initial_beam_into(self, tensor):
         check(_lib.lib().hps_engine_initial_beam(self._h, C.c_void_p(tensor.data_ptr())))
 
+    # ---- several steps in flight on one device (pipeline.run_local_pipeline) ----------------------------
+    def record_event(self, slot):
+        """Mark this engine's stream; returns the event another engine can wait for."""
+        ev = C.c_void_p()
+        check(_lib.lib().hps_engine_record_event(self._h, int(slot), C.byref(ev)))
+        return ev.value
+
+    def wait_event(self, event):
+        """This engine's stream waits (on the device) for an event recorded by another engine."""
+        if event is not None:
+            check(_lib.lib().hps_engine_wait_event(self._h, C.c_void_p(event)))
+
+    def copy_async(self, dst, src):
+        """dst.copy_(src) for two float64 device tensors, on this engine's stream."""
+        assert dst.numel() == src.numel()
+        check(_lib.lib().hps_engine_copy_async(self._h, C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()),
+                                               dst.numel() * 8))
+
     def phase_times(self):
         ms = (C.c_double * 7)()
         n = C.c_long()

@@ -58,6 +58,7 @@ struct Engine {
     bool diagnostics = false;
     bool profiling = false;
     std::vector<hipEvent_t> ev; size_t ev_used = 0;      // 11 events per profiled slice
+    std::vector<hipEvent_t> hand_ev;                     // hps_engine_record_event pool (no timing)
     void mark ();
     long total_vcycles = 0, slices_done = 0;
     // predictor-corrector Bx/By (hipace.bxby_solver = predictor-corrector): d_pc = {sum |B|, sum |B - B_iter|, halo

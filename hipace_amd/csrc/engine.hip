@@ -255,6 +255,7 @@ Engine::~Engine ()
     (void)hipFree(d_Bimp); (void)hipFree(d_beam_overflow); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
     (void)hipFree(d_pc); if (h_pc) (void)hipHostFree(h_pc);
     for (auto e : ev) (void)hipEventDestroy(e);
+    for (auto e : hand_ev) if (e) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
 }
 
@@ -847,6 +848,31 @@ extern "C" int hps_engine_stats (void* h, long* vc, long* sl)
     Engine* E = static_cast<Engine*>(h);
     if (vc) *vc = E->total_vcycles;
     if (sl) *sl = E->slices_done;
+    return HPS_OK;
+}
+extern "C" int hps_engine_record_event (void* h, int slot, void** out)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(slot >= 0 && slot < (1 << 20) && out, "hps_engine_record_event: bad slot");
+    if ((size_t)slot >= E->hand_ev.size()) E->hand_ev.resize((size_t)slot + 1, nullptr);
+    if (!E->hand_ev[slot]) HPS_HIP_CHECK(hipEventCreateWithFlags(&E->hand_ev[slot], hipEventDisableTiming));
+    HPS_HIP_CHECK(hipEventRecord(E->hand_ev[slot], E->st));
+    *out = E->hand_ev[slot];
+    return HPS_OK;
+}
+extern "C" int hps_engine_wait_event (void* h, void* event)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(event, "hps_engine_wait_event: null event");
+    HPS_HIP_CHECK(hipStreamWaitEvent(E->st, static_cast<hipEvent_t>(event), 0));
+    return HPS_OK;
+}
+extern "C" int hps_engine_copy_async (void* h, void* dst, const void* src, long bytes)
+{
+    Engine* E = static_cast<Engine*>(h);
+    if (bytes <= 0) return HPS_OK;
+    HPS_REQUIRE(dst && src, "hps_engine_copy_async: null pointer");
+    HPS_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, E->st));
     return HPS_OK;
 }
 extern "C" int hps_engine_pc_stats (void* h, long* its, double* err_sum)

@@ -217,3 +217,92 @@ def _run_pipeline_moving(engine, rank, world, n_steps, device, on_step_end):
     for rq in pending_send:
         rq.wait()
     return solved
+
+
+def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_step=None):
+    """Several time steps in flight on ONE device: the ring pipeline with all its stages in this process.
+
+    engines[j] (one stream each, all on `device`) runs steps j, j+L, ... < n_steps, L = len(engines), exactly as rank j
+    of `run_pipeline` would; what couples them is the same per-slice beam hand-off, here a device-to-device copy
+    (MultiBuffer.cpp:299-308, the reference's in-process "send to myself") ordered by stream events instead of
+    messages: engine j solves slice k of step s only after engine j-1 has pushed slices k and k-1 of step s-1.  One
+    host thread per engine (the multigrid's stopping rule synchronises its stream once per slice; ctypes releases
+    the GIL), so while one step sits in a latency-bound phase -- the lower multigrid levels, a DST pass, a launch gap
+    -- the kernels of the others fill the device.  Static beam only (hipace.dt = 0, as every BASELINE deck).
+
+    Returns the number of slices solved (all engines).
+    """
+    import threading
+    L = len(engines)
+    nz = engines[0].deck["nz"]
+    per_step = slices_per_step or nz
+    assert per_step >= 2, "a step needs at least two slices"
+    assert not getattr(engines[0], "moving", False), "run_local_pipeline hands a static beam on (hipace.dt = 0)"
+    nbeam, off = engines[0].beam_layout()
+    bufs = [[torch.zeros(max(7 * nbeam, 1), dtype=torch.float64, device=device) for _ in range(2)] for _ in range(L)]
+    engines[0].initial_beam_into(bufs[0][0])          # only the head of the ring injects the beam
+    engines[0].sync()
+
+    def block(buf, q):
+        p = q                                          # q-th slice from the head = block q
+        return buf[7 * off[p]:7 * off[p + 1]]
+
+    cond = threading.Condition()
+    progress = [0] * L                                 # slices enqueued so far by each engine
+    events = [dict() for _ in range(L)]                # (local step, q) -> event recorded after that slice
+    errors = []
+    solved = [0] * L
+
+    def lane(j):
+        try:
+            eng, pj = engines[j], (j - 1) % L
+            for m, step in enumerate(range(j, n_steps, L)):
+                buf = bufs[j][m % 2]
+                mp = (step - 1 - pj) // L if step > 0 else None     # the local step of my predecessor that feeds me
+                eng.set_beam_storage(buf, injected_beam_support=True)
+                eng.begin_step()
+                copied = 0
+                for q in range(per_step):
+                    if mp is not None:
+                        need = min(q + 1, per_step - 1)             # this slice's beam and the next one's (jx/jy source)
+                        with cond:
+                            while progress[pj] < mp * per_step + need + 1 and not errors:
+                                cond.wait(timeout=1.0)
+                            ev = events[pj].get((mp, need))
+                        if errors:
+                            return
+                        eng.wait_event(ev)
+                        src = bufs[pj][mp % 2]
+                        while copied <= need:
+                            d, s_ = block(buf, copied), block(src, copied)
+                            if d.numel() > 0:
+                                eng.copy_async(d, s_)
+                            copied += 1
+                    eng.solve_slice(nz - 1 - q)
+                    ev = eng.record_event((m % 2) * per_step + q)
+                    solved[j] += 1
+                    with cond:
+                        events[j][(m, q)] = ev
+                        events[j].pop((m - 2, q), None)
+                        progress[j] = m * per_step + q + 1
+                        cond.notify_all()
+                if on_step_end is not None:
+                    on_step_end(step, eng)
+        except BaseException as e:      # noqa: BLE001 -- re-raised on the caller's thread
+            with cond:
+                errors.append(e)
+                cond.notify_all()
+
+    if L == 1:
+        lane(0)
+    else:
+        threads = [threading.Thread(target=lane, args=(j,), name=f"hps-step-lane-{j}") for j in range(L)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    if errors:
+        raise errors[0]
+    for e in engines:
+        e.sync()
+    return sum(solved)

@@ -245,6 +245,15 @@ int hps_engine_import_beam_slice (void* handle, int islice, const double* msg_de
  * this to restore the support box of the injected beam. */
 int hps_engine_assume_initial_beam_support (void* handle);
 
+/* Several time steps in flight on ONE device (hipace_amd/pipeline.py::run_local_pipeline): every step runs in its own
+ * engine on its own stream, coupled only by the per-slice beam hand-off.  record_event marks the engine's stream
+ * (pool slot `slot`, created on first use) and returns the event; wait_event makes the engine's stream wait for an
+ * event recorded by another engine -- the device-side form of "slice k of the previous step has been pushed".
+ * copy_async is a device-to-device copy on the engine's stream (the in-process hand-off, MultiBuffer.cpp:299-308). */
+int hps_engine_record_event (void* handle, int slot, void** event_out);
+int hps_engine_wait_event (void* handle, void* event);
+int hps_engine_copy_async (void* handle, void* dst_dev, const void* src_dev, long bytes);
+
 /* ---- ring pipeline over time steps (utils/MultiBuffer.H:21-34; MultiBuffer.cpp:444-609) --------
  * The hand-off itself is issued by the host driver (hipace_amd/pipeline.py) with RCCL
  * point-to-point (torch.distributed backend "nccl") on the beam blocks above. */

@@ -298,8 +298,8 @@ class Engine:
         self.g = lib().orc_engine_guards(self._h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_engine_destroy(self._h)
+        if getattr(self, "_h", None) and _LIB is not None:     # (_LIB is gone at interpreter shutdown)
+            _LIB.orc_engine_destroy(self._h)
             self._h = None
 
     def run(self):
@@ -394,6 +394,16 @@ class Engine:
 
     def sync(self):
         pass
+
+    # stream coupling of pipeline.run_local_pipeline: the oracle runs on the calling thread, nothing to order
+    def record_event(self, slot):
+        return None
+
+    def wait_event(self, event):
+        pass
+
+    def copy_async(self, dst, src):
+        dst.copy_(src)
 
     def checksums(self):
         out = np.zeros(self.ncomp)

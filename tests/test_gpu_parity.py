@@ -584,3 +584,29 @@ def test_beam_sort_by_box_bit_exact(api, oracle, n, num_boxes):
     assert np.array_equal(got.boxOffsets, want[1])
     assert np.array_equal(got.boxPermutations, want[2])
     assert int(got.boxCounts.sum()) == n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes,n_steps", [(2, 3), (3, 5)])
+def test_several_steps_in_flight_on_one_gpu(api, lanes, n_steps):
+    """pipeline.run_local_pipeline on the GPU: `lanes` engines on their own streams, coupled by events and the
+    per-slice beam copy, reproduce the reference's blowout_wake checksums on every step."""
+    import torch
+    from hipace_amd.pipeline import run_local_pipeline
+    gold = json.load(open(os.path.join(GOLD, "blowout_wake_explicit.2Rank.json")))["lev=0"]
+    deck = decks.blowout_wake()
+    deck["n_steps"] = 1
+    engs = [api.SliceEngine(deck, tile_size=16, sort_period=16) for _ in range(lanes)]
+    for e in engs:
+        e.set_diagnostics(True)
+    got = {}
+
+    def on_step_end(step, eng):
+        eng.sync()
+        got[step] = eng.checksums()
+
+    solved = run_local_pipeline(engs, n_steps, torch.device("cuda", 0), on_step_end)
+    assert solved == n_steps * deck["nz"] and sorted(got) == list(range(n_steps))
+    for step, cs in got.items():
+        for k, v in gold.items():
+            assert abs(cs[k] - v) <= 1e-9 * abs(v), (step, k, cs[k], v)

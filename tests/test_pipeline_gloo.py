@@ -120,3 +120,26 @@ def test_ring_pipeline_hands_a_moving_beam_on(oracle, world, n_steps):
             for k, v in want[step].items():
                 assert cs[k] == v, (rank, step, k, cs[k], v)
     assert seen == set(range(n_steps))
+
+
+@pytest.mark.parametrize("lanes,n_steps", [(1, 2), (2, 3), (3, 4), (3, 7)])
+def test_local_pipeline_several_steps_in_flight(oracle, lanes, n_steps):
+    """pipeline.run_local_pipeline: the ring with all its stages in one process (one engine per step in flight, one
+    host thread each, hand-off by copy) gives every step the checksums of a single run -- also when the ring closes
+    (more steps than lanes)."""
+    from hipace_amd.pipeline import run_local_pipeline
+    ref = oracle.Engine(_deck())
+    ref.run()
+    want = ref.checksums()
+    engs = [oracle.Engine(_deck()) for _ in range(lanes)]
+    got = {}
+
+    def on_step_end(step, eng):
+        got[step] = eng.checksums()
+
+    solved = run_local_pipeline(engs, n_steps, "cpu", on_step_end)
+    assert solved == n_steps * _deck()["nz"]
+    assert sorted(got) == list(range(n_steps))
+    for step, cs in got.items():
+        for k, v in want.items():
+            assert abs(cs[k] - v) <= 1e-12 * max(abs(v), 1e-300), (step, k, cs[k], v)
