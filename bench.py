@@ -81,6 +81,10 @@ def main():
     ap.add_argument("--tile", type=int, default=16, help="particle tile size (0, 16, 32)")
     ap.add_argument("--sort-period", type=int, default=128, help="max slices between particle re-sorts (adaptive below)")
     ap.add_argument("--cpu-slices", type=int, default=4, help="slices of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="time steps in flight on one GPU (hipace_amd/pipeline.py::run_local_pipeline): L engines on L "
+                         "streams, step s+1 trails step s by the per-slice beam hand-off.  Needs --steps >= L boxes; "
+                         "N = 1 only.  Default 1 = the same schedule as one rank of the multi-GPU ring")
     ap.add_argument("--config2", action="store_true",
                     help="BASELINE config 2 instead of the headline workload: linear_wake 256x256x512, 4 ppc, "
                          "predictor-corrector Bx/By solver (not the judged bench line)")
@@ -108,6 +112,11 @@ def main():
         # (the loop's cost depends on the slice: every run_slices() starts a box from its head)
         args.cpu_slices = 0
     eng = api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period)
+    lanes = 1
+    if world == 1 and args.inflight > 1 and not args.config2:
+        lanes = max(1, min(args.inflight, args.steps // nz))      # whole boxes only: head slices are cheaper than the rest
+    engines = [eng] + [api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period)
+                       for _ in range(lanes - 1)]
 
     def run_slices(count, profile=False):
         done = 0
@@ -125,10 +134,17 @@ def main():
             dist.barrier()
 
     run_slices(args.warmup)
-    eng.set_profiling(True)
+    if lanes > 1:
+        from hipace_amd.pipeline import run_local_pipeline
+        run_local_pipeline(engines, lanes, torch.device("cuda", local), slices_per_step=max(2, args.warmup))   # warm every lane
+    for e in engines:
+        e.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
-    if world == 1:
+    if world == 1 and lanes > 1:
+        boxes = args.steps // nz
+        args.steps = run_local_pipeline(engines, boxes, torch.device("cuda", local))
+    elif world == 1:
         run_slices(args.steps)
     else:
         # ring pipeline over time steps: every rank sweeps `steps` slices of its own step(s); the beam
@@ -143,6 +159,12 @@ def main():
     dt = time.perf_counter() - t0
     phases, nprof = eng.phase_times()
     eng.set_profiling(False)
+    for e in engines[1:]:            # phase times: mean over the lanes (intervals overlap in wall time)
+        ph, n = e.phase_times()
+        e.set_profiling(False)
+        for k in phases:
+            phases[k] += ph[k]
+        nprof += n
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -165,7 +187,8 @@ def main():
                                     "order 2, explicit Bx/By solver, dt=0 (BASELINE.md section 3)") if not args.config2 else
                                    "linear_wake.normalized 256x256x512, 4 ppc, order 2, predictor-corrector Bx/By solver "
                                    "(tolerance 4e-2, <= 30 iterations, mixing 0.05), dt=0 (BASELINE.json configs[1])",
-                       "parallelism": f"time-step pipeline x{world}"},
+                       "parallelism": f"time-step pipeline x{world}" + (f", {lanes} steps in flight per GPU" if lanes > 1 else "")},
+            "steps_in_flight": lanes,
             "phase_ms_per_slice": per_kernel,
             "vcycles_per_slice": eng.stats()["vcycles"] / max(eng.stats()["slices"], 1),
             "pc_iterations_per_slice": eng.pc_stats()[0] / max(eng.stats()["slices"], 1) if args.config2 else None,
