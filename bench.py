@@ -108,12 +108,12 @@ def main():
         nz, args.n, args.ppc = 512, 256, 2
         deck = decks.predictor_corrector(decks.linear_wake(), 4.0e-2, 30, 0.05)
         deck.update(nx=256, ny=256, nz=nz, plasma_ppc=(2, 2))
-        args.steps = min(args.steps, nz)
+        args.steps = min(args.steps, nz) if args.inflight <= 1 else args.steps
         # (the loop's cost depends on the slice: every run_slices() starts a box from its head)
         args.cpu_slices = 0
     eng = api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period)
     lanes = 1
-    if world == 1 and args.inflight > 1 and not args.config2:
+    if world == 1 and args.inflight > 1:
         lanes = max(1, min(args.inflight, args.steps // nz))      # whole boxes only: head slices are cheaper than the rest
     engines = [eng] + [api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period)
                        for _ in range(lanes - 1)]
