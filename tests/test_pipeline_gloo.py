@@ -61,7 +61,7 @@ def _worker(rank, world, port, n_steps, out, moving=False, pc=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_steps,pc", [(2, 3, False), (2, 2, False), (1, 2, False), (2, 2, True)])
+@pytest.mark.parametrize("world,n_steps,pc", [(2, 3, False), (2, 2, False), (1, 2, False), (2, 2, True), (4, 9, False)])
 def test_ring_pipeline_matches_single_process(oracle, world, n_steps, pc):
     ref = oracle.Engine(_deck(pc))
     ref.run()
