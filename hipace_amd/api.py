@@ -342,6 +342,24 @@ class SliceEngine:
     def initial_beam_into(self, tensor):
         check(_lib.lib().hps_engine_initial_beam(self._h, C.c_void_p(tensor.data_ptr())))
 
+    # ---- field diagnostics (Fields::Copy) -----------------------------------------------------------------
+    def set_field_diagnostic(self, names, coarsening=(1, 1, 1)):
+        """diagnostic.field_data = names, diagnostic.coarsening = cx cy cz (diag_type xyz, whole box)."""
+        idx = _lib.CIDX_PC if self.deck.get("bxby_solver", 0) else _lib.CIDX
+        comps = (C.c_int * len(names))(*[idx[n] for n in names])
+        co = (C.c_int * 3)(*coarsening)
+        check(_lib.lib().hps_engine_set_field_diagnostic(self._h, len(names), comps, co))
+        self._fd = (list(names), tuple(coarsening))
+
+    def field_diagnostic(self):
+        """-> dict name -> array [nz/cz, ny/cy, nx/cx] of the step that is being (or has just been) solved."""
+        names, co = self._fd
+        d = self.deck
+        shp = (len(names), d["nz"] // co[2], d["ny"] // co[1], d["nx"] // co[0])
+        out = np.empty(shp)
+        check(_lib.lib().hps_engine_field_diagnostic(self._h, out.ctypes.data_as(C.c_void_p)))
+        return {n: out[i] for i, n in enumerate(names)}
+
     # ---- several steps in flight on one device (pipeline.run_local_pipeline) ----------------------------
     def record_event(self, slot):
         """Mark this engine's stream; returns the event another engine can wait for."""

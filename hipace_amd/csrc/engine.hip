@@ -254,6 +254,7 @@ Engine::~Engine ()
     (void)hipFree(bm_store); (void)hipFree(bm_nsub); (void)hipFree(bm_nsub_scr); (void)hipFree(d_B); (void)hipFree(d_nfront);
     (void)hipFree(d_Bimp); (void)hipFree(d_beam_overflow); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
     (void)hipFree(d_pc); if (h_pc) (void)hipHostFree(h_pc);
+    (void)hipFree(d_fd); (void)hipFree(d_fd_comps);
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto e : hand_ev) if (e) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
@@ -475,6 +476,7 @@ int Engine::begin_step ()
     // ResetAllQuantities (Hipace.cpp:730-742)
     HPS_HIP_CHECK(hipMemsetAsync(slab.p, 0, (size_t)slab.nstride*ncomp*sizeof(double), st));
     HPS_HIP_CHECK(hipMemsetAsync(d_checksum, 0, HPS_PC_NCOMP_MAX*sizeof(double), st));
+    if (d_fd) HPS_HIP_CHECK(hipMemsetAsync(d_fd, 0, fd_comps.size()*(size_t)(d.nx/fd_c[0])*(d.ny/fd_c[1])*(d.nz/fd_c[2])*sizeof(double), st));
     if (np > 0) {
         const int nppc = d.plasma_ppc[0]*d.plasma_ppc[1];
         hipLaunchKernelGGL(k_init_plasma, dim3(ceil_div(np, 256)), dim3(256), 0, st, pl, d.nx, d.ny,
@@ -519,6 +521,66 @@ void Engine::mark ()
     if (!profiling) return;
     if (ev_used == ev.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev.push_back(e); }
     (void)hipEventRecord(ev[ev_used++], st);
+}
+
+// ---- field diagnostics (Fields::Copy, fields/Fields.cpp:413-533) ---------------------------------------------------
+// F(i,j,k,n) += rel_z * sum_{iy,ix} sy[iy] sx[ix] slab(i_cell+ix, j_cell+iy, comp n), order-1 shape factors at the
+// diagnostic cell centre, slab zero-extended beyond its guard cells (guarded_field_xy, Fields.cpp:331-358)
+__global__ __launch_bounds__(256)
+void k_diag_copy (SlabView f, int ncomp_slab, const int* __restrict__ comps, int ncd, double* __restrict__ F,
+                  int nxc, int nyc, long kplane_off, long comp_stride, double rel_z,
+                  double dxc, double dyc, double poff_dx, double poff_dy, double poff_cx, double poff_cy,
+                  double dx_inv, double dy_inv)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= nxc) return;
+    const double x = i*dxc + poff_dx, y = j*dyc + poff_dy;
+    const double xmid = (x - poff_cx)*dx_inv, ymid = (y - poff_cy)*dy_inv;
+    const int ic = (int)floor(xmid), jc = (int)floor(ymid);
+    const double tx = xmid - ic, ty = ymid - jc;
+    const double sx[2] = {1.0 - tx, tx}, sy[2] = {1.0 - ty, ty};
+    for (int n = 0; n < ncd; ++n) {
+        const int m = comps[n];
+        double v = 0.0;
+        for (int iy = 0; iy < 2; ++iy) for (int ix = 0; ix < 2; ++ix) {
+            const int ii = ic + ix, jj = jc + iy;
+            const bool in = ii >= -f.ng && ii < f.nx + f.ng && jj >= -f.ng && jj < f.ny + f.ng;
+            v += sx[ix]*sy[iy]*(in ? f(ii, jj, m) : 0.0);
+        }
+        F[n*comp_stride + kplane_off + (long)j*nxc + i] += rel_z*v;
+    }
+    (void)ncomp_slab;
+}
+
+int Engine::fill_field_diagnostic (int islice)
+{
+    if (fd_comps.empty()) return HPS_OK;
+    const int nxc = d.nx/fd_c[0], nyc = d.ny/fd_c[1], nzc = d.nz/fd_c[2];
+    const double dzc = (d.hi[2] - d.lo[2])/nzc, dxc = (d.hi[0] - d.lo[0])/nxc, dyc = (d.hi[1] - d.lo[1])/nyc;
+    // GetPosOffset (fields/Fields.H:71-77) of the calculation and of the diagnostic geometry
+    auto poff = [] (double lo, double hi, double h, int n) { return 0.5*(lo + hi - h*(n - 1)); };
+    const double poff_cz = poff(d.lo[2], d.hi[2], gm.dz, d.nz), poff_dz = poff(d.lo[2], d.hi[2], dzc, nzc);
+    const double poff_dx = poff(d.lo[0], d.hi[0], dxc, nxc), poff_dy = poff(d.lo[1], d.hi[1], dyc, nyc);
+    // which diagnostic planes this slice contributes to (order 1 in z, :428-468)
+    const double pos_min = (islice - 1)*gm.dz + poff_cz, pos_max = (islice + 1)*gm.dz + poff_cz;
+    const int k_min = (int)std::round((pos_min - poff_dz)*(1.0/dzc)), k_max = (int)std::round((pos_max - poff_dz)*(1.0/dzc));
+    SlabView f(slab);
+    const long plane = (long)nxc*nyc, cstride = plane*nzc;
+    for (int k = std::max(k_min, 0); k <= std::min(k_max, nzc - 1); ++k) {
+        const double pos = k*dzc + poff_dz;
+        const double mid = (pos - poff_cz)*(1.0/gm.dz);
+        const int kc = (int)std::floor(mid);
+        const double t = mid - kc;
+        double rel = 0.0;
+        if (kc == islice) rel = 1.0 - t;
+        if (kc + 1 == islice) rel = t;
+        if (rel == 0.0) continue;
+        hipLaunchKernelGGL(k_diag_copy, dim3(ceil_div(nxc, 256), nyc), dim3(256), 0, st, f, ncomp, d_fd_comps, (int)fd_comps.size(),
+                           d_fd, nxc, nyc, (long)k*plane, cstride, rel, dxc, dyc, poff_dx, poff_dy, gm.xoff, gm.yoff,
+                           1.0/gm.dx, 1.0/gm.dy);
+    }
+    return HPS_OK;
 }
 
 // ---- predictor-corrector Bx/By (Hipace::PredictorCorrectorLoopToSolveBxBy, Hipace.cpp:935-1031) ----------------
@@ -698,6 +760,7 @@ int Engine::solve_slice_pc (int islice)
     mark();   // b6
     if (diagnostics)
         hipLaunchKernelGGL(k_checksum, dim3(64, ncomp), b256, 0, st, f, ncomp, d_checksum);
+    if ((e = fill_field_diagnostic(islice))) return e;
     mark();   // b7
     if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st))) return e; }
     else        { if ((e = hps_advance_plasma(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; }
@@ -779,6 +842,7 @@ int Engine::solve_slice (int islice)
     mark();   // b6
     if (diagnostics)
         hipLaunchKernelGGL(k_checksum, dim3(64, ncomp), b256, 0, st, f, ncomp, d_checksum);
+    if ((e = fill_field_diagnostic(islice))) return e;      // FillFieldDiagnostics (Hipace.cpp:691)
 
     mark();   // b7
     // gather + push (Hipace.cpp:699-701)
@@ -848,6 +912,36 @@ extern "C" int hps_engine_stats (void* h, long* vc, long* sl)
     Engine* E = static_cast<Engine*>(h);
     if (vc) *vc = E->total_vcycles;
     if (sl) *sl = E->slices_done;
+    return HPS_OK;
+}
+extern "C" int hps_engine_set_field_diagnostic (void* h, int ncomps, const int* comps, const int coarsening[3])
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    (void)hipFree(E->d_fd); (void)hipFree(E->d_fd_comps); E->d_fd = nullptr; E->d_fd_comps = nullptr; E->fd_comps.clear();
+    if (ncomps <= 0) return HPS_OK;
+    HPS_REQUIRE(comps && coarsening, "hps_engine_set_field_diagnostic: null argument");
+    for (int k = 0; k < ncomps; ++k) HPS_REQUIRE(comps[k] >= 0 && comps[k] < E->ncomp, "hps_engine_set_field_diagnostic: bad component");
+    const int n3[3] = {E->d.nx, E->d.ny, E->d.nz};
+    for (int q = 0; q < 3; ++q) {
+        HPS_REQUIRE(coarsening[q] >= 1 && n3[q] % coarsening[q] == 0, "hps_engine_set_field_diagnostic: sizes must be divisible by the coarsening");
+        E->fd_c[q] = coarsening[q];
+    }
+    E->fd_comps.assign(comps, comps + ncomps);
+    const size_t cells = (size_t)(n3[0]/E->fd_c[0])*(n3[1]/E->fd_c[1])*(n3[2]/E->fd_c[2]);
+    HPS_HIP_CHECK(hipMalloc(&E->d_fd, ncomps*cells*sizeof(double)));
+    HPS_HIP_CHECK(hipMemset(E->d_fd, 0, ncomps*cells*sizeof(double)));
+    HPS_HIP_CHECK(hipMalloc(&E->d_fd_comps, ncomps*sizeof(int)));
+    HPS_HIP_CHECK(hipMemcpy(E->d_fd_comps, comps, ncomps*sizeof(int), hipMemcpyHostToDevice));
+    return HPS_OK;
+}
+extern "C" int hps_engine_field_diagnostic (void* h, double* out)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E->d_fd && out, "hps_engine_field_diagnostic: no diagnostic set");
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    const size_t cells = (size_t)(E->d.nx/E->fd_c[0])*(E->d.ny/E->fd_c[1])*(E->d.nz/E->fd_c[2]);
+    HPS_HIP_CHECK(hipMemcpy(out, E->d_fd, E->fd_comps.size()*cells*sizeof(double), hipMemcpyDeviceToHost));
     return HPS_OK;
 }
 extern "C" int hps_engine_record_event (void* h, int slot, void** out)

@@ -204,6 +204,16 @@ int hps_engine_stats (void* handle, long* total_vcycles, long* slices_done);
 int hps_engine_pc_stats (void* handle, long* iterations, double* error_sum);
 /* accumulate the per-slice checksums (costs one reduction pass per slice; off by default) */
 int hps_engine_set_diagnostics (void* handle, int on);
+/* Field diagnostics (Fields::Copy, fields/Fields.cpp:413-533; geometry of Diagnostic::ResizeFDiagFAB,
+ * diagnostics/Diagnostic.cpp:300-390; diag_type xyz over the whole box, level 0): a device-resident 3-D array
+ * F[ncomps][nz/cz][ny/cy][nx/cx] (x fastest) that every solved slice adds its share to -- linear interpolation of the
+ * zero-extended slab components onto the diagnostic grid in x, y and z, exactly as diagnostic.coarsening = cx cy cz
+ * does (1 1 1 = plain copy).  Sizes must be divisible by the coarsening.  The array is cleared by
+ * hps_engine_begin_step; hps_engine_field_diagnostic copies it to the host (synchronises the stream).
+ * Call set before hps_engine_begin_step; ncomps = 0 switches it off. */
+int hps_engine_set_field_diagnostic (void* handle, int ncomps, const int* comps, const int coarsening[3]);
+int hps_engine_field_diagnostic (void* handle, double* out_host);
+
 /* particle tiling of the engine: tile_size 0 = per-particle global-atomic kernels, 16 | 32 = LDS
  * tiles, re-sorted after sort_period slices at the latest (plasmas.reorder_period of the reference; see hps_engine_sorts).
  * Call before hps_engine_begin_step. */

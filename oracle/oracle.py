@@ -272,6 +272,66 @@ def mg_solve1(sol2, rhs2, acf, nx, ny, g, dx, dy, tol_rel=1e-4, tol_abs=2.225073
     return it, rn.value
 
 
+class FieldDiagnostic:
+    """Fields::Copy (fields/Fields.cpp:413-533) on the diagnostic geometry of Diagnostic::ResizeFDiagFAB
+    (diagnostics/Diagnostic.cpp:300-390; diag_type xyz, whole box, level 0): every solved slice adds
+    rel_z[k] * sum_{iy,ix} sy[iy] sx[ix] slab(i_cell+ix, j_cell+iy, comp) to F(i, j, k, comp), with the order-1 shape
+    factors (ShapeFactors.H:56-67) of the diagnostic cell centres in x, y and of the diagnostic planes in z; the slab is
+    zero-extended beyond its guard cells (guarded_field_xy, Fields.cpp:331-358).  Feed it the engine's slab after every
+    solve_slice: push and ShiftSlices leave the field components untouched."""
+
+    def __init__(self, deck, comps, coarsening=(1, 1, 1)):
+        self.d, self.comps, self.c = deck, list(comps), tuple(coarsening)
+        nx, ny, nz = deck["nx"], deck["ny"], deck["nz"]
+        assert nx % self.c[0] == 0 and ny % self.c[1] == 0 and nz % self.c[2] == 0
+        self.n = (nx // self.c[0], ny // self.c[1], nz // self.c[2])
+        self.F = np.zeros((len(self.comps), self.n[2], self.n[1], self.n[0]))
+
+    @staticmethod
+    def _poff(lo, hi, h, n):          # GetPosOffset (fields/Fields.H:71-77)
+        return 0.5 * (lo + hi - h * (n - 1))
+
+    def add_slice(self, islice, slab, g):
+        d = self.d
+        h = [(d["hi"][q] - d["lo"][q]) / (d["nx"], d["ny"], d["nz"])[q] for q in range(3)]
+        hc = [(d["hi"][q] - d["lo"][q]) / self.n[q] for q in range(3)]
+        pc = [self._poff(d["lo"][q], d["hi"][q], h[q], (d["nx"], d["ny"], d["nz"])[q]) for q in range(3)]
+        pd = [self._poff(d["lo"][q], d["hi"][q], hc[q], self.n[q]) for q in range(3)]
+
+        def round_half_away(v):
+            return int(np.floor(abs(v) + 0.5) * np.sign(v))
+        k_min = round_half_away(((islice - 1) * h[2] + pc[2] - pd[2]) * (1.0 / hc[2]))
+        k_max = round_half_away(((islice + 1) * h[2] + pc[2] - pd[2]) * (1.0 / hc[2]))
+        # transverse weights of the diagnostic cell centres
+        def weights(q, ncoarse):
+            x = np.arange(ncoarse) * hc[q] + pd[q]
+            mid = (x - pc[q]) * (1.0 / h[q])
+            cell = np.floor(mid).astype(np.int64)
+            t = mid - cell
+            return cell, np.stack([1.0 - t, t])
+        ic, sx = weights(0, self.n[0])
+        jc, sy = weights(1, self.n[1])
+        ny_p, nx_p = slab.shape[1], slab.shape[2]
+        for k in range(max(k_min, 0), min(k_max, self.n[2] - 1) + 1):
+            mid = (k * hc[2] + pd[2] - pc[2]) * (1.0 / h[2])
+            kc = int(np.floor(mid))
+            t = mid - kc
+            rel = (1.0 - t) if kc == islice else (t if kc + 1 == islice else 0.0)
+            if rel == 0.0:
+                continue
+            for n, m in enumerate(self.comps):
+                A = slab[m]
+                v = np.zeros((self.n[1], self.n[0]))
+                for iy in range(2):
+                    for ix in range(2):
+                        jj = jc + iy + g
+                        ii = ic + ix + g
+                        ok = ((jj >= 0) & (jj < ny_p))[:, None] & ((ii >= 0) & (ii < nx_p))[None, :]
+                        val = A[np.clip(jj, 0, ny_p - 1)[:, None], np.clip(ii, 0, nx_p - 1)[None, :]]
+                        v = v + (sx[ix][None, :] * sy[iy][:, None]) * np.where(ok, val, 0.0)
+                self.F[n, k] += rel * v
+
+
 def beam_sort_by_box(z, plo_z, dz, num_boxes):
     """BoxSorter::sortParticlesByBox (particles/sorting/BoxSort.cpp:14-78), serial CPU semantics: box =
     static_cast<int>((z - plo_z) * dzi) (truncation toward zero), out of [0, num_boxes] -> num_boxes; counts,

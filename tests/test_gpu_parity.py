@@ -610,3 +610,37 @@ def test_several_steps_in_flight_on_one_gpu(api, lanes, n_steps):
     for step, cs in got.items():
         for k, v in gold.items():
             assert abs(cs[k] - v) <= 1e-9 * abs(v), (step, k, cs[k], v)
+
+
+# ---- field diagnostics (Fields::Copy into the 3-D output array) ------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("coarsening", [(1, 1, 1), (3, 4, 5), (2, 2, 2)])
+def test_field_diagnostic_matches_oracle(api, oracle, coarsening):
+    """hps_engine_set_field_diagnostic / field_diagnostic against the oracle's restatement of Fields::Copy (itself
+    pinned by the reference's analysis_coarsening criterion): 60 x 60 x 100 blowout deck, the fields the reference's
+    coarsening test writes, <= 1e-9 of each field's maximum; coarsening 1 1 1 also reproduces the checksums."""
+    deck = decks.blowout_wake()
+    deck.update(nx=60, ny=60, nz=100, n_steps=1)
+    names = ["Ez", "ExmBy", "EypBx", "Bx", "By", "Bz"]
+    ge = api.SliceEngine(deck, tile_size=16, sort_period=16)
+    ge.set_diagnostics(True)
+    ge.set_field_diagnostic(names, coarsening)
+    oe = oracle.Engine(deck)
+    od = oracle.FieldDiagnostic(deck, [oracle.CIDX[n] for n in names], coarsening)
+    ge.begin_step()
+    oe.begin_step()
+    for isl in range(deck["nz"] - 1, -1, -1):
+        ge.solve_slice(isl)
+        oe.solve_slice(isl)
+        od.add_slice(isl, oe.slab(), oe.g)
+    got = ge.field_diagnostic()
+    for n, name in enumerate(names):
+        assert got[name].shape == od.F[n].shape
+        assert np.abs(got[name] - od.F[n]).max() <= 1e-9 * np.abs(od.F[n]).max(), name
+    if coarsening == (1, 1, 1):
+        cs = ge.checksums()
+        for name in names:
+            assert abs(np.abs(got[name]).sum() - cs[name]) <= 1e-12 * cs[name]
+    # a second step starts from a cleared array
+    ge.begin_step()
+    assert all(np.all(v == 0.0) for v in ge.field_diagnostic().values())

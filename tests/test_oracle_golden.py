@@ -71,3 +71,34 @@ def test_predictor_corrector_agrees_with_explicit_solver(oracle):
             den[k] += float((a ** 2).sum())
     for k in names:
         assert num[k] / den[k] < 0.006, (k, num[k] / den[k])
+
+
+def test_field_diagnostic_coarsening_as_the_reference_checks_it(oracle):
+    """tests/output_coarsening.2Rank.sh -> examples/blowout_wake/analysis_coarsening.py:27-40: the output written with
+    diagnostic.coarsening = 3 4 5 on 60 x 60 x 100 cells equals (F[2::5, 1::4, 1::3] + F[2::5, 2::4, 1::3]) / 2 of the
+    full-resolution output to 3e-14 of its maximum (odd factors pick the centre cell, even ones average the two
+    central cells).  Pins the oracle's restatement of Fields::Copy and of the diagnostic geometry."""
+    import numpy as np
+    deck = decks.blowout_wake()
+    deck.update(nx=60, ny=60, nz=100, n_steps=1)
+    eng = oracle.Engine(deck)
+    names = ["Ez", "ExmBy", "EypBx", "Bx", "By", "Bz"]
+    comps = [oracle.CIDX[n] for n in names]
+    fine = oracle.FieldDiagnostic(deck, comps, (1, 1, 1))
+    coarse = oracle.FieldDiagnostic(deck, comps, (3, 4, 5))
+    eng.begin_step()
+    for isl in range(deck["nz"] - 1, -1, -1):
+        eng.solve_slice(isl)
+        sl = eng.slab()
+        fine.add_slice(isl, sl, eng.g)
+        coarse.add_slice(isl, sl, eng.g)
+    assert coarse.F.shape == (6, 20, 15, 20)
+    for n in range(len(names)):
+        F = fine.F[n]
+        want = (F[2::5, 1::4, 1::3] + F[2::5, 2::4, 1::3]) / 2
+        err = np.max(np.abs(coarse.F[n] - want)) / np.max(np.abs(want))
+        assert err < 3.0e-14, (names[n], err)
+    # coarsening 1 1 1 is a plain copy of the slices
+    cs = eng.checksums()
+    for n, name in enumerate(names):
+        assert abs(np.abs(fine.F[n]).sum() - cs[name]) <= 1e-12 * cs[name]
