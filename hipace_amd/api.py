@@ -360,6 +360,19 @@ class SliceEngine:
         check(_lib.lib().hps_engine_field_diagnostic(self._h, out.ctypes.data_as(C.c_void_p)))
         return {n: out[i] for i, n in enumerate(names)}
 
+    INSITU_FIELDS = ["[Ex^2]", "[Ey^2]", "[Ez^2]", "[Bx^2]", "[By^2]", "[Bz^2]", "[ExmBy^2]", "[EypBx^2]", "[jz_beam]",
+                     "[Ez*jz_beam]"]
+
+    def set_insitu_fields(self, on=True):
+        """fields.insitu_period: per-slice reductions of Fields::InSituComputeDiags."""
+        check(_lib.lib().hps_engine_set_insitu_fields(self._h, int(on)))
+
+    def insitu_fields(self):
+        """-> dict name -> array[nz] (index = islice) with the reference's names (Fields.cpp:1380-1389)."""
+        out = np.empty((10, self.deck["nz"]))
+        check(_lib.lib().hps_engine_insitu_fields(self._h, out.ctypes.data_as(C.c_void_p)))
+        return {n: out[i] for i, n in enumerate(self.INSITU_FIELDS)}
+
     # ---- several steps in flight on one device (pipeline.run_local_pipeline) ----------------------------
     def record_event(self, slot):
         """Mark this engine's stream; returns the event another engine can wait for."""

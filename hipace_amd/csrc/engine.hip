@@ -254,7 +254,7 @@ Engine::~Engine ()
     (void)hipFree(bm_store); (void)hipFree(bm_nsub); (void)hipFree(bm_nsub_scr); (void)hipFree(d_B); (void)hipFree(d_nfront);
     (void)hipFree(d_Bimp); (void)hipFree(d_beam_overflow); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
     (void)hipFree(d_pc); if (h_pc) (void)hipHostFree(h_pc);
-    (void)hipFree(d_fd); (void)hipFree(d_fd_comps);
+    (void)hipFree(d_fd); (void)hipFree(d_fd_comps); (void)hipFree(d_insitu);
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto e : hand_ev) if (e) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
@@ -476,6 +476,7 @@ int Engine::begin_step ()
     // ResetAllQuantities (Hipace.cpp:730-742)
     HPS_HIP_CHECK(hipMemsetAsync(slab.p, 0, (size_t)slab.nstride*ncomp*sizeof(double), st));
     HPS_HIP_CHECK(hipMemsetAsync(d_checksum, 0, HPS_PC_NCOMP_MAX*sizeof(double), st));
+    if (d_insitu) HPS_HIP_CHECK(hipMemsetAsync(d_insitu, 0, (size_t)10*d.nz*sizeof(double), st));
     if (d_fd) HPS_HIP_CHECK(hipMemsetAsync(d_fd, 0, fd_comps.size()*(size_t)(d.nx/fd_c[0])*(d.ny/fd_c[1])*(d.nz/fd_c[2])*sizeof(double), st));
     if (np > 0) {
         const int nppc = d.plasma_ppc[0]*d.plasma_ppc[1];
@@ -551,6 +552,35 @@ void k_diag_copy (SlabView f, int ncomp_slab, const int* __restrict__ comps, int
         F[n*comp_stride + kplane_off + (long)j*nxc + i] += rel_z*v;
     }
     (void)ncomp_slab;
+}
+
+// Fields::InSituComputeDiags (fields/Fields.cpp:1288-1347): ten sums over the valid cells of one slice
+__global__ __launch_bounds__(256)
+void k_insitu_fields (SlabView f, double clight, double dxdydz, double* out, int nz, int islice)
+{
+    double s[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const long cells = (long)f.nx*f.ny;
+    for (long c = (long)blockIdx.x*blockDim.x + threadIdx.x; c < cells; c += (long)gridDim.x*blockDim.x) {
+        const int j = (int)(c / f.nx), i = (int)(c - (long)j*f.nx);
+        const long o = f.off(i, j);
+        const double exmby = f.p[HPS_C_EXMBY*f.ns + o], eypbx = f.p[HPS_C_EYPBX*f.ns + o], ez = f.p[HPS_C_EZ*f.ns + o];
+        const double bx = f.p[HPS_C_BX*f.ns + o], by = f.p[HPS_C_BY*f.ns + o], bz = f.p[HPS_C_BZ*f.ns + o];
+        const double jzb = f.p[HPS_C_JZB*f.ns + o];
+        const double ex = exmby + by*clight, ey = eypbx - bx*clight;
+        s[0] += ex*ex; s[1] += ey*ey; s[2] += ez*ez; s[3] += bx*bx; s[4] += by*by; s[5] += bz*bz;
+        s[6] += exmby*exmby; s[7] += eypbx*eypbx; s[8] += jzb; s[9] += ez*jzb;
+    }
+    __shared__ double part[4][10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        double v = s[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10)
+        atomic_add_f64(out + (long)threadIdx.x*nz + islice,
+                       (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x])*dxdydz);
 }
 
 int Engine::fill_field_diagnostic (int islice)
@@ -843,6 +873,8 @@ int Engine::solve_slice (int islice)
     if (diagnostics)
         hipLaunchKernelGGL(k_checksum, dim3(64, ncomp), b256, 0, st, f, ncomp, d_checksum);
     if ((e = fill_field_diagnostic(islice))) return e;      // FillFieldDiagnostics (Hipace.cpp:691)
+    if (d_insitu)                                           // Fields::InSituComputeDiags (Hipace.cpp:686)
+        hipLaunchKernelGGL(k_insitu_fields, dim3(64), b256, 0, st, f, gm.c, gm.dx*gm.dy*gm.dz, d_insitu, d.nz, islice);
 
     mark();   // b7
     // gather + push (Hipace.cpp:699-701)
@@ -912,6 +944,25 @@ extern "C" int hps_engine_stats (void* h, long* vc, long* sl)
     Engine* E = static_cast<Engine*>(h);
     if (vc) *vc = E->total_vcycles;
     if (sl) *sl = E->slices_done;
+    return HPS_OK;
+}
+extern "C" int hps_engine_set_insitu_fields (void* h, int on)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    (void)hipFree(E->d_insitu); E->d_insitu = nullptr;
+    if (!on) return HPS_OK;
+    if (E->pc) { set_error("hps_engine_set_insitu_fields: explicit solver only (needs jz_beam), as the reference"); return HPS_ERR_UNSUPPORTED; }
+    HPS_HIP_CHECK(hipMalloc(&E->d_insitu, (size_t)10*E->d.nz*sizeof(double)));
+    HPS_HIP_CHECK(hipMemset(E->d_insitu, 0, (size_t)10*E->d.nz*sizeof(double)));
+    return HPS_OK;
+}
+extern "C" int hps_engine_insitu_fields (void* h, double* out)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E->d_insitu && out, "hps_engine_insitu_fields: not switched on");
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    HPS_HIP_CHECK(hipMemcpy(out, E->d_insitu, (size_t)10*E->d.nz*sizeof(double), hipMemcpyDeviceToHost));
     return HPS_OK;
 }
 extern "C" int hps_engine_set_field_diagnostic (void* h, int ncomps, const int* comps, const int coarsening[3])

@@ -214,6 +214,13 @@ int hps_engine_set_diagnostics (void* handle, int on);
 int hps_engine_set_field_diagnostic (void* handle, int ncomps, const int* comps, const int coarsening[3]);
 int hps_engine_field_diagnostic (void* handle, double* out_host);
 
+/* In-situ field reductions (Fields::InSituComputeDiags, fields/Fields.cpp:1288-1347; explicit solver only, as the
+ * reference): per solved slice, dx dy dz * sum over the valid cells of {Ex^2, Ey^2, Ez^2, Bx^2, By^2, Bz^2, ExmBy^2,
+ * EypBx^2, jz_beam, Ez jz_beam} with Ex = ExmBy + c By, Ey = EypBx - c Bx.  out_host[q*nz + islice], q = 0..9, for the
+ * step that is being (or has just been) solved; cleared by hps_engine_begin_step; synchronises the stream. */
+int hps_engine_set_insitu_fields (void* handle, int on);
+int hps_engine_insitu_fields (void* handle, double* out_host /* [10*nz] */);
+
 /* particle tiling of the engine: tile_size 0 = per-particle global-atomic kernels, 16 | 32 = LDS
  * tiles, re-sorted after sort_period slices at the latest (plasmas.reorder_period of the reference; see hps_engine_sorts).
  * Call before hps_engine_begin_step. */

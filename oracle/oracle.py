@@ -332,6 +332,18 @@ class FieldDiagnostic:
                 self.F[n, k] += rel * v
 
 
+def insitu_fields(slab, g, deck, clight=1.0):
+    """Fields::InSituComputeDiags (fields/Fields.cpp:1288-1347) of one slice from the explicit-solver slab: the ten
+    sums over the valid cells, times dx dy dz, in the reference's order."""
+    v = lambda name: slab[CIDX[name]][g:-g, g:-g]
+    dxdydz = np.prod([(deck["hi"][q] - deck["lo"][q]) / (deck["nx"], deck["ny"], deck["nz"])[q] for q in range(3)])
+    ex = v("ExmBy") + v("By") * clight
+    ey = v("EypBx") - v("Bx") * clight
+    terms = [ex ** 2, ey ** 2, v("Ez") ** 2, v("Bx") ** 2, v("By") ** 2, v("Bz") ** 2, v("ExmBy") ** 2, v("EypBx") ** 2,
+             v("jz_beam"), v("Ez") * v("jz_beam")]
+    return np.array([t.sum() for t in terms]) * dxdydz
+
+
 def beam_sort_by_box(z, plo_z, dz, num_boxes):
     """BoxSorter::sortParticlesByBox (particles/sorting/BoxSort.cpp:14-78), serial CPU semantics: box =
     static_cast<int>((z - plo_z) * dzi) (truncation toward zero), out of [0, num_boxes] -> num_boxes; counts,

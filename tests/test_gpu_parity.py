@@ -644,3 +644,26 @@ def test_field_diagnostic_matches_oracle(api, oracle, coarsening):
     # a second step starts from a cleared array
     ge.begin_step()
     assert all(np.all(v == 0.0) for v in ge.field_diagnostic().values())
+
+
+@pytest.mark.gpu
+def test_insitu_field_reductions_match_oracle(api, oracle):
+    """Fields::InSituComputeDiags: the ten per-slice reductions of every slice of the blowout_wake deck against the
+    oracle's restatement on its own slab (<= 1e-10 of each quantity's largest slice value)."""
+    deck = decks.blowout_wake()
+    deck["n_steps"] = 1
+    ge = api.SliceEngine(deck, tile_size=16, sort_period=16)
+    ge.set_insitu_fields(True)
+    oe = oracle.Engine(deck)
+    ge.begin_step()
+    oe.begin_step()
+    want = np.zeros((10, deck["nz"]))
+    for isl in range(deck["nz"] - 1, -1, -1):
+        ge.solve_slice(isl)
+        oe.solve_slice(isl)
+        # jz_beam of this slice is still in place after the push (ShiftSlices moves jx/jy only)
+        want[:, isl] = oracle.insitu_fields(oe.slab(), oe.g, deck)
+    got = ge.insitu_fields()
+    for q, name in enumerate(api.SliceEngine.INSITU_FIELDS):
+        scale = np.abs(want[q]).max()
+        assert scale > 0 and np.abs(got[name] - want[q]).max() <= 1e-10 * scale, name
