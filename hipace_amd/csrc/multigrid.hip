@@ -1063,6 +1063,8 @@ struct Multigrid {
     // device / pinned buffers: one header slot (MG_NSUB words: a caller's counters ride along with the norm
     // read-back, see hps_mg_rider) followed by the norm slots; d_norms / h_norms point at slot 0
     unsigned long long *d_buf = nullptr, *h_buf = nullptr;
+    unsigned long long* h_buf_dev = nullptr;    // device address of the (mapped) pinned buffer: k_post_norms writes it
+    unsigned long long* h_seq = nullptr; unsigned long long* h_seq_dev = nullptr; unsigned long long seq = 0;
     unsigned long long* d_norms = nullptr;      // [0] residual, [1] rhs
     unsigned long long* h_norms = nullptr;      // pinned copy of d_norms (2 + MG_MAX_VCYCLES slots)
     int last_iters = 1;                         // V-cycles of the previous solve = speculation depth
@@ -1161,7 +1163,10 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
     HPS_HIP_CHECK(hipMalloc(&M->d_low, low.size()*sizeof(LowLev)));
     HPS_HIP_CHECK(hipMemcpy(M->d_low, low.data(), low.size()*sizeof(LowLev), hipMemcpyHostToDevice));
     HPS_HIP_CHECK(hipMalloc(&M->d_buf, (3 + MG_MAX_VCYCLES)*MG_NSUB*sizeof(unsigned long long)));
-    HPS_HIP_CHECK(hipHostMalloc(&M->h_buf, (3 + MG_MAX_VCYCLES)*MG_NSUB*sizeof(unsigned long long)));
+    HPS_HIP_CHECK(hipHostMalloc(&M->h_buf, ((3 + MG_MAX_VCYCLES)*MG_NSUB + 8)*sizeof(unsigned long long), hipHostMallocMapped));
+    HPS_HIP_CHECK(hipHostGetDevicePointer((void**)&M->h_buf_dev, M->h_buf, 0));
+    M->h_seq = M->h_buf + (3 + MG_MAX_VCYCLES)*MG_NSUB; M->h_seq_dev = M->h_buf_dev + (3 + MG_MAX_VCYCLES)*MG_NSUB;
+    *M->h_seq = 0ULL;
     HPS_HIP_CHECK(hipMemset(M->d_buf, 0, (3 + MG_MAX_VCYCLES)*MG_NSUB*sizeof(unsigned long long)));
     memset(M->h_buf, 0, (3 + MG_MAX_VCYCLES)*MG_NSUB*sizeof(unsigned long long));
     M->d_norms = M->d_buf + MG_NSUB; M->h_norms = M->h_buf + MG_NSUB;
@@ -1264,6 +1269,18 @@ static void vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
     restrict_residual_if_nodal<CC>(M, 0, sr, st);
 }
 
+// norm slots (and the rider words) -> mapped host memory, sequence number last behind a system-scope fence: the host
+// polls it instead of a DMA copy + stream synchronise (one round trip per solve, two when the speculation fell short)
+__global__ __launch_bounds__(256)
+void k_post_norms (const unsigned long long* __restrict__ src, volatile unsigned long long* dst, int nwords,
+                   volatile unsigned long long* seq_slot, unsigned long long seq)
+{
+    for (int w = threadIdx.x; w < nwords; w += blockDim.x) dst[w] = src[w];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { *seq_slot = seq; }
+}
+
 template <bool CC>
 static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_iters, int* iters_out, double* resnorm_out,
                         hipStream_t st)
@@ -1316,8 +1333,19 @@ static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_it
             }
             vcycle<CC>(M, enq, tol_rel, tol_abs, st);
         }
-        HPS_HIP_CHECK(hipMemcpyAsync(M->h_buf, M->d_buf, (3 + enq)*MG_NSUB*sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        HPS_HIP_CHECK(hipStreamSynchronize(st));
+        ++M->seq;
+        hipLaunchKernelGGL(k_post_norms, dim3(1), dim3(256), 0, st, M->d_buf, (volatile unsigned long long*)M->h_buf_dev,
+                           (3 + enq)*MG_NSUB, (volatile unsigned long long*)M->h_seq_dev, M->seq);
+        {   volatile unsigned long long* hs = M->h_seq;
+            long spins = 0;
+            while (*hs != M->seq) {
+                if ((++spins & 0xfffff) == 0 && hipStreamQuery(st) != hipErrorNotReady) {      // a failed launch must not hang us
+                    if (*hs == M->seq) break;
+                    HPS_HIP_CHECK(hipStreamSynchronize(st));
+                    if (*hs != M->seq) { set_error("hps_mg_solve1: the norm read-back never arrived"); return HPS_ERR_HIP; }
+                }
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE); }
         // replay the stopping rule on the host (solve_doit :1352-1398)
         const double res0 = slot_value(0), rhs0 = slot_value(1);
         const double max_norm = (rhs0 >= res0) ? rhs0 : res0;
