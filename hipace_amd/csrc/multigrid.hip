@@ -1064,6 +1064,7 @@ struct Multigrid {
     // read-back, see hps_mg_rider) followed by the norm slots; d_norms / h_norms point at slot 0
     unsigned long long *d_buf = nullptr, *h_buf = nullptr;
     unsigned long long* h_buf_dev = nullptr;    // device address of the (mapped) pinned buffer: k_post_norms writes it
+    long dbg_trips = 0, dbg_solves = 0, dbg_hist[8] = {0,0,0,0,0,0,0,0};
     unsigned long long* h_seq = nullptr; unsigned long long* h_seq_dev = nullptr; unsigned long long seq = 0;
     unsigned long long* d_norms = nullptr;      // [0] residual, [1] rhs
     unsigned long long* h_norms = nullptr;      // pinned copy of d_norms (2 + MG_MAX_VCYCLES slots)
@@ -1077,6 +1078,7 @@ struct Multigrid {
 
     ~Multigrid () {
         for (auto& l : L) { (void)hipFree(l.acf); (void)hipFree(l.res); (void)hipFree(l.cor); (void)hipFree(l.rescor); }
+        if (getenv("HPS_MG_DEBUG")) fprintf(stderr, "mg: solves %ld trips %ld hist %ld %ld %ld %ld %ld %ld\n", dbg_solves, dbg_trips, dbg_hist[0], dbg_hist[1], dbg_hist[2], dbg_hist[3], dbg_hist[4], dbg_hist[5]);
         (void)hipFree(d_buf); (void)hipFree(d_low); (void)hipFree(tmp0); (void)hipFree(d_low2);
         if (h_buf) (void)hipHostFree(h_buf);
     }
@@ -1333,7 +1335,7 @@ static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_it
             }
             vcycle<CC>(M, enq, tol_rel, tol_abs, st);
         }
-        ++M->seq;
+        ++M->seq; ++M->dbg_trips;
         hipLaunchKernelGGL(k_post_norms, dim3(1), dim3(256), 0, st, M->d_buf, (volatile unsigned long long*)M->h_buf_dev,
                            (3 + enq)*MG_NSUB, (volatile unsigned long long*)M->h_seq_dev, M->seq);
         {   volatile unsigned long long* hs = M->h_seq;
@@ -1362,7 +1364,7 @@ static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_it
         nspec = 1;
     }
     if (diverged) { set_error("hps_mg_solve1: diverging"); status = HPS_ERR_MG_DIVERGED; }
-    M->last_iters = std::max(1, iters);
+    M->last_iters = std::max(1, iters); ++M->dbg_solves; ++M->dbg_hist[std::min(iters, 7)];
     if (iters == 0) {
         // converged on entry: solution = cor[0] of the initial smoothing (solve_doit :1419-1426)
         const LevBox& b0 = M->L[0].b;
