@@ -61,7 +61,7 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         slot[c] = on ? na++ : -1;
     }
 
-    const int tile = blockIdx.x;
+    const int tile = offsets[gridDim.x + 2 + blockIdx.x];     // launch order: heaviest tile first (sort.hip)
     const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
     const int tid = threadIdx.x;
     PT_STAMP(0);
@@ -196,7 +196,7 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
     extern __shared__ __attribute__((aligned(16))) double lds[];     // [4 cached][R*R] + [2 accum][R*R]
     double* img = lds;
     double* acc = lds + 4*PL;
-    const int tile = blockIdx.x;
+    const int tile = offsets[gridDim.x + 2 + blockIdx.x];     // launch order: heaviest tile first (sort.hip)
     const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
     const int tid = threadIdx.x;
     const int cc[4] = {cBz, cEz, cExmBy, cEypBx};
@@ -300,7 +300,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     constexpr int R = TS + 2*TILE_HALO;
     constexpr int NS = ORDER + 2;
     extern __shared__ __attribute__((aligned(16))) double img[];     // [5][R*R]
-    const int tile = blockIdx.x;
+    const int tile = offsets[gridDim.x + 2 + blockIdx.x];     // launch order: heaviest tile first (sort.hip)
     const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
     const int tid = threadIdx.x;
     const int cc[5] = {cPsi, cEz, cBx, cBy, cBz};

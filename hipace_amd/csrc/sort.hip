@@ -80,6 +80,23 @@ void k_tile_offsets (const unsigned int* keys, long n, int ntiles, int per_tile,
     for (int t = prev + 1; t <= cur; ++t) offsets[t] = (int)p;
 }
 
+// launch order of the tile kernels: workgroup b works on tile order[b], heaviest tile first (longest-processing-time
+// first: behind a driver the sheet is very uneven over the tiles and the tail of a launch was a few heavy tiles)
+__global__ __launch_bounds__(256)
+void k_tile_order_keys (const int* offsets, int ntiles, unsigned int* keys, unsigned int* vals)
+{
+    const int t = blockIdx.x*blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    keys[t] = 0xFFFFFFFFu - (unsigned int)(offsets[t + 1] - offsets[t]);
+    vals[t] = (unsigned int)t;
+}
+__global__ __launch_bounds__(256)
+void k_tile_order_identity (int* order, int ntiles)
+{
+    const int t = blockIdx.x*blockDim.x + threadIdx.x;
+    if (t < ntiles) order[t] = t;
+}
+
 __global__ __launch_bounds__(256)
 void k_permute (hps_plasma src, hps_plasma dst, const unsigned int* perm)
 {
@@ -97,7 +114,7 @@ void k_permute (hps_plasma src, hps_plasma dst, const unsigned int* perm)
 Tiling::~Tiling ()
 {
     (void)hipFree(offsets); (void)hipFree(keys_a); (void)hipFree(keys_b); (void)hipFree(idx_a); (void)hipFree(idx_b);
-    (void)hipFree(temp); (void)hipFree(cell_first);
+    (void)hipFree(temp); (void)hipFree(cell_first); (void)hipFree(okeys); (void)hipFree(otemp);
 }
 
 int tiling_create (int nx, int ny, int ts, long capacity, Tiling** out)
@@ -107,8 +124,13 @@ int tiling_create (int nx, int ny, int ts, long capacity, Tiling** out)
     T->g.nx = nx; T->g.ny = ny; T->g.ts = ts;
     T->g.ntx = (nx + ts - 1)/ts; T->g.nty = (ny + ts - 1)/ts; T->g.ntiles = T->g.ntx*T->g.nty;
     T->capacity = capacity;
-    HPS_HIP_CHECK(hipMalloc(&T->offsets, (T->g.ntiles + 2)*sizeof(int)));
-    HPS_HIP_CHECK(hipMemset(T->offsets, 0, (T->g.ntiles + 2)*sizeof(int)));
+    HPS_HIP_CHECK(hipMalloc(&T->offsets, (2*T->g.ntiles + 2)*sizeof(int)));
+    HPS_HIP_CHECK(hipMemset(T->offsets, 0, (2*T->g.ntiles + 2)*sizeof(int)));
+    hipLaunchKernelGGL(k_tile_order_identity, dim3(ceil_div(T->g.ntiles, 256)), dim3(256), 0, (hipStream_t)0, T->offsets + T->g.ntiles + 2, T->g.ntiles);
+    HPS_HIP_CHECK(hipDeviceSynchronize());
+    HPS_HIP_CHECK(hipMalloc(&T->okeys, 3*(size_t)T->g.ntiles*sizeof(unsigned int)));
+    HPS_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, T->otemp_bytes, T->okeys, T->okeys, T->okeys, T->okeys, (size_t)T->g.ntiles, 0, 32, (hipStream_t)0));
+    HPS_HIP_CHECK(hipMalloc(&T->otemp, T->otemp_bytes));
     HPS_HIP_CHECK(hipMalloc(&T->keys_a, capacity*sizeof(unsigned int)));
     HPS_HIP_CHECK(hipMalloc(&T->keys_b, capacity*sizeof(unsigned int)));
     HPS_HIP_CHECK(hipMalloc(&T->idx_a, capacity*sizeof(unsigned int)));
@@ -149,6 +171,11 @@ int tiling_sort (Tiling* T, const hps_plasma& src, const hps_plasma& dst, const 
                                             T->key2_bits, st));
     hipLaunchKernelGGL(k_tile_offsets, gn1, b256, 0, st, T->keys_b, n, T->g.ntiles, RANK_CAP*ncell, T->offsets);
     hipLaunchKernelGGL(k_permute, dim3(ceil_div(n, 256)), dim3(256), 0, st, src, dst, T->idx_a);
+    {   const int nt = T->g.ntiles;
+        unsigned int *ka = T->okeys, *kb = T->okeys + nt, *va = T->okeys + 2*nt;
+        hipLaunchKernelGGL(k_tile_order_keys, dim3(ceil_div(nt, 256)), b256, 0, st, T->offsets, nt, ka, va);
+        size_t ob = T->otemp_bytes;
+        HPS_HIP_CHECK(rocprim::radix_sort_pairs(T->otemp, ob, ka, kb, va, reinterpret_cast<unsigned int*>(T->offsets + nt + 2), (size_t)nt, 0, 32, st)); }
     HPS_HIP_CHECK(hipGetLastError());
     T->sorted_n = n;
     return HPS_OK;

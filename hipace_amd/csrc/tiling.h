@@ -10,7 +10,8 @@ struct TileGeom { int nx, ny, ts, ntx, nty, ntiles; double xoff, yoff, dx_inv, d
 struct Tiling {
     TileGeom g{};
     long capacity = 0, sorted_n = 0;
-    int* offsets = nullptr;                       // [ntiles + 2], device
+    int* offsets = nullptr;                       // [ntiles + 2] offsets, then [ntiles] launch order (heaviest tile first), device
+    unsigned int *okeys = nullptr; void* otemp = nullptr; size_t otemp_bytes = 0;      // scratch of the launch-order sort
     unsigned int *keys_a = nullptr, *keys_b = nullptr, *idx_a = nullptr, *idx_b = nullptr;
     void* temp = nullptr; size_t temp_bytes = 0; int key_bits = 0, key2_bits = 0;
     int* cell_first = nullptr;                    // [ntiles*ts*ts + 2] run starts of the cell keys
