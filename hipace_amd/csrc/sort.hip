@@ -22,7 +22,10 @@
 
 namespace hps {
 
-constexpr int RANK_CAP = 16;
+#ifndef HPS_RANK_CAP
+#define HPS_RANK_CAP 16
+#endif
+constexpr int RANK_CAP = HPS_RANK_CAP;
 
 // (tile, cell in tile) of the nearest cell; invalid particles get tile = ntiles, cell 0
 __device__ __forceinline__ unsigned int cell_key (double x, double y, uint64_t id, const TileGeom& t)
