@@ -1062,7 +1062,7 @@ extern "C" int hps_engine_beam_info (void* h, long* nbeam, long* offsets_host)
 extern "C" int hps_engine_set_beam_storage (void* h, double* storage_dev)
 {
     Engine* E = static_cast<Engine*>(h);
-    HPS_REQUIRE(!(E->moving && storage_dev), "hps_engine_set_beam_storage: caller-owned beam blocks need hipace.dt = 0 (the moving beam's slice hand-off through the ring is not built yet)");
+    HPS_REQUIRE(!(E->moving && storage_dev), "hps_engine_set_beam_storage: caller-owned static beam blocks need hipace.dt = 0; a moving beam is handed on with hps_engine_set_beam_import / export_beam_slice / import_beam_slice");
     E->beam_cur = storage_dev ? storage_dev : E->beam_data;
     // caller-owned particles may sit anywhere: treat the whole plane as beam support until told otherwise
     E->beam_box = storage_dev ? E->full_box : E->beam_box_init;

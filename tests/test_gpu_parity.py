@@ -667,3 +667,46 @@ def test_insitu_field_reductions_match_oracle(api, oracle):
     for q, name in enumerate(api.SliceEngine.INSITU_FIELDS):
         scale = np.abs(want[q]).max()
         assert scale > 0 and np.abs(got[name] - want[q]).max() <= 1e-10 * scale, name
+
+
+# ---- error behaviour: status + message instead of the reference's amrex::Abort ------------------------------------
+@pytest.mark.gpu
+def test_error_behaviour(api):
+    """Where the reference aborts the process (AMREX_ALWAYS_ASSERT / amrex::Abort), the C ABI returns a status and
+    hps_last_error() names the call; the Python mirror raises HpsError (a RuntimeError).  Nothing is computed."""
+    import torch
+    from hipace_amd import _lib
+    g = G2
+
+    def fails(fn, needle):
+        with pytest.raises(RuntimeError) as ei:
+            fn()
+        assert needle in str(ei.value), str(ei.value)
+
+    # solver / slab size mismatch, bad component (HpMultiGrid.H:168-175 center_box asserts; Fields getField)
+    f = api.Fields(64, 64, g, 6)
+    ps = api.FFTPoissonSolver(32, 32, 0.1, 0.1)
+    fails(lambda: ps.SolvePoissonEquation(f, 1), "does not match")
+    fails(lambda: api.FFTPoissonSolver(64, 64, 0.1, 0.1).SolvePoissonEquation(f, 9), "component")
+    mg = api.MultiGrid(32, 32, 0.1, 0.1)
+    fails(lambda: mg.solve1(f, 0, 2, 4), "does not match")
+    fails(lambda: api.MultiGrid(64, 64, 0.1, 0.1).solve1(f, 5, 2, 4), "component")      # sol needs 2 adjacent comps
+    # hpmg aborts when nummaxiter V-cycles do not reach the tolerance (HpMultiGrid.cpp:1409-1416)
+    f.t[2:4, g:-g, g:-g] = torch.randn((2, 64, 64), dtype=torch.float64, device="cuda")
+    f.t[4] = 1.0
+    fails(lambda: api.MultiGrid(64, 64, 0.1, 0.1).solve1(f, 0, 2, 4, tol_rel=1e-14, nummaxiter=1), "not converged")
+    # deposition order, tile size, guard cells
+    fails(lambda: api.Tiling(64, 64, 24, 100), "tile_size")
+    deck = decks.blowout_wake()
+    fails(lambda: api.SliceEngine(dict(deck, order=4)), "depos_order")
+    fails(lambda: api.SliceEngine(dict(deck, plasma_radius=3.0)), "plasma radius")
+    fails(lambda: api.SliceEngine(dict(deck, field_bc=1)), "Dirichlet")
+    # engine options that do not apply
+    eng = api.SliceEngine(deck)
+    fails(lambda: eng.set_field_diagnostic(["Ez"], (3, 1, 1)), "divisible")             # 64 % 3 != 0
+    pc = api.SliceEngine(decks.predictor_corrector(deck))
+    fails(lambda: pc.set_insitu_fields(True), "explicit solver only")
+    mv = api.SliceEngine(decks.beam_evolution())
+    buf = torch.zeros(7 * max(mv.beam_layout()[0], 1), dtype=torch.float64, device="cuda")
+    fails(lambda: mv.set_beam_storage(buf), "dt")
+    assert isinstance(_lib.lib().hps_last_error(), bytes)
