@@ -219,29 +219,55 @@ def _run_pipeline_moving(engine, rank, world, n_steps, device, on_step_end):
     return solved
 
 
-def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_step=None):
-    """Several time steps in flight on ONE device: the ring pipeline with all its stages in this process.
+def make_edge_groups(world):
+    """Process groups for the ring edges of `run_local_pipeline` with world > 1 (collective: every rank calls it, in
+    the same order).  Edge r -> r+1 uses group colour(r); a rank's incoming and outgoing edge never share a group, so
+    its receiving thread and its sending thread each own one communicator (a proper edge colouring of the ring: two
+    colours, three when the ring is odd)."""
+    if world == 1:
+        return None
+    return [dist.new_group(list(range(world))) for _ in range(3)]
 
-    engines[j] (one stream each, all on `device`) runs steps j, j+L, ... < n_steps, L = len(engines), exactly as rank j
-    of `run_pipeline` would; what couples them is the same per-slice beam hand-off, here a device-to-device copy
-    (MultiBuffer.cpp:299-308, the reference's in-process "send to myself") ordered by stream events instead of
-    messages: engine j solves slice k of step s only after engine j-1 has pushed slices k and k-1 of step s-1.  One
-    host thread per engine (the multigrid's stopping rule synchronises its stream once per slice; ctypes releases
-    the GIL), so while one step sits in a latency-bound phase -- the lower multigrid levels, a DST pass, a launch gap
-    -- the kernels of the others fill the device.  Static beam only (hipace.dt = 0, as every BASELINE deck).
 
-    Returns the number of slices solved (all engines).
+def _edge_colour(r, world):
+    return 2 if (world % 2 == 1 and r == world - 1) else r % 2
+
+
+def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_step=None, rank=0, world=1,
+                       groups=None):
+    """Several time steps in flight on ONE device: the ring pipeline with L = len(engines) of its stages in this process.
+
+    Stage g = rank*L + j (engine j of this rank, one stream each, all on `device`) runs steps g, g+G, ... < n_steps,
+    G = world*L, exactly as rank g of `run_pipeline` would.  What couples the stages is the same per-slice beam
+    hand-off: stage g solves slice k of step s only after stage g-1 has pushed slices k and k-1 of step s-1.  Between
+    two engines of this process that is a device-to-device copy (MultiBuffer.cpp:299-308, the reference's in-process
+    "send to myself") ordered by stream events; between the last engine of a rank and the first engine of the next
+    rank (world > 1) it is one point-to-point message per slice on that edge's own process group (`make_edge_groups`:
+    the sending and the receiving thread of a rank never share a communicator, every edge carries one ordered sequence
+    of messages posted in the same order on both sides).  One host thread per engine (the multigrid's stopping rule
+    holds its host thread once per slice; ctypes releases the GIL), so while one step sits in a latency-bound phase --
+    the lower multigrid levels, a DST pass, a launch gap -- the kernels of the others fill the device.  Static beam
+    only (hipace.dt = 0, as every BASELINE deck).
+
+    Returns the number of slices this process solved.
     """
     import threading
     L = len(engines)
+    G = world * L
     nz = engines[0].deck["nz"]
     per_step = slices_per_step or nz
     assert per_step >= 2, "a step needs at least two slices"
     assert not getattr(engines[0], "moving", False), "run_local_pipeline hands a static beam on (hipace.dt = 0)"
+    assert world == 1 or groups is not None, "world > 1 needs make_edge_groups(world)"
+    on_gpu = str(device) != "cpu"
     nbeam, off = engines[0].beam_layout()
     bufs = [[torch.zeros(max(7 * nbeam, 1), dtype=torch.float64, device=device) for _ in range(2)] for _ in range(L)]
-    engines[0].initial_beam_into(bufs[0][0])          # only the head of the ring injects the beam
-    engines[0].sync()
+    if rank == 0:
+        engines[0].initial_beam_into(bufs[0][0])      # only the head of the ring injects the beam
+        engines[0].sync()
+    prev_rank, next_rank = (rank - 1) % world, (rank + 1) % world
+    g_in = groups[_edge_colour(prev_rank, world)] if world > 1 else None
+    g_out = groups[_edge_colour(rank, world)] if world > 1 else None
 
     def block(buf, q):
         p = q                                          # q-th slice from the head = block q
@@ -255,32 +281,60 @@ def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_st
 
     def lane(j):
         try:
+            if on_gpu:
+                torch.cuda.set_device(device)
             eng, pj = engines[j], (j - 1) % L
-            for m, step in enumerate(range(j, n_steps, L)):
+            stage = rank * L + j
+            remote_in = world > 1 and j == 0           # my predecessor stage lives on the previous rank
+            remote_out = world > 1 and j == L - 1      # my successor stage lives on the next rank
+            sends = []
+            for m, step in enumerate(range(stage, n_steps, G)):
                 buf = bufs[j][m % 2]
-                mp = (step - 1 - pj) // L if step > 0 else None     # the local step of my predecessor that feeds me
+                fed = step > 0                          # step 0 starts from the injected beam
+                mp = (step - 1 - (rank * L + pj)) // G if (fed and not remote_in) else None
                 eng.set_beam_storage(buf, injected_beam_support=True)
                 eng.begin_step()
                 copied = 0
                 for q in range(per_step):
-                    if mp is not None:
+                    if fed:
                         need = min(q + 1, per_step - 1)             # this slice's beam and the next one's (jx/jy source)
-                        with cond:
-                            while progress[pj] < mp * per_step + need + 1 and not errors:
-                                cond.wait(timeout=1.0)
-                            ev = events[pj].get((mp, need))
-                        if errors:
-                            return
-                        eng.wait_event(ev)
-                        src = bufs[pj][mp % 2]
-                        while copied <= need:
-                            d, s_ = block(buf, copied), block(src, copied)
-                            if d.numel() > 0:
-                                eng.copy_async(d, s_)
-                            copied += 1
+                        if remote_in:
+                            landed = False
+                            while copied <= need:
+                                d = block(buf, copied)
+                                if d.numel() > 0:
+                                    dist.irecv(d, src=prev_rank, group=g_in).wait()
+                                    landed = True
+                                copied += 1
+                            if landed and on_gpu:
+                                torch.cuda.current_stream().synchronize()   # data landed before the engine's stream reads it
+                        else:
+                            with cond:
+                                while progress[pj] < mp * per_step + need + 1 and not errors:
+                                    cond.wait(timeout=1.0)
+                                ev = events[pj].get((mp, need))
+                            if errors:
+                                return
+                            eng.wait_event(ev)
+                            src = bufs[pj][mp % 2]
+                            while copied <= need:
+                                d, s_ = block(buf, copied), block(src, copied)
+                                if d.numel() > 0:
+                                    eng.copy_async(d, s_)
+                                copied += 1
                     eng.solve_slice(nz - 1 - q)
-                    ev = eng.record_event((m % 2) * per_step + q)
                     solved[j] += 1
+                    if remote_out:
+                        if step + 1 < n_steps:
+                            t = block(buf, q)
+                            if t.numel() > 0:
+                                eng.sync()                          # the slice's beam block is final before it is sent
+                                sends.append(dist.isend(t, dst=next_rank, group=g_out))
+                                # never block on a send here: with one stage per rank this thread also posts the
+                                # receives its peer's sends are waiting for (a whole step of blocks may be in flight)
+                                while sends and sends[0].is_completed():
+                                    sends.pop(0)
+                    ev = eng.record_event((m % 2) * per_step + q)
                     with cond:
                         events[j][(m, q)] = ev
                         events[j].pop((m - 2, q), None)
@@ -288,6 +342,8 @@ def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_st
                         cond.notify_all()
                 if on_step_end is not None:
                     on_step_end(step, eng)
+            for rq in sends:
+                rq.wait()
         except BaseException as e:      # noqa: BLE001 -- re-raised on the caller's thread
             with cond:
                 errors.append(e)

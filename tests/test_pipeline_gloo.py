@@ -143,3 +143,54 @@ def test_local_pipeline_several_steps_in_flight(oracle, lanes, n_steps):
     for step, cs in got.items():
         for k, v in want.items():
             assert abs(cs[k] - v) <= 1e-12 * max(abs(v), 1e-300), (step, k, cs[k], v)
+
+
+def _lanes_worker(rank, world, port, lanes, n_steps, out):
+    import torch.distributed as dist
+    from hipace_amd.pipeline import make_edge_groups, run_local_pipeline
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    groups = make_edge_groups(world)
+    engs = [O.Engine(_deck()) for _ in range(lanes)]
+    sums = {}
+
+    def on_step_end(step, eng):
+        sums[step] = eng.checksums()
+
+    solved = run_local_pipeline(engs, n_steps, "cpu", on_step_end, rank=rank, world=world, groups=groups)
+    out.put((rank, solved, sums))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,lanes,n_steps", [(2, 2, 9), (3, 2, 13), (2, 1, 5), (2, 3, 6)])
+def test_ring_of_ranks_with_several_stages_each(oracle, world, lanes, n_steps):
+    """run_local_pipeline with world > 1: `lanes` pipeline stages per rank (stage = rank*lanes + lane), in-process
+    hand-off between the stages of a rank, one message per slice on the rank-to-rank edges (each edge on its own
+    process group; odd rings need the third colour).  Every step of the closed ring has the checksums of a single run."""
+    ref = oracle.Engine(_deck())
+    ref.run()
+    want = ref.checksums()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lanes_worker, args=(r, world, port, lanes, n_steps, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seen = {}
+    G = world * lanes
+    for rank, solved, sums in results:
+        for step, cs in sums.items():
+            assert rank * lanes <= step % G < (rank + 1) * lanes          # the stage that ran it lives on this rank
+            seen[step] = cs
+    assert sorted(seen) == list(range(n_steps))
+    assert sum(r[1] for r in results) == n_steps * _deck()["nz"]
+    for step, cs in seen.items():
+        for k, v in want.items():
+            assert abs(cs[k] - v) <= 1e-12 * max(abs(v), 1e-300), (step, k, cs[k], v)
