@@ -97,6 +97,8 @@ _SIGS = {
     "hps_beam_sort_by_box": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "hps_engine_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "hps_engine_set_insitu_plasma": (C.c_int, [C.c_void_p, C.c_double]),
+    "hps_engine_insitu_plasma": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_set_insitu_fields": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_insitu_fields": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_set_field_diagnostic": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

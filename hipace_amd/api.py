@@ -363,6 +363,18 @@ class SliceEngine:
     INSITU_FIELDS = ["[Ex^2]", "[Ey^2]", "[Ez^2]", "[Bx^2]", "[By^2]", "[Bz^2]", "[ExmBy^2]", "[EypBx^2]", "[jz_beam]",
                      "[Ez*jz_beam]"]
 
+    INSITU_PLASMA = ["sum(w)", "[x]", "[x^2]", "[y]", "[y^2]", "[ux]", "[ux^2]", "[uy]", "[uy^2]", "[uz]", "[uz^2]", "[ga]",
+                     "[ga^2]", "[(ga-1)*(1-vz)]", "Np"]
+
+    def set_insitu_plasma(self, radius=float("inf")):
+        """plasma.insitu_period / insitu_radius: per-slice moments of PlasmaParticleContainer::InSituComputeDiags."""
+        check(_lib.lib().hps_engine_set_insitu_plasma(self._h, min(float(radius), 1.0e300)))
+
+    def insitu_plasma(self):
+        out = np.empty((15, self.deck["nz"]))
+        check(_lib.lib().hps_engine_insitu_plasma(self._h, out.ctypes.data_as(C.c_void_p)))
+        return {n: out[i] for i, n in enumerate(self.INSITU_PLASMA)}
+
     def set_insitu_fields(self, on=True):
         """fields.insitu_period: per-slice reductions of Fields::InSituComputeDiags."""
         check(_lib.lib().hps_engine_set_insitu_fields(self._h, int(on)))

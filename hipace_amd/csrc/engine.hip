@@ -254,7 +254,7 @@ Engine::~Engine ()
     (void)hipFree(bm_store); (void)hipFree(bm_nsub); (void)hipFree(bm_nsub_scr); (void)hipFree(d_B); (void)hipFree(d_nfront);
     (void)hipFree(d_Bimp); (void)hipFree(d_beam_overflow); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
     (void)hipFree(d_pc); if (h_pc) (void)hipHostFree(h_pc);
-    (void)hipFree(d_fd); (void)hipFree(d_fd_comps); (void)hipFree(d_insitu);
+    (void)hipFree(d_fd); (void)hipFree(d_fd_comps); (void)hipFree(d_insitu); (void)hipFree(d_insitu_pl);
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto e : hand_ev) if (e) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
@@ -476,6 +476,7 @@ int Engine::begin_step ()
     // ResetAllQuantities (Hipace.cpp:730-742)
     HPS_HIP_CHECK(hipMemsetAsync(slab.p, 0, (size_t)slab.nstride*ncomp*sizeof(double), st));
     HPS_HIP_CHECK(hipMemsetAsync(d_checksum, 0, HPS_PC_NCOMP_MAX*sizeof(double), st));
+    if (d_insitu_pl) HPS_HIP_CHECK(hipMemsetAsync(d_insitu_pl, 0, (size_t)15*d.nz*sizeof(double), st));
     if (d_insitu) HPS_HIP_CHECK(hipMemsetAsync(d_insitu, 0, (size_t)10*d.nz*sizeof(double), st));
     if (d_fd) HPS_HIP_CHECK(hipMemsetAsync(d_fd, 0, fd_comps.size()*(size_t)(d.nx/fd_c[0])*(d.ny/fd_c[1])*(d.nz/fd_c[2])*sizeof(double), st));
     if (np > 0) {
@@ -581,6 +582,38 @@ void k_insitu_fields (SlabView f, double clight, double dxdydz, double* out, int
     if (threadIdx.x < 10)
         atomic_add_f64(out + (long)threadIdx.x*nz + islice,
                        (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x])*dxdydz);
+}
+
+// PlasmaParticleContainer::InSituComputeDiags (particles/plasma/PlasmaParticleContainer.cpp:443-530): raw sums
+__global__ __launch_bounds__(256)
+void k_insitu_plasma (hps_plasma pl, double clight_inv, double radius_sq, double* out, int nz, int islice)
+{
+    double s[15];
+#pragma unroll
+    for (int q = 0; q < 15; ++q) s[q] = 0.0;
+    for (long ip = (long)blockIdx.x*blockDim.x + threadIdx.x; ip < pl.n; ip += (long)gridDim.x*blockDim.x) {
+        const double x = pl.x[ip], y = pl.y[ip];
+        if (!(pl.idcpu[ip] & HPS_ID_VALID) || x*x + y*y > radius_sq) continue;
+        const double ux = pl.ux[ip]*clight_inv, uy = pl.uy[ip]*clight_inv, psi = pl.psi[ip];
+        const double gamma = (1.0 + ux*ux + uy*uy + psi*psi)/(2.0*psi);
+        const double uz = gamma - psi;
+        const double w = pl.w[ip]*gamma/psi;
+        const double energy = pl.w[ip]*(gamma - 1.0);
+        s[0] += w; s[1] += w*x; s[2] += w*x*x; s[3] += w*y; s[4] += w*y*y; s[5] += w*ux; s[6] += w*ux*ux;
+        s[7] += w*uy; s[8] += w*uy*uy; s[9] += w*uz; s[10] += w*uz*uz; s[11] += w*gamma; s[12] += w*gamma*gamma;
+        s[13] += energy; s[14] += 1.0;
+    }
+    __shared__ double part[4][15];
+#pragma unroll
+    for (int q = 0; q < 15; ++q) {
+        double v = s[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 15)
+        atomic_add_f64(out + (long)threadIdx.x*nz + islice,
+                       part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 int Engine::fill_field_diagnostic (int islice)
@@ -718,6 +751,8 @@ int Engine::solve_slice_pc (int islice)
     int e;
 
     mark();   // b0
+    if (d_insitu_pl && np > 0)
+        hipLaunchKernelGGL(k_insitu_plasma, dim3(256), b256, 0, st, pl, 1.0/gm.c, insitu_pl_radius*insitu_pl_radius, d_insitu_pl, d.nz, islice);
     // InitializeSlices (fields/Fields.cpp:565-570); ExmBy, EypBx are rewritten by k_grad_psi up to the outermost
     // guard ring, which stays zero from begin_step
     {   CompList z{0, {}}, zb{0, {}};
@@ -817,6 +852,8 @@ int Engine::solve_slice (int islice)
     int e;
 
     mark();   // b0
+    if (d_insitu_pl && np > 0)        // m_multi_plasma.InSituComputeDiags (Hipace.cpp:590)
+        hipLaunchKernelGGL(k_insitu_plasma, dim3(256), b256, 0, st, pl, 1.0/gm.c, insitu_pl_radius*insitu_pl_radius, d_insitu_pl, d.nz, islice);
     // InitializeSlices (fields/Fields.cpp:535-586)
     const CellBox bb{beam_box.ilo, beam_box.ihi, beam_box.jlo, beam_box.jhi};
     {   CompList z{0, {}}, zb{0, {}};
@@ -944,6 +981,30 @@ extern "C" int hps_engine_stats (void* h, long* vc, long* sl)
     Engine* E = static_cast<Engine*>(h);
     if (vc) *vc = E->total_vcycles;
     if (sl) *sl = E->slices_done;
+    return HPS_OK;
+}
+extern "C" int hps_engine_set_insitu_plasma (void* h, double radius)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    (void)hipFree(E->d_insitu_pl); E->d_insitu_pl = nullptr; E->insitu_pl_radius = radius;
+    if (!(radius > 0.0)) return HPS_OK;
+    HPS_HIP_CHECK(hipMalloc(&E->d_insitu_pl, (size_t)15*E->d.nz*sizeof(double)));
+    HPS_HIP_CHECK(hipMemset(E->d_insitu_pl, 0, (size_t)15*E->d.nz*sizeof(double)));
+    return HPS_OK;
+}
+extern "C" int hps_engine_insitu_plasma (void* h, double* out)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E->d_insitu_pl && out, "hps_engine_insitu_plasma: not switched on");
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    const int nz = E->d.nz;
+    HPS_HIP_CHECK(hipMemcpy(out, E->d_insitu_pl, (size_t)15*nz*sizeof(double), hipMemcpyDeviceToHost));
+    // averages: everything but sum(w), the energy and the count is divided by sum(w) (:511-516)
+    for (int k = 0; k < nz; ++k) {
+        const double sw = out[k], inv = sw <= 0.0 ? 0.0 : 1.0/sw;
+        for (int q = 1; q <= 12; ++q) out[(size_t)q*nz + k] *= inv;
+    }
     return HPS_OK;
 }
 extern "C" int hps_engine_set_insitu_fields (void* h, int on)

@@ -221,6 +221,14 @@ int hps_engine_field_diagnostic (void* handle, double* out_host);
 int hps_engine_set_insitu_fields (void* handle, int on);
 int hps_engine_insitu_fields (void* handle, double* out_host /* [10*nz] */);
 
+/* In-situ plasma moments (PlasmaParticleContainer::InSituComputeDiags, particles/plasma/PlasmaParticleContainer.cpp:
+ * 443-530), taken at the start of every slice (Hipace.cpp:590) over the valid particles within `radius` of the axis:
+ * out_host[q*nz + islice], q = 0..14 = sum(w), [x], [x^2], [y], [y^2], [ux], [ux^2], [uy], [uy^2], [uz], [uz^2], [ga],
+ * [ga^2] (averages: divided by sum(w)), [(ga-1)(1-vz)] (sum), Np (count, as a double), with w = weight * gamma/psi.
+ * radius <= 0 switches it off; cleared by hps_engine_begin_step; reading synchronises the stream. */
+int hps_engine_set_insitu_plasma (void* handle, double radius);
+int hps_engine_insitu_plasma (void* handle, double* out_host /* [15*nz] */);
+
 /* particle tiling of the engine: tile_size 0 = per-particle global-atomic kernels, 16 | 32 = LDS
  * tiles, re-sorted after sort_period slices at the latest (plasmas.reorder_period of the reference; see hps_engine_sorts).
  * Call before hps_engine_begin_step. */

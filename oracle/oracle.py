@@ -332,6 +332,23 @@ class FieldDiagnostic:
                 self.F[n, k] += rel * v
 
 
+def insitu_plasma(real, valid, radius=np.inf, clight=1.0):
+    """PlasmaParticleContainer::InSituComputeDiags (particles/plasma/PlasmaParticleContainer.cpp:443-530) of a
+    plasma sheet (the 11 real arrays in PlasmaIdx order + validity): the 15 per-slice entries."""
+    x, y, wt, ux, uy, psi = real[0], real[1], real[2], real[3] / clight, real[4] / clight, real[5]
+    keep = (valid != 0) & (x * x + y * y <= radius * radius)
+    x, y, wt, ux, uy, psi = (a[keep] for a in (x, y, wt, ux, uy, psi))
+    gamma = (1.0 + ux * ux + uy * uy + psi * psi) / (2.0 * psi)
+    uz = gamma - psi
+    w = wt * gamma / psi
+    raw = np.array([w.sum(), (w * x).sum(), (w * x * x).sum(), (w * y).sum(), (w * y * y).sum(), (w * ux).sum(),
+                    (w * ux * ux).sum(), (w * uy).sum(), (w * uy * uy).sum(), (w * uz).sum(), (w * uz * uz).sum(),
+                    (w * gamma).sum(), (w * gamma * gamma).sum(), (wt * (gamma - 1.0)).sum(), float(keep.sum())])
+    inv = 0.0 if raw[0] <= 0.0 else 1.0 / raw[0]
+    raw[1:13] *= inv
+    return raw
+
+
 def insitu_fields(slab, g, deck, clight=1.0):
     """Fields::InSituComputeDiags (fields/Fields.cpp:1288-1347) of one slice from the explicit-solver slab: the ten
     sums over the valid cells, times dx dy dz, in the reference's order."""

@@ -710,3 +710,29 @@ def test_error_behaviour(api):
     buf = torch.zeros(7 * max(mv.beam_layout()[0], 1), dtype=torch.float64, device="cuda")
     fails(lambda: mv.set_beam_storage(buf), "dt")
     assert isinstance(_lib.lib().hps_last_error(), bytes)
+
+
+@pytest.mark.gpu
+def test_insitu_plasma_moments_match_oracle(api, oracle):
+    """PlasmaParticleContainer::InSituComputeDiags: the 15 per-slice entries (taken before the slice is solved, within
+    a radius of 4) against the oracle's restatement on its own particle sheet."""
+    deck = decks.blowout_wake()
+    deck.update(nz=40, n_steps=1)
+    ge = api.SliceEngine(deck, tile_size=16, sort_period=8)
+    ge.set_insitu_plasma(4.0)
+    oe = oracle.Engine(deck)
+    ge.begin_step()
+    oe.begin_step()
+    want = np.zeros((15, deck["nz"]))
+    for isl in range(deck["nz"] - 1, -1, -1):
+        oreal, ovalid = oe.particles()
+        want[:, isl] = oracle.insitu_plasma(oreal, ovalid, 4.0)
+        ge.solve_slice(isl)
+        oe.solve_slice(isl)
+    got = ge.insitu_plasma()
+    assert np.array_equal(got["Np"], want[14])                       # particle counts: exact
+    for q, name in enumerate(api.SliceEngine.INSITU_PLASMA[:14]):
+        scale = max(np.abs(want[q]).max(), 1e-300)
+        # first moments of a symmetric sheet are pure cancellation: compare against the second moments' scale
+        ref = max(scale, np.sqrt(np.abs(want[min(q + 1, 13)]).max()) if name in ("[x]", "[y]", "[ux]", "[uy]") else scale)
+        assert np.abs(got[name] - want[q]).max() <= 1e-9 * ref, name
