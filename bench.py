@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--tile", type=int, default=16, help="particle tile size (0, 16, 32)")
     ap.add_argument("--sort-period", type=int, default=128, help="max slices between particle re-sorts (adaptive below)")
     ap.add_argument("--cpu-slices", type=int, default=4, help="slices of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--profile-stride", type=int, default=7,
+                    help="HIP-event phase timers (and with them the roofline's kernel duration) on every n-th slice of the "
+                         "timed region: the 11 event records of a timed slice cost 4.5 %% of it")
     ap.add_argument("--inflight", type=int, default=1,
                     help="time steps in flight on one GPU (hipace_amd/pipeline.py::run_local_pipeline): L engines on L "
                          "streams, step s+1 trails step s by the per-slice beam hand-off.  Needs --steps >= L boxes.  "
@@ -140,7 +143,7 @@ def main():
         groups = make_edge_groups(world)
         run_local_pipeline(engines, lanes, torch.device("cuda", local), slices_per_step=max(2, args.warmup))   # warm every lane
     for e in engines:
-        e.set_profiling(True)
+        e.set_profiling(True, stride=args.profile_stride)
     barrier()
     t0 = time.perf_counter()
     if lanes > 1:

@@ -106,6 +106,7 @@ _SIGS = {
     "hps_engine_record_event": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "hps_engine_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_copy_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]),
+    "hps_engine_set_profiling_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_pc_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_double)]),
     "hps_engine_set_diagnostics": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_set_tiling": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

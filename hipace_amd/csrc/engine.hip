@@ -520,7 +520,7 @@ int Engine::deposit_beam_slice (int islice, int cjx, int cjy, int cjz)
 
 void Engine::mark ()
 {
-    if (!profiling) return;
+    if (!prof_now) return;
     if (ev_used == ev.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev.push_back(e); }
     (void)hipEventRecord(ev[ev_used++], st);
 }
@@ -750,6 +750,7 @@ int Engine::solve_slice_pc (int islice)
     const long nval = (long)d.nx*d.ny;
     int e;
 
+    prof_now = profiling && (slices_done % prof_stride == 0);
     mark();   // b0
     if (d_insitu_pl && np > 0)
         hipLaunchKernelGGL(k_insitu_plasma, dim3(256), b256, 0, st, pl, 1.0/gm.c, insitu_pl_radius*insitu_pl_radius, d_insitu_pl, d.nz, islice);
@@ -851,6 +852,7 @@ int Engine::solve_slice (int islice)
     const dim3 gvalid(ceil_div(d.nx, 256), d.ny);
     int e;
 
+    prof_now = profiling && (slices_done % prof_stride == 0);
     mark();   // b0
     if (d_insitu_pl && np > 0)        // m_multi_plasma.InSituComputeDiags (Hipace.cpp:590)
         hipLaunchKernelGGL(k_insitu_plasma, dim3(256), b256, 0, st, pl, 1.0/gm.c, insitu_pl_radius*insitu_pl_radius, d_insitu_pl, d.nz, islice);
@@ -1092,7 +1094,14 @@ extern "C" int hps_engine_set_profiling (void* h, int on)
 {
     Engine* E = static_cast<Engine*>(h);
     HPS_HIP_CHECK(hipStreamSynchronize(E->st));
-    E->profiling = (on != 0); E->ev_used = 0;
+    E->profiling = (on != 0); E->ev_used = 0; E->prof_now = false;
+    return HPS_OK;
+}
+extern "C" int hps_engine_set_profiling_stride (void* h, int stride)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(stride >= 1, "hps_engine_set_profiling_stride: stride >= 1");
+    E->prof_stride = stride;
     return HPS_OK;
 }
 extern "C" int hps_engine_phase_times (void* h, double* ms, long* nsl)
