@@ -164,6 +164,35 @@ void k_sxsy_beam (SlabView f, int cSx, int cSy, int cJzb, int cNx, int cNy, int 
     f.p[cSx*f.ns + o] = -mu0*(-dx_jzb + dz_jxb);
 }
 
+// -grad Psi (k_grad_psi) and the beam part of Sx, Sy (k_sxsy_beam) in one pass over the plane: one launch less per slice
+__global__ __launch_bounds__(256)
+void k_gradpsi_sxsy (SlabView f, int cPsi, int cExmBy, int cEypBx, double hdx_inv, double hdy_inv,
+                     int cSx, int cSy, int cJzb, int cNx, int cNy, int cPx, int cPy,
+                     double mu0, double dx2, double dy2, double dz2, CellBox bb)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x - f.ng;
+    const int j = blockIdx.y - f.ng;
+    if (i >= f.nx + f.ng) return;
+    const long o = f.off(i, j);
+    const int gg = f.ng - 1;
+    if (i >= -gg && i < f.nx + gg && j >= -gg && j < f.ny + gg) {
+        const double* P = f.p + cPsi*f.ns + o;
+        f.p[cExmBy*f.ns + o] = -(P[1] - P[-1])*hdx_inv;
+        f.p[cEypBx*f.ns + o] = -(P[f.js] - P[-f.js])*hdy_inv;
+    }
+    const int ia = i + f.ng, ja = j + f.ng;
+    if (i < 0 || i >= f.nx || j < 0 || j >= f.ny || ia < bb.ilo || ia > bb.ihi || ja < bb.jlo || ja > bb.jhi) {
+        f.p[cSy*f.ns + o] = 0.0; f.p[cSx*f.ns + o] = 0.0; return;
+    }
+    const double* J = f.p + cJzb*f.ns + o;
+    const double dx_jzb = (J[1] - J[-1])/dx2;
+    const double dy_jzb = (J[f.js] - J[-f.js])/dy2;
+    const double dz_jxb = (f.p[cPx*f.ns + o] - f.p[cNx*f.ns + o])/dz2;
+    const double dz_jyb = (f.p[cPy*f.ns + o] - f.p[cNy*f.ns + o])/dz2;
+    f.p[cSy*f.ns + o] =  mu0*(-dy_jzb + dz_jyb);
+    f.p[cSx*f.ns + o] = -mu0*(-dx_jzb + dz_jxb);
+}
+
 // per-component sum |Q| over the valid cells, accumulated into acc[n]
 __global__ __launch_bounds__(256)
 void k_checksum (SlabView f, int ncomp, double* acc)
@@ -229,6 +258,35 @@ void k_beam_deposit (SlabView f, BeamView b, long first, long count, int cjx, in
             const double s = sx[ix]*sy[iy];
             if (cjx >= 0) { atomic_add_f64(p + cjx*f.ns, s*(wq*(ux*gaminv))); atomic_add_f64(p + cjy*f.ns, s*(wq*(uy*gaminv))); }
             if (cjz >= 0) atomic_add_f64(p + cjz*f.ns, s*(wq*(uz*gaminv)));
+        }
+    }
+}
+
+// the two beam deposits of a slice of the explicit schedule in one launch: jz of this slice's block (workgroups
+// [0, nbA)) and jx, jy of the next slice's block (the rest) -- different components, no ordering between them
+template <int ORDER>
+__global__ __launch_bounds__(256)
+void k_beam_deposit_pair (SlabView f, BeamView bA, long countA, int nbA, int cjzA, BeamView bB, long countB, int cjxB, int cjyB,
+                          double q_invvol, double clightsq_inv, double dx_inv, double dy_inv, double xoff, double yoff)
+{
+    const bool second = (int)blockIdx.x >= nbA;
+    const BeamView& b = second ? bB : bA;
+    const long ip = (long)(second ? blockIdx.x - nbA : blockIdx.x)*blockDim.x + threadIdx.x;
+    if (ip >= (second ? countB : countA)) return;
+    const double ux = b.ux[ip], uy = b.uy[ip], uz = b.uz[ip];
+    const double gaminv = 1.0/sqrt(1.0 + ux*ux*clightsq_inv + uy*uy*clightsq_inv + uz*uz*clightsq_inv);
+    const double wq = q_invvol*b.w[ip];
+    double sx[ORDER + 1], sy[ORDER + 1];
+    const int i0 = shape_weights<ORDER>((b.x[ip] - xoff)*dx_inv, sx);
+    const int j0 = shape_weights<ORDER>((b.y[ip] - yoff)*dy_inv, sy);
+#pragma unroll
+    for (int iy = 0; iy <= ORDER; ++iy) {
+#pragma unroll
+        for (int ix = 0; ix <= ORDER; ++ix) {
+            double* p = f.p + f.off(i0 + ix, j0 + iy);
+            const double s = sx[ix]*sy[iy];
+            if (second) { atomic_add_f64(p + cjxB*f.ns, s*(wq*(ux*gaminv))); atomic_add_f64(p + cjyB*f.ns, s*(wq*(uy*gaminv))); }
+            else atomic_add_f64(p + cjzA*f.ns, s*(wq*(uz*gaminv)));
         }
     }
 }
@@ -878,7 +936,25 @@ int Engine::solve_slice (int islice)
         if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st))) return e; }
         else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
     mark();   // b2
-    if ((e = deposit_beam_slice(islice, -1, -1, HPS_C_JZB))) return e;
+    // static beam: jz of this slice and jx, jy of the next one in one launch (Hipace.cpp:613-614, 656-657); a moving
+    // beam keeps the two calls (the next slice's block is only final once this slice's push has handed its slipped
+    // particles on -- it is deposited after the solves below as before)
+    const bool pair = !moving && nbeam > 0;
+    if (pair) {
+        const long fA = beam_off[d.nz - 1 - islice], cA = beam_off[d.nz - islice] - fA;
+        const long fB = islice >= 1 ? beam_off[d.nz - islice] : 0, cB = islice >= 1 ? beam_off[d.nz - islice + 1] - fB : 0;
+        if (cA + cB > 0) {
+            double* pa = beam_cur + 7*fA; double* pb = beam_cur + 7*fB;
+            const BeamView bA{pa, pa + cA, pa + 2*cA, pa + 3*cA, pa + 4*cA, pa + 5*cA, pa + 6*cA};
+            const BeamView bB{pb, pb + cB, pb + 2*cB, pb + 3*cB, pb + 4*cB, pb + 5*cB, pb + 6*cB};
+            const int nbA = (int)ceil_div(cA, 256), nbB = (int)ceil_div(cB, 256);
+            const double csq_inv = 1.0/(gm.c*gm.c);
+#define HPS_PAIR(O) hipLaunchKernelGGL(k_beam_deposit_pair<O>, dim3(nbA + nbB), b256, 0, st, f, bA, cA, nbA, HPS_C_JZB, bB, cB, HPS_C_N_JXB, \
+                                       HPS_C_N_JYB, d.beam_charge*1.0, csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff)
+            switch (d.order) { case 0: HPS_PAIR(0); break; case 1: HPS_PAIR(1); break; case 2: HPS_PAIR(2); break; default: HPS_PAIR(3); break; }
+#undef HPS_PAIR
+        }
+    } else if ((e = deposit_beam_slice(islice, -1, -1, HPS_C_JZB))) return e;
 
     // AddRhoIons + Psi, Ez, Bz solves + -grad Psi (fields/Fields.cpp:840-957)
     {   const double fa = 1.0/(gm.ep0*gm.c);
@@ -888,14 +964,21 @@ int Engine::solve_slice (int islice)
                            staging, (long)d.nx*d.ny);
         const int comps[3] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BZ};
         if ((e = hps_poisson_solve_batch(ps, 3, staging, slab, comps, st))) return e; }
-    hipLaunchKernelGGL(k_grad_psi, dim3(ceil_div(d.nx + 2*(g - 1), 256), d.ny + 2*(g - 1)), b256, 0, st, f, HPS_C_PSI,
-                       HPS_C_EXMBY, HPS_C_EYPBX, 0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy));
-
-    mark();   // b3
-    // beam jx, jy of the next slice; beam part of Sx, Sy; plasma part of Sx, Sy (Hipace.cpp:656-663)
-    if ((e = deposit_beam_slice(islice - 1, HPS_C_N_JXB, HPS_C_N_JYB, -1))) return e;
-    hipLaunchKernelGGL(k_sxsy_beam, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_SX, HPS_C_SY, HPS_C_JZB, HPS_C_N_JXB, HPS_C_N_JYB,
-                       HPS_C_P_JXB, HPS_C_P_JYB, gm.mu0, 2.0*gm.dx, 2.0*gm.dy, 2.0*gm.dz, bb);
+    if (pair) {
+        // -grad Psi and the beam part of Sx, Sy (Hipace.cpp:659-660) in one pass
+        hipLaunchKernelGGL(k_gradpsi_sxsy, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_PSI, HPS_C_EXMBY, HPS_C_EYPBX,
+                           0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy), HPS_C_SX, HPS_C_SY, HPS_C_JZB, HPS_C_N_JXB, HPS_C_N_JYB, HPS_C_P_JXB, HPS_C_P_JYB,
+                           gm.mu0, 2.0*gm.dx, 2.0*gm.dy, 2.0*gm.dz, bb);
+        mark();   // b3
+    } else {
+        hipLaunchKernelGGL(k_grad_psi, dim3(ceil_div(d.nx + 2*(g - 1), 256), d.ny + 2*(g - 1)), b256, 0, st, f, HPS_C_PSI,
+                           HPS_C_EXMBY, HPS_C_EYPBX, 0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy));
+        mark();   // b3
+        // beam jx, jy of the next slice; beam part of Sx, Sy (Hipace.cpp:656-660)
+        if ((e = deposit_beam_slice(islice - 1, HPS_C_N_JXB, HPS_C_N_JYB, -1))) return e;
+        hipLaunchKernelGGL(k_sxsy_beam, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_SX, HPS_C_SY, HPS_C_JZB, HPS_C_N_JXB, HPS_C_N_JYB,
+                           HPS_C_P_JXB, HPS_C_P_JYB, gm.mu0, 2.0*gm.dx, 2.0*gm.dy, 2.0*gm.dz, bb);
+    }
     mark();   // b4
     {   const int cache[4] = {HPS_C_BZ, HPS_C_EZ, HPS_C_EXMBY, HPS_C_EYPBX};
         const int depos[2] = {HPS_C_SY, HPS_C_SX};
