@@ -44,7 +44,7 @@ def pmc_traffic(kernel_prefix):
     k_copy_comps / k_zero_comps / k_init_plasma, whose byte counts are known: FETCH x2, WRITE x1.
     Only valid for the default 1024^2 x 4 ppc workload the counters were collected on."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01g_pmc_fetch_write_per_kernel.csv")
+    path = os.path.join(ROOT, "profiles", "r01h_pmc_fetch_write_per_kernel.csv")
     if not os.path.exists(path):
         return None
     with open(path) as f:
