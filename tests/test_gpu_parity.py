@@ -736,3 +736,30 @@ def test_insitu_plasma_moments_match_oracle(api, oracle):
         # first moments of a symmetric sheet are pure cancellation: compare against the second moments' scale
         ref = max(scale, np.sqrt(np.abs(want[min(q + 1, 13)]).max()) if name in ("[x]", "[y]", "[ux]", "[uy]") else scale)
         assert np.abs(got[name] - want[q]).max() <= 1e-9 * ref, name
+
+
+@pytest.mark.gpu
+def test_bench_line_contract():
+    """bench.py prints one JSON line with the agreed keys (a short run: 96 timed slices of the headline workload)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "96", "--warmup", "8",
+                          "--cpu-slices", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 96 and d["warmup"] == 8 and d["unit"] == "slices/s"
+    assert d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.05 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "slices/s" and c["value"] > 0
+    assert "workload" in d["config"] and "model" not in d["config"]
