@@ -43,6 +43,8 @@ _DEFAULT = dict(
     predcorr_max_iter=30,    # hipace.predcorr_max_iterations (Hipace.H:213)
     predcorr_mix=0.05,       # hipace.predcorr_B_mixing_factor (Hipace.H:222)
     field_bc=0,              # boundary.field: 0 Dirichlet; 1 Open exists in the CPU oracle only (the engine refuses it)
+    laser_on=0,              # lasers.names != no_laser: a Gaussian envelope (laser/Laser.H:32-45), static (step 0 only)
+    laser_a0=0.0, laser_w0=1.0, laser_L0=1.0, laser_lambda0=0.8e-6, laser_pos=(0.0, 0.0, 0.0),
 )
 
 
@@ -104,6 +106,15 @@ def beam_in_vacuum_open_boundary():
     return d
 
 
+def laser_blowout_wake():
+    """tests/laser_blowout_wake_explicit.1Rank.sh:32-45: blowout_wake deck without a beam, driven by a Gaussian laser
+    pulse (a0 = 4.5, w0 = 4, L0 = 2) on 128 x 128 x 100 cells, max_step = 0."""
+    d = copy.deepcopy(_DEFAULT)
+    d.update(nx=128, ny=128, nz=100, lo=(-20.0, -20.0, -7.5), hi=(20.0, 20.0, 6.0), beam_profile=-1, n_steps=1,
+             laser_on=1, laser_a0=4.5, laser_w0=4.0, laser_L0=2.0, laser_lambda0=0.8e-6, laser_pos=(0.0, 0.0, 0.0))
+    return d
+
+
 def predictor_corrector(base, tol=1.0e-4, max_iter=7, mix=0.0635):
     """`base` with hipace.bxby_solver = predictor-corrector; the defaults are the settings of the reference's own
     predictor-corrector-vs-explicit test (tests/ion_motion.SI.1Rank.sh:30-34)."""
@@ -112,5 +123,5 @@ def predictor_corrector(base, tol=1.0e-4, max_iter=7, mix=0.0635):
     return d
 
 
-NAMED = dict(linear_wake_gaussian=linear_wake_gaussian, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
+NAMED = dict(linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
              beam_evolution=beam_evolution, beam_in_vacuum_open_boundary=beam_in_vacuum_open_boundary)

@@ -226,9 +226,29 @@ struct Geom {
 // serial semantics of            particles/deposition/DepositionUtil.H:256-264
 // comp = {jx, jy, jz, rho, chi, rhomjz}, -1 to skip
 // ---------------------------------------------------------------------------------------------
-long deposit_current (const Slab& f, const Plasma& pl, const Geom& gm, const int* comp,
-                      Real charge, Real mass, int order, Real max_qsa, int can_ionize)
+// doLaserGatherShapeN (particles/particles_utils/FieldGather.H:236-331): |a|^2 (and optionally its centred x, y
+// differences) at the particle with the plain deposition-order shape
+void laser_gather (int order, Real xp, Real yp, const Slab& f, int aabs_comp, Real dx_inv, Real dy_inv, Real xoff, Real yoff,
+                   Real& A, Real* ADx, Real* ADy)
 {
+    Real sx[4], sy[4];
+    const int i0 = shape_factor(order, sx, (xp - xoff)*dx_inv);
+    const int j0 = shape_factor(order, sy, (yp - yoff)*dy_inv);
+    for (int iy = 0; iy <= order; ++iy) for (int ix = 0; ix <= order; ++ix) {
+        const int i = i0 + ix, j = j0 + iy;
+        A += sx[ix]*sy[iy]*f(i, j, aabs_comp);
+        if (ADx) {
+            *ADx += sx[ix]*sy[iy]*0.5*dx_inv*(f(i+1, j, aabs_comp) - f(i-1, j, aabs_comp));
+            *ADy += sx[ix]*sy[iy]*0.5*dy_inv*(f(i, j+1, aabs_comp) - f(i, j-1, aabs_comp));
+        }
+    }
+}
+
+long deposit_current (const Slab& f, const Plasma& pl, const Geom& gm, const int* comp,
+                      Real charge, Real mass, int order, Real max_qsa, int can_ionize, int aabs_comp = -1)
+{
+    // laser_norm (PlasmaDepositCurrent.cpp:80-81)
+    const Real laser_norm = (charge/gm.q_e)*(gm.m_e/mass)*(charge/gm.q_e)*(gm.m_e/mass);
     const Real dx_inv = 1.0/gm.dx, dy_inv = 1.0/gm.dy, dz_inv = 1.0/gm.dz;
     const Real invvol = gm.normalized ? gm.dx*gm.dy*dx_inv*dy_inv : dx_inv*dy_inv*dz_inv;
     const Real clight = gm.c, clightinv = 1.0/gm.c;
@@ -246,7 +266,11 @@ long deposit_current (const Slab& f, const Plasma& pl, const Geom& gm, const int
         if (can_ionize) { q_invvol *= pl.ion_lev[ip]; q_mu0_mass_ratio *= pl.ion_lev[ip]; }
         const Real xmid = (xp - gm.xoff)*dx_inv;
         const Real ymid = (yp - gm.yoff)*dy_inv;
-        const Real Aabssqp = 0.0;
+        Real Aabssqp = 0.0;
+        if (aabs_comp >= 0) {
+            laser_gather(order, xp, yp, f, aabs_comp, dx_inv, dy_inv, gm.xoff, gm.yoff, Aabssqp, nullptr, nullptr);
+            Aabssqp *= laser_norm*(can_ionize ? (Real)pl.ion_lev[ip]*pl.ion_lev[ip] : 1.0);
+        }
         const Real gamma_psi = 0.5*((1.0 + 0.5*Aabssqp)*psi_inv*psi_inv
                                     + vx_c*vx_c*clightinv*clightinv
                                     + vy_c*vy_c*clightinv*clightinv + 1.0);
@@ -280,8 +304,10 @@ long deposit_current (const Slab& f, const Plasma& pl, const Geom& gm, const int
 // ---------------------------------------------------------------------------------------------
 void explicit_deposit (const Slab& f, const Plasma& pl, const Geom& gm, const int* cache,
                        const int* depos, Real charge, Real mass, int order, int dtype,
-                       int can_ionize)
+                       int can_ionize, int aabs_comp = -1)
 {
+    // "The laser a0 is always normalized" (ExplicitDeposition.cpp:57-58)
+    const Real laser_fac = (gm.m_e/gm.q_e)*(gm.m_e/gm.q_e);
     const Real dx_inv = 1.0/gm.dx, dy_inv = 1.0/gm.dy, dz_inv = 1.0/gm.dz;
     const Real invvol = gm.normalized ? gm.dx*gm.dy*dx_inv*dy_inv : dx_inv*dy_inv*dz_inv;
     const Real a_clight = gm.c, clight_inv = 1.0/gm.c;
@@ -299,7 +325,11 @@ void explicit_deposit (const Slab& f, const Plasma& pl, const Geom& gm, const in
         const Real charge_density_mu0 = q_invvol_mu0*pl.w[ip];
         const Real xmid = (xp - gm.xoff)*dx_inv;
         const Real ymid = (yp - gm.yoff)*dy_inv;
-        const Real Aabssqp = 0.0;
+        Real Aabssqp = 0.0;
+        if (aabs_comp >= 0) {
+            laser_gather(order, xp, yp, f, aabs_comp, dx_inv, dy_inv, gm.xoff, gm.yoff, Aabssqp, nullptr, nullptr);
+            Aabssqp *= laser_fac*q_mass_ratio*q_mass_ratio;
+        }
         const Real gamma_psi = 0.5*((1.0 + 0.5*Aabssqp)*psi_inv*psi_inv + vx*vx + vy*vy + 1.0);
         for (int iy = 0; iy <= order + dtype; ++iy) {
             for (int ix = 0; ix <= order + dtype; ++ix) {
@@ -314,7 +344,11 @@ void explicit_deposit (const Slab& f, const Plasma& pl, const Geom& gm, const in
                 const Real Ez_v = f(i,j,cache[1]);
                 const Real ExmBy_v = f(i,j,cache[2]);
                 const Real EypBx_v = f(i,j,cache[3]);
-                const Real AabssqDxp = 0.0, AabssqDyp = 0.0;
+                Real AabssqDxp = 0.0, AabssqDyp = 0.0;
+                if (aabs_comp >= 0 && shape_x*shape_y != 0.0) {        // (:215-226)
+                    AabssqDxp = (f(i+1,j,aabs_comp) - f(i-1,j,aabs_comp))*0.5*dx_inv*laser_fac*a_clight;
+                    AabssqDyp = (f(i,j+1,aabs_comp) - f(i,j-1,aabs_comp))*0.5*dy_inv*laser_fac*a_clight;
+                }
                 f(i,j,depos[0]) += charge_density_mu0*(
                     - shape_x*shape_y*(
                         - Bz_v*vx
@@ -439,8 +473,9 @@ bool enforce_bc (const Geom& gm, Real& x, Real& y, Real& ux, Real& uy, Real& w, 
 // ---------------------------------------------------------------------------------------------
 void advance_plasma (const Slab& f, const Plasma& pl, const Geom& gm, const int* comp,
                      Real charge, Real mass, int order, int temp_slice, int n_subcycles,
-                     int can_ionize)
+                     int can_ionize, int aabs_comp = -1)
 {
+    const Real laser_norm = (charge/gm.q_e)*(gm.m_e/mass)*(charge/gm.q_e)*(gm.m_e/mass);      // (:77-78)
     const Real dx_inv = 1.0/gm.dx, dy_inv = 1.0/gm.dy;
     const Real dz = gm.dz/n_subcycles;
     const Real clight = gm.c, clight_inv = 1.0/gm.c;
@@ -448,9 +483,10 @@ void advance_plasma (const Slab& f, const Plasma& pl, const Geom& gm, const int*
     for (long ip = 0; ip < pl.n; ++ip) {
         if (!pl.valid[ip]) continue;
         Real ExmByp = 0, EypBxp = 0, Ezp = 0, Bxp = 0, Byp = 0, Bzp = 0;
-        const Real Aabssqp = 0, AabssqDxp = 0, AabssqDyp = 0;
+        Real Aabssqp = 0, AabssqDxp = 0, AabssqDyp = 0;
         Real qmc = charge_mass_clight_ratio;
-        if (can_ionize) qmc *= pl.ion_lev[ip];
+        Real laser_norm_ion = laser_norm;
+        if (can_ionize) { qmc *= pl.ion_lev[ip]; laser_norm_ion *= (Real)pl.ion_lev[ip]*pl.ion_lev[ip]; }
         bool dead = false;
         for (int isc = 0; isc < n_subcycles && !dead; ++isc) {
             Real xp = pl.x_prev[ip];
@@ -460,6 +496,13 @@ void advance_plasma (const Slab& f, const Plasma& pl, const Geom& gm, const int*
                    dx_inv, dy_inv, gm.xoff, gm.yoff);
             Bxp *= clight;
             Byp *= clight;
+            if (aabs_comp >= 0) {       // (:121-131)
+                Aabssqp = 0; AabssqDxp = 0; AabssqDyp = 0;
+                laser_gather(order, xp, yp, f, aabs_comp, dx_inv, dy_inv, gm.xoff, gm.yoff, Aabssqp, &AabssqDxp, &AabssqDyp);
+                Aabssqp *= 0.5*laser_norm_ion;
+                AabssqDxp *= 0.25*clight*laser_norm_ion;
+                AabssqDyp *= 0.25*clight*laser_norm_ion;
+            }
 
             const int nsub = 4;
             const Real sdz = dz/nsub;
@@ -895,6 +938,9 @@ struct Deck {
     double predcorr_mix;         // hipace.predcorr_B_mixing_factor (Hipace.H:222, 0.05)
     int field_bc;                // boundary.field: 0 Dirichlet, 1 Open (oracle only: pins the predictor-corrector
                                  // path on beam_in_vacuum_open_boundary.normalized.1Rank.json)
+    // Gaussian laser envelope (laser/Laser.H:32-45, MultiLaser.cpp:881-919), static: only step 0 is restated (the
+    // envelope solver that advances it to the next time step is not), explicit solver only
+    int laser_on; double laser_a0, laser_w0, laser_L0, laser_lambda0, laser_pos[3];
 };
 
 // particles of one beam slice; [0, nreg) were on the slice when the step began ("regular"), the rest slipped in
@@ -917,12 +963,14 @@ struct Engine {
     std::vector<double> checksum;      // per comp: sum |Q| over all valid cells and slices
     long total_vcycles; long n_qsa_total;
     long pc_iterations = 0; double pc_err_sum = 0.0;     // Hipace.cpp:964,1028 (m_predcorr_avg_*)
+    int c_aabs = -1; double laser_envelope_sum = 0.0;    // slab component of |a|^2; sum |a| over the box ("laserEnvelope")
     double t_deposit, t_explicit, t_push, t_poisson, t_mg, t_other;
 
     explicit Engine (const Deck& dk) : d(dk), ps(nullptr), mg(nullptr) {
         // Fields::AllocData guards (fields/Fields.cpp:63-64)
         g = (d.order + 1)/2 + 1;
         ncomp = d.bxby_solver ? (d.deposit_rho ? 23 : 22) : (d.deposit_rho ? 22 : 21);
+        if (d.laser_on && !d.bxby_solver) c_aabs = ncomp++;        // appended last
         gm.dx = (d.hi[0] - d.lo[0])/d.nx; gm.dy = (d.hi[1] - d.lo[1])/d.ny; gm.dz = (d.hi[2] - d.lo[2])/d.nz;
         gm.xoff = 0.5*(d.lo[0] + d.hi[0] - gm.dx*(d.nx - 1));
         gm.yoff = 0.5*(d.lo[1] + d.hi[1] - gm.dy*(d.ny - 1));
@@ -1157,6 +1205,35 @@ struct Engine {
         }
     }
 
+    // Step 0 of the laser: InitLaserSlice's Gaussian envelope on this slice (laser/MultiLaser.cpp:881-919, defaults of
+    // laser/Laser.H: CEP 0, no propagation angle, no pulse-front tilt, focus at the position) and UpdateLaserAabs
+    // (:214-291): aabs = |a|^2 on the field grid.  Laser grid = field grid and lasers.interp_order = 1, so the
+    // interpolation weight is 1 on the cell itself; cells outside the laser box (the guard cells) get 0.
+    void update_laser_aabs (int islice, bool accumulate) {
+        const double k0 = 2.0*M_PI/d.laser_lambda0;
+        const double pz = 0.5*(d.lo[2] + d.hi[2] - gm.dz*(d.nz - 1));
+        const double a0 = d.laser_a0, w0 = d.laser_w0, L0 = d.laser_L0, z0 = d.laser_pos[2];
+        zero_comp(c_aabs);
+        const cplx I(0.0, 1.0);
+        double sum_abs = 0.0;
+        for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i) {
+            const double x = i*gm.dx + gm.xoff - d.laser_pos[0];
+            const double y = j*gm.dy + gm.yoff - d.laser_pos[1];
+            const double z = islice*gm.dz + pz - z0;
+            const double yp = y, zp = z;                          // cos(0) y - sin(0) z, sin(0) y + cos(0) z
+            const cplx diffract_factor = 1.0 + I*(zp - 0.0 + z0*1.0)*2.0/(k0*w0*w0);
+            const cplx inv_complex_waist_2 = 1.0/(w0*w0*diffract_factor);
+            const cplx prefactor = a0/diffract_factor;
+            const cplx time_exponent = zp*zp/(L0*L0);
+            const cplx stcfactor = prefactor*std::exp(-time_exponent);
+            const cplx exp_argument = -(x*x + yp*yp)*inv_complex_waist_2;
+            const cplx envelope = stcfactor*std::exp(exp_argument)*std::exp(I*yp*k0*0.0 + 0.0);
+            slab(i, j, c_aabs) = envelope.real()*envelope.real() + envelope.imag()*envelope.imag();
+            sum_abs += std::abs(envelope);
+        }
+        if (accumulate) laser_envelope_sum += sum_abs;
+    }
+
     static double now () {
         struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9*ts.tv_nsec;
     }
@@ -1292,10 +1369,11 @@ struct Engine {
         // InitializeSlices (fields/Fields.cpp:535-586)
         for (int c : {(int)chi, (int)Sy, (int)Sx, (int)ExmBy, (int)EypBx, (int)jzb, (int)rhomjz, (int)N_jxb, (int)N_jyb}) zero_comp(c);
         if (d.deposit_rho) zero_comp(rho);
+        if (c_aabs >= 0) update_laser_aabs(islice, accumulate);
         double t1 = now(); t_other += t1 - t0;
         // plasma deposit jx jy [rho] chi rhomjz (Hipace.cpp:609-610)
         { const int comp[6] = {jx, jy, -1, d.deposit_rho ? (int)rho : -1, chi, rhomjz};
-          n_qsa_total += deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0); }
+          n_qsa_total += deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, c_aabs); }
         double t2 = now(); t_deposit += t2 - t1;
         if (moving) deposit_beam(store[islice], -1, -1, jzb, store[islice].nreg);
         else deposit_beam(beam_this, -1, -1, jzb);
@@ -1313,7 +1391,7 @@ struct Engine {
         init_sxsy_with_beam();
         double t5 = now(); t_other += t5 - t4;
         { const int cache[4] = {Bz, Ez, ExmBy, EypBx}; const int depos[2] = {Sy, Sx};
-          explicit_deposit(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0); }
+          explicit_deposit(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, c_aabs); }
         double t6 = now(); t_explicit += t6 - t5;
         // ExplicitMGSolveBxBy (Hipace.cpp:793-933)
         { const int it = mg->solve1(slab.comp(Bx), slab.comp(By), slab.comp(Sy), slab.comp(Sx), slab.comp(chi),
@@ -1330,7 +1408,7 @@ struct Engine {
         }
         double t8 = now(); t_other += t8 - t7;
         { const int comp[5] = {Psi, Ez, Bx, By, Bz};
-          advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0); }
+          advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, c_aabs); }
         if (moving) {
             // beam diagnostics before the push (Hipace.cpp:685-686), then push and hand the slipped particles
             // to the next slice (:704-706)
@@ -1441,6 +1519,7 @@ struct Engine {
         deposit_current(slab, pl, gm, comp, -d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0);
         std::fill(checksum.begin(), checksum.end(), 0.0);
         for (double& v : beam_diag) v = 0.0;
+        laser_envelope_sum = 0.0;
         if (d.dt != 0.0) {
             ensure_store();
             if (beam_import) {
@@ -1579,6 +1658,7 @@ struct orc_deck {
     int bc; double mg_tol_rel, mg_tol_abs; int deposit_rho; int n_steps;
     double dt; int beam_n_subcycles; double beam_mass; double ext_E_slope[2];
     int bxby_solver; double predcorr_tol; int predcorr_max_iter; double predcorr_mix; int field_bc;
+    int laser_on; double laser_a0, laser_w0, laser_L0, laser_lambda0, laser_pos[3];
 };
 
 void* orc_engine_create (const orc_deck* k) {
@@ -1595,6 +1675,8 @@ void* orc_engine_create (const orc_deck* k) {
     d.bxby_solver=k->bxby_solver; d.predcorr_tol=k->predcorr_tol > 0.0 ? k->predcorr_tol : 4e-2;
     d.predcorr_max_iter=k->predcorr_max_iter > 0 ? k->predcorr_max_iter : 30; d.predcorr_mix=k->predcorr_mix > 0.0 ? k->predcorr_mix : 0.05;
     d.field_bc=k->field_bc;
+    d.laser_on=k->laser_on; d.laser_a0=k->laser_a0; d.laser_w0=k->laser_w0; d.laser_L0=k->laser_L0; d.laser_lambda0=k->laser_lambda0;
+    for (int i=0;i<3;++i) d.laser_pos[i]=k->laser_pos[i];
     return new Engine(d);
 }
 void orc_engine_destroy (void* h) { delete static_cast<Engine*>(h); }
@@ -1611,6 +1693,8 @@ void orc_engine_checksums (void* h, double* out) { Engine* e = static_cast<Engin
 long orc_engine_vcycles (void* h) { return static_cast<Engine*>(h)->total_vcycles; }
 long orc_engine_pc_iterations (void* h) { return static_cast<Engine*>(h)->pc_iterations; }
 double orc_engine_pc_error_sum (void* h) { return static_cast<Engine*>(h)->pc_err_sum; }
+int orc_engine_aabs_comp (void* h) { return static_cast<Engine*>(h)->c_aabs; }
+double orc_engine_laser_envelope_sum (void* h) { return static_cast<Engine*>(h)->laser_envelope_sum; }
 void orc_engine_times (void* h, double* t6) { Engine* e = static_cast<Engine*>(h);
     t6[0]=e->t_deposit; t6[1]=e->t_explicit; t6[2]=e->t_push; t6[3]=e->t_poisson; t6[4]=e->t_mg; t6[5]=e->t_other; }
 long orc_engine_beam_layout (void* h, long* offsets) {

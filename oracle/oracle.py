@@ -62,7 +62,9 @@ class Deck(C.Structure):
                 ("deposit_rho", C.c_int), ("n_steps", C.c_int),
                 ("dt", C.c_double), ("beam_n_subcycles", C.c_int), ("beam_mass", C.c_double), ("ext_E_slope", C.c_double * 2),
                 ("bxby_solver", C.c_int), ("predcorr_tol", C.c_double), ("predcorr_max_iter", C.c_int),
-                ("predcorr_mix", C.c_double), ("field_bc", C.c_int)]
+                ("predcorr_mix", C.c_double), ("field_bc", C.c_int),
+                ("laser_on", C.c_int), ("laser_a0", C.c_double), ("laser_w0", C.c_double), ("laser_L0", C.c_double),
+                ("laser_lambda0", C.c_double), ("laser_pos", C.c_double * 3)]
 
 
 def fill_struct(st, d):
@@ -497,8 +499,21 @@ class Engine:
     def checksums(self):
         out = np.zeros(self.ncomp)
         lib().orc_engine_checksums(self._h, _ptr(out))
-        names = COMPS_PC if self.deck.get("bxby_solver", 0) else COMPS
-        return {names[i]: out[i] for i in range(self.ncomp)}
+        names = self.comp_names()
+        cs = {names[i]: out[i] for i in range(self.ncomp)}
+        if "aabs" in cs:
+            L = lib()
+            L.orc_engine_laser_envelope_sum.restype = C.c_double
+            L.orc_engine_laser_envelope_sum.argtypes = [C.c_void_p]
+            cs["laserEnvelope"] = L.orc_engine_laser_envelope_sum(self._h)
+        return cs
+
+    def comp_names(self):
+        """Names of the slab components of this engine (rho and aabs are optional and come last)."""
+        if self.deck.get("bxby_solver", 0):
+            return list(COMPS_PC[:22]) + (["rho"] if self.deck.get("deposit_rho", 0) else [])
+        return list(COMPS[:21]) + (["rho"] if self.deck.get("deposit_rho", 0) else []) + \
+            (["aabs"] if self.deck.get("laser_on", 0) else [])
 
     def vcycles(self):
         return lib().orc_engine_vcycles(self._h)
