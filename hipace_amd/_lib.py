@@ -42,7 +42,9 @@ class Deck(C.Structure):
                 ("deposit_rho", C.c_int), ("n_steps", C.c_int),
                 ("dt", C.c_double), ("beam_n_subcycles", C.c_int), ("beam_mass", C.c_double), ("ext_E_slope", C.c_double * 2),
                 ("bxby_solver", C.c_int), ("predcorr_tol", C.c_double), ("predcorr_max_iter", C.c_int),
-                ("predcorr_mix", C.c_double), ("field_bc", C.c_int)]
+                ("predcorr_mix", C.c_double), ("field_bc", C.c_int),
+                ("laser_on", C.c_int), ("laser_a0", C.c_double), ("laser_w0", C.c_double), ("laser_L0", C.c_double),
+                ("laser_lambda0", C.c_double), ("laser_pos", C.c_double * 3)]
 
 
 # engine component names, index = value of the HPS_C_* enum in include/hpslice.h
@@ -107,6 +109,13 @@ _SIGS = {
     "hps_engine_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_copy_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]),
     "hps_engine_set_profiling_stride": (C.c_int, [C.c_void_p, C.c_int]),
+    "hps_engine_laser_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "hps_deposit_current_laser": (C.c_int, [Slab, Plasma, Geom, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double,
+                                            C.c_int, C.c_void_p, C.c_void_p]),
+    "hps_explicit_deposit_laser": (C.c_int, [Slab, Plasma, Geom, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int,
+                                             C.c_int, C.c_int, C.c_void_p]),
+    "hps_advance_plasma_laser": (C.c_int, [Slab, Plasma, Geom, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_void_p]),
     "hps_engine_pc_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_double)]),
     "hps_engine_set_diagnostics": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_set_tiling": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

@@ -415,8 +415,20 @@ class SliceEngine:
     def checksums(self):
         out = (C.c_double * self.ncomp)()
         check(_lib.lib().hps_engine_checksums(self._h, out))
-        names = _lib.COMPS_PC if self.deck.get("bxby_solver", 0) else COMPS
-        return {names[i]: out[i] for i in range(self.ncomp)}
+        names = self.comp_names()
+        cs = {names[i]: out[i] for i in range(self.ncomp)}
+        if "aabs" in cs:
+            tot = C.c_double()
+            check(_lib.lib().hps_engine_laser_info(self._h, None, C.byref(tot)))
+            cs["laserEnvelope"] = tot.value
+        return cs
+
+    def comp_names(self):
+        """Names of the slab components of this engine (rho and aabs are optional and come last)."""
+        if self.deck.get("bxby_solver", 0):
+            return list(_lib.COMPS_PC[:22]) + (["rho"] if self.deck.get("deposit_rho", 0) else [])
+        return list(COMPS[:21]) + (["rho"] if self.deck.get("deposit_rho", 0) else []) + \
+            (["aabs"] if self.deck.get("laser_on", 0) else [])
 
     def pc_stats(self):
         """(predictor-corrector iterations so far, sum over slices of the final relative B-field error)."""

@@ -66,6 +66,7 @@ struct Engine {
     bool pc = false; double* d_pc = nullptr; double* h_pc = nullptr; double* h_pc_dev = nullptr; double pc_seq = 0.0; long pc_iterations = 0; double pc_err_sum = 0.0;
     double pc_tol = 4e-2, pc_mix = 0.05; int pc_max_iter = 30;
     int solve_slice_pc (int islice);
+    int c_aabs = -1; double* d_laser_sum = nullptr;       // laser: slab component of |a|^2, device sum of |a| (diagnostics)
     // field diagnostic (Fields::Copy): components, coarsening, device array [ncomps][nzc][nyc][nxc]
     std::vector<int> fd_comps; int fd_c[3] = {1, 1, 1}; double* d_fd = nullptr; int* d_fd_comps = nullptr;
     int fill_field_diagnostic (int islice);

@@ -312,6 +312,7 @@ Engine::~Engine ()
     (void)hipFree(bm_store); (void)hipFree(bm_nsub); (void)hipFree(bm_nsub_scr); (void)hipFree(d_B); (void)hipFree(d_nfront);
     (void)hipFree(d_Bimp); (void)hipFree(d_beam_overflow); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
     (void)hipFree(d_pc); if (h_pc) (void)hipHostFree(h_pc);
+    (void)hipFree(d_laser_sum);
     (void)hipFree(d_fd); (void)hipFree(d_fd_comps); (void)hipFree(d_insitu); (void)hipFree(d_insitu_pl);
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto e : hand_ev) if (e) (void)hipEventDestroy(e);
@@ -433,6 +434,12 @@ int Engine::create (const hps_deck& deck, int device)
     HPS_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     g = (d.order + 1)/2 + 1;                       // Fields::AllocData (fields/Fields.cpp:63-64)
     ncomp = pc ? (d.deposit_rho ? HPS_PC_RHO + 1 : HPS_PC_RHO) : (d.deposit_rho ? HPS_C_RHO + 1 : HPS_C_RHO);
+    if (d.laser_on) {
+        if (pc) { set_error("hps_engine_create: the laser needs the explicit solver"); return HPS_ERR_UNSUPPORTED; }
+        HPS_REQUIRE(d.laser_w0 > 0.0 && d.laser_L0 > 0.0 && d.laser_lambda0 > 0.0, "hps_engine_create: laser w0, L0, lambda0 must be positive");
+        c_aabs = ncomp++;                // appended last
+        tile_size = 0;                   // the LDS-tile kernels do not carry the laser terms yet
+    }
     gm.dx = (d.hi[0] - d.lo[0])/d.nx; gm.dy = (d.hi[1] - d.lo[1])/d.ny; gm.dz = (d.hi[2] - d.lo[2])/d.nz;
     gm.xoff = 0.5*(d.lo[0] + d.hi[0] - gm.dx*(d.nx - 1));
     gm.yoff = 0.5*(d.lo[1] + d.hi[1] - gm.dy*(d.ny - 1));
@@ -462,6 +469,8 @@ int Engine::create (const hps_deck& deck, int device)
         HPS_HIP_CHECK(hipMalloc(&pl.idcpu, (size_t)np*sizeof(uint64_t)));
         HPS_HIP_CHECK(hipMalloc(&pl.ion_lev, (size_t)np*sizeof(int32_t)));
     }
+    HPS_HIP_CHECK(hipMalloc(&d_laser_sum, sizeof(double)));
+    HPS_HIP_CHECK(hipMemset(d_laser_sum, 0, sizeof(double)));
     HPS_HIP_CHECK(hipMalloc(&d_nqsa, sizeof(int)));
     HPS_HIP_CHECK(hipMemset(d_nqsa, 0, sizeof(int)));
     HPS_HIP_CHECK(hipMalloc(&d_checksum, HPS_PC_NCOMP_MAX*sizeof(double)));
@@ -534,6 +543,7 @@ int Engine::begin_step ()
     // ResetAllQuantities (Hipace.cpp:730-742)
     HPS_HIP_CHECK(hipMemsetAsync(slab.p, 0, (size_t)slab.nstride*ncomp*sizeof(double), st));
     HPS_HIP_CHECK(hipMemsetAsync(d_checksum, 0, HPS_PC_NCOMP_MAX*sizeof(double), st));
+    HPS_HIP_CHECK(hipMemsetAsync(d_laser_sum, 0, sizeof(double), st));
     if (d_insitu_pl) HPS_HIP_CHECK(hipMemsetAsync(d_insitu_pl, 0, (size_t)15*d.nz*sizeof(double), st));
     if (d_insitu) HPS_HIP_CHECK(hipMemsetAsync(d_insitu, 0, (size_t)10*d.nz*sizeof(double), st));
     if (d_fd) HPS_HIP_CHECK(hipMemsetAsync(d_fd, 0, fd_comps.size()*(size_t)(d.nx/fd_c[0])*(d.ny/fd_c[1])*(d.nz/fd_c[2])*sizeof(double), st));
@@ -581,6 +591,45 @@ void Engine::mark ()
     if (!prof_now) return;
     if (ev_used == ev.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev.push_back(e); }
     (void)hipEventRecord(ev[ev_used++], st);
+}
+
+// ---- laser envelope at step 0 (MultiLaser::InitLaserSlice :881-919 + UpdateLaserAabs :214-291) -------------------------
+// aabs(i,j) = |a(x_i, y_j, z_slice)|^2 on the valid cells (the laser grid is the field grid, lasers.interp_order = 1: the
+// interpolation weight is 1 on the cell itself), 0 in the guard cells (outside the laser box); optionally sum |a|
+struct LaserPars { double a0, w0, L0, k0, x0, y0, z0; };
+__global__ __launch_bounds__(256)
+void k_laser_aabs (SlabView f, int c_aabs, LaserPars L, double z, double dx, double dy, double xoff, double yoff, double* sum_abs)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x - f.ng;
+    const int j = blockIdx.y - f.ng;
+    double mag = 0.0;
+    if (i < f.nx + f.ng) {
+        double v = 0.0;
+        if (i >= 0 && i < f.nx && j >= 0 && j < f.ny) {
+            const double x = i*dx + xoff - L.x0, y = j*dy + yoff - L.y0, zp = z - L.z0;
+            // diffract_factor D = 1 + i q, q = (zp - zfoc + z0) 2/(k0 w0^2), zfoc = 0
+            const double q = (zp + L.z0)*2.0/(L.k0*L.w0*L.w0);
+            const double den = 1.0 + q*q;
+            const double dr = 1.0/den, di = -q/den;                     // 1/D
+            const double wr = dr/(L.w0*L.w0), wi = di/(L.w0*L.w0);       // 1/(w0^2 D)
+            const double r2 = x*x + y*y;
+            const double er = -r2*wr - zp*zp/(L.L0*L.L0), ei = -r2*wi;   // exponent
+            const double m = exp(er);
+            double sn, cs; sincos(ei, &sn, &cs);
+            const double ar = L.a0*dr, ai = L.a0*di;                     // prefactor a0/D
+            const double re = m*(ar*cs - ai*sn), im = m*(ar*sn + ai*cs);
+            v = re*re + im*im;
+            mag = sqrt(v);
+        }
+        f.p[c_aabs*f.ns + f.off(i, j)] = v;
+    }
+    if (sum_abs) {
+        for (int o = 32; o > 0; o >>= 1) mag += __shfl_xor(mag, o);
+        __shared__ double part[4];
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mag;
+        __syncthreads();
+        if (threadIdx.x == 0) atomic_add_f64(sum_abs, part[0] + part[1] + part[2] + part[3]);
+    }
 }
 
 // ---- field diagnostics (Fields::Copy, fields/Fields.cpp:413-533) ---------------------------------------------------
@@ -924,6 +973,13 @@ int Engine::solve_slice (int islice)
         if (d.deposit_rho) z.c[z.n++] = HPS_C_RHO;
         for (int c : {HPS_C_JZB, HPS_C_N_JXB, HPS_C_N_JYB}) zb.c[zb.n++] = c;
         hipLaunchKernelGGL(k_zero_comps, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, z, zb, bb); }
+    if (c_aabs >= 0) {
+        // UpdateLaserAabs (Hipace.cpp:603): the step-0 envelope of this slice
+        const double pz = 0.5*(d.lo[2] + d.hi[2] - gm.dz*(d.nz - 1));
+        const LaserPars L{d.laser_a0, d.laser_w0, d.laser_L0, 2.0*3.14159265358979323846/d.laser_lambda0, d.laser_pos[0], d.laser_pos[1], d.laser_pos[2]};
+        hipLaunchKernelGGL(k_laser_aabs, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, c_aabs, L, islice*gm.dz + pz,
+                           gm.dx, gm.dy, gm.xoff, gm.yoff, diagnostics ? d_laser_sum : (double*)nullptr);
+    }
 
     mark();   // b1
     // plasma: jx, jy, [rho], chi, rhomjz (Hipace.cpp:609-610); beam: jz_beam on This (:613-614)
@@ -934,7 +990,7 @@ int Engine::solve_slice (int islice)
     mark();   // b1b
     {   const int comp[6] = {HPS_C_JX, HPS_C_JY, -1, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_CHI, HPS_C_RHOMJZ};
         if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st))) return e; }
-        else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
+        else        { if ((e = hps_deposit_current_laser(slab, pl, gm, comp, c_aabs, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
     mark();   // b2
     // static beam: jz of this slice and jx, jy of the next one in one launch (Hipace.cpp:613-614, 656-657); a moving
     // beam keeps the two calls (the next slice's block is only final once this slice's push has handed its slipped
@@ -983,7 +1039,7 @@ int Engine::solve_slice (int islice)
     {   const int cache[4] = {HPS_C_BZ, HPS_C_EZ, HPS_C_EXMBY, HPS_C_EYPBX};
         const int depos[2] = {HPS_C_SY, HPS_C_SX};
         if (tiling) { if ((e = explicit_deposit_tiled(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, tiling, d_nfallback, st))) return e; }
-        else        { if ((e = hps_explicit_deposit(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, st))) return e; } }
+        else        { if ((e = hps_explicit_deposit_laser(slab, pl, gm, cache, c_aabs, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, st))) return e; } }
 
     mark();   // b5
     // Bx, By: Helmholtz multigrid from the previous slice's field (Hipace.cpp:793-933)
@@ -1002,7 +1058,7 @@ int Engine::solve_slice (int islice)
     // gather + push (Hipace.cpp:699-701)
     {   const int comp[5] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ};
         if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st))) return e; }
-        else        { if ((e = hps_advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; } }
+        else        { if ((e = hps_advance_plasma_laser(slab, pl, gm, comp, c_aabs, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; } }
 
     // beam push and hand-off of the slipped particles (Hipace.cpp:704-706)
     if (moving && nbeam > 0) { if ((e = beam_push_moving(*this, islice))) return e; }
@@ -1166,6 +1222,16 @@ extern "C" int hps_engine_copy_async (void* h, void* dst, const void* src, long 
     HPS_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, E->st));
     return HPS_OK;
 }
+extern "C" int hps_engine_laser_info (void* h, int* aabs_comp, double* sum_host)
+{
+    Engine* E = static_cast<Engine*>(h);
+    if (aabs_comp) *aabs_comp = E->c_aabs;
+    if (sum_host) {
+        HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+        HPS_HIP_CHECK(hipMemcpy(sum_host, E->d_laser_sum, sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return HPS_OK;
+}
 extern "C" int hps_engine_pc_stats (void* h, long* its, double* err_sum)
 {
     Engine* E = static_cast<Engine*>(h);
@@ -1279,7 +1345,8 @@ extern "C" int hps_engine_set_tiling (void* h, int tile_size, int sort_period)
     HPS_REQUIRE(tile_size == 0 || tile_size == 16 || tile_size == 32, "hps_engine_set_tiling: tile_size must be 0, 16 or 32");
     HPS_REQUIRE(sort_period >= 1, "hps_engine_set_tiling: sort_period must be >= 1");
     HPS_REQUIRE(E->tiling == nullptr, "hps_engine_set_tiling: call before the first hps_engine_begin_step");
-    E->tile_size = tile_size; E->sort_period = sort_period;
+    E->tile_size = (E->c_aabs >= 0) ? 0 : tile_size;      // a laser run stays on the per-particle kernels
+    E->sort_period = sort_period;
     return HPS_OK;
 }
 extern "C" int hps_engine_fallbacks (void* h, long* n)

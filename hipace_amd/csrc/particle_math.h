@@ -15,6 +15,9 @@ struct PartConsts {
     double plo0, plo1, phi0, phi1;
     double dz;
     int bc, can_ionize, temp_slice, n_subcycles;
+    // laser envelope (use_laser of the reference's operators): slab component of |a|^2 (-1 = no laser) and the
+    // operator's normalisation of it (laser_norm / laser_fac)
+    int aabs; double laser_fac;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -41,6 +44,34 @@ __device__ __forceinline__ void zeta_derivs (const T& ux, const T& uy, const T& 
     dux = (gamma_psi*F.ExmBy + F.Byc + (uy*F.Bz)*psi_inv)*qmc;
     duy = (gamma_psi*F.EypBx - F.Bxc - (ux*F.Bz)*psi_inv)*qmc;
     dpsi = (((ux*F.ExmBy + uy*F.EypBx)*c_inv)*psi_inv - F.Ez)*(qmc*c_inv);
+}
+
+// the same with the ponderomotive terms of a laser envelope (PushPlasmaParticles.H:59-72): A = Aabssq_norm,
+// ADx, ADy = AabssqD{x,y}_norm
+struct LaserFld { double A, ADx, ADy; };
+template <class T>
+__device__ __forceinline__ void zeta_derivs_laser (const T& ux, const T& uy, const T& psi_inv, const Fld& F, const LaserFld& Lf,
+                                                   double c_inv, double qmc, T& dux, T& duy, T& dpsi)
+{
+    const double ci2 = c_inv*c_inv;
+    const T gamma_psi = (psi_inv*psi_inv)*0.5*( (ux*ux)*ci2 + (uy*uy)*ci2 + (1.0 + Lf.A) ) + 0.5;
+    dux = (gamma_psi*F.ExmBy + F.Byc + (uy*F.Bz)*psi_inv)*qmc - psi_inv*Lf.ADx;
+    duy = (gamma_psi*F.EypBx - F.Bxc - (ux*F.Bz)*psi_inv)*qmc - psi_inv*Lf.ADy;
+    dpsi = (((ux*F.ExmBy + uy*F.EypBx)*c_inv)*psi_inv - F.Ez)*(qmc*c_inv);
+}
+__device__ __forceinline__ void taylor2_substep_laser (double& ux, double& uy, double& psi, const Fld& F, const LaserFld& Lf,
+                                                       double c_inv, double qmc, double sdz)
+{
+    const double psi_inv = 1.0/psi;
+    double dux, duy, dpsi;
+    zeta_derivs_laser<double>(ux, uy, psi_inv, F, Lf, c_inv, qmc, dux, duy, dpsi);
+    const D2 uxd{ux, dux}, uyd{uy, duy}, pid{psi_inv, -psi_inv*psi_inv*dpsi};
+    D2 ddux, dduy, ddpsi;
+    zeta_derivs_laser<D2>(uxd, uyd, pid, F, Lf, c_inv, qmc, ddux, dduy, ddpsi);
+    const double h2 = 0.5*sdz*sdz;
+    ux += sdz*dux + h2*ddux.e;
+    uy += sdz*duy + h2*dduy.e;
+    psi += sdz*dpsi + h2*ddpsi.e;
 }
 
 __device__ __forceinline__ void taylor2_substep (double& ux, double& uy, double& psi, const Fld& F,
@@ -86,6 +117,7 @@ inline PartConsts base_consts (const hps_geom& g)
     k.c = g.c; k.c_inv = 1.0/g.c;
     k.plo0 = g.plo[0]; k.plo1 = g.plo[1]; k.phi0 = g.phi[0]; k.phi1 = g.phi[1];
     k.bc = g.bc;
+    k.aabs = -1; k.laser_fac = 0.0;
     return k;
 }
 

@@ -28,7 +28,19 @@ void k_deposit_current (SlabView f, hps_plasma pl, DepComps cm, PartConsts k, in
     double q_mu0_mass = k.b;                  // charge * mu0 / mass
     if (k.can_ionize) { const double il = (double)pl.ion_lev[ip]; q_invvol *= il; q_mu0_mass *= il; }
 
-    const double gamma_psi = 0.5*(psi_inv*psi_inv + vx_c*vx_c*k.c_inv*k.c_inv
+    // laser: |a|^2 at the particle with the plain shape (doLaserGatherShapeN, FieldGather.H:298-331), times laser_norm
+    double Aabssq = 0.0;
+    if (k.aabs >= 0) {
+        double lx[ORDER + 1], ly[ORDER + 1];
+        const int li = shape_weights<ORDER>((pl.x[ip] - k.xoff)*k.dx_inv, lx);
+        const int lj = shape_weights<ORDER>((pl.y[ip] - k.yoff)*k.dy_inv, ly);
+#pragma unroll
+        for (int iy = 0; iy <= ORDER; ++iy)
+#pragma unroll
+            for (int ix = 0; ix <= ORDER; ++ix) Aabssq += lx[ix]*ly[iy]*f.p[k.aabs*f.ns + f.off(li + ix, lj + iy)];
+        Aabssq *= k.laser_fac*(k.can_ionize ? (double)pl.ion_lev[ip]*(double)pl.ion_lev[ip] : 1.0);
+    }
+    const double gamma_psi = 0.5*((1.0 + 0.5*Aabssq)*psi_inv*psi_inv + vx_c*vx_c*k.c_inv*k.c_inv
                                   + vy_c*vy_c*k.c_inv*k.c_inv + 1.0);
     if (gamma_psi < 0.0 || gamma_psi > k.max_qsa || psi_inv < 0.0) {
         // particle violates the quasi-static approximation: drop it
@@ -83,12 +95,23 @@ void k_explicit_deposit (SlabView f, hps_plasma pl, int cBz, int cEz, int cExmBy
     double q_mass = k.b;            // charge / mass
     if (k.can_ionize) { const double il = (double)pl.ion_lev[ip]; q_invvol_mu0 *= il; q_mass *= il; }
     const double cdm = q_invvol_mu0*pl.w[ip];
-    const double gp = 0.5*(psi_inv*psi_inv + vx*vx + vy*vy + 1.0);
+    const double xmid = (pl.x[ip] - k.xoff)*k.dx_inv;
+    const double ymid = (pl.y[ip] - k.yoff)*k.dy_inv;
+    // laser: |a|^2 gathered first with the plain shape (ExplicitDeposition.cpp:167-174), its gradient per stencil cell
+    double Aabssq = 0.0;
+    if (k.aabs >= 0) {
+        double lx[ORDER + 1], ly[ORDER + 1];
+        const int li = shape_weights<ORDER>(xmid, lx), lj = shape_weights<ORDER>(ymid, ly);
+#pragma unroll
+        for (int iy = 0; iy <= ORDER; ++iy)
+#pragma unroll
+            for (int ix = 0; ix <= ORDER; ++ix) Aabssq += lx[ix]*ly[iy]*f.p[k.aabs*f.ns + f.off(li + ix, lj + iy)];
+        Aabssq *= k.laser_fac*q_mass*q_mass;
+    }
+    const double gp = 0.5*((1.0 + 0.5*Aabssq)*psi_inv*psi_inv + vx*vx + vy*vy + 1.0);
 
     double sx[NS], dsx[NS], sy[NS], dsy[NS];
     int i0, j0;
-    const double xmid = (pl.x[ip] - k.xoff)*k.dx_inv;
-    const double ymid = (pl.y[ip] - k.yoff)*k.dy_inv;
     if constexpr (DT == 2) { i0 = centred_weights<ORDER>(xmid, sx, dsx); j0 = centred_weights<ORDER>(ymid, sy, dsy); }
     else                   { i0 = nodal_weights<ORDER>(xmid, sx, dsx);   j0 = nodal_weights<ORDER>(ymid, sy, dsy); }
 
@@ -111,11 +134,17 @@ void k_explicit_deposit (SlabView f, hps_plasma pl, int cBz, int cEz, int cExmBy
             const double ss = sx[ix]*sy[iy];
             const double dxs = dsx[ix]*sy[iy]*k.dx_inv;
             const double sdy = sx[ix]*dsy[iy]*k.dy_inv;
+            double ADx = 0.0, ADy = 0.0;
+            if (k.aabs >= 0 && ss != 0.0) {      // (:215-226)
+                const double* a = p + k.aabs*f.ns;
+                ADx = (a[1] - a[-1])*0.5*k.dx_inv*k.laser_fac*k.c;
+                ADy = (a[f.js] - a[-f.js])*0.5*k.dy_inv*k.laser_fac*k.c;
+            }
             const double sy_add = cdm*(
-                - ss*( -Bz*vx + (Ez*vy + ExmBy*(-vxvy) + EypBx*gy)*k.c_inv )*qp
+                - ss*( -Bz*vx + (Ez*vy + ExmBy*(-vxvy) + EypBx*gy)*k.c_inv - 0.25*ADy*qp )*qp
                 + ( -dxs*(-vxvy) - sdy*(gy - 1.0) )*k.c);
             const double sx_add = cdm*(
-                + ss*( Bz*vy + (Ez*vx + ExmBy*gx + EypBx*(-vxvy))*k.c_inv )*qp
+                + ss*( Bz*vy + (Ez*vx + ExmBy*gx + EypBx*(-vxvy))*k.c_inv - 0.25*ADx*qp )*qp
                 + ( dxs*(gx - 1.0) + sdy*(-vxvy) )*k.c);
             atomic_add_f64(p + cSy*f.ns, sy_add);
             atomic_add_f64(p + cSx*f.ns, sx_add);
@@ -164,14 +193,38 @@ void k_advance_plasma (SlabView f, hps_plasma pl, int cPsi, int cEz, int cBx, in
         }
         F.Bxc *= k.c;
         F.Byc *= k.c;
+        // laser: |a|^2 and its centred gradient with the plain shape (doLaserGatherShapeN, FieldGather.H:236-280)
+        LaserFld Lf{0.0, 0.0, 0.0};
+        if (k.aabs >= 0) {
+            double lx[ORDER + 1], ly[ORDER + 1];
+            const int li = shape_weights<ORDER>((xp - k.xoff)*k.dx_inv, lx);
+            const int lj = shape_weights<ORDER>((yp - k.yoff)*k.dy_inv, ly);
+#pragma unroll
+            for (int iy = 0; iy <= ORDER; ++iy)
+#pragma unroll
+                for (int ix = 0; ix <= ORDER; ++ix) {
+                    const double* a = f.p + k.aabs*f.ns + f.off(li + ix, lj + iy);
+                    const double w = lx[ix]*ly[iy];
+                    Lf.A += w*a[0];
+                    Lf.ADx += w*0.5*k.dx_inv*(a[1] - a[-1]);
+                    Lf.ADy += w*0.5*k.dy_inv*(a[f.js] - a[-f.js]);
+                }
+            const double ln = k.laser_fac*(k.can_ionize ? (double)pl.ion_lev[ip]*(double)pl.ion_lev[ip] : 1.0);
+            Lf.A *= 0.5*ln; Lf.ADx *= 0.25*k.c*ln; Lf.ADy *= 0.25*k.c*ln;
+        }
 
         const double dz = k.dz;
         const double sdz = dz*0.25;
         double ux = pl.ux_half[ip], uy = pl.uy_half[ip], psi = pl.psi_half[ip];
 
         // momenta t-1/2 -> t+1/2 with the fields at t (4 second-order Taylor sub-steps)
+        if (k.aabs >= 0) {
 #pragma unroll 1
-        for (int s = 0; s < 4; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
+            for (int s = 0; s < 4; ++s) taylor2_substep_laser(ux, uy, psi, F, Lf, k.c_inv, qmc, sdz);
+        } else {
+#pragma unroll 1
+            for (int s = 0; s < 4; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
+        }
 
         // positions t -> t+1 with the momenta at t+1/2
         const double pinv = 1.0/psi;
@@ -191,8 +244,13 @@ void k_advance_plasma (SlabView f, hps_plasma pl, int cPsi, int cEz, int cBx, in
         }
 
         // extra half push t+1/2 -> t+1: time-centred state used by the deposition only
+        if (k.aabs >= 0) {
 #pragma unroll 1
-        for (int s = 0; s < 2; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
+            for (int s = 0; s < 2; ++s) taylor2_substep_laser(ux, uy, psi, F, Lf, k.c_inv, qmc, sdz);
+        } else {
+#pragma unroll 1
+            for (int s = 0; s < 2; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
+        }
         pl.ux[ip] = ux; pl.uy[ip] = uy; pl.psi[ip] = psi;
     }
 }
@@ -201,10 +259,11 @@ void k_advance_plasma (SlabView f, hps_plasma pl, int cPsi, int cEz, int cBx, in
 
 using namespace hps;
 
-extern "C" int hps_deposit_current (hps_slab slab, hps_plasma pl, hps_geom g, const int comp[6],
-                                    double charge, double mass, int order, double max_qsa,
-                                    int can_ionize, int* n_qsa, hps_stream stream)
+static int deposit_current_impl (hps_slab slab, hps_plasma pl, hps_geom g, const int comp[6],
+                                 double charge, double mass, int order, double max_qsa,
+                                 int can_ionize, int* n_qsa, hps_stream stream, int aabs_comp)
 {
+    HPS_REQUIRE(aabs_comp >= -1 && aabs_comp < slab.ncomp, "hps_deposit_current: bad aabs component");
     HPS_REQUIRE(order >= 0 && order <= 3, "hps_deposit_current: depos_order must be 0..3");
     if (int e = check_stencil(slab, (order + 1)/2, "hps_deposit_current")) return e;
     for (int c = 0; c < 6; ++c) HPS_REQUIRE(comp[c] >= -1 && comp[c] < slab.ncomp, "hps_deposit_current: bad component");
@@ -214,6 +273,7 @@ extern "C" int hps_deposit_current (hps_slab slab, hps_plasma pl, hps_geom g, co
     k.a = charge*invvol_of(g);
     k.b = charge*g.mu0/mass;
     k.max_qsa = max_qsa; k.can_ionize = can_ionize;
+    k.aabs = aabs_comp; k.laser_fac = (charge/g.q_e)*(g.m_e/mass)*(charge/g.q_e)*(g.m_e/mass);     // laser_norm
     DepComps cm{comp[0], comp[1], comp[2], comp[3], comp[4], comp[5]};
     const dim3 grid(ceil_div(pl.n, 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
@@ -228,6 +288,19 @@ extern "C" int hps_deposit_current (hps_slab slab, hps_plasma pl, hps_geom g, co
     return HPS_OK;
 }
 
+extern "C" int hps_deposit_current (hps_slab slab, hps_plasma pl, hps_geom g, const int comp[6],
+                                    double charge, double mass, int order, double max_qsa,
+                                    int can_ionize, int* n_qsa, hps_stream stream)
+{
+    return deposit_current_impl(slab, pl, g, comp, charge, mass, order, max_qsa, can_ionize, n_qsa, stream, -1);
+}
+extern "C" int hps_deposit_current_laser (hps_slab slab, hps_plasma pl, hps_geom g, const int comp[6], int aabs_comp,
+                                          double charge, double mass, int order, double max_qsa,
+                                          int can_ionize, int* n_qsa, hps_stream stream)
+{
+    return deposit_current_impl(slab, pl, g, comp, charge, mass, order, max_qsa, can_ionize, n_qsa, stream, aabs_comp);
+}
+
 template <int DT>
 static void launch_explicit (int order, dim3 grid, dim3 block, hipStream_t st, SlabView f, hps_plasma pl,
                              const int* ca, const int* de, PartConsts k)
@@ -240,10 +313,11 @@ static void launch_explicit (int order, dim3 grid, dim3 block, hipStream_t st, S
     }
 }
 
-extern "C" int hps_explicit_deposit (hps_slab slab, hps_plasma pl, hps_geom g, const int cache[4],
-                                     const int depos[2], double charge, double mass, int order,
-                                     int dtype, int can_ionize, hps_stream stream)
+static int explicit_deposit_impl (hps_slab slab, hps_plasma pl, hps_geom g, const int cache[4],
+                                  const int depos[2], double charge, double mass, int order,
+                                  int dtype, int can_ionize, hps_stream stream, int aabs_comp)
 {
+    HPS_REQUIRE(aabs_comp >= -1 && aabs_comp < slab.ncomp, "hps_explicit_deposit: bad aabs component");
     HPS_REQUIRE(order >= 0 && order <= 3, "hps_explicit_deposit: depos_order must be 0..3");
     if (dtype != 1 && dtype != 2) {
         set_error("hps_explicit_deposit: derivative_type 1 (nodal) or 2 (centred) only");
@@ -257,6 +331,7 @@ extern "C" int hps_explicit_deposit (hps_slab slab, hps_plasma pl, hps_geom g, c
     k.a = charge*invvol_of(g)*g.mu0;
     k.b = charge/mass;
     k.can_ionize = can_ionize;
+    k.aabs = aabs_comp; k.laser_fac = (g.m_e/g.q_e)*(g.m_e/g.q_e);        // laser_fac: a0 is always normalised
     const dim3 grid(ceil_div(pl.n, 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 2) launch_explicit<2>(order, grid, block, st, SlabView(slab), pl, cache, depos, k);
@@ -264,11 +339,24 @@ extern "C" int hps_explicit_deposit (hps_slab slab, hps_plasma pl, hps_geom g, c
     HPS_HIP_CHECK(hipGetLastError());
     return HPS_OK;
 }
-
-extern "C" int hps_advance_plasma (hps_slab slab, hps_plasma pl, hps_geom g, const int comp[5],
-                                   double charge, double mass, int order, int temp_slice,
-                                   int n_subcycles, int can_ionize, hps_stream stream)
+extern "C" int hps_explicit_deposit (hps_slab slab, hps_plasma pl, hps_geom g, const int cache[4],
+                                     const int depos[2], double charge, double mass, int order,
+                                     int dtype, int can_ionize, hps_stream stream)
 {
+    return explicit_deposit_impl(slab, pl, g, cache, depos, charge, mass, order, dtype, can_ionize, stream, -1);
+}
+extern "C" int hps_explicit_deposit_laser (hps_slab slab, hps_plasma pl, hps_geom g, const int cache[4], int aabs_comp,
+                                           const int depos[2], double charge, double mass, int order,
+                                           int dtype, int can_ionize, hps_stream stream)
+{
+    return explicit_deposit_impl(slab, pl, g, cache, depos, charge, mass, order, dtype, can_ionize, stream, aabs_comp);
+}
+
+static int advance_plasma_impl (hps_slab slab, hps_plasma pl, hps_geom g, const int comp[5],
+                                double charge, double mass, int order, int temp_slice,
+                                int n_subcycles, int can_ionize, hps_stream stream, int aabs_comp)
+{
+    HPS_REQUIRE(aabs_comp >= -1 && aabs_comp < slab.ncomp, "hps_advance_plasma: bad aabs component");
     HPS_REQUIRE(order >= 0 && order <= 3, "hps_advance_plasma: depos_order must be 0..3");
     HPS_REQUIRE(n_subcycles >= 1, "hps_advance_plasma: n_subcycles must be >= 1");
     if (int e = check_stencil(slab, (order + 1)/2 + 1, "hps_advance_plasma")) return e;
@@ -278,6 +366,7 @@ extern "C" int hps_advance_plasma (hps_slab slab, hps_plasma pl, hps_geom g, con
     k.a = charge/(mass*g.c);
     k.dz = g.dz/n_subcycles;
     k.temp_slice = temp_slice; k.n_subcycles = n_subcycles; k.can_ionize = can_ionize;
+    k.aabs = aabs_comp; k.laser_fac = (charge/g.q_e)*(g.m_e/mass)*(charge/g.q_e)*(g.m_e/mass);     // laser_norm
     const dim3 grid(ceil_div(pl.n, 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
     SlabView f(slab);
@@ -289,4 +378,16 @@ extern "C" int hps_advance_plasma (hps_slab slab, hps_plasma pl, hps_geom g, con
     }
     HPS_HIP_CHECK(hipGetLastError());
     return HPS_OK;
+}
+extern "C" int hps_advance_plasma (hps_slab slab, hps_plasma pl, hps_geom g, const int comp[5],
+                                   double charge, double mass, int order, int temp_slice,
+                                   int n_subcycles, int can_ionize, hps_stream stream)
+{
+    return advance_plasma_impl(slab, pl, g, comp, charge, mass, order, temp_slice, n_subcycles, can_ionize, stream, -1);
+}
+extern "C" int hps_advance_plasma_laser (hps_slab slab, hps_plasma pl, hps_geom g, const int comp[5], int aabs_comp,
+                                         double charge, double mass, int order, int temp_slice,
+                                         int n_subcycles, int can_ionize, hps_stream stream)
+{
+    return advance_plasma_impl(slab, pl, g, comp, charge, mass, order, temp_slice, n_subcycles, can_ionize, stream, aabs_comp);
 }

@@ -85,6 +85,18 @@ int hps_advance_plasma (hps_slab slab, hps_plasma plasma, hps_geom geom, const i
                         double charge, double mass, int depos_order, int temp_slice,
                         int n_subcycles, int can_ionize, hps_stream stream);
 
+/* The same three operators with a laser envelope (use_laser = true of the reference's compile-time options):
+ * aabs_comp = slab component holding |a|^2 (Comps[This]["aabs"]); -1 = no laser = the calls above. */
+int hps_deposit_current_laser (hps_slab slab, hps_plasma plasma, hps_geom geom, const int comp[6], int aabs_comp,
+                               double charge, double mass, int depos_order, double max_qsa_weighting,
+                               int can_ionize, int* n_qsa_violation, hps_stream stream);
+int hps_explicit_deposit_laser (hps_slab slab, hps_plasma plasma, hps_geom geom, const int cache[4], int aabs_comp,
+                                const int depos[2], double charge, double mass, int depos_order,
+                                int derivative_type, int can_ionize, hps_stream stream);
+int hps_advance_plasma_laser (hps_slab slab, hps_plasma plasma, hps_geom geom, const int comp[5], int aabs_comp,
+                              double charge, double mass, int depos_order, int temp_slice,
+                              int n_subcycles, int can_ionize, hps_stream stream);
+
 /* ---- tile-sorted sheet: LDS-tile variants of the three operators -------------------------- */
 
 /* Reorder hook (PlasmaParticleContainer::ReorderParticles, particles/plasma/
@@ -171,6 +183,11 @@ typedef struct {
      * hipace.predcorr_B_error_tolerance (0 -> 4e-2), predcorr_max_iterations (0 -> 30), predcorr_B_mixing_factor
      * (0 -> 0.05) (Hipace.H:210-222).  field_bc: boundary.field, 0 Dirichlet; anything else is refused. */
     int bxby_solver; double predcorr_tol; int predcorr_max_iter; double predcorr_mix; int field_bc;
+    /* SURVEY 8f-2, first half: a wake driven by a Gaussian laser envelope (laser/Laser.H:32-45, defaults CEP 0, no
+     * angle, focus at the position).  Static: the engine evaluates the step-0 envelope slice by slice (|a|^2 into the
+     * slab component "aabs", appended last) and applies it in the deposition, the explicit source and the pusher;
+     * the envelope solver that advances it to the next time step is not built.  Explicit solver, untiled kernels. */
+    int laser_on; double laser_a0, laser_w0, laser_L0, laser_lambda0, laser_pos[3];
 } hps_deck;
 
 /* slab component indices of the engine (explicit-solver layout of fields/Fields.cpp:70-122) */
@@ -202,6 +219,9 @@ int hps_engine_stats (void* handle, long* total_vcycles, long* slices_done);
 /* predictor-corrector: iterations so far and the sum over slices of the final relative B-field error
  * (m_predcorr_avg_iterations / m_predcorr_avg_B_error of Hipace.cpp:964,1028 before the division by nz) */
 int hps_engine_pc_stats (void* handle, long* iterations, double* error_sum);
+/* laser: index of the slab component "aabs" (-1 without a laser) and sum |a| over the slices solved in this step
+ * (the "laserEnvelope" checksum; needs hps_engine_set_diagnostics; synchronises the stream) */
+int hps_engine_laser_info (void* handle, int* aabs_comp, double* envelope_abs_sum_host);
 /* accumulate the per-slice checksums (costs one reduction pass per slice; off by default) */
 int hps_engine_set_diagnostics (void* handle, int on);
 /* Field diagnostics (Fields::Copy, fields/Fields.cpp:413-533; geometry of Diagnostic::ResizeFDiagFAB,
