@@ -45,6 +45,9 @@ _DEFAULT = dict(
     field_bc=0,              # boundary.field: 0 Dirichlet; 1 Open exists in the CPU oracle only (the engine refuses it)
     laser_on=0,              # lasers.names != no_laser: a Gaussian envelope (laser/Laser.H:32-45), static (step 0 only)
     laser_a0=0.0, laser_w0=1.0, laser_L0=1.0, laser_lambda0=0.8e-6, laser_pos=(0.0, 0.0, 0.0),
+    laser_zfoc=0.0,          # laser.focal_distance
+    laser_solver=0,          # lasers.solver_type: 0 keep the envelope static, 1 "fft" (MultiLaser::AdvanceSliceFFT)
+    laser_use_phase=1,       # lasers.use_phase (MultiLaser.H:203)
 )
 
 
@@ -112,6 +115,18 @@ def laser_blowout_wake():
     d = copy.deepcopy(_DEFAULT)
     d.update(nx=128, ny=128, nz=100, lo=(-20.0, -20.0, -7.5), hi=(20.0, 20.0, 6.0), beam_profile=-1, n_steps=1,
              laser_on=1, laser_a0=4.5, laser_w0=4.0, laser_L0=2.0, laser_lambda0=0.8e-6, laser_pos=(0.0, 0.0, 0.0))
+    return d
+
+
+def laser_evolution():
+    """tests/laser_evolution.SI.2Rank.sh with lasers.solver_type = fft (examples/laser/inputs_SI): a Gaussian pulse in
+    vacuum, 128 x 128 x 50 cells, 31 steps of c dt = 70 um.  The reference runs it in SI units with kp_inv = 10 um;
+    here lengths are in units of kp_inv (the envelope equation has no other scale in vacuum)."""
+    d = copy.deepcopy(_DEFAULT)
+    d.update(nx=128, ny=128, nz=50, lo=(-6.0, -6.0, -8.0), hi=(6.0, 6.0, 6.0), order=0, plasma_ppc=(0, 0), plasma_density=0.0,
+             beam_profile=-1, n_steps=31, dt=7.0,
+             laser_on=1, laser_a0=1.0, laser_w0=2.0, laser_L0=2.0, laser_lambda0=0.08, laser_pos=(0.0, 0.0, 0.0),
+             laser_zfoc=100.0, laser_solver=1, laser_use_phase=1)
     return d
 
 

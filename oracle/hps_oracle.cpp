@@ -941,6 +941,9 @@ struct Deck {
     // Gaussian laser envelope (laser/Laser.H:32-45, MultiLaser.cpp:881-919), static: only step 0 is restated (the
     // envelope solver that advances it to the next time step is not), explicit solver only
     int laser_on; double laser_a0, laser_w0, laser_L0, laser_lambda0, laser_pos[3];
+    double laser_zfoc;           // laser.focal_distance (Laser.H:43)
+    int laser_solver;            // lasers.solver_type: 0 = envelope kept static, 1 = "fft" (MultiLaser::AdvanceSliceFFT)
+    int laser_use_phase;         // lasers.use_phase (MultiLaser.H:203, default true)
 };
 
 // particles of one beam slice; [0, nreg) were on the slice when the step began ("regular"), the rest slipped in
@@ -964,6 +967,9 @@ struct Engine {
     long total_vcycles; long n_qsa_total;
     long pc_iterations = 0; double pc_err_sum = 0.0;     // Hipace.cpp:964,1028 (m_predcorr_avg_*)
     int c_aabs = -1; double laser_envelope_sum = 0.0;    // slab component of |a|^2; sum |a| over the box ("laserEnvelope")
+    // envelope at time steps n-1, n, n+1 for every slice, valid cells only ([islice][j][i]); what the reference keeps in
+    // the 9 slots of its laser slab + the MultiBuffer (utils/MultiBuffer.cpp:840-852, 913-925)
+    std::vector<cplx> la_nm1, la_n00, la_np1; int laser_steps = 0;
     double t_deposit, t_explicit, t_push, t_poisson, t_mg, t_other;
 
     explicit Engine (const Deck& dk) : d(dk), ps(nullptr), mg(nullptr) {
@@ -1205,33 +1211,126 @@ struct Engine {
         }
     }
 
-    // Step 0 of the laser: InitLaserSlice's Gaussian envelope on this slice (laser/MultiLaser.cpp:881-919, defaults of
-    // laser/Laser.H: CEP 0, no propagation angle, no pulse-front tilt, focus at the position) and UpdateLaserAabs
-    // (:214-291): aabs = |a|^2 on the field grid.  Laser grid = field grid and lasers.interp_order = 1, so the
-    // interpolation weight is 1 on the cell itself; cells outside the laser box (the guard cells) get 0.
-    void update_laser_aabs (int islice, bool accumulate) {
+    // InitLaserSlice's Gaussian envelope (laser/MultiLaser.cpp:881-919; Laser.H defaults: CEP 0, no propagation angle,
+    // no pulse-front tilt) on slice islice
+    void init_laser_slice (int islice, cplx* out) const {
         const double k0 = 2.0*M_PI/d.laser_lambda0;
         const double pz = 0.5*(d.lo[2] + d.hi[2] - gm.dz*(d.nz - 1));
-        const double a0 = d.laser_a0, w0 = d.laser_w0, L0 = d.laser_L0, z0 = d.laser_pos[2];
-        zero_comp(c_aabs);
+        const double a0 = d.laser_a0, w0 = d.laser_w0, L0 = d.laser_L0, z0 = d.laser_pos[2], zfoc = d.laser_zfoc;
         const cplx I(0.0, 1.0);
-        double sum_abs = 0.0;
         for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i) {
             const double x = i*gm.dx + gm.xoff - d.laser_pos[0];
             const double y = j*gm.dy + gm.yoff - d.laser_pos[1];
             const double z = islice*gm.dz + pz - z0;
             const double yp = y, zp = z;                          // cos(0) y - sin(0) z, sin(0) y + cos(0) z
-            const cplx diffract_factor = 1.0 + I*(zp - 0.0 + z0*1.0)*2.0/(k0*w0*w0);
+            const cplx diffract_factor = 1.0 + I*(zp - zfoc + z0*1.0)*2.0/(k0*w0*w0);
             const cplx inv_complex_waist_2 = 1.0/(w0*w0*diffract_factor);
             const cplx prefactor = a0/diffract_factor;
             const cplx time_exponent = zp*zp/(L0*L0);
             const cplx stcfactor = prefactor*std::exp(-time_exponent);
             const cplx exp_argument = -(x*x + yp*yp)*inv_complex_waist_2;
-            const cplx envelope = stcfactor*std::exp(exp_argument)*std::exp(I*yp*k0*0.0 + 0.0);
-            slab(i, j, c_aabs) = envelope.real()*envelope.real() + envelope.imag()*envelope.imag();
-            sum_abs += std::abs(envelope);
+            out[(size_t)j*d.nx + i] = stcfactor*std::exp(exp_argument)*std::exp(I*yp*k0*0.0 + 0.0);
+        }
+    }
+    // UpdateLaserAabs (:214-291): aabs = |a_n|^2 on the field grid.  Laser grid = field grid and lasers.interp_order = 1,
+    // so the interpolation weight is 1 on the cell itself; cells outside the laser box (the guard cells) get 0.
+    void update_laser_aabs (int islice, bool accumulate) {
+        const cplx* a = la_n00.data() + (size_t)islice*d.nx*d.ny;
+        zero_comp(c_aabs);
+        double sum_abs = 0.0;
+        for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i) {
+            const cplx e = a[(size_t)j*d.nx + i];
+            slab(i, j, c_aabs) = e.real()*e.real() + e.imag()*e.imag();
+            sum_abs += std::abs(e);
         }
         if (accumulate) laser_envelope_sum += sum_abs;
+    }
+    // 2-D complex DFT of an ny x nx array in place; sign = -1 forward, +1 backward (unnormalised)
+    void fft2 (std::vector<cplx>& a, int sign) const {
+        const int nx = d.nx, ny = d.ny;
+        auto run = [&] (int n, long stride, long nrows, long rstride) {
+            std::vector<cplx> tw((size_t)n), in((size_t)n), out((size_t)n);
+            for (int k = 0; k < n; ++k) { const double ang = sign*2.0*M_PI*k/n; tw[k] = cplx(std::cos(ang), std::sin(ang)); }
+            for (long r = 0; r < nrows; ++r) {
+                cplx* base = a.data() + r*rstride;
+                for (int k = 0; k < n; ++k) in[k] = base[(long)k*stride];
+                fft_rec(n, 1, in.data(), out.data(), tw, n);
+                for (int k = 0; k < n; ++k) base[(long)k*stride] = out[k];
+            }
+        };
+        run(nx, 1, ny, nx);
+        run(ny, nx, nx, 1);
+    }
+    // MultiLaser::AdvanceSliceFFT (laser/MultiLaser.cpp:609-801): a_{n+1} on slice j from a_n, a_{n-1} on slices j, j+1,
+    // j+2 and a_{n+1} on j+1, j+2 (zeros beyond the head of the box), chi of this slice; level 0, laser grid = field grid
+    void advance_laser_slice (int islice) {
+        const int nx = d.nx, ny = d.ny; const size_t pl2 = (size_t)nx*ny;
+        const double dx = gm.dx, dy = gm.dy, dz = gm.dz, c = gm.c, dt = d.dt;
+        const double k0 = 2.0*M_PI/d.laser_lambda0;
+        const cplx I(0.0, 1.0);
+        static const std::vector<cplx> zeros_dummy;
+        std::vector<cplx> zero(pl2, cplx(0.0, 0.0));
+        auto at = [&] (const std::vector<cplx>& v, int sl) -> const cplx* { return (sl < d.nz) ? v.data() + (size_t)sl*pl2 : zero.data(); };
+        const cplx *n00j00 = at(la_n00, islice), *n00jp1 = at(la_n00, islice + 1), *n00jp2 = at(la_n00, islice + 2);
+        const cplx *nm1j00 = at(la_nm1, islice), *nm1jp1 = at(la_nm1, islice + 1), *nm1jp2 = at(la_nm1, islice + 2);
+        const cplx *np1jp1 = at(la_np1, islice + 1), *np1jp2 = at(la_np1, islice + 2);
+        const int step = laser_steps;
+        const int imid = (nx + 1)/2, jmid = (ny + 1)/2;
+        double tj00 = 0.0, tjp1 = 0.0, tjp2 = 0.0;
+        if (d.laser_use_phase) {
+            cplx s0 = 0.0, s1 = 0.0, s2 = 0.0;
+            for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+                const bool kx_ = (nx % 2 == 0) ? (i == imid - 1 || i == imid) : (i == imid);
+                const bool ky_ = (ny % 2 == 0) ? (j == jmid - 1 || j == jmid) : (j == jmid);
+                if (kx_ && ky_) { s0 += n00j00[(size_t)j*nx + i]; s1 += n00jp1[(size_t)j*nx + i]; s2 += n00jp2[(size_t)j*nx + i]; }
+            }
+            tj00 = std::atan2(s0.imag(), s0.real()); tjp1 = std::atan2(s1.imag(), s1.real()); tjp2 = std::atan2(s2.imag(), s2.real());
+        }
+        double dt1 = tj00 - tjp1, dt2 = tjp1 - tjp2;
+        if (dt1 < -1.5*M_PI) dt1 += 2.0*M_PI;
+        if (dt1 >  1.5*M_PI) dt1 -= 2.0*M_PI;
+        if (dt2 < -1.5*M_PI) dt2 += 2.0*M_PI;
+        if (dt2 >  1.5*M_PI) dt2 -= 2.0*M_PI;
+        const cplx exp1 = std::exp(I*(tj00 - tjp1)), exp2 = std::exp(I*(tj00 - tjp2));
+        const double djn = (-3.0*dt1 + dt2)/(2.0*dz);
+        std::vector<cplx> rhs(pl2);
+        const cplx* lapsrc = (step == 0) ? n00j00 : nm1j00;
+        for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const size_t o = (size_t)j*nx + i;
+            cplx lapA(0.0, 0.0);
+            if (i > 0 && i < nx - 1 && j > 0 && j < ny - 1)
+                lapA = (lapsrc[o + 1] + lapsrc[o - 1] - 2.0*lapsrc[o])/(dx*dx) + (lapsrc[o + nx] + lapsrc[o - nx] - 2.0*lapsrc[o])/(dy*dy);
+            const double chi_v = slab(i, j, chi);
+            if (step == 0) {
+                rhs[o] = 8.0/(c*dt*dz)*(-np1jp1[o] + n00jp1[o])*exp1
+                       + 2.0/(c*dt*dz)*(+np1jp2[o] - n00jp2[o])*exp2
+                       + 2.0*chi_v*n00j00[o]
+                       - lapA
+                       + (-6.0/(c*dt*dz) + 4.0*I*djn/(c*dt) + I*4.0*k0/(c*dt))*n00j00[o];
+            } else {
+                rhs[o] = 4.0/(c*dt*dz)*(-np1jp1[o] + nm1jp1[o])*exp1
+                       + 1.0/(c*dt*dz)*(+np1jp2[o] - nm1jp2[o])*exp2
+                       - 4.0/(c*c*dt*dt)*n00j00[o]
+                       + 2.0*chi_v*n00j00[o]
+                       - lapA
+                       + (-3.0/(c*dt*dz) + 2.0*I*djn/(c*dt) + 2.0/(c*c*dt*dt) + I*2.0*k0/(c*dt))*nm1j00[o];
+            }
+        }
+        fft2(rhs, -1);
+        const double dkx = 2.0*M_PI/(d.hi[0] - d.lo[0]), dky = 2.0*M_PI/(d.hi[1] - d.lo[1]);
+        const cplx acoeff = (step == 0) ? cplx(6.0/(c*dt*dz), 0.0) - I*4.0*(k0 + djn)/(c*dt)
+                                        : cplx(3.0/(c*dt*dz) + 2.0/(c*c*dt*dt), 0.0) - I*2.0*(k0 + djn)/(c*dt);
+        for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
+            const double kx = (i < imid) ? dkx*i : dkx*(i - nx);
+            const double ky = (j < jmid) ? dky*j : dky*(j - ny);
+            const cplx den = kx*kx + ky*ky + acoeff;
+            const cplx inv = (std::abs(den) > 0.0) ? 1.0/den : cplx(0.0, 0.0);
+            rhs[(size_t)j*nx + i] *= -inv;
+        }
+        fft2(rhs, +1);
+        const double inv_n = 1.0/((double)nx*ny);
+        cplx* out = la_np1.data() + (size_t)islice*pl2;
+        for (size_t o = 0; o < pl2; ++o) out[o] = rhs[o]*inv_n;
     }
 
     static double now () {
@@ -1382,6 +1481,8 @@ struct Engine {
         if (d.deposit_rho) for (long k = 0; k < slab.ns; ++k) slab.comp(rho)[k] += slab.comp(Ion_rhomjz)[k];
         double t3 = now(); t_other += t3 - t2;
         solve_psi_ez_bz(rhomjz, jx, jy, Psi, Ez, Bz, ExmBy, EypBx);
+        // m_multi_laser.AdvanceSlice (Hipace.cpp:637)
+        if (c_aabs >= 0 && d.laser_solver == 1 && d.dt != 0.0) advance_laser_slice(islice);
         double t4 = now(); t_poisson += t4 - t3;
         if (moving) { if (islice - 1 >= 0) deposit_beam(store[islice - 1], N_jxb, N_jyb, -1, store[islice - 1].nreg); }
         else {
@@ -1520,6 +1621,18 @@ struct Engine {
         std::fill(checksum.begin(), checksum.end(), 0.0);
         for (double& v : beam_diag) v = 0.0;
         laser_envelope_sum = 0.0;
+        if (c_aabs >= 0) {
+            const size_t tot = (size_t)d.nx*d.ny*d.nz;
+            if (la_n00.empty()) {
+                la_n00.assign(tot, cplx(0.0, 0.0)); la_nm1.assign(tot, cplx(0.0, 0.0)); la_np1.assign(tot, cplx(0.0, 0.0));
+                for (int k = 0; k < d.nz; ++k) init_laser_slice(k, la_n00.data() + (size_t)k*d.nx*d.ny);
+                laser_steps = 0;
+            } else if (d.laser_solver == 1 && d.dt != 0.0) {
+                // what put_data / get_data move between two steps: a_{n+1} -> a_n, a_n -> a_{n-1} (MultiBuffer.cpp:840-852, 913-925)
+                la_nm1.swap(la_n00); la_n00.swap(la_np1);
+                ++laser_steps;
+            }
+        }
         if (d.dt != 0.0) {
             ensure_store();
             if (beam_import) {
@@ -1659,6 +1772,7 @@ struct orc_deck {
     double dt; int beam_n_subcycles; double beam_mass; double ext_E_slope[2];
     int bxby_solver; double predcorr_tol; int predcorr_max_iter; double predcorr_mix; int field_bc;
     int laser_on; double laser_a0, laser_w0, laser_L0, laser_lambda0, laser_pos[3];
+    double laser_zfoc; int laser_solver; int laser_use_phase;
 };
 
 void* orc_engine_create (const orc_deck* k) {
@@ -1677,6 +1791,7 @@ void* orc_engine_create (const orc_deck* k) {
     d.field_bc=k->field_bc;
     d.laser_on=k->laser_on; d.laser_a0=k->laser_a0; d.laser_w0=k->laser_w0; d.laser_L0=k->laser_L0; d.laser_lambda0=k->laser_lambda0;
     for (int i=0;i<3;++i) d.laser_pos[i]=k->laser_pos[i];
+    d.laser_zfoc=k->laser_zfoc; d.laser_solver=k->laser_solver; d.laser_use_phase=k->laser_use_phase;
     return new Engine(d);
 }
 void orc_engine_destroy (void* h) { delete static_cast<Engine*>(h); }
@@ -1695,6 +1810,8 @@ long orc_engine_pc_iterations (void* h) { return static_cast<Engine*>(h)->pc_ite
 double orc_engine_pc_error_sum (void* h) { return static_cast<Engine*>(h)->pc_err_sum; }
 int orc_engine_aabs_comp (void* h) { return static_cast<Engine*>(h)->c_aabs; }
 double orc_engine_laser_envelope_sum (void* h) { return static_cast<Engine*>(h)->laser_envelope_sum; }
+// envelope a_n of the step that has begun, [nz][ny][nx] complex (interleaved re, im); null without a laser
+const double* orc_engine_laser_envelope (void* h) { Engine* e = static_cast<Engine*>(h); return e->la_n00.empty() ? nullptr : reinterpret_cast<const double*>(e->la_n00.data()); }
 void orc_engine_times (void* h, double* t6) { Engine* e = static_cast<Engine*>(h);
     t6[0]=e->t_deposit; t6[1]=e->t_explicit; t6[2]=e->t_push; t6[3]=e->t_poisson; t6[4]=e->t_mg; t6[5]=e->t_other; }
 long orc_engine_beam_layout (void* h, long* offsets) {

@@ -64,7 +64,8 @@ class Deck(C.Structure):
                 ("bxby_solver", C.c_int), ("predcorr_tol", C.c_double), ("predcorr_max_iter", C.c_int),
                 ("predcorr_mix", C.c_double), ("field_bc", C.c_int),
                 ("laser_on", C.c_int), ("laser_a0", C.c_double), ("laser_w0", C.c_double), ("laser_L0", C.c_double),
-                ("laser_lambda0", C.c_double), ("laser_pos", C.c_double * 3)]
+                ("laser_lambda0", C.c_double), ("laser_pos", C.c_double * 3),
+                ("laser_zfoc", C.c_double), ("laser_solver", C.c_int), ("laser_use_phase", C.c_int)]
 
 
 def fill_struct(st, d):
@@ -507,6 +508,17 @@ class Engine:
             L.orc_engine_laser_envelope_sum.argtypes = [C.c_void_p]
             cs["laserEnvelope"] = L.orc_engine_laser_envelope_sum(self._h)
         return cs
+
+    def laser_envelope(self):
+        """a_n of the step that has begun: complex array [nz, ny, nx]."""
+        L = lib()
+        L.orc_engine_laser_envelope.restype = C.c_void_p
+        L.orc_engine_laser_envelope.argtypes = [C.c_void_p]
+        ptr = L.orc_engine_laser_envelope(self._h)
+        d = self.deck
+        n = d["nz"] * d["ny"] * d["nx"]
+        buf = (C.c_double * (2 * n)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.complex128).reshape(d["nz"], d["ny"], d["nx"])
 
     def comp_names(self):
         """Names of the slab components of this engine (rho and aabs are optional and come last)."""

@@ -107,3 +107,29 @@ def test_field_diagnostic_coarsening_as_the_reference_checks_it(oracle):
     cs = eng.checksums()
     for n, name in enumerate(names):
         assert abs(np.abs(fine.F[n]).sum() - cs[name]) <= 1e-12 * cs[name]
+
+
+def test_laser_evolution_fft_solver_reproduces_reference_checksums(oracle):
+    """tests/laser_evolution.SI.2Rank.sh (last run: lasers.solver_type = fft): a Gaussian pulse focused 1 mm ahead
+    propagates through vacuum for 30 steps of c dt = 70 um (MultiLaser::AdvanceSliceFFT with the on-axis phase terms).
+    The fixture holds the checksums of the xz diagnostic slice of step 30: the envelope and |a|^2 interpolated onto
+    y = 0, i.e. the mean of the two central rows (Diagnostic::TrimIOBox, diagnostics/Diagnostic.cpp:392-407)."""
+    import numpy as np
+    gold = json.load(open(os.path.join(GOLD, "laser_evolution.SI.2Rank.json")))["lev=0"]
+    deck = decks.laser_evolution()
+    eng = oracle.Engine(deck)
+    for step in range(deck["n_steps"]):
+        eng.begin_step()
+        for isl in range(deck["nz"] - 1, -1, -1):
+            eng.solve_slice(isl)
+    a = eng.laser_envelope()
+    ny = deck["ny"]
+    env = np.abs(0.5 * (a[:, ny // 2 - 1, :] + a[:, ny // 2, :])).sum()
+    aabs = np.abs(a) ** 2
+    aabs_xz = (0.5 * (aabs[:, ny // 2 - 1, :] + aabs[:, ny // 2, :])).sum()
+    assert abs(env - gold["laserEnvelope"]) <= 1e-11 * gold["laserEnvelope"], (env, gold["laserEnvelope"])
+    assert abs(aabs_xz - gold["aabs"]) <= 1e-11 * gold["aabs"], (aabs_xz, gold["aabs"])
+    cs = eng.checksums()
+    for k, v in gold.items():
+        if v == 0.0 and k in cs:
+            assert cs[k] == 0.0, k          # vacuum: no wake
