@@ -44,7 +44,8 @@ class Deck(C.Structure):
                 ("bxby_solver", C.c_int), ("predcorr_tol", C.c_double), ("predcorr_max_iter", C.c_int),
                 ("predcorr_mix", C.c_double), ("field_bc", C.c_int),
                 ("laser_on", C.c_int), ("laser_a0", C.c_double), ("laser_w0", C.c_double), ("laser_L0", C.c_double),
-                ("laser_lambda0", C.c_double), ("laser_pos", C.c_double * 3)]
+                ("laser_lambda0", C.c_double), ("laser_pos", C.c_double * 3),
+                ("laser_zfoc", C.c_double), ("laser_solver", C.c_int), ("laser_use_phase", C.c_int)]
 
 
 # engine component names, index = value of the HPS_C_* enum in include/hpslice.h
@@ -109,6 +110,7 @@ _SIGS = {
     "hps_engine_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_copy_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]),
     "hps_engine_set_profiling_stride": (C.c_int, [C.c_void_p, C.c_int]),
+    "hps_engine_laser_envelope": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_laser_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "hps_deposit_current_laser": (C.c_int, [Slab, Plasma, Geom, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double,
                                             C.c_int, C.c_void_p, C.c_void_p]),

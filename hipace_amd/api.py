@@ -423,6 +423,13 @@ class SliceEngine:
             cs["laserEnvelope"] = tot.value
         return cs
 
+    def laser_envelope(self):
+        """a_n of the step that has begun: complex array [nz, ny, nx]."""
+        d = self.deck
+        out = np.empty((d["nz"], d["ny"], d["nx"]), dtype=np.complex128)
+        check(_lib.lib().hps_engine_laser_envelope(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def comp_names(self):
         """Names of the slab components of this engine (rho and aabs are optional and come last)."""
         if self.deck.get("bxby_solver", 0):

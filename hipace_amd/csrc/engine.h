@@ -10,6 +10,8 @@ void mg_rider (void* mg_handle, int** dev_words, const int** host_words);     //
 
 namespace hps {
 
+struct LaserState;      // laser.hip
+
 struct BeamView { double *x, *y, *z, *ux, *uy, *uz, *w; };
 struct BeamSoA { double *x, *y, *z, *ux, *uy, *uz, *w; int* nsub; };     // moving beam (beam.hip); nsub < 0: absorbed
 
@@ -67,6 +69,7 @@ struct Engine {
     double pc_tol = 4e-2, pc_mix = 0.05; int pc_max_iter = 30;
     int solve_slice_pc (int islice);
     int c_aabs = -1; double* d_laser_sum = nullptr;       // laser: slab component of |a|^2, device sum of |a| (diagnostics)
+    LaserState* laser = nullptr;                          // envelope arrays + solver (laser.hip)
     // field diagnostic (Fields::Copy): components, coarsening, device array [ncomps][nzc][nyc][nxc]
     std::vector<int> fd_comps; int fd_c[3] = {1, 1, 1}; double* d_fd = nullptr; int* d_fd_comps = nullptr;
     int fill_field_diagnostic (int islice);
@@ -82,6 +85,12 @@ struct Engine {
     int run_step ();
 };
 
+int laser_create (Engine& E);                                                // laser.hip
+void laser_destroy (Engine& E);
+int laser_begin_step (Engine& E);
+int laser_update_aabs (Engine& E, int islice, double* sum_abs);
+int laser_advance_slice (Engine& E, int islice);
+int laser_copy_envelope (Engine& E, double* out_host);
 int beam_deposit_moving (Engine& E, int p, int cjx, int cjy, int cjz);      // beam.hip
 int beam_push_moving (Engine& E, int islice);
 int beam_export_slice (Engine& E, int islice, double* msg_dev, long cap);

@@ -313,6 +313,7 @@ Engine::~Engine ()
     (void)hipFree(d_Bimp); (void)hipFree(d_beam_overflow); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
     (void)hipFree(d_pc); if (h_pc) (void)hipHostFree(h_pc);
     (void)hipFree(d_laser_sum);
+    if (laser) laser_destroy(*this);
     (void)hipFree(d_fd); (void)hipFree(d_fd_comps); (void)hipFree(d_insitu); (void)hipFree(d_insitu_pl);
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto e : hand_ev) if (e) (void)hipEventDestroy(e);
@@ -437,6 +438,7 @@ int Engine::create (const hps_deck& deck, int device)
     if (d.laser_on) {
         if (pc) { set_error("hps_engine_create: the laser needs the explicit solver"); return HPS_ERR_UNSUPPORTED; }
         HPS_REQUIRE(d.laser_w0 > 0.0 && d.laser_L0 > 0.0 && d.laser_lambda0 > 0.0, "hps_engine_create: laser w0, L0, lambda0 must be positive");
+        if (d.laser_solver != 0 && d.laser_solver != 1) { set_error("hps_engine_create: lasers.solver_type fft (1) only; the multigrid envelope solver is not built"); return HPS_ERR_UNSUPPORTED; }
         c_aabs = ncomp++;                // appended last
         tile_size = 0;                   // the LDS-tile kernels do not carry the laser terms yet
     }
@@ -491,6 +493,7 @@ int Engine::create (const hps_deck& deck, int device)
         HPS_HIP_CHECK(hipHostGetDevicePointer((void**)&h_pc_dev, h_pc, 0));
         d_nfallback = reinterpret_cast<int*>(d_pc + 2); h_nfallback = reinterpret_cast<const int*>(h_pc + 2);
     }
+    if (c_aabs >= 0) { if (int e = laser_create(*this)) return e; }
     return init_beam();
 }
 
@@ -544,6 +547,7 @@ int Engine::begin_step ()
     HPS_HIP_CHECK(hipMemsetAsync(slab.p, 0, (size_t)slab.nstride*ncomp*sizeof(double), st));
     HPS_HIP_CHECK(hipMemsetAsync(d_checksum, 0, HPS_PC_NCOMP_MAX*sizeof(double), st));
     HPS_HIP_CHECK(hipMemsetAsync(d_laser_sum, 0, sizeof(double), st));
+    if (laser) { if (int e = laser_begin_step(*this)) return e; }
     if (d_insitu_pl) HPS_HIP_CHECK(hipMemsetAsync(d_insitu_pl, 0, (size_t)15*d.nz*sizeof(double), st));
     if (d_insitu) HPS_HIP_CHECK(hipMemsetAsync(d_insitu, 0, (size_t)10*d.nz*sizeof(double), st));
     if (d_fd) HPS_HIP_CHECK(hipMemsetAsync(d_fd, 0, fd_comps.size()*(size_t)(d.nx/fd_c[0])*(d.ny/fd_c[1])*(d.nz/fd_c[2])*sizeof(double), st));
@@ -591,45 +595,6 @@ void Engine::mark ()
     if (!prof_now) return;
     if (ev_used == ev.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev.push_back(e); }
     (void)hipEventRecord(ev[ev_used++], st);
-}
-
-// ---- laser envelope at step 0 (MultiLaser::InitLaserSlice :881-919 + UpdateLaserAabs :214-291) -------------------------
-// aabs(i,j) = |a(x_i, y_j, z_slice)|^2 on the valid cells (the laser grid is the field grid, lasers.interp_order = 1: the
-// interpolation weight is 1 on the cell itself), 0 in the guard cells (outside the laser box); optionally sum |a|
-struct LaserPars { double a0, w0, L0, k0, x0, y0, z0; };
-__global__ __launch_bounds__(256)
-void k_laser_aabs (SlabView f, int c_aabs, LaserPars L, double z, double dx, double dy, double xoff, double yoff, double* sum_abs)
-{
-    const int i = blockIdx.x*blockDim.x + threadIdx.x - f.ng;
-    const int j = blockIdx.y - f.ng;
-    double mag = 0.0;
-    if (i < f.nx + f.ng) {
-        double v = 0.0;
-        if (i >= 0 && i < f.nx && j >= 0 && j < f.ny) {
-            const double x = i*dx + xoff - L.x0, y = j*dy + yoff - L.y0, zp = z - L.z0;
-            // diffract_factor D = 1 + i q, q = (zp - zfoc + z0) 2/(k0 w0^2), zfoc = 0
-            const double q = (zp + L.z0)*2.0/(L.k0*L.w0*L.w0);
-            const double den = 1.0 + q*q;
-            const double dr = 1.0/den, di = -q/den;                     // 1/D
-            const double wr = dr/(L.w0*L.w0), wi = di/(L.w0*L.w0);       // 1/(w0^2 D)
-            const double r2 = x*x + y*y;
-            const double er = -r2*wr - zp*zp/(L.L0*L.L0), ei = -r2*wi;   // exponent
-            const double m = exp(er);
-            double sn, cs; sincos(ei, &sn, &cs);
-            const double ar = L.a0*dr, ai = L.a0*di;                     // prefactor a0/D
-            const double re = m*(ar*cs - ai*sn), im = m*(ar*sn + ai*cs);
-            v = re*re + im*im;
-            mag = sqrt(v);
-        }
-        f.p[c_aabs*f.ns + f.off(i, j)] = v;
-    }
-    if (sum_abs) {
-        for (int o = 32; o > 0; o >>= 1) mag += __shfl_xor(mag, o);
-        __shared__ double part[4];
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mag;
-        __syncthreads();
-        if (threadIdx.x == 0) atomic_add_f64(sum_abs, part[0] + part[1] + part[2] + part[3]);
-    }
 }
 
 // ---- field diagnostics (Fields::Copy, fields/Fields.cpp:413-533) ---------------------------------------------------
@@ -974,11 +939,8 @@ int Engine::solve_slice (int islice)
         for (int c : {HPS_C_JZB, HPS_C_N_JXB, HPS_C_N_JYB}) zb.c[zb.n++] = c;
         hipLaunchKernelGGL(k_zero_comps, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, z, zb, bb); }
     if (c_aabs >= 0) {
-        // UpdateLaserAabs (Hipace.cpp:603): the step-0 envelope of this slice
-        const double pz = 0.5*(d.lo[2] + d.hi[2] - gm.dz*(d.nz - 1));
-        const LaserPars L{d.laser_a0, d.laser_w0, d.laser_L0, 2.0*3.14159265358979323846/d.laser_lambda0, d.laser_pos[0], d.laser_pos[1], d.laser_pos[2]};
-        hipLaunchKernelGGL(k_laser_aabs, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, c_aabs, L, islice*gm.dz + pz,
-                           gm.dx, gm.dy, gm.xoff, gm.yoff, diagnostics ? d_laser_sum : (double*)nullptr);
+        // UpdateLaserAabs (Hipace.cpp:603)
+        if ((e = laser_update_aabs(*this, islice, diagnostics ? d_laser_sum : nullptr))) return e;
     }
 
     mark();   // b1
@@ -1020,6 +982,8 @@ int Engine::solve_slice (int islice)
                            staging, (long)d.nx*d.ny);
         const int comps[3] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BZ};
         if ((e = hps_poisson_solve_batch(ps, 3, staging, slab, comps, st))) return e; }
+    // m_multi_laser.AdvanceSlice (Hipace.cpp:637): a_{n+1} of this slice from chi and the neighbouring slices
+    if (c_aabs >= 0 && d.laser_solver == 1 && d.dt != 0.0) { if ((e = laser_advance_slice(*this, islice))) return e; }
     if (pair) {
         // -grad Psi and the beam part of Sx, Sy (Hipace.cpp:659-660) in one pass
         hipLaunchKernelGGL(k_gradpsi_sxsy, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_PSI, HPS_C_EXMBY, HPS_C_EYPBX,
@@ -1221,6 +1185,12 @@ extern "C" int hps_engine_copy_async (void* h, void* dst, const void* src, long 
     HPS_REQUIRE(dst && src, "hps_engine_copy_async: null pointer");
     HPS_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, E->st));
     return HPS_OK;
+}
+extern "C" int hps_engine_laser_envelope (void* h, double* out_host)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E->laser && out_host, "hps_engine_laser_envelope: no laser");
+    return laser_copy_envelope(*E, out_host);
 }
 extern "C" int hps_engine_laser_info (void* h, int* aabs_comp, double* sum_host)
 {

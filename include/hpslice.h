@@ -183,11 +183,13 @@ typedef struct {
      * hipace.predcorr_B_error_tolerance (0 -> 4e-2), predcorr_max_iterations (0 -> 30), predcorr_B_mixing_factor
      * (0 -> 0.05) (Hipace.H:210-222).  field_bc: boundary.field, 0 Dirichlet; anything else is refused. */
     int bxby_solver; double predcorr_tol; int predcorr_max_iter; double predcorr_mix; int field_bc;
-    /* SURVEY 8f-2, first half: a wake driven by a Gaussian laser envelope (laser/Laser.H:32-45, defaults CEP 0, no
-     * angle, focus at the position).  Static: the engine evaluates the step-0 envelope slice by slice (|a|^2 into the
-     * slab component "aabs", appended last) and applies it in the deposition, the explicit source and the pusher;
-     * the envelope solver that advances it to the next time step is not built.  Explicit solver, untiled kernels. */
+    /* a Gaussian laser envelope (laser/Laser.H:32-45; CEP 0, no propagation angle) drives the wake:
+     * |a|^2 goes into the slab component "aabs" (appended last) and enters the deposition, the explicit source and the
+     * pusher.  laser_solver = 1 ("fft", MultiLaser::AdvanceSliceFFT) advances the envelope by hipace.dt every step
+     * (laser_use_phase = lasers.use_phase); 0 keeps it static.  The multigrid envelope solver is not built.
+     * Explicit solver, per-particle kernels. */
     int laser_on; double laser_a0, laser_w0, laser_L0, laser_lambda0, laser_pos[3];
+    double laser_zfoc; int laser_solver; int laser_use_phase;
 } hps_deck;
 
 /* slab component indices of the engine (explicit-solver layout of fields/Fields.cpp:70-122) */
@@ -222,6 +224,8 @@ int hps_engine_pc_stats (void* handle, long* iterations, double* error_sum);
 /* laser: index of the slab component "aabs" (-1 without a laser) and sum |a| over the slices solved in this step
  * (the "laserEnvelope" checksum; needs hps_engine_set_diagnostics; synchronises the stream) */
 int hps_engine_laser_info (void* handle, int* aabs_comp, double* envelope_abs_sum_host);
+/* the envelope a_n of the step that has begun: [nz][ny][nx] complex (re, im interleaved) to the host; synchronises */
+int hps_engine_laser_envelope (void* handle, double* out_host);
 /* accumulate the per-slice checksums (costs one reduction pass per slice; off by default) */
 int hps_engine_set_diagnostics (void* handle, int on);
 /* Field diagnostics (Fields::Copy, fields/Fields.cpp:413-533; geometry of Diagnostic::ResizeFDiagFAB,

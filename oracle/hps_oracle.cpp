@@ -1294,13 +1294,17 @@ struct Engine {
         const cplx exp1 = std::exp(I*(tj00 - tjp1)), exp2 = std::exp(I*(tj00 - tjp2));
         const double djn = (-3.0*dt1 + dt2)/(2.0*dz);
         std::vector<cplx> rhs(pl2);
+        const double chi0 = d.plasma_density > 0.0 ? d.plasma_density*d.plasma_charge*d.plasma_charge*gm.mu0/d.plasma_mass : 0.0;
         const cplx* lapsrc = (step == 0) ? n00j00 : nm1j00;
         for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
             const size_t o = (size_t)j*nx + i;
             cplx lapA(0.0, 0.0);
             if (i > 0 && i < nx - 1 && j > 0 && j < ny - 1)
                 lapA = (lapsrc[o + 1] + lapsrc[o - 1] - 2.0*lapsrc[o])/(dx*dx) + (lapsrc[o + nx] + lapsrc[o - nx] - 2.0*lapsrc[o])/(dy*dy);
-            const double chi_v = slab(i, j, chi);
+            // InterpolateChi (:334-407): chi of the field slab inside the box shrunk by the guard width, the chi of the
+            // unperturbed plasma (SetInitialChi :293-332) outside
+            const bool inside = i >= g && i < nx - g && j >= g && j < ny - g;
+            const double chi_v = inside ? slab(i, j, chi) : chi0;
             if (step == 0) {
                 rhs[o] = 8.0/(c*dt*dz)*(-np1jp1[o] + n00jp1[o])*exp1
                        + 2.0/(c*dt*dz)*(+np1jp2[o] - n00jp2[o])*exp2

@@ -837,3 +837,47 @@ def test_laser_wake_slice_by_slice_vs_oracle(api, oracle):
             gs, os_ = ge.slab(), oe.slab()
             for c in range(ge.ncomp):
                 assert rel_err(gs[c], os_[c]) < 1e-9, (isl, names[c], rel_err(gs[c], os_[c]))
+
+
+@pytest.mark.gpu
+def test_laser_evolution_fft_solver_matches_reference_checksums(api):
+    """tests/laser_evolution.SI.2Rank.sh (lasers.solver_type = fft) on the GPU: 30 steps of the envelope solver in
+    vacuum, then the checksums of the xz diagnostic slice (mean of the two central rows) as in the fixture."""
+    gold = json.load(open(os.path.join(GOLD, "laser_evolution.SI.2Rank.json")))["lev=0"]
+    deck = decks.laser_evolution()
+    eng = api.SliceEngine(deck)
+    for step in range(deck["n_steps"]):
+        eng.run_step()
+    a = eng.laser_envelope()
+    ny = deck["ny"]
+    env = np.abs(0.5 * (a[:, ny // 2 - 1, :] + a[:, ny // 2, :])).sum()
+    aabs = np.abs(a) ** 2
+    aabs_xz = (0.5 * (aabs[:, ny // 2 - 1, :] + aabs[:, ny // 2, :])).sum()
+    assert abs(env - gold["laserEnvelope"]) <= 1e-9 * gold["laserEnvelope"], (env, gold["laserEnvelope"])
+    assert abs(aabs_xz - gold["aabs"]) <= 1e-9 * gold["aabs"], (aabs_xz, gold["aabs"])
+
+
+@pytest.mark.gpu
+def test_evolving_laser_in_plasma_vs_oracle(api, oracle):
+    """Laser pulse in a plasma, envelope advanced by the FFT solver with the plasma's chi: three steps, the envelope
+    array and every slab component of the last slice against the oracle."""
+    deck = decks.laser_blowout_wake()
+    deck.update(nx=64, ny=64, nz=30, lo=(-16.0, -16.0, -4.0), hi=(16.0, 16.0, 4.0), laser_a0=1.5, laser_lambda0=0.4,
+                laser_solver=1, dt=5.0, n_steps=3)
+    ge = api.SliceEngine(deck)
+    oe = oracle.Engine(deck)
+    first = None
+    for step in range(3):
+        ge.begin_step()
+        oe.begin_step()
+        for isl in range(deck["nz"] - 1, -1, -1):
+            ge.solve_slice(isl)
+            oe.solve_slice(isl)
+        ga, oa = ge.laser_envelope(), oe.laser_envelope()
+        assert np.abs(ga - oa).max() <= 1e-9 * np.abs(oa).max(), step
+        first = oa.copy() if first is None else first
+    assert np.abs(oa - first).max() > 1e-2 * np.abs(first).max()          # the pulse did evolve
+    gs, os_ = ge.slab(), oe.slab()
+    names = ge.comp_names()
+    for c in range(ge.ncomp):
+        assert rel_err(gs[c], os_[c]) < 1e-8, (names[c], rel_err(gs[c], os_[c]))
