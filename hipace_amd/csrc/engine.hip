@@ -13,13 +13,13 @@ namespace hps {
 
 int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[6], double charge,
                            double mass, int order, double max_qsa, int can_ionize, int* n_qsa, Tiling* T, int* n_fallback,
-                           hipStream_t st);
+                           hipStream_t st, int aabs_comp = -1);
 int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int cache[4], const int depos[2],
                             double charge, double mass, int order, int dtype, int can_ionize, Tiling* T, int* n_fallback,
-                            hipStream_t st);
+                            hipStream_t st, int aabs_comp = -1);
 int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], double charge,
                           double mass, int order, int temp_slice, int n_subcycles, int can_ionize, Tiling* T,
-                          int* n_fallback, hipStream_t st);
+                          int* n_fallback, hipStream_t st, int aabs_comp = -1);
 
 static thread_local std::string g_err;
 void set_error (const std::string& msg) { g_err = msg; }
@@ -440,7 +440,6 @@ int Engine::create (const hps_deck& deck, int device)
         HPS_REQUIRE(d.laser_w0 > 0.0 && d.laser_L0 > 0.0 && d.laser_lambda0 > 0.0, "hps_engine_create: laser w0, L0, lambda0 must be positive");
         if (d.laser_solver != 0 && d.laser_solver != 1) { set_error("hps_engine_create: lasers.solver_type fft (1) only; the multigrid envelope solver is not built"); return HPS_ERR_UNSUPPORTED; }
         c_aabs = ncomp++;                // appended last
-        tile_size = 0;                   // the LDS-tile kernels do not carry the laser terms yet
     }
     gm.dx = (d.hi[0] - d.lo[0])/d.nx; gm.dy = (d.hi[1] - d.lo[1])/d.ny; gm.dz = (d.hi[2] - d.lo[2])/d.nz;
     gm.xoff = 0.5*(d.lo[0] + d.hi[0] - gm.dx*(d.nx - 1));
@@ -951,7 +950,7 @@ int Engine::solve_slice (int islice)
     ++since_sort;
     mark();   // b1b
     {   const int comp[6] = {HPS_C_JX, HPS_C_JY, -1, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_CHI, HPS_C_RHOMJZ};
-        if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st))) return e; }
+        if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st, c_aabs))) return e; }
         else        { if ((e = hps_deposit_current_laser(slab, pl, gm, comp, c_aabs, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
     mark();   // b2
     // static beam: jz of this slice and jx, jy of the next one in one launch (Hipace.cpp:613-614, 656-657); a moving
@@ -1002,7 +1001,7 @@ int Engine::solve_slice (int islice)
     mark();   // b4
     {   const int cache[4] = {HPS_C_BZ, HPS_C_EZ, HPS_C_EXMBY, HPS_C_EYPBX};
         const int depos[2] = {HPS_C_SY, HPS_C_SX};
-        if (tiling) { if ((e = explicit_deposit_tiled(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, tiling, d_nfallback, st))) return e; }
+        if (tiling) { if ((e = explicit_deposit_tiled(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, tiling, d_nfallback, st, c_aabs))) return e; }
         else        { if ((e = hps_explicit_deposit_laser(slab, pl, gm, cache, c_aabs, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, st))) return e; } }
 
     mark();   // b5
@@ -1021,7 +1020,7 @@ int Engine::solve_slice (int islice)
     mark();   // b7
     // gather + push (Hipace.cpp:699-701)
     {   const int comp[5] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ};
-        if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st))) return e; }
+        if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st, c_aabs))) return e; }
         else        { if ((e = hps_advance_plasma_laser(slab, pl, gm, comp, c_aabs, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; } }
 
     // beam push and hand-off of the slipped particles (Hipace.cpp:704-706)
@@ -1315,8 +1314,7 @@ extern "C" int hps_engine_set_tiling (void* h, int tile_size, int sort_period)
     HPS_REQUIRE(tile_size == 0 || tile_size == 16 || tile_size == 32, "hps_engine_set_tiling: tile_size must be 0, 16 or 32");
     HPS_REQUIRE(sort_period >= 1, "hps_engine_set_tiling: sort_period must be >= 1");
     HPS_REQUIRE(E->tiling == nullptr, "hps_engine_set_tiling: call before the first hps_engine_begin_step");
-    E->tile_size = (E->c_aabs >= 0) ? 0 : tile_size;      // a laser run stays on the per-particle kernels
-    E->sort_period = sort_period;
+    E->tile_size = tile_size; E->sort_period = sort_period;
     return HPS_OK;
 }
 extern "C" int hps_engine_fallbacks (void* h, long* n)

@@ -46,6 +46,39 @@ __device__ __forceinline__ void zeta_derivs (const T& ux, const T& uy, const T& 
     dpsi = (((ux*F.ExmBy + uy*F.EypBx)*c_inv)*psi_inv - F.Ez)*(qmc*c_inv);
 }
 
+// |a|^2 at a particle with the plain deposition-order shape, read from the slab in global memory (doLaserGatherShapeN,
+// particles/particles_utils/FieldGather.H:236-331); the second form also returns the centred x, y differences
+template <int ORDER>
+__device__ __forceinline__ double laser_gather (const SlabView& f, int aabs, double xmid, double ymid)
+{
+    double lx[ORDER + 1], ly[ORDER + 1];
+    const int li = shape_weights<ORDER>(xmid, lx), lj = shape_weights<ORDER>(ymid, ly);
+    double A = 0.0;
+#pragma unroll
+    for (int iy = 0; iy <= ORDER; ++iy)
+#pragma unroll
+        for (int ix = 0; ix <= ORDER; ++ix) A += lx[ix]*ly[iy]*f.p[aabs*f.ns + f.off(li + ix, lj + iy)];
+    return A;
+}
+template <int ORDER>
+__device__ __forceinline__ void laser_gather_grad (const SlabView& f, int aabs, double xmid, double ymid, double dx_inv, double dy_inv,
+                                                   double& A, double& ADx, double& ADy)
+{
+    double lx[ORDER + 1], ly[ORDER + 1];
+    const int li = shape_weights<ORDER>(xmid, lx), lj = shape_weights<ORDER>(ymid, ly);
+    A = 0.0; ADx = 0.0; ADy = 0.0;
+#pragma unroll
+    for (int iy = 0; iy <= ORDER; ++iy)
+#pragma unroll
+        for (int ix = 0; ix <= ORDER; ++ix) {
+            const double* a = f.p + aabs*f.ns + f.off(li + ix, lj + iy);
+            const double w = lx[ix]*ly[iy];
+            A += w*a[0];
+            ADx += w*0.5*dx_inv*(a[1] - a[-1]);
+            ADy += w*0.5*dy_inv*(a[f.js] - a[-f.js]);
+        }
+}
+
 // the same with the ponderomotive terms of a laser envelope (PushPlasmaParticles.H:59-72): A = Aabssq_norm,
 // ADx, ADy = AabssqD{x,y}_norm
 struct LaserFld { double A, ADx, ADy; };

@@ -45,7 +45,7 @@ __device__ __forceinline__ double lds_get (const double* p)
 // (An XCD-chunked tile order -- contiguous tile runs per XCD -- was measured slower here: 916 vs 953 slices/s.)
 // MASK: compile-time set of deposited components (bit c = DepComps entry c), -1 = decide at run time.
 // With a compile-time set the 9x4 accumulations are straight-line ds_add_f64 with immediate offsets.
-template <int ORDER, int TS, int MASK>
+template <int ORDER, int TS, int MASK, bool LASER = false>
 __global__ __launch_bounds__(256)
 void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx, DepComps cm,
                       PartConsts k, int* n_qsa, int* n_fallback)
@@ -111,7 +111,15 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         double q_invvol = k.a*cur.w;
         double q_mu0_mass = k.b;
         if (k.can_ionize) { const double il = (double)cur.ion; q_invvol *= il; q_mu0_mass *= il; }
-        const double gamma_psi = 0.5*(psi_inv*psi_inv + vx_c*vx_c*k.c_inv*k.c_inv + vy_c*vy_c*k.c_inv*k.c_inv + 1.0);
+        double gamma_psi;
+        if constexpr (LASER) {
+            // |a|^2 from the slab (cached global reads; the LDS image holds the accumulators only)
+            double A = laser_gather<ORDER>(f, k.aabs, (cur.x - k.xoff)*k.dx_inv, (cur.y - k.yoff)*k.dy_inv)*k.laser_fac;
+            if (k.can_ionize) A *= (double)cur.ion*(double)cur.ion;
+            gamma_psi = 0.5*((1.0 + 0.5*A)*psi_inv*psi_inv + vx_c*vx_c*k.c_inv*k.c_inv + vy_c*vy_c*k.c_inv*k.c_inv + 1.0);
+        } else {
+            gamma_psi = 0.5*(psi_inv*psi_inv + vx_c*vx_c*k.c_inv*k.c_inv + vy_c*vy_c*k.c_inv*k.c_inv + 1.0);
+        }
         if (gamma_psi < 0.0 || gamma_psi > k.max_qsa || psi_inv < 0.0) {
             if (n_qsa) atomicAdd(n_qsa, 1);
             pl.w[ip] = 0.0;
@@ -185,7 +193,7 @@ __device__ __forceinline__ void load_region (double* img, const SlabView& f, con
     }
 }
 
-template <int ORDER, int DT, int TS>
+template <int ORDER, int DT, int TS, bool LASER = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // 128 VGPRs: 4 workgroups per CU
 void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
                        int cBz, int cEz, int cExmBy, int cEypBx, int cSy, int cSx, PartConsts k, int* n_fallback)
@@ -232,11 +240,17 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
         double q_invvol_mu0 = k.a, q_mass = k.b;
         if (k.can_ionize) { const double il = (double)cur.ion; q_invvol_mu0 *= il; q_mass *= il; }
         const double cdm = q_invvol_mu0*cur.w;
-        const double gp = 0.5*(psi_inv*psi_inv + vx*vx + vy*vy + 1.0);
-        double sx[NS], dsx[NS], sy[NS], dsy[NS];
-        int i0, j0;
         const double xmid = (cur.x - k.xoff)*k.dx_inv;
         const double ymid = (cur.y - k.yoff)*k.dy_inv;
+        double gp;
+        if constexpr (LASER) {
+            const double A = laser_gather<ORDER>(f, k.aabs, xmid, ymid)*k.laser_fac*q_mass*q_mass;
+            gp = 0.5*((1.0 + 0.5*A)*psi_inv*psi_inv + vx*vx + vy*vy + 1.0);
+        } else {
+            gp = 0.5*(psi_inv*psi_inv + vx*vx + vy*vy + 1.0);
+        }
+        double sx[NS], dsx[NS], sy[NS], dsy[NS];
+        int i0, j0;
         if constexpr (DT == 2) { i0 = centred_weights<ORDER>(xmid, sx, dsx); j0 = centred_weights<ORDER>(ymid, sy, dsy); }
         else                   { i0 = nodal_weights<ORDER>(xmid, sx, dsx);   j0 = nodal_weights<ORDER>(ymid, sy, dsy); }
         const double qp = q_mass*psi_inv;
@@ -270,8 +284,17 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
                 const double ss = sx[ix]*sy[iy];
                 const double dxs = dsx[ix]*sy[iy];
                 const double sdy = sx[ix]*dsy[iy];
-                const double ty = fma(a1, Bz, fma(a2, Ez, fma(a3, ExmBy, a4*EypBx)));
-                const double tx = fma(b1, Bz, fma(b2, Ez, fma(b3, ExmBy, b4*EypBx)));
+                double ty = fma(a1, Bz, fma(a2, Ez, fma(a3, ExmBy, a4*EypBx)));
+                double tx = fma(b1, Bz, fma(b2, Ez, fma(b3, ExmBy, b4*EypBx)));
+                if constexpr (LASER) {
+                    // gradient of |a|^2 at this stencil cell (ExplicitDeposition.cpp:211-226), from the slab
+                    if (ss != 0.0) {
+                        const double* a = f.p + k.aabs*f.ns + f.off(i0 + ix, j0 + iy);
+                        const double lf = 0.25*cq*qp*k.laser_fac*k.c;
+                        ty = fma(lf*0.5*k.dy_inv, a[f.js] - a[-f.js], ty);
+                        tx = fma(-lf*0.5*k.dx_inv, a[1] - a[-1], tx);
+                    }
+                }
                 const double sy_add = fma(ss, ty, fma(a5, dxs, a6*sdy));
                 const double sx_add = fma(ss, tx, fma(b5, dxs, b6*sdy));
                 if (local) { lds_add(acc + ls, sy_add); lds_add(acc + PL + ls, sx_add); }
@@ -292,7 +315,7 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
     }
 }
 
-template <int ORDER, int TS>
+template <int ORDER, int TS, bool LASER = false>
 __global__ __launch_bounds__(256)
 void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
                       int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, int* n_fallback)
@@ -372,10 +395,22 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             }
             F.Bxc *= k.c;
             F.Byc *= k.c;
+            LaserFld Lf{0.0, 0.0, 0.0};
+            if constexpr (LASER) {
+                // |a|^2 and its gradient from the slab (cached global reads), PlasmaParticleAdvance.cpp:121-131
+                laser_gather_grad<ORDER>(f, k.aabs, (xp - k.xoff)*k.dx_inv, (yp - k.yoff)*k.dy_inv, k.dx_inv, k.dy_inv, Lf.A, Lf.ADx, Lf.ADy);
+                const double ln = k.laser_fac*(k.can_ionize ? (double)pl.ion_lev[ip]*(double)pl.ion_lev[ip] : 1.0);
+                Lf.A *= 0.5*ln; Lf.ADx *= 0.25*k.c*ln; Lf.ADy *= 0.25*k.c*ln;
+            }
             const double dz = k.dz, sdz = dz*0.25;
             double ux = pl.ux_half[ip], uy = pl.uy_half[ip], psi = pl.psi_half[ip];
+            if constexpr (LASER) {
 #pragma unroll 1
-            for (int s = 0; s < 4; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
+                for (int s = 0; s < 4; ++s) taylor2_substep_laser(ux, uy, psi, F, Lf, k.c_inv, qmc, sdz);
+            } else {
+#pragma unroll 1
+                for (int s = 0; s < 4; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
+            }
             const double pinv = 1.0/psi;
             xp += dz*k.c_inv*(ux*pinv);
             yp += dz*k.c_inv*(uy*pinv);
@@ -391,8 +426,13 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
                 if (pl.x_prev != pl.x) pl.x_prev[ip] = xp;      // (aliased by the engine: already stored)
                 if (pl.y_prev != pl.y) pl.y_prev[ip] = yp;
             }
+            if constexpr (LASER) {
 #pragma unroll 1
-            for (int s = 0; s < 2; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
+                for (int s = 0; s < 2; ++s) taylor2_substep_laser(ux, uy, psi, F, Lf, k.c_inv, qmc, sdz);
+            } else {
+#pragma unroll 1
+                for (int s = 0; s < 2; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
+            }
             pl.ux[ip] = ux; pl.uy[ip] = uy; pl.psi[ip] = psi;
         }
     }
@@ -416,11 +456,12 @@ static int set_lds (K kernel, size_t bytes)
 
 int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[6], double charge,
                            double mass, int order, double max_qsa, int can_ionize, int* n_qsa, Tiling* T, int* n_fallback,
-                           hipStream_t st)
+                           hipStream_t st, int aabs_comp)
 {
     if (pl.n == 0) return HPS_OK;
     PartConsts k = base_consts(g);
     k.a = charge*invvol_of(g); k.b = charge*g.mu0/mass; k.max_qsa = max_qsa; k.can_ionize = can_ionize;
+    k.aabs = aabs_comp; k.laser_fac = (charge/g.q_e)*(g.m_e/mass)*(charge/g.q_e)*(g.m_e/mass);
     DepComps cm{comp[0], comp[1], comp[2], comp[3], comp[4], comp[5]};
     int na = 0; for (int c = 0; c < 6; ++c) na += comp[c] >= 0;
     const int R = T->g.ts + 2*TILE_HALO;
@@ -429,35 +470,46 @@ int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
     int mask = 0; for (int c = 0; c < 6; ++c) mask |= (comp[c] >= 0) << c;
 #define CALLM(O, S, M) { if (int e = set_lds(k_deposit_tiled<O, S, M>, lds)) return e; \
         hipLaunchKernelGGL((k_deposit_tiled<O, S, M>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback); }
-#define CALL(O, S) { if (mask == 51) CALLM(O, S, 51) else if (mask == 59) CALLM(O, S, 59) else if (mask == 32) CALLM(O, S, 32) \
+#define CALLL(O, S, M) { if (int e = set_lds(k_deposit_tiled<O, S, M, true>, lds)) return e; \
+        hipLaunchKernelGGL((k_deposit_tiled<O, S, M, true>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback); }
+#define CALL(O, S) { if (aabs_comp >= 0) { if (mask == 51) CALLL(O, S, 51) else CALLL(O, S, -1) } \
+                     else if (mask == 51) CALLM(O, S, 51) else if (mask == 59) CALLM(O, S, 59) else if (mask == 32) CALLM(O, S, 32) \
                      else if (mask == 3) CALLM(O, S, 3) else if (mask == 39) CALLM(O, S, 39) else if (mask == 47) CALLM(O, S, 47) else CALLM(O, S, -1) }
     HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
 #undef CALL
 #undef CALLM
+#undef CALLL
     HPS_HIP_CHECK(hipGetLastError());
     return HPS_OK;
 }
 
 int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int cache[4], const int depos[2],
                             double charge, double mass, int order, int dtype, int can_ionize, Tiling* T, int* n_fallback,
-                            hipStream_t st)
+                            hipStream_t st, int aabs_comp)
 {
     if (pl.n == 0) return HPS_OK;
     PartConsts k = base_consts(g);
     k.a = charge*invvol_of(g)*g.mu0; k.b = charge/mass; k.can_ionize = can_ionize;
+    k.aabs = aabs_comp; k.laser_fac = (g.m_e/g.q_e)*(g.m_e/g.q_e);
     const int R = T->g.ts + 2*TILE_HALO;
     const size_t lds = (size_t)6*R*(R + HPS_EXPL_PAD)*sizeof(double);
     SlabView f(slab);
     if (dtype == 2) {
-#define CALL(O, S) { if (int e = set_lds(k_explicit_tiled<O, 2, S>, lds)) return e; \
+#define CALL(O, S) { if (aabs_comp >= 0) { if (int e = set_lds(k_explicit_tiled<O, 2, S, true>, lds)) return e; \
+        hipLaunchKernelGGL((k_explicit_tiled<O, 2, S, true>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
+                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback); } else { \
+        if (int e = set_lds(k_explicit_tiled<O, 2, S>, lds)) return e; \
         hipLaunchKernelGGL((k_explicit_tiled<O, 2, S>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
-                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback); }
+                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback); } }
         HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
 #undef CALL
     } else {
-#define CALL(O, S) { if (int e = set_lds(k_explicit_tiled<O, 1, S>, lds)) return e; \
+#define CALL(O, S) { if (aabs_comp >= 0) { if (int e = set_lds(k_explicit_tiled<O, 1, S, true>, lds)) return e; \
+        hipLaunchKernelGGL((k_explicit_tiled<O, 1, S, true>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
+                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback); } else { \
+        if (int e = set_lds(k_explicit_tiled<O, 1, S>, lds)) return e; \
         hipLaunchKernelGGL((k_explicit_tiled<O, 1, S>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
-                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback); }
+                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback); } }
         HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
 #undef CALL
     }
@@ -467,18 +519,22 @@ int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hp
 
 int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], double charge,
                           double mass, int order, int temp_slice, int n_subcycles, int can_ionize, Tiling* T,
-                          int* n_fallback, hipStream_t st)
+                          int* n_fallback, hipStream_t st, int aabs_comp)
 {
     if (pl.n == 0) return HPS_OK;
     PartConsts k = base_consts(g);
     k.a = charge/(mass*g.c); k.dz = g.dz/n_subcycles;
+    k.aabs = aabs_comp; k.laser_fac = (charge/g.q_e)*(g.m_e/mass)*(charge/g.q_e)*(g.m_e/mass);
     k.temp_slice = temp_slice; k.n_subcycles = n_subcycles; k.can_ionize = can_ionize;
     const int R = T->g.ts + 2*TILE_HALO;
     const size_t lds = (size_t)5*R*R*sizeof(double);
     SlabView f(slab);
-#define CALL(O, S) { if (int e = set_lds(k_advance_tiled<O, S>, lds)) return e; \
+#define CALL(O, S) { if (aabs_comp >= 0) { if (int e = set_lds(k_advance_tiled<O, S, true>, lds)) return e; \
+        hipLaunchKernelGGL((k_advance_tiled<O, S, true>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
+                           comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback); } else { \
+        if (int e = set_lds(k_advance_tiled<O, S>, lds)) return e; \
         hipLaunchKernelGGL((k_advance_tiled<O, S>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
-                           comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback); }
+                           comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback); } }
     HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
 #undef CALL
     HPS_HIP_CHECK(hipGetLastError());
@@ -521,7 +577,7 @@ extern "C" int hps_deposit_current_tiled (hps_slab slab, hps_plasma pl, hps_geom
     if (int e = check_tiling(tiling, slab, pl, "hps_deposit_current_tiled")) return e;
     for (int c = 0; c < 6; ++c) HPS_REQUIRE(comp[c] >= -1 && comp[c] < slab.ncomp, "hps_deposit_current_tiled: bad component");
     return deposit_current_tiled(slab, pl, g, comp, charge, mass, order, max_qsa, can_ionize, n_qsa,
-                                 static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream);
+                                 static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1);
 }
 
 extern "C" int hps_explicit_deposit_tiled (hps_slab slab, hps_plasma pl, hps_geom g, const int cache[4], const int depos[2],
@@ -533,7 +589,7 @@ extern "C" int hps_explicit_deposit_tiled (hps_slab slab, hps_plasma pl, hps_geo
     if (int e = check_stencil(slab, (order + 1)/2 + 1, "hps_explicit_deposit_tiled")) return e;
     if (int e = check_tiling(tiling, slab, pl, "hps_explicit_deposit_tiled")) return e;
     return explicit_deposit_tiled(slab, pl, g, cache, depos, charge, mass, order, dtype, can_ionize,
-                                  static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream);
+                                  static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1);
 }
 
 extern "C" int hps_advance_plasma_tiled (hps_slab slab, hps_plasma pl, hps_geom g, const int comp[5], double charge,
@@ -545,5 +601,5 @@ extern "C" int hps_advance_plasma_tiled (hps_slab slab, hps_plasma pl, hps_geom 
     if (int e = check_stencil(slab, (order + 1)/2 + 1, "hps_advance_plasma_tiled")) return e;
     if (int e = check_tiling(tiling, slab, pl, "hps_advance_plasma_tiled")) return e;
     return advance_plasma_tiled(slab, pl, g, comp, charge, mass, order, temp_slice, n_subcycles, can_ionize,
-                                static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream);
+                                static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1);
 }

@@ -805,12 +805,13 @@ def test_engine_variants_vs_oracle(api, oracle, case):
 
 # ---- laser-driven wake (first half: static Gaussian envelope) ------------------------------------------
 @pytest.mark.gpu
-def test_laser_blowout_wake_matches_reference_checksums(api):
+@pytest.mark.parametrize("tile_size", [0, 16])
+def test_laser_blowout_wake_matches_reference_checksums(api, tile_size):
     """tests/laser_blowout_wake_explicit.1Rank.sh: no beam, a Gaussian laser pulse (a0 = 4.5) drives the wake through
     |a|^2 in the deposition, the explicit source and the pusher -- all 18 checksums of the reference's fixture
     (the reference skips Sx, Sy, chi; they agree too), incl. aabs and laserEnvelope."""
     gold = json.load(open(os.path.join(GOLD, "laser_blowout_wake_explicit.1Rank.json")))["lev=0"]
-    eng = api.SliceEngine(decks.laser_blowout_wake(), tile_size=16)      # tiling is dropped for a laser run
+    eng = api.SliceEngine(decks.laser_blowout_wake(), tile_size=tile_size, sort_period=8)
     eng.set_diagnostics(True)
     eng.run_step()
     cs = eng.checksums()
@@ -825,7 +826,7 @@ def test_laser_blowout_wake_matches_reference_checksums(api):
 def test_laser_wake_slice_by_slice_vs_oracle(api, oracle):
     deck = decks.laser_blowout_wake()
     deck.update(nx=64, ny=64, nz=40, lo=(-16.0, -16.0, -3.0), hi=(16.0, 16.0, 3.0), laser_pos=(1.0, -0.5, 0.5), order=3)
-    ge = api.SliceEngine(deck)
+    ge = api.SliceEngine(deck, tile_size=16, sort_period=5)
     oe = oracle.Engine(deck)
     ge.begin_step()
     oe.begin_step()
@@ -864,7 +865,7 @@ def test_evolving_laser_in_plasma_vs_oracle(api, oracle):
     deck = decks.laser_blowout_wake()
     deck.update(nx=64, ny=64, nz=30, lo=(-16.0, -16.0, -4.0), hi=(16.0, 16.0, 4.0), laser_a0=1.5, laser_lambda0=0.4,
                 laser_solver=1, dt=5.0, n_steps=3)
-    ge = api.SliceEngine(deck)
+    ge = api.SliceEngine(deck, tile_size=16, sort_period=7)
     oe = oracle.Engine(deck)
     first = None
     for step in range(3):
