@@ -110,6 +110,10 @@ _SIGS = {
     "hps_engine_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_copy_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]),
     "hps_engine_set_profiling_stride": (C.c_int, [C.c_void_p, C.c_int]),
+    "hps_engine_set_laser_import": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "hps_engine_export_laser_slice": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "hps_engine_import_laser_slice": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "hps_engine_import_laser_from": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "hps_engine_laser_envelope": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_laser_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "hps_deposit_current_laser": (C.c_int, [Slab, Plasma, Geom, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double,

@@ -423,6 +423,26 @@ class SliceEngine:
             cs["laserEnvelope"] = tot.value
         return cs
 
+    # ---- ring hand-off of the laser envelope ---------------------------------------------------------------
+    @property
+    def has_laser(self):
+        return bool(self.deck.get("laser_on", 0))
+
+    def laser_message_doubles(self):
+        return 4 * self.deck["nx"] * self.deck["ny"]
+
+    def set_laser_import(self, on, step=0):
+        check(_lib.lib().hps_engine_set_laser_import(self._h, int(on), int(step)))
+
+    def export_laser_slice(self, islice, msg):
+        check(_lib.lib().hps_engine_export_laser_slice(self._h, islice, C.c_void_p(msg.data_ptr())))
+
+    def import_laser_slice(self, islice, msg):
+        check(_lib.lib().hps_engine_import_laser_slice(self._h, islice, C.c_void_p(msg.data_ptr())))
+
+    def import_laser_from(self, islice, src):
+        check(_lib.lib().hps_engine_import_laser_from(self._h, islice, src._h))
+
     def laser_envelope(self):
         """a_n of the step that has begun: complex array [nz, ny, nx]."""
         d = self.deck

@@ -1185,6 +1185,31 @@ extern "C" int hps_engine_copy_async (void* h, void* dst, const void* src, long 
     HPS_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, E->st));
     return HPS_OK;
 }
+extern "C" int hps_engine_set_laser_import (void* h, int on, int step)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E->laser, "hps_engine_set_laser_import: no laser");
+    return laser_set_import(*E, on, step);
+}
+extern "C" int hps_engine_export_laser_slice (void* h, int islice, double* msg_dev)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E->laser && msg_dev && islice >= 0 && islice < E->d.nz, "hps_engine_export_laser_slice: bad argument");
+    return laser_export_slice(*E, islice, msg_dev);
+}
+extern "C" int hps_engine_import_laser_slice (void* h, int islice, const double* msg_dev)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E->laser && msg_dev && islice >= 0 && islice < E->d.nz, "hps_engine_import_laser_slice: bad argument");
+    return laser_import_slice(*E, islice, msg_dev);
+}
+extern "C" int hps_engine_import_laser_from (void* h, int islice, void* src)
+{
+    Engine* E = static_cast<Engine*>(h); Engine* S = static_cast<Engine*>(src);
+    HPS_REQUIRE(E->laser && S && S->laser && islice >= 0 && islice < E->d.nz && S->d.nx == E->d.nx && S->d.ny == E->d.ny && S->d.nz == E->d.nz,
+                "hps_engine_import_laser_from: bad argument");
+    return laser_import_from(*E, islice, *S);
+}
 extern "C" int hps_engine_laser_envelope (void* h, double* out_host)
 {
     Engine* E = static_cast<Engine*>(h);

@@ -26,6 +26,7 @@ struct LaserState {
     LaserPhase* phase = nullptr;
     rocfft_plan fwd = nullptr, bwd = nullptr; rocfft_execution_info info = nullptr; void* fft_work = nullptr;
     int steps = 0; bool initialised = false;
+    bool import_mode = false;        // ring pipeline: a_n, a_{n-1} of the coming step arrive through laser_import_slice
     ~LaserState () {
         if (fwd) rocfft_plan_destroy(fwd);
         if (bwd) rocfft_plan_destroy(bwd);
@@ -243,7 +244,9 @@ int laser_begin_step (Engine& E)
 {
     LaserState* L = E.laser;
     const hps_deck& d = E.d;
-    if (!L->initialised) {
+    if (L->import_mode) {
+        L->initialised = true;       // levels are filled slice by slice; the driver has set the step index
+    } else if (!L->initialised) {
         const double zoff = 0.5*(d.lo[2] + d.hi[2] - E.gm.dz*(d.nz - 1));
         hipLaunchKernelGGL(k_laser_init, dim3(ceil_div(d.nx, 256), d.ny, d.nz), dim3(256), 0, E.st, L->n00, d.nx, d.ny, d.nz, laser_pars(d),
                            E.gm.dx, E.gm.dy, E.gm.dz, E.gm.xoff, E.gm.yoff, zoff);
@@ -290,6 +293,44 @@ int laser_advance_slice (Engine& E, int islice)
     hipLaunchKernelGGL(k_laser_store, dim3(ceil_div((long)plane, 256)), block, 0, E.st, L->work, L->np1 + (size_t)islice*plane, (long)plane,
                        1.0/(double)plane);
     HPS_HIP_CHECK(hipGetLastError());
+    return HPS_OK;
+}
+
+// ring hand-off of the envelope (MultiBuffer.cpp:840-852, 913-925): a stage passes {a_{n+1}, a_n} of a slice on, the next
+// one stores them as its {a_n, a_{n-1}}.  msg = [2][ny][nx] complex on the device; both asynchronous on the stream.
+int laser_set_import (Engine& E, int on, int step)
+{
+    E.laser->import_mode = (on != 0); E.laser->steps = step;
+    return HPS_OK;
+}
+int laser_export_slice (Engine& E, int islice, double* msg_dev)
+{
+    LaserState* L = E.laser;
+    const size_t plane = (size_t)L->nx*L->ny;
+    const double2* newest = L->np1 ? L->np1 : L->n00;
+    HPS_HIP_CHECK(hipMemcpyAsync(msg_dev, newest + (size_t)islice*plane, plane*sizeof(double2), hipMemcpyDeviceToDevice, E.st));
+    HPS_HIP_CHECK(hipMemcpyAsync(msg_dev + 2*plane, L->n00 + (size_t)islice*plane, plane*sizeof(double2), hipMemcpyDeviceToDevice, E.st));
+    return HPS_OK;
+}
+int laser_import_slice (Engine& E, int islice, const double* msg_dev)
+{
+    LaserState* L = E.laser;
+    const size_t plane = (size_t)L->nx*L->ny;
+    HPS_HIP_CHECK(hipMemcpyAsync(L->n00 + (size_t)islice*plane, msg_dev, plane*sizeof(double2), hipMemcpyDeviceToDevice, E.st));
+    if (L->nm1) HPS_HIP_CHECK(hipMemcpyAsync(L->nm1 + (size_t)islice*plane, msg_dev + 2*plane, plane*sizeof(double2), hipMemcpyDeviceToDevice, E.st));
+    return HPS_OK;
+}
+
+// in-process hand-off (several steps in flight on one device): the same two planes straight from the engine that ran
+// the previous step, on the receiving engine's stream (the caller has made it wait for the sender's slice event)
+int laser_import_from (Engine& E, int islice, Engine& src)
+{
+    LaserState* L = E.laser; LaserState* P = src.laser;
+    const size_t plane = (size_t)L->nx*L->ny;
+    const double2* newest = P->np1 ? P->np1 : P->n00;
+    // a_n -> a_{n-1} first: with one stage in flight source and destination are the same engine
+    if (L->nm1) HPS_HIP_CHECK(hipMemcpyAsync(L->nm1 + (size_t)islice*plane, P->n00 + (size_t)islice*plane, plane*sizeof(double2), hipMemcpyDeviceToDevice, E.st));
+    if (newest != L->n00) HPS_HIP_CHECK(hipMemcpyAsync(L->n00 + (size_t)islice*plane, newest + (size_t)islice*plane, plane*sizeof(double2), hipMemcpyDeviceToDevice, E.st));
     return HPS_OK;
 }
 

@@ -257,10 +257,12 @@ def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_st
     nz = engines[0].deck["nz"]
     per_step = slices_per_step or nz
     assert per_step >= 2, "a step needs at least two slices"
-    assert not getattr(engines[0], "moving", False), "run_local_pipeline hands a static beam on (hipace.dt = 0)"
     assert world == 1 or groups is not None, "world > 1 needs make_edge_groups(world)"
+    laser = bool(getattr(engines[0], "has_laser", False))
+    assert not (laser and world > 1), "the laser's time levels travel between the stages of one process only (so far)"
     on_gpu = str(device) != "cpu"
     nbeam, off = engines[0].beam_layout()
+    assert nbeam == 0 or not getattr(engines[0], "moving", False), "run_local_pipeline hands a static beam on (hipace.dt = 0)"
     bufs = [[torch.zeros(max(7 * nbeam, 1), dtype=torch.float64, device=device) for _ in range(2)] for _ in range(L)]
     if rank == 0:
         engines[0].initial_beam_into(bufs[0][0])      # only the head of the ring injects the beam
@@ -292,9 +294,15 @@ def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_st
                 buf = bufs[j][m % 2]
                 fed = step > 0                          # step 0 starts from the injected beam
                 mp = (step - 1 - (rank * L + pj)) // G if (fed and not remote_in) else None
-                eng.set_beam_storage(buf, injected_beam_support=True)
+                if nbeam > 0:
+                    eng.set_beam_storage(buf, injected_beam_support=True)
+                if laser:
+                    # the stage that runs step 0 evaluates the initial envelope; every later step receives a_n, a_{n-1}
+                    # slice by slice from the stage that ran the step before (MultiBuffer.cpp:840-852, 913-925)
+                    eng.set_laser_import(fed, step)
                 eng.begin_step()
                 copied = 0
+                lcopied = 0
                 for q in range(per_step):
                     if fed:
                         need = min(q + 1, per_step - 1)             # this slice's beam and the next one's (jx/jy source)
@@ -322,6 +330,10 @@ def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_st
                                 if d.numel() > 0:
                                     eng.copy_async(d, s_)
                                 copied += 1
+                            if laser:
+                                while lcopied <= need:
+                                    eng.import_laser_from(nz - 1 - lcopied, engines[pj])
+                                    lcopied += 1
                     eng.solve_slice(nz - 1 - q)
                     solved[j] += 1
                     if remote_out:

@@ -226,6 +226,16 @@ int hps_engine_pc_stats (void* handle, long* iterations, double* error_sum);
 int hps_engine_laser_info (void* handle, int* aabs_comp, double* envelope_abs_sum_host);
 /* the envelope a_n of the step that has begun: [nz][ny][nx] complex (re, im interleaved) to the host; synchronises */
 int hps_engine_laser_envelope (void* handle, double* out_host);
+/* Ring hand-off of the envelope (MultiBuffer::pack_data / unpack_data, utils/MultiBuffer.cpp:840-852, 913-925): a
+ * stage passes {a_{n+1}, a_n} of a slice on (msg_dev = [2][ny][nx] complex = 4 nx ny doubles on the device), the next
+ * stage stores them as its {a_n, a_{n-1}}.  Import mode (set before hps_engine_begin_step, with the index of the
+ * time step the engine is about to run) keeps begin_step from initialising / rotating the time levels itself. */
+int hps_engine_set_laser_import (void* handle, int on, int step);
+int hps_engine_export_laser_slice (void* handle, int islice, double* msg_dev);
+int hps_engine_import_laser_slice (void* handle, int islice, const double* msg_dev);
+/* the same hand-off inside one process (several steps in flight on one device): straight from the engine that ran the
+ * previous step, on the receiving engine's stream (make it wait for the sender's slice event first) */
+int hps_engine_import_laser_from (void* handle, int islice, void* src_engine);
 /* accumulate the per-slice checksums (costs one reduction pass per slice; off by default) */
 int hps_engine_set_diagnostics (void* handle, int on);
 /* Field diagnostics (Fields::Copy, fields/Fields.cpp:413-533; geometry of Diagnostic::ResizeFDiagFAB,

@@ -970,6 +970,7 @@ struct Engine {
     // envelope at time steps n-1, n, n+1 for every slice, valid cells only ([islice][j][i]); what the reference keeps in
     // the 9 slots of its laser slab + the MultiBuffer (utils/MultiBuffer.cpp:840-852, 913-925)
     std::vector<cplx> la_nm1, la_n00, la_np1; int laser_steps = 0;
+    bool laser_import = false;     // ring pipeline: a_n and a_{n-1} of the coming step arrive slice by slice
     double t_deposit, t_explicit, t_push, t_poisson, t_mg, t_other;
 
     explicit Engine (const Deck& dk) : d(dk), ps(nullptr), mg(nullptr) {
@@ -1629,8 +1630,9 @@ struct Engine {
             const size_t tot = (size_t)d.nx*d.ny*d.nz;
             if (la_n00.empty()) {
                 la_n00.assign(tot, cplx(0.0, 0.0)); la_nm1.assign(tot, cplx(0.0, 0.0)); la_np1.assign(tot, cplx(0.0, 0.0));
-                for (int k = 0; k < d.nz; ++k) init_laser_slice(k, la_n00.data() + (size_t)k*d.nx*d.ny);
-                laser_steps = 0;
+                if (!laser_import) { for (int k = 0; k < d.nz; ++k) init_laser_slice(k, la_n00.data() + (size_t)k*d.nx*d.ny); laser_steps = 0; }
+            } else if (laser_import) {
+                // a_n, a_{n-1} of this step come through import_laser_slice; laser_steps is set by the driver
             } else if (d.laser_solver == 1 && d.dt != 0.0) {
                 // what put_data / get_data move between two steps: a_{n+1} -> a_n, a_n -> a_{n-1} (MultiBuffer.cpp:840-852, 913-925)
                 la_nm1.swap(la_n00); la_n00.swap(la_np1);
@@ -1815,6 +1817,29 @@ double orc_engine_pc_error_sum (void* h) { return static_cast<Engine*>(h)->pc_er
 int orc_engine_aabs_comp (void* h) { return static_cast<Engine*>(h)->c_aabs; }
 double orc_engine_laser_envelope_sum (void* h) { return static_cast<Engine*>(h)->laser_envelope_sum; }
 // envelope a_n of the step that has begun, [nz][ny][nx] complex (interleaved re, im); null without a laser
+// ring hand-off of the envelope (MultiBuffer.cpp:840-852, 913-925): what a stage passes on for slice islice is
+// {a_{n+1}, a_n}, which the next stage stores as its {a_n, a_{n-1}}
+void orc_engine_set_laser_import (void* h, int on, int step) { Engine* e = static_cast<Engine*>(h); e->laser_import = (on != 0); e->laser_steps = step; }
+void orc_engine_export_laser_slice (void* h, int islice, double* out /* [2][ny][nx] complex */) {
+    Engine* e = static_cast<Engine*>(h); const size_t pl2 = (size_t)e->d.nx*e->d.ny;
+    const bool evolve = e->d.laser_solver == 1 && e->d.dt != 0.0;
+    std::memcpy(out, (evolve ? e->la_np1 : e->la_n00).data() + (size_t)islice*pl2, pl2*sizeof(cplx));
+    std::memcpy(out + 2*pl2, e->la_n00.data() + (size_t)islice*pl2, pl2*sizeof(cplx));
+}
+void orc_engine_import_laser_slice (void* h, int islice, const double* in) {
+    Engine* e = static_cast<Engine*>(h); const size_t pl2 = (size_t)e->d.nx*e->d.ny;
+    std::memcpy(static_cast<void*>(e->la_n00.data() + (size_t)islice*pl2), in, pl2*sizeof(cplx));
+    std::memcpy(static_cast<void*>(e->la_nm1.data() + (size_t)islice*pl2), in + 2*pl2, pl2*sizeof(cplx));
+}
+// in-process hand-off: the same, straight from the engine that ran the previous step
+void orc_engine_import_laser_from (void* h, int islice, void* src) {
+    Engine* e = static_cast<Engine*>(h); Engine* p = static_cast<Engine*>(src); const size_t pl2 = (size_t)e->d.nx*e->d.ny;
+    const bool evolve = p->d.laser_solver == 1 && p->d.dt != 0.0;
+    // a_n -> a_{n-1} first: with one stage in flight source and destination are the same engine
+    std::copy(p->la_n00.begin() + (size_t)islice*pl2, p->la_n00.begin() + (size_t)(islice + 1)*pl2, e->la_nm1.begin() + (size_t)islice*pl2);
+    std::copy((evolve ? p->la_np1 : p->la_n00).begin() + (size_t)islice*pl2, (evolve ? p->la_np1 : p->la_n00).begin() + (size_t)(islice + 1)*pl2,
+              e->la_n00.begin() + (size_t)islice*pl2);
+}
 const double* orc_engine_laser_envelope (void* h) { Engine* e = static_cast<Engine*>(h); return e->la_n00.empty() ? nullptr : reinterpret_cast<const double*>(e->la_n00.data()); }
 void orc_engine_times (void* h, double* t6) { Engine* e = static_cast<Engine*>(h);
     t6[0]=e->t_deposit; t6[1]=e->t_explicit; t6[2]=e->t_push; t6[3]=e->t_poisson; t6[4]=e->t_mg; t6[5]=e->t_other; }

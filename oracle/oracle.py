@@ -509,6 +509,38 @@ class Engine:
             cs["laserEnvelope"] = L.orc_engine_laser_envelope_sum(self._h)
         return cs
 
+    # ---- ring hand-off of the laser envelope (same interface as hipace_amd.api.SliceEngine) ----------------
+    @property
+    def has_laser(self):
+        return bool(self.deck.get("laser_on", 0))
+
+    def laser_message_doubles(self):
+        return 4 * self.deck["nx"] * self.deck["ny"]
+
+    def set_laser_import(self, on, step=0):
+        L = lib()
+        L.orc_engine_set_laser_import.restype = None
+        L.orc_engine_set_laser_import.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_engine_set_laser_import(self._h, int(on), int(step))
+
+    def export_laser_slice(self, islice, msg):
+        L = lib()
+        L.orc_engine_export_laser_slice.restype = None
+        L.orc_engine_export_laser_slice.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_engine_export_laser_slice(self._h, islice, C.c_void_p(msg.data_ptr()))
+
+    def import_laser_slice(self, islice, msg):
+        L = lib()
+        L.orc_engine_import_laser_slice.restype = None
+        L.orc_engine_import_laser_slice.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_engine_import_laser_slice(self._h, islice, C.c_void_p(msg.data_ptr()))
+
+    def import_laser_from(self, islice, src):
+        L = lib()
+        L.orc_engine_import_laser_from.restype = None
+        L.orc_engine_import_laser_from.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_engine_import_laser_from(self._h, islice, src._h)
+
     def laser_envelope(self):
         """a_n of the step that has begun: complex array [nz, ny, nx]."""
         L = lib()

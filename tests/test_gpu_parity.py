@@ -882,3 +882,29 @@ def test_evolving_laser_in_plasma_vs_oracle(api, oracle):
     names = ge.comp_names()
     for c in range(ge.ncomp):
         assert rel_err(gs[c], os_[c]) < 1e-8, (names[c], rel_err(gs[c], os_[c]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_laser_envelope_through_steps_in_flight_on_one_gpu(api, lanes):
+    """run_local_pipeline with an evolving laser pulse: the stages hand a_{n+1}, a_n on slice by slice on the device;
+    five steps give the envelope of one engine running them in turn."""
+    import torch
+    from hipace_amd.pipeline import run_local_pipeline
+    d = decks.laser_blowout_wake()
+    d.update(nx=64, ny=64, nz=24, lo=(-16.0, -16.0, -4.0), hi=(16.0, 16.0, 4.0), laser_a0=1.5, laser_lambda0=0.4,
+             laser_solver=1, dt=5.0)
+    ref = api.SliceEngine(d, tile_size=16, sort_period=8)
+    want = {}
+    for s in range(5):
+        ref.run_step()
+        want[s] = ref.laser_envelope()
+    engs = [api.SliceEngine(d, tile_size=16, sort_period=8) for _ in range(lanes)]
+    got = {}
+
+    def on_step_end(step, eng):
+        got[step] = eng.laser_envelope()
+
+    run_local_pipeline(engs, 5, torch.device("cuda", 0), on_step_end)
+    for s in range(5):
+        assert np.abs(got[s] - want[s]).max() <= 1e-10 * np.abs(want[s]).max(), s

@@ -194,3 +194,35 @@ def test_ring_of_ranks_with_several_stages_each(oracle, world, lanes, n_steps):
     for step, cs in seen.items():
         for k, v in want.items():
             assert abs(cs[k] - v) <= 1e-12 * max(abs(v), 1e-300), (step, k, cs[k], v)
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 3])
+def test_local_pipeline_hands_the_laser_envelope_on(oracle, lanes):
+    """An evolving laser pulse in a plasma with several steps in flight: every stage receives a_n and a_{n-1} of its step
+    slice by slice from the stage that ran the step before (MultiBuffer.cpp:840-852, 913-925) -- envelope and checksums
+    of five steps identical to one engine running them in turn."""
+    import numpy as np
+    from hipace_amd.pipeline import run_local_pipeline
+    d = decks.laser_blowout_wake()
+    d.update(nx=32, ny=32, nz=16, lo=(-16.0, -16.0, -4.0), hi=(16.0, 16.0, 4.0), laser_a0=1.5, laser_lambda0=0.4,
+             laser_solver=1, dt=5.0)
+    ref = oracle.Engine(d)
+    want = {}
+    for s in range(5):
+        ref.begin_step()
+        for k in range(d["nz"] - 1, -1, -1):
+            ref.solve_slice(k)
+        want[s] = (ref.checksums(), ref.laser_envelope().copy())
+    assert np.abs(want[4][1] - want[0][1]).max() > 1e-2 * np.abs(want[0][1]).max()
+    engs = [oracle.Engine(d) for _ in range(lanes)]
+    got = {}
+
+    def on_step_end(step, eng):
+        got[step] = (eng.checksums(), eng.laser_envelope().copy())
+
+    run_local_pipeline(engs, 5, "cpu", on_step_end)
+    assert sorted(got) == list(range(5))
+    for s in range(5):
+        assert np.array_equal(got[s][1], want[s][1]), s
+        for k, v in want[s][0].items():
+            assert abs(got[s][0][k] - v) <= 1e-12 * max(abs(v), 1e-300), (s, k)
