@@ -908,3 +908,43 @@ def test_laser_envelope_through_steps_in_flight_on_one_gpu(api, lanes):
     run_local_pipeline(engs, 5, torch.device("cuda", 0), on_step_end)
     for s in range(5):
         assert np.abs(got[s] - want[s]).max() <= 1e-10 * np.abs(want[s]).max(), s
+
+
+@pytest.mark.gpu
+def test_laser_slice_messages_round_trip(api):
+    """hps_engine_export_laser_slice / import_laser_slice (the device-side pack / unpack of the envelope's hand-off,
+    MultiBuffer.cpp:840-852, 913-925): what engine A passes on after a step is what engine B starts its next step from."""
+    import torch
+    d = decks.laser_blowout_wake()
+    d.update(nx=64, ny=64, nz=12, lo=(-16.0, -16.0, -3.0), hi=(16.0, 16.0, 3.0), laser_a0=1.5, laser_lambda0=0.4,
+             laser_solver=1, dt=5.0)
+    a = api.SliceEngine(d)
+    ref = api.SliceEngine(d)
+    a.run_step()
+    ref.run_step()
+    ref.run_step()                       # the reference engine runs step 1 itself
+    b = api.SliceEngine(d)
+    b.set_laser_import(True, 1)
+    b.begin_step()
+    msg = torch.zeros(a.laser_message_doubles(), dtype=torch.float64, device="cuda")
+    for isl in range(d["nz"] - 1, -1, -1):
+        a.export_laser_slice(isl, msg)
+        a.sync()
+        b.import_laser_slice(isl, msg)
+        b.sync()
+    for isl in range(d["nz"] - 1, -1, -1):
+        b.solve_slice(isl)
+    assert np.abs(b.laser_envelope() - ref.laser_envelope()).max() <= 1e-12 * np.abs(ref.laser_envelope()).max()
+    # and the step after that agrees too (a_{n-1} arrived as well)
+    c = api.SliceEngine(d)
+    c.set_laser_import(True, 2)
+    c.begin_step()
+    for isl in range(d["nz"] - 1, -1, -1):
+        b.export_laser_slice(isl, msg)
+        b.sync()
+        c.import_laser_slice(isl, msg)
+        c.sync()
+    for isl in range(d["nz"] - 1, -1, -1):
+        c.solve_slice(isl)
+    ref.run_step()
+    assert np.abs(c.laser_envelope() - ref.laser_envelope()).max() <= 1e-10 * np.abs(ref.laser_envelope()).max()
