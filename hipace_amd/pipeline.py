@@ -259,7 +259,6 @@ def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_st
     assert per_step >= 2, "a step needs at least two slices"
     assert world == 1 or groups is not None, "world > 1 needs make_edge_groups(world)"
     laser = bool(getattr(engines[0], "has_laser", False))
-    assert not (laser and world > 1), "the laser's time levels travel between the stages of one process only (so far)"
     on_gpu = str(device) != "cpu"
     nbeam, off = engines[0].beam_layout()
     assert nbeam == 0 or not getattr(engines[0], "moving", False), "run_local_pipeline hands a static beam on (hipace.dt = 0)"
@@ -290,6 +289,9 @@ def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_st
             remote_in = world > 1 and j == 0           # my predecessor stage lives on the previous rank
             remote_out = world > 1 and j == L - 1      # my successor stage lives on the next rank
             sends = []
+            # laser messages on the rank-to-rank edges: {a_{n+1}, a_n} of a slice, packed / unpacked on the device
+            lmsg_in = torch.zeros(eng.laser_message_doubles(), dtype=torch.float64, device=device) if (laser and remote_in) else None
+            lpool = []                                  # (buffer, request) of the laser sends in flight
             for m, step in enumerate(range(stage, n_steps, G)):
                 buf = bufs[j][m % 2]
                 fed = step > 0                          # step 0 starts from the injected beam
@@ -307,15 +309,20 @@ def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_st
                     if fed:
                         need = min(q + 1, per_step - 1)             # this slice's beam and the next one's (jx/jy source)
                         if remote_in:
-                            landed = False
+                            # same order as the sender posts them: per slice the beam block (if any), then the laser
                             while copied <= need:
                                 d = block(buf, copied)
                                 if d.numel() > 0:
                                     dist.irecv(d, src=prev_rank, group=g_in).wait()
-                                    landed = True
+                                    if on_gpu:
+                                        torch.cuda.current_stream().synchronize()   # landed before the engine's stream reads it
+                                if laser:
+                                    dist.irecv(lmsg_in, src=prev_rank, group=g_in).wait()
+                                    if on_gpu:
+                                        torch.cuda.current_stream().synchronize()
+                                    eng.import_laser_slice(nz - 1 - copied, lmsg_in)
+                                    eng.sync()                      # lmsg_in is free for the next slice
                                 copied += 1
-                            if landed and on_gpu:
-                                torch.cuda.current_stream().synchronize()   # data landed before the engine's stream reads it
                         else:
                             with cond:
                                 while progress[pj] < mp * per_step + need + 1 and not errors:
@@ -346,6 +353,15 @@ def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_st
                                 # receives its peer's sends are waiting for (a whole step of blocks may be in flight)
                                 while sends and sends[0].is_completed():
                                     sends.pop(0)
+                            if laser:
+                                free = [k for k, (_, rq) in enumerate(lpool) if rq.is_completed()]
+                                if free:
+                                    lb = lpool.pop(free[0])[0]
+                                else:                               # never wait for a send (see above): take a new buffer
+                                    lb = torch.zeros(eng.laser_message_doubles(), dtype=torch.float64, device=device)
+                                eng.export_laser_slice(nz - 1 - q, lb)
+                                eng.sync()
+                                lpool.append((lb, dist.isend(lb, dst=next_rank, group=g_out)))
                     ev = eng.record_event((m % 2) * per_step + q)
                     with cond:
                         events[j][(m, q)] = ev
@@ -355,6 +371,8 @@ def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_st
                 if on_step_end is not None:
                     on_step_end(step, eng)
             for rq in sends:
+                rq.wait()
+            for _, rq in lpool:
                 rq.wait()
         except BaseException as e:      # noqa: BLE001 -- re-raised on the caller's thread
             with cond:

@@ -226,3 +226,64 @@ def test_local_pipeline_hands_the_laser_envelope_on(oracle, lanes):
         assert np.array_equal(got[s][1], want[s][1]), s
         for k, v in want[s][0].items():
             assert abs(got[s][0][k] - v) <= 1e-12 * max(abs(v), 1e-300), (s, k)
+
+
+def _laser_deck():
+    d = decks.laser_blowout_wake()
+    d.update(nx=32, ny=32, nz=16, lo=(-16.0, -16.0, -4.0), hi=(16.0, 16.0, 4.0), laser_a0=1.5, laser_lambda0=0.4,
+             laser_solver=1, dt=5.0)
+    return d
+
+
+def _laser_lanes_worker(rank, world, port, lanes, n_steps, out):
+    import torch.distributed as dist
+    from hipace_amd.pipeline import make_edge_groups, run_local_pipeline
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    groups = make_edge_groups(world)
+    engs = [O.Engine(_laser_deck()) for _ in range(lanes)]
+    res = {}
+
+    def on_step_end(step, eng):
+        res[step] = (eng.checksums(), eng.laser_envelope().copy())
+
+    run_local_pipeline(engs, n_steps, "cpu", on_step_end, rank=rank, world=world, groups=groups)
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,lanes,n_steps", [(2, 1, 5), (2, 2, 6)])
+def test_laser_envelope_travels_between_ranks(oracle, world, lanes, n_steps):
+    """The laser's time levels on the rank-to-rank edges of run_local_pipeline: one message per slice ({a_{n+1}, a_n},
+    packed and unpacked by the engines), in the same order as the beam blocks; every step has the envelope and the
+    checksums of a single engine running the steps in turn."""
+    import numpy as np
+    d = _laser_deck()
+    ref = oracle.Engine(d)
+    want = {}
+    for s in range(n_steps):
+        ref.begin_step()
+        for k in range(d["nz"] - 1, -1, -1):
+            ref.solve_slice(k)
+        want[s] = (ref.checksums(), ref.laser_envelope().copy())
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_laser_lanes_worker, args=(r, world, port, lanes, n_steps, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got = {}
+    for _, res in results:
+        got.update(res)
+    assert sorted(got) == list(range(n_steps))
+    for s in range(n_steps):
+        assert np.array_equal(got[s][1], want[s][1]), s
+        for k, v in want[s][0].items():
+            assert abs(got[s][0][k] - v) <= 1e-12 * max(abs(v), 1e-300), (s, k)
