@@ -149,18 +149,20 @@ def main():
 
     run_slices(args.warmup)
     groups = None
-    if lanes > 1:
+    staged = lanes > 1 or (args.config5 and world > 1)       # the laser's time levels travel through the multi-stage ring only
+    if staged:
         from hipace_amd.pipeline import make_edge_groups, run_local_pipeline
         groups = make_edge_groups(world)
+    if lanes > 1:
         run_local_pipeline(engines, lanes, torch.device("cuda", local), slices_per_step=max(2, args.warmup))   # warm every lane
     for e in engines:
         e.set_profiling(True, stride=args.profile_stride)
     barrier()
     t0 = time.perf_counter()
-    if lanes > 1:
+    if staged:
         # `lanes` pipeline stages per GPU; every stage sweeps whole boxes.  world > 1 (opt-in, --inflight): stage
         # r*lanes + l on rank r, RCCL only on the rank-to-rank edges
-        boxes = (args.steps // nz) * world
+        boxes = max(1, args.steps // nz) * world
         args.steps = run_local_pipeline(engines, boxes, torch.device("cuda", local), rank=rank, world=world, groups=groups)
     elif world == 1:
         run_slices(args.steps)
