@@ -229,7 +229,7 @@ int beam_deposit_moving (Engine& E, int p, int cjx, int cjy, int cjz)
     if (bound <= 0) return HPS_OK;
     const SlabView f(E.slab);
     const PartConsts k = base_consts(E.gm);
-    const double q_invvol = E.d.beam_charge*1.0, csq_inv = 1.0/(E.gm.c*E.gm.c);
+    const double q_invvol = E.d.beam_charge*(E.d.si_units ? 1.0/(E.gm.dx*E.gm.dy*E.gm.dz) : 1.0), csq_inv = 1.0/(E.gm.c*E.gm.c);
     const dim3 grid(ceil_div(bound, 256)), block(256);
 #define CALL(O) hipLaunchKernelGGL(k_beam_deposit_dyn<O>, grid, block, 0, E.st, f, E.bm, E.d_B, E.d_nfront, p, cjx, cjy, cjz, q_invvol, csq_inv, k)
     HPS_BEAM_ORDER(E.d.order, CALL)

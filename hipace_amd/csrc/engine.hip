@@ -353,7 +353,7 @@ int Engine::init_beam ()
                 if (dens <= 0.0) continue;
                 h[0].push_back(x); h[1].push_back(y); h[2].push_back(z);
                 h[3].push_back(d.beam_umean[0]*gm.c); h[4].push_back(d.beam_umean[1]*gm.c); h[5].push_back(d.beam_umean[2]*gm.c);
-                h[6].push_back(std::fabs(dens/nppc));
+                h[6].push_back(std::fabs(dens*(d.si_units ? gm.dx*gm.dy*gm.dz/nppc : 1.0/nppc)));      // scale_fac, BeamParticleContainerInit.cpp:215-216
             }
         }
     }
@@ -445,8 +445,11 @@ int Engine::create (const hps_deck& deck, int device)
     gm.xoff = 0.5*(d.lo[0] + d.hi[0] - gm.dx*(d.nx - 1));
     gm.yoff = 0.5*(d.lo[1] + d.hi[1] - gm.dy*(d.ny - 1));
     gm.c = gm.ep0 = gm.mu0 = gm.q_e = gm.m_e = 1.0;
+    if (d.si_units) {       // make_constants_SI (utils/Constants.H:15-24, 2018 CODATA)
+        gm.c = 299792458.0; gm.ep0 = 8.8541878128e-12; gm.mu0 = 1.25663706212e-06; gm.q_e = 1.602176634e-19; gm.m_e = 9.1093837015e-31;
+    }
     gm.plo[0] = d.lo[0]; gm.plo[1] = d.lo[1]; gm.phi[0] = d.hi[0]; gm.phi[1] = d.hi[1];
-    gm.bc = d.bc; gm.normalized = 1;
+    gm.bc = d.bc; gm.normalized = d.si_units ? 0 : 1;
 
     slab.nx = d.nx; slab.ny = d.ny; slab.ng = g; slab.ncomp = ncomp;
     slab.jstride = d.nx + 2*g; slab.nstride = slab.jstride*(d.ny + 2*g);
@@ -553,7 +556,8 @@ int Engine::begin_step ()
     if (np > 0) {
         const int nppc = d.plasma_ppc[0]*d.plasma_ppc[1];
         hipLaunchKernelGGL(k_init_plasma, dim3(ceil_div(np, 256)), dim3(256), 0, st, pl, d.nx, d.ny,
-                           d.plasma_ppc[0], d.plasma_ppc[1], d.lo[0], d.lo[1], gm.dx, gm.dy, d.plasma_density*(1.0/nppc));
+                           d.plasma_ppc[0], d.plasma_ppc[1], d.lo[0], d.lo[1], gm.dx, gm.dy,
+                           d.plasma_density*(d.si_units ? gm.dx*gm.dy*gm.dz/nppc : 1.0/nppc));     // scale_fac, PlasmaParticleContainerInit.cpp:40-41
         // neutralising ion background, deposited once per step with charge -q (MultiPlasma.cpp:106-118)
         const int comp[6] = {-1, -1, -1, -1, -1, pc ? (int)HPS_PC_ION_RHOMJZ : (int)HPS_C_ION_RHOMJZ};
         if (tiling) {
@@ -576,7 +580,7 @@ int Engine::deposit_beam_slice (int islice, int cjx, int cjy, int cjz)
     double* blk = beam_cur + 7*first0;
     const BeamView beam{blk, blk + count, blk + 2*count, blk + 3*count, blk + 4*count, blk + 5*count, blk + 6*count};
     const long first = 0;
-    const double q_invvol = d.beam_charge*1.0;      // normalised units, level 0
+    const double q_invvol = d.beam_charge*(d.si_units ? 1.0/(gm.dx*gm.dy*gm.dz) : 1.0);      // BeamDepositCurrent.cpp:70-83, level 0
     const double csq_inv = 1.0/(gm.c*gm.c);
     const dim3 grid(ceil_div(count, 256)), block(256);
     SlabView f(slab);
@@ -967,7 +971,7 @@ int Engine::solve_slice (int islice)
             const int nbA = (int)ceil_div(cA, 256), nbB = (int)ceil_div(cB, 256);
             const double csq_inv = 1.0/(gm.c*gm.c);
 #define HPS_PAIR(O) hipLaunchKernelGGL(k_beam_deposit_pair<O>, dim3(nbA + nbB), b256, 0, st, f, bA, cA, nbA, HPS_C_JZB, bB, cB, HPS_C_N_JXB, \
-                                       HPS_C_N_JYB, d.beam_charge*1.0, csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff)
+                                       HPS_C_N_JYB, d.beam_charge*(d.si_units ? 1.0/(gm.dx*gm.dy*gm.dz) : 1.0), csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff)
             switch (d.order) { case 0: HPS_PAIR(0); break; case 1: HPS_PAIR(1); break; case 2: HPS_PAIR(2); break; default: HPS_PAIR(3); break; }
 #undef HPS_PAIR
         }

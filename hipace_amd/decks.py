@@ -48,6 +48,7 @@ _DEFAULT = dict(
     laser_zfoc=0.0,          # laser.focal_distance
     laser_solver=0,          # lasers.solver_type: 0 keep the envelope static, 1 "fft" (MultiLaser::AdvanceSliceFFT)
     laser_use_phase=1,       # lasers.use_phase (MultiLaser.H:203)
+    si_units=0,              # hipace.normalized_units = 0: SI constants, charges and masses in C and kg, weights = charges
 )
 
 
@@ -130,6 +131,23 @@ def laser_evolution():
     return d
 
 
+# 2018 CODATA values of utils/Constants.H:15-24
+SI = dict(c=299792458.0, ep0=8.8541878128e-12, mu0=1.25663706212e-06, q_e=1.602176634e-19, m_e=9.1093837015e-31)
+
+
+def laser_blowout_wake_SI():
+    """tests/laser_blowout_wake_explicit.SI.1Rank.sh (examples/blowout_wake/inputs_SI): the laser-driven wake in SI
+    units, kp_inv = 10 um, n_e = wp^2 m_e eps0 / q_e^2 with wp = c kp -- the deck of BASELINE config 5 at test size."""
+    kp_inv = 10.0e-6
+    wp = SI["c"] / kp_inv
+    ne = wp ** 2 * SI["m_e"] * SI["ep0"] / SI["q_e"] ** 2
+    d = laser_blowout_wake()
+    d.update(si_units=1, lo=(-20.0 * kp_inv, -20.0 * kp_inv, -7.5 * kp_inv), hi=(20.0 * kp_inv, 20.0 * kp_inv, 6.0 * kp_inv),
+             plasma_density=ne, plasma_charge=-SI["q_e"], plasma_mass=SI["m_e"],
+             laser_w0=4.0 * kp_inv, laser_L0=2.0 * kp_inv, laser_lambda0=0.8e-6)
+    return d
+
+
 def predictor_corrector(base, tol=1.0e-4, max_iter=7, mix=0.0635):
     """`base` with hipace.bxby_solver = predictor-corrector; the defaults are the settings of the reference's own
     predictor-corrector-vs-explicit test (tests/ion_motion.SI.1Rank.sh:30-34)."""
@@ -138,5 +156,5 @@ def predictor_corrector(base, tol=1.0e-4, max_iter=7, mix=0.0635):
     return d
 
 
-NAMED = dict(linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
+NAMED = dict(linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, laser_blowout_wake_SI=laser_blowout_wake_SI, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
              beam_evolution=beam_evolution, beam_in_vacuum_open_boundary=beam_in_vacuum_open_boundary)

@@ -190,6 +190,9 @@ typedef struct {
      * Explicit solver, per-particle kernels. */
     int laser_on; double laser_a0, laser_w0, laser_L0, laser_lambda0, laser_pos[3];
     double laser_zfoc; int laser_solver; int laser_use_phase;
+    /* hipace.normalized_units = 0: the constants of utils/Constants.H:15-24 (2018 CODATA), charges in C, masses in kg,
+     * densities in m^-3, lengths in m; particle weights are then numbers of particles (scale_fac = dx dy dz / ppc) */
+    int si_units;
 } hps_deck;
 
 /* slab component indices of the engine (explicit-solver layout of fields/Fields.cpp:70-122) */

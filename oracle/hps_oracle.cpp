@@ -941,6 +941,7 @@ struct Deck {
     // Gaussian laser envelope (laser/Laser.H:32-45, MultiLaser.cpp:881-919), static: only step 0 is restated (the
     // envelope solver that advances it to the next time step is not), explicit solver only
     int laser_on; double laser_a0, laser_w0, laser_L0, laser_lambda0, laser_pos[3];
+    int si_units;                // hipace.normalized_units = 0: PhysConst of utils/Constants.H:15-24, weights are charges
     double laser_zfoc;           // laser.focal_distance (Laser.H:43)
     int laser_solver;            // lasers.solver_type: 0 = envelope kept static, 1 = "fft" (MultiLaser::AdvanceSliceFFT)
     int laser_use_phase;         // lasers.use_phase (MultiLaser.H:203, default true)
@@ -982,8 +983,11 @@ struct Engine {
         gm.xoff = 0.5*(d.lo[0] + d.hi[0] - gm.dx*(d.nx - 1));
         gm.yoff = 0.5*(d.lo[1] + d.hi[1] - gm.dy*(d.ny - 1));
         gm.c = 1; gm.ep0 = 1; gm.mu0 = 1; gm.q_e = 1; gm.m_e = 1;   // make_constants_normalized
+        if (d.si_units) {            // make_constants_SI (2018 CODATA, utils/Constants.H:15-24)
+            gm.c = 299792458.0; gm.ep0 = 8.8541878128e-12; gm.mu0 = 1.25663706212e-06; gm.q_e = 1.602176634e-19; gm.m_e = 9.1093837015e-31;
+        }
         gm.plo[0] = d.lo[0]; gm.plo[1] = d.lo[1]; gm.phi[0] = d.hi[0]; gm.phi[1] = d.hi[1];
-        gm.bc = d.bc; gm.normalized = 1;
+        gm.bc = d.bc; gm.normalized = d.si_units ? 0 : 1;
         const long js = d.nx + 2*g, ns = js*(d.ny + 2*g);
         slab_data.assign((size_t)ns*ncomp, 0.0);
         slab = Slab{slab_data.data(), d.nx, d.ny, g, ncomp, js, ns};
@@ -1004,7 +1008,8 @@ struct Engine {
     // fixed ppc, uniform density, no fine patch, u = 0; ppc index outermost (:192)
     void init_plasma () {
         const int nppc = d.plasma_ppc[0]*d.plasma_ppc[1];
-        const double scale = nppc <= 0 ? 0. : 1.0/nppc;
+        // scale_fac (PlasmaParticleContainerInit.cpp:40-41): density per particle, or in SI the number of electrons it stands for
+        const double scale = nppc <= 0 ? 0. : (d.si_units ? gm.dx*gm.dy*gm.dz/nppc : 1.0/nppc);
         const double rad = d.plasma_radius > 0 ? d.plasma_radius : std::numeric_limits<double>::infinity();
         std::vector<double> xs, ys;
         for (int ip = 0; ip < nppc; ++ip) {
@@ -1075,7 +1080,7 @@ struct Engine {
         b = Beam();
         if (d.beam_profile < 0) return;
         const int nppc = d.beam_ppc[0]*d.beam_ppc[1]*d.beam_ppc[2];
-        const double scale = 1.0/nppc;
+        const double scale = d.si_units ? gm.dx*gm.dy*gm.dz/nppc : 1.0/nppc;      // BeamParticleContainerInit.cpp:215-216
         const int ny_p = d.beam_ppc[1], nz_p = d.beam_ppc[2];
         for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i) {
             for (int ip = 0; ip < nppc; ++ip) {
@@ -1100,7 +1105,7 @@ struct Engine {
     // DepositCurrentSlice for beams (deposition/BeamDepositCurrent.cpp:21-195)
     void deposit_beam (const Beam& b, int cjx, int cjy, int cjz, long count = -1) {
         const double dxi = 1.0/gm.dx, dyi = 1.0/gm.dy;
-        const double invvol = 1.0;   // normalised, lev 0
+        const double invvol = d.si_units ? dxi*dyi*(1.0/gm.dz) : 1.0;      // BeamDepositCurrent.cpp:70-83, level 0
         const double clightsq = 1.0/(gm.c*gm.c);
         const double q = d.beam_charge;
         const size_t np = count < 0 ? b.x.size() : (size_t)count;     // getNumParticles: without slipped (:100)
@@ -1778,7 +1783,7 @@ struct orc_deck {
     double dt; int beam_n_subcycles; double beam_mass; double ext_E_slope[2];
     int bxby_solver; double predcorr_tol; int predcorr_max_iter; double predcorr_mix; int field_bc;
     int laser_on; double laser_a0, laser_w0, laser_L0, laser_lambda0, laser_pos[3];
-    double laser_zfoc; int laser_solver; int laser_use_phase;
+    double laser_zfoc; int laser_solver; int laser_use_phase; int si_units;
 };
 
 void* orc_engine_create (const orc_deck* k) {
@@ -1797,7 +1802,7 @@ void* orc_engine_create (const orc_deck* k) {
     d.field_bc=k->field_bc;
     d.laser_on=k->laser_on; d.laser_a0=k->laser_a0; d.laser_w0=k->laser_w0; d.laser_L0=k->laser_L0; d.laser_lambda0=k->laser_lambda0;
     for (int i=0;i<3;++i) d.laser_pos[i]=k->laser_pos[i];
-    d.laser_zfoc=k->laser_zfoc; d.laser_solver=k->laser_solver; d.laser_use_phase=k->laser_use_phase;
+    d.laser_zfoc=k->laser_zfoc; d.laser_solver=k->laser_solver; d.laser_use_phase=k->laser_use_phase; d.si_units=k->si_units;
     return new Engine(d);
 }
 void orc_engine_destroy (void* h) { delete static_cast<Engine*>(h); }

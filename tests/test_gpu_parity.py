@@ -948,3 +948,20 @@ def test_laser_slice_messages_round_trip(api):
         c.solve_slice(isl)
     ref.run_step()
     assert np.abs(c.laser_envelope() - ref.laser_envelope()).max() <= 1e-10 * np.abs(ref.laser_envelope()).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile_size", [0, 16])
+def test_laser_blowout_wake_SI_matches_reference_checksums(api, tile_size):
+    """tests/laser_blowout_wake_explicit.SI.1Rank.sh: the laser-driven wake in SI units (hipace.normalized_units = 0;
+    the deck of BASELINE config 5 at test size) -- all 18 checksums of the reference's fixture."""
+    gold = json.load(open(os.path.join(GOLD, "laser_blowout_wake_explicit.SI.1Rank.json")))["lev=0"]
+    eng = api.SliceEngine(decks.laser_blowout_wake_SI(), tile_size=tile_size, sort_period=8)
+    eng.set_diagnostics(True)
+    eng.run_step()
+    cs = eng.checksums()
+    for k, v in gold.items():
+        if v == 0.0:
+            assert cs[k] == 0.0, k
+        else:
+            assert abs(cs[k] - v) <= 1e-9 * abs(v), (k, cs[k], v)

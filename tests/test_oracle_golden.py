@@ -25,7 +25,9 @@ CASES = [("linear_wake", "linear_wake.normalized.1Rank"),
          ("beam_in_vacuum_open_boundary", "beam_in_vacuum_open_boundary.normalized.1Rank"),
          # a wake driven by a Gaussian laser pulse instead of a beam: |a|^2 in the deposition, the explicit source and
          # the pusher (tests/laser_blowout_wake_explicit.1Rank.sh; the reference skips Sx Sy chi, they agree too)
-         ("laser_blowout_wake", "laser_blowout_wake_explicit.1Rank")]
+         ("laser_blowout_wake", "laser_blowout_wake_explicit.1Rank"),
+         # the same wake in SI units (hipace.normalized_units = 0): the deck of BASELINE config 5 at test size
+         ("laser_blowout_wake_SI", "laser_blowout_wake_explicit.SI.1Rank")]
 
 
 @pytest.mark.parametrize("name,js", CASES)
