@@ -148,6 +148,44 @@ def laser_blowout_wake_SI():
     return d
 
 
+def _ne_SI(kp_inv=10.0e-6):
+    wp = SI["c"] / kp_inv
+    return wp ** 2 * SI["m_e"] * SI["ep0"] / SI["q_e"] ** 2
+
+
+def blowout_wake_SI():
+    """examples/blowout_wake/inputs_SI (run next to the normalised deck by tests/blowout_wake.2Rank.sh): the same physics
+    with kp_inv = 10 um."""
+    kp_inv = 10.0e-6
+    ne = _ne_SI(kp_inv)
+    d = blowout_wake()
+    d.update(si_units=1, lo=(-8.0 * kp_inv, -8.0 * kp_inv, -6.0 * kp_inv), hi=(8.0 * kp_inv, 8.0 * kp_inv, 6.0 * kp_inv),
+             beam_zmin=-59.0e-6, beam_zmax=59.0e-6, beam_radius=12.0e-6, beam_density=3.0 * ne,
+             beam_pos_std=(3.0e-6, 3.0e-6, 14.1e-6), beam_charge=-SI["q_e"], beam_mass=SI["m_e"],
+             plasma_density=ne, plasma_charge=-SI["q_e"], plasma_mass=SI["m_e"])
+    return d
+
+
+def linear_wake_SI():
+    """tests/linear_wake.SI.1Rank.sh (examples/linear_wake/inputs_SI + rho)."""
+    d = linear_wake()
+    ne = _ne_SI()
+    d.update(si_units=1, lo=(-100.0e-6, -100.0e-6, -75.0e-6), hi=(100.0e-6, 100.0e-6, 20.0e-6),
+             beam_zmin=-10.0e-6, beam_zmax=10.0e-6, beam_radius=30.0e-6, beam_density=0.01 * ne,
+             beam_charge=-SI["q_e"], beam_mass=SI["m_e"], plasma_density=ne, plasma_charge=-SI["q_e"], plasma_mass=SI["m_e"])
+    return d
+
+
+def beam_in_vacuum_SI():
+    """tests/beam_in_vacuum.SI.1Rank.sh (examples/beam_in_vacuum/inputs_SI, order 0, MG_tolerance_rel = 1e-5).  The deck
+    has two identical beams on top of each other; one beam of twice the density deposits the same currents."""
+    d = beam_in_vacuum()
+    d.update(si_units=1, lo=(-2000.0e-6, -2000.0e-6, -20.0e-6), hi=(2000.0e-6, 2000.0e-6, 20.0e-6),
+             beam_zmin=-100.0e-6, beam_zmax=100.0e-6, beam_radius=10.0e-6, beam_density=2 * 1.4119793504295784e23,
+             beam_charge=-SI["q_e"], beam_mass=SI["m_e"], mg_tol_rel=1.0e-5, order=0)
+    return d
+
+
 def predictor_corrector(base, tol=1.0e-4, max_iter=7, mix=0.0635):
     """`base` with hipace.bxby_solver = predictor-corrector; the defaults are the settings of the reference's own
     predictor-corrector-vs-explicit test (tests/ion_motion.SI.1Rank.sh:30-34)."""
@@ -156,5 +194,5 @@ def predictor_corrector(base, tol=1.0e-4, max_iter=7, mix=0.0635):
     return d
 
 
-NAMED = dict(linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, laser_blowout_wake_SI=laser_blowout_wake_SI, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
+NAMED = dict(linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, laser_blowout_wake_SI=laser_blowout_wake_SI, linear_wake_SI=linear_wake_SI, blowout_wake_SI=blowout_wake_SI, beam_in_vacuum_SI=beam_in_vacuum_SI, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
              beam_evolution=beam_evolution, beam_in_vacuum_open_boundary=beam_in_vacuum_open_boundary)

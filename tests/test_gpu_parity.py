@@ -175,7 +175,8 @@ def test_multigrid_solve1(api, oracle, nx, ny, warm):
     assert np.array_equal(out[2:5], slab[2:5])
 
 
-@pytest.mark.parametrize("name,js", [("linear_wake", "linear_wake.normalized.1Rank"),
+@pytest.mark.parametrize("name,js", [("linear_wake_SI", "linear_wake.SI.1Rank"), ("beam_in_vacuum_SI", "beam_in_vacuum.SI.1Rank"),
+                                     ("linear_wake", "linear_wake.normalized.1Rank"),
                                      ("blowout_wake", "blowout_wake_explicit.2Rank")])
 def test_engine_reproduces_reference_checksums(api, name, js):
     """North-star parity bar: field checksums within 1e-6 of the reference's CPU goldens."""

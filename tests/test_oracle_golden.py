@@ -27,7 +27,10 @@ CASES = [("linear_wake", "linear_wake.normalized.1Rank"),
          # the pusher (tests/laser_blowout_wake_explicit.1Rank.sh; the reference skips Sx Sy chi, they agree too)
          ("laser_blowout_wake", "laser_blowout_wake_explicit.1Rank"),
          # the same wake in SI units (hipace.normalized_units = 0): the deck of BASELINE config 5 at test size
-         ("laser_blowout_wake_SI", "laser_blowout_wake_explicit.SI.1Rank")]
+         ("laser_blowout_wake_SI", "laser_blowout_wake_explicit.SI.1Rank"),
+         # more of the SI fixtures (the beam block of these is not compared: the SI files store u / c and charges)
+         ("linear_wake_SI", "linear_wake.SI.1Rank"),
+         ("beam_in_vacuum_SI", "beam_in_vacuum.SI.1Rank")]
 
 
 @pytest.mark.parametrize("name,js", CASES)
@@ -42,7 +45,7 @@ def test_oracle_reproduces_reference_checksums(oracle, name, js):
             assert cs[k] == 0.0, (k, cs[k])
         else:
             assert abs(cs[k] - v) <= 1e-11 * abs(v), (k, cs[k], v)
-    if "beam" not in gold:
+    if "beam" not in gold or decks.NAMED[name]().get("si_units", 0):
         return
     # beam block: particle count, sum w, sum |x|, |y|, |z|, |uz|
     b = eng.beam_stats()
@@ -135,3 +138,28 @@ def test_laser_evolution_fft_solver_reproduces_reference_checksums(oracle):
     for k, v in gold.items():
         if v == 0.0 and k in cs:
             assert cs[k] == 0.0, k          # vacuum: no wake
+
+
+def test_SI_and_normalised_units_give_the_same_wake(oracle):
+    """tests/blowout_wake.2Rank.sh runs the blowout deck in SI and in normalised units and compares them
+    (examples/blowout_wake/analysis.py).  Here: every field checksum of the SI run, divided by its unit (E0 = m_e c wp / q_e,
+    kp_inv = 10 um), equals the normalised run's -- which is itself pinned on blowout_wake_explicit.2Rank.json."""
+    SI = decks.SI
+    kp_inv = 10.0e-6
+    wp = SI["c"] / kp_inv
+    ne = wp ** 2 * SI["m_e"] * SI["ep0"] / SI["q_e"] ** 2
+    E0 = SI["m_e"] * SI["c"] * wp / SI["q_e"]
+    unit = {"Ez": E0, "ExmBy": E0, "EypBx": E0, "Bx": E0 / SI["c"], "By": E0 / SI["c"], "Bz": E0 / SI["c"], "Psi": E0 * kp_inv,
+            "jz_beam": SI["q_e"] * ne * SI["c"], "jx": SI["q_e"] * ne * SI["c"], "jy": SI["q_e"] * ne * SI["c"],
+            "rhomjz": SI["q_e"] * ne, "chi": 1.0 / kp_inv ** 2,
+            "Sx": E0 / SI["c"] / kp_inv ** 2, "Sy": E0 / SI["c"] / kp_inv ** 2}
+    dn = decks.blowout_wake()
+    dn["n_steps"] = 1
+    ds = decks.blowout_wake_SI()
+    ds["n_steps"] = 1
+    en, es = oracle.Engine(dn), oracle.Engine(ds)
+    en.run()
+    es.run()
+    cn, cs = en.checksums(), es.checksums()
+    for k, u in unit.items():
+        assert abs(cs[k] / u - cn[k]) <= 2e-9 * abs(cn[k]), (k, cs[k] / u, cn[k])
