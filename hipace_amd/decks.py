@@ -176,6 +176,13 @@ def linear_wake_SI():
     return d
 
 
+def beam_in_vacuum_1Rank():
+    """tests/beam_in_vacuum.normalized.1Rank.sh: as the Serial run with hipace.MG_tolerance_rel = 1e-5."""
+    d = beam_in_vacuum()
+    d.update(mg_tol_rel=1.0e-5)
+    return d
+
+
 def beam_in_vacuum_SI():
     """tests/beam_in_vacuum.SI.1Rank.sh (examples/beam_in_vacuum/inputs_SI, order 0, MG_tolerance_rel = 1e-5).  The deck
     has two identical beams on top of each other; one beam of twice the density deposits the same currents."""
@@ -194,5 +201,5 @@ def predictor_corrector(base, tol=1.0e-4, max_iter=7, mix=0.0635):
     return d
 
 
-NAMED = dict(linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, laser_blowout_wake_SI=laser_blowout_wake_SI, linear_wake_SI=linear_wake_SI, blowout_wake_SI=blowout_wake_SI, beam_in_vacuum_SI=beam_in_vacuum_SI, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
+NAMED = dict(linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, laser_blowout_wake_SI=laser_blowout_wake_SI, linear_wake_SI=linear_wake_SI, blowout_wake_SI=blowout_wake_SI, beam_in_vacuum_SI=beam_in_vacuum_SI, beam_in_vacuum_1Rank=beam_in_vacuum_1Rank, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
              beam_evolution=beam_evolution, beam_in_vacuum_open_boundary=beam_in_vacuum_open_boundary)

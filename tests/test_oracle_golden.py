@@ -30,7 +30,8 @@ CASES = [("linear_wake", "linear_wake.normalized.1Rank"),
          ("laser_blowout_wake_SI", "laser_blowout_wake_explicit.SI.1Rank"),
          # more of the SI fixtures (the beam block of these is not compared: the SI files store u / c and charges)
          ("linear_wake_SI", "linear_wake.SI.1Rank"),
-         ("beam_in_vacuum_SI", "beam_in_vacuum.SI.1Rank")]
+         ("beam_in_vacuum_SI", "beam_in_vacuum.SI.1Rank"),
+         ("beam_in_vacuum_1Rank", "beam_in_vacuum.normalized.1Rank")]      # multigrid tolerance 1e-5
 
 
 @pytest.mark.parametrize("name,js", CASES)
