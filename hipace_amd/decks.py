@@ -193,6 +193,20 @@ def beam_in_vacuum_SI():
     return d
 
 
+def beam_in_vacuum_SI_Serial():
+    """tests/beam_in_vacuum.SI.Serial.sh: the SI deck with the multigrid solver's default tolerance."""
+    d = beam_in_vacuum_SI()
+    d.update(mg_tol_rel=beam_in_vacuum()["mg_tol_rel"])
+    return d
+
+
+def blowout_wake_step0():
+    """tests/blowout_wake.Serial.sh: examples/blowout_wake/inputs_normalized as it stands (max_step = 0: one time step)."""
+    d = blowout_wake()
+    d["n_steps"] = 1
+    return d
+
+
 def predictor_corrector(base, tol=1.0e-4, max_iter=7, mix=0.0635):
     """`base` with hipace.bxby_solver = predictor-corrector; the defaults are the settings of the reference's own
     predictor-corrector-vs-explicit test (tests/ion_motion.SI.1Rank.sh:30-34)."""
@@ -201,5 +215,5 @@ def predictor_corrector(base, tol=1.0e-4, max_iter=7, mix=0.0635):
     return d
 
 
-NAMED = dict(linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, laser_blowout_wake_SI=laser_blowout_wake_SI, linear_wake_SI=linear_wake_SI, blowout_wake_SI=blowout_wake_SI, beam_in_vacuum_SI=beam_in_vacuum_SI, beam_in_vacuum_1Rank=beam_in_vacuum_1Rank, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
+NAMED = dict(beam_in_vacuum_SI_Serial=beam_in_vacuum_SI_Serial, blowout_wake_step0=blowout_wake_step0, linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, laser_blowout_wake_SI=laser_blowout_wake_SI, linear_wake_SI=linear_wake_SI, blowout_wake_SI=blowout_wake_SI, beam_in_vacuum_SI=beam_in_vacuum_SI, beam_in_vacuum_1Rank=beam_in_vacuum_1Rank, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
              beam_evolution=beam_evolution, beam_in_vacuum_open_boundary=beam_in_vacuum_open_boundary)

@@ -177,7 +177,10 @@ def test_multigrid_solve1(api, oracle, nx, ny, warm):
 
 @pytest.mark.parametrize("name,js", [("linear_wake_SI", "linear_wake.SI.1Rank"), ("beam_in_vacuum_SI", "beam_in_vacuum.SI.1Rank"),
                                      ("linear_wake", "linear_wake.normalized.1Rank"),
-                                     ("blowout_wake", "blowout_wake_explicit.2Rank")])
+                                     ("blowout_wake", "blowout_wake_explicit.2Rank"), ("blowout_wake", "blowout_wake.2Rank"),
+                                     ("beam_in_vacuum", "beam_in_vacuum.normalized.Serial"),
+                                     ("beam_in_vacuum_1Rank", "beam_in_vacuum.normalized.1Rank"),
+                                     ("beam_in_vacuum_SI_Serial", "beam_in_vacuum.SI.Serial")])
 def test_engine_reproduces_reference_checksums(api, name, js):
     """North-star parity bar: field checksums within 1e-6 of the reference's CPU goldens."""
     gold = json.load(open(os.path.join(GOLD, js + ".json")))["lev=0"]
