@@ -81,6 +81,7 @@ struct Engine {
     int init_beam ();
     int begin_step ();
     int deposit_beam_slice (int islice, int cjx, int cjy, int cjz);
+    void deposit_grid_current (int islice, int cjz);
     int solve_slice (int islice);
     int run_step ();
 };

@@ -126,6 +126,19 @@ void k_rhs_lincomb (SlabView f, int cA, int dirA, double fa, int cB, int dirB, d
     staging[(long)j*f.nx + i] = fa*(A[sa] - A[-sa]) + fb*(B[sb] - B[-sb]);
 }
 
+// GridCurrent::DepositCurrentSlice (utils/GridCurrent.cpp:25-71): valid cells; amp = peak * exp(-dz^2/2) of the slice
+__global__ __launch_bounds__(256)
+void k_grid_current (SlabView f, int cjz, double xlo, double ylo, double dx, double dy, double mx, double my, double sx, double sy,
+                     double amp)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= f.nx) return;
+    const double delta_x = (xlo + (i + 0.5)*dx - mx) / sx;
+    const double delta_y = (ylo + (j + 0.5)*dy - my) / sy;
+    f(i, j, cjz) += amp*exp(-0.5*(delta_x*delta_x + delta_y*delta_y));
+}
+
 // ExmBy = -dPsi/dx, EypBx = -dPsi/dy on the box grown by (guards-1) (fields/Fields.cpp:931-956)
 __global__ __launch_bounds__(256)
 void k_grad_psi (SlabView f, int cPsi, int cExmBy, int cEypBx, double hdx_inv, double hdy_inv)
@@ -373,6 +386,7 @@ int Engine::init_beam ()
             beam_box_init.jlo = std::max(0,      (int)std::floor((ylo - gm.yoff)/gm.dy + 0.5) - m + g);
             beam_box_init.jhi = std::min(jn - 1, (int)std::floor((yhi - gm.yoff)/gm.dy + 0.5) + m + g);
         }
+        if (d.grid_current_on) beam_box_init = full_box;      // the grid current fills jz_beam of every cell
         beam_box = beam_box_init;
     }
     if (nbeam > 0) {
@@ -569,6 +583,16 @@ int Engine::begin_step ()
     }
     HPS_HIP_CHECK(hipGetLastError());
     return HPS_OK;
+}
+
+// m_grid_current.DepositCurrentSlice (Hipace.cpp:629); z of the slice is plo[2] + islice*dz (GridCurrent.cpp:44)
+void Engine::deposit_grid_current (int islice, int cjz)
+{
+    if (!d.grid_current_on) return;
+    const double delta_z = (d.lo[2] + islice*gm.dz - d.grid_current_mean[2]) / d.grid_current_std[2];
+    hipLaunchKernelGGL(k_grid_current, dim3(ceil_div(d.nx, 256), d.ny), dim3(256), 0, st, SlabView(slab), cjz, d.lo[0], d.lo[1], gm.dx,
+                       gm.dy, d.grid_current_mean[0], d.grid_current_mean[1], d.grid_current_std[0], d.grid_current_std[1],
+                       d.grid_current_peak*std::exp(-0.5*(delta_z*delta_z)));
 }
 
 int Engine::deposit_beam_slice (int islice, int cjx, int cjy, int cjz)
@@ -845,6 +869,7 @@ int Engine::solve_slice_pc (int islice)
         else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
     mark();   // b2
     if ((e = deposit_beam_slice(islice, HPS_PC_JX, HPS_PC_JY, HPS_PC_JZ))) return e;
+    deposit_grid_current(islice, HPS_PC_JZ);
     {   const double fa = 1.0/(gm.ep0*gm.c);
         hipLaunchKernelGGL(k_rhs_all, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_PC_RHOMJZ,
                            HPS_PC_ION_RHOMJZ, d.deposit_rho ? HPS_PC_RHO : -1, HPS_PC_JX, HPS_PC_JY, 1.0/gm.ep0,
@@ -976,6 +1001,7 @@ int Engine::solve_slice (int islice)
 #undef HPS_PAIR
         }
     } else if ((e = deposit_beam_slice(islice, -1, -1, HPS_C_JZB))) return e;
+    deposit_grid_current(islice, HPS_C_JZB);
 
     // AddRhoIons + Psi, Ez, Bz solves + -grad Psi (fields/Fields.cpp:840-957)
     {   const double fa = 1.0/(gm.ep0*gm.c);

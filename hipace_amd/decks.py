@@ -48,6 +48,7 @@ _DEFAULT = dict(
     laser_zfoc=0.0,          # laser.focal_distance
     laser_solver=0,          # lasers.solver_type: 0 keep the envelope static, 1 "fft" (MultiLaser::AdvanceSliceFFT)
     laser_use_phase=1,       # lasers.use_phase (MultiLaser.H:203)
+    grid_current_on=0, grid_current_peak=0.0, grid_current_mean=(0.0, 0.0, 0.0), grid_current_std=(1.0, 1.0, 1.0),   # grid_current.*
     si_units=0,              # hipace.normalized_units = 0: SI constants, charges and masses in C and kg, weights = charges
 )
 
@@ -193,6 +194,16 @@ def beam_in_vacuum_SI():
     return d
 
 
+def grid_current():
+    """tests/grid_current.1Rank.sh: the beam_in_vacuum deck at 32^3, order 0, a Gaussian beam of density 0.2 and a grid
+    current (grid_current.*, utils/GridCurrent.cpp) of the same shape, which cancels most of the beam's current"""
+    d = beam_in_vacuum()
+    d.update(nx=32, ny=32, nz=32, lo=(-8.0, -8.0, -6.0), hi=(8.0, 8.0, 6.0), n_steps=2, order=0, beam_profile=0, beam_density=0.2,
+             beam_radius=1.0, beam_pos_mean=(0.0, 0.0, 0.0), beam_pos_std=(0.3, 0.3, 1.41), beam_ppc=(1, 1, 1),
+             grid_current_on=1, grid_current_peak=0.2, grid_current_mean=(0.0, 0.0, 0.0), grid_current_std=(0.3, 0.3, 1.41))
+    return d
+
+
 def beam_in_vacuum_SI_Serial():
     """tests/beam_in_vacuum.SI.Serial.sh: the SI deck with the multigrid solver's default tolerance."""
     d = beam_in_vacuum_SI()
@@ -215,5 +226,5 @@ def predictor_corrector(base, tol=1.0e-4, max_iter=7, mix=0.0635):
     return d
 
 
-NAMED = dict(beam_in_vacuum_SI_Serial=beam_in_vacuum_SI_Serial, blowout_wake_step0=blowout_wake_step0, linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, laser_blowout_wake_SI=laser_blowout_wake_SI, linear_wake_SI=linear_wake_SI, blowout_wake_SI=blowout_wake_SI, beam_in_vacuum_SI=beam_in_vacuum_SI, beam_in_vacuum_1Rank=beam_in_vacuum_1Rank, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
+NAMED = dict(grid_current=grid_current, beam_in_vacuum_SI_Serial=beam_in_vacuum_SI_Serial, blowout_wake_step0=blowout_wake_step0, linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, laser_blowout_wake_SI=laser_blowout_wake_SI, linear_wake_SI=linear_wake_SI, blowout_wake_SI=blowout_wake_SI, beam_in_vacuum_SI=beam_in_vacuum_SI, beam_in_vacuum_1Rank=beam_in_vacuum_1Rank, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
              beam_evolution=beam_evolution, beam_in_vacuum_open_boundary=beam_in_vacuum_open_boundary)

@@ -193,6 +193,9 @@ typedef struct {
     /* hipace.normalized_units = 0: the constants of utils/Constants.H:15-24 (2018 CODATA), charges in C, masses in kg,
      * densities in m^-3, lengths in m; particle weights are then numbers of particles (scale_fac = dx dy dz / ppc) */
     int si_units;
+    /* grid_current.* (utils/GridCurrent.cpp:13-23): a Gaussian current density added to jz_beam (explicit solver) or jz
+     * (predictor-corrector) of every slice, GridCurrent::DepositCurrentSlice (:25-71, called at Hipace.cpp:629) */
+    int grid_current_on; double grid_current_peak, grid_current_mean[3], grid_current_std[3];
 } hps_deck;
 
 /* slab component indices of the engine (explicit-solver layout of fields/Fields.cpp:70-122) */

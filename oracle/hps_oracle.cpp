@@ -14,7 +14,7 @@
 //   tests/checksum/benchmarks_json/beam_evolution.1Rank.json                              (moving beam, 21 steps)
 //   tests/checksum/benchmarks_json/beam_in_vacuum_open_boundary.normalized.1Rank.json     (predictor-corrector loop)
 //   tests/checksum/benchmarks_json/{beam_in_vacuum.normalized.1Rank,beam_in_vacuum.SI.1Rank,beam_in_vacuum.SI.Serial}.json
-//   tests/checksum/benchmarks_json/{linear_wake.SI.1Rank,blowout_wake.2Rank,blowout_wake.Serial}.json
+//   tests/checksum/benchmarks_json/{linear_wake.SI.1Rank,blowout_wake.2Rank,blowout_wake.Serial,grid_current.1Rank}.json
 //   tests/checksum/benchmarks_json/{laser_blowout_wake_explicit.1Rank,laser_blowout_wake_explicit.SI.1Rank}.json
 //   tests/checksum/benchmarks_json/laser_evolution.SI.2Rank.json                          (FFT envelope solver, 30 steps)
 // (copied as data fixtures into tests/golden/), see tests/test_oracle_golden.py.  Parts no checksum of the
@@ -949,6 +949,8 @@ struct Deck {
     double laser_zfoc;           // laser.focal_distance (Laser.H:43)
     int laser_solver;            // lasers.solver_type: 0 = envelope kept static, 1 = "fft" (MultiLaser::AdvanceSliceFFT)
     int laser_use_phase;         // lasers.use_phase (MultiLaser.H:203, default true)
+    int grid_current_on = 0;     // grid_current.use_grid_current (utils/GridCurrent.cpp:13-23)
+    double grid_current_peak = 0., grid_current_mean[3] = {0., 0., 0.}, grid_current_std[3] = {1., 1., 1.};
 };
 
 // particles of one beam slice; [0, nreg) were on the slice when the step began ("regular"), the rest slipped in
@@ -1107,6 +1109,23 @@ struct Engine {
     }
 
     // DepositCurrentSlice for beams (deposition/BeamDepositCurrent.cpp:21-195)
+    // GridCurrent::DepositCurrentSlice (utils/GridCurrent.cpp:25-71): valid cells only; z of the slice is
+    // plo[2] + islice*dz (no half cell), x and y are cell centres
+    void deposit_grid_current (int islice, int cjz) {
+        if (!d.grid_current_on) return;
+        const double z = d.lo[2] + islice*gm.dz;
+        const double delta_z = (z - d.grid_current_mean[2]) / d.grid_current_std[2];
+        const double long_pos_factor = std::exp(-0.5*(delta_z*delta_z));
+        for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i) {
+            const double x = d.lo[0] + (i + 0.5)*gm.dx;
+            const double y = d.lo[1] + (j + 0.5)*gm.dy;
+            const double delta_x = (x - d.grid_current_mean[0]) / d.grid_current_std[0];
+            const double delta_y = (y - d.grid_current_mean[1]) / d.grid_current_std[1];
+            const double trans_pos_factor = std::exp(-0.5*(delta_x*delta_x + delta_y*delta_y));
+            slab(i, j, cjz) += d.grid_current_peak*trans_pos_factor*long_pos_factor;
+        }
+    }
+
     void deposit_beam (const Beam& b, int cjx, int cjy, int cjz, long count = -1) {
         const double dxi = 1.0/gm.dx, dyi = 1.0/gm.dy;
         const double invvol = d.si_units ? dxi*dyi*(1.0/gm.dz) : 1.0;      // BeamDepositCurrent.cpp:70-83, level 0
@@ -1399,6 +1418,7 @@ struct Engine {
         else deposit_beam(beam_this, pjx, pjy, pjz);
         for (long k = 0; k < slab.ns; ++k) slab.comp(prhomjz)[k] += slab.comp(pIon_rhomjz)[k];
         if (d.deposit_rho) for (long k = 0; k < slab.ns; ++k) slab.comp(prho)[k] += slab.comp(pIon_rhomjz)[k];
+        deposit_grid_current(islice, pjz);      // Hipace.cpp:629
         double t3 = now(); t_other += t3 - t2;
         solve_psi_ez_bz(prhomjz, pjx, pjy, pPsi, pEz, pBz, pExmBy, pEypBx);
         double t4 = now(); t_poisson += t4 - t3;
@@ -1493,6 +1513,7 @@ struct Engine {
         // AddRhoIons (fields/Fields.cpp:606-615)
         for (long k = 0; k < slab.ns; ++k) slab.comp(rhomjz)[k] += slab.comp(Ion_rhomjz)[k];
         if (d.deposit_rho) for (long k = 0; k < slab.ns; ++k) slab.comp(rho)[k] += slab.comp(Ion_rhomjz)[k];
+        deposit_grid_current(islice, jzb);      // Hipace.cpp:629
         double t3 = now(); t_other += t3 - t2;
         solve_psi_ez_bz(rhomjz, jx, jy, Psi, Ez, Bz, ExmBy, EypBx);
         // m_multi_laser.AdvanceSlice (Hipace.cpp:637)
@@ -1788,6 +1809,7 @@ struct orc_deck {
     int bxby_solver; double predcorr_tol; int predcorr_max_iter; double predcorr_mix; int field_bc;
     int laser_on; double laser_a0, laser_w0, laser_L0, laser_lambda0, laser_pos[3];
     double laser_zfoc; int laser_solver; int laser_use_phase; int si_units;
+    int grid_current_on; double grid_current_peak, grid_current_mean[3], grid_current_std[3];
 };
 
 void* orc_engine_create (const orc_deck* k) {
@@ -1807,6 +1829,8 @@ void* orc_engine_create (const orc_deck* k) {
     d.laser_on=k->laser_on; d.laser_a0=k->laser_a0; d.laser_w0=k->laser_w0; d.laser_L0=k->laser_L0; d.laser_lambda0=k->laser_lambda0;
     for (int i=0;i<3;++i) d.laser_pos[i]=k->laser_pos[i];
     d.laser_zfoc=k->laser_zfoc; d.laser_solver=k->laser_solver; d.laser_use_phase=k->laser_use_phase; d.si_units=k->si_units;
+    d.grid_current_on=k->grid_current_on; d.grid_current_peak=k->grid_current_peak;
+    for (int i=0;i<3;++i){d.grid_current_mean[i]=k->grid_current_mean[i]; d.grid_current_std[i]=k->grid_current_std[i];}
     return new Engine(d);
 }
 void orc_engine_destroy (void* h) { delete static_cast<Engine*>(h); }

@@ -65,7 +65,9 @@ class Deck(C.Structure):
                 ("predcorr_mix", C.c_double), ("field_bc", C.c_int),
                 ("laser_on", C.c_int), ("laser_a0", C.c_double), ("laser_w0", C.c_double), ("laser_L0", C.c_double),
                 ("laser_lambda0", C.c_double), ("laser_pos", C.c_double * 3),
-                ("laser_zfoc", C.c_double), ("laser_solver", C.c_int), ("laser_use_phase", C.c_int), ("si_units", C.c_int)]
+                ("laser_zfoc", C.c_double), ("laser_solver", C.c_int), ("laser_use_phase", C.c_int), ("si_units", C.c_int),
+                ("grid_current_on", C.c_int), ("grid_current_peak", C.c_double), ("grid_current_mean", C.c_double * 3),
+                ("grid_current_std", C.c_double * 3)]
 
 
 def fill_struct(st, d):

@@ -180,7 +180,8 @@ def test_multigrid_solve1(api, oracle, nx, ny, warm):
                                      ("blowout_wake", "blowout_wake_explicit.2Rank"), ("blowout_wake", "blowout_wake.2Rank"),
                                      ("beam_in_vacuum", "beam_in_vacuum.normalized.Serial"),
                                      ("beam_in_vacuum_1Rank", "beam_in_vacuum.normalized.1Rank"),
-                                     ("beam_in_vacuum_SI_Serial", "beam_in_vacuum.SI.Serial")])
+                                     ("beam_in_vacuum_SI_Serial", "beam_in_vacuum.SI.Serial"),
+                                     ("grid_current", "grid_current.1Rank")])
 def test_engine_reproduces_reference_checksums(api, name, js):
     """North-star parity bar: field checksums within 1e-6 of the reference's CPU goldens."""
     gold = json.load(open(os.path.join(GOLD, js + ".json")))["lev=0"]
@@ -805,6 +806,34 @@ def test_engine_variants_vs_oracle(api, oracle, case):
     greal, gvalid = ge.particles()
     oreal, ovalid = oe.particles()
     assert int(gvalid.sum()) == int(ovalid.sum())              # absorbed / dropped particles: same count
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["explicit", "predictor-corrector"])
+def test_grid_current_drives_a_plasma_wake_vs_oracle(api, oracle, solver):
+    """grid_current.* (utils/GridCurrent.cpp:25-71) on a plasma, no beam: the Gaussian current on the grid is the only
+    driver; it goes into jz_beam (explicit solver) or jz (predictor-corrector).  Every slab component vs the oracle."""
+    deck = decks.blowout_wake()
+    deck.update(nz=24, n_steps=1, lo=(-8.0, -8.0, -1.8), hi=(8.0, 8.0, 1.8), beam_profile=-1,
+                grid_current_on=1, grid_current_peak=-0.5, grid_current_mean=(0.5, -0.25, 2.0), grid_current_std=(0.6, 0.4, 1.0))
+    if solver != "explicit":
+        deck = decks.predictor_corrector(deck, tol=1e-3, max_iter=5, mix=0.05)
+    ge = api.SliceEngine(deck, tile_size=16, sort_period=6)
+    oe = oracle.Engine(deck)
+    ge.begin_step()
+    oe.begin_step()
+    for isl in range(deck["nz"] - 1, -1, -1):
+        ge.solve_slice(isl)
+        oe.solve_slice(isl)
+    gs, os_ = ge.slab(), oe.slab()
+    names = ge.comp_names()
+    assert np.abs(os_[names.index("Bx")]).max() > 1e-3
+    for c in range(ge.ncomp):
+        assert rel_err(gs[c], os_[c]) < 1e-9, (solver, names[c], rel_err(gs[c], os_[c]))
+    if solver == "explicit":
+        assert ge.stats()["vcycles"] == oe.vcycles()
+    else:
+        assert ge.pc_stats()[0] == oe.pc_stats()[0]
 
 
 # ---- laser-driven wake (SURVEY 8f-2, first half: static Gaussian envelope) ------------------------------------------

@@ -36,7 +36,9 @@ CASES = [("linear_wake", "linear_wake.normalized.1Rank"),
          # tests/blowout_wake.2Rank.sh checks its normalised run against this file (same deck as blowout_wake_explicit)
          ("blowout_wake", "blowout_wake.2Rank"),
          # tests/blowout_wake.Serial.sh: an older file the reference itself only holds to --rtol 2e-2 (RTOL below)
-         ("blowout_wake_step0", "blowout_wake.Serial")]
+         ("blowout_wake_step0", "blowout_wake.Serial"),
+         # grid_current.* (utils/GridCurrent.cpp): a Gaussian current on the grid that cancels the beam's
+         ("grid_current", "grid_current.1Rank")]
 RTOL = {"blowout_wake.Serial": 2.0e-2}
 
 
