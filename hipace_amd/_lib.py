@@ -103,6 +103,8 @@ _SIGS = {
                                        C.c_void_p, C.c_void_p]),
     "hps_engine_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "hps_engine_set_insitu_plasma": (C.c_int, [C.c_void_p, C.c_double]),
+    "hps_engine_set_insitu_beam": (C.c_int, [C.c_void_p, C.c_double]),
+    "hps_engine_insitu_beam": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_insitu_plasma": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_set_insitu_fields": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_insitu_fields": (C.c_int, [C.c_void_p, C.c_void_p]),

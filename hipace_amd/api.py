@@ -368,6 +368,19 @@ class SliceEngine:
     INSITU_PLASMA = ["sum(w)", "[x]", "[x^2]", "[y]", "[y^2]", "[ux]", "[ux^2]", "[uy]", "[uy^2]", "[uz]", "[uz^2]", "[ga]",
                      "[ga^2]", "[(ga-1)*(1-vz)]", "Np"]
 
+    INSITU_BEAM = ["sum(w)", "[x]", "[x^2]", "[y]", "[y^2]", "[z]", "[z^2]", "[ux]", "[ux^2]", "[uy]", "[uy^2]", "[uz]", "[uz^2]",
+                   "[x*ux]", "[y*uy]", "[z*uz]", "[x*uy]", "[y*ux]", "[ux/uz]", "[uy/uz]", "[ga]", "[ga^2]", "Np"]
+
+    def set_insitu_beam(self, radius=float("inf")):
+        """<beam>.insitu_period / insitu_radius: per-slice moments of BeamParticleContainer::InSituComputeDiags."""
+        check(_lib.lib().hps_engine_set_insitu_beam(self._h, min(float(radius), 1.0e300)))
+
+    def insitu_beam(self):
+        """-> dict name -> array[nz] (index = islice), names as the reference's in-situ file (BeamParticleContainer.cpp:625-650)."""
+        out = np.empty((23, self.deck["nz"]))
+        check(_lib.lib().hps_engine_insitu_beam(self._h, out.ctypes.data_as(C.c_void_p)))
+        return {n: out[i] for i, n in enumerate(self.INSITU_BEAM)}
+
     def set_insitu_plasma(self, radius=float("inf")):
         """plasma.insitu_period / insitu_radius: per-slice moments of PlasmaParticleContainer::InSituComputeDiags."""
         check(_lib.lib().hps_engine_set_insitu_plasma(self._h, min(float(radius), 1.0e300)))

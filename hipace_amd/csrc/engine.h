@@ -73,6 +73,8 @@ struct Engine {
     // field diagnostic (Fields::Copy): components, coarsening, device array [ncomps][nzc][nyc][nxc]
     std::vector<int> fd_comps; int fd_c[3] = {1, 1, 1}; double* d_fd = nullptr; int* d_fd_comps = nullptr;
     int fill_field_diagnostic (int islice);
+    double* d_insitu_bm = nullptr; double insitu_bm_radius = 0.0;     // [23][nz] raw sums of the beam moments
+    void insitu_beam (int islice);
     double* d_insitu_pl = nullptr; double insitu_pl_radius = 0.0;     // [15][nz] raw sums of the plasma moments
     double* d_insitu = nullptr;      // [10][nz] in-situ field reductions (Fields::InSituComputeDiags)
 

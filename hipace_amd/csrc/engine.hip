@@ -327,7 +327,7 @@ Engine::~Engine ()
     (void)hipFree(d_pc); if (h_pc) (void)hipHostFree(h_pc);
     (void)hipFree(d_laser_sum);
     if (laser) laser_destroy(*this);
-    (void)hipFree(d_fd); (void)hipFree(d_fd_comps); (void)hipFree(d_insitu); (void)hipFree(d_insitu_pl);
+    (void)hipFree(d_fd); (void)hipFree(d_fd_comps); (void)hipFree(d_insitu); (void)hipFree(d_insitu_pl); (void)hipFree(d_insitu_bm);
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto e : hand_ev) if (e) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
@@ -565,6 +565,7 @@ int Engine::begin_step ()
     HPS_HIP_CHECK(hipMemsetAsync(d_laser_sum, 0, sizeof(double), st));
     if (laser) { if (int e = laser_begin_step(*this)) return e; }
     if (d_insitu_pl) HPS_HIP_CHECK(hipMemsetAsync(d_insitu_pl, 0, (size_t)15*d.nz*sizeof(double), st));
+    if (d_insitu_bm) HPS_HIP_CHECK(hipMemsetAsync(d_insitu_bm, 0, (size_t)23*d.nz*sizeof(double), st));
     if (d_insitu) HPS_HIP_CHECK(hipMemsetAsync(d_insitu, 0, (size_t)10*d.nz*sizeof(double), st));
     if (d_fd) HPS_HIP_CHECK(hipMemsetAsync(d_fd, 0, fd_comps.size()*(size_t)(d.nx/fd_c[0])*(d.ny/fd_c[1])*(d.nz/fd_c[2])*sizeof(double), st));
     if (np > 0) {
@@ -713,6 +714,66 @@ void k_insitu_plasma (hps_plasma pl, double clight_inv, double radius_sq, double
     if (threadIdx.x < 15)
         atomic_add_f64(out + (long)threadIdx.x*nz + islice,
                        part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// BeamParticleContainer::InSituComputeDiags (particles/beam/BeamParticleContainer.cpp:476-556): raw sums over the
+// particles of the slice (slipped-in ones excluded, :494).  Static beam: count_static particles behind b; moving beam:
+// the block [B[p] + nfront[p], B[p+1]) of the SoA, nsub < 0 = absorbed.
+__global__ __launch_bounds__(256)
+void k_insitu_beam (BeamView b, const int* __restrict__ nsub, const long* __restrict__ B, const int* __restrict__ nfront, int p,
+                    long count_static, double clight_inv, double radius_sq, double* out, int nz, int islice)
+{
+    long first = 0, count = count_static;
+    if (B) { first = B[p] + nfront[p]; count = B[p + 1] - first; }
+    double s[23];
+#pragma unroll
+    for (int q = 0; q < 23; ++q) s[q] = 0.0;
+    for (long t = (long)blockIdx.x*blockDim.x + threadIdx.x; t < count; t += (long)gridDim.x*blockDim.x) {
+        const long ip = first + t;
+        const double x = b.x[ip], y = b.y[ip], z = b.z[ip];
+        if ((nsub && nsub[ip] < 0) || x*x + y*y > radius_sq) continue;
+        const double ux = b.ux[ip]*clight_inv, uy = b.uy[ip]*clight_inv, uz = b.uz[ip]*clight_inv, w = b.w[ip];
+        const double uz_inv = uz == 0.0 ? 0.0 : 1.0/uz;
+        const double gamma = sqrt(1.0 + ux*ux + uy*uy + uz*uz);
+        s[0] += w; s[1] += w*x; s[2] += w*x*x; s[3] += w*y; s[4] += w*y*y; s[5] += w*z; s[6] += w*z*z; s[7] += w*ux; s[8] += w*ux*ux;
+        s[9] += w*uy; s[10] += w*uy*uy; s[11] += w*uz; s[12] += w*uz*uz; s[13] += w*x*ux; s[14] += w*y*uy; s[15] += w*z*uz;
+        s[16] += w*x*uy; s[17] += w*y*ux; s[18] += w*ux*uz_inv; s[19] += w*uy*uz_inv; s[20] += w*gamma; s[21] += w*gamma*gamma;
+        s[22] += 1.0;
+    }
+    __shared__ double part[4][23];
+#pragma unroll
+    for (int q = 0; q < 23; ++q) {
+        double v = s[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 23) {
+        const double v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (v != 0.0) atomic_add_f64(out + (long)threadIdx.x*nz + islice, v);
+    }
+}
+
+// m_multi_beam.InSituComputeDiags (Hipace.cpp:681): after the field solves, before the beam push
+void Engine::insitu_beam (int islice)
+{
+    if (!d_insitu_bm || nbeam == 0) return;
+    const double r2 = insitu_bm_radius*insitu_bm_radius;
+    if (moving) {
+        const int p = d.nz - 1 - islice;
+        const long bound = beam_bound(p);
+        if (bound <= 0) return;
+        const BeamView b{bm.x, bm.y, bm.z, bm.ux, bm.uy, bm.uz, bm.w};
+        hipLaunchKernelGGL(k_insitu_beam, dim3((unsigned)std::min<long>(ceil_div(bound, 256), 64)), dim3(256), 0, st, b, bm.nsub, d_B, d_nfront, p,
+                           0L, 1.0/gm.c, r2, d_insitu_bm, d.nz, islice);
+    } else {
+        const long first0 = beam_off[d.nz - 1 - islice], count = beam_off[d.nz - islice] - first0;
+        if (count <= 0) return;
+        double* blk = beam_cur + 7*first0;
+        const BeamView b{blk, blk + count, blk + 2*count, blk + 3*count, blk + 4*count, blk + 5*count, blk + 6*count};
+        hipLaunchKernelGGL(k_insitu_beam, dim3((unsigned)std::min<long>(ceil_div(count, 256), 64)), dim3(256), 0, st, b, (const int*)nullptr,
+                           (const long*)nullptr, (const int*)nullptr, 0, count, 1.0/gm.c, r2, d_insitu_bm, d.nz, islice);
+    }
 }
 
 int Engine::fill_field_diagnostic (int islice)
@@ -930,6 +991,7 @@ int Engine::solve_slice_pc (int islice)
     mark();   // b7
     if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st))) return e; }
     else        { if ((e = hps_advance_plasma(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; }
+    insitu_beam(islice);
     if (moving && nbeam > 0) { if ((e = beam_push_moving(*this, islice))) return e; }
     mark();   // b8
     // ShiftSlices (fields/Fields.cpp:600-603): PCPrevIter <- Previous <- This for Bx By, Previous <- This for jx jy
@@ -1054,6 +1116,7 @@ int Engine::solve_slice (int islice)
         else        { if ((e = hps_advance_plasma_laser(slab, pl, gm, comp, c_aabs, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; } }
 
     // beam push and hand-off of the slipped particles (Hipace.cpp:704-706)
+    insitu_beam(islice);
     if (moving && nbeam > 0) { if ((e = beam_push_moving(*this, islice))) return e; }
     mark();   // b8
     // ShiftSlices (fields/Fields.cpp:588-604)
@@ -1125,6 +1188,30 @@ extern "C" int hps_engine_set_insitu_plasma (void* h, double radius)
     if (!(radius > 0.0)) return HPS_OK;
     HPS_HIP_CHECK(hipMalloc(&E->d_insitu_pl, (size_t)15*E->d.nz*sizeof(double)));
     HPS_HIP_CHECK(hipMemset(E->d_insitu_pl, 0, (size_t)15*E->d.nz*sizeof(double)));
+    return HPS_OK;
+}
+extern "C" int hps_engine_set_insitu_beam (void* h, double radius)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    (void)hipFree(E->d_insitu_bm); E->d_insitu_bm = nullptr; E->insitu_bm_radius = radius;
+    if (!(radius > 0.0)) return HPS_OK;
+    HPS_HIP_CHECK(hipMalloc(&E->d_insitu_bm, (size_t)23*E->d.nz*sizeof(double)));
+    HPS_HIP_CHECK(hipMemset(E->d_insitu_bm, 0, (size_t)23*E->d.nz*sizeof(double)));
+    return HPS_OK;
+}
+extern "C" int hps_engine_insitu_beam (void* h, double* out)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E->d_insitu_bm && out, "hps_engine_insitu_beam: not switched on");
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    const int nz = E->d.nz;
+    HPS_HIP_CHECK(hipMemcpy(out, E->d_insitu_bm, (size_t)23*nz*sizeof(double), hipMemcpyDeviceToHost));
+    // averages: everything but sum(w) and the count is divided by sum(w) (BeamParticleContainer.cpp:542-548)
+    for (int k = 0; k < nz; ++k) {
+        const double sw = out[k], inv = sw <= 0.0 ? 0.0 : 1.0/sw;
+        for (int q = 1; q <= 21; ++q) out[(size_t)q*nz + k] *= inv;
+    }
     return HPS_OK;
 }
 extern "C" int hps_engine_insitu_plasma (void* h, double* out)

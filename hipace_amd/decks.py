@@ -211,6 +211,13 @@ def beam_in_vacuum_SI_Serial():
     return d
 
 
+def reset():
+    """tests/reset.2Rank.sh: the blowout deck for three time steps (max_step = 2, dt = 0) with MG_tolerance_rel = 1e-5"""
+    d = blowout_wake()
+    d.update(n_steps=3, mg_tol_rel=1.0e-5)
+    return d
+
+
 def blowout_wake_step0():
     """tests/blowout_wake.Serial.sh: examples/blowout_wake/inputs_normalized as it stands (max_step = 0: one time step)."""
     d = blowout_wake()
@@ -226,5 +233,5 @@ def predictor_corrector(base, tol=1.0e-4, max_iter=7, mix=0.0635):
     return d
 
 
-NAMED = dict(grid_current=grid_current, beam_in_vacuum_SI_Serial=beam_in_vacuum_SI_Serial, blowout_wake_step0=blowout_wake_step0, linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, laser_blowout_wake_SI=laser_blowout_wake_SI, linear_wake_SI=linear_wake_SI, blowout_wake_SI=blowout_wake_SI, beam_in_vacuum_SI=beam_in_vacuum_SI, beam_in_vacuum_1Rank=beam_in_vacuum_1Rank, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
+NAMED = dict(reset=reset, grid_current=grid_current, beam_in_vacuum_SI_Serial=beam_in_vacuum_SI_Serial, blowout_wake_step0=blowout_wake_step0, linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, laser_blowout_wake_SI=laser_blowout_wake_SI, linear_wake_SI=linear_wake_SI, blowout_wake_SI=blowout_wake_SI, beam_in_vacuum_SI=beam_in_vacuum_SI, beam_in_vacuum_1Rank=beam_in_vacuum_1Rank, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
              beam_evolution=beam_evolution, beam_in_vacuum_open_boundary=beam_in_vacuum_open_boundary)

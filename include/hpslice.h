@@ -267,6 +267,14 @@ int hps_engine_insitu_fields (void* handle, double* out_host /* [10*nz] */);
  * [ga^2] (averages: divided by sum(w)), [(ga-1)(1-vz)] (sum), Np (count, as a double), with w = weight * gamma/psi.
  * radius <= 0 switches it off; cleared by hps_engine_begin_step; reading synchronises the stream. */
 int hps_engine_set_insitu_plasma (void* handle, double radius);
+/* In-situ beam moments (BeamParticleContainer::InSituComputeDiags, particles/beam/BeamParticleContainer.cpp:476-556),
+ * taken after the field solves and before the beam push (Hipace.cpp:681) over the slice's own valid particles (those
+ * that slipped in from the slice ahead are not counted, :494) within `radius` of the axis: out_host[q*nz + islice],
+ * q = 0..22 = sum(w), [x], [x^2], [y], [y^2], [z], [z^2], [ux], [ux^2], [uy], [uy^2], [uz], [uz^2], [x*ux], [y*uy],
+ * [z*uz], [x*uy], [y*ux], [ux/uz], [uy/uz], [ga], [ga^2] (averages: divided by sum(w)), Np (count, as a double), with
+ * u = proper velocity / c.  radius <= 0 switches it off; cleared by hps_engine_begin_step; reading synchronises. */
+int hps_engine_set_insitu_beam (void* handle, double radius);
+int hps_engine_insitu_beam (void* handle, double* out_host /* [23*nz] */);
 int hps_engine_insitu_plasma (void* handle, double* out_host /* [15*nz] */);
 
 /* particle tiling of the engine: tile_size 0 = per-particle global-atomic kernels, 16 | 32 = LDS

@@ -1474,6 +1474,7 @@ struct Engine {
         double t8 = now(); t_other += t8 - t7;
         { const int comp[5] = {pPsi, pEz, pBx, pBy, pBz};
           advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0); }
+        insitu_beam_slice(islice);
         if (moving) {
             const Beam& b = store[islice];
             for (long k = 0; k < b.nreg; ++k) {
@@ -1545,6 +1546,7 @@ struct Engine {
         double t8 = now(); t_other += t8 - t7;
         { const int comp[5] = {Psi, Ez, Bx, By, Bz};
           advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, c_aabs); }
+        insitu_beam_slice(islice);
         if (moving) {
             // beam diagnostics before the push (Hipace.cpp:685-686), then push and hand the slipped particles
             // to the next slice (:704-706)
@@ -1578,6 +1580,30 @@ struct Engine {
 
     // AdvanceBeamParticlesSlice (particles/pusher/BeamParticleAdvance.cpp:20-336) without radiation reaction,
     // spin and mesh refinement; external field E = (s0 x, s1 y, 0) (ExternalFields.H:29-56)
+    // BeamParticleContainer::InSituComputeDiags (particles/beam/BeamParticleContainer.cpp:476-556): the 23 per-slice
+    // entries of the particles of this slice (slipped ones excluded, :494), before the beam push (Hipace.cpp:681)
+    std::vector<double> insitu_bm; double insitu_bm_radius = 0.0;
+    void insitu_beam_slice (int islice) {
+        if (!(insitu_bm_radius > 0.0)) return;
+        const bool moving = (d.dt != 0.0);
+        const Beam& b = moving ? store[islice] : beam_this;
+        const long n = moving ? b.nreg : (long)b.x.size();
+        const double clight_inv = 1.0/gm.c, radius_sq = insitu_bm_radius*insitu_bm_radius;
+        double s[23]; for (double& v : s) v = 0.0;
+        for (long ip = 0; ip < n; ++ip) {
+            const double x = b.x[ip], y = b.y[ip], z = b.z[ip];
+            const double ux = b.ux[ip]*clight_inv, uy = b.uy[ip]*clight_inv, uz = b.uz[ip]*clight_inv, w = b.w[ip];
+            const double uz_inv = uz == 0.0 ? 0.0 : 1.0/uz;
+            if ((!b.valid.empty() && !b.valid[ip]) || x*x + y*y > radius_sq) continue;
+            const double gamma = std::sqrt(1.0 + ux*ux + uy*uy + uz*uz);
+            const double t[23] = {w, w*x, w*x*x, w*y, w*y*y, w*z, w*z*z, w*ux, w*ux*ux, w*uy, w*uy*uy, w*uz, w*uz*uz, w*x*ux, w*y*uy,
+                                  w*z*uz, w*x*uy, w*y*ux, w*ux*uz_inv, w*uy*uz_inv, w*gamma, w*gamma*gamma, 1.0};
+            for (int q = 0; q < 23; ++q) s[q] += t[q];
+        }
+        const double sum_w_inv = s[0] <= 0.0 ? 0.0 : 1.0/s[0];
+        for (int q = 0; q < 23; ++q) insitu_bm[(size_t)q*d.nz + islice] = s[q]*((q == 0 || q == 22) ? 1.0 : sum_w_inv);
+    }
+
     void advance_beam_slice (int islice) {
         Beam& b = store[islice];
         const int nsc = d.beam_n_subcycles;
@@ -1927,5 +1953,9 @@ void orc_engine_beam_slice (void* h, int islice, double* out7n) {       // [7][c
     const std::vector<double>* a[7] = {&b.x, &b.y, &b.z, &b.ux, &b.uy, &b.uz, &b.w};
     for (int k = 0; k < 7; ++k) for (size_t i = 0; i < n; ++i) out7n[k*n + i] = (*a[k])[i];
 }
+void orc_engine_set_insitu_beam (void* h, double radius) {
+    Engine* e = static_cast<Engine*>(h); e->insitu_bm_radius = radius; e->insitu_bm.assign((size_t)23*e->d.nz, 0.0); }
+void orc_engine_insitu_beam (void* h, double* out /* [23][nz] */) {
+    Engine* e = static_cast<Engine*>(h); std::copy(e->insitu_bm.begin(), e->insitu_bm.end(), out); }
 
 } // extern "C"

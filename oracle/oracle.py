@@ -476,6 +476,21 @@ class Engine:
             L.orc_engine_beam_slice(self._h, islice, _ptr(out))
         return out
 
+    def set_insitu_beam(self, radius=np.inf):
+        L = lib()
+        L.orc_engine_set_insitu_beam.restype = None
+        L.orc_engine_set_insitu_beam.argtypes = [C.c_void_p, C.c_double]
+        L.orc_engine_set_insitu_beam(self._h, min(float(radius), 1.0e300))
+
+    def insitu_beam(self):
+        """BeamParticleContainer::InSituComputeDiags: (23, nz) array, index = islice, of the step solved last."""
+        L = lib()
+        L.orc_engine_insitu_beam.restype = None
+        L.orc_engine_insitu_beam.argtypes = [C.c_void_p, C.c_void_p]
+        out = np.zeros((23, self.deck["nz"]))
+        L.orc_engine_insitu_beam(self._h, _ptr(out))
+        return out
+
     def set_beam_storage(self, tensor, injected_beam_support=False):
         """tensor: CPU float64 torch tensor or numpy array of 7*nbeam doubles (kept alive by the caller)."""
         self._beam_keep = tensor

@@ -181,7 +181,7 @@ def test_multigrid_solve1(api, oracle, nx, ny, warm):
                                      ("beam_in_vacuum", "beam_in_vacuum.normalized.Serial"),
                                      ("beam_in_vacuum_1Rank", "beam_in_vacuum.normalized.1Rank"),
                                      ("beam_in_vacuum_SI_Serial", "beam_in_vacuum.SI.Serial"),
-                                     ("grid_current", "grid_current.1Rank")])
+                                     ("grid_current", "grid_current.1Rank"), ("reset", "reset.2Rank")])
 def test_engine_reproduces_reference_checksums(api, name, js):
     """North-star parity bar: field checksums within 1e-6 of the reference's CPU goldens."""
     gold = json.load(open(os.path.join(GOLD, js + ".json")))["lev=0"]
@@ -741,6 +741,44 @@ def test_insitu_plasma_moments_match_oracle(api, oracle):
         # first moments of a symmetric sheet are pure cancellation: compare against the second moments' scale
         ref = max(scale, np.sqrt(np.abs(want[min(q + 1, 13)]).max()) if name in ("[x]", "[y]", "[ux]", "[uy]") else scale)
         assert np.abs(got[name] - want[q]).max() <= 1e-9 * ref, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["static", "moving"])
+def test_insitu_beam_moments_match_oracle(api, oracle, case):
+    """BeamParticleContainer::InSituComputeDiags: the 23 per-slice entries (after the field solves, before the beam
+    push; particles that slipped in from the slice ahead are not counted) against the oracle.  static: the blowout deck
+    (dt = 0, within a radius of 0.5); moving: four steps of the beam_evolution deck with a time step large enough for
+    particles to slip."""
+    if case == "static":
+        deck = decks.blowout_wake()
+        deck.update(nz=40, n_steps=1)
+        radius = 0.5
+    else:
+        deck = decks.beam_evolution()
+        deck.update(n_steps=4, dt=30.0, beam_umean=(0.0, 0.0, 20.0))
+        radius = float("inf")
+    ge = api.SliceEngine(deck, tile_size=16, sort_period=8)
+    oe = oracle.Engine(deck)
+    ge.set_insitu_beam(radius)
+    oe.set_insitu_beam(radius)
+    for _ in range(deck["n_steps"]):
+        ge.run_step()
+        oe.begin_step()
+        for isl in range(deck["nz"] - 1, -1, -1):
+            oe.solve_slice(isl)
+    got, want = ge.insitu_beam(), oe.insitu_beam()
+    assert want[22].sum() > 0 and np.array_equal(got["Np"], want[22])           # particle counts: exact
+    if case == "moving":
+        assert want[22].sum() < oe.beam_layout()[0]                                # some have slipped or left
+    for q, name in enumerate(api.SliceEngine.INSITU_BEAM[:22]):
+        scale = max(np.abs(want[q]).max(), 1e-300)
+        # first moments of a symmetric beam are pure cancellation: compare against the second moments' scale
+        if name in ("[x]", "[y]", "[ux]", "[uy]"):
+            scale = max(scale, np.sqrt(np.abs(want[q + 1]).max()))
+        elif name in ("[x*ux]", "[y*uy]", "[x*uy]", "[y*ux]", "[ux/uz]", "[uy/uz]"):
+            scale = max(scale, np.sqrt(np.abs(want[2]).max() * np.abs(want[8]).max()), 1e-12)
+        assert np.abs(got[name] - want[q]).max() <= 1e-9 * scale, (name, np.abs(got[name] - want[q]).max(), scale)
 
 
 @pytest.mark.gpu

@@ -10,6 +10,7 @@ them at rtol 1e-12 on CPU (tests/linear_wake.normalized.1Rank.sh:29).  We demand
 import json
 import os
 
+import numpy as np
 import pytest
 
 from hipace_amd import decks
@@ -38,7 +39,8 @@ CASES = [("linear_wake", "linear_wake.normalized.1Rank"),
          # tests/blowout_wake.Serial.sh: an older file the reference itself only holds to --rtol 2e-2 (RTOL below)
          ("blowout_wake_step0", "blowout_wake.Serial"),
          # grid_current.* (utils/GridCurrent.cpp): a Gaussian current on the grid that cancels the beam's
-         ("grid_current", "grid_current.1Rank")]
+         ("grid_current", "grid_current.1Rank"),
+         ("reset", "reset.2Rank")]       # three time steps of the blowout deck, multigrid tolerance 1e-5
 RTOL = {"blowout_wake.Serial": 2.0e-2}
 
 
@@ -173,3 +175,32 @@ def test_SI_and_normalised_units_give_the_same_wake(oracle):
     cn, cs = en.checksums(), es.checksums()
     for k, u in unit.items():
         assert abs(cs[k] / u - cn[k]) <= 2e-9 * abs(cn[k]), (k, cs[k] / u, cn[k])
+
+
+def test_oracle_beam_insitu_moments_against_numpy(oracle):
+    """BeamParticleContainer::InSituComputeDiags (particles/beam/BeamParticleContainer.cpp:476-556) of the first step of
+    the beam_evolution deck: the oracle's 23 entries per slice against a numpy evaluation on the slice's particles as
+    they sit there before the step (nothing has slipped yet)."""
+    deck = decks.beam_evolution()
+    deck["n_steps"] = 1
+    oe = oracle.Engine(deck)
+    oe.set_insitu_beam(0.8)
+    oe.begin_step()
+    want = np.zeros((23, deck["nz"]))
+    for isl in range(deck["nz"] - 1, -1, -1):
+        x, y, z, ux, uy, uz, w = oe.beam_slice(isl)
+        keep = x * x + y * y <= 0.8 ** 2
+        x, y, z, ux, uy, uz, w = (a[keep] for a in (x, y, z, ux, uy, uz, w))
+        ga = np.sqrt(1.0 + ux * ux + uy * uy + uz * uz)
+        raw = np.array([t.sum() for t in (w, w * x, w * x * x, w * y, w * y * y, w * z, w * z * z, w * ux, w * ux * ux, w * uy,
+                                          w * uy * uy, w * uz, w * uz * uz, w * x * ux, w * y * uy, w * z * uz, w * x * uy,
+                                          w * y * ux, w * ux / uz, w * uy / uz, w * ga, w * ga * ga, np.ones_like(w))])
+        if raw[0] > 0:
+            raw[1:22] /= raw[0]
+        want[:, isl] = raw
+        oe.solve_slice(isl)
+    got = oe.insitu_beam()
+    assert want[22].sum() > 0 and np.array_equal(got[22], want[22])
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    for q in range(22):
+        assert np.abs(got[q] - want[q]).max() <= 1e-12 * max(np.abs(want[q]).max(), 1e-3), q
