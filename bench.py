@@ -88,6 +88,8 @@ def main():
                     help="time steps in flight on one GPU (hipace_amd/pipeline.py::run_local_pipeline): L engines on L "
                          "streams, step s+1 trails step s by the per-slice beam hand-off.  Needs --steps >= L boxes.  "
                          "Default 1; with --gpus N > 1 every rank runs L stages of the ring (gloo-tested, not yet on RCCL)")
+    ap.add_argument("--laser-solver", choices=["fft", "multigrid"], default="fft",
+                    help="--config5: lasers.solver_type (multigrid = hpmg system type 2, the reference's default)")
     ap.add_argument("--config5", action="store_true",
                     help="BASELINE config 5 without its ionisation (not built): laser_blowout_wake 1024x1024x2048, 4 ppc, a "
                          "Gaussian laser pulse drives the wake and is advanced by the FFT envelope solver on every slice; "
@@ -122,7 +124,7 @@ def main():
         nz = 2048
         deck = decks.synthetic(args.n, nz, args.ppc)
         deck.update(beam_profile=-1, lo=(-20.0, -20.0, -15.0), hi=(20.0, 20.0, 6.0), laser_on=1, laser_a0=4.5, laser_w0=4.0,
-                    laser_L0=2.0, laser_lambda0=0.08, laser_solver=1, dt=5.0)
+                    laser_L0=2.0, laser_lambda0=0.08, laser_solver=2 if args.laser_solver == "multigrid" else 1, dt=5.0)
         args.cpu_slices = 0
         args.inflight = 1
     eng = api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period)
@@ -198,7 +200,7 @@ def main():
         achieved = ab[dom] / (per_kernel[dom] * 1e-3) / 1e9 if per_kernel[dom] > 0 else 0.0
         out = {
             "metric": "transverse slices/s at 256^2 x 4ppc (predictor-corrector solver)" if args.config2 else
-                      "transverse slices/s at 1024^2 x 4ppc with a laser envelope (explicit solver, FFT envelope solver)" if args.config5 else
+                      f"transverse slices/s at 1024^2 x 4ppc with a laser envelope (explicit solver, {args.laser_solver} envelope solver)" if args.config5 else
                       "transverse slices/s at 1024^2 x 4ppc (explicit solver)",
             "value": total / dt, "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -206,7 +208,7 @@ def main():
             "particle_pushes_per_s": total / dt * args.ppc * args.ppc * args.n * args.n,
             "config": {"workload": ("linear_wake.normalized 256x256x512, 4 ppc, order 2, predictor-corrector Bx/By solver "
                                     "(tolerance 4e-2, <= 30 iterations, mixing 0.05), dt=0 (BASELINE.json configs[1])") if args.config2 else
-                                   (f"laser_blowout_wake {args.n}x{args.n}x{nz}, 4 ppc, order 2, Gaussian laser a0=4.5 + FFT envelope "
+                                   (f"laser_blowout_wake {args.n}x{args.n}x{nz}, 4 ppc, order 2, Gaussian laser a0=4.5 + {args.laser_solver} envelope "
                                     "solver every slice, no ionisation (BASELINE.json configs[4] without its ionisation)") if args.config5 else
                                    (f"blowout_wake synthetic {args.n}x{args.n}x{nz}, {args.ppc * args.ppc} ppc, "
                                     "order 2, explicit Bx/By solver, dt=0 (BASELINE.md section 3)"),

@@ -47,7 +47,7 @@ class Deck(C.Structure):
                 ("laser_lambda0", C.c_double), ("laser_pos", C.c_double * 3),
                 ("laser_zfoc", C.c_double), ("laser_solver", C.c_int), ("laser_use_phase", C.c_int), ("si_units", C.c_int),
                 ("grid_current_on", C.c_int), ("grid_current_peak", C.c_double), ("grid_current_mean", C.c_double * 3),
-                ("grid_current_std", C.c_double * 3)]
+                ("grid_current_std", C.c_double * 3), ("laser_mg_tol_rel", C.c_double), ("laser_mg_tol_abs", C.c_double)]
 
 
 # engine component names, index = value of the HPS_C_* enum in include/hpslice.h
@@ -88,6 +88,11 @@ _SIGS = {
     "hps_mg_solve1": (C.c_int, [C.c_void_p, Slab, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
                                 C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p]),
     "hps_mg_destroy": (C.c_int, [C.c_void_p]),
+    "hps_mg2_create": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
+    "hps_mg2_solve2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
+                                 C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p]),
+    "hps_mg2_destroy": (C.c_int, [C.c_void_p]),
+    "hps_engine_laser_vcycles": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
     "hps_engine_create": (C.c_int, [C.POINTER(Deck), C.c_int, C.POINTER(C.c_void_p)]),
     "hps_engine_destroy": (C.c_int, [C.c_void_p]),
     "hps_engine_begin_step": (C.c_int, [C.c_void_p]),

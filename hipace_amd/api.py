@@ -223,6 +223,29 @@ class FFTPoissonSolver:
             self._h = None
 
 
+class MultiGrid2:
+    """hpmg::MultiGrid system type 2 (complex coefficient: the laser envelope solve), solve2 with an array Re and a scalar
+    Im coefficient.  sol2 / rhs2: CUDA float64 tensors (2, ny, nx); acoef_real (ny, nx); acoef_imag a 1-element tensor."""
+
+    def __init__(self, nx, ny, dx, dy):
+        self._h = C.c_void_p()
+        check(_lib.lib().hps_mg2_create(nx, ny, dx, dy, C.byref(self._h)))
+
+    def solve2(self, sol2, rhs2, acoef_real, acoef_imag, tol_rel=1e-4, tol_abs=0.0, nummaxiter=200):
+        it = C.c_int()
+        rn = C.c_double()
+        for t in (sol2, rhs2, acoef_real, acoef_imag):
+            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float64
+        check(_lib.lib().hps_mg2_solve2(self._h, sol2.data_ptr(), rhs2.data_ptr(), acoef_real.data_ptr(), acoef_imag.data_ptr(),
+                                        tol_rel, tol_abs, nummaxiter, C.byref(it), C.byref(rn), _stream()))
+        return it.value, rn.value
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.lib().hps_mg2_destroy(self._h)
+            self._h = None
+
+
 class MultiGrid:
     """hpmg::MultiGrid system type 1."""
 
@@ -370,6 +393,11 @@ class SliceEngine:
 
     INSITU_BEAM = ["sum(w)", "[x]", "[x^2]", "[y]", "[y^2]", "[z]", "[z^2]", "[ux]", "[ux^2]", "[uy]", "[uy^2]", "[uz]", "[uz^2]",
                    "[x*ux]", "[y*uy]", "[z*uz]", "[x*uy]", "[y*ux]", "[ux/uz]", "[uy/uz]", "[ga]", "[ga^2]", "Np"]
+
+    def laser_vcycles(self):
+        n = C.c_long()
+        check(_lib.lib().hps_engine_laser_vcycles(self._h, C.byref(n)))
+        return n.value
 
     def set_insitu_beam(self, radius=float("inf")):
         """<beam>.insitu_period / insitu_radius: per-slice moments of BeamParticleContainer::InSituComputeDiags."""

@@ -94,6 +94,7 @@ int laser_begin_step (Engine& E);
 int laser_update_aabs (Engine& E, int islice, double* sum_abs);
 int laser_advance_slice (Engine& E, int islice);
 int laser_copy_envelope (Engine& E, double* out_host);
+long laser_mg_vcycles (Engine& E);
 int laser_set_import (Engine& E, int on, int step);
 int laser_export_slice (Engine& E, int islice, double* msg_dev);
 int laser_import_slice (Engine& E, int islice, const double* msg_dev);

@@ -452,7 +452,7 @@ int Engine::create (const hps_deck& deck, int device)
     if (d.laser_on) {
         if (pc) { set_error("hps_engine_create: the laser needs the explicit solver"); return HPS_ERR_UNSUPPORTED; }
         HPS_REQUIRE(d.laser_w0 > 0.0 && d.laser_L0 > 0.0 && d.laser_lambda0 > 0.0, "hps_engine_create: laser w0, L0, lambda0 must be positive");
-        if (d.laser_solver != 0 && d.laser_solver != 1) { set_error("hps_engine_create: lasers.solver_type fft (1) only; the multigrid envelope solver is not built"); return HPS_ERR_UNSUPPORTED; }
+        if (d.laser_solver < 0 || d.laser_solver > 2) { set_error("hps_engine_create: lasers.solver_type must be 0 (static), 1 (fft) or 2 (multigrid)"); return HPS_ERR_UNSUPPORTED; }
         c_aabs = ncomp++;                // appended last
     }
     gm.dx = (d.hi[0] - d.lo[0])/d.nx; gm.dy = (d.hi[1] - d.lo[1])/d.ny; gm.dz = (d.hi[2] - d.lo[2])/d.nz;
@@ -1074,7 +1074,7 @@ int Engine::solve_slice (int islice)
         const int comps[3] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BZ};
         if ((e = hps_poisson_solve_batch(ps, 3, staging, slab, comps, st))) return e; }
     // m_multi_laser.AdvanceSlice (Hipace.cpp:637): a_{n+1} of this slice from chi and the neighbouring slices
-    if (c_aabs >= 0 && d.laser_solver == 1 && d.dt != 0.0) { if ((e = laser_advance_slice(*this, islice))) return e; }
+    if (c_aabs >= 0 && d.laser_solver >= 1 && d.dt != 0.0) { if ((e = laser_advance_slice(*this, islice))) return e; }
     if (pair) {
         // -grad Psi and the beam part of Sx, Sy (Hipace.cpp:659-660) in one pass
         hipLaunchKernelGGL(k_gradpsi_sxsy, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_PSI, HPS_C_EXMBY, HPS_C_EYPBX,
@@ -1341,6 +1341,13 @@ extern "C" int hps_engine_laser_info (void* h, int* aabs_comp, double* sum_host)
         HPS_HIP_CHECK(hipStreamSynchronize(E->st));
         HPS_HIP_CHECK(hipMemcpy(sum_host, E->d_laser_sum, sizeof(double), hipMemcpyDeviceToHost));
     }
+    return HPS_OK;
+}
+extern "C" int hps_engine_laser_vcycles (void* h, long* vcycles)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(vcycles, "hps_engine_laser_vcycles: null argument");
+    *vcycles = E->laser ? laser_mg_vcycles(*E) : 0;
     return HPS_OK;
 }
 extern "C" int hps_engine_pc_stats (void* h, long* its, double* err_sum)

@@ -19,12 +19,20 @@ namespace hps {
 
 struct LaserPhase { double2 exp1, exp2; double djn, pad; };
 
+int mg2_create_internal (int nx, int ny, double dx, double dy, void** h);       // multigrid2.hip
+int mg2_solve_internal (void* h, double* sol, const double* rhs, const double* ar, const double* ai, double tol_rel, double tol_abs,
+                        int maxiter, int* iters, hipStream_t st);
+void mg2_destroy_internal (void* h);
+
 struct LaserState {
     int nx = 0, ny = 0, nz = 0;
     double2 *nm1 = nullptr, *n00 = nullptr, *np1 = nullptr;      // [nz][ny][nx]
     double2* work = nullptr;                                       // [ny][nx] right-hand side / solution
     LaserPhase* phase = nullptr;
     rocfft_plan fwd = nullptr, bwd = nullptr; rocfft_execution_info info = nullptr; void* fft_work = nullptr;
+    // lasers.solver_type = multigrid (multigrid2.hip): planar [2][ny][nx] solution (kept from slice to slice: the next
+    // solve's initial guess, as np1j00 in the reference) and right-hand side, Re of the coefficient, its Im (one double)
+    void* mg = nullptr; double *mg_sol = nullptr, *mg_rhs = nullptr, *mg_acf_real = nullptr, *mg_acf_imag = nullptr; long mg_vcycles = 0;
     int steps = 0; bool initialised = false;
     bool import_mode = false;        // ring pipeline: a_n, a_{n-1} of the coming step arrive through laser_import_slice
     ~LaserState () {
@@ -32,6 +40,8 @@ struct LaserState {
         if (bwd) rocfft_plan_destroy(bwd);
         if (info) rocfft_execution_info_destroy(info);
         (void)hipFree(nm1); (void)hipFree(n00); (void)hipFree(np1); (void)hipFree(work); (void)hipFree(phase); (void)hipFree(fft_work);
+        if (mg) mg2_destroy_internal(mg);
+        (void)hipFree(mg_sol); (void)hipFree(mg_rhs); (void)hipFree(mg_acf_real); (void)hipFree(mg_acf_imag);
     }
 };
 
@@ -125,7 +135,8 @@ struct LaserSlices { const double2 *n00j00, *n00jp1, *n00jp2, *nm1j00, *nm1jp1, 
 // right-hand side of the envelope equation (:700-749)
 __global__ __launch_bounds__(256)
 void k_laser_rhs (LaserSlices S, SlabView f, int c_chi, double chi0, int gshrink, const LaserPhase* ph, int step,
-                  double dx, double dy, double dz, double c, double dt, double k0, double2* rhs)
+                  double dx, double dy, double dz, double c, double dt, double k0, double2* rhs,
+                  double* mg_rhs, double* mg_acf_real, double* mg_acf_imag)
 {
     const int i = blockIdx.x*blockDim.x + threadIdx.x;
     const int j = blockIdx.y;
@@ -146,12 +157,15 @@ void k_laser_rhs (LaserSlices S, SlabView f, int c_chi, double chi0, int gshrink
     const double chi = inside ? f.p[c_chi*f.ns + f.off(i, j)] : chi0;
     const double2 an00j00 = ld(S.n00j00), anp1jp1 = ld(S.np1jp1), anp1jp2 = ld(S.np1jp2);
     const double cdz = 1.0/(c*dt*dz), cdt = 1.0/(c*dt);
+    // chi term: 2 chi a_n on the right-hand side (fft, :713-740); multigrid with MG_average_rhs = 1: chi a_n (first step)
+    // or chi a_{n-1}, the other half in the operator (:575-598)
+    const bool mgs = (mg_rhs != nullptr);
     double2 r;
     if (step == 0) {
         const double2 an00jp1 = ld(S.n00jp1), an00jp2 = ld(S.n00jp2);
         r = cscale(8.0*cdz, cmul(csub(an00jp1, anp1jp1), exp1));
         r = cadd(r, cscale(2.0*cdz, cmul(csub(anp1jp2, an00jp2), exp2)));
-        r = cadd(r, cscale(2.0*chi, an00j00));
+        r = cadd(r, cscale((mgs ? 1.0 : 2.0)*chi, an00j00));
         r = csub(r, lap);
         r = cadd(r, cmul(make_double2(-6.0*cdz, 4.0*djn*cdt + 4.0*k0*cdt), an00j00));
     } else {
@@ -159,11 +173,23 @@ void k_laser_rhs (LaserSlices S, SlabView f, int c_chi, double chi0, int gshrink
         r = cscale(4.0*cdz, cmul(csub(anm1jp1, anp1jp1), exp1));
         r = cadd(r, cscale(1.0*cdz, cmul(csub(anp1jp2, anm1jp2), exp2)));
         r = csub(r, cscale(4.0*cdt*cdt, an00j00));
-        r = cadd(r, cscale(2.0*chi, an00j00));
+        r = cadd(r, mgs ? cscale(chi, anm1j00) : cscale(2.0*chi, an00j00));
         r = csub(r, lap);
         r = cadd(r, cmul(make_double2(-3.0*cdz + 2.0*cdt*cdt, 2.0*djn*cdt + 2.0*k0*cdt), anm1j00));
     }
-    rhs[o] = r;
+    if (!mgs) { rhs[o] = r; return; }
+    const long plane = (long)nx*ny;
+    mg_rhs[o] = r.x; mg_rhs[plane + o] = r.y;
+    mg_acf_real[o] = ((step == 0) ? 6.0*cdz : 3.0*cdz + 2.0*cdt*cdt) + chi;                 // :520-523, 571-572
+    if (o == 0) *mg_acf_imag = (step == 0) ? -4.0*(k0 + djn)*cdt : -2.0*(k0 + djn)*cdt;    // :524-525
+}
+
+// planar (Re plane, Im plane) -> complex
+__global__ __launch_bounds__(256)
+void k_laser_from_planar (const double* __restrict__ p, double2* __restrict__ out, long plane)
+{
+    const long o = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (o < plane) out[o] = make_double2(p[o], p[plane + o]);
 }
 
 // divide by -(k^2 + a) in Fourier space (:754-772)
@@ -210,11 +236,22 @@ int laser_create (Engine& E)
     const size_t plane = (size_t)d.nx*d.ny, tot = plane*d.nz;
     HPS_HIP_CHECK(hipMalloc(&L->n00, tot*sizeof(double2)));
     HPS_HIP_CHECK(hipMalloc(&L->phase, sizeof(LaserPhase)));
-    if (d.laser_solver == 1 && d.dt != 0.0) {
+    if (d.laser_solver >= 1 && d.dt != 0.0) {
         HPS_HIP_CHECK(hipMalloc(&L->nm1, tot*sizeof(double2)));
         HPS_HIP_CHECK(hipMalloc(&L->np1, tot*sizeof(double2)));
         HPS_HIP_CHECK(hipMemset(L->nm1, 0, tot*sizeof(double2)));
         HPS_HIP_CHECK(hipMemset(L->np1, 0, tot*sizeof(double2)));
+    }
+    if (d.laser_solver == 2 && d.dt != 0.0) {
+        if (d.nx % 2 || d.ny % 2) { set_error("laser: the multigrid envelope solver needs even nx, ny (cell-centred hpmg box)"); return HPS_ERR_UNSUPPORTED; }
+        if (int e = mg2_create_internal(d.nx, d.ny, E.gm.dx, E.gm.dy, &L->mg)) return e;
+        HPS_HIP_CHECK(hipMalloc(&L->mg_sol, 2*plane*sizeof(double)));
+        HPS_HIP_CHECK(hipMemset(L->mg_sol, 0, 2*plane*sizeof(double)));
+        HPS_HIP_CHECK(hipMalloc(&L->mg_rhs, 2*plane*sizeof(double)));
+        HPS_HIP_CHECK(hipMalloc(&L->mg_acf_real, plane*sizeof(double)));
+        HPS_HIP_CHECK(hipMalloc(&L->mg_acf_imag, sizeof(double)));
+    }
+    if (d.laser_solver == 1 && d.dt != 0.0) {
         HPS_HIP_CHECK(hipMalloc(&L->work, plane*sizeof(double2)));
         static bool setup = false;
         if (!setup) { rocfft_setup(); setup = true; }
@@ -268,7 +305,7 @@ int laser_update_aabs (Engine& E, int islice, double* sum_abs)
     return HPS_OK;
 }
 
-// MultiLaser::AdvanceSlice with lasers.solver_type = fft
+// MultiLaser::AdvanceSlice: lasers.solver_type = fft (AdvanceSliceFFT) or multigrid (AdvanceSliceMG)
 int laser_advance_slice (Engine& E, int islice)
 {
     LaserState* L = E.laser;
@@ -284,7 +321,18 @@ int laser_advance_slice (Engine& E, int islice)
     const dim3 grid(ceil_div(d.nx, 256), d.ny), block(256);
     const double chi0 = d.plasma_density > 0.0 ? d.plasma_density*d.plasma_charge*d.plasma_charge*E.gm.mu0/d.plasma_mass : 0.0;
     hipLaunchKernelGGL(k_laser_rhs, grid, block, 0, E.st, S, SlabView(E.slab), (int)HPS_C_CHI, chi0, E.g, L->phase, L->steps,
-                       E.gm.dx, E.gm.dy, E.gm.dz, E.gm.c, d.dt, k0, L->work);
+                       E.gm.dx, E.gm.dy, E.gm.dz, E.gm.c, d.dt, k0, L->work, L->mg_rhs, L->mg_acf_real, L->mg_acf_imag);
+    if (L->mg) {
+        // MultiLaser::AdvanceSliceMG (:430-608): hpmg system type 2, at most 200 V-cycles; the initial guess is the solution
+        // of the slice solved before this one (np1j00 is left in place by ShiftLaserSlices, :208)
+        int iters = 0;
+        if (int e = mg2_solve_internal(L->mg, L->mg_sol, L->mg_rhs, L->mg_acf_real, L->mg_acf_imag,
+                                       d.laser_mg_tol_rel > 0.0 ? d.laser_mg_tol_rel : 1.0e-4, d.laser_mg_tol_abs, 200, &iters, E.st)) return e;
+        L->mg_vcycles += iters;
+        hipLaunchKernelGGL(k_laser_from_planar, dim3(ceil_div((long)plane, 256)), block, 0, E.st, L->mg_sol, L->np1 + (size_t)islice*plane, (long)plane);
+        HPS_HIP_CHECK(hipGetLastError());
+        return HPS_OK;
+    }
     void* buf[1] = {L->work};
     if (rocfft_execute(L->fwd, buf, nullptr, L->info) != rocfft_status_success) { set_error("laser: forward FFT failed"); return HPS_ERR_FFT; }
     hipLaunchKernelGGL(k_laser_divide, grid, block, 0, E.st, L->work, d.nx, d.ny, 2.0*3.14159265358979323846/(d.hi[0] - d.lo[0]),
@@ -333,6 +381,8 @@ int laser_import_from (Engine& E, int islice, Engine& src)
     if (newest != L->n00) HPS_HIP_CHECK(hipMemcpyAsync(L->n00 + (size_t)islice*plane, newest + (size_t)islice*plane, plane*sizeof(double2), hipMemcpyDeviceToDevice, E.st));
     return HPS_OK;
 }
+
+long laser_mg_vcycles (Engine& E) { return E.laser ? E.laser->mg_vcycles : 0; }
 
 int laser_copy_envelope (Engine& E, double* out_host)
 {

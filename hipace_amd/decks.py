@@ -46,7 +46,8 @@ _DEFAULT = dict(
     laser_on=0,              # lasers.names != no_laser: a Gaussian envelope (laser/Laser.H:32-45), static (step 0 only)
     laser_a0=0.0, laser_w0=1.0, laser_L0=1.0, laser_lambda0=0.8e-6, laser_pos=(0.0, 0.0, 0.0),
     laser_zfoc=0.0,          # laser.focal_distance
-    laser_solver=0,          # lasers.solver_type: 0 keep the envelope static, 1 "fft" (MultiLaser::AdvanceSliceFFT)
+    laser_solver=0,          # lasers.solver_type: 0 keep the envelope static, 1 "fft" (AdvanceSliceFFT), 2 "multigrid" (AdvanceSliceMG)
+    laser_mg_tol_rel=1.0e-4, laser_mg_tol_abs=0.0,      # lasers.MG_tolerance_rel / MG_tolerance_abs
     laser_use_phase=1,       # lasers.use_phase (MultiLaser.H:203)
     grid_current_on=0, grid_current_peak=0.0, grid_current_mean=(0.0, 0.0, 0.0), grid_current_std=(1.0, 1.0, 1.0),   # grid_current.*
     si_units=0,              # hipace.normalized_units = 0: SI constants, charges and masses in C and kg, weights = charges

@@ -164,6 +164,18 @@ int hps_mg_solve1 (void* handle, hps_slab slab, int sol_comp, int rhs_comp, int 
                    double* resnorm_host, hps_stream stream);
 int hps_mg_destroy (void* handle);
 
+/* hpmg::MultiGrid, system type 2 (mg_solver/HpMultiGrid.H:48,84-87 solve2 with an array Re and a scalar Im coefficient;
+ * .cpp:296-334 gs2, :192-208 residual2r/2i, :1239-1262), the envelope solve of MultiLaser::AdvanceSliceMG:
+ *     -(ar + i ai)(sol_r + i sol_i) + Lap(sol_r + i sol_i) = rhs_r + i rhs_i,   homogeneous Dirichlet,
+ * on a cell-centred nx x ny box (even nx, ny).  sol2 / rhs2: device arrays [2][ny][nx] (Re plane, Im plane) without guard
+ * cells, sol2 in: initial guess, out: solution; acoef_real_dev [ny][nx]; acoef_imag_dev: ONE double on the device (the
+ * caller's kernels produce it).  Blocks the host until converged; HPS_ERR_MG_MAXITER / HPS_ERR_MG_DIVERGED where hpmg aborts. */
+int hps_mg2_create (int nx, int ny, double dx, double dy, void** handle);
+int hps_mg2_solve2 (void* handle, double* sol2_dev, const double* rhs2_dev, const double* acoef_real_dev,
+                    const double* acoef_imag_dev, double tol_rel, double tol_abs, int max_iters, int* iters_host,
+                    double* resnorm_host, hps_stream stream);
+int hps_mg2_destroy (void* handle);
+
 /* ---- slice engine (Hipace::Evolve / SolveOneSlice, explicit solver; Hipace.cpp:393-728) -- */
 
 typedef struct {
@@ -196,6 +208,9 @@ typedef struct {
     /* grid_current.* (utils/GridCurrent.cpp:13-23): a Gaussian current density added to jz_beam (explicit solver) or jz
      * (predictor-corrector) of every slice, GridCurrent::DepositCurrentSlice (:25-71, called at Hipace.cpp:629) */
     int grid_current_on; double grid_current_peak, grid_current_mean[3], grid_current_std[3];
+    /* laser_solver = 2: lasers.solver_type = multigrid (MultiLaser::AdvanceSliceMG, laser/MultiLaser.cpp:430-608: hpmg
+     * system type 2, MG_average_rhs = 1, at most 200 V-cycles); lasers.MG_tolerance_rel (0 -> 1e-4) / MG_tolerance_abs */
+    double laser_mg_tol_rel, laser_mg_tol_abs;
 } hps_deck;
 
 /* slab component indices of the engine (explicit-solver layout of fields/Fields.cpp:70-122) */
@@ -273,6 +288,8 @@ int hps_engine_set_insitu_plasma (void* handle, double radius);
  * q = 0..22 = sum(w), [x], [x^2], [y], [y^2], [z], [z^2], [ux], [ux^2], [uy], [uy^2], [uz], [uz^2], [x*ux], [y*uy],
  * [z*uz], [x*uy], [y*ux], [ux/uz], [uy/uz], [ga], [ga^2] (averages: divided by sum(w)), Np (count, as a double), with
  * u = proper velocity / c.  radius <= 0 switches it off; cleared by hps_engine_begin_step; reading synchronises. */
+/* V-cycles of the multigrid envelope solver so far (laser_solver = 2), 0 otherwise */
+int hps_engine_laser_vcycles (void* handle, long* vcycles);
 int hps_engine_set_insitu_beam (void* handle, double radius);
 int hps_engine_insitu_beam (void* handle, double* out_host /* [23*nz] */);
 int hps_engine_insitu_plasma (void* handle, double* out_host /* [15*nz] */);

@@ -638,25 +638,26 @@ struct PoissonSolver {
 };
 
 // ---------------------------------------------------------------------------------------------
-// hpmg::MultiGrid, system type 1            mg_solver/HpMultiGrid.cpp (CPU path)
-//   -acoef*sol + Lap(sol) = rhs, homogeneous Dirichlet, sol/rhs 2 comps, acoef 1 comp
+// hpmg::MultiGrid, system types 1 and 2     mg_solver/HpMultiGrid.cpp (CPU path)
+//   type 1: -acoef*sol + Lap(sol) = rhs, homogeneous Dirichlet, sol/rhs 2 comps, acoef 1 comp
+//   type 2: -(ar + i ai)(sol_r + i sol_i) + Lap(sol_r + i sol_i) = rhs_r + i rhs_i, acoef 2 comps (laser envelope)
 // gsrb_cached (:595-740) is an exact re-expression of 4 global red-black sweeps (+ residual),
 // so it is restated as global sweeps (gsrb :367-407, gs1 :265-292, residual1 :184-190).
 // ---------------------------------------------------------------------------------------------
 struct MGLevel {
     int lox, loy, hix, hiy;   // index bounds of the level box (incl. boundary nodes if nodal)
     int nxb, nyb;             // box lengths
-    std::vector<double> acf, res, cor, rescor;   // acf 1 comp; others 2 comps
+    std::vector<double> acf, res, cor, rescor;   // acf 1 comp (type 2: 2 comps); others 2 comps
     long idx (int i, int j) const { return (long)(i - lox) + (long)(j - loy)*nxb; }
     long csz () const { return (long)nxb*nyb; }
 };
 
 struct MG {
-    bool cc; double dx, dy; int nlev; std::vector<MGLevel> L;
+    bool cc; double dx, dy; int nlev; std::vector<MGLevel> L; int sys = 1;
     // external arrays for level 0 (user memory, arbitrary strides, index origin shift)
     double *sol0, *sol1; const double *rhs0, *rhs1; long ext_js; int ext_shift_i, ext_shift_j;
 
-    MG (int nx, int ny, double dx_, double dy_) : dx(dx_), dy(dy_) {
+    MG (int nx, int ny, double dx_, double dy_, int system_type = 1) : dx(dx_), dy(dy_), sys(system_type) {
         // ctor / level build (HpMultiGrid.cpp:1043-1072)
         cc = (nx % 2 == 0);
         int lx = nx, ly = ny;   // cc: number of cells; nodal: box is 0..n+1 => n+2 nodes
@@ -665,7 +666,7 @@ struct MG {
         for (int il = 0; il < 31; ++il) {
             MGLevel lev; lev.lox = 0; lev.loy = 0; lev.hix = hx; lev.hiy = hy;
             lev.nxb = hx + 1; lev.nyb = hy + 1;
-            lev.acf.assign((size_t)lev.csz(), 0.0);
+            lev.acf.assign((size_t)lev.csz()*sys, 0.0);
             lev.res.assign((size_t)lev.csz()*2, 0.0);
             lev.cor.assign((size_t)lev.csz()*2, 0.0);
             lev.rescor.assign((size_t)lev.csz()*2, 0.0);
@@ -714,6 +715,40 @@ struct MG {
         const double c0_inv = 1.0/c0;
         phi(i,j,n) = (rhs - lap)*c0_inv;
     }
+    // gs2 (:296-334): the 2x2 system of the real and the imaginary part solved at once
+    inline void gs2 (int i, int j, const MGLevel& l, const View& phi, double rhs_r, double rhs_i,
+                     double ar, double ai, double facx, double facy) const {
+        double lap[2];
+        double c0 = -2.0*(facx + facy);
+        if (cc && i == l.lox)      { lap[0] = facx*(4./3.)*phi(i+1,j,0); lap[1] = facx*(4./3.)*phi(i+1,j,1); c0 -= 2.0*facx; }
+        else if (cc && i == l.hix) { lap[0] = facx*(4./3.)*phi(i-1,j,0); lap[1] = facx*(4./3.)*phi(i-1,j,1); c0 -= 2.0*facx; }
+        else { lap[0] = facx*(phi(i-1,j,0) + phi(i+1,j,0)); lap[1] = facx*(phi(i-1,j,1) + phi(i+1,j,1)); }
+        if (cc && j == l.loy)      { lap[0] += facy*(4./3.)*phi(i,j+1,0); lap[1] += facy*(4./3.)*phi(i,j+1,1); c0 -= 2.0*facy; }
+        else if (cc && j == l.hiy) { lap[0] += facy*(4./3.)*phi(i,j-1,0); lap[1] += facy*(4./3.)*phi(i,j-1,1); c0 -= 2.0*facy; }
+        else { lap[0] += facy*(phi(i,j-1,0) + phi(i,j+1,0)); lap[1] += facy*(phi(i,j-1,1) + phi(i,j+1,1)); }
+        double c[2] = {c0 - ar, -ai};
+        const double cmag = 1.0/(c[0]*c[0] + c[1]*c[1]);
+        c[0] *= cmag; c[1] *= cmag;
+        phi(i,j,0) = (rhs_r - lap[0])*c[0] + (rhs_i - lap[1])*c[1];
+        phi(i,j,1) = (rhs_i - lap[1])*c[0] - (rhs_r - lap[0])*c[1];
+    }
+    // one point of a sweep / of the residual for either system type
+    inline void gs_point (int i, int j, const MGLevel& l, const View& phi, const CView& rhs, const CView& acf,
+                          double facx, double facy) const {
+        if (sys == 1) { gs1(i, j, 0, l, phi, rhs(i,j,0), acf(i,j,0), facx, facy); gs1(i, j, 1, l, phi, rhs(i,j,1), acf(i,j,0), facx, facy); }
+        else gs2(i, j, l, phi, rhs(i,j,0), rhs(i,j,1), acf(i,j,0), acf(i,j,1), facx, facy);
+    }
+    inline void res_point (int i, int j, const MGLevel& l, const View& phi, const CView& rhs, const CView& acf,
+                           double facx, double facy, double& r0, double& r1) const {
+        if (sys == 1) {
+            r0 = residual1(i, j, 0, l, phi, rhs(i,j,0), acf(i,j,0), facx, facy);
+            r1 = residual1(i, j, 1, l, phi, rhs(i,j,1), acf(i,j,0), facx, facy);
+        } else {      // residual2r, residual2i (:192-208)
+            const double ar = acf(i,j,0), ai = acf(i,j,1);
+            r0 = residual1(i, j, 0, l, phi, rhs(i,j,0), 0.0, facx, facy) + (ar*phi(i,j,0) - ai*phi(i,j,1));
+            r1 = residual1(i, j, 1, l, phi, rhs(i,j,1), 0.0, facx, facy) + (ai*phi(i,j,0) + ar*phi(i,j,1));
+        }
+    }
     // laplacian (:162-182) + residual1 (:184-190)
     inline double residual1 (int i, int j, int n, const MGLevel& l, const View& phi, double rhs,
                              double acf, double facx, double facy) const {
@@ -744,17 +779,11 @@ struct MG {
         }
         for (int icolor = 0; icolor < 4; ++icolor) {
             for (int j = jl; j <= jh; ++j) for (int i = il; i <= ih; ++i) {
-                if ((i + j + icolor) % 2 == 0) {
-                    gs1(i, j, 0, l, w, rhs(i,j,0), acf(i,j,0), facx, facy);
-                    gs1(i, j, 1, l, w, rhs(i,j,1), acf(i,j,0), facx, facy);
-                }
+                if ((i + j + icolor) % 2 == 0) gs_point(i, j, l, w, rhs, acf, facx, facy);
             }
         }
         for (int j = jl; j <= jh; ++j) for (int i = il; i <= ih; ++i) {
-            if (do_res) {
-                (*res)(i,j,0) = residual1(i, j, 0, l, w, rhs(i,j,0), acf(i,j,0), facx, facy);
-                (*res)(i,j,1) = residual1(i, j, 1, l, w, rhs(i,j,1), acf(i,j,0), facx, facy);
-            }
+            if (do_res) res_point(i, j, l, w, rhs, acf, facx, facy, (*res)(i,j,0), (*res)(i,j,1));
             phi_out(i,j,0) = w(i,j,0);
             phi_out(i,j,1) = w(i,j,1);
         }
@@ -767,10 +796,7 @@ struct MG {
         const double facx = 1.0/(ldx*ldx), facy = 1.0/(ldy*ldy);
         const CView acf = clv(l, l.acf);
         for (int j = jl; j <= jh; ++j) for (int i = il; i <= ih; ++i) {
-            if ((i + j + icolor) % 2 == 0) {
-                gs1(i, j, 0, l, phi, rhs(i,j,0), acf(i,j,0), facx, facy);
-                gs1(i, j, 1, l, phi, rhs(i,j,1), acf(i,j,0), facx, facy);
-            }
+            if ((i + j + icolor) % 2 == 0) gs_point(i, j, l, phi, rhs, acf, facx, facy);
         }
     }
 
@@ -853,7 +879,7 @@ struct MG {
 
     // average_down_acoef (:1640-1700)
     void average_down_acoef () {
-        for (int il = 1; il < nlev; ++il) restriction(il, L[il].acf, L[il-1].acf, 1);
+        for (int il = 1; il < nlev; ++il) restriction(il, L[il].acf, L[il-1].acf, sys);
     }
 
     // solve1 (:1169-1190) + solve_doit (:1307-1427).  Arrays are slab components with guards:
@@ -869,7 +895,29 @@ struct MG {
         for (int j = l0.loy; j <= l0.hiy; ++j) for (int i = l0.lox; i <= l0.hix; ++i)
             l0.acf[l0.idx(i,j)] = acf_c[(i - sh + g) + (long)(j - sh + g)*js];
         average_down_acoef();
+        return solve_doit(tol_rel, tol_abs, maxiter, resnorm_out);
+    }
 
+    // solve2 (:1239-1262): acoef_real an array, acoef_imag a scalar (the laser envelope solve); same array conventions
+    int solve2 (double* sol_c0, double* sol_c1, const double* rhs_c0, const double* rhs_c1,
+                const double* acf_real, double acf_imag, long js, int g, double tol_rel, double tol_abs, int maxiter,
+                double* resnorm_out) {
+        const int sh = cc ? 0 : 1;
+        sol0 = sol_c0; sol1 = sol_c1; rhs0 = rhs_c0; rhs1 = rhs_c1; ext_js = js;
+        ext_shift_i = g - sh; ext_shift_j = g - sh;
+        MGLevel& l0 = L[0];
+        for (int j = l0.loy; j <= l0.hiy; ++j) for (int i = l0.lox; i <= l0.hix; ++i) {
+            const bool in = cc || (i >= 1 && i <= l0.hix - 1 && j >= 1 && j <= l0.hiy - 1);
+            l0.acf[l0.idx(i,j)] = in ? acf_real[(i - sh + g) + (long)(j - sh + g)*js] : 0.0;
+            l0.acf[l0.csz() + l0.idx(i,j)] = acf_imag;
+        }
+        average_down_acoef();
+        return solve_doit(tol_rel, tol_abs, maxiter, resnorm_out);
+    }
+
+    // solve_doit (:1307-1427)
+    int solve_doit (double tol_rel, double tol_abs, int maxiter, double* resnorm_out) {
+        MGLevel& l0 = L[0];
         View cor0 = lv(l0, l0.cor); View rc0 = lv(l0, l0.rescor);
         View s = solv(); CView sin{s.p, s.js, s.ns, s.oi, s.oj};
         gsrb4(0, false, true, cor0, rhsv(), &rc0, &sin, dx, dy);
@@ -947,7 +995,9 @@ struct Deck {
     int laser_on; double laser_a0, laser_w0, laser_L0, laser_lambda0, laser_pos[3];
     int si_units;                // hipace.normalized_units = 0: PhysConst of utils/Constants.H:15-24, weights are charges
     double laser_zfoc;           // laser.focal_distance (Laser.H:43)
-    int laser_solver;            // lasers.solver_type: 0 = envelope kept static, 1 = "fft" (MultiLaser::AdvanceSliceFFT)
+    int laser_solver;            // lasers.solver_type: 0 = envelope kept static, 1 = "fft" (MultiLaser::AdvanceSliceFFT),
+                                 // 2 = "multigrid" (MultiLaser::AdvanceSliceMG, MG_average_rhs = 1)
+    double laser_mg_tol_rel = 1.e-4, laser_mg_tol_abs = 0.0;      // lasers.MG_tolerance_rel / _abs (MultiLaser.H:216-217)
     int laser_use_phase;         // lasers.use_phase (MultiLaser.H:203, default true)
     int grid_current_on = 0;     // grid_current.use_grid_current (utils/GridCurrent.cpp:13-23)
     double grid_current_peak = 0., grid_current_mean[3] = {0., 0., 0.}, grid_current_std[3] = {1., 1., 1.};
@@ -977,6 +1027,7 @@ struct Engine {
     // envelope at time steps n-1, n, n+1 for every slice, valid cells only ([islice][j][i]); what the reference keeps in
     // the 9 slots of its laser slab + the MultiBuffer (utils/MultiBuffer.cpp:840-852, 913-925)
     std::vector<cplx> la_nm1, la_n00, la_np1; int laser_steps = 0;
+    MG* laser_mg = nullptr; std::vector<double> laser_mg_guess; long laser_vcycles = 0;      // lasers.solver_type = multigrid
     bool laser_import = false;     // ring pipeline: a_n and a_{n-1} of the coming step arrive slice by slice
     double t_deposit, t_explicit, t_push, t_poisson, t_mg, t_other;
 
@@ -1323,6 +1374,7 @@ struct Engine {
         const cplx exp1 = std::exp(I*(tj00 - tjp1)), exp2 = std::exp(I*(tj00 - tjp2));
         const double djn = (-3.0*dt1 + dt2)/(2.0*dz);
         std::vector<cplx> rhs(pl2);
+        std::vector<double> acf_real(d.laser_solver == 2 ? pl2 : 0);
         const double chi0 = d.plasma_density > 0.0 ? d.plasma_density*d.plasma_charge*d.plasma_charge*gm.mu0/d.plasma_mass : 0.0;
         const cplx* lapsrc = (step == 0) ? n00j00 : nm1j00;
         for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
@@ -1334,20 +1386,41 @@ struct Engine {
             // unperturbed plasma (SetInitialChi :293-332) outside
             const bool inside = i >= g && i < nx - g && j >= g && j < ny - g;
             const double chi_v = inside ? slab(i, j, chi) : chi0;
+            // chi term: FFT solver 2 chi a_n on the right-hand side (:713-740); multigrid solver with MG_average_rhs (the
+            // default): chi a_n (first step) / chi a_{n-1}, the other chi a_{n+1} sits in the operator (:575-598)
+            const bool mgs = (d.laser_solver == 2);
+            if (mgs) acf_real[o] = ((step == 0) ? 6.0/(c*dt*dz) : 3.0/(c*dt*dz) + 2.0/(c*c*dt*dt)) + chi_v;
             if (step == 0) {
                 rhs[o] = 8.0/(c*dt*dz)*(-np1jp1[o] + n00jp1[o])*exp1
                        + 2.0/(c*dt*dz)*(+np1jp2[o] - n00jp2[o])*exp2
-                       + 2.0*chi_v*n00j00[o]
+                       + (mgs ? 1.0 : 2.0)*chi_v*n00j00[o]
                        - lapA
                        + (-6.0/(c*dt*dz) + 4.0*I*djn/(c*dt) + I*4.0*k0/(c*dt))*n00j00[o];
             } else {
                 rhs[o] = 4.0/(c*dt*dz)*(-np1jp1[o] + nm1jp1[o])*exp1
                        + 1.0/(c*dt*dz)*(+np1jp2[o] - nm1jp2[o])*exp2
                        - 4.0/(c*c*dt*dt)*n00j00[o]
-                       + 2.0*chi_v*n00j00[o]
+                       + (mgs ? chi_v*nm1j00[o] : 2.0*chi_v*n00j00[o])
                        - lapA
                        + (-3.0/(c*dt*dz) + 2.0*I*djn/(c*dt) + 2.0/(c*c*dt*dt) + I*2.0*k0/(c*dt))*nm1j00[o];
             }
+        }
+        if (d.laser_solver == 2) {
+            // AdvanceSliceMG (laser/MultiLaser.cpp:430-608): hpmg system type 2 on the laser box; the initial guess is
+            // what np1j00 holds -- the solution of the slice solved before this one (ShiftLaserSlices leaves it, :208)
+            const double acf_imag = (step == 0) ? -4.0*(k0 + djn)/(c*dt) : -2.0*(k0 + djn)/(c*dt);
+            if (!laser_mg) laser_mg = new MG(nx, ny, dx, dy, 2);
+            if (laser_mg_guess.size() != 2*pl2) laser_mg_guess.assign(2*pl2, 0.0);
+            std::vector<double> r2(2*pl2);
+            for (size_t o = 0; o < pl2; ++o) { r2[o] = rhs[o].real(); r2[pl2 + o] = rhs[o].imag(); }
+            double* sol = laser_mg_guess.data();
+            const int it = laser_mg->solve2(sol, sol + pl2, r2.data(), r2.data() + pl2, acf_real.data(), acf_imag, nx, 0,
+                                            d.laser_mg_tol_rel, d.laser_mg_tol_abs, 200, nullptr);
+            if (it < 0) { std::fprintf(stderr, "oracle: laser multigrid solve failed on slice %d\n", islice); std::abort(); }
+            laser_vcycles += it;
+            cplx* out = la_np1.data() + (size_t)islice*pl2;
+            for (size_t o = 0; o < pl2; ++o) out[o] = cplx(sol[o], sol[pl2 + o]);
+            return;
         }
         fft2(rhs, -1);
         const double dkx = 2.0*M_PI/(d.hi[0] - d.lo[0]), dky = 2.0*M_PI/(d.hi[1] - d.lo[1]);
@@ -1518,7 +1591,7 @@ struct Engine {
         double t3 = now(); t_other += t3 - t2;
         solve_psi_ez_bz(rhomjz, jx, jy, Psi, Ez, Bz, ExmBy, EypBx);
         // m_multi_laser.AdvanceSlice (Hipace.cpp:637)
-        if (c_aabs >= 0 && d.laser_solver == 1 && d.dt != 0.0) advance_laser_slice(islice);
+        if (c_aabs >= 0 && d.laser_solver >= 1 && d.dt != 0.0) advance_laser_slice(islice);
         double t4 = now(); t_poisson += t4 - t3;
         if (moving) { if (islice - 1 >= 0) deposit_beam(store[islice - 1], N_jxb, N_jyb, -1, store[islice - 1].nreg); }
         else {
@@ -1689,7 +1762,7 @@ struct Engine {
                 if (!laser_import) { for (int k = 0; k < d.nz; ++k) init_laser_slice(k, la_n00.data() + (size_t)k*d.nx*d.ny); laser_steps = 0; }
             } else if (laser_import) {
                 // a_n, a_{n-1} of this step come through import_laser_slice; laser_steps is set by the driver
-            } else if (d.laser_solver == 1 && d.dt != 0.0) {
+            } else if (d.laser_solver >= 1 && d.dt != 0.0) {
                 // what put_data / get_data move between two steps: a_{n+1} -> a_n, a_n -> a_{n-1} (MultiBuffer.cpp:840-852, 913-925)
                 la_nm1.swap(la_n00); la_n00.swap(la_np1);
                 ++laser_steps;
@@ -1814,6 +1887,13 @@ void orc_poisson_solve (void* h, double* staging) { static_cast<PoissonSolver*>(
 void orc_poisson_destroy (void* h) { delete static_cast<PoissonSolver*>(h); }
 void orc_dst1 (int n, double* x, long stride) { DstPlan p(n); p.apply(x, stride); }
 
+// system type 2 on planar arrays without guards: sol2 / rhs2 [2][ny][nx], acf_real [ny][nx]; -> V-cycles or -1
+int orc_mg2_solve2 (int nx, int ny, double dx, double dy, double* sol2, const double* rhs2, const double* acf_real, double acf_imag,
+                    double tol_rel, double tol_abs, int maxiter, double* resnorm) {
+    MG m(nx, ny, dx, dy, 2);
+    const long pl = (long)nx*ny;
+    return m.solve2(sol2, sol2 + pl, rhs2, rhs2 + pl, acf_real, acf_imag, nx, 0, tol_rel, tol_abs, maxiter, resnorm);
+}
 void* orc_mg_create (int nx, int ny, double dx, double dy) { return new MG(nx, ny, dx, dy); }
 int orc_mg_nlev (void* h) { return static_cast<MG*>(h)->nlev; }
 // sol/rhs: 2 adjacent components each; acf 1 component, all with g guards, row stride nx+2g
@@ -1836,6 +1916,7 @@ struct orc_deck {
     int laser_on; double laser_a0, laser_w0, laser_L0, laser_lambda0, laser_pos[3];
     double laser_zfoc; int laser_solver; int laser_use_phase; int si_units;
     int grid_current_on; double grid_current_peak, grid_current_mean[3], grid_current_std[3];
+    double laser_mg_tol_rel, laser_mg_tol_abs;
 };
 
 void* orc_engine_create (const orc_deck* k) {
@@ -1857,6 +1938,7 @@ void* orc_engine_create (const orc_deck* k) {
     d.laser_zfoc=k->laser_zfoc; d.laser_solver=k->laser_solver; d.laser_use_phase=k->laser_use_phase; d.si_units=k->si_units;
     d.grid_current_on=k->grid_current_on; d.grid_current_peak=k->grid_current_peak;
     for (int i=0;i<3;++i){d.grid_current_mean[i]=k->grid_current_mean[i]; d.grid_current_std[i]=k->grid_current_std[i];}
+    d.laser_mg_tol_rel = k->laser_mg_tol_rel > 0.0 ? k->laser_mg_tol_rel : 1.e-4; d.laser_mg_tol_abs = k->laser_mg_tol_abs;
     return new Engine(d);
 }
 void orc_engine_destroy (void* h) { delete static_cast<Engine*>(h); }
@@ -1881,7 +1963,7 @@ double orc_engine_laser_envelope_sum (void* h) { return static_cast<Engine*>(h)-
 void orc_engine_set_laser_import (void* h, int on, int step) { Engine* e = static_cast<Engine*>(h); e->laser_import = (on != 0); e->laser_steps = step; }
 void orc_engine_export_laser_slice (void* h, int islice, double* out /* [2][ny][nx] complex */) {
     Engine* e = static_cast<Engine*>(h); const size_t pl2 = (size_t)e->d.nx*e->d.ny;
-    const bool evolve = e->d.laser_solver == 1 && e->d.dt != 0.0;
+    const bool evolve = e->d.laser_solver >= 1 && e->d.dt != 0.0;
     std::memcpy(out, (evolve ? e->la_np1 : e->la_n00).data() + (size_t)islice*pl2, pl2*sizeof(cplx));
     std::memcpy(out + 2*pl2, e->la_n00.data() + (size_t)islice*pl2, pl2*sizeof(cplx));
 }
@@ -1893,7 +1975,7 @@ void orc_engine_import_laser_slice (void* h, int islice, const double* in) {
 // in-process hand-off: the same, straight from the engine that ran the previous step
 void orc_engine_import_laser_from (void* h, int islice, void* src) {
     Engine* e = static_cast<Engine*>(h); Engine* p = static_cast<Engine*>(src); const size_t pl2 = (size_t)e->d.nx*e->d.ny;
-    const bool evolve = p->d.laser_solver == 1 && p->d.dt != 0.0;
+    const bool evolve = p->d.laser_solver >= 1 && p->d.dt != 0.0;
     // a_n -> a_{n-1} first: with one stage in flight source and destination are the same engine
     std::copy(p->la_n00.begin() + (size_t)islice*pl2, p->la_n00.begin() + (size_t)(islice + 1)*pl2, e->la_nm1.begin() + (size_t)islice*pl2);
     std::copy((evolve ? p->la_np1 : p->la_n00).begin() + (size_t)islice*pl2, (evolve ? p->la_np1 : p->la_n00).begin() + (size_t)(islice + 1)*pl2,
@@ -1953,6 +2035,7 @@ void orc_engine_beam_slice (void* h, int islice, double* out7n) {       // [7][c
     const std::vector<double>* a[7] = {&b.x, &b.y, &b.z, &b.ux, &b.uy, &b.uz, &b.w};
     for (int k = 0; k < 7; ++k) for (size_t i = 0; i < n; ++i) out7n[k*n + i] = (*a[k])[i];
 }
+long orc_engine_laser_vcycles (void* h) { return static_cast<Engine*>(h)->laser_vcycles; }
 void orc_engine_set_insitu_beam (void* h, double radius) {
     Engine* e = static_cast<Engine*>(h); e->insitu_bm_radius = radius; e->insitu_bm.assign((size_t)23*e->d.nz, 0.0); }
 void orc_engine_insitu_beam (void* h, double* out /* [23][nz] */) {

@@ -67,7 +67,7 @@ class Deck(C.Structure):
                 ("laser_lambda0", C.c_double), ("laser_pos", C.c_double * 3),
                 ("laser_zfoc", C.c_double), ("laser_solver", C.c_int), ("laser_use_phase", C.c_int), ("si_units", C.c_int),
                 ("grid_current_on", C.c_int), ("grid_current_peak", C.c_double), ("grid_current_mean", C.c_double * 3),
-                ("grid_current_std", C.c_double * 3)]
+                ("grid_current_std", C.c_double * 3), ("laser_mg_tol_rel", C.c_double), ("laser_mg_tol_abs", C.c_double)]
 
 
 def fill_struct(st, d):
@@ -277,6 +277,20 @@ def mg_solve1(sol2, rhs2, acf, nx, ny, g, dx, dy, tol_rel=1e-4, tol_abs=2.225073
     return it, rn.value
 
 
+def mg_solve2(sol2, rhs2, acf_real, acf_imag, dx, dy, tol_rel=1e-4, tol_abs=0.0, maxiter=200):
+    """hpmg system type 2 (the laser envelope solve): sol2 / rhs2 (2, ny, nx) Re and Im planes, acf_real (ny, nx), acf_imag a
+    scalar; sol2 (in: initial guess) updated in place. -> (V-cycles, resnorm)."""
+    assert sol2.flags.c_contiguous and rhs2.flags.c_contiguous and acf_real.flags.c_contiguous
+    ny, nx = acf_real.shape
+    L = lib()
+    L.orc_mg2_solve2.restype = C.c_int
+    L.orc_mg2_solve2.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                 C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]
+    rn = C.c_double()
+    it = L.orc_mg2_solve2(nx, ny, dx, dy, _ptr(sol2), _ptr(rhs2), _ptr(acf_real), acf_imag, tol_rel, tol_abs, maxiter, C.byref(rn))
+    return it, rn.value
+
+
 class FieldDiagnostic:
     """Fields::Copy (fields/Fields.cpp:413-533) on the diagnostic geometry of Diagnostic::ResizeFDiagFAB
     (diagnostics/Diagnostic.cpp:300-390; diag_type xyz, whole box, level 0): every solved slice adds
@@ -475,6 +489,12 @@ class Engine:
         if n:
             L.orc_engine_beam_slice(self._h, islice, _ptr(out))
         return out
+
+    def laser_vcycles(self):
+        L = lib()
+        L.orc_engine_laser_vcycles.restype = C.c_long
+        L.orc_engine_laser_vcycles.argtypes = [C.c_void_p]
+        return L.orc_engine_laser_vcycles(self._h)
 
     def set_insitu_beam(self, radius=np.inf):
         L = lib()

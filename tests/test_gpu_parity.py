@@ -930,12 +930,42 @@ def test_laser_evolution_fft_solver_matches_reference_checksums(api):
 
 
 @pytest.mark.gpu
-def test_evolving_laser_in_plasma_vs_oracle(api, oracle):
-    """Laser pulse in a plasma, envelope advanced by the FFT solver with the plasma's chi: three steps, the envelope
-    array and every slab component of the last slice against the oracle."""
+@pytest.mark.parametrize("warm", [False, True])
+def test_multigrid2_solve2_vs_oracle(api, oracle, warm):
+    """hps_mg2_solve2 (hpmg system type 2: complex coefficient, Re an array, Im a scalar) on a 96 x 64 box against the
+    oracle: same number of V-cycles, solution to 1e-10, from a zero and from a non-zero initial guess."""
+    import torch
+    rng = np.random.default_rng(11)
+    nx, ny, dx, dy = 96, 64, 0.11, 0.13
+    rhs = rng.standard_normal((2, ny, nx))
+    ar = 3.0 + rng.random((ny, nx))
+    ai = -7.5
+    sol = 0.02 * rng.standard_normal((2, ny, nx)) if warm else np.zeros((2, ny, nx))
+    want = sol.copy()
+    it_ref, rn_ref = oracle.mg_solve2(want, rhs, ar, ai, dx, dy, tol_rel=1e-6)
+    assert it_ref >= 2
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device="cuda").contiguous()
+    tsol, trhs, tar, tai = t(sol), t(rhs), t(ar), t(np.array([ai]))
+    it, rn = api.MultiGrid2(nx, ny, dx, dy).solve2(tsol, trhs, tar, tai, tol_rel=1e-6)
+    assert it == it_ref
+    assert rel_err(tsol.cpu().numpy(), want) < 1e-10
+    assert abs(rn - rn_ref) <= 1e-6 * rn_ref
+    # the equation itself: -(ar + i ai) phi + Lap(phi) = rhs at an interior point, to the solver's tolerance
+    ph = want[0] + 1j * want[1]
+    j, i = 20, 30
+    lap = (ph[j, i - 1] + ph[j, i + 1] - 2 * ph[j, i]) / dx ** 2 + (ph[j - 1, i] + ph[j + 1, i] - 2 * ph[j, i]) / dy ** 2
+    assert abs(lap - (ar[j, i] + 1j * ai) * ph[j, i] - (rhs[0, j, i] + 1j * rhs[1, j, i])) < 1e-4 * np.abs(rhs).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", [1, 2])
+def test_evolving_laser_in_plasma_vs_oracle(api, oracle, solver):
+    """Laser pulse in a plasma, envelope advanced with the plasma's chi by the FFT solver (1, AdvanceSliceFFT) or the
+    multigrid solver (2, AdvanceSliceMG = hpmg system type 2, initial guess = the previous slice's solution): three steps,
+    the envelope array and every slab component of the last slice against the oracle; multigrid: same V-cycle count."""
     deck = decks.laser_blowout_wake()
     deck.update(nx=64, ny=64, nz=30, lo=(-16.0, -16.0, -4.0), hi=(16.0, 16.0, 4.0), laser_a0=1.5, laser_lambda0=0.4,
-                laser_solver=1, dt=5.0, n_steps=3)
+                laser_solver=solver, dt=5.0, n_steps=3)
     ge = api.SliceEngine(deck, tile_size=16, sort_period=7)
     oe = oracle.Engine(deck)
     first = None
@@ -949,6 +979,7 @@ def test_evolving_laser_in_plasma_vs_oracle(api, oracle):
         assert np.abs(ga - oa).max() <= 1e-9 * np.abs(oa).max(), step
         first = oa.copy() if first is None else first
     assert np.abs(oa - first).max() > 1e-2 * np.abs(first).max()          # the pulse did evolve
+    assert ge.laser_vcycles() == oe.laser_vcycles() and (ge.laser_vcycles() > 0) == (solver == 2)
     gs, os_ = ge.slab(), oe.slab()
     names = ge.comp_names()
     for c in range(ge.ncomp):
