@@ -216,6 +216,7 @@ def main():
             "steps_in_flight": lanes,
             "phase_ms_per_slice": per_kernel,
             "vcycles_per_slice": eng.stats()["vcycles"] / max(eng.stats()["slices"], 1),
+            "laser_vcycles_per_slice": (eng.laser_vcycles() / max(eng.stats()["slices"], 1)) if args.config5 else None,
             "pc_iterations_per_slice": eng.pc_stats()[0] / max(eng.stats()["slices"], 1) if args.config2 else None,
             "particle_sorts": eng.sorts() if args.tile else 0,
             "halo_fallbacks": eng.fallbacks() if args.tile else 0,

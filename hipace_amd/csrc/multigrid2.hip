@@ -9,15 +9,16 @@
 // the laser grid of the slice engine is).  The real and the imaginary part are coupled through ai, so a point update
 // solves the 2x2 system at once.
 //
-// This solver is off the headline path (one envelope solve per slice next to 5 field solves): levels with <= 4096 cells run
-// whole sweeps sequences in one 1024-thread workgroup (colour after colour behind __syncthreads, arrays in L2), larger
-// levels take one launch per colour; the planes are planar [2][ny][nx] without guard cells.
+// Levels with <= 4096 cells run whole sweep sequences in one 1024-thread workgroup (colour after colour behind
+// __syncthreads, arrays in L2); larger levels use an LDS-tiled kernel that does the four sweeps, the residual and (up-leg)
+// the prolongation in one pass.  The planes are planar [2][ny][nx] without guard cells.
 #include "common.h"
 
 #include <vector>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 namespace hps {
 
@@ -127,31 +128,213 @@ void k2_maxabs (const double* __restrict__ p, long n, unsigned long long* norm)
     if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(norm, (unsigned long long)__double_as_longlong(m));
 }
 
+// ---- LDS-tiled form of gsrb_4_residual for the large levels ----------------------------------------------------------
+// A 256-thread workgroup owns a 64 x 32 tile and carries a 5-cell halo: sweep s (0..3) is applied to the cells within
+// 4 - s cells of the tile (what the tile's final values and its residual depend on), so four sweeps + residual cost one
+// read of phi / rhs / acf (1.4-1.5x with the halo) and one write instead of five passes.  Out of place (a neighbour's
+// halo read must see the old values); the up-leg's prolongation is fused into the load (src = fin + crse(i/2, j/2)).
+enum { SRC2_ZERO = 0, SRC2_DIRECT = 1, SRC2_PROLONG = 2 };
+// Tile 64 x 32 on the large levels (LDS region 74 x 42, swept region 72 x 40 = 12 cells per thread); 32 x 16 on levels of
+// <= 256^2 cells, where the count of workgroups and the latency of a launch matter more than the halo's extra reads.
+template <int T2X, int T2Y>
+__global__ __launch_bounds__(256)
+void k2_smooth_tile (Lev2 l, int src_mode, const double* __restrict__ fin, const double* __restrict__ crse, int cnx, long cn,
+                     double* __restrict__ phi_out, const double* __restrict__ rhs, const double* __restrict__ acf,
+                     int do_res, double* __restrict__ res, unsigned long long* norm)
+{
+    constexpr int T2H = 5, T2W = T2X + 2*T2H, T2HH = T2Y + 2*T2H;
+    constexpr int T2RW = T2X + 8, T2RH = T2Y + 8, T2K = (T2RW*T2RH + 255)/256;
+    __shared__ double sp[2][T2HH][T2W];
+    const int ti0 = blockIdx.x*T2X, tj0 = blockIdx.y*T2Y;
+    // load phi on the tile + halo (zero outside the domain: never read by the wall stencils)
+    for (int q = threadIdx.x; q < T2W*T2HH; q += 256) {
+        const int lj = q / T2W, li = q - lj*T2W;
+        const int gi = ti0 - T2H + li, gj = tj0 - T2H + lj;
+        double vr = 0.0, vi = 0.0;
+        if (src_mode != SRC2_ZERO && gi >= 0 && gi < l.nx && gj >= 0 && gj < l.ny) {
+            const long o = (long)gj*l.nx + gi;
+            vr = fin[o]; vi = fin[l.n + o];
+            if (src_mode == SRC2_PROLONG) { const long oc = (long)(gj/2)*cnx + gi/2; vr += crse[oc]; vi += crse[cn + oc]; }
+        }
+        sp[0][lj][li] = vr; sp[1][lj][li] = vi;
+    }
+    // per-cell constants of the swept region in registers: rhs and the inverse of the diagonal (gs2 :325-330)
+    double rr[T2K], ri[T2K], cr[T2K], ci[T2K];
+#pragma unroll
+    for (int k = 0; k < T2K; ++k) {
+        const int q = threadIdx.x + k*256;
+        const int rj = q / T2RW, rix = q - rj*T2RW;
+        const int gi = ti0 - 4 + rix, gj = tj0 - 4 + rj;
+        rr[k] = 0.0; ri[k] = 0.0; cr[k] = 0.0; ci[k] = 0.0;
+        if (q < T2RW*T2RH && gi >= 0 && gi < l.nx && gj >= 0 && gj < l.ny) {
+            const long o = (long)gj*l.nx + gi;
+            double c0 = -2.0*(l.facx + l.facy);
+            if (gi == 0 || gi == l.nx - 1) c0 -= 2.0*l.facx;
+            if (gj == 0 || gj == l.ny - 1) c0 -= 2.0*l.facy;
+            double a = c0 - acf[o], b = -acf[l.n + o];
+            const double cmag = 1.0/(a*a + b*b);
+            cr[k] = a*cmag; ci[k] = b*cmag;
+            rr[k] = rhs[o]; ri[k] = rhs[l.n + o];
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int k = 0; k < T2K; ++k) {
+            const int q = threadIdx.x + k*256;
+            const int rj = q / T2RW, rix = q - rj*T2RW;
+            const int gi = ti0 - 4 + rix, gj = tj0 - 4 + rj;
+            // distance to the tile, colour, domain
+            const int dxh = max(max(4 - rix, rix - (T2X + 3)), 0), dyh = max(max(4 - rj, rj - (T2Y + 3)), 0);
+            if (q >= T2RW*T2RH || max(dxh, dyh) > 4 - s || ((gi + gj + s) & 1) || gi < 0 || gi >= l.nx || gj < 0 || gj >= l.ny) continue;
+            const int li = rix + 1, lj = rj + 1;
+            double lap0, lap1;
+            if (gi == 0)             { lap0 = l.facx*(4./3.)*sp[0][lj][li + 1]; lap1 = l.facx*(4./3.)*sp[1][lj][li + 1]; }
+            else if (gi == l.nx - 1) { lap0 = l.facx*(4./3.)*sp[0][lj][li - 1]; lap1 = l.facx*(4./3.)*sp[1][lj][li - 1]; }
+            else { lap0 = l.facx*(sp[0][lj][li - 1] + sp[0][lj][li + 1]); lap1 = l.facx*(sp[1][lj][li - 1] + sp[1][lj][li + 1]); }
+            if (gj == 0)             { lap0 += l.facy*(4./3.)*sp[0][lj + 1][li]; lap1 += l.facy*(4./3.)*sp[1][lj + 1][li]; }
+            else if (gj == l.ny - 1) { lap0 += l.facy*(4./3.)*sp[0][lj - 1][li]; lap1 += l.facy*(4./3.)*sp[1][lj - 1][li]; }
+            else { lap0 += l.facy*(sp[0][lj - 1][li] + sp[0][lj + 1][li]); lap1 += l.facy*(sp[1][lj - 1][li] + sp[1][lj + 1][li]); }
+            const double a = rr[k] - lap0, b = ri[k] - lap1;
+            sp[0][lj][li] = a*cr[k] + b*ci[k];
+            sp[1][lj][li] = b*cr[k] - a*ci[k];
+        }
+        __syncthreads();
+    }
+    // tile out; residual2r / 2i (:192-208) and its max-norm
+    double m = 0.0;
+    for (int q = threadIdx.x; q < T2X*T2Y; q += 256) {
+        const int tj = q / T2X, tix = q - tj*T2X;
+        const int gi = ti0 + tix, gj = tj0 + tj;
+        if (gi >= l.nx || gj >= l.ny) continue;
+        const int li = tix + T2H, lj = tj + T2H;
+        const long o = (long)gj*l.nx + gi;
+        const double pr = sp[0][lj][li], pi = sp[1][lj][li];
+        phi_out[o] = pr; phi_out[l.n + o] = pi;
+        if (!do_res) continue;
+        double lp[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const double p0 = sp[n][lj][li];
+            double lap = -2.0*(l.facx + l.facy)*p0;
+            if (gi == 0)             lap += l.facx*((4./3.)*sp[n][lj][li + 1] - 2.0*p0);
+            else if (gi == l.nx - 1) lap += l.facx*((4./3.)*sp[n][lj][li - 1] - 2.0*p0);
+            else                     lap += l.facx*(sp[n][lj][li - 1] + sp[n][lj][li + 1]);
+            if (gj == 0)             lap += l.facy*((4./3.)*sp[n][lj + 1][li] - 2.0*p0);
+            else if (gj == l.ny - 1) lap += l.facy*((4./3.)*sp[n][lj - 1][li] - 2.0*p0);
+            else                     lap += l.facy*(sp[n][lj - 1][li] + sp[n][lj + 1][li]);
+            lp[n] = lap;
+        }
+        const double ar = acf[o], ai = acf[l.n + o];
+        const double r0 = rhs[o] - lp[0] + (ar*pr - ai*pi), r1 = rhs[l.n + o] - lp[1] + (ai*pr + ar*pi);
+        res[o] = r0; res[l.n + o] = r1;
+        m = fmax(m, fmax(fabs(r0), fabs(r1)));
+    }
+    if (do_res && norm) {
+        for (int sh = 32; sh > 0; sh >>= 1) m = fmax(m, __shfl_xor(m, sh));
+        if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(norm, (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+// ---- the lower part of the V-cycle in one workgroup ------------------------------------------------------------------
+// All levels from the first one with <= 256 cells down to the coarsest: zero guess, 4 sweeps, residual, restriction on
+// the way down, the bottom sweeps, prolongation + 4 sweeps on the way up -- arrays in LDS, one launch instead of ~5 per level.
+constexpr int LOW2_MAX_CELLS = 256, LOW2_MAX_LEVELS = 8;
+struct Low2 { int nlev; Lev2 l[LOW2_MAX_LEVELS]; int off[LOW2_MAX_LEVELS]; int numsweeps; };
+
+__device__ __forceinline__ void lds_sweeps (const Lev2& l, double* phi, const double* rhs, const double* acf, int nsweeps)
+{
+    for (int c = 0; c < nsweeps; ++c) {
+        for (int o = threadIdx.x; o < (int)l.n; o += blockDim.x) {
+            const int j = o / l.nx, i = o - j*l.nx;
+            if (((i + j + c) & 1) == 0) gs2_point(l, i, j, phi, rhs, acf);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256)
+void k2_lower_v (Low2 lv, const double* __restrict__ rhs_top, const double* const* __restrict__ acf_levels, double* __restrict__ cor_top)
+{
+    __shared__ double lds[8*(LOW2_MAX_CELLS + LOW2_MAX_CELLS/4 + LOW2_MAX_CELLS/16 + LOW2_MAX_CELLS/64 + 8)];
+    auto PHI = [&] (int k) { return lds + lv.off[k]; };
+    auto RHS = [&] (int k) { return lds + lv.off[k] + 2*lv.l[k].n; };
+    auto ACF = [&] (int k) { return lds + lv.off[k] + 4*lv.l[k].n; };
+    auto TMP = [&] (int k) { return lds + lv.off[k] + 6*lv.l[k].n; };
+    for (int k = 0; k < lv.nlev; ++k)
+        for (int o = threadIdx.x; o < 2*(int)lv.l[k].n; o += blockDim.x) {
+            ACF(k)[o] = acf_levels[k][o];
+            PHI(k)[o] = 0.0;
+            if (k == 0) RHS(0)[o] = rhs_top[o];
+        }
+    __syncthreads();
+    for (int k = 0; k < lv.nlev - 1; ++k) {
+        const Lev2& l = lv.l[k]; const Lev2& c = lv.l[k + 1];
+        lds_sweeps(l, PHI(k), RHS(k), ACF(k), 4);
+        for (int o = threadIdx.x; o < (int)l.n; o += blockDim.x) {
+            const int j = o / l.nx, i = o - j*l.nx;
+            const double pr = PHI(k)[o], pi = PHI(k)[l.n + o], ar = ACF(k)[o], ai = ACF(k)[l.n + o];
+            TMP(k)[o] = RHS(k)[o] - lap2(l, i, j, PHI(k) + o) + (ar*pr - ai*pi);
+            TMP(k)[l.n + o] = RHS(k)[l.n + o] - lap2(l, i, j, PHI(k) + l.n + o) + (ai*pr + ar*pi);
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < 2*(int)c.n; o += blockDim.x) {
+            const int n = o / (int)c.n, q = o - n*(int)c.n;
+            const int j = q / c.nx, i = q - j*c.nx;
+            const double* p = TMP(k) + (long)n*l.n + (long)(2*j)*l.nx + 2*i;
+            RHS(k + 1)[o] = 0.25*(p[0] + p[1] + p[l.nx] + p[l.nx + 1]);
+        }
+        __syncthreads();
+    }
+    lds_sweeps(lv.l[lv.nlev - 1], PHI(lv.nlev - 1), RHS(lv.nlev - 1), ACF(lv.nlev - 1), lv.numsweeps);
+    for (int k = lv.nlev - 2; k >= 0; --k) {
+        const Lev2& l = lv.l[k]; const Lev2& c = lv.l[k + 1];
+        for (int o = threadIdx.x; o < 2*(int)l.n; o += blockDim.x) {
+            const int n = o / (int)l.n, q = o - n*(int)l.n;
+            const int j = q / l.nx, i = q - j*l.nx;
+            PHI(k)[o] += PHI(k + 1)[(long)n*c.n + (long)(j/2)*c.nx + i/2];
+        }
+        __syncthreads();
+        lds_sweeps(l, PHI(k), RHS(k), ACF(k), 4);
+    }
+    for (int o = threadIdx.x; o < 2*(int)lv.l[0].n; o += blockDim.x) cor_top[o] = PHI(0)[o];
+}
+
 struct Multigrid2 {
     int nx = 0, ny = 0; double dx = 0, dy = 0;
     std::vector<Lev2> L;
     std::vector<double*> acf, res, cor, rescor;      // per level, 2 planes each
     unsigned long long* d_norm = nullptr;            // [2]: residual, rhs
+    int low_top = -1; Low2 low{}; double** d_low_acf = nullptr;      // levels low_top .. coarsest run in k2_lower_v
     long total_vcycles = 0;
     ~Multigrid2 () {
         for (auto& v : {acf, res, cor, rescor}) for (double* p : v) (void)hipFree(p);
-        (void)hipFree(d_norm);
+        (void)hipFree(d_norm); (void)hipFree(d_low_acf);
     }
 };
 
-static const long SINGLE_BLOCK_CELLS = 4096;
+static const long SINGLE_BLOCK_CELLS = LOW2_MAX_CELLS;      // above: the LDS-tiled kernel
 
-// gsrb_4_residual (:742-848) in place on phi
-static void sweeps4 (const Lev2& l, double* phi, const double* rhs, const double* acf, bool do_res, double* res,
-                     unsigned long long* norm, hipStream_t st)
+// gsrb_4_residual (:742-848): out = 4 sweeps of src (zero | fin | fin + prolonged crse), optionally res = rhs - L(out) and
+// its max-norm.  out must not alias fin.
+static void smooth4 (const Lev2& l, int src_mode, const double* fin, const double* crse, const Lev2* cl, double* out,
+                     const double* rhs, const double* acf, bool do_res, double* res, unsigned long long* norm, hipStream_t st)
 {
-    if (l.n <= SINGLE_BLOCK_CELLS) {
-        hipLaunchKernelGGL(k2_sweeps, dim3(1), dim3(1024), 0, st, l, phi, rhs, acf, 0, 4, do_res ? 1 : 0, res, norm);
+    if (l.n > SINGLE_BLOCK_CELLS) {
+        static const long big = getenv("HPS_MG2_BIG") ? atol(getenv("HPS_MG2_BIG")) : 256L*256L;      // measured: 65536 = 262144 > all small
+        if (l.n > big)
+            hipLaunchKernelGGL((k2_smooth_tile<64, 32>), dim3(ceil_div(l.nx, 64), ceil_div(l.ny, 32)), dim3(256), 0, st, l, src_mode, fin, crse,
+                               cl ? cl->nx : 0, cl ? cl->n : 0L, out, rhs, acf, do_res ? 1 : 0, res, norm);
+        else
+            hipLaunchKernelGGL((k2_smooth_tile<32, 16>), dim3(ceil_div(l.nx, 32), ceil_div(l.ny, 16)), dim3(256), 0, st, l, src_mode, fin, crse,
+                               cl ? cl->nx : 0, cl ? cl->n : 0L, out, rhs, acf, do_res ? 1 : 0, res, norm);
         return;
     }
-    const dim3 grid((unsigned)std::min<long>(ceil_div(l.n, 1024), 1024)), block(1024);
-    for (int c = 0; c < 4; ++c) hipLaunchKernelGGL(k2_sweeps, grid, block, 0, st, l, phi, rhs, acf, c, 1, 0, res, norm);
-    if (do_res) hipLaunchKernelGGL(k2_sweeps, grid, block, 0, st, l, phi, rhs, acf, 0, 0, 1, res, norm);
+    if (src_mode == SRC2_ZERO) (void)hipMemsetAsync(out, 0, (size_t)2*l.n*sizeof(double), st);
+    else if (src_mode == SRC2_DIRECT) (void)hipMemcpyAsync(out, fin, (size_t)2*l.n*sizeof(double), hipMemcpyDeviceToDevice, st);
+    else hipLaunchKernelGGL(k2_interp_add, dim3(ceil_div(2*l.n, 256)), dim3(256), 0, st, l, *cl, out, fin, crse);
+    hipLaunchKernelGGL(k2_sweeps, dim3(1), dim3(1024), 0, st, l, out, rhs, acf, 0, 4, do_res ? 1 : 0, res, norm);
 }
 
 static int mg2_create (int nx, int ny, double dx, double dy, Multigrid2** out)
@@ -172,6 +355,21 @@ static int mg2_create (int nx, int ny, double dx, double dy, Multigrid2** out)
         M->acf.push_back(p[0]); M->res.push_back(p[1]); M->cor.push_back(p[2]); M->rescor.push_back(p[3]);
     }
     HPS_HIP_CHECK(hipMalloc(&M->d_norm, 2*sizeof(unsigned long long)));
+    // the lower V: from the first level (not level 0) with <= LOW2_MAX_CELLS cells
+    const int nl = (int)M->L.size();
+    for (int il = 1; il < nl; ++il) if (M->L[il].n <= LOW2_MAX_CELLS && nl - il <= LOW2_MAX_LEVELS) { M->low_top = il; break; }
+    if (M->low_top >= 1) {
+        Low2& lv = M->low; lv.nlev = nl - M->low_top;
+        int off = 0; std::vector<double*> ptrs;
+        for (int k = 0; k < lv.nlev; ++k) { lv.l[k] = M->L[M->low_top + k]; lv.off[k] = off; off += 8*(int)lv.l[k].n; ptrs.push_back(M->acf[M->low_top + k]); }
+        const Lev2& lb = M->L[nl - 1];
+        lv.numsweeps = std::max(16, (std::max(lb.nx, lb.ny) + 1)/2*2);
+        if (off > 8*(LOW2_MAX_CELLS + LOW2_MAX_CELLS/4 + LOW2_MAX_CELLS/16 + LOW2_MAX_CELLS/64 + 8)) M->low_top = -1;      // odd shapes: generic path
+        else {
+            HPS_HIP_CHECK(hipMalloc(&M->d_low_acf, ptrs.size()*sizeof(double*)));
+            HPS_HIP_CHECK(hipMemcpy(M->d_low_acf, ptrs.data(), ptrs.size()*sizeof(double*), hipMemcpyHostToDevice));
+        }
+    }
     *out = M;
     return HPS_OK;
 }
@@ -192,16 +390,16 @@ static int read_norm (Multigrid2* M, int which, double* v, hipStream_t st)
 static void vcycle2 (Multigrid2* M, double* sol, const double* rhs, hipStream_t st)
 {
     const int maxl = (int)M->L.size() - 1;
-    for (int il = 0; il < maxl; ++il) {
+    const int top = (M->low_top >= 1) ? M->low_top : maxl;      // the levels [top, maxl] are the bottom part
+    for (int il = 0; il < top; ++il) {
         const Lev2& l = M->L[il];
-        if (il > 0) {
-            (void)hipMemsetAsync(M->cor[il], 0, (size_t)2*l.n*sizeof(double), st);
-            sweeps4(l, M->cor[il], M->res[il], M->acf[il], true, M->rescor[il], nullptr, st);
-        }
+        if (il > 0) smooth4(l, SRC2_ZERO, nullptr, nullptr, nullptr, M->cor[il], M->res[il], M->acf[il], true, M->rescor[il], nullptr, st);
         const Lev2& c = M->L[il + 1];
         hipLaunchKernelGGL(k2_restrict, dim3(ceil_div(2*c.n, 256)), dim3(256), 0, st, c, l, M->res[il + 1], M->rescor[il], 2);
     }
-    {   // bottomsolve, CPU branch (:1583-1593)
+    if (M->low_top >= 1) {
+        hipLaunchKernelGGL(k2_lower_v, dim3(1), dim3(256), 0, st, M->low, M->res[top], (const double* const*)M->d_low_acf, M->cor[top]);
+    } else {   // bottomsolve, CPU branch (:1583-1593)
         const Lev2& l = M->L[maxl];
         (void)hipMemsetAsync(M->cor[maxl], 0, (size_t)2*l.n*sizeof(double), st);
         const int numsweeps = std::max(16, (std::max(l.nx, l.ny) + 1)/2*2);
@@ -213,17 +411,16 @@ static void vcycle2 (Multigrid2* M, double* sol, const double* rhs, hipStream_t 
                 hipLaunchKernelGGL(k2_sweeps, grid, dim3(1024), 0, st, l, M->cor[maxl], M->res[maxl], M->acf[maxl], s, 1, 0, (double*)nullptr, (unsigned long long*)nullptr);
         }
     }
-    for (int il = maxl - 1; il >= 0; --il) {
+    for (int il = top - 1; il >= 0; --il) {
         const Lev2& l = M->L[il]; const Lev2& c = M->L[il + 1];
-        double* phi = (il == 0) ? sol : M->cor[il];
-        hipLaunchKernelGGL(k2_interp_add, dim3(ceil_div(2*l.n, 256)), dim3(256), 0, st, l, c, phi, M->cor[il], M->cor[il + 1]);
-        sweeps4(l, phi, (il == 0) ? rhs : M->res[il], M->acf[il], false, nullptr, nullptr, st);
+        // interpolation + 4 sweeps; the result replaces cor[il] (level 0: the solution)
+        double* out = (il == 0) ? sol : M->rescor[il];
+        smooth4(l, SRC2_PROLONG, M->cor[il], M->cor[il + 1], &c, out, (il == 0) ? rhs : M->res[il], M->acf[il], false, nullptr, nullptr, st);
+        if (il > 0) std::swap(M->cor[il], M->rescor[il]);
     }
     // cor0 = 4 more sweeps of the solution, residual behind them
-    const Lev2& l0 = M->L[0];
-    (void)hipMemcpyAsync(M->cor[0], sol, (size_t)2*l0.n*sizeof(double), hipMemcpyDeviceToDevice, st);
     (void)hipMemsetAsync(M->d_norm, 0, sizeof(unsigned long long), st);
-    sweeps4(l0, M->cor[0], rhs, M->acf[0], true, M->rescor[0], M->d_norm, st);
+    smooth4(M->L[0], SRC2_DIRECT, sol, nullptr, nullptr, M->cor[0], rhs, M->acf[0], true, M->rescor[0], M->d_norm, st);
 }
 
 static int mg2_solve2 (Multigrid2* M, double* sol, const double* rhs, const double* acf_real, const double* acf_imag, double tol_rel,
@@ -234,10 +431,9 @@ static int mg2_solve2 (Multigrid2* M, double* sol, const double* rhs, const doub
     for (size_t il = 1; il < M->L.size(); ++il)      // average_down_acoef (:1640-1700)
         hipLaunchKernelGGL(k2_restrict, dim3(ceil_div(2*M->L[il].n, 256)), dim3(256), 0, st, M->L[il], M->L[il - 1], M->acf[il], M->acf[il - 1], 2);
     // solve_doit (:1307-1427)
-    (void)hipMemcpyAsync(M->cor[0], sol, (size_t)2*l0.n*sizeof(double), hipMemcpyDeviceToDevice, st);
     (void)hipMemsetAsync(M->d_norm, 0, 2*sizeof(unsigned long long), st);
-    sweeps4(l0, M->cor[0], rhs, M->acf[0], true, M->rescor[0], M->d_norm, st);
-    hipLaunchKernelGGL(k2_maxabs, dim3(64), dim3(256), 0, st, rhs, 2*l0.n, M->d_norm + 1);
+    smooth4(l0, SRC2_DIRECT, sol, nullptr, nullptr, M->cor[0], rhs, M->acf[0], true, M->rescor[0], M->d_norm, st);
+    hipLaunchKernelGGL(k2_maxabs, dim3((unsigned)std::min<long>(ceil_div(2*l0.n, 1024), 2048)), dim3(256), 0, st, rhs, 2*l0.n, M->d_norm + 1);
     HPS_HIP_CHECK(hipGetLastError());
     double resnorm0 = 0.0, rhsnorm0 = 0.0;
     if (int e = read_norm(M, 0, &resnorm0, st)) return e;
