@@ -128,6 +128,15 @@ void k2_maxabs (const double* __restrict__ p, long n, unsigned long long* norm)
     if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(norm, (unsigned long long)__double_as_longlong(m));
 }
 
+// the two norm words -> mapped host memory, sequence number last behind a system-scope fence; the host polls it (as
+// k_post_norms of multigrid.hip) instead of a DMA copy + stream synchronise
+__global__ void k2_post_norms (const unsigned long long* __restrict__ src, volatile unsigned long long* dst, unsigned long long seq)
+{
+    dst[0] = src[0]; dst[1] = src[1];
+    __threadfence_system();
+    dst[2] = seq;
+}
+
 // ---- LDS-tiled form of gsrb_4_residual for the large levels ----------------------------------------------------------
 // A 256-thread workgroup owns a 64 x 32 tile and carries a 5-cell halo: sweep s (0..3) is applied to the cells within
 // 4 - s cells of the tile (what the tile's final values and its residual depend on), so four sweeps + residual cost one
@@ -140,7 +149,7 @@ template <int T2X, int T2Y>
 __global__ __launch_bounds__(256)
 void k2_smooth_tile (Lev2 l, int src_mode, const double* __restrict__ fin, const double* __restrict__ crse, int cnx, long cn,
                      double* __restrict__ phi_out, const double* __restrict__ rhs, const double* __restrict__ acf,
-                     int do_res, double* __restrict__ res, unsigned long long* norm)
+                     int do_res, double* __restrict__ res, unsigned long long* norm, double* __restrict__ crse_res, int crx, long crn)
 {
     constexpr int T2H = 5, T2W = T2X + 2*T2H, T2HH = T2Y + 2*T2H;
     constexpr int T2RW = T2X + 8, T2RH = T2Y + 8, T2K = (T2RW*T2RH + 255)/256;
@@ -202,17 +211,12 @@ void k2_smooth_tile (Lev2 l, int src_mode, const double* __restrict__ fin, const
         }
         __syncthreads();
     }
-    // tile out; residual2r / 2i (:192-208) and its max-norm
+    // tile out; residual2r / 2i (:192-208), its max-norm and -- with a coarser level -- its restriction (restrict_cc
+    // :29-37) straight from registers: the fine residual then never goes to memory
     double m = 0.0;
-    for (int q = threadIdx.x; q < T2X*T2Y; q += 256) {
-        const int tj = q / T2X, tix = q - tj*T2X;
-        const int gi = ti0 + tix, gj = tj0 + tj;
-        if (gi >= l.nx || gj >= l.ny) continue;
-        const int li = tix + T2H, lj = tj + T2H;
+    auto residual = [&] (int gi, int gj, int li, int lj, double& r0, double& r1) {
         const long o = (long)gj*l.nx + gi;
         const double pr = sp[0][lj][li], pi = sp[1][lj][li];
-        phi_out[o] = pr; phi_out[l.n + o] = pi;
-        if (!do_res) continue;
         double lp[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
@@ -227,7 +231,40 @@ void k2_smooth_tile (Lev2 l, int src_mode, const double* __restrict__ fin, const
             lp[n] = lap;
         }
         const double ar = acf[o], ai = acf[l.n + o];
-        const double r0 = rhs[o] - lp[0] + (ar*pr - ai*pi), r1 = rhs[l.n + o] - lp[1] + (ai*pr + ar*pi);
+        r0 = rhs[o] - lp[0] + (ar*pr - ai*pi); r1 = rhs[l.n + o] - lp[1] + (ai*pr + ar*pi);
+    };
+    if (do_res && crse_res) {
+        for (int q = threadIdx.x; q < (T2X/2)*(T2Y/2); q += 256) {
+            const int cj = q / (T2X/2), cix = q - cj*(T2X/2);
+            const int gi0 = ti0 + 2*cix, gj0 = tj0 + 2*cj;
+            if (gi0 >= l.nx || gj0 >= l.ny) continue;          // nx, ny even: the 2 x 2 block is inside or outside as a whole
+            double s0 = 0.0, s1 = 0.0;
+            // order of restrict_cc: (2i,2j) + (2i+1,2j) + (2i,2j+1) + (2i+1,2j+1)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int gi = gi0 + (b & 1), gj = gj0 + (b >> 1);
+                const int li = gi - ti0 + T2H, lj = gj - tj0 + T2H;
+                const long o = (long)gj*l.nx + gi;
+                phi_out[o] = sp[0][lj][li]; phi_out[l.n + o] = sp[1][lj][li];
+                double r0, r1;
+                residual(gi, gj, li, lj, r0, r1);
+                s0 += r0; s1 += r1;
+                m = fmax(m, fmax(fabs(r0), fabs(r1)));
+            }
+            const long oc = (long)(gj0/2)*crx + gi0/2;
+            crse_res[oc] = 0.25*s0; crse_res[crn + oc] = 0.25*s1;
+        }
+    } else
+    for (int q = threadIdx.x; q < T2X*T2Y; q += 256) {
+        const int tj = q / T2X, tix = q - tj*T2X;
+        const int gi = ti0 + tix, gj = tj0 + tj;
+        if (gi >= l.nx || gj >= l.ny) continue;
+        const int li = tix + T2H, lj = tj + T2H;
+        const long o = (long)gj*l.nx + gi;
+        phi_out[o] = sp[0][lj][li]; phi_out[l.n + o] = sp[1][lj][li];
+        if (!do_res) continue;
+        double r0, r1;
+        residual(gi, gj, li, lj, r0, r1);
         res[o] = r0; res[l.n + o] = r1;
         m = fmax(m, fmax(fabs(r0), fabs(r1)));
     }
@@ -306,35 +343,44 @@ struct Multigrid2 {
     std::vector<Lev2> L;
     std::vector<double*> acf, res, cor, rescor;      // per level, 2 planes each
     unsigned long long* d_norm = nullptr;            // [2]: residual, rhs
+    unsigned long long *h_post = nullptr, *h_post_dev = nullptr, seq = 0;      // mapped pinned: [0] residual, [1] rhs norm, [2] sequence
+    bool res1_ready = false;      // res[1] already holds the restricted level-0 residual (fused into the tile kernel)
     int low_top = -1; Low2 low{}; double** d_low_acf = nullptr;      // levels low_top .. coarsest run in k2_lower_v
     long total_vcycles = 0;
     ~Multigrid2 () {
         for (auto& v : {acf, res, cor, rescor}) for (double* p : v) (void)hipFree(p);
         (void)hipFree(d_norm); (void)hipFree(d_low_acf);
+        if (h_post) (void)hipHostFree(h_post);
     }
 };
 
 static const long SINGLE_BLOCK_CELLS = LOW2_MAX_CELLS;      // above: the LDS-tiled kernel
 
 // gsrb_4_residual (:742-848): out = 4 sweeps of src (zero | fin | fin + prolonged crse), optionally res = rhs - L(out) and
-// its max-norm.  out must not alias fin.
-static void smooth4 (const Lev2& l, int src_mode, const double* fin, const double* crse, const Lev2* cl, double* out,
-                     const double* rhs, const double* acf, bool do_res, double* res, unsigned long long* norm, hipStream_t st)
+// its max-norm.  out must not alias fin.  With crse_res (the next level's right-hand side) the tiled path restricts the
+// residual itself and returns true (res is then not written); false: the caller restricts res.
+static bool smooth4 (const Lev2& l, int src_mode, const double* fin, const double* crse, const Lev2* cl, double* out,
+                     const double* rhs, const double* acf, bool do_res, double* res, unsigned long long* norm, hipStream_t st,
+                     double* crse_res = nullptr, const Lev2* crl = nullptr)
 {
     if (l.n > SINGLE_BLOCK_CELLS) {
         static const long big = getenv("HPS_MG2_BIG") ? atol(getenv("HPS_MG2_BIG")) : 256L*256L;      // measured: 65536 = 262144 > all small
+        const bool fuse = do_res && crse_res && crl && l.nx % 2 == 0 && l.ny % 2 == 0;
         if (l.n > big)
             hipLaunchKernelGGL((k2_smooth_tile<64, 32>), dim3(ceil_div(l.nx, 64), ceil_div(l.ny, 32)), dim3(256), 0, st, l, src_mode, fin, crse,
-                               cl ? cl->nx : 0, cl ? cl->n : 0L, out, rhs, acf, do_res ? 1 : 0, res, norm);
+                               cl ? cl->nx : 0, cl ? cl->n : 0L, out, rhs, acf, do_res ? 1 : 0, res, norm, fuse ? crse_res : (double*)nullptr,
+                               fuse ? crl->nx : 0, fuse ? crl->n : 0L);
         else
             hipLaunchKernelGGL((k2_smooth_tile<32, 16>), dim3(ceil_div(l.nx, 32), ceil_div(l.ny, 16)), dim3(256), 0, st, l, src_mode, fin, crse,
-                               cl ? cl->nx : 0, cl ? cl->n : 0L, out, rhs, acf, do_res ? 1 : 0, res, norm);
-        return;
+                               cl ? cl->nx : 0, cl ? cl->n : 0L, out, rhs, acf, do_res ? 1 : 0, res, norm, fuse ? crse_res : (double*)nullptr,
+                               fuse ? crl->nx : 0, fuse ? crl->n : 0L);
+        return fuse;
     }
     if (src_mode == SRC2_ZERO) (void)hipMemsetAsync(out, 0, (size_t)2*l.n*sizeof(double), st);
     else if (src_mode == SRC2_DIRECT) (void)hipMemcpyAsync(out, fin, (size_t)2*l.n*sizeof(double), hipMemcpyDeviceToDevice, st);
     else hipLaunchKernelGGL(k2_interp_add, dim3(ceil_div(2*l.n, 256)), dim3(256), 0, st, l, *cl, out, fin, crse);
     hipLaunchKernelGGL(k2_sweeps, dim3(1), dim3(1024), 0, st, l, out, rhs, acf, 0, 4, do_res ? 1 : 0, res, norm);
+    return false;
 }
 
 static int mg2_create (int nx, int ny, double dx, double dy, Multigrid2** out)
@@ -355,6 +401,9 @@ static int mg2_create (int nx, int ny, double dx, double dy, Multigrid2** out)
         M->acf.push_back(p[0]); M->res.push_back(p[1]); M->cor.push_back(p[2]); M->rescor.push_back(p[3]);
     }
     HPS_HIP_CHECK(hipMalloc(&M->d_norm, 2*sizeof(unsigned long long)));
+    HPS_HIP_CHECK(hipHostMalloc(&M->h_post, 4*sizeof(unsigned long long), hipHostMallocMapped));
+    HPS_HIP_CHECK(hipHostGetDevicePointer((void**)&M->h_post_dev, M->h_post, 0));
+    M->h_post[0] = M->h_post[1] = M->h_post[2] = 0ULL;
     // the lower V: from the first level (not level 0) with <= LOW2_MAX_CELLS cells
     const int nl = (int)M->L.size();
     for (int il = 1; il < nl; ++il) if (M->L[il].n <= LOW2_MAX_CELLS && nl - il <= LOW2_MAX_LEVELS) { M->low_top = il; break; }
@@ -374,15 +423,24 @@ static int mg2_create (int nx, int ny, double dx, double dy, Multigrid2** out)
     return HPS_OK;
 }
 
-static int read_norm (Multigrid2* M, int which, double* v, hipStream_t st)
+// both norms (residual, rhs) of the stream's work so far
+static int read_norms (Multigrid2* M, double* resnorm, double* rhsnorm, hipStream_t st)
 {
-    unsigned long long bits = 0;
-    HPS_HIP_CHECK(hipMemcpyAsync(&bits, M->d_norm + which, sizeof(bits), hipMemcpyDeviceToHost, st));
-    HPS_HIP_CHECK(hipStreamSynchronize(st));
-    long long b = (long long)bits; double d;
-    static_assert(sizeof(d) == sizeof(b), "");
-    std::memcpy(&d, &b, sizeof(d));
-    *v = d;
+    ++M->seq;
+    hipLaunchKernelGGL(k2_post_norms, dim3(1), dim3(1), 0, st, M->d_norm, (volatile unsigned long long*)M->h_post_dev, M->seq);
+    volatile unsigned long long* hs = M->h_post + 2;
+    long spins = 0;
+    while (*hs != M->seq) {
+        if ((++spins & 0xfffff) == 0 && hipStreamQuery(st) != hipErrorNotReady) {      // a failed launch must not hang us
+            if (*hs == M->seq) break;
+            HPS_HIP_CHECK(hipStreamSynchronize(st));
+            if (*hs != M->seq) { set_error("hps_mg2_solve2: the norm read-back never arrived"); return HPS_ERR_HIP; }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    auto val = [&] (int k) { unsigned long long b = ((volatile unsigned long long*)M->h_post)[k]; double d; std::memcpy(&d, &b, sizeof(d)); return d; };
+    *resnorm = val(0);
+    if (rhsnorm) *rhsnorm = val(1);
     return HPS_OK;
 }
 
@@ -392,10 +450,11 @@ static void vcycle2 (Multigrid2* M, double* sol, const double* rhs, hipStream_t 
     const int maxl = (int)M->L.size() - 1;
     const int top = (M->low_top >= 1) ? M->low_top : maxl;      // the levels [top, maxl] are the bottom part
     for (int il = 0; il < top; ++il) {
-        const Lev2& l = M->L[il];
-        if (il > 0) smooth4(l, SRC2_ZERO, nullptr, nullptr, nullptr, M->cor[il], M->res[il], M->acf[il], true, M->rescor[il], nullptr, st);
-        const Lev2& c = M->L[il + 1];
-        hipLaunchKernelGGL(k2_restrict, dim3(ceil_div(2*c.n, 256)), dim3(256), 0, st, c, l, M->res[il + 1], M->rescor[il], 2);
+        const Lev2& l = M->L[il]; const Lev2& c = M->L[il + 1];
+        bool restricted = (il == 0) ? M->res1_ready : false;      // level 0: done by the smooth that produced the residual
+        if (il > 0) restricted = smooth4(l, SRC2_ZERO, nullptr, nullptr, nullptr, M->cor[il], M->res[il], M->acf[il], true, M->rescor[il], nullptr, st,
+                                         M->res[il + 1], &c);
+        if (!restricted) hipLaunchKernelGGL(k2_restrict, dim3(ceil_div(2*c.n, 256)), dim3(256), 0, st, c, l, M->res[il + 1], M->rescor[il], 2);
     }
     if (M->low_top >= 1) {
         hipLaunchKernelGGL(k2_lower_v, dim3(1), dim3(256), 0, st, M->low, M->res[top], (const double* const*)M->d_low_acf, M->cor[top]);
@@ -420,7 +479,8 @@ static void vcycle2 (Multigrid2* M, double* sol, const double* rhs, hipStream_t 
     }
     // cor0 = 4 more sweeps of the solution, residual behind them
     (void)hipMemsetAsync(M->d_norm, 0, sizeof(unsigned long long), st);
-    smooth4(M->L[0], SRC2_DIRECT, sol, nullptr, nullptr, M->cor[0], rhs, M->acf[0], true, M->rescor[0], M->d_norm, st);
+    M->res1_ready = smooth4(M->L[0], SRC2_DIRECT, sol, nullptr, nullptr, M->cor[0], rhs, M->acf[0], true, M->rescor[0], M->d_norm, st,
+                            maxl >= 1 ? M->res[1] : nullptr, maxl >= 1 ? &M->L[1] : nullptr);
 }
 
 static int mg2_solve2 (Multigrid2* M, double* sol, const double* rhs, const double* acf_real, const double* acf_imag, double tol_rel,
@@ -432,12 +492,13 @@ static int mg2_solve2 (Multigrid2* M, double* sol, const double* rhs, const doub
         hipLaunchKernelGGL(k2_restrict, dim3(ceil_div(2*M->L[il].n, 256)), dim3(256), 0, st, M->L[il], M->L[il - 1], M->acf[il], M->acf[il - 1], 2);
     // solve_doit (:1307-1427)
     (void)hipMemsetAsync(M->d_norm, 0, 2*sizeof(unsigned long long), st);
-    smooth4(l0, SRC2_DIRECT, sol, nullptr, nullptr, M->cor[0], rhs, M->acf[0], true, M->rescor[0], M->d_norm, st);
+    const bool has1 = M->L.size() >= 2;
+    M->res1_ready = smooth4(l0, SRC2_DIRECT, sol, nullptr, nullptr, M->cor[0], rhs, M->acf[0], true, M->rescor[0], M->d_norm, st,
+                            has1 ? M->res[1] : nullptr, has1 ? &M->L[1] : nullptr);
     hipLaunchKernelGGL(k2_maxabs, dim3((unsigned)std::min<long>(ceil_div(2*l0.n, 1024), 2048)), dim3(256), 0, st, rhs, 2*l0.n, M->d_norm + 1);
     HPS_HIP_CHECK(hipGetLastError());
     double resnorm0 = 0.0, rhsnorm0 = 0.0;
-    if (int e = read_norm(M, 0, &resnorm0, st)) return e;
-    if (int e = read_norm(M, 1, &rhsnorm0, st)) return e;
+    if (int e = read_norms(M, &resnorm0, &rhsnorm0, st)) return e;
     const double max_norm = (rhsnorm0 >= resnorm0) ? rhsnorm0 : resnorm0;
     const double res_target = std::max(tol_abs, std::max(tol_rel, 1.e-16)*max_norm);
     int iters = 0; double norminf = resnorm0;
@@ -447,7 +508,7 @@ static int mg2_solve2 (Multigrid2* M, double* sol, const double* rhs, const doub
             vcycle2(M, sol, rhs, st);
             HPS_HIP_CHECK(hipGetLastError());
             ++iters;
-            if (int e = read_norm(M, 0, &norminf, st)) return e;
+            if (int e = read_norms(M, &norminf, nullptr, st)) return e;
             converged = (norminf <= res_target);
             if (converged) break;
             if (!(norminf <= 1.e20*max_norm)) { diverged = true; break; }
