@@ -138,25 +138,25 @@ __global__ void k2_post_norms (const unsigned long long* __restrict__ src, volat
 }
 
 // ---- LDS-tiled form of gsrb_4_residual for the large levels ----------------------------------------------------------
-// A 256-thread workgroup owns a 64 x 32 tile and carries a 5-cell halo: sweep s (0..3) is applied to the cells within
+// A workgroup (512 threads on a 64 x 32 tile, 256 on a 32 x 16 one) owns a tile and carries a 5-cell halo: sweep s (0..3) is applied to the cells within
 // 4 - s cells of the tile (what the tile's final values and its residual depend on), so four sweeps + residual cost one
 // read of phi / rhs / acf (1.4-1.5x with the halo) and one write instead of five passes.  Out of place (a neighbour's
 // halo read must see the old values); the up-leg's prolongation is fused into the load (src = fin + crse(i/2, j/2)).
 enum { SRC2_ZERO = 0, SRC2_DIRECT = 1, SRC2_PROLONG = 2 };
 // Tile 64 x 32 on the large levels (LDS region 74 x 42, swept region 72 x 40 = 12 cells per thread); 32 x 16 on levels of
 // <= 256^2 cells, where the count of workgroups and the latency of a launch matter more than the halo's extra reads.
-template <int T2X, int T2Y>
-__global__ __launch_bounds__(256)
+template <int T2X, int T2Y, int NT>
+__global__ __launch_bounds__(NT)
 void k2_smooth_tile (Lev2 l, int src_mode, const double* __restrict__ fin, const double* __restrict__ crse, int cnx, long cn,
                      double* __restrict__ phi_out, const double* __restrict__ rhs, const double* __restrict__ acf,
                      int do_res, double* __restrict__ res, unsigned long long* norm, double* __restrict__ crse_res, int crx, long crn)
 {
     constexpr int T2H = 5, T2W = T2X + 2*T2H, T2HH = T2Y + 2*T2H;
-    constexpr int T2RW = T2X + 8, T2RH = T2Y + 8, T2K = (T2RW*T2RH + 255)/256;
+    constexpr int T2RW = T2X + 8, T2RH = T2Y + 8, T2K = (T2RW*T2RH + NT - 1)/NT;
     __shared__ double sp[2][T2HH][T2W];
     const int ti0 = blockIdx.x*T2X, tj0 = blockIdx.y*T2Y;
     // load phi on the tile + halo (zero outside the domain: never read by the wall stencils)
-    for (int q = threadIdx.x; q < T2W*T2HH; q += 256) {
+    for (int q = threadIdx.x; q < T2W*T2HH; q += NT) {
         const int lj = q / T2W, li = q - lj*T2W;
         const int gi = ti0 - T2H + li, gj = tj0 - T2H + lj;
         double vr = 0.0, vi = 0.0;
@@ -171,7 +171,7 @@ void k2_smooth_tile (Lev2 l, int src_mode, const double* __restrict__ fin, const
     double rr[T2K], ri[T2K], cr[T2K], ci[T2K];
 #pragma unroll
     for (int k = 0; k < T2K; ++k) {
-        const int q = threadIdx.x + k*256;
+        const int q = threadIdx.x + k*NT;
         const int rj = q / T2RW, rix = q - rj*T2RW;
         const int gi = ti0 - 4 + rix, gj = tj0 - 4 + rj;
         rr[k] = 0.0; ri[k] = 0.0; cr[k] = 0.0; ci[k] = 0.0;
@@ -191,7 +191,7 @@ void k2_smooth_tile (Lev2 l, int src_mode, const double* __restrict__ fin, const
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int k = 0; k < T2K; ++k) {
-            const int q = threadIdx.x + k*256;
+            const int q = threadIdx.x + k*NT;
             const int rj = q / T2RW, rix = q - rj*T2RW;
             const int gi = ti0 - 4 + rix, gj = tj0 - 4 + rj;
             // distance to the tile, colour, domain
@@ -234,7 +234,7 @@ void k2_smooth_tile (Lev2 l, int src_mode, const double* __restrict__ fin, const
         r0 = rhs[o] - lp[0] + (ar*pr - ai*pi); r1 = rhs[l.n + o] - lp[1] + (ai*pr + ar*pi);
     };
     if (do_res && crse_res) {
-        for (int q = threadIdx.x; q < (T2X/2)*(T2Y/2); q += 256) {
+        for (int q = threadIdx.x; q < (T2X/2)*(T2Y/2); q += NT) {
             const int cj = q / (T2X/2), cix = q - cj*(T2X/2);
             const int gi0 = ti0 + 2*cix, gj0 = tj0 + 2*cj;
             if (gi0 >= l.nx || gj0 >= l.ny) continue;          // nx, ny even: the 2 x 2 block is inside or outside as a whole
@@ -255,7 +255,7 @@ void k2_smooth_tile (Lev2 l, int src_mode, const double* __restrict__ fin, const
             crse_res[oc] = 0.25*s0; crse_res[crn + oc] = 0.25*s1;
         }
     } else
-    for (int q = threadIdx.x; q < T2X*T2Y; q += 256) {
+    for (int q = threadIdx.x; q < T2X*T2Y; q += NT) {
         const int tj = q / T2X, tix = q - tj*T2X;
         const int gi = ti0 + tix, gj = tj0 + tj;
         if (gi >= l.nx || gj >= l.ny) continue;
@@ -367,11 +367,11 @@ static bool smooth4 (const Lev2& l, int src_mode, const double* fin, const doubl
         static const long big = getenv("HPS_MG2_BIG") ? atol(getenv("HPS_MG2_BIG")) : 256L*256L;      // measured: 65536 = 262144 > all small
         const bool fuse = do_res && crse_res && crl && l.nx % 2 == 0 && l.ny % 2 == 0;
         if (l.n > big)
-            hipLaunchKernelGGL((k2_smooth_tile<64, 32>), dim3(ceil_div(l.nx, 64), ceil_div(l.ny, 32)), dim3(256), 0, st, l, src_mode, fin, crse,
+            hipLaunchKernelGGL((k2_smooth_tile<64, 32, 512>), dim3(ceil_div(l.nx, 64), ceil_div(l.ny, 32)), dim3(512), 0, st, l, src_mode, fin, crse,
                                cl ? cl->nx : 0, cl ? cl->n : 0L, out, rhs, acf, do_res ? 1 : 0, res, norm, fuse ? crse_res : (double*)nullptr,
                                fuse ? crl->nx : 0, fuse ? crl->n : 0L);
         else
-            hipLaunchKernelGGL((k2_smooth_tile<32, 16>), dim3(ceil_div(l.nx, 32), ceil_div(l.ny, 16)), dim3(256), 0, st, l, src_mode, fin, crse,
+            hipLaunchKernelGGL((k2_smooth_tile<32, 16, 256>), dim3(ceil_div(l.nx, 32), ceil_div(l.ny, 16)), dim3(256), 0, st, l, src_mode, fin, crse,
                                cl ? cl->nx : 0, cl ? cl->n : 0L, out, rhs, acf, do_res ? 1 : 0, res, norm, fuse ? crse_res : (double*)nullptr,
                                fuse ? crl->nx : 0, fuse ? crl->n : 0L);
         return fuse;
