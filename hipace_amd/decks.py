@@ -178,6 +178,22 @@ def linear_wake_SI():
     return d
 
 
+def gaussian_linear_wake():
+    """tests/gaussian_linear_wake.normalized.1Rank.sh: the linear_wake deck with a wide Gaussian beam (+ rho)"""
+    d = linear_wake()
+    d.update(beam_profile=0, beam_zmin=-5.9, beam_zmax=5.9, beam_radius=10.0, beam_pos_mean=(0.0, 0.0, 0.0), beam_pos_std=(2.0, 2.0, 1.41),
+             lo=(-10.0, -10.0, -6.0), hi=(10.0, 10.0, 6.0), deposit_rho=1)
+    return d
+
+
+def gaussian_linear_wake_SI():
+    """tests/gaussian_linear_wake.SI.1Rank.sh: the same in SI units (examples/linear_wake/inputs_SI)"""
+    d = linear_wake_SI()
+    d.update(beam_profile=0, beam_zmin=-59.0e-6, beam_zmax=59.0e-6, beam_radius=100.0e-6, beam_pos_mean=(0.0, 0.0, 0.0),
+             beam_pos_std=(20.0e-6, 20.0e-6, 14.1e-6), lo=(-100.0e-6, -100.0e-6, -60.0e-6), hi=(100.0e-6, 100.0e-6, 60.0e-6), deposit_rho=1)
+    return d
+
+
 def beam_in_vacuum_1Rank():
     """tests/beam_in_vacuum.normalized.1Rank.sh: as the Serial run with hipace.MG_tolerance_rel = 1e-5."""
     d = beam_in_vacuum()
@@ -234,5 +250,5 @@ def predictor_corrector(base, tol=1.0e-4, max_iter=7, mix=0.0635):
     return d
 
 
-NAMED = dict(reset=reset, grid_current=grid_current, beam_in_vacuum_SI_Serial=beam_in_vacuum_SI_Serial, blowout_wake_step0=blowout_wake_step0, linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, laser_blowout_wake_SI=laser_blowout_wake_SI, linear_wake_SI=linear_wake_SI, blowout_wake_SI=blowout_wake_SI, beam_in_vacuum_SI=beam_in_vacuum_SI, beam_in_vacuum_1Rank=beam_in_vacuum_1Rank, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
+NAMED = dict(gaussian_linear_wake=gaussian_linear_wake, gaussian_linear_wake_SI=gaussian_linear_wake_SI, reset=reset, grid_current=grid_current, beam_in_vacuum_SI_Serial=beam_in_vacuum_SI_Serial, blowout_wake_step0=blowout_wake_step0, linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, laser_blowout_wake_SI=laser_blowout_wake_SI, linear_wake_SI=linear_wake_SI, blowout_wake_SI=blowout_wake_SI, beam_in_vacuum_SI=beam_in_vacuum_SI, beam_in_vacuum_1Rank=beam_in_vacuum_1Rank, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
              beam_evolution=beam_evolution, beam_in_vacuum_open_boundary=beam_in_vacuum_open_boundary)

@@ -16,6 +16,7 @@
 //   tests/checksum/benchmarks_json/{beam_in_vacuum.normalized.1Rank,beam_in_vacuum.SI.1Rank,beam_in_vacuum.SI.Serial}.json
 //   tests/checksum/benchmarks_json/{linear_wake.SI.1Rank,blowout_wake.2Rank,blowout_wake.Serial,grid_current.1Rank}.json
 //   tests/checksum/benchmarks_json/{laser_blowout_wake_explicit.1Rank,laser_blowout_wake_explicit.SI.1Rank}.json
+//   tests/checksum/benchmarks_json/{gaussian_linear_wake.normalized.1Rank,gaussian_linear_wake.SI.1Rank,reset.2Rank}.json
 //   tests/checksum/benchmarks_json/laser_evolution.SI.2Rank.json                          (FFT envelope solver, 30 steps)
 // (copied as data fixtures into tests/golden/), see tests/test_oracle_golden.py.  Parts no checksum of the
 // reference covers are pinned on the reference's own analysis criteria instead (predictor-corrector vs explicit

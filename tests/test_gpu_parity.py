@@ -181,7 +181,9 @@ def test_multigrid_solve1(api, oracle, nx, ny, warm):
                                      ("beam_in_vacuum", "beam_in_vacuum.normalized.Serial"),
                                      ("beam_in_vacuum_1Rank", "beam_in_vacuum.normalized.1Rank"),
                                      ("beam_in_vacuum_SI_Serial", "beam_in_vacuum.SI.Serial"),
-                                     ("grid_current", "grid_current.1Rank"), ("reset", "reset.2Rank")])
+                                     ("grid_current", "grid_current.1Rank"), ("reset", "reset.2Rank"),
+                                     ("gaussian_linear_wake", "gaussian_linear_wake.normalized.1Rank"),
+                                     ("gaussian_linear_wake_SI", "gaussian_linear_wake.SI.1Rank")])
 def test_engine_reproduces_reference_checksums(api, name, js):
     """North-star parity bar: field checksums within 1e-6 of the reference's CPU goldens."""
     gold = json.load(open(os.path.join(GOLD, js + ".json")))["lev=0"]

@@ -40,7 +40,10 @@ CASES = [("linear_wake", "linear_wake.normalized.1Rank"),
          ("blowout_wake_step0", "blowout_wake.Serial"),
          # grid_current.* (utils/GridCurrent.cpp): a Gaussian current on the grid that cancels the beam's
          ("grid_current", "grid_current.1Rank"),
-         ("reset", "reset.2Rank")]       # three time steps of the blowout deck, multigrid tolerance 1e-5
+         ("reset", "reset.2Rank"),
+         # the linear_wake deck with a wide Gaussian beam from fixed_ppc (tests/gaussian_linear_wake.*.1Rank.sh)
+         ("gaussian_linear_wake", "gaussian_linear_wake.normalized.1Rank"),
+         ("gaussian_linear_wake_SI", "gaussian_linear_wake.SI.1Rank")]       # three time steps of the blowout deck, multigrid tolerance 1e-5
 RTOL = {"blowout_wake.Serial": 2.0e-2}
 
 
