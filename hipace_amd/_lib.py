@@ -47,7 +47,8 @@ class Deck(C.Structure):
                 ("laser_lambda0", C.c_double), ("laser_pos", C.c_double * 3),
                 ("laser_zfoc", C.c_double), ("laser_solver", C.c_int), ("laser_use_phase", C.c_int), ("si_units", C.c_int),
                 ("grid_current_on", C.c_int), ("grid_current_peak", C.c_double), ("grid_current_mean", C.c_double * 3),
-                ("grid_current_std", C.c_double * 3), ("laser_mg_tol_rel", C.c_double), ("laser_mg_tol_abs", C.c_double)]
+                ("grid_current_std", C.c_double * 3), ("laser_mg_tol_rel", C.c_double), ("laser_mg_tol_abs", C.c_double),
+                ("beam_radiation_reaction", C.c_int), ("background_density_SI", C.c_double), ("beam_no_z_push", C.c_int)]
 
 
 # engine component names, index = value of the HPS_C_* enum in include/hpslice.h

@@ -22,6 +22,9 @@ struct BeamPushConsts {
     double ex_slope, ey_slope; // beams.external_E = (ex_slope*x, ey_slope*y, 0)
     int nsc;
     PartConsts pc;             // geometry, boundary
+    // radiation reaction (BeamParticleAdvance.cpp:101-113, 244-297): rr != 0 switches it on
+    int rr, normalized, no_z_push;
+    double RRcoeff, E0, wp_inv, c_SI;
 };
 
 template <int ORDER>
@@ -94,16 +97,33 @@ void k_beam_push (SlabView f, BeamSoA b, const long* __restrict__ B, int p, int 
         // ApplyExternalField (particles/pusher/ExternalFields.H:29-56), E = (ex_slope x, ey_slope y, 0), B = 0
         ExmBy += k.ex_slope*xp;
         EypBx += k.ey_slope*yp;
-        const double ux_next = ux + k.dt*k.qm*(ExmBy + (k.c - uz*gi)*By + uy*gi*Bz);
-        const double uy_next = uy + k.dt*k.qm*(EypBx + (uz*gi - k.c)*Bx - ux*gi*Bz);
+        double ux_next = ux + k.dt*k.qm*(ExmBy + (k.c - uz*gi)*By + uy*gi*Bz);
+        double uy_next = uy + k.dt*k.qm*(EypBx + (uz*gi - k.c)*Bx - ux*gi*Bz);
         const double ux_i = (ux_next + ux)*0.5, uy_i = (uy_next + uy)*0.5;
         const double uz_i = uz + k.dt*0.5*k.qm*Ez;
         const double gii = 1.0/sqrt(1.0 + (ux_i*ux_i + uy_i*uy_i + uz_i*uz_i)*k.inv_c2);
-        const double uz_next = uz + k.dt*k.qm*(Ez + (ux_i*By - uy_i*Bx)*gii);
+        double uz_next = uz + k.dt*k.qm*(Ez + (ux_i*By - uy_i*Bx)*gii);
+        if (k.rr) {      // classical radiation reaction in SI quantities (:244-297)
+            const double icSI = 1.0/k.c_SI, ic = 1.0/k.c;
+            double Ex = ExmBy + k.c*By, Ey = EypBx - k.c*Bx, Ezs = Ez, Bxs = Bx, Bys = By, Bzs = Bz;
+            if (k.normalized) { Ex *= k.E0; Ey *= k.E0; Ezs *= k.E0; Bxs *= k.E0*icSI; Bys *= k.E0*icSI; Bzs *= k.E0*icSI; }
+            const double gam = sqrt(1.0 + (ux_i*ux_i + uy_i*uy_i + uz_i*uz_i)*k.inv_c2);
+            const double vx = ux_i*gii*k.c_SI*ic, vy = uy_i*gii*k.c_SI*ic, vz = uz_i*gii*k.c_SI*ic;
+            const double bx = vx*icSI, by = vy*icSI, bz = vz*icSI;
+            const double flx = (Ex + vy*Bzs - vz*Bys), fly = (Ey + vz*Bxs - vx*Bzs), flz = (Ezs + vx*Bys - vy*Bxs);
+            const double fl2 = flx*flx + fly*fly + flz*flz;
+            const double bE = (bx*Ex + by*Ey + bz*Ezs);
+            const double coeff = gam*gam*(fl2 - bE*bE);
+            const double frx = k.RRcoeff*(k.c_SI*(fly*Bzs - flz*Bys) + bE*Ex - coeff*bx);
+            const double fry = k.RRcoeff*(k.c_SI*(flz*Bxs - flx*Bzs) + bE*Ey - coeff*by);
+            const double frz = k.RRcoeff*(k.c_SI*(flx*Bys - fly*Bxs) + bE*Ezs - coeff*bz);
+            const double sc = k.dt*k.wp_inv*k.c*icSI;
+            ux_next += frx*sc; uy_next += fry*sc; uz_next += frz*sc;
+        }
         const double gni = 1.0/sqrt(1.0 + (ux_next*ux_next + uy_next*uy_next + uz_next*uz_next)*k.inv_c2);
         xp += k.dt*0.5*ux_next*gni;
         yp += k.dt*0.5*uy_next*gni;
-        zp += k.dt*(uz_next*gni - k.c);                       // do_z_push
+        if (!k.no_z_push) zp += k.dt*(uz_next*gni - k.c);     // do_z_push (:316)
         ux = ux_next; uy = uy_next; uz = uz_next;
     }
     if (apply_particle_bc(k.pc, xp, yp, ux, uy)) { b.w[ip] = 0.0; b.nsub[ip] = -1; return; }
@@ -216,6 +236,13 @@ static BeamPushConsts push_consts (const Engine& E, int islice)
     k.min_z = d.lo[2] + islice*E.gm.dz;
     k.ex_slope = d.ext_E_slope[0]; k.ey_slope = d.ext_E_slope[1];
     k.pc = base_consts(E.gm);
+    // radiation reaction constants (:101-113), PhysConstSI of utils/Constants.H:15-24
+    const double cSI = 299792458.0, qeSI = 1.602176634e-19, meSI = 9.1093837015e-31, ep0SI = 8.8541878128e-12, reSI = 2.817940326204929e-15;
+    k.rr = d.beam_radiation_reaction; k.normalized = d.si_units ? 0 : 1; k.no_z_push = d.beam_no_z_push; k.c_SI = cSI;
+    const double q_over_mc = k.normalized ? k.qm/cSI*qeSI/meSI : k.qm/cSI;
+    k.RRcoeff = (2.0/3.0)*reSI*q_over_mc*q_over_mc;
+    k.wp_inv = (k.normalized && d.background_density_SI > 0.0) ? std::sqrt(ep0SI*meSI/(d.background_density_SI*qeSI*qeSI)) : 1.0;
+    k.E0 = k.normalized ? meSI*cSI/k.wp_inv/qeSI : 1.0;
     return k;
 }
 

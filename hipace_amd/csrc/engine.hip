@@ -449,6 +449,8 @@ int Engine::create (const hps_deck& deck, int device)
     HPS_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     g = (d.order + 1)/2 + 1;                       // Fields::AllocData (fields/Fields.cpp:63-64)
     ncomp = pc ? (d.deposit_rho ? HPS_PC_RHO + 1 : HPS_PC_RHO) : (d.deposit_rho ? HPS_C_RHO + 1 : HPS_C_RHO);
+    if (d.beam_radiation_reaction && !d.si_units && !(d.background_density_SI > 0.0)) {      // BeamParticleAdvance.cpp:39-43
+        set_error("hps_engine_create: radiation reaction in normalised units needs background_density_SI"); return HPS_ERR_ARG; }
     if (d.laser_on) {
         if (pc) { set_error("hps_engine_create: the laser needs the explicit solver"); return HPS_ERR_UNSUPPORTED; }
         HPS_REQUIRE(d.laser_w0 > 0.0 && d.laser_L0 > 0.0 && d.laser_lambda0 > 0.0, "hps_engine_create: laser w0, L0, lambda0 must be positive");

@@ -47,6 +47,7 @@ _DEFAULT = dict(
     laser_a0=0.0, laser_w0=1.0, laser_L0=1.0, laser_lambda0=0.8e-6, laser_pos=(0.0, 0.0, 0.0),
     laser_zfoc=0.0,          # laser.focal_distance
     laser_solver=0,          # lasers.solver_type: 0 keep the envelope static, 1 "fft" (AdvanceSliceFFT), 2 "multigrid" (AdvanceSliceMG)
+    beam_radiation_reaction=0, background_density_SI=0.0, beam_no_z_push=0,      # <beam>.do_radiation_reaction, hipace.background_density_SI, <beam>.do_z_push = 0
     laser_mg_tol_rel=1.0e-4, laser_mg_tol_abs=0.0,      # lasers.MG_tolerance_rel / MG_tolerance_abs
     laser_use_phase=1,       # lasers.use_phase (MultiLaser.H:203)
     grid_current_on=0, grid_current_peak=0.0, grid_current_mean=(0.0, 0.0, 0.0), grid_current_std=(1.0, 1.0, 1.0),   # grid_current.*
@@ -194,6 +195,20 @@ def gaussian_linear_wake_SI():
     return d
 
 
+def radiation_reaction():
+    """examples/beam_in_vacuum/inputs_RR (tests/radiation_reaction.1Rank.sh) in normalised units (n0 = 5e24 m^-3): a
+    gamma = 2000 beam in the linear focusing field E = (x/2, y/2, 0) of a blowout, no z push, 50 sub-cycles, steps of
+    30 / omega_beta; the beam comes from fixed_ppc (flat top of radius 2.5 / kp, at rest transversely) instead of the
+    reference's random Gaussian."""
+    d = beam_evolution()
+    w_beta = 1.0 / (2.0 * 2000.0) ** 0.5
+    d.update(nx=32, ny=32, nz=10, lo=(-12.6, -12.6, -4.2), hi=(12.6, 12.6, 4.2), beam_profile=1, beam_zmin=-2.0, beam_zmax=2.0,
+             beam_radius=2.5, beam_density=1.0e-10, beam_umean=(0.0, 0.0, 2000.0), beam_ppc=(2, 2, 1), ext_E_slope=(0.5, 0.5),
+             dt=30.0 / w_beta, n_steps=6, beam_n_subcycles=50, beam_radiation_reaction=1, background_density_SI=5.0e24,
+             beam_no_z_push=1)
+    return d
+
+
 def beam_in_vacuum_1Rank():
     """tests/beam_in_vacuum.normalized.1Rank.sh: as the Serial run with hipace.MG_tolerance_rel = 1e-5."""
     d = beam_in_vacuum()
@@ -250,5 +265,5 @@ def predictor_corrector(base, tol=1.0e-4, max_iter=7, mix=0.0635):
     return d
 
 
-NAMED = dict(gaussian_linear_wake=gaussian_linear_wake, gaussian_linear_wake_SI=gaussian_linear_wake_SI, reset=reset, grid_current=grid_current, beam_in_vacuum_SI_Serial=beam_in_vacuum_SI_Serial, blowout_wake_step0=blowout_wake_step0, linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, laser_blowout_wake_SI=laser_blowout_wake_SI, linear_wake_SI=linear_wake_SI, blowout_wake_SI=blowout_wake_SI, beam_in_vacuum_SI=beam_in_vacuum_SI, beam_in_vacuum_1Rank=beam_in_vacuum_1Rank, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
+NAMED = dict(radiation_reaction=radiation_reaction, gaussian_linear_wake=gaussian_linear_wake, gaussian_linear_wake_SI=gaussian_linear_wake_SI, reset=reset, grid_current=grid_current, beam_in_vacuum_SI_Serial=beam_in_vacuum_SI_Serial, blowout_wake_step0=blowout_wake_step0, linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, laser_blowout_wake_SI=laser_blowout_wake_SI, linear_wake_SI=linear_wake_SI, blowout_wake_SI=blowout_wake_SI, beam_in_vacuum_SI=beam_in_vacuum_SI, beam_in_vacuum_1Rank=beam_in_vacuum_1Rank, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
              beam_evolution=beam_evolution, beam_in_vacuum_open_boundary=beam_in_vacuum_open_boundary)

@@ -211,6 +211,10 @@ typedef struct {
     /* laser_solver = 2: lasers.solver_type = multigrid (MultiLaser::AdvanceSliceMG, laser/MultiLaser.cpp:430-608: hpmg
      * system type 2, MG_average_rhs = 1, at most 200 V-cycles); lasers.MG_tolerance_rel (0 -> 1e-4) / MG_tolerance_abs */
     double laser_mg_tol_rel, laser_mg_tol_abs;
+    /* <beam>.do_radiation_reaction (classical Landau-Lifshitz force in the beam push, particles/pusher/
+     * BeamParticleAdvance.cpp:244-297; in normalised units it needs hipace.background_density_SI to convert the fields)
+     * and <beam>.do_z_push (0 = skip z += dt (vz - c), :316; the ABI reads beam_no_z_push so that 0 keeps the default) */
+    int beam_radiation_reaction; double background_density_SI; int beam_no_z_push;
 } hps_deck;
 
 /* slab component indices of the engine (explicit-solver layout of fields/Fields.cpp:70-122) */

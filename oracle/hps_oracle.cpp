@@ -999,6 +999,7 @@ struct Deck {
     int laser_solver;            // lasers.solver_type: 0 = envelope kept static, 1 = "fft" (MultiLaser::AdvanceSliceFFT),
                                  // 2 = "multigrid" (MultiLaser::AdvanceSliceMG, MG_average_rhs = 1)
     double laser_mg_tol_rel = 1.e-4, laser_mg_tol_abs = 0.0;      // lasers.MG_tolerance_rel / _abs (MultiLaser.H:216-217)
+    int beam_radiation_reaction = 0; double background_density_SI = 0.0; int beam_no_z_push = 0;
     int laser_use_phase;         // lasers.use_phase (MultiLaser.H:203, default true)
     int grid_current_on = 0;     // grid_current.use_grid_current (utils/GridCurrent.cpp:13-23)
     double grid_current_peak = 0., grid_current_mean[3] = {0., 0., 0.}, grid_current_std[3] = {1., 1., 1.};
@@ -1652,8 +1653,6 @@ struct Engine {
         store_ready = true;
     }
 
-    // AdvanceBeamParticlesSlice (particles/pusher/BeamParticleAdvance.cpp:20-336) without radiation reaction,
-    // spin and mesh refinement; external field E = (s0 x, s1 y, 0) (ExternalFields.H:29-56)
     // BeamParticleContainer::InSituComputeDiags (particles/beam/BeamParticleContainer.cpp:476-556): the 23 per-slice
     // entries of the particles of this slice (slipped ones excluded, :494), before the beam push (Hipace.cpp:681)
     std::vector<double> insitu_bm; double insitu_bm_radius = 0.0;
@@ -1678,8 +1677,19 @@ struct Engine {
         for (int q = 0; q < 23; ++q) insitu_bm[(size_t)q*d.nz + islice] = s[q]*((q == 0 || q == 22) ? 1.0 : sum_w_inv);
     }
 
+    // AdvanceBeamParticlesSlice (particles/pusher/BeamParticleAdvance.cpp:20-336) without spin and mesh refinement;
+    // external field E = (s0 x, s1 y, 0) (ExternalFields.H:29-56); optional radiation reaction (:244-297)
     void advance_beam_slice (int islice) {
         Beam& b = store[islice];
+        // radiation reaction constants (:101-113), PhysConstSI of utils/Constants.H:15-24
+        const bool rr = d.beam_radiation_reaction != 0;
+        const double cSI = 299792458.0, qeSI = 1.602176634e-19, meSI = 9.1093837015e-31, ep0SI = 8.8541878128e-12, reSI = 2.817940326204929e-15;
+        const bool normalized = !d.si_units;
+        const double q_over_mc = normalized ? (d.beam_charge/d.beam_mass)/cSI*qeSI/meSI : (d.beam_charge/d.beam_mass)/cSI;
+        const double RRcoeff = (2.0/3.0)*reSI*q_over_mc*q_over_mc;
+        const double wp_inv = normalized ? std::sqrt(ep0SI*meSI/(d.background_density_SI*qeSI*qeSI)) : 1.0;
+        const double E0 = normalized ? meSI*cSI/wp_inv/qeSI : 1.0;
+        const double inv_clight_SI = 1.0/cSI, inv_clight = 1.0/gm.c;
         const int nsc = d.beam_n_subcycles;
         const Real dt = d.dt/nsc;
         const Real clight = gm.c, inv_c2 = 1.0/(gm.c*gm.c);
@@ -1705,16 +1715,34 @@ struct Engine {
                     const Real Ex = d.ext_E_slope[0]*xp, Ey = d.ext_E_slope[1]*yp, Ezx = 0.0, Bx_ = 0.0, By_ = 0.0, Bz_ = 0.0;
                     ExmByp += Ex - clight*By_; EypBxp += Ey + clight*Bx_; Ezp += Ezx; Bxp += Bx_; Byp += By_; Bzp += Bz_;
                 }
-                const Real ux_next = ux + dt*qm*(ExmByp + (clight - uz*gammap_inv)*Byp + uy*gammap_inv*Bzp);
-                const Real uy_next = uy + dt*qm*(EypBxp + (uz*gammap_inv - clight)*Bxp - ux*gammap_inv*Bzp);
+                Real ux_next = ux + dt*qm*(ExmByp + (clight - uz*gammap_inv)*Byp + uy*gammap_inv*Bzp);
+                Real uy_next = uy + dt*qm*(EypBxp + (uz*gammap_inv - clight)*Bxp - ux*gammap_inv*Bzp);
                 const Real ux_i = (ux_next + ux)*0.5, uy_i = (uy_next + uy)*0.5;
                 const Real uz_i = uz + dt*0.5*qm*Ezp;
                 const Real gamma_i_inv = 1.0/std::sqrt(1.0 + (ux_i*ux_i + uy_i*uy_i + uz_i*uz_i)*inv_c2);
-                const Real uz_next = uz + dt*qm*(Ezp + (ux_i*Byp - uy_i*Bxp)*gamma_i_inv);
+                Real uz_next = uz + dt*qm*(Ezp + (ux_i*Byp - uy_i*Bxp)*gamma_i_inv);
+                if (rr) {      // :244-297
+                    Real Exp = ExmByp + clight*Byp, Eyp = EypBxp - clight*Bxp;
+                    if (normalized) { Exp *= E0; Eyp *= E0; Ezp *= E0; Bxp *= E0*inv_clight_SI; Byp *= E0*inv_clight_SI; Bzp *= E0*inv_clight_SI; }
+                    const Real gamma_i = std::sqrt(1.0 + (ux_i*ux_i + uy_i*uy_i + uz_i*uz_i)*inv_c2);
+                    const Real vx_n = ux_i*gamma_i_inv*cSI*inv_clight, vy_n = uy_i*gamma_i_inv*cSI*inv_clight, vz_n = uz_i*gamma_i_inv*cSI*inv_clight;
+                    const Real bx_n = vx_n*inv_clight_SI, by_n = vy_n*inv_clight_SI, bz_n = vz_n*inv_clight_SI;
+                    const Real flx_q = (Exp + vy_n*Bzp - vz_n*Byp), fly_q = (Eyp + vz_n*Bxp - vx_n*Bzp), flz_q = (Ezp + vx_n*Byp - vy_n*Bxp);
+                    const Real fl_q2 = flx_q*flx_q + fly_q*fly_q + flz_q*flz_q;
+                    const Real bdotE = (bx_n*Exp + by_n*Eyp + bz_n*Ezp);
+                    const Real bdotE2 = bdotE*bdotE;
+                    const Real coeff = gamma_i*gamma_i*(fl_q2 - bdotE2);
+                    const Real frx = RRcoeff*(cSI*(fly_q*Bzp - flz_q*Byp) + bdotE*Exp - coeff*bx_n);
+                    const Real fry = RRcoeff*(cSI*(flz_q*Bxp - flx_q*Bzp) + bdotE*Eyp - coeff*by_n);
+                    const Real frz = RRcoeff*(cSI*(flx_q*Byp - fly_q*Bxp) + bdotE*Ezp - coeff*bz_n);
+                    ux_next += frx*dt*wp_inv*clight*inv_clight_SI;
+                    uy_next += fry*dt*wp_inv*clight*inv_clight_SI;
+                    uz_next += frz*dt*wp_inv*clight*inv_clight_SI;
+                }
                 const Real gamma_next_inv = 1.0/std::sqrt(1.0 + (ux_next*ux_next + uy_next*uy_next + uz_next*uz_next)*inv_c2);
                 xp += dt*0.5*ux_next*gamma_next_inv;
                 yp += dt*0.5*uy_next*gamma_next_inv;
-                zp += dt*(uz_next*gamma_next_inv - clight);     // do_z_push (default true)
+                if (!d.beam_no_z_push) zp += dt*(uz_next*gamma_next_inv - clight);     // do_z_push (default true, :316)
                 ux = ux_next; uy = uy_next; uz = uz_next;
             }
             if (gone) continue;
@@ -1918,6 +1946,7 @@ struct orc_deck {
     double laser_zfoc; int laser_solver; int laser_use_phase; int si_units;
     int grid_current_on; double grid_current_peak, grid_current_mean[3], grid_current_std[3];
     double laser_mg_tol_rel, laser_mg_tol_abs;
+    int beam_radiation_reaction; double background_density_SI; int beam_no_z_push;
 };
 
 void* orc_engine_create (const orc_deck* k) {
@@ -1939,6 +1968,7 @@ void* orc_engine_create (const orc_deck* k) {
     d.laser_zfoc=k->laser_zfoc; d.laser_solver=k->laser_solver; d.laser_use_phase=k->laser_use_phase; d.si_units=k->si_units;
     d.grid_current_on=k->grid_current_on; d.grid_current_peak=k->grid_current_peak;
     for (int i=0;i<3;++i){d.grid_current_mean[i]=k->grid_current_mean[i]; d.grid_current_std[i]=k->grid_current_std[i];}
+    d.beam_radiation_reaction=k->beam_radiation_reaction; d.background_density_SI=k->background_density_SI; d.beam_no_z_push=k->beam_no_z_push;
     d.laser_mg_tol_rel = k->laser_mg_tol_rel > 0.0 ? k->laser_mg_tol_rel : 1.e-4; d.laser_mg_tol_abs = k->laser_mg_tol_abs;
     return new Engine(d);
 }

@@ -467,6 +467,42 @@ def test_beam_slipping_matches_oracle(api, oracle):
 
 
 @pytest.mark.gpu
+def test_beam_push_with_radiation_reaction_matches_oracle(api, oracle):
+    """<beam>.do_radiation_reaction and do_z_push = 0 (particles/pusher/BeamParticleAdvance.cpp:244-297, 316) on the deck of
+    the oracle's theory test (examples/beam_in_vacuum/inputs_RR in normalised units): every particle's state after six
+    steps equals the oracle's to 1e-10, and the energy lost is the oracle's."""
+    deck = decks.radiation_reaction()
+    eng = api.SliceEngine(deck, tile_size=0)
+    eng.set_insitu_beam(float("inf"))
+    for _ in range(deck["n_steps"]):
+        eng.run_step()
+    ref = oracle.Engine(deck)
+    ref.set_insitu_beam(float("inf"))
+    ref.run()
+    bnd, soa = eng.beam_state()
+    nz = deck["nz"]
+    total = 0
+    for p in range(nz):
+        want = ref.beam_slice(nz - 1 - p)
+        got = soa[:, bnd[p]:bnd[p + 1]]
+        assert got.shape == want.shape, (p, got.shape, want.shape)
+        total += want.shape[1]
+        if want.shape[1]:
+            # symmetric partners share |x|, |y| to rounding: order by rounded keys
+            ko = np.lexsort((np.round(want[1], 6), np.round(want[0], 6))); kg = np.lexsort((np.round(got[1], 6), np.round(got[0], 6)))
+            assert np.abs(got[:, kg] - want[:, ko]).max() <= 1e-10 * np.abs(want).max()
+    assert total > 100
+    gi, oi = eng.insitu_beam(), ref.insitu_beam()
+    w = oi[0]
+    g_ref = (w * oi[20]).sum() / w.sum()
+    g_gpu = (gi["sum(w)"] * gi["[ga]"]).sum() / gi["sum(w)"].sum()
+    assert 2000.0 - g_ref > 5.0 and abs(g_gpu - g_ref) < 1e-9 * g_ref
+    # normalised units without hipace.background_density_SI: refused as the reference asserts (:39-43)
+    with pytest.raises(RuntimeError):
+        api.SliceEngine(dict(deck, background_density_SI=0.0))
+
+
+@pytest.mark.gpu
 def test_moving_beam_through_the_ring_hand_off(api, oracle):
     """world = 1 pipeline (in-process hand-off through export / import messages on the device) of a beam that slips
     every step: per-step checksums equal those of the oracle stepping the same deck."""

@@ -245,3 +245,42 @@ def test_laser_evolution_multigrid_solver_follows_theory_and_the_fft_solver(orac
             fe.solve_slice(isl)
     af = fe.laser_envelope()
     assert np.abs(a - af).max() <= 2e-3 * np.abs(af).max(), np.abs(a - af).max() / np.abs(af).max()
+
+
+def test_radiation_reaction_energy_loss_follows_theory(oracle):
+    """<beam>.do_radiation_reaction (particles/pusher/BeamParticleAdvance.cpp:244-297), pinned as the reference pins it
+    (tests/radiation_reaction.1Rank.sh -> examples/beam_in_vacuum/analysis_RR.py, eq. 31-32 of the paper cited there):
+    mean gamma after t follows gamma0 / (1 + nu t) with nu = tau_r c^2 K^4 gamma0 <x_m^2> / 2, K = kp / sqrt(2), x_m the
+    betatron amplitude (here: the initial radius, the particles start at rest) -- to 1e-3 of gamma as the reference asks,
+    and to 15 % of the energy actually lost (difference to the same run without the switch: 12.1 against 11.0 of the
+    period-averaged theory, with 0.6 rad of betatron phase per sub-cycle)."""
+    SI = decks.SI
+    deck = decks.radiation_reaction()
+    means = {}
+    for rr in (1, 0):
+        d = dict(deck, beam_radiation_reaction=rr)
+        eng = oracle.Engine(d)
+        eng.set_insitu_beam(np.inf)
+        hist = []
+        for step in range(d["n_steps"]):
+            eng.begin_step()
+            for isl in range(d["nz"] - 1, -1, -1):
+                eng.solve_slice(isl)
+            m = eng.insitu_beam()
+            w = m[0]
+            hist.append(((w * m[20]).sum() / w.sum(), (w * (m[2] + m[4])).sum() / w.sum()))      # <gamma>, <x^2 + y^2>
+        means[rr] = hist
+    g0, r2 = means[1][0]
+    wp = np.sqrt(5.0e24 * SI["q_e"] ** 2 / (SI["m_e"] * SI["ep0"]))
+    tau_r = 2.0 * 2.817940326204929e-15 / (3.0 * SI["c"]) * wp                 # in units of 1 / wp
+    nu = tau_r * 0.25 * g0 * r2 / 2.0                                          # K^4 = 1/4 with kp = c = 1
+    t = (deck["n_steps"] - 1) * deck["dt"]
+    g_theo = g0 / (1.0 + nu * t)
+    g_sim = means[1][-1][0]
+    assert abs(g0 - np.sqrt(1.0 + 2000.0 ** 2)) < 1e-9 * g0
+    assert g0 - g_theo > 5.0                                                   # the deck does radiate: ~ 0.7 % of gamma
+    assert abs(g_sim - g_theo) / g_theo < 1e-3
+    # against the same run without the switch (its gamma only breathes with the betatron phase, by x^2 / 4 < 1)
+    g_off = means[0][-1][0]
+    assert abs(g_off - g0) < 1e-3 * g0
+    assert abs((g_off - g_sim) - (g0 - g_theo)) < 0.15 * (g0 - g_theo), (g_off - g_sim, g0 - g_theo)
