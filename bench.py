@@ -8,13 +8,25 @@ hipace.dt = 0.  The default run times one whole box (1024 slices = one time step
 per-step plasma re-initialisation); slices/s = slices / wall time, particle-pushes/s = 4*1024^2
 times that.  All inputs are generated on the device before the timed region.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  The path shards as the
-reference does, over time steps (rank r runs steps r, r+N, ...: Hipace.cpp:400-401), each rank
-sweeping the whole box; weak scaling, value = total slices of all ranks / max-over-ranks time.
+--steps K < 1024: the cost of a slice varies along the box (the head slices ahead of the driver see an
+unperturbed sheet: fewer multigrid V-cycles, even tiles), so a short run is NOT taken at the head: the
+engine first runs (untimed) down to slice --start-slice, where a window of K slices costs what the whole
+box costs on average, then W warm-up slices, then exactly K timed slices.  The line says which slices were
+timed and how many V-cycles they needed.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL; `python bench.py --gpus N` without
+torchrun re-executes itself under `python -m torch.distributed.run`).  The path shards as the reference
+does, over time steps (rank r runs steps r, r+N, ...: Hipace.cpp:400-401), each rank sweeping the whole box
+and handing every slice's beam block to the next rank over the C-ABI RCCL ring (hps_ring_*, one message per
+slice, event-ordered, no host synchronisation per slice).  Weak scaling, value = total slices of all
+ranks / max-over-ranks time.  K >= 1024: whole steps, pipeline fill included.  K < 1024: the pipeline is
+filled before the clock starts (rank r runs 2r slices behind rank 0, as the hand-off requires), then every
+rank times K slices.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,6 +35,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PMC_SUMMARY = "r02_pmc_fetch_write_per_kernel.csv"      # profiles/: rocprofv3 --pmc summary of the shipped kernels
+START_SLICE_DEFAULT = 600  # short runs start here (from the head); see profiles/r02_slice_cost_profile.json
 
 
 def algorithmic_bytes(n, ppc2):
@@ -40,72 +54,121 @@ def algorithmic_bytes(n, ppc2):
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of `kernel_prefix` from the committed rocprofv3 --pmc summary (two separate
     passes, FETCH_SIZE and WRITE_SIZE, scripts/pmc_traffic.py).  Units are KB; on gfx950 FETCH_SIZE reports
-    half of the bytes of a coalesced read (MI355X_MICROARCH.md, HBM section) -- calibrated here on
+    half of the bytes of a coalesced read (MI355X_MICROARCH.md, HBM section) -- calibrated on
     k_copy_comps / k_zero_comps / k_init_plasma, whose byte counts are known: FETCH x2, WRITE x1.
-    Only valid for the default 1024^2 x 4 ppc workload the counters were collected on."""
+    Only valid for the default 1024^2 x 4 ppc workload the counters were collected on.  Returns
+    (bytes, source) -- NOT measured in this run: the counters need their own rocprofv3 passes."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01h_pmc_fetch_write_per_kernel.csv")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        for r in csv.DictReader(f):
-            if r["kernel"].startswith(kernel_prefix):
-                return (2.0 * float(r["FETCH_SIZE_raw_per_launch"]) + float(r["WRITE_SIZE_raw_per_launch"])) * 1024.0
-    return None
+    for name in (PMC_SUMMARY, "r01h_pmc_fetch_write_per_kernel.csv"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if r["kernel"].startswith(kernel_prefix):
+                    b = (2.0 * float(r["FETCH_SIZE_raw_per_launch"]) + float(r["WRITE_SIZE_raw_per_launch"])) * 1024.0
+                    return b, f"committed rocprofv3 --pmc summary profiles/{name} (FETCH_SIZE x2 + WRITE_SIZE, separate passes; not collected in this run)"
+    return None, None
 
 
-def cpu_baseline(n, ppc, nslices):
-    """Time the CPU oracle (single-thread restatement of the reference's serial path) on the head
-    `nslices` slices of the same deck."""
+def cpu_baseline(n, ppc, nslices, threads):
+    """Time the CPU oracle (restatement of the reference's CPU path) on the head `nslices` slices of the same deck:
+    one thread (the reference's serial build) and `threads` OpenMP threads (4-colour tiles in the scatter kernels, as
+    the reference's OpenMP build does: DepositionUtil.H:232-253)."""
     from hipace_amd import decks
     from oracle import oracle as O
     deck = decks.synthetic(n, 1024, ppc)
-    eng = O.Engine(deck)
-    eng.begin_step()
-    t0 = time.perf_counter()
-    for k in range(nslices):
-        eng.solve_slice(deck["nz"] - 1 - k)
-    dt = time.perf_counter() - t0
-    return dict(value=nslices / dt, unit="slices/s", cores=1, kind="port",
-                sample=f"oracle (serial C++ restatement, g++ -O2), head {nslices} slices of the same "
-                       f"{n}x{n}x1024 {ppc * ppc}ppc deck, {dt:.1f} s")
+    host = os.cpu_count() or 1
+    legs = {}
+    for nt in sorted({1, max(1, threads)}):
+        O.set_threads(nt)
+        eng = O.Engine(deck)
+        eng.begin_step()
+        t0 = time.perf_counter()
+        for k in range(nslices):
+            eng.solve_slice(deck["nz"] - 1 - k)
+        dt = time.perf_counter() - t0
+        legs[nt] = (nslices / dt, dt)
+        del eng
+    O.set_threads(1)
+    best = max(legs)
+    out = dict(value=legs[best][0], unit="slices/s", cores=best, host_cores=host, kind="port",
+               serial_value=legs[1][0],
+               sample=f"oracle (C++ restatement of the reference's CPU path, g++ -O2 -fopenmp), head {nslices} slices of the same "
+                      f"{n}x{n}x1024 {ppc * ppc}ppc deck: 1 thread {legs[1][1]:.1f} s"
+                      + (f", {best} threads {legs[best][1]:.1f} s" if best > 1 else ""))
+    return out
+
+
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1024, help="timed slices")
+    ap.add_argument("--steps", type=int, default=1024, help="timed slices (per GPU)")
     ap.add_argument("--warmup", type=int, default=64, help="untimed warm-up slices")
     ap.add_argument("--n", type=int, default=1024, help="transverse cells per side")
     ap.add_argument("--ppc", type=int, default=2, help="plasma particles per cell per direction")
     ap.add_argument("--tile", type=int, default=16, help="particle tile size (0, 16, 32)")
     ap.add_argument("--sort-period", type=int, default=128, help="max slices between particle re-sorts (adaptive below)")
     ap.add_argument("--cpu-slices", type=int, default=4, help="slices of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--profile-stride", type=int, default=7,
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline's OpenMP leg (0 = all host cores)")
+    ap.add_argument("--start-slice", type=int, default=-1,
+                    help="--steps < nz: slice (counted from the head) where the warm-up + timed window starts; -1 = "
+                         f"{START_SLICE_DEFAULT} scaled to the box (a window there costs what the whole box costs on average)")
+    ap.add_argument("--profile-stride", type=int, default=0,
                     help="HIP-event phase timers (and with them the roofline's kernel duration) on every n-th slice of the "
-                         "timed region: the 11 event records of a timed slice cost 4.5 %% of it")
+                         "timed region: the 11 event records of a timed slice cost 4.5 %% of it.  0 = 7 for whole boxes, 1 "
+                         "when fewer than 64 slices are timed")
     ap.add_argument("--inflight", type=int, default=1,
                     help="time steps in flight on one GPU (hipace_amd/pipeline.py::run_local_pipeline): L engines on L "
-                         "streams, step s+1 trails step s by the per-slice beam hand-off.  Needs --steps >= L boxes.  "
-                         "Default 1; with --gpus N > 1 every rank runs L stages of the ring (gloo-tested, not yet on RCCL)")
+                         "streams, step s+1 trails step s by the per-slice beam hand-off.  Needs --steps >= L boxes; one GPU only")
     ap.add_argument("--laser-solver", choices=["fft", "multigrid"], default="fft",
                     help="--config5: lasers.solver_type (multigrid = hpmg system type 2, the reference's default)")
     ap.add_argument("--config5", action="store_true",
-                    help="BASELINE config 5 without its ionisation (not built): laser_blowout_wake 1024x1024x2048, 4 ppc, a "
-                         "Gaussian laser pulse drives the wake and is advanced by the FFT envelope solver on every slice; "
-                         "the three time levels of the envelope (3 x 34 GB) stay in HBM (not the judged bench line)")
+                    help="BASELINE config 5: laser_blowout_wake 1024x1024x2048, 4 ppc, a Gaussian laser pulse drives the wake "
+                         "and is advanced by the envelope solver on every slice; the time levels of the envelope stay in HBM "
+                         "(not the judged bench line)")
     ap.add_argument("--config2", action="store_true",
                     help="BASELINE config 2 instead of the headline workload: linear_wake 256x256x512, 4 ppc, "
                          "predictor-corrector Bx/By solver (not the judged bench line)")
+    ap.add_argument("--spawn-check", action="store_true",
+                    help="only check the launch path: every rank joins the process group (gloo, no GPU needed) and rank 0 "
+                         "prints how many ranks there are")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    from hipace_amd import api, decks
-
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(respawn_under_torchrun(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
+
+    import torch
+    import torch.distributed as dist
+    if args.spawn_check:
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"spawn_check": True, "n_gpus": int(t.item()), "world_size": dist.get_world_size()}))
+        dist.destroy_process_group()
+        return
+
+    from hipace_amd import api, decks
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local)
     if world > 1:
@@ -117,8 +180,6 @@ def main():
         nz, args.n, args.ppc = 512, 256, 2
         deck = decks.predictor_corrector(decks.linear_wake(), 4.0e-2, 30, 0.05)
         deck.update(nx=256, ny=256, nz=nz, plasma_ppc=(2, 2))
-        args.steps = min(args.steps, nz) if args.inflight <= 1 else args.steps
-        # (the loop's cost depends on the slice: every run_slices() starts a box from its head)
         args.cpu_slices = 0
     if args.config5:
         nz = 2048
@@ -127,21 +188,17 @@ def main():
                     laser_L0=2.0, laser_lambda0=0.08, laser_solver=2 if args.laser_solver == "multigrid" else 1, dt=5.0)
         args.cpu_slices = 0
         args.inflight = 1
+    if world > 1:
+        args.inflight = 1
     eng = api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period)
     lanes = 1
     if args.inflight > 1:
-        lanes = max(1, min(args.inflight, args.steps // nz))      # whole boxes only: head slices are cheaper than the rest
+        lanes = max(1, min(args.inflight, args.steps // nz))      # whole boxes only
     engines = [eng] + [api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period)
                        for _ in range(lanes - 1)]
-
-    def run_slices(count, profile=False):
-        done = 0
-        while done < count:
-            eng.begin_step()
-            m = min(nz, count - done)
-            for k in range(m):
-                eng.solve_slice(nz - 1 - k)
-            done += m
+    short = args.steps < nz and lanes == 1
+    stride = args.profile_stride if args.profile_stride > 0 else (1 if args.steps < 64 else 7)
+    dev = torch.device("cuda", local)
 
     def barrier():
         eng.sync()
@@ -149,36 +206,84 @@ def main():
         if world > 1:
             dist.barrier()
 
-    run_slices(args.warmup)
-    groups = None
-    staged = lanes > 1 or (args.config5 and world > 1)       # the laser's time levels travel through the multi-stage ring only
-    if staged:
-        from hipace_amd.pipeline import make_edge_groups, run_local_pipeline
-        groups = make_edge_groups(world)
-    if lanes > 1:
-        run_local_pipeline(engines, lanes, torch.device("cuda", local), slices_per_step=max(2, args.warmup))   # warm every lane
-    for e in engines:
-        e.set_profiling(True, stride=args.profile_stride)
-    barrier()
-    t0 = time.perf_counter()
-    if staged:
-        # `lanes` pipeline stages per GPU; every stage sweeps whole boxes.  world > 1 (opt-in, --inflight): stage
-        # r*lanes + l on rank r, RCCL only on the rank-to-rank edges
-        boxes = max(1, args.steps // nz) * world
-        args.steps = run_local_pipeline(engines, boxes, torch.device("cuda", local), rank=rank, world=world, groups=groups)
-    elif world == 1:
-        run_slices(args.steps)
+    def profiling(on):
+        for e in engines:
+            e.set_profiling(on, stride=stride)
+
+    transport = None
+    if world > 1:
+        from hipace_amd.pipeline import RcclTransport
+        transport = RcclTransport(rank, world, local)          # communicators are created before the clock starts
+
+    clock = {}
+    stats0 = {}
+    timed_first = 0
+    if short:
+        # one step per rank; untimed down to the representative region, then warm-up, then K timed slices
+        start = args.start_slice if args.start_slice >= 0 else (START_SLICE_DEFAULT * nz) // 1024
+        start = max(0, min(start, nz - args.steps - args.warmup))
+        lead = start + args.warmup                              # untimed slices of rank 0
+        lead = max(lead, 2 * (world - 1))                       # every rank needs a non-negative untimed part
+        assert lead + args.steps <= nz, "window does not fit the box"
+        counts = [lead - 2 * r + args.steps for r in range(world)]
+        first = lead - 2 * rank
+        timed_first = first
+
+        def on_slice(m, q):
+            if q == first:
+                if transport is not None:
+                    eng.sync()
+                    transport.sync_sends()
+                barrier()
+                stats0.update(eng.stats())
+                profiling(True)
+                clock["t0"] = time.perf_counter()
+            elif q == first + args.steps:
+                eng.sync()
+                if transport is not None:
+                    transport.sync_sends()
+                clock["t1"] = time.perf_counter()
+
+        if world == 1:
+            eng.begin_step()
+            for q in range(counts[0]):
+                on_slice(0, q)
+                eng.solve_slice(nz - 1 - q)
+            on_slice(0, counts[0])
+        else:
+            from hipace_amd.pipeline import run_pipeline
+            run_pipeline(eng, rank, world, world, dev, slices_per_step=counts, transport=transport, on_slice=on_slice)
+        barrier()
+        dt = clock["t1"] - clock["t0"]
     else:
-        # ring pipeline over time steps: every rank sweeps `steps` slices of its own step(s); the beam
-        # slices travel rank -> rank+1 through RCCL (hipace_amd/pipeline.py)
-        from hipace_amd.pipeline import run_pipeline
-        per_step = max(min(args.steps, nz), 2 * world)      # the ring needs 2 slices of skew per rank
-        steps_per_rank = max(1, args.steps // nz)
-        solved = run_pipeline(eng, rank, world, world * steps_per_rank, torch.device("cuda", local),
-                              slices_per_step=per_step)
-        args.steps = solved
-    barrier()
-    dt = time.perf_counter() - t0
+        def run_slices(count):
+            done = 0
+            while done < count:
+                eng.begin_step()
+                m = min(nz, count - done)
+                for k in range(m):
+                    eng.solve_slice(nz - 1 - k)
+                done += m
+
+        run_slices(args.warmup)
+        if lanes > 1:
+            from hipace_amd.pipeline import run_local_pipeline
+            run_local_pipeline(engines, lanes, dev, slices_per_step=max(2, args.warmup))   # warm every lane
+        barrier()
+        stats0.update(eng.stats())
+        profiling(True)
+        t0 = time.perf_counter()
+        if lanes > 1:
+            args.steps = run_local_pipeline(engines, max(1, args.steps // nz), dev)
+        elif world == 1:
+            run_slices(args.steps)
+        else:
+            # ring pipeline over time steps: every rank sweeps whole boxes; the beam slices travel rank -> rank+1
+            from hipace_amd.pipeline import run_pipeline
+            steps_per_rank = max(1, args.steps // nz)
+            args.steps = run_pipeline(eng, rank, world, world * steps_per_rank, dev, transport=transport)
+        barrier()
+        dt = time.perf_counter() - t0
     phases, nprof = eng.phase_times()
     eng.set_profiling(False)
     for e in engines[1:]:            # phase times: mean over the lanes (intervals overlap in wall time)
@@ -187,6 +292,7 @@ def main():
         for k in phases:
             phases[k] += ph[k]
         nprof += n
+    ring_stats = transport.stats() if transport is not None else None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -194,10 +300,20 @@ def main():
 
     if rank == 0:
         total = args.steps * world
+        st1 = eng.stats()
+        nsl = max(st1["slices"] - stats0.get("slices", 0), 1)
         ab = algorithmic_bytes(args.n, args.ppc * args.ppc)
         per_kernel = {k: phases[k] / max(nprof, 1) for k in phases}
         dom = "deposit_current"
-        achieved = ab[dom] / (per_kernel[dom] * 1e-3) / 1e9 if per_kernel[dom] > 0 else 0.0
+        # the interval between two HIP events around ONE kernel = the kernel + what an interval costs by itself; the
+        # schedule has one interval without any kernel (two records back to back), measured on the same slices: subtract
+        # it.  (rocprofv3's kernel duration is begin -> end of the kernel alone.)
+        overhead = per_kernel.pop("empty_interval", 0.0)
+        raw = per_kernel[dom]
+        kernel_ms = max(raw - overhead, 0.0) if lanes == 1 else raw
+        achieved = ab[dom] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        headline = args.tile == 16 and args.n == 1024 and args.ppc == 2 and not args.config5 and not args.config2
+        traffic, traffic_source = pmc_traffic("void hps::k_deposit_tiled<2, 16, 51>") if headline else (None, None)
         out = {
             "metric": "transverse slices/s at 256^2 x 4ppc (predictor-corrector solver)" if args.config2 else
                       f"transverse slices/s at 1024^2 x 4ppc with a laser envelope (explicit solver, {args.laser_solver} envelope solver)" if args.config5 else
@@ -213,22 +329,32 @@ def main():
                                    (f"blowout_wake synthetic {args.n}x{args.n}x{nz}, {args.ppc * args.ppc} ppc, "
                                     "order 2, explicit Bx/By solver, dt=0 (BASELINE.md section 3)"),
                        "parallelism": f"time-step pipeline x{world}" + (f", {lanes} steps in flight per GPU" if lanes > 1 else "")},
+            "timed_slices": ({"first": timed_first, "last": timed_first + args.steps - 1, "counted_from": "head of the box",
+                              "pipeline_prefilled": world > 1} if short else
+                             {"whole_boxes": max(1, args.steps // nz), "pipeline_prefilled": False}),
             "steps_in_flight": lanes,
             "phase_ms_per_slice": per_kernel,
-            "vcycles_per_slice": eng.stats()["vcycles"] / max(eng.stats()["slices"], 1),
-            "laser_vcycles_per_slice": (eng.laser_vcycles() / max(eng.stats()["slices"], 1)) if args.config5 else None,
-            "pc_iterations_per_slice": eng.pc_stats()[0] / max(eng.stats()["slices"], 1) if args.config2 else None,
+            "profiled_slices": nprof,
+            "vcycles_per_slice": (st1["vcycles"] - stats0.get("vcycles", 0)) / nsl,
+            "laser_vcycles_per_slice": (eng.laser_vcycles() / max(st1["slices"], 1)) if args.config5 else None,
+            "pc_iterations_per_slice": eng.pc_stats()[0] / max(st1["slices"], 1) if args.config2 else None,
             "particle_sorts": eng.sorts() if args.tile else 0,
             "halo_fallbacks": eng.fallbacks() if args.tile else 0,
+            "ring": ring_stats,
             "roofline": {"bound": "hbm", "kernel": "k_deposit_tiled<2,%d>" % args.tile if args.tile else "k_deposit_current<2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic("void hps::k_deposit_tiled<2, 16, 51>") if (args.tile == 16 and args.n == 1024 and args.ppc == 2 and not args.config5) else None,
-                         "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": per_kernel[dom]},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": kernel_ms,
+                         "event_interval_ms": raw, "empty_event_interval_ms": overhead,
+                         "duration_source": f"HIP events on the engine's stream around the kernel, {nprof} launches of the timed region, "
+                                            "minus the interval between two back-to-back event records measured on the same slices"},
         }
         if args.cpu_slices > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.n, args.ppc, args.cpu_slices)
+            out["cpu_baseline"] = cpu_baseline(args.n, args.ppc, args.cpu_slices, args.cpu_threads or (os.cpu_count() or 1))
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
+        if transport is not None:
+            transport.close()
         dist.destroy_process_group()
 
 

@@ -148,6 +148,16 @@ _SIGS = {
     "hps_engine_beam_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.c_void_p]),
     "hps_engine_set_beam_storage": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_initial_beam": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hps_ring_unique_id": (C.c_int, [C.c_char_p]),
+    "hps_ring_init": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "hps_ring_send_slice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "hps_ring_recv_slice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "hps_ring_sendrecv_self": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "hps_ring_stream_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "hps_ring_sync_sends": (C.c_int, [C.c_void_p]),
+    "hps_ring_sync": (C.c_int, [C.c_void_p]),
+    "hps_ring_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "hps_ring_destroy": (C.c_int, [C.c_void_p]),
     "hps_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long]),
     "hps_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long]),
     "hps_device_count": (C.c_int, [C.POINTER(C.c_int)]),

@@ -447,10 +447,10 @@ class SliceEngine:
                                                dst.numel() * 8))
 
     def phase_times(self):
-        ms = (C.c_double * 7)()
+        ms = (C.c_double * 8)()
         n = C.c_long()
         check(_lib.lib().hps_engine_phase_times(self._h, ms, C.byref(n)))
-        names = ["deposit_current", "poisson", "explicit_deposit", "mg_solve1", "advance_plasma", "other", "sort"]
+        names = ["deposit_current", "poisson", "explicit_deposit", "mg_solve1", "advance_plasma", "other", "sort", "empty_interval"]
         return {k: ms[i] for i, k in enumerate(names)}, n.value
 
     def checksums(self):

@@ -33,10 +33,9 @@ void k_beam_deposit_dyn (SlabView f, BeamSoA b, const long* __restrict__ B, cons
                          int cjx, int cjy, int cjz, double q_invvol, double clightsq_inv, PartConsts k)
 {
     const long first = B[p] + nfront[p], count = B[p + 1] - first;
-    const long t = (long)blockIdx.x*blockDim.x + threadIdx.x;
-    if (t >= count) return;
+    for (long t = (long)blockIdx.x*blockDim.x + threadIdx.x; t < count; t += (long)gridDim.x*blockDim.x) {
     const long ip = first + t;
-    if (b.nsub[ip] < 0) return;                 // absorbed at the boundary
+    if (b.nsub[ip] < 0) continue;               // absorbed at the boundary
     const double ux = b.ux[ip], uy = b.uy[ip], uz = b.uz[ip];
     const double gaminv = 1.0/sqrt(1.0 + ux*ux*clightsq_inv + uy*uy*clightsq_inv + uz*uz*clightsq_inv);
     const double wq = q_invvol*b.w[ip];
@@ -53,6 +52,7 @@ void k_beam_deposit_dyn (SlabView f, BeamSoA b, const long* __restrict__ B, cons
             if (cjz >= 0) atomic_add_f64(q + cjz*f.ns, s*(wq*(uz*gaminv)));
         }
     }
+    }
 }
 
 template <int ORDER>
@@ -62,18 +62,18 @@ void k_beam_push (SlabView f, BeamSoA b, const long* __restrict__ B, int p, int 
 {
     constexpr int NS = ORDER + 2;
     const long first = B[p], count = B[p + 1] - first;       // slipped-in particles included (:131)
-    const long t = (long)blockIdx.x*blockDim.x + threadIdx.x;
-    if (t >= count) return;
+    for (long t = (long)blockIdx.x*blockDim.x + threadIdx.x; t < count; t += (long)gridDim.x*blockDim.x) {
     const long ip = first + t;
     int i = b.nsub[ip];
-    if (i < 0) return;
+    if (i < 0) continue;
     double xp = b.x[ip], yp = b.y[ip], zp = b.z[ip], ux = b.ux[ip], uy = b.uy[ip], uz = b.uz[ip];
+    bool absorbed = false;
     for (; i < k.nsc; ++i) {
         if (zp < k.min_z) break;                              // not on this slice any more (:150-153)
         const double gi = 1.0/sqrt(1.0 + (ux*ux + uy*uy + uz*uz)*k.inv_c2);
         xp += k.dt*0.5*ux*gi;
         yp += k.dt*0.5*uy*gi;
-        if (apply_particle_bc(k.pc, xp, yp, ux, uy)) { b.w[ip] = 0.0; b.nsub[ip] = -1; return; }
+        if (apply_particle_bc(k.pc, xp, yp, ux, uy)) { absorbed = true; break; }
         // doGatherShapeN (particles/particles_utils/FieldGather.H:45-96)
         double sx[NS], dsx[NS], sy[NS], dsy[NS];
         const int i0 = nodal_weights<ORDER>((xp - k.pc.xoff)*k.pc.dx_inv, sx, dsx);
@@ -126,9 +126,10 @@ void k_beam_push (SlabView f, BeamSoA b, const long* __restrict__ B, int p, int 
         if (!k.no_z_push) zp += k.dt*(uz_next*gni - k.c);     // do_z_push (:316)
         ux = ux_next; uy = uy_next; uz = uz_next;
     }
-    if (apply_particle_bc(k.pc, xp, yp, ux, uy)) { b.w[ip] = 0.0; b.nsub[ip] = -1; return; }
+    if (absorbed || apply_particle_bc(k.pc, xp, yp, ux, uy)) { b.w[ip] = 0.0; b.nsub[ip] = -1; continue; }
     b.x[ip] = xp; b.y[ip] = yp; b.z[ip] = zp; b.nsub[ip] = i;
     b.ux[ip] = ux; b.uy[ip] = uy; b.uz[ip] = uz;
+    }
 }
 
 // One workgroup: particles of slice p with z < min_z go to the end of the slice's range, the boundary to
@@ -257,7 +258,7 @@ int beam_deposit_moving (Engine& E, int p, int cjx, int cjy, int cjz)
     const SlabView f(E.slab);
     const PartConsts k = base_consts(E.gm);
     const double q_invvol = E.d.beam_charge*(E.d.si_units ? 1.0/(E.gm.dx*E.gm.dy*E.gm.dz) : 1.0), csq_inv = 1.0/(E.gm.c*E.gm.c);
-    const dim3 grid(ceil_div(bound, 256)), block(256);
+    const dim3 grid((unsigned)std::min<long>(ceil_div(bound, 256), 2048)), block(256);
 #define CALL(O) hipLaunchKernelGGL(k_beam_deposit_dyn<O>, grid, block, 0, E.st, f, E.bm, E.d_B, E.d_nfront, p, cjx, cjy, cjz, q_invvol, csq_inv, k)
     HPS_BEAM_ORDER(E.d.order, CALL)
 #undef CALL
@@ -271,7 +272,7 @@ int beam_push_moving (Engine& E, int islice)
     if (bound <= 0) return HPS_OK;
     const SlabView f(E.slab);
     const BeamPushConsts k = push_consts(E, islice);
-    const dim3 grid(ceil_div(bound, 256)), block(256);
+    const dim3 grid((unsigned)std::min<long>(ceil_div(bound, 256), 2048)), block(256);
 #define CALL(O) hipLaunchKernelGGL(k_beam_push<O>, grid, block, 0, E.st, f, E.bm, E.d_B, p, HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ, k)
     HPS_BEAM_ORDER(E.d.order, CALL)
 #undef CALL

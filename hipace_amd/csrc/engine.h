@@ -46,10 +46,14 @@ struct Engine {
     // ring hand-off: import mode (the slices of the coming step arrive as messages), start offsets of the imported
     // blocks, per-message capacity, overflow counter
     bool beam_import = false; long* d_Bimp = nullptr; long beam_cap = 0; int* d_beam_overflow = nullptr;
-    long beam_bound (int p) const {      // upper bound of slice p's size during this step: own + what may slip in
+    // upper bound of slice p's size during this step.  A particle may slip through SEVERAL slices in one step (it is
+    // pushed again on every slice it lands on, BeamParticleAdvance.cpp:131 "IncludingSlipped"), so everything ahead of
+    // slice p counts: own + all of slices 0..p-1 as of begin_step.  The kernels loop grid-stride over the device-side
+    // count, so the bound only sizes (and caps) the launch.
+    long beam_bound (int p) const {
         if (p < 0 || p >= d.nz) return 0;
-        if (beam_import) return 2*beam_cap;
-        return (h_B[p + 1] - h_B[p]) + (p > 0 ? h_B[p] - h_B[p - 1] : 0);
+        if (beam_import) return std::max(nbeam, 1L);
+        return h_B[p + 1] - h_B[0];
     }
     // support of the beam currents in padded-array cells (deposit footprint + the centred differences taken of
     // them); the beam planes are identically zero outside, so the slab kernels skip them there

@@ -1,0 +1,265 @@
+// ring.hip -- transport of the time-step ring pipeline: one slice hand-off per rank and slice, RCCL point-to-point
+// over xGMI (the reference: MultiBuffer::{make_progress, get_data, put_data}, utils/MultiBuffer.cpp:287-609, MPI
+// Isend / Irecv between ring neighbours; in-process copy when a rank sends to itself, :299-308).
+//
+// One process per GPU.  Every EDGE r -> r+1 of the ring is its own 2-rank communicator (the sender is comm rank 0),
+// so a rank's receive path (its predecessor's edge) and its send path (its own edge) never share a communicator or
+// a stream: ncclRecv runs on the ring's receive stream, ncclSend on its send stream, and the two progress
+// independently -- a rank only ever waits for its predecessor, not for its successor's schedule (a grouped
+// send+recv on one communicator would step all ranks in lock-step and pay max-over-ranks jitter on every slice:
+// the multigrid's V-cycle count differs from slice to slice).  Ordering against the engine is by events only:
+// a send waits (on the device) for the event the engine recorded behind the slice's last kernel, the engine waits
+// for the event the ring records behind a receive.  No host synchronisation per slice.
+//
+// RCCL is opened with dlopen so that the library loads (and the rest of the ABI works) in a process that never
+// touches the ring; when torch has already loaded its librccl.so.1 the same object is reused.
+#include "common.h"
+
+#include <dlfcn.h>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+// the few RCCL entry points the ring needs (rccl.h: NCCL 2.x ABI; ncclUniqueId = 128 bytes, ncclChar = 0)
+struct NcclId { char internal[HPS_RING_ID_BYTES]; };
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+
+struct Rccl {
+    void* so = nullptr;
+    ncclResult_t (*GetUniqueId)(NcclId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, NcclId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    const char* (*GetLastError)(ncclComm_t) = nullptr;
+};
+
+Rccl g_rccl;
+
+int load_rccl ()
+{
+    if (g_rccl.so) return HPS_OK;
+    void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!so) so = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!so) { hps::set_error(std::string("hps_ring: cannot open librccl.so.1: ") + dlerror()); return HPS_ERR_COMM; }
+#define HPS_SYM(field, name) \
+    *reinterpret_cast<void**>(&g_rccl.field) = dlsym(so, name); \
+    if (!g_rccl.field) { hps::set_error(std::string("hps_ring: librccl lacks ") + name); dlclose(so); return HPS_ERR_COMM; }
+    HPS_SYM(GetUniqueId, "ncclGetUniqueId")
+    HPS_SYM(CommInitRank, "ncclCommInitRank")
+    HPS_SYM(CommDestroy, "ncclCommDestroy")
+    HPS_SYM(Send, "ncclSend")
+    HPS_SYM(Recv, "ncclRecv")
+    HPS_SYM(GroupStart, "ncclGroupStart")
+    HPS_SYM(GroupEnd, "ncclGroupEnd")
+    HPS_SYM(GetErrorString, "ncclGetErrorString")
+#undef HPS_SYM
+    *reinterpret_cast<void**>(&g_rccl.GetLastError) = dlsym(so, "ncclGetLastError");      // optional
+    g_rccl.so = so;
+    return HPS_OK;
+}
+
+#define HPS_NCCL_CHECK(expr)                                                                          \
+    do {                                                                                              \
+        ncclResult_t r_ = (expr);                                                                     \
+        if (r_ != 0) {                                                                                \
+            hps::set_error(std::string(#expr) + ": " + g_rccl.GetErrorString(r_) +                    \
+                           (g_rccl.GetLastError ? std::string(" / ") + g_rccl.GetLastError(nullptr) : std::string())); \
+            return HPS_ERR_COMM;                                                                      \
+        }                                                                                             \
+    } while (0)
+
+struct Ring {
+    int rank = 0, world = 1, device = 0;
+    ncclComm_t comm_in = nullptr, comm_out = nullptr;      // edge (rank-1 -> rank): I am comm rank 1; edge (rank -> rank+1): comm rank 0
+    ncclComm_t comm_self = nullptr;                        // world == 1: one 1-rank communicator ("send to myself")
+    hipStream_t st_recv = nullptr, st_send = nullptr;
+    std::vector<hipEvent_t> ev_recv, ev_send;
+    long n_sent = 0, n_received = 0; long long bytes_sent = 0, bytes_received = 0;
+};
+
+// proper edge colouring of the ring: two colours, three when the ring is odd.  Communicators are created colour by
+// colour, so no rank waits in one ncclCommInitRank for a peer that waits for it in another.
+int edge_colour (int e, int world) { return (world % 2 == 1 && e == world - 1) ? 2 : e % 2; }
+
+int event_of (std::vector<hipEvent_t>& pool, int slot, hipEvent_t* out)
+{
+    HPS_REQUIRE(slot >= 0 && slot < (1 << 20), "hps_ring: bad event slot");
+    if ((size_t)slot >= pool.size()) pool.resize((size_t)slot + 1, nullptr);
+    if (!pool[slot]) HPS_HIP_CHECK(hipEventCreateWithFlags(&pool[slot], hipEventDisableTiming));
+    *out = pool[slot];
+    return HPS_OK;
+}
+
+} // namespace
+
+extern "C" int hps_ring_destroy (void* handle);
+
+extern "C" int hps_ring_unique_id (char* id_out)
+{
+    HPS_REQUIRE(id_out, "hps_ring_unique_id: null argument");
+    if (int e = load_rccl()) return e;
+    NcclId id;
+    HPS_NCCL_CHECK(g_rccl.GetUniqueId(&id));
+    std::memcpy(id_out, id.internal, HPS_RING_ID_BYTES);
+    return HPS_OK;
+}
+
+extern "C" int hps_ring_init (int rank, int world, int device, const char* id_edge_in, const char* id_edge_out, void** handle)
+{
+    HPS_REQUIRE(handle && world >= 1 && rank >= 0 && rank < world, "hps_ring_init: bad rank / world");
+    HPS_REQUIRE(id_edge_out && (world == 1 || id_edge_in), "hps_ring_init: the ids of both edges are needed");
+    if (int e = load_rccl()) return e;
+    HPS_HIP_CHECK(hipSetDevice(device));
+    Ring* R = new Ring;
+    R->rank = rank; R->world = world; R->device = device;
+    // both above the engine's stream: a hand-off is short and sits on the critical path of the next rank
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&R->st_recv, hipStreamNonBlocking, hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&R->st_send, hipStreamNonBlocking, hi) != hipSuccess) {
+        hps_ring_destroy(R); hps::set_error("hps_ring_init: cannot create the ring's streams"); return HPS_ERR_HIP;
+    }
+    NcclId id;
+    if (world == 1) {
+        std::memcpy(id.internal, id_edge_out, HPS_RING_ID_BYTES);
+        ncclResult_t r = g_rccl.CommInitRank(&R->comm_self, 1, id, 0);
+        if (r != 0) { hps_ring_destroy(R); hps::set_error(std::string("hps_ring_init: ncclCommInitRank: ") + g_rccl.GetErrorString(r)); return HPS_ERR_COMM; }
+    } else {
+        const int e_out = rank, e_in = (rank + world - 1) % world;
+        for (int colour = 0; colour < 3; ++colour) {
+            ncclResult_t r = 0;
+            if (edge_colour(e_out, world) == colour) {
+                std::memcpy(id.internal, id_edge_out, HPS_RING_ID_BYTES);
+                r = g_rccl.CommInitRank(&R->comm_out, 2, id, 0);
+            }
+            if (r == 0 && edge_colour(e_in, world) == colour) {
+                std::memcpy(id.internal, id_edge_in, HPS_RING_ID_BYTES);
+                r = g_rccl.CommInitRank(&R->comm_in, 2, id, 1);
+            }
+            if (r != 0) { hps_ring_destroy(R); hps::set_error(std::string("hps_ring_init: ncclCommInitRank: ") + g_rccl.GetErrorString(r)); return HPS_ERR_COMM; }
+        }
+    }
+    *handle = R;
+    return HPS_OK;
+}
+
+// put_data (MultiBuffer.cpp:444-493): `bytes` at msg_dev go to the next rank.  The send stream first waits for
+// `after_event` (recorded by the engine behind the slice's last kernel; NULL = nothing to wait for); *done_event is
+// recorded behind the send: the buffer may be overwritten once it has fired.
+extern "C" int hps_ring_send_slice (void* handle, const void* msg_dev, long bytes, void* after_event, int slot, void** done_event)
+{
+    Ring* R = static_cast<Ring*>(handle);
+    HPS_REQUIRE(R && R->comm_out, "hps_ring_send_slice: the ring has no outgoing edge (world = 1: use hps_ring_sendrecv_self)");
+    HPS_REQUIRE(msg_dev && bytes > 0, "hps_ring_send_slice: empty message");
+    if (after_event) HPS_HIP_CHECK(hipStreamWaitEvent(R->st_send, static_cast<hipEvent_t>(after_event), 0));
+    HPS_NCCL_CHECK(g_rccl.Send(msg_dev, (size_t)bytes, /*ncclChar*/ 0, /*peer*/ 1, R->comm_out, R->st_send));
+    hipEvent_t ev;
+    if (int e = event_of(R->ev_send, slot, &ev)) return e;
+    HPS_HIP_CHECK(hipEventRecord(ev, R->st_send));
+    if (done_event) *done_event = ev;
+    ++R->n_sent; R->bytes_sent += bytes;
+    return HPS_OK;
+}
+
+// get_data (MultiBuffer.cpp:495-609): post the receive of the next message of the previous rank into msg_dev.  The
+// receive stream first waits for `after_event` (the buffer's previous contents are no longer needed); *done_event
+// fires when the data has landed -- make the engine's stream wait for it (hps_engine_wait_event).
+extern "C" int hps_ring_recv_slice (void* handle, void* msg_dev, long bytes, void* after_event, int slot, void** done_event)
+{
+    Ring* R = static_cast<Ring*>(handle);
+    HPS_REQUIRE(R && R->comm_in, "hps_ring_recv_slice: the ring has no incoming edge (world = 1: use hps_ring_sendrecv_self)");
+    HPS_REQUIRE(msg_dev && bytes > 0, "hps_ring_recv_slice: empty message");
+    if (after_event) HPS_HIP_CHECK(hipStreamWaitEvent(R->st_recv, static_cast<hipEvent_t>(after_event), 0));
+    HPS_NCCL_CHECK(g_rccl.Recv(msg_dev, (size_t)bytes, /*ncclChar*/ 0, /*peer*/ 0, R->comm_in, R->st_recv));
+    hipEvent_t ev;
+    if (int e = event_of(R->ev_recv, slot, &ev)) return e;
+    HPS_HIP_CHECK(hipEventRecord(ev, R->st_recv));
+    if (done_event) *done_event = ev;
+    ++R->n_received; R->bytes_received += bytes;
+    return HPS_OK;
+}
+
+// world = 1: the rank is its own neighbour (MultiBuffer.cpp:299-308).  Send and receive of one message as ONE RCCL
+// group on the 1-rank communicator (a lone self-send would wait for its receive forever).
+extern "C" int hps_ring_sendrecv_self (void* handle, const void* src_dev, void* dst_dev, long bytes, void* after_event, int slot,
+                                       void** done_event)
+{
+    Ring* R = static_cast<Ring*>(handle);
+    HPS_REQUIRE(R && R->comm_self, "hps_ring_sendrecv_self: needs a ring of one rank");
+    HPS_REQUIRE(src_dev && dst_dev && bytes > 0, "hps_ring_sendrecv_self: empty message");
+    if (after_event) HPS_HIP_CHECK(hipStreamWaitEvent(R->st_send, static_cast<hipEvent_t>(after_event), 0));
+    HPS_NCCL_CHECK(g_rccl.GroupStart());
+    ncclResult_t r1 = g_rccl.Send(src_dev, (size_t)bytes, 0, 0, R->comm_self, R->st_send);
+    ncclResult_t r2 = g_rccl.Recv(dst_dev, (size_t)bytes, 0, 0, R->comm_self, R->st_send);
+    HPS_NCCL_CHECK(g_rccl.GroupEnd());
+    HPS_NCCL_CHECK(r1); HPS_NCCL_CHECK(r2);
+    hipEvent_t ev;
+    if (int e = event_of(R->ev_send, slot, &ev)) return e;
+    HPS_HIP_CHECK(hipEventRecord(ev, R->st_send));
+    if (done_event) *done_event = ev;
+    ++R->n_sent; ++R->n_received; R->bytes_sent += bytes; R->bytes_received += bytes;
+    return HPS_OK;
+}
+
+// make the ring's receive (which = 0) or send (which = 1) stream wait for an event of another stream, e.g. "the engine
+// has finished the step that last used these receive buffers"
+extern "C" int hps_ring_stream_wait (void* handle, int which, void* event)
+{
+    Ring* R = static_cast<Ring*>(handle);
+    HPS_REQUIRE(R && event && (which == 0 || which == 1), "hps_ring_stream_wait: bad argument");
+    HPS_HIP_CHECK(hipStreamWaitEvent(which == 0 ? R->st_recv : R->st_send, static_cast<hipEvent_t>(event), 0));
+    return HPS_OK;
+}
+
+// host waits until every message handed to hps_ring_send_slice so far has left (the receives posted ahead stay posted)
+extern "C" int hps_ring_sync_sends (void* handle)
+{
+    Ring* R = static_cast<Ring*>(handle);
+    HPS_REQUIRE(R, "hps_ring_sync_sends: null ring");
+    HPS_HIP_CHECK(hipStreamSynchronize(R->st_send));
+    return HPS_OK;
+}
+
+extern "C" int hps_ring_sync (void* handle)
+{
+    Ring* R = static_cast<Ring*>(handle);
+    HPS_REQUIRE(R, "hps_ring_sync: null ring");
+    HPS_HIP_CHECK(hipStreamSynchronize(R->st_send));
+    HPS_HIP_CHECK(hipStreamSynchronize(R->st_recv));
+    return HPS_OK;
+}
+
+extern "C" int hps_ring_stats (void* handle, long* n_sent, long* n_received, long long* bytes_sent, long long* bytes_received)
+{
+    Ring* R = static_cast<Ring*>(handle);
+    HPS_REQUIRE(R, "hps_ring_stats: null ring");
+    if (n_sent) *n_sent = R->n_sent;
+    if (n_received) *n_received = R->n_received;
+    if (bytes_sent) *bytes_sent = R->bytes_sent;
+    if (bytes_received) *bytes_received = R->bytes_received;
+    return HPS_OK;
+}
+
+extern "C" int hps_ring_destroy (void* handle)
+{
+    Ring* R = static_cast<Ring*>(handle);
+    if (!R) return HPS_OK;
+    (void)hipSetDevice(R->device);
+    if (R->st_send) (void)hipStreamSynchronize(R->st_send);
+    if (R->st_recv) (void)hipStreamSynchronize(R->st_recv);
+    if (R->comm_out) g_rccl.CommDestroy(R->comm_out);
+    if (R->comm_in) g_rccl.CommDestroy(R->comm_in);
+    if (R->comm_self) g_rccl.CommDestroy(R->comm_self);
+    for (auto e : R->ev_recv) if (e) (void)hipEventDestroy(e);
+    for (auto e : R->ev_send) if (e) (void)hipEventDestroy(e);
+    if (R->st_send) (void)hipStreamDestroy(R->st_send);
+    if (R->st_recv) (void)hipStreamDestroy(R->st_recv);
+    delete R;
+    return HPS_OK;
+}

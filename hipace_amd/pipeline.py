@@ -1,26 +1,32 @@
 """Time-step ring pipeline over the GPUs of one node.
 
 The reference does not decompose a slice or the zeta axis; it pipelines *time steps* over ranks
-(src/Hipace.cpp:400-401: rank r runs steps r, r+N, ...) and hands the freshly pushed beam slice of
-step s to the rank that runs step s+1 (src/utils/MultiBuffer.cpp:444-609; in-process "send to
-myself" when there is one rank, :299-308).  This module is that schedule for `SliceEngine`.
+(src/Hipace.cpp:400-401: rank r runs steps r, r+N, ...) and hands the freshly pushed beam slice (and the laser
+envelope of that slice) of step s to the rank that runs step s+1 (src/utils/MultiBuffer.cpp:287-609; in-process "send
+to myself" when there is one rank, :299-308).  This module is the host driver of that schedule for `SliceEngine`.
 
-Transport: torch.distributed point-to-point -- backend "nccl" (= RCCL over xGMI) between GPUs,
-"gloo" in the CPU tests.  One message per slice: the slice's beam block, `7*count` doubles
-(x, y, z, ux, uy, uz, w), contiguous in the engine's beam storage (include/hpslice.h,
-hps_engine_beam_info).
+Transport: `RcclTransport` = the C-ABI ring of include/hpslice.h (hps_ring_*: ncclSend / ncclRecv over xGMI, one
+2-rank communicator and one stream per ring edge); `GlooTransport` = torch.distributed point-to-point on host tensors
+for the CPU tests (the oracle engine stands in for the HIP engine).  One message per slice and kind, in a fixed order
+per edge: for every slice (head first) the beam message, then the laser message:
+  * static beam (hipace.dt = 0): the slice's beam block, `7*count` doubles, straight out of / into the engine's beam
+    storage (hps_engine_beam_info / set_beam_storage); empty blocks are not sent;
+  * moving beam: `1 + 7*cap` doubles packed / unpacked on the device (hps_engine_export_beam_slice / import_beam_slice);
+  * laser: `4 nx ny` doubles ({a_{n+1}, a_n} of the slice, hps_engine_export_laser_slice / import_laser_slice).
 
-Deadlock freedom by construction: all ranks advance through the same global pipeline *ticks*.
-Rank r is 2r ticks behind rank 0 (solving slice k needs the beam of slice k AND of slice k-1, whose
-jx/jy feed the explicit source term: Hipace.cpp:639-657, so a rank trails its predecessor by two
-slices).  In tick t every rank posts, in one batch (= one RCCL group),
-  * the send of the slice it solved in tick t-1 (if a later step exists), and
-  * the receive of the slice its ring predecessor solved in tick t-1 (if that feeds one of its steps).
-For r > 0 that is slice k-1 while it solves slice k in the same tick; rank 0 receives the slices of
-its next step early (its predecessor, rank N-1, is only 2(N-1) ticks behind; requires nz >= 2N)
-into the other of two beam buffers.  Every posted send therefore has a matching receive posted in
-the same tick on the peer, and a rank only ever waits for messages of earlier-or-equal ticks.
+No host synchronisation per slice.  The engine records an event behind every slice; the send waits for it on the
+ring's send stream; the engine's stream waits for the event the ring records behind a receive.  Receives are posted a
+whole step ahead (two steps' worth of beam buffers: the slot of (step m+1, slice j) is free once step m-1 is done), as
+the reference's MultiBuffer does with its default unlimited `max_leading_slices` -- that is what lets the ring close
+(more steps than ranks) without a rank ever waiting for its successor.  The laser messages are 33 MB per slice at
+1024^2: they are posted `laser_lookahead` slices ahead when the ring does not close (n_steps <= ranks) and a whole step
+ahead when it does (the reference's requirement max_trailing_slices * n_ranks > nslices, MultiBuffer.cpp:87-91).
+
+Dependencies: solving slice k of step s+1 needs the beam of slices k and k-1 of step s (the next slice's jx / jy feed
+the explicit source term, Hipace.cpp:639-657), so a rank trails its predecessor by two slices.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -29,250 +35,356 @@ def steps_of_rank(rank, world, n_steps):
     return list(range(rank, n_steps, world))
 
 
-class _Sched:
-    """Who solves what in which tick."""
+class GlooTransport:
+    """torch.distributed point-to-point on host tensors (CPU tests; the oracle engine is synchronous).  What the ring
+    calls an event is a request here, and waiting happens on the host."""
 
-    def __init__(self, world, n_steps, nz, per_step=None):
-        self.world, self.n_steps, self.nz = world, n_steps, nz
-        self.per_step = per_step or nz        # slices solved per step (head slices first)
+    def __init__(self, rank, world, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.prev, self.next = (rank - 1) % world, (rank + 1) % world
+        self._sends, self._recvs = [], []
 
-    def work(self, rank, tick):
-        """(step, islice, local_step_index) solved by `rank` in `tick`, or None."""
-        loc = tick - 2 * rank
-        if loc < 0:
-            return None
-        m, q = divmod(loc, self.per_step)
-        step = rank + m * self.world
-        if step >= self.n_steps:
-            return None
-        return step, self.nz - 1 - q, m
+    def send(self, t, after_event=None, slot=0):
+        rq = dist.isend(t, self.next, group=self.group)
+        self._sends.append(rq)
+        if len(self._sends) > 64:
+            self._sends = [r for r in self._sends if not r.is_completed()]
+        return rq
 
-    def n_ticks(self):
-        last = 0
-        for r in range(self.world):
-            n = len(steps_of_rank(r, self.world, self.n_steps))
-            last = max(last, 2 * r + n * self.per_step)
-        return last + 1      # one more tick to flush the final sends (there are none, but keep symmetric)
+    def recv(self, t, after_event=None, slot=0):
+        if after_event is not None and not after_event.is_completed():
+            after_event.wait()
+        rq = dist.irecv(t, self.prev, group=self.group)
+        self._recvs.append(rq)
+        if len(self._recvs) > 64:
+            self._recvs = [r for r in self._recvs if not r.is_completed()]
+        return rq
 
+    def engine_wait(self, engine, ev):
+        if ev is not None and not ev.is_completed():
+            ev.wait()
 
-def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_per_step=None):
-    """Run steps rank, rank+world, ... < n_steps of `engine` with the per-slice ring hand-off.
+    def recv_after(self, ev):
+        if ev is not None and hasattr(ev, "wait") and not ev.is_completed():
+            ev.wait()
 
-    engine: SliceEngine-like (begin_step, solve_slice, sync, beam_layout, set_beam_storage,
-    initial_beam_into).  slices_per_step < nz solves only the head slices of every step
-    (benchmark runs shorter than one box).  Returns the number of slices this rank solved.
-    """
-    nz = engine.deck["nz"]
-    per_step = slices_per_step or nz
-    assert per_step >= 2 * world, "the ring pipeline needs at least 2 slices per rank"
-    if getattr(engine, "moving", False):
-        assert per_step == nz, "a moving beam (hipace.dt != 0) needs whole steps"
-        return _run_pipeline_moving(engine, rank, world, n_steps, device, on_step_end)
-    sched = _Sched(world, n_steps, nz, per_step)
-    nbeam, off = engine.beam_layout()
-    bufs = [torch.zeros(max(7 * nbeam, 1), dtype=torch.float64, device=device) for _ in range(2)]
-    if rank == 0:
-        engine.initial_beam_into(bufs[0])       # only the head rank injects the beam (as the reference)
-    prev, nxt = (rank - 1) % world, (rank + 1) % world
-
-    def block(buf, islice):
-        p = nz - 1 - islice
-        return buf[7 * off[p]:7 * off[p + 1]]
-
-    pending_recv = {}     # (local step index, islice) -> request
-    pending_send = []
-    solved = 0
-    for tick in range(sched.n_ticks()):
-        ops = []
-        # what my predecessor solved in the previous tick feeds my step (its step + 1)
-        pw = sched.work(prev, tick - 1)
-        if pw is not None and pw[0] + 1 < n_steps and (pw[0] + 1) % world == rank:
-            m_target = (pw[0] + 1 - rank) // world
-            t = block(bufs[m_target % 2], pw[1])
-            if t.numel() > 0:
-                if world == 1:
-                    pass                      # in-process hand-off below
-                else:
-                    ops.append(("recv", dist.P2POp(dist.irecv, t, prev), (m_target, pw[1])))
-        # what I solved in the previous tick goes to my successor
-        mw = sched.work(rank, tick - 1)
-        if mw is not None and mw[0] + 1 < n_steps:
-            t = block(bufs[mw[2] % 2], mw[1])
-            if t.numel() > 0:
-                if world == 1:
-                    block(bufs[(mw[2] + 1) % 2], mw[1]).copy_(t)      # MultiBuffer.cpp:299-308
-                else:
-                    ops.append(("send", dist.P2POp(dist.isend, t, nxt), None))
-        # one batch per tick (one RCCL group: the send and the receive of a rank progress together, so a
-        # closed ring -- more steps than ranks -- cannot park every rank in a receive whose matching send is
-        # queued behind another receive).  Every send posted in tick t has its receive posted in tick t of
-        # the successor, and a rank posts its batch before it waits for anything of that tick.
-        if ops:
-            reqs = dist.batch_isend_irecv([o[1] for o in ops])
-            for i, o in enumerate(ops):
-                rq = reqs[i] if len(reqs) == len(ops) else reqs[-1]     # coalescing back-ends: one request per batch
-                if o[0] == "recv":
-                    pending_recv[o[2]] = rq
-                else:
-                    pending_send.append(rq)
-
-        w = sched.work(rank, tick)
-        if w is None:
-            continue
-        step, islice, m = w
-        if islice == nz - 1:
-            engine.set_beam_storage(bufs[m % 2], injected_beam_support=True)     # hipace.dt = 0: the beam never moves
-            engine.begin_step()
-        waited = False
-        for key in ((m, islice), (m, islice - 1)):            # this slice's beam and the next one's (jx/jy source)
-            rq = pending_recv.pop(key, None)
-            if rq is not None:
+    def sync_sends(self):
+        for rq in self._sends:
+            if not rq.is_completed():       # (a second wait on a finished gloo request never returns)
                 rq.wait()
-                waited = True
-        if waited and str(device) != "cpu":
-            torch.cuda.current_stream().synchronize()         # data landed before the engine's stream reads it
-        engine.solve_slice(islice)
-        engine.sync()                                         # the slice's beam block is final before it is sent
-        solved += 1
-        while len(pending_send) > 4:
-            pending_send.pop(0).wait()
-        if islice == nz - per_step and on_step_end is not None:
-            on_step_end(step)
-    for rq in pending_send:
-        rq.wait()
-    return solved
+        self._sends = []
+
+    def finish(self):
+        self.sync_sends()
+        for rq in self._recvs:
+            if not rq.is_completed():
+                rq.wait()
+        self._recvs = []
+
+    def close(self):
+        pass
 
 
-def _run_pipeline_moving(engine, rank, world, n_steps, device, on_step_end):
-    """hipace.dt != 0: what sits on a slice after its push travels as one fixed-size message
-    [count | 7 rows of `cap` doubles] (engine.export_beam_slice) and becomes the next step's slice
-    (engine.import_beam_slice) -- MultiBuffer::put_data / get_data (utils/MultiBuffer.cpp:444-609).  Same tick
-    schedule as the static path; the head rank injects the beam (its first step only)."""
-    nz = engine.deck["nz"]
-    sched = _Sched(world, n_steps, nz, nz)
-    cap = engine.beam_capacity()
-    mlen = 1 + 7 * cap
-    prev, nxt = (rank - 1) % world, (rank + 1) % world
-    # receive slots: two steps' worth (a rank may hold the early slices of its next step); send slots rotate
-    rpool = [[torch.zeros(mlen, dtype=torch.float64, device=device) for _ in range(nz)] for _ in range(2)]
-    spool = [torch.zeros(mlen, dtype=torch.float64, device=device) for _ in range(8)]
-    pending_recv, pending_send, have = {}, [], set()
-    exported = {}          # tick -> send slot holding the slice solved in that tick
-    solved = 0
-    for tick in range(sched.n_ticks()):
-        ops = []
-        pw = sched.work(prev, tick - 1)
-        if world > 1 and pw is not None and pw[0] + 1 < n_steps and (pw[0] + 1) % world == rank:
-            m_target = (pw[0] + 1 - rank) // world
-            ops.append(("recv", dist.P2POp(dist.irecv, rpool[m_target % 2][nz - 1 - pw[1]], prev), (m_target, pw[1])))
-        mw = sched.work(rank, tick - 1)
-        if world > 1 and mw is not None and mw[0] + 1 < n_steps:
-            ops.append(("send", dist.P2POp(dist.isend, exported.pop(tick - 1), nxt), None))
-        if ops:
-            reqs = dist.batch_isend_irecv([o[1] for o in ops])
-            for i, o in enumerate(ops):
-                rq = reqs[i] if len(reqs) == len(ops) else reqs[-1]
-                if o[0] == "recv":
-                    pending_recv[o[2]] = rq
-                else:
-                    pending_send.append(rq)
+class RcclTransport:
+    """The C-ABI ring (include/hpslice.h hps_ring_*): RCCL ncclSend / ncclRecv on device buffers, one 2-rank communicator
+    and one stream per ring edge.  Bootstrap: every rank makes the id of its outgoing edge, all ids are exchanged through
+    the torch.distributed group (any backend), hps_ring_init is collective."""
 
-        w = sched.work(rank, tick)
-        if w is None:
-            continue
-        step, islice, m = w
-        from_ring = step > 0                                    # step 0 is the injected beam of the head rank
-        if islice == nz - 1:
-            engine.set_beam_import(from_ring)
-            engine.begin_step()
-        if from_ring:
-            waited = False
-            for k in (islice, islice - 1):                      # this slice and the next one (jx/jy source)
-                if k < 0 or (m, k) in have:
-                    continue
-                rq = pending_recv.pop((m, k), None)
-                if rq is not None:
-                    rq.wait()
-                    waited = True
-                if waited and str(device) != "cpu":
-                    torch.cuda.current_stream().synchronize()
-                engine.import_beam_slice(k, rpool[m % 2][nz - 1 - k])
-                have.add((m, k))
-        engine.solve_slice(islice)
-        if step + 1 < n_steps:
-            if world == 1:
-                engine.export_beam_slice(islice, rpool[(m + 1) % 2][nz - 1 - islice])      # in-process hand-off
-            else:
-                slot = spool[tick % len(spool)]
-                engine.export_beam_slice(islice, slot)
-                exported[tick] = slot
-        engine.sync()                                         # the message is complete before it is sent
-        solved += 1
-        while len(pending_send) > 4:
-            pending_send.pop(0).wait()
-        if islice == 0:
-            have = {h for h in have if h[0] != m}
-            if on_step_end is not None:
-                on_step_end(step)
-    for rq in pending_send:
-        rq.wait()
-    return solved
+    def __init__(self, rank, world, device_index, group=None):
+        from . import _lib
+        self._lib, self._check = _lib.lib(), _lib.check
+        self.rank, self.world = rank, world
+        my = C.create_string_buffer(128)
+        self._check(self._lib.hps_ring_unique_id(my))
+        ids = [None] * world
+        if world > 1:
+            dist.all_gather_object(ids, my.raw, group=group)
+        else:
+            ids[0] = my.raw
+        h = C.c_void_p()
+        self._check(self._lib.hps_ring_init(rank, world, int(device_index), ids[(rank - 1) % world] if world > 1 else None,
+                                            ids[rank], C.byref(h)))
+        self._h = h
+
+    def send(self, t, after_event=None, slot=0):
+        done = C.c_void_p()
+        self._check(self._lib.hps_ring_send_slice(self._h, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(),
+                                                  C.c_void_p(after_event) if after_event else None, int(slot), C.byref(done)))
+        return done.value
+
+    def recv(self, t, after_event=None, slot=0):
+        done = C.c_void_p()
+        self._check(self._lib.hps_ring_recv_slice(self._h, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(),
+                                                  C.c_void_p(after_event) if after_event else None, int(slot), C.byref(done)))
+        return done.value
+
+    def sendrecv_self(self, src, dst, after_event=None, slot=0):
+        done = C.c_void_p()
+        self._check(self._lib.hps_ring_sendrecv_self(self._h, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()),
+                                                     src.numel() * src.element_size(),
+                                                     C.c_void_p(after_event) if after_event else None, int(slot), C.byref(done)))
+        return done.value
+
+    def engine_wait(self, engine, ev):
+        engine.wait_event(ev)
+
+    def recv_after(self, ev):
+        if ev:
+            self._check(self._lib.hps_ring_stream_wait(self._h, 0, C.c_void_p(ev)))
+
+    def sync_sends(self):
+        self._check(self._lib.hps_ring_sync_sends(self._h))
+
+    def finish(self):
+        self._check(self._lib.hps_ring_sync(self._h))
+
+    def stats(self):
+        ns, nr, bs, br = C.c_long(), C.c_long(), C.c_longlong(), C.c_longlong()
+        self._check(self._lib.hps_ring_stats(self._h, C.byref(ns), C.byref(nr), C.byref(bs), C.byref(br)))
+        return dict(sent=ns.value, received=nr.value, bytes_sent=bs.value, bytes_received=br.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hps_ring_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
 
 
-def make_edge_groups(world):
-    """Process groups for the ring edges of `run_local_pipeline` with world > 1 (collective: every rank calls it, in
-    the same order).  Edge r -> r+1 uses group colour(r); a rank's incoming and outgoing edge never share a group, so
-    its receiving thread and its sending thread each own one communicator (a proper edge colouring of the ring: two
-    colours, three when the ring is odd)."""
+def make_transport(rank, world, device):
+    """The transport `run_pipeline` uses by default: none for one rank (in-process hand-off), gloo point-to-point on
+    the CPU, the RCCL ring on a GPU."""
     if world == 1:
         return None
-    return [dist.new_group(list(range(world))) for _ in range(3)]
+    if str(device) == "cpu":
+        return GlooTransport(rank, world)
+    dev = torch.device(device)
+    return RcclTransport(rank, world, dev.index if dev.index is not None else torch.cuda.current_device())
 
 
-def _edge_colour(r, world):
-    return 2 if (world % 2 == 1 and r == world - 1) else r % 2
+# event-pool slots of the engine (hps_engine_record_event) used by the driver
+_EV_SLICE, _EV_STEP, _EV_LFREE = 0, 64, 80
 
 
-def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_step=None, rank=0, world=1,
-                       groups=None):
-    """Several time steps in flight on ONE device: the ring pipeline with L = len(engines) of its stages in this process.
+def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_per_step=None, transport=None,
+                 laser_lookahead=8, on_slice=None):
+    """Run steps rank, rank+world, ... < n_steps of `engine` with the per-slice ring hand-off.
 
-    Stage g = rank*L + j (engine j of this rank, one stream each, all on `device`) runs steps g, g+G, ... < n_steps,
-    G = world*L, exactly as rank g of `run_pipeline` would.  What couples the stages is the same per-slice beam
-    hand-off: stage g solves slice k of step s only after stage g-1 has pushed slices k and k-1 of step s-1.  Between
-    two engines of this process that is a device-to-device copy (MultiBuffer.cpp:299-308, the reference's in-process
-    "send to myself") ordered by stream events; between the last engine of a rank and the first engine of the next
-    rank (world > 1) it is one point-to-point message per slice on that edge's own process group (`make_edge_groups`:
-    the sending and the receiving thread of a rank never share a communicator, every edge carries one ordered sequence
-    of messages posted in the same order on both sides).  One host thread per engine (the multigrid's stopping rule
-    holds its host thread once per slice; ctypes releases the GIL), so while one step sits in a latency-bound phase --
-    the lower multigrid levels, a DST pass, a launch gap -- the kernels of the others fill the device.  Static beam
-    only (hipace.dt = 0, as every BASELINE deck).
+    engine: SliceEngine-like (begin_step, solve_slice, sync, record_event, wait_event, copy_async, beam_layout,
+    set_beam_storage, initial_beam_into, ...; the oracle's Engine has the same interface).
+    slices_per_step: None = whole steps; an int = only the head slices of every step (benchmark runs shorter than one
+    box); a list with one entry per rank (non-increasing, n_steps <= world) lets the ranks stop at different slices --
+    the pre-filled pipeline of bench.py.  on_slice(m, q): called before slice q (from the head) of this rank's m-th
+    step is solved, and once more with q = number of slices after the last one.
+    Returns the number of slices this rank solved.
+    """
+    nz = engine.deck["nz"]
+    if slices_per_step is None:
+        counts = [nz] * world
+    elif isinstance(slices_per_step, int):
+        counts = [slices_per_step] * world
+    else:
+        counts = [int(c) for c in slices_per_step]
+        assert len(counts) == world and all(counts[r] >= counts[r + 1] for r in range(world - 1))
+        assert len(set(counts)) == 1 or n_steps <= world, "rank-dependent slice counts need a ring that does not close"
+    per, per_prev = counts[rank], counts[(rank - 1) % world]
+    assert 1 <= per <= nz and per_prev <= nz
+    moving = bool(getattr(engine, "moving", False))
+    laser = bool(getattr(engine, "has_laser", False))
+    assert not (moving and (per != nz or per_prev != nz)), "a moving beam (hipace.dt != 0) needs whole steps"
+    my_steps = steps_of_rank(rank, world, n_steps)
+    own_transport = transport is None and world > 1
+    T = make_transport(rank, world, device) if own_transport else transport
+    assert world == 1 or T is not None
+    closes = n_steps > world
+    f64 = dict(dtype=torch.float64, device=device)
 
-    Returns the number of slices this process solved.
+    nbeam, off = engine.beam_layout()
+    bufs = rpool = spool = None
+    if moving:
+        cap = engine.beam_capacity()
+        mlen = 1 + 7 * cap
+        # receive slots: two steps' worth (a rank holds the early slices of its next step); send slots rotate
+        rpool = [[torch.zeros(mlen, **f64) for _ in range(nz)] for _ in range(2)]
+        spool = [torch.zeros(mlen, **f64) for _ in range(16)] if world > 1 else []
+    else:
+        bufs = [torch.zeros(max(7 * nbeam, 1), **f64) for _ in range(2)]
+        if rank == 0:
+            engine.initial_beam_into(bufs[0])        # only the head rank injects the beam (as the reference)
+    spool_done = [None] * (len(spool) if spool else 0)
+    ring_laser = laser and world > 1                 # one rank: the engine rotates its own time levels
+    lookahead = per_prev
+    lpool, lspool = [], []
+    if ring_laser:
+        llen = engine.laser_message_doubles()
+        if not closes:
+            lookahead = max(2, min(laser_lookahead, per_prev))
+        lpool = [torch.zeros(llen, **f64) for _ in range(lookahead + 3)]
+        lspool = [torch.zeros(llen, **f64) for _ in range(4)]
+    lpool_free = [None] * len(lpool)
+    lspool_done = [None] * len(lspool)
+
+    def block(buf, q):                                # q-th slice from the head = block q
+        return buf[7 * off[q]:7 * off[q + 1]]
+
+    # ---- receives, in the order the previous rank sends: per fed step, per slice: beam message, laser message ----
+    fed_steps = [(m, s) for m, s in enumerate(my_steps) if s > 0] if world > 1 else []
+    fed_index = {m: f for f, (m, _) in enumerate(fed_steps)}
+    n_incoming = len(fed_steps) * per_prev
+    recv_ev = {}                                      # (m, j, kind) -> event [, laser pool slot]
+    send_done_static = {}                             # (m % 2, j) -> event of the last send out of that block
+    step_done = [None, None]
+    state = dict(posted=0, nl=0, ns=0, nls=0)
+
+    def post_until(frontier):
+        """post the receives of the incoming slices with linear index < frontier"""
+        frontier = min(frontier, n_incoming)
+        while state["posted"] < frontier:
+            f, j = divmod(state["posted"], per_prev)
+            m = fed_steps[f][0]
+            if moving:
+                if j == 0 and step_done[m % 2] is not None:
+                    T.recv_after(step_done[m % 2])    # the slots' previous contents (step m-2) have been imported
+                recv_ev[(m, j, 0)] = (T.recv(rpool[m % 2][j], None, ((m % 2) * nz + j) * 2), None)
+            else:
+                blk = block(bufs[m % 2], j)
+                if blk.numel() > 0:
+                    recv_ev[(m, j, 0)] = (T.recv(blk, send_done_static.pop((m % 2, j), None), ((m % 2) * nz + j) * 2), None)
+            if ring_laser:
+                k = state["nl"] % len(lpool)
+                state["nl"] += 1
+                recv_ev[(m, j, 1)] = (T.recv(lpool[k], lpool_free[k], ((m % 2) * nz + j) * 2 + 1), k)
+                lpool_free[k] = None
+            state["posted"] += 1
+
+    solved = 0
+    for m, step in enumerate(my_steps):
+        fed = step > 0
+        from_ring = fed and world > 1
+        if moving:
+            engine.set_beam_import(fed)
+        else:
+            engine.set_beam_storage(bufs[m % 2], injected_beam_support=True)     # hipace.dt = 0: the beam never moves
+        if ring_laser:
+            # the rank that runs step 0 evaluates the initial envelope; every later step receives a_n, a_{n-1} slice by
+            # slice from the rank that ran the step before (MultiBuffer.cpp:840-852, 913-925)
+            engine.set_laser_import(fed, step)
+        engine.begin_step()
+        imported = -1
+        for q in range(per):
+            if on_slice is not None:
+                on_slice(m, q)
+            islice = nz - 1 - q
+            if world > 1:
+                if from_ring:
+                    pos = fed_index[m] * per_prev + q
+                else:                                  # step 0 of the head rank: the next fed step starts `per - q` slices on
+                    nxt = fed_index.get(m + 1)
+                    pos = (nxt * per_prev - (per - q)) if nxt is not None else n_incoming
+                post_until(pos + lookahead + 1)
+            if from_ring:
+                need = min(q + 1, per_prev - 1)        # this slice's beam and the next one's (jx/jy source)
+                post_until(fed_index[m] * per_prev + need + 1)
+                while imported < need:
+                    imported += 1
+                    ev = recv_ev.pop((m, imported, 0), None)
+                    if ev is not None:
+                        T.engine_wait(engine, ev[0])
+                        if moving:
+                            engine.import_beam_slice(nz - 1 - imported, rpool[m % 2][imported])
+                    if ring_laser:
+                        ev, k = recv_ev.pop((m, imported, 1))
+                        T.engine_wait(engine, ev)
+                        engine.import_laser_slice(nz - 1 - imported, lpool[k])
+                        lpool_free[k] = engine.record_event(_EV_LFREE + k)
+            elif fed and moving and world == 1:
+                for k in (q, q + 1):                   # in-process hand-off: the blocks were exported by the previous step
+                    if k < nz and imported < k:
+                        engine.import_beam_slice(nz - 1 - k, rpool[m % 2][k])
+                        imported = k
+            engine.solve_slice(islice)
+            solved += 1
+            if step + 1 < n_steps:
+                if world == 1:                         # MultiBuffer.cpp:299-308: send to myself
+                    if moving:
+                        engine.export_beam_slice(islice, rpool[(m + 1) % 2][q])
+                    else:
+                        src, dst = block(bufs[m % 2], q), block(bufs[(m + 1) % 2], q)
+                        if src.numel() > 0:
+                            engine.copy_async(dst, src)
+                else:
+                    out = []
+                    if moving:
+                        k = state["ns"] % len(spool)
+                        state["ns"] += 1
+                        T.engine_wait(engine, spool_done[k])          # the slot's previous message has left
+                        engine.export_beam_slice(islice, spool[k])
+                        out.append(("b", k, spool[k]))
+                    else:
+                        blk = block(bufs[m % 2], q)
+                        if blk.numel() > 0:
+                            out.append(("s", q, blk))
+                    if ring_laser:
+                        k = state["nls"] % len(lspool)
+                        state["nls"] += 1
+                        T.engine_wait(engine, lspool_done[k])
+                        engine.export_laser_slice(islice, lspool[k])
+                        out.append(("l", k, lspool[k]))
+                    if out:
+                        ev = engine.record_event(_EV_SLICE + q % 64)  # the slice (its push, the exports) is done
+                        for kind, k, t in out:
+                            if kind == "b":
+                                spool_done[k] = T.send(t, ev, 4 * nz + k)
+                            elif kind == "l":
+                                lspool_done[k] = T.send(t, ev, 4 * nz + 32 + k)
+                            else:
+                                send_done_static[(m % 2, k)] = T.send(t, ev, (m % 2) * nz + k)
+        if moving:
+            step_done[m % 2] = engine.record_event(_EV_STEP + m % 2)
+        if on_slice is not None:
+            on_slice(m, per)
+        if on_step_end is not None:
+            on_step_end(step)
+    if world > 1:
+        post_until(n_incoming)                         # what the previous rank sends beyond my last slice is still received
+        engine.sync()
+        T.finish()
+        if own_transport:
+            T.close()
+    return solved
+
+
+def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_step=None):
+    """Several time steps in flight on ONE device: the ring pipeline with all L = len(engines) of its stages in this
+    process.
+
+    Stage j (engine j, one stream each, all on `device`) runs steps j, j+L, ... < n_steps, exactly as rank j of
+    `run_pipeline` would.  What couples the stages is the same per-slice beam hand-off: stage j solves slice k of step s
+    only after stage j-1 has pushed slices k and k-1 of step s-1 -- here a device-to-device copy
+    (MultiBuffer.cpp:299-308, the reference's in-process "send to myself") ordered by stream events.  One host thread
+    per engine (the multigrid's stopping rule holds its host thread once per slice; ctypes releases the GIL), so while
+    one step sits in a latency-bound phase -- the lower multigrid levels, a DST pass, a launch gap -- the kernels of the
+    others fill the device.  Static beam only (hipace.dt = 0, as every BASELINE deck).  One process only: between
+    ranks the hand-off is `run_pipeline`'s (one stage per rank; all RCCL calls of a rank come from one thread).
+
+    Returns the number of slices solved.
     """
     import threading
     L = len(engines)
-    G = world * L
     nz = engines[0].deck["nz"]
     per_step = slices_per_step or nz
     assert per_step >= 2, "a step needs at least two slices"
-    assert world == 1 or groups is not None, "world > 1 needs make_edge_groups(world)"
     laser = bool(getattr(engines[0], "has_laser", False))
     on_gpu = str(device) != "cpu"
     nbeam, off = engines[0].beam_layout()
     assert nbeam == 0 or not getattr(engines[0], "moving", False), "run_local_pipeline hands a static beam on (hipace.dt = 0)"
     bufs = [[torch.zeros(max(7 * nbeam, 1), dtype=torch.float64, device=device) for _ in range(2)] for _ in range(L)]
-    if rank == 0:
-        engines[0].initial_beam_into(bufs[0][0])      # only the head of the ring injects the beam
-        engines[0].sync()
-    prev_rank, next_rank = (rank - 1) % world, (rank + 1) % world
-    g_in = groups[_edge_colour(prev_rank, world)] if world > 1 else None
-    g_out = groups[_edge_colour(rank, world)] if world > 1 else None
+    engines[0].initial_beam_into(bufs[0][0])          # only the head of the ring injects the beam
+    engines[0].sync()
 
-    def block(buf, q):
-        p = q                                          # q-th slice from the head = block q
-        return buf[7 * off[p]:7 * off[p + 1]]
+    def block(buf, q):                                 # q-th slice from the head = block q
+        return buf[7 * off[q]:7 * off[q + 1]]
 
     cond = threading.Condition()
     progress = [0] * L                                 # slices enqueued so far by each engine
@@ -285,17 +397,10 @@ def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_st
             if on_gpu:
                 torch.cuda.set_device(device)
             eng, pj = engines[j], (j - 1) % L
-            stage = rank * L + j
-            remote_in = world > 1 and j == 0           # my predecessor stage lives on the previous rank
-            remote_out = world > 1 and j == L - 1      # my successor stage lives on the next rank
-            sends = []
-            # laser messages on the rank-to-rank edges: {a_{n+1}, a_n} of a slice, packed / unpacked on the device
-            lmsg_in = torch.zeros(eng.laser_message_doubles(), dtype=torch.float64, device=device) if (laser and remote_in) else None
-            lpool = []                                  # (buffer, request) of the laser sends in flight
-            for m, step in enumerate(range(stage, n_steps, G)):
+            for m, step in enumerate(range(j, n_steps, L)):
                 buf = bufs[j][m % 2]
                 fed = step > 0                          # step 0 starts from the injected beam
-                mp = (step - 1 - (rank * L + pj)) // G if (fed and not remote_in) else None
+                mp = (step - 1 - pj) // L if fed else None
                 if nbeam > 0:
                     eng.set_beam_storage(buf, injected_beam_support=True)
                 if laser:
@@ -308,61 +413,26 @@ def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_st
                 for q in range(per_step):
                     if fed:
                         need = min(q + 1, per_step - 1)             # this slice's beam and the next one's (jx/jy source)
-                        if remote_in:
-                            # same order as the sender posts them: per slice the beam block (if any), then the laser
-                            while copied <= need:
-                                d = block(buf, copied)
-                                if d.numel() > 0:
-                                    dist.irecv(d, src=prev_rank, group=g_in).wait()
-                                    if on_gpu:
-                                        torch.cuda.current_stream().synchronize()   # landed before the engine's stream reads it
-                                if laser:
-                                    dist.irecv(lmsg_in, src=prev_rank, group=g_in).wait()
-                                    if on_gpu:
-                                        torch.cuda.current_stream().synchronize()
-                                    eng.import_laser_slice(nz - 1 - copied, lmsg_in)
-                                    eng.sync()                      # lmsg_in is free for the next slice
-                                copied += 1
-                        else:
-                            with cond:
-                                while progress[pj] < mp * per_step + need + 1 and not errors:
-                                    cond.wait(timeout=1.0)
-                                ev = events[pj].get((mp, need))
-                            if errors:
-                                return
-                            eng.wait_event(ev)
-                            src = bufs[pj][mp % 2]
-                            while copied <= need:
-                                d, s_ = block(buf, copied), block(src, copied)
-                                if d.numel() > 0:
-                                    eng.copy_async(d, s_)
-                                copied += 1
-                            if laser:
-                                while lcopied <= need:
-                                    eng.import_laser_from(nz - 1 - lcopied, engines[pj])
-                                    lcopied += 1
+                        with cond:
+                            while progress[pj] < mp * per_step + need + 1 and not errors:
+                                cond.wait(timeout=1.0)
+                            ev = events[pj].get((mp, need))
+                        if errors:
+                            return
+                        eng.wait_event(ev)
+                        src = bufs[pj][mp % 2]
+                        while copied <= need:
+                            d, s_ = block(buf, copied), block(src, copied)
+                            if d.numel() > 0:
+                                eng.copy_async(d, s_)
+                            copied += 1
+                        if laser:
+                            while lcopied <= need:
+                                eng.import_laser_from(nz - 1 - lcopied, engines[pj])
+                                lcopied += 1
                     eng.solve_slice(nz - 1 - q)
                     solved[j] += 1
-                    if remote_out:
-                        if step + 1 < n_steps:
-                            t = block(buf, q)
-                            if t.numel() > 0:
-                                eng.sync()                          # the slice's beam block is final before it is sent
-                                sends.append(dist.isend(t, dst=next_rank, group=g_out))
-                                # never block on a send here: with one stage per rank this thread also posts the
-                                # receives its peer's sends are waiting for (a whole step of blocks may be in flight)
-                                while sends and sends[0].is_completed():
-                                    sends.pop(0)
-                            if laser:
-                                free = [k for k, (_, rq) in enumerate(lpool) if rq.is_completed()]
-                                if free:
-                                    lb = lpool.pop(free[0])[0]
-                                else:                               # never wait for a send (see above): take a new buffer
-                                    lb = torch.zeros(eng.laser_message_doubles(), dtype=torch.float64, device=device)
-                                eng.export_laser_slice(nz - 1 - q, lb)
-                                eng.sync()
-                                lpool.append((lb, dist.isend(lb, dst=next_rank, group=g_out)))
-                    ev = eng.record_event((m % 2) * per_step + q)
+                    ev = eng.record_event(128 + (m % 2) * per_step + q)
                     with cond:
                         events[j][(m, q)] = ev
                         events[j].pop((m - 2, q), None)
@@ -370,10 +440,6 @@ def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_st
                         cond.notify_all()
                 if on_step_end is not None:
                     on_step_end(step, eng)
-            for rq in sends:
-                rq.wait()
-            for _, rq in lpool:
-                rq.wait()
         except BaseException as e:      # noqa: BLE001 -- re-raised on the caller's thread
             with cond:
                 errors.append(e)

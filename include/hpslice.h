@@ -198,8 +198,8 @@ typedef struct {
     /* a Gaussian laser envelope (laser/Laser.H:32-45; CEP 0, no propagation angle) drives the wake:
      * |a|^2 goes into the slab component "aabs" (appended last) and enters the deposition, the explicit source and the
      * pusher.  laser_solver = 1 ("fft", MultiLaser::AdvanceSliceFFT) advances the envelope by hipace.dt every step
-     * (laser_use_phase = lasers.use_phase); 0 keeps it static.  The multigrid envelope solver is not built.
-     * Explicit solver, per-particle kernels. */
+     * (laser_use_phase = lasers.use_phase); 2 ("multigrid", MultiLaser::AdvanceSliceMG, hpmg system type 2) likewise;
+     * 0 keeps it static.  Explicit solver only; LDS-tile and per-particle kernels. */
     int laser_on; double laser_a0, laser_w0, laser_L0, laser_lambda0, laser_pos[3];
     double laser_zfoc; int laser_solver; int laser_use_phase;
     /* hipace.normalized_units = 0: the constants of utils/Constants.H:15-24 (2018 CODATA), charges in C, masses in kg,
@@ -309,7 +309,9 @@ int hps_engine_sorts (void* handle, long* n_sorts_host);
 /* HIP-event phase timers on the engine's stream.  phase_times sums, over the slices solved since
  * profiling was switched on (or since the last call), the milliseconds spent in
  * {deposit_current, poisson x3 (+rhs, grad), explicit_deposit, mg_solve1, advance_plasma, other,
- * particle re-sort} into ms_host[7] and stores the slice count; it synchronises the stream. */
+ * particle re-sort, empty interval} into ms_host[8] and stores the slice count; it synchronises the stream.
+ * "empty interval" = two event records back to back (no kernel between them; 0 when the schedule has no such pair):
+ * what every interval carries on top of its kernels. */
 int hps_engine_set_profiling (void* handle, int on);
 /* time every stride-th slice only (default 1): the 11 event records of a profiled slice cost about 3.4 us each
  * (4.5 % of a 1024^2 slice at stride 1, measured); phase_times then sums over the profiled slices */
@@ -351,9 +353,36 @@ int hps_engine_record_event (void* handle, int slot, void** event_out);
 int hps_engine_wait_event (void* handle, void* event);
 int hps_engine_copy_async (void* handle, void* dst_dev, const void* src_dev, long bytes);
 
-/* ---- ring pipeline over time steps (utils/MultiBuffer.H:21-34; MultiBuffer.cpp:444-609) --------
- * The hand-off itself is issued by the host driver (hipace_amd/pipeline.py) with RCCL
- * point-to-point (torch.distributed backend "nccl") on the beam blocks above. */
+/* ---- ring pipeline over time steps: the transport (utils/MultiBuffer.H:21-34; MultiBuffer.cpp:287-609) --------
+ * One process per GPU; rank r runs time steps r, r+N, ... (Hipace.cpp:400-401) and hands every pushed beam slice (and
+ * the laser envelope of the slice) to rank r+1.  The reference does that with MPI_Isend / MPI_Irecv between ring
+ * neighbours (MultiBuffer::make_progress :287-442, put_data :444-493, get_data :495-609); here it is RCCL
+ * ncclSend / ncclRecv over xGMI on device buffers.  Every edge r -> r+1 of the ring is its own 2-rank communicator
+ * with its own stream, so sends and receives of a rank progress independently; ordering against the engine is by
+ * events only (hps_engine_record_event / hps_engine_wait_event), never by a host synchronisation.
+ *
+ * Bootstrap (host driver, e.g. hipace_amd/pipeline.py over torch.distributed's store): rank r makes the id of ITS
+ * outgoing edge with hps_ring_unique_id and hands it to rank r+1; hps_ring_init(rank, world, device, id of the edge
+ * (r-1 -> r), id of the edge (r -> r+1)) is collective over the ring.  world = 1: id_edge_in may be NULL, the ring is
+ * a 1-rank communicator and hps_ring_sendrecv_self is the hand-off (MultiBuffer.cpp:299-308, "send to myself"). */
+#define HPS_RING_ID_BYTES 128
+int hps_ring_unique_id (char* id_out /* [HPS_RING_ID_BYTES] */);
+int hps_ring_init (int rank, int world, int device, const char* id_edge_in, const char* id_edge_out, void** ring);
+/* put_data: `bytes` at msg_dev go to rank+1.  The send waits (on the device) for after_event (hipEvent_t, may be NULL);
+ * *done_event (pool slot `slot` of the ring's send events) fires when msg_dev may be overwritten. */
+int hps_ring_send_slice (void* ring, const void* msg_dev, long bytes, void* after_event, int slot, void** done_event);
+/* get_data: post the receive of the next message from rank-1 into msg_dev (messages arrive in the order they were
+ * sent).  The receive waits for after_event (may be NULL); *done_event (pool slot `slot` of the receive events) fires
+ * when the data has landed: hps_engine_wait_event(engine, *done_event) before the slice that reads it. */
+int hps_ring_recv_slice (void* ring, void* msg_dev, long bytes, void* after_event, int slot, void** done_event);
+int hps_ring_sendrecv_self (void* ring, const void* src_dev, void* dst_dev, long bytes, void* after_event, int slot,
+                            void** done_event);
+/* the ring's receive (which = 0) or send (which = 1) stream waits for an event of another stream */
+int hps_ring_stream_wait (void* ring, int which, void* event);
+int hps_ring_sync_sends (void* ring);           /* host waits until everything sent so far has left */
+int hps_ring_sync (void* ring);                 /* host waits for both streams of the ring (end of a run) */
+int hps_ring_stats (void* ring, long* n_sent, long* n_received, long long* bytes_sent, long long* bytes_received);
+int hps_ring_destroy (void* ring);
 
 /* ---- utilities ---------------------------------------------------------------------------- */
 int hps_memcpy_d2h (void* dst_host, const void* src_dev, long bytes);

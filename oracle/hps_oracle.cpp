@@ -39,10 +39,20 @@
 #include <limits>
 #include <vector>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 namespace {
 
 using std::size_t;
 typedef double Real;
+
+// CPU-baseline leg of bench.py: number of OpenMP threads (orc_set_threads).  1 = the reference's serial CPU path,
+// exactly the loops below in their written order (what the golden checksums are pinned on).  > 1 = the reference's
+// OpenMP build: scatter kernels over 4-colour tiles (particles/deposition/DepositionUtil.H:204-253), everything else
+// `omp parallel for` over independent rows / particles (bit-identical to the serial loops).
+int g_threads = 1;
 
 // ---------------------------------------------------------------------------------------------
 // Shape factors                                  particles/particles_utils/ShapeFactors.H
@@ -226,6 +236,41 @@ struct Geom {
     int normalized;
 };
 
+// Particle loop of a scatter kernel.  One thread: particles in storage order (DepositionUtil.H:256-264).  Several:
+// particles binned by the tile of their nearest cell, tiles visited in 4 colours so that no two threads write to the
+// same cell (DepositionUtil.H:204-253, hipace.tile_size = 32 >= the widest stencil).
+template <class F>
+void scatter_loop (const Plasma& pl, const Geom& gm, int nx, int ny, F&& body)
+{
+    if (g_threads <= 1) { for (long ip = 0; ip < pl.n; ++ip) body(ip); return; }
+    const int ts = 32;
+    const int ntx = (nx + ts - 1)/ts, nty = (ny + ts - 1)/ts;
+    std::vector<long> offs((size_t)ntx*nty + 2, 0);
+    std::vector<int> tile_of((size_t)pl.n);
+    const Real dx_inv = 1.0/gm.dx, dy_inv = 1.0/gm.dy;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (long ip = 0; ip < pl.n; ++ip) {
+        int t = ntx*nty;
+        if (pl.valid[ip]) {
+            int ci = (int)std::floor((pl.x[ip] - gm.xoff)*dx_inv + 0.5), cj = (int)std::floor((pl.y[ip] - gm.yoff)*dy_inv + 0.5);
+            ci = std::min(std::max(ci, 0), nx - 1); cj = std::min(std::max(cj, 0), ny - 1);
+            t = (ci/ts)*nty + cj/ts;
+        }
+        tile_of[(size_t)ip] = t;
+    }
+    for (long ip = 0; ip < pl.n; ++ip) ++offs[(size_t)tile_of[(size_t)ip] + 1];
+    for (size_t t = 0; t + 1 < offs.size(); ++t) offs[t + 1] += offs[t];
+    std::vector<long> perm((size_t)pl.n), cur(offs.begin(), offs.end() - 1);
+    for (long ip = 0; ip < pl.n; ++ip) perm[(size_t)cur[(size_t)tile_of[(size_t)ip]]++] = ip;
+    for (int px = 0; px < 2; ++px) for (int py = 0; py < 2; ++py) {
+#pragma omp parallel for collapse(2) num_threads(g_threads) schedule(dynamic)
+        for (int tx = px; tx < ntx; tx += 2) for (int ty = py; ty < nty; ty += 2) {
+            const size_t t = (size_t)tx*nty + ty;
+            for (long q = offs[t]; q < offs[t + 1]; ++q) body(perm[(size_t)q]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Plasma current deposition      particles/deposition/PlasmaDepositCurrent.cpp:155-246,
 // serial semantics of            particles/deposition/DepositionUtil.H:256-264
@@ -260,8 +305,8 @@ long deposit_current (const Slab& f, const Plasma& pl, const Geom& gm, const int
     const Real charge_invvol = charge*invvol;
     const Real charge_mu0_mass_ratio = charge*gm.mu0/mass;
     long n_qsa = 0;
-    for (long ip = 0; ip < pl.n; ++ip) {
-        if (!pl.valid[ip]) continue;
+    scatter_loop(pl, gm, f.nx, f.ny, [&] (long ip) {
+        if (!pl.valid[ip]) return;
         const Real psi_inv = 1.0/pl.psi[ip];
         const Real xp = pl.x[ip], yp = pl.y[ip];
         const Real vx_c = pl.ux[ip]*psi_inv;
@@ -280,7 +325,9 @@ long deposit_current (const Slab& f, const Plasma& pl, const Geom& gm, const int
                                     + vx_c*vx_c*clightinv*clightinv
                                     + vy_c*vy_c*clightinv*clightinv + 1.0);
         if (gamma_psi < 0.0 || gamma_psi > max_qsa || psi_inv < 0.0) {
-            ++n_qsa; pl.w[ip] = 0.0; pl.valid[ip] = 0; continue;
+#pragma omp atomic
+            ++n_qsa;
+            pl.w[ip] = 0.0; pl.valid[ip] = 0; return;
         }
         Real sx[4], sy[4];
         const int i0 = shape_factor(order, sx, xmid);
@@ -299,7 +346,7 @@ long deposit_current (const Slab& f, const Plasma& pl, const Geom& gm, const int
                 if (comp[5] != -1) f(i,j,comp[5]) += charge_density;
             }
         }
-    }
+    });
     return n_qsa;
 }
 
@@ -318,8 +365,8 @@ void explicit_deposit (const Slab& f, const Plasma& pl, const Geom& gm, const in
     const Real a_clight = gm.c, clight_inv = 1.0/gm.c;
     const Real charge_invvol_mu0 = charge*invvol*gm.mu0;
     const Real charge_mass_ratio = charge/mass;
-    for (long ip = 0; ip < pl.n; ++ip) {
-        if (!pl.valid[ip]) continue;
+    scatter_loop(pl, gm, f.nx, f.ny, [&] (long ip) {
+        if (!pl.valid[ip]) return;
         const Real psi_inv = 1.0/pl.psi[ip];
         const Real xp = pl.x[ip], yp = pl.y[ip];
         const Real vx = pl.ux[ip]*psi_inv*clight_inv;
@@ -384,7 +431,7 @@ void explicit_deposit (const Slab& f, const Plasma& pl, const Geom& gm, const in
                     ))*a_clight);
             }
         }
-    }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -485,6 +532,7 @@ void advance_plasma (const Slab& f, const Plasma& pl, const Geom& gm, const int*
     const Real dz = gm.dz/n_subcycles;
     const Real clight = gm.c, clight_inv = 1.0/gm.c;
     const Real charge_mass_clight_ratio = charge/(mass*gm.c);
+#pragma omp parallel for num_threads(g_threads) schedule(static) if(g_threads > 1)
     for (long ip = 0; ip < pl.n; ++ip) {
         if (!pl.valid[ip]) continue;
         Real ExmByp = 0, EypBxp = 0, Ezp = 0, Bxp = 0, Byp = 0, Bzp = 0;
@@ -601,11 +649,22 @@ struct DstPlan {
         }
     }
     // in-place RODFT00: X_k = 2 sum_j x_j sin(pi (j+1)(k+1)/(n+1)), strided
-    void apply (double* x, long stride) {
+    void apply (double* x, long stride) { apply_with(x, stride, a, b); }
+    void apply_with (double* x, long stride, std::vector<cplx>& a, std::vector<cplx>& b) const {
         a[0] = 0; a[n+1] = 0;
         for (int j = 0; j < n; ++j) { a[j+1] = x[j*stride]; a[N2-1-j] = -x[j*stride]; }
         fft_rec(N2, 1, a.data(), b.data(), tw, N2);
         for (int k = 0; k < n; ++k) x[k*stride] = -b[k+1].imag();
+    }
+    // all `count` transforms of a pass (x + q*step, element stride `stride`); threads own whole transforms
+    void apply_many (double* x, long stride, long step, int count) {
+        if (g_threads <= 1) { for (int q = 0; q < count; ++q) apply(x + q*step, stride); return; }
+#pragma omp parallel num_threads(g_threads)
+        {
+            std::vector<cplx> ta((size_t)N2), tb((size_t)N2);
+#pragma omp for schedule(static)
+            for (int q = 0; q < count; ++q) apply_with(x + q*step, stride, ta, tb);
+        }
     }
 };
 
@@ -630,11 +689,11 @@ struct PoissonSolver {
         bool all_zero = true;   // exact shortcut: a zero source has the zero solution
         for (size_t k = 0; k < (size_t)nx*ny && all_zero; ++k) all_zero = (st[k] == 0.0);
         if (all_zero) return;
-        for (int j = 0; j < ny; ++j) px.apply(st + (size_t)j*nx, 1);
-        for (int i = 0; i < nx; ++i) py.apply(st + i, nx);
+        px.apply_many(st, 1, nx, ny);
+        py.apply_many(st, nx, 1, nx);
         for (size_t k = 0; k < (size_t)nx*ny; ++k) st[k] *= eig[k];
-        for (int j = 0; j < ny; ++j) px.apply(st + (size_t)j*nx, 1);
-        for (int i = 0; i < nx; ++i) py.apply(st + i, nx);
+        px.apply_many(st, 1, nx, ny);
+        py.apply_many(st, nx, 1, nx);
     }
 };
 
@@ -778,11 +837,15 @@ struct MG {
             for (int n = 0; n < 2; ++n) for (int j = jl; j <= jh; ++j) for (int i = il; i <= ih; ++i)
                 w(i,j,n) = (*phi_in)(i,j,n);
         }
+        const bool par = g_threads > 1 && (long)(ih - il + 1)*(jh - jl + 1) >= 4096;
         for (int icolor = 0; icolor < 4; ++icolor) {
+            // cells of one colour do not read each other: rows can go to different threads, same result
+#pragma omp parallel for num_threads(g_threads) schedule(static) if(par)
             for (int j = jl; j <= jh; ++j) for (int i = il; i <= ih; ++i) {
                 if ((i + j + icolor) % 2 == 0) gs_point(i, j, l, w, rhs, acf, facx, facy);
             }
         }
+#pragma omp parallel for num_threads(g_threads) schedule(static) if(par)
         for (int j = jl; j <= jh; ++j) for (int i = il; i <= ih; ++i) {
             if (do_res) res_point(i, j, l, w, rhs, acf, facx, facy, (*res)(i,j,0), (*res)(i,j,1));
             phi_out(i,j,0) = w(i,j,0);
@@ -807,6 +870,7 @@ struct MG {
         int il, jl, ih, jh; valid(c, il, jl, ih, jh);
         View crse{crse_a.data(), c.nxb, c.csz(), 0, 0};
         CView fine{fine_a.data(), f.nxb, f.csz(), 0, 0};
+#pragma omp parallel for collapse(2) num_threads(g_threads) schedule(static) if(g_threads > 1 && (long)(ih - il + 1)*(jh - jl + 1) >= 4096)
         for (int n = 0; n < ncomp; ++n) for (int j = jl; j <= jh; ++j) for (int i = il; i <= ih; ++i) {
             if (cc) {
                 crse(i,j,n) = 0.25*(fine(2*i,2*j,n) + fine(2*i+1,2*j,n) + fine(2*i,2*j+1,n) + fine(2*i+1,2*j+1,n));
@@ -825,6 +889,7 @@ struct MG {
         MGLevel& f = L[ilev]; MGLevel& c = L[ilev+1];
         int il, jl, ih, jh; valid(f, il, jl, ih, jh);
         CView fin = clv(f, f.cor); CView crse = clv(c, c.cor); View fout = lv(f, f.rescor);
+#pragma omp parallel for collapse(2) num_threads(g_threads) schedule(static) if(g_threads > 1 && (long)(ih - il + 1)*(jh - jl + 1) >= 4096)
         for (int n = 0; n < 2; ++n) for (int j = jl; j <= jh; ++j) for (int i = il; i <= ih; ++i) {
             const int ic = coarsen2(i), jc = coarsen2(j);
             if (cc) {
@@ -1948,6 +2013,16 @@ struct orc_deck {
     double laser_mg_tol_rel, laser_mg_tol_abs;
     int beam_radiation_reaction; double background_density_SI; int beam_no_z_push;
 };
+
+// threads of the CPU-baseline leg (see g_threads); returns the number actually set
+int orc_set_threads (int n) {
+#ifdef _OPENMP
+    g_threads = std::max(1, std::min(n, omp_get_max_threads() > 0 ? std::max(omp_get_max_threads(), n) : n));
+#else
+    (void)n; g_threads = 1;
+#endif
+    return g_threads;
+}
 
 void* orc_engine_create (const orc_deck* k) {
     Deck d;

@@ -32,6 +32,16 @@ def build(force=False):
     return so
 
 
+def set_threads(n):
+    """OpenMP threads of the oracle's hot loops (bench.py's CPU-baseline leg).  1 (the default) = the serial path the golden
+    checksums are pinned on; > 1 = 4-colour tiles in the scatter kernels (DepositionUtil.H:204-253), parallel rows
+    elsewhere."""
+    L = lib()
+    L.orc_set_threads.restype = C.c_int
+    L.orc_set_threads.argtypes = [C.c_int]
+    return L.orc_set_threads(int(n))
+
+
 class Slab(C.Structure):
     _fields_ = [("p", C.c_void_p), ("nx", C.c_int), ("ny", C.c_int), ("g", C.c_int), ("ncomp", C.c_int)]
 

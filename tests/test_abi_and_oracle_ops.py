@@ -186,3 +186,42 @@ def test_oracle_beam_box_sort_against_a_serial_loop(oracle):
         assert np.array_equal(c, np.array(cnt, dtype=np.uint64))
         assert np.array_equal(o, np.array(off, dtype=np.uint64))
         assert np.array_equal(p, np.array(perm, dtype=np.uint64))
+
+
+def test_oracle_openmp_leg_agrees_with_the_serial_path(oracle):
+    """bench.py's CPU baseline times the oracle with 1 thread and with all host cores (4-colour tiles in the scatter
+    kernels, DepositionUtil.H:204-253).  The threaded leg must compute the same slices: same V-cycle counts, fields equal
+    to summation-order rounding."""
+    d = decks.blowout_wake()
+    d.update(nx=96, ny=96, nz=10, lo=(-8.0, -8.0, -0.6), hi=(8.0, 8.0, 0.6), plasma_ppc=(2, 2))
+    res = []
+    try:
+        for nt in (1, 4):
+            assert oracle.set_threads(nt) == nt
+            e = oracle.Engine(d)
+            e.run()
+            res.append((e.slab().copy(), e.vcycles(), e.checksums()))
+    finally:
+        oracle.set_threads(1)
+    assert res[0][1] == res[1][1] > 0
+    for c in range(res[0][0].shape[0]):
+        assert np.abs(res[0][0][c] - res[1][0][c]).max() <= 1e-9 * max(np.abs(res[0][0][c]).max(), 1e-300), c
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run with N ranks (one
+    per GPU); a launcher that started a different number of ranks is refused.  (--spawn-check: launch path only, gloo.)"""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-check"], capture_output=True,
+                         text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d == {"spawn_check": True, "n_gpus": 2, "world_size": 2}
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-check"], capture_output=True,
+                         text=True, timeout=120, cwd=ROOT, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "--gpus 2" in bad.stderr

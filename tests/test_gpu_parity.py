@@ -81,9 +81,9 @@ def test_explicit_deposit(api, oracle, order, dtype):
     assert np.array_equal(out[rest], slab[rest])
 
 
-@pytest.mark.parametrize("order", [0, 1, 2, 3])
-@pytest.mark.parametrize("bc", [0, 1, 2])
-def test_advance_plasma(api, oracle, order, bc):
+@pytest.mark.parametrize("order,bc,nsc", [(o, b, 1) for o in (0, 1, 2, 3) for b in (0, 1, 2)] + [(2, 1, 2), (3, 0, 3), (1, 2, 2)])
+def test_advance_plasma(api, oracle, order, bc, nsc):
+    """nsc = <plasma>.n_subcycles (PlasmaParticleAdvance.cpp:92-217: the gather is repeated at the new position)."""
     n = 64
     g = (order + 1) // 2 + 1
     real, valid, ion = thermal_sheet(n, n, LO, HI, ppc=2, seed=11 + bc, u_std=0.3)
@@ -96,12 +96,12 @@ def test_advance_plasma(api, oracle, order, bc):
     slab = smooth_slab(n, n, g, amp=0.2)
     r2, v2 = real.copy(), valid.copy()
     oracle.advance_plasma(slab, n, n, g, r2, v2, ion, _oracle_geom(oracle, n, n, dz=0.4, bc=bc),
-                          [11, 7, 8, 9, 10], -1.0, 1.0, order)
+                          [11, 7, 8, 9, 10], -1.0, 1.0, order, n_subcycles=nsc)
     assert 0.1 < r2[5][v2 != 0].min() and r2[5].max() < 20.0     # well-conditioned inputs
     f = api.Fields(n, n, g, NCOMP, data=slab)
     pl = api.PlasmaSheet(real, valid, ion)
     api.AdvancePlasmaParticles(pl, f, api.Geometry(n, n, LO, HI, 0.4, bc=bc), -1.0, 1.0, order, Psi=11, Ez=7, Bx=8,
-                               By=9, Bz=10)
+                               By=9, Bz=10, n_subcycles=nsc)
     greal, gvalid = pl.numpy()
     assert np.array_equal(gvalid, v2)
     if bc == 2:
@@ -436,12 +436,18 @@ def test_beam_evolution_matches_reference_checksums(api, oracle):
 
 
 @pytest.mark.gpu
-def test_beam_slipping_matches_oracle(api, oracle):
+@pytest.mark.parametrize("dt,n_steps", [(0.9, 6), (4.0, 2)])
+def test_beam_slipping_matches_oracle(api, oracle, dt, n_steps):
     """A slow, hot beam (u_z = 1.2: v_z = 0.77 c) falls back through the slices: the slice populations and every
-    particle's state after 6 steps equal the oracle's (as sets: the device partition is not order preserving)."""
+    particle's state after the steps equal the oracle's (as sets: the device partition is not order preserving).
+    dt = 4: a particle slips 0.23*4/0.4 = 2.3 cells per step, i.e. through SEVERAL slices in one step, and is pushed again
+    on every slice it lands on (BeamParticleAdvance.cpp:131, "IncludingSlipped") -- slices that were empty at the start
+    of the step fill up during it."""
     deck = decks.beam_evolution()
     deck.update(nz=12, lo=(-2.0, -2.0, -2.4), hi=(2.0, 2.0, 2.4), beam_zmin=-1.0, beam_zmax=1.6, beam_umean=(0.0, 0.0, 1.2),
-                beam_density=1.0e-3, n_steps=6, dt=0.9, beam_n_subcycles=4, ext_E_slope=(0.3, 0.2))
+                beam_density=1.0e-3, n_steps=n_steps, dt=dt, beam_n_subcycles=4 if dt < 1 else 16, ext_E_slope=(0.3, 0.2))
+    if dt > 1:
+        deck.update(beam_zmin=0.4, beam_zmax=1.6)        # three populated slices at the head, nine empty ones behind
     eng = api.SliceEngine(deck, tile_size=0)
     eng.set_diagnostics(True)
     for _ in range(deck["n_steps"]):
@@ -842,8 +848,76 @@ def test_bench_line_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.05 < r["frac"] < 1.0
     assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "slices/s" and c["value"] > 0
+    assert c["kind"] == "port" and 1 <= c["cores"] <= c["host_cores"] and c["unit"] == "slices/s" and c["value"] > 0
+    assert c["serial_value"] > 0
     assert "workload" in d["config"] and "model" not in d["config"]
+    # a short run is not taken at the (cheap) head of the box, every timed slice carries the event timers, and the
+    # line says where the traffic figure comes from
+    t = d["timed_slices"]
+    assert t["first"] >= 400 and t["last"] - t["first"] + 1 == 96 and d["profiled_slices"] == 96 // 7 + (96 % 7 > 0)
+    assert r["traffic"] is None or "profiles/" in r["traffic_source"]
+    assert d["vcycles_per_slice"] > 1.0
+
+
+@pytest.mark.gpu
+def test_bench_short_run_times_every_slice():
+    """The driver's `--steps 20 --warmup 5`: 20 slices at the representative window, timers on every one of them."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                          "--cpu-slices", "0"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["profiled_slices"] == 20
+    assert d["timed_slices"]["first"] >= 400 and d["vcycles_per_slice"] > 1.0
+
+
+@pytest.mark.gpu
+def test_rccl_ring_carries_the_beam_on_one_gpu(api):
+    """The C-ABI ring on RCCL with the one rank a 1-GPU box has: hps_ring_init makes a 1-rank communicator and
+    hps_ring_sendrecv_self (MultiBuffer.cpp:299-308, "send to myself") moves every beam block of step 0 into the storage
+    step 1 reads -- ncclSend / ncclRecv, ordered against the engine by events only.  Step 1 reproduces the reference's
+    checksums, i.e. the beam did arrive through RCCL."""
+    import torch
+    from hipace_amd.pipeline import RcclTransport
+    gold = json.load(open(os.path.join(GOLD, "blowout_wake_explicit.2Rank.json")))["lev=0"]
+    deck = decks.blowout_wake()
+    nz = deck["nz"]
+    eng = api.SliceEngine(deck)
+    eng.set_diagnostics(True)
+    T = RcclTransport(0, 1, 0)
+    nbeam, off = eng.beam_layout()
+    bufs = [torch.zeros(7 * nbeam, dtype=torch.float64, device="cuda") for _ in range(2)]
+    eng.initial_beam_into(bufs[0])
+    moved = 0
+    landed = {}
+    eng.set_beam_storage(bufs[0], injected_beam_support=True)
+    eng.begin_step()
+    for q in range(nz):
+        eng.solve_slice(nz - 1 - q)
+        if off[q + 1] > off[q]:
+            ev = eng.record_event(q % 64)                  # behind the slice's last kernel
+            src, dst = bufs[0][7 * off[q]:7 * off[q + 1]], bufs[1][7 * off[q]:7 * off[q + 1]]
+            landed[q] = T.sendrecv_self(src, dst, ev, q)   # ncclSend + ncclRecv as one group on the ring's stream
+            moved += src.numel() * 8
+    eng.set_beam_storage(bufs[1], injected_beam_support=True)
+    eng.begin_step()
+    for q in range(nz):
+        for j in (q, q + 1):
+            if j in landed:
+                eng.wait_event(landed.pop(j))              # device-side: the block has landed
+        eng.solve_slice(nz - 1 - q)
+    eng.sync()
+    T.finish()
+    st = T.stats()
+    assert st["sent"] == st["received"] > 0 and st["bytes_sent"] == moved == 7 * 8 * nbeam
+    assert torch.equal(bufs[0], bufs[1])
+    cs = eng.checksums()
+    for k, v in gold.items():
+        if v != 0.0:
+            assert abs(cs[k] - v) <= 1e-9 * abs(v), (k, cs[k], v)
+    T.close()
 
 
 @pytest.mark.gpu

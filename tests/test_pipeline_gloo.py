@@ -1,4 +1,4 @@
-"""Ring pipeline over time steps, world_size 2, gloo on CPU.
+"""Ring pipeline over time steps, world_size 2-4, gloo on CPU.
 
 The product driver (hipace_amd/pipeline.py) is run unchanged; the CPU oracle engine stands in for
 the HIP engine (same beam-block interface), so this checks the message schedule: the head rank
@@ -145,57 +145,6 @@ def test_local_pipeline_several_steps_in_flight(oracle, lanes, n_steps):
             assert abs(cs[k] - v) <= 1e-12 * max(abs(v), 1e-300), (step, k, cs[k], v)
 
 
-def _lanes_worker(rank, world, port, lanes, n_steps, out):
-    import torch.distributed as dist
-    from hipace_amd.pipeline import make_edge_groups, run_local_pipeline
-    from oracle import oracle as O
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    groups = make_edge_groups(world)
-    engs = [O.Engine(_deck()) for _ in range(lanes)]
-    sums = {}
-
-    def on_step_end(step, eng):
-        sums[step] = eng.checksums()
-
-    solved = run_local_pipeline(engs, n_steps, "cpu", on_step_end, rank=rank, world=world, groups=groups)
-    out.put((rank, solved, sums))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("world,lanes,n_steps", [(2, 2, 9), (3, 2, 13), (2, 1, 5), (2, 3, 6)])
-def test_ring_of_ranks_with_several_stages_each(oracle, world, lanes, n_steps):
-    """run_local_pipeline with world > 1: `lanes` pipeline stages per rank (stage = rank*lanes + lane), in-process
-    hand-off between the stages of a rank, one message per slice on the rank-to-rank edges (each edge on its own
-    process group; odd rings need the third colour).  Every step of the closed ring has the checksums of a single run."""
-    ref = oracle.Engine(_deck())
-    ref.run()
-    want = ref.checksums()
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_lanes_worker, args=(r, world, port, lanes, n_steps, out)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = [out.get(timeout=240) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    seen = {}
-    G = world * lanes
-    for rank, solved, sums in results:
-        for step, cs in sums.items():
-            assert rank * lanes <= step % G < (rank + 1) * lanes          # the stage that ran it lives on this rank
-            seen[step] = cs
-    assert sorted(seen) == list(range(n_steps))
-    assert sum(r[1] for r in results) == n_steps * _deck()["nz"]
-    for step, cs in seen.items():
-        for k, v in want.items():
-            assert abs(cs[k] - v) <= 1e-12 * max(abs(v), 1e-300), (step, k, cs[k], v)
-
-
 @pytest.mark.parametrize("lanes", [1, 2, 3])
 def test_local_pipeline_hands_the_laser_envelope_on(oracle, lanes):
     """An evolving laser pulse in a plasma with several steps in flight: every stage receives a_n and a_{n-1} of its step
@@ -235,31 +184,31 @@ def _laser_deck():
     return d
 
 
-def _laser_lanes_worker(rank, world, port, lanes, n_steps, out):
+def _laser_worker(rank, world, port, n_steps, out):
     import torch.distributed as dist
-    from hipace_amd.pipeline import make_edge_groups, run_local_pipeline
+    from hipace_amd.pipeline import run_pipeline
     from oracle import oracle as O
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    groups = make_edge_groups(world)
-    engs = [O.Engine(_laser_deck()) for _ in range(lanes)]
+    eng = O.Engine(_laser_deck())
     res = {}
 
-    def on_step_end(step, eng):
+    def on_step_end(step):
         res[step] = (eng.checksums(), eng.laser_envelope().copy())
 
-    run_local_pipeline(engs, n_steps, "cpu", on_step_end, rank=rank, world=world, groups=groups)
+    run_pipeline(eng, rank, world, n_steps, "cpu", on_step_end, laser_lookahead=3)
     out.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,lanes,n_steps", [(2, 1, 5), (2, 2, 6)])
-def test_laser_envelope_travels_between_ranks(oracle, world, lanes, n_steps):
-    """The laser's time levels on the rank-to-rank edges of run_local_pipeline: one message per slice ({a_{n+1}, a_n},
-    packed and unpacked by the engines), in the same order as the beam blocks; every step has the envelope and the
-    checksums of a single engine running the steps in turn."""
+@pytest.mark.parametrize("world,n_steps", [(2, 2), (2, 5), (3, 4)])
+def test_laser_envelope_travels_between_ranks(oracle, world, n_steps):
+    """The laser's time levels on the ring: one message per slice ({a_{n+1}, a_n}, packed and unpacked by the engines)
+    behind the slice's beam block; every step has the envelope and the checksums of a single engine running the steps in
+    turn -- with a short receive look-ahead when the ring does not close (n_steps <= ranks) and a whole step of it when
+    it does."""
     import numpy as np
     d = _laser_deck()
     ref = oracle.Engine(d)
@@ -272,7 +221,7 @@ def test_laser_envelope_travels_between_ranks(oracle, world, lanes, n_steps):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_laser_lanes_worker, args=(r, world, port, lanes, n_steps, out)) for r in range(world)]
+    procs = [ctx.Process(target=_laser_worker, args=(r, world, port, n_steps, out)) for r in range(world)]
     for p in procs:
         p.start()
     results = [out.get(timeout=240) for _ in range(world)]
@@ -287,3 +236,57 @@ def test_laser_envelope_travels_between_ranks(oracle, world, lanes, n_steps):
         assert np.array_equal(got[s][1], want[s][1]), s
         for k, v in want[s][0].items():
             assert abs(got[s][0][k] - v) <= 1e-12 * max(abs(v), 1e-300), (s, k)
+
+
+def _prefilled_worker(rank, world, port, counts, out):
+    import torch.distributed as dist
+    from hipace_amd.pipeline import run_pipeline
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = O.Engine(_deck())
+    seen = []
+    marks = {}
+
+    def on_slice(m, q):
+        seen.append((m, q))
+        if q == counts[rank] - 4:          # every rank pauses 4 slices before ITS end: rank r is 2r slices behind rank 0
+            dist.barrier()
+            marks["paused_at"] = q
+
+    solved = run_pipeline(eng, rank, world, world, "cpu", slices_per_step=counts, on_slice=on_slice)
+    out.put((rank, solved, seen, marks, eng.checksums()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_prefilled_pipeline_with_rank_dependent_slice_counts(oracle, world):
+    """bench.py's short timed runs: rank r solves 2r slices fewer than rank 0, so that all ranks can pause at a barrier
+    with the pipeline filled (rank r-1 two slices ahead of rank r) and then time the same number of slices each.  The
+    ranks stop at different slices, the barrier inside the run does not deadlock, and what a later rank computed for its
+    slices equals the single-process result for those slices."""
+    n0 = 16
+    counts = [n0 - 2 * r for r in range(world)]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prefilled_worker, args=(r, world, port, counts, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, solved, seen, marks, cs in results:
+        assert solved == counts[rank]
+        assert seen == [(0, q) for q in range(counts[rank] + 1)]
+        assert marks["paused_at"] == counts[rank] - 4
+        ref = oracle.Engine(_deck())
+        ref.begin_step()
+        for q in range(counts[rank]):
+            ref.solve_slice(_deck()["nz"] - 1 - q)
+        want = ref.checksums()
+        for k, v in want.items():
+            assert abs(cs[k] - v) <= 1e-12 * max(abs(v), 1e-300), (rank, k, cs[k], v)
