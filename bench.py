@@ -34,9 +34,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+CPU_THREADS_DEFAULT = 32  # OpenMP leg of the CPU baseline: more threads than this lose on the 256-core host (profiles/r02b_cpu_threads.json)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PMC_SUMMARY = "r02_pmc_fetch_write_per_kernel.csv"      # profiles/: rocprofv3 --pmc summary of the shipped kernels
-START_SLICE_DEFAULT = 600  # short runs start here (from the head); see profiles/r02_slice_cost_profile.json
+START_SLICE_DEFAULT = 700  # short runs start here (from the head); see profiles/r02a_slice_cost_profile.json
 
 
 def algorithmic_bytes(n, ppc2):
@@ -124,7 +125,8 @@ def main():
     ap.add_argument("--tile", type=int, default=16, help="particle tile size (0, 16, 32)")
     ap.add_argument("--sort-period", type=int, default=128, help="max slices between particle re-sorts (adaptive below)")
     ap.add_argument("--cpu-slices", type=int, default=4, help="slices of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline's OpenMP leg (0 = all host cores)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help=f"threads of the CPU baseline's OpenMP leg (0 = min(host cores, {CPU_THREADS_DEFAULT}))")
     ap.add_argument("--start-slice", type=int, default=-1,
                     help="--steps < nz: slice (counted from the head) where the warm-up + timed window starts; -1 = "
                          f"{START_SLICE_DEFAULT} scaled to the box (a window there costs what the whole box costs on average)")
@@ -207,8 +209,9 @@ def main():
             dist.barrier()
 
     def profiling(on):
+        # short runs time every slice: only the 4 event records the roofline needs (11 would cost 4.5 % of a slice)
         for e in engines:
-            e.set_profiling(on, stride=stride)
+            e.set_profiling(on, stride=stride, light=short)
 
     transport = None
     if world > 1:
@@ -311,6 +314,8 @@ def main():
         overhead = per_kernel.pop("empty_interval", 0.0)
         raw = per_kernel[dom]
         kernel_ms = max(raw - overhead, 0.0) if lanes == 1 else raw
+        if short:       # light timers: only the deposition was timed
+            per_kernel = {k: (v if k == dom else None) for k, v in per_kernel.items()}
         achieved = ab[dom] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         headline = args.tile == 16 and args.n == 1024 and args.ppc == 2 and not args.config5 and not args.config2
         traffic, traffic_source = pmc_traffic("void hps::k_deposit_tiled<2, 16, 51>") if headline else (None, None)
@@ -349,7 +354,7 @@ def main():
                                             "minus the interval between two back-to-back event records measured on the same slices"},
         }
         if args.cpu_slices > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.n, args.ppc, args.cpu_slices, args.cpu_threads or (os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(args.n, args.ppc, args.cpu_slices, args.cpu_threads or min(os.cpu_count() or 1, CPU_THREADS_DEFAULT))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

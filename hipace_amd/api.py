@@ -344,10 +344,11 @@ class SliceEngine:
     def set_diagnostics(self, on=True):
         check(_lib.lib().hps_engine_set_diagnostics(self._h, int(on)))
 
-    def set_profiling(self, on=True, stride=1):
-        """HIP-event phase timers; stride > 1 times every stride-th slice only (an event record costs ~3.4 us)."""
+    def set_profiling(self, on=True, stride=1, light=False):
+        """HIP-event phase timers; stride > 1 times every stride-th slice only (an event record costs ~3.4 us);
+        light: only the deposition kernel and the kernel-free interval (4 records per slice instead of 11)."""
         check(_lib.lib().hps_engine_set_profiling_stride(self._h, int(stride)))
-        check(_lib.lib().hps_engine_set_profiling(self._h, int(on)))
+        check(_lib.lib().hps_engine_set_profiling(self._h, (2 if light else 1) if on else 0))
 
     def beam_layout(self):
         """-> (nbeam, offsets[nz+1]): block p (p-th slice from the head) holds particles offsets[p]:offsets[p+1]."""

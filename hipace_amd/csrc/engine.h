@@ -62,7 +62,7 @@ struct Engine {
     int* d_nqsa = nullptr;
     double* d_checksum = nullptr;
     bool diagnostics = false;
-    bool profiling = false; int prof_stride = 1; bool prof_now = false;      // events on every prof_stride-th slice
+    bool profiling = false; bool prof_light = false; int prof_stride = 1; bool prof_now = false;      // events on every prof_stride-th slice
     std::vector<hipEvent_t> ev; size_t ev_used = 0;      // 11 events per profiled slice
     std::vector<hipEvent_t> hand_ev;                     // hps_engine_record_event pool (no timing)
     void mark ();

@@ -632,8 +632,11 @@ int Engine::deposit_beam_slice (int islice, int cjx, int cjy, int cjz)
 void Engine::mark ()
 {
     if (!prof_now) return;
+    const int k = (int)(ev_used % 11);                  // which of the 11 marks of a slice this is
     if (ev_used == ev.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev.push_back(e); }
-    (void)hipEventRecord(ev[ev_used++], st);
+    // light mode: only the marks around the deposition kernel (2, 3) and the kernel-free pair (4, 5)
+    if (!prof_light || (k >= 2 && k <= 5)) (void)hipEventRecord(ev[ev_used], st);
+    ++ev_used;
 }
 
 // ---- field diagnostics (Fields::Copy, fields/Fields.cpp:413-533) ---------------------------------------------------
@@ -1372,7 +1375,7 @@ extern "C" int hps_engine_set_profiling (void* h, int on)
 {
     Engine* E = static_cast<Engine*>(h);
     HPS_HIP_CHECK(hipStreamSynchronize(E->st));
-    E->profiling = (on != 0); E->ev_used = 0; E->prof_now = false;
+    E->profiling = (on != 0); E->prof_light = (on == 2); E->ev_used = 0; E->prof_now = false;
     return HPS_OK;
 }
 extern "C" int hps_engine_set_profiling_stride (void* h, int stride)
@@ -1395,6 +1398,7 @@ extern "C" int hps_engine_phase_times (void* h, double* ms, long* nsl)
     const bool empty4 = !E->pc && !E->moving && E->nbeam > 0;
     for (size_t s = 0; s < ns; ++s)
         for (int k = 0; k < 10; ++k) {
+            if (E->prof_light && k != 2 && k != 4) continue;     // light mode recorded marks 2..5 only
             float t = 0.f;
             HPS_HIP_CHECK(hipEventElapsedTime(&t, E->ev[s*11 + k], E->ev[s*11 + k + 1]));
             ms[phase_of[k]] += t;

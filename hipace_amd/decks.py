@@ -52,7 +52,39 @@ _DEFAULT = dict(
     laser_use_phase=1,       # lasers.use_phase (MultiLaser.H:203)
     grid_current_on=0, grid_current_peak=0.0, grid_current_mean=(0.0, 0.0, 0.0), grid_current_std=(1.0, 1.0, 1.0),   # grid_current.*
     si_units=0,              # hipace.normalized_units = 0: SI constants, charges and masses in C and kg, weights = charges
+    # second plasma species "ion" with ADK field ionisation; the released electrons join the first species
+    # (<ion>.ionization_product, PlasmaParticleContainer.cpp:61-90, 261-440)
+    plasma_no_neutralize=0,  # <plasma>.neutralize_background = false for the first species
+    ion_on=0, ion_ppc=(0, 0), ion_density=0.0, ion_mass=0.0, ion_charge=0.0, ion_init_level=0, ion_Z=0,
+    ion_energies=(0.0,) * 56, ion_seed=0,
 )
+
+# Ionisation energies in eV of a few elements: NIST Atomic Spectra Database (Kramida, Ralchenko, Reader and NIST ASD
+# Team, ver. 5.2), the values the reference tabulates in utils/IonizationEnergiesTable.H.
+IONIZATION_ENERGIES_EV = {
+    "H": (13.59843449,),
+    "He": (24.58738880, 54.4177650),
+    "Li": (5.39171495, 75.6400964, 122.4543581),
+    "N": (14.53413, 29.60125, 47.4453, 77.4735, 97.8901, 552.06732, 667.046116),
+    "Ar": (15.7596117, 27.62967, 40.735, 59.58, 74.84, 91.290, 124.41, 143.4567, 422.60, 479.76, 540.4, 619.0, 685.5,
+           755.13, 855.5, 918.375, 4120.6656, 4426.2228),
+}
+M_P_DA = 1.007276466621      # proton mass in Da; <plasma>.mass_Da is converted with m_p / 1.007276466621 (PlasmaParticleContainer.cpp:118-122)
+
+
+def with_ion_species(d, element, density, ppc=(1, 1), mass_Da=None, initial_level=0, seed=0):
+    """Add the species "ion" of `element` to deck d (in place): <ion>.element / mass_Da / initial_ion_level / ppc /
+    density, ionization_product = the first species.  Charge +e per level, mass in units of the deck (kg in SI, electron
+    masses in normalised units)."""
+    en = IONIZATION_ENERGIES_EV[element]
+    m_p_SI, m_e_SI, q_e_SI = 1.67262192369e-27, 9.1093837015e-31, 1.602176634e-19
+    mass_Da = mass_Da if mass_Da is not None else {"H": 1.008, "He": 4.002602, "Li": 6.94, "N": 14.007, "Ar": 39.948}[element]
+    mass_SI = m_p_SI * mass_Da / M_P_DA
+    si = bool(d.get("si_units", 0))
+    d.update(ion_on=1, ion_ppc=tuple(ppc), ion_density=density, ion_mass=mass_SI if si else mass_SI / m_e_SI,
+             ion_charge=q_e_SI if si else 1.0, ion_init_level=initial_level, ion_Z=len(en),
+             ion_energies=tuple(en) + (0.0,) * (56 - len(en)), ion_seed=seed)
+    return d
 
 
 def blowout_wake():
@@ -267,3 +299,19 @@ def predictor_corrector(base, tol=1.0e-4, max_iter=7, mix=0.0635):
 
 NAMED = dict(radiation_reaction=radiation_reaction, gaussian_linear_wake=gaussian_linear_wake, gaussian_linear_wake_SI=gaussian_linear_wake_SI, reset=reset, grid_current=grid_current, beam_in_vacuum_SI_Serial=beam_in_vacuum_SI_Serial, blowout_wake_step0=blowout_wake_step0, linear_wake_gaussian=linear_wake_gaussian, laser_blowout_wake=laser_blowout_wake, laser_blowout_wake_SI=laser_blowout_wake_SI, linear_wake_SI=linear_wake_SI, blowout_wake_SI=blowout_wake_SI, beam_in_vacuum_SI=beam_in_vacuum_SI, beam_in_vacuum_1Rank=beam_in_vacuum_1Rank, blowout_wake=blowout_wake, linear_wake=linear_wake, beam_in_vacuum=beam_in_vacuum,
              beam_evolution=beam_evolution, beam_in_vacuum_open_boundary=beam_in_vacuum_open_boundary)
+
+
+def ionization_SI():
+    """examples/blowout_wake/inputs_ionization_SI as tests/ionization.2Rank.sh runs it (hipace.dt = 1e-12, max_step = 2):
+    neutral hydrogen (one macro-atom per cell), no electrons to begin with (elec.ppc = 0 0), a flat-top driver whose field
+    ionises the gas; the released electrons form the wake."""
+    ne = 1.25e24
+    c, ep0, q_e, m_e = 299792458.0, 8.8541878128e-12, 1.602176634e-19, 9.1093837015e-31
+    kp_inv = c / (ne * q_e * q_e / (ep0 * m_e)) ** 0.5
+    d = copy.deepcopy(_DEFAULT)
+    d.update(nx=64, ny=64, nz=100, lo=(-20.0e-6, -20.0e-6, -30.0e-6), hi=(20.0e-6, 20.0e-6, 30.0e-6), order=2, si_units=1,
+             plasma_ppc=(0, 0), plasma_density=ne, plasma_charge=-q_e, plasma_mass=m_e, plasma_no_neutralize=1,
+             beam_profile=1, beam_zmin=25.0e-6 - 2.0 * kp_inv, beam_zmax=25.0e-6, beam_radius=kp_inv / 2.0, beam_density=4.0 * ne,
+             beam_umean=(0.0, 0.0, 2000.0), beam_ppc=(1, 1, 1), beam_charge=-q_e, beam_mass=m_e,
+             n_steps=3, dt=1.0e-12, bc=1)
+    return with_ion_species(d, "H", ne, ppc=(1, 1), mass_Da=1.008, initial_level=0)

@@ -312,6 +312,7 @@ int hps_engine_sorts (void* handle, long* n_sorts_host);
  * particle re-sort, empty interval} into ms_host[8] and stores the slice count; it synchronises the stream.
  * "empty interval" = two event records back to back (no kernel between them; 0 when the schedule has no such pair):
  * what every interval carries on top of its kernels. */
+/* on = 1: all phases; on = 2: only the deposition kernel and the empty interval (4 event records per slice instead of 11) */
 int hps_engine_set_profiling (void* handle, int on);
 /* time every stride-th slice only (default 1): the 11 event records of a profiled slice cost about 3.4 us each
  * (4.5 % of a 1024^2 slice at stride 1, measured); phase_times then sums over the profiled slices */

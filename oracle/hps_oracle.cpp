@@ -1068,6 +1068,12 @@ struct Deck {
     int laser_use_phase;         // lasers.use_phase (MultiLaser.H:203, default true)
     int grid_current_on = 0;     // grid_current.use_grid_current (utils/GridCurrent.cpp:13-23)
     double grid_current_peak = 0., grid_current_mean[3] = {0., 0., 0.}, grid_current_std[3] = {1., 1., 1.};
+    // second plasma species "ion" with ADK field ionisation (ionization_product = the first species):
+    // PlasmaParticleContainer.cpp:61-90 (element, mass_Da, initial_ion_level, can_ionize), PlasmaParticleContainerInit.cpp:382-464
+    int plasma_no_neutralize = 0;      // <plasma>.neutralize_background = false for the first species
+    int ion_on = 0; int ion_ppc[2] = {0, 0}; double ion_density = 0., ion_mass = 0., ion_charge = 0.;
+    int ion_init_level = 0; int ion_Z = 0; double ion_energies[56] = {0.};       // eV, IonizationEnergiesTable.H (NIST)
+    unsigned long long ion_seed = 0;   // counter-based generator (the reference draws from amrex::Random: sequence not reproducible)
 };
 
 // particles of one beam slice; [0, nreg) were on the slice when the step began ("regular"), the rest slipped in
@@ -1078,6 +1084,10 @@ struct Engine {
     Deck d; Geom gm; int g; int ncomp;
     std::vector<double> slab_data; Slab slab;
     std::vector<double> pdata; std::vector<int32_t> pvalid, pion; Plasma pl;
+    long pl_cap = 0;                         // capacity of the first species' arrays (grows by ionisation)
+    std::vector<double> idata; std::vector<int32_t> ivalid, ilev; std::vector<uint64_t> iuid; Plasma ipl;      // species "ion"
+    std::vector<double> adk_prefactor, adk_exp_prefactor, adk_power;
+    long n_ionized_total = 0; int cur_step = -1;
     PoissonSolver* ps; MG* mg; std::vector<double> staging;
     Beam beam_this, beam_next; int beam_this_slice = -2;      // slice whose particles beam_this holds
     // dt != 0: the beam lives in per-slice stores across the time steps (index = islice)
@@ -1116,6 +1126,7 @@ struct Engine {
         slab_data.assign((size_t)ns*ncomp, 0.0);
         slab = Slab{slab_data.data(), d.nx, d.ny, g, ncomp, js, ns};
         ps = new PoissonSolver(d.nx, d.ny, gm.dx, gm.dy);
+        init_ionization();
         mg = d.bxby_solver ? nullptr : new MG(d.nx, d.ny, gm.dx, gm.dy);
         staging.assign((size_t)d.nx*d.ny, 0.0);
         checksum.assign((size_t)ncomp, 0.0);
@@ -1130,34 +1141,142 @@ struct Engine {
 
     // PlasmaParticleContainer::InitParticles (plasma/PlasmaParticleContainerInit.cpp:17-378),
     // fixed ppc, uniform density, no fine patch, u = 0; ppc index outermost (:192)
-    void init_plasma () {
-        const int nppc = d.plasma_ppc[0]*d.plasma_ppc[1];
-        // scale_fac (PlasmaParticleContainerInit.cpp:40-41): density per particle, or in SI the number of electrons it stands for
-        const double scale = nppc <= 0 ? 0. : (d.si_units ? gm.dx*gm.dy*gm.dz/nppc : 1.0/nppc);
+    // positions of the fixed-ppc lattice of one species (ppc index outermost, :192)
+    void lattice (const int ppc[2], double density, std::vector<double>& xs, std::vector<double>& ys) const {
+        const int nppc = ppc[0]*ppc[1];
         const double rad = d.plasma_radius > 0 ? d.plasma_radius : std::numeric_limits<double>::infinity();
-        std::vector<double> xs, ys;
         for (int ip = 0; ip < nppc; ++ip) {
-            const int ixp = ip % d.plasma_ppc[0], iyp = ip / d.plasma_ppc[0];
-            const double r0 = (0.5 + ixp)/d.plasma_ppc[0], r1 = (0.5 + iyp)/d.plasma_ppc[1];
+            const int ixp = ip % ppc[0], iyp = ip / ppc[0];
+            const double r0 = (0.5 + ixp)/ppc[0], r1 = (0.5 + iyp)/ppc[1];
             for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i) {
                 const double x = d.lo[0] + (i + r0)*gm.dx;
                 const double y = d.lo[1] + (j + r1)*gm.dy;
                 const double rsq = x*x + y*y;
                 if (x >= gm.phi[0] || x < gm.plo[0] || y >= gm.phi[1] || y < gm.plo[1] ||
-                    rsq > rad*rad || d.plasma_density <= 0.0) continue;
+                    rsq > rad*rad || density <= 0.0) continue;
                 xs.push_back(x); ys.push_back(y);
             }
         }
+    }
+    static void fill_species (Plasma& p, const std::vector<double>& xs, const std::vector<double>& ys, double w, int lev) {
+        for (long k = 0; k < (long)xs.size(); ++k) {
+            p.x[k] = xs[k]; p.y[k] = ys[k]; p.w[k] = w;
+            p.ux[k] = 0; p.uy[k] = 0; p.psi[k] = std::sqrt(1.0) - 0.0;
+            p.x_prev[k] = xs[k]; p.y_prev[k] = ys[k];
+            p.ux_half[k] = 0; p.uy_half[k] = 0; p.psi_half[k] = p.psi[k];
+            p.valid[k] = 1; p.ion_lev[k] = lev;
+        }
+    }
+
+    // PlasmaParticleContainer::InitParticles (plasma/PlasmaParticleContainerInit.cpp:17-378),
+    // fixed ppc, uniform density, no fine patch, u = 0; ppc index outermost (:192)
+    void init_plasma () {
+        const int nppc = d.plasma_ppc[0]*d.plasma_ppc[1];
+        // scale_fac (PlasmaParticleContainerInit.cpp:40-41): density per particle, or in SI the number of electrons it stands for
+        const double scale = nppc <= 0 ? 0. : (d.si_units ? gm.dx*gm.dy*gm.dz/nppc : 1.0/nppc);
+        std::vector<double> xs, ys;
+        lattice(d.plasma_ppc, d.plasma_density, xs, ys);
         const long n = (long)xs.size();
-        pdata.assign((size_t)n*11, 0.0); pvalid.assign((size_t)n, 1); pion.assign((size_t)n, 0);
+        // species "ion": every ion can release Z - initial level electrons into the first species
+        std::vector<double> ixs, iys;
+        if (d.ion_on) lattice(d.ion_ppc, d.ion_density, ixs, iys);
+        const long ni = (long)ixs.size();
+        const long cap = n + ni*std::max(d.ion_Z - d.ion_init_level, 0);
+        if (cap != pl_cap || pdata.empty()) {
+            pl_cap = cap;
+            pdata.assign((size_t)std::max(cap, 1L)*11, 0.0); pvalid.assign((size_t)std::max(cap, 1L), 0); pion.assign((size_t)std::max(cap, 1L), 0);
+        }
         double* b = pdata.data();
-        pl = Plasma{b, b+n, b+2*n, b+3*n, b+4*n, b+5*n, b+6*n, b+7*n, b+8*n, b+9*n, b+10*n,
+        const long c = std::max(cap, 1L);
+        pl = Plasma{b, b+c, b+2*c, b+3*c, b+4*c, b+5*c, b+6*c, b+7*c, b+8*c, b+9*c, b+10*c,
                     pvalid.data(), pion.data(), n};
-        for (long k = 0; k < n; ++k) {
-            pl.x[k] = xs[k]; pl.y[k] = ys[k]; pl.w[k] = d.plasma_density*scale;
-            pl.ux[k] = 0; pl.uy[k] = 0; pl.psi[k] = std::sqrt(1.0) - 0.0;
-            pl.x_prev[k] = xs[k]; pl.y_prev[k] = ys[k];
-            pl.ux_half[k] = 0; pl.uy_half[k] = 0; pl.psi_half[k] = pl.psi[k];
+        fill_species(pl, xs, ys, d.plasma_density*scale, 0);
+        if (d.ion_on) {
+            const int inppc = d.ion_ppc[0]*d.ion_ppc[1];
+            const double iscale = inppc <= 0 ? 0. : (d.si_units ? gm.dx*gm.dy*gm.dz/inppc : 1.0/inppc);
+            idata.assign((size_t)std::max(ni, 1L)*11, 0.0); ivalid.assign((size_t)std::max(ni, 1L), 1); ilev.assign((size_t)std::max(ni, 1L), 0);
+            iuid.resize((size_t)std::max(ni, 1L));
+            double* q = idata.data();
+            const long m = std::max(ni, 1L);
+            ipl = Plasma{q, q+m, q+2*m, q+3*m, q+4*m, q+5*m, q+6*m, q+7*m, q+8*m, q+9*m, q+10*m, ivalid.data(), ilev.data(), ni};
+            fill_species(ipl, ixs, iys, d.ion_density*iscale, d.ion_init_level);
+            for (long k = 0; k < ni; ++k) iuid[(size_t)k] = (uint64_t)k;       // lattice index: the generator's key
+        }
+    }
+
+    // InitIonizationModule (PlasmaParticleContainerInit.cpp:382-464): ADK prefactors (Chen, JCP 236 (2013), eq. (2);
+    // l = m = 0, the approximate expressions without the Gamma function of the angular part)
+    void init_ionization () {
+        if (!d.ion_on || d.ion_Z <= 0) return;
+        const double cSI = 299792458.0, qeSI = 1.602176634e-19, meSI = 9.1093837015e-31, ep0SI = 8.8541878128e-12;
+        const double alpha = 0.0072973525693, r_e = 2.8179403227e-15;
+        const double a3 = alpha*alpha*alpha, a4 = a3*alpha;
+        const double wa = a3*cSI/r_e;
+        const double Ea = meSI*cSI*cSI/qeSI*a4/r_e;
+        const double UH = 13.59843449;                    // table_ionization_energies[0]
+        const double l_eff = std::sqrt(UH/d.ion_energies[0]) - 1.0;
+        const double wp = std::sqrt(d.background_density_SI*qeSI*qeSI/(ep0SI*meSI));
+        const double dt = d.si_units ? gm.dz/cSI : gm.dz/wp;
+        adk_power.assign(d.ion_Z, 0.0); adk_prefactor.assign(d.ion_Z, 0.0); adk_exp_prefactor.assign(d.ion_Z, 0.0);
+        for (int i = 0; i < d.ion_Z; ++i) {
+            const double Uion = d.ion_energies[i];
+            const double n_eff = (i + 1)*std::sqrt(UH/Uion);
+            const double C2 = std::pow(2, 2*n_eff)/(n_eff*std::tgamma(n_eff + l_eff + 1)*std::tgamma(n_eff - l_eff));
+            adk_power[i] = -(2*n_eff - 1);
+            adk_prefactor[i] = dt*wa*C2*(Uion/(2*UH))*std::pow(2*std::pow((Uion/UH), 3./2)*Ea, 2*n_eff - 1);
+            adk_exp_prefactor[i] = -2./3*std::pow(Uion/UH, 3./2)*Ea;
+        }
+    }
+
+    // uniform deviate in [0, 1) of (seed, ion, time step, slice): counter based, so that the HIP kernel draws the same
+    // number for the same ion whatever the order of its particles (two rounds of the splitmix64 finaliser)
+    static double ion_uniform (uint64_t seed, uint64_t uid, uint64_t step, uint64_t islice) {
+        uint64_t z = seed + 0x9E3779B97F4A7C15ULL*(uid + 1) + 0xBF58476D1CE4E5B9ULL*(step + 1) + 0x94D049BB133111EBULL*(islice + 1);
+        for (int r = 0; r < 2; ++r) {
+            z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+            z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+            z ^= z >> 31;
+        }
+        return (double)(z >> 11)*(1.0/9007199254740992.0);
+    }
+
+    // PlasmaParticleContainer::IonizationModule (PlasmaParticleContainer.cpp:261-440): ADK probability from |E| at the
+    // ion (fields of This slice, gathered at x_prev, y_prev), one draw per ion and slice, the released electron joins the
+    // product species at rest at the ion's position with the ion's weight.  An ion that has lost all Z electrons cannot
+    // ionise (the reference reads past the end of its ADK tables there).
+    void ionization_module (int islice) {
+        if (!d.ion_on || adk_prefactor.empty()) return;
+        const int comp[5] = {Psi, Ez, Bx, By, Bz};
+        const double cSI = 299792458.0, qeSI = 1.602176634e-19, meSI = 9.1093837015e-31, ep0SI = 8.8541878128e-12;
+        const double wp = std::sqrt(d.background_density_SI*qeSI*qeSI/(ep0SI*meSI));
+        const double E0 = d.si_units ? 1.0 : wp*meSI*cSI/qeSI;
+        const double clightsq = 1.0/(gm.c*gm.c);
+        for (long ip = 0; ip < ipl.n; ++ip) {
+            if (!ipl.valid[ip]) continue;
+            const int lev = ipl.ion_lev[ip];
+            if (lev >= d.ion_Z) continue;
+            Real ExmByp = 0, EypBxp = 0, Ezp = 0, Bxp = 0, Byp = 0, Bzp = 0;
+            gather(d.order, ipl.x_prev[ip], ipl.y_prev[ip], ExmByp, EypBxp, Ezp, Bxp, Byp, Bzp, slab, comp, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff);
+            const Real Exp = ExmByp + Byp*gm.c;
+            const Real Eyp = EypBxp - Bxp*gm.c;
+            const Real Ep = std::sqrt(Exp*Exp + Eyp*Eyp + Ezp*Ezp)*E0;
+            const Real ux = ipl.ux_half[ip], uy = ipl.uy_half[ip], psi = ipl.psi_half[ip];
+            const Real gammap = (1.0 + ux*ux*clightsq + uy*uy*clightsq + psi*psi)/(2.0*psi);
+            // gamma / (psi + 1) to complete dt for QSA
+            const Real w_dtau = gammap/psi*adk_prefactor[lev]*std::pow(Ep, adk_power[lev])*std::exp(adk_exp_prefactor[lev]/Ep);
+            const Real p = 1.0 - std::exp(-w_dtau);
+            const Real draw = ion_uniform(d.ion_seed, iuid[(size_t)ip], (uint64_t)cur_step, (uint64_t)islice);
+            if (draw < p) {
+                ipl.ion_lev[ip] += 1;
+                const long k = pl.n;
+                if (k >= pl_cap) { std::fprintf(stderr, "oracle: ionisation product species is full\n"); std::abort(); }
+                pl.x[k] = ipl.x[ip]; pl.y[k] = ipl.y[ip]; pl.w[k] = ipl.w[ip];
+                pl.ux[k] = 0; pl.uy[k] = 0; pl.psi[k] = 1.0;
+                pl.x_prev[k] = ipl.x_prev[ip]; pl.y_prev[k] = ipl.y_prev[ip];
+                pl.ux_half[k] = 0; pl.uy_half[k] = 0; pl.psi_half[k] = 1.0;
+                pl.valid[k] = 1; pl.ion_lev[k] = 0;
+                ++pl.n; ++n_ionized_total;
+            }
         }
     }
 
@@ -1647,7 +1766,9 @@ struct Engine {
         double t1 = now(); t_other += t1 - t0;
         // plasma deposit jx jy [rho] chi rhomjz (Hipace.cpp:609-610)
         { const int comp[6] = {jx, jy, -1, d.deposit_rho ? (int)rho : -1, chi, rhomjz};
-          n_qsa_total += deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, c_aabs); }
+          n_qsa_total += deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, c_aabs);
+          // MultiPlasma::DepositCurrent: every species in turn (MultiPlasma.cpp:78-87); ions weigh in with their level
+          if (d.ion_on) n_qsa_total += deposit_current(slab, ipl, gm, comp, d.ion_charge, d.ion_mass, d.order, d.max_qsa, 1, c_aabs); }
         double t2 = now(); t_deposit += t2 - t1;
         if (moving) deposit_beam(store[islice], -1, -1, jzb, store[islice].nreg);
         else deposit_beam(beam_this, -1, -1, jzb);
@@ -1668,7 +1789,8 @@ struct Engine {
         init_sxsy_with_beam();
         double t5 = now(); t_other += t5 - t4;
         { const int cache[4] = {Bz, Ez, ExmBy, EypBx}; const int depos[2] = {Sy, Sx};
-          explicit_deposit(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, c_aabs); }
+          explicit_deposit(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, c_aabs);
+          if (d.ion_on) explicit_deposit(slab, ipl, gm, cache, depos, d.ion_charge, d.ion_mass, d.order, d.deriv_type, 1, c_aabs); }
         double t6 = now(); t_explicit += t6 - t5;
         // ExplicitMGSolveBxBy (Hipace.cpp:793-933)
         { const int it = mg->solve1(slab.comp(Bx), slab.comp(By), slab.comp(Sy), slab.comp(Sx), slab.comp(chi),
@@ -1684,8 +1806,10 @@ struct Engine {
             }
         }
         double t8 = now(); t_other += t8 - t7;
+        ionization_module(islice);               // DoFieldIonization (Hipace.cpp:693-696), before the push
         { const int comp[5] = {Psi, Ez, Bx, By, Bz};
-          advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, c_aabs); }
+          advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, c_aabs);
+          if (d.ion_on) advance_plasma(slab, ipl, gm, comp, d.ion_charge, d.ion_mass, d.order, 0, d.n_subcycles, 1, c_aabs); }
         insitu_beam_slice(islice);
         if (moving) {
             // beam diagnostics before the push (Hipace.cpp:685-686), then push and hand the slipped particles
@@ -1843,9 +1967,11 @@ struct Engine {
         std::fill(slab_data.begin(), slab_data.end(), 0.0);     // ResetAllQuantities
         beam_this_slice = -2;
         init_plasma();
+        ++cur_step;
         // DepositNeutralizingBackground (plasma/MultiPlasma.cpp:106-118): rhomjz only, charge -q
         const int comp[6] = {-1, -1, -1, -1, -1, d.bxby_solver ? (int)pIon_rhomjz : (int)Ion_rhomjz};
-        deposit_current(slab, pl, gm, comp, -d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0);
+        if (!d.plasma_no_neutralize)
+            deposit_current(slab, pl, gm, comp, -d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0);
         std::fill(checksum.begin(), checksum.end(), 0.0);
         for (double& v : beam_diag) v = 0.0;
         laser_envelope_sum = 0.0;
@@ -2012,6 +2138,8 @@ struct orc_deck {
     int grid_current_on; double grid_current_peak, grid_current_mean[3], grid_current_std[3];
     double laser_mg_tol_rel, laser_mg_tol_abs;
     int beam_radiation_reaction; double background_density_SI; int beam_no_z_push;
+    int plasma_no_neutralize; int ion_on; int ion_ppc[2]; double ion_density, ion_mass, ion_charge; int ion_init_level, ion_Z;
+    double ion_energies[56]; unsigned long long ion_seed;
 };
 
 // threads of the CPU-baseline leg (see g_threads); returns the number actually set
@@ -2045,6 +2173,9 @@ void* orc_engine_create (const orc_deck* k) {
     for (int i=0;i<3;++i){d.grid_current_mean[i]=k->grid_current_mean[i]; d.grid_current_std[i]=k->grid_current_std[i];}
     d.beam_radiation_reaction=k->beam_radiation_reaction; d.background_density_SI=k->background_density_SI; d.beam_no_z_push=k->beam_no_z_push;
     d.laser_mg_tol_rel = k->laser_mg_tol_rel > 0.0 ? k->laser_mg_tol_rel : 1.e-4; d.laser_mg_tol_abs = k->laser_mg_tol_abs;
+    d.plasma_no_neutralize=k->plasma_no_neutralize; d.ion_on=k->ion_on; d.ion_ppc[0]=k->ion_ppc[0]; d.ion_ppc[1]=k->ion_ppc[1];
+    d.ion_density=k->ion_density; d.ion_mass=k->ion_mass; d.ion_charge=k->ion_charge; d.ion_init_level=k->ion_init_level;
+    d.ion_Z=std::min(std::max(k->ion_Z, 0), 56); for (int i=0;i<56;++i) d.ion_energies[i]=k->ion_energies[i]; d.ion_seed=k->ion_seed;
     return new Engine(d);
 }
 void orc_engine_destroy (void* h) { delete static_cast<Engine*>(h); }
@@ -2056,6 +2187,21 @@ int orc_engine_guards (void* h) { return static_cast<Engine*>(h)->g; }
 long orc_engine_nparticles (void* h) { return static_cast<Engine*>(h)->pl.n; }
 double* orc_engine_slab (void* h) { return static_cast<Engine*>(h)->slab_data.data(); }
 double* orc_engine_particles (void* h) { return static_cast<Engine*>(h)->pdata.data(); }
+// the 11 arrays of the first species are `stride` doubles apart (its capacity: ionisation adds particles)
+long orc_engine_particle_stride (void* h) { return std::max(static_cast<Engine*>(h)->pl_cap, 1L); }
+// species "ion": count, the 11 arrays (stride = max(count, 1)), validity flags, ionisation levels; electrons released so far
+long orc_engine_nions (void* h) { Engine* e = static_cast<Engine*>(h); return e->d.ion_on ? e->ipl.n : 0; }
+double* orc_engine_ions (void* h) { return static_cast<Engine*>(h)->idata.data(); }
+int32_t* orc_engine_ion_valid (void* h) { return static_cast<Engine*>(h)->ivalid.data(); }
+int32_t* orc_engine_ion_levels (void* h) { return static_cast<Engine*>(h)->ilev.data(); }
+long orc_engine_n_ionized (void* h) { return static_cast<Engine*>(h)->n_ionized_total; }
+void orc_adk_tables (void* h, double* prefactor, double* exp_prefactor, double* power) {
+    Engine* e = static_cast<Engine*>(h);
+    for (size_t i = 0; i < e->adk_prefactor.size(); ++i) { prefactor[i] = e->adk_prefactor[i]; exp_prefactor[i] = e->adk_exp_prefactor[i]; power[i] = e->adk_power[i]; }
+}
+double orc_ion_uniform (unsigned long long seed, unsigned long long uid, unsigned long long step, unsigned long long islice) {
+    return Engine::ion_uniform(seed, uid, step, islice);
+}
 int32_t* orc_engine_valid (void* h) { return static_cast<Engine*>(h)->pvalid.data(); }
 void orc_engine_checksums (void* h, double* out) { Engine* e = static_cast<Engine*>(h); for (int n = 0; n < e->ncomp; ++n) out[n] = e->checksum[n]; }
 long orc_engine_vcycles (void* h) { return static_cast<Engine*>(h)->total_vcycles; }

@@ -78,7 +78,10 @@ class Deck(C.Structure):
                 ("laser_zfoc", C.c_double), ("laser_solver", C.c_int), ("laser_use_phase", C.c_int), ("si_units", C.c_int),
                 ("grid_current_on", C.c_int), ("grid_current_peak", C.c_double), ("grid_current_mean", C.c_double * 3),
                 ("grid_current_std", C.c_double * 3), ("laser_mg_tol_rel", C.c_double), ("laser_mg_tol_abs", C.c_double),
-                ("beam_radiation_reaction", C.c_int), ("background_density_SI", C.c_double), ("beam_no_z_push", C.c_int)]
+                ("beam_radiation_reaction", C.c_int), ("background_density_SI", C.c_double), ("beam_no_z_push", C.c_int),
+                ("plasma_no_neutralize", C.c_int), ("ion_on", C.c_int), ("ion_ppc", C.c_int * 2), ("ion_density", C.c_double),
+                ("ion_mass", C.c_double), ("ion_charge", C.c_double), ("ion_init_level", C.c_int), ("ion_Z", C.c_int),
+                ("ion_energies", C.c_double * 56), ("ion_seed", C.c_ulonglong)]
 
 
 def fill_struct(st, d):
@@ -437,12 +440,47 @@ class Engine:
         return np.frombuffer(buf, dtype=np.float64).reshape(self.ncomp, ny + 2 * g, nx + 2 * g)
 
     def particles(self):
-        n = lib().orc_engine_nparticles(self._h)
+        L = lib()
+        n = L.orc_engine_nparticles(self._h)
         if n == 0:
             return np.zeros((11, 0)), np.zeros(0, dtype=np.int32)
-        buf = (C.c_double * (11 * n)).from_address(lib().orc_engine_particles(self._h))
-        vb = (C.c_int32 * n).from_address(lib().orc_engine_valid(self._h))
-        return np.frombuffer(buf, dtype=np.float64).reshape(11, n), np.frombuffer(vb, dtype=np.int32)
+        L.orc_engine_particle_stride.restype = C.c_long
+        L.orc_engine_particle_stride.argtypes = [C.c_void_p]
+        stride = L.orc_engine_particle_stride(self._h)
+        buf = (C.c_double * (11 * stride)).from_address(L.orc_engine_particles(self._h))
+        vb = (C.c_int32 * n).from_address(L.orc_engine_valid(self._h))
+        return np.frombuffer(buf, dtype=np.float64).reshape(11, stride)[:, :n], np.frombuffer(vb, dtype=np.int32)
+
+    def ions(self):
+        """Species "ion" (ADK ionisation): (real (11, n), valid (n,), ion_lev (n,))."""
+        L = lib()
+        for f, r in (("orc_engine_nions", C.c_long), ("orc_engine_ions", C.c_void_p), ("orc_engine_ion_valid", C.c_void_p),
+                     ("orc_engine_ion_levels", C.c_void_p), ("orc_engine_n_ionized", C.c_long)):
+            getattr(L, f).restype = r
+            getattr(L, f).argtypes = [C.c_void_p]
+        n = L.orc_engine_nions(self._h)
+        if n == 0:
+            return np.zeros((11, 0)), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32)
+        buf = (C.c_double * (11 * n)).from_address(L.orc_engine_ions(self._h))
+        vb = (C.c_int32 * n).from_address(L.orc_engine_ion_valid(self._h))
+        lb = (C.c_int32 * n).from_address(L.orc_engine_ion_levels(self._h))
+        return np.frombuffer(buf, dtype=np.float64).reshape(11, n), np.frombuffer(vb, dtype=np.int32), np.frombuffer(lb, dtype=np.int32)
+
+    def n_ionized(self):
+        L = lib()
+        L.orc_engine_n_ionized.restype = C.c_long
+        L.orc_engine_n_ionized.argtypes = [C.c_void_p]
+        return L.orc_engine_n_ionized(self._h)
+
+    def adk_tables(self):
+        """(prefactor, exp_prefactor, power) of InitIonizationModule, one entry per ionisation level."""
+        z = int(self.deck.get("ion_Z", 0))
+        out = [np.zeros(max(z, 1)) for _ in range(3)]
+        L = lib()
+        L.orc_adk_tables.restype = None
+        L.orc_adk_tables.argtypes = [C.c_void_p] * 4
+        L.orc_adk_tables(self._h, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]))
+        return [o[:z] for o in out]
 
     # --- beam blocks, same layout and method names as hipace_amd.api.SliceEngine (pipeline tests) ---
     def beam_layout(self):
