@@ -48,7 +48,10 @@ class Deck(C.Structure):
                 ("laser_zfoc", C.c_double), ("laser_solver", C.c_int), ("laser_use_phase", C.c_int), ("si_units", C.c_int),
                 ("grid_current_on", C.c_int), ("grid_current_peak", C.c_double), ("grid_current_mean", C.c_double * 3),
                 ("grid_current_std", C.c_double * 3), ("laser_mg_tol_rel", C.c_double), ("laser_mg_tol_abs", C.c_double),
-                ("beam_radiation_reaction", C.c_int), ("background_density_SI", C.c_double), ("beam_no_z_push", C.c_int)]
+                ("beam_radiation_reaction", C.c_int), ("background_density_SI", C.c_double), ("beam_no_z_push", C.c_int),
+                ("plasma_no_neutralize", C.c_int), ("ion_on", C.c_int), ("ion_ppc", C.c_int * 2), ("ion_density", C.c_double),
+                ("ion_mass", C.c_double), ("ion_charge", C.c_double), ("ion_init_level", C.c_int), ("ion_Z", C.c_int),
+                ("ion_energies", C.c_double * 56), ("ion_seed", C.c_ulonglong)]
 
 
 # engine component names, index = value of the HPS_C_* enum in include/hpslice.h
@@ -104,6 +107,8 @@ _SIGS = {
     "hps_engine_slab": (Slab, [C.c_void_p]),
     "hps_engine_plasma": (Plasma, [C.c_void_p]),
     "hps_engine_stream": (C.c_void_p, [C.c_void_p]),
+    "hps_engine_ions": (Plasma, [C.c_void_p]),
+    "hps_engine_ion_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "hps_engine_checksums": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_beam_sort_by_box": (C.c_int, [C.c_void_p, C.c_long, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),

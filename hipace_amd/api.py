@@ -518,6 +518,29 @@ class SliceEngine:
         check(_lib.lib().hps_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(s.p), out.nbytes))
         return out
 
+    def ions(self):
+        """Species "ion" (deck ion_on): (real (11, n), valid (n,), ion_lev (n,), key (n,)) -- key = the ion's lattice index,
+        which the tile sort moves with the particle (the id bits of idcpu)."""
+        self.sync()
+        p = _lib.lib().hps_engine_ions(self._h)
+        n = p.n
+        real = np.empty((11, n), dtype=np.float64)
+        idc = np.empty(n, dtype=np.uint64)
+        lev = np.empty(n, dtype=np.int32)
+        if n:
+            for k, name in enumerate(PL_REAL):
+                check(_lib.lib().hps_memcpy_d2h(real[k].ctypes.data_as(C.c_void_p), C.c_void_p(getattr(p, name)), real[k].nbytes))
+            check(_lib.lib().hps_memcpy_d2h(idc.ctypes.data_as(C.c_void_p), C.c_void_p(p.idcpu), idc.nbytes))
+            check(_lib.lib().hps_memcpy_d2h(lev.ctypes.data_as(C.c_void_p), C.c_void_p(p.ion_lev), lev.nbytes))
+        key = ((idc >> np.uint64(24)) & np.uint64((1 << 39) - 1)).astype(np.int64) - 1
+        return real, ((idc >> np.uint64(63)) & np.uint64(1)).astype(np.int32), lev, key
+
+    def ion_stats(self):
+        """(electrons released by the species "ion" since the engine was created, particles of the first species now)."""
+        a, b = C.c_long(), C.c_long()
+        check(_lib.lib().hps_engine_ion_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def particles(self):
         self.sync()
         p = _lib.lib().hps_engine_plasma(self._h)

@@ -23,7 +23,22 @@ struct Engine {
     hps_slab slab{};
     hps_plasma pl{};
     double* pl_real = nullptr;
-    long np = 0;
+    long np = 0;                   // particles of the first species NOW (grows when the species "ion" releases electrons)
+    long np_cap = 0, np_init = 0;  // capacity of its arrays; particles InitParticles creates
+    // species "ion" with ADK field ionisation (ionization.hip): tile-sorted once per step (ions hardly move); released
+    // electrons are appended to `pl` behind the tile-sorted body and run through the per-particle kernels until the next
+    // re-sort.  Counters on the device {electrons, overflow, blocks done, ionised}, the count comes back through mapped
+    // host memory (no stream synchronisation).
+    struct Ions { hps_plasma pl{}, pl_alt{}; double *real = nullptr, *real_alt = nullptr; Tiling* tiling = nullptr; long n = 0;
+                  double* d_adk = nullptr; unsigned long long* d_cnt = nullptr; long long* h_cnt = nullptr; long long* h_cnt_dev = nullptr;
+                  long long seq = 0; long n_ionized = 0; bool pending = false; } ion;
+    int step_index = -1;           // time step that has begun (the ionisation draws are keyed by it)
+    int ionize_slice (int islice);             // ionization.hip: launch
+    int ionize_collect ();                     // ...: wait for the electron count of the slice
+    hps_plasma tail_of (const hps_plasma& p, long first, long n) const;
+    int species_deposit (const hps_plasma& p, Tiling* T, const int comp[6], double charge, double mass, int can_ionize);
+    int species_explicit (const hps_plasma& p, Tiling* T, const int cache[4], const int depos[2], double charge, double mass, int can_ionize);
+    int species_advance (const hps_plasma& p, Tiling* T, const int comp[5], double charge, double mass, int temp_slice, int can_ionize);
     // tile-sorted sheet (sort.hip): second SoA buffer + tiling state
     Tiling* tiling = nullptr; int tile_size = 16, sort_period = 128, since_sort = 0;
     hps_plasma pl_alt{}; double* pl_real_alt = nullptr;
@@ -92,6 +107,8 @@ struct Engine {
     int run_step ();
 };
 
+int ion_create (Engine& E);                                                  // ionization.hip
+void ion_destroy (Engine& E);
 int laser_create (Engine& E);                                                // laser.hip
 void laser_destroy (Engine& E);
 int laser_begin_step (Engine& E);

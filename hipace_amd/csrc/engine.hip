@@ -228,11 +228,11 @@ void k_checksum (SlabView f, int ncomp, double* acc)
 // plasma sheet on the fixed-ppc lattice, ppc index outermost so that consecutive lanes own
 // consecutive cells (PlasmaParticleContainerInit.cpp:192-313, ParticleUtil.H:72-83)
 __global__ __launch_bounds__(256)
-void k_init_plasma (hps_plasma pl, int nx, int ny, int ppcx, int ppcy, double lox, double loy, double dx, double dy,
-                    double weight)
+void k_init_plasma (hps_plasma pl, long n, int nx, int ny, int ppcx, int ppcy, double lox, double loy, double dx, double dy,
+                    double weight, int level, int keyed)
 {
     const long k = (long)blockIdx.x*blockDim.x + threadIdx.x;
-    if (k >= pl.n) return;
+    if (k >= n) return;
     const long cells = (long)nx*ny;
     const int ip = (int)(k / cells);
     const long c = k - (long)ip*cells;
@@ -244,8 +244,10 @@ void k_init_plasma (hps_plasma pl, int nx, int ny, int ppcx, int ppcy, double lo
     pl.ux[k] = 0.0; pl.uy[k] = 0.0; pl.psi[k] = 1.0;
     pl.x_prev[k] = x; pl.y_prev[k] = y;
     pl.ux_half[k] = 0.0; pl.uy_half[k] = 0.0; pl.psi_half[k] = 1.0;
-    pl.idcpu[k] = HPS_ID_VALID | (1ULL << 24);      // id = 1, cpu (level) = 0
-    pl.ion_lev[k] = 0;
+    // id = 1, cpu (level) = 0.  A species that can ionise carries its lattice index + 1 in the id bits: the key of its
+    // random draws (ionization.hip); the reference only ever reads the sign of the id
+    pl.idcpu[k] = HPS_ID_VALID | ((keyed ? (unsigned long long)(k + 1) : 1ULL) << 24);
+    pl.ion_lev[k] = level;
 }
 
 // beam slice deposit (particles/deposition/BeamDepositCurrent.cpp:21-195), depos_order_z = 0
@@ -327,6 +329,7 @@ Engine::~Engine ()
     (void)hipFree(d_pc); if (h_pc) (void)hipHostFree(h_pc);
     (void)hipFree(d_laser_sum);
     if (laser) laser_destroy(*this);
+    ion_destroy(*this);
     (void)hipFree(d_fd); (void)hipFree(d_fd_comps); (void)hipFree(d_insitu); (void)hipFree(d_insitu_pl); (void)hipFree(d_insitu_bm);
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto e : hand_ev) if (e) (void)hipEventDestroy(e);
@@ -477,20 +480,33 @@ int Engine::create (const hps_deck& deck, int device)
 
     const int nppc = d.plasma_ppc[0]*d.plasma_ppc[1];
     np = (d.plasma_density > 0.0) ? (long)nppc*d.nx*d.ny : 0;
+    np_init = np; np_cap = np;
+    if (d.ion_on) {
+        if (pc) { set_error("hps_engine_create: ionisation needs the explicit solver"); return HPS_ERR_UNSUPPORTED; }
+        HPS_REQUIRE(d.ion_ppc[0] >= 1 && d.ion_ppc[1] >= 1 && d.ion_density > 0.0 && d.ion_mass > 0.0 && d.ion_charge != 0.0,
+                    "hps_engine_create: the ion species needs ppc, density, mass and charge");
+        ion.n = (long)d.ion_ppc[0]*d.ion_ppc[1]*d.nx*d.ny;
+        if (int e = ion_create(*this)) return e;
+        // every ion can release Z - initial level electrons into the first species
+        np_cap = np_init + ion.n*(long)(d.ion_Z - d.ion_init_level);
+    }
     std::memset(&pl, 0, sizeof(pl));
     pl.n = np;
-    if (np > 0) {
-        HPS_HIP_CHECK(hipMalloc(&pl_real, (size_t)np*11*sizeof(double)));
-        double** arr[11] = {&pl.x, &pl.y, &pl.w, &pl.ux, &pl.uy, &pl.psi, &pl.x_prev, &pl.y_prev, &pl.ux_half, &pl.uy_half, &pl.psi_half};
-        for (int k = 0; k < 11; ++k) *arr[k] = pl_real + (size_t)k*np;
+    auto alloc_sheet = [&] (hps_plasma& p, double*& real, long cap, bool alias) -> int {
+        HPS_HIP_CHECK(hipMalloc(&real, (size_t)cap*11*sizeof(double)));
+        double** arr[11] = {&p.x, &p.y, &p.w, &p.ux, &p.uy, &p.psi, &p.x_prev, &p.y_prev, &p.ux_half, &p.uy_half, &p.psi_half};
+        for (int k = 0; k < 11; ++k) *arr[k] = real + (size_t)k*cap;
         // explicit solver: every push commits its state (temp_slice = false), so x_prev == x and y_prev == y at
         // all times (PlasmaParticleAdvance.cpp:176-188): alias them -- two arrays less to write per push and to
         // move per re-sort.  The C ABI keeps 11 pointers; the kernels skip the second store when two coincide.
         // (the predictor-corrector pushes to temporary slices from x_prev: separate arrays there)
-        if (!pc) { pl.x_prev = pl.x; pl.y_prev = pl.y; }
-        HPS_HIP_CHECK(hipMalloc(&pl.idcpu, (size_t)np*sizeof(uint64_t)));
-        HPS_HIP_CHECK(hipMalloc(&pl.ion_lev, (size_t)np*sizeof(int32_t)));
-    }
+        if (alias) { p.x_prev = p.x; p.y_prev = p.y; }
+        HPS_HIP_CHECK(hipMalloc(&p.idcpu, (size_t)cap*sizeof(uint64_t)));
+        HPS_HIP_CHECK(hipMalloc(&p.ion_lev, (size_t)cap*sizeof(int32_t)));
+        return HPS_OK;
+    };
+    if (np_cap > 0) { if (int e = alloc_sheet(pl, pl_real, np_cap, !pc)) return e; }
+    if (ion.n > 0) { ion.pl.n = ion.n; if (int e = alloc_sheet(ion.pl, ion.real, ion.n, true)) return e; }
     HPS_HIP_CHECK(hipMalloc(&d_laser_sum, sizeof(double)));
     HPS_HIP_CHECK(hipMemset(d_laser_sum, 0, sizeof(double)));
     HPS_HIP_CHECK(hipMalloc(&d_nqsa, sizeof(int)));
@@ -519,22 +535,32 @@ int Engine::create (const hps_deck& deck, int device)
 
 int Engine::setup_tiling ()
 {
-    if (tile_size == 0 || np == 0 || tiling) return HPS_OK;
-    if (int e = tiling_create(d.nx, d.ny, tile_size, np, &tiling)) return e;
-    std::memset(&pl_alt, 0, sizeof(pl_alt));
+    if (tile_size == 0 || np_cap == 0 || tiling) return HPS_OK;
+    auto second = [&] (hps_plasma& alt, double*& real, long cap, bool alias) -> int {
+        std::memset(&alt, 0, sizeof(alt));
+        HPS_HIP_CHECK(hipMalloc(&real, (size_t)cap*11*sizeof(double)));
+        double** arr[11] = {&alt.x, &alt.y, &alt.w, &alt.ux, &alt.uy, &alt.psi, &alt.x_prev, &alt.y_prev,
+                            &alt.ux_half, &alt.uy_half, &alt.psi_half};
+        for (int k = 0; k < 11; ++k) *arr[k] = real + (size_t)k*cap;
+        if (alias) { alt.x_prev = alt.x; alt.y_prev = alt.y; }
+        HPS_HIP_CHECK(hipMalloc(&alt.idcpu, (size_t)cap*sizeof(uint64_t)));
+        HPS_HIP_CHECK(hipMalloc(&alt.ion_lev, (size_t)cap*sizeof(int32_t)));
+        return HPS_OK;
+    };
+    if (int e = tiling_create(d.nx, d.ny, tile_size, np_cap, &tiling)) return e;
+    if (int e = second(pl_alt, pl_real_alt, np_cap, !pc)) return e;
     pl_alt.n = np;
-    HPS_HIP_CHECK(hipMalloc(&pl_real_alt, (size_t)np*11*sizeof(double)));
-    double** arr[11] = {&pl_alt.x, &pl_alt.y, &pl_alt.w, &pl_alt.ux, &pl_alt.uy, &pl_alt.psi, &pl_alt.x_prev, &pl_alt.y_prev,
-                        &pl_alt.ux_half, &pl_alt.uy_half, &pl_alt.psi_half};
-    for (int k = 0; k < 11; ++k) *arr[k] = pl_real_alt + (size_t)k*np;
-    if (!pc) { pl_alt.x_prev = pl_alt.x; pl_alt.y_prev = pl_alt.y; }
-    HPS_HIP_CHECK(hipMalloc(&pl_alt.idcpu, (size_t)np*sizeof(uint64_t)));
-    HPS_HIP_CHECK(hipMalloc(&pl_alt.ion_lev, (size_t)np*sizeof(int32_t)));
+    if (ion.n > 0) {
+        if (int e = tiling_create(d.nx, d.ny, tile_size, ion.n, &ion.tiling)) return e;
+        if (int e = second(ion.pl_alt, ion.real_alt, ion.n, true)) return e;
+        ion.pl_alt.n = ion.n;
+    }
     return HPS_OK;
 }
 
 int Engine::resort ()
 {
+    pl_alt.n = pl.n;
     if (int e = tiling_sort(tiling, pl, pl_alt, gm, st)) return e;
     std::swap(pl, pl_alt);
     std::swap(pl_real, pl_real_alt);
@@ -579,19 +605,40 @@ int Engine::begin_step ()
     if (d_insitu_bm) HPS_HIP_CHECK(hipMemsetAsync(d_insitu_bm, 0, (size_t)23*d.nz*sizeof(double), st));
     if (d_insitu) HPS_HIP_CHECK(hipMemsetAsync(d_insitu, 0, (size_t)10*d.nz*sizeof(double), st));
     if (d_fd) HPS_HIP_CHECK(hipMemsetAsync(d_fd, 0, fd_comps.size()*(size_t)(d.nx/fd_c[0])*(d.ny/fd_c[1])*(d.nz/fd_c[2])*sizeof(double), st));
+    ++step_index;
+    if (int e = ionize_collect()) return e;
+    np = np_init; pl.n = np; pl_alt.n = np;
     if (np > 0) {
         const int nppc = d.plasma_ppc[0]*d.plasma_ppc[1];
-        hipLaunchKernelGGL(k_init_plasma, dim3(ceil_div(np, 256)), dim3(256), 0, st, pl, d.nx, d.ny,
+        hipLaunchKernelGGL(k_init_plasma, dim3(ceil_div(np, 256)), dim3(256), 0, st, pl, np, d.nx, d.ny,
                            d.plasma_ppc[0], d.plasma_ppc[1], d.lo[0], d.lo[1], gm.dx, gm.dy,
-                           d.plasma_density*(d.si_units ? gm.dx*gm.dy*gm.dz/nppc : 1.0/nppc));     // scale_fac, PlasmaParticleContainerInit.cpp:40-41
+                           d.plasma_density*(d.si_units ? gm.dx*gm.dy*gm.dz/nppc : 1.0/nppc), 0, 0);     // scale_fac, PlasmaParticleContainerInit.cpp:40-41
+    }
+    if (tiling) { if (int e = resort()) return e; }
+    if (np > 0 && !d.plasma_no_neutralize) {
         // neutralising ion background, deposited once per step with charge -q (MultiPlasma.cpp:106-118)
         const int comp[6] = {-1, -1, -1, -1, -1, pc ? (int)HPS_PC_ION_RHOMJZ : (int)HPS_C_ION_RHOMJZ};
         if (tiling) {
-            if (int e = resort()) return e;
             if (int e = deposit_current_tiled(slab, pl, gm, comp, -d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st)) return e;
         } else {
             if (int e = hps_deposit_current(slab, pl, gm, comp, -d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st)) return e;
         }
+    }
+    if (ion.n > 0) {
+        // the species "ion": every macro-ion back on its lattice point at its initial level; the product species is back
+        // to its own InitParticles count
+        const int inppc = d.ion_ppc[0]*d.ion_ppc[1];
+        hipLaunchKernelGGL(k_init_plasma, dim3(ceil_div(ion.n, 256)), dim3(256), 0, st, ion.pl, ion.n, d.nx, d.ny,
+                           d.ion_ppc[0], d.ion_ppc[1], d.lo[0], d.lo[1], gm.dx, gm.dy,
+                           d.ion_density*(d.si_units ? gm.dx*gm.dy*gm.dz/inppc : 1.0/inppc), d.ion_init_level, 1);
+        if (ion.tiling) {
+            ion.pl_alt.n = ion.n;
+            if (int e = tiling_sort(ion.tiling, ion.pl, ion.pl_alt, gm, st)) return e;
+            std::swap(ion.pl, ion.pl_alt); std::swap(ion.real, ion.real_alt);
+        }
+        const unsigned long long c0[4] = {(unsigned long long)np_init, 0ULL, 0ULL, (unsigned long long)ion.n_ionized};
+        HPS_HIP_CHECK(hipMemcpyAsync(ion.d_cnt, c0, sizeof(c0), hipMemcpyHostToDevice, st));
+        HPS_HIP_CHECK(hipStreamSynchronize(st));      // c0 is on the stack
     }
     HPS_HIP_CHECK(hipGetLastError());
     return HPS_OK;
@@ -626,6 +673,42 @@ int Engine::deposit_beam_slice (int islice, int cjx, int cjy, int cjz)
         case 2: hipLaunchKernelGGL(k_beam_deposit<2>, grid, block, 0, st, f, beam, first, count, cjx, cjy, cjz, q_invvol, csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff); break;
         default: hipLaunchKernelGGL(k_beam_deposit<3>, grid, block, 0, st, f, beam, first, count, cjx, cjy, cjz, q_invvol, csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff); break;
     }
+    return HPS_OK;
+}
+
+hps_plasma Engine::tail_of (const hps_plasma& p, long first, long n) const
+{
+    hps_plasma t = p;
+    double** arr[11] = {&t.x, &t.y, &t.w, &t.ux, &t.uy, &t.psi, &t.x_prev, &t.y_prev, &t.ux_half, &t.uy_half, &t.psi_half};
+    for (int k = 0; k < 11; ++k) *arr[k] += first;      // (x_prev / y_prev stay aliased to x / y where they were)
+    t.idcpu += first; t.ion_lev += first; t.n = n;
+    return t;
+}
+
+// The three particle operators over one species: LDS-tile kernels over the tile-sorted body of the sheet, per-particle
+// kernels over what has been appended behind it since the last sort (electrons released by the species "ion").
+int Engine::species_deposit (const hps_plasma& p, Tiling* T, const int comp[6], double charge, double mass, int can_ionize)
+{
+    if (p.n == 0) return HPS_OK;
+    if (!T) return hps_deposit_current_laser(slab, p, gm, comp, c_aabs, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, st);
+    if (T->sorted_n > 0) { if (int e = deposit_current_tiled(slab, p, gm, comp, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, T, d_nfallback, st, c_aabs)) return e; }
+    if (p.n > T->sorted_n) return hps_deposit_current_laser(slab, tail_of(p, T->sorted_n, p.n - T->sorted_n), gm, comp, c_aabs, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, st);
+    return HPS_OK;
+}
+int Engine::species_explicit (const hps_plasma& p, Tiling* T, const int cache[4], const int depos[2], double charge, double mass, int can_ionize)
+{
+    if (p.n == 0) return HPS_OK;
+    if (!T) return hps_explicit_deposit_laser(slab, p, gm, cache, c_aabs, depos, charge, mass, d.order, d.deriv_type, can_ionize, st);
+    if (T->sorted_n > 0) { if (int e = explicit_deposit_tiled(slab, p, gm, cache, depos, charge, mass, d.order, d.deriv_type, can_ionize, T, d_nfallback, st, c_aabs)) return e; }
+    if (p.n > T->sorted_n) return hps_explicit_deposit_laser(slab, tail_of(p, T->sorted_n, p.n - T->sorted_n), gm, cache, c_aabs, depos, charge, mass, d.order, d.deriv_type, can_ionize, st);
+    return HPS_OK;
+}
+int Engine::species_advance (const hps_plasma& p, Tiling* T, const int comp[5], double charge, double mass, int temp_slice, int can_ionize)
+{
+    if (p.n == 0) return HPS_OK;
+    if (!T) return hps_advance_plasma_laser(slab, p, gm, comp, c_aabs, charge, mass, d.order, temp_slice, d.n_subcycles, can_ionize, st);
+    if (T->sorted_n > 0) { if (int e = advance_plasma_tiled(slab, p, gm, comp, charge, mass, d.order, temp_slice, d.n_subcycles, can_ionize, T, d_nfallback, st, c_aabs)) return e; }
+    if (p.n > T->sorted_n) return hps_advance_plasma_laser(slab, tail_of(p, T->sorted_n, p.n - T->sorted_n), gm, comp, c_aabs, charge, mass, d.order, temp_slice, d.n_subcycles, can_ionize, st);
     return HPS_OK;
 }
 
@@ -1051,12 +1134,16 @@ int Engine::solve_slice (int islice)
     // plasma: jx, jy, [rho], chi, rhomjz (Hipace.cpp:609-610); beam: jz_beam on This (:613-614)
     // re-sort after sort_period slices at the latest, earlier once more than 1/256 of the sheet has left
     // the halo of its tile (h_nfallback is as of the previous slice's multigrid sync)
-    if (tiling && (since_sort >= sort_period || (since_sort >= 2 && *h_nfallback - fb_at_sort > np/256))) { if ((e = resort())) return e; }
+    // (with a species "ion": also once the electrons appended behind the sorted body since the last sort -- they run
+    // through the per-particle kernels -- are more than 1/32 of the sheet)
+    if (tiling && (since_sort >= sort_period || (since_sort >= 2 && *h_nfallback - fb_at_sort > np/256) ||
+                   (since_sort >= 1 && np - tiling->sorted_n > std::max(np/32, 16384L)))) { if ((e = resort())) return e; }
     ++since_sort;
     mark();   // b1b
     {   const int comp[6] = {HPS_C_JX, HPS_C_JY, -1, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_CHI, HPS_C_RHOMJZ};
-        if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st, c_aabs))) return e; }
-        else        { if ((e = hps_deposit_current_laser(slab, pl, gm, comp, c_aabs, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
+        if ((e = species_deposit(pl, tiling, comp, d.plasma_charge, d.plasma_mass, 0))) return e;
+        // MultiPlasma::DepositCurrent: every species in turn (MultiPlasma.cpp:78-87); an ion weighs in with its level
+        if (ion.n > 0) { if ((e = species_deposit(ion.pl, ion.tiling, comp, d.ion_charge, d.ion_mass, 1))) return e; } }
     mark();   // b2
     // static beam: jz of this slice and jx, jy of the next one in one launch (Hipace.cpp:613-614, 656-657); a moving
     // beam keeps the two calls (the next slice's block is only final once this slice's push has handed its slipped
@@ -1107,8 +1194,8 @@ int Engine::solve_slice (int islice)
     mark();   // b4
     {   const int cache[4] = {HPS_C_BZ, HPS_C_EZ, HPS_C_EXMBY, HPS_C_EYPBX};
         const int depos[2] = {HPS_C_SY, HPS_C_SX};
-        if (tiling) { if ((e = explicit_deposit_tiled(slab, pl, gm, cache, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, tiling, d_nfallback, st, c_aabs))) return e; }
-        else        { if ((e = hps_explicit_deposit_laser(slab, pl, gm, cache, c_aabs, depos, d.plasma_charge, d.plasma_mass, d.order, d.deriv_type, 0, st))) return e; } }
+        if ((e = species_explicit(pl, tiling, cache, depos, d.plasma_charge, d.plasma_mass, 0))) return e;
+        if (ion.n > 0) { if ((e = species_explicit(ion.pl, ion.tiling, cache, depos, d.ion_charge, d.ion_mass, 1))) return e; } }
 
     mark();   // b5
     // Bx, By: Helmholtz multigrid from the previous slice's field (Hipace.cpp:793-933)
@@ -1126,8 +1213,14 @@ int Engine::solve_slice (int islice)
     mark();   // b7
     // gather + push (Hipace.cpp:699-701)
     {   const int comp[5] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ};
-        if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st, c_aabs))) return e; }
-        else        { if ((e = hps_advance_plasma_laser(slab, pl, gm, comp, c_aabs, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; } }
+        if (ion.n > 0) {
+            // DoFieldIonization (Hipace.cpp:693-696), then the ions' own push; the host learns how many electrons the
+            // slice has released while that push runs
+            if ((e = ionize_slice(islice))) return e;
+            if ((e = species_advance(ion.pl, ion.tiling, comp, d.ion_charge, d.ion_mass, 0, 1))) return e;
+            if ((e = ionize_collect())) return e;
+        }
+        if ((e = species_advance(pl, tiling, comp, d.plasma_charge, d.plasma_mass, 0, 0))) return e; }
 
     // beam push and hand-off of the slipped particles (Hipace.cpp:704-706)
     insitu_beam(islice);
@@ -1179,6 +1272,23 @@ extern "C" int hps_engine_info (void* h, int* ncomp, int* ng, long* np)
 }
 extern "C" hps_slab hps_engine_slab (void* h) { return static_cast<Engine*>(h)->slab; }
 extern "C" hps_plasma hps_engine_plasma (void* h) { return static_cast<Engine*>(h)->pl; }
+extern "C" hps_plasma hps_engine_ions (void* h)
+{
+    Engine* E = static_cast<Engine*>(h);
+    (void)hipStreamSynchronize(E->st);
+    hps_plasma p = E->ion.pl;
+    p.n = E->ion.n;
+    return p;
+}
+extern "C" int hps_engine_ion_stats (void* h, long* n_ionized, long* n_product)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    if (int e = E->ionize_collect()) return e;
+    if (n_ionized) *n_ionized = E->ion.n_ionized;
+    if (n_product) *n_product = E->np;
+    return HPS_OK;
+}
 extern "C" hps_stream hps_engine_stream (void* h) { return static_cast<Engine*>(h)->st; }
 extern "C" int hps_engine_checksums (void* h, double* out)
 {

@@ -1,0 +1,229 @@
+// ionization.hip -- ADK field ionisation of the plasma species "ion" (SURVEY 8f-2):
+// PlasmaParticleContainer::InitIonizationModule (particles/plasma/PlasmaParticleContainerInit.cpp:382-464) and
+// PlasmaParticleContainer::IonizationModule (particles/plasma/PlasmaParticleContainer.cpp:261-440), called once per slice
+// after the field solves and before the plasma push (Hipace.cpp:693-696).
+//
+// The reference runs two passes (decide + mask with an atomic count, then a second kernel that hands out electron
+// slots with another atomic per new electron, with a stream synchronisation in between to resize the product
+// species).  Here it is ONE kernel: every wave decides for its 64 ions, takes its block of electron slots with one
+// atomic per wave (ballot + popcount), and writes the electrons straight behind the product species' sheet, whose
+// arrays are allocated once for the most electrons the ions can release.  The new count reaches the host through
+// mapped host memory (posted by the last workgroup to finish), which the host polls after it has enqueued the push
+// of the ions -- no stream synchronisation.
+//
+// Random numbers: one uniform deviate per (ion, slice, time step) from a counter-based generator keyed by the ion's
+// lattice index, which travels in the id bits of idcpu (the reference only ever reads the sign of that field), so
+// that the draw does not depend on the order the tile sort has put the ions in.  Same integer arithmetic as the
+// oracle's ion_uniform.
+#include "common.h"
+#include "particle_math.h"
+#include "engine.h"
+
+#include <cmath>
+
+namespace hps {
+
+struct IonConsts {
+    PartConsts pc;
+    double E0, clightsq_inv;
+    int Z;
+    unsigned long long seed, step, islice;
+    long cap;                   // capacity of the product species' arrays
+};
+
+__device__ __forceinline__ double ion_uniform (unsigned long long seed, unsigned long long uid, unsigned long long step,
+                                               unsigned long long islice)
+{
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ULL*(uid + 1) + 0xBF58476D1CE4E5B9ULL*(step + 1) + 0x94D049BB133111EBULL*(islice + 1);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+        z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+    }
+    return (double)(z >> 11)*(1.0/9007199254740992.0);
+}
+
+// cnt = {electrons in the product sheet, overflow flag, workgroups done, ionisations so far}
+template <int ORDER>
+__global__ __launch_bounds__(256)
+void k_ionize (SlabView f, hps_plasma ion, hps_plasma el, const double* __restrict__ adk, int cPsi, int cEz, int cBx, int cBy, int cBz,
+               IonConsts k, unsigned long long* cnt, volatile long long* host, long long seq)
+{
+    constexpr int NS = ORDER + 2;
+    const long ip = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    bool ionize = false;
+    if (ip < ion.n) {
+        const uint64_t id = ion.idcpu[ip];
+        const int lev = ion.ion_lev[ip];
+        // an ion that has lost all Z electrons cannot ionise (the reference reads past the end of its tables there)
+        if ((id & HPS_ID_VALID) && lev < k.Z) {
+            // doGatherShapeN at (x_prev, y_prev) (PlasmaParticleContainer.cpp:341-350)
+            const double xp = ion.x_prev[ip], yp = ion.y_prev[ip];
+            double sx[NS], dsx[NS], sy[NS], dsy[NS];
+            const int i0 = nodal_weights<ORDER>((xp - k.pc.xoff)*k.pc.dx_inv, sx, dsx);
+            const int j0 = nodal_weights<ORDER>((yp - k.pc.yoff)*k.pc.dy_inv, sy, dsy);
+            double ExmBy = 0.0, EypBx = 0.0, Ez = 0.0, Bx = 0.0, By = 0.0;
+#pragma unroll
+            for (int iy = 0; iy < NS; ++iy) {
+                const long row = f.off(i0, j0 + iy);
+#pragma unroll
+                for (int ix = 0; ix < NS; ++ix) {
+                    const double* p = f.p + row + ix;
+                    const double psi_c = p[cPsi*f.ns];
+                    const double ss = sx[ix]*sy[iy];
+                    ExmBy += (dsx[ix]*sy[iy])*psi_c*k.pc.dx_inv;
+                    EypBx += (sx[ix]*dsy[iy])*psi_c*k.pc.dy_inv;
+                    Ez += ss*p[cEz*f.ns];
+                    Bx += ss*p[cBx*f.ns];
+                    By += ss*p[cBy*f.ns];
+                }
+            }
+            (void)cBz;
+            const double Ex = ExmBy + By*k.pc.c;
+            const double Ey = EypBx - Bx*k.pc.c;
+            const double Ep = sqrt(Ex*Ex + Ey*Ey + Ez*Ez)*k.E0;
+            const double ux = ion.ux_half[ip], uy = ion.uy_half[ip], psi = ion.psi_half[ip];
+            const double gammap = (1.0 + ux*ux*k.clightsq_inv + uy*uy*k.clightsq_inv + psi*psi)/(2.0*psi);
+            // gamma / psi completes dt for the quasi-static frame (:362-366)
+            const double w_dtau = gammap/psi*adk[lev]*pow(Ep, adk[2*k.Z + lev])*exp(adk[k.Z + lev]/Ep);
+            const double p = 1.0 - exp(-w_dtau);
+            const unsigned long long uid = ((id >> 24) & ((1ULL << 39) - 1)) - 1;
+            ionize = ion_uniform(k.seed, uid, k.step, k.islice) < p;
+            if (ionize) ion.ion_lev[ip] = lev + 1;
+        }
+    }
+    // one atomic per wave: a block of electron slots behind the product species' sheet
+    const unsigned long long mask = __ballot(ionize);
+    if (mask != 0ULL) {
+        const int lane = threadIdx.x & 63;
+        unsigned long long base = 0;
+        if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(cnt, (unsigned long long)__popcll(mask));
+        base = __shfl(base, __ffsll((long long)mask) - 1);
+        if (ionize) {
+            const long q = (long)base + __popcll(mask & ((1ULL << lane) - 1ULL));
+            if (q < k.cap) {
+                // the electron starts at rest on the ion (:404-433); id 2, level 0 of the mesh
+                el.x[q] = ion.x[ip]; el.y[q] = ion.y[ip]; el.w[q] = ion.w[ip];
+                el.ux[q] = 0.0; el.uy[q] = 0.0; el.psi[q] = 1.0;
+                if (el.x_prev != el.x) el.x_prev[q] = ion.x_prev[ip];
+                if (el.y_prev != el.y) el.y_prev[q] = ion.y_prev[ip];
+                el.ux_half[q] = 0.0; el.uy_half[q] = 0.0; el.psi_half[q] = 1.0;
+                el.idcpu[q] = HPS_ID_VALID | (2ULL << 24);
+                el.ion_lev[q] = 0;
+            } else {
+                atomicExch(cnt + 1, 1ULL);
+            }
+        }
+        if (lane == __ffsll((long long)mask) - 1) atomicAdd(cnt + 3, (unsigned long long)__popcll(mask));
+    }
+    // the last workgroup posts {electrons, overflow, ionisations, seq} to the host (seq last, behind a system fence)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(cnt + 2, 1ULL) == (unsigned long long)gridDim.x - 1ULL) {
+            cnt[2] = 0ULL;
+            __threadfence();
+            host[0] = (long long)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host[1] = (long long)__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host[2] = (long long)__hip_atomic_load(cnt + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            host[3] = seq;
+        }
+    }
+}
+
+// InitIonizationModule: ADK prefactors (Chen et al., JCP 236 (2013), eq. (2); l = m = 0, the approximate expressions
+// without the Gamma function of the angular part); adk = [prefactor[Z] | exp_prefactor[Z] | power[Z]] on the device
+int ion_create (Engine& E)
+{
+    const hps_deck& d = E.d;
+    HPS_REQUIRE(d.ion_Z >= 1 && d.ion_Z <= HPS_MAX_ION_LEVELS, "hps_engine_create: ion_Z out of range");
+    HPS_REQUIRE(d.ion_init_level >= 0 && d.ion_init_level <= d.ion_Z, "hps_engine_create: the initial ion level must be specified (0 .. Z)");
+    for (int i = 0; i < d.ion_Z; ++i) HPS_REQUIRE(d.ion_energies[i] > 0.0, "hps_engine_create: ionisation energies must be positive");
+    HPS_REQUIRE(d.si_units || d.background_density_SI > 0.0,
+                "hps_engine_create: ionisation in normalised units needs hipace.background_density_SI");      // (:391-396)
+    HPS_REQUIRE(std::fabs(d.plasma_charge/d.ion_charge + 1.0) < 1e-3, "hps_engine_create: ion and ionisation product charges have to be opposite");   // (:404-405)
+    const double cSI = 299792458.0, qeSI = 1.602176634e-19, meSI = 9.1093837015e-31, ep0SI = 8.8541878128e-12;
+    const double alpha = 0.0072973525693, r_e = 2.8179403227e-15;
+    const double a3 = alpha*alpha*alpha, a4 = a3*alpha;
+    const double wa = a3*cSI/r_e;
+    const double Ea = meSI*cSI*cSI/qeSI*a4/r_e;
+    const double UH = 13.59843449;                    // ionisation energy of hydrogen, entry 0 of the reference's table
+    const double l_eff = std::sqrt(UH/d.ion_energies[0]) - 1.0;
+    const double wp = std::sqrt(d.background_density_SI*qeSI*qeSI/(ep0SI*meSI));
+    const double dt = d.si_units ? E.gm.dz/cSI : E.gm.dz/wp;
+    std::vector<double> adk((size_t)3*d.ion_Z);
+    for (int i = 0; i < d.ion_Z; ++i) {
+        const double Uion = d.ion_energies[i];
+        const double n_eff = (i + 1)*std::sqrt(UH/Uion);
+        const double C2 = std::pow(2, 2*n_eff)/(n_eff*std::tgamma(n_eff + l_eff + 1)*std::tgamma(n_eff - l_eff));
+        adk[i] = dt*wa*C2*(Uion/(2*UH))*std::pow(2*std::pow((Uion/UH), 3./2)*Ea, 2*n_eff - 1);
+        adk[d.ion_Z + i] = -2./3*std::pow(Uion/UH, 3./2)*Ea;
+        adk[2*d.ion_Z + i] = -(2*n_eff - 1);
+    }
+    HPS_HIP_CHECK(hipMalloc(&E.ion.d_adk, adk.size()*sizeof(double)));
+    HPS_HIP_CHECK(hipMemcpy(E.ion.d_adk, adk.data(), adk.size()*sizeof(double), hipMemcpyHostToDevice));
+    HPS_HIP_CHECK(hipMalloc(&E.ion.d_cnt, 4*sizeof(unsigned long long)));
+    HPS_HIP_CHECK(hipMemset(E.ion.d_cnt, 0, 4*sizeof(unsigned long long)));
+    HPS_HIP_CHECK(hipHostMalloc(&E.ion.h_cnt, 4*sizeof(long long), hipHostMallocMapped));
+    for (int i = 0; i < 4; ++i) E.ion.h_cnt[i] = 0;
+    HPS_HIP_CHECK(hipHostGetDevicePointer((void**)&E.ion.h_cnt_dev, E.ion.h_cnt, 0));
+    return HPS_OK;
+}
+
+void ion_destroy (Engine& E)
+{
+    (void)hipFree(E.ion.d_adk); (void)hipFree(E.ion.d_cnt);
+    if (E.ion.h_cnt) (void)hipHostFree(E.ion.h_cnt);
+    (void)hipFree(E.ion.real); (void)hipFree(E.ion.pl.idcpu); (void)hipFree(E.ion.pl.ion_lev);
+    (void)hipFree(E.ion.real_alt); (void)hipFree(E.ion.pl_alt.idcpu); (void)hipFree(E.ion.pl_alt.ion_lev);
+    delete E.ion.tiling;
+}
+
+int Engine::ionize_slice (int islice)
+{
+    if (!d.ion_on || ion.n == 0) return HPS_OK;
+    IonConsts k{};
+    k.pc = base_consts(gm);
+    const double cSI = 299792458.0, qeSI = 1.602176634e-19, meSI = 9.1093837015e-31, ep0SI = 8.8541878128e-12;
+    const double wp = std::sqrt(d.background_density_SI*qeSI*qeSI/(ep0SI*meSI));
+    k.E0 = d.si_units ? 1.0 : wp*meSI*cSI/qeSI;
+    k.clightsq_inv = 1.0/(gm.c*gm.c);
+    k.Z = d.ion_Z; k.seed = d.ion_seed; k.step = (unsigned long long)step_index; k.islice = (unsigned long long)islice;
+    k.cap = np_cap;
+    ++ion.seq;
+    const SlabView f(slab);
+    const dim3 grid(ceil_div(ion.n, 256)), block(256);
+#define CALL(O) hipLaunchKernelGGL(k_ionize<O>, grid, block, 0, st, f, ion.pl, pl, ion.d_adk, HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ, \
+                                   k, ion.d_cnt, (volatile long long*)ion.h_cnt_dev, ion.seq)
+    switch (d.order) { case 0: CALL(0); break; case 1: CALL(1); break; case 2: CALL(2); break; default: CALL(3); break; }
+#undef CALL
+    HPS_HIP_CHECK(hipGetLastError());
+    ion.pending = true;
+    return HPS_OK;
+}
+
+// wait for the post of the last k_ionize; fall back to the stream's status every so often so that a failed launch
+// cannot hang the host
+int Engine::ionize_collect ()
+{
+    if (!ion.pending) return HPS_OK;
+    ion.pending = false;
+    volatile long long* hp = ion.h_cnt;
+    long spins = 0;
+    while (hp[3] != ion.seq) {
+        if ((++spins & 0xfffff) == 0 && hipStreamQuery(st) != hipErrorNotReady) {
+            if (hp[3] == ion.seq) break;
+            HPS_HIP_CHECK(hipStreamSynchronize(st));
+            if (hp[3] != ion.seq) { set_error("ionisation: the electron count never arrived"); return HPS_ERR_HIP; }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (hp[1] != 0) { set_error("ionisation: the product species' arrays are full"); return HPS_ERR_ARG; }
+    np = (long)hp[0]; pl.n = np; pl_alt.n = np;
+    ion.n_ionized = (long)hp[2];
+    return HPS_OK;
+}
+
+} // namespace hps

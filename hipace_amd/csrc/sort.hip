@@ -159,7 +159,7 @@ int tiling_sort (Tiling* T, const hps_plasma& src, const hps_plasma& dst, const 
     if (src.n > T->capacity) { set_error("hps_reorder_particles: more particles than the tiling capacity"); return HPS_ERR_ARG; }
     T->g.xoff = g.xoff; T->g.yoff = g.yoff; T->g.dx_inv = 1.0/g.dx; T->g.dy_inv = 1.0/g.dy;
     const long n = src.n;
-    if (n == 0) { HPS_HIP_CHECK(hipMemsetAsync(T->offsets, 0, (T->g.ntiles + 2)*sizeof(int), st)); return HPS_OK; }
+    if (n == 0) { HPS_HIP_CHECK(hipMemsetAsync(T->offsets, 0, (T->g.ntiles + 2)*sizeof(int), st)); T->sorted_n = 0; return HPS_OK; }
     const int ncell = T->g.ts*T->g.ts;
     const int nkeys1 = T->g.ntiles*ncell + 1;
     const dim3 gn(ceil_div(n, 256)), gn1(ceil_div(n + 1, 256)), b256(256);

@@ -315,3 +315,12 @@ def ionization_SI():
              beam_umean=(0.0, 0.0, 2000.0), beam_ppc=(1, 1, 1), beam_charge=-q_e, beam_mass=m_e,
              n_steps=3, dt=1.0e-12, bc=1)
     return with_ion_species(d, "H", ne, ppc=(1, 1), mass_Da=1.008, initial_level=0)
+
+
+def laser_ionization_SI():
+    """BASELINE config 5 at test size: the laser-driven wake of tests/laser_blowout_wake_explicit.SI.1Rank.sh in a gas that
+    also holds neutral nitrogen (a fifth of the electron density, one macro-atom per cell) -- the wake's field ionises the
+    atoms it reaches (ADK), the released electrons join the plasma electrons.  Neutral atoms and electron + ion pairs
+    carry no net charge, so the pre-formed plasma stays neutralised by its own background."""
+    d = laser_blowout_wake_SI()
+    return with_ion_species(d, "N", 0.2 * d["plasma_density"], ppc=(1, 1), initial_level=0, seed=5)

@@ -178,6 +178,7 @@ int hps_mg2_destroy (void* handle);
 
 /* ---- slice engine (Hipace::Evolve / SolveOneSlice, explicit solver; Hipace.cpp:393-728) -- */
 
+#define HPS_MAX_ION_LEVELS 56
 typedef struct {
     int nx, ny, nz; double lo[3], hi[3];
     int order; int deriv_type;
@@ -215,6 +216,17 @@ typedef struct {
      * BeamParticleAdvance.cpp:244-297; in normalised units it needs hipace.background_density_SI to convert the fields)
      * and <beam>.do_z_push (0 = skip z += dt (vz - c), :316; the ABI reads beam_no_z_push so that 0 keeps the default) */
     int beam_radiation_reaction; double background_density_SI; int beam_no_z_push;
+    /* SURVEY 8f-2, ionisation: a second plasma species "ion" that can be field-ionised (ADK), its electrons joining the
+     * first species -- <ion>.ionization_product = <plasma> (particles/plasma/PlasmaParticleContainer.cpp:61-90, 261-440;
+     * InitIonizationModule, PlasmaParticleContainerInit.cpp:382-464).  plasma_no_neutralize: <plasma>.neutralize_background
+     * = false (the ions are particles now).  ion_charge: charge of ONE level (+q_e; the deposits and the push weigh it with
+     * the particle's ion_lev), ion_energies: the element's ionisation energies in eV (NIST; the reference tabulates them in
+     * utils/IonizationEnergiesTable.H), ion_Z of them.  In normalised units background_density_SI must be set.
+     * ion_seed: key of the counter-based random number generator (one draw per ion, slice and step; the reference draws
+     * from amrex::Random, whose sequence is not reproducible).  Explicit solver only. */
+    int plasma_no_neutralize;
+    int ion_on; int ion_ppc[2]; double ion_density, ion_mass, ion_charge; int ion_init_level, ion_Z;
+    double ion_energies[HPS_MAX_ION_LEVELS]; unsigned long long ion_seed;
 } hps_deck;
 
 /* slab component indices of the engine (explicit-solver layout of fields/Fields.cpp:70-122) */
@@ -239,6 +251,10 @@ int hps_engine_sync (void* handle);
 int hps_engine_info (void* handle, int* ncomp, int* nguards, long* nparticles);
 hps_slab hps_engine_slab (void* handle);
 hps_plasma hps_engine_plasma (void* handle);
+/* species "ion" (hps_deck.ion_on): its sheet, the electrons it has released since hps_engine_create and the size of the
+ * first species now (hps_engine_plasma().n follows it); synchronises the stream */
+hps_plasma hps_engine_ions (void* handle);
+int hps_engine_ion_stats (void* handle, long* n_ionized_host, long* n_product_host);
 hps_stream hps_engine_stream (void* handle);
 /* sum |Q| per component over valid cells and all slices of the current step (host array[ncomp]) */
 int hps_engine_checksums (void* handle, double* out_host);

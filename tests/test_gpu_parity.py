@@ -1181,3 +1181,84 @@ def test_laser_blowout_wake_SI_matches_reference_checksums(api, tile_size):
             assert cs[k] == 0.0, k
         else:
             assert abs(cs[k] - v) <= 1e-9 * abs(v), (k, cs[k], v)
+
+
+# ---- ADK field ionisation: species "ion" + released electrons (BASELINE config 5) -----------------------
+def _compare_ion_run(api, oracle, deck, tile_size, n_steps, tol=1e-8):
+    """GPU engine against the oracle, step by step: same key -> the same draw for every ion whatever the tile sort did
+    to its position in the sheet, so the same ions ionise on the same slices; fields, ion levels (matched by lattice
+    index) and the set of released electrons agree."""
+    ge = api.SliceEngine(deck, tile_size=tile_size)
+    ge.set_diagnostics(True)
+    oe = oracle.Engine(deck)
+    nz = deck["nz"]
+    total = 0
+    for step in range(n_steps):
+        ge.begin_step()
+        oe.begin_step()
+        for k in range(nz - 1, -1, -1):
+            ge.solve_slice(k)
+            oe.solve_slice(k)
+        gs, os_ = ge.slab(), oe.slab()
+        for c, name in enumerate(ge.comp_names()):
+            scale = max(np.abs(os_[c]).max(), 1e-300)
+            assert np.abs(gs[c] - os_[c]).max() <= tol * scale, (step, name, np.abs(gs[c] - os_[c]).max() / scale)
+        gc, oc = ge.checksums(), oe.checksums()
+        for name, v in oc.items():
+            assert abs(gc[name] - v) <= tol * max(abs(v), 1e-300), (step, name, gc[name], v)
+        # ions: levels by lattice index (bit-exact integer state)
+        greal, gvalid, glev, gkey = ge.ions()
+        oreal, ovalid, olev = oe.ions()
+        assert sorted(gkey) == list(range(len(olev)))
+        assert np.array_equal(glev[np.argsort(gkey)], olev)
+        assert np.array_equal(gvalid[np.argsort(gkey)], ovalid)
+        # electrons: as many, and the same particles (the device appends them in the order its waves finish)
+        n_ion, n_el = ge.ion_stats()
+        er, ev = ge.particles()
+        orl, ovl = oe.particles()
+        assert er.shape == orl.shape and n_el == orl.shape[1] and np.array_equal(np.sort(ev), np.sort(ovl))
+        total += int((olev - deck["ion_init_level"]).sum())
+        assert n_ion == total == oe.n_ionized()
+        if er.shape[1]:
+            kg = np.lexsort((np.round(er[1] / deck["hi"][1], 9), np.round(er[0] / deck["hi"][0], 9), np.round(er[2] / er[2].max(), 9)))
+            ko = np.lexsort((np.round(orl[1] / deck["hi"][1], 9), np.round(orl[0] / deck["hi"][0], 9), np.round(orl[2] / orl[2].max(), 9)))
+            for q in (0, 1, 2, 3, 4, 5):
+                sc = max(np.abs(orl[q]).max(), 1e-300)
+                assert np.abs(er[q][kg] - orl[q][ko]).max() <= 1e-7 * sc, (step, q)
+    return total
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile_size", [0, 16])
+def test_ionization_deck_matches_oracle(api, oracle, tile_size):
+    """tests/ionization.2Rank.sh's deck (neutral hydrogen, a flat-top driver, hipace.dt = 1e-12): the oracle is pinned on
+    the reference's ionization.2Rank.json to what the random draws leave open (tests/test_oracle_golden.py); the HIP
+    engine equals the oracle with the same generator key -- both plasma species, the moving beam, two steps."""
+    deck = decks.ionization_SI()
+    n = _compare_ion_run(api, oracle, deck, tile_size, 2)
+    assert n > 500
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile_size,solver", [(16, 1), (0, 1), (16, 2)])
+def test_laser_wake_with_ionization_matches_oracle(api, oracle, tile_size, solver):
+    """BASELINE config 5 at test size: the laser-driven wake in a gas with neutral nitrogen that the wake ionises, the
+    envelope advanced by the FFT / multigrid solver over two steps; every slab component, the ion levels and the
+    released electrons equal the oracle's."""
+    deck = decks.laser_ionization_SI()
+    deck.update(nx=64, ny=64, nz=60, laser_solver=solver, dt=6.0 * 10.0e-6 / 299792458.0, n_steps=2)
+    n = _compare_ion_run(api, oracle, deck, tile_size, 2, tol=1e-7)
+    assert n > 100
+
+
+@pytest.mark.gpu
+def test_ionization_refusals(api):
+    deck = decks.ionization_SI()
+    with pytest.raises(RuntimeError):
+        api.SliceEngine(dict(deck, bxby_solver=1))                       # explicit solver only
+    with pytest.raises(RuntimeError):
+        api.SliceEngine(dict(deck, ion_charge=deck["plasma_charge"]))    # product and ion charges must be opposite
+    norm = decks.blowout_wake()
+    decks.with_ion_species(norm, "H", 1.0)
+    with pytest.raises(RuntimeError):
+        api.SliceEngine(norm)                                            # normalised units need background_density_SI
