@@ -14,11 +14,22 @@
 #include "particle_math.h"
 #include "tiling.h"
 
+#include <cstdlib>
+
 namespace hps {
 
-#ifndef HPS_EXPL_PAD
-#define HPS_EXPL_PAD 2      /* LDS row pitch R+2: fewer bank conflicts between the stencil rows (measured -2.5 %) */
-#endif
+// LDS row pitch of the explicit deposition's images: R + PAD doubles.  With the cells of a tile numbered in 4 x 8 blocks
+// (sort.hip: cell_in_tile) the 32 lanes of a half-wave work on x + pitch*y, x < 4, y < 8: pitch = 36 (PAD 8, = +4 mod 32)
+// puts them on 32 different bank pairs; PAD 2 is the best for the row-by-row numbering (measured -2.5 % against 0).
+static int expl_pad ()
+{
+    static int pad = -1;
+    if (pad < 0) {
+        pad = 8;
+        if (const char* e = std::getenv("HPS_EXPL_PAD")) { const int v = std::atoi(e); if (v == 2 || v == 8) pad = v; }
+    }
+    return pad;
+}
 #ifndef HPS_TILE_HALO
 #define HPS_TILE_HALO 6
 #endif
@@ -193,13 +204,13 @@ __device__ __forceinline__ void load_region (double* img, const SlabView& f, con
     }
 }
 
-template <int ORDER, int DT, int TS, bool LASER = false>
+template <int ORDER, int DT, int TS, bool LASER = false, int PAD = 8>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // 128 VGPRs: 4 workgroups per CU
 void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
                        int cBz, int cEz, int cExmBy, int cEypBx, int cSy, int cSx, PartConsts k, int* n_fallback)
 {
     constexpr int R = TS + 2*TILE_HALO;
-    constexpr int RP = R + HPS_EXPL_PAD, PL = RP*R;     // row pitch and plane size of the LDS images
+    constexpr int RP = R + PAD, PL = RP*R;     // row pitch and plane size of the LDS images
     constexpr int NS = ORDER + DT + 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];     // [4 cached][R*R] + [2 accum][R*R]
     double* img = lds;
@@ -492,27 +503,24 @@ int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hp
     k.a = charge*invvol_of(g)*g.mu0; k.b = charge/mass; k.can_ionize = can_ionize;
     k.aabs = aabs_comp; k.laser_fac = (g.m_e/g.q_e)*(g.m_e/g.q_e);
     const int R = T->g.ts + 2*TILE_HALO;
-    const size_t lds = (size_t)6*R*(R + HPS_EXPL_PAD)*sizeof(double);
+    const int pad = expl_pad();
+    const size_t lds = (size_t)6*R*(R + pad)*sizeof(double);
     SlabView f(slab);
+#define HPS_EXPL_LAUNCH(O, D, S, L, P) { if (int e = set_lds(k_explicit_tiled<O, D, S, L, P>, lds)) return e; \
+        hipLaunchKernelGGL((k_explicit_tiled<O, D, S, L, P>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
+                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback); }
+#define HPS_EXPL_PADS(O, D, S, L) { if (pad == 8) HPS_EXPL_LAUNCH(O, D, S, L, 8) else HPS_EXPL_LAUNCH(O, D, S, L, 2) }
     if (dtype == 2) {
-#define CALL(O, S) { if (aabs_comp >= 0) { if (int e = set_lds(k_explicit_tiled<O, 2, S, true>, lds)) return e; \
-        hipLaunchKernelGGL((k_explicit_tiled<O, 2, S, true>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
-                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback); } else { \
-        if (int e = set_lds(k_explicit_tiled<O, 2, S>, lds)) return e; \
-        hipLaunchKernelGGL((k_explicit_tiled<O, 2, S>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
-                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback); } }
+#define CALL(O, S) { if (aabs_comp >= 0) HPS_EXPL_PADS(O, 2, S, true) else HPS_EXPL_PADS(O, 2, S, false) }
         HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
 #undef CALL
     } else {
-#define CALL(O, S) { if (aabs_comp >= 0) { if (int e = set_lds(k_explicit_tiled<O, 1, S, true>, lds)) return e; \
-        hipLaunchKernelGGL((k_explicit_tiled<O, 1, S, true>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
-                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback); } else { \
-        if (int e = set_lds(k_explicit_tiled<O, 1, S>, lds)) return e; \
-        hipLaunchKernelGGL((k_explicit_tiled<O, 1, S>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
-                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback); } }
+#define CALL(O, S) { if (aabs_comp >= 0) HPS_EXPL_PADS(O, 1, S, true) else HPS_EXPL_PADS(O, 1, S, false) }
         HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
 #undef CALL
     }
+#undef HPS_EXPL_PADS
+#undef HPS_EXPL_LAUNCH
     HPS_HIP_CHECK(hipGetLastError());
     return HPS_OK;
 }

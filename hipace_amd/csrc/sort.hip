@@ -17,15 +17,33 @@
 #include "common.h"
 #include "tiling.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
 namespace hps {
 
+#ifndef HPS_CELL_BLOCK_W
+#define HPS_CELL_BLOCK_W 4
+#endif
 #ifndef HPS_RANK_CAP
 #define HPS_RANK_CAP 16
 #endif
 constexpr int RANK_CAP = HPS_RANK_CAP;
+
+// Number of cell (x, y) inside its tile.  The particles of a tile are interleaved over its cells in this order, so 32
+// consecutive numbers are the cells the lanes of a half-wave work on at the same time, and their LDS words must fall
+// into 32 different bank pairs.  Row by row (bw = ts) a half-wave covers two rows of 16 cells: with the row pitches of
+// the LDS images (28, 30 doubles) the second row lands on the banks of the first (2-way conflicts on every access).
+// In blocks of bw = 4 cells across and 8 down, word = x + pitch*y with pitch = 28 or 36 = -4 or +4 (mod 32): 32
+// different bank pairs.
+__host__ __device__ __forceinline__ int cell_in_tile (int x, int y, int ts, int bw)
+{
+    if (bw >= ts) return y*ts + x;
+    const int bh = 32/bw;                        // 32 cells per block
+    const int bx = x/bw, by = y/bh, nbx = ts/bw;
+    return ((by*nbx + bx)*bh + (y - by*bh))*bw + (x - bx*bw);
+}
 
 // (tile, cell in tile) of the nearest cell; invalid particles get tile = ntiles, cell 0
 __device__ __forceinline__ unsigned int cell_key (double x, double y, uint64_t id, const TileGeom& t)
@@ -37,7 +55,7 @@ __device__ __forceinline__ unsigned int cell_key (double x, double y, uint64_t i
     ci = min(max(ci, 0), t.nx - 1);
     cj = min(max(cj, 0), t.ny - 1);
     const int tile = (cj / t.ts)*t.ntx + (ci / t.ts);
-    return (unsigned int)(tile*ncell + (cj % t.ts)*t.ts + (ci % t.ts));
+    return (unsigned int)(tile*ncell + cell_in_tile(ci % t.ts, cj % t.ts, t.ts, t.bw));
 }
 
 __global__ __launch_bounds__(256)
@@ -126,6 +144,9 @@ int tiling_create (int nx, int ny, int ts, long capacity, Tiling** out)
     Tiling* T = new Tiling;
     T->g.nx = nx; T->g.ny = ny; T->g.ts = ts;
     T->g.ntx = (nx + ts - 1)/ts; T->g.nty = (ny + ts - 1)/ts; T->g.ntiles = T->g.ntx*T->g.nty;
+    T->g.bw = HPS_CELL_BLOCK_W;
+    if (const char* e = std::getenv("HPS_CELL_BLOCK_W")) { const int v = std::atoi(e); if (v == 4 || v == 8 || v == 16 || v == 32) T->g.bw = v; }
+    if (T->g.bw > ts) T->g.bw = ts;
     T->capacity = capacity;
     HPS_HIP_CHECK(hipMalloc(&T->offsets, (2*T->g.ntiles + 2)*sizeof(int)));
     HPS_HIP_CHECK(hipMemset(T->offsets, 0, (2*T->g.ntiles + 2)*sizeof(int)));

@@ -5,7 +5,9 @@
 
 namespace hps {
 
-struct TileGeom { int nx, ny, ts, ntx, nty, ntiles; double xoff, yoff, dx_inv, dy_inv; };
+struct TileGeom { int nx, ny, ts, ntx, nty, ntiles; double xoff, yoff, dx_inv, dy_inv;
+                  int bw;      // cells of a tile are numbered in blocks of bw x (32/bw) cells (bw = ts: row by row)
+};
 
 struct Tiling {
     TileGeom g{};

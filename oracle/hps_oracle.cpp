@@ -2059,6 +2059,15 @@ void orc_gather (orc_slab s, orc_geom g, const int* comp, int order, double xp, 
 // reference; bit-exactness is defined between this restatement and the HIP path).
 void orc_tile_sort (orc_plasma p, orc_geom g, int nx, int ny, int ts, uint32_t* perm, int32_t* offsets)
 {
+    // numbering of the cells inside a tile: blocks of bw x (32/bw) cells (sort.hip: cell_in_tile; HPS_CELL_BLOCK_W as there)
+    int bw = 4;
+    if (const char* e = std::getenv("HPS_CELL_BLOCK_W")) { const int v = std::atoi(e); if (v == 4 || v == 8 || v == 16 || v == 32) bw = v; }
+    if (bw > ts) bw = ts;
+    auto cell_in_tile = [&] (int x, int y) {
+        if (bw >= ts) return y*ts + x;
+        const int bh = 32/bw, bx = x/bw, by = y/bh, nbx = ts/bw;
+        return ((by*nbx + bx)*bh + (y - by*bh))*bw + (x - bx*bw);
+    };
     // pass 1: stable order by (tile, cell in tile) of the nearest cell, invalid particles last;
     // rank = position inside the run of equal keys (capped); pass 2: stable order by
     // (tile, rank, cell in tile): the particles of a tile interleaved over its cells.
@@ -2074,7 +2083,7 @@ void orc_tile_sort (orc_plasma p, orc_geom g, int nx, int ny, int ts, uint32_t* 
             int cj = (int)std::floor((p.y[k] - g.yoff)*dy_inv + 0.5);
             ci = std::min(std::max(ci, 0), nx - 1);
             cj = std::min(std::max(cj, 0), ny - 1);
-            c = (long)((cj/ts)*ntx + (ci/ts))*ncell + (cj % ts)*ts + (ci % ts);
+            c = (long)((cj/ts)*ntx + (ci/ts))*ncell + cell_in_tile(ci % ts, cj % ts);
         }
         key1[k] = c;
     }
