@@ -5,6 +5,7 @@
 #include "common.h"
 #include <vector>
 #include "tiling.h"
+#include "particle_math.h"
 
 void mg_rider (void* mg_handle, int** dev_words, const int** host_words);     // multigrid.hip
 
@@ -33,7 +34,8 @@ struct Engine {
                   double* d_adk = nullptr; unsigned long long* d_cnt = nullptr; long long* h_cnt = nullptr; long long* h_cnt_dev = nullptr;
                   long long seq = 0; long n_ionized = 0; bool pending = false; } ion;
     int step_index = -1;           // time step that has begun (the ionisation draws are keyed by it)
-    int ionize_slice (int islice);             // ionization.hip: launch
+    IonArgs ion_args (int islice);             // ionization.hip: kernel arguments of this slice's ionisation
+    int ionize_slice (int islice);             // ...: launch of the per-particle form
     int ionize_collect ();                     // ...: wait for the electron count of the slice
     hps_plasma tail_of (const hps_plasma& p, long first, long n) const;
     int species_deposit (const hps_plasma& p, Tiling* T, const int comp[6], double charge, double mass, int can_ionize);

@@ -19,7 +19,7 @@ int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hp
                             hipStream_t st, int aabs_comp = -1);
 int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], double charge,
                           double mass, int order, int temp_slice, int n_subcycles, int can_ionize, Tiling* T,
-                          int* n_fallback, hipStream_t st, int aabs_comp = -1);
+                          int* n_fallback, hipStream_t st, int aabs_comp = -1, const IonArgs* ion = nullptr);
 
 static thread_local std::string g_err;
 void set_error (const std::string& msg) { g_err = msg; }
@@ -1216,8 +1216,13 @@ int Engine::solve_slice (int islice)
         if (ion.n > 0) {
             // DoFieldIonization (Hipace.cpp:693-696), then the ions' own push; the host learns how many electrons the
             // slice has released while that push runs
-            if ((e = ionize_slice(islice))) return e;
-            if ((e = species_advance(ion.pl, ion.tiling, comp, d.ion_charge, d.ion_mass, 0, 1))) return e;
+            if (ion.tiling) {       // decided inside the ions' LDS-tile push, on the fields it gathers anyway
+                const IonArgs ia = ion_args(islice);
+                if ((e = advance_plasma_tiled(slab, ion.pl, gm, comp, d.ion_charge, d.ion_mass, d.order, 0, d.n_subcycles, 1, ion.tiling, d_nfallback, st, c_aabs, &ia))) return e;
+            } else {
+                if ((e = ionize_slice(islice))) return e;
+                if ((e = species_advance(ion.pl, ion.tiling, comp, d.ion_charge, d.ion_mass, 0, 1))) return e;
+            }
             if ((e = ionize_collect())) return e;
         }
         if ((e = species_advance(pl, tiling, comp, d.plasma_charge, d.plasma_mass, 0, 0))) return e; }

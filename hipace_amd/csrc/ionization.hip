@@ -23,32 +23,11 @@
 
 namespace hps {
 
-struct IonConsts {
-    PartConsts pc;
-    double E0, clightsq_inv;
-    int Z;
-    unsigned long long seed, step, islice;
-    long cap;                   // capacity of the product species' arrays
-};
-
-__device__ __forceinline__ double ion_uniform (unsigned long long seed, unsigned long long uid, unsigned long long step,
-                                               unsigned long long islice)
-{
-    unsigned long long z = seed + 0x9E3779B97F4A7C15ULL*(uid + 1) + 0xBF58476D1CE4E5B9ULL*(step + 1) + 0x94D049BB133111EBULL*(islice + 1);
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
-        z ^= z >> 27; z *= 0x94D049BB133111EBULL;
-        z ^= z >> 31;
-    }
-    return (double)(z >> 11)*(1.0/9007199254740992.0);
-}
-
-// cnt = {electrons in the product sheet, overflow flag, workgroups done, ionisations so far}
+// per-particle form (tile_size = 0, or a sheet without a tiling); the LDS-tile form is fused into the ions' push
+// (particles_tiled.hip: k_advance_tiled<.., IONIZE>), which gathers the same fields anyway
 template <int ORDER>
 __global__ __launch_bounds__(256)
-void k_ionize (SlabView f, hps_plasma ion, hps_plasma el, const double* __restrict__ adk, int cPsi, int cEz, int cBx, int cBy, int cBz,
-               IonConsts k, unsigned long long* cnt, volatile long long* host, long long seq)
+void k_ionize (SlabView f, hps_plasma ion, int cPsi, int cEz, int cBx, int cBy, PartConsts k, IonArgs a)
 {
     constexpr int NS = ORDER + 2;
     const long ip = (long)blockIdx.x*blockDim.x + threadIdx.x;
@@ -57,12 +36,12 @@ void k_ionize (SlabView f, hps_plasma ion, hps_plasma el, const double* __restri
         const uint64_t id = ion.idcpu[ip];
         const int lev = ion.ion_lev[ip];
         // an ion that has lost all Z electrons cannot ionise (the reference reads past the end of its tables there)
-        if ((id & HPS_ID_VALID) && lev < k.Z) {
+        if ((id & HPS_ID_VALID) && lev < a.Z) {
             // doGatherShapeN at (x_prev, y_prev) (PlasmaParticleContainer.cpp:341-350)
             const double xp = ion.x_prev[ip], yp = ion.y_prev[ip];
             double sx[NS], dsx[NS], sy[NS], dsy[NS];
-            const int i0 = nodal_weights<ORDER>((xp - k.pc.xoff)*k.pc.dx_inv, sx, dsx);
-            const int j0 = nodal_weights<ORDER>((yp - k.pc.yoff)*k.pc.dy_inv, sy, dsy);
+            const int i0 = nodal_weights<ORDER>((xp - k.xoff)*k.dx_inv, sx, dsx);
+            const int j0 = nodal_weights<ORDER>((yp - k.yoff)*k.dy_inv, sy, dsy);
             double ExmBy = 0.0, EypBx = 0.0, Ez = 0.0, Bx = 0.0, By = 0.0;
 #pragma unroll
             for (int iy = 0; iy < NS; ++iy) {
@@ -72,65 +51,20 @@ void k_ionize (SlabView f, hps_plasma ion, hps_plasma el, const double* __restri
                     const double* p = f.p + row + ix;
                     const double psi_c = p[cPsi*f.ns];
                     const double ss = sx[ix]*sy[iy];
-                    ExmBy += (dsx[ix]*sy[iy])*psi_c*k.pc.dx_inv;
-                    EypBx += (sx[ix]*dsy[iy])*psi_c*k.pc.dy_inv;
+                    ExmBy += (dsx[ix]*sy[iy])*psi_c*k.dx_inv;
+                    EypBx += (sx[ix]*dsy[iy])*psi_c*k.dy_inv;
                     Ez += ss*p[cEz*f.ns];
                     Bx += ss*p[cBx*f.ns];
                     By += ss*p[cBy*f.ns];
                 }
             }
-            (void)cBz;
-            const double Ex = ExmBy + By*k.pc.c;
-            const double Ey = EypBx - Bx*k.pc.c;
-            const double Ep = sqrt(Ex*Ex + Ey*Ey + Ez*Ez)*k.E0;
-            const double ux = ion.ux_half[ip], uy = ion.uy_half[ip], psi = ion.psi_half[ip];
-            const double gammap = (1.0 + ux*ux*k.clightsq_inv + uy*uy*k.clightsq_inv + psi*psi)/(2.0*psi);
-            // gamma / psi completes dt for the quasi-static frame (:362-366)
-            const double w_dtau = gammap/psi*adk[lev]*pow(Ep, adk[2*k.Z + lev])*exp(adk[k.Z + lev]/Ep);
-            const double p = 1.0 - exp(-w_dtau);
-            const unsigned long long uid = ((id >> 24) & ((1ULL << 39) - 1)) - 1;
-            ionize = ion_uniform(k.seed, uid, k.step, k.islice) < p;
+            ionize = adk_decide(a, ExmBy + By*k.c, EypBx - Bx*k.c, Ez, ion.ux_half[ip], ion.uy_half[ip], ion.psi_half[ip], lev, id);
             if (ionize) ion.ion_lev[ip] = lev + 1;
         }
     }
-    // one atomic per wave: a block of electron slots behind the product species' sheet
-    const unsigned long long mask = __ballot(ionize);
-    if (mask != 0ULL) {
-        const int lane = threadIdx.x & 63;
-        unsigned long long base = 0;
-        if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(cnt, (unsigned long long)__popcll(mask));
-        base = __shfl(base, __ffsll((long long)mask) - 1);
-        if (ionize) {
-            const long q = (long)base + __popcll(mask & ((1ULL << lane) - 1ULL));
-            if (q < k.cap) {
-                // the electron starts at rest on the ion (:404-433); id 2, level 0 of the mesh
-                el.x[q] = ion.x[ip]; el.y[q] = ion.y[ip]; el.w[q] = ion.w[ip];
-                el.ux[q] = 0.0; el.uy[q] = 0.0; el.psi[q] = 1.0;
-                if (el.x_prev != el.x) el.x_prev[q] = ion.x_prev[ip];
-                if (el.y_prev != el.y) el.y_prev[q] = ion.y_prev[ip];
-                el.ux_half[q] = 0.0; el.uy_half[q] = 0.0; el.psi_half[q] = 1.0;
-                el.idcpu[q] = HPS_ID_VALID | (2ULL << 24);
-                el.ion_lev[q] = 0;
-            } else {
-                atomicExch(cnt + 1, 1ULL);
-            }
-        }
-        if (lane == __ffsll((long long)mask) - 1) atomicAdd(cnt + 3, (unsigned long long)__popcll(mask));
-    }
-    // the last workgroup posts {electrons, overflow, ionisations, seq} to the host (seq last, behind a system fence)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(cnt + 2, 1ULL) == (unsigned long long)gridDim.x - 1ULL) {
-            cnt[2] = 0ULL;
-            __threadfence();
-            host[0] = (long long)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            host[1] = (long long)__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            host[2] = (long long)__hip_atomic_load(cnt + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence_system();
-            host[3] = seq;
-        }
-    }
+    const long q = ip < ion.n ? ip : 0;
+    adk_emit(a, ionize, ion.x[q], ion.y[q], ion.x_prev[q], ion.y_prev[q], ion.w[q]);
+    adk_post(a);
 }
 
 // InitIonizationModule: ADK prefactors (Chen et al., JCP 236 (2013), eq. (2); l = m = 0, the approximate expressions
@@ -181,26 +115,32 @@ void ion_destroy (Engine& E)
     delete E.ion.tiling;
 }
 
+IonArgs Engine::ion_args (int islice)
+{
+    IonArgs a{};
+    const double cSI = 299792458.0, qeSI = 1.602176634e-19, meSI = 9.1093837015e-31, ep0SI = 8.8541878128e-12;
+    const double wp = std::sqrt(d.background_density_SI*qeSI*qeSI/(ep0SI*meSI));
+    a.el = pl; a.adk = ion.d_adk; a.cnt = ion.d_cnt; a.host = (volatile long long*)ion.h_cnt_dev;
+    a.E0 = d.si_units ? 1.0 : wp*meSI*cSI/qeSI;
+    a.clightsq_inv = 1.0/(gm.c*gm.c);
+    a.Z = d.ion_Z; a.seed = d.ion_seed; a.step = (unsigned long long)step_index; a.islice = (unsigned long long)islice;
+    a.cap = np_cap;
+    a.seq = ++ion.seq;
+    ion.pending = true;
+    return a;
+}
+
 int Engine::ionize_slice (int islice)
 {
     if (!d.ion_on || ion.n == 0) return HPS_OK;
-    IonConsts k{};
-    k.pc = base_consts(gm);
-    const double cSI = 299792458.0, qeSI = 1.602176634e-19, meSI = 9.1093837015e-31, ep0SI = 8.8541878128e-12;
-    const double wp = std::sqrt(d.background_density_SI*qeSI*qeSI/(ep0SI*meSI));
-    k.E0 = d.si_units ? 1.0 : wp*meSI*cSI/qeSI;
-    k.clightsq_inv = 1.0/(gm.c*gm.c);
-    k.Z = d.ion_Z; k.seed = d.ion_seed; k.step = (unsigned long long)step_index; k.islice = (unsigned long long)islice;
-    k.cap = np_cap;
-    ++ion.seq;
+    const IonArgs a = ion_args(islice);
+    const PartConsts k = base_consts(gm);
     const SlabView f(slab);
     const dim3 grid(ceil_div(ion.n, 256)), block(256);
-#define CALL(O) hipLaunchKernelGGL(k_ionize<O>, grid, block, 0, st, f, ion.pl, pl, ion.d_adk, HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ, \
-                                   k, ion.d_cnt, (volatile long long*)ion.h_cnt_dev, ion.seq)
+#define CALL(O) hipLaunchKernelGGL(k_ionize<O>, grid, block, 0, st, f, ion.pl, HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, k, a)
     switch (d.order) { case 0: CALL(0); break; case 1: CALL(1); break; case 2: CALL(2); break; default: CALL(3); break; }
 #undef CALL
     HPS_HIP_CHECK(hipGetLastError());
-    ion.pending = true;
     return HPS_OK;
 }
 

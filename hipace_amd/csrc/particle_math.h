@@ -143,6 +143,97 @@ __device__ __forceinline__ bool apply_particle_bc (const PartConsts& k, double& 
     return false;
 }
 
+// ---- ADK field ionisation (ionization.hip; fused into the ions' LDS-tile push in particles_tiled.hip) -----------------
+// uniform deviate in [0, 1) of (seed, ion, time step, slice): counter based (two rounds of the splitmix64 finaliser), same
+// integer arithmetic as the oracle's ion_uniform
+__device__ __forceinline__ double ion_uniform (unsigned long long seed, unsigned long long uid, unsigned long long step,
+                                               unsigned long long islice)
+{
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ULL*(uid + 1) + 0xBF58476D1CE4E5B9ULL*(step + 1) + 0x94D049BB133111EBULL*(islice + 1);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+        z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+    }
+    return (double)(z >> 11)*(1.0/9007199254740992.0);
+}
+
+struct IonArgs {
+    hps_plasma el;                       // product species: electrons are appended behind cnt[0] particles
+    const double* adk;                   // [prefactor[Z] | exp_prefactor[Z] | power[Z]]
+    unsigned long long* cnt;             // {electrons in el, overflow flag, workgroups done, ionisations so far}
+    volatile long long* host; long long seq;      // mapped host memory the last workgroup posts {cnt[0], cnt[1], cnt[3], seq} to
+    double E0, clightsq_inv; int Z;
+    unsigned long long seed, step, islice;
+    long cap;                            // capacity of el's arrays
+};
+
+// One ion's decision (PlasmaParticleContainer.cpp:352-372) from the fields gathered at (x_prev, y_prev): Ex, Ey, Ez in the
+// engine's units.  Returns true if the ion loses an electron on this slice.
+__device__ __forceinline__ bool adk_decide (const IonArgs& a, double Ex, double Ey, double Ez, double ux, double uy, double psi,
+                                            int lev, uint64_t id)
+{
+    const double Ep = sqrt(Ex*Ex + Ey*Ey + Ez*Ez)*a.E0;
+    const double gammap = (1.0 + ux*ux*a.clightsq_inv + uy*uy*a.clightsq_inv + psi*psi)/(2.0*psi);
+    // gamma / psi completes dt for the quasi-static frame (:362-366)
+    const double w_dtau = gammap/psi*a.adk[lev]*pow(Ep, a.adk[2*a.Z + lev])*exp(a.adk[a.Z + lev]/Ep);
+    const double p = 1.0 - exp(-w_dtau);
+    const unsigned long long uid = ((id >> 24) & ((1ULL << 39) - 1)) - 1;
+    return ion_uniform(a.seed, uid, a.step, a.islice) < p;
+}
+
+// The lanes of a wave that ionise take a block of electron slots with ONE atomic (ballot + popcount) and write their
+// electrons: at rest on the ion, with its weight (PlasmaParticleContainer.cpp:404-433); id 2, level 0 of the mesh.
+// Call with `ionize` false from lanes that do not ionise; the lanes of the wave that have left the loop do not matter.
+__device__ __forceinline__ void adk_emit (const IonArgs& a, bool ionize, double x, double y, double xprev, double yprev, double w)
+{
+    const unsigned long long mask = __ballot(ionize);
+    if (mask == 0ULL) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) {
+        base = atomicAdd(a.cnt, (unsigned long long)__popcll(mask));
+        atomicAdd(a.cnt + 3, (unsigned long long)__popcll(mask));
+    }
+    base = __shfl(base, leader);
+    if (ionize) {
+        const long q = (long)base + __popcll(mask & ((1ULL << lane) - 1ULL));
+        if (q < a.cap) {
+            const hps_plasma& el = a.el;
+            el.x[q] = x; el.y[q] = y; el.w[q] = w;
+            el.ux[q] = 0.0; el.uy[q] = 0.0; el.psi[q] = 1.0;
+            if (el.x_prev != el.x) el.x_prev[q] = xprev;
+            if (el.y_prev != el.y) el.y_prev[q] = yprev;
+            el.ux_half[q] = 0.0; el.uy_half[q] = 0.0; el.psi_half[q] = 1.0;
+            el.idcpu[q] = HPS_ID_VALID | (2ULL << 24);
+            el.ion_lev[q] = 0;
+        } else {
+            atomicExch(a.cnt + 1, 1ULL);
+        }
+    }
+}
+
+// the last workgroup of the launch posts {electrons, overflow, ionisations, seq} to the host (seq last, behind a
+// system-scope fence); call from every workgroup after its last adk_emit
+__device__ __forceinline__ void adk_post (const IonArgs& a)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(a.cnt + 2, 1ULL) == (unsigned long long)gridDim.x - 1ULL) {
+            a.cnt[2] = 0ULL;
+            __threadfence();
+            a.host[0] = (long long)__hip_atomic_load(a.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.host[1] = (long long)__hip_atomic_load(a.cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.host[2] = (long long)__hip_atomic_load(a.cnt + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            a.host[3] = a.seq;
+        }
+    }
+}
+
 inline PartConsts base_consts (const hps_geom& g)
 {
     PartConsts k{};

@@ -18,14 +18,14 @@
 
 namespace hps {
 
-// LDS row pitch of the explicit deposition's images: R + PAD doubles.  With the cells of a tile numbered in 4 x 8 blocks
-// (sort.hip: cell_in_tile) the 32 lanes of a half-wave work on x + pitch*y, x < 4, y < 8: pitch = 36 (PAD 8, = +4 mod 32)
-// puts them on 32 different bank pairs; PAD 2 is the best for the row-by-row numbering (measured -2.5 % against 0).
+// LDS row pitch of the explicit deposition's images: R + PAD doubles.  PAD 2 is the best for the row-by-row numbering of
+// a tile's cells (measured -2.5 % against 0; PAD 8 with it: 136.5 against 124.8 us); PAD 8 (pitch 36 = +4 mod 32) goes
+// with the 4 x 8-block numbering (sort.hip: cell_in_tile, HPS_CELL_BLOCK_W=4), which is not the default.
 static int expl_pad ()
 {
     static int pad = -1;
     if (pad < 0) {
-        pad = 8;
+        pad = 2;
         if (const char* e = std::getenv("HPS_EXPL_PAD")) { const int v = std::atoi(e); if (v == 2 || v == 8) pad = v; }
     }
     return pad;
@@ -116,6 +116,7 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         const Rec cur = rec[u];
         const uint64_t id = cur.id;
         if (!(id & HPS_ID_VALID)) continue;
+        if (k.can_ionize && cur.ion == 0) continue;      // a neutral atom deposits nothing (every term carries its level)
         const double psi_inv = 1.0/cur.psi;
         const double vx_c = cur.ux*psi_inv;
         const double vy_c = cur.uy*psi_inv;
@@ -204,7 +205,7 @@ __device__ __forceinline__ void load_region (double* img, const SlabView& f, con
     }
 }
 
-template <int ORDER, int DT, int TS, bool LASER = false, int PAD = 8>
+template <int ORDER, int DT, int TS, bool LASER = false, int PAD = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // 128 VGPRs: 4 workgroups per CU
 void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
                        int cBz, int cEz, int cExmBy, int cEypBx, int cSy, int cSx, PartConsts k, int* n_fallback)
@@ -245,6 +246,7 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
         const Rec cur = nxt;
         if (ip + 256 < pend) nxt = fetch(ip + 256);
         if (!(cur.id & HPS_ID_VALID)) continue;
+        if (k.can_ionize && cur.ion == 0) continue;      // a neutral atom deposits nothing (every term carries its level)
         const double psi_inv = 1.0/cur.psi;
         const double vx = cur.ux*psi_inv*k.c_inv;
         const double vy = cur.uy*psi_inv*k.c_inv;
@@ -326,10 +328,14 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
     }
 }
 
-template <int ORDER, int TS, bool LASER = false>
+// IONIZE: the species can be field-ionised (ADK, ionization.hip).  The decision needs exactly the fields the push gathers,
+// so it is taken here, between the gather and the push (the reference ionises, then pushes: Hipace.cpp:693-701): the ion's
+// level goes up, its electron is appended to the product species, and the push runs with the new charge.  A neutral
+// atom at rest is not pushed at all (zero charge: the push would leave every quantity as it is).
+template <int ORDER, int TS, bool LASER = false, bool IONIZE = false>
 __global__ __launch_bounds__(256)
 void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
-                      int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, int* n_fallback)
+                      int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, int* n_fallback, IonArgs ia)
 {
     constexpr int R = TS + 2*TILE_HALO;
     constexpr int NS = ORDER + 2;
@@ -406,6 +412,17 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             }
             F.Bxc *= k.c;
             F.Byc *= k.c;
+            if constexpr (IONIZE) {
+                if (isc == 0) {
+                    int lev = pl.ion_lev[ip];
+                    const double uxh = pl.ux_half[ip], uyh = pl.uy_half[ip];
+                    // an ion that has lost all Z electrons cannot ionise (the reference reads past the end of its tables)
+                    const bool ionize = lev < ia.Z && adk_decide(ia, F.ExmBy + F.Byc, F.EypBx - F.Bxc, F.Ez, uxh, uyh, pl.psi_half[ip], lev, id);
+                    if (ionize) { ++lev; pl.ion_lev[ip] = lev; qmc = k.a*(double)lev; }
+                    adk_emit(ia, ionize, pl.x[ip], pl.y[ip], xp, yp, pl.w[ip]);
+                    if (lev == 0 && uxh == 0.0 && uyh == 0.0) break;
+                }
+            }
             LaserFld Lf{0.0, 0.0, 0.0};
             if constexpr (LASER) {
                 // |a|^2 and its gradient from the slab (cached global reads), PlasmaParticleAdvance.cpp:121-131
@@ -448,6 +465,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         }
     }
     if (n_fallback && nfb) atomicAdd(n_fallback, nfb);
+    if constexpr (IONIZE) adk_post(ia);
 }
 
 template <class K>
@@ -527,7 +545,7 @@ int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hp
 
 int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], double charge,
                           double mass, int order, int temp_slice, int n_subcycles, int can_ionize, Tiling* T,
-                          int* n_fallback, hipStream_t st, int aabs_comp)
+                          int* n_fallback, hipStream_t st, int aabs_comp, const IonArgs* ion)
 {
     if (pl.n == 0) return HPS_OK;
     PartConsts k = base_consts(g);
@@ -537,14 +555,15 @@ int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_
     const int R = T->g.ts + 2*TILE_HALO;
     const size_t lds = (size_t)5*R*R*sizeof(double);
     SlabView f(slab);
-#define CALL(O, S) { if (aabs_comp >= 0) { if (int e = set_lds(k_advance_tiled<O, S, true>, lds)) return e; \
-        hipLaunchKernelGGL((k_advance_tiled<O, S, true>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
-                           comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback); } else { \
-        if (int e = set_lds(k_advance_tiled<O, S>, lds)) return e; \
-        hipLaunchKernelGGL((k_advance_tiled<O, S>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
-                           comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback); } }
+    const IonArgs ia = ion ? *ion : IonArgs{};
+#define HPS_ADV(O, S, L, I) { if (int e = set_lds(k_advance_tiled<O, S, L, I>, lds)) return e; \
+        hipLaunchKernelGGL((k_advance_tiled<O, S, L, I>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
+                           comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback, ia); }
+#define CALL(O, S) { if (ion) { if (aabs_comp >= 0) HPS_ADV(O, S, true, true) else HPS_ADV(O, S, false, true) } \
+                     else     { if (aabs_comp >= 0) HPS_ADV(O, S, true, false) else HPS_ADV(O, S, false, false) } }
     HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
 #undef CALL
+#undef HPS_ADV
     HPS_HIP_CHECK(hipGetLastError());
     return HPS_OK;
 }
@@ -609,5 +628,5 @@ extern "C" int hps_advance_plasma_tiled (hps_slab slab, hps_plasma pl, hps_geom 
     if (int e = check_stencil(slab, (order + 1)/2 + 1, "hps_advance_plasma_tiled")) return e;
     if (int e = check_tiling(tiling, slab, pl, "hps_advance_plasma_tiled")) return e;
     return advance_plasma_tiled(slab, pl, g, comp, charge, mass, order, temp_slice, n_subcycles, can_ionize,
-                                static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1);
+                                static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr);
 }

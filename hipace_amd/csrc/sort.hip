@@ -24,7 +24,7 @@
 namespace hps {
 
 #ifndef HPS_CELL_BLOCK_W
-#define HPS_CELL_BLOCK_W 4
+#define HPS_CELL_BLOCK_W 32     /* >= tile size: row by row.  4 (blocks of 4 x 8 cells) was measured: deposit 75.2 -> 73.9 us, explicit deposit 124.8 -> 133.4 us, 1222 -> 1211 slices/s */
 #endif
 #ifndef HPS_RANK_CAP
 #define HPS_RANK_CAP 16
@@ -33,10 +33,12 @@ constexpr int RANK_CAP = HPS_RANK_CAP;
 
 // Number of cell (x, y) inside its tile.  The particles of a tile are interleaved over its cells in this order, so 32
 // consecutive numbers are the cells the lanes of a half-wave work on at the same time, and their LDS words must fall
-// into 32 different bank pairs.  Row by row (bw = ts) a half-wave covers two rows of 16 cells: with the row pitches of
-// the LDS images (28, 30 doubles) the second row lands on the banks of the first (2-way conflicts on every access).
-// In blocks of bw = 4 cells across and 8 down, word = x + pitch*y with pitch = 28 or 36 = -4 or +4 (mod 32): 32
-// different bank pairs.
+// into 32 different bank pairs.  Row by row (bw = ts, the default) a half-wave covers two rows of 16 cells: with the row
+// pitches of the LDS images (28, 30 doubles) the second row lands on the banks of the first.  In blocks of bw = 4 cells
+// across and 8 down, word = x + pitch*y with pitch = 28 or 36 = -4 or +4 (mod 32) would be 32 different bank pairs for
+// a wave that starts on a block -- measured (HPS_CELL_BLOCK_W=4, HPS_EXPL_PAD=8) it is slower than row by row: behind the
+// driver the cells hold 0 .. 16 particles, the waves do not start on block boundaries, and the taller footprint of a
+// wave costs the explicit deposition more than the aligned case gains.
 __host__ __device__ __forceinline__ int cell_in_tile (int x, int y, int ts, int bw)
 {
     if (bw >= ts) return y*ts + x;

@@ -2060,7 +2060,7 @@ void orc_gather (orc_slab s, orc_geom g, const int* comp, int order, double xp, 
 void orc_tile_sort (orc_plasma p, orc_geom g, int nx, int ny, int ts, uint32_t* perm, int32_t* offsets)
 {
     // numbering of the cells inside a tile: blocks of bw x (32/bw) cells (sort.hip: cell_in_tile; HPS_CELL_BLOCK_W as there)
-    int bw = 4;
+    int bw = 32;
     if (const char* e = std::getenv("HPS_CELL_BLOCK_W")) { const int v = std::atoi(e); if (v == 4 || v == 8 || v == 16 || v == 32) bw = v; }
     if (bw > ts) bw = ts;
     auto cell_in_tile = [&] (int x, int y) {
