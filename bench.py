@@ -144,6 +144,8 @@ def main():
                     help="BASELINE config 5: laser_blowout_wake 1024x1024x2048, 4 ppc, a Gaussian laser pulse drives the wake "
                          "and is advanced by the envelope solver on every slice; the time levels of the envelope stay in HBM "
                          "(not the judged bench line)")
+    ap.add_argument("--fuse", action="store_true",
+                    help="fused schedule: the push of slice k also deposits the currents of slice k-1 (hps_engine_set_fusion)")
     ap.add_argument("--no-ionization", action="store_true", help="--config5 without the ionisable species")
     ap.add_argument("--config2", action="store_true",
                     help="BASELINE config 2 instead of the headline workload: linear_wake 256x256x512, 4 ppc, "
@@ -205,6 +207,9 @@ def main():
         lanes = max(1, min(args.inflight, args.steps // nz))      # whole boxes only
     engines = [eng] + [api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period)
                        for _ in range(lanes - 1)]
+    if args.fuse:
+        for e in engines:
+            e.set_fusion(True)
     short = args.steps < nz and lanes == 1
     stride = args.profile_stride if args.profile_stride > 0 else (1 if args.steps < 64 else 7)
     dev = torch.device("cuda", local)
@@ -356,7 +361,7 @@ def main():
             "timed_slices": ({"first": timed_first, "last": timed_first + args.steps - 1, "counted_from": "head of the box",
                               "pipeline_prefilled": world > 1} if short else
                              {"whole_boxes": max(1, args.steps // nz), "pipeline_prefilled": False}),
-            "steps_in_flight": lanes,
+            "steps_in_flight": lanes, "fused_push_deposit": bool(args.fuse),
             "phase_ms_per_slice": per_kernel,
             "profiled_slices": nprof,
             "vcycles_per_slice": (st1["vcycles"] - stats0.get("vcycles", 0)) / nsl,

@@ -331,6 +331,10 @@ class SliceEngine:
         check(_lib.lib().hps_engine_beam_state(self._h, bnd.ctypes.data_as(C.c_void_p), soa.ctypes.data_as(C.c_void_p) if nbeam else None))
         return bnd, soa[:, :nbeam].reshape(7, nbeam) if nbeam else soa[:, :0]
 
+    def set_fusion(self, on=True):
+        """Push of slice k and deposition of slice k-1 in one pass over the sheet (include/hpslice.h: hps_engine_set_fusion)."""
+        check(_lib.lib().hps_engine_set_fusion(self._h, int(on)))
+
     def fallbacks(self):
         n = C.c_long()
         check(_lib.lib().hps_engine_fallbacks(self._h, C.byref(n)))

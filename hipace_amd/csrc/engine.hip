@@ -20,6 +20,9 @@ int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hp
 int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], double charge,
                           double mass, int order, int temp_slice, int n_subcycles, int can_ionize, Tiling* T,
                           int* n_fallback, hipStream_t st, int aabs_comp = -1, const IonArgs* ion = nullptr);
+int advance_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], const int dep_comp[6],
+                           double charge, double mass, int order, int n_subcycles, double max_qsa, int* n_qsa, Tiling* T,
+                           int* n_fallback, hipStream_t st);
 
 static thread_local std::string g_err;
 void set_error (const std::string& msg) { g_err = msg; }
@@ -69,6 +72,28 @@ void k_shift_slices (double* p, long ns, long plane, int js, CellBox bb)
         p[HPS_C_JXB*ns + s] = njx;   p[HPS_C_JYB*ns + s] = njy;
     }
     p[HPS_C_JX*ns + s] = njx; p[HPS_C_JY*ns + s] = njy;
+}
+
+// ShiftSlices (fields/Fields.cpp:588-604) of this slice AND InitializeSlices (:535-586) of the next one in one pass: what
+// the fused push + deposition (k_advance_deposit_tiled) needs done before it deposits into the next slice's jx jy chi
+// rhomjz [rho].  Inside the beam's box also jz_beam and the Next beam currents are cleared.
+__global__ __launch_bounds__(256)
+void k_shift_zero (double* p, long ns, long plane, int js, CellBox bb, int c_rho)
+{
+    const long s = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (s >= plane) return;
+    const int j = (int)(s / js), i = (int)(s - (long)j*js);
+    double njx = 0.0, njy = 0.0;
+    if (i >= bb.ilo && i <= bb.ihi && j >= bb.jlo && j <= bb.jhi) {
+        const double tjx = p[HPS_C_JXB*ns + s], tjy = p[HPS_C_JYB*ns + s];
+        njx = p[HPS_C_N_JXB*ns + s]; njy = p[HPS_C_N_JYB*ns + s];
+        p[HPS_C_P_JXB*ns + s] = tjx; p[HPS_C_P_JYB*ns + s] = tjy;
+        p[HPS_C_JXB*ns + s] = njx;   p[HPS_C_JYB*ns + s] = njy;
+        p[HPS_C_N_JXB*ns + s] = 0.0; p[HPS_C_N_JYB*ns + s] = 0.0; p[HPS_C_JZB*ns + s] = 0.0;
+    }
+    p[HPS_C_JX*ns + s] = njx; p[HPS_C_JY*ns + s] = njy;
+    p[HPS_C_CHI*ns + s] = 0.0; p[HPS_C_RHOMJZ*ns + s] = 0.0;
+    if (c_rho >= 0) p[c_rho*ns + s] = 0.0;
 }
 
 // AddRhoIons (fields/Fields.cpp:606-615) fused with the Psi source  -rhomjz/ep0  (:887-888)
@@ -606,6 +631,7 @@ int Engine::begin_step ()
     if (d_insitu) HPS_HIP_CHECK(hipMemsetAsync(d_insitu, 0, (size_t)10*d.nz*sizeof(double), st));
     if (d_fd) HPS_HIP_CHECK(hipMemsetAsync(d_fd, 0, fd_comps.size()*(size_t)(d.nx/fd_c[0])*(d.ny/fd_c[1])*(d.nz/fd_c[2])*sizeof(double), st));
     ++step_index;
+    ahead_for = -1;
     if (int e = ionize_collect()) return e;
     np = np_init; pl.n = np; pl_alt.n = np;
     if (np > 0) {
@@ -1117,6 +1143,11 @@ int Engine::solve_slice (int islice)
         hipLaunchKernelGGL(k_insitu_plasma, dim3(256), b256, 0, st, pl, 1.0/gm.c, insitu_pl_radius*insitu_pl_radius, d_insitu_pl, d.nz, islice);
     // InitializeSlices (fields/Fields.cpp:535-586)
     const CellBox bb{beam_box.ilo, beam_box.ihi, beam_box.jlo, beam_box.jhi};
+    // the previous slice's fused push + deposition has already shifted / zeroed the slab and deposited this slice's
+    // plasma currents (k_shift_zero + k_advance_deposit_tiled)
+    const bool ahead = (ahead_for == islice);
+    ahead_for = -1;
+    if (!ahead)
     {   CompList z{0, {}}, zb{0, {}};
         // Sx, Sy are written as whole planes by k_sxsy_beam; ExmBy, EypBx by k_grad_psi up to the outermost
         // guard ring, which nothing ever writes (it keeps the zeros of begin_step); the beam planes only
@@ -1140,6 +1171,7 @@ int Engine::solve_slice (int islice)
                    (since_sort >= 1 && np - tiling->sorted_n > std::max(np/32, 16384L)))) { if ((e = resort())) return e; }
     ++since_sort;
     mark();   // b1b
+    if (!ahead)
     {   const int comp[6] = {HPS_C_JX, HPS_C_JY, -1, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_CHI, HPS_C_RHOMJZ};
         if ((e = species_deposit(pl, tiling, comp, d.plasma_charge, d.plasma_mass, 0))) return e;
         // MultiPlasma::DepositCurrent: every species in turn (MultiPlasma.cpp:78-87); an ion weighs in with its level
@@ -1225,14 +1257,25 @@ int Engine::solve_slice (int islice)
             }
             if ((e = ionize_collect())) return e;
         }
-        if ((e = species_advance(pl, tiling, comp, d.plasma_charge, d.plasma_mass, 0, 0))) return e; }
+        // push of this slice and deposition of the next one in one pass over the sheet (static beam, no laser, one
+        // plasma species, the whole sheet inside the tile-sorted body)
+        const bool fuse = fuse_push_deposit && tiling && islice > 0 && !moving && c_aabs < 0 && ion.n == 0 && np > 0 && tiling->sorted_n == np;
+        if (fuse) {
+            hipLaunchKernelGGL(k_shift_zero, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, bb, d.deposit_rho ? (int)HPS_C_RHO : -1);
+            const int dep[6] = {HPS_C_JX, HPS_C_JY, -1, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_CHI, HPS_C_RHOMJZ};
+            if ((e = advance_deposit_tiled(slab, pl, gm, comp, dep, d.plasma_charge, d.plasma_mass, d.order, d.n_subcycles, d.max_qsa, d_nqsa, tiling, d_nfallback, st))) return e;
+            ahead_for = islice - 1;
+        } else {
+            if ((e = species_advance(pl, tiling, comp, d.plasma_charge, d.plasma_mass, 0, 0))) return e;
+        } }
 
     // beam push and hand-off of the slipped particles (Hipace.cpp:704-706)
     insitu_beam(islice);
     if (moving && nbeam > 0) { if ((e = beam_push_moving(*this, islice))) return e; }
     mark();   // b8
     // ShiftSlices (fields/Fields.cpp:588-604)
-    hipLaunchKernelGGL(k_shift_slices, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, bb);
+    if (ahead_for != islice - 1)
+        hipLaunchKernelGGL(k_shift_slices, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, bb);
     mark();   // b9
     HPS_HIP_CHECK(hipGetLastError());
     ++slices_done;
@@ -1598,6 +1641,11 @@ extern "C" int hps_engine_set_tiling (void* h, int tile_size, int sort_period)
     HPS_REQUIRE(sort_period >= 1, "hps_engine_set_tiling: sort_period must be >= 1");
     HPS_REQUIRE(E->tiling == nullptr, "hps_engine_set_tiling: call before the first hps_engine_begin_step");
     E->tile_size = tile_size; E->sort_period = sort_period;
+    return HPS_OK;
+}
+extern "C" int hps_engine_set_fusion (void* h, int on)
+{
+    static_cast<Engine*>(h)->fuse_push_deposit = (on != 0);
     return HPS_OK;
 }
 extern "C" int hps_engine_fallbacks (void* h, long* n)

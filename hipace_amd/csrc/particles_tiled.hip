@@ -468,6 +468,182 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     if constexpr (IONIZE) adk_post(ia);
 }
 
+// Gather + push of slice k and the current deposition of slice k-1 in ONE pass over the sheet ("fused lower
+// bound": the deposition re-reads 56 B per particle that the push has just had in registers).  The workgroup keeps the
+// field image of its tile (as k_advance_tiled) AND the deposition accumulators (as k_deposit_tiled) in LDS; a particle
+// is pushed (PlasmaParticleAdvance.cpp:92-217) and its new state deposited at once into the components of the NEXT
+// slice (PlasmaDepositCurrent.cpp:155-246), which the engine has shifted / zeroed before the launch.  The QSA check of
+// the deposition invalidates the particle here, exactly as the stand-alone deposition at the start of the next slice
+// would.  No laser, no ionisable species (those keep the two kernels).
+template <int ORDER, int TS, int MASK>
+__global__ __launch_bounds__(256)
+void k_advance_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
+                              int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, DepComps cm, PartConsts kd,
+                              int* n_qsa, int* n_fallback)
+{
+    constexpr int R = TS + 2*TILE_HALO;
+    constexpr int NS = ORDER + 2;
+    extern __shared__ __attribute__((aligned(16))) double img[];     // [5][R*R] field image, then [active comps][R*R] accumulators
+    double* acc = img + 5*R*R;
+    const int gc[6] = {cm.jx, cm.jy, cm.jz, cm.rho, cm.chi, cm.rhomjz};
+    int slot[6]; int na = 0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { const bool on = (MASK >> c) & 1; slot[c] = on ? na++ : -1; }
+    const int tile = offsets[gridDim.x + 2 + blockIdx.x];     // launch order: heaviest tile first (sort.hip)
+    const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
+    const int tid = threadIdx.x;
+    const int cc[5] = {cPsi, cEz, cBx, cBy, cBz};
+    load_region<R>(img, f, cc, 5, ox, oy, tid);
+    {
+        double2* z = (double2*)acc;
+        for (int s = tid; s < na*R*R/2; s += 256) z[s] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+
+    const int pend = offsets[tile + 1];
+    int nfb = 0;
+    for (int ip = offsets[tile] + tid; ip < pend; ip += 256) {
+        const uint64_t id = pl.idcpu[ip];
+        if (!(id & HPS_ID_VALID)) continue;
+        const double qmc = k.a;
+        bool dead = false;
+        double xp = 0.0, yp = 0.0, ux = 0.0, uy = 0.0, psi = 1.0;
+        for (int isc = 0; isc < k.n_subcycles && !dead; ++isc) {
+            xp = pl.x_prev[ip];
+            yp = pl.y_prev[ip];
+            double sx[NS], dsx[NS], sy[NS], dsy[NS];
+            const int i0 = nodal_weights<ORDER>((xp - k.xoff)*k.dx_inv, sx, dsx);
+            const int j0 = nodal_weights<ORDER>((yp - k.yoff)*k.dy_inv, sy, dsy);
+            const int li = i0 - ox, lj = j0 - oy;
+            const bool local = (li >= 0 && li + NS <= R && lj >= 0 && lj + NS <= R);
+            if (!local) ++nfb;
+            Fld F{0, 0, 0, 0, 0, 0};
+            if (local) {
+                const double* b = img + lj*R + li;
+#pragma unroll 1
+                for (int iy = 0; iy < NS; ++iy) {
+                    double rp = 0.0, rd = 0.0, rez = 0.0, rbx = 0.0, rby = 0.0, rbz = 0.0;
+#pragma unroll
+                    for (int ix = 0; ix < NS; ++ix) {
+                        const int ls = iy*R + ix;
+                        const double psi_c = lds_get(b + ls);
+                        rp = fma(sx[ix], psi_c, rp);
+                        rd = fma(dsx[ix], psi_c, rd);
+                        rez = fma(sx[ix], lds_get(b + R*R + ls), rez);
+                        rbx = fma(sx[ix], lds_get(b + 2*R*R + ls), rbx);
+                        rby = fma(sx[ix], lds_get(b + 3*R*R + ls), rby);
+                        rbz = fma(sx[ix], lds_get(b + 4*R*R + ls), rbz);
+                    }
+                    F.ExmBy = fma(sy[iy], rd, F.ExmBy);
+                    F.EypBx = fma(dsy[iy], rp, F.EypBx);
+                    F.Ez  = fma(sy[iy], rez, F.Ez);
+                    F.Bxc = fma(sy[iy], rbx, F.Bxc);
+                    F.Byc = fma(sy[iy], rby, F.Byc);
+                    F.Bz  = fma(sy[iy], rbz, F.Bz);
+                }
+                F.ExmBy *= k.dx_inv;
+                F.EypBx *= k.dy_inv;
+            } else {
+#pragma unroll 1
+                for (int iy = 0; iy < NS; ++iy) {
+#pragma unroll
+                    for (int ix = 0; ix < NS; ++ix) {
+                        const double* p = f.p + f.off(i0 + ix, j0 + iy);
+                        const double psi_c = p[cPsi*f.ns];
+                        const double ss = sx[ix]*sy[iy];
+                        F.ExmBy += (dsx[ix]*sy[iy])*psi_c*k.dx_inv;
+                        F.EypBx += (sx[ix]*dsy[iy])*psi_c*k.dy_inv;
+                        F.Ez  += ss*p[cEz*f.ns];
+                        F.Bxc += ss*p[cBx*f.ns];
+                        F.Byc += ss*p[cBy*f.ns];
+                        F.Bz  += ss*p[cBz*f.ns];
+                    }
+                }
+            }
+            F.Bxc *= k.c;
+            F.Byc *= k.c;
+            const double dz = k.dz, sdz = dz*0.25;
+            ux = pl.ux_half[ip]; uy = pl.uy_half[ip]; psi = pl.psi_half[ip];
+#pragma unroll 1
+            for (int s = 0; s < 4; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
+            const double pinv = 1.0/psi;
+            xp += dz*k.c_inv*(ux*pinv);
+            yp += dz*k.c_inv*(uy*pinv);
+            if (apply_particle_bc(k, xp, yp, ux, uy)) {
+                pl.w[ip] = 0.0;
+                pl.idcpu[ip] = id & ~HPS_ID_VALID;
+                dead = true;
+                break;
+            }
+            pl.x[ip] = xp; pl.y[ip] = yp;
+            pl.ux_half[ip] = ux; pl.uy_half[ip] = uy; pl.psi_half[ip] = psi;
+            if (pl.x_prev != pl.x) pl.x_prev[ip] = xp;      // (aliased by the engine: already stored)
+            if (pl.y_prev != pl.y) pl.y_prev[ip] = yp;
+#pragma unroll 1
+            for (int s = 0; s < 2; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
+            pl.ux[ip] = ux; pl.uy[ip] = uy; pl.psi[ip] = psi;
+        }
+        if (dead) continue;
+        // ---- DepositCurrent of the pushed particle into the next slice (same arithmetic as k_deposit_tiled) ----
+        const double w = pl.w[ip];
+        const double psi_inv = 1.0/psi;
+        const double vx_c = ux*psi_inv;
+        const double vy_c = uy*psi_inv;
+        const double q_invvol = kd.a*w;
+        const double gamma_psi = 0.5*(psi_inv*psi_inv + vx_c*vx_c*kd.c_inv*kd.c_inv + vy_c*vy_c*kd.c_inv*kd.c_inv + 1.0);
+        if (gamma_psi < 0.0 || gamma_psi > kd.max_qsa || psi_inv < 0.0) {
+            if (n_qsa) atomicAdd(n_qsa, 1);
+            pl.w[ip] = 0.0;
+            pl.idcpu[ip] = id & ~HPS_ID_VALID;
+            continue;
+        }
+        double wx[ORDER + 1], wy[ORDER + 1];
+        const int i0 = shape_weights<ORDER>((xp - kd.xoff)*kd.dx_inv, wx);
+        const int j0 = shape_weights<ORDER>((yp - kd.yoff)*kd.dy_inv, wy);
+        const double wv[6] = {vx_c, vy_c, (gamma_psi - 1.0)*kd.c, gamma_psi, kd.b*psi_inv, 1.0};
+        const int li = i0 - ox, lj = j0 - oy;
+        if (li >= 0 && li + ORDER < R && lj >= 0 && lj + ORDER < R) {
+#pragma unroll
+            for (int iy = 0; iy <= ORDER; ++iy) {
+#pragma unroll
+                for (int ix = 0; ix <= ORDER; ++ix) {
+                    const double cd = q_invvol*wx[ix]*wy[iy];
+                    double* p = acc + (lj + iy)*R + li + ix;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) if (slot[c] >= 0) lds_add(p + slot[c]*R*R, cd*wv[c]);
+                }
+            }
+        } else {
+            ++nfb;
+#pragma unroll
+            for (int iy = 0; iy <= ORDER; ++iy) {
+#pragma unroll
+                for (int ix = 0; ix <= ORDER; ++ix) {
+                    const double cd = q_invvol*wx[ix]*wy[iy];
+                    double* p = f.p + f.off(i0 + ix, j0 + iy);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) if (slot[c] >= 0) atomic_add_f64(p + gc[c]*f.ns, cd*wv[c]);
+                }
+            }
+        }
+    }
+    if (n_fallback && nfb) atomicAdd(n_fallback, nfb);
+    __syncthreads();
+    for (int s = tid; s < R*R; s += 256) {
+        const int lj = s / R, li = s - lj*R;
+        const int i = ox + li, j = oy + lj;
+        if (i < -f.ng || i >= f.nx + f.ng || j < -f.ng || j >= f.ny + f.ng) continue;
+        double* p = f.p + f.off(i, j);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            if (slot[c] >= 0) {
+                const double v = acc[slot[c]*R*R + s];
+                if (v != 0.0) atomic_add_f64(p + gc[c]*f.ns, v);
+            }
+        }
+    }
+}
+
 template <class K>
 static int set_lds (K kernel, size_t bytes)
 {
@@ -564,6 +740,33 @@ int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_
     HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
 #undef CALL
 #undef HPS_ADV
+    HPS_HIP_CHECK(hipGetLastError());
+    return HPS_OK;
+}
+
+// push of this slice + deposition into the next one (k_advance_deposit_tiled); dep_comp as DepositCurrent's comp[6]
+int advance_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], const int dep_comp[6],
+                           double charge, double mass, int order, int n_subcycles, double max_qsa, int* n_qsa, Tiling* T,
+                           int* n_fallback, hipStream_t st)
+{
+    if (pl.n == 0) return HPS_OK;
+    PartConsts k = base_consts(g);
+    k.a = charge/(mass*g.c); k.dz = g.dz/n_subcycles; k.temp_slice = 0; k.n_subcycles = n_subcycles; k.can_ionize = 0;
+    PartConsts kd = base_consts(g);
+    kd.a = charge*invvol_of(g); kd.b = charge*g.mu0/mass; kd.max_qsa = max_qsa; kd.can_ionize = 0;
+    DepComps cm{dep_comp[0], dep_comp[1], dep_comp[2], dep_comp[3], dep_comp[4], dep_comp[5]};
+    int mask = 0, na = 0; for (int c = 0; c < 6; ++c) { mask |= (dep_comp[c] >= 0) << c; na += dep_comp[c] >= 0; }
+    if (mask != 51 && mask != 59) { set_error("advance_deposit_tiled: deposits jx jy chi rhomjz [rho] only"); return HPS_ERR_UNSUPPORTED; }
+    const int R = T->g.ts + 2*TILE_HALO;
+    const size_t lds = (size_t)(5 + na)*R*R*sizeof(double);
+    SlabView f(slab);
+#define HPS_AD(O, S, M) { if (int e = set_lds(k_advance_deposit_tiled<O, S, M>, lds)) return e; \
+        hipLaunchKernelGGL((k_advance_deposit_tiled<O, S, M>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
+                           comp[0], comp[1], comp[2], comp[3], comp[4], k, cm, kd, n_qsa, n_fallback); }
+#define CALL(O, S) { if (mask == 51) HPS_AD(O, S, 51) else HPS_AD(O, S, 59) }
+    HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
+#undef CALL
+#undef HPS_AD
     HPS_HIP_CHECK(hipGetLastError());
     return HPS_OK;
 }

@@ -319,6 +319,11 @@ int hps_engine_insitu_plasma (void* handle, double* out_host /* [15*nz] */);
  * Call before hps_engine_begin_step. */
 int hps_engine_set_tiling (void* handle, int tile_size, int sort_period);
 int hps_engine_fallbacks (void* handle, long* n_fallback_host);
+/* Fused schedule: the gather + push of slice k also deposits the pushed particles' currents into slice k-1 (one pass over
+ * the sheet instead of two; the slab is shifted / cleared before it).  After hps_engine_solve_slice(k) the components jx,
+ * jy, chi, rhomjz [, rho] then already belong to slice k-1; everything else, the per-slice checksums and diagnostics are
+ * unchanged.  Applies to the explicit solver with a static beam, no laser and one plasma species; off by default. */
+int hps_engine_set_fusion (void* handle, int on);
 /* number of particle re-sorts so far (periodic + adaptive: the sheet is re-sorted after sort_period slices at the
    latest, earlier once more than 1/256 of it has left the halo of its tile) */
 int hps_engine_sorts (void* handle, long* n_sorts_host);

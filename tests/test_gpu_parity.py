@@ -1262,3 +1262,45 @@ def test_ionization_refusals(api):
     decks.with_ion_species(norm, "H", 1.0)
     with pytest.raises(RuntimeError):
         api.SliceEngine(norm)                                            # normalised units need background_density_SI
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ts,rho", [(16, 0), (32, 0), (16, 1)])
+def test_fused_push_and_deposit_schedule(api, ts, rho):
+    """hps_engine_set_fusion: the push of slice k deposits the currents of slice k-1 in the same pass over the sheet.  The
+    per-slice checksums (taken when all components of a slice are final) reproduce the reference's fixture exactly as the
+    two-kernel schedule does, every slab component that does not belong to the next slice yet equals the two-kernel
+    schedule's after each slice, and so does the particle sheet."""
+    gold = json.load(open(os.path.join(GOLD, "blowout_wake_explicit.2Rank.json")))["lev=0"]
+    deck = decks.blowout_wake()
+    deck.update(deposit_rho=rho)
+    a = api.SliceEngine(deck, tile_size=ts, sort_period=7)
+    b = api.SliceEngine(deck, tile_size=ts, sort_period=7)
+    b.set_fusion(True)
+    for e in (a, b):
+        e.set_diagnostics(True)
+        e.begin_step()
+    nz = deck["nz"]
+    names = a.comp_names()
+    ahead = {"jx", "jy", "chi", "rhomjz", "rho", "jx_beam", "jy_beam", "jz_beam", "N_jx_beam", "N_jy_beam", "P_jx_beam", "P_jy_beam"}
+    for k in range(nz - 1, -1, -1):
+        a.solve_slice(k)
+        b.solve_slice(k)
+        if k % 9 == 0 or k < 3:
+            sa, sb = a.slab(), b.slab()
+            for c, nm in enumerate(names):
+                if nm in ahead and k > 0:
+                    continue
+                sc = max(np.abs(sa[c]).max(), 1e-300)
+                assert np.abs(sa[c] - sb[c]).max() <= 1e-10 * sc, (k, nm)
+            ra, va = a.particles()
+            rb, vb = b.particles()
+            assert np.array_equal(va, vb)
+            for q in range(11):
+                assert np.abs(ra[q] - rb[q]).max() <= 1e-10 * max(np.abs(ra[q]).max(), 1e-300), (k, q)
+    ca, cb = a.checksums(), b.checksums()
+    for nm, v in gold.items():
+        if v != 0.0:
+            assert abs(cb[nm] - v) <= 1e-9 * abs(v), (nm, cb[nm], v)
+    for nm, v in ca.items():
+        assert abs(cb[nm] - v) <= 1e-10 * max(abs(v), 1e-300), (nm, cb[nm], v)
