@@ -142,6 +142,7 @@ _SIGS = {
     "hps_engine_set_tiling": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "hps_engine_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
     "hps_engine_set_fusion": (C.c_int, [C.c_void_p, C.c_int]),
+    "hps_engine_set_density_profile": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hps_engine_sorts": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
     "hps_engine_assume_initial_beam_support": (C.c_int, [C.c_void_p]),
     "hps_engine_beam_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

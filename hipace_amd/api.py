@@ -331,6 +331,13 @@ class SliceEngine:
         check(_lib.lib().hps_engine_beam_state(self._h, bnd.ctypes.data_as(C.c_void_p), soa.ctypes.data_as(C.c_void_p) if nbeam else None))
         return bnd, soa[:, :nbeam].reshape(7, nbeam) if nbeam else soa[:, :0]
 
+    def set_density_profile(self, r=(), fr=(), ct=(), ft=()):
+        """n(x, y, ct) = density * f_r(r) * f_t(c t): piecewise-linear tables (hps_engine_set_density_profile)."""
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (r, fr, ct, ft)]
+        assert len(a[0]) == len(a[1]) and len(a[2]) == len(a[3])
+        p = [x.ctypes.data_as(C.c_void_p) if len(x) else None for x in a]
+        check(_lib.lib().hps_engine_set_density_profile(self._h, len(a[0]), p[0], p[1], len(a[2]), p[2], p[3]))
+
     def set_fusion(self, on=True):
         """Push of slice k and deposition of slice k-1 in one pass over the sheet (include/hpslice.h: hps_engine_set_fusion)."""
         check(_lib.lib().hps_engine_set_fusion(self._h, int(on)))

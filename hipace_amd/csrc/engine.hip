@@ -250,11 +250,26 @@ void k_checksum (SlabView f, int ncomp, double* acc)
     (void)ncomp;
 }
 
+// piecewise-linear table, constant beyond its ends; n = 0: the factor is 1
+__host__ __device__ inline double table_value (const double* x, const double* f, int n, double v)
+{
+    if (n <= 0) return 1.0;
+    if (v <= x[0]) return f[0];
+    if (v >= x[n - 1]) return f[n - 1];
+    int k = 1;
+    while (x[k] < v) ++k;
+    const double t = (v - x[k - 1])/(x[k] - x[k - 1]);
+    return f[k - 1] + t*(f[k] - f[k - 1]);
+}
+
+// weight = density(x, y, c t) * scale_fac (PlasmaParticleContainerInit.cpp:246-313) with the tabulated profile
+// density * f_r(r) * f_t: prof = [r[nr] | f_r[nr]] on the device, ft the time factor of this step; a lattice point
+// whose density is <= 0 holds no particle (the reference does not create it: here its slot is invalid)
 // plasma sheet on the fixed-ppc lattice, ppc index outermost so that consecutive lanes own
 // consecutive cells (PlasmaParticleContainerInit.cpp:192-313, ParticleUtil.H:72-83)
 __global__ __launch_bounds__(256)
 void k_init_plasma (hps_plasma pl, long n, int nx, int ny, int ppcx, int ppcy, double lox, double loy, double dx, double dy,
-                    double weight, int level, int keyed)
+                    double weight, int level, int keyed, const double* __restrict__ prof, int nr, double ft)
 {
     const long k = (long)blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -265,13 +280,14 @@ void k_init_plasma (hps_plasma pl, long n, int nx, int ny, int ppcx, int ppcy, d
     const int ixp = ip % ppcx, iyp = ip / ppcx;
     const double x = lox + (i + (0.5 + ixp)/ppcx)*dx;
     const double y = loy + (j + (0.5 + iyp)/ppcy)*dy;
-    pl.x[k] = x; pl.y[k] = y; pl.w[k] = weight;
+    const double fac = ft*table_value(prof, prof + nr, nr, sqrt(x*x + y*y));
+    pl.x[k] = x; pl.y[k] = y; pl.w[k] = fac > 0.0 ? weight*fac : 0.0;
     pl.ux[k] = 0.0; pl.uy[k] = 0.0; pl.psi[k] = 1.0;
     pl.x_prev[k] = x; pl.y_prev[k] = y;
     pl.ux_half[k] = 0.0; pl.uy_half[k] = 0.0; pl.psi_half[k] = 1.0;
     // id = 1, cpu (level) = 0.  A species that can ionise carries its lattice index + 1 in the id bits: the key of its
     // random draws (ionization.hip); the reference only ever reads the sign of the id
-    pl.idcpu[k] = HPS_ID_VALID | ((keyed ? (unsigned long long)(k + 1) : 1ULL) << 24);
+    pl.idcpu[k] = (fac > 0.0 ? HPS_ID_VALID : 0ULL) | ((keyed ? (unsigned long long)(k + 1) : 1ULL) << 24);
     pl.ion_lev[k] = level;
 }
 
@@ -355,6 +371,7 @@ Engine::~Engine ()
     (void)hipFree(d_laser_sum);
     if (laser) laser_destroy(*this);
     ion_destroy(*this);
+    (void)hipFree(d_prof_r);
     (void)hipFree(d_fd); (void)hipFree(d_fd_comps); (void)hipFree(d_insitu); (void)hipFree(d_insitu_pl); (void)hipFree(d_insitu_bm);
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto e : hand_ev) if (e) (void)hipEventDestroy(e);
@@ -631,14 +648,17 @@ int Engine::begin_step ()
     if (d_insitu) HPS_HIP_CHECK(hipMemsetAsync(d_insitu, 0, (size_t)10*d.nz*sizeof(double), st));
     if (d_fd) HPS_HIP_CHECK(hipMemsetAsync(d_fd, 0, fd_comps.size()*(size_t)(d.nx/fd_c[0])*(d.ny/fd_c[1])*(d.nz/fd_c[2])*sizeof(double), st));
     ++step_index;
-    ahead_for = -1;
+    ahead_for = -2;
+    // time factor of the density profile at z = c t of this step (UpdateDensityFunction, PlasmaParticleContainer.cpp:211-217)
+    prof_ft = table_value(prof_t.data(), prof_f_t.data(), (int)prof_t.size(), gm.c*d.dt*step_index);
     if (int e = ionize_collect()) return e;
     np = np_init; pl.n = np; pl_alt.n = np;
     if (np > 0) {
         const int nppc = d.plasma_ppc[0]*d.plasma_ppc[1];
         hipLaunchKernelGGL(k_init_plasma, dim3(ceil_div(np, 256)), dim3(256), 0, st, pl, np, d.nx, d.ny,
                            d.plasma_ppc[0], d.plasma_ppc[1], d.lo[0], d.lo[1], gm.dx, gm.dy,
-                           d.plasma_density*(d.si_units ? gm.dx*gm.dy*gm.dz/nppc : 1.0/nppc), 0, 0);     // scale_fac, PlasmaParticleContainerInit.cpp:40-41
+                           d.plasma_density*(d.si_units ? gm.dx*gm.dy*gm.dz/nppc : 1.0/nppc), 0, 0,     // scale_fac, PlasmaParticleContainerInit.cpp:40-41
+                           d_prof_r, (int)prof_r.size(), prof_ft);
     }
     if (tiling) { if (int e = resort()) return e; }
     if (np > 0 && !d.plasma_no_neutralize) {
@@ -656,7 +676,8 @@ int Engine::begin_step ()
         const int inppc = d.ion_ppc[0]*d.ion_ppc[1];
         hipLaunchKernelGGL(k_init_plasma, dim3(ceil_div(ion.n, 256)), dim3(256), 0, st, ion.pl, ion.n, d.nx, d.ny,
                            d.ion_ppc[0], d.ion_ppc[1], d.lo[0], d.lo[1], gm.dx, gm.dy,
-                           d.ion_density*(d.si_units ? gm.dx*gm.dy*gm.dz/inppc : 1.0/inppc), d.ion_init_level, 1);
+                           d.ion_density*(d.si_units ? gm.dx*gm.dy*gm.dz/inppc : 1.0/inppc), d.ion_init_level, 1,
+                           d_prof_r, (int)prof_r.size(), prof_ft);
         if (ion.tiling) {
             ion.pl_alt.n = ion.n;
             if (int e = tiling_sort(ion.tiling, ion.pl, ion.pl_alt, gm, st)) return e;
@@ -1146,7 +1167,7 @@ int Engine::solve_slice (int islice)
     // the previous slice's fused push + deposition has already shifted / zeroed the slab and deposited this slice's
     // plasma currents (k_shift_zero + k_advance_deposit_tiled)
     const bool ahead = (ahead_for == islice);
-    ahead_for = -1;
+    ahead_for = -2;
     if (!ahead)
     {   CompList z{0, {}}, zb{0, {}};
         // Sx, Sy are written as whole planes by k_sxsy_beam; ExmBy, EypBx by k_grad_psi up to the outermost
@@ -1641,6 +1662,25 @@ extern "C" int hps_engine_set_tiling (void* h, int tile_size, int sort_period)
     HPS_REQUIRE(sort_period >= 1, "hps_engine_set_tiling: sort_period must be >= 1");
     HPS_REQUIRE(E->tiling == nullptr, "hps_engine_set_tiling: call before the first hps_engine_begin_step");
     E->tile_size = tile_size; E->sort_period = sort_period;
+    return HPS_OK;
+}
+extern "C" int hps_engine_set_density_profile (void* h, int nr, const double* r_host, const double* fr_host, int nt, const double* ct_host,
+                                              const double* ft_host)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(nr >= 0 && nt >= 0 && (nr == 0 || (r_host && fr_host)) && (nt == 0 || (ct_host && ft_host)), "hps_engine_set_density_profile: bad argument");
+    for (int k = 1; k < nr; ++k) HPS_REQUIRE(r_host[k] > r_host[k - 1], "hps_engine_set_density_profile: r must increase");
+    for (int k = 1; k < nt; ++k) HPS_REQUIRE(ct_host[k] > ct_host[k - 1], "hps_engine_set_density_profile: ct must increase");
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    (void)hipFree(E->d_prof_r); E->d_prof_r = nullptr;
+    E->prof_r.assign(r_host, r_host + nr);
+    E->prof_t.assign(ct_host, ct_host + nt); E->prof_f_t.assign(ft_host, ft_host + nt);
+    if (nr > 0) {
+        std::vector<double> both(r_host, r_host + nr);
+        both.insert(both.end(), fr_host, fr_host + nr);
+        HPS_HIP_CHECK(hipMalloc(&E->d_prof_r, both.size()*sizeof(double)));
+        HPS_HIP_CHECK(hipMemcpy(E->d_prof_r, both.data(), both.size()*sizeof(double), hipMemcpyHostToDevice));
+    }
     return HPS_OK;
 }
 extern "C" int hps_engine_set_fusion (void* h, int on)

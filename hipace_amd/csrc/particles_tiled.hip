@@ -193,10 +193,10 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
 }
 
 // image of `nc` slab components over the tile region into LDS (0 outside the slab box)
-template <int R, int RP = R>
+template <int R, int RP = R, int NT = 256>
 __device__ __forceinline__ void load_region (double* img, const SlabView& f, const int* comps, int nc, int ox, int oy, int tid)
 {
-    for (int s = tid; s < R*R; s += 256) {
+    for (int s = tid; s < R*R; s += NT) {
         const int lj = s / R, li = s - lj*R;
         const int i = ox + li, j = oy + lj;
         const bool in = (i >= -f.ng && i < f.nx + f.ng && j >= -f.ng && j < f.ny + f.ng);
@@ -475,8 +475,8 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
 // slice (PlasmaDepositCurrent.cpp:155-246), which the engine has shifted / zeroed before the launch.  The QSA check of
 // the deposition invalidates the particle here, exactly as the stand-alone deposition at the start of the next slice
 // would.  No laser, no ionisable species (those keep the two kernels).
-template <int ORDER, int TS, int MASK>
-__global__ __launch_bounds__(256)
+template <int ORDER, int TS, int MASK, int NT>
+__global__ __launch_bounds__(NT)
 void k_advance_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
                               int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, DepComps cm, PartConsts kd,
                               int* n_qsa, int* n_fallback)
@@ -493,16 +493,16 @@ void k_advance_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__
     const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
     const int tid = threadIdx.x;
     const int cc[5] = {cPsi, cEz, cBx, cBy, cBz};
-    load_region<R>(img, f, cc, 5, ox, oy, tid);
+    load_region<R, R, NT>(img, f, cc, 5, ox, oy, tid);
     {
         double2* z = (double2*)acc;
-        for (int s = tid; s < na*R*R/2; s += 256) z[s] = make_double2(0.0, 0.0);
+        for (int s = tid; s < na*R*R/2; s += NT) z[s] = make_double2(0.0, 0.0);
     }
     __syncthreads();
 
     const int pend = offsets[tile + 1];
     int nfb = 0;
-    for (int ip = offsets[tile] + tid; ip < pend; ip += 256) {
+    for (int ip = offsets[tile] + tid; ip < pend; ip += NT) {
         const uint64_t id = pl.idcpu[ip];
         if (!(id & HPS_ID_VALID)) continue;
         const double qmc = k.a;
@@ -629,7 +629,7 @@ void k_advance_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__
     }
     if (n_fallback && nfb) atomicAdd(n_fallback, nfb);
     __syncthreads();
-    for (int s = tid; s < R*R; s += 256) {
+    for (int s = tid; s < R*R; s += NT) {
         const int lj = s / R, li = s - lj*R;
         const int i = ox + li, j = oy + lj;
         if (i < -f.ng || i >= f.nx + f.ng || j < -f.ng || j >= f.ny + f.ng) continue;
@@ -760,10 +760,13 @@ int advance_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
     const int R = T->g.ts + 2*TILE_HALO;
     const size_t lds = (size_t)(5 + na)*R*R*sizeof(double);
     SlabView f(slab);
-#define HPS_AD(O, S, M) { if (int e = set_lds(k_advance_deposit_tiled<O, S, M>, lds)) return e; \
-        hipLaunchKernelGGL((k_advance_deposit_tiled<O, S, M>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
+    static int nt = 0;
+    if (nt == 0) { nt = 512; if (const char* e = std::getenv("HPS_FUSED_THREADS")) { const int v = std::atoi(e); if (v == 256 || v == 512) nt = v; } }
+#define HPS_AD(O, S, M, N) { if (int e = set_lds(k_advance_deposit_tiled<O, S, M, N>, lds)) return e; \
+        hipLaunchKernelGGL((k_advance_deposit_tiled<O, S, M, N>), dim3(T->g.ntiles), dim3(N), lds, st, f, pl, T->offsets, T->g.ntx, \
                            comp[0], comp[1], comp[2], comp[3], comp[4], k, cm, kd, n_qsa, n_fallback); }
-#define CALL(O, S) { if (mask == 51) HPS_AD(O, S, 51) else HPS_AD(O, S, 59) }
+#define CALL(O, S) { if (nt == 512) { if (mask == 51) HPS_AD(O, S, 51, 512) else HPS_AD(O, S, 59, 512) } \
+                     else           { if (mask == 51) HPS_AD(O, S, 51, 256) else HPS_AD(O, S, 59, 256) } }
     HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
 #undef CALL
 #undef HPS_AD

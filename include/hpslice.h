@@ -319,6 +319,14 @@ int hps_engine_insitu_plasma (void* handle, double* out_host /* [15*nz] */);
  * Call before hps_engine_begin_step. */
 int hps_engine_set_tiling (void* handle, int tile_size, int sort_period);
 int hps_engine_fallbacks (void* handle, long* n_fallback_host);
+/* Plasma density profile (InitParticles evaluates <plasma>.density(x,y,z) per particle with z = c t,
+ * PlasmaParticleContainerInit.cpp:246-313; UpdateDensityFunction / density_table_file, PlasmaParticleContainer.cpp:98-117,
+ * 211-217).  The input parser is out of scope; the profile is tabulated: n(x, y, ct) = <species>.density * f_r(sqrt(x^2 +
+ * y^2)) * f_t(c t), both piecewise linear (constant beyond the ends of a table; n = 0 entries: factor 1), t = hipace.dt *
+ * step.  Plasma channels and density ramps are of this form.  A lattice point whose density is <= 0 carries no particle
+ * (min_density = 0).  Applies to every plasma species from the next hps_engine_begin_step on. */
+int hps_engine_set_density_profile (void* handle, int nr, const double* r_host, const double* fr_host, int nt,
+                                    const double* ct_host, const double* ft_host);
 /* Fused schedule: the gather + push of slice k also deposits the pushed particles' currents into slice k-1 (one pass over
  * the sheet instead of two; the slab is shifted / cleared before it).  After hps_engine_solve_slice(k) the components jx,
  * jy, chi, rhomjz [, rho] then already belong to slice k-1; everything else, the per-slice checksums and diagnostics are

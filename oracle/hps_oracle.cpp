@@ -1088,6 +1088,22 @@ struct Engine {
     std::vector<double> idata; std::vector<int32_t> ivalid, ilev; std::vector<uint64_t> iuid; Plasma ipl;      // species "ion"
     std::vector<double> adk_prefactor, adk_exp_prefactor, adk_power;
     long n_ionized_total = 0; int cur_step = -1;
+    // plasma density profile n(x, y, ct) = density * f_r(sqrt(x^2 + y^2)) * f_t(c t), both piecewise linear tables (constant
+    // beyond their ends); the tabulated stand-in of <plasma>.density(x,y,z) (PlasmaParticleContainerInit.cpp:246-313: the
+    // function is evaluated per particle with z = c t; particles with density <= min_density = 0 are not created)
+    std::vector<double> prof_r, prof_fr, prof_t, prof_ft;
+    static double table (const std::vector<double>& x, const std::vector<double>& f, double v) {
+        if (x.empty()) return 1.0;
+        if (v <= x.front()) return f.front();
+        if (v >= x.back()) return f.back();
+        size_t k = 1;
+        while (x[k] < v) ++k;
+        const double t = (v - x[k-1])/(x[k] - x[k-1]);
+        return f[k-1] + t*(f[k] - f[k-1]);
+    }
+    double profile (double x, double y) const {
+        return table(prof_r, prof_fr, std::sqrt(x*x + y*y))*table(prof_t, prof_ft, gm.c*d.dt*std::max(cur_step, 0));
+    }
     PoissonSolver* ps; MG* mg; std::vector<double> staging;
     Beam beam_this, beam_next; int beam_this_slice = -2;      // slice whose particles beam_this holds
     // dt != 0: the beam lives in per-slice stores across the time steps (index = islice)
@@ -1142,7 +1158,7 @@ struct Engine {
     // PlasmaParticleContainer::InitParticles (plasma/PlasmaParticleContainerInit.cpp:17-378),
     // fixed ppc, uniform density, no fine patch, u = 0; ppc index outermost (:192)
     // positions of the fixed-ppc lattice of one species (ppc index outermost, :192)
-    void lattice (const int ppc[2], double density, std::vector<double>& xs, std::vector<double>& ys) const {
+    void lattice (const int ppc[2], double density, std::vector<double>& xs, std::vector<double>& ys, std::vector<uint64_t>* slot = nullptr) const {
         const int nppc = ppc[0]*ppc[1];
         const double rad = d.plasma_radius > 0 ? d.plasma_radius : std::numeric_limits<double>::infinity();
         for (int ip = 0; ip < nppc; ++ip) {
@@ -1153,14 +1169,15 @@ struct Engine {
                 const double y = d.lo[1] + (j + r1)*gm.dy;
                 const double rsq = x*x + y*y;
                 if (x >= gm.phi[0] || x < gm.plo[0] || y >= gm.phi[1] || y < gm.plo[1] ||
-                    rsq > rad*rad || density <= 0.0) continue;
+                    rsq > rad*rad || density*profile(x, y) <= 0.0) continue;
                 xs.push_back(x); ys.push_back(y);
+                if (slot) slot->push_back((uint64_t)ip*d.nx*d.ny + (uint64_t)j*d.nx + i);     // lattice point: the generator's key
             }
         }
     }
-    static void fill_species (Plasma& p, const std::vector<double>& xs, const std::vector<double>& ys, double w, int lev) {
+    void fill_species (Plasma& p, const std::vector<double>& xs, const std::vector<double>& ys, double w, int lev) const {
         for (long k = 0; k < (long)xs.size(); ++k) {
-            p.x[k] = xs[k]; p.y[k] = ys[k]; p.w[k] = w;
+            p.x[k] = xs[k]; p.y[k] = ys[k]; p.w[k] = w*profile(xs[k], ys[k]);
             p.ux[k] = 0; p.uy[k] = 0; p.psi[k] = std::sqrt(1.0) - 0.0;
             p.x_prev[k] = xs[k]; p.y_prev[k] = ys[k];
             p.ux_half[k] = 0; p.uy_half[k] = 0; p.psi_half[k] = p.psi[k];
@@ -1178,8 +1195,8 @@ struct Engine {
         lattice(d.plasma_ppc, d.plasma_density, xs, ys);
         const long n = (long)xs.size();
         // species "ion": every ion can release Z - initial level electrons into the first species
-        std::vector<double> ixs, iys;
-        if (d.ion_on) lattice(d.ion_ppc, d.ion_density, ixs, iys);
+        std::vector<double> ixs, iys; std::vector<uint64_t> islot;
+        if (d.ion_on) lattice(d.ion_ppc, d.ion_density, ixs, iys, &islot);
         const long ni = (long)ixs.size();
         const long cap = n + ni*std::max(d.ion_Z - d.ion_init_level, 0);
         if (cap != pl_cap || pdata.empty()) {
@@ -1200,7 +1217,7 @@ struct Engine {
             const long m = std::max(ni, 1L);
             ipl = Plasma{q, q+m, q+2*m, q+3*m, q+4*m, q+5*m, q+6*m, q+7*m, q+8*m, q+9*m, q+10*m, ivalid.data(), ilev.data(), ni};
             fill_species(ipl, ixs, iys, d.ion_density*iscale, d.ion_init_level);
-            for (long k = 0; k < ni; ++k) iuid[(size_t)k] = (uint64_t)k;       // lattice index: the generator's key
+            for (long k = 0; k < ni; ++k) iuid[(size_t)k] = islot[(size_t)k];
         }
     }
 
@@ -1966,8 +1983,8 @@ struct Engine {
     void begin_step () {
         std::fill(slab_data.begin(), slab_data.end(), 0.0);     // ResetAllQuantities
         beam_this_slice = -2;
-        init_plasma();
         ++cur_step;
+        init_plasma();
         // DepositNeutralizingBackground (plasma/MultiPlasma.cpp:106-118): rhomjz only, charge -q
         const int comp[6] = {-1, -1, -1, -1, -1, d.bxby_solver ? (int)pIon_rhomjz : (int)Ion_rhomjz};
         if (!d.plasma_no_neutralize)
@@ -2207,6 +2224,10 @@ long orc_engine_n_ionized (void* h) { return static_cast<Engine*>(h)->n_ionized_
 void orc_adk_tables (void* h, double* prefactor, double* exp_prefactor, double* power) {
     Engine* e = static_cast<Engine*>(h);
     for (size_t i = 0; i < e->adk_prefactor.size(); ++i) { prefactor[i] = e->adk_prefactor[i]; exp_prefactor[i] = e->adk_exp_prefactor[i]; power[i] = e->adk_power[i]; }
+}
+void orc_engine_set_density_profile (void* h, int nr, const double* r, const double* fr, int nt, const double* ct, const double* ft) {
+    Engine* e = static_cast<Engine*>(h);
+    e->prof_r.assign(r, r + nr); e->prof_fr.assign(fr, fr + nr); e->prof_t.assign(ct, ct + nt); e->prof_ft.assign(ft, ft + nt);
 }
 double orc_ion_uniform (unsigned long long seed, unsigned long long uid, unsigned long long step, unsigned long long islice) {
     return Engine::ion_uniform(seed, uid, step, islice);

@@ -451,6 +451,15 @@ class Engine:
         vb = (C.c_int32 * n).from_address(L.orc_engine_valid(self._h))
         return np.frombuffer(buf, dtype=np.float64).reshape(11, stride)[:, :n], np.frombuffer(vb, dtype=np.int32)
 
+    def set_density_profile(self, r=(), fr=(), ct=(), ft=()):
+        """n(x, y, ct) = density * f_r(r) * f_t(c t), piecewise linear tables (see hps_engine_set_density_profile)."""
+        L = lib()
+        L.orc_engine_set_density_profile.restype = None
+        L.orc_engine_set_density_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (r, fr, ct, ft)]
+        assert len(a[0]) == len(a[1]) and len(a[2]) == len(a[3])
+        L.orc_engine_set_density_profile(self._h, len(a[0]), _ptr(a[0]), _ptr(a[1]), len(a[2]), _ptr(a[2]), _ptr(a[3]))
+
     def ions(self):
         """Species "ion" (ADK ionisation): (real (11, n), valid (n,), ion_lev (n,))."""
         L = lib()

@@ -1304,3 +1304,68 @@ def test_fused_push_and_deposit_schedule(api, ts, rho):
             assert abs(cb[nm] - v) <= 1e-9 * abs(v), (nm, cb[nm], v)
     for nm, v in ca.items():
         assert abs(cb[nm] - v) <= 1e-10 * max(abs(v), 1e-300), (nm, cb[nm], v)
+
+
+@pytest.mark.gpu
+def test_openpmd_output_of_the_engine(api, tmp_path):
+    """the engine's field diagnostic and beam written in the openPMD hierarchy (hipace_amd/openpmd_writer.py)
+    and reduced as the reference's checksum backend does (tests/openpmd_shim.py) reproduce the reference's JSON."""
+    import torch
+    from hipace_amd import openpmd_writer as W
+    from tests import openpmd_shim as S
+    gold = json.load(open(os.path.join(GOLD, "blowout_wake_explicit.2Rank.json")))
+    deck = decks.blowout_wake()
+    eng = api.SliceEngine(deck)
+    names = list(gold["lev=0"])
+    eng.set_field_diagnostic(names)
+    nb, off = eng.beam_layout()
+    buf = torch.zeros(7 * nb, dtype=torch.float64, device="cuda")
+    eng.initial_beam_into(buf)
+    h = buf.cpu().numpy()
+    rows = [np.concatenate([h[7 * off[p]:7 * off[p + 1]].reshape(7, -1)[k] for p in range(len(off) - 1)]) for k in range(7)]
+    for step in range(deck["n_steps"]):
+        eng.run_step()
+        W.write_engine_output(eng, str(tmp_path), step, beam=np.stack(rows))
+    cs = S.checksums(str(tmp_path))
+    for grp in ("lev=0", "beam"):
+        for k, v in gold[grp].items():
+            assert abs(cs[grp][k] - v) <= 1e-9 * max(abs(v), 1e-300), (grp, k, cs[grp][k], v)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile_size", [0, 16])
+def test_plasma_density_profile_matches_oracle(api, oracle, tile_size):
+    """InitParticles with a density that depends on (x, y, c t) (PlasmaParticleContainerInit.cpp:246-313), here the
+    tabulated form n = n0 f_r(r) f_t(ct): a parabolic plasma channel that ends at r = 6 (no particles beyond) and a
+    density up-ramp over three time steps.  Slab and particle sheet equal the oracle's after every step."""
+    deck = decks.blowout_wake()
+    deck.update(nz=20, lo=(-8.0, -8.0, -1.2), hi=(8.0, 8.0, 1.2), beam_zmin=-1.1, beam_zmax=1.1, n_steps=3, dt=2.0, plasma_ppc=(2, 2),
+                beam_umean=(0.0, 0.0, 1.0e6), beam_n_subcycles=1)
+    r = np.array([0.0, 1.0, 2.0, 4.0, 6.0, 6.01])
+    fr = np.array([1.0, 1.05, 1.2, 1.8, 2.8, 0.0])
+    ct, ft = np.array([0.0, 4.0]), np.array([0.25, 1.0])
+    ge = api.SliceEngine(deck, tile_size=tile_size)
+    oe = oracle.Engine(deck)
+    ge.set_density_profile(r, fr, ct, ft)
+    oe.set_density_profile(r, fr, ct, ft)
+    sums = []
+    for step in range(3):
+        ge.begin_step()
+        oe.begin_step()
+        for k in range(deck["nz"] - 1, -1, -1):
+            ge.solve_slice(k)
+            oe.solve_slice(k)
+        gs, os_ = ge.slab(), oe.slab()
+        for c, name in enumerate(ge.comp_names()):
+            scale = max(np.abs(os_[c]).max(), 1e-300)
+            assert np.abs(gs[c] - os_[c]).max() <= 1e-9 * scale, (step, name)
+        gr, gv = ge.particles()
+        orl, ov = oe.particles()
+        keep = gv != 0
+        assert keep.sum() == orl.shape[1] == int(ov.sum()) and keep.sum() < gv.size       # the channel's edge removed some
+        kg = np.lexsort((np.round(gr[7][keep], 9), np.round(gr[6][keep], 9)))
+        ko = np.lexsort((np.round(orl[7], 9), np.round(orl[6], 9)))
+        sums.append(orl[2].sum())
+        for q in range(11):
+            assert np.abs(gr[q][keep][kg] - orl[q][ko]).max() <= 1e-9 * max(np.abs(orl[q]).max(), 1e-300), (step, q)
+    assert sums[0] < sums[1] < sums[2] and abs(sums[2] / sums[0] - 4.0) < 0.05         # the ramp: 0.25 -> 0.625 -> 1
