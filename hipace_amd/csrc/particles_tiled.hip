@@ -284,32 +284,42 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
         for (int iy = 0; iy < NS; ++iy) {
 #pragma unroll
             for (int ix = 0; ix < NS; ++ix) {
-                if (DT == 2 && (ix == 0 || ix == NS - 1) && (iy == 0 || iy == NS - 1)) continue;
-                double Bz, Ez, ExmBy, EypBx;
+                // centred-derivative shapes (DT == 2): the plain shape vanishes on the outer ring of the stencil
+                // (s[0] = s[NS-1] = 0 for every order), so there the cached fields do not enter at all -- only one of the
+                // two derivative terms does: no LDS reads for 12 of the 21 cells (order 2)
+                const bool xedge = (DT == 2) && (ix == 0 || ix == NS - 1), yedge = (DT == 2) && (iy == 0 || iy == NS - 1);
+                if (xedge && yedge) continue;
+                const bool ring = xedge || yedge;
                 double* gp_ = nullptr; int ls = 0;
-                if (local) {
-                    ls = (lj + iy)*RP + li + ix;
-                    Bz = lds_get(img + ls); Ez = lds_get(img + PL + ls); ExmBy = lds_get(img + 2*PL + ls); EypBx = lds_get(img + 3*PL + ls);
+                if (local) ls = (lj + iy)*RP + li + ix;
+                else       gp_ = f.p + f.off(i0 + ix, j0 + iy);
+                double sy_add, sx_add;
+                if (ring) {
+                    // xedge: sx = 0 -> only dsx*sy survives; yedge: sy = 0 -> only sx*dsy
+                    const double dd = xedge ? dsx[ix]*sy[iy] : sx[ix]*dsy[iy];
+                    sy_add = (xedge ? a5 : a6)*dd;
+                    sx_add = (xedge ? b5 : b6)*dd;
                 } else {
-                    gp_ = f.p + f.off(i0 + ix, j0 + iy);
-                    Bz = gp_[cBz*f.ns]; Ez = gp_[cEz*f.ns]; ExmBy = gp_[cExmBy*f.ns]; EypBx = gp_[cEypBx*f.ns];
-                }
-                const double ss = sx[ix]*sy[iy];
-                const double dxs = dsx[ix]*sy[iy];
-                const double sdy = sx[ix]*dsy[iy];
-                double ty = fma(a1, Bz, fma(a2, Ez, fma(a3, ExmBy, a4*EypBx)));
-                double tx = fma(b1, Bz, fma(b2, Ez, fma(b3, ExmBy, b4*EypBx)));
-                if constexpr (LASER) {
-                    // gradient of |a|^2 at this stencil cell (ExplicitDeposition.cpp:211-226), from the slab
-                    if (ss != 0.0) {
-                        const double* a = f.p + k.aabs*f.ns + f.off(i0 + ix, j0 + iy);
-                        const double lf = 0.25*cq*qp*k.laser_fac*k.c;
-                        ty = fma(lf*0.5*k.dy_inv, a[f.js] - a[-f.js], ty);
-                        tx = fma(-lf*0.5*k.dx_inv, a[1] - a[-1], tx);
+                    double Bz, Ez, ExmBy, EypBx;
+                    if (local) { Bz = lds_get(img + ls); Ez = lds_get(img + PL + ls); ExmBy = lds_get(img + 2*PL + ls); EypBx = lds_get(img + 3*PL + ls); }
+                    else       { Bz = gp_[cBz*f.ns]; Ez = gp_[cEz*f.ns]; ExmBy = gp_[cExmBy*f.ns]; EypBx = gp_[cEypBx*f.ns]; }
+                    const double ss = sx[ix]*sy[iy];
+                    const double dxs = dsx[ix]*sy[iy];
+                    const double sdy = sx[ix]*dsy[iy];
+                    double ty = fma(a1, Bz, fma(a2, Ez, fma(a3, ExmBy, a4*EypBx)));
+                    double tx = fma(b1, Bz, fma(b2, Ez, fma(b3, ExmBy, b4*EypBx)));
+                    if constexpr (LASER) {
+                        // gradient of |a|^2 at this stencil cell (ExplicitDeposition.cpp:211-226), from the slab
+                        if (ss != 0.0) {
+                            const double* a = f.p + k.aabs*f.ns + f.off(i0 + ix, j0 + iy);
+                            const double lf = 0.25*cq*qp*k.laser_fac*k.c;
+                            ty = fma(lf*0.5*k.dy_inv, a[f.js] - a[-f.js], ty);
+                            tx = fma(-lf*0.5*k.dx_inv, a[1] - a[-1], tx);
+                        }
                     }
+                    sy_add = fma(ss, ty, fma(a5, dxs, a6*sdy));
+                    sx_add = fma(ss, tx, fma(b5, dxs, b6*sdy));
                 }
-                const double sy_add = fma(ss, ty, fma(a5, dxs, a6*sdy));
-                const double sx_add = fma(ss, tx, fma(b5, dxs, b6*sdy));
                 if (local) { lds_add(acc + ls, sy_add); lds_add(acc + PL + ls, sx_add); }
                 else       { atomic_add_f64(gp_ + cSy*f.ns, sy_add); atomic_add_f64(gp_ + cSx*f.ns, sx_add); }
             }
