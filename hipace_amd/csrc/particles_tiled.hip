@@ -53,6 +53,37 @@ __device__ __forceinline__ double lds_get (const double* p)
     return *(const lds_double*)p;
 }
 
+// |a|^2 of the laser envelope from one more plane of the tile's LDS image (the LASER variants of the three kernels): the
+// plain-shape gather of doLaserGatherShapeN (FieldGather.H:236-331) with the same weights and summation order as
+// laser_gather / laser_gather_grad (particle_math.h), so the result does not depend on which path a particle takes.
+// (li, lj) = left-most stencil cell relative to the image, pitch = row pitch of the plane.
+template <int ORDER>
+__device__ __forceinline__ double laser_gather_lds (const double* a, int pitch, int li, int lj, const double* lx, const double* ly)
+{
+    double A = 0.0;
+#pragma unroll
+    for (int iy = 0; iy <= ORDER; ++iy)
+#pragma unroll
+        for (int ix = 0; ix <= ORDER; ++ix) A += lx[ix]*ly[iy]*lds_get(a + (lj + iy)*pitch + li + ix);
+    return A;
+}
+template <int ORDER>
+__device__ __forceinline__ void laser_gather_grad_lds (const double* a, int pitch, int li, int lj, const double* lx, const double* ly,
+                                                       double dx_inv, double dy_inv, double& A, double& ADx, double& ADy)
+{
+    A = 0.0; ADx = 0.0; ADy = 0.0;
+#pragma unroll
+    for (int iy = 0; iy <= ORDER; ++iy)
+#pragma unroll
+        for (int ix = 0; ix <= ORDER; ++ix) {
+            const double* c = a + (lj + iy)*pitch + li + ix;
+            const double w = lx[ix]*ly[iy];
+            A += w*lds_get(c);
+            ADx += w*0.5*dx_inv*(lds_get(c + 1) - lds_get(c - 1));
+            ADy += w*0.5*dy_inv*(lds_get(c + pitch) - lds_get(c - pitch));
+        }
+}
+
 // (An XCD-chunked tile order -- contiguous tile runs per XCD -- was measured slower here: 916 vs 953 slices/s.)
 // MASK: compile-time set of deposited components (bit c = DepComps entry c), -1 = decide at run time.
 // With a compile-time set the 9x4 accumulations are straight-line ds_add_f64 with immediate offsets.
@@ -101,6 +132,8 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         double2* z = (double2*)acc;
         for (int s = tid; s < na*R*R/2; s += 256) z[s] = make_double2(0.0, 0.0);
     }
+    double* aimg = acc + na*R*R;          // LASER: |a|^2 over the tile region
+    if constexpr (LASER) { const int ca[1] = {k.aabs}; load_region<R>(aimg, f, ca, 1, ox, oy, tid); }
     __syncthreads();
     PT_STAMP(1);
 
@@ -123,10 +156,16 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         double q_invvol = k.a*cur.w;
         double q_mu0_mass = k.b;
         if (k.can_ionize) { const double il = (double)cur.ion; q_invvol *= il; q_mu0_mass *= il; }
+        double sx[ORDER + 1], sy[ORDER + 1];
+        const int i0 = shape_weights<ORDER>((cur.x - k.xoff)*k.dx_inv, sx);
+        const int j0 = shape_weights<ORDER>((cur.y - k.yoff)*k.dy_inv, sy);
+        const int li = i0 - ox, lj = j0 - oy;
+        const bool local = (li >= 0 && li + ORDER < R && lj >= 0 && lj + ORDER < R);
         double gamma_psi;
         if constexpr (LASER) {
-            // |a|^2 from the slab (cached global reads; the LDS image holds the accumulators only)
-            double A = laser_gather<ORDER>(f, k.aabs, (cur.x - k.xoff)*k.dx_inv, (cur.y - k.yoff)*k.dy_inv)*k.laser_fac;
+            // |a|^2 with the deposition's own shape: from the LDS image, from the slab for a particle outside the halo
+            double A = (local ? laser_gather_lds<ORDER>(aimg, R, li, lj, sx, sy)
+                              : laser_gather<ORDER>(f, k.aabs, (cur.x - k.xoff)*k.dx_inv, (cur.y - k.yoff)*k.dy_inv))*k.laser_fac;
             if (k.can_ionize) A *= (double)cur.ion*(double)cur.ion;
             gamma_psi = 0.5*((1.0 + 0.5*A)*psi_inv*psi_inv + vx_c*vx_c*k.c_inv*k.c_inv + vy_c*vy_c*k.c_inv*k.c_inv + 1.0);
         } else {
@@ -138,13 +177,9 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             pl.idcpu[ip] = id & ~HPS_ID_VALID;
             continue;
         }
-        double sx[ORDER + 1], sy[ORDER + 1];
-        const int i0 = shape_weights<ORDER>((cur.x - k.xoff)*k.dx_inv, sx);
-        const int j0 = shape_weights<ORDER>((cur.y - k.yoff)*k.dy_inv, sy);
         // per-component weights in DepComps order
         const double wv[6] = {vx_c, vy_c, (gamma_psi - 1.0)*k.c, gamma_psi, q_mu0_mass*psi_inv, 1.0};
-        const int li = i0 - ox, lj = j0 - oy;
-        if (li >= 0 && li + ORDER < R && lj >= 0 && lj + ORDER < R) {
+        if (local) {
 #pragma unroll
             for (int iy = 0; iy <= ORDER; ++iy) {
 #pragma unroll
@@ -213,9 +248,10 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
     constexpr int R = TS + 2*TILE_HALO;
     constexpr int RP = R + PAD, PL = RP*R;     // row pitch and plane size of the LDS images
     constexpr int NS = ORDER + DT + 1;
-    extern __shared__ __attribute__((aligned(16))) double lds[];     // [4 cached][R*R] + [2 accum][R*R]
+    extern __shared__ __attribute__((aligned(16))) double lds[];     // [4 cached][R*R] + [2 accum][R*R] (+ |a|^2 with a laser)
     double* img = lds;
     double* acc = lds + 4*PL;
+    double* aimg = lds + 6*PL;
     const int tile = offsets[gridDim.x + 2 + blockIdx.x];     // launch order: heaviest tile first (sort.hip)
     const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
     const int tid = threadIdx.x;
@@ -235,6 +271,7 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
     Rec nxt{};
     if (ipb < pend) nxt = fetch(ipb);
     load_region<R, RP>(img, f, cc, 4, ox, oy, tid);
+    if constexpr (LASER) { const int ca[1] = {k.aabs}; load_region<R, RP>(aimg, f, ca, 1, ox, oy, tid); }
     {
         double2* z = (double2*)acc;
         for (int s = tid; s < PL; s += 256) z[s] = make_double2(0.0, 0.0);
@@ -255,17 +292,24 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
         const double cdm = q_invvol_mu0*cur.w;
         const double xmid = (cur.x - k.xoff)*k.dx_inv;
         const double ymid = (cur.y - k.yoff)*k.dy_inv;
-        double gp;
-        if constexpr (LASER) {
-            const double A = laser_gather<ORDER>(f, k.aabs, xmid, ymid)*k.laser_fac*q_mass*q_mass;
-            gp = 0.5*((1.0 + 0.5*A)*psi_inv*psi_inv + vx*vx + vy*vy + 1.0);
-        } else {
-            gp = 0.5*(psi_inv*psi_inv + vx*vx + vy*vy + 1.0);
-        }
         double sx[NS], dsx[NS], sy[NS], dsy[NS];
         int i0, j0;
         if constexpr (DT == 2) { i0 = centred_weights<ORDER>(xmid, sx, dsx); j0 = centred_weights<ORDER>(ymid, sy, dsy); }
         else                   { i0 = nodal_weights<ORDER>(xmid, sx, dsx);   j0 = nodal_weights<ORDER>(ymid, sy, dsy); }
+        const int li = i0 - ox, lj = j0 - oy;
+        // the whole stencil, and with a laser also the ring around its inner cells (the gradient of |a|^2), inside the image
+        const bool local = LASER ? (li >= 1 && li + NS + 1 <= R && lj >= 1 && lj + NS + 1 <= R)
+                                 : (li >= 0 && li + NS <= R && lj >= 0 && lj + NS <= R);
+        double gp;
+        if constexpr (LASER) {
+            double lx[ORDER + 1], ly[ORDER + 1];
+            const int ai = shape_weights<ORDER>(xmid, lx), aj = shape_weights<ORDER>(ymid, ly);
+            const double A = (local ? laser_gather_lds<ORDER>(aimg, RP, ai - ox, aj - oy, lx, ly)
+                                    : laser_gather<ORDER>(f, k.aabs, xmid, ymid))*k.laser_fac*q_mass*q_mass;
+            gp = 0.5*((1.0 + 0.5*A)*psi_inv*psi_inv + vx*vx + vy*vy + 1.0);
+        } else {
+            gp = 0.5*(psi_inv*psi_inv + vx*vx + vy*vy + 1.0);
+        }
         const double qp = q_mass*psi_inv;
         const double vxvy = vx*vy, gy = gp - vy*vy, gx = gp - vx*vx;
         // the source terms of ExplicitDeposition.cpp:225-252 are linear in the cached fields and in the
@@ -277,8 +321,6 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
         const double b1 = cq*vy, b2 = cqc*vx, b3 = cqc*gx, b4 = -cqc*vxvy, b5 = cc*(gx - 1.0), b6 = -cc*vxvy;
 #pragma unroll
         for (int m = 0; m < NS; ++m) { dsx[m] *= k.dx_inv; dsy[m] *= k.dy_inv; }
-        const int li = i0 - ox, lj = j0 - oy;
-        const bool local = (li >= 0 && li + NS <= R && lj >= 0 && lj + NS <= R);
         if (!local) ++nfb;
 #pragma unroll
         for (int iy = 0; iy < NS; ++iy) {
@@ -311,10 +353,17 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
                     if constexpr (LASER) {
                         // gradient of |a|^2 at this stencil cell (ExplicitDeposition.cpp:211-226), from the slab
                         if (ss != 0.0) {
-                            const double* a = f.p + k.aabs*f.ns + f.off(i0 + ix, j0 + iy);
                             const double lf = 0.25*cq*qp*k.laser_fac*k.c;
-                            ty = fma(lf*0.5*k.dy_inv, a[f.js] - a[-f.js], ty);
-                            tx = fma(-lf*0.5*k.dx_inv, a[1] - a[-1], tx);
+                            double ady, adx;
+                            if (local) {
+                                const double* a = aimg + ls;
+                                ady = lds_get(a + RP) - lds_get(a - RP); adx = lds_get(a + 1) - lds_get(a - 1);
+                            } else {
+                                const double* a = f.p + k.aabs*f.ns + f.off(i0 + ix, j0 + iy);
+                                ady = a[f.js] - a[-f.js]; adx = a[1] - a[-1];
+                            }
+                            ty = fma(lf*0.5*k.dy_inv, ady, ty);
+                            tx = fma(-lf*0.5*k.dx_inv, adx, tx);
                         }
                     }
                     sy_add = fma(ss, ty, fma(a5, dxs, a6*sdy));
@@ -355,6 +404,8 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     const int tid = threadIdx.x;
     const int cc[5] = {cPsi, cEz, cBx, cBy, cBz};
     load_region<R>(img, f, cc, 5, ox, oy, tid);
+    double* aimg = img + 5*R*R;           // LASER: |a|^2 over the tile region
+    if constexpr (LASER) { const int ca[1] = {k.aabs}; load_region<R>(aimg, f, ca, 1, ox, oy, tid); }
     __syncthreads();
 
     // (prefetching the next particle's state during the push was measured: 225 VGPRs, same 185 us --
@@ -378,28 +429,44 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             if (!local) ++nfb;
             Fld F{0, 0, 0, 0, 0, 0};
             if (local) {
-                // tensor-product gather: x sums per stencil row, then one y weight per row and component
+                // tensor-product gather: x sums per stencil row, then one y weight per row and component.
+                // The nodal-derivative set has NS = ORDER + 2 points of which the plain shape uses ORDER + 1: s[0] or
+                // s[NS-1] is exactly 0 (which one depends on the particle's half of the cell).  Psi needs all NS x NS
+                // cells (its derivative weights are full); Ez, Bx, By, Bz only the (NS-1) x (NS-1) cells where the plain
+                // weights live -- 52 LDS reads per particle instead of 80 (order 2), the skipped terms are exact zeros.
                 const double* b = img + lj*R + li;
 #pragma unroll 1
                 for (int iy = 0; iy < NS; ++iy) {
-                    double rp = 0.0, rd = 0.0, rez = 0.0, rbx = 0.0, rby = 0.0, rbz = 0.0;
+                    double rp = 0.0, rd = 0.0;
 #pragma unroll
                     for (int ix = 0; ix < NS; ++ix) {
-                        const int ls = iy*R + ix;
-                        const double psi_c = lds_get(b + ls);
+                        const double psi_c = lds_get(b + iy*R + ix);
                         rp = fma(sx[ix], psi_c, rp);
                         rd = fma(dsx[ix], psi_c, rd);
-                        rez = fma(sx[ix], lds_get(b + R*R + ls), rez);
-                        rbx = fma(sx[ix], lds_get(b + 2*R*R + ls), rbx);
-                        rby = fma(sx[ix], lds_get(b + 3*R*R + ls), rby);
-                        rbz = fma(sx[ix], lds_get(b + 4*R*R + ls), rbz);
                     }
                     F.ExmBy = fma(sy[iy], rd, F.ExmBy);
                     F.EypBx = fma(dsy[iy], rp, F.EypBx);
-                    F.Ez  = fma(sy[iy], rez, F.Ez);
-                    F.Bxc = fma(sy[iy], rbx, F.Bxc);
-                    F.Byc = fma(sy[iy], rby, F.Byc);
-                    F.Bz  = fma(sy[iy], rbz, F.Bz);
+                }
+                const int x0 = (sx[NS - 1] == 0.0) ? 0 : 1, y0 = (sy[NS - 1] == 0.0) ? 0 : 1;
+                double px[NS - 1], py[NS - 1];
+#pragma unroll
+                for (int m = 0; m < NS - 1; ++m) { px[m] = x0 ? sx[m + 1] : sx[m]; py[m] = y0 ? sy[m + 1] : sy[m]; }
+                const double* bq = b + R*R + y0*R + x0;
+#pragma unroll 1
+                for (int ky = 0; ky < NS - 1; ++ky) {
+                    double rez = 0.0, rbx = 0.0, rby = 0.0, rbz = 0.0;
+#pragma unroll
+                    for (int kx = 0; kx < NS - 1; ++kx) {
+                        const int ls = ky*R + kx;
+                        rez = fma(px[kx], lds_get(bq + ls), rez);
+                        rbx = fma(px[kx], lds_get(bq + R*R + ls), rbx);
+                        rby = fma(px[kx], lds_get(bq + 2*R*R + ls), rby);
+                        rbz = fma(px[kx], lds_get(bq + 3*R*R + ls), rbz);
+                    }
+                    F.Ez  = fma(py[ky], rez, F.Ez);
+                    F.Bxc = fma(py[ky], rbx, F.Bxc);
+                    F.Byc = fma(py[ky], rby, F.Byc);
+                    F.Bz  = fma(py[ky], rbz, F.Bz);
                 }
                 F.ExmBy *= k.dx_inv;
                 F.EypBx *= k.dy_inv;
@@ -435,8 +502,14 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             }
             LaserFld Lf{0.0, 0.0, 0.0};
             if constexpr (LASER) {
-                // |a|^2 and its gradient from the slab (cached global reads), PlasmaParticleAdvance.cpp:121-131
-                laser_gather_grad<ORDER>(f, k.aabs, (xp - k.xoff)*k.dx_inv, (yp - k.yoff)*k.dy_inv, k.dx_inv, k.dy_inv, Lf.A, Lf.ADx, Lf.ADy);
+                // |a|^2 and its centred gradient with the plain shape (PlasmaParticleAdvance.cpp:121-131): from the LDS image
+                // when the stencil and its ring lie inside it, from the slab otherwise
+                double lx[ORDER + 1], ly[ORDER + 1];
+                const int ai = shape_weights<ORDER>((xp - k.xoff)*k.dx_inv, lx) - ox, aj = shape_weights<ORDER>((yp - k.yoff)*k.dy_inv, ly) - oy;
+                if (ai >= 1 && ai + ORDER + 1 < R && aj >= 1 && aj + ORDER + 1 < R)
+                    laser_gather_grad_lds<ORDER>(aimg, R, ai, aj, lx, ly, k.dx_inv, k.dy_inv, Lf.A, Lf.ADx, Lf.ADy);
+                else
+                    laser_gather_grad<ORDER>(f, k.aabs, (xp - k.xoff)*k.dx_inv, (yp - k.yoff)*k.dy_inv, k.dx_inv, k.dy_inv, Lf.A, Lf.ADx, Lf.ADy);
                 const double ln = k.laser_fac*(k.can_ionize ? (double)pl.ion_lev[ip]*(double)pl.ion_lev[ip] : 1.0);
                 Lf.A *= 0.5*ln; Lf.ADx *= 0.25*k.c*ln; Lf.ADy *= 0.25*k.c*ln;
             }
@@ -680,7 +753,7 @@ int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
     DepComps cm{comp[0], comp[1], comp[2], comp[3], comp[4], comp[5]};
     int na = 0; for (int c = 0; c < 6; ++c) na += comp[c] >= 0;
     const int R = T->g.ts + 2*TILE_HALO;
-    const size_t lds = (size_t)na*R*R*sizeof(double);
+    const size_t lds = (size_t)(na + (aabs_comp >= 0 ? 1 : 0))*R*R*sizeof(double);
     SlabView f(slab);
     int mask = 0; for (int c = 0; c < 6; ++c) mask |= (comp[c] >= 0) << c;
 #define CALLM(O, S, M) { if (int e = set_lds(k_deposit_tiled<O, S, M>, lds)) return e; \
@@ -708,7 +781,7 @@ int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hp
     k.aabs = aabs_comp; k.laser_fac = (g.m_e/g.q_e)*(g.m_e/g.q_e);
     const int R = T->g.ts + 2*TILE_HALO;
     const int pad = expl_pad();
-    const size_t lds = (size_t)6*R*(R + pad)*sizeof(double);
+    const size_t lds = (size_t)(aabs_comp >= 0 ? 7 : 6)*R*(R + pad)*sizeof(double);
     SlabView f(slab);
 #define HPS_EXPL_LAUNCH(O, D, S, L, P) { if (int e = set_lds(k_explicit_tiled<O, D, S, L, P>, lds)) return e; \
         hipLaunchKernelGGL((k_explicit_tiled<O, D, S, L, P>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
@@ -739,7 +812,7 @@ int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_
     k.aabs = aabs_comp; k.laser_fac = (charge/g.q_e)*(g.m_e/mass)*(charge/g.q_e)*(g.m_e/mass);
     k.temp_slice = temp_slice; k.n_subcycles = n_subcycles; k.can_ionize = can_ionize;
     const int R = T->g.ts + 2*TILE_HALO;
-    const size_t lds = (size_t)5*R*R*sizeof(double);
+    const size_t lds = (size_t)(aabs_comp >= 0 ? 6 : 5)*R*R*sizeof(double);
     SlabView f(slab);
     const IonArgs ia = ion ? *ion : IonArgs{};
 #define HPS_ADV(O, S, L, I) { if (int e = set_lds(k_advance_tiled<O, S, L, I>, lds)) return e; \
