@@ -51,7 +51,8 @@ class Deck(C.Structure):
                 ("beam_radiation_reaction", C.c_int), ("background_density_SI", C.c_double), ("beam_no_z_push", C.c_int),
                 ("plasma_no_neutralize", C.c_int), ("ion_on", C.c_int), ("ion_ppc", C.c_int * 2), ("ion_density", C.c_double),
                 ("ion_mass", C.c_double), ("ion_charge", C.c_double), ("ion_init_level", C.c_int), ("ion_Z", C.c_int),
-                ("ion_energies", C.c_double * 56), ("ion_seed", C.c_ulonglong)]
+                ("ion_energies", C.c_double * 56), ("ion_seed", C.c_ulonglong),
+                ("beam_spin_tracking", C.c_int), ("beam_initial_spin", C.c_double * 3), ("beam_spin_anom", C.c_double)]
 
 
 # engine component names, index = value of the HPS_C_* enum in include/hpslice.h
@@ -147,6 +148,8 @@ _SIGS = {
     "hps_engine_assume_initial_beam_support": (C.c_int, [C.c_void_p]),
     "hps_engine_beam_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hps_engine_beam_capacity": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
+    "hps_engine_beam_message_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "hps_engine_beam_spin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_set_beam_import": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_export_beam_slice": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "hps_engine_import_beam_slice": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

@@ -311,6 +311,19 @@ class SliceEngine:
         check(_lib.lib().hps_engine_beam_capacity(self._h, C.byref(n)))
         return n.value
 
+    def beam_message_doubles(self):
+        """Length of a hand-off message of the moving beam: 1 + rows*capacity (7 rows, 10 with spin tracking)."""
+        r = C.c_int()
+        check(_lib.lib().hps_engine_beam_message_rows(self._h, C.byref(r)))
+        return 1 + r.value * self.beam_capacity()
+
+    def beam_spin(self):
+        """<beam>.do_spin_tracking: (3, nbeam) array sx sy sz in the particle order of beam_state()."""
+        nbeam, _ = self.beam_layout()
+        out = np.zeros((3, max(nbeam, 1)), dtype=np.float64)
+        check(_lib.lib().hps_engine_beam_spin(self._h, out.ctypes.data_as(C.c_void_p) if nbeam else None))
+        return out[:, :nbeam]
+
     def set_beam_import(self, on):
         check(_lib.lib().hps_engine_set_beam_import(self._h, int(on)))
 

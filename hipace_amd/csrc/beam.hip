@@ -25,6 +25,8 @@ struct BeamPushConsts {
     // radiation reaction (BeamParticleAdvance.cpp:101-113, 244-297): rr != 0 switches it on
     int rr, normalized, no_z_push;
     double RRcoeff, E0, wp_inv, c_SI;
+    // spin tracking (:218-238): spin != 0 switches it on
+    int spin; double spin_anom;
 };
 
 template <int ORDER>
@@ -67,6 +69,8 @@ void k_beam_push (SlabView f, BeamSoA b, const long* __restrict__ B, int p, int 
     int i = b.nsub[ip];
     if (i < 0) continue;
     double xp = b.x[ip], yp = b.y[ip], zp = b.z[ip], ux = b.ux[ip], uy = b.uy[ip], uz = b.uz[ip];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    if (k.spin) { s0 = b.sx[ip]; s1 = b.sy[ip]; s2 = b.sz[ip]; }
     bool absorbed = false;
     for (; i < k.nsc; ++i) {
         if (zp < k.min_z) break;                              // not on this slice any more (:150-153)
@@ -102,6 +106,25 @@ void k_beam_push (SlabView f, BeamSoA b, const long* __restrict__ B, int p, int 
         const double ux_i = (ux_next + ux)*0.5, uy_i = (uy_next + uy)*0.5;
         const double uz_i = uz + k.dt*0.5*k.qm*Ez;
         const double gii = 1.0/sqrt(1.0 + (ux_i*ux_i + uy_i*uy_i + uz_i*uz_i)*k.inv_c2);
+        if (k.spin) {      // Thomas-BMT precession as a Boris-type rotation (:218-238)
+            const double ic = 1.0/k.c;
+            const double E0_ = ExmBy + k.c*By, E1_ = EypBx - k.c*Bx, E2_ = Ez;
+            const double u0 = ux_i*ic, u1 = uy_i*ic, u2 = uz_i*ic;
+            const double be0 = u0*gii, be1 = u1*gii, be2 = u2*gii;
+            const double gp1 = gii/(1.0 + gii);
+            const double x0 = be1*E2_ - be2*E1_, x1 = be2*E0_ - be0*E2_, x2 = be0*E1_ - be1*E0_;      // beta x E
+            const double bdB = be0*Bx + be1*By + be2*Bz;
+            const double aq = fabs(k.qm);
+            const double h0 = aq*(Bx*gii - x0*ic*gp1 + k.spin_anom*(Bx - gp1*u0*bdB - x0*ic))*k.dt*0.5;
+            const double h1 = aq*(By*gii - x1*ic*gp1 + k.spin_anom*(By - gp1*u1*bdB - x1*ic))*k.dt*0.5;
+            const double h2 = aq*(Bz*gii - x2*ic*gp1 + k.spin_anom*(Bz - gp1*u2*bdB - x2*ic))*k.dt*0.5;
+            const double p0 = s0 + (h1*s2 - h2*s1), p1 = s1 + (h2*s0 - h0*s2), p2 = s2 + (h0*s1 - h1*s0);   // s' = s + h x s
+            const double o = 1.0/(1.0 + (h0*h0 + h1*h1 + h2*h2));
+            const double hd = h0*p0 + h1*p1 + h2*p2;
+            s0 = o*(p0 + (hd*h0 + (h1*p2 - h2*p1)));
+            s1 = o*(p1 + (hd*h1 + (h2*p0 - h0*p2)));
+            s2 = o*(p2 + (hd*h2 + (h0*p1 - h1*p0)));
+        }
         double uz_next = uz + k.dt*k.qm*(Ez + (ux_i*By - uy_i*Bx)*gii);
         if (k.rr) {      // classical radiation reaction in SI quantities (:244-297)
             const double icSI = 1.0/k.c_SI, ic = 1.0/k.c;
@@ -129,6 +152,7 @@ void k_beam_push (SlabView f, BeamSoA b, const long* __restrict__ B, int p, int 
     if (absorbed || apply_particle_bc(k.pc, xp, yp, ux, uy)) { b.w[ip] = 0.0; b.nsub[ip] = -1; continue; }
     b.x[ip] = xp; b.y[ip] = yp; b.z[ip] = zp; b.nsub[ip] = i;
     b.ux[ip] = ux; b.uy[ip] = uy; b.uz[ip] = uz;
+    if (k.spin) { b.sx[ip] = s0; b.sy[ip] = s1; b.sz[ip] = s2; }
     }
 }
 
@@ -156,6 +180,7 @@ void k_beam_partition (BeamSoA b, BeamSoA scr, long* B, int* nfront, int p, doub
         const long dst = slip ? count - 1 - atomicAdd(&s_cnt[1], 1) : atomicAdd(&s_cnt[0], 1);
         scr.x[dst] = b.x[ip]; scr.y[dst] = b.y[ip]; scr.z[dst] = b.z[ip]; scr.ux[dst] = b.ux[ip];
         scr.uy[dst] = b.uy[ip]; scr.uz[dst] = b.uz[ip]; scr.w[dst] = b.w[ip]; scr.nsub[dst] = b.nsub[ip];
+        if (b.sx) { scr.sx[dst] = b.sx[ip]; scr.sy[dst] = b.sy[ip]; scr.sz[dst] = b.sz[ip]; }
     }
     __threadfence_block();
     __syncthreads();
@@ -163,6 +188,7 @@ void k_beam_partition (BeamSoA b, BeamSoA scr, long* B, int* nfront, int p, doub
         const long ip = first + q;
         b.x[ip] = scr.x[q]; b.y[ip] = scr.y[q]; b.z[ip] = scr.z[q]; b.ux[ip] = scr.ux[q];
         b.uy[ip] = scr.uy[q]; b.uz[ip] = scr.uz[q]; b.w[ip] = scr.w[q]; b.nsub[ip] = scr.nsub[q];
+        if (b.sx) { b.sx[ip] = scr.sx[q]; b.sy[ip] = scr.sy[q]; b.sz[ip] = scr.sz[q]; }
     }
     if (t == 0) { B[p + 1] = first + count - nslip; nfront[p + 1] = nslip; }
 }
@@ -174,10 +200,10 @@ void k_beam_export (BeamSoA b, const long* __restrict__ B, int p, double* __rest
 {
     const long first = B[p], count = B[p + 1] - first;
     if (blockIdx.x == 0 && threadIdx.x == 0) { msg[0] = (double)min(count, cap); if (count > cap) atomicAdd(overflow, 1); }
-    const double* a[7] = {b.x, b.y, b.z, b.ux, b.uy, b.uz, b.w};
+    const double* a[10] = {b.x, b.y, b.z, b.ux, b.uy, b.uz, b.w, b.sx, b.sy, b.sz};
+    const int rows = b.sx ? 10 : 7;
     for (long q = (long)blockIdx.x*blockDim.x + threadIdx.x; q < min(count, cap); q += (long)gridDim.x*blockDim.x)
-#pragma unroll
-        for (int k = 0; k < 7; ++k) msg[1 + k*cap + q] = a[k][first + q];
+        for (int k = 0; k < rows; ++k) msg[1 + k*cap + q] = a[k][first + q];
 }
 
 // block p of the coming step: placed behind the blocks imported so far (imp[p] = where it starts); every later
@@ -189,10 +215,10 @@ void k_beam_import (BeamSoA b, long* B, long* imp, int p, int nz, const double* 
     long count = (long)msg[0];
     if (count > cap) count = cap;
     if (start + count > capacity) { count = capacity - start; if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(overflow, 1); }
-    double* a[7] = {b.x, b.y, b.z, b.ux, b.uy, b.uz, b.w};
+    double* a[10] = {b.x, b.y, b.z, b.ux, b.uy, b.uz, b.w, b.sx, b.sy, b.sz};
+    const int rows = b.sx ? 10 : 7;
     for (long q = (long)blockIdx.x*blockDim.x + threadIdx.x; q < count; q += (long)gridDim.x*blockDim.x) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) a[k][start + q] = msg[1 + k*cap + q];
+        for (int k = 0; k < rows; ++k) a[k][start + q] = msg[1 + k*cap + q];
         b.nsub[start + q] = 0;
     }
 }
@@ -244,6 +270,7 @@ static BeamPushConsts push_consts (const Engine& E, int islice)
     k.RRcoeff = (2.0/3.0)*reSI*q_over_mc*q_over_mc;
     k.wp_inv = (k.normalized && d.background_density_SI > 0.0) ? std::sqrt(ep0SI*meSI/(d.background_density_SI*qeSI*qeSI)) : 1.0;
     k.E0 = k.normalized ? meSI*cSI/k.wp_inv/qeSI : 1.0;
+    k.spin = d.beam_spin_tracking; k.spin_anom = d.beam_spin_anom != 0.0 ? d.beam_spin_anom : 0.00115965218128;
     return k;
 }
 

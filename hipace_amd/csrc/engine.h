@@ -14,7 +14,8 @@ namespace hps {
 struct LaserState;      // laser.hip
 
 struct BeamView { double *x, *y, *z, *ux, *uy, *uz, *w; };
-struct BeamSoA { double *x, *y, *z, *ux, *uy, *uz, *w; int* nsub; };     // moving beam (beam.hip); nsub < 0: absorbed
+struct BeamSoA { double *x, *y, *z, *ux, *uy, *uz, *w; int* nsub;      // moving beam (beam.hip); nsub < 0: absorbed
+                 double *sx, *sy, *sz; };                              // spin (do_spin_tracking), null otherwise
 
 struct Engine {
     hps_deck d{};
@@ -61,7 +62,7 @@ struct Engine {
     double* beam_data = nullptr; double* beam_init = nullptr; double* beam_cur = nullptr;
     long nbeam = 0; std::vector<long> beam_off;
     // hipace.dt != 0 (beam.hip): global SoA + device-resident slice boundaries B[nz+1] and slipped-front counts
-    bool moving = false; int steps_begun = 0;
+    bool moving = false; int steps_begun = 0; int beam_rows = 7;     // rows of a hand-off message (10 with spin)
     BeamSoA bm{}, bm_scr{}; double* bm_store = nullptr; int* bm_nsub = nullptr; int* bm_nsub_scr = nullptr;
     long* d_B = nullptr; int* d_nfront = nullptr; std::vector<long> h_B;      // h_B: boundaries as of begin_step
     // ring hand-off: import mode (the slices of the coming step arrive as messages), start offsets of the imported

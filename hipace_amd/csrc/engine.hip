@@ -452,13 +452,26 @@ int Engine::init_beam ()
     if (moving) {
         // global SoA in head-first order + device boundaries (beam.hip)
         const long nb = std::max(nbeam, 1L);
-        HPS_HIP_CHECK(hipMalloc(&bm_store, (size_t)14*nb*sizeof(double)));
+        const bool spin = d.beam_spin_tracking != 0;
+        beam_rows = spin ? 10 : 7;
+        HPS_HIP_CHECK(hipMalloc(&bm_store, (size_t)2*beam_rows*nb*sizeof(double)));
         HPS_HIP_CHECK(hipMalloc(&bm_nsub, (size_t)nb*sizeof(int)));
         HPS_HIP_CHECK(hipMalloc(&bm_nsub_scr, (size_t)nb*sizeof(int)));
         double* a = bm_store;
-        bm = BeamSoA{a, a + nb, a + 2*nb, a + 3*nb, a + 4*nb, a + 5*nb, a + 6*nb, bm_nsub};
-        a += 7*nb;
-        bm_scr = BeamSoA{a, a + nb, a + 2*nb, a + 3*nb, a + 4*nb, a + 5*nb, a + 6*nb, bm_nsub_scr};
+        bm = BeamSoA{a, a + nb, a + 2*nb, a + 3*nb, a + 4*nb, a + 5*nb, a + 6*nb, bm_nsub,
+                     spin ? a + 7*nb : nullptr, spin ? a + 8*nb : nullptr, spin ? a + 9*nb : nullptr};
+        a += (size_t)beam_rows*nb;
+        bm_scr = BeamSoA{a, a + nb, a + 2*nb, a + 3*nb, a + 4*nb, a + 5*nb, a + 6*nb, bm_nsub_scr,
+                         spin ? a + 7*nb : nullptr, spin ? a + 8*nb : nullptr, spin ? a + 9*nb : nullptr};
+        if (spin && nbeam > 0) {       // initial_spin, normalised, for every particle (BeamParticleContainer.cpp:390-402)
+            const double* s0 = d.beam_initial_spin;
+            const double nrm = std::sqrt(s0[0]*s0[0] + s0[1]*s0[1] + s0[2]*s0[2]);
+            HPS_REQUIRE(nrm > 0.0, "hps_engine_create: beam initial_spin must not vanish");
+            for (int q = 0; q < 3; ++q) {
+                std::vector<double> v((size_t)nbeam, s0[q]/nrm);
+                HPS_HIP_CHECK(hipMemcpy(bm_store + (size_t)(7 + q)*nb, v.data(), nbeam*sizeof(double), hipMemcpyHostToDevice));
+            }
+        }
         for (int k = 0; k < 7 && nbeam > 0; ++k)
             HPS_HIP_CHECK(hipMemcpy(bm_store + (size_t)k*nb, h[k].data(), nbeam*sizeof(double), hipMemcpyHostToDevice));
         HPS_HIP_CHECK(hipMemset(bm_nsub, 0, (size_t)nb*sizeof(int)));
@@ -489,6 +502,7 @@ int Engine::create (const hps_deck& deck, int device)
     if (d.n_subcycles == 0) d.n_subcycles = 1;       // <plasma>.n_subcycles default (particles/plasma/PlasmaParticleContainer.H:182)
     if (d.field_bc != 0) { set_error("hps_engine_create: only boundary.field = Dirichlet is built"); return HPS_ERR_UNSUPPORTED; }
     pc = (d.bxby_solver != 0);
+    HPS_REQUIRE(!(d.beam_spin_tracking && d.dt == 0.0), "hps_engine_create: spin tracking needs a moving beam (hipace.dt != 0)");
     if (d.predcorr_tol > 0.0) pc_tol = d.predcorr_tol;
     if (d.predcorr_max_iter > 0) pc_max_iter = d.predcorr_max_iter;
     if (d.predcorr_mix > 0.0) pc_mix = d.predcorr_mix;
@@ -1608,6 +1622,21 @@ extern "C" int hps_engine_beam_capacity (void* h, long* cap)
     Engine* E = static_cast<Engine*>(h);
     HPS_REQUIRE(E->moving, "hps_engine_beam_capacity: the engine's beam is static (hipace.dt = 0)");
     *cap = E->beam_cap;
+    return HPS_OK;
+}
+extern "C" int hps_engine_beam_message_rows (void* h, int* rows)
+{
+    *rows = static_cast<Engine*>(h)->beam_rows;
+    return HPS_OK;
+}
+extern "C" int hps_engine_beam_spin (void* h, double* soa_host)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E->moving && E->bm.sx && soa_host, "hps_engine_beam_spin: the beam has no spin (do_spin_tracking with hipace.dt != 0)");
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    const double* a[3] = {E->bm.sx, E->bm.sy, E->bm.sz};
+    for (int q = 0; q < 3; ++q)
+        if (E->nbeam > 0) HPS_HIP_CHECK(hipMemcpy(soa_host + (size_t)q*E->nbeam, a[q], E->nbeam*sizeof(double), hipMemcpyDeviceToHost));
     return HPS_OK;
 }
 extern "C" int hps_engine_set_beam_import (void* h, int on)

@@ -429,44 +429,31 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             if (!local) ++nfb;
             Fld F{0, 0, 0, 0, 0, 0};
             if (local) {
-                // tensor-product gather: x sums per stencil row, then one y weight per row and component.
-                // The nodal-derivative set has NS = ORDER + 2 points of which the plain shape uses ORDER + 1: s[0] or
-                // s[NS-1] is exactly 0 (which one depends on the particle's half of the cell).  Psi needs all NS x NS
-                // cells (its derivative weights are full); Ez, Bx, By, Bz only the (NS-1) x (NS-1) cells where the plain
-                // weights live -- 52 LDS reads per particle instead of 80 (order 2), the skipped terms are exact zeros.
+                // tensor-product gather: x sums per stencil row, then one y weight per row and component
+                // (reading only the (NS-1) x (NS-1) cells on which the plain weights of Ez, Bx, By, Bz are non-zero -- one
+                // of s[0], s[NS-1] is always exactly 0 -- was measured: 52 instead of 80 LDS reads per particle, but the
+                // lane-dependent base address costs more than the reads save: 171 against 166 us)
                 const double* b = img + lj*R + li;
 #pragma unroll 1
                 for (int iy = 0; iy < NS; ++iy) {
-                    double rp = 0.0, rd = 0.0;
+                    double rp = 0.0, rd = 0.0, rez = 0.0, rbx = 0.0, rby = 0.0, rbz = 0.0;
 #pragma unroll
                     for (int ix = 0; ix < NS; ++ix) {
-                        const double psi_c = lds_get(b + iy*R + ix);
+                        const int ls = iy*R + ix;
+                        const double psi_c = lds_get(b + ls);
                         rp = fma(sx[ix], psi_c, rp);
                         rd = fma(dsx[ix], psi_c, rd);
+                        rez = fma(sx[ix], lds_get(b + R*R + ls), rez);
+                        rbx = fma(sx[ix], lds_get(b + 2*R*R + ls), rbx);
+                        rby = fma(sx[ix], lds_get(b + 3*R*R + ls), rby);
+                        rbz = fma(sx[ix], lds_get(b + 4*R*R + ls), rbz);
                     }
                     F.ExmBy = fma(sy[iy], rd, F.ExmBy);
                     F.EypBx = fma(dsy[iy], rp, F.EypBx);
-                }
-                const int x0 = (sx[NS - 1] == 0.0) ? 0 : 1, y0 = (sy[NS - 1] == 0.0) ? 0 : 1;
-                double px[NS - 1], py[NS - 1];
-#pragma unroll
-                for (int m = 0; m < NS - 1; ++m) { px[m] = x0 ? sx[m + 1] : sx[m]; py[m] = y0 ? sy[m + 1] : sy[m]; }
-                const double* bq = b + R*R + y0*R + x0;
-#pragma unroll 1
-                for (int ky = 0; ky < NS - 1; ++ky) {
-                    double rez = 0.0, rbx = 0.0, rby = 0.0, rbz = 0.0;
-#pragma unroll
-                    for (int kx = 0; kx < NS - 1; ++kx) {
-                        const int ls = ky*R + kx;
-                        rez = fma(px[kx], lds_get(bq + ls), rez);
-                        rbx = fma(px[kx], lds_get(bq + R*R + ls), rbx);
-                        rby = fma(px[kx], lds_get(bq + 2*R*R + ls), rby);
-                        rbz = fma(px[kx], lds_get(bq + 3*R*R + ls), rbz);
-                    }
-                    F.Ez  = fma(py[ky], rez, F.Ez);
-                    F.Bxc = fma(py[ky], rbx, F.Bxc);
-                    F.Byc = fma(py[ky], rby, F.Byc);
-                    F.Bz  = fma(py[ky], rbz, F.Bz);
+                    F.Ez  = fma(sy[iy], rez, F.Ez);
+                    F.Bxc = fma(sy[iy], rbx, F.Bxc);
+                    F.Byc = fma(sy[iy], rby, F.Byc);
+                    F.Bz  = fma(sy[iy], rbz, F.Bz);
                 }
                 F.ExmBy *= k.dx_inv;
                 F.EypBx *= k.dy_inv;

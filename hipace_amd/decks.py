@@ -57,6 +57,8 @@ _DEFAULT = dict(
     plasma_no_neutralize=0,  # <plasma>.neutralize_background = false for the first species
     ion_on=0, ion_ppc=(0, 0), ion_density=0.0, ion_mass=0.0, ion_charge=0.0, ion_init_level=0, ion_Z=0,
     ion_energies=(0.0,) * 56, ion_seed=0,
+    # <beam>.do_spin_tracking, initial_spin, spin_anom (BeamParticleContainer.cpp:105-109; anomalous magnetic moment of the electron)
+    beam_spin_tracking=0, beam_initial_spin=(1.0, 0.0, 0.0), beam_spin_anom=0.00115965218128,
 )
 
 # Ionisation energies in eV of a few elements: NIST Atomic Spectra Database (Kramida, Ralchenko, Reader and NIST ASD

@@ -203,8 +203,7 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
     nbeam, off = engine.beam_layout()
     bufs = rpool = spool = None
     if moving:
-        cap = engine.beam_capacity()
-        mlen = 1 + 7 * cap
+        mlen = engine.beam_message_doubles()
         # receive slots: two steps' worth (a rank holds the early slices of its next step); send slots rotate
         rpool = [[torch.zeros(mlen, **f64) for _ in range(nz)] for _ in range(2)]
         spool = [torch.zeros(mlen, **f64) for _ in range(16)] if world > 1 else []

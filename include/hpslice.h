@@ -227,6 +227,11 @@ typedef struct {
     int plasma_no_neutralize;
     int ion_on; int ion_ppc[2]; double ion_density, ion_mass, ion_charge; int ion_init_level, ion_Z;
     double ion_energies[HPS_MAX_ION_LEVELS]; unsigned long long ion_seed;
+    /* <beam>.do_spin_tracking (moving beam only): every beam particle carries a spin vector, initial_spin (normalised)
+     * for all of them, precessing by the Thomas-BMT equation in the beam push (particles/pusher/BeamParticleAdvance.cpp:
+     * 218-238; spin_anom = anomalous magnetic moment, 0 -> the electron's 0.00115965218128).  The spin travels with the
+     * particle through the slipped-particle hand-off and the ring messages (3 more rows). */
+    int beam_spin_tracking; double beam_initial_spin[3]; double beam_spin_anom;
 } hps_deck;
 
 /* slab component indices of the engine (explicit-solver layout of fields/Fields.cpp:70-122) */
@@ -365,6 +370,10 @@ int hps_engine_beam_state (void* handle, long* boundaries_host, double* soa_host
  * import (import mode on, set before hps_engine_begin_step; slices in head-first order, slice k-1 before slice k is
  * solved): the regular particles of that slice for the step that has begun.  All asynchronous on the engine's stream. */
 int hps_engine_beam_capacity (void* handle, long* cap_host);
+/* rows of a hand-off message: 7, or 10 with spin tracking (sx sy sz behind w); a message is 1 + rows*cap doubles */
+int hps_engine_beam_message_rows (void* handle, int* rows_host);
+/* spin tracking: the three spin arrays [3][nbeam] in the order of hps_engine_beam_state; synchronises the stream */
+int hps_engine_beam_spin (void* handle, double* soa_host);
 int hps_engine_set_beam_import (void* handle, int on);
 int hps_engine_export_beam_slice (void* handle, int islice, double* msg_dev);
 int hps_engine_import_beam_slice (void* handle, int islice, const double* msg_dev);

@@ -1074,11 +1074,14 @@ struct Deck {
     int ion_on = 0; int ion_ppc[2] = {0, 0}; double ion_density = 0., ion_mass = 0., ion_charge = 0.;
     int ion_init_level = 0; int ion_Z = 0; double ion_energies[56] = {0.};       // eV, IonizationEnergiesTable.H (NIST)
     unsigned long long ion_seed = 0;   // counter-based generator (the reference draws from amrex::Random: sequence not reproducible)
+    // <beam>.do_spin_tracking, initial_spin, spin_anom (BeamParticleContainer.cpp:105-109, .H:236-241)
+    int beam_spin_tracking = 0; double beam_initial_spin[3] = {1., 0., 0.}; double beam_spin_anom = 0.00115965218128;
 };
 
 // particles of one beam slice; [0, nreg) were on the slice when the step began ("regular"), the rest slipped in
 // from the slice ahead during this step (BeamParticleContainer.H:175-182)
-struct Beam { std::vector<double> x, y, z, ux, uy, uz, w; std::vector<int> nsub; std::vector<int32_t> valid; long nreg = 0; };
+struct Beam { std::vector<double> x, y, z, ux, uy, uz, w; std::vector<int> nsub; std::vector<int32_t> valid; long nreg = 0;
+              std::vector<double> sx, sy, sz; };      // spin (<beam>.do_spin_tracking: three runtime real components)
 
 struct Engine {
     Deck d; Geom gm; int g; int ncomp;
@@ -1855,6 +1858,11 @@ struct Engine {
             Beam& b = store[isl];
             gen_beam_slice(isl, b);
             b.nsub.assign(b.x.size(), 0); b.valid.assign(b.x.size(), 1); b.nreg = (long)b.x.size();
+            if (d.beam_spin_tracking) {      // initial_spin, normalised (BeamParticleContainer.cpp:390-402)
+                const double* s0 = d.beam_initial_spin;
+                const double nrm = std::sqrt(s0[0]*s0[0] + s0[1]*s0[1] + s0[2]*s0[2]);
+                b.sx.assign(b.x.size(), s0[0]/nrm); b.sy.assign(b.x.size(), s0[1]/nrm); b.sz.assign(b.x.size(), s0[2]/nrm);
+            }
         }
         store_ready = true;
     }
@@ -1909,6 +1917,8 @@ struct Engine {
             Real xp = b.x[ip], yp = b.y[ip], zp = b.z[ip], ux = b.ux[ip], uy = b.uy[ip], uz = b.uz[ip];
             int i = b.nsub[ip];
             bool gone = false;
+            Real spin[3] = {0., 0., 0.};
+            if (d.beam_spin_tracking) { spin[0] = b.sx[ip]; spin[1] = b.sy[ip]; spin[2] = b.sz[ip]; }
             for (; i < nsc; ++i) {
                 if (zp < min_z) break;                         // not on this slice any more (:150-153)
                 const Real gammap_inv = 1.0/std::sqrt(1.0 + (ux*ux + uy*uy + uz*uz)*inv_c2);
@@ -1926,6 +1936,29 @@ struct Engine {
                 const Real ux_i = (ux_next + ux)*0.5, uy_i = (uy_next + uy)*0.5;
                 const Real uz_i = uz + dt*0.5*qm*Ezp;
                 const Real gamma_i_inv = 1.0/std::sqrt(1.0 + (ux_i*ux_i + uy_i*uy_i + uz_i*uz_i)*inv_c2);
+                if (d.beam_spin_tracking) {      // Thomas-BMT precession, Boris-type rotation (:218-238)
+                    const Real E[3] = {ExmByp + clight*Byp, EypBxp - clight*Bxp, Ezp};
+                    const Real B[3] = {Bxp, Byp, Bzp};
+                    const Real u[3] = {ux_i*inv_clight, uy_i*inv_clight, uz_i*inv_clight};
+                    const Real beta[3] = {u[0]*gamma_i_inv, u[1]*gamma_i_inv, u[2]*gamma_i_inv};
+                    const Real gamma_inv_p1 = gamma_i_inv/(1.0 + gamma_i_inv);
+                    auto cross = [] (const Real* a, const Real* c, Real* o) { o[0] = a[1]*c[2] - a[2]*c[1]; o[1] = a[2]*c[0] - a[0]*c[2]; o[2] = a[0]*c[1] - a[1]*c[0]; };
+                    auto dot = [] (const Real* a, const Real* c) { return a[0]*c[0] + a[1]*c[1] + a[2]*c[2]; };
+                    Real bxE[3]; cross(beta, E, bxE);
+                    const Real bdB = dot(beta, B);
+                    Real h[3];
+                    for (int q = 0; q < 3; ++q) {
+                        const Real omega = std::abs(qm)*(B[q]*gamma_i_inv - bxE[q]*inv_clight*gamma_inv_p1
+                            + d.beam_spin_anom*(B[q] - gamma_inv_p1*u[q]*bdB - bxE[q]*inv_clight));
+                        h[q] = omega*dt*0.5;
+                    }
+                    Real hxs[3]; cross(h, spin, hxs);
+                    const Real sp[3] = {spin[0] + hxs[0], spin[1] + hxs[1], spin[2] + hxs[2]};
+                    const Real o = 1.0/(1.0 + dot(h, h));
+                    Real hxsp[3]; cross(h, sp, hxsp);
+                    const Real hds = dot(h, sp);
+                    for (int q = 0; q < 3; ++q) spin[q] = o*(sp[q] + (hds*h[q] + hxsp[q]));
+                }
                 Real uz_next = uz + dt*qm*(Ezp + (ux_i*Byp - uy_i*Bxp)*gamma_i_inv);
                 if (rr) {      // :244-297
                     Real Exp = ExmByp + clight*Byp, Eyp = EypBxp - clight*Bxp;
@@ -1954,6 +1987,7 @@ struct Engine {
             if (gone) continue;
             if (enforce_bc(gm, xp, yp, ux, uy, b.w[ip], b.valid[ip])) continue;
             b.x[ip] = xp; b.y[ip] = yp; b.z[ip] = zp; b.nsub[ip] = i; b.ux[ip] = ux; b.uy[ip] = uy; b.uz[ip] = uz;
+            if (d.beam_spin_tracking) { b.sx[ip] = spin[0]; b.sy[ip] = spin[1]; b.sz[ip] = spin[2]; }
         }
     }
 
@@ -1966,6 +2000,7 @@ struct Engine {
         auto push = [] (Beam& t, const Beam& f, size_t k) {
             t.x.push_back(f.x[k]); t.y.push_back(f.y[k]); t.z.push_back(f.z[k]); t.ux.push_back(f.ux[k]);
             t.uy.push_back(f.uy[k]); t.uz.push_back(f.uz[k]); t.w.push_back(f.w[k]); t.nsub.push_back(f.nsub[k]); t.valid.push_back(1);
+            if (!f.sx.empty()) { t.sx.push_back(f.sx[k]); t.sy.push_back(f.sy[k]); t.sz.push_back(f.sz[k]); }
         };
         for (size_t k = 0; k < b.x.size(); ++k) {
             if (!b.valid[k]) continue;
@@ -2166,6 +2201,7 @@ struct orc_deck {
     int beam_radiation_reaction; double background_density_SI; int beam_no_z_push;
     int plasma_no_neutralize; int ion_on; int ion_ppc[2]; double ion_density, ion_mass, ion_charge; int ion_init_level, ion_Z;
     double ion_energies[56]; unsigned long long ion_seed;
+    int beam_spin_tracking; double beam_initial_spin[3]; double beam_spin_anom;
 };
 
 // threads of the CPU-baseline leg (see g_threads); returns the number actually set
@@ -2202,6 +2238,8 @@ void* orc_engine_create (const orc_deck* k) {
     d.plasma_no_neutralize=k->plasma_no_neutralize; d.ion_on=k->ion_on; d.ion_ppc[0]=k->ion_ppc[0]; d.ion_ppc[1]=k->ion_ppc[1];
     d.ion_density=k->ion_density; d.ion_mass=k->ion_mass; d.ion_charge=k->ion_charge; d.ion_init_level=k->ion_init_level;
     d.ion_Z=std::min(std::max(k->ion_Z, 0), 56); for (int i=0;i<56;++i) d.ion_energies[i]=k->ion_energies[i]; d.ion_seed=k->ion_seed;
+    d.beam_spin_tracking=k->beam_spin_tracking; for (int i=0;i<3;++i) d.beam_initial_spin[i]=k->beam_initial_spin[i];
+    d.beam_spin_anom = k->beam_spin_anom != 0.0 ? k->beam_spin_anom : 0.00115965218128;
     return new Engine(d);
 }
 void orc_engine_destroy (void* h) { delete static_cast<Engine*>(h); }
@@ -2316,6 +2354,12 @@ void orc_engine_beam_slice (void* h, int islice, double* out7n) {       // [7][c
     const Beam& b = e->store[islice]; const size_t n = b.x.size();
     const std::vector<double>* a[7] = {&b.x, &b.y, &b.z, &b.ux, &b.uy, &b.uz, &b.w};
     for (int k = 0; k < 7; ++k) for (size_t i = 0; i < n; ++i) out7n[k*n + i] = (*a[k])[i];
+}
+void orc_engine_beam_spin (void* h, int islice, double* out3n) {       // [3][count]: sx sy sz (do_spin_tracking)
+    Engine* e = static_cast<Engine*>(h); e->ensure_store();
+    const Beam& b = e->store[islice]; const size_t n = b.sx.size();
+    const std::vector<double>* a[3] = {&b.sx, &b.sy, &b.sz};
+    for (int k = 0; k < 3; ++k) for (size_t i = 0; i < n; ++i) out3n[k*n + i] = (*a[k])[i];
 }
 long orc_engine_laser_vcycles (void* h) { return static_cast<Engine*>(h)->laser_vcycles; }
 void orc_engine_set_insitu_beam (void* h, double radius) {

@@ -81,7 +81,8 @@ class Deck(C.Structure):
                 ("beam_radiation_reaction", C.c_int), ("background_density_SI", C.c_double), ("beam_no_z_push", C.c_int),
                 ("plasma_no_neutralize", C.c_int), ("ion_on", C.c_int), ("ion_ppc", C.c_int * 2), ("ion_density", C.c_double),
                 ("ion_mass", C.c_double), ("ion_charge", C.c_double), ("ion_init_level", C.c_int), ("ion_Z", C.c_int),
-                ("ion_energies", C.c_double * 56), ("ion_seed", C.c_ulonglong)]
+                ("ion_energies", C.c_double * 56), ("ion_seed", C.c_ulonglong),
+                ("beam_spin_tracking", C.c_int), ("beam_initial_spin", C.c_double * 3), ("beam_spin_anom", C.c_double)]
 
 
 def fill_struct(st, d):
@@ -506,6 +507,9 @@ class Engine:
         """Particles a slice block may hold in the hand-off messages (twice the fullest injected slice)."""
         return 2 * max(self.beam_slice(i).shape[1] for i in range(self.deck["nz"])) if not getattr(self, "_cap", None) else self._cap
 
+    def beam_message_doubles(self):
+        return 1 + 7 * self.beam_capacity()
+
     def set_beam_import(self, on):
         if not getattr(self, "_cap", None):
             self._cap = self.beam_capacity()
@@ -546,6 +550,17 @@ class Engine:
         out = np.zeros((7, n), dtype=np.float64)
         if n:
             L.orc_engine_beam_slice(self._h, islice, _ptr(out))
+        return out
+
+    def beam_spin(self, islice):
+        """<beam>.do_spin_tracking: (3, count) array sx sy sz of the particles sitting on slice `islice` now."""
+        L = lib()
+        L.orc_engine_beam_spin.restype = None
+        L.orc_engine_beam_spin.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        n = self.beam_slice(islice).shape[1]
+        out = np.zeros((3, n), dtype=np.float64)
+        if n:
+            L.orc_engine_beam_spin(self._h, islice, _ptr(out))
         return out
 
     def laser_vcycles(self):
