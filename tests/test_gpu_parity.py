@@ -1369,3 +1369,36 @@ def test_plasma_density_profile_matches_oracle(api, oracle, tile_size):
         for q in range(11):
             assert np.abs(gr[q][keep][kg] - orl[q][ko]).max() <= 1e-9 * max(np.abs(orl[q]).max(), 1e-300), (step, q)
     assert sums[0] < sums[1] < sums[2] and abs(sums[2] / sums[0] - 4.0) < 0.05         # the ramp: 0.25 -> 0.625 -> 1
+
+
+@pytest.mark.gpu
+def test_beam_spin_tracking_matches_oracle(api, oracle):
+    """<beam>.do_spin_tracking: the spin vectors after six steps of a beam that slips through the slices (the partition
+    kernel has to carry them along) equal the oracle's, particle by particle."""
+    deck = decks.beam_evolution()
+    deck.update(nz=12, lo=(-2.0, -2.0, -2.4), hi=(2.0, 2.0, 2.4), beam_zmin=-1.0, beam_zmax=1.6, beam_umean=(0.0, 0.0, 1.2),
+                beam_density=1.0e-3, n_steps=6, dt=0.9, beam_n_subcycles=4, ext_E_slope=(0.3, 0.2),
+                beam_spin_tracking=1, beam_initial_spin=(1.0, 1.0, 0.5))
+    eng = api.SliceEngine(deck, tile_size=0)
+    for _ in range(deck["n_steps"]):
+        eng.run_step()
+    ref = oracle.Engine(deck)
+    ref.run()
+    bnd, soa = eng.beam_state()
+    spin = eng.beam_spin()
+    nz = deck["nz"]
+    turned = 0.0
+    s0 = np.array([1.0, 1.0, 0.5]) / 1.5
+    for p in range(nz):
+        want, wsp = ref.beam_slice(nz - 1 - p), ref.beam_spin(nz - 1 - p)
+        got, gsp = soa[:, bnd[p]:bnd[p + 1]], spin[:, bnd[p]:bnd[p + 1]]
+        assert got.shape == want.shape and gsp.shape == wsp.shape
+        if want.shape[1]:
+            ko = np.lexsort((want[1], want[0])); kg = np.lexsort((got[1], got[0]))
+            assert np.abs(got[:, kg] - want[:, ko]).max() <= 1e-10 * np.abs(want).max()
+            assert np.abs(gsp[:, kg] - wsp[:, ko]).max() <= 1e-10
+            assert np.abs(np.sqrt((gsp ** 2).sum(0)) - 1.0).max() < 1e-12
+            turned = max(turned, np.abs(wsp - s0[:, None]).max())
+    assert turned > 1e-3            # the deck does make the spins precess
+    with pytest.raises(RuntimeError):
+        api.SliceEngine(dict(decks.blowout_wake(), beam_spin_tracking=1))       # needs a moving beam

@@ -399,3 +399,38 @@ def test_openpmd_output_reproduces_the_reference_checksums(oracle, tmp_path):
     arr, info = ts.get_field("Ez", 1)
     assert arr.shape == (deck["nz"], deck["ny"], deck["nx"]) and info["axisLabels"] == ["z", "y", "x"] and info["dataOrder"] == "C"
     assert abs(info["gridSpacing"][0] - (deck["hi"][2] - deck["lo"][2]) / deck["nz"]) < 1e-15
+
+
+def _spin_deck(mass):
+    d = decks.beam_evolution()
+    d.update(nz=4, lo=(-2.0, -2.0, -0.4), hi=(2.0, 2.0, 0.4), beam_zmin=-0.39, beam_zmax=0.39, beam_radius=1.0, beam_ppc=(1, 1, 1),
+             beam_umean=(0.0, 0.0, 50.0), beam_mass=mass, ext_E_slope=(0.5, 0.5), dt=0.2, n_steps=10, beam_n_subcycles=4,
+             beam_spin_tracking=1, beam_initial_spin=(2.0, 0.0, 0.0), beam_no_z_push=1)
+    return d
+
+
+def test_spin_tracking_follows_thomas_bmt(oracle):
+    """<beam>.do_spin_tracking (BeamParticleAdvance.cpp:218-238) has no test in the reference; the restatement is checked
+    against the Thomas-BMT precession it integrates: a heavy particle (it hardly moves in the time of the test) of
+    gamma = 50 in the static field E = (x/2, y/2, 0), B = 0 precesses with Omega = -|q/m| (beta x E)/c (1/(gamma + 1) + a), so
+    after time T its spin, initially along x, is x + (Omega x x) T to first order in the angle.  |s| = 1 to rounding."""
+    d = _spin_deck(1.0e3)
+    eng = oracle.Engine(d)
+    eng.run()
+    anom, T = d["beam_spin_anom"], d["dt"] * d["n_steps"]
+    total = 0
+    for isl in range(d["nz"]):
+        b, sp = eng.beam_slice(isl), eng.beam_spin(isl)
+        if b.shape[1] == 0:
+            continue
+        total += b.shape[1]
+        assert np.abs(np.sqrt((sp ** 2).sum(0)) - 1.0).max() < 1e-13
+        g = np.sqrt(1.0 + b[5] ** 2)
+        f = abs(d["beam_charge"] / d["beam_mass"]) * (1.0 / g / (1.0 + 1.0 / g) + anom) * (b[5] / g)
+        om_y, om_x = -f * 0.5 * b[0], f * 0.5 * b[1]
+        angle = np.hypot(om_x, om_y).max() * T
+        assert 1e-6 < angle < 1e-3
+        # s = x-hat + (Omega x x-hat) T = (1, Omega_z T, -Omega_y T); Omega_z = 0
+        assert np.abs(sp[1]).max() <= 1e-3 * angle and np.abs(sp[2] + om_y * T).max() <= 2e-3 * angle
+        assert np.abs(sp[0] - 1.0).max() <= angle ** 2
+    assert total > 500
