@@ -607,7 +607,10 @@ int Engine::setup_tiling ()
     if (int e = second(pl_alt, pl_real_alt, np_cap, !pc)) return e;
     pl_alt.n = np;
     if (ion.n > 0) {
-        if (int e = tiling_create(d.nx, d.ny, tile_size, ion.n, &ion.tiling)) return e;
+        // a species with at most one particle per cell gets 32 x 32-cell tiles: a 16 x 16 tile would hold 256 of them, one
+        // per thread, and the tile's fixed cost (field image, accumulator flush) would dominate its kernels
+        const int ion_ts = (d.ion_ppc[0]*d.ion_ppc[1] <= 1) ? 32 : tile_size;
+        if (int e = tiling_create(d.nx, d.ny, ion_ts, ion.n, &ion.tiling)) return e;
         if (int e = second(ion.pl_alt, ion.real_alt, ion.n, true)) return e;
         ion.pl_alt.n = ion.n;
     }

@@ -87,7 +87,7 @@ int ion_create (Engine& E)
     const double l_eff = std::sqrt(UH/d.ion_energies[0]) - 1.0;
     const double wp = std::sqrt(d.background_density_SI*qeSI*qeSI/(ep0SI*meSI));
     const double dt = d.si_units ? E.gm.dz/cSI : E.gm.dz/wp;
-    std::vector<double> adk((size_t)3*d.ion_Z);
+    std::vector<double> adk((size_t)4*d.ion_Z);
     for (int i = 0; i < d.ion_Z; ++i) {
         const double Uion = d.ion_energies[i];
         const double n_eff = (i + 1)*std::sqrt(UH/Uion);
@@ -95,6 +95,14 @@ int ion_create (Engine& E)
         adk[i] = dt*wa*C2*(Uion/(2*UH))*std::pow(2*std::pow((Uion/UH), 3./2)*Ea, 2*n_eff - 1);
         adk[d.ion_Z + i] = -2./3*std::pow(Uion/UH, 3./2)*Ea;
         adk[2*d.ion_Z + i] = -(2*n_eff - 1);
+        // field below which w = prefactor E^power exp(exp_prefactor / E) < 1e-20 (w grows with E there): bisection in ln E
+        auto lnw = [&] (double E) { return std::log(adk[i]) + adk[2*d.ion_Z + i]*std::log(E) + adk[d.ion_Z + i]/E; };
+        double lo = 1.0, hi = -adk[d.ion_Z + i];          // ln w(hi) = ln(prefactor) + power ln(hi) - 1: the far side of the bend
+        adk[3*d.ion_Z + i] = 0.0;
+        if (lnw(lo) < std::log(1e-20) && lnw(hi) > std::log(1e-20)) {
+            for (int it = 0; it < 200; ++it) { const double mid = std::sqrt(lo*hi); (lnw(mid) < std::log(1e-20) ? lo : hi) = mid; }
+            adk[3*d.ion_Z + i] = lo;
+        }
     }
     HPS_HIP_CHECK(hipMalloc(&E.ion.d_adk, adk.size()*sizeof(double)));
     HPS_HIP_CHECK(hipMemcpy(E.ion.d_adk, adk.data(), adk.size()*sizeof(double), hipMemcpyHostToDevice));

@@ -172,7 +172,7 @@ __device__ __forceinline__ double ion_uniform (unsigned long long seed, unsigned
 
 struct IonArgs {
     hps_plasma el;                       // product species: electrons are appended behind cnt[0] particles
-    const double* adk;                   // [prefactor[Z] | exp_prefactor[Z] | power[Z]]
+    const double* adk;                   // [prefactor[Z] | exp_prefactor[Z] | power[Z] | field below which nothing can ionise[Z]]
     unsigned long long* cnt;             // {electrons in el, overflow flag, workgroups done, ionisations so far}
     volatile long long* host; long long seq;      // mapped host memory the last workgroup posts {cnt[0], cnt[1], cnt[3], seq} to
     double E0, clightsq_inv; int Z;
@@ -187,6 +187,10 @@ __device__ __forceinline__ bool adk_decide (const IonArgs& a, double Ex, double 
 {
     const double Ep = sqrt(Ex*Ex + Ey*Ey + Ez*Ez)*a.E0;
     const double gammap = (1.0 + ux*ux*a.clightsq_inv + uy*uy*a.clightsq_inv + psi*psi)/(2.0*psi);
+    // Below adk[3 Z + lev] the rate is so small (w_dtau < 1e-20 for gamma/psi = 1) that 1 - exp(-w_dtau) is exactly 0 in
+    // double precision -- no draw can be below it: skip the pow and the two exp (most atoms of a slice sit in such a field).
+    // The bound leaves a factor 1e3 for gamma/psi; beyond that the full expression is evaluated.
+    if (Ep < a.adk[3*a.Z + lev] && gammap < 1.0e3*psi) return false;
     // gamma / psi completes dt for the quasi-static frame (:362-366)
     const double w_dtau = gammap/psi*a.adk[lev]*pow(Ep, a.adk[2*a.Z + lev])*exp(a.adk[a.Z + lev]/Ep);
     const double p = 1.0 - exp(-w_dtau);
