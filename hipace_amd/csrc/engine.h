@@ -33,7 +33,7 @@ struct Engine {
     // host memory (no stream synchronisation).
     struct Ions { hps_plasma pl{}, pl_alt{}; double *real = nullptr, *real_alt = nullptr; Tiling* tiling = nullptr; long n = 0;
                   double* d_adk = nullptr; unsigned long long* d_cnt = nullptr; long long* h_cnt = nullptr; long long* h_cnt_dev = nullptr;
-                  long long seq = 0; long n_ionized = 0; bool pending = false; } ion;
+                  long long seq = 0; long n_ionized = 0; bool pending = false; int* d_tile_flag = nullptr; } ion;
     // tabulated plasma density profile (hps_engine_set_density_profile): radial table on the device, time table on the host
     std::vector<double> prof_r, prof_t, prof_f_t; double* d_prof_r = nullptr; double prof_ft = 1.0;
     // fused push(k) + deposit(k-1) (k_advance_deposit_tiled): ahead_for = slice whose plasma currents are already deposited

@@ -13,10 +13,10 @@ namespace hps {
 
 int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[6], double charge,
                            double mass, int order, double max_qsa, int can_ionize, int* n_qsa, Tiling* T, int* n_fallback,
-                           hipStream_t st, int aabs_comp = -1);
+                           hipStream_t st, int aabs_comp = -1, const int* tile_flag = nullptr);
 int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int cache[4], const int depos[2],
                             double charge, double mass, int order, int dtype, int can_ionize, Tiling* T, int* n_fallback,
-                            hipStream_t st, int aabs_comp = -1);
+                            hipStream_t st, int aabs_comp = -1, const int* tile_flag = nullptr);
 int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], double charge,
                           double mass, int order, int temp_slice, int n_subcycles, int can_ionize, Tiling* T,
                           int* n_fallback, hipStream_t st, int aabs_comp = -1, const IonArgs* ion = nullptr);
@@ -613,6 +613,7 @@ int Engine::setup_tiling ()
         if (int e = tiling_create(d.nx, d.ny, ion_ts, ion.n, &ion.tiling)) return e;
         if (int e = second(ion.pl_alt, ion.real_alt, ion.n, true)) return e;
         ion.pl_alt.n = ion.n;
+        HPS_HIP_CHECK(hipMalloc(&ion.d_tile_flag, (size_t)ion.tiling->g.ntiles*sizeof(int)));
     }
     return HPS_OK;
 }
@@ -699,6 +700,8 @@ int Engine::begin_step ()
             ion.pl_alt.n = ion.n;
             if (int e = tiling_sort(ion.tiling, ion.pl, ion.pl_alt, gm, st)) return e;
             std::swap(ion.pl, ion.pl_alt); std::swap(ion.real, ion.real_alt);
+            // every tile may hold charged ions if the species starts ionised; else none does until the push says so
+            HPS_HIP_CHECK(hipMemsetAsync(ion.d_tile_flag, d.ion_init_level > 0 ? 0x01 : 0, (size_t)ion.tiling->g.ntiles*sizeof(int), st));
         }
         const unsigned long long c0[4] = {(unsigned long long)np_init, 0ULL, 0ULL, (unsigned long long)ion.n_ionized};
         HPS_HIP_CHECK(hipMemcpyAsync(ion.d_cnt, c0, sizeof(c0), hipMemcpyHostToDevice, st));
@@ -755,7 +758,7 @@ int Engine::species_deposit (const hps_plasma& p, Tiling* T, const int comp[6], 
 {
     if (p.n == 0) return HPS_OK;
     if (!T) return hps_deposit_current_laser(slab, p, gm, comp, c_aabs, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, st);
-    if (T->sorted_n > 0) { if (int e = deposit_current_tiled(slab, p, gm, comp, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, T, d_nfallback, st, c_aabs)) return e; }
+    if (T->sorted_n > 0) { if (int e = deposit_current_tiled(slab, p, gm, comp, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, T, d_nfallback, st, c_aabs, T == ion.tiling ? ion.d_tile_flag : nullptr)) return e; }
     if (p.n > T->sorted_n) return hps_deposit_current_laser(slab, tail_of(p, T->sorted_n, p.n - T->sorted_n), gm, comp, c_aabs, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, st);
     return HPS_OK;
 }
@@ -763,7 +766,7 @@ int Engine::species_explicit (const hps_plasma& p, Tiling* T, const int cache[4]
 {
     if (p.n == 0) return HPS_OK;
     if (!T) return hps_explicit_deposit_laser(slab, p, gm, cache, c_aabs, depos, charge, mass, d.order, d.deriv_type, can_ionize, st);
-    if (T->sorted_n > 0) { if (int e = explicit_deposit_tiled(slab, p, gm, cache, depos, charge, mass, d.order, d.deriv_type, can_ionize, T, d_nfallback, st, c_aabs)) return e; }
+    if (T->sorted_n > 0) { if (int e = explicit_deposit_tiled(slab, p, gm, cache, depos, charge, mass, d.order, d.deriv_type, can_ionize, T, d_nfallback, st, c_aabs, T == ion.tiling ? ion.d_tile_flag : nullptr)) return e; }
     if (p.n > T->sorted_n) return hps_explicit_deposit_laser(slab, tail_of(p, T->sorted_n, p.n - T->sorted_n), gm, cache, c_aabs, depos, charge, mass, d.order, d.deriv_type, can_ionize, st);
     return HPS_OK;
 }

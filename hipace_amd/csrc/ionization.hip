@@ -20,6 +20,7 @@
 #include "engine.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace hps {
 
@@ -120,7 +121,7 @@ void ion_destroy (Engine& E)
     if (E.ion.h_cnt) (void)hipHostFree(E.ion.h_cnt);
     (void)hipFree(E.ion.real); (void)hipFree(E.ion.pl.idcpu); (void)hipFree(E.ion.pl.ion_lev);
     (void)hipFree(E.ion.real_alt); (void)hipFree(E.ion.pl_alt.idcpu); (void)hipFree(E.ion.pl_alt.ion_lev);
-    delete E.ion.tiling;
+    delete E.ion.tiling; (void)hipFree(E.ion.d_tile_flag);
 }
 
 IonArgs Engine::ion_args (int islice)
@@ -132,7 +133,7 @@ IonArgs Engine::ion_args (int islice)
     a.E0 = d.si_units ? 1.0 : wp*meSI*cSI/qeSI;
     a.clightsq_inv = 1.0/(gm.c*gm.c);
     a.Z = d.ion_Z; a.seed = d.ion_seed; a.step = (unsigned long long)step_index; a.islice = (unsigned long long)islice;
-    a.cap = np_cap;
+    a.cap = np_cap; a.tile_flag = ion.d_tile_flag;
     a.seq = ++ion.seq;
     ion.pending = true;
     return a;

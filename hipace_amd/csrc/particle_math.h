@@ -178,6 +178,7 @@ struct IonArgs {
     double E0, clightsq_inv; int Z;
     unsigned long long seed, step, islice;
     long cap;                            // capacity of el's arrays
+    int* tile_flag;                      // [tiles of the ion tiling] 1 = the tile holds a charged ion (written by the ions' tile push)
 };
 
 // One ion's decision (PlasmaParticleContainer.cpp:352-372) from the fields gathered at (x_prev, y_prev): Ex, Ey, Ez in the

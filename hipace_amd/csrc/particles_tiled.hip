@@ -90,9 +90,11 @@ __device__ __forceinline__ void laser_gather_grad_lds (const double* a, int pitc
 template <int ORDER, int TS, int MASK, bool LASER = false>
 __global__ __launch_bounds__(256)
 void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx, DepComps cm,
-                      PartConsts k, int* n_qsa, int* n_fallback)
+                      PartConsts k, int* n_qsa, int* n_fallback, const int* __restrict__ tile_flag)
 {
     constexpr int R = TS + 2*TILE_HALO;
+    // an ionisable species: tiles that hold no charged ion have nothing to deposit (flag written by the species' push)
+    if (tile_flag && !tile_flag[offsets[gridDim.x + 2 + blockIdx.x]]) return;
     extern __shared__ __attribute__((aligned(16))) double acc[];     // [active comps][R*R]
     const int gc[6] = {cm.jx, cm.jy, cm.jz, cm.rho, cm.chi, cm.rhomjz};
     // slot of each component (compacted)
@@ -243,10 +245,12 @@ __device__ __forceinline__ void load_region (double* img, const SlabView& f, con
 template <int ORDER, int DT, int TS, bool LASER = false, int PAD = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // 128 VGPRs: 4 workgroups per CU
 void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
-                       int cBz, int cEz, int cExmBy, int cEypBx, int cSy, int cSx, PartConsts k, int* n_fallback)
+                       int cBz, int cEz, int cExmBy, int cEypBx, int cSy, int cSx, PartConsts k, int* n_fallback,
+                       const int* __restrict__ tile_flag)
 {
     constexpr int R = TS + 2*TILE_HALO;
     constexpr int RP = R + PAD, PL = RP*R;     // row pitch and plane size of the LDS images
+    if (tile_flag && !tile_flag[offsets[gridDim.x + 2 + blockIdx.x]]) return;      // no charged ion in this tile (see k_deposit_tiled)
     constexpr int NS = ORDER + DT + 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];     // [4 cached][R*R] + [2 accum][R*R] (+ |a|^2 with a laser)
     double* img = lds;
@@ -398,6 +402,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
 {
     constexpr int R = TS + 2*TILE_HALO;
     constexpr int NS = ORDER + 2;
+    int charged = 0;          // IONIZE: does this thread hold an ion of level > 0 after the slice?
     extern __shared__ __attribute__((aligned(16))) double img[];     // [5][R*R]
     const int tile = offsets[gridDim.x + 2 + blockIdx.x];     // launch order: heaviest tile first (sort.hip)
     const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
@@ -484,6 +489,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
                     const bool ionize = lev < ia.Z && adk_decide(ia, F.ExmBy + F.Byc, F.EypBx - F.Bxc, F.Ez, uxh, uyh, pl.psi_half[ip], lev, id);
                     if (ionize) { ++lev; pl.ion_lev[ip] = lev; qmc = k.a*(double)lev; }
                     adk_emit(ia, ionize, pl.x[ip], pl.y[ip], xp, yp, pl.w[ip]);
+                    charged |= (lev > 0);
                     if (lev == 0 && uxh == 0.0 && uyh == 0.0) break;
                 }
             }
@@ -535,7 +541,12 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         }
     }
     if (n_fallback && nfb) atomicAdd(n_fallback, nfb);
-    if constexpr (IONIZE) adk_post(ia);
+    if constexpr (IONIZE) {
+        // tiles without a charged ion are skipped by the species' deposition kernels on the next slice
+        const int any = __syncthreads_or(charged);
+        if (ia.tile_flag && tid == 0) ia.tile_flag[tile] = any;
+        adk_post(ia);
+    }
 }
 
 // Gather + push of slice k and the current deposition of slice k-1 in ONE pass over the sheet ("fused lower
@@ -731,7 +742,7 @@ static int set_lds (K kernel, size_t bytes)
 
 int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[6], double charge,
                            double mass, int order, double max_qsa, int can_ionize, int* n_qsa, Tiling* T, int* n_fallback,
-                           hipStream_t st, int aabs_comp)
+                           hipStream_t st, int aabs_comp, const int* tile_flag)
 {
     if (pl.n == 0) return HPS_OK;
     PartConsts k = base_consts(g);
@@ -744,9 +755,9 @@ int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
     SlabView f(slab);
     int mask = 0; for (int c = 0; c < 6; ++c) mask |= (comp[c] >= 0) << c;
 #define CALLM(O, S, M) { if (int e = set_lds(k_deposit_tiled<O, S, M>, lds)) return e; \
-        hipLaunchKernelGGL((k_deposit_tiled<O, S, M>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback); }
+        hipLaunchKernelGGL((k_deposit_tiled<O, S, M>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag); }
 #define CALLL(O, S, M) { if (int e = set_lds(k_deposit_tiled<O, S, M, true>, lds)) return e; \
-        hipLaunchKernelGGL((k_deposit_tiled<O, S, M, true>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback); }
+        hipLaunchKernelGGL((k_deposit_tiled<O, S, M, true>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag); }
 #define CALL(O, S) { if (aabs_comp >= 0) { if (mask == 51) CALLL(O, S, 51) else CALLL(O, S, -1) } \
                      else if (mask == 51) CALLM(O, S, 51) else if (mask == 59) CALLM(O, S, 59) else if (mask == 32) CALLM(O, S, 32) \
                      else if (mask == 3) CALLM(O, S, 3) else if (mask == 39) CALLM(O, S, 39) else if (mask == 47) CALLM(O, S, 47) else CALLM(O, S, -1) }
@@ -760,7 +771,7 @@ int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
 
 int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int cache[4], const int depos[2],
                             double charge, double mass, int order, int dtype, int can_ionize, Tiling* T, int* n_fallback,
-                            hipStream_t st, int aabs_comp)
+                            hipStream_t st, int aabs_comp, const int* tile_flag)
 {
     if (pl.n == 0) return HPS_OK;
     PartConsts k = base_consts(g);
@@ -772,7 +783,7 @@ int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hp
     SlabView f(slab);
 #define HPS_EXPL_LAUNCH(O, D, S, L, P) { if (int e = set_lds(k_explicit_tiled<O, D, S, L, P>, lds)) return e; \
         hipLaunchKernelGGL((k_explicit_tiled<O, D, S, L, P>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
-                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback); }
+                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback, tile_flag); }
 #define HPS_EXPL_PADS(O, D, S, L) { if (pad == 8) HPS_EXPL_LAUNCH(O, D, S, L, 8) else HPS_EXPL_LAUNCH(O, D, S, L, 2) }
     if (dtype == 2) {
 #define CALL(O, S) { if (aabs_comp >= 0) HPS_EXPL_PADS(O, 2, S, true) else HPS_EXPL_PADS(O, 2, S, false) }
@@ -881,7 +892,7 @@ extern "C" int hps_deposit_current_tiled (hps_slab slab, hps_plasma pl, hps_geom
     if (int e = check_tiling(tiling, slab, pl, "hps_deposit_current_tiled")) return e;
     for (int c = 0; c < 6; ++c) HPS_REQUIRE(comp[c] >= -1 && comp[c] < slab.ncomp, "hps_deposit_current_tiled: bad component");
     return deposit_current_tiled(slab, pl, g, comp, charge, mass, order, max_qsa, can_ionize, n_qsa,
-                                 static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1);
+                                 static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr);
 }
 
 extern "C" int hps_explicit_deposit_tiled (hps_slab slab, hps_plasma pl, hps_geom g, const int cache[4], const int depos[2],
@@ -893,7 +904,7 @@ extern "C" int hps_explicit_deposit_tiled (hps_slab slab, hps_plasma pl, hps_geo
     if (int e = check_stencil(slab, (order + 1)/2 + 1, "hps_explicit_deposit_tiled")) return e;
     if (int e = check_tiling(tiling, slab, pl, "hps_explicit_deposit_tiled")) return e;
     return explicit_deposit_tiled(slab, pl, g, cache, depos, charge, mass, order, dtype, can_ionize,
-                                  static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1);
+                                  static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr);
 }
 
 extern "C" int hps_advance_plasma_tiled (hps_slab slab, hps_plasma pl, hps_geom g, const int comp[5], double charge,
