@@ -152,6 +152,48 @@ class RcclTransport:
         self.close()
 
 
+class RcclSelfRing(RcclTransport):
+    """One rank that is its own ring neighbour, with the hand-off going through RCCL all the same (MultiBuffer.cpp:299-308
+    with the transport left in): `run_pipeline(..., transport=RcclSelfRing(device))` then runs the multi-rank code path --
+    receives posted a step ahead, sends behind the engine's events, the engine waiting for receive events, buffers reused
+    behind send / import events -- on a single GPU.  A receive is only remembered when it is posted; the message's
+    ncclSend + ncclRecv are issued as one group when the matching send comes (messages are matched in order, as on an
+    edge between two ranks), and the event the engine later waits for is looked up then."""
+    self_ring = True
+
+    def __init__(self, device_index):
+        super().__init__(0, 1, device_index)
+        self._posted, self._done, self._n_posted, self._n_sent = [], {}, 0, 0
+
+    def recv(self, t, after_event=None, slot=0):
+        self._posted.append((t, after_event))
+        self._n_posted += 1
+        return ("self", self._n_posted - 1)
+
+    def send(self, t, after_event=None, slot=0):
+        dst, free_ev = self._posted.pop(0)
+        assert dst.numel() == t.numel(), "self ring: message sizes of send and posted receive differ"
+        if free_ev:                       # the receive buffer's previous contents are no longer needed
+            self._check(self._lib.hps_ring_stream_wait(self._h, 1, C.c_void_p(free_ev)))
+        ev = self.sendrecv_self(t, dst, after_event, slot)
+        self._done[self._n_sent] = ev
+        self._n_sent += 1
+        return ev
+
+    def engine_wait(self, engine, ev):
+        if isinstance(ev, tuple):         # a receive: its message has been sent by now (the previous step is over)
+            ev = self._done.pop(ev[1])
+        engine.wait_event(ev)
+
+    def recv_after(self, ev):
+        if ev:
+            self._check(self._lib.hps_ring_stream_wait(self._h, 1, C.c_void_p(ev)))
+
+    def finish(self):
+        assert not self._posted, "self ring: receives without a matching send"
+        super().finish()
+
+
 def make_transport(rank, world, device):
     """The transport `run_pipeline` uses by default: none for one rank (in-process hand-off), gloo point-to-point on
     the CPU, the RCCL ring on a GPU."""
@@ -197,6 +239,7 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
     own_transport = transport is None and world > 1
     T = make_transport(rank, world, device) if own_transport else transport
     assert world == 1 or T is not None
+    ring = world > 1 or bool(getattr(T, "self_ring", False))      # hand-off through the transport (else: in-process copies)
     closes = n_steps > world
     f64 = dict(dtype=torch.float64, device=device)
 
@@ -206,13 +249,13 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
         mlen = engine.beam_message_doubles()
         # receive slots: two steps' worth (a rank holds the early slices of its next step); send slots rotate
         rpool = [[torch.zeros(mlen, **f64) for _ in range(nz)] for _ in range(2)]
-        spool = [torch.zeros(mlen, **f64) for _ in range(16)] if world > 1 else []
+        spool = [torch.zeros(mlen, **f64) for _ in range(16)] if ring else []
     else:
         bufs = [torch.zeros(max(7 * nbeam, 1), **f64) for _ in range(2)]
         if rank == 0:
             engine.initial_beam_into(bufs[0])        # only the head rank injects the beam (as the reference)
     spool_done = [None] * (len(spool) if spool else 0)
-    ring_laser = laser and world > 1                 # one rank: the engine rotates its own time levels
+    ring_laser = laser and ring                      # one rank without a transport: the engine rotates its own time levels
     lookahead = per_prev
     lpool, lspool = [], []
     if ring_laser:
@@ -228,7 +271,7 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
         return buf[7 * off[q]:7 * off[q + 1]]
 
     # ---- receives, in the order the previous rank sends: per fed step, per slice: beam message, laser message ----
-    fed_steps = [(m, s) for m, s in enumerate(my_steps) if s > 0] if world > 1 else []
+    fed_steps = [(m, s) for m, s in enumerate(my_steps) if s > 0] if ring else []
     fed_index = {m: f for f, (m, _) in enumerate(fed_steps)}
     n_incoming = len(fed_steps) * per_prev
     recv_ev = {}                                      # (m, j, kind) -> event [, laser pool slot]
@@ -260,7 +303,7 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
     solved = 0
     for m, step in enumerate(my_steps):
         fed = step > 0
-        from_ring = fed and world > 1
+        from_ring = fed and ring
         if moving:
             engine.set_beam_import(fed)
         else:
@@ -275,7 +318,7 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
             if on_slice is not None:
                 on_slice(m, q)
             islice = nz - 1 - q
-            if world > 1:
+            if ring:
                 if from_ring:
                     pos = fed_index[m] * per_prev + q
                 else:                                  # step 0 of the head rank: the next fed step starts `per - q` slices on
@@ -297,7 +340,7 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
                         T.engine_wait(engine, ev)
                         engine.import_laser_slice(nz - 1 - imported, lpool[k])
                         lpool_free[k] = engine.record_event(_EV_LFREE + k)
-            elif fed and moving and world == 1:
+            elif fed and moving and not ring:
                 for k in (q, q + 1):                   # in-process hand-off: the blocks were exported by the previous step
                     if k < nz and imported < k:
                         engine.import_beam_slice(nz - 1 - k, rpool[m % 2][k])
@@ -305,7 +348,7 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
             engine.solve_slice(islice)
             solved += 1
             if step + 1 < n_steps:
-                if world == 1:                         # MultiBuffer.cpp:299-308: send to myself
+                if not ring:                           # MultiBuffer.cpp:299-308: send to myself
                     if moving:
                         engine.export_beam_slice(islice, rpool[(m + 1) % 2][q])
                     else:
@@ -345,7 +388,7 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
             on_slice(m, per)
         if on_step_end is not None:
             on_step_end(step)
-    if world > 1:
+    if ring:
         post_until(n_incoming)                         # what the previous rank sends beyond my last slice is still received
         engine.sync()
         T.finish()

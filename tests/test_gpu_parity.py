@@ -153,9 +153,11 @@ def test_poisson_batch(api, oracle):
     assert np.all(out[[0, 3, 5]] == 0)
 
 
-@pytest.mark.parametrize("nx,ny", [(64, 64), (32, 32), (96, 48), (63, 63), (31, 63)])
+@pytest.mark.parametrize("nx,ny", [(64, 64), (32, 32), (96, 48), (63, 63), (31, 63), (512, 512), (1024, 1024), (1023, 1023)])
 @pytest.mark.parametrize("warm", [False, True])
 def test_multigrid_solve1(api, oracle, nx, ny, warm):
+    """Stand-alone hpmg solve1 against the oracle, up to the headline size (every kernel of the V-cycle: LDS-tiled
+    smoothers of the fine levels, fused level-0 end pass, k_lower_v2 / k_lower_v) with equal V-cycle counts."""
     rng = np.random.default_rng(nx + 7 * ny)
     g = G2
     dx, dy = 16.0 / nx, 16.0 / ny
@@ -1402,3 +1404,88 @@ def test_beam_spin_tracking_matches_oracle(api, oracle):
     assert turned > 1e-3            # the deck does make the spins precess
     with pytest.raises(RuntimeError):
         api.SliceEngine(dict(decks.blowout_wake(), beam_spin_tracking=1))       # needs a moving beam
+
+
+# ---- the multi-rank code path of the ring driver on the one GPU of the box (RcclSelfRing) ------------------------------
+@pytest.mark.gpu
+def test_ring_driver_on_rccl_static_beam(api):
+    """run_pipeline with its hand-off going through RCCL although there is one rank: receives posted a whole step ahead,
+    ncclSend behind the engine's event of the slice, the engine's stream waiting for the receive event, blocks reused
+    behind their last send -- no host synchronisation per slice.  Three steps (the ring closes twice); every step has the
+    reference's checksums, i.e. every block arrived before it was read."""
+    import torch
+    from hipace_amd.pipeline import RcclSelfRing, run_pipeline
+    gold = json.load(open(os.path.join(GOLD, "blowout_wake_explicit.2Rank.json")))["lev=0"]
+    deck = decks.blowout_wake()
+    eng = api.SliceEngine(deck)
+    eng.set_diagnostics(True)
+    T = RcclSelfRing(0)
+    sums = {}
+    solved = run_pipeline(eng, 0, 1, 3, torch.device("cuda", 0), on_step_end=lambda s: sums.__setitem__(s, eng.checksums()), transport=T)
+    assert solved == 3 * deck["nz"] and set(sums) == {0, 1, 2}
+    st = T.stats()
+    nb, off = eng.beam_layout()
+    nonempty = int((np.diff(off) > 0).sum())
+    assert st["sent"] == st["received"] == 2 * nonempty and st["bytes_sent"] == 2 * 7 * 8 * nb
+    for s in (1, 2):
+        for k, v in gold.items():
+            if v != 0.0:
+                assert abs(sums[s][k] - v) <= 1e-9 * abs(v), (s, k, sums[s][k], v)
+    T.close()
+
+
+@pytest.mark.gpu
+def test_ring_driver_on_rccl_moving_beam(api, oracle):
+    """The same with a beam that slips every step: fixed-size messages packed and unpacked on the device, send slots
+    reused behind their send events; per-step checksums equal the oracle stepping the same deck."""
+    import torch
+    from hipace_amd.pipeline import RcclSelfRing, run_pipeline
+    deck = decks.beam_evolution()
+    deck.update(nz=12, lo=(-2.0, -2.0, -2.4), hi=(2.0, 2.0, 2.4), beam_zmin=-1.0, beam_zmax=1.6, beam_umean=(0.0, 0.0, 1.2),
+                beam_density=1.0e-3, n_steps=4, dt=0.9, beam_n_subcycles=4, ext_E_slope=(0.3, 0.2))
+    ref = oracle.Engine(deck)
+    want = {}
+    for s in range(deck["n_steps"]):
+        ref.begin_step()
+        for k in range(deck["nz"] - 1, -1, -1):
+            ref.solve_slice(k)
+        want[s] = ref.checksums()
+    eng = api.SliceEngine(deck, tile_size=0)
+    eng.set_diagnostics(True)
+    T = RcclSelfRing(0)
+    got = {}
+    solved = run_pipeline(eng, 0, 1, deck["n_steps"], torch.device("cuda", 0), on_step_end=lambda s: got.__setitem__(s, eng.checksums()), transport=T)
+    assert solved == deck["n_steps"] * deck["nz"] and T.stats()["sent"] == 3 * deck["nz"]
+    for s in want:
+        for k in ("jz_beam", "jx_beam", "Bx", "By", "Ez", "Sx", "Sy"):
+            assert abs(got[s][k] - want[s][k]) <= 1e-9 * max(abs(want[s][k]), 1e-300), (s, k, got[s][k], want[s][k])
+    eng.beam_state()
+    T.close()
+
+
+@pytest.mark.gpu
+def test_ring_driver_on_rccl_laser(api):
+    """... and with an evolving laser pulse: the envelope's two time levels of every slice travel behind the slice's beam
+    message (here there is no beam), with a whole step of receive look-ahead; envelope and checksums of four steps equal
+    one engine that rotates its own time levels."""
+    import torch
+    from hipace_amd.pipeline import RcclSelfRing, run_pipeline
+    d = decks.laser_blowout_wake()
+    d.update(nx=32, ny=32, nz=16, lo=(-16.0, -16.0, -4.0), hi=(16.0, 16.0, 4.0), laser_a0=1.5, laser_lambda0=0.4, laser_solver=1, dt=5.0)
+    ref = api.SliceEngine(d)
+    ref.set_diagnostics(True)
+    want = {}
+    for s in range(4):
+        ref.run_step()
+        want[s] = (ref.checksums(), ref.laser_envelope().copy())
+    eng = api.SliceEngine(d)
+    eng.set_diagnostics(True)
+    T = RcclSelfRing(0)
+    got = {}
+    run_pipeline(eng, 0, 1, 4, torch.device("cuda", 0), on_step_end=lambda s: got.__setitem__(s, (eng.checksums(), eng.laser_envelope().copy())), transport=T)
+    assert T.stats()["sent"] == 3 * d["nz"]
+    for s in range(4):
+        assert np.abs(got[s][1] - want[s][1]).max() <= 1e-12 * np.abs(want[s][1]).max(), s
+        for k, v in want[s][0].items():
+            assert abs(got[s][0][k] - v) <= 1e-10 * max(abs(v), 1e-300), (s, k)
+    T.close()
