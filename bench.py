@@ -144,6 +144,10 @@ def main():
                     help="BASELINE config 5: laser_blowout_wake 1024x1024x2048, 4 ppc, a Gaussian laser pulse drives the wake "
                          "and is advanced by the envelope solver on every slice; the time levels of the envelope stay in HBM "
                          "(not the judged bench line)")
+    ap.add_argument("--ring-self", action="store_true",
+                    help="one GPU, but every slice's hand-off goes through the RCCL ring (hipace_amd.pipeline.RcclSelfRing): the "
+                         "multi-rank code path with the rank as its own neighbour -- what the ring costs per slice.  Needs "
+                         "--steps >= 2 boxes")
     ap.add_argument("--fuse", action="store_true",
                     help="fused schedule: the push of slice k also deposits the currents of slice k-1 (hps_engine_set_fusion)")
     ap.add_argument("--no-ionization", action="store_true", help="--config5 without the ionisable species")
@@ -210,7 +214,7 @@ def main():
     if args.fuse:
         for e in engines:
             e.set_fusion(True)
-    short = args.steps < nz and lanes == 1
+    short = args.steps < nz and lanes == 1 and not args.ring_self
     stride = args.profile_stride if args.profile_stride > 0 else (1 if args.steps < 64 else 7)
     dev = torch.device("cuda", local)
 
@@ -301,6 +305,10 @@ def main():
         t0 = time.perf_counter()
         if lanes > 1:
             args.steps = run_local_pipeline(engines, max(1, args.steps // nz), dev)
+        elif world == 1 and args.ring_self:
+            from hipace_amd.pipeline import RcclSelfRing, run_pipeline
+            transport = RcclSelfRing(local)
+            args.steps = run_pipeline(eng, 0, 1, max(2, args.steps // nz), dev, transport=transport)
         elif world == 1:
             run_slices(args.steps)
         else:
