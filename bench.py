@@ -349,7 +349,7 @@ def main():
             per_kernel = {k: (v if k == dom else None) for k, v in per_kernel.items()}
         achieved = ab[dom] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         headline = args.tile == 16 and args.n == 1024 and args.ppc == 2 and not args.config5 and not args.config2
-        traffic, traffic_source = pmc_traffic("void hps::k_deposit_tiled<2, 16, 51>") if headline else (None, None)
+        traffic, traffic_source = pmc_traffic("void hps::k_deposit_tiled<2, 16, 51") if headline else (None, None)
         out = {
             "metric": "transverse slices/s at 256^2 x 4ppc (predictor-corrector solver)" if args.config2 else
                       f"transverse slices/s at 1024^2 x 4ppc with a laser envelope (explicit solver, {args.laser_solver} envelope solver)" if args.config5 else
