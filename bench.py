@@ -233,6 +233,9 @@ def main():
     if world > 1:
         from hipace_amd.pipeline import RcclTransport
         transport = RcclTransport(rank, world, local)          # communicators are created before the clock starts
+    elif args.ring_self:
+        from hipace_amd.pipeline import RcclSelfRing
+        transport = RcclSelfRing(local)
 
     clock = {}
     stats0 = {}
@@ -306,8 +309,7 @@ def main():
         if lanes > 1:
             args.steps = run_local_pipeline(engines, max(1, args.steps // nz), dev)
         elif world == 1 and args.ring_self:
-            from hipace_amd.pipeline import RcclSelfRing, run_pipeline
-            transport = RcclSelfRing(local)
+            from hipace_amd.pipeline import run_pipeline
             args.steps = run_pipeline(eng, 0, 1, max(2, args.steps // nz), dev, transport=transport)
         elif world == 1:
             run_slices(args.steps)
