@@ -14,11 +14,19 @@ eng = api.SliceEngine(deck, tile_size=16, sort_period=128)
 eng.begin_step()
 for k in range(64): eng.solve_slice(1023 - k)
 eng.sync()
-T = pipeline.RcclSelfRing(0)
+PLAIN = "--plain" in sys.argv
+T = None if PLAIN else pipeline.RcclSelfRing(0)
 for n in ("solve_slice", "record_event", "wait_event", "begin_step", "set_beam_storage"): timed(eng, n)
-for n in ("send", "recv", "engine_wait", "sendrecv_self"): timed(T, n, "T." + n)
+if T is not None:
+    for n in ("send", "recv", "engine_wait", "sendrecv_self"): timed(T, n, "T." + n)
 t0 = time.perf_counter()
-solved = pipeline.run_pipeline(eng, 0, 1, 2, torch.device("cuda", 0), slices_per_step=300, transport=T)
+if PLAIN:
+    solved = 0
+    for s in range(2):
+        eng.begin_step()
+        for k in range(300): eng.solve_slice(1023 - k); solved += 1
+else:
+    solved = pipeline.run_pipeline(eng, 0, 1, 2, torch.device("cuda", 0), slices_per_step=300, transport=T)
 eng.sync()
 dt = time.perf_counter() - t0
 print("slices", solved, "wall ms/slice", 1e3*dt/solved)
