@@ -8,6 +8,13 @@
 #include "particle_math.h"
 
 void mg_rider (void* mg_handle, int** dev_words, const int** host_words);     // multigrid.hip
+namespace hps {
+// hps_mg_solve1 in two halves (multigrid.hip): kernels enqueued between them are gated on mg_gate_after_enqueued
+int mg_solve1_begin (void* mg_handle, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, double tol_rel, double tol_abs,
+                     int max_iters, hipStream_t st);
+const int* mg_gate_after_enqueued (void* mg_handle);
+int mg_solve1_finish (void* mg_handle, int* iters_out, double* resnorm_out, int* extra, hipStream_t st);
+}
 
 namespace hps {
 
@@ -38,6 +45,7 @@ struct Engine {
     std::vector<double> prof_r, prof_t, prof_f_t; double* d_prof_r = nullptr; double prof_ft = 1.0;
     // fused push(k) + deposit(k-1) (k_advance_deposit_tiled): ahead_for = slice whose plasma currents are already deposited
     bool fuse_push_deposit = false; int ahead_for = -2;
+    bool gate_push = true;                      // push enqueued behind the multigrid's V-cycles, gated on its stopping rule (HPS_GATED_PUSH=0: off)
     int step_index = -1;           // time step that has begun (the ionisation draws are keyed by it)
     IonArgs ion_args (int islice);             // ionization.hip: kernel arguments of this slice's ionisation
     int ionize_slice (int islice);             // ...: launch of the per-particle form

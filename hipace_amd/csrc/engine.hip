@@ -6,6 +6,7 @@
 #include "engine.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -19,7 +20,7 @@ int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hp
                             hipStream_t st, int aabs_comp = -1, const int* tile_flag = nullptr);
 int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], double charge,
                           double mass, int order, int temp_slice, int n_subcycles, int can_ionize, Tiling* T,
-                          int* n_fallback, hipStream_t st, int aabs_comp = -1, const IonArgs* ion = nullptr);
+                          int* n_fallback, hipStream_t st, int aabs_comp = -1, const IonArgs* ion = nullptr, const int* go = nullptr);
 int advance_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], const int dep_comp[6],
                            double charge, double mass, int order, int n_subcycles, double max_qsa, int* n_qsa, Tiling* T,
                            int* n_fallback, hipStream_t st);
@@ -502,6 +503,7 @@ int Engine::create (const hps_deck& deck, int device)
     if (d.n_subcycles == 0) d.n_subcycles = 1;       // <plasma>.n_subcycles default (particles/plasma/PlasmaParticleContainer.H:182)
     if (d.field_bc != 0) { set_error("hps_engine_create: only boundary.field = Dirichlet is built"); return HPS_ERR_UNSUPPORTED; }
     pc = (d.bxby_solver != 0);
+    if (const char* v = std::getenv("HPS_GATED_PUSH")) gate_push = std::atoi(v) != 0;
     HPS_REQUIRE(!(d.beam_spin_tracking && d.dt == 0.0), "hps_engine_create: spin tracking needs a moving beam (hipace.dt != 0)");
     if (d.predcorr_tol > 0.0) pc_tol = d.predcorr_tol;
     if (d.predcorr_max_iter > 0) pc_max_iter = d.predcorr_max_iter;
@@ -779,11 +781,22 @@ int Engine::species_advance (const hps_plasma& p, Tiling* T, const int comp[5], 
     return HPS_OK;
 }
 
+// HPS_EVENT_FENCE: 0 = HIP's default system-scope release at every event, 1 (default) = none at the engine's own
+// events (their consumers are streams of this device; measured: ring hand-off 14 us per slice cheaper),
+// 2 = none at the ring's events either (no further gain)
+unsigned event_flags (bool timing)
+{
+    static const int mode = [] { const char* v = std::getenv("HPS_EVENT_FENCE"); return v ? std::atoi(v) : 1; }();
+    unsigned f = timing ? 0u : (unsigned)hipEventDisableTiming;
+    if (mode >= 1) f |= timing ? (unsigned)hipEventReleaseToDevice : (unsigned)hipEventDisableSystemFence;
+    return f;
+}
+
 void Engine::mark ()
 {
     if (!prof_now) return;
     const int k = (int)(ev_used % 11);                  // which of the 11 marks of a slice this is
-    if (ev_used == ev.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev.push_back(e); }
+    if (ev_used == ev.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, event_flags(true)); ev.push_back(e); }
     // light mode: only the marks around the deposition kernel (2, 3) and the kernel-free pair (4, 5)
     if (!prof_light || (k >= 2 && k <= 5)) (void)hipEventRecord(ev[ev_used], st);
     ++ev_used;
@@ -1271,11 +1284,26 @@ int Engine::solve_slice (int islice)
         if (ion.n > 0) { if ((e = species_explicit(ion.pl, ion.tiling, cache, depos, d.ion_charge, d.ion_mass, 1))) return e; } }
 
     mark();   // b5
-    // Bx, By: Helmholtz multigrid from the previous slice's field (Hipace.cpp:793-933)
-    {   int iters = 0;
-        if ((e = hps_mg_solve1(mg, slab, HPS_C_BX, HPS_C_SY, HPS_C_CHI, d.mg_tol_rel, d.mg_tol_abs, 200, &iters, nullptr, st))) return e;
-        total_vcycles += iters; }
+    // Bx, By: Helmholtz multigrid from the previous slice's field (Hipace.cpp:793-933).  The plain case (one tile-sorted
+    // species, nothing that reads the fields between the solve and the push) enqueues the push BEHIND the speculated
+    // V-cycles, gated on the solve's own stopping rule, and only then waits for the norms: the device goes from the last
+    // V-cycle straight into the push instead of idling until the host has seen the norms and launched it.
+    const bool fuse = fuse_push_deposit && tiling && islice > 0 && !moving && c_aabs < 0 && ion.n == 0 && np > 0 && tiling->sorted_n == np;
+    const bool gated = gate_push && tiling && !fuse && ion.n == 0 && np > 0 && tiling->sorted_n == np && !diagnostics && !d_fd && !d_insitu;
+    const int comp_push[5] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ};
+    {   int iters = 0, extra = 0;
+        if ((e = mg_solve1_begin(mg, slab, HPS_C_BX, HPS_C_SY, HPS_C_CHI, d.mg_tol_rel, d.mg_tol_abs, 200, st))) return e;
+        if (gated) {
+            mark();   // b6
+            mark();   // b7
+            if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st, c_aabs, nullptr, mg_gate_after_enqueued(mg)))) return e;
+        }
+        if ((e = mg_solve1_finish(mg, &iters, nullptr, &extra, st))) return e;
+        total_vcycles += iters;
+        // the speculated V-cycles were not enough (the gated push has not run): the host has added the rest, push now
+        if (gated && extra) { if ((e = species_advance(pl, tiling, comp_push, d.plasma_charge, d.plasma_mass, 0, 0))) return e; } }
 
+    if (!gated) {
     mark();   // b6
     if (diagnostics)
         hipLaunchKernelGGL(k_checksum, dim3(64, ncomp), b256, 0, st, f, ncomp, d_checksum);
@@ -1285,7 +1313,7 @@ int Engine::solve_slice (int islice)
 
     mark();   // b7
     // gather + push (Hipace.cpp:699-701)
-    {   const int comp[5] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ};
+    {   const int* comp = comp_push;
         if (ion.n > 0) {
             // DoFieldIonization (Hipace.cpp:693-696), then the ions' own push; the host learns how many electrons the
             // slice has released while that push runs
@@ -1300,7 +1328,6 @@ int Engine::solve_slice (int islice)
         }
         // push of this slice and deposition of the next one in one pass over the sheet (static beam, no laser, one
         // plasma species, the whole sheet inside the tile-sorted body)
-        const bool fuse = fuse_push_deposit && tiling && islice > 0 && !moving && c_aabs < 0 && ion.n == 0 && np > 0 && tiling->sorted_n == np;
         if (fuse) {
             hipLaunchKernelGGL(k_shift_zero, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, bb, d.deposit_rho ? (int)HPS_C_RHO : -1);
             const int dep[6] = {HPS_C_JX, HPS_C_JY, -1, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_CHI, HPS_C_RHOMJZ};
@@ -1309,6 +1336,7 @@ int Engine::solve_slice (int islice)
         } else {
             if ((e = species_advance(pl, tiling, comp, d.plasma_charge, d.plasma_mass, 0, 0))) return e;
         } }
+    }
 
     // beam push and hand-off of the slipped particles (Hipace.cpp:704-706)
     insitu_beam(islice);
@@ -1495,7 +1523,7 @@ extern "C" int hps_engine_record_event (void* h, int slot, void** out)
     Engine* E = static_cast<Engine*>(h);
     HPS_REQUIRE(slot >= 0 && slot < (1 << 20) && out, "hps_engine_record_event: bad slot");
     if ((size_t)slot >= E->hand_ev.size()) E->hand_ev.resize((size_t)slot + 1, nullptr);
-    if (!E->hand_ev[slot]) HPS_HIP_CHECK(hipEventCreateWithFlags(&E->hand_ev[slot], hipEventDisableTiming));
+    if (!E->hand_ev[slot]) HPS_HIP_CHECK(hipEventCreateWithFlags(&E->hand_ev[slot], event_flags(false)));
     HPS_HIP_CHECK(hipEventRecord(E->hand_ev[slot], E->st));
     *out = E->hand_ev[slot];
     return HPS_OK;

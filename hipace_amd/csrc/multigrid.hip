@@ -18,6 +18,7 @@
 //  * k_lower_v: every level with <= 32x32 unknowns runs inside ONE 1024-thread workgroup with all
 //    its arrays in LDS (whole lower V incl. the 16 bottom sweeps), replacing ~4 launches per level.
 #include "common.h"
+#include "mg_gate.h"
 
 #include <vector>
 #include <algorithm>
@@ -153,28 +154,6 @@ __device__ __forceinline__ double prolong_at (const FView& crse, int i, int j, i
 // if V-cycle k-1 already met the target (an inactive V-cycle leaves its slot at 0, which switches
 // off all later ones).  k < 0: unconditional.
 constexpr int MG_MAX_VCYCLES = 1024;
-constexpr int MG_NSUB = 16;       // a norm slot is MG_NSUB words (workgroups spread their atomics: same-address
-                                  // L2 atomics serialise at ~20 ns each); its value is the maximum over them
-struct StopRule { const unsigned long long* norms; int k; double tol_rel, tol_abs; };
-
-__device__ __forceinline__ double norm_slot (const unsigned long long* norms, int slot)
-{
-    unsigned long long m = 0ULL;      // non-negative doubles order like their bit patterns
-#pragma unroll
-    for (int q = 0; q < MG_NSUB; ++q) { const unsigned long long v = norms[slot*MG_NSUB + q]; m = v > m ? v : m; }
-    return __longlong_as_double((long long)m);
-}
-
-__device__ __forceinline__ bool vcycle_active (const StopRule& sr)
-{
-    if (sr.k < 0) return true;
-    const double res0 = norm_slot(sr.norms, 0), rhs0 = norm_slot(sr.norms, 1);
-    const double prev = (sr.k == 0) ? res0 : norm_slot(sr.norms, 2 + sr.k - 1);
-    const double max_norm = (rhs0 >= res0) ? rhs0 : res0;
-    const double target = fmax(sr.tol_abs, fmax(sr.tol_rel, 1.e-16)*max_norm);
-    return prev > target && prev <= 1.e20*max_norm;
-}
-
 // max-norm accumulation: one fire-and-forget atomic per workgroup into one of the slot's words
 template <int NT>
 __device__ __forceinline__ void block_max_to (unsigned long long* slot, double v, double* s_red)
@@ -1055,6 +1034,9 @@ struct MGLevelDev { LevBox b; long cells; double *acf, *res, *cor, *rescor; };
 
 constexpr long LOWV_MAX_CELLS = 34*34;     // levels with at most ~32x32 unknowns run in k_lower_v (LDS resident)
 
+constexpr int MG_GO_WORD = 8;      // int word of the header slot that k_post_norms sets: 1 = the solve is over
+struct SolveRun { int enq, nspec, nzeroed, max_iters; double tol_rel, tol_abs; bool cc; };
+
 struct Multigrid {
     bool cc; int nx, ny; double dx, dy;
     std::vector<MGLevelDev> L;
@@ -1069,6 +1051,7 @@ struct Multigrid {
     unsigned long long* d_norms = nullptr;      // [0] residual, [1] rhs
     unsigned long long* h_norms = nullptr;      // pinned copy of d_norms (2 + MG_MAX_VCYCLES slots)
     int last_iters = 1;                         // V-cycles of the previous solve = speculation depth
+    SolveRun run{};                             // the solve between mg_solve1_begin and mg_solve1_finish
     bool use_low2 = false; Low2 low2{}; Low2* d_low2 = nullptr; size_t low2_lds = 0;   // cell-centred register/LDS lower V
     double* tmp0 = nullptr;                     // level-0 scratch: smoothed solution before the last GSRB^4
     bool fuse_level0 = true, cor_in_tmp = false; // fused 8-sweep end of the V-cycle; which buffer holds cor[0]
@@ -1275,17 +1258,38 @@ static void vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
 // polls it instead of a DMA copy + stream synchronise (one round trip per solve, two when the speculation fell short)
 __global__ __launch_bounds__(256)
 void k_post_norms (const unsigned long long* __restrict__ src, volatile unsigned long long* dst, int nwords,
-                   volatile unsigned long long* seq_slot, unsigned long long seq)
+                   volatile unsigned long long* seq_slot, unsigned long long seq, int* go_word, StopRule after)
 {
+    // one word for the kernels enqueued behind this solve before the host has seen its norms (the gated plasma push):
+    // is the solve over after the V-cycles enqueued so far?
+    if (threadIdx.x == 0) *go_word = vcycle_active(after) ? 0 : 1;
     for (int w = threadIdx.x; w < nwords; w += blockDim.x) dst[w] = src[w];
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) { *seq_slot = seq; }
 }
 
+// one batch of (gated) V-cycles and the post of all norms so far to the host
 template <bool CC>
-static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_iters, int* iters_out, double* resnorm_out,
-                        hipStream_t st)
+static void enqueue_cycles (Multigrid* M, hipStream_t st)
+{
+    SolveRun& r = M->run;
+    for (int v = 0; v < r.nspec && r.enq < r.max_iters; ++v, ++r.enq) {
+        if (r.enq >= r.nzeroed) {        // more slots than foreseen: zero the next batch (rare)
+            const int more = std::min(r.max_iters - r.nzeroed, 64);
+            (void)hipMemsetAsync(M->d_norms + (2 + r.nzeroed)*MG_NSUB, 0, more*MG_NSUB*sizeof(unsigned long long), st);
+            r.nzeroed += more;
+        }
+        vcycle<CC>(M, r.enq, r.tol_rel, r.tol_abs, st);
+    }
+    ++M->seq; ++M->dbg_trips;
+    hipLaunchKernelGGL(k_post_norms, dim3(1), dim3(256), 0, st, M->d_buf, (volatile unsigned long long*)M->h_buf_dev,
+                       (3 + r.enq)*MG_NSUB, (volatile unsigned long long*)M->h_seq_dev, M->seq,
+                       reinterpret_cast<int*>(M->d_buf) + MG_GO_WORD, StopRule{M->d_norms, r.enq, r.tol_rel, r.tol_abs});
+}
+
+template <bool CC>
+static int solve1_begin (Multigrid* M, double tol_rel, double tol_abs, int max_iters, hipStream_t st)
 {
     const int lb = M->lowv_begin;
     max_iters = std::min(max_iters, MG_MAX_VCYCLES);
@@ -1317,27 +1321,29 @@ static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_it
     launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), FView{}, M->rhs, M->acf0, M->sol, FView{}, M->lv(0, M->L[0].rescor),
                                         M->lv(1, M->L[1].res), M->d_norms, M->d_norms + MG_NSUB, always, st);
     restrict_residual_if_nodal<CC>(M, 0, always, st);
+    M->run = SolveRun{0, nspec, nzeroed, max_iters, tol_rel, tol_abs, CC};
+    enqueue_cycles<CC>(M, st);
+    HPS_HIP_CHECK(hipGetLastError());
+    return HPS_OK;
+}
+
+// read the norms back, replay the stopping rule on the host (solve_doit :1352-1398), enqueue one more V-cycle at a time
+// while it says so.  *extra: did that happen (then kernels gated on gate_after_enqueued() have not run)?
+template <bool CC>
+static int solve1_finish (Multigrid* M, int* iters_out, double* resnorm_out, int* extra, hipStream_t st)
+{
+    SolveRun& r = M->run;
     int status = HPS_OK;
-    int enq = 0, iters = 0;
+    int iters = 0;
     double last_norm = 0.0;
-    bool converged = false, diverged = false;
+    bool converged = false, diverged = false, first_trip = true;
+    if (extra) *extra = 0;
     auto slot_value = [M] (int slot) {
         unsigned long long m = 0ULL;
         for (int q = 0; q < MG_NSUB; ++q) m = std::max(m, M->h_norms[slot*MG_NSUB + q]);
         double dd; memcpy(&dd, &m, 8); return dd;
     };
     while (true) {
-        for (int v = 0; v < nspec && enq < max_iters; ++v, ++enq) {
-            if (enq >= nzeroed) {        // more slots than foreseen: zero the next batch (rare)
-                const int more = std::min(max_iters - nzeroed, 64);
-                HPS_HIP_CHECK(hipMemsetAsync(M->d_norms + (2 + nzeroed)*MG_NSUB, 0, more*MG_NSUB*sizeof(unsigned long long), st));
-                nzeroed += more;
-            }
-            vcycle<CC>(M, enq, tol_rel, tol_abs, st);
-        }
-        ++M->seq; ++M->dbg_trips;
-        hipLaunchKernelGGL(k_post_norms, dim3(1), dim3(256), 0, st, M->d_buf, (volatile unsigned long long*)M->h_buf_dev,
-                           (3 + enq)*MG_NSUB, (volatile unsigned long long*)M->h_seq_dev, M->seq);
         {   volatile unsigned long long* hs = M->h_seq;
             long spins = 0;
             while (*hs != M->seq) {
@@ -1348,20 +1354,28 @@ static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_it
                 }
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE); }
-        // replay the stopping rule on the host (solve_doit :1352-1398)
         const double res0 = slot_value(0), rhs0 = slot_value(1);
         const double max_norm = (rhs0 >= res0) ? rhs0 : res0;
-        const double target = std::max(tol_abs, std::max(tol_rel, 1.e-16)*max_norm);
+        const double target = std::max(r.tol_abs, std::max(r.tol_rel, 1.e-16)*max_norm);
         last_norm = res0; iters = 0;
         converged = (res0 <= target); diverged = false;
-        for (int k = 0; k < enq && !converged && !diverged; ++k) {
+        for (int k = 0; k < r.enq && !converged && !diverged; ++k) {
             last_norm = slot_value(2 + k); ++iters;
             if (last_norm <= target) converged = true;
             else if (!(last_norm <= 1.e20*max_norm)) diverged = true;
         }
+        if (first_trip) {
+            // what the device-side gate of the kernels enqueued behind the first batch has seen (vcycle_active, k = enq)
+            const double prev = (r.enq == 0) ? res0 : slot_value(2 + r.enq - 1);
+            const bool gate_active = prev > target && prev <= 1.e20*max_norm;
+            if (gate_active != !(converged || diverged)) { set_error("hps_mg_solve1: host and device stopping rules disagree"); return HPS_ERR_HIP; }
+            if (extra) *extra = gate_active ? 1 : 0;
+            first_trip = false;
+        }
         if (converged || diverged) break;
-        if (enq >= max_iters) { set_error("hps_mg_solve1: not converged after max_iters V-cycles"); status = HPS_ERR_MG_MAXITER; break; }
-        nspec = 1;
+        if (r.enq >= r.max_iters) { set_error("hps_mg_solve1: not converged after max_iters V-cycles"); status = HPS_ERR_MG_MAXITER; break; }
+        r.nspec = 1;
+        enqueue_cycles<CC>(M, st);
     }
     if (diverged) { set_error("hps_mg_solve1: diverging"); status = HPS_ERR_MG_DIVERGED; }
     M->last_iters = std::max(1, iters); ++M->dbg_solves; ++M->dbg_hist[std::min(iters, 7)];
@@ -1377,8 +1391,7 @@ static int solve1_impl (Multigrid* M, double tol_rel, double tol_abs, int max_it
     return status;
 }
 
-int mg_solve1 (Multigrid* M, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, double tol_rel, double tol_abs,
-               int max_iters, int* iters_out, double* resnorm_out, hipStream_t st)
+static void set_views (Multigrid* M, const hps_slab& s, int sol_comp, int rhs_comp, int acf_comp)
 {
     // centre the slab box on the level-0 box (center_box, HpMultiGrid.H:168-175)
     const int sh = M->cc ? 0 : 1;
@@ -1386,8 +1399,32 @@ int mg_solve1 (Multigrid* M, hps_slab s, int sol_comp, int rhs_comp, int acf_com
     M->sol  = FView{s.p + (long)sol_comp*s.nstride, s.jstride, s.nstride, o, o};
     M->rhs  = FView{s.p + (long)rhs_comp*s.nstride, s.jstride, s.nstride, o, o};
     M->acf0 = FView{s.p + (long)acf_comp*s.nstride, s.jstride, s.nstride, o, o};
-    return M->cc ? solve1_impl<true>(M, tol_rel, tol_abs, max_iters, iters_out, resnorm_out, st)
-                 : solve1_impl<false>(M, tol_rel, tol_abs, max_iters, iters_out, resnorm_out, st);
+}
+
+// the solve in two halves: begin enqueues the speculated V-cycles and the post of their norms; finish waits for the
+// norms.  Kernels enqueued in between must be gated on the word at mg_gate_after_enqueued (they run iff it is 1: the solve is over).
+int mg_solve1_begin (void* handle, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, double tol_rel, double tol_abs,
+                     int max_iters, hipStream_t st)
+{
+    Multigrid* M = static_cast<Multigrid*>(handle);
+    set_views(M, s, sol_comp, rhs_comp, acf_comp);
+    return M->cc ? solve1_begin<true>(M, tol_rel, tol_abs, max_iters, st) : solve1_begin<false>(M, tol_rel, tol_abs, max_iters, st);
+}
+const int* mg_gate_after_enqueued (void* handle)
+{
+    return reinterpret_cast<const int*>(static_cast<Multigrid*>(handle)->d_buf) + MG_GO_WORD;
+}
+int mg_solve1_finish (void* handle, int* iters_out, double* resnorm_out, int* extra, hipStream_t st)
+{
+    Multigrid* M = static_cast<Multigrid*>(handle);
+    return M->cc ? solve1_finish<true>(M, iters_out, resnorm_out, extra, st) : solve1_finish<false>(M, iters_out, resnorm_out, extra, st);
+}
+
+int mg_solve1 (Multigrid* M, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, double tol_rel, double tol_abs,
+               int max_iters, int* iters_out, double* resnorm_out, hipStream_t st)
+{
+    if (int e = mg_solve1_begin(M, s, sol_comp, rhs_comp, acf_comp, tol_rel, tol_abs, max_iters, st)) return e;
+    return mg_solve1_finish(M, iters_out, resnorm_out, nullptr, st);
 }
 
 } // namespace hps

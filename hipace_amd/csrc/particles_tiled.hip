@@ -398,10 +398,14 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
 template <int ORDER, int TS, bool LASER = false, bool IONIZE = false>
 __global__ __launch_bounds__(256)
 void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
-                      int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, int* n_fallback, IonArgs ia)
+                      int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, int* n_fallback, IonArgs ia, const int* go)
 {
     constexpr int R = TS + 2*TILE_HALO;
     constexpr int NS = ORDER + 2;
+    // enqueued behind a multigrid solve whose norms the host has not seen yet: run only if that solve is over (*go == 1,
+    // set by the solve's k_post_norms; else the host adds V-cycles and launches the push again).  The word is loaded
+    // here and looked at after the field image's loads are in flight.
+    const int go_now = go ? *go : 1;
     int charged = 0;          // IONIZE: does this thread hold an ion of level > 0 after the slice?
     extern __shared__ __attribute__((aligned(16))) double img[];     // [5][R*R]
     const int tile = offsets[gridDim.x + 2 + blockIdx.x];     // launch order: heaviest tile first (sort.hip)
@@ -411,6 +415,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     load_region<R>(img, f, cc, 5, ox, oy, tid);
     double* aimg = img + 5*R*R;           // LASER: |a|^2 over the tile region
     if constexpr (LASER) { const int ca[1] = {k.aabs}; load_region<R>(aimg, f, ca, 1, ox, oy, tid); }
+    if (!go_now) return;
     __syncthreads();
 
     // (prefetching the next particle's state during the push was measured: 225 VGPRs, same 185 us --
@@ -802,7 +807,7 @@ int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hp
 
 int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], double charge,
                           double mass, int order, int temp_slice, int n_subcycles, int can_ionize, Tiling* T,
-                          int* n_fallback, hipStream_t st, int aabs_comp, const IonArgs* ion)
+                          int* n_fallback, hipStream_t st, int aabs_comp, const IonArgs* ion, const int* go)
 {
     if (pl.n == 0) return HPS_OK;
     PartConsts k = base_consts(g);
@@ -815,7 +820,7 @@ int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_
     const IonArgs ia = ion ? *ion : IonArgs{};
 #define HPS_ADV(O, S, L, I) { if (int e = set_lds(k_advance_tiled<O, S, L, I>, lds)) return e; \
         hipLaunchKernelGGL((k_advance_tiled<O, S, L, I>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
-                           comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback, ia); }
+                           comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback, ia, go); }
 #define CALL(O, S) { if (ion) { if (aabs_comp >= 0) HPS_ADV(O, S, true, true) else HPS_ADV(O, S, false, true) } \
                      else     { if (aabs_comp >= 0) HPS_ADV(O, S, true, false) else HPS_ADV(O, S, false, false) } }
     HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
@@ -916,5 +921,5 @@ extern "C" int hps_advance_plasma_tiled (hps_slab slab, hps_plasma pl, hps_geom 
     if (int e = check_stencil(slab, (order + 1)/2 + 1, "hps_advance_plasma_tiled")) return e;
     if (int e = check_tiling(tiling, slab, pl, "hps_advance_plasma_tiled")) return e;
     return advance_plasma_tiled(slab, pl, g, comp, charge, mass, order, temp_slice, n_subcycles, can_ionize,
-                                static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr);
+                                static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr, nullptr);
 }

@@ -16,6 +16,7 @@
 #include "common.h"
 
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -91,7 +92,8 @@ int event_of (std::vector<hipEvent_t>& pool, int slot, hipEvent_t* out)
 {
     HPS_REQUIRE(slot >= 0 && slot < (1 << 20), "hps_ring: bad event slot");
     if ((size_t)slot >= pool.size()) pool.resize((size_t)slot + 1, nullptr);
-    if (!pool[slot]) HPS_HIP_CHECK(hipEventCreateWithFlags(&pool[slot], hipEventDisableTiming));
+    static const bool nofence = [] { const char* v = std::getenv("HPS_EVENT_FENCE"); return v && std::atoi(v) >= 2; }();
+    if (!pool[slot]) HPS_HIP_CHECK(hipEventCreateWithFlags(&pool[slot], hipEventDisableTiming | (nofence ? hipEventDisableSystemFence : 0u)));
     *out = pool[slot];
     return HPS_OK;
 }
