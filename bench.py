@@ -144,6 +144,8 @@ def main():
                     help="BASELINE config 5: laser_blowout_wake 1024x1024x2048, 4 ppc, a Gaussian laser pulse drives the wake "
                          "and is advanced by the envelope solver on every slice; the time levels of the envelope stay in HBM "
                          "(not the judged bench line)")
+    ap.add_argument("--handoff-batch", type=int, default=8,
+                    help="slices per beam hand-off group on the ring (hipace_amd.pipeline.run_pipeline); 1 = one hand-off per slice")
     ap.add_argument("--ring-self", action="store_true",
                     help="one GPU, but every slice's hand-off goes through the RCCL ring (hipace_amd.pipeline.RcclSelfRing): the "
                          "multi-rank code path with the rank as its own neighbour -- what the ring costs per slice.  Needs "
@@ -245,10 +247,13 @@ def main():
         start = args.start_slice if args.start_slice >= 0 else (START_SLICE_DEFAULT * nz) // 1024
         start = max(0, min(start, nz - args.steps - args.warmup))
         lead = start + args.warmup                              # untimed slices of rank 0
-        lead = max(lead, 2 * (world - 1))                       # every rank needs a non-negative untimed part
+        # rank r runs `lag` slices behind rank r-1: it needs the beam of its next slice, which arrives with that
+        # slice's hand-off group (run_pipeline's handoff_batch), and one slice of slack on top
+        lag = 2 if args.handoff_batch <= 1 else args.handoff_batch + 2
+        lead = max(lead, lag * (world - 1))                     # every rank needs a non-negative untimed part
         assert lead + args.steps <= nz, "window does not fit the box"
-        counts = [lead - 2 * r + args.steps for r in range(world)]
-        first = lead - 2 * rank
+        counts = [lead - lag * r + args.steps for r in range(world)]
+        first = lead - lag * rank
         timed_first = first
 
         def on_slice(m, q):
@@ -274,7 +279,8 @@ def main():
             on_slice(0, counts[0])
         else:
             from hipace_amd.pipeline import run_pipeline
-            run_pipeline(eng, rank, world, world, dev, slices_per_step=counts, transport=transport, on_slice=on_slice)
+            run_pipeline(eng, rank, world, world, dev, slices_per_step=counts, transport=transport, on_slice=on_slice,
+                         handoff_batch=args.handoff_batch)
         barrier()
         dt = clock["t1"] - clock["t0"]
     else:
@@ -310,14 +316,14 @@ def main():
             args.steps = run_local_pipeline(engines, max(1, args.steps // nz), dev)
         elif world == 1 and args.ring_self:
             from hipace_amd.pipeline import run_pipeline
-            args.steps = run_pipeline(eng, 0, 1, max(2, args.steps // nz), dev, transport=transport)
+            args.steps = run_pipeline(eng, 0, 1, max(2, args.steps // nz), dev, transport=transport, handoff_batch=args.handoff_batch)
         elif world == 1:
             run_slices(args.steps)
         else:
             # ring pipeline over time steps: every rank sweeps whole boxes; the beam slices travel rank -> rank+1
             from hipace_amd.pipeline import run_pipeline
             steps_per_rank = max(1, args.steps // nz)
-            args.steps = run_pipeline(eng, rank, world, world * steps_per_rank, dev, transport=transport)
+            args.steps = run_pipeline(eng, rank, world, world * steps_per_rank, dev, transport=transport, handoff_batch=args.handoff_batch)
         barrier()
         dt = time.perf_counter() - t0
     phases, nprof = eng.phase_times()

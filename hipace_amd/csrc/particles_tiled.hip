@@ -404,7 +404,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     constexpr int NS = ORDER + 2;
     // enqueued behind a multigrid solve whose norms the host has not seen yet: run only if that solve is over (*go == 1,
     // set by the solve's k_post_norms; else the host adds V-cycles and launches the push again).  The word is loaded
-    // here and looked at after the field image's loads are in flight.
+    // here and looked at behind the barrier that waits for the field image anyway.
     const int go_now = go ? *go : 1;
     int charged = 0;          // IONIZE: does this thread hold an ion of level > 0 after the slice?
     extern __shared__ __attribute__((aligned(16))) double img[];     // [5][R*R]
@@ -415,8 +415,8 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     load_region<R>(img, f, cc, 5, ox, oy, tid);
     double* aimg = img + 5*R*R;           // LASER: |a|^2 over the tile region
     if constexpr (LASER) { const int ca[1] = {k.aabs}; load_region<R>(aimg, f, ca, 1, ox, oy, tid); }
-    if (!go_now) return;
     __syncthreads();
+    if (!go_now) return;
 
     // (prefetching the next particle's state during the push was measured: 225 VGPRs, same 185 us --
     //  the kernel is bound by its fp64 instruction stream, not by load latency)

@@ -64,6 +64,10 @@ class GlooTransport:
         if ev is not None and not ev.is_completed():
             ev.wait()
 
+    def engine_wait_ordered(self, engine, evs):
+        for ev in evs:
+            self.engine_wait(engine, ev)
+
     def recv_after(self, ev):
         if ev is not None and hasattr(ev, "wait") and not ev.is_completed():
             ev.wait()
@@ -128,6 +132,11 @@ class RcclTransport:
     def engine_wait(self, engine, ev):
         engine.wait_event(ev)
 
+    def engine_wait_ordered(self, engine, evs):
+        """events of receives in the order they were posted: they complete in that order (one stream), the last one says it all"""
+        if evs:
+            self.engine_wait(engine, evs[-1])
+
     def recv_after(self, ev):
         if ev:
             self._check(self._lib.hps_ring_stream_wait(self._h, 0, C.c_void_p(ev)))
@@ -185,6 +194,11 @@ class RcclSelfRing(RcclTransport):
             ev = self._done.pop(ev[1])
         engine.wait_event(ev)
 
+    def engine_wait_ordered(self, engine, evs):
+        evs = [self._done.pop(ev[1]) if isinstance(ev, tuple) else ev for ev in evs]
+        if evs:
+            engine.wait_event(evs[-1])
+
     def recv_after(self, ev):
         if ev:
             self._check(self._lib.hps_ring_stream_wait(self._h, 1, C.c_void_p(ev)))
@@ -210,7 +224,7 @@ _EV_SLICE, _EV_STEP, _EV_LFREE = 0, 64, 80
 
 
 def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_per_step=None, transport=None,
-                 laser_lookahead=8, on_slice=None):
+                 laser_lookahead=8, on_slice=None, handoff_batch=8):
     """Run steps rank, rank+world, ... < n_steps of `engine` with the per-slice ring hand-off.
 
     engine: SliceEngine-like (begin_step, solve_slice, sync, record_event, wait_event, copy_async, beam_layout,
@@ -219,6 +233,10 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
     box); a list with one entry per rank (non-increasing, n_steps <= world) lets the ranks stop at different slices --
     the pre-filled pipeline of bench.py.  on_slice(m, q): called before slice q (from the head) of this rank's m-th
     step is solved, and once more with q = number of slices after the last one.
+    handoff_batch: a static beam (hipace.dt = 0, no laser) is handed on in groups of this many slices -- one event on the
+    engine's stream and one wait per group instead of per slice (measured on the RCCL ring: each costs the engine
+    about 10 us); the rank behind runs that many slices later, nothing else changes.  A moving beam and a laser are
+    handed on slice by slice.
     Returns the number of slices this rank solved.
     """
     nz = engine.deck["nz"]
@@ -256,6 +274,7 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
             engine.initial_beam_into(bufs[0])        # only the head rank injects the beam (as the reference)
     spool_done = [None] * (len(spool) if spool else 0)
     ring_laser = laser and ring                      # one rank without a transport: the engine rotates its own time levels
+    batch = 1 if (moving or ring_laser) else max(1, int(handoff_batch))
     lookahead = per_prev
     lpool, lspool = [], []
     if ring_laser:
@@ -301,6 +320,7 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
             state["posted"] += 1
 
     solved = 0
+    held = []                                         # static beam blocks waiting for their group's hand-off
     for m, step in enumerate(my_steps):
         fed = step > 0
         from_ring = fed and ring
@@ -327,7 +347,13 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
                 post_until(pos + lookahead + 1)
             if from_ring:
                 need = min(q + 1, per_prev - 1)        # this slice's beam and the next one's (jx/jy source)
+                if batch > 1:                          # ... which arrive with the rest of their group
+                    need = min((need // batch + 1) * batch - 1, per_prev - 1)
                 post_until(fed_index[m] * per_prev + need + 1)
+                if batch > 1 and imported < need:
+                    evs = [recv_ev.pop((m, j, 0), None) for j in range(imported + 1, need + 1)]
+                    T.engine_wait_ordered(engine, [ev[0] for ev in evs if ev is not None])
+                    imported = need
                 while imported < need:
                     imported += 1
                     ev = recv_ev.pop((m, imported, 0), None)
@@ -366,7 +392,9 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
                     else:
                         blk = block(bufs[m % 2], q)
                         if blk.numel() > 0:
-                            out.append(("s", q, blk))
+                            held.append(("s", q, blk))
+                        if (q + 1) % batch == 0 or q == per - 1:
+                            out, held = held, []
                     if ring_laser:
                         k = state["nls"] % len(lspool)
                         state["nls"] += 1

@@ -238,7 +238,7 @@ def test_laser_envelope_travels_between_ranks(oracle, world, n_steps):
             assert abs(got[s][0][k] - v) <= 1e-12 * max(abs(v), 1e-300), (s, k)
 
 
-def _prefilled_worker(rank, world, port, counts, out):
+def _prefilled_worker(rank, world, port, counts, batch, out):
     import torch.distributed as dist
     from hipace_amd.pipeline import run_pipeline
     from oracle import oracle as O
@@ -255,24 +255,25 @@ def _prefilled_worker(rank, world, port, counts, out):
             dist.barrier()
             marks["paused_at"] = q
 
-    solved = run_pipeline(eng, rank, world, world, "cpu", slices_per_step=counts, on_slice=on_slice)
+    solved = run_pipeline(eng, rank, world, world, "cpu", slices_per_step=counts, on_slice=on_slice, handoff_batch=batch)
     out.put((rank, solved, seen, marks, eng.checksums()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_prefilled_pipeline_with_rank_dependent_slice_counts(oracle, world):
-    """bench.py's short timed runs: rank r solves 2r slices fewer than rank 0, so that all ranks can pause at a barrier
-    with the pipeline filled (rank r-1 two slices ahead of rank r) and then time the same number of slices each.  The
-    ranks stop at different slices, the barrier inside the run does not deadlock, and what a later rank computed for its
-    slices equals the single-process result for those slices."""
+@pytest.mark.parametrize("world,batch", [(2, 1), (3, 1), (2, 3), (3, 2)])
+def test_prefilled_pipeline_with_rank_dependent_slice_counts(oracle, world, batch):
+    """bench.py's short timed runs: rank r solves lag*r slices fewer than rank 0 (lag = 2, or the hand-off group + 2), so
+    that all ranks can pause at a barrier with the pipeline filled (rank r-1 that far ahead of rank r) and then time the
+    same number of slices each.  The ranks stop at different slices, the barrier inside the run does not deadlock, and
+    what a later rank computed for its slices equals the single-process result for those slices."""
     n0 = 16
-    counts = [n0 - 2 * r for r in range(world)]
+    lag = 2 if batch == 1 else batch + 2
+    counts = [n0 - lag * r for r in range(world)]
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_prefilled_worker, args=(r, world, port, counts, out)) for r in range(world)]
+    procs = [ctx.Process(target=_prefilled_worker, args=(r, world, port, counts, batch, out)) for r in range(world)]
     for p in procs:
         p.start()
     results = [out.get(timeout=240) for _ in range(world)]
