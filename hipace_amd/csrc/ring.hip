@@ -147,6 +147,28 @@ extern "C" int hps_ring_init (int rank, int world, int device, const char* id_ed
             if (r != 0) { hps_ring_destroy(R); hps::set_error(std::string("hps_ring_init: ncclCommInitRank: ") + g_rccl.GetErrorString(r)); return HPS_ERR_COMM; }
         }
     }
+    // One message around every edge now: RCCL connects a peer on the first send / receive, and the first launch of its
+    // kernel makes the runtime set up that queue's scratch -- measured on MI355X as one stall of 35-50 ms of ALL streams
+    // of the process, in the middle of the first step that carries a beam, if it is left to the first hand-off.
+    {   const size_t nb = 1 << 20;
+        char* tmp = nullptr;
+        if (hipMalloc(&tmp, 2*nb) != hipSuccess) { hps_ring_destroy(R); hps::set_error("hps_ring_init: out of device memory"); return HPS_ERR_HIP; }
+        (void)hipMemset(tmp, 0, 2*nb);
+        ncclResult_t r1 = 0, r2 = 0, r3 = 0, r4 = 0;
+        if (world == 1) {
+            r3 = g_rccl.GroupStart();
+            r1 = g_rccl.Send(tmp, nb, 0, 0, R->comm_self, R->st_send);
+            r2 = g_rccl.Recv(tmp + nb, nb, 0, 0, R->comm_self, R->st_send);
+            r4 = g_rccl.GroupEnd();
+        } else {
+            r1 = g_rccl.Send(tmp, nb, 0, 1, R->comm_out, R->st_send);
+            r2 = g_rccl.Recv(tmp + nb, nb, 0, 0, R->comm_in, R->st_recv);
+        }
+        const hipError_t h1 = hipStreamSynchronize(R->st_send), h2 = hipStreamSynchronize(R->st_recv);
+        (void)hipFree(tmp);
+        if (r1 != 0 || r2 != 0 || r3 != 0 || r4 != 0 || h1 != hipSuccess || h2 != hipSuccess) {
+            hps_ring_destroy(R); hps::set_error("hps_ring_init: the warm-up message around the ring failed"); return HPS_ERR_COMM; }
+    }
     *handle = R;
     return HPS_OK;
 }
@@ -196,11 +218,18 @@ extern "C" int hps_ring_sendrecv_self (void* handle, const void* src_dev, void* 
     HPS_REQUIRE(R && R->comm_self, "hps_ring_sendrecv_self: needs a ring of one rank");
     HPS_REQUIRE(src_dev && dst_dev && bytes > 0, "hps_ring_sendrecv_self: empty message");
     if (after_event) HPS_HIP_CHECK(hipStreamWaitEvent(R->st_send, static_cast<hipEvent_t>(after_event), 0));
-    HPS_NCCL_CHECK(g_rccl.GroupStart());
-    ncclResult_t r1 = g_rccl.Send(src_dev, (size_t)bytes, 0, 0, R->comm_self, R->st_send);
-    ncclResult_t r2 = g_rccl.Recv(dst_dev, (size_t)bytes, 0, 0, R->comm_self, R->st_send);
-    HPS_NCCL_CHECK(g_rccl.GroupEnd());
-    HPS_NCCL_CHECK(r1); HPS_NCCL_CHECK(r2);
+    // HPS_RING_SELF_COPY=1 (diagnostic): the same choreography with a device copy in place of the RCCL pair -- what of the
+    // ring's cost is the RCCL kernel running beside the engine's, and what is the events and the host calls
+    static const bool plain_copy = [] { const char* v = std::getenv("HPS_RING_SELF_COPY"); return v && std::atoi(v) != 0; }();
+    if (plain_copy) {
+        HPS_HIP_CHECK(hipMemcpyAsync(dst_dev, src_dev, (size_t)bytes, hipMemcpyDeviceToDevice, R->st_send));
+    } else {
+        HPS_NCCL_CHECK(g_rccl.GroupStart());
+        ncclResult_t r1 = g_rccl.Send(src_dev, (size_t)bytes, 0, 0, R->comm_self, R->st_send);
+        ncclResult_t r2 = g_rccl.Recv(dst_dev, (size_t)bytes, 0, 0, R->comm_self, R->st_send);
+        HPS_NCCL_CHECK(g_rccl.GroupEnd());
+        HPS_NCCL_CHECK(r1); HPS_NCCL_CHECK(r2);
+    }
     hipEvent_t ev;
     if (int e = event_of(R->ev_send, slot, &ev)) return e;
     HPS_HIP_CHECK(hipEventRecord(ev, R->st_send));

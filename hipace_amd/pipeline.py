@@ -25,6 +25,7 @@ ahead when it does (the reference's requirement max_trailing_slices * n_ranks > 
 Dependencies: solving slice k of step s+1 needs the beam of slices k and k-1 of step s (the next slice's jx / jy feed
 the explicit source term, Hipace.cpp:639-657), so a rank trails its predecessor by two slices.
 """
+import gc
 import ctypes as C
 
 import torch
@@ -223,8 +224,21 @@ def make_transport(rank, world, device):
 _EV_SLICE, _EV_STEP, _EV_LFREE = 0, 64, 80
 
 
-def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_per_step=None, transport=None,
-                 laser_lookahead=8, on_slice=None, handoff_batch=8):
+def run_pipeline(*args, **kwargs):
+    """`_run_pipeline` with Python's cyclic garbage collector kept out of the way: the driver allocates small objects per
+    slice (views, tuples, events), and with torch imported one full collection over the heap takes 30-50 ms -- measured as
+    one stall of that length in the middle of the first step, with the device running dry (the whole difference between
+    the ring and the plain slice loop on one GPU).  What exists now is parked in the permanent generation for the run."""
+    gc.collect()
+    gc.freeze()
+    try:
+        return _run_pipeline(*args, **kwargs)
+    finally:
+        gc.unfreeze()
+
+
+def _run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_per_step=None, transport=None,
+                  laser_lookahead=8, on_slice=None, handoff_batch=8):
     """Run steps rank, rank+world, ... < n_steps of `engine` with the per-slice ring hand-off.
 
     engine: SliceEngine-like (begin_step, solve_slice, sync, record_event, wait_event, copy_async, beam_layout,
@@ -425,7 +439,17 @@ def run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_
     return solved
 
 
-def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_step=None):
+def run_local_pipeline(*args, **kwargs):
+    """`_run_local_pipeline` with the cyclic garbage collector parked (see run_pipeline)."""
+    gc.collect()
+    gc.freeze()
+    try:
+        return _run_local_pipeline(*args, **kwargs)
+    finally:
+        gc.unfreeze()
+
+
+def _run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_step=None):
     """Several time steps in flight on ONE device: the ring pipeline with all L = len(engines) of its stages in this
     process.
 
