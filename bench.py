@@ -318,7 +318,12 @@ def main():
             args.steps = run_local_pipeline(engines, max(1, args.steps // nz), dev)
         elif world == 1 and args.ring_self:
             from hipace_amd.pipeline import run_pipeline
-            args.steps = run_pipeline(eng, 0, 1, max(2, args.steps // nz), dev, transport=transport, handoff_batch=args.handoff_batch)
+            stamps = []
+            tl = (lambda m, q: stamps.append((m, q, time.perf_counter())) if q % 64 == 0 else None) if os.environ.get("BENCH_TIMELINE") else None
+            args.steps = run_pipeline(eng, 0, 1, max(2, args.steps // nz), dev, transport=transport, handoff_batch=args.handoff_batch,
+                                      on_slice=tl)
+            for a, b in zip(stamps, stamps[1:]):
+                print(f"timeline step {a[0]} slice {a[1]:4d}: {1e3 * (b[2] - a[2]) / 64:.4f} ms/slice", file=sys.stderr)
         elif world == 1:
             run_slices(args.steps)
         else:

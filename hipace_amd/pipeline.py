@@ -229,8 +229,7 @@ def run_pipeline(*args, **kwargs):
     slice (views, tuples, events), and with torch imported one full collection over the heap takes 30-50 ms -- measured as
     one stall of that length in the middle of the first step, with the device running dry (the whole difference between
     the ring and the plain slice loop on one GPU).  What exists now is parked in the permanent generation for the run."""
-    gc.collect()
-    gc.freeze()
+    gc.freeze()                     # (no collection first: that is the 30-50 ms pass this is here to avoid)
     try:
         return _run_pipeline(*args, **kwargs)
     finally:
@@ -441,7 +440,6 @@ def _run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices
 
 def run_local_pipeline(*args, **kwargs):
     """`_run_local_pipeline` with the cyclic garbage collector parked (see run_pipeline)."""
-    gc.collect()
     gc.freeze()
     try:
         return _run_local_pipeline(*args, **kwargs)
