@@ -113,10 +113,28 @@ def respawn_under_torchrun(n):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    return subprocess.call(cmd, env=env, stdout=_JSON_OUT)       # the ranks inherit the real stdout (rank 0 prints the line)
+
+
+_JSON_OUT = None
+
+
+def claim_stdout():
+    """Keep file descriptor 1 for the ONE JSON line: libraries under us write there too (RCCL prints a version banner
+    from C stdio when a communicator is created).  Everything else that goes to stdout ends up on stderr."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    print(json.dumps(obj), file=_JSON_OUT or sys.stdout, flush=True)
 
 
 def main():
+    claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024, help="timed slices (per GPU)")
@@ -176,7 +194,7 @@ def main():
         t = torch.ones(1)
         dist.all_reduce(t)
         if rank == 0:
-            print(json.dumps({"spawn_check": True, "n_gpus": int(t.item()), "world_size": dist.get_world_size()}))
+            emit({"spawn_check": True, "n_gpus": int(t.item()), "world_size": dist.get_world_size()})
         dist.destroy_process_group()
         return
 
@@ -404,7 +422,7 @@ def main():
         }
         if args.cpu_slices > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.n, args.ppc, args.cpu_slices, args.cpu_threads or min(os.cpu_count() or 1, CPU_THREADS_DEFAULT))
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.barrier()
         if transport is not None:
