@@ -201,8 +201,12 @@ def main():
     from hipace_amd import api, decks
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local)
+    ctl = None
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # a host-only group for the barrier in the middle of a run: torch's RCCL barrier is a kernel plus a wait that may
+        # synchronise the whole device, and the ring's posted-ahead receives sit on that device until their data comes
+        ctl = dist.new_group(backend="gloo")
 
     nz = 1024
     deck = decks.synthetic(args.n, nz, args.ppc)
@@ -279,9 +283,16 @@ def main():
         def on_slice(m, q):
             if q == first:
                 if transport is not None:
+                    # mid-run, pipeline filled: this rank's receives of the slices to come are posted (a whole step
+                    # ahead, so that the previous rank's sends never wait for this one) and their RCCL kernels sit on
+                    # the ring's receive stream until the data comes -- a device-wide synchronise would wait for
+                    # messages the previous rank only sends after this barrier.  Synchronise what the clock is about:
+                    # the engine's stream and the sends.
                     eng.sync()
                     transport.sync_sends()
-                barrier()
+                    dist.barrier(group=ctl)
+                else:
+                    barrier()
                 stats0.update(eng.stats())
                 profiling(True)
                 clock["t0"] = time.perf_counter()

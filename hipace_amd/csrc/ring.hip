@@ -147,27 +147,35 @@ extern "C" int hps_ring_init (int rank, int world, int device, const char* id_ed
             if (r != 0) { hps_ring_destroy(R); hps::set_error(std::string("hps_ring_init: ncclCommInitRank: ") + g_rccl.GetErrorString(r)); return HPS_ERR_COMM; }
         }
     }
-    // One message around every edge now: RCCL connects a peer on the first send / receive, and the first launch of its
-    // kernel makes the runtime set up that queue's scratch -- measured on MI355X as one stall of 35-50 ms of ALL streams
-    // of the process, in the middle of the first step that carries a beam, if it is left to the first hand-off.
-    {   const size_t nb = 1 << 20;
+    // One message over every edge now, edge colour by edge colour.  RCCL connects two peers on their first send / receive
+    // -- a rendezvous of the two hosts inside ncclSend / ncclRecv (the connect data travels over the bootstrap network) --
+    // and a ring whose ranks make their first calls in pipeline order would wait in a circle: rank 0 posts its receive from
+    // rank N-1 first, rank N-1 its receive from N-2, ..., rank 1 its receive from rank 0.  Colour by colour a rank has at
+    // most one edge in play and its partner on that edge is in the same phase, so every first call finds its match; from
+    // here on sends and receives only enqueue.  (It also takes the first launch of RCCL's kernel, which makes the runtime
+    // set up that queue's scratch, out of the first hand-off.)
+    {   const size_t nb = 1 << 16;
         char* tmp = nullptr;
         if (hipMalloc(&tmp, 2*nb) != hipSuccess) { hps_ring_destroy(R); hps::set_error("hps_ring_init: out of device memory"); return HPS_ERR_HIP; }
         (void)hipMemset(tmp, 0, 2*nb);
-        ncclResult_t r1 = 0, r2 = 0, r3 = 0, r4 = 0;
+        bool ok = true;
         if (world == 1) {
-            r3 = g_rccl.GroupStart();
-            r1 = g_rccl.Send(tmp, nb, 0, 0, R->comm_self, R->st_send);
-            r2 = g_rccl.Recv(tmp + nb, nb, 0, 0, R->comm_self, R->st_send);
-            r4 = g_rccl.GroupEnd();
+            ok = ok && g_rccl.GroupStart() == 0;
+            ok = ok && g_rccl.Send(tmp, nb, 0, 0, R->comm_self, R->st_send) == 0;
+            ok = ok && g_rccl.Recv(tmp + nb, nb, 0, 0, R->comm_self, R->st_send) == 0;
+            ok = ok && g_rccl.GroupEnd() == 0;
+            ok = ok && hipStreamSynchronize(R->st_send) == hipSuccess;
         } else {
-            r1 = g_rccl.Send(tmp, nb, 0, 1, R->comm_out, R->st_send);
-            r2 = g_rccl.Recv(tmp + nb, nb, 0, 0, R->comm_in, R->st_recv);
+            const int e_out = rank, e_in = (rank + world - 1) % world;
+            for (int colour = 0; colour < 3 && ok; ++colour) {
+                if (edge_colour(e_out, world) == colour)
+                    ok = ok && g_rccl.Send(tmp, nb, 0, 1, R->comm_out, R->st_send) == 0 && hipStreamSynchronize(R->st_send) == hipSuccess;
+                if (edge_colour(e_in, world) == colour)
+                    ok = ok && g_rccl.Recv(tmp + nb, nb, 0, 0, R->comm_in, R->st_recv) == 0 && hipStreamSynchronize(R->st_recv) == hipSuccess;
+            }
         }
-        const hipError_t h1 = hipStreamSynchronize(R->st_send), h2 = hipStreamSynchronize(R->st_recv);
         (void)hipFree(tmp);
-        if (r1 != 0 || r2 != 0 || r3 != 0 || r4 != 0 || h1 != hipSuccess || h2 != hipSuccess) {
-            hps_ring_destroy(R); hps::set_error("hps_ring_init: the warm-up message around the ring failed"); return HPS_ERR_COMM; }
+        if (!ok) { hps_ring_destroy(R); hps::set_error("hps_ring_init: the warm-up message over the ring's edges failed"); return HPS_ERR_COMM; }
     }
     *handle = R;
     return HPS_OK;
