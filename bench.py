@@ -30,6 +30,11 @@ import subprocess
 import sys
 import time
 
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # before HIP starts: the engine's stream, the ring's send and receive streams and torch's own streams must not end up
+    # sharing a hardware queue (a send queued behind a receive that waits for its data would close a circle around the ring)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
