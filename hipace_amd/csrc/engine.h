@@ -104,6 +104,15 @@ struct Engine {
     int solve_slice_pc (int islice);
     int c_aabs = -1; double* d_laser_sum = nullptr;       // laser: slab component of |a|^2, device sum of |a| (diagnostics)
     LaserState* laser = nullptr;                          // envelope arrays + solver (laser.hip)
+    // The envelope's advance of a slice needs chi of the slice and the envelope of the slices before it -- nothing else
+    // of the slice needs its result.  It runs on a stream of its own beside the explicit deposition, the Bx/By multigrid
+    // and the push (HPS_LASER_ASYNC=0: on the engine's stream, in the reference's place, Hipace.cpp:637).
+    hipStream_t st_laser = nullptr; hipEvent_t ev_lfork = nullptr, ev_ldone = nullptr;
+    bool laser_async = true, laser_pending = false;
+    hipStream_t laser_stream () const { return (laser_async && st_laser) ? st_laser : st; }
+    int fork_laser ();          // the laser stream may read what the engine's stream has written so far
+    int laser_done ();          // mark the end of the laser stream's work of this slice
+    int join_laser ();          // the engine's stream waits for the laser stream's last slice (no-op if none is pending)
     // field diagnostic (Fields::Copy): components, coarsening, device array [ncomps][nzc][nyc][nxc]
     std::vector<int> fd_comps; int fd_c[3] = {1, 1, 1}; double* d_fd = nullptr; int* d_fd_comps = nullptr;
     int fill_field_diagnostic (int islice);
@@ -124,6 +133,7 @@ struct Engine {
 
 int ion_create (Engine& E);                                                  // ionization.hip
 void ion_destroy (Engine& E);
+unsigned event_flags (bool timing);                                           // engine.hip
 int laser_create (Engine& E);                                                // laser.hip
 void laser_destroy (Engine& E);
 int laser_begin_step (Engine& E);

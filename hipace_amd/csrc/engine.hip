@@ -376,6 +376,9 @@ Engine::~Engine ()
     (void)hipFree(d_fd); (void)hipFree(d_fd_comps); (void)hipFree(d_insitu); (void)hipFree(d_insitu_pl); (void)hipFree(d_insitu_bm);
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto e : hand_ev) if (e) (void)hipEventDestroy(e);
+    if (st_laser) (void)hipStreamDestroy(st_laser);
+    if (ev_lfork) (void)hipEventDestroy(ev_lfork);
+    if (ev_ldone) (void)hipEventDestroy(ev_ldone);
     if (st) (void)hipStreamDestroy(st);
 }
 
@@ -510,6 +513,15 @@ int Engine::create (const hps_deck& deck, int device)
     if (d.predcorr_mix > 0.0) pc_mix = d.predcorr_mix;
     HPS_HIP_CHECK(hipSetDevice(device));
     HPS_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (const char* v = std::getenv("HPS_LASER_ASYNC")) laser_async = std::atoi(v) != 0;
+    if (laser_async && d.laser_on && d.laser_solver >= 1 && d.dt != 0.0) {
+        // below the engine's stream: its kernels fill what the slice leaves idle, they are not to win a CU from it
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HPS_HIP_CHECK(hipStreamCreateWithPriority(&st_laser, hipStreamNonBlocking, lo));
+        HPS_HIP_CHECK(hipEventCreateWithFlags(&ev_lfork, event_flags(false)));
+        HPS_HIP_CHECK(hipEventCreateWithFlags(&ev_ldone, event_flags(false)));
+    }
     g = (d.order + 1)/2 + 1;                       // Fields::AllocData (fields/Fields.cpp:63-64)
     ncomp = pc ? (d.deposit_rho ? HPS_PC_RHO + 1 : HPS_PC_RHO) : (d.deposit_rho ? HPS_C_RHO + 1 : HPS_C_RHO);
     if (d.beam_radiation_reaction && !d.si_units && !(d.background_density_SI > 0.0)) {      // BeamParticleAdvance.cpp:39-43
@@ -662,6 +674,7 @@ int Engine::begin_step ()
     HPS_HIP_CHECK(hipMemsetAsync(slab.p, 0, (size_t)slab.nstride*ncomp*sizeof(double), st));
     HPS_HIP_CHECK(hipMemsetAsync(d_checksum, 0, HPS_PC_NCOMP_MAX*sizeof(double), st));
     HPS_HIP_CHECK(hipMemsetAsync(d_laser_sum, 0, sizeof(double), st));
+    if (int e = join_laser()) return e;        // the time levels rotate: the last slice's envelope must be in
     if (laser) { if (int e = laser_begin_step(*this)) return e; }
     if (d_insitu_pl) HPS_HIP_CHECK(hipMemsetAsync(d_insitu_pl, 0, (size_t)15*d.nz*sizeof(double), st));
     if (d_insitu_bm) HPS_HIP_CHECK(hipMemsetAsync(d_insitu_bm, 0, (size_t)23*d.nz*sizeof(double), st));
@@ -790,6 +803,28 @@ unsigned event_flags (bool timing)
     unsigned f = timing ? 0u : (unsigned)hipEventDisableTiming;
     if (mode >= 1) f |= timing ? (unsigned)hipEventReleaseToDevice : (unsigned)hipEventDisableSystemFence;
     return f;
+}
+
+int Engine::fork_laser ()
+{
+    if (laser_stream() == st) return HPS_OK;
+    HPS_HIP_CHECK(hipEventRecord(ev_lfork, st));
+    HPS_HIP_CHECK(hipStreamWaitEvent(st_laser, ev_lfork, 0));
+    return HPS_OK;
+}
+int Engine::laser_done ()
+{
+    if (laser_stream() == st) return HPS_OK;
+    HPS_HIP_CHECK(hipEventRecord(ev_ldone, st_laser));
+    laser_pending = true;
+    return HPS_OK;
+}
+int Engine::join_laser ()
+{
+    if (!laser_pending) return HPS_OK;
+    HPS_HIP_CHECK(hipStreamWaitEvent(st, ev_ldone, 0));
+    laser_pending = false;
+    return HPS_OK;
 }
 
 void Engine::mark ()
@@ -1192,6 +1227,7 @@ int Engine::solve_slice (int islice)
     int e;
 
     prof_now = profiling && (slices_done % prof_stride == 0);
+    if ((e = join_laser())) return e;          // the envelope solver of the previous slice has read its chi
     mark();   // b0
     if (d_insitu_pl && np > 0)        // m_multi_plasma.InSituComputeDiags (Hipace.cpp:590)
         hipLaunchKernelGGL(k_insitu_plasma, dim3(256), b256, 0, st, pl, 1.0/gm.c, insitu_pl_radius*insitu_pl_radius, d_insitu_pl, d.nz, islice);
@@ -1261,7 +1297,17 @@ int Engine::solve_slice (int islice)
         const int comps[3] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BZ};
         if ((e = hps_poisson_solve_batch(ps, 3, staging, slab, comps, st))) return e; }
     // m_multi_laser.AdvanceSlice (Hipace.cpp:637): a_{n+1} of this slice from chi and the neighbouring slices
-    if (c_aabs >= 0 && d.laser_solver >= 1 && d.dt != 0.0) { if ((e = laser_advance_slice(*this, islice))) return e; }
+    // On the laser's own stream when there is one, forked here (chi is final; nothing else of this slice needs a_{n+1}).
+    // FFT solver (0.11 ms of bandwidth-bound passes at 1024^2): enqueued at once; beside the explicit deposition or beside
+    // the Bx/By multigrid it gets half of its time back either way (measured: 898 -> 949 slices/s on config 5 without the
+    // dopant; stream priority makes no difference).  Multigrid solver (0.7 ms, latency-bound, holds the host once per
+    // V-cycle): enqueued further down, when the engine's stream has the explicit deposition and the Bx/By V-cycles
+    // queued (545 -> 706 slices/s).
+    const bool laser_now = c_aabs >= 0 && d.laser_solver >= 1 && d.dt != 0.0;
+    const bool laser_split = laser_now && laser_stream() != st;
+    if (laser_now && !laser_split) { if ((e = laser_advance_slice(*this, islice))) return e; }
+    if (laser_split) { if ((e = fork_laser())) return e; }
+    if (laser_split && d.laser_solver == 1) { if ((e = laser_advance_slice(*this, islice)) || (e = laser_done())) return e; }
     if (pair) {
         // -grad Psi and the beam part of Sx, Sy (Hipace.cpp:659-660) in one pass
         hipLaunchKernelGGL(k_gradpsi_sxsy, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_PSI, HPS_C_EXMBY, HPS_C_EYPBX,
@@ -1298,6 +1344,7 @@ int Engine::solve_slice (int islice)
             mark();   // b7
             if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st, c_aabs, nullptr, mg_gate_after_enqueued(mg)))) return e;
         }
+        if (laser_split && d.laser_solver == 2) { if ((e = laser_advance_slice(*this, islice)) || (e = laser_done())) return e; }
         if ((e = mg_solve1_finish(mg, &iters, nullptr, &extra, st))) return e;
         total_vcycles += iters;
         // the speculated V-cycles were not enough (the gated push has not run): the host has added the rest, push now
@@ -1378,7 +1425,13 @@ extern "C" int hps_engine_destroy (void* h) { delete static_cast<Engine*>(h); re
 extern "C" int hps_engine_begin_step (void* h) { return static_cast<Engine*>(h)->begin_step(); }
 extern "C" int hps_engine_solve_slice (void* h, int islice) { return static_cast<Engine*>(h)->solve_slice(islice); }
 extern "C" int hps_engine_run_step (void* h) { return static_cast<Engine*>(h)->run_step(); }
-extern "C" int hps_engine_sync (void* h) { HPS_HIP_CHECK(hipStreamSynchronize(static_cast<Engine*>(h)->st)); return HPS_OK; }
+extern "C" int hps_engine_sync (void* h)
+{
+    Engine* E = static_cast<Engine*>(h);
+    if (int e = E->join_laser()) return e;
+    HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    return HPS_OK;
+}
 extern "C" int hps_engine_info (void* h, int* ncomp, int* ng, long* np)
 {
     Engine* E = static_cast<Engine*>(h);
@@ -1524,6 +1577,7 @@ extern "C" int hps_engine_record_event (void* h, int slot, void** out)
     HPS_REQUIRE(slot >= 0 && slot < (1 << 20) && out, "hps_engine_record_event: bad slot");
     if ((size_t)slot >= E->hand_ev.size()) E->hand_ev.resize((size_t)slot + 1, nullptr);
     if (!E->hand_ev[slot]) HPS_HIP_CHECK(hipEventCreateWithFlags(&E->hand_ev[slot], event_flags(false)));
+    if (int e = E->join_laser()) return e;     // "everything the engine has been given so far" includes the laser stream's slice
     HPS_HIP_CHECK(hipEventRecord(E->hand_ev[slot], E->st));
     *out = E->hand_ev[slot];
     return HPS_OK;

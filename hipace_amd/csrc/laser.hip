@@ -268,7 +268,7 @@ int laser_create (Engine& E)
             HPS_HIP_CHECK(hipMalloc(&L->fft_work, std::max(wf, wb)));
             rocfft_execution_info_set_work_buffer(L->info, L->fft_work, std::max(wf, wb));
         }
-        rocfft_execution_info_set_stream(L->info, E.st);
+        rocfft_execution_info_set_stream(L->info, E.laser_stream());
     }
     return HPS_OK;
 }
@@ -310,6 +310,7 @@ int laser_advance_slice (Engine& E, int islice)
 {
     LaserState* L = E.laser;
     if (!L->np1) return HPS_OK;
+    const hipStream_t ls = E.laser_stream();       // ordered against the engine's stream by Engine::fork_laser / join_laser
     const hps_deck& d = E.d;
     const size_t plane = (size_t)d.nx*d.ny;
     auto at = [&] (const double2* base, int sl) -> const double2* { return sl < d.nz ? base + (size_t)sl*plane : nullptr; };
@@ -317,28 +318,28 @@ int laser_advance_slice (Engine& E, int islice)
                         at(L->nm1, islice), at(L->nm1, islice + 1), at(L->nm1, islice + 2),
                         at(L->np1, islice + 1), at(L->np1, islice + 2)};
     const double k0 = 2.0*3.14159265358979323846/d.laser_lambda0;
-    hipLaunchKernelGGL(k_laser_phase, dim3(1), dim3(1), 0, E.st, S.n00j00, S.n00jp1, S.n00jp2, d.nx, d.ny, d.laser_use_phase, E.gm.dz, L->phase);
+    hipLaunchKernelGGL(k_laser_phase, dim3(1), dim3(1), 0, ls, S.n00j00, S.n00jp1, S.n00jp2, d.nx, d.ny, d.laser_use_phase, E.gm.dz, L->phase);
     const dim3 grid(ceil_div(d.nx, 256), d.ny), block(256);
     const double chi0 = d.plasma_density > 0.0 ? d.plasma_density*d.plasma_charge*d.plasma_charge*E.gm.mu0/d.plasma_mass : 0.0;
-    hipLaunchKernelGGL(k_laser_rhs, grid, block, 0, E.st, S, SlabView(E.slab), (int)HPS_C_CHI, chi0, E.g, L->phase, L->steps,
+    hipLaunchKernelGGL(k_laser_rhs, grid, block, 0, ls, S, SlabView(E.slab), (int)HPS_C_CHI, chi0, E.g, L->phase, L->steps,
                        E.gm.dx, E.gm.dy, E.gm.dz, E.gm.c, d.dt, k0, L->work, L->mg_rhs, L->mg_acf_real, L->mg_acf_imag);
     if (L->mg) {
         // MultiLaser::AdvanceSliceMG (:430-608): hpmg system type 2, at most 200 V-cycles; the initial guess is the solution
         // of the slice solved before this one (np1j00 is left in place by ShiftLaserSlices, :208)
         int iters = 0;
         if (int e = mg2_solve_internal(L->mg, L->mg_sol, L->mg_rhs, L->mg_acf_real, L->mg_acf_imag,
-                                       d.laser_mg_tol_rel > 0.0 ? d.laser_mg_tol_rel : 1.0e-4, d.laser_mg_tol_abs, 200, &iters, E.st)) return e;
+                                       d.laser_mg_tol_rel > 0.0 ? d.laser_mg_tol_rel : 1.0e-4, d.laser_mg_tol_abs, 200, &iters, ls)) return e;
         L->mg_vcycles += iters;
-        hipLaunchKernelGGL(k_laser_from_planar, dim3(ceil_div((long)plane, 256)), block, 0, E.st, L->mg_sol, L->np1 + (size_t)islice*plane, (long)plane);
+        hipLaunchKernelGGL(k_laser_from_planar, dim3(ceil_div((long)plane, 256)), block, 0, ls, L->mg_sol, L->np1 + (size_t)islice*plane, (long)plane);
         HPS_HIP_CHECK(hipGetLastError());
         return HPS_OK;
     }
     void* buf[1] = {L->work};
     if (rocfft_execute(L->fwd, buf, nullptr, L->info) != rocfft_status_success) { set_error("laser: forward FFT failed"); return HPS_ERR_FFT; }
-    hipLaunchKernelGGL(k_laser_divide, grid, block, 0, E.st, L->work, d.nx, d.ny, 2.0*3.14159265358979323846/(d.hi[0] - d.lo[0]),
+    hipLaunchKernelGGL(k_laser_divide, grid, block, 0, ls, L->work, d.nx, d.ny, 2.0*3.14159265358979323846/(d.hi[0] - d.lo[0]),
                        2.0*3.14159265358979323846/(d.hi[1] - d.lo[1]), L->phase, L->steps, E.gm.dz, E.gm.c, d.dt, k0);
     if (rocfft_execute(L->bwd, buf, nullptr, L->info) != rocfft_status_success) { set_error("laser: backward FFT failed"); return HPS_ERR_FFT; }
-    hipLaunchKernelGGL(k_laser_store, dim3(ceil_div((long)plane, 256)), block, 0, E.st, L->work, L->np1 + (size_t)islice*plane, (long)plane,
+    hipLaunchKernelGGL(k_laser_store, dim3(ceil_div((long)plane, 256)), block, 0, ls, L->work, L->np1 + (size_t)islice*plane, (long)plane,
                        1.0/(double)plane);
     HPS_HIP_CHECK(hipGetLastError());
     return HPS_OK;
@@ -353,6 +354,7 @@ int laser_set_import (Engine& E, int on, int step)
 }
 int laser_export_slice (Engine& E, int islice, double* msg_dev)
 {
+    if (int e = E.join_laser()) return e;
     LaserState* L = E.laser;
     const size_t plane = (size_t)L->nx*L->ny;
     const double2* newest = L->np1 ? L->np1 : L->n00;
@@ -386,6 +388,7 @@ long laser_mg_vcycles (Engine& E) { return E.laser ? E.laser->mg_vcycles : 0; }
 
 int laser_copy_envelope (Engine& E, double* out_host)
 {
+    if (int e = E.join_laser()) return e;
     LaserState* L = E.laser;
     HPS_HIP_CHECK(hipStreamSynchronize(E.st));
     HPS_HIP_CHECK(hipMemcpy(out_host, L->n00, (size_t)L->nx*L->ny*L->nz*sizeof(double2), hipMemcpyDeviceToHost));
