@@ -179,6 +179,9 @@ def main():
     ap.add_argument("--config2", action="store_true",
                     help="BASELINE config 2 instead of the headline workload: linear_wake 256x256x512, 4 ppc, "
                          "predictor-corrector Bx/By solver (not the judged bench line)")
+    ap.add_argument("--watchdog", type=float, default=1500.0,
+                    help="N > 1: seconds after which a rank that is still running gives up with exit code 3 (a ring that "
+                         "cannot connect must not hold the node)")
     ap.add_argument("--spawn-check", action="store_true",
                     help="only check the launch path: every rank joins the process group (gloo, no GPU needed) and rank 0 "
                          "prints how many ranks there are")
@@ -208,6 +211,15 @@ def main():
     torch.cuda.set_device(local)
     ctl = None
     if world > 1:
+        import threading
+
+        def give_up():
+            print(f"bench.py: rank {rank} of {world} still running after {args.watchdog:.0f} s -- giving up", file=sys.stderr, flush=True)
+            os._exit(3)
+
+        dog = threading.Timer(args.watchdog, give_up)
+        dog.daemon = True
+        dog.start()
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         # a host-only group for the barrier in the middle of a run: torch's RCCL barrier is a kernel plus a wait that may
         # synchronise the whole device, and the ring's posted-ahead receives sit on that device until their data comes
