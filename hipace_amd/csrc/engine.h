@@ -40,7 +40,9 @@ struct Engine {
     // host memory (no stream synchronisation).
     struct Ions { hps_plasma pl{}, pl_alt{}; double *real = nullptr, *real_alt = nullptr; Tiling* tiling = nullptr; long n = 0;
                   double* d_adk = nullptr; unsigned long long* d_cnt = nullptr; long long* h_cnt = nullptr; long long* h_cnt_dev = nullptr;
-                  long long seq = 0; long n_ionized = 0; bool pending = false; int* d_tile_flag = nullptr; } ion;
+                  long long seq = 0; long n_ionized = 0; bool pending = false; int* d_tile_flag = nullptr;
+                  double* d_fbound = nullptr;       // [5][tiles] field maxima of the slice (k_ion_field_bounds; HPS_ION_TILE_SKIP=0: off)
+                } ion;
     // tabulated plasma density profile (hps_engine_set_density_profile): radial table on the device, time table on the host
     std::vector<double> prof_r, prof_t, prof_f_t; double* d_prof_r = nullptr; double prof_ft = 1.0;
     // fused push(k) + deposit(k-1) (k_advance_deposit_tiled): ahead_for = slice whose plasma currents are already deposited
@@ -50,6 +52,7 @@ struct Engine {
     IonArgs ion_args (int islice);             // ionization.hip: kernel arguments of this slice's ionisation
     int ionize_slice (int islice);             // ...: launch of the per-particle form
     int ionize_collect ();                     // ...: wait for the electron count of the slice
+    int ion_field_bounds ();                   // ...: per-tile field maxima for the tile skip of the ions' push
     hps_plasma tail_of (const hps_plasma& p, long first, long n) const;
     int species_deposit (const hps_plasma& p, Tiling* T, const int comp[6], double charge, double mass, int can_ionize);
     int species_explicit (const hps_plasma& p, Tiling* T, const int cache[4], const int depos[2], double charge, double mass, int can_ionize);

@@ -628,6 +628,8 @@ int Engine::setup_tiling ()
         if (int e = second(ion.pl_alt, ion.real_alt, ion.n, true)) return e;
         ion.pl_alt.n = ion.n;
         HPS_HIP_CHECK(hipMalloc(&ion.d_tile_flag, (size_t)ion.tiling->g.ntiles*sizeof(int)));
+        {   const char* v = std::getenv("HPS_ION_TILE_SKIP");
+            if (!(v && std::atoi(v) == 0)) HPS_HIP_CHECK(hipMalloc(&ion.d_fbound, (size_t)5*ion.tiling->g.ntiles*sizeof(double))); }
     }
     return HPS_OK;
 }
@@ -1365,6 +1367,7 @@ int Engine::solve_slice (int islice)
             // DoFieldIonization (Hipace.cpp:693-696), then the ions' own push; the host learns how many electrons the
             // slice has released while that push runs
             if (ion.tiling) {       // decided inside the ions' LDS-tile push, on the fields it gathers anyway
+                if ((e = ion_field_bounds())) return e;
                 const IonArgs ia = ion_args(islice);
                 if ((e = advance_plasma_tiled(slab, ion.pl, gm, comp, d.ion_charge, d.ion_mass, d.order, 0, d.n_subcycles, 1, ion.tiling, d_nfallback, st, c_aabs, &ia))) return e;
             } else {

@@ -68,6 +68,50 @@ void k_ionize (SlabView f, hps_plasma ion, int cPsi, int cEz, int cBx, int cBy, 
     adk_post(a);
 }
 
+// Block maxima for adk_tile_below_threshold: one workgroup per tile of the ion tiling scans the tile's cells (the edge
+// tiles take the guard cells with them) -- 4 planes read once, 32 MB at 1024^2.
+__global__ __launch_bounds__(256)
+void k_ion_field_bounds (SlabView f, int cPsi, int cEz, int cBx, int cBy, int ts, int ntx, int nty, double* out)
+{
+    const int tx = blockIdx.x % ntx, ty = blockIdx.x / ntx;
+    const int i0 = tx == 0 ? -f.ng : tx*ts, i1 = tx == ntx - 1 ? f.nx + f.ng : (tx + 1)*ts;
+    const int j0 = ty == 0 ? -f.ng : ty*ts, j1 = ty == nty - 1 ? f.ny + f.ng : (ty + 1)*ts;
+    const int w = i1 - i0, n = w*(j1 - j0);
+    double m[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int s = threadIdx.x; s < n; s += 256) {
+        const int lj = s / w, i = i0 + (s - lj*w), j = j0 + lj;
+        const long o = f.off(i, j);
+        const double psi = f.p[cPsi*f.ns + o];
+        if (i + 1 < f.nx + f.ng) m[0] = fmax(m[0], fabs(f.p[cPsi*f.ns + o + 1] - psi));
+        if (j + 1 < f.ny + f.ng) m[1] = fmax(m[1], fabs(f.p[cPsi*f.ns + o + f.js] - psi));
+        m[2] = fmax(m[2], fabs(f.p[cBx*f.ns + o]));
+        m[3] = fmax(m[3], fabs(f.p[cBy*f.ns + o]));
+        m[4] = fmax(m[4], fabs(f.p[cEz*f.ns + o]));
+    }
+    __shared__ double red[4][5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        double v = m[q];
+        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const int q = threadIdx.x;
+        out[(long)q*ntx*nty + blockIdx.x] = fmax(fmax(red[0][q], red[1][q]), fmax(red[2][q], red[3][q]));
+    }
+}
+
+int Engine::ion_field_bounds ()
+{
+    if (!ion.tiling || !ion.d_fbound) return HPS_OK;
+    const TileGeom& g = ion.tiling->g;
+    hipLaunchKernelGGL(k_ion_field_bounds, dim3(g.ntiles), dim3(256), 0, st, SlabView(slab), HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, g.ts, g.ntx, g.nty,
+                       ion.d_fbound);
+    HPS_HIP_CHECK(hipGetLastError());
+    return HPS_OK;
+}
+
 // InitIonizationModule: ADK prefactors (Chen et al., JCP 236 (2013), eq. (2); l = m = 0, the approximate expressions
 // without the Gamma function of the angular part); adk = [prefactor[Z] | exp_prefactor[Z] | power[Z]] on the device
 int ion_create (Engine& E)
@@ -121,7 +165,7 @@ void ion_destroy (Engine& E)
     if (E.ion.h_cnt) (void)hipHostFree(E.ion.h_cnt);
     (void)hipFree(E.ion.real); (void)hipFree(E.ion.pl.idcpu); (void)hipFree(E.ion.pl.ion_lev);
     (void)hipFree(E.ion.real_alt); (void)hipFree(E.ion.pl_alt.idcpu); (void)hipFree(E.ion.pl_alt.ion_lev);
-    delete E.ion.tiling; (void)hipFree(E.ion.d_tile_flag);
+    delete E.ion.tiling; (void)hipFree(E.ion.d_tile_flag); (void)hipFree(E.ion.d_fbound);
 }
 
 IonArgs Engine::ion_args (int islice)
@@ -134,6 +178,9 @@ IonArgs Engine::ion_args (int islice)
     a.clightsq_inv = 1.0/(gm.c*gm.c);
     a.Z = d.ion_Z; a.seed = d.ion_seed; a.step = (unsigned long long)step_index; a.islice = (unsigned long long)islice;
     a.cap = np_cap; a.tile_flag = ion.d_tile_flag;
+    a.fbound = (ion.tiling && ion.d_fbound) ? ion.d_fbound : nullptr;
+    if (ion.tiling) { a.fb_ntx = ion.tiling->g.ntx; a.fb_nty = ion.tiling->g.nty; }
+    a.fb_dx_inv = 1.0/gm.dx; a.fb_dy_inv = 1.0/gm.dy; a.fb_c = gm.c;
     a.seq = ++ion.seq;
     ion.pending = true;
     return a;

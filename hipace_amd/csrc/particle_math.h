@@ -179,6 +179,9 @@ struct IonArgs {
     unsigned long long seed, step, islice;
     long cap;                            // capacity of el's arrays
     int* tile_flag;                      // [tiles of the ion tiling] 1 = the tile holds a charged ion (written by the ions' tile push)
+    const double* fbound;                // [5][tiles] max over the tile's cells of |d_x psi|, |d_y psi| (staggered), |Bx|, |By|, |Ez|
+                                         // (k_ion_field_bounds), or null; ntx, nty = tiles per direction
+    int fb_ntx, fb_nty; double fb_dx_inv, fb_dy_inv, fb_c;
 };
 
 // One ion's decision (PlasmaParticleContainer.cpp:352-372) from the fields gathered at (x_prev, y_prev): Ex, Ey, Ez in the
@@ -197,6 +200,28 @@ __device__ __forceinline__ bool adk_decide (const IonArgs& a, double Ex, double 
     const double p = 1.0 - exp(-w_dtau);
     const unsigned long long uid = ((id >> 24) & ((1ULL << 39) - 1)) - 1;
     return ion_uniform(a.seed, uid, a.step, a.islice) < p;
+}
+
+// Upper bound of the field an atom of tile (tx, ty) can see, from the block maxima of the 3 x 3 tiles around it (the
+// stencil of a particle of the tile stays inside the tile's halo < one tile).  The gathered ExmBy is a convex combination
+// of staggered differences of psi (the derivative of the quadratic shape is the difference of two linear ones), Ez, Bx, By
+// are convex combinations of cell values: |E| <= sqrt((max|d_x psi|/dx + c max|By|)^2 + (max|d_y psi|/dy + c max|Bx|)^2 +
+// max|Ez|^2).  True = no neutral atom at rest in the tile can ionise (adk_decide's own early-out would take each of them).
+__device__ __forceinline__ bool adk_tile_below_threshold (const IonArgs& a, int tx, int ty)
+{
+    double m[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    const long nt = (long)a.fb_ntx*a.fb_nty;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int bx = tx + dx, by = ty + dy;
+            if (bx < 0 || by < 0 || bx >= a.fb_ntx || by >= a.fb_nty) continue;
+            const long b = (long)by*a.fb_ntx + bx;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) m[q] = fmax(m[q], a.fbound[q*nt + b]);
+        }
+    const double ex = m[0]*a.fb_dx_inv + a.fb_c*m[3], ey = m[1]*a.fb_dy_inv + a.fb_c*m[2];
+    const double Ep = sqrt(ex*ex + ey*ey + m[4]*m[4])*a.E0;
+    return Ep*(1.0 + 1.0e-9) < a.adk[3*a.Z];
 }
 
 // The lanes of a wave that ionise take a block of electron slots with ONE atomic (ballot + popcount) and write their

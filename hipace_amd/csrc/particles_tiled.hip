@@ -409,6 +409,14 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     int charged = 0;          // IONIZE: does this thread hold an ion of level > 0 after the slice?
     extern __shared__ __attribute__((aligned(16))) double img[];     // [5][R*R]
     const int tile = offsets[gridDim.x + 2 + blockIdx.x];     // launch order: heaviest tile first (sort.hip)
+    if constexpr (IONIZE) {
+        // a tile of neutral atoms at rest (no charged ion so far) in a field below the threshold of the first level:
+        // nothing to decide, nothing to push -- most tiles of a slice (the field image is not even loaded)
+        if (ia.fbound && ia.tile_flag && ia.tile_flag[tile] == 0 && adk_tile_below_threshold(ia, tile % ntx, tile / ntx)) {
+            adk_post(ia);
+            return;
+        }
+    }
     const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
     const int tid = threadIdx.x;
     const int cc[5] = {cPsi, cEz, cBx, cBy, cBz};
