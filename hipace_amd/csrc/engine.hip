@@ -1363,6 +1363,7 @@ int Engine::solve_slice (int islice)
     mark();   // b7
     // gather + push (Hipace.cpp:699-701)
     {   const int* comp = comp_push;
+        bool body_done = false;
         if (ion.n > 0) {
             // DoFieldIonization (Hipace.cpp:693-696), then the ions' own push; the host learns how many electrons the
             // slice has released while that push runs
@@ -1374,6 +1375,12 @@ int Engine::solve_slice (int islice)
                 if ((e = ionize_slice(islice))) return e;
                 if ((e = species_advance(ion.pl, ion.tiling, comp, d.ion_charge, d.ion_mass, 0, 1))) return e;
             }
+            // the electrons' tile-sorted body does not depend on how many electrons the slice has released: push it while the
+            // count travels to the host, then the tail with the new count
+            if (tiling && tiling->sorted_n > 0 && !fuse) {
+                if ((e = advance_plasma_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st, c_aabs))) return e;
+                body_done = true;
+            }
             if ((e = ionize_collect())) return e;
         }
         // push of this slice and deposition of the next one in one pass over the sheet (static beam, no laser, one
@@ -1383,6 +1390,8 @@ int Engine::solve_slice (int islice)
             const int dep[6] = {HPS_C_JX, HPS_C_JY, -1, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_CHI, HPS_C_RHOMJZ};
             if ((e = advance_deposit_tiled(slab, pl, gm, comp, dep, d.plasma_charge, d.plasma_mass, d.order, d.n_subcycles, d.max_qsa, d_nqsa, tiling, d_nfallback, st))) return e;
             ahead_for = islice - 1;
+        } else if (body_done) {
+            if (pl.n > tiling->sorted_n) { if ((e = hps_advance_plasma_laser(slab, tail_of(pl, tiling->sorted_n, pl.n - tiling->sorted_n), gm, comp, c_aabs, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; }
         } else {
             if ((e = species_advance(pl, tiling, comp, d.plasma_charge, d.plasma_mass, 0, 0))) return e;
         } }
