@@ -1489,3 +1489,61 @@ def test_ring_driver_on_rccl_laser(api):
         for k, v in want[s][0].items():
             assert abs(got[s][0][k] - v) <= 1e-10 * max(abs(v), 1e-300), (s, k)
     T.close()
+
+
+def _run_with_env(api, var, value, deck, n_steps, tile_size=16):
+    """one engine created with an HPS_* switch set (the library reads them when the engine is created)"""
+    old = os.environ.get(var)
+    os.environ[var] = value
+    try:
+        e = api.SliceEngine(deck, tile_size=tile_size, sort_period=7)
+    finally:
+        if old is None:
+            del os.environ[var]
+        else:
+            os.environ[var] = old
+    for _ in range(n_steps):
+        e.begin_step()
+        for k in range(deck["nz"] - 1, -1, -1):
+            e.solve_slice(k)
+    e.sync()
+    return e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["gated_push", "laser_stream_fft", "laser_stream_mg", "ion_tile_skip"])
+def test_schedules_do_not_change_results(api, case):
+    """The engine's scheduling choices -- the push enqueued behind the multigrid's V-cycles and gated on its stopping rule,
+    the envelope solver on a stream of its own, the tiles of atoms that cannot ionise skipped before their image is loaded --
+    against the plain schedule (each has an HPS_* switch): same slab, same particles, same envelope, same ion levels and
+    released electrons.  No diagnostics here: they would keep the gated push off."""
+    if case == "gated_push":
+        var, deck, steps = "HPS_GATED_PUSH", decks.blowout_wake(), 1
+    elif case.startswith("laser_stream"):
+        var, steps = "HPS_LASER_ASYNC", 3
+        deck = decks.laser_blowout_wake()
+        deck.update(nx=64, ny=64, nz=30, lo=(-16.0, -16.0, -4.0), hi=(16.0, 16.0, 4.0), laser_a0=1.5, laser_lambda0=0.4,
+                    laser_solver=1 if case.endswith("fft") else 2, dt=5.0, n_steps=3)
+    else:
+        var, steps = "HPS_ION_TILE_SKIP", 2
+        deck = decks.laser_ionization_SI()
+        deck.update(nx=128, ny=128, nz=60, laser_solver=1, dt=6.0 * 10.0e-6 / 299792458.0, n_steps=2)
+    a = _run_with_env(api, var, "1", deck, steps)
+    b = _run_with_env(api, var, "0", deck, steps)
+    sa, sb = a.slab(), b.slab()
+    for c, nm in enumerate(a.comp_names()):
+        sc = max(np.abs(sb[c]).max(), 1e-300)
+        assert np.abs(sa[c] - sb[c]).max() <= 1e-12 * sc, (case, nm)
+    ra, va = a.particles()
+    rb, vb = b.particles()
+    assert ra.shape == rb.shape and np.array_equal(np.sort(va), np.sort(vb))
+    if case == "ion_tile_skip":
+        (_, _, la, ka), (_, _, lb, kb) = a.ions(), b.ions()
+        assert np.array_equal(la[np.argsort(ka)], lb[np.argsort(kb)])
+        assert a.ion_stats() == b.ion_stats() and a.ion_stats()[0] > 100
+    else:
+        assert np.abs(ra - rb).max() <= 1e-12 * np.abs(rb).max()
+    if case.startswith("laser_stream"):
+        ea, eb = a.laser_envelope(), b.laser_envelope()
+        assert np.abs(ea - eb).max() <= 1e-13 * np.abs(eb).max()
+        assert a.laser_vcycles() == b.laser_vcycles()
