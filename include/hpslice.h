@@ -252,7 +252,7 @@ int hps_engine_destroy (void* handle);
 int hps_engine_begin_step (void* handle);                 /* Evolve :401-471: reset, plasma, ions */
 int hps_engine_solve_slice (void* handle, int islice);    /* SolveOneSlice :556-728               */
 int hps_engine_run_step (void* handle);                   /* begin_step + all slices head->tail   */
-int hps_engine_sync (void* handle);
+int hps_engine_sync (void* handle);                       /* host waits for the engine's stream (and, through it, the laser stream) */
 int hps_engine_info (void* handle, int* ncomp, int* nguards, long* nparticles);
 hps_slab hps_engine_slab (void* handle);
 hps_plasma hps_engine_plasma (void* handle);
@@ -387,7 +387,10 @@ int hps_engine_assume_initial_beam_support (void* handle);
  * engine on its own stream, coupled only by the per-slice beam hand-off.  record_event marks the engine's stream
  * (pool slot `slot`, created on first use) and returns the event; wait_event makes the engine's stream wait for an
  * event recorded by another engine -- the device-side form of "slice k of the previous step has been pushed".
- * copy_async is a device-to-device copy on the engine's stream (the in-process hand-off, MultiBuffer.cpp:299-308). */
+ * copy_async is a device-to-device copy on the engine's stream (the in-process hand-off, MultiBuffer.cpp:299-308).
+ * The event covers everything the engine has been given so far, the envelope solver's slice on the engine's laser
+ * stream included.  It is for streams of the engine's device (another engine, the ring's send stream): it is recorded
+ * without the system-scope fence HIP puts behind an event by default (HPS_EVENT_FENCE=0 restores it). */
 int hps_engine_record_event (void* handle, int slot, void** event_out);
 int hps_engine_wait_event (void* handle, void* event);
 int hps_engine_copy_async (void* handle, void* dst_dev, const void* src_dev, long bytes);
@@ -403,7 +406,13 @@ int hps_engine_copy_async (void* handle, void* dst_dev, const void* src_dev, lon
  * Bootstrap (host driver, e.g. hipace_amd/pipeline.py over torch.distributed's store): rank r makes the id of ITS
  * outgoing edge with hps_ring_unique_id and hands it to rank r+1; hps_ring_init(rank, world, device, id of the edge
  * (r-1 -> r), id of the edge (r -> r+1)) is collective over the ring.  world = 1: id_edge_in may be NULL, the ring is
- * a 1-rank communicator and hps_ring_sendrecv_self is the hand-off (MultiBuffer.cpp:299-308, "send to myself"). */
+ * a 1-rank communicator and hps_ring_sendrecv_self is the hand-off (MultiBuffer.cpp:299-308, "send to myself").
+ * hps_ring_init also sends one small message over each of the rank's edges (edge colour by edge colour, like the
+ * communicator creation): RCCL connects two peers inside their first ncclSend / ncclRecv -- a rendezvous of the two
+ * hosts -- and that must not be left to the pipeline's first hand-offs, whose order around the ring is a circle.
+ * Afterwards hps_ring_send_slice / recv_slice only enqueue.  A rank must not synchronise its whole device
+ * (hipDeviceSynchronize) while receives it has posted ahead are waiting for their data; hps_engine_sync,
+ * hps_ring_sync_sends and hps_ring_sync wait for one stream each. */
 #define HPS_RING_ID_BYTES 128
 int hps_ring_unique_id (char* id_out /* [HPS_RING_ID_BYTES] */);
 int hps_ring_init (int rank, int world, int device, const char* id_edge_in, const char* id_edge_out, void** ring);
