@@ -167,7 +167,7 @@ def main():
                     help="BASELINE config 5: laser_blowout_wake 1024x1024x2048, 4 ppc, a Gaussian laser pulse drives the wake "
                          "and is advanced by the envelope solver on every slice; the time levels of the envelope stay in HBM "
                          "(not the judged bench line)")
-    ap.add_argument("--handoff-batch", type=int, default=8,
+    ap.add_argument("--handoff-batch", type=int, default=1,
                     help="slices per beam hand-off group on the ring (hipace_amd.pipeline.run_pipeline); 1 = one hand-off per slice")
     ap.add_argument("--ring-self", action="store_true",
                     help="one GPU, but every slice's hand-off goes through the RCCL ring (hipace_amd.pipeline.RcclSelfRing): the "

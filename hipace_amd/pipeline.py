@@ -237,7 +237,7 @@ def run_pipeline(*args, **kwargs):
 
 
 def _run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_per_step=None, transport=None,
-                  laser_lookahead=8, on_slice=None, handoff_batch=8):
+                  laser_lookahead=8, on_slice=None, handoff_batch=1):
     """Run steps rank, rank+world, ... < n_steps of `engine` with the per-slice ring hand-off.
 
     engine: SliceEngine-like (begin_step, solve_slice, sync, record_event, wait_event, copy_async, beam_layout,
@@ -246,10 +246,11 @@ def _run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices
     box); a list with one entry per rank (non-increasing, n_steps <= world) lets the ranks stop at different slices --
     the pre-filled pipeline of bench.py.  on_slice(m, q): called before slice q (from the head) of this rank's m-th
     step is solved, and once more with q = number of slices after the last one.
-    handoff_batch: a static beam (hipace.dt = 0, no laser) is handed on in groups of this many slices -- one event on the
-    engine's stream and one wait per group instead of per slice (measured on the RCCL ring: each costs the engine
-    about 10 us); the rank behind runs that many slices later, nothing else changes.  A moving beam and a laser are
-    handed on slice by slice.
+    handoff_batch: 1 = one hand-off per slice, as the reference.  > 1: a static beam (hipace.dt = 0, no laser) is handed on
+    in groups of that many slices -- one event on the engine's stream and one wait per group -- and the rank behind runs
+    that many slices later (a longer pipeline fill).  Measured on the RCCL ring of one GPU: no difference in the rate
+    (the events are not what a hand-off costs), so the default stays 1.  A moving beam and a laser are always handed on
+    slice by slice.
     Returns the number of slices this rank solved.
     """
     nz = engine.deck["nz"]

@@ -42,7 +42,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_steps, out, moving=False, pc=False):
+def _worker(rank, world, port, n_steps, out, moving=False, pc=False, batch=1):
     import torch.distributed as dist
     from hipace_amd.pipeline import run_pipeline
     from oracle import oracle as O
@@ -55,14 +55,15 @@ def _worker(rank, world, port, n_steps, out, moving=False, pc=False):
     def on_step_end(step):
         sums[step] = eng.checksums()
 
-    solved = run_pipeline(eng, rank, world, n_steps, "cpu", on_step_end)
+    solved = run_pipeline(eng, rank, world, n_steps, "cpu", on_step_end, handoff_batch=batch)
     out.put((rank, solved, sums))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_steps,pc", [(2, 3, False), (2, 2, False), (1, 2, False), (2, 2, True), (4, 9, False)])
-def test_ring_pipeline_matches_single_process(oracle, world, n_steps, pc):
+@pytest.mark.parametrize("world,n_steps,pc,batch", [(2, 3, False, 1), (2, 2, False, 1), (1, 2, False, 1), (2, 2, True, 1), (4, 9, False, 1),
+                                                    (2, 3, False, 4), (3, 7, False, 8)])
+def test_ring_pipeline_matches_single_process(oracle, world, n_steps, pc, batch):
     ref = oracle.Engine(_deck(pc))
     ref.run()
     want = ref.checksums()
@@ -70,7 +71,7 @@ def test_ring_pipeline_matches_single_process(oracle, world, n_steps, pc):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_steps, out, False, pc)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_steps, out, False, pc, batch)) for r in range(world)]
     for p in procs:
         p.start()
     results = [out.get(timeout=240) for _ in range(world)]
