@@ -223,7 +223,20 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         # a host-only group for the barrier in the middle of a run: torch's RCCL barrier is a kernel plus a wait that may
         # synchronise the whole device, and the ring's posted-ahead receives sit on that device until their data comes
-        ctl = dist.new_group(backend="gloo")
+        try:
+            ctl = dist.new_group(backend="gloo")
+        except Exception as exc:      # no usable host interface for gloo: meet on torch's RCCL group, waiting for ITS stream only
+            print(f"bench.py: no gloo group for the mid-run barrier ({exc}); using an all-reduce on torch's stream", file=sys.stderr)
+            ctl = None
+
+    def meet_mid_run():
+        """all ranks have arrived -- without a device-wide synchronise (see on_slice below)"""
+        if ctl is not None:
+            dist.barrier(group=ctl)
+        else:
+            t = torch.zeros(1, device="cuda")
+            dist.all_reduce(t)
+            torch.cuda.current_stream().synchronize()
 
     nz = 1024
     deck = decks.synthetic(args.n, nz, args.ppc)
@@ -307,7 +320,7 @@ def main():
                     # the engine's stream and the sends.
                     eng.sync()
                     transport.sync_sends()
-                    dist.barrier(group=ctl)
+                    meet_mid_run()
                 else:
                     barrier()
                 stats0.update(eng.stats())
