@@ -319,6 +319,26 @@ def ionization_SI():
     return with_ion_species(d, "H", ne, ppc=(1, 1), mass_Da=1.008, initial_level=0)
 
 
+def ion_motion_SI(nz=200):
+    """examples/linear_wake/inputs_ion_motion_SI (tests/ion_motion.SI.1Rank.sh): electrons and MOBILE ions (mass 5 m_e "for
+    testing", one particle per cell each, no neutralising background for either) behind an off-axis driver.  The ions are
+    the second species at its top level (hydrogen, level 1 of 1: nothing left to ionise).  The reference's driver is a
+    fixed_weight Gaussian drawn from amrex::Random; here a flat-top of the same peak density, length and offset (the
+    deck pins the two-species push and deposition, not the beam's random positions)."""
+    c, ep0, q_e, m_e = 299792458.0, 8.8541878128e-12, 1.602176634e-19, 9.1093837015e-31
+    kp_inv = 10.0e-6
+    ne = (c / kp_inv) ** 2 * m_e * ep0 / (q_e * q_e)
+    d = copy.deepcopy(_DEFAULT)
+    d.update(nx=64, ny=64, nz=nz, lo=(-8 * kp_inv, -8 * kp_inv, -6 * kp_inv), hi=(8 * kp_inv, 8 * kp_inv, 6 * kp_inv), order=2, si_units=1,
+             plasma_ppc=(1, 1), plasma_density=ne, plasma_charge=-q_e, plasma_mass=m_e, plasma_no_neutralize=1,
+             beam_profile=1, beam_zmin=0.6 * kp_inv, beam_zmax=3.4 * kp_inv, beam_radius=0.8 * kp_inv, beam_density=ne,
+             beam_pos_mean=(0.25 * kp_inv, 0.0, 2.0 * kp_inv), beam_umean=(10.0, 20.0, 100.0), beam_ppc=(1, 1, 1), beam_charge=-q_e, beam_mass=m_e,
+             n_steps=1, dt=0.0, bc=1)
+    with_ion_species(d, "H", ne, ppc=(1, 1), initial_level=1)
+    d["ion_mass"] = 5.0 * m_e
+    return d
+
+
 def laser_ionization_SI():
     """BASELINE config 5 at test size: the laser-driven wake of tests/laser_blowout_wake_explicit.SI.1Rank.sh in a gas that
     also holds neutral nitrogen (a fifth of the electron density, one macro-atom per cell) -- the wake's field ionises the

@@ -1547,3 +1547,22 @@ def test_schedules_do_not_change_results(api, case):
         ea, eb = a.laser_envelope(), b.laser_envelope()
         assert np.abs(ea - eb).max() <= 1e-13 * np.abs(eb).max()
         assert a.laser_vcycles() == b.laser_vcycles()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile_size", [0, 16])
+def test_mobile_ions_match_oracle(api, oracle, tile_size):
+    """examples/linear_wake/inputs_ion_motion_SI (tests/ion_motion.SI.1Rank.sh) with a deterministic driver: electrons and
+    mobile ions of 5 electron masses, one particle per cell each, neither with a neutralising background -- the second
+    species at its top level (nothing to ionise).  Every slab component, both sheets and the ions' levels equal the
+    oracle's; the ions do move."""
+    deck = decks.ion_motion_SI(60)
+    n = _compare_ion_run(api, oracle, deck, tile_size, 1)
+    assert n == 0
+    ge = api.SliceEngine(deck, tile_size=tile_size)
+    ge.begin_step()
+    for k in range(deck["nz"] - 1, -1, -1):
+        ge.solve_slice(k)
+    real, valid, lev, _ = ge.ions()
+    assert lev.min() == 1 and lev.max() == 1
+    assert np.abs(real[3]).max() > 1e6          # transverse momentum of the ions (u = gamma v, SI)
