@@ -102,7 +102,7 @@ struct Engine {
     long total_vcycles = 0, slices_done = 0;
     // predictor-corrector Bx/By (hipace.bxby_solver = predictor-corrector): d_pc = {sum |B|, sum |B - B_iter|, halo
     // fallback counter (int), spare}, h_pc its pinned image read back once per iteration
-    bool pc = false; double* d_pc = nullptr; double* h_pc = nullptr; double* h_pc_dev = nullptr; double pc_seq = 0.0; long pc_iterations = 0; double pc_err_sum = 0.0;
+    bool pc = false; double* d_pc = nullptr; double* d_pc_aux = nullptr; double* h_pc = nullptr; double* h_pc_dev = nullptr; double pc_seq = 0.0; long pc_iterations = 0; double pc_err_sum = 0.0;
     double pc_tol = 4e-2, pc_mix = 0.05; int pc_max_iter = 30;
     int solve_slice_pc (int islice);
     int c_aabs = -1; double* d_laser_sum = nullptr;       // laser: slab component of |a|^2, device sum of |a| (diagnostics)

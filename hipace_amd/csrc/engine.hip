@@ -368,7 +368,7 @@ Engine::~Engine ()
     (void)hipFree(staging); (void)hipFree(beam_data); (void)hipFree(beam_init);
     (void)hipFree(bm_store); (void)hipFree(bm_nsub); (void)hipFree(bm_nsub_scr); (void)hipFree(d_B); (void)hipFree(d_nfront);
     (void)hipFree(d_Bimp); (void)hipFree(d_beam_overflow); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
-    (void)hipFree(d_pc); if (h_pc) (void)hipHostFree(h_pc);
+    (void)hipFree(d_pc); (void)hipFree(d_pc_aux); if (h_pc) (void)hipHostFree(h_pc);
     (void)hipFree(d_laser_sum);
     if (laser) laser_destroy(*this);
     ion_destroy(*this);
@@ -594,6 +594,8 @@ int Engine::create (const hps_deck& deck, int device)
         // no multigrid solves in this mode: the counter travels with the per-iteration read-back of the B error
         HPS_HIP_CHECK(hipMalloc(&d_pc, 4*sizeof(double)));
         HPS_HIP_CHECK(hipMemset(d_pc, 0, 4*sizeof(double)));
+        HPS_HIP_CHECK(hipMalloc(&d_pc_aux, 4*sizeof(double)));      // error of the last two iterations (k_pc_mix)
+        HPS_HIP_CHECK(hipMemset(d_pc_aux, 0, 4*sizeof(double)));
         HPS_HIP_CHECK(hipHostMalloc(&h_pc, 4*sizeof(double), hipHostMallocMapped));
         std::memset(h_pc, 0, 4*sizeof(double));
         HPS_HIP_CHECK(hipHostGetDevicePointer((void**)&h_pc_dev, h_pc, 0));
@@ -1099,9 +1101,16 @@ void k_rhs_bxby (SlabView f, double mu0, double hdx_inv, double hdy_inv, double 
 
 // MixAndShiftBfields (fields/Fields.cpp:1175-1231) + the reset of the temporary currents (Hipace.cpp:1000-1003)
 __global__ __launch_bounds__(256)
-void k_pc_mix (double* p, long ns, long plane, double w_it, double w_prev, double mix)
+void k_pc_mix (double* p, long ns, long plane, const double* sums, double* err_slots, int it, double mix)
 {
     const long s = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    // the weights of Hipace.cpp:1005-1014 from this iteration's error and the previous one's, on the device: the kernel is
+    // enqueued before the host has read the error.  err_slots[it & 1] <- err for the next iteration (nobody reads that slot now)
+    const double err = sums[0] > 0.0 ? sums[1]/sums[0] : 0.0;
+    const double err_prev = (it == 1) ? err : err_slots[(it - 1) & 1];
+    double w_it = 0.5, w_prev = 0.5;
+    if (err != 0.0 || err_prev != 0.0) { w_it = err_prev/(err + err_prev); w_prev = err/(err + err_prev); }
+    if (s == 0) err_slots[it & 1] = err;
     if (s >= plane) return;
     for (int c = 0; c < 2; ++c) {
         const double it = p[(HPS_PC_IT_BX + c)*ns + s];
@@ -1161,9 +1170,12 @@ int Engine::solve_slice_pc (int islice)
     HPS_HIP_CHECK(hipMemsetAsync(d_pc, 0, 2*sizeof(double), st));
     hipLaunchKernelGGL(k_rel_b_error, dim3(128), b256, 0, st, f, HPS_PC_P_BX, HPS_PC_PIT_BX, d_pc, (volatile double*)nullptr, 0.0);
     hipLaunchKernelGGL(k_pc_guess, gplane, b256, 0, st, slab.p, slab.nstride, plane, d_pc, pc_tol);
-    double err = 1.0, err_prev = 1.0;
+    double err = 1.0;
     int it = 0;
     const int comp_push[5] = {HPS_PC_PSI, HPS_PC_EZ, HPS_PC_BX, HPS_PC_BY, HPS_PC_BZ};
+    // The mixing weights of an iteration are computed on the device (k_pc_mix) and the mixing is enqueued before the host
+    // waits for the iteration's error: it runs while the error travels (config 2: +5 % iterations per second).  Enqueuing
+    // the next iteration's push there as well, gated on the loop's condition, was measured and gains nothing more.
     while (err > pc_tol && it < pc_max_iter) {
         ++it; ++pc_iterations;
         // plasma to the temporary next slice, its jx jy (+ the beam's) there
@@ -1179,6 +1191,7 @@ int Engine::solve_slice_pc (int islice)
             if ((e = hps_poisson_solve_batch(ps, 2, staging, slab, comps, st))) return e; }
         pc_seq += 1.0;
         hipLaunchKernelGGL(k_rel_b_error, dim3(128), b256, 0, st, f, HPS_PC_BX, HPS_PC_IT_BX, d_pc, (volatile double*)h_pc_dev, pc_seq);
+        hipLaunchKernelGGL(k_pc_mix, gplane, b256, 0, st, slab.p, slab.nstride, plane, d_pc, d_pc_aux, it, pc_mix);
         {   // wait for the post; fall back to the stream's status every so often so that a failed launch cannot hang us
             volatile double* hp = h_pc;
             long spins = 0;
@@ -1191,11 +1204,6 @@ int Engine::solve_slice_pc (int islice)
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE); }
         err = h_pc[0] > 0.0 ? h_pc[1]/h_pc[0] : 0.0;
-        if (it == 1) err_prev = err;
-        double w_it = 0.5, w_prev = 0.5;
-        if (err != 0.0 || err_prev != 0.0) { w_it = err_prev/(err + err_prev); w_prev = err/(err + err_prev); }
-        hipLaunchKernelGGL(k_pc_mix, gplane, b256, 0, st, slab.p, slab.nstride, plane, w_it, w_prev, pc_mix);
-        err_prev = err;
     }
     pc_err_sum += err;
     mark();   // b6
