@@ -1566,3 +1566,32 @@ def test_mobile_ions_match_oracle(api, oracle, tile_size):
     real, valid, lev, _ = ge.ions()
     assert lev.min() == 1 and lev.max() == 1
     assert np.abs(real[3]).max() > 1e6          # transverse momentum of the ions (u = gamma v, SI)
+
+
+@pytest.mark.gpu
+def test_cpp_host_runs_the_ring_through_the_c_abi(api, tmp_path):
+    """examples/ring_host.cpp: a C++ program above include/hpslice.h (no Python, no torch in the process) that runs three
+    time steps of the blowout_wake deck slice by slice and hands every beam block of a step to the next one through the
+    RCCL ring, ordered by events -- the loop a maintainer of the reference would write in Hipace::Evolve.  Every step
+    reproduces the reference's checksums, and 2/3 of all beam bytes went through the ring."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "ring_host")
+    assert os.path.exists(exe), "examples/ring_host is missing: run __graft_entry__.build()"
+    gold = json.load(open(os.path.join(GOLD, "blowout_wake_explicit.2Rank.json")))["lev=0"]
+    deck = decks.blowout_wake()
+    eng = api.SliceEngine(deck)
+    names = eng.comp_names()
+    nbeam, _ = eng.beam_layout()
+    path = tmp_path / "deck.bin"
+    path.write_bytes(bytes(eng._dk))                     # the hps_deck the engine was created from
+    del eng
+    out = subprocess.run([exe, str(path), "3", "16"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    steps = [l.split() for l in out.stdout.splitlines() if l.startswith("step ")]
+    assert [int(s[1]) for s in steps] == [0, 1, 2]
+    for s in steps:
+        cs = dict(zip(names, map(float, s[2:])))
+        for k, v in gold.items():
+            assert abs(cs[k] - v) <= 1e-9 * abs(v), (s[1], k, cs[k], v)
+    ring = [l.split() for l in out.stdout.splitlines() if l.startswith("ring ")][0]
+    assert int(ring[1]) == int(ring[2]) > 0 and int(ring[3]) == 2 * 7 * 8 * nbeam
