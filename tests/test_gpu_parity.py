@@ -1576,7 +1576,9 @@ def test_cpp_host_runs_the_ring_through_the_c_abi(api, tmp_path):
     reproduces the reference's checksums, and 2/3 of all beam bytes went through the ring."""
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "ring_host")
-    assert os.path.exists(exe), "examples/ring_host is missing: run __graft_entry__.build()"
+    if not os.path.exists(exe):                          # normally built by __graft_entry__.build()
+        import __graft_entry__
+        __graft_entry__.build_cpp_host()
     gold = json.load(open(os.path.join(GOLD, "blowout_wake_explicit.2Rank.json")))["lev=0"]
     deck = decks.blowout_wake()
     eng = api.SliceEngine(deck)
