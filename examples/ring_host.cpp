@@ -4,13 +4,14 @@
 // transport left in): every pushed beam slice of step m goes through RCCL into the storage step m+1 reads, ordered against
 // the engine by events only -- the schedule of hipace_amd/pipeline.py::run_pipeline for a static beam (hipace.dt = 0).
 //
-//   ring_host <deck.bin> <n_steps> [tile_size]      deck.bin = the bytes of an hps_deck (tests write it with ctypes)
+//   ring_host <deck.bin> <n_steps> [tile_size [sort_period]]      deck.bin = the bytes of an hps_deck (tests write it with ctypes)
 //
 // Prints one line per time step: "step <m> <name>=<checksum> ..." with the components in slab order.
 #include "hpslice.h"
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -21,21 +22,22 @@
 
 int main (int argc, char** argv)
 {
-    if (argc < 3) { std::fprintf(stderr, "usage: ring_host <deck.bin> <n_steps> [tile_size]\n"); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: ring_host <deck.bin> <n_steps> [tile_size [sort_period]]\n"); return 2; }
     hps_deck deck;
     {   std::FILE* fp = std::fopen(argv[1], "rb");
         if (!fp || std::fread(&deck, 1, sizeof(deck), fp) != sizeof(deck)) { std::fprintf(stderr, "cannot read an hps_deck of %zu bytes from %s\n", sizeof(deck), argv[1]); return 2; }
         std::fclose(fp); }
     const int n_steps = std::atoi(argv[2]);
     const int tile = argc > 3 ? std::atoi(argv[3]) : 16;
+    const int sort_period = argc > 4 ? std::atoi(argv[4]) : 128;
     if (deck.dt != 0.0) { std::fprintf(stderr, "ring_host hands a static beam on (hipace.dt = 0)\n"); return 2; }
     const int dev = 0, nz = deck.nz;
     HIPCHECK(hipSetDevice(dev));
 
     void* eng = nullptr;
     CHECK(hps_engine_create(&deck, dev, &eng));
-    CHECK(hps_engine_set_tiling(eng, tile, 7));
-    CHECK(hps_engine_set_diagnostics(eng, 1));
+    CHECK(hps_engine_set_tiling(eng, tile, sort_period));
+    CHECK(hps_engine_set_diagnostics(eng, std::getenv("RING_HOST_NO_DIAG") ? 0 : 1));      // (checksums cost a kernel per slice)
     int ncomp = 0, ng = 0; long np = 0;
     CHECK(hps_engine_info(eng, &ncomp, &ng, &np));
 
@@ -60,6 +62,7 @@ int main (int argc, char** argv)
     std::vector<double> sums((size_t)ncomp);
     for (int m = 0; m < n_steps; ++m) {
         const int cur = m % 2, nxt = (m + 1) % 2;
+        const auto t0 = std::chrono::steady_clock::now();
         CHECK(hps_engine_set_beam_storage(eng, buf[cur]));
         CHECK(hps_engine_assume_initial_beam_support(eng));
         CHECK(hps_engine_begin_step(eng));
@@ -83,6 +86,8 @@ int main (int argc, char** argv)
             }
         }
         CHECK(hps_engine_sync(eng));
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::fprintf(stderr, "step %d: %.3f ms per slice, %.1f slices/s\n", m, ms/nz, 1e3*nz/ms);
         CHECK(hps_engine_checksums(eng, sums.data()));
         std::printf("step %d", m);
         for (int c = 0; c < ncomp; ++c) std::printf(" %.17g", sums[(size_t)c]);
