@@ -34,6 +34,12 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     # before HIP starts: the engine's stream, the ring's send and receive streams and torch's own streams must not end up
     # sharing a hardware queue (a send queued behind a receive that waits for its data would close a circle around the ring)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    if "--config5" not in sys.argv:
+        # A receive posted ahead is an RCCL kernel that waits on the device for its data: by default 16 workgroups for a
+        # 1 MB beam block (measured: grid 4096 x 256 threads), i.e. 16 CUs' worth of slots held while the engine runs.  Two
+        # channels carry a block in 84 us (12 GB/s against the 1.3 GB/s a slice hand-off needs); the laser's 33 MB per slice
+        # (config 5) keep RCCL's default.
+        os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", "2")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
