@@ -275,9 +275,7 @@ def main():
         for e in engines:
             e.set_fusion(True)
     short = args.steps < nz and lanes == 1 and not args.ring_self
-    # (with the ring's streams active beside the engine's, a timed event record costs the engine ~10 us instead of ~2:
-    #  sample fewer slices there)
-    stride = args.profile_stride if args.profile_stride > 0 else (1 if args.steps < 64 else (29 if (world > 1 or args.ring_self) else 7))
+    stride = args.profile_stride if args.profile_stride > 0 else (1 if args.steps < 64 else 7)
     dev = torch.device("cuda", local)
 
     def barrier():
