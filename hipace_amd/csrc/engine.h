@@ -47,6 +47,7 @@ struct Engine {
     std::vector<double> prof_r, prof_t, prof_f_t; double* d_prof_r = nullptr; double prof_ft = 1.0;
     // fused push(k) + deposit(k-1) (k_advance_deposit_tiled): ahead_for = slice whose plasma currents are already deposited
     bool fuse_push_deposit = false; int ahead_for = -2;
+    long fallback_div = 256;                    // re-sort once more than np / fallback_div particle visits since the last sort left their tile's halo (HPS_SORT_FALLBACK_DIV)
     bool gate_push = true;                      // push enqueued behind the multigrid's V-cycles, gated on its stopping rule (HPS_GATED_PUSH=0: off)
     int step_index = -1;           // time step that has begun (the ionisation draws are keyed by it)
     IonArgs ion_args (int islice);             // ionization.hip: kernel arguments of this slice's ionisation

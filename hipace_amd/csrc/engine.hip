@@ -507,6 +507,7 @@ int Engine::create (const hps_deck& deck, int device)
     if (d.field_bc != 0) { set_error("hps_engine_create: only boundary.field = Dirichlet is built"); return HPS_ERR_UNSUPPORTED; }
     pc = (d.bxby_solver != 0);
     if (const char* v = std::getenv("HPS_GATED_PUSH")) gate_push = std::atoi(v) != 0;
+    if (const char* v = std::getenv("HPS_SORT_FALLBACK_DIV")) { const long q = std::atol(v); if (q >= 1) fallback_div = q; }
     HPS_REQUIRE(!(d.beam_spin_tracking && d.dt == 0.0), "hps_engine_create: spin tracking needs a moving beam (hipace.dt != 0)");
     if (d.predcorr_tol > 0.0) pc_tol = d.predcorr_tol;
     if (d.predcorr_max_iter > 0) pc_max_iter = d.predcorr_max_iter;
@@ -1144,7 +1145,7 @@ int Engine::solve_slice_pc (int islice)
         if (d.deposit_rho) z.c[z.n++] = HPS_PC_RHO;
         hipLaunchKernelGGL(k_zero_comps, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, z, zb, CellBox{0, -1, 0, -1}); }
     mark();   // b1
-    if (tiling && (since_sort >= sort_period || (since_sort >= 2 && *h_nfallback - fb_at_sort > np/256))) { if ((e = resort())) return e; }
+    if (tiling && (since_sort >= sort_period || (since_sort >= 2 && *h_nfallback - fb_at_sort > np/fallback_div))) { if ((e = resort())) return e; }
     ++since_sort;
     mark();   // b1b
     // plasma: jx jy jz [rho] rhomjz (Hipace.cpp:616-618); beams deposit into the same jx jy jz (:620-623)
@@ -1267,7 +1268,7 @@ int Engine::solve_slice (int islice)
     // the halo of its tile (h_nfallback is as of the previous slice's multigrid sync)
     // (with a species "ion": also once the electrons appended behind the sorted body since the last sort -- they run
     // through the per-particle kernels -- are more than 1/32 of the sheet)
-    if (tiling && (since_sort >= sort_period || (since_sort >= 2 && *h_nfallback - fb_at_sort > np/256) ||
+    if (tiling && (since_sort >= sort_period || (since_sort >= 2 && *h_nfallback - fb_at_sort > np/fallback_div) ||
                    (since_sort >= 1 && np - tiling->sorted_n > std::max(np/32, 16384L)))) { if ((e = resort())) return e; }
     ++since_sort;
     mark();   // b1b
