@@ -6,7 +6,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO = os.path.join(CSRC, "libhpslice.so")
+SO = os.environ.get("HPS_LIB") or os.path.join(CSRC, "libhpslice.so")      # HPS_LIB: a diagnostic build (make stamps)
 _LIB = None
 
 
@@ -127,6 +127,7 @@ _SIGS = {
     "hps_engine_copy_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]),
     "hps_engine_set_profiling_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_set_laser_import": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "hps_engine_set_step": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_export_laser_slice": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "hps_engine_import_laser_slice": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "hps_engine_import_laser_from": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

@@ -497,6 +497,10 @@ class SliceEngine:
     def laser_message_doubles(self):
         return 4 * self.deck["nx"] * self.deck["ny"]
 
+    def set_step(self, step):
+        """physical time step of the next begin_step (pipeline stages run steps r, r + N, ...)"""
+        check(_lib.lib().hps_engine_set_step(self._h, int(step)))
+
     def set_laser_import(self, on, step=0):
         check(_lib.lib().hps_engine_set_laser_import(self._h, int(on), int(step)))
 

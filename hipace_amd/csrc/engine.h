@@ -49,7 +49,8 @@ struct Engine {
     bool fuse_push_deposit = false; int ahead_for = -2;
     long fallback_div = 256;                    // re-sort once more than np / fallback_div particle visits since the last sort left their tile's halo (HPS_SORT_FALLBACK_DIV)
     bool gate_push = true;                      // push enqueued behind the multigrid's V-cycles, gated on its stopping rule (HPS_GATED_PUSH=0: off)
-    int step_index = -1;           // time step that has begun (the ionisation draws are keyed by it)
+    int step_index = -1;           // physical time step that has begun (density profile's time factor, ionisation draws)
+    int next_step = -1;            // hps_engine_set_step: the step the next begin_step starts (-1: the one after step_index)
     IonArgs ion_args (int islice);             // ionization.hip: kernel arguments of this slice's ionisation
     int ionize_slice (int islice);             // ...: launch of the per-particle form
     int ionize_collect ();                     // ...: wait for the electron count of the slice

@@ -685,7 +685,8 @@ int Engine::begin_step ()
     if (d_insitu_bm) HPS_HIP_CHECK(hipMemsetAsync(d_insitu_bm, 0, (size_t)23*d.nz*sizeof(double), st));
     if (d_insitu) HPS_HIP_CHECK(hipMemsetAsync(d_insitu, 0, (size_t)10*d.nz*sizeof(double), st));
     if (d_fd) HPS_HIP_CHECK(hipMemsetAsync(d_fd, 0, fd_comps.size()*(size_t)(d.nx/fd_c[0])*(d.ny/fd_c[1])*(d.nz/fd_c[2])*sizeof(double), st));
-    ++step_index;
+    step_index = (next_step >= 0) ? next_step : step_index + 1;      // Hipace::m_physical_time (PlasmaParticleContainerInit.cpp:90)
+    next_step = -1;
     ahead_for = -2;
     // time factor of the density profile at z = c t of this step (UpdateDensityFunction, PlasmaParticleContainer.cpp:211-217)
     prof_ft = table_value(prof_t.data(), prof_f_t.data(), (int)prof_t.size(), gm.c*d.dt*step_index);
@@ -1616,6 +1617,13 @@ extern "C" int hps_engine_copy_async (void* h, void* dst, const void* src, long 
     if (bytes <= 0) return HPS_OK;
     HPS_REQUIRE(dst && src, "hps_engine_copy_async: null pointer");
     HPS_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, E->st));
+    return HPS_OK;
+}
+extern "C" int hps_engine_set_step (void* h, int step)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E && step >= 0, "hps_engine_set_step: bad argument");
+    E->next_step = step;
     return HPS_OK;
 }
 extern "C" int hps_engine_set_laser_import (void* h, int on, int step)

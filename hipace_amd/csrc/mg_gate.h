@@ -17,14 +17,28 @@ __device__ __forceinline__ double norm_slot (const unsigned long long* norms, in
     return __longlong_as_double((long long)m);
 }
 
+// The rule, evaluated by a whole wave: lane q reads sub-word q of the three slots it needs (three coalesced 128-byte
+// loads in one batch -- the previous-slot index depends on k by arithmetic, not by a branch, so there is no second,
+// dependent trip to memory), a butterfly over the 16 lanes of a group takes the maxima, and the verdict comes back
+// wave-uniform (read-first-lane), so that the `return` behind it is a scalar branch.  (Written as 48 reads per lane the
+// compiler emitted 17 vector loads per wave and batch: every wave of every workgroup pushed them through its CU's
+// address unit at the head of the kernel.)  All lanes of the wave must be active.
 __device__ __forceinline__ bool vcycle_active (const StopRule& sr)
 {
     if (sr.k < 0) return true;
-    const double res0 = norm_slot(sr.norms, 0), rhs0 = norm_slot(sr.norms, 1);
-    const double prev = (sr.k == 0) ? res0 : norm_slot(sr.norms, 2 + sr.k - 1);
+    const int q = threadIdx.x & (MG_NSUB - 1);
+    const int pslot = (sr.k == 0) ? 0 : 1 + sr.k;
+    unsigned long long a = sr.norms[q], b = sr.norms[MG_NSUB + q], c = sr.norms[pslot*MG_NSUB + q];
+#pragma unroll
+    for (int o = MG_NSUB/2; o > 0; o >>= 1) {
+        const unsigned long long a2 = __shfl_xor(a, o), b2 = __shfl_xor(b, o), c2 = __shfl_xor(c, o);
+        a = a2 > a ? a2 : a; b = b2 > b ? b2 : b; c = c2 > c ? c2 : c;
+    }
+    const double res0 = __longlong_as_double((long long)a), rhs0 = __longlong_as_double((long long)b), prev = __longlong_as_double((long long)c);
     const double max_norm = (rhs0 >= res0) ? rhs0 : res0;
     const double target = fmax(sr.tol_abs, fmax(sr.tol_rel, 1.e-16)*max_norm);
-    return prev > target && prev <= 1.e20*max_norm;
+    const int act = (prev > target && prev <= 1.e20*max_norm) ? 1 : 0;
+    return __builtin_amdgcn_readfirstlane(act) != 0;
 }
 
 

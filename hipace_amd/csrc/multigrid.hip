@@ -38,9 +38,18 @@ struct LevBox { int lox, loy, hix, hiy;      // index bounds of the level box (w
 
 enum { SRC_ZERO = 0, SRC_DIRECT = 1, SRC_PROLONG = 2 };
 
+// A value that must be in its register here: keeps the compiler from sinking a load below the gate that follows it.
+#define HPS_KEEP(x) asm volatile("" :: "v"(x))
+
 // optional shader-clock stamps of workgroup 0 (set through hps_mg_debug_stamps)
+// -- only in the diagnostic build (make stamps: -DHPS_STAMPS): the read of the pointer is one more dependent trip to
+// memory at the head of every kernel, ~1 us behind a kernel boundary
+#ifdef HPS_STAMPS
 __device__ long long* g_mg_dbg = nullptr;
 #define MG_STAMP(i) do { if (g_mg_dbg && blockIdx.x == 0 && threadIdx.x == 0) g_mg_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MG_STAMP(i) do { } while (0)
+#endif
 
 // Smoother tile shapes: TX x TY cells swept by NT threads (TX*TY/2/NT cell pairs per thread).  A
 // workgroup streams its tile through one CU (~10 B/clk from memory, one instruction stream per
@@ -177,7 +186,7 @@ template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, bool INTERIOR, i
 __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], double* s_red, const LevBox& b, const FView& phi_out,
                                              const FView& phi_out2, const FView& rhs, const FView& acf, const FView& phi_in, const FView& crse,
                                              const FView& res_out, const FView& cres_out, double facx, double facy,
-                                             int gi0, int gj0, unsigned long long* resnorm, unsigned long long* rhsnorm)
+                                             int gi0, int gj0, unsigned long long* resnorm, unsigned long long* rhsnorm, const StopRule& sr)
 {
     constexpr int E = DO_RES ? NSW : NSW - 1;         // rim of the swept tile that is not final
     constexpr int GT_X = TS::TX, GT_Y = TS::TY, GA_X = TS::AX, GA_Y = TS::AY, MG_NT = TS::NT, GPAIRS = TS::GPAIRS, PR = TS::PR;
@@ -233,6 +242,21 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
                 if (SRC == SRC_PROLONG) { a0 += prolong_at<CC>(crse, ic, jc, 0); a1 += prolong_at<CC>(crse, ic, jc, 1); }
                 const bool inside = INTERIOR || (ic == i && jc == j);
                 v0[m] = inside ? a0 : 0.0; v1[m] = inside ? a1 : 0.0;
+            }
+        }
+        {   // The gate of a speculative V-cycle, read while ALL the tile's loads are in flight (a kernel's first dependent
+            // read of global memory costs ~1.5 us behind a kernel boundary; read first, the gate was one such trip ahead
+            // of the loads).  HPS_KEEP: the loads must not sink below the branch.
+            // Only the 4-sweep kernels of the coarser levels do this (a handful of workgroups, each a chain of latencies);
+            // the 8-sweep pass of level 0 is bound by bandwidth and registers (all its operands live at once would cost
+            // it a workgroup per CU) and reads its gate first.
+            if (NSW == 4) {
+                const bool active = vcycle_active(sr);
+#pragma unroll
+                for (int m = 0; m < GPAIRS; ++m) { HPS_KEEP(r0[m][0]); HPS_KEEP(r0[m][1]); HPS_KEEP(r1[m][0]); HPS_KEEP(r1[m][1]); HPS_KEEP(ac[m][0]); HPS_KEEP(ac[m][1]); }
+#pragma unroll
+                for (int m = 0; m < NF; ++m) { HPS_KEEP(v0[m]); HPS_KEEP(v1[m]); }
+                if (!active) return;
             }
         }
         // LDS layout: the two colours of the red-black ordering in separate planes (cell (li, lj) of the
@@ -332,13 +356,13 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
 // NSW red-black half-sweeps per launch: 4 (one GSRB^4 of the reference) or 8 (the two consecutive
 // GSRB^4 that end a V-cycle on level 0, fused: one pass over HBM instead of two)
 template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, int NSW = 4>
-__global__ __launch_bounds__(TS::NT)
+__global__ __launch_bounds__(TS::NT, 4)      // at most 128 VGPRs: two 512-thread workgroups per CU (several variants sit at 113-130)
 void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FView phi_in, FView crse, FView res_out,
                FView cres_out, double facx, double facy, int ntx, unsigned long long* resnorm,
                unsigned long long* rhsnorm, StopRule sr)
 {
     static_assert(!FUSE_R || (CC && DO_RES), "fused restriction is cell-centred only");
-    if (!vcycle_active(sr)) return;
+    if (NSW != 4 && !vcycle_active(sr)) return;       // (the 4-sweep kernels read the gate behind their loads, see smooth_tile)
     constexpr int GT_X = TS::TX, GT_Y = TS::TY;
     __shared__ double s_phi[2][TS::AY*TS::AX];
     __shared__ double s_red[TS::NT/64];
@@ -355,9 +379,9 @@ void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FV
     const bool interior = (gi0 - 1 >= b.vlx) && (gi0 + GT_X <= b.vhx) && (gj0 - 1 >= b.vly) && (gj0 + GT_Y <= b.vhy)
                        && (gi0 > b.lox) && (gi0 + GT_X - 1 < b.hix) && (gj0 > b.loy) && (gj0 + GT_Y - 1 < b.hiy);
     if (interior) smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, true, NSW>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
-                                                             facx, facy, gi0, gj0, resnorm, rhsnorm);
+                                                             facx, facy, gi0, gj0, resnorm, rhsnorm, sr);
     else          smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, false, NSW>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
-                                                              facx, facy, gi0, gj0, resnorm, rhsnorm);
+                                                              facx, facy, gi0, gj0, resnorm, rhsnorm, sr);
 }
 
 // coarse = R(fine): 4-average (cell-centred) or 9-point full weighting (nodal)
@@ -982,11 +1006,256 @@ void k_lower_v2 (const Low2* __restrict__ dp, const double* __restrict__ acf_g, 
     MG_STAMP(14);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_lower_v3: the same lower V with ONE field component per workgroup (grid = 2).  The two components of the solve only
+// meet in the norm, which the lower V does not take, so two workgroups on two CUs need no synchronisation at all, and
+// every barrier phase of the 64 x 64 and 32 x 32 levels carries half the LDS traffic and half the fp64 instruction
+// stream of k_lower_v2 (one CU's LDS pipe and VALUs were what bounded those phases: ~1800 cycles per half-sweep).
+// LDS per level, single component: level A one ringed plane (cor); below it four: cor | res | acf | 1/diag.
+// Level A's inverse diagonals come from k_acf_pyramid (cinv_g: 4 divisions per thread and V-cycle less).  The gate of
+// the speculative V-cycle is evaluated AFTER the level-A loads have been issued: a kernel's first dependent read of
+// global memory costs ~1.5 us behind a kernel boundary (scripts/ubench/launch_floor.hip), and the two now overlap.
+
+template <bool WAVE>
+__device__ __forceinline__ void low_down_s (lds_double* base, const Low2& d, int l, int t, double fx, double fy, int nsw, bool last)
+{
+    const int nx = d.nx[l], ny = d.ny[l];
+    Blk B; int i, j;
+    blk_geometry(B, base + d.off[l], nx, ny, t, fx, fy, i, j);
+    const int ps = B.pitch*(ny + 2);
+    const lds_double* r = B.c0 + ps;
+    const int ok[4] = {0, 1, B.pitch, B.pitch + 1};
+    double a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int o = B.ok[k] ? ok[k] : 0;
+        B.r0[k] = r[o]; B.r1[k] = 0.0; a[k] = r[ps + o]; B.ci[k] = r[2*ps + o];
+    }
+    if (last && nx <= 2 && ny <= 2) { blk_single_sweeps<false>(B, nsw); lvl_sync<WAVE>(); }
+    else blk_down_sweeps<WAVE, false>(B, nsw);
+    if (!last) {
+        double q0[4], q1[4];
+        blk_residual<false>(B, i, j, cc_box(nx, ny), a, fx, fy, q0, q1);
+        if (B.act) {
+            const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
+            base[d.off[l+1] + psn + ((j >> 1) + 1)*pn + (i >> 1) + 1] = 0.25*(q0[0] + q0[1] + q0[2] + q0[3]);
+        }
+        lvl_sync<WAVE>();
+    }
+}
+
+template <bool WAVE>
+__device__ __forceinline__ void low_up_s (lds_double* base, const Low2& d, int l, int t, double fx, double fy)
+{
+    const int nx = d.nx[l], ny = d.ny[l];
+    Blk B; int i, j;
+    blk_geometry(B, base + d.off[l], nx, ny, t, fx, fy, i, j);
+    const int ps = B.pitch*(ny + 2);
+    const lds_double* r = B.c0 + ps;
+    const int ok[4] = {0, 1, B.pitch, B.pitch + 1};
+    const int pn = d.nx[l+1] + 2;
+    const lds_double* kc = base + d.off[l+1] + ((j >> 1) + 1)*pn + (i >> 1) + 1;
+    const double k0 = B.act ? kc[0] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int o = B.ok[k] ? ok[k] : 0;
+        B.r0[k] = r[o]; B.r1[k] = 0.0; B.ci[k] = r[2*ps + o];
+        const double c0 = B.c0[o];
+        B.v0[k] = B.ok[k] ? c0 + k0 : 0.0;
+        if (B.ok[k]) B.c0[o] = B.v0[k];
+        B.v1[k] = 0.0;
+    }
+    lvl_sync<WAVE>();
+    blk_sweep<0, WAVE, false>(B); blk_sweep<1, WAVE, false>(B); blk_sweep<0, WAVE, false>(B); blk_sweep<1, WAVE, false>(B);
+}
+
+// levels of at most 8 x 8 cells in one wave, one lane per cell
+__device__ __forceinline__ void tiny_down_s (lds_double* base, const Low2& d, int l, int t, double fx, double fy)
+{
+    const int nx = d.nx[l], ny = d.ny[l], pitch = nx + 2, ps = pitch*(ny + 2);
+    const int i = t & 7, j = t >> 3;
+    const bool ok = (i < nx) && (j < ny);
+    const int o = ok ? (j + 1)*pitch + i + 1 : pitch + 1;
+    lds_double* c0 = base + d.off[l] + o;
+    const double r0 = c0[ps], a = c0[2*ps], ci = c0[3*ps];
+    const double fxm = wall_mult<true>(i, 0, nx - 1, fx), fym = wall_mult<true>(j, 0, ny - 1, fy);
+    if (ok && (((i + j) & 1) == 0)) c0[0] = r0*ci;                          // sweep 0 from cor = 0
+    lvl_sync<true>();
+    for (int s = 1; s < 4; ++s) {
+        if (ok && (((i + j + s) & 1) == 0)) c0[0] = (r0 - offdiag_m((const lds_double*)c0, pitch, fxm, fym))*ci;
+        lvl_sync<true>();
+    }
+    const LevBox b = cc_box(nx, ny);
+    const double u0 = residual_at<false>((const lds_double*)c0, pitch, i, j, b, r0, a, fx, fy);
+    const double q0 = ok ? u0 : 0.0;
+    const double b0 = __shfl_down(q0, 1), g0 = __shfl_down(q0, 8), e0 = __shfl_down(q0, 9);
+    if (ok && !(i & 1) && !(j & 1)) {
+        const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
+        base[d.off[l+1] + psn + ((j >> 1) + 1)*pn + (i >> 1) + 1] = 0.25*(q0 + b0 + g0 + e0);
+    }
+    lvl_sync<true>();
+}
+
+__device__ __forceinline__ void tiny_up_s (lds_double* base, const Low2& d, int l, int t, double fx, double fy)
+{
+    const int nx = d.nx[l], ny = d.ny[l], pitch = nx + 2, ps = pitch*(ny + 2);
+    const int i = t & 7, j = t >> 3;
+    const bool ok = (i < nx) && (j < ny);
+    const int o = ok ? (j + 1)*pitch + i + 1 : pitch + 1;
+    lds_double* c0 = base + d.off[l] + o;
+    const double r0 = c0[ps], ci = c0[3*ps];
+    const double fxm = wall_mult<true>(i, 0, nx - 1, fx), fym = wall_mult<true>(j, 0, ny - 1, fy);
+    if (ok) {
+        const int pn = d.nx[l+1] + 2;
+        c0[0] = c0[0] + base[d.off[l+1] + ((j >> 1) + 1)*pn + (i >> 1) + 1];
+    }
+    lvl_sync<true>();
+    for (int s = 0; s < 4; ++s) {
+        if (ok && (((i + j + s) & 1) == 0)) c0[0] = (r0 - offdiag_m((const lds_double*)c0, pitch, fxm, fym))*ci;
+        lvl_sync<true>();
+    }
+}
+
+__global__ __launch_bounds__(1024)
+void k_lower_v3 (const Low2* __restrict__ dp, const double* __restrict__ acf_g, const double* __restrict__ cinv_g,
+                 const double* __restrict__ res_g, double* __restrict__ cor_g, int nxA, int nyA, double facx0, double facy0,
+                 int nsweeps_bottom, StopRule sr)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    lds_double* base = (lds_double*)lds_raw;
+    const int t = threadIdx.x;
+    const Low2& d = *dp;          // (level A's size comes by value: the first loads must not wait for this read)
+    const int nl = d.nl;
+    const int cellsA = nxA*nyA;
+    res_g += (long)blockIdx.x*cellsA; cor_g += (long)blockIdx.x*cellsA;      // this workgroup's component
+    const LevBox bA = cc_box(nxA, nyA);
+    Blk A; int iA, jA;
+    blk_geometry(A, base, nxA, nyA, t, facx0, facy0, iA, jA);       // (d.off[0] = 0)
+    // ---- level A: rhs, coefficient and inverse diagonal of the thread's block from HBM, issued before the gate is read
+    double aA[4], rA[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = iA + (k & 1), j = jA + (k >> 1);
+        const int g = min(i, nxA - 1) + min(j, nyA - 1)*nxA;
+        const double v0 = res_g[g], v2 = acf_g[g], v3 = cinv_g[g];
+        rA[k] = A.ok[k] ? v0 : 0.0; aA[k] = A.ok[k] ? v2 : 0.0; A.ci[k] = A.ok[k] ? v3 : 0.0;
+        A.r0[k] = rA[k]; A.r1[k] = 0.0;
+    }
+    const bool active = vcycle_active(sr);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { HPS_KEEP(rA[k]); HPS_KEEP(aA[k]); HPS_KEEP(A.ci[k]); }
+    if (!active) return;
+    MG_STAMP(8);
+    // only the correction planes need zeros (ring + the cells of the colour the first half-sweep skips)
+    for (int l = 0; l < nl; ++l) {
+        const int n1 = (d.nx[l] + 2)*(d.ny[l] + 2);
+        lds_double* c = base + d.off[l];
+        for (int s = t; s < n1; s += 1024) c[s] = 0.0;
+    }
+    __syncthreads();
+    // ---- coefficient hierarchy (average_down_acoef) and inverse diagonals of the levels below
+    if (nl > 1 && A.act) {
+        const int p1 = d.nx[1] + 2, ps1 = p1*(d.ny[1] + 2);
+        base[d.off[1] + 2*ps1 + ((jA >> 1) + 1)*p1 + (iA >> 1) + 1] = 0.25*(aA[0] + aA[1] + aA[2] + aA[3]);
+    }
+    __syncthreads();
+    for (int l = 1; l < nl; ++l) {
+        const double fx = lvl_fac(facx0, l), fy = lvl_fac(facy0, l);
+        const int nx = d.nx[l], ny = d.ny[l];
+        Blk B; int i, j;
+        blk_geometry(B, base + d.off[l], nx, ny, t, fx, fy, i, j);
+        const int ps = B.pitch*(ny + 2);
+        lds_double* acf = B.c0 + 2*ps;
+        const int ok[4] = {0, 1, B.pitch, B.pitch + 1};
+        if (B.act) {          // (whole waves have no block on the small levels: they skip the divisions)
+            double a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = B.ok[k] ? acf[ok[k]] : 0.0;
+            if (l + 1 < nl) {     // the next level's coefficient first: the divisions below are off the critical path
+                const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
+                base[d.off[l+1] + 2*psn + ((j >> 1) + 1)*pn + (i >> 1) + 1] = 0.25*(a[0] + a[1] + a[2] + a[3]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (B.ok[k]) acf[ps + ok[k]] = 1.0/diag_c0<true>(i + (k & 1), j + (k >> 1), cc_box(nx, ny), a[k], fx, fy);
+        }
+        __syncthreads();
+    }
+    MG_STAMP(9);
+    // ---- level A down-leg
+    const bool bottomA = (nl == 1);
+    blk_down_sweeps<false, false>(A, bottomA ? nsweeps_bottom : 4);
+    if (!bottomA) {
+        double q0[4], q1[4];
+        blk_residual<false>(A, iA, jA, bA, aA, facx0, facy0, q0, q1);
+        if (A.act) {
+            const int p1 = d.nx[1] + 2, ps1 = p1*(d.ny[1] + 2);
+            base[d.off[1] + ps1 + ((jA >> 1) + 1)*p1 + (iA >> 1) + 1] = 0.25*(q0[0] + q0[1] + q0[2] + q0[3]);
+        }
+        __syncthreads();
+    }
+    MG_STAMP(10);
+    if (!bottomA) {
+        // lw = first level whose blocks (and those of every level below it) fit wave 0
+        int lw = 1;
+        for (; lw < nl; ++lw) {
+            const int nbx = (d.nx[lw] + 1) >> 1, nby = (d.ny[lw] + 1) >> 1;
+            int lg = 0; while ((1 << lg) < nbx) ++lg;
+            if ((nby << lg) <= 64) break;
+        }
+        for (int l = 1; l < lw; ++l)
+            low_down_s<false>(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l), (l == nl - 1) ? nsweeps_bottom : 4, l == nl - 1);
+        MG_STAMP(11);
+        if (lw < nl) {
+            if (t < 64) {
+                for (int l = lw; l < nl; ++l) {
+                    MG_STAMP(16 + l);
+                    const bool tiny = (d.nx[l] <= 8 && d.ny[l] <= 8 && l < nl - 1);
+                    if (tiny) tiny_down_s(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l));
+                    else low_down_s<true>(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l), (l == nl - 1) ? nsweeps_bottom : 4, l == nl - 1);
+                }
+                for (int l = nl - 2; l >= lw; --l) {
+                    MG_STAMP(32 + l);
+                    if (d.nx[l] <= 8 && d.ny[l] <= 8) tiny_up_s(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l));
+                    else low_up_s<true>(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l));
+                }
+            }
+            __syncthreads();
+        }
+        MG_STAMP(12);
+        for (int l = min(lw - 1, nl - 2); l >= 1; --l)
+            low_up_s<false>(base, d, l, t, lvl_fac(facx0, l), lvl_fac(facy0, l));
+        // ---- level A up-leg: correction back from LDS, prolongation, 4 sweeps
+        const int p1 = d.nx[1] + 2;
+        const lds_double* kc = base + d.off[1] + ((jA >> 1) + 1)*p1 + (iA >> 1) + 1;
+        const double k0 = A.act ? kc[0] : 0.0;
+        const int ok[4] = {0, 1, A.pitch, A.pitch + 1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int o = A.ok[k] ? ok[k] : 0;
+            const double c0 = A.c0[o];
+            A.v0[k] = A.ok[k] ? c0 + k0 : 0.0;
+            if (A.ok[k]) A.c0[o] = A.v0[k];
+            A.r0[k] = rA[k];
+        }
+        __syncthreads();
+        blk_sweep<0, false, false>(A); blk_sweep<1, false, false>(A); blk_sweep<0, false, false>(A); blk_sweep<1, false, false>(A);
+    }
+    MG_STAMP(13);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int g = min(iA + (k & 1), nxA - 1) + min(jA + (k >> 1), nyA - 1)*nxA;
+        if (A.ok[k]) cor_g[g] = A.v0[k];
+    }
+    MG_STAMP(14);
+}
+
 // Coefficient pyramid, cell-centred (average_down_acoef, HpMultiGrid.cpp:1640-1700): one launch
 // derives levels 1..nlev_out from level 0.  A workgroup owns a 32 x 32 block of level-0 cells;
 // thread t holds the level-1 cell (t & 15, t >> 4) of the block and levels 2.. go through LDS.
 // The nested 0.25*(((a+b)+c)+d) order of restrict_cc is kept at every level.
-struct PyrOut { double* p[5]; int nx[5], ny[5]; };      // levels 1..5, row pitch = nx
+struct PyrOut { double* p[5]; int nx[5], ny[5];      // levels 1..5, row pitch = nx
+                double* cinv; int cinv_l; double cfx, cfy; };      // inverse diagonals of level 1 + cinv_l (k_lower_v3's level A), or null
 
 __global__ __launch_bounds__(256)
 void k_acf_pyramid (FView acf0, int nx0, int ny0, PyrOut out, int nlev_out, unsigned long long* zero, int nzero)
@@ -1002,7 +1271,10 @@ void k_acf_pyramid (FView acf0, int nx0, int ny0, PyrOut out, int nlev_out, unsi
         const int i = bi + 2*li, j = bj + 2*lj;
         if (i + 1 < nx0 && j + 1 < ny0) v = 0.25*(acf0(i, j, 0) + acf0(i+1, j, 0) + acf0(i, j+1, 0) + acf0(i+1, j+1, 0));
         const int ic = (bi >> 1) + li, jc = (bj >> 1) + lj;
-        if (ic < out.nx[0] && jc < out.ny[0]) out.p[0][ic + (long)jc*out.nx[0]] = v;
+        if (ic < out.nx[0] && jc < out.ny[0]) {
+            out.p[0][ic + (long)jc*out.nx[0]] = v;
+            if (out.cinv && out.cinv_l == 0) out.cinv[ic + (long)jc*out.nx[0]] = 1.0/diag_c0<true>(ic, jc, cc_box(out.nx[0], out.ny[0]), v, out.cfx, out.cfy);
+        }
         s_a[0][t] = v;
     }
     int n = 16, cur = 0;
@@ -1015,11 +1287,21 @@ void k_acf_pyramid (FView acf0, int nx0, int ny0, PyrOut out, int nlev_out, unsi
             const int w = 2*n;
             v = 0.25*(f[2*li + 2*lj*w] + f[2*li + 1 + 2*lj*w] + f[2*li + (2*lj + 1)*w] + f[2*li + 1 + (2*lj + 1)*w]);
             const int ic = (bi >> (l + 1)) + li, jc = (bj >> (l + 1)) + lj;
-            if (ic < out.nx[l] && jc < out.ny[l]) out.p[l][ic + (long)jc*out.nx[l]] = v;
+            if (ic < out.nx[l] && jc < out.ny[l]) {
+                out.p[l][ic + (long)jc*out.nx[l]] = v;
+                if (out.cinv && out.cinv_l == l) out.cinv[ic + (long)jc*out.nx[l]] = 1.0/diag_c0<true>(ic, jc, cc_box(out.nx[l], out.ny[l]), v, out.cfx, out.cfy);
+            }
             s_a[cur ^ 1][t] = v;
         }
         cur ^= 1;
     }
+}
+
+// inverse diagonals of a cell-centred level (grids whose level A lies below the pyramid kernel's five levels)
+__global__ void k_level_cinv (const double* __restrict__ acf, double* __restrict__ cinv, int nx, int ny, double fx, double fy)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (i < nx && j < ny) cinv[i + (long)j*nx] = 1.0/diag_c0<true>(i, j, cc_box(nx, ny), acf[i + (long)j*nx], fx, fy);
 }
 
 __global__ void k_copy2 (LevBox b, FView dst, FView src)
@@ -1053,6 +1335,8 @@ struct Multigrid {
     int last_iters = 1;                         // V-cycles of the previous solve = speculation depth
     SolveRun run{};                             // the solve between mg_solve1_begin and mg_solve1_finish
     bool use_low2 = false; Low2 low2{}; Low2* d_low2 = nullptr; size_t low2_lds = 0;   // cell-centred register/LDS lower V
+    bool use_low3 = false; Low2 low3{}; Low2* d_low3 = nullptr; size_t low3_lds = 0;   // ... one component per workgroup (k_lower_v3)
+    double* cinvA = nullptr;                    // inverse diagonals of level lowv_begin (written with the coefficient pyramid)
     double* tmp0 = nullptr;                     // level-0 scratch: smoothed solution before the last GSRB^4
     bool fuse_level0 = true, cor_in_tmp = false; // fused 8-sweep end of the V-cycle; which buffer holds cor[0]
     long small_tile_cells = 300L*300L;          // levels up to this many cells use TileSmall
@@ -1062,7 +1346,7 @@ struct Multigrid {
     ~Multigrid () {
         for (auto& l : L) { (void)hipFree(l.acf); (void)hipFree(l.res); (void)hipFree(l.cor); (void)hipFree(l.rescor); }
         if (getenv("HPS_MG_DEBUG")) fprintf(stderr, "mg: solves %ld trips %ld hist %ld %ld %ld %ld %ld %ld\n", dbg_solves, dbg_trips, dbg_hist[0], dbg_hist[1], dbg_hist[2], dbg_hist[3], dbg_hist[4], dbg_hist[5]);
-        (void)hipFree(d_buf); (void)hipFree(d_low); (void)hipFree(tmp0); (void)hipFree(d_low2);
+        (void)hipFree(d_buf); (void)hipFree(d_low); (void)hipFree(tmp0); (void)hipFree(d_low2); (void)hipFree(d_low3); (void)hipFree(cinvA);
         if (h_buf) (void)hipHostFree(h_buf);
     }
     FView lv (int il, double* p) const {
@@ -1130,6 +1414,21 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
                 HPS_HIP_CHECK(hipFuncSetAttribute((const void*)k_lower_v2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->low2_lds));
             HPS_HIP_CHECK(hipMalloc(&M->d_low2, sizeof(Low2)));
             HPS_HIP_CHECK(hipMemcpy(M->d_low2, &d, sizeof(Low2), hipMemcpyHostToDevice));
+            if (!getenv("HPS_MG_LOWV2")) {
+                // the same levels, one component per workgroup: level A one plane, the others cor | res | acf | 1/diag
+                M->use_low3 = true;
+                Low2& e = M->low3;
+                e = d;
+                int off3 = 0;
+                for (int k = 0; k < e.nl; ++k) { e.off[k] = off3; off3 += (k == 0 ? 1 : 4)*(e.nx[k] + 2)*(e.ny[k] + 2); }
+                e.total = off3;
+                M->low3_lds = (size_t)off3*sizeof(double);
+                if (M->low3_lds > 64*1024)
+                    HPS_HIP_CHECK(hipFuncSetAttribute((const void*)k_lower_v3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->low3_lds));
+                HPS_HIP_CHECK(hipMalloc(&M->d_low3, sizeof(Low2)));
+                HPS_HIP_CHECK(hipMemcpy(M->d_low3, &e, sizeof(Low2), hipMemcpyHostToDevice));
+                HPS_HIP_CHECK(hipMalloc(&M->cinvA, (size_t)d.nx[0]*d.ny[0]*sizeof(double)));
+            }
             break;
         }
     }
@@ -1219,7 +1518,10 @@ static void vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
         const double ldx = M->dx*fac, ldy = M->dy*fac;
         const LevBox& bb = M->L[nl-1].b;
         const int nsweeps = std::max(16, (std::max(bb.hix - bb.lox + 1, bb.hiy - bb.loy + 1) + 1)/2*2);
-        if (M->use_low2)
+        if (M->use_low3)
+            hipLaunchKernelGGL(k_lower_v3, dim3(2), dim3(1024), M->low3_lds, st, M->d_low3, M->L[lb].acf, M->cinvA, M->L[lb].res, M->L[lb].cor,
+                               M->low3.nx[0], M->low3.ny[0], 1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr);
+        else if (M->use_low2)
             hipLaunchKernelGGL(k_lower_v2, dim3(1), dim3(1024), M->low2_lds, st, M->d_low2, M->L[lb].acf, M->L[lb].res, M->L[lb].cor,
                                1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr);
         else
@@ -1262,7 +1564,8 @@ void k_post_norms (const unsigned long long* __restrict__ src, volatile unsigned
 {
     // one word for the kernels enqueued behind this solve before the host has seen its norms (the gated plasma push):
     // is the solve over after the V-cycles enqueued so far?
-    if (threadIdx.x == 0) *go_word = vcycle_active(after) ? 0 : 1;
+    {   const bool act = vcycle_active(after);      // (whole waves: the rule is read lane-parallel)
+        if (threadIdx.x == 0) *go_word = act ? 0 : 1; }
     for (int w = threadIdx.x; w < nwords; w += blockDim.x) dst[w] = src[w];
     __threadfence_system();
     __syncthreads();
@@ -1305,6 +1608,8 @@ static int solve1_begin (Multigrid* M, double tol_rel, double tol_abs, int max_i
         PyrOut po{};
         const int np = std::min(lb, 5);
         for (int il = 1; il <= np; ++il) { po.p[il-1] = M->L[il].acf; po.nx[il-1] = M->L[il].b.hix + 1; po.ny[il-1] = M->L[il].b.hiy + 1; }
+        const double lfac = (double)(1 << lb), lfx = 1.0/(M->dx*lfac*M->dx*lfac), lfy = 1.0/(M->dy*lfac*M->dy*lfac);
+        if (M->use_low3 && lb <= np) { po.cinv = M->cinvA; po.cinv_l = lb - 1; po.cfx = lfx; po.cfy = lfy; }
         hipLaunchKernelGGL(k_acf_pyramid, dim3(ceil_div(M->nx, 32), ceil_div(M->ny, 32)), dim3(256), 0, st, M->acf0, M->nx, M->ny, po, np,
                            M->d_norms, nzero_words);
         first = np + 1;
@@ -1316,6 +1621,12 @@ static int solve1_begin (Multigrid* M, double tol_rel, double tol_abs, int max_i
         FView fine = (il == 1) ? M->acf0 : M->lv(il-1, M->L[il-1].acf);
         hipLaunchKernelGGL(k_restrict<CC>, dim3(ceil_div(cb.vhx - cb.vlx + 1, 64), cb.vhy - cb.vly + 1), dim3(64), 0, st,
                            cb, M->lv(il, M->L[il].acf), fine, 1, always);
+    }
+    if (CC && M->use_low3 && lb > 5) {
+        const double lfac = (double)(1 << lb);
+        const int lnx = M->L[lb].b.hix + 1, lny = M->L[lb].b.hiy + 1;
+        hipLaunchKernelGGL(k_level_cinv, dim3(ceil_div(lnx, 64), lny), dim3(64), 0, st, M->L[lb].acf, M->cinvA, lnx, lny,
+                           1.0/(M->dx*lfac*M->dx*lfac), 1.0/(M->dy*lfac*M->dy*lfac));
     }
     // cor[0] = GSRB^4(sol), residual norm, rhs norm, res[1] = R(residual)  (solve_doit :1319-1346)
     launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), FView{}, M->rhs, M->acf0, M->sol, FView{}, M->lv(0, M->L[0].rescor),
@@ -1465,6 +1776,9 @@ void mg_rider (void* handle, int** dev_words, const int** host_words)
 
 extern "C" int hps_mg_debug_stamps (long long* stamps16_host)
 {
+#ifndef HPS_STAMPS
+    (void)stamps16_host; set_error("hps_mg_debug_stamps: the library was built without -DHPS_STAMPS (make stamps)"); return HPS_ERR_UNSUPPORTED;
+#else
     static long long* d = nullptr;
     if (!d) {
         HPS_HIP_CHECK(hipMalloc(&d, 48*sizeof(long long)));
@@ -1475,6 +1789,7 @@ extern "C" int hps_mg_debug_stamps (long long* stamps16_host)
     HPS_HIP_CHECK(hipDeviceSynchronize());
     HPS_HIP_CHECK(hipMemcpy(stamps16_host, d, 48*sizeof(long long), hipMemcpyDeviceToHost));
     return HPS_OK;
+#endif
 }
 
 extern "C" int hps_mg_destroy (void* handle)

@@ -36,8 +36,12 @@ static int expl_pad ()
 constexpr int TILE_HALO = HPS_TILE_HALO;
 
 // optional shader-clock stamps of one workgroup (hps_particles_debug_stamps)
+#ifdef HPS_STAMPS      // diagnostic build only (make stamps): reading the pointer is a dependent trip to memory at the head of the kernel
 __device__ long long* g_pt_dbg = nullptr;
 #define PT_STAMP(i) do { if (g_pt_dbg && blockIdx.x == 2000 && threadIdx.x == 0) g_pt_dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PT_STAMP(i) do { } while (0)
+#endif
 
 struct CompSlots { int n; int comp[6]; };   // active deposition components, in DepComps order
 
@@ -875,6 +879,9 @@ using namespace hps;
 
 extern "C" int hps_particles_debug_stamps (long long* stamps8_host)
 {
+#ifndef HPS_STAMPS
+    (void)stamps8_host; set_error("hps_particles_debug_stamps: the library was built without -DHPS_STAMPS (make stamps)"); return HPS_ERR_UNSUPPORTED;
+#else
     static long long* d = nullptr;
     if (!d) {
         HPS_HIP_CHECK(hipMalloc(&d, 8*sizeof(long long)));
@@ -885,6 +892,7 @@ extern "C" int hps_particles_debug_stamps (long long* stamps8_host)
     HPS_HIP_CHECK(hipDeviceSynchronize());
     HPS_HIP_CHECK(hipMemcpy(stamps8_host, d, 8*sizeof(long long), hipMemcpyDeviceToHost));
     return HPS_OK;
+#endif
 }
 
 static int check_tiling (void* tiling, const hps_slab& s, const hps_plasma& pl, const char* what)

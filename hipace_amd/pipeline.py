@@ -346,6 +346,8 @@ def _run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices
             # the rank that runs step 0 evaluates the initial envelope; every later step receives a_n, a_{n-1} slice by
             # slice from the rank that ran the step before (MultiBuffer.cpp:840-852, 913-925)
             engine.set_laser_import(fed, step)
+        if hasattr(engine, "set_step"):
+            engine.set_step(step)                      # the physical step: density profile's time factor, ionisation draws
         engine.begin_step()
         imported = -1
         for q in range(per):
@@ -500,6 +502,8 @@ def _run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_s
                     # the stage that runs step 0 evaluates the initial envelope; every later step receives a_n, a_{n-1}
                     # slice by slice from the stage that ran the step before (MultiBuffer.cpp:840-852, 913-925)
                     eng.set_laser_import(fed, step)
+                if hasattr(eng, "set_step"):
+                    eng.set_step(step)
                 eng.begin_step()
                 copied = 0
                 lcopied = 0

@@ -250,6 +250,11 @@ enum { HPS_PC_N_JX = 0, HPS_PC_N_JY, HPS_PC_EXMBY, HPS_PC_EYPBX, HPS_PC_EZ, HPS_
 int hps_engine_create (const hps_deck* deck, int device, void** handle);
 int hps_engine_destroy (void* handle);
 int hps_engine_begin_step (void* handle);                 /* Evolve :401-471: reset, plasma, ions */
+/* The physical time step the next hps_engine_begin_step starts (Hipace::m_physical_time = step * dt,
+ * PlasmaParticleContainerInit.cpp:90): the density profile's time factor and the key of the ionisation draws follow it.
+ * Without a call an engine counts its own begin_step calls -- right for one engine running every step; a pipeline stage
+ * that runs steps r, r + N, ... (Hipace.cpp:400-401) must say which step it is about to run. */
+int hps_engine_set_step (void* handle, int step);
 int hps_engine_solve_slice (void* handle, int islice);    /* SolveOneSlice :556-728               */
 int hps_engine_run_step (void* handle);                   /* begin_step + all slices head->tail   */
 int hps_engine_sync (void* handle);                       /* host waits for the engine's stream (and, through it, the laser stream) */

@@ -1090,7 +1090,7 @@ struct Engine {
     long pl_cap = 0;                         // capacity of the first species' arrays (grows by ionisation)
     std::vector<double> idata; std::vector<int32_t> ivalid, ilev; std::vector<uint64_t> iuid; Plasma ipl;      // species "ion"
     std::vector<double> adk_prefactor, adk_exp_prefactor, adk_power;
-    long n_ionized_total = 0; int cur_step = -1;
+    long n_ionized_total = 0; int cur_step = -1, next_step = -1;
     // plasma density profile n(x, y, ct) = density * f_r(sqrt(x^2 + y^2)) * f_t(c t), both piecewise linear tables (constant
     // beyond their ends); the tabulated stand-in of <plasma>.density(x,y,z) (PlasmaParticleContainerInit.cpp:246-313: the
     // function is evaluated per particle with z = c t; particles with density <= min_density = 0 are not created)
@@ -2018,7 +2018,7 @@ struct Engine {
     void begin_step () {
         std::fill(slab_data.begin(), slab_data.end(), 0.0);     // ResetAllQuantities
         beam_this_slice = -2;
-        ++cur_step;
+        cur_step = (next_step >= 0) ? next_step : cur_step + 1; next_step = -1;
         init_plasma();
         // DepositNeutralizingBackground (plasma/MultiPlasma.cpp:106-118): rhomjz only, charge -q
         const int comp[6] = {-1, -1, -1, -1, -1, d.bxby_solver ? (int)pIon_rhomjz : (int)Ion_rhomjz};
@@ -2280,6 +2280,7 @@ double orc_engine_laser_envelope_sum (void* h) { return static_cast<Engine*>(h)-
 // envelope a_n of the step that has begun, [nz][ny][nx] complex (interleaved re, im); null without a laser
 // ring hand-off of the envelope (MultiBuffer.cpp:840-852, 913-925): what a stage passes on for slice islice is
 // {a_{n+1}, a_n}, which the next stage stores as its {a_n, a_{n-1}}
+void orc_engine_set_step (void* h, int step) { static_cast<Engine*>(h)->next_step = step; }
 void orc_engine_set_laser_import (void* h, int on, int step) { Engine* e = static_cast<Engine*>(h); e->laser_import = (on != 0); e->laser_steps = step; }
 void orc_engine_export_laser_slice (void* h, int islice, double* out /* [2][ny][nx] complex */) {
     Engine* e = static_cast<Engine*>(h); const size_t pl2 = (size_t)e->d.nx*e->d.ny;

@@ -627,6 +627,12 @@ class Engine:
     def laser_message_doubles(self):
         return 4 * self.deck["nx"] * self.deck["ny"]
 
+    def set_step(self, step):
+        L = lib()
+        L.orc_engine_set_step.restype = None
+        L.orc_engine_set_step.argtypes = [C.c_void_p, C.c_int]
+        L.orc_engine_set_step(self._h, int(step))
+
     def set_laser_import(self, on, step=0):
         L = lib()
         L.orc_engine_set_laser_import.restype = None
