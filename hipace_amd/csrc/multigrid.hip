@@ -585,7 +585,8 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
 // HBM for the up-leg).  Levels of at most 64 blocks run in wave 0 alone without workgroup barriers.
 // The first sweep of every down-leg level starts from cor = 0, where the update is rhs/diag exactly.
 constexpr int LOW2_MAXLEV = 8;
-struct Low2 { int nl; int total; int nx[LOW2_MAXLEV], ny[LOW2_MAXLEV], off[LOW2_MAXLEV]; };
+struct Low2 { int nl; int total; int nx[LOW2_MAXLEV], ny[LOW2_MAXLEV], off[LOW2_MAXLEV];
+              int coff[LOW2_MAXLEV], cbase, ctot; };      // k_lower_v3: the levels' [acf | 1/diag] planes, one contiguous image from cbase
 
 __device__ __forceinline__ LevBox cc_box (int nx, int ny) { return LevBox{0, 0, nx - 1, ny - 1, 0, 0, nx - 1, ny - 1}; }
 
@@ -738,7 +739,7 @@ __device__ __forceinline__ void blk_geometry (Blk& B, lds_double* lev, int nx, i
                                               int cmp = 0)
 {
     const int nbx = (nx + 1) >> 1, nby = (ny + 1) >> 1;
-    int lg = 0; while ((1 << lg) < nbx) ++lg;                  // blocks per row rounded up to a power of two
+    const int lg = (nbx <= 1) ? 0 : 32 - __clz(nbx - 1);       // blocks per row rounded up to a power of two
     const int bi = t & ((1 << lg) - 1), bj = t >> lg;
     B.act = (bi < nbx) && (bj < nby);
     i = 2*bi; j = 2*bj;
@@ -1024,12 +1025,13 @@ __device__ __forceinline__ void low_down_s (lds_double* base, const Low2& d, int
     blk_geometry(B, base + d.off[l], nx, ny, t, fx, fy, i, j);
     const int ps = B.pitch*(ny + 2);
     const lds_double* r = B.c0 + ps;
+    const lds_double* cf = base + d.coff[l] + (B.c0 - (base + d.off[l]));      // the block's cell 0 in the acf plane
     const int ok[4] = {0, 1, B.pitch, B.pitch + 1};
     double a[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int o = B.ok[k] ? ok[k] : 0;
-        B.r0[k] = r[o]; B.r1[k] = 0.0; a[k] = r[ps + o]; B.ci[k] = r[2*ps + o];
+        B.r0[k] = r[o]; B.r1[k] = 0.0; a[k] = cf[o]; B.ci[k] = cf[ps + o];
     }
     if (last && nx <= 2 && ny <= 2) { blk_single_sweeps<false>(B, nsw); lvl_sync<WAVE>(); }
     else blk_down_sweeps<WAVE, false>(B, nsw);
@@ -1052,6 +1054,7 @@ __device__ __forceinline__ void low_up_s (lds_double* base, const Low2& d, int l
     blk_geometry(B, base + d.off[l], nx, ny, t, fx, fy, i, j);
     const int ps = B.pitch*(ny + 2);
     const lds_double* r = B.c0 + ps;
+    const lds_double* cf = base + d.coff[l] + (B.c0 - (base + d.off[l]));
     const int ok[4] = {0, 1, B.pitch, B.pitch + 1};
     const int pn = d.nx[l+1] + 2;
     const lds_double* kc = base + d.off[l+1] + ((j >> 1) + 1)*pn + (i >> 1) + 1;
@@ -1059,7 +1062,7 @@ __device__ __forceinline__ void low_up_s (lds_double* base, const Low2& d, int l
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int o = B.ok[k] ? ok[k] : 0;
-        B.r0[k] = r[o]; B.r1[k] = 0.0; B.ci[k] = r[2*ps + o];
+        B.r0[k] = r[o]; B.r1[k] = 0.0; B.ci[k] = cf[ps + o];
         const double c0 = B.c0[o];
         B.v0[k] = B.ok[k] ? c0 + k0 : 0.0;
         if (B.ok[k]) B.c0[o] = B.v0[k];
@@ -1077,7 +1080,8 @@ __device__ __forceinline__ void tiny_down_s (lds_double* base, const Low2& d, in
     const bool ok = (i < nx) && (j < ny);
     const int o = ok ? (j + 1)*pitch + i + 1 : pitch + 1;
     lds_double* c0 = base + d.off[l] + o;
-    const double r0 = c0[ps], a = c0[2*ps], ci = c0[3*ps];
+    const lds_double* cf = base + d.coff[l] + o;
+    const double r0 = c0[ps], a = cf[0], ci = cf[ps];
     const double fxm = wall_mult<true>(i, 0, nx - 1, fx), fym = wall_mult<true>(j, 0, ny - 1, fy);
     if (ok && (((i + j) & 1) == 0)) c0[0] = r0*ci;                          // sweep 0 from cor = 0
     lvl_sync<true>();
@@ -1103,7 +1107,7 @@ __device__ __forceinline__ void tiny_up_s (lds_double* base, const Low2& d, int 
     const bool ok = (i < nx) && (j < ny);
     const int o = ok ? (j + 1)*pitch + i + 1 : pitch + 1;
     lds_double* c0 = base + d.off[l] + o;
-    const double r0 = c0[ps], ci = c0[3*ps];
+    const double r0 = c0[ps], ci = base[d.coff[l] + ps + o];
     const double fxm = wall_mult<true>(i, 0, nx - 1, fx), fym = wall_mult<true>(j, 0, ny - 1, fy);
     if (ok) {
         const int pn = d.nx[l+1] + 2;
@@ -1118,13 +1122,13 @@ __device__ __forceinline__ void tiny_up_s (lds_double* base, const Low2& d, int 
 
 __global__ __launch_bounds__(1024)
 void k_lower_v3 (const Low2* __restrict__ dp, const double* __restrict__ acf_g, const double* __restrict__ cinv_g,
-                 const double* __restrict__ res_g, double* __restrict__ cor_g, int nxA, int nyA, double facx0, double facy0,
-                 int nsweeps_bottom, StopRule sr)
+                 const double* __restrict__ res_g, double* __restrict__ cor_g, double* __restrict__ coef_g, int nxA, int nyA, int ctot,
+                 double facx0, double facy0, int nsweeps_bottom, StopRule sr)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_double* base = (lds_double*)lds_raw;
     const int t = threadIdx.x;
-    const Low2& d = *dp;          // (level A's size comes by value: the first loads must not wait for this read)
+    const Low2& d = *dp;          // (level A's size and the image's length come by value: the first loads must not wait for this read)
     const int nl = d.nl;
     const int cellsA = nxA*nyA;
     res_g += (long)blockIdx.x*cellsA; cor_g += (long)blockIdx.x*cellsA;      // this workgroup's component
@@ -1141,9 +1145,18 @@ void k_lower_v3 (const Low2* __restrict__ dp, const double* __restrict__ acf_g, 
         rA[k] = A.ok[k] ? v0 : 0.0; aA[k] = A.ok[k] ? v2 : 0.0; A.ci[k] = A.ok[k] ? v3 : 0.0;
         A.r0[k] = rA[k]; A.r1[k] = 0.0;
     }
+    // The [acf | 1/diag] planes of the levels below A depend on the coefficient only: the first V-cycle of a solve derives
+    // them (average_down_acoef + one division per cell) and leaves the image in coef_g, the later ones copy it in.
+    const bool derive = (sr.k <= 0);
+    constexpr int NIMG = 4;      // image words per thread (LOW2 levels below 64 x 64: 3264 doubles)
+    double img[NIMG];
+#pragma unroll
+    for (int m = 0; m < NIMG; ++m) { const int q = min(t + 1024*m, ctot - 1); img[m] = derive ? 0.0 : coef_g[q]; }
     const bool active = vcycle_active(sr);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { HPS_KEEP(rA[k]); HPS_KEEP(aA[k]); HPS_KEEP(A.ci[k]); }
+#pragma unroll
+    for (int m = 0; m < NIMG; ++m) HPS_KEEP(img[m]);
     if (!active) return;
     MG_STAMP(8);
     // only the correction planes need zeros (ring + the cells of the colour the first half-sweep skips)
@@ -1152,34 +1165,42 @@ void k_lower_v3 (const Low2* __restrict__ dp, const double* __restrict__ acf_g, 
         lds_double* c = base + d.off[l];
         for (int s = t; s < n1; s += 1024) c[s] = 0.0;
     }
-    __syncthreads();
-    // ---- coefficient hierarchy (average_down_acoef) and inverse diagonals of the levels below
-    if (nl > 1 && A.act) {
-        const int p1 = d.nx[1] + 2, ps1 = p1*(d.ny[1] + 2);
-        base[d.off[1] + 2*ps1 + ((jA >> 1) + 1)*p1 + (iA >> 1) + 1] = 0.25*(aA[0] + aA[1] + aA[2] + aA[3]);
+    if (!derive) {
+#pragma unroll
+        for (int m = 0; m < NIMG; ++m) if (t + 1024*m < ctot) base[d.cbase + t + 1024*m] = img[m];
+        for (int q = t + 1024*NIMG; q < ctot; q += 1024) base[d.cbase + q] = coef_g[q];      // (larger level sets)
     }
     __syncthreads();
-    for (int l = 1; l < nl; ++l) {
-        const double fx = lvl_fac(facx0, l), fy = lvl_fac(facy0, l);
-        const int nx = d.nx[l], ny = d.ny[l];
-        Blk B; int i, j;
-        blk_geometry(B, base + d.off[l], nx, ny, t, fx, fy, i, j);
-        const int ps = B.pitch*(ny + 2);
-        lds_double* acf = B.c0 + 2*ps;
-        const int ok[4] = {0, 1, B.pitch, B.pitch + 1};
-        if (B.act) {          // (whole waves have no block on the small levels: they skip the divisions)
-            double a[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] = B.ok[k] ? acf[ok[k]] : 0.0;
-            if (l + 1 < nl) {     // the next level's coefficient first: the divisions below are off the critical path
-                const int pn = d.nx[l+1] + 2, psn = pn*(d.ny[l+1] + 2);
-                base[d.off[l+1] + 2*psn + ((j >> 1) + 1)*pn + (i >> 1) + 1] = 0.25*(a[0] + a[1] + a[2] + a[3]);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (B.ok[k]) acf[ps + ok[k]] = 1.0/diag_c0<true>(i + (k & 1), j + (k >> 1), cc_box(nx, ny), a[k], fx, fy);
+    if (derive) {
+        // ---- coefficient hierarchy (average_down_acoef) and inverse diagonals of the levels below
+        if (nl > 1 && A.act) {
+            const int p1 = d.nx[1] + 2;
+            base[d.coff[1] + ((jA >> 1) + 1)*p1 + (iA >> 1) + 1] = 0.25*(aA[0] + aA[1] + aA[2] + aA[3]);
         }
         __syncthreads();
+        for (int l = 1; l < nl; ++l) {
+            const double fx = lvl_fac(facx0, l), fy = lvl_fac(facy0, l);
+            const int nx = d.nx[l], ny = d.ny[l];
+            Blk B; int i, j;
+            blk_geometry(B, base + d.coff[l], nx, ny, t, fx, fy, i, j);     // c0 = the block's cell 0 in the acf plane
+            const int ps = B.pitch*(ny + 2);
+            lds_double* acf = B.c0;
+            const int ok[4] = {0, 1, B.pitch, B.pitch + 1};
+            if (B.act) {          // (whole waves have no block on the small levels: they skip the divisions)
+                double a[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] = B.ok[k] ? acf[ok[k]] : 0.0;
+                if (l + 1 < nl) {     // the next level's coefficient first: the divisions below are off the critical path
+                    const int pn = d.nx[l+1] + 2;
+                    base[d.coff[l+1] + ((j >> 1) + 1)*pn + (i >> 1) + 1] = 0.25*(a[0] + a[1] + a[2] + a[3]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (B.ok[k]) acf[ps + ok[k]] = 1.0/diag_c0<true>(i + (k & 1), j + (k >> 1), cc_box(nx, ny), a[k], fx, fy);
+            }
+            __syncthreads();
+        }
+        if (blockIdx.x == 0) for (int q = t; q < ctot; q += 1024) coef_g[q] = base[d.cbase + q];
     }
     MG_STAMP(9);
     // ---- level A down-leg
@@ -1337,7 +1358,9 @@ struct Multigrid {
     bool use_low2 = false; Low2 low2{}; Low2* d_low2 = nullptr; size_t low2_lds = 0;   // cell-centred register/LDS lower V
     bool use_low3 = false; Low2 low3{}; Low2* d_low3 = nullptr; size_t low3_lds = 0;   // ... one component per workgroup (k_lower_v3)
     double* cinvA = nullptr;                    // inverse diagonals of level lowv_begin (written with the coefficient pyramid)
+    double* coef_img = nullptr;                 // [acf | 1/diag] planes of the levels below it (left by the first V-cycle of a solve)
     double* tmp0 = nullptr;                     // level-0 scratch: smoothed solution before the last GSRB^4
+    bool init_huge = false;                     // HPS_MG_INIT_HUGE=1: the initial level-0 pass on 64 x 48 tiles (measured: 235 against 230 us per solve)
     bool fuse_level0 = true, cor_in_tmp = false; // fused 8-sweep end of the V-cycle; which buffer holds cor[0]
     long small_tile_cells = 300L*300L;          // levels up to this many cells use TileSmall
     long mid_tile_cells = 0;                    // ... up to this many TileMid
@@ -1346,7 +1369,7 @@ struct Multigrid {
     ~Multigrid () {
         for (auto& l : L) { (void)hipFree(l.acf); (void)hipFree(l.res); (void)hipFree(l.cor); (void)hipFree(l.rescor); }
         if (getenv("HPS_MG_DEBUG")) fprintf(stderr, "mg: solves %ld trips %ld hist %ld %ld %ld %ld %ld %ld\n", dbg_solves, dbg_trips, dbg_hist[0], dbg_hist[1], dbg_hist[2], dbg_hist[3], dbg_hist[4], dbg_hist[5]);
-        (void)hipFree(d_buf); (void)hipFree(d_low); (void)hipFree(tmp0); (void)hipFree(d_low2); (void)hipFree(d_low3); (void)hipFree(cinvA);
+        (void)hipFree(d_buf); (void)hipFree(d_low); (void)hipFree(tmp0); (void)hipFree(d_low2); (void)hipFree(d_low3); (void)hipFree(cinvA); (void)hipFree(coef_img);
         if (h_buf) (void)hipHostFree(h_buf);
     }
     FView lv (int il, double* p) const {
@@ -1387,6 +1410,7 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
     }
     if (M->nlev() < 2) { delete M; set_error("hps_mg_create: grid too small to coarsen"); return HPS_ERR_ARG; }
     if (const char* e = getenv("HPS_MG_SMALL_CELLS")) M->small_tile_cells = atol(e);
+    if (const char* e = getenv("HPS_MG_INIT_HUGE")) M->init_huge = atoi(e) != 0;
     if (const char* e = getenv("HPS_MG_MID_CELLS")) M->mid_tile_cells = atol(e);
     const int nl = M->nlev();
     M->lowv_begin = nl - 1;
@@ -1420,8 +1444,13 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
                 Low2& e = M->low3;
                 e = d;
                 int off3 = 0;
-                for (int k = 0; k < e.nl; ++k) { e.off[k] = off3; off3 += (k == 0 ? 1 : 4)*(e.nx[k] + 2)*(e.ny[k] + 2); }
+                for (int k = 0; k < e.nl; ++k) { e.off[k] = off3; off3 += (k == 0 ? 1 : 2)*(e.nx[k] + 2)*(e.ny[k] + 2); }      // cor [| res]
+                e.cbase = off3; e.coff[0] = off3;
+                for (int k = 1; k < e.nl; ++k) { e.coff[k] = off3; off3 += 2*(e.nx[k] + 2)*(e.ny[k] + 2); }                        // acf | 1/diag
+                e.ctot = std::max(off3 - e.cbase, 1);
                 e.total = off3;
+                HPS_HIP_CHECK(hipMalloc(&M->coef_img, (size_t)e.ctot*sizeof(double)));
+                HPS_HIP_CHECK(hipMemset(M->coef_img, 0, (size_t)e.ctot*sizeof(double)));
                 M->low3_lds = (size_t)off3*sizeof(double);
                 if (M->low3_lds > 64*1024)
                     HPS_HIP_CHECK(hipFuncSetAttribute((const void*)k_lower_v3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)M->low3_lds));
@@ -1520,7 +1549,7 @@ static void vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
         const int nsweeps = std::max(16, (std::max(bb.hix - bb.lox + 1, bb.hiy - bb.loy + 1) + 1)/2*2);
         if (M->use_low3)
             hipLaunchKernelGGL(k_lower_v3, dim3(2), dim3(1024), M->low3_lds, st, M->d_low3, M->L[lb].acf, M->cinvA, M->L[lb].res, M->L[lb].cor,
-                               M->low3.nx[0], M->low3.ny[0], 1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr);
+                               M->coef_img, M->low3.nx[0], M->low3.ny[0], M->low3.ctot, 1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr);
         else if (M->use_low2)
             hipLaunchKernelGGL(k_lower_v2, dim3(1), dim3(1024), M->low2_lds, st, M->d_low2, M->L[lb].acf, M->L[lb].res, M->L[lb].cor,
                                1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr);
@@ -1629,6 +1658,11 @@ static int solve1_begin (Multigrid* M, double tol_rel, double tol_abs, int max_i
                            1.0/(M->dx*lfac*M->dx*lfac), 1.0/(M->dy*lfac*M->dy*lfac));
     }
     // cor[0] = GSRB^4(sol), residual norm, rhs norm, res[1] = R(residual)  (solve_doit :1319-1346)
+    // (optional 64 x 48 tiles: 494 workgroups at 1024^2 instead of 817 -- measured slower, see init_huge)
+    if (M->init_huge && M->L[0].cells > M->small_tile_cells)
+        launch_smooth_ts<TileHuge, CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), FView{}, M->rhs, M->acf0, M->sol, FView{}, M->lv(0, M->L[0].rescor),
+                                                         M->lv(1, M->L[1].res), M->d_norms, M->d_norms + MG_NSUB, always, st);
+    else
     launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), FView{}, M->rhs, M->acf0, M->sol, FView{}, M->lv(0, M->L[0].rescor),
                                         M->lv(1, M->L[1].res), M->d_norms, M->d_norms + MG_NSUB, always, st);
     restrict_residual_if_nodal<CC>(M, 0, always, st);
