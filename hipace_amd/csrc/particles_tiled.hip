@@ -395,12 +395,19 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
     }
 }
 
+// array element at a 32-bit byte offset from a uniform base: global_load / global_store with an SGPR base and one offset VGPR
+template <class T> __device__ __forceinline__ T ldo (const T* base, unsigned o) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + o); }
+template <class T> __device__ __forceinline__ void sto (T* base, unsigned o, T v) { *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + o) = v; }
+
 // IONIZE: the species can be field-ionised (ADK, ionization.hip).  The decision needs exactly the fields the push gathers,
 // so it is taken here, between the gather and the push (the reference ionises, then pushes: Hipace.cpp:693-701): the ion's
 // level goes up, its electron is appended to the product species, and the push runs with the new charge.  A neutral
 // atom at rest is not pushed at all (zero charge: the push would leave every quantity as it is).
+#ifndef HPS_PUSH_WAVES
+#define HPS_PUSH_WAVES 3
+#endif
 template <int ORDER, int TS, bool LASER = false, bool IONIZE = false>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((LASER || IONIZE) ? 1 : HPS_PUSH_WAVES)))
 void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
                       int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, int* n_fallback, IonArgs ia, const int* go)
 {
@@ -430,19 +437,46 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     __syncthreads();
     if (!go_now) return;
 
-    // (prefetching the next particle's state during the push was measured: 225 VGPRs, same 185 us --
-    //  the kernel is bound by its fp64 instruction stream, not by load latency)
-    const int pend = offsets[tile + 1];
+    // The thread's particles are ip = first + 256 m.  Per particle the kernel needs idcpu, x_prev, y_prev and the three
+    // half-step momenta: read one after the other where they are used (the validity bit first), that was three dependent
+    // trips to memory per particle against ~1 us of arithmetic, with three waves per SIMD to hide them: the waves of
+    // the round-2 kernel lived 29 us for 4-5 particles and issued VALU instructions a fifth of that time.  Now all six
+    // values of particle m + 1 are requested before particle m is worked on (14 VGPRs), and every array is addressed
+    // as uniform base + one 32-bit byte offset (the file is compiled with -disable-lsr: the loop-strength-reduction
+    // pass otherwise keeps a 64-bit pointer per array and iteration in VGPRs, 24 registers here).
+    const unsigned pend = (unsigned)offsets[tile + 1];
     int nfb = 0;
-    for (int ip = offsets[tile] + tid; ip < pend; ip += 256) {
-        const uint64_t id = pl.idcpu[ip];
+    struct PIn { uint64_t id; double xp, yp, uxh, uyh, psih; };
+    auto fetch = [&] (unsigned ip) {
+        PIn q;
+        const unsigned o = ip*8u;
+        q.id = ldo(pl.idcpu, o); q.xp = ldo(pl.x_prev, o); q.yp = ldo(pl.y_prev, o);
+        q.uxh = ldo(pl.ux_half, o); q.uyh = ldo(pl.uy_half, o); q.psih = ldo(pl.psi_half, o);
+        return q;
+    };
+#ifdef HPS_PUSH_PREFETCH
+    unsigned ip = (unsigned)offsets[tile] + tid;
+    PIn nxt{0, 0.0, 0.0, 0.0, 0.0, 1.0};
+    if (ip < pend) nxt = fetch(ip);
+    for (; ip < pend; ip += 256) {
+        __builtin_assume(ip < (1u << 28));
+        const PIn cur = nxt;
+        if (ip + 256 < pend) nxt = fetch(ip + 256);
+#else
+    for (unsigned ip = (unsigned)offsets[tile] + tid; ip < pend; ip += 256) {
+        __builtin_assume(ip < (1u << 28));
+        const PIn cur = fetch(ip);          // one batch of six loads, one trip to memory per particle
+#endif
+        const unsigned o8 = ip*8u;
+        const uint64_t id = cur.id;
         if (!(id & HPS_ID_VALID)) continue;
         double qmc = k.a;
         if (k.can_ionize) qmc *= (double)pl.ion_lev[ip];
         bool dead = false;
         for (int isc = 0; isc < k.n_subcycles && !dead; ++isc) {
-            double xp = pl.x_prev[ip];
-            double yp = pl.y_prev[ip];
+            // (sub-cycles after the first re-read what the one before has committed, as the reference does)
+            double xp = isc == 0 ? cur.xp : ldo(pl.x_prev, o8);
+            double yp = isc == 0 ? cur.yp : ldo(pl.y_prev, o8);
             double sx[NS], dsx[NS], sy[NS], dsy[NS];
             const int i0 = nodal_weights<ORDER>((xp - k.xoff)*k.dx_inv, sx, dsx);
             const int j0 = nodal_weights<ORDER>((yp - k.yoff)*k.dy_inv, sy, dsy);
@@ -501,9 +535,9 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             if constexpr (IONIZE) {
                 if (isc == 0) {
                     int lev = pl.ion_lev[ip];
-                    const double uxh = pl.ux_half[ip], uyh = pl.uy_half[ip];
+                    const double uxh = cur.uxh, uyh = cur.uyh;
                     // an ion that has lost all Z electrons cannot ionise (the reference reads past the end of its tables)
-                    const bool ionize = lev < ia.Z && adk_decide(ia, F.ExmBy + F.Byc, F.EypBx - F.Bxc, F.Ez, uxh, uyh, pl.psi_half[ip], lev, id);
+                    const bool ionize = lev < ia.Z && adk_decide(ia, F.ExmBy + F.Byc, F.EypBx - F.Bxc, F.Ez, uxh, uyh, cur.psih, lev, id);
                     if (ionize) { ++lev; pl.ion_lev[ip] = lev; qmc = k.a*(double)lev; }
                     adk_emit(ia, ionize, pl.x[ip], pl.y[ip], xp, yp, pl.w[ip]);
                     charged |= (lev > 0);
@@ -524,7 +558,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
                 Lf.A *= 0.5*ln; Lf.ADx *= 0.25*k.c*ln; Lf.ADy *= 0.25*k.c*ln;
             }
             const double dz = k.dz, sdz = dz*0.25;
-            double ux = pl.ux_half[ip], uy = pl.uy_half[ip], psi = pl.psi_half[ip];
+            double ux = isc == 0 ? cur.uxh : ldo(pl.ux_half, o8), uy = isc == 0 ? cur.uyh : ldo(pl.uy_half, o8), psi = isc == 0 ? cur.psih : ldo(pl.psi_half, o8);
             if constexpr (LASER) {
 #pragma unroll 1
                 for (int s = 0; s < 4; ++s) taylor2_substep_laser(ux, uy, psi, F, Lf, k.c_inv, qmc, sdz);
@@ -536,16 +570,16 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             xp += dz*k.c_inv*(ux*pinv);
             yp += dz*k.c_inv*(uy*pinv);
             if (apply_particle_bc(k, xp, yp, ux, uy)) {
-                pl.w[ip] = 0.0;
-                pl.idcpu[ip] = id & ~HPS_ID_VALID;
+                sto(pl.w, o8, 0.0);
+                sto(pl.idcpu, o8, (uint64_t)(id & ~HPS_ID_VALID));
                 dead = true;
                 break;
             }
-            pl.x[ip] = xp; pl.y[ip] = yp;
+            sto(pl.x, o8, xp); sto(pl.y, o8, yp);
             if (!k.temp_slice) {
-                pl.ux_half[ip] = ux; pl.uy_half[ip] = uy; pl.psi_half[ip] = psi;
-                if (pl.x_prev != pl.x) pl.x_prev[ip] = xp;      // (aliased by the engine: already stored)
-                if (pl.y_prev != pl.y) pl.y_prev[ip] = yp;
+                sto(pl.ux_half, o8, ux); sto(pl.uy_half, o8, uy); sto(pl.psi_half, o8, psi);
+                if (pl.x_prev != pl.x) sto(pl.x_prev, o8, xp);      // (aliased by the engine: already stored)
+                if (pl.y_prev != pl.y) sto(pl.y_prev, o8, yp);
             }
             if constexpr (LASER) {
 #pragma unroll 1
@@ -554,7 +588,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
 #pragma unroll 1
                 for (int s = 0; s < 2; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
             }
-            pl.ux[ip] = ux; pl.uy[ip] = uy; pl.psi[ip] = psi;
+            sto(pl.ux, o8, ux); sto(pl.uy, o8, uy); sto(pl.psi, o8, psi);
         }
     }
     if (n_fallback && nfb) atomicAdd(n_fallback, nfb);
