@@ -14,6 +14,12 @@ engine first runs (untimed) down to slice --start-slice, where a window of K sli
 box costs on average, then W warm-up slices, then exactly K timed slices.  The line says which slices were
 timed and how many V-cycles they needed.
 
+Several time steps in flight: after the headline measurement (one engine, `value`) the same workload is timed with
+--inflight L (default 3) engines on L streams of the GPU, L consecutive time steps trailing one another by the per-slice
+beam hand-off (hipace_amd/pipeline.py::run_lanes; the reference gets the same effect with several MPI ranks per device,
+Hipace.cpp:400-401): `value_steps_in_flight`, `steps_in_flight`.  A slice is a chain of dependent, often latency-bound
+kernels; the only independent work there is are the other time steps of the pipeline.
+
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL; `python bench.py --gpus N` without
 torchrun re-executes itself under `python -m torch.distributed.run`).  The path shards as the reference
 does, over time steps (rank r runs steps r, r+N, ...: Hipace.cpp:400-401), each rank sweeping the whole box
@@ -164,9 +170,13 @@ def main():
                     help="HIP-event phase timers (and with them the roofline's kernel duration) on every n-th slice of the "
                          "timed region: the 11 event records of a timed slice cost 4.5 %% of it.  0 = 7 for whole boxes, 1 "
                          "when fewer than 64 slices are timed")
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="time steps in flight on one GPU (hipace_amd/pipeline.py::run_local_pipeline): L engines on L "
-                         "streams, step s+1 trails step s by the per-slice beam hand-off.  Needs --steps >= L boxes; one GPU only")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="second measurement: L time steps in flight on the GPU (hipace_amd/pipeline.py::run_lanes: L engines on L "
+                         "streams driven by one host thread, step s+1 trails step s by the per-slice beam hand-off) -> "
+                         "value_steps_in_flight; `value` is always the one-engine number.  1 = skip.  N > 1: L stages per rank on "
+                         "the ring, only with --inflight-ring")
+    ap.add_argument("--inflight-ring", action="store_true",
+                    help="N > 1: also time --inflight stages per rank on the RCCL ring (world x L stages)")
     ap.add_argument("--laser-solver", choices=["fft", "multigrid"], default="fft",
                     help="--config5: lasers.solver_type (multigrid = hpmg system type 2, the reference's default)")
     ap.add_argument("--config5", action="store_true",
@@ -263,14 +273,14 @@ def main():
             deck["background_density_SI"] = 2.8239587008591567e23
         args.cpu_slices = 0
         args.inflight = 1
-    if world > 1:
+    if world > 1 and not args.inflight_ring:
         args.inflight = 1
+    if args.ring_self or args.fuse or args.config2:
+        args.inflight = 1                       # (the predictor-corrector loop holds the host once per iteration: its slice has no
+                                                #  enqueue-only first half for a one-thread driver of several engines to interleave)
     eng = api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period)
-    lanes = 1
-    if args.inflight > 1:
-        lanes = max(1, min(args.inflight, args.steps // nz))      # whole boxes only
-    engines = [eng] + [api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period)
-                       for _ in range(lanes - 1)]
+    lanes = 1                                   # the headline measurement: one engine
+    engines = [eng]
     if args.fuse:
         for e in engines:
             e.set_fusion(True)
@@ -370,16 +380,11 @@ def main():
             del warm
         else:
             run_slices(args.warmup)
-        if lanes > 1:
-            from hipace_amd.pipeline import run_local_pipeline
-            run_local_pipeline(engines, lanes, dev, slices_per_step=max(2, args.warmup))   # warm every lane
         barrier()
         stats0.update(eng.stats())
         profiling(True)
         t0 = time.perf_counter()
-        if lanes > 1:
-            args.steps = run_local_pipeline(engines, max(1, args.steps // nz), dev)
-        elif world == 1 and args.ring_self:
+        if world == 1 and args.ring_self:
             from hipace_amd.pipeline import run_pipeline
             stamps = []
             tl = (lambda m, q: stamps.append((m, q, time.perf_counter())) if q % 64 == 0 else None) if os.environ.get("BENCH_TIMELINE") else None
@@ -409,10 +414,70 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    st_headline = eng.stats()
+    snap = dict(laser_vc=eng.laser_vcycles() if args.config5 else None, pc=eng.pc_stats()[0] if args.config2 else None,
+                sorts=eng.sorts() if args.tile else 0, fallbacks=eng.fallbacks() if args.tile else 0,
+                ion=eng.ion_stats() if (args.config5 and not args.no_ionization) else None)
+
+    # ---- second measurement: L time steps in flight per GPU (pipeline.run_lanes) --------------------------------------
+    inflight = None
+    L = max(1, args.inflight)
+    if L > 1:
+        from hipace_amd.pipeline import run_lanes
+        lane_engines = [eng] + [api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period) for _ in range(L - 1)]
+        W = world * L
+        lagL = 2                                                 # a stage trails the one ahead by the hand-off of two slices
+        if args.steps < nz:
+            # steady-state window: every stage runs (untimed) to its place in the box -- stage v `lagL*v` slices behind stage
+            # 0 --, then all of them time `steps` slices at once.  The clock is the device's: an event on each engine's
+            # stream at the first and behind the last timed slice (one host thread drives the stages and must not stop).
+            startL = args.start_slice if args.start_slice >= 0 else (START_SLICE_DEFAULT * nz) // 1024
+            leadL = max(min(startL, nz - args.steps - args.warmup) + args.warmup, lagL * (W - 1))
+            assert leadL + args.steps <= nz, "window does not fit the box"
+            countsL = [leadL - lagL * v + args.steps for v in range(W)]
+            streams = [torch.cuda.ExternalStream(e.stream_handle(), device=dev) for e in lane_engines]
+            ref_ev = torch.cuda.Event(enable_timing=True)
+            ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(L)]
+            ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(L)]
+            barrier()
+            ref_ev.record(streams[0])
+
+            def on_slice_L(j, m, q):
+                first = leadL - lagL * (rank * L + j)
+                if q == first:
+                    ev0[j].record(streams[j])
+                elif q == first + args.steps:
+                    ev1[j].record(streams[j])
+
+            run_lanes(lane_engines, rank, world, W, dev, slices_per_step=countsL, transport=transport, on_slice=on_slice_L)
+            barrier()
+            t_start = min(ref_ev.elapsed_time(e) for e in ev0)
+            t_end = max(ref_ev.elapsed_time(e) for e in ev1)
+            dtL = 1e-3 * (t_end - t_start)
+            nL = args.steps
+            whole = False
+        else:
+            boxes = max(1, args.steps // nz)
+            run_lanes(lane_engines, rank, world, W, dev, slices_per_step=max(2, min(args.warmup, nz)), transport=transport)   # warm every stage
+            barrier()
+            t0 = time.perf_counter()
+            solvedL = run_lanes(lane_engines, rank, world, W * boxes, dev, transport=transport)
+            barrier()
+            dtL = time.perf_counter() - t0
+            nL = solvedL // L
+            whole = True
+        if world > 1:
+            t = torch.tensor([dtL], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtL = t.item()
+        inflight = dict(value=W * nL / dtL, stages_per_gpu=L, slices_per_stage=nL, seconds=dtL,
+                        window="whole boxes, pipeline fill included" if whole else
+                               f"{nL} slices per stage in steady state (device clock: events on the stages' streams)")
+        del lane_engines[1:]
 
     if rank == 0:
         total = args.steps * world
-        st1 = eng.stats()
+        st1 = st_headline
         nsl = max(st1["slices"] - stats0.get("slices", 0), 1)
         ab = algorithmic_bytes(args.n, args.ppc * args.ppc)
         per_kernel = {k: phases[k] / max(nprof, 1) for k in phases}
@@ -443,19 +508,23 @@ def main():
                                     "field-ionised by the wake (ADK), released electrons join the plasma") + " (BASELINE.json configs[4])") if args.config5 else
                                    (f"blowout_wake synthetic {args.n}x{args.n}x{nz}, {args.ppc * args.ppc} ppc, "
                                     "order 2, explicit Bx/By solver, dt=0 (BASELINE.md section 3)"),
-                       "parallelism": f"time-step pipeline x{world}" + (f", {lanes} steps in flight per GPU" if lanes > 1 else "")},
+                       "parallelism": f"time-step pipeline x{world}; `value`: one time step per GPU at a time, `value_steps_in_flight`: "
+                                      f"{max(1, args.inflight)} per GPU"},
             "timed_slices": ({"first": timed_first, "last": timed_first + args.steps - 1, "counted_from": "head of the box",
                               "pipeline_prefilled": world > 1} if short else
                              {"whole_boxes": max(1, args.steps // nz), "pipeline_prefilled": False}),
-            "steps_in_flight": lanes, "fused_push_deposit": bool(args.fuse),
+            "steps_in_flight": inflight["stages_per_gpu"] if inflight else 1,
+            "value_steps_in_flight": inflight["value"] if inflight else None,
+            "in_flight": inflight,
+            "fused_push_deposit": bool(args.fuse),
             "phase_ms_per_slice": per_kernel,
             "profiled_slices": nprof,
             "vcycles_per_slice": (st1["vcycles"] - stats0.get("vcycles", 0)) / nsl,
-            "laser_vcycles_per_slice": (eng.laser_vcycles() / max(st1["slices"], 1)) if args.config5 else None,
-            "pc_iterations_per_slice": eng.pc_stats()[0] / max(st1["slices"], 1) if args.config2 else None,
-            "particle_sorts": eng.sorts() if args.tile else 0,
-            "halo_fallbacks": eng.fallbacks() if args.tile else 0,
-            "ionization": (dict(zip(("electrons_released", "product_species_particles"), eng.ion_stats()))
+            "laser_vcycles_per_slice": (snap["laser_vc"] / max(st1["slices"], 1)) if args.config5 else None,
+            "pc_iterations_per_slice": snap["pc"] / max(st1["slices"], 1) if args.config2 else None,
+            "particle_sorts": snap["sorts"],
+            "halo_fallbacks": snap["fallbacks"],
+            "ionization": (dict(zip(("electrons_released", "product_species_particles"), snap["ion"]))
                            if (args.config5 and not args.no_ionization) else None),
             "ring": ring_stats,
             "roofline": {"bound": "hbm", "kernel": "k_deposit_tiled<2,%d>" % args.tile if args.tile else "k_deposit_current<2>", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -292,6 +292,13 @@ class SliceEngine:
     def solve_slice(self, islice):
         check(_lib.lib().hps_engine_solve_slice(self._h, islice))
 
+    def solve_slice_begin(self, islice):
+        """the slice up to the Bx/By solve's norm read-back, enqueued without waiting (see hps_engine_solve_slice_begin)"""
+        check(_lib.lib().hps_engine_solve_slice_begin(self._h, islice))
+
+    def solve_slice_finish(self, islice):
+        check(_lib.lib().hps_engine_solve_slice_finish(self._h, islice))
+
     def run_step(self):
         check(_lib.lib().hps_engine_run_step(self._h))
 
@@ -454,6 +461,10 @@ class SliceEngine:
         return {n: out[i] for i, n in enumerate(self.INSITU_FIELDS)}
 
     # ---- several steps in flight on one device (pipeline.run_local_pipeline) ----------------------------
+    def stream_handle(self):
+        """the engine's hipStream_t as an integer (torch.cuda.ExternalStream(handle) for timing events)"""
+        return _lib.lib().hps_engine_stream(self._h)
+
     def record_event(self, slot):
         """Mark this engine's stream; returns the event another engine can wait for."""
         ev = C.c_void_p()

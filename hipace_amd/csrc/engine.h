@@ -133,6 +133,9 @@ struct Engine {
     int deposit_beam_slice (int islice, int cjx, int cjy, int cjz);
     void deposit_grid_current (int islice, int cjz);
     int solve_slice (int islice);
+    int solve_slice_begin (int islice);      // ... in two halves: everything up to the Bx/By solve's norm read-back is enqueued,
+    int solve_slice_finish (int islice);     // then the host waits for the norms and enqueues the rest
+    int pending_slice = -1; bool pend_fuse = false, pend_gated = false;
     int run_step ();
 };
 

@@ -1228,9 +1228,20 @@ int Engine::solve_slice_pc (int islice)
     return HPS_OK;
 }
 
+// The slice in two halves for a host that drives several engines from one thread (several time steps in flight on one
+// device, hps_engine_solve_slice_begin / _finish): begin enqueues everything up to and including the speculated V-cycles of
+// the Bx/By solve (and the gated push behind them) and returns without waiting for the device; finish waits for the
+// solve's norms -- the one host wait of a slice -- and enqueues the rest.  solve_slice = begin + finish.
 int Engine::solve_slice (int islice)
 {
-    if (pc) return solve_slice_pc(islice);
+    if (int e = solve_slice_begin(islice)) return e;
+    return solve_slice_finish(islice);
+}
+
+int Engine::solve_slice_begin (int islice)
+{
+    HPS_REQUIRE(pending_slice == -1, "hps_engine_solve_slice_begin: the previous slice has not been finished");
+    if (pc) { if (int e = solve_slice_pc(islice)) return e; pending_slice = islice; return HPS_OK; }
     SlabView f(slab);
     const long plane = slab.nstride;
     const dim3 b256(256);
@@ -1357,6 +1368,26 @@ int Engine::solve_slice (int islice)
             if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st, c_aabs, nullptr, mg_gate_after_enqueued(mg)))) return e;
         }
         if (laser_split && d.laser_solver == 2) { if ((e = laser_advance_slice(*this, islice)) || (e = laser_done())) return e; }
+        pending_slice = islice; pend_fuse = fuse; pend_gated = gated;
+        HPS_HIP_CHECK(hipGetLastError());
+        return HPS_OK;
+    }
+}
+
+int Engine::solve_slice_finish (int islice)
+{
+    HPS_REQUIRE(pending_slice == islice, "hps_engine_solve_slice_finish: not the slice that hps_engine_solve_slice_begin started");
+    pending_slice = -1;
+    if (pc) return HPS_OK;
+    SlabView f(slab);
+    const long plane = slab.nstride;
+    const dim3 b256(256);
+    const dim3 gplane(ceil_div(plane, 256));
+    const CellBox bb{beam_box.ilo, beam_box.ihi, beam_box.jlo, beam_box.jhi};
+    const bool fuse = pend_fuse, gated = pend_gated;
+    const int comp_push[5] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ};
+    int e;
+    {   int iters = 0, extra = 0;
         if ((e = mg_solve1_finish(mg, &iters, nullptr, &extra, st))) return e;
         total_vcycles += iters;
         // the speculated V-cycles were not enough (the gated push has not run): the host has added the rest, push now
@@ -1446,6 +1477,8 @@ extern "C" int hps_engine_create (const hps_deck* deck, int device, void** handl
 extern "C" int hps_engine_destroy (void* h) { delete static_cast<Engine*>(h); return HPS_OK; }
 extern "C" int hps_engine_begin_step (void* h) { return static_cast<Engine*>(h)->begin_step(); }
 extern "C" int hps_engine_solve_slice (void* h, int islice) { return static_cast<Engine*>(h)->solve_slice(islice); }
+extern "C" int hps_engine_solve_slice_begin (void* h, int islice) { return static_cast<Engine*>(h)->solve_slice_begin(islice); }
+extern "C" int hps_engine_solve_slice_finish (void* h, int islice) { return static_cast<Engine*>(h)->solve_slice_finish(islice); }
 extern "C" int hps_engine_run_step (void* h) { return static_cast<Engine*>(h)->run_step(); }
 extern "C" int hps_engine_sync (void* h)
 {

@@ -69,6 +69,12 @@ class GlooTransport:
         for ev in evs:
             self.engine_wait(engine, ev)
 
+    def ready(self, ev):
+        return True
+
+    def can_send(self):
+        return True
+
     def recv_after(self, ev):
         if ev is not None and hasattr(ev, "wait") and not ev.is_completed():
             ev.wait()
@@ -137,6 +143,12 @@ class RcclTransport:
         """events of receives in the order they were posted: they complete in that order (one stream), the last one says it all"""
         if evs:
             self.engine_wait(engine, evs[-1])
+
+    def ready(self, ev):
+        return True
+
+    def can_send(self):
+        return True
 
     def recv_after(self, ev):
         if ev:
@@ -209,6 +221,121 @@ class RcclSelfRing(RcclTransport):
         super().finish()
 
 
+def _wait_generic(engine, ev):
+    """wait for an event of any transport: None, a gloo request (host wait), or a device event handle (the engine's stream
+    waits for it)"""
+    if ev is None:
+        return
+    if hasattr(ev, "is_completed"):
+        if not ev.is_completed():
+            ev.wait()
+        return
+    engine.wait_event(ev)
+
+
+class LocalEdge:
+    """The edge stage v -> stage v + 1 when both live in this process (several time steps in flight on one device, driven
+    by one host thread): MultiBuffer.cpp:299-308's "send to myself" between two engines.  A message is a device-to-device
+    copy on the SENDING engine's stream (behind the slice that produced it, ahead of the event the receiver waits for);
+    receives are only remembered when they are posted and matched in order when the send comes, as on an edge between two
+    ranks.  `_EV_LOCAL` slots of the sending engine's event pool rotate (an enqueued wait keeps the record it saw)."""
+
+    def __init__(self):
+        self.posted, self.done, self.n_posted, self.n_sent = [], {}, 0, 0
+        self.pending_after = None
+        self.tx_engine = None
+        self.messages = 0
+
+    def post(self, t, after_event):
+        if after_event is None:
+            after_event, self.pending_after = self.pending_after, None
+        self.posted.append((t, after_event))
+        self.n_posted += 1
+        return ("loc", self, self.n_posted - 1)
+
+    def can_send(self):
+        return bool(self.posted)
+
+    def send(self, engine, t):
+        dst, free_ev = self.posted.pop(0)
+        assert dst.numel() == t.numel(), "local edge: message sizes of send and posted receive differ"
+        _wait_generic(engine, free_ev)            # the receive buffer's previous contents are no longer needed
+        engine.copy_async(dst, t)
+        ev = engine.record_event(_EV_LOCAL + self.n_sent % 2048)
+        self.done[self.n_sent] = ev
+        self.n_sent += 1
+        self.messages += 1
+        return ev
+
+
+class StageTransport:
+    """What one pipeline stage sees of its two edges: receives come from `rx` (a LocalEdge, or a ring / gloo transport),
+    sends go to `tx`.  Events are device event handles (or gloo requests on the CPU) whichever side made them, so a buffer
+    that is received into and later sent from can be ordered across the two."""
+
+    def __init__(self, engine, rx, tx):
+        self.engine, self.rx, self.tx = engine, rx, tx
+        self.self_ring = True                      # always hand on through the transport (never the one-engine in-process path)
+
+    # ---- receive side
+    def recv(self, t, after_event=None, slot=0):
+        if isinstance(self.rx, LocalEdge):
+            return self.rx.post(t, after_event)
+        return self.rx.recv(t, after_event, slot)
+
+    def recv_after(self, ev):
+        if isinstance(self.rx, LocalEdge):
+            self.rx.pending_after = ev
+        else:
+            self.rx.recv_after(ev)
+
+    def ready(self, ev):
+        """has the message behind this receive ticket been sent (a local edge's tickets only; anything else is an event)?"""
+        return not (isinstance(ev, tuple) and ev and ev[0] == "loc") or ev[2] in ev[1].done
+
+    def _resolve(self, ev):
+        if isinstance(ev, tuple) and ev and ev[0] == "loc":
+            return ev[1].done.pop(ev[2])
+        return ev
+
+    def engine_wait(self, engine, ev):
+        ev = self._resolve(ev)
+        if isinstance(ev, tuple):                  # a ticket of the ring transport behind rx (RcclSelfRing): only it can resolve it
+            self.rx.engine_wait(engine, ev)
+        else:
+            _wait_generic(engine, ev)
+
+    def engine_wait_ordered(self, engine, evs):
+        if isinstance(self.rx, LocalEdge):
+            for ev in evs:
+                self.engine_wait(engine, ev)
+        else:
+            self.rx.engine_wait_ordered(engine, evs)
+
+    # ---- send side
+    def can_send(self):
+        return self.tx.can_send() if isinstance(self.tx, LocalEdge) else True
+
+    def send(self, t, after_event=None, slot=0):
+        if isinstance(self.tx, LocalEdge):
+            return self.tx.send(self.engine, t)
+        return self.tx.send(t, after_event, slot)
+
+    def sync_sends(self):
+        if self.tx is not None and not isinstance(self.tx, LocalEdge):
+            self.tx.sync_sends()
+
+    def finish(self):
+        done = set()
+        for side in (self.rx, self.tx):
+            if side is not None and not isinstance(side, LocalEdge) and id(side) not in done:
+                done.add(id(side))
+                side.finish()
+
+    def close(self):
+        pass
+
+
 def make_transport(rank, world, device):
     """The transport `run_pipeline` uses by default: none for one rank (in-process hand-off), gloo point-to-point on
     the CPU, the RCCL ring on a GPU."""
@@ -221,24 +348,85 @@ def make_transport(rank, world, device):
 
 
 # event-pool slots of the engine (hps_engine_record_event) used by the driver
-_EV_SLICE, _EV_STEP, _EV_LFREE = 0, 64, 80
+_EV_SLICE, _EV_STEP, _EV_LFREE, _EV_LOCAL = 0, 64, 80, 4096
+
+
+def _drive(gens):
+    """One host thread, several stages: every generator runs to its next yield in turn ("work": a slice has been enqueued
+    and its norm read-back is pending; "wait": a local edge has nothing for it yet).  Returns the generators' results."""
+    live = list(range(len(gens)))
+    results = [None] * len(gens)
+    idle_rounds = 0
+    while live:
+        worked = False
+        for k in list(live):
+            try:
+                tag = next(gens[k])
+                worked = worked or tag != "wait"
+            except StopIteration as stop:
+                results[k] = stop.value
+                live.remove(k)
+                worked = True
+        idle_rounds = 0 if worked else idle_rounds + 1
+        if idle_rounds > 1000:
+            raise RuntimeError("pipeline stages of this process wait for one another (local edges): deadlock")
+    return results
 
 
 def run_pipeline(*args, **kwargs):
-    """`_run_pipeline` with Python's cyclic garbage collector kept out of the way: the driver allocates small objects per
-    slice (views, tuples, events), and with torch imported one full collection over the heap takes 30-50 ms -- measured as
-    one stall of that length in the middle of the first step, with the device running dry (the whole difference between
-    the ring and the plain slice loop on one GPU).  What exists now is parked in the permanent generation for the run."""
+    """One stage per process: `_stage` driven to its end, with Python's cyclic garbage collector kept out of the way: the
+    driver allocates small objects per slice (views, tuples, events), and with torch imported one full collection over the
+    heap takes 30-50 ms -- measured as one stall of that length in the middle of the first step, with the device running dry
+    (the whole difference between the ring and the plain slice loop on one GPU).  What exists now is parked in the permanent
+    generation for the run."""
     gc.freeze()                     # (no collection first: that is the 30-50 ms pass this is here to avoid)
     try:
-        return _run_pipeline(*args, **kwargs)
+        return _drive([_stage(*args, **kwargs)])[0]
     finally:
         gc.unfreeze()
 
 
-def _run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices_per_step=None, transport=None,
-                  laser_lookahead=8, on_slice=None, handoff_batch=1):
-    """Run steps rank, rank+world, ... < n_steps of `engine` with the per-slice ring hand-off.
+def run_lanes(engines, rank, world, n_steps, device, on_step_end=None, slices_per_step=None, transport=None,
+              laser_lookahead=8, on_slice=None, handoff_batch=1):
+    """Several pipeline stages per process: L = len(engines) engines (one stream each) on this rank's device are the stages
+    rank*L .. rank*L + L - 1 of a ring of world*L stages; stage v runs the time steps v, v + world*L, ... (Hipace.cpp:400-401
+    with several ranks per device).  The edges between the stages of a process are `LocalEdge`s (device copies ordered by
+    events), the edge that leaves the process is `transport` (RcclTransport / GlooTransport; none with one process, where the
+    last stage hands back to the first).  ONE host thread drives all stages (`_drive`): each engine's slice is enqueued up
+    to its Bx/By norm read-back (hps_engine_solve_slice_begin), then the next stage gets its turn, then the read-backs are
+    awaited in the same order -- the device always holds L slices' worth of kernels on L streams, and every call into the
+    ring comes from this thread.
+    on_step_end(step, engine), on_slice(stage_in_process, m, q): as `_stage`'s, with the stage's engine / index added.
+    slices_per_step: as `_stage`'s; a list has one entry per STAGE of the whole ring (world*L).
+    Returns the number of slices solved by this process."""
+    L = len(engines)
+    W = world * L
+    own = transport is None and world > 1
+    ringT = make_transport(rank, world, device) if own else transport
+    edges = [LocalEdge() for _ in range(L)]        # edges[j]: stage j -> stage j + 1 of this process (the last one closes the loop when world == 1)
+    gens = []
+    for j, eng in enumerate(engines):
+        rx = edges[j - 1] if (j > 0 or world == 1) else ringT
+        tx = edges[j] if (j < L - 1 or world == 1) else ringT
+        T = StageTransport(eng, rx, tx)
+        ose = (lambda step, e=eng: on_step_end(step, e)) if on_step_end is not None else None
+        osl = (lambda m, q, jj=j: on_slice(jj, m, q)) if on_slice is not None else None
+        gens.append(_stage(eng, rank * L + j, W, n_steps, device, ose, slices_per_step, T, laser_lookahead, osl, handoff_batch))
+    gc.freeze()
+    try:
+        solved = _drive(gens)
+    finally:
+        gc.unfreeze()
+    if own and ringT is not None:
+        ringT.close()
+    return sum(solved)
+
+
+def _stage(engine, rank, world, n_steps, device, on_step_end=None, slices_per_step=None, transport=None,
+           laser_lookahead=8, on_slice=None, handoff_batch=1):
+    """Stage `rank` of a ring of `world` stages (a generator, see `_drive`): run steps rank, rank+world, ... < n_steps of
+    `engine` with the per-slice hand-off.  Yields "work" between the two halves of a slice (solve_slice_begin /
+    solve_slice_finish) and "wait" while a local edge has no message / no posted receive for it yet.
 
     engine: SliceEngine-like (begin_step, solve_slice, sync, record_event, wait_event, copy_async, beam_layout,
     set_beam_storage, initial_beam_into, ...; the oracle's Engine has the same interface).
@@ -368,17 +556,24 @@ def _run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices
                 post_until(fed_index[m] * per_prev + need + 1)
                 if batch > 1 and imported < need:
                     evs = [recv_ev.pop((m, j, 0), None) for j in range(imported + 1, need + 1)]
+                    for ev in evs:
+                        while ev is not None and not T.ready(ev[0]):
+                            yield "wait"
                     T.engine_wait_ordered(engine, [ev[0] for ev in evs if ev is not None])
                     imported = need
                 while imported < need:
                     imported += 1
                     ev = recv_ev.pop((m, imported, 0), None)
                     if ev is not None:
+                        while not T.ready(ev[0]):      # (a local edge: the stage ahead has not sent it yet)
+                            yield "wait"
                         T.engine_wait(engine, ev[0])
                         if moving:
                             engine.import_beam_slice(nz - 1 - imported, rpool[m % 2][imported])
                     if ring_laser:
                         ev, k = recv_ev.pop((m, imported, 1))
+                        while not T.ready(ev):
+                            yield "wait"
                         T.engine_wait(engine, ev)
                         engine.import_laser_slice(nz - 1 - imported, lpool[k])
                         lpool_free[k] = engine.record_event(_EV_LFREE + k)
@@ -387,7 +582,11 @@ def _run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices
                     if k < nz and imported < k:
                         engine.import_beam_slice(nz - 1 - k, rpool[m % 2][k])
                         imported = k
-            engine.solve_slice(islice)
+            # the slice in two halves: everything up to the Bx/By solve's norm read-back is enqueued, the other stages of
+            # this process (if any) get their turn, then the host waits for the norms and enqueues the rest
+            engine.solve_slice_begin(islice)
+            yield "work"
+            engine.solve_slice_finish(islice)
             solved += 1
             if step + 1 < n_steps:
                 if not ring:                           # MultiBuffer.cpp:299-308: send to myself
@@ -420,6 +619,8 @@ def _run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices
                     if out:
                         ev = engine.record_event(_EV_SLICE + q % 64)  # the slice (its push, the exports) is done
                         for kind, k, t in out:
+                            while not T.can_send():    # (a local edge: the stage behind has not posted its receive yet)
+                                yield "wait"
                             if kind == "b":
                                 spool_done[k] = T.send(t, ev, 4 * nz + k)
                             elif kind == "l":
@@ -441,117 +642,12 @@ def _run_pipeline(engine, rank, world, n_steps, device, on_step_end=None, slices
     return solved
 
 
-def run_local_pipeline(*args, **kwargs):
-    """`_run_local_pipeline` with the cyclic garbage collector parked (see run_pipeline)."""
-    gc.freeze()
-    try:
-        return _run_local_pipeline(*args, **kwargs)
-    finally:
-        gc.unfreeze()
-
-
-def _run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_step=None):
-    """Several time steps in flight on ONE device: the ring pipeline with all L = len(engines) of its stages in this
-    process.
-
-    Stage j (engine j, one stream each, all on `device`) runs steps j, j+L, ... < n_steps, exactly as rank j of
-    `run_pipeline` would.  What couples the stages is the same per-slice beam hand-off: stage j solves slice k of step s
-    only after stage j-1 has pushed slices k and k-1 of step s-1 -- here a device-to-device copy
-    (MultiBuffer.cpp:299-308, the reference's in-process "send to myself") ordered by stream events.  One host thread
-    per engine (the multigrid's stopping rule holds its host thread once per slice; ctypes releases the GIL), so while
-    one step sits in a latency-bound phase -- the lower multigrid levels, a DST pass, a launch gap -- the kernels of the
-    others fill the device.  Static beam only (hipace.dt = 0, as every BASELINE deck).  One process only: between
-    ranks the hand-off is `run_pipeline`'s (one stage per rank; all RCCL calls of a rank come from one thread).
-
-    Returns the number of slices solved.
-    """
-    import threading
-    L = len(engines)
-    nz = engines[0].deck["nz"]
-    per_step = slices_per_step or nz
-    assert per_step >= 2, "a step needs at least two slices"
-    laser = bool(getattr(engines[0], "has_laser", False))
-    on_gpu = str(device) != "cpu"
-    nbeam, off = engines[0].beam_layout()
-    assert nbeam == 0 or not getattr(engines[0], "moving", False), "run_local_pipeline hands a static beam on (hipace.dt = 0)"
-    bufs = [[torch.zeros(max(7 * nbeam, 1), dtype=torch.float64, device=device) for _ in range(2)] for _ in range(L)]
-    engines[0].initial_beam_into(bufs[0][0])          # only the head of the ring injects the beam
-    engines[0].sync()
-
-    def block(buf, q):                                 # q-th slice from the head = block q
-        return buf[7 * off[q]:7 * off[q + 1]]
-
-    cond = threading.Condition()
-    progress = [0] * L                                 # slices enqueued so far by each engine
-    events = [dict() for _ in range(L)]                # (local step, q) -> event recorded after that slice
-    errors = []
-    solved = [0] * L
-
-    def lane(j):
-        try:
-            if on_gpu:
-                torch.cuda.set_device(device)
-            eng, pj = engines[j], (j - 1) % L
-            for m, step in enumerate(range(j, n_steps, L)):
-                buf = bufs[j][m % 2]
-                fed = step > 0                          # step 0 starts from the injected beam
-                mp = (step - 1 - pj) // L if fed else None
-                if nbeam > 0:
-                    eng.set_beam_storage(buf, injected_beam_support=True)
-                if laser:
-                    # the stage that runs step 0 evaluates the initial envelope; every later step receives a_n, a_{n-1}
-                    # slice by slice from the stage that ran the step before (MultiBuffer.cpp:840-852, 913-925)
-                    eng.set_laser_import(fed, step)
-                if hasattr(eng, "set_step"):
-                    eng.set_step(step)
-                eng.begin_step()
-                copied = 0
-                lcopied = 0
-                for q in range(per_step):
-                    if fed:
-                        need = min(q + 1, per_step - 1)             # this slice's beam and the next one's (jx/jy source)
-                        with cond:
-                            while progress[pj] < mp * per_step + need + 1 and not errors:
-                                cond.wait(timeout=1.0)
-                            ev = events[pj].get((mp, need))
-                        if errors:
-                            return
-                        eng.wait_event(ev)
-                        src = bufs[pj][mp % 2]
-                        while copied <= need:
-                            d, s_ = block(buf, copied), block(src, copied)
-                            if d.numel() > 0:
-                                eng.copy_async(d, s_)
-                            copied += 1
-                        if laser:
-                            while lcopied <= need:
-                                eng.import_laser_from(nz - 1 - lcopied, engines[pj])
-                                lcopied += 1
-                    eng.solve_slice(nz - 1 - q)
-                    solved[j] += 1
-                    ev = eng.record_event(128 + (m % 2) * per_step + q)
-                    with cond:
-                        events[j][(m, q)] = ev
-                        events[j].pop((m - 2, q), None)
-                        progress[j] = m * per_step + q + 1
-                        cond.notify_all()
-                if on_step_end is not None:
-                    on_step_end(step, eng)
-        except BaseException as e:      # noqa: BLE001 -- re-raised on the caller's thread
-            with cond:
-                errors.append(e)
-                cond.notify_all()
-
-    if L == 1:
-        lane(0)
-    else:
-        threads = [threading.Thread(target=lane, args=(j,), name=f"hps-step-lane-{j}") for j in range(L)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-    if errors:
-        raise errors[0]
-    for e in engines:
-        e.sync()
-    return sum(solved)
+def run_local_pipeline(engines, n_steps, device, on_step_end=None, slices_per_step=None):
+    """Several time steps in flight on ONE device: the ring pipeline with all L = len(engines) of its stages in this process
+    (`run_lanes` with one process).  Stage j (engine j, one stream each, all on `device`) runs steps j, j+L, ... < n_steps,
+    exactly as rank j of `run_pipeline` would; what couples the stages is the same per-slice hand-off -- stage j solves
+    slice k of step s only after stage j-1 has pushed slices k and k-1 of step s-1 -- here device-to-device copies ordered
+    by stream events (`LocalEdge`; MultiBuffer.cpp:299-308, the reference's in-process "send to myself").  While one step
+    sits in a latency-bound phase -- the lower multigrid levels, a DST pass, a launch gap -- the kernels of the others fill
+    the device.  One host thread drives all engines (round 2 had one thread per engine).  Returns the number of slices solved."""
+    return run_lanes(engines, 0, 1, n_steps, device, on_step_end, slices_per_step)

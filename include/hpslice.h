@@ -256,6 +256,13 @@ int hps_engine_begin_step (void* handle);                 /* Evolve :401-471: re
  * that runs steps r, r + N, ... (Hipace.cpp:400-401) must say which step it is about to run. */
 int hps_engine_set_step (void* handle, int step);
 int hps_engine_solve_slice (void* handle, int islice);    /* SolveOneSlice :556-728               */
+/* The slice in two halves, for ONE host thread that keeps several engines (time steps in flight on one device, the
+ * stages of a pipeline) busy: begin enqueues everything up to and including the speculated V-cycles of the Bx/By solve
+ * and the push gated on them, without waiting for the device; finish waits for that solve's norms (the one host wait of
+ * a slice, Hipace.cpp:919-921) and enqueues the rest.  hps_engine_solve_slice(k) = begin(k) + finish(k); between the two
+ * halves of one engine only calls on OTHER engines are allowed. */
+int hps_engine_solve_slice_begin (void* handle, int islice);
+int hps_engine_solve_slice_finish (void* handle, int islice);
 int hps_engine_run_step (void* handle);                   /* begin_step + all slices head->tail   */
 int hps_engine_sync (void* handle);                       /* host waits for the engine's stream (and, through it, the laser stream) */
 int hps_engine_info (void* handle, int* ncomp, int* nguards, long* nparticles);

@@ -434,6 +434,12 @@ class Engine:
     def solve_slice(self, islice):
         lib().orc_engine_solve_slice(self._h, islice)
 
+    def solve_slice_begin(self, islice):      # the driver's two halves of a slice: the oracle is synchronous
+        self.solve_slice(islice)
+
+    def solve_slice_finish(self, islice):
+        pass
+
     def slab(self):
         nx, ny, g = self.deck["nx"], self.deck["ny"], self.g
         n = self.ncomp * (ny + 2 * g) * (nx + 2 * g)

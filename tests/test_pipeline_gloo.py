@@ -292,3 +292,68 @@ def test_prefilled_pipeline_with_rank_dependent_slice_counts(oracle, world, batc
         want = ref.checksums()
         for k, v in want.items():
             assert abs(cs[k] - v) <= 1e-12 * max(abs(v), 1e-300), (rank, k, cs[k], v)
+
+
+def _lanes_worker(rank, world, port, lanes, n_steps, kind, out):
+    import torch.distributed as dist
+    from hipace_amd.pipeline import run_lanes
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    deck = {"static": _deck, "moving": _moving_deck, "laser": _laser_deck}[kind]()
+    engs = [O.Engine(deck) for _ in range(lanes)]
+    res = {}
+
+    def on_step_end(step, eng):
+        res[step] = (eng.checksums(), eng.laser_envelope().copy() if kind == "laser" else None)
+
+    solved = run_lanes(engs, rank, world, n_steps, "cpu", on_step_end, laser_lookahead=3)
+    out.put((rank, solved, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,lanes,n_steps,kind", [(2, 2, 4, "static"), (2, 2, 9, "static"), (2, 2, 6, "moving"), (2, 2, 5, "laser"),
+                                                      (3, 2, 7, "static"), (2, 3, 8, "static")])
+def test_several_stages_per_rank_on_the_ring(oracle, world, lanes, n_steps, kind):
+    """pipeline.run_lanes: `lanes` engines per process are consecutive stages of a ring of world x lanes stages (several
+    time steps in flight per device AND several devices: Hipace.cpp:400-401 with several ranks per GPU).  The edges inside
+    a process are device copies, the edge that leaves it is the transport; ONE host thread per process drives its engines
+    and makes every transport call.  Every step has exactly the checksums (and envelope) of one engine running the steps
+    in turn -- open and closed ring, static beam, moving beam, evolving laser pulse."""
+    import numpy as np
+    deck = {"static": _deck, "moving": _moving_deck, "laser": _laser_deck}[kind]()
+    ref = oracle.Engine(deck)
+    want = {}
+    for s in range(n_steps):
+        ref.begin_step()
+        for k in range(deck["nz"] - 1, -1, -1):
+            ref.solve_slice(k)
+        want[s] = (ref.checksums(), ref.laser_envelope().copy() if kind == "laser" else None)
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lanes_worker, args=(r, world, port, lanes, n_steps, kind, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got = {}
+    W = world * lanes
+    for rank, solved, res in results:
+        mine = [s for s in range(n_steps) if (s % W) // lanes == rank]
+        assert sorted(res) == mine, (rank, sorted(res), mine)
+        assert solved == deck["nz"] * len(mine)
+        got.update(res)
+    assert sorted(got) == list(range(n_steps))
+    for s in range(n_steps):
+        if kind == "laser":
+            assert np.array_equal(got[s][1], want[s][1]), s
+        for k, v in want[s][0].items():
+            if kind == "static":
+                assert abs(got[s][0][k] - v) <= 1e-12 * max(abs(v), 1e-300), (s, k)
+            else:
+                assert got[s][0][k] == v, (s, k, got[s][0][k], v)
