@@ -229,8 +229,17 @@ def main():
     if world > 1:
         import threading
 
+        progress = {"phase": "start", "slice": -1, "transport": None}
+
         def give_up():
-            print(f"bench.py: rank {rank} of {world} still running after {args.watchdog:.0f} s -- giving up", file=sys.stderr, flush=True)
+            # fail loudly: where this rank was and what its ring has carried so far, then exit (the driver sees code 3)
+            st = None
+            try:
+                st = progress["transport"].stats() if progress["transport"] is not None else None
+            except Exception as exc:      # noqa: BLE001
+                st = f"unavailable ({exc})"
+            print(f"bench.py: rank {rank} of {world} still running after {args.watchdog:.0f} s -- giving up; phase {progress['phase']}, "
+                  f"last slice enqueued {progress['slice']}, ring {st}", file=sys.stderr, flush=True)
             os._exit(3)
 
         dog = threading.Timer(args.watchdog, give_up)
@@ -302,7 +311,10 @@ def main():
     transport = None
     if world > 1:
         from hipace_amd.pipeline import RcclTransport
+        progress["phase"] = "ring init"
         transport = RcclTransport(rank, world, local)          # communicators are created before the clock starts
+        progress["transport"] = transport
+        progress["phase"] = "headline run"
     elif args.ring_self:
         from hipace_amd.pipeline import RcclSelfRing
         transport = RcclSelfRing(local)
@@ -325,6 +337,8 @@ def main():
         timed_first = first
 
         def on_slice(m, q):
+            if world > 1:
+                progress["slice"] = q
             if q == first:
                 if transport is not None:
                     # mid-run, pipeline filled: this rank's receives of the slices to come are posted (a whole step
@@ -420,6 +434,8 @@ def main():
                 ion=eng.ion_stats() if (args.config5 and not args.no_ionization) else None)
 
     # ---- second measurement: L time steps in flight per GPU (pipeline.run_lanes) --------------------------------------
+    if world > 1:
+        progress["phase"] = "steps-in-flight run"
     inflight = None
     L = max(1, args.inflight)
     if L > 1:
@@ -511,7 +527,12 @@ def main():
                        "parallelism": f"time-step pipeline x{world}; `value`: one time step per GPU at a time, `value_steps_in_flight`: "
                                       f"{max(1, args.inflight)} per GPU"},
             "timed_slices": ({"first": timed_first, "last": timed_first + args.steps - 1, "counted_from": "head of the box",
-                              "pipeline_prefilled": world > 1} if short else
+                              "pipeline_prefilled": world > 1,
+                              # N > 1: the clock starts with the pipeline filled, so `value` is a steady-state rate, not
+                              # nz*nsteps / wall(Evolve): the last rank starts fill_slices slices after the first, and a whole
+                              # run of one step per rank would come out at value_including_fill
+                              "fill_slices": lag * (world - 1) if world > 1 else 0,
+                              "value_including_fill": (total / dt) * nz / (nz + lag * (world - 1)) if world > 1 else None} if short else
                              {"whole_boxes": max(1, args.steps // nz), "pipeline_prefilled": False}),
             "steps_in_flight": inflight["stages_per_gpu"] if inflight else 1,
             "value_steps_in_flight": inflight["value"] if inflight else None,

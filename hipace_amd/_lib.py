@@ -92,6 +92,8 @@ _SIGS = {
     "hps_mg_create": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
     "hps_mg_solve1": (C.c_int, [C.c_void_p, Slab, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
                                 C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p]),
+    "hps_mg_solve1_fabs": (C.c_int, [C.c_void_p, Slab, Slab, Slab, C.c_double, C.c_double, C.c_int,
+                                     C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p]),
     "hps_mg_destroy": (C.c_int, [C.c_void_p]),
     "hps_mg2_create": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
     "hps_mg2_solve2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
@@ -169,6 +171,7 @@ _SIGS = {
     "hps_ring_stream_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "hps_ring_sync_sends": (C.c_int, [C.c_void_p]),
     "hps_ring_sync": (C.c_int, [C.c_void_p]),
+    "hps_ring_sync_timeout": (C.c_int, [C.c_void_p, C.c_double]),
     "hps_ring_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "hps_ring_destroy": (C.c_int, [C.c_void_p]),
     "hps_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long]),

@@ -261,6 +261,15 @@ class MultiGrid:
                                        nummaxiter, C.byref(it), C.byref(rn), _stream()))
         return it.value, rn.value
 
+    def solve1_fabs(self, sol, rhs, acoef, tol_rel=1e-4, tol_abs=2.2250738585072014e-308, nummaxiter=200):
+        """hpmg::MultiGrid::solve1(sol, rhs, acoef, ...) with three separate `Fields` (HpMultiGrid.H:64-66): sol and rhs with
+        two components, acoef with one; sol is the initial guess on entry."""
+        it = C.c_int()
+        rn = C.c_double()
+        check(_lib.lib().hps_mg_solve1_fabs(self._h, sol.struct(), rhs.struct(), acoef.struct(), tol_rel, tol_abs, nummaxiter,
+                                            C.byref(it), C.byref(rn), _stream()))
+        return it.value, rn.value
+
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:
             _lib.lib().hps_mg_destroy(self._h)

@@ -270,7 +270,7 @@ static BeamPushConsts push_consts (const Engine& E, int islice)
     k.RRcoeff = (2.0/3.0)*reSI*q_over_mc*q_over_mc;
     k.wp_inv = (k.normalized && d.background_density_SI > 0.0) ? std::sqrt(ep0SI*meSI/(d.background_density_SI*qeSI*qeSI)) : 1.0;
     k.E0 = k.normalized ? meSI*cSI/k.wp_inv/qeSI : 1.0;
-    k.spin = d.beam_spin_tracking; k.spin_anom = d.beam_spin_anom != 0.0 ? d.beam_spin_anom : 0.00115965218128;
+    k.spin = d.beam_spin_tracking; k.spin_anom = d.beam_spin_anom;      // (0 = pure Thomas precession; hosts that want the electron pass 0.00115965218128, as decks.py does)
     return k;
 }
 

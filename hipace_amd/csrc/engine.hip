@@ -1485,6 +1485,13 @@ extern "C" int hps_engine_sync (void* h)
     Engine* E = static_cast<Engine*>(h);
     if (int e = E->join_laser()) return e;
     HPS_HIP_CHECK(hipStreamSynchronize(E->st));
+    if (E->moving && E->d_beam_overflow) {
+        // a slice that outgrew the hand-off capacity lost particles: say so at the end of the step that did it (also the last
+        // step of a run, and a stage that runs one step only), not at the next begin_step of this engine
+        int ov = 0;
+        HPS_HIP_CHECK(hipMemcpy(&ov, E->d_beam_overflow, sizeof(int), hipMemcpyDeviceToHost));
+        HPS_REQUIRE(ov == 0, "moving beam: a slice outgrew the hand-off capacity (twice the fullest injected slice): particles were lost");
+    }
     return HPS_OK;
 }
 extern "C" int hps_engine_info (void* h, int* ncomp, int* ng, long* np)

@@ -178,6 +178,7 @@ IonArgs Engine::ion_args (int islice)
     a.clightsq_inv = 1.0/(gm.c*gm.c);
     a.Z = d.ion_Z; a.seed = d.ion_seed; a.step = (unsigned long long)step_index; a.islice = (unsigned long long)islice;
     a.cap = np_cap; a.tile_flag = ion.d_tile_flag;
+    a.product_init_lev = 0;       // the product species is the first (electron) species: not ionisable here, its particles carry level 0
     a.fbound = (ion.tiling && ion.d_fbound) ? ion.d_fbound : nullptr;
     if (ion.tiling) { a.fb_ntx = ion.tiling->g.ntx; a.fb_nty = ion.tiling->g.nty; }
     a.fb_dx_inv = 1.0/gm.dx; a.fb_dy_inv = 1.0/gm.dy; a.fb_c = gm.c;

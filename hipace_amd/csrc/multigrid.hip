@@ -1798,6 +1798,28 @@ extern "C" int hps_mg_solve1 (void* handle, hps_slab slab, int sol_comp, int rhs
                      (hipStream_t)stream);
 }
 
+// hpmg::MultiGrid::solve1 with its own argument list (HpMultiGrid.H:64-66: FArrayBox& sol, FArrayBox const& rhs,
+// FArrayBox const& acoef): three separate views -- sol and rhs with two components each, acoef with one -- that need
+// not live in one slab.  Each view is centred on the solver's box as center_box does (HpMultiGrid.H:168-175).
+extern "C" int hps_mg_solve1_fabs (void* handle, hps_slab sol2, hps_slab rhs2, hps_slab acoef1, double tol_rel, double tol_abs,
+                                   int max_iters, int* iters_host, double* resnorm_host, hps_stream stream)
+{
+    HPS_REQUIRE(handle && sol2.p && rhs2.p && acoef1.p, "hps_mg_solve1_fabs: null argument");
+    Multigrid* M = static_cast<Multigrid*>(handle);
+    for (const hps_slab* s : {&sol2, &rhs2, &acoef1}) {
+        HPS_REQUIRE(s->nx == M->nx && s->ny == M->ny, "hps_mg_solve1_fabs: view size does not match the solver");
+        HPS_REQUIRE(M->cc || s->ng >= 1, "hps_mg_solve1_fabs: node-centred solve needs >= 1 guard cell in every view");
+    }
+    HPS_REQUIRE(sol2.ncomp >= 2 && rhs2.ncomp >= 2 && acoef1.ncomp >= 1, "hps_mg_solve1_fabs: sol and rhs need two components, acoef one");
+    const int sh = M->cc ? 0 : 1;
+    M->sol  = FView{sol2.p, sol2.jstride, sol2.nstride, sol2.ng - sh, sol2.ng - sh};
+    M->rhs  = FView{rhs2.p, rhs2.jstride, rhs2.nstride, rhs2.ng - sh, rhs2.ng - sh};
+    M->acf0 = FView{acoef1.p, acoef1.jstride, acoef1.nstride, acoef1.ng - sh, acoef1.ng - sh};
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = M->cc ? solve1_begin<true>(M, tol_rel, tol_abs, max_iters, st) : solve1_begin<false>(M, tol_rel, tol_abs, max_iters, st)) return e;
+    return mg_solve1_finish(M, iters_host, resnorm_host, nullptr, st);
+}
+
 // debug: first call arms the stamps, later calls read the 16 slots back
 // A header slot of the norm buffer for the caller's own device counters: they reach the host with the read-back
 // every solve does anyway (the engine's halo-fallback counter uses word 0).

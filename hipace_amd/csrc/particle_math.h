@@ -178,6 +178,7 @@ struct IonArgs {
     double E0, clightsq_inv; int Z;
     unsigned long long seed, step, islice;
     long cap;                            // capacity of el's arrays
+    int product_init_lev;                // ion_lev of a released electron: the product species' m_init_ion_lev (PlasmaParticleContainer.cpp:430)
     int* tile_flag;                      // [tiles of the ion tiling] 1 = the tile holds a charged ion (written by the ions' tile push)
     const double* fbound;                // [5][tiles] max over the tile's cells of |d_x psi|, |d_y psi| (staggered), |Bx|, |By|, |Ez|
                                          // (k_ion_field_bounds), or null; ntx, nty = tiles per direction
@@ -249,7 +250,7 @@ __device__ __forceinline__ void adk_emit (const IonArgs& a, bool ionize, double 
             if (el.y_prev != el.y) el.y_prev[q] = yprev;
             el.ux_half[q] = 0.0; el.uy_half[q] = 0.0; el.psi_half[q] = 1.0;
             el.idcpu[q] = HPS_ID_VALID | (2ULL << 24);
-            el.ion_lev[q] = 0;
+            el.ion_lev[q] = a.product_init_lev;
         } else {
             atomicExch(a.cnt + 1, 1ULL);
         }

@@ -17,6 +17,10 @@
 
 #include <dlfcn.h>
 #include <cstdlib>
+#include <cstdio>
+#include <chrono>
+#include <thread>
+#include <string>
 #include <cstring>
 #include <vector>
 
@@ -117,6 +121,18 @@ extern "C" int hps_ring_init (int rank, int world, int device, const char* id_ed
     HPS_REQUIRE(handle && world >= 1 && rank >= 0 && rank < world, "hps_ring_init: bad rank / world");
     HPS_REQUIRE(id_edge_out && (world == 1 || id_edge_in), "hps_ring_init: the ids of both edges are needed");
     if (int e = load_rccl()) return e;
+    if (world > 1) {
+        // A receive posted ahead is an RCCL kernel that sits on the device until its data comes.  If the runtime maps the
+        // ring's receive stream, its send stream and the engine's stream onto one hardware queue, a send queued behind such
+        // a receive never runs and the ring waits in a circle.  ROCm's default is 4 hardware queues per process; the ring
+        // needs every stream of the process on its own queue: refuse to start with fewer than 8 (set before HIP starts).
+        const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+        if (!q || std::atoi(q) < 8) {
+            hps::set_error("hps_ring_init: set GPU_MAX_HW_QUEUES >= 8 in the environment before the process touches HIP (the ring's "
+                           "posted-ahead receives must not share a hardware queue with its sends or the engine's stream)");
+            return HPS_ERR_ARG;
+        }
+    }
     HPS_HIP_CHECK(hipSetDevice(device));
     Ring* R = new Ring;
     R->rank = rank; R->world = world; R->device = device;
@@ -257,21 +273,63 @@ extern "C" int hps_ring_stream_wait (void* handle, int which, void* event)
 }
 
 // host waits until every message handed to hps_ring_send_slice so far has left (the receives posted ahead stay posted)
+// A ring that cannot make progress (a peer died, a receive posted ahead sits on the hardware queue its matching send is
+// queued behind) must fail loudly instead of holding the node: the host waits for the ring's streams by polling, and gives
+// up after `seconds` (HPS_RING_TIMEOUT_S in the environment for hps_ring_sync / hps_ring_sync_sends, default 900) with the
+// rank's message counters in the error text.
+static int ring_wait (Ring* R, bool sends, bool recvs, double seconds, const char* what)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (true) {
+        const hipError_t a = sends ? hipStreamQuery(R->st_send) : hipSuccess;
+        const hipError_t b = recvs ? hipStreamQuery(R->st_recv) : hipSuccess;
+        if (a == hipSuccess && b == hipSuccess) return HPS_OK;
+        if ((a != hipSuccess && a != hipErrorNotReady) || (b != hipSuccess && b != hipErrorNotReady)) {
+            hps::set_error(std::string(what) + ": " + hipGetErrorString(a != hipSuccess && a != hipErrorNotReady ? a : b));
+            return HPS_ERR_HIP;
+        }
+        if ((++spins & 0x3ff) == 0) {
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (dt > seconds) {
+                char buf[384];
+                std::snprintf(buf, sizeof buf, "%s: rank %d of %d still waiting after %.0f s (%s%s pending); sent %ld messages / %lld bytes, "
+                              "received %ld / %lld -- a peer is gone or the ring's streams share a hardware queue (GPU_MAX_HW_QUEUES)",
+                              what, R->rank, R->world, dt, a == hipErrorNotReady ? "sends" : "", b == hipErrorNotReady ? " receives" : "",
+                              R->n_sent, R->bytes_sent, R->n_received, R->bytes_received);
+                hps::set_error(buf);
+                return HPS_ERR_COMM;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
+}
+static double ring_timeout_env ()
+{
+    const char* e = std::getenv("HPS_RING_TIMEOUT_S");
+    const double v = e ? std::atof(e) : 900.0;
+    return v > 0.0 ? v : 900.0;
+}
+
 extern "C" int hps_ring_sync_sends (void* handle)
 {
     Ring* R = static_cast<Ring*>(handle);
     HPS_REQUIRE(R, "hps_ring_sync_sends: null ring");
-    HPS_HIP_CHECK(hipStreamSynchronize(R->st_send));
-    return HPS_OK;
+    return ring_wait(R, true, false, ring_timeout_env(), "hps_ring_sync_sends");
 }
 
 extern "C" int hps_ring_sync (void* handle)
 {
     Ring* R = static_cast<Ring*>(handle);
     HPS_REQUIRE(R, "hps_ring_sync: null ring");
-    HPS_HIP_CHECK(hipStreamSynchronize(R->st_send));
-    HPS_HIP_CHECK(hipStreamSynchronize(R->st_recv));
-    return HPS_OK;
+    return ring_wait(R, true, true, ring_timeout_env(), "hps_ring_sync");
+}
+
+extern "C" int hps_ring_sync_timeout (void* handle, double seconds)
+{
+    Ring* R = static_cast<Ring*>(handle);
+    HPS_REQUIRE(R && seconds > 0.0, "hps_ring_sync_timeout: bad argument");
+    return ring_wait(R, true, true, seconds, "hps_ring_sync_timeout");
 }
 
 extern "C" int hps_ring_stats (void* handle, long* n_sent, long* n_received, long long* bytes_sent, long long* bytes_received)

@@ -162,6 +162,11 @@ int hps_mg_create (int nx, int ny, double dx, double dy, void** handle);
 int hps_mg_solve1 (void* handle, hps_slab slab, int sol_comp, int rhs_comp, int acoef_comp,
                    double tol_rel, double tol_abs, int max_iters, int* iters_host,
                    double* resnorm_host, hps_stream stream);
+/* the same with the reference's own argument list (HpMultiGrid.H:64-66: FArrayBox& sol, FArrayBox const& rhs,
+ * FArrayBox const& acoef): three views that need not share a slab -- sol2 and rhs2 with (at least) two components,
+ * acoef1 with one; component 0 of each view is used (point .p at the first component wanted) */
+int hps_mg_solve1_fabs (void* handle, hps_slab sol2, hps_slab rhs2, hps_slab acoef1, double tol_rel, double tol_abs,
+                        int max_iters, int* iters_host, double* resnorm_host, hps_stream stream);
 int hps_mg_destroy (void* handle);
 
 /* hpmg::MultiGrid, system type 2 (mg_solver/HpMultiGrid.H:48,84-87 solve2 with an array Re and a scalar Im coefficient;
@@ -229,7 +234,7 @@ typedef struct {
     double ion_energies[HPS_MAX_ION_LEVELS]; unsigned long long ion_seed;
     /* <beam>.do_spin_tracking (moving beam only): every beam particle carries a spin vector, initial_spin (normalised)
      * for all of them, precessing by the Thomas-BMT equation in the beam push (particles/pusher/BeamParticleAdvance.cpp:
-     * 218-238; spin_anom = anomalous magnetic moment, 0 -> the electron's 0.00115965218128).  The spin travels with the
+     * 218-238; spin_anom = anomalous magnetic moment as given: the electron's is 0.00115965218128, 0 is pure Thomas precession).  The spin travels with the
      * particle through the slipped-particle hand-off and the ring messages (3 more rows). */
     int beam_spin_tracking; double beam_initial_spin[3]; double beam_spin_anom;
 } hps_deck;
@@ -441,6 +446,11 @@ int hps_ring_sendrecv_self (void* ring, const void* src_dev, void* dst_dev, long
 int hps_ring_stream_wait (void* ring, int which, void* event);
 int hps_ring_sync_sends (void* ring);           /* host waits until everything sent so far has left */
 int hps_ring_sync (void* ring);                 /* host waits for both streams of the ring (end of a run) */
+/* Both waits poll and give up with HPS_ERR_COMM (the rank's message counters in hps_last_error) after HPS_RING_TIMEOUT_S
+ * seconds (environment, default 900) -- hps_ring_sync_timeout with the limit as an argument: a ring whose peer is gone, or
+ * whose posted-ahead receives share a hardware queue with the sends they wait for, fails loudly instead of hanging.
+ * hps_ring_init refuses to start a ring of 2+ ranks unless GPU_MAX_HW_QUEUES >= 8 is set in the environment. */
+int hps_ring_sync_timeout (void* ring, double seconds);
 int hps_ring_stats (void* ring, long* n_sent, long* n_received, long long* bytes_sent, long long* bytes_received);
 int hps_ring_destroy (void* ring);
 

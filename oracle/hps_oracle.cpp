@@ -2239,7 +2239,7 @@ void* orc_engine_create (const orc_deck* k) {
     d.ion_density=k->ion_density; d.ion_mass=k->ion_mass; d.ion_charge=k->ion_charge; d.ion_init_level=k->ion_init_level;
     d.ion_Z=std::min(std::max(k->ion_Z, 0), 56); for (int i=0;i<56;++i) d.ion_energies[i]=k->ion_energies[i]; d.ion_seed=k->ion_seed;
     d.beam_spin_tracking=k->beam_spin_tracking; for (int i=0;i<3;++i) d.beam_initial_spin[i]=k->beam_initial_spin[i];
-    d.beam_spin_anom = k->beam_spin_anom != 0.0 ? k->beam_spin_anom : 0.00115965218128;
+    d.beam_spin_anom = k->beam_spin_anom;      // as given (0 = pure Thomas precession)
     return new Engine(d);
 }
 void orc_engine_destroy (void* h) { delete static_cast<Engine*>(h); }

@@ -225,3 +225,34 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-check"], capture_output=True,
                          text=True, timeout=120, cwd=ROOT, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert bad.returncode != 0 and "--gpus 2" in bad.stderr
+
+
+def test_openpmd_json_document(tmp_path):
+    """hipace_amd/openpmd_writer.py with json_too: the iteration in the layout of openPMD-api's JSON backend -- groups as nested
+    objects, attributes as {"datatype", "value"}, datasets as {"datatype", "data"}, constant components as value + shape --
+    holds exactly what the npz container holds (the layout itself could not be opened with openPMD-api here: not installed)."""
+    import json
+    import numpy as np
+    from hipace_amd import openpmd_writer as W
+    rng = np.random.default_rng(3)
+    fields = {"Ez": rng.standard_normal((4, 3, 5)), "rho": rng.standard_normal((4, 3, 5))}
+    beam = dict(x=rng.random(7), y=rng.random(7), z=rng.random(7), ux=rng.random(7), uy=rng.random(7), uz=rng.random(7), w=rng.random(7),
+                charge=-1.0, mass=1.0)
+    fn = W.write_iteration(str(tmp_path), 12, 0.5, 0.1, dict(lo=(-1.0, -2.0, -3.0), hi=(1.0, 2.0, 3.0)), fields, {"beam": beam}, json_too=True)
+    doc = json.load(open(fn.replace(".npz", ".json")))
+    assert doc["attributes"]["openPMD"] == {"datatype": "STRING", "value": "1.1.0"}
+    assert doc["attributes"]["basePath"]["value"] == "/data/%T/" and doc["platform_byte_widths"]["DOUBLE"] == 8
+    it = doc["data"]["12"]
+    assert it["attributes"]["time"] == {"datatype": "DOUBLE", "value": 0.5}
+    ez = it["fields"]["Ez"]
+    assert ez["datatype"] == "DOUBLE" and ez["attributes"]["axisLabels"] == {"datatype": "VEC_STRING", "value": ["z", "y", "x"]}
+    assert ez["attributes"]["unitDimension"]["datatype"] == "ARR_DBL_7" and len(ez["attributes"]["gridSpacing"]["value"]) == 3
+    sp = it["particles"]["beam"]
+    assert sp["charge"]["attributes"]["value"]["value"] == -1.0 and sp["charge"]["attributes"]["shape"] == {"datatype": "VEC_ULONG", "value": [7]}
+    assert sp["id"]["datatype"] == "ULONG" and sp["position"]["x"]["datatype"] == "DOUBLE"
+    arrays, attrs = W.read_openpmd_json(fn.replace(".npz", ".json"))
+    z = np.load(fn)
+    for k in z.files:
+        if k != "__attrs__":
+            assert np.array_equal(arrays[k], z[k]), k
+    assert attrs["/data/12/fields/rho"]["gridGlobalOffset"] == [-3.0, -2.0, -1.0]

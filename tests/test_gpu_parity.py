@@ -177,6 +177,28 @@ def test_multigrid_solve1(api, oracle, nx, ny, warm):
     assert np.array_equal(out[2:5], slab[2:5])
 
 
+def test_multigrid_solve1_with_the_references_argument_list(api, oracle):
+    """hps_mg_solve1_fabs: hpmg::MultiGrid::solve1(sol, rhs, acoef, ...) with three separate fabs (HpMultiGrid.H:64-66), here with
+    three different guard widths -- same V-cycle count and solution as the oracle, both centrings."""
+    for nx, ny in ((96, 64), (63, 63)):
+        rng = np.random.default_rng(nx)
+        dx, dy = 16.0 / nx, 16.0 / ny
+        rhs = rng.standard_normal((2, ny, nx))
+        acf = 0.5 + rng.random((ny + 2 * G2, nx + 2 * G2))
+        guess = 0.05 * rng.standard_normal((2, ny, nx))
+        sol = np.zeros((2, ny + 2 * G2, nx + 2 * G2)); sol[:, G2:-G2, G2:-G2] = guess
+        rhs_g = np.zeros_like(sol); rhs_g[:, G2:-G2, G2:-G2] = rhs
+        it_ref, rn_ref = oracle.mg_solve1(sol, rhs_g, acf, nx, ny, G2, dx, dy)
+        gs, gr, ga = 1, 3, G2                                  # guard cells of the three views
+        fs = api.Fields(nx, ny, gs, 2); fs.t[:, gs:-gs, gs:-gs] = __import__("torch").tensor(guess, device="cuda")
+        fr = api.Fields(nx, ny, gr, 2); fr.t[:, gr:-gr, gr:-gr] = __import__("torch").tensor(rhs, device="cuda")
+        fa = api.Fields(nx, ny, ga, 1, data=acf[None])
+        it, rn = api.MultiGrid(nx, ny, dx, dy).solve1_fabs(fs, fr, fa)
+        assert it == it_ref and it_ref >= 1
+        assert rel_err(fs.numpy()[:, gs:-gs, gs:-gs], sol[:, G2:-G2, G2:-G2]) < 1e-10
+        assert abs(rn - rn_ref) <= 1e-6 * rn_ref
+
+
 @pytest.mark.parametrize("name,js", [("linear_wake_SI", "linear_wake.SI.1Rank"), ("beam_in_vacuum_SI", "beam_in_vacuum.SI.1Rank"),
                                      ("linear_wake", "linear_wake.normalized.1Rank"),
                                      ("blowout_wake", "blowout_wake_explicit.2Rank"), ("blowout_wake", "blowout_wake.2Rank"),
@@ -1045,11 +1067,11 @@ def test_laser_evolution_fft_solver_matches_reference_checksums(api):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("warm", [False, True])
-@pytest.mark.parametrize("nx,ny", [(96, 64), (320, 224), (48, 40)])
+@pytest.mark.parametrize("nx,ny", [(96, 64), (320, 224), (48, 40), (1024, 1024)])
 def test_multigrid2_solve2_vs_oracle(api, oracle, warm, nx, ny):
     """hps_mg2_solve2 (hpmg system type 2: complex coefficient, Re an array, Im a scalar) against the oracle: same number
     of V-cycles, solution to 1e-10, from a zero and from a non-zero initial guess.  96 x 64: one LDS-tiled level;
-    320 x 224: three of them with ragged tile edges; 48 x 40: single-workgroup levels only."""
+    320 x 224: three of them with ragged tile edges; 48 x 40: single-workgroup levels only; 1024 x 1024: BASELINE config 5's size."""
     import torch
     rng = np.random.default_rng(11)
     dx, dy = 0.11, 0.13
@@ -1597,3 +1619,31 @@ def test_cpp_host_runs_the_ring_through_the_c_abi(api, tmp_path):
             assert abs(cs[k] - v) <= 1e-9 * abs(v), (s[1], k, cs[k], v)
     ring = [l.split() for l in out.stdout.splitlines() if l.startswith("ring ")][0]
     assert int(ring[1]) == int(ring[2]) > 0 and int(ring[3]) == 2 * 7 * 8 * nbeam
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stages,n_steps", [(1, 2), (2, 3), (3, 7)])
+def test_cpp_pipeline_host_with_several_stages_per_rank(api, tmp_path, stages, n_steps):
+    """examples/pipeline_host.cpp: the multi-rank C++ host (rank / world / edge ids through files; several stages per rank
+    on in-process edges, the RCCL ring between processes, one host thread, slices in two halves) run as one rank: every
+    step -- open and closed ring -- reproduces the reference's checksums.  (Two ranks need two GPUs: RCCL refuses two ranks on
+    one device; the between-process branch of this host has not run.)"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "pipeline_host")
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build_cpp_host()
+    gold = json.load(open(os.path.join(GOLD, "blowout_wake_explicit.2Rank.json")))["lev=0"]
+    eng = api.SliceEngine(decks.blowout_wake())
+    names = eng.comp_names()
+    path = tmp_path / "deck.bin"
+    path.write_bytes(bytes(eng._dk))
+    del eng
+    out = subprocess.run([exe, str(path), str(n_steps), "0", "1", str(tmp_path), str(stages)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    steps = [l.split() for l in out.stdout.splitlines() if l.startswith("step ")]
+    assert sorted(int(s[1]) for s in steps) == list(range(n_steps))
+    for s in steps:
+        cs = dict(zip(names, map(float, s[2:])))
+        for k, v in gold.items():
+            assert abs(cs[k] - v) <= 1e-9 * abs(v), (s[1], k, cs[k], v)
