@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
 R=$PWD
 cd /tmp && rm -rf /tmp/prof_q
-timeout 900 rocprofv3 --kernel-trace -d /tmp/prof_q -o kt -- python $R/bench.py --cpu-slices 0 "$@" > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
+timeout 900 rocprofv3 --kernel-trace -d /tmp/prof_q -o kt -- python $R/bench.py --cpu-slices 0 --inflight 1 "$@" > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
 DB=$(find /tmp/prof_q -name "*.db" | head -1)
 python $R/scripts/kstats.py $DB 1088 40 > $OUT/${TAG}_kstats.txt
 python $R/scripts/kstats_csv.py $DB > $OUT/${TAG}_kernel_stats.csv
