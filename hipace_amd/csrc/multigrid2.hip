@@ -58,6 +58,22 @@ __device__ __forceinline__ double lap2 (const Lev2& l, int i, int j, const doubl
     return lap;
 }
 
+// max-norm accumulation: one atomic per workgroup into one of the slot's MG2_NSUB words (same-address atomics serialise in
+// the L2 at ~20 ns each: one per wave of a 512-workgroup launch cost more than the launch's arithmetic); the value of a slot
+// is the maximum over its words (k2_post_norms).  Call from every thread of the workgroup.
+constexpr int MG2_NSUB = 16;
+__device__ __forceinline__ void block_max_to_slot (unsigned long long* slot, double m)
+{
+    __shared__ double s_bm[16];
+    for (int s = 32; s > 0; s >>= 1) m = fmax(m, __shfl_xor(m, s));
+    if ((threadIdx.x & 63) == 0) s_bm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (unsigned w = 1; w < (blockDim.x >> 6); ++w) m = fmax(m, s_bm[w]);
+        if (m > 0.0) atomicMax(slot + (blockIdx.x & (MG2_NSUB - 1)), (unsigned long long)__double_as_longlong(m));
+    }
+}
+
 // `ncolors` sweeps starting with colour `color0`, then (do_res) res = rhs - L(phi) and its max-norm.  More than one sweep or
 // sweeps + residual in one launch need a single workgroup.
 __global__ __launch_bounds__(1024)
@@ -82,10 +98,7 @@ void k2_sweeps (Lev2 l, double* phi, const double* __restrict__ rhs, const doubl
         res[o] = r0; res[l.n + o] = r1;
         m = fmax(m, fmax(fabs(r0), fabs(r1)));
     }
-    if (norm) {
-        for (int s = 32; s > 0; s >>= 1) m = fmax(m, __shfl_xor(m, s));
-        if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(norm, (unsigned long long)__double_as_longlong(m));
-    }
+    if (norm) block_max_to_slot(norm, m);
 }
 
 // crse = mean of the 4 fine cells (restrict_cc :29-37), ncomp planes
@@ -124,15 +137,16 @@ void k2_maxabs (const double* __restrict__ p, long n, unsigned long long* norm)
 {
     double m = 0.0;
     for (long o = (long)blockIdx.x*blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x*blockDim.x) m = fmax(m, fabs(p[o]));
-    for (int s = 32; s > 0; s >>= 1) m = fmax(m, __shfl_xor(m, s));
-    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(norm, (unsigned long long)__double_as_longlong(m));
+    block_max_to_slot(norm, m);      // (one atomic per wave of 2048 workgroups on one word made this reduction of 16 MB take 96 us)
 }
 
 // the two norm words -> mapped host memory, sequence number last behind a system-scope fence; the host polls it (as
 // k_post_norms of multigrid.hip) instead of a DMA copy + stream synchronise
 __global__ void k2_post_norms (const unsigned long long* __restrict__ src, volatile unsigned long long* dst, unsigned long long seq)
 {
-    dst[0] = src[0]; dst[1] = src[1];
+    unsigned long long a = 0ULL, b = 0ULL;      // non-negative doubles order like their bit patterns
+    for (int q = 0; q < MG2_NSUB; ++q) { a = src[q] > a ? src[q] : a; b = src[MG2_NSUB + q] > b ? src[MG2_NSUB + q] : b; }
+    dst[0] = a; dst[1] = b;
     __threadfence_system();
     dst[2] = seq;
 }
@@ -268,10 +282,7 @@ void k2_smooth_tile (Lev2 l, int src_mode, const double* __restrict__ fin, const
         res[o] = r0; res[l.n + o] = r1;
         m = fmax(m, fmax(fabs(r0), fabs(r1)));
     }
-    if (do_res && norm) {
-        for (int sh = 32; sh > 0; sh >>= 1) m = fmax(m, __shfl_xor(m, sh));
-        if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(norm, (unsigned long long)__double_as_longlong(m));
-    }
+    if (do_res && norm) block_max_to_slot(norm, m);
 }
 
 // ---- the lower part of the V-cycle in one workgroup ------------------------------------------------------------------
@@ -342,7 +353,7 @@ struct Multigrid2 {
     int nx = 0, ny = 0; double dx = 0, dy = 0;
     std::vector<Lev2> L;
     std::vector<double*> acf, res, cor, rescor;      // per level, 2 planes each
-    unsigned long long* d_norm = nullptr;            // [2]: residual, rhs
+    unsigned long long* d_norm = nullptr;            // [2][MG2_NSUB]: residual, rhs (a slot's value = the maximum over its words)
     unsigned long long *h_post = nullptr, *h_post_dev = nullptr, seq = 0;      // mapped pinned: [0] residual, [1] rhs norm, [2] sequence
     bool res1_ready = false;      // res[1] already holds the restricted level-0 residual (fused into the tile kernel)
     int low_top = -1; Low2 low{}; double** d_low_acf = nullptr;      // levels low_top .. coarsest run in k2_lower_v
@@ -400,7 +411,7 @@ static int mg2_create (int nx, int ny, double dx, double dy, Multigrid2** out)
         for (int k = 0; k < 4; ++k) { HPS_HIP_CHECK(hipMalloc(&p[k], (size_t)2*l.n*sizeof(double))); HPS_HIP_CHECK(hipMemset(p[k], 0, (size_t)2*l.n*sizeof(double))); }
         M->acf.push_back(p[0]); M->res.push_back(p[1]); M->cor.push_back(p[2]); M->rescor.push_back(p[3]);
     }
-    HPS_HIP_CHECK(hipMalloc(&M->d_norm, 2*sizeof(unsigned long long)));
+    HPS_HIP_CHECK(hipMalloc(&M->d_norm, 2*MG2_NSUB*sizeof(unsigned long long)));
     HPS_HIP_CHECK(hipHostMalloc(&M->h_post, 4*sizeof(unsigned long long), hipHostMallocMapped));
     HPS_HIP_CHECK(hipHostGetDevicePointer((void**)&M->h_post_dev, M->h_post, 0));
     M->h_post[0] = M->h_post[1] = M->h_post[2] = 0ULL;
@@ -478,7 +489,7 @@ static void vcycle2 (Multigrid2* M, double* sol, const double* rhs, hipStream_t 
         if (il > 0) std::swap(M->cor[il], M->rescor[il]);
     }
     // cor0 = 4 more sweeps of the solution, residual behind them
-    (void)hipMemsetAsync(M->d_norm, 0, sizeof(unsigned long long), st);
+    (void)hipMemsetAsync(M->d_norm, 0, MG2_NSUB*sizeof(unsigned long long), st);
     M->res1_ready = smooth4(M->L[0], SRC2_DIRECT, sol, nullptr, nullptr, M->cor[0], rhs, M->acf[0], true, M->rescor[0], M->d_norm, st,
                             maxl >= 1 ? M->res[1] : nullptr, maxl >= 1 ? &M->L[1] : nullptr);
 }
@@ -491,11 +502,11 @@ static int mg2_solve2 (Multigrid2* M, double* sol, const double* rhs, const doub
     for (size_t il = 1; il < M->L.size(); ++il)      // average_down_acoef (:1640-1700)
         hipLaunchKernelGGL(k2_restrict, dim3(ceil_div(2*M->L[il].n, 256)), dim3(256), 0, st, M->L[il], M->L[il - 1], M->acf[il], M->acf[il - 1], 2);
     // solve_doit (:1307-1427)
-    (void)hipMemsetAsync(M->d_norm, 0, 2*sizeof(unsigned long long), st);
+    (void)hipMemsetAsync(M->d_norm, 0, 2*MG2_NSUB*sizeof(unsigned long long), st);
     const bool has1 = M->L.size() >= 2;
     M->res1_ready = smooth4(l0, SRC2_DIRECT, sol, nullptr, nullptr, M->cor[0], rhs, M->acf[0], true, M->rescor[0], M->d_norm, st,
                             has1 ? M->res[1] : nullptr, has1 ? &M->L[1] : nullptr);
-    hipLaunchKernelGGL(k2_maxabs, dim3((unsigned)std::min<long>(ceil_div(2*l0.n, 1024), 2048)), dim3(256), 0, st, rhs, 2*l0.n, M->d_norm + 1);
+    hipLaunchKernelGGL(k2_maxabs, dim3((unsigned)std::min<long>(ceil_div(2*l0.n, 2048), 512)), dim3(256), 0, st, rhs, 2*l0.n, M->d_norm + MG2_NSUB);
     HPS_HIP_CHECK(hipGetLastError());
     double resnorm0 = 0.0, rhsnorm0 = 0.0;
     if (int e = read_norms(M, &resnorm0, &rhsnorm0, st)) return e;

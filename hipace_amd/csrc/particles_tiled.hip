@@ -406,8 +406,11 @@ template <class T> __device__ __forceinline__ void sto (T* base, unsigned o, T v
 #ifndef HPS_PUSH_WAVES
 #define HPS_PUSH_WAVES 3
 #endif
+#ifndef HPS_PUSH_WAVES_ION
+#define HPS_PUSH_WAVES_ION 2
+#endif
 template <int ORDER, int TS, bool LASER = false, bool IONIZE = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((LASER || IONIZE) ? 1 : HPS_PUSH_WAVES)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IONIZE ? HPS_PUSH_WAVES_ION : HPS_PUSH_WAVES)))
 void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
                       int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, int* n_fallback, IonArgs ia, const int* go)
 {
