@@ -136,6 +136,8 @@ struct Engine {
     int solve_slice_begin (int islice);      // ... in two halves: everything up to the Bx/By solve's norm read-back is enqueued,
     int solve_slice_finish (int islice);     // then the host waits for the norms and enqueues the rest
     int pending_slice = -1; bool pend_fuse = false, pend_gated = false;
+    bool lazy_shift = true, shift_pending = false;      // ShiftSlices deferred to the next slice's InitializeSlices pass (HPS_LAZY_SHIFT=0: off)
+    void flush_shift ();
     int run_step ();
 };
 

@@ -507,6 +507,7 @@ int Engine::create (const hps_deck& deck, int device)
     if (d.field_bc != 0) { set_error("hps_engine_create: only boundary.field = Dirichlet is built"); return HPS_ERR_UNSUPPORTED; }
     pc = (d.bxby_solver != 0);
     if (const char* v = std::getenv("HPS_GATED_PUSH")) gate_push = std::atoi(v) != 0;
+    if (const char* v = std::getenv("HPS_LAZY_SHIFT")) lazy_shift = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_SORT_FALLBACK_DIV")) { const long q = std::atol(v); if (q >= 1) fallback_div = q; }
     HPS_REQUIRE(!(d.beam_spin_tracking && d.dt == 0.0), "hps_engine_create: spin tracking needs a moving beam (hipace.dt != 0)");
     if (d.predcorr_tol > 0.0) pc_tol = d.predcorr_tol;
@@ -675,6 +676,7 @@ int Engine::begin_step ()
         HPS_HIP_CHECK(hipStreamSynchronize(st));
         ++steps_begun;
     }
+    shift_pending = false;      // (the slab is cleared whole below)
     // ResetAllQuantities (Hipace.cpp:730-742)
     HPS_HIP_CHECK(hipMemsetAsync(slab.p, 0, (size_t)slab.nstride*ncomp*sizeof(double), st));
     HPS_HIP_CHECK(hipMemsetAsync(d_checksum, 0, HPS_PC_NCOMP_MAX*sizeof(double), st));
@@ -1232,6 +1234,14 @@ int Engine::solve_slice_pc (int islice)
 // device, hps_engine_solve_slice_begin / _finish): begin enqueues everything up to and including the speculated V-cycles of
 // the Bx/By solve (and the gated push behind them) and returns without waiting for the device; finish waits for the
 // solve's norms -- the one host wait of a slice -- and enqueues the rest.  solve_slice = begin + finish.
+void Engine::flush_shift ()
+{
+    if (!shift_pending) return;
+    shift_pending = false;
+    const CellBox bb{beam_box.ilo, beam_box.ihi, beam_box.jlo, beam_box.jhi};
+    hipLaunchKernelGGL(k_shift_slices, dim3(ceil_div(slab.nstride, 256)), dim3(256), 0, st, slab.p, slab.nstride, slab.nstride, (int)slab.jstride, bb);
+}
+
 int Engine::solve_slice (int islice)
 {
     if (int e = solve_slice_begin(islice)) return e;
@@ -1260,7 +1270,14 @@ int Engine::solve_slice_begin (int islice)
     // plasma currents (k_shift_zero + k_advance_deposit_tiled)
     const bool ahead = (ahead_for == islice);
     ahead_for = -2;
-    if (!ahead)
+    // ShiftSlices of the slice before, left pending at its end (lazy_shift), and this slice's InitializeSlices in one pass
+    bool zeroed = false;
+    if (shift_pending) {
+        shift_pending = false;
+        if (!ahead) { hipLaunchKernelGGL(k_shift_zero, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, bb, d.deposit_rho ? (int)HPS_C_RHO : -1); zeroed = true; }
+        else hipLaunchKernelGGL(k_shift_slices, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, bb);
+    }
+    if (!ahead && !zeroed)
     {   CompList z{0, {}}, zb{0, {}};
         // Sx, Sy are written as whole planes by k_sxsy_beam; ExmBy, EypBx by k_grad_psi up to the outermost
         // guard ring, which nothing ever writes (it keeps the zeros of begin_step); the beam planes only
@@ -1443,8 +1460,12 @@ int Engine::solve_slice_finish (int islice)
     if (moving && nbeam > 0) { if ((e = beam_push_moving(*this, islice))) return e; }
     mark();   // b8
     // ShiftSlices (fields/Fields.cpp:588-604)
-    if (ahead_for != islice - 1)
-        hipLaunchKernelGGL(k_shift_slices, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, bb);
+    // (lazy_shift: left to the start of the next slice, where it shares a pass with InitializeSlices; anything that looks at
+    //  the slab in between -- hps_engine_slab, _sync, the diagnostics' accessors -- runs it first: flush_shift)
+    if (ahead_for != islice - 1) {
+        if (lazy_shift && islice > 0) shift_pending = true;
+        else hipLaunchKernelGGL(k_shift_slices, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, bb);
+    }
     mark();   // b9
     HPS_HIP_CHECK(hipGetLastError());
     ++slices_done;
@@ -1483,6 +1504,7 @@ extern "C" int hps_engine_run_step (void* h) { return static_cast<Engine*>(h)->r
 extern "C" int hps_engine_sync (void* h)
 {
     Engine* E = static_cast<Engine*>(h);
+    E->flush_shift();
     if (int e = E->join_laser()) return e;
     HPS_HIP_CHECK(hipStreamSynchronize(E->st));
     if (E->moving && E->d_beam_overflow) {
@@ -1502,7 +1524,7 @@ extern "C" int hps_engine_info (void* h, int* ncomp, int* ng, long* np)
     if (np) *np = E->np;
     return HPS_OK;
 }
-extern "C" hps_slab hps_engine_slab (void* h) { return static_cast<Engine*>(h)->slab; }
+extern "C" hps_slab hps_engine_slab (void* h) { Engine* E = static_cast<Engine*>(h); E->flush_shift(); return E->slab; }
 extern "C" hps_plasma hps_engine_plasma (void* h) { return static_cast<Engine*>(h)->pl; }
 extern "C" hps_plasma hps_engine_ions (void* h)
 {

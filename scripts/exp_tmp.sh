@@ -1,5 +1,7 @@
-python -m pytest tests -m gpu -x -q -k "multigrid2 or laser or ioniz" 2>&1 | grep -E "passed|failed" | tail -2
-pj() { python -c "import json,sys; d=json.loads(sys.stdin.read()); p=d['phase_ms_per_slice']; print(round(d['value'],1), {k: round(v,4) for k,v in p.items() if v}, d.get('laser_vcycles_per_slice'))"; }
-python bench.py --config5 --steps 2048 | pj
-python bench.py --config5 --steps 2048 --laser-solver multigrid | pj
-python bench.py --config5 --steps 2048 --laser-solver multigrid --no-ionization | pj
+pj() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],1), d.get('value_steps_in_flight'))"; }
+python bench.py --cpu-slices 0 | pj
+GPU_MAX_HW_QUEUES=8 python bench.py --cpu-slices 0 | pj
+GPU_MAX_HW_QUEUES=2 python bench.py --cpu-slices 0 | pj
+python bench.py --cpu-slices 0 --inflight 4 --steps 4096 | pj
+GPU_MAX_HW_QUEUES=8 python bench.py --cpu-slices 0 --inflight 4 --steps 4096 | pj
+python bench.py --cpu-slices 0 --inflight 2 --steps 2048 | pj
