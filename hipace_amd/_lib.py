@@ -106,6 +106,7 @@ _SIGS = {
     "hps_engine_solve_slice": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_solve_slice_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_solve_slice_finish": (C.c_int, [C.c_void_p, C.c_int]),
+    "hps_engine_slice_ready": (C.c_int, [C.c_void_p]),
     "hps_engine_run_step": (C.c_int, [C.c_void_p]),
     "hps_engine_sync": (C.c_int, [C.c_void_p]),
     "hps_engine_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long)]),

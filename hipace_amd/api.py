@@ -308,6 +308,10 @@ class SliceEngine:
     def solve_slice_finish(self, islice):
         check(_lib.lib().hps_engine_solve_slice_finish(self._h, islice))
 
+    def slice_ready(self):
+        """would solve_slice_finish return without waiting for the device?"""
+        return bool(_lib.lib().hps_engine_slice_ready(self._h))
+
     def run_step(self):
         check(_lib.lib().hps_engine_run_step(self._h))
 

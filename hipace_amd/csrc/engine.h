@@ -13,6 +13,7 @@ namespace hps {
 int mg_solve1_begin (void* mg_handle, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, double tol_rel, double tol_abs,
                      int max_iters, hipStream_t st);
 const int* mg_gate_after_enqueued (void* mg_handle);
+bool mg_solve1_ready (void* mg_handle);
 int mg_solve1_finish (void* mg_handle, int* iters_out, double* resnorm_out, int* extra, hipStream_t st);
 }
 

@@ -1499,6 +1499,12 @@ extern "C" int hps_engine_destroy (void* h) { delete static_cast<Engine*>(h); re
 extern "C" int hps_engine_begin_step (void* h) { return static_cast<Engine*>(h)->begin_step(); }
 extern "C" int hps_engine_solve_slice (void* h, int islice) { return static_cast<Engine*>(h)->solve_slice(islice); }
 extern "C" int hps_engine_solve_slice_begin (void* h, int islice) { return static_cast<Engine*>(h)->solve_slice_begin(islice); }
+extern "C" int hps_engine_slice_ready (void* h)
+{
+    Engine* E = static_cast<Engine*>(h);
+    if (E->pending_slice < 0 || E->pc) return 1;
+    return mg_solve1_ready(E->mg) ? 1 : 0;
+}
 extern "C" int hps_engine_solve_slice_finish (void* h, int islice) { return static_cast<Engine*>(h)->solve_slice_finish(islice); }
 extern "C" int hps_engine_run_step (void* h) { return static_cast<Engine*>(h)->run_step(); }
 extern "C" int hps_engine_sync (void* h)

@@ -1759,6 +1759,12 @@ const int* mg_gate_after_enqueued (void* handle)
 {
     return reinterpret_cast<const int*>(static_cast<Multigrid*>(handle)->d_buf) + MG_GO_WORD;
 }
+// have the norms of the batch enqueued by mg_solve1_begin arrived (mg_solve1_finish would not wait)?
+bool mg_solve1_ready (void* handle)
+{
+    Multigrid* M = static_cast<Multigrid*>(handle);
+    return *(volatile unsigned long long*)M->h_seq == M->seq;
+}
 int mg_solve1_finish (void* handle, int* iters_out, double* resnorm_out, int* extra, hipStream_t st)
 {
     Multigrid* M = static_cast<Multigrid*>(handle);

@@ -268,6 +268,9 @@ int hps_engine_solve_slice (void* handle, int islice);    /* SolveOneSlice :556-
  * halves of one engine only calls on OTHER engines are allowed. */
 int hps_engine_solve_slice_begin (void* handle, int islice);
 int hps_engine_solve_slice_finish (void* handle, int islice);
+/* 1 if hps_engine_solve_slice_finish would not wait for the device (the norms of the slice begun have arrived), else 0: a host
+ * that drives several engines finishes whichever is ready first */
+int hps_engine_slice_ready (void* handle);
 int hps_engine_run_step (void* handle);                   /* begin_step + all slices head->tail   */
 int hps_engine_sync (void* handle);                       /* host waits for the engine's stream (and, through it, the laser stream) */
 int hps_engine_info (void* handle, int* ncomp, int* nguards, long* nparticles);
