@@ -519,7 +519,7 @@ def main():
             "particle_pushes_per_s": total / dt * args.ppc * args.ppc * args.n * args.n,
             "config": {"workload": ("linear_wake.normalized 256x256x512, 4 ppc, order 2, predictor-corrector Bx/By solver "
                                     "(tolerance 4e-2, <= 30 iterations, mixing 0.05), dt=0 (BASELINE.json configs[1])") if args.config2 else
-                                   (f"laser_blowout_wake {args.n}x{args.n}x{nz}, 4 ppc, order 2, Gaussian laser a0=4.5 + {args.laser_solver} envelope "
+                                   (f"laser_blowout_wake {args.n}x{args.n}x{nz} in NORMALISED units (BASELINE names the .SI twin of the deck: same kernels, other constants), 4 ppc, order 2, Gaussian laser a0=4.5 + {args.laser_solver} envelope "
                                     "solver every slice" + (", no ionisation" if args.no_ionization else ", neutral N (0.2 n_e, 1 macro-atom per cell) "
                                     "field-ionised by the wake (ADK), released electrons join the plasma") + " (BASELINE.json configs[4])") if args.config5 else
                                    (f"blowout_wake synthetic {args.n}x{args.n}x{nz}, {args.ppc * args.ppc} ppc, "
