@@ -333,11 +333,14 @@ __device__ __forceinline__ void sym_stage (lds_double* cbuf, const double2* __re
             const double sr = xa.x + xb.x, si = xa.y + xb.y, dr = xa.x - xb.x, di = xa.y - xb.y;
             ssum.x += sr; ssum.y += si;
             // wave-uniform address: the table is read through the scalar cache, not the LDS pipe
-            const double2* __restrict__ row = cs + ((n - 1)*H + (k0 - 1));
+            // (through the constant address space: the load stays a scalar one whatever else the kernel does ahead of it --
+            //  a harmless edit at the kernel's head once turned these into vector loads: 74 -> 108 VGPRs, 150 -> 185 us)
+            typedef const __attribute__((address_space(4))) double cdouble;
+            cdouble* row = (cdouble*)(cs + ((n - 1)*H + (k0 - 1)));
 #pragma unroll
             for (int kk = 0; kk < KB; ++kk) {
                 if (k0 + kk <= H) {
-                    const double2 c = row[kk];            // (cos, sin)(2 pi n k / M)
+                    const double2 c = make_double2(row[2*kk], row[2*kk + 1]);            // (cos, sin)(2 pi n k / M)
                     pr[kk] = fma(sr, c.x, pr[kk]); pim[kk] = fma(si, c.x, pim[kk]);
                     qr[kk] = fma(dr, c.y, qr[kk]); qi[kk] = fma(di, c.y, qi[kk]);
                 }
