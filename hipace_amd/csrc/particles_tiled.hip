@@ -139,7 +139,7 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         for (int s = tid; s < na*R*R/2; s += 256) z[s] = make_double2(0.0, 0.0);
     }
     double* aimg = acc + na*R*R;          // LASER: |a|^2 over the tile region
-    if constexpr (LASER) { const int ca[1] = {k.aabs}; load_region<R>(aimg, f, ca, 1, ox, oy, tid); }
+    if constexpr (LASER) { const int ca[1] = {k.aabs}; load_region<R, R, 256, 1>(aimg, f, ca, 1, ox, oy, tid); }
     __syncthreads();
     PT_STAMP(1);
 
@@ -233,16 +233,32 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     PT_STAMP(4);
 }
 
-// image of `nc` slab components over the tile region into LDS (0 outside the slab box)
-template <int R, int RP = R, int NT = 256>
+// image of `nc` slab components over the tile region into LDS (0 outside the slab box).  All loads of a thread are issued
+// before its first LDS store (the loop over the thread's cells is unrolled by hand: its trip count depends on the thread, and
+// left to the compiler every round of loads waited for the one before -- four trips to memory at the head of each tile)
+template <int R, int RP = R, int NT = 256, int NC = 6>
 __device__ __forceinline__ void load_region (double* img, const SlabView& f, const int* comps, int nc, int ox, int oy, int tid)
 {
-    for (int s = tid; s < R*R; s += NT) {
+    constexpr int NIT = (R*R + NT - 1)/NT;
+    double v[NIT][NC];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int s = min(tid + it*NT, R*R - 1);
         const int lj = s / R, li = s - lj*R;
         const int i = ox + li, j = oy + lj;
         const bool in = (i >= -f.ng && i < f.nx + f.ng && j >= -f.ng && j < f.ny + f.ng);
         const long o = in ? f.off(i, j) : 0;
-        for (int c = 0; c < nc; ++c) img[c*RP*R + lj*RP + li] = in ? f.p[comps[c]*f.ns + o] : 0.0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { v[it][c] = 0.0; if (c < nc) { const double q = f.p[comps[c]*f.ns + o]; v[it][c] = in ? q : 0.0; } }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int s = tid + it*NT;
+        if (s < R*R) {
+            const int lj = s / R, li = s - lj*R;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) if (c < nc) img[c*RP*R + lj*RP + li] = v[it][c];
+        }
     }
 }
 
@@ -278,8 +294,8 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
     const int ipb = offsets[tile] + tid;
     Rec nxt{};
     if (ipb < pend) nxt = fetch(ipb);
-    load_region<R, RP>(img, f, cc, 4, ox, oy, tid);
-    if constexpr (LASER) { const int ca[1] = {k.aabs}; load_region<R, RP>(aimg, f, ca, 1, ox, oy, tid); }
+    load_region<R, RP, 256, 4>(img, f, cc, 4, ox, oy, tid);
+    if constexpr (LASER) { const int ca[1] = {k.aabs}; load_region<R, RP, 256, 1>(aimg, f, ca, 1, ox, oy, tid); }
     {
         double2* z = (double2*)acc;
         for (int s = tid; s < PL; s += 256) z[s] = make_double2(0.0, 0.0);
@@ -434,9 +450,9 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
     const int tid = threadIdx.x;
     const int cc[5] = {cPsi, cEz, cBx, cBy, cBz};
-    load_region<R>(img, f, cc, 5, ox, oy, tid);
+    load_region<R, R, 256, 5>(img, f, cc, 5, ox, oy, tid);
     double* aimg = img + 5*R*R;           // LASER: |a|^2 over the tile region
-    if constexpr (LASER) { const int ca[1] = {k.aabs}; load_region<R>(aimg, f, ca, 1, ox, oy, tid); }
+    if constexpr (LASER) { const int ca[1] = {k.aabs}; load_region<R, R, 256, 1>(aimg, f, ca, 1, ox, oy, tid); }
     __syncthreads();
     if (!go_now) return;
 
@@ -628,7 +644,7 @@ void k_advance_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__
     const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
     const int tid = threadIdx.x;
     const int cc[5] = {cPsi, cEz, cBx, cBy, cBz};
-    load_region<R, R, NT>(img, f, cc, 5, ox, oy, tid);
+    load_region<R, R, NT, 5>(img, f, cc, 5, ox, oy, tid);
     {
         double2* z = (double2*)acc;
         for (int s = tid; s < na*R*R/2; s += NT) z[s] = make_double2(0.0, 0.0);

@@ -1,2 +1,4 @@
-pj() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],1), round(d['phase_ms_per_slice']['poisson'],4))"; }
-for s in 0 1 2 3 4; do echo stagger $s; HPS_DST_STAGGER=$s python bench.py --cpu-slices 0 --inflight 1 | pj; done
+python -m pytest tests -m gpu -x -q -k "advance_plasma or explicit_deposit or slice_by_slice or golden or laser_wake" 2>&1 | grep -E "passed|failed" | tail -2
+pj() { python -c "import json,sys; d=json.loads(sys.stdin.read()); p=d['phase_ms_per_slice']; print(round(d['value'],1), d.get('value_steps_in_flight'), {k: round(v,4) for k,v in p.items() if v})"; }
+python bench.py --cpu-slices 0 | pj
+python bench.py --cpu-slices 0 | pj
