@@ -91,19 +91,33 @@ __device__ __forceinline__ void cmac (double2& acc, const double2 x, const doubl
     acc.y = fma(x.x, w.y, acc.y); acc.y = fma(x.y, w.x, acc.y);
 }
 
-// coalesced copy of T row pairs into LDS as complex (x_a[j], x_b[j]) at [t][j], j < n = N-1
+// coalesced copy of T row pairs into LDS as complex (x_a[j], x_b[j]) at [t][j], j < n = N-1.  All loads of a thread are
+// issued before its first LDS store (clamped addresses + selects instead of branches: written as a loop with conditional
+// pointers this was six rounds of load -> wait -> store at the head of every pass)
 template <int T, int N, int NT = 256>
 __device__ __forceinline__ void load_row_pairs (lds_double* cbuf, const DstArgs& a, int row0, int total_rows, int tid)
 {
-    constexpr int n = N - 1;
+    constexpr int n = N - 1, NJ = (n + NT - 1)/NT;
+    double va[T][NJ], vb[T][NJ];
+    bool oka[T], okb[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const int ra = row0 + 2*t, rb = ra + 1;
-        const double* pa = nullptr; const double* pb = nullptr;
-        if (ra < total_rows) { const int pl = ra / a.rows_per_plane; pa = a.src[pl] + (long)(ra - pl*a.rows_per_plane)*a.src_pitch; }
-        if (rb < total_rows) { const int pl = rb / a.rows_per_plane; pb = a.src[pl] + (long)(rb - pl*a.rows_per_plane)*a.src_pitch; }
-#pragma unroll 4
-        for (int j = tid; j < n; j += NT) stc(cbuf, t*N + j, pa ? pa[j] : 0.0, pb ? pb[j] : 0.0);
+        oka[t] = ra < total_rows; okb[t] = rb < total_rows;
+        const int ca = min(ra, total_rows - 1), cb = min(rb, total_rows - 1);
+        const int pla = ca / a.rows_per_plane, plb = cb / a.rows_per_plane;
+        const double* pa = a.src[pla] + (long)(ca - pla*a.rows_per_plane)*a.src_pitch;
+        const double* pb = a.src[plb] + (long)(cb - plb*a.rows_per_plane)*a.src_pitch;
+#pragma unroll
+        for (int m = 0; m < NJ; ++m) { const int j = min(tid + NT*m, n - 1); va[t][m] = pa[j]; vb[t][m] = pb[j]; }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int m = 0; m < NJ; ++m) {
+            const int j = tid + NT*m;
+            if (j < n) stc(cbuf, t*N + j, oka[t] ? va[t][m] : 0.0, okb[t] ? vb[t][m] : 0.0);
+        }
     }
 }
 
@@ -130,11 +144,26 @@ __device__ __forceinline__ void pre_to_regs (const lds_double* cbuf, int tid, do
     }
 }
 
-// r_a = Re X, r_b = Im X with X[q] stored at [q % N1][q / N1]; T_k from r_{k+1}, r_{N-1-k}; store
+// r_a = Re X, r_b = Im X with X[q] stored at [q % N1][q / N1]; T_k from r_{k+1}, r_{N-1-k}; store.  The factors a thread
+// needs from global memory (1/(4 sin), the optional scale rows) are requested ahead of the loop over the row pairs.
 template <int T, int N1, int N2, int NT = 256>
 __device__ __forceinline__ void post_store (const lds_double* cbuf, const DstArgs& a, int row0, int total_rows, int tid)
 {
-    constexpr int N = N1*N2, n = N - 1;
+    constexpr int N = N1*N2, n = N - 1, NK = (n + NT - 1)/NT;
+    double is[NK], sca[T][NK], scb[T][NK];
+#pragma unroll
+    for (int m = 0; m < NK; ++m) is[m] = a.isin4[min(tid + NT*m, n - 1)];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int ra = min(row0 + 2*t, total_rows - 1), rb = min(row0 + 2*t + 1, total_rows - 1);
+        const int ja = ra - (ra / a.rows_per_plane)*a.rows_per_plane, jb = rb - (rb / a.rows_per_plane)*a.rows_per_plane;
+#pragma unroll
+        for (int m = 0; m < NK; ++m) {
+            const int k = min(tid + NT*m, n - 1);
+            sca[t][m] = a.scale ? a.scale[(long)ja*n + k] : 1.0;
+            scb[t][m] = a.scale ? a.scale[(long)jb*n + k] : 1.0;
+        }
+    }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const int ra = row0 + 2*t, rb = ra + 1;
@@ -143,19 +172,19 @@ __device__ __forceinline__ void post_store (const lds_double* cbuf, const DstArg
         const int ja = ra - pla*a.rows_per_plane, jb = rb - plb*a.rows_per_plane;
         double* da = a.dst[pla] + (long)ja*a.dst_pitch;
         double* db = (rb < total_rows) ? a.dst[plb] + (long)jb*a.dst_pitch : nullptr;
-        const double* sa = a.scale ? a.scale + (long)ja*n : nullptr;
-        const double* sb = a.scale ? a.scale + (long)jb*n : nullptr;
-#pragma unroll 2
-        for (int k = tid; k < n; k += NT) {
-            const int q1 = k + 1, q2 = N - 1 - k;
-            const double2 x1 = ldc(cbuf, t*N + (q1 % N1)*N2 + q1/N1);
-            const double2 x2 = ldc(cbuf, t*N + (q2 % N1)*N2 + q2/N1);
-            const double is = a.isin4[k];
-            double ta = 0.5*(x2.x - x1.x) + (x1.x + x2.x)*is;
-            double tb = 0.5*(x2.y - x1.y) + (x1.y + x2.y)*is;
-            if (sa) { ta *= sa[k]; if (db) tb *= sb[k]; }
-            da[k] = ta;
-            if (db) db[k] = tb;
+#pragma unroll
+        for (int m = 0; m < NK; ++m) {
+            const int k = tid + NT*m;
+            if (k < n) {
+                const int q1 = k + 1, q2 = N - 1 - k;
+                const double2 x1 = ldc(cbuf, t*N + (q1 % N1)*N2 + q1/N1);
+                const double2 x2 = ldc(cbuf, t*N + (q2 % N1)*N2 + q2/N1);
+                double ta = 0.5*(x2.x - x1.x) + (x1.x + x2.x)*is[m];
+                double tb = 0.5*(x2.y - x1.y) + (x1.y + x2.y)*is[m];
+                if (a.scale) { ta *= sca[t][m]; tb *= scb[t][m]; }
+                da[k] = ta;
+                if (db) db[k] = tb;
+            }
         }
     }
 }
