@@ -449,22 +449,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     }
     const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
     const int tid = threadIdx.x;
-    const int cc[5] = {cPsi, cEz, cBx, cBy, cBz};
-    load_region<R, R, 256, 5>(img, f, cc, 5, ox, oy, tid);
-    double* aimg = img + 5*R*R;           // LASER: |a|^2 over the tile region
-    if constexpr (LASER) { const int ca[1] = {k.aabs}; load_region<R, R, 256, 1>(aimg, f, ca, 1, ox, oy, tid); }
-    __syncthreads();
-    if (!go_now) return;
-
-    // The thread's particles are ip = first + 256 m.  Per particle the kernel needs idcpu, x_prev, y_prev and the three
-    // half-step momenta: read one after the other where they are used (the validity bit first), that was three dependent
-    // trips to memory per particle against ~1 us of arithmetic, with three waves per SIMD to hide them: the waves of
-    // the round-2 kernel lived 29 us for 4-5 particles and issued VALU instructions a fifth of that time.  Now all six
-    // values of particle m + 1 are requested before particle m is worked on (14 VGPRs), and every array is addressed
-    // as uniform base + one 32-bit byte offset (the file is compiled with -disable-lsr: the loop-strength-reduction
-    // pass otherwise keeps a 64-bit pointer per array and iteration in VGPRs, 24 registers here).
     const unsigned pend = (unsigned)offsets[tile + 1];
-    int nfb = 0;
     struct PIn { uint64_t id; double xp, yp, uxh, uyh, psih; };
     auto fetch = [&] (unsigned ip) {
         PIn q;
@@ -473,10 +458,28 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         q.uxh = ldo(pl.ux_half, o); q.uyh = ldo(pl.uy_half, o); q.psih = ldo(pl.psi_half, o);
         return q;
     };
-#ifdef HPS_PUSH_PREFETCH
+#ifndef HPS_PUSH_NO_PREFETCH
+    // the thread's first particle is requested ahead of the field image: its six values arrive with the image's
     unsigned ip = (unsigned)offsets[tile] + tid;
     PIn nxt{0, 0.0, 0.0, 0.0, 0.0, 1.0};
     if (ip < pend) nxt = fetch(ip);
+#endif
+    const int cc[5] = {cPsi, cEz, cBx, cBy, cBz};
+    load_region<R, R, 256, 5>(img, f, cc, 5, ox, oy, tid);
+    double* aimg = img + 5*R*R;           // LASER: |a|^2 over the tile region
+    if constexpr (LASER) { const int ca[1] = {k.aabs}; load_region<R, R, 256, 1>(aimg, f, ca, 1, ox, oy, tid); }
+    __syncthreads();
+    if (!go_now) return;
+    int nfb = 0;
+
+    // The thread's particles are ip = first + 256 m.  Per particle the kernel needs idcpu, x_prev, y_prev and the three
+    // half-step momenta: read one after the other where they are used (the validity bit first), that was three dependent
+    // trips to memory per particle against ~1 us of arithmetic, with three waves per SIMD to hide them: the waves of
+    // the round-2 kernel lived 29 us for 4-5 particles and issued VALU instructions a fifth of that time.  Now all six
+    // values of particle m + 1 are requested before particle m is worked on (14 VGPRs), and every array is addressed
+    // as uniform base + one 32-bit byte offset (the file is compiled with -disable-lsr: the loop-strength-reduction
+    // pass otherwise keeps a 64-bit pointer per array and iteration in VGPRs, 24 registers here).
+#ifndef HPS_PUSH_NO_PREFETCH
     for (; ip < pend; ip += 256) {
         __builtin_assume(ip < (1u << 28));
         const PIn cur = nxt;
@@ -509,8 +512,15 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
                 // of s[0], s[NS-1] is always exactly 0 -- was measured: 52 instead of 80 LDS reads per particle, but the
                 // lane-dependent base address costs more than the reads save: 171 against 166 us)
                 const double* b = img + lj*R + li;
+#ifndef HPS_PUSH_ROLLED_ROWS
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
                 for (int iy = 0; iy < NS; ++iy) {
+#ifndef HPS_PUSH_ROLLED_ROWS
+                    asm volatile("" ::: "memory");      // one stencil row of LDS reads in flight at a time
+#endif
                     double rp = 0.0, rd = 0.0, rez = 0.0, rbx = 0.0, rby = 0.0, rbz = 0.0;
 #pragma unroll
                     for (int ix = 0; ix < NS; ++ix) {
