@@ -109,11 +109,12 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         slot[c] = on ? na++ : -1;
     }
 
-    const int tile = offsets[gridDim.x + 2 + blockIdx.x];     // launch order: heaviest tile first (sort.hip)
+    const int4 lrec = reinterpret_cast<const int4*>(offsets + tile_launch_offset(gridDim.x))[blockIdx.x];     // {tile, first, end}: launch order = heaviest tile first (sort.hip)
+    const int tile = lrec.x;
     const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
     const int tid = threadIdx.x;
     PT_STAMP(0);
-    const int pend = offsets[tile + 1];
+    const int pend = lrec.z;
     int nfb = 0;
     struct Rec { double x, y, w, ux, uy, psi; uint64_t id; int ion; };
     auto fetch = [&] (int ip) {
@@ -129,7 +130,7 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     // zeroed, so its HBM latency hides behind the zeroing.
     constexpr int NB = 4;
     Rec rec[NB];
-    const int ipb = offsets[tile] + tid;
+    const int ipb = lrec.y + tid;
     if (ipb < pend) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) rec[u] = fetch(min(ipb + 256*u, pend - 1));
@@ -276,13 +277,14 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
     double* img = lds;
     double* acc = lds + 4*PL;
     double* aimg = lds + 6*PL;
-    const int tile = offsets[gridDim.x + 2 + blockIdx.x];     // launch order: heaviest tile first (sort.hip)
+    const int4 lrec = reinterpret_cast<const int4*>(offsets + tile_launch_offset(gridDim.x))[blockIdx.x];     // {tile, first, end} of this workgroup (sort.hip)
+    const int tile = lrec.x;
     const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
     const int tid = threadIdx.x;
     const int cc[4] = {cBz, cEz, cExmBy, cEypBx};
     // software pipeline over the tile's particles: the next particle's record is in flight while the
     // current one is deposited; the first one is requested ahead of the field-image load
-    const int pend = offsets[tile + 1];
+    const int pend = lrec.z;
     struct Rec { double x, y, w, ux, uy, psi; uint64_t id; int ion; };
     auto fetch = [&] (int ip) {
         Rec r;
@@ -291,7 +293,7 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
         r.ion = k.can_ionize ? pl.ion_lev[ip] : 1;
         return r;
     };
-    const int ipb = offsets[tile] + tid;
+    const int ipb = lrec.y + tid;
     Rec nxt{};
     if (ipb < pend) nxt = fetch(ipb);
     load_region<R, RP, 256, 4>(img, f, cc, 4, ox, oy, tid);
@@ -438,7 +440,8 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     const int go_now = go ? *go : 1;
     int charged = 0;          // IONIZE: does this thread hold an ion of level > 0 after the slice?
     extern __shared__ __attribute__((aligned(16))) double img[];     // [5][R*R]
-    const int tile = offsets[gridDim.x + 2 + blockIdx.x];     // launch order: heaviest tile first (sort.hip)
+    const int4 lrec = reinterpret_cast<const int4*>(offsets + tile_launch_offset(gridDim.x))[blockIdx.x];     // {tile, first, end} of this workgroup (sort.hip)
+    const int tile = lrec.x;
     if constexpr (IONIZE) {
         // a tile of neutral atoms at rest (no charged ion so far) in a field below the threshold of the first level:
         // nothing to decide, nothing to push -- most tiles of a slice (the field image is not even loaded)
@@ -449,7 +452,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     }
     const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
     const int tid = threadIdx.x;
-    const unsigned pend = (unsigned)offsets[tile + 1];
+    const unsigned pend = (unsigned)lrec.z;
     struct PIn { uint64_t id; double xp, yp, uxh, uyh, psih; };
     auto fetch = [&] (unsigned ip) {
         PIn q;
@@ -460,7 +463,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     };
 #ifndef HPS_PUSH_NO_PREFETCH
     // the thread's first particle is requested ahead of the field image: its six values arrive with the image's
-    unsigned ip = (unsigned)offsets[tile] + tid;
+    unsigned ip = (unsigned)lrec.y + tid;
     PIn nxt{0, 0.0, 0.0, 0.0, 0.0, 1.0};
     if (ip < pend) nxt = fetch(ip);
 #endif
@@ -485,7 +488,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         const PIn cur = nxt;
         if (ip + 256 < pend) nxt = fetch(ip + 256);
 #else
-    for (unsigned ip = (unsigned)offsets[tile] + tid; ip < pend; ip += 256) {
+    for (unsigned ip = (unsigned)lrec.y + tid; ip < pend; ip += 256) {
         __builtin_assume(ip < (1u << 28));
         const PIn cur = fetch(ip);          // one batch of six loads, one trip to memory per particle
 #endif

@@ -119,6 +119,16 @@ void k_tile_order_identity (int* order, int ntiles)
     const int t = blockIdx.x*blockDim.x + threadIdx.x;
     if (t < ntiles) order[t] = t;
 }
+// launch[b] = {tile, first particle, end} of workgroup b: ONE 16-byte scalar load at the head of a tile kernel instead of the
+// chain order[b] -> offsets[tile], offsets[tile + 1] (two dependent trips to memory before the first particle is requested)
+__global__ __launch_bounds__(256)
+void k_tile_launch_info (const int* offsets, int ntiles, int4* launch)
+{
+    const int b = blockIdx.x*blockDim.x + threadIdx.x;
+    if (b >= ntiles) return;
+    const int t = offsets[ntiles + 2 + b];
+    launch[b] = make_int4(t, offsets[t], offsets[t + 1], 0);
+}
 
 __global__ __launch_bounds__(256)
 void k_permute (hps_plasma src, hps_plasma dst, const unsigned int* perm)
@@ -150,9 +160,10 @@ int tiling_create (int nx, int ny, int ts, long capacity, Tiling** out)
     if (const char* e = std::getenv("HPS_CELL_BLOCK_W")) { const int v = std::atoi(e); if (v == 4 || v == 8 || v == 16 || v == 32) T->g.bw = v; }
     if (T->g.bw > ts) T->g.bw = ts;
     T->capacity = capacity;
-    HPS_HIP_CHECK(hipMalloc(&T->offsets, (2*T->g.ntiles + 2)*sizeof(int)));
-    HPS_HIP_CHECK(hipMemset(T->offsets, 0, (2*T->g.ntiles + 2)*sizeof(int)));
+    HPS_HIP_CHECK(hipMalloc(&T->offsets, (tile_launch_offset(T->g.ntiles) + 4*T->g.ntiles)*sizeof(int)));
+    HPS_HIP_CHECK(hipMemset(T->offsets, 0, (tile_launch_offset(T->g.ntiles) + 4*T->g.ntiles)*sizeof(int)));
     hipLaunchKernelGGL(k_tile_order_identity, dim3(ceil_div(T->g.ntiles, 256)), dim3(256), 0, (hipStream_t)0, T->offsets + T->g.ntiles + 2, T->g.ntiles);
+    hipLaunchKernelGGL(k_tile_launch_info, dim3(ceil_div(T->g.ntiles, 256)), dim3(256), 0, (hipStream_t)0, T->offsets, T->g.ntiles, reinterpret_cast<int4*>(T->offsets + tile_launch_offset(T->g.ntiles)));
     HPS_HIP_CHECK(hipDeviceSynchronize());
     HPS_HIP_CHECK(hipMalloc(&T->okeys, 3*(size_t)T->g.ntiles*sizeof(unsigned int)));
     HPS_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, T->otemp_bytes, T->okeys, T->okeys, T->okeys, T->okeys, (size_t)T->g.ntiles, 0, 32, (hipStream_t)0));
@@ -182,7 +193,11 @@ int tiling_sort (Tiling* T, const hps_plasma& src, const hps_plasma& dst, const 
     if (src.n > T->capacity) { set_error("hps_reorder_particles: more particles than the tiling capacity"); return HPS_ERR_ARG; }
     T->g.xoff = g.xoff; T->g.yoff = g.yoff; T->g.dx_inv = 1.0/g.dx; T->g.dy_inv = 1.0/g.dy;
     const long n = src.n;
-    if (n == 0) { HPS_HIP_CHECK(hipMemsetAsync(T->offsets, 0, (T->g.ntiles + 2)*sizeof(int), st)); T->sorted_n = 0; return HPS_OK; }
+    if (n == 0) {
+        HPS_HIP_CHECK(hipMemsetAsync(T->offsets, 0, (T->g.ntiles + 2)*sizeof(int), st));
+        hipLaunchKernelGGL(k_tile_launch_info, dim3(ceil_div(T->g.ntiles, 256)), dim3(256), 0, st, T->offsets, T->g.ntiles, reinterpret_cast<int4*>(T->offsets + tile_launch_offset(T->g.ntiles)));
+        T->sorted_n = 0; return HPS_OK;
+    }
     const int ncell = T->g.ts*T->g.ts;
     const int nkeys1 = T->g.ntiles*ncell + 1;
     const dim3 gn(ceil_div(n, 256)), gn1(ceil_div(n + 1, 256)), b256(256);
@@ -201,7 +216,8 @@ int tiling_sort (Tiling* T, const hps_plasma& src, const hps_plasma& dst, const 
         unsigned int *ka = T->okeys, *kb = T->okeys + nt, *va = T->okeys + 2*nt;
         hipLaunchKernelGGL(k_tile_order_keys, dim3(ceil_div(nt, 256)), b256, 0, st, T->offsets, nt, ka, va);
         size_t ob = T->otemp_bytes;
-        HPS_HIP_CHECK(rocprim::radix_sort_pairs(T->otemp, ob, ka, kb, va, reinterpret_cast<unsigned int*>(T->offsets + nt + 2), (size_t)nt, 0, 32, st)); }
+        HPS_HIP_CHECK(rocprim::radix_sort_pairs(T->otemp, ob, ka, kb, va, reinterpret_cast<unsigned int*>(T->offsets + nt + 2), (size_t)nt, 0, 32, st));
+        hipLaunchKernelGGL(k_tile_launch_info, dim3(ceil_div(nt, 256)), b256, 0, st, T->offsets, nt, reinterpret_cast<int4*>(T->offsets + tile_launch_offset(nt))); }
     HPS_HIP_CHECK(hipGetLastError());
     T->sorted_n = n;
     return HPS_OK;

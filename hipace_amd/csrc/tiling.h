@@ -12,13 +12,17 @@ struct TileGeom { int nx, ny, ts, ntx, nty, ntiles; double xoff, yoff, dx_inv, d
 struct Tiling {
     TileGeom g{};
     long capacity = 0, sorted_n = 0;
-    int* offsets = nullptr;                       // [ntiles + 2] offsets, then [ntiles] launch order (heaviest tile first), device
+    int* offsets = nullptr;                       // [ntiles + 2] offsets, then [ntiles] launch order (heaviest tile first), then (16-byte
+                                                  // aligned, tile_launch_offset) [ntiles] int4 {tile, first, end, 0} per workgroup, device
     unsigned int *okeys = nullptr; void* otemp = nullptr; size_t otemp_bytes = 0;      // scratch of the launch-order sort
     unsigned int *keys_a = nullptr, *keys_b = nullptr, *idx_a = nullptr, *idx_b = nullptr;
     void* temp = nullptr; size_t temp_bytes = 0; int key_bits = 0, key2_bits = 0;
     int* cell_first = nullptr;                    // [ntiles*ts*ts + 2] run starts of the cell keys
     ~Tiling ();
 };
+
+// int index of the per-workgroup launch records inside Tiling::offsets
+__host__ __device__ inline int tile_launch_offset (int ntiles) { return (2*ntiles + 2 + 3) & ~3; }
 
 int tiling_create (int nx, int ny, int ts, long capacity, Tiling** out);
 int tiling_sort (Tiling* T, const hps_plasma& src, const hps_plasma& dst, const hps_geom& g, hipStream_t st);
