@@ -37,11 +37,14 @@ struct CellBox { int ilo, ihi, jlo, jhi; };     // padded-array cell range, incl
 
 // zero the components of `full` everywhere and those of `boxed` inside the box
 __global__ __launch_bounds__(256)
-void k_zero_comps (double* p, long ns, long plane, int js, CompList full, CompList boxed, CellBox bb)
+void k_zero_comps (double* p, long ns, long plane, int js, CompList full, CompList boxed, CellBox bb, CompList from_ion = CompList{0, {}}, int c_ion = -1)
 {
     const long s = (long)blockIdx.x*blockDim.x + threadIdx.x;
     if (s >= plane) return;
     for (int k = 0; k < full.n; ++k) p[full.c[k]*ns + s] = 0.0;
+    // AddRhoIons (fields/Fields.cpp:606-615) ahead of the deposition instead of behind it: the charge planes start from the
+    // neutralising background and the plasma is added on top (one pass over them less per slice)
+    if (c_ion >= 0) { const double ion = p[c_ion*ns + s]; for (int k = 0; k < from_ion.n; ++k) p[from_ion.c[k]*ns + s] = ion; }
     const int j = (int)(s / js), i = (int)(s - (long)j*js);
     if (i >= bb.ilo && i <= bb.ihi && j >= bb.jlo && j <= bb.jhi)
         for (int k = 0; k < boxed.n; ++k) p[boxed.c[k]*ns + s] = 0.0;
@@ -79,7 +82,7 @@ void k_shift_slices (double* p, long ns, long plane, int js, CellBox bb)
 // the fused push + deposition (k_advance_deposit_tiled) needs done before it deposits into the next slice's jx jy chi
 // rhomjz [rho].  Inside the beam's box also jz_beam and the Next beam currents are cleared.
 __global__ __launch_bounds__(256)
-void k_shift_zero (double* p, long ns, long plane, int js, CellBox bb, int c_rho)
+void k_shift_zero (double* p, long ns, long plane, int js, CellBox bb, int c_rho, int c_ion = -1)
 {
     const long s = (long)blockIdx.x*blockDim.x + threadIdx.x;
     if (s >= plane) return;
@@ -93,8 +96,9 @@ void k_shift_zero (double* p, long ns, long plane, int js, CellBox bb, int c_rho
         p[HPS_C_N_JXB*ns + s] = 0.0; p[HPS_C_N_JYB*ns + s] = 0.0; p[HPS_C_JZB*ns + s] = 0.0;
     }
     p[HPS_C_JX*ns + s] = njx; p[HPS_C_JY*ns + s] = njy;
-    p[HPS_C_CHI*ns + s] = 0.0; p[HPS_C_RHOMJZ*ns + s] = 0.0;
-    if (c_rho >= 0) p[c_rho*ns + s] = 0.0;
+    const double ion = c_ion >= 0 ? p[c_ion*ns + s] : 0.0;      // AddRhoIons ahead of the deposition (see k_zero_comps)
+    p[HPS_C_CHI*ns + s] = 0.0; p[HPS_C_RHOMJZ*ns + s] = ion;
+    if (c_rho >= 0) p[c_rho*ns + s] = ion;
 }
 
 // AddRhoIons (fields/Fields.cpp:606-615) fused with the Psi source  -rhomjz/ep0  (:887-888)
@@ -123,10 +127,16 @@ void k_rhs_all (SlabView f, int c_rhomjz, int c_ion, int c_rho, int c_jx, int c_
     const int j = blockIdx.y - f.ng;
     if (i >= f.nx + f.ng) return;
     const long o = f.off(i, j);
-    const double ion = f.p[c_ion*f.ns + o];
-    const double r = f.p[c_rhomjz*f.ns + o] + ion;
-    f.p[c_rhomjz*f.ns + o] = r;
-    if (c_rho >= 0) f.p[c_rho*f.ns + o] += ion;
+    double r;
+    if (c_ion >= 0) {
+        const double ion = f.p[c_ion*f.ns + o];
+        r = f.p[c_rhomjz*f.ns + o] + ion;
+        f.p[c_rhomjz*f.ns + o] = r;
+        if (c_rho >= 0) f.p[c_rho*f.ns + o] += ion;
+    } else {      // the background is in already (k_zero_comps / k_shift_zero): valid cells only
+        if (!(i >= 0 && i < f.nx && j >= 0 && j < f.ny)) return;
+        r = f.p[c_rhomjz*f.ns + o];
+    }
     if (i >= 0 && i < f.nx && j >= 0 && j < f.ny) {
         const long so = (long)j*f.nx + i;
         const double* X = f.p + c_jx*f.ns + o;
@@ -1274,7 +1284,7 @@ int Engine::solve_slice_begin (int islice)
     bool zeroed = false;
     if (shift_pending) {
         shift_pending = false;
-        if (!ahead) { hipLaunchKernelGGL(k_shift_zero, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, bb, d.deposit_rho ? (int)HPS_C_RHO : -1); zeroed = true; }
+        if (!ahead) { hipLaunchKernelGGL(k_shift_zero, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, bb, d.deposit_rho ? (int)HPS_C_RHO : -1, (int)HPS_C_ION_RHOMJZ); zeroed = true; }
         else hipLaunchKernelGGL(k_shift_slices, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, bb);
     }
     if (!ahead && !zeroed)
@@ -1285,7 +1295,9 @@ int Engine::solve_slice_begin (int islice)
         for (int c : {HPS_C_CHI, HPS_C_RHOMJZ}) z.c[z.n++] = c;
         if (d.deposit_rho) z.c[z.n++] = HPS_C_RHO;
         for (int c : {HPS_C_JZB, HPS_C_N_JXB, HPS_C_N_JYB}) zb.c[zb.n++] = c;
-        hipLaunchKernelGGL(k_zero_comps, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, z, zb, bb); }
+        CompList fi{0, {}};
+        fi.c[fi.n++] = HPS_C_RHOMJZ; if (d.deposit_rho) fi.c[fi.n++] = HPS_C_RHO;
+        hipLaunchKernelGGL(k_zero_comps, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, z, zb, bb, fi, (int)HPS_C_ION_RHOMJZ); }
     if (c_aabs >= 0) {
         // UpdateLaserAabs (Hipace.cpp:603)
         if ((e = laser_update_aabs(*this, islice, diagnostics ? d_laser_sum : nullptr))) return e;
@@ -1331,7 +1343,7 @@ int Engine::solve_slice_begin (int islice)
     // AddRhoIons + Psi, Ez, Bz solves + -grad Psi (fields/Fields.cpp:840-957)
     {   const double fa = 1.0/(gm.ep0*gm.c);
         hipLaunchKernelGGL(k_rhs_all, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_RHOMJZ,
-                           HPS_C_ION_RHOMJZ, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_JX, HPS_C_JY, 1.0/gm.ep0,
+                           -1 /* AddRhoIons: done by the slice's zeroing pass */, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_JX, HPS_C_JY, 1.0/gm.ep0,
                            fa*0.5*(1.0/gm.dx), fa*0.5*(1.0/gm.dy), gm.mu0*0.5*(1.0/gm.dy), -gm.mu0*0.5*(1.0/gm.dx),
                            staging, (long)d.nx*d.ny);
         const int comps[3] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BZ};
@@ -1444,7 +1456,7 @@ int Engine::solve_slice_finish (int islice)
         // push of this slice and deposition of the next one in one pass over the sheet (static beam, no laser, one
         // plasma species, the whole sheet inside the tile-sorted body)
         if (fuse) {
-            hipLaunchKernelGGL(k_shift_zero, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, bb, d.deposit_rho ? (int)HPS_C_RHO : -1);
+            hipLaunchKernelGGL(k_shift_zero, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, bb, d.deposit_rho ? (int)HPS_C_RHO : -1, (int)HPS_C_ION_RHOMJZ);
             const int dep[6] = {HPS_C_JX, HPS_C_JY, -1, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_CHI, HPS_C_RHOMJZ};
             if ((e = advance_deposit_tiled(slab, pl, gm, comp, dep, d.plasma_charge, d.plasma_mass, d.order, d.n_subcycles, d.max_qsa, d_nqsa, tiling, d_nfallback, st))) return e;
             ahead_for = islice - 1;
