@@ -6,6 +6,7 @@
 #include <vector>
 #include "tiling.h"
 #include "particle_math.h"
+#include "poisson_src.h"
 
 void mg_rider (void* mg_handle, int** dev_words, const int** host_words);     // multigrid.hip
 namespace hps {
@@ -139,6 +140,7 @@ struct Engine {
     int pending_slice = -1; bool pend_fuse = false, pend_gated = false;
     bool lazy_shift = true, shift_pending = false;      // ShiftSlices deferred to the next slice's InitializeSlices pass (HPS_LAZY_SHIFT=0: off)
     void flush_shift ();
+    bool fuse_sources = true;       // the Poisson sources formed inside the first transform pass (HPS_FUSE_SOURCES=0: k_rhs_all + staging planes)
     int run_step ();
 };
 

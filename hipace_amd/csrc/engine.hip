@@ -518,6 +518,7 @@ int Engine::create (const hps_deck& deck, int device)
     pc = (d.bxby_solver != 0);
     if (const char* v = std::getenv("HPS_GATED_PUSH")) gate_push = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_LAZY_SHIFT")) lazy_shift = std::atoi(v) != 0;
+    if (const char* v = std::getenv("HPS_FUSE_SOURCES")) fuse_sources = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_SORT_FALLBACK_DIV")) { const long q = std::atol(v); if (q >= 1) fallback_div = q; }
     HPS_REQUIRE(!(d.beam_spin_tracking && d.dt == 0.0), "hps_engine_create: spin tracking needs a moving beam (hipace.dt != 0)");
     if (d.predcorr_tol > 0.0) pc_tol = d.predcorr_tol;
@@ -1342,12 +1343,26 @@ int Engine::solve_slice_begin (int islice)
 
     // AddRhoIons + Psi, Ez, Bz solves + -grad Psi (fields/Fields.cpp:840-957)
     {   const double fa = 1.0/(gm.ep0*gm.c);
-        hipLaunchKernelGGL(k_rhs_all, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_RHOMJZ,
-                           -1 /* AddRhoIons: done by the slice's zeroing pass */, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_JX, HPS_C_JY, 1.0/gm.ep0,
-                           fa*0.5*(1.0/gm.dx), fa*0.5*(1.0/gm.dy), gm.mu0*0.5*(1.0/gm.dy), -gm.mu0*0.5*(1.0/gm.dx),
-                           staging, (long)d.nx*d.ny);
+        const double fez_x = fa*0.5*(1.0/gm.dx), fez_y = fa*0.5*(1.0/gm.dy), fbz_y = gm.mu0*0.5*(1.0/gm.dy), fbz_x = -gm.mu0*0.5*(1.0/gm.dx);
         const int comps[3] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BZ};
-        if ((e = hps_poisson_solve_batch(ps, 3, staging, slab, comps, st))) return e; }
+        if (fuse_sources && poisson_sources_fusable(ps)) {
+            // the three sources (fields/Fields.cpp:887-912) are formed by the first transform pass while it loads its rows:
+            // -rhomjz/ep0;  (d_x jx + d_y jy)/(ep0 c);  mu0 (d_y jx - d_x jy) -- centred differences, guard cells read as they are
+            const long js = slab.jstride;
+            const double* R = slab.p + (long)HPS_C_RHOMJZ*slab.nstride + g + (long)g*js;       // cell (0, 0) of the planes
+            const double* X = slab.p + (long)HPS_C_JX*slab.nstride + g + (long)g*js;
+            const double* Y = slab.p + (long)HPS_C_JY*slab.nstride + g + (long)g*js;
+            const PoissonSrc spec[3] = {
+                {1, {R, nullptr}, {nullptr, nullptr}, {-1.0/gm.ep0, 0.0}},
+                {2, {X + 1, Y + js}, {X - 1, Y - js}, {fez_x, fez_y}},
+                {2, {X + js, Y + 1}, {X - js, Y - 1}, {fbz_y, fbz_x}}};
+            if ((e = poisson_solve_batch_src(ps, 3, spec, js, slab, comps, st))) return e;
+        } else {
+            hipLaunchKernelGGL(k_rhs_all, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_RHOMJZ,
+                               -1 /* AddRhoIons: done by the slice's zeroing pass */, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_JX, HPS_C_JY, 1.0/gm.ep0,
+                               fez_x, fez_y, fbz_y, fbz_x, staging, (long)d.nx*d.ny);
+            if ((e = hps_poisson_solve_batch(ps, 3, staging, slab, comps, st))) return e;
+        } }
     // m_multi_laser.AdvanceSlice (Hipace.cpp:637): a_{n+1} of this slice from chi and the neighbouring slices
     // On the laser's own stream when there is one, forked here (chi is final; nothing else of this slice needs a_{n+1}).
     // FFT solver (0.11 ms of bandwidth-bound passes at 1024^2): enqueued at once; beside the explicit deposition or beside

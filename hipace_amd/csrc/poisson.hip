@@ -21,6 +21,7 @@
 //    Pass structure per solve: DSTx | transpose | DSTy * eigenvalues | DSTy | transpose | DSTx.
 //  * rocFFT batched C2R + separate pre/post kernels for every other N.
 #include "common.h"
+#include "poisson_src.h"
 
 #include <rocfft/rocfft.h>
 #include <vector>
@@ -65,6 +66,10 @@ struct DstArgs {
     const double* ma;               // MFMA operand tables of the two small-DFT stages (k_dst_rows_mfma)
     const double* mb;
     int rows_per_plane, nplanes;
+    // k_dst_rows_sym<.., true>: the rows of plane b are not read but formed from other planes while they are loaded,
+    // value = sum over the plane's pairs of c * (p[idx] - q[idx]) (q may be null), idx = row*src_pitch + column -- the Poisson
+    // sources of a slice straight from the slab's charge and current planes (no staging planes, no source kernel)
+    const double* sp[DST_MAXPLANES][2]; const double* sq[DST_MAXPLANES][2]; double sc[DST_MAXPLANES][2]; int npairs[DST_MAXPLANES];
     long long* dbg;                 // optional: shader-clock stamps of workgroup 0 at the phase boundaries
 };
 #ifdef HPS_POISSON_STAMPS
@@ -117,6 +122,44 @@ __device__ __forceinline__ void load_row_pairs (lds_double* cbuf, const DstArgs&
         for (int m = 0; m < NJ; ++m) {
             const int j = tid + NT*m;
             if (j < n) stc(cbuf, t*N + j, oka[t] ? va[t][m] : 0.0, okb[t] ? vb[t][m] : 0.0);
+        }
+    }
+}
+
+// the same with the rows formed from other planes while they are loaded (DstArgs::sp / sq / sc)
+template <int T, int N, int NT = 256>
+__device__ __forceinline__ void load_row_pairs_src (lds_double* cbuf, const DstArgs& a, int row0, int total_rows, int tid)
+{
+    constexpr int n = N - 1, NJ = (n + NT - 1)/NT;
+    double v[T][2][NJ];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = min(row0 + 2*t + h, total_rows - 1);
+            const int pl = r / a.rows_per_plane;
+            const long ro = (long)(r - pl*a.rows_per_plane)*a.src_pitch;
+            const int np = a.npairs[pl];
+            const double* p0 = a.sp[pl][0] + ro; const double* q0 = a.sq[pl][0] ? a.sq[pl][0] + ro : nullptr;
+            const double c0 = a.sc[pl][0];
+            if (np == 1) {
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { const int j = min(tid + NT*m, n - 1); v[t][h][m] = q0 ? c0*(p0[j] - q0[j]) : c0*p0[j]; }
+            } else {
+                const double* p1 = a.sp[pl][1] + ro; const double* q1 = a.sq[pl][1] + ro;
+                const double c1 = a.sc[pl][1];
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { const int j = min(tid + NT*m, n - 1); v[t][h][m] = c0*(p0[j] - q0[j]) + c1*(p1[j] - q1[j]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const bool oka = row0 + 2*t < total_rows, okb = row0 + 2*t + 1 < total_rows;
+#pragma unroll
+        for (int m = 0; m < NJ; ++m) {
+            const int j = tid + NT*m;
+            if (j < n) stc(cbuf, t*N + j, oka ? v[t][0][m] : 0.0, okb ? v[t][1][m] : 0.0);
         }
     }
 }
@@ -396,7 +439,7 @@ __device__ __forceinline__ void sym_stage (lds_double* cbuf, const double2* __re
     __syncthreads();
 }
 
-template <int N1, int N2>
+template <int N1, int N2, bool SRC = false>
 __global__ __launch_bounds__(DSTS_NT)
 void k_dst_rows_sym (DstArgs a)
 {
@@ -413,7 +456,8 @@ void k_dst_rows_sym (DstArgs a)
 
     HPS_STAMP_DECL;
     HPS_STAMP(0);
-    load_row_pairs<T, N, NT>(cbuf, a, row0, total_rows, tid);
+    if (SRC) load_row_pairs_src<T, N, NT>(cbuf, a, row0, total_rows, tid);
+    else load_row_pairs<T, N, NT>(cbuf, a, row0, total_rows, tid);
     __syncthreads();
     HPS_STAMP(1);
     {
@@ -785,10 +829,10 @@ void k_dense_product (GemmArgs g)
 
 typedef void (*dst_kernel_t)(DstArgs);
 typedef void (*dst_cols_kernel_t)(DstArgs, int);
-struct DstImpl { int N, N1, N2; dst_kernel_t kernel; bool sym; int T; int nt; dst_cols_kernel_t cols; dst_kernel_t mfma; };
+struct DstImpl { int N, N1, N2; dst_kernel_t kernel; bool sym; int T; int nt; dst_cols_kernel_t cols; dst_kernel_t mfma; dst_kernel_t src; };
 
-#define HPS_DST_IMPL(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows<N1, N2>, false, DST_T, 256, nullptr, nullptr}
-#define HPS_DST_SYM(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows_sym<N1, N2>, true, DSTS_T, DSTS_NT, k_dst_cols_sym<N1, N2>, k_dst_rows_mfma<N1, N2>}
+#define HPS_DST_IMPL(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows<N1, N2>, false, DST_T, 256, nullptr, nullptr, nullptr}
+#define HPS_DST_SYM(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows_sym<N1, N2>, true, DSTS_T, DSTS_NT, k_dst_cols_sym<N1, N2>, k_dst_rows_mfma<N1, N2>, k_dst_rows_sym<N1, N2, true>}
 static const DstImpl g_dst_impls[] = {
     HPS_DST_SYM(25, 41),    // nx = 1024
     HPS_DST_SYM(19, 27),    // 512
@@ -900,6 +944,7 @@ struct Poisson {
     int nx = 0, ny = 0;
     // own-transform back-end
     dst_kernel_t kx = nullptr, ky = nullptr;
+    dst_kernel_t kx_src = nullptr;      // the x pass with its rows formed from other planes (sym kernels only)
     dst_cols_kernel_t kcols = nullptr; size_t lds_cols = 0;     // y direction on column blocks (symmetric factorisations)
     double2 *tab_x = nullptr, *tab_y = nullptr;        // each: [fa | fb | tw] concatenated
     double *mtab_x = nullptr, *mtab_y = nullptr;       // MFMA operand tables [stage A | stage B] (k_dst_rows_mfma)
@@ -1000,7 +1045,7 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
     const DstImpl* ix = allow_own ? find_dst_impl(Nx) : nullptr;
     const DstImpl* iy = allow_own ? find_dst_impl(Ny) : nullptr;
     if (ix && iy) {
-        P->kx = ix->kernel; P->ky = iy->kernel;
+        P->kx = ix->kernel; P->ky = iy->kernel; P->kx_src = ix->src;
         int e;
         size_t nax, nbx, nay, nby;
         if ((e = upload_tables(ix->N1, ix->N2, ix->sym, &P->tab_x, &nax, &nbx)) ||
@@ -1016,7 +1061,7 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
             size_t fx = 0, fy = 0;
             if ((e = upload_mfma_tables(ix->N1, ix->N2, &P->mtab_x, &fx)) || (e = upload_mfma_tables(iy->N1, iy->N2, &P->mtab_y, &fy))) { delete P; return e; }
             P->ma_x = P->mtab_x; P->mb_x = P->mtab_x + fx; P->ma_y = P->mtab_y; P->mb_y = P->mtab_y + fy;
-            P->kx = ix->mfma; P->ky = iy->mfma;
+            P->kx = ix->mfma; P->ky = iy->mfma; P->kx_src = nullptr;
         }
         if (iy->cols && getenv("HPS_POISSON_COLS")) {      // measured no faster than rows + transposes (0.143 ms both): off by default
             P->kcols = iy->cols;
@@ -1026,6 +1071,7 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
         P->lds_x = ((size_t)ix->T*Nx + nax + nbx)*sizeof(double2);
         P->lds_y = ((size_t)iy->T*Ny + nay + nby)*sizeof(double2);
         if (P->lds_x > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->kx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_x));
+        if (P->kx_src && P->lds_x > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->kx_src, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_x));
         if (P->lds_y > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->ky, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_y));
         HPS_HIP_CHECK(hipMalloc(&P->buf_a, (size_t)DST_MAXPLANES*nx*ny*sizeof(double)));
         HPS_HIP_CHECK(hipMalloc(&P->buf_b, (size_t)DST_MAXPLANES*nx*ny*sizeof(double)));
@@ -1129,8 +1175,35 @@ static int solve_rocfft (Poisson* P, const double* src, long src_pitch, double* 
 
 // nb independent solves in one batch: src[b] = nx*ny source with row pitch src_pitch,
 // dst[b] = pointer to cell (0,0) of the target plane with row pitch dst_pitch
+static double* slab_cell00 (const hps_slab& s, int comp)
+{
+    return s.p + (long)comp*s.nstride + s.ng + (long)s.ng*s.jstride;
+}
+
+// `spec` (optional, own sym transform without the column kernel only: poisson_sources_fusable): the sources are not read from
+// `src` but formed from other planes while the first pass loads its rows (PoissonSrc: value = sum of c*(p - q) pairs)
+static int poisson_solve_batch_impl (Poisson* P, int nb, const double* const* src, long src_pitch, double* const* dst, long dst_pitch,
+                                     const PoissonSrc* spec, hipStream_t st);
 int poisson_solve_batch (Poisson* P, int nb, const double* const* src, long src_pitch, double* const* dst, long dst_pitch,
                          hipStream_t st)
+{
+    return poisson_solve_batch_impl(P, nb, src, src_pitch, dst, dst_pitch, nullptr, st);
+}
+bool poisson_sources_fusable (void* handle)
+{
+    Poisson* P = static_cast<Poisson*>(handle);
+    return P->own() && P->kx_src && !P->kcols && !P->dense();
+}
+int poisson_solve_batch_src (void* handle, int nb, const PoissonSrc* spec, long src_pitch, hps_slab dst, const int* dst_comps, hipStream_t st)
+{
+    Poisson* P = static_cast<Poisson*>(handle);
+    HPS_REQUIRE(poisson_sources_fusable(P) && nb >= 1 && nb <= DST_MAXPLANES, "poisson_solve_batch_src: not available for this solver");
+    double* d[DST_MAXPLANES];
+    for (int b = 0; b < nb; ++b) d[b] = slab_cell00(dst, dst_comps[b]);
+    return poisson_solve_batch_impl(P, nb, nullptr, src_pitch, d, dst.jstride, spec, st);
+}
+static int poisson_solve_batch_impl (Poisson* P, int nb, const double* const* src, long src_pitch, double* const* dst, long dst_pitch,
+                                     const PoissonSrc* spec, hipStream_t st)
 {
     if (nb > DST_MAXPLANES) { set_error("poisson_solve_batch: too many planes"); return HPS_ERR_ARG; }
     if (P->dense()) {
@@ -1168,10 +1241,18 @@ int poisson_solve_batch (Poisson* P, int nb, const double* const* src, long src_
     DstArgs a{};
     a.dbg = P->dbg;
     // 1: DST along x of the sources -> A
-    for (int b = 0; b < nb; ++b) { a.src[b] = src[b]; a.dst[b] = P->buf_a + b*plane; }
+    for (int b = 0; b < nb; ++b) { a.src[b] = spec ? nullptr : src[b]; a.dst[b] = P->buf_a + b*plane; }
     a.src_pitch = src_pitch; a.dst_pitch = nx; a.scale = nullptr; a.fa = P->fa_x; a.fb = P->fb_x; a.tw = P->tw_x; a.isin4 = P->isin_x;
     a.ma = P->ma_x; a.mb = P->mb_x;
     a.rows_per_plane = ny; a.nplanes = nb;
+    if (spec) {
+        for (int b = 0; b < nb; ++b) {
+            a.npairs[b] = spec[b].npairs;
+            for (int k = 0; k < 2; ++k) { a.sp[b][k] = spec[b].p[k]; a.sq[b][k] = spec[b].q[k]; a.sc[b][k] = spec[b].c[k]; }
+        }
+        hipLaunchKernelGGL(P->kx_src, rows_grid(ny*nb, P->tx), dim3(P->ntx), P->lds_x, st, a);
+        for (int b = 0; b < nb; ++b) a.npairs[b] = 0;
+    } else
     hipLaunchKernelGGL(P->kx, rows_grid(ny*nb, P->tx), dim3(P->ntx), P->lds_x, st, a);
     if (P->kcols) {
         // 2-5: DST along y, inverse eigenvalues, DST along y -- in place on column blocks of A
@@ -1221,10 +1302,6 @@ extern "C" int hps_poisson_create (int nx, int ny, double dx, double dy, void** 
     return HPS_OK;
 }
 
-static double* slab_cell00 (const hps_slab& s, int comp)
-{
-    return s.p + (long)comp*s.nstride + s.ng + (long)s.ng*s.jstride;
-}
 
 extern "C" int hps_poisson_solve (void* handle, const double* staging, hps_slab dst, int dst_comp, hps_stream stream)
 {
