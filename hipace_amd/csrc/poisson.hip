@@ -189,10 +189,11 @@ __device__ __forceinline__ void pre_to_regs (const lds_double* cbuf, int tid, do
 
 // r_a = Re X, r_b = Im X with X[q] stored at [q % N1][q / N1]; T_k from r_{k+1}, r_{N-1-k}; store.  The factors a thread
 // needs from global memory (1/(4 sin), the optional scale rows) are requested ahead of the loop over the row pairs.
-template <int T, int N1, int N2, int NT = 256>
+template <int T, int N1, int N2, int NT = 256, bool NOSCALE = false>
 __device__ __forceinline__ void post_store (const lds_double* cbuf, const DstArgs& a, int row0, int total_rows, int tid)
 {
     constexpr int N = N1*N2, n = N - 1, NK = (n + NT - 1)/NT;
+    const double* scale = NOSCALE ? nullptr : a.scale;
     double is[NK], sca[T][NK], scb[T][NK];
 #pragma unroll
     for (int m = 0; m < NK; ++m) is[m] = a.isin4[min(tid + NT*m, n - 1)];
@@ -203,8 +204,8 @@ __device__ __forceinline__ void post_store (const lds_double* cbuf, const DstArg
 #pragma unroll
         for (int m = 0; m < NK; ++m) {
             const int k = min(tid + NT*m, n - 1);
-            sca[t][m] = a.scale ? a.scale[(long)ja*n + k] : 1.0;
-            scb[t][m] = a.scale ? a.scale[(long)jb*n + k] : 1.0;
+            sca[t][m] = scale ? scale[(long)ja*n + k] : 1.0;
+            scb[t][m] = scale ? scale[(long)jb*n + k] : 1.0;
         }
     }
 #pragma unroll
@@ -224,7 +225,7 @@ __device__ __forceinline__ void post_store (const lds_double* cbuf, const DstArg
                 const double2 x2 = ldc(cbuf, t*N + (q2 % N1)*N2 + q2/N1);
                 double ta = 0.5*(x2.x - x1.x) + (x1.x + x2.x)*is[m];
                 double tb = 0.5*(x2.y - x1.y) + (x1.y + x2.y)*is[m];
-                if (a.scale) { ta *= sca[t][m]; tb *= scb[t][m]; }
+                if (scale) { ta *= sca[t][m]; tb *= scb[t][m]; }
                 da[k] = ta;
                 if (db) db[k] = tb;
             }
@@ -439,12 +440,13 @@ __device__ __forceinline__ void sym_stage (lds_double* cbuf, const double2* __re
     __syncthreads();
 }
 
-template <int N1, int N2, bool SRC = false>
-__global__ __launch_bounds__(DSTS_NT)
-void k_dst_rows_sym (DstArgs a)
+template <int N1, int N2, bool SRC = false, bool TWICE = false>
+__global__ __launch_bounds__(DSTS_NT) void k_dst_rows_sym (DstArgs a)
 {
+    // TWICE: the two y passes of a solve in one kernel -- transform the rows, multiply by a.scale (the inverse eigenvalues),
+    // transform them again, all in LDS: one launch, one write and one read of the planes less than two passes
     static_assert(N1 % 2 == 1 && N2 % 2 == 1, "symmetric kernel needs odd factors");
-    constexpr int N = N1*N2, T = DSTS_T, NT = DSTS_NT;
+    constexpr int N = N1*N2, n = N - 1, T = DSTS_T, NT = DSTS_NT;
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_double* cbuf = (lds_double*)lds_raw;          // [T][N] complex working set
     const double2* __restrict__ csa = a.fa;           // [H1][H1] (cos, sin)(2 pi n k / N1)
@@ -460,32 +462,65 @@ void k_dst_rows_sym (DstArgs a)
     else load_row_pairs<T, N, NT>(cbuf, a, row0, total_rows, tid);
     __syncthreads();
     HPS_STAMP(1);
-    {
-        constexpr int PP = (N/2 + NT)/NT;
-        double wr[T][PP], wi[T][PP], vr[T][PP], vi[T][PP];
-        pre_to_regs<T, N, PP, NT>(cbuf, tid, wr, wi, vr, vi);
-        __syncthreads();
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
+    for (int pass = 0; pass < (TWICE ? 2 : 1); ++pass) {
+        {
+            constexpr int PP = (N/2 + NT)/NT;
+            double wr[T][PP], wi[T][PP], vr[T][PP], vi[T][PP];
+            pre_to_regs<T, N, PP, NT>(cbuf, tid, wr, wi, vr, vi);
+            __syncthreads();
 #pragma unroll
-            for (int m = 0; m < PP; ++m) {
-                const int p = tid + NT*m;
-                if (p <= N/2) {
-                    stc(cbuf, t*N + p, wr[t][m], wi[t][m]);
-                    if (p > 0) stc(cbuf, t*N + N - p, vr[t][m], vi[t][m]);
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int m = 0; m < PP; ++m) {
+                    const int p = tid + NT*m;
+                    if (p <= N/2) {
+                        stc(cbuf, t*N + p, wr[t][m], wi[t][m]);
+                        if (p > 0) stc(cbuf, t*N + N - p, vr[t][m], vi[t][m]);
+                    }
                 }
             }
         }
+        __syncthreads();
+        HPS_STAMP(2);
+        // stage A: DFT-N1 over n1 (stride N2) of column n2, twiddle w_N^(n2 k1), result at [k1][n2]
+        sym_stage<N1, N2, N2, N2, 1, true, T, NT/64>(cbuf, csa, a.tw, wave, lane);
+        HPS_STAMP(3);
+        // stage B: DFT-N2 over n2 (stride 1) of row k1, result X[k1 + N1 k2] at [k1][k2]
+        sym_stage<N2, 1, 1, N1, N2, false, T, NT/64>(cbuf, csb, nullptr, wave, lane);
+        HPS_STAMP(4);
+        if (TWICE && pass == 0) {
+            // T_k of both rows of every pair (times the scale) -> registers -> back to [t][k] as the next pass's input
+            constexpr int NK = (n + NT - 1)/NT;
+            double ta[T][NK], tb[T][NK];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int ra = min(row0 + 2*t, total_rows - 1), rb = min(row0 + 2*t + 1, total_rows - 1);
+                const int ja = ra - (ra / a.rows_per_plane)*a.rows_per_plane, jb = rb - (rb / a.rows_per_plane)*a.rows_per_plane;
+#pragma unroll
+                for (int m = 0; m < NK; ++m) {
+                    const int k = min(tid + NT*m, n - 1);
+                    const int q1 = k + 1, q2 = N - 1 - k;
+                    const double2 x1 = ldc(cbuf, t*N + (q1 % N1)*N2 + q1/N1);
+                    const double2 x2 = ldc(cbuf, t*N + (q2 % N1)*N2 + q2/N1);
+                    const double is = a.isin4[k];
+                    ta[t][m] = (0.5*(x2.x - x1.x) + (x1.x + x2.x)*is)*a.scale[(long)ja*n + k];
+                    tb[t][m] = (0.5*(x2.y - x1.y) + (x1.y + x2.y)*is)*a.scale[(long)jb*n + k];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int m = 0; m < NK; ++m) {
+                    const int k = tid + NT*m;
+                    if (k < n) stc(cbuf, t*N + k, ta[t][m], tb[t][m]);
+                }
+            }
+            __syncthreads();
+        }
     }
-    __syncthreads();
-    HPS_STAMP(2);
-    // stage A: DFT-N1 over n1 (stride N2) of column n2, twiddle w_N^(n2 k1), result at [k1][n2]
-    sym_stage<N1, N2, N2, N2, 1, true, T, NT/64>(cbuf, csa, a.tw, wave, lane);
-    HPS_STAMP(3);
-    // stage B: DFT-N2 over n2 (stride 1) of row k1, result X[k1 + N1 k2] at [k1][k2]
-    sym_stage<N2, 1, 1, N1, N2, false, T, NT/64>(cbuf, csb, nullptr, wave, lane);
-    HPS_STAMP(4);
-    post_store<T, N1, N2, NT>(cbuf, a, row0, total_rows, tid);
+    post_store<T, N1, N2, NT, TWICE>(cbuf, a, row0, total_rows, tid);
     HPS_STAMP(5);
     HPS_STAMP_FLUSH;
 }
@@ -829,10 +864,10 @@ void k_dense_product (GemmArgs g)
 
 typedef void (*dst_kernel_t)(DstArgs);
 typedef void (*dst_cols_kernel_t)(DstArgs, int);
-struct DstImpl { int N, N1, N2; dst_kernel_t kernel; bool sym; int T; int nt; dst_cols_kernel_t cols; dst_kernel_t mfma; dst_kernel_t src; };
+struct DstImpl { int N, N1, N2; dst_kernel_t kernel; bool sym; int T; int nt; dst_cols_kernel_t cols; dst_kernel_t mfma; dst_kernel_t src; dst_kernel_t twice; };
 
-#define HPS_DST_IMPL(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows<N1, N2>, false, DST_T, 256, nullptr, nullptr, nullptr}
-#define HPS_DST_SYM(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows_sym<N1, N2>, true, DSTS_T, DSTS_NT, k_dst_cols_sym<N1, N2>, k_dst_rows_mfma<N1, N2>, k_dst_rows_sym<N1, N2, true>}
+#define HPS_DST_IMPL(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows<N1, N2>, false, DST_T, 256, nullptr, nullptr, nullptr, nullptr}
+#define HPS_DST_SYM(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows_sym<N1, N2>, true, DSTS_T, DSTS_NT, k_dst_cols_sym<N1, N2>, k_dst_rows_mfma<N1, N2>, k_dst_rows_sym<N1, N2, true>, k_dst_rows_sym<N1, N2, false, true>}
 static const DstImpl g_dst_impls[] = {
     HPS_DST_SYM(25, 41),    // nx = 1024
     HPS_DST_SYM(19, 27),    // 512
@@ -945,6 +980,7 @@ struct Poisson {
     // own-transform back-end
     dst_kernel_t kx = nullptr, ky = nullptr;
     dst_kernel_t kx_src = nullptr;      // the x pass with its rows formed from other planes (sym kernels only)
+    dst_kernel_t ky2 = nullptr;         // both y passes (transform, inverse eigenvalues, transform) in one launch (sym kernels; HPS_POISSON_Y2=0: off)
     dst_cols_kernel_t kcols = nullptr; size_t lds_cols = 0;     // y direction on column blocks (symmetric factorisations)
     double2 *tab_x = nullptr, *tab_y = nullptr;        // each: [fa | fb | tw] concatenated
     double *mtab_x = nullptr, *mtab_y = nullptr;       // MFMA operand tables [stage A | stage B] (k_dst_rows_mfma)
@@ -1046,6 +1082,7 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
     const DstImpl* iy = allow_own ? find_dst_impl(Ny) : nullptr;
     if (ix && iy) {
         P->kx = ix->kernel; P->ky = iy->kernel; P->kx_src = ix->src;
+        {   const char* v = getenv("HPS_POISSON_Y2"); P->ky2 = (v && atoi(v) == 0) ? nullptr : iy->twice; }
         int e;
         size_t nax, nbx, nay, nby;
         if ((e = upload_tables(ix->N1, ix->N2, ix->sym, &P->tab_x, &nax, &nbx)) ||
@@ -1061,7 +1098,7 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
             size_t fx = 0, fy = 0;
             if ((e = upload_mfma_tables(ix->N1, ix->N2, &P->mtab_x, &fx)) || (e = upload_mfma_tables(iy->N1, iy->N2, &P->mtab_y, &fy))) { delete P; return e; }
             P->ma_x = P->mtab_x; P->mb_x = P->mtab_x + fx; P->ma_y = P->mtab_y; P->mb_y = P->mtab_y + fy;
-            P->kx = ix->mfma; P->ky = iy->mfma; P->kx_src = nullptr;
+            P->kx = ix->mfma; P->ky = iy->mfma; P->kx_src = nullptr; P->ky2 = nullptr;
         }
         if (iy->cols && getenv("HPS_POISSON_COLS")) {      // measured no faster than rows + transposes (0.143 ms both): off by default
             P->kcols = iy->cols;
@@ -1073,6 +1110,7 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
         if (P->lds_x > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->kx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_x));
         if (P->kx_src && P->lds_x > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->kx_src, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_x));
         if (P->lds_y > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->ky, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_y));
+        if (P->ky2 && P->lds_y > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->ky2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_y));
         HPS_HIP_CHECK(hipMalloc(&P->buf_a, (size_t)DST_MAXPLANES*nx*ny*sizeof(double)));
         HPS_HIP_CHECK(hipMalloc(&P->buf_b, (size_t)DST_MAXPLANES*nx*ny*sizeof(double)));
     } else if (allow_own && nx <= 512 && ny <= 512) {
@@ -1269,11 +1307,18 @@ static int poisson_solve_batch_impl (Poisson* P, int nb, const double* const* sr
         a.src_pitch = ny; a.dst_pitch = ny; a.scale = P->eig; a.fa = P->fa_y; a.fb = P->fb_y; a.tw = P->tw_y; a.isin4 = P->isin_y;
         a.ma = P->ma_y; a.mb = P->mb_y;
         a.rows_per_plane = nx;
+        if (P->ky2) {
+            // 3 + 4 in one launch: transform, inverse eigenvalues, transform again (in LDS) -> back into B
+            for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_b + b*plane; a.dst[b] = P->buf_b + b*plane; }
+            hipLaunchKernelGGL(P->ky2, rows_grid(nx*nb, P->ty), dim3(P->nty), P->lds_y, st, a);
+            a.scale = nullptr;
+        } else {
         hipLaunchKernelGGL(P->ky, rows_grid(nx*nb, P->ty), dim3(P->nty), P->lds_y, st, a);
         // 4: DST along y again -> B
         for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_a + b*plane; a.dst[b] = P->buf_b + b*plane; }
         a.scale = nullptr;
         hipLaunchKernelGGL(P->ky, rows_grid(nx*nb, P->ty), dim3(P->nty), P->lds_y, st, a);
+        }
         // 5: transpose back -> A[j][k]
         hipLaunchKernelGGL(k_transpose, dim3(ceil_div(ny, 32), ceil_div(nx, 32), nb), dim3(256), 0, st, P->buf_b, P->buf_a, nx, ny, plane);
     }
