@@ -713,7 +713,7 @@ void k_dst_cols_sym (DstArgs a, int ncols)
         cbuf[2*((c >> 1)*N + j) + (c & 1)] = v;
     }
     __syncthreads();
-#pragma unroll 1
+#pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         {
             constexpr int PP = (N/2 + NT)/NT;
