@@ -593,7 +593,10 @@ __device__ __forceinline__ LevBox cc_box (int nx, int ny) { return LevBox{0, 0, 
 template <bool WAVE>
 __device__ __forceinline__ void lvl_sync ()
 {
-    if (WAVE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // one wave: LDS is in order, keep the compiler in order
+    // one wave: its DS instructions reach the LDS in program order, so a read issued behind a write sees it without the
+    // wave waiting for the write to retire -- only the compiler has to be kept in order (the s_waitcnt that stood here
+    // stalled every one of the ~60 phases of the one-wave levels for the write's round trip)
+    if (WAVE) asm volatile("" ::: "memory");
     else __syncthreads();
 }
 
@@ -678,27 +681,29 @@ __device__ __forceinline__ void blk_down_sweeps (Blk& B, int nsw)
 template <bool TWO = true>
 __device__ __forceinline__ void blk_single_sweeps (Blk& B, int nsw)
 {
+    // (every neighbour outside the block is the zero ring: 0 + v == v exactly, so the sums with it are left out -- this is a
+    //  chain of 2 nsw dependent half-sweeps in one lane, every instruction of it is on the V-cycle's critical path)
 #pragma unroll
     for (int k = 0; k < 4; ++k) { B.v0[k] = 0.0; B.v1[k] = 0.0; }
     if (B.act) {
         for (int s = 0; s < nsw; s += 2) {
-            {   const double a0 = (B.r0[0] - (B.fxm[0]*(0.0 + B.v0[1]) + B.fym[0]*(0.0 + B.v0[2])))*B.ci[0];
-                const double b0 = (B.r0[3] - (B.fxm[1]*(B.v0[2] + 0.0) + B.fym[1]*(B.v0[1] + 0.0)))*B.ci[3];
+            {   const double a0 = (B.r0[0] - (B.fxm[0]*B.v0[1] + B.fym[0]*B.v0[2]))*B.ci[0];
+                const double b0 = (B.r0[3] - (B.fxm[1]*B.v0[2] + B.fym[1]*B.v0[1]))*B.ci[3];
                 if (B.ok[0]) B.v0[0] = a0;
                 if (B.ok[3]) B.v0[3] = b0;
                 if (TWO) {
-                    const double a1 = (B.r1[0] - (B.fxm[0]*(0.0 + B.v1[1]) + B.fym[0]*(0.0 + B.v1[2])))*B.ci[0];
-                    const double b1 = (B.r1[3] - (B.fxm[1]*(B.v1[2] + 0.0) + B.fym[1]*(B.v1[1] + 0.0)))*B.ci[3];
+                    const double a1 = (B.r1[0] - (B.fxm[0]*B.v1[1] + B.fym[0]*B.v1[2]))*B.ci[0];
+                    const double b1 = (B.r1[3] - (B.fxm[1]*B.v1[2] + B.fym[1]*B.v1[1]))*B.ci[3];
                     if (B.ok[0]) B.v1[0] = a1;
                     if (B.ok[3]) B.v1[3] = b1;
                 } }
-            {   const double a0 = (B.r0[1] - (B.fxm[1]*(B.v0[0] + 0.0) + B.fym[0]*(0.0 + B.v0[3])))*B.ci[1];
-                const double b0 = (B.r0[2] - (B.fxm[0]*(0.0 + B.v0[3]) + B.fym[1]*(B.v0[0] + 0.0)))*B.ci[2];
+            {   const double a0 = (B.r0[1] - (B.fxm[1]*B.v0[0] + B.fym[0]*B.v0[3]))*B.ci[1];
+                const double b0 = (B.r0[2] - (B.fxm[0]*B.v0[3] + B.fym[1]*B.v0[0]))*B.ci[2];
                 if (B.ok[1]) B.v0[1] = a0;
                 if (B.ok[2]) B.v0[2] = b0;
                 if (TWO) {
-                    const double a1 = (B.r1[1] - (B.fxm[1]*(B.v1[0] + 0.0) + B.fym[0]*(0.0 + B.v1[3])))*B.ci[1];
-                    const double b1 = (B.r1[2] - (B.fxm[0]*(0.0 + B.v1[3]) + B.fym[1]*(B.v1[0] + 0.0)))*B.ci[2];
+                    const double a1 = (B.r1[1] - (B.fxm[1]*B.v1[0] + B.fym[0]*B.v1[3]))*B.ci[1];
+                    const double b1 = (B.r1[2] - (B.fxm[0]*B.v1[3] + B.fym[1]*B.v1[0]))*B.ci[2];
                     if (B.ok[1]) B.v1[1] = a1;
                     if (B.ok[2]) B.v1[2] = b1;
                 } }
