@@ -501,7 +501,7 @@ int Engine::init_beam ()
         long mx = 0;
         for (int p = 0; p < d.nz; ++p) mx = std::max(mx, beam_off[p + 1] - beam_off[p]);
         beam_cap = std::max(2*mx, 1L);                 // particles a slice may hold in a hand-off message
-        beam_box = beam_box_init = full_box;          // a moving beam may go anywhere
+        if (nbeam > 0) beam_box = beam_box_init = full_box;          // a moving beam may go anywhere (no beam at all, e.g. a laser driver: the box stays empty)
     }
     return HPS_OK;
 }
@@ -1375,8 +1375,8 @@ int Engine::solve_slice_begin (int islice)
     if (laser_now && !laser_split) { if ((e = laser_advance_slice(*this, islice))) return e; }
     if (laser_split) { if ((e = fork_laser())) return e; }
     if (laser_split && d.laser_solver == 1) { if ((e = laser_advance_slice(*this, islice)) || (e = laser_done())) return e; }
-    if (pair) {
-        // -grad Psi and the beam part of Sx, Sy (Hipace.cpp:659-660) in one pass
+    if (pair || nbeam == 0) {
+        // -grad Psi and the beam part of Sx, Sy (Hipace.cpp:659-660) in one pass (without a beam there is no deposition between them either)
         hipLaunchKernelGGL(k_gradpsi_sxsy, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_PSI, HPS_C_EXMBY, HPS_C_EYPBX,
                            0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy), HPS_C_SX, HPS_C_SY, HPS_C_JZB, HPS_C_N_JXB, HPS_C_N_JYB, HPS_C_P_JXB, HPS_C_P_JYB,
                            gm.mu0, 2.0*gm.dx, 2.0*gm.dy, 2.0*gm.dz, bb);

@@ -427,6 +427,9 @@ template <class T> __device__ __forceinline__ void sto (T* base, unsigned o, T v
 #ifndef HPS_PUSH_WAVES_ION
 #define HPS_PUSH_WAVES_ION 2
 #endif
+#ifndef HPS_PUSH_PF_LASER
+#define HPS_PUSH_PF_LASER 1
+#endif
 template <int ORDER, int TS, bool LASER = false, bool IONIZE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IONIZE ? HPS_PUSH_WAVES_ION : HPS_PUSH_WAVES)))
 void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
@@ -461,12 +464,17 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         q.uxh = ldo(pl.ux_half, o); q.uyh = ldo(pl.uy_half, o); q.psih = ldo(pl.psi_half, o);
         return q;
     };
-#ifndef HPS_PUSH_NO_PREFETCH
     // the thread's first particle is requested ahead of the field image: its six values arrive with the image's
+    // (HPS_PUSH_PF_LASER=0: the laser variant without the prefetch -- 12 instead of 20 B of scratch per lane under the
+    // 168-register cap, and slower: config 5 946 against 968 slices/s)
+#ifndef HPS_PUSH_NO_PREFETCH
+    constexpr bool PF = HPS_PUSH_PF_LASER || !LASER;
+#else
+    constexpr bool PF = false;
+#endif
     unsigned ip = (unsigned)lrec.y + tid;
     PIn nxt{0, 0.0, 0.0, 0.0, 0.0, 1.0};
-    if (ip < pend) nxt = fetch(ip);
-#endif
+    if constexpr (PF) { if (ip < pend) nxt = fetch(ip); }
     const int cc[5] = {cPsi, cEz, cBx, cBy, cBz};
     load_region<R, R, 256, 5>(img, f, cc, 5, ox, oy, tid);
     double* aimg = img + 5*R*R;           // LASER: |a|^2 over the tile region
@@ -482,16 +490,11 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     // values of particle m + 1 are requested before particle m is worked on (14 VGPRs), and every array is addressed
     // as uniform base + one 32-bit byte offset (the file is compiled with -disable-lsr: the loop-strength-reduction
     // pass otherwise keeps a 64-bit pointer per array and iteration in VGPRs, 24 registers here).
-#ifndef HPS_PUSH_NO_PREFETCH
     for (; ip < pend; ip += 256) {
         __builtin_assume(ip < (1u << 28));
-        const PIn cur = nxt;
-        if (ip + 256 < pend) nxt = fetch(ip + 256);
-#else
-    for (unsigned ip = (unsigned)lrec.y + tid; ip < pend; ip += 256) {
-        __builtin_assume(ip < (1u << 28));
-        const PIn cur = fetch(ip);          // one batch of six loads, one trip to memory per particle
-#endif
+        PIn cur;
+        if constexpr (PF) { cur = nxt; if (ip + 256 < pend) nxt = fetch(ip + 256); }
+        else cur = fetch(ip);               // one batch of six loads, one trip to memory per particle
         const unsigned o8 = ip*8u;
         const uint64_t id = cur.id;
         if (!(id & HPS_ID_VALID)) continue;

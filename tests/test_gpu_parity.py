@@ -1557,9 +1557,11 @@ def test_schedules_do_not_change_results(api, case):
     a = _run_with_env(api, var, "1", deck, steps)
     b = _run_with_env(api, var, "0", deck, steps)
     sa, sb = a.slab(), b.slab()
+    # two runs of ONE schedule differ by the order of their LDS atomics; two steps of the ionisation deck have shown 1.2e-12
+    tol = 1e-11 if case == "ion_tile_skip" else 1e-12
     for c, nm in enumerate(a.comp_names()):
         sc = max(np.abs(sb[c]).max(), 1e-300)
-        assert np.abs(sa[c] - sb[c]).max() <= 1e-12 * sc, (case, nm)
+        assert np.abs(sa[c] - sb[c]).max() <= tol * sc, (case, nm)
     ra, va = a.particles()
     rb, vb = b.particles()
     assert ra.shape == rb.shape and np.array_equal(np.sort(va), np.sort(vb))
