@@ -58,6 +58,8 @@ struct Engine {
     int ionize_collect ();                     // ...: wait for the electron count of the slice
     int ion_field_bounds ();                   // ...: per-tile field maxima for the tile skip of the ions' push
     hps_plasma tail_of (const hps_plasma& p, long first, long n) const;
+    bool fold_tail = true;                     // the particles behind the tile-sorted body ride in the tile kernels' launches (HPS_FOLD_TAIL=0: off)
+    TailWork fold_tail_of (const hps_plasma& p, const Tiling* T, long margin, long* covered) const;
     int species_deposit (const hps_plasma& p, Tiling* T, const int comp[6], double charge, double mass, int can_ionize);
     int species_explicit (const hps_plasma& p, Tiling* T, const int cache[4], const int depos[2], double charge, double mass, int can_ionize);
     int species_advance (const hps_plasma& p, Tiling* T, const int comp[5], double charge, double mass, int temp_slice, int can_ionize);

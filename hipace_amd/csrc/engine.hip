@@ -14,13 +14,14 @@ namespace hps {
 
 int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[6], double charge,
                            double mass, int order, double max_qsa, int can_ionize, int* n_qsa, Tiling* T, int* n_fallback,
-                           hipStream_t st, int aabs_comp = -1, const int* tile_flag = nullptr);
+                           hipStream_t st, int aabs_comp = -1, const int* tile_flag = nullptr, TailWork tw = TailWork{});
 int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int cache[4], const int depos[2],
                             double charge, double mass, int order, int dtype, int can_ionize, Tiling* T, int* n_fallback,
-                            hipStream_t st, int aabs_comp = -1, const int* tile_flag = nullptr);
+                            hipStream_t st, int aabs_comp = -1, const int* tile_flag = nullptr, TailWork tw = TailWork{});
 int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], double charge,
                           double mass, int order, int temp_slice, int n_subcycles, int can_ionize, Tiling* T,
-                          int* n_fallback, hipStream_t st, int aabs_comp = -1, const IonArgs* ion = nullptr, const int* go = nullptr);
+                          int* n_fallback, hipStream_t st, int aabs_comp = -1, const IonArgs* ion = nullptr, const int* go = nullptr,
+                          TailWork tw = TailWork{});
 int advance_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], const int dep_comp[6],
                            double charge, double mass, int order, int n_subcycles, double max_qsa, int* n_qsa, Tiling* T,
                            int* n_fallback, hipStream_t st);
@@ -517,6 +518,7 @@ int Engine::create (const hps_deck& deck, int device)
     if (d.field_bc != 0) { set_error("hps_engine_create: only boundary.field = Dirichlet is built"); return HPS_ERR_UNSUPPORTED; }
     pc = (d.bxby_solver != 0);
     if (const char* v = std::getenv("HPS_GATED_PUSH")) gate_push = std::atoi(v) != 0;
+    if (const char* v = std::getenv("HPS_FOLD_TAIL")) fold_tail = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_LAZY_SHIFT")) lazy_shift = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_FUSE_SOURCES")) fuse_sources = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_SORT_FALLBACK_DIV")) { const long q = std::atol(v); if (q >= 1) fallback_div = q; }
@@ -786,30 +788,46 @@ hps_plasma Engine::tail_of (const hps_plasma& p, long first, long n) const
     return t;
 }
 
-// The three particle operators over one species: LDS-tile kernels over the tile-sorted body of the sheet, per-particle
-// kernels over what has been appended behind it since the last sort (electrons released by the species "ion").
+// The three particle operators over one species: LDS-tile kernels over the tile-sorted body of the sheet; what has been
+// appended behind it since the last sort (electrons released by the species "ion": some hundred particles) rides in the same
+// launch on up to 64 extra workgroups (TailWork; HPS_FOLD_TAIL=0: per-particle kernels of their own, 10-40 us of latency
+// chains per launch), anything beyond those goes through the per-particle kernels.
+TailWork Engine::fold_tail_of (const hps_plasma& p, const Tiling* T, long margin, long* covered) const
+{
+    TailWork tw;
+    *covered = T->sorted_n;
+    if (!fold_tail || T != tiling || T->sorted_n <= 0) return tw;
+    const long nt = p.n - T->sorted_n + margin;
+    if (nt <= 0) return tw;
+    tw.first = (int)T->sorted_n; tw.nwg = (int)std::min<long>(ceil_div(nt, 256), 64);
+    *covered = T->sorted_n + 256L*tw.nwg;
+    return tw;
+}
 int Engine::species_deposit (const hps_plasma& p, Tiling* T, const int comp[6], double charge, double mass, int can_ionize)
 {
     if (p.n == 0) return HPS_OK;
     if (!T) return hps_deposit_current_laser(slab, p, gm, comp, c_aabs, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, st);
-    if (T->sorted_n > 0) { if (int e = deposit_current_tiled(slab, p, gm, comp, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, T, d_nfallback, st, c_aabs, T == ion.tiling ? ion.d_tile_flag : nullptr)) return e; }
-    if (p.n > T->sorted_n) return hps_deposit_current_laser(slab, tail_of(p, T->sorted_n, p.n - T->sorted_n), gm, comp, c_aabs, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, st);
+    long covered; const TailWork tw = fold_tail_of(p, T, 0, &covered);
+    if (T->sorted_n > 0) { if (int e = deposit_current_tiled(slab, p, gm, comp, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, T, d_nfallback, st, c_aabs, T == ion.tiling ? ion.d_tile_flag : nullptr, tw)) return e; }
+    if (p.n > covered) return hps_deposit_current_laser(slab, tail_of(p, covered, p.n - covered), gm, comp, c_aabs, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, st);
     return HPS_OK;
 }
 int Engine::species_explicit (const hps_plasma& p, Tiling* T, const int cache[4], const int depos[2], double charge, double mass, int can_ionize)
 {
     if (p.n == 0) return HPS_OK;
     if (!T) return hps_explicit_deposit_laser(slab, p, gm, cache, c_aabs, depos, charge, mass, d.order, d.deriv_type, can_ionize, st);
-    if (T->sorted_n > 0) { if (int e = explicit_deposit_tiled(slab, p, gm, cache, depos, charge, mass, d.order, d.deriv_type, can_ionize, T, d_nfallback, st, c_aabs, T == ion.tiling ? ion.d_tile_flag : nullptr)) return e; }
-    if (p.n > T->sorted_n) return hps_explicit_deposit_laser(slab, tail_of(p, T->sorted_n, p.n - T->sorted_n), gm, cache, c_aabs, depos, charge, mass, d.order, d.deriv_type, can_ionize, st);
+    long covered; const TailWork tw = fold_tail_of(p, T, 0, &covered);
+    if (T->sorted_n > 0) { if (int e = explicit_deposit_tiled(slab, p, gm, cache, depos, charge, mass, d.order, d.deriv_type, can_ionize, T, d_nfallback, st, c_aabs, T == ion.tiling ? ion.d_tile_flag : nullptr, tw)) return e; }
+    if (p.n > covered) return hps_explicit_deposit_laser(slab, tail_of(p, covered, p.n - covered), gm, cache, c_aabs, depos, charge, mass, d.order, d.deriv_type, can_ionize, st);
     return HPS_OK;
 }
 int Engine::species_advance (const hps_plasma& p, Tiling* T, const int comp[5], double charge, double mass, int temp_slice, int can_ionize)
 {
     if (p.n == 0) return HPS_OK;
     if (!T) return hps_advance_plasma_laser(slab, p, gm, comp, c_aabs, charge, mass, d.order, temp_slice, d.n_subcycles, can_ionize, st);
-    if (T->sorted_n > 0) { if (int e = advance_plasma_tiled(slab, p, gm, comp, charge, mass, d.order, temp_slice, d.n_subcycles, can_ionize, T, d_nfallback, st, c_aabs)) return e; }
-    if (p.n > T->sorted_n) return hps_advance_plasma_laser(slab, tail_of(p, T->sorted_n, p.n - T->sorted_n), gm, comp, c_aabs, charge, mass, d.order, temp_slice, d.n_subcycles, can_ionize, st);
+    long covered; const TailWork tw = fold_tail_of(p, T, 0, &covered);
+    if (T->sorted_n > 0) { if (int e = advance_plasma_tiled(slab, p, gm, comp, charge, mass, d.order, temp_slice, d.n_subcycles, can_ionize, T, d_nfallback, st, c_aabs, nullptr, nullptr, tw)) return e; }
+    if (p.n > covered) return hps_advance_plasma_laser(slab, tail_of(p, covered, p.n - covered), gm, comp, c_aabs, charge, mass, d.order, temp_slice, d.n_subcycles, can_ionize, st);
     return HPS_OK;
 }
 
@@ -1448,7 +1466,7 @@ int Engine::solve_slice_finish (int islice)
     mark();   // b7
     // gather + push (Hipace.cpp:699-701)
     {   const int* comp = comp_push;
-        bool body_done = false;
+        bool body_done = false; long body_covered = 0;
         if (ion.n > 0) {
             // DoFieldIonization (Hipace.cpp:693-696), then the ions' own push; the host learns how many electrons the
             // slice has released while that push runs
@@ -1462,8 +1480,12 @@ int Engine::solve_slice_finish (int islice)
             }
             // the electrons' tile-sorted body does not depend on how many electrons the slice has released: push it while the
             // count travels to the host, then the tail with the new count
+            // (the tail's workgroups in that launch read the count on the device -- the ions' push is ahead of them on the
+            //  stream --, with room for 256 electrons more than the host knows of; whoever is beyond that is pushed below)
             if (tiling && tiling->sorted_n > 0 && !fuse) {
-                if ((e = advance_plasma_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st, c_aabs))) return e;
+                TailWork tw = fold_tail_of(pl, tiling, 256, &body_covered);
+                if (tw.nwg) tw.live_n = ion.d_cnt;
+                if ((e = advance_plasma_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st, c_aabs, nullptr, nullptr, tw))) return e;
                 body_done = true;
             }
             if ((e = ionize_collect())) return e;
@@ -1476,7 +1498,7 @@ int Engine::solve_slice_finish (int islice)
             if ((e = advance_deposit_tiled(slab, pl, gm, comp, dep, d.plasma_charge, d.plasma_mass, d.order, d.n_subcycles, d.max_qsa, d_nqsa, tiling, d_nfallback, st))) return e;
             ahead_for = islice - 1;
         } else if (body_done) {
-            if (pl.n > tiling->sorted_n) { if ((e = hps_advance_plasma_laser(slab, tail_of(pl, tiling->sorted_n, pl.n - tiling->sorted_n), gm, comp, c_aabs, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; }
+            if (pl.n > body_covered) { if ((e = hps_advance_plasma_laser(slab, tail_of(pl, body_covered, pl.n - body_covered), gm, comp, c_aabs, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; }
         } else {
             if ((e = species_advance(pl, tiling, comp, d.plasma_charge, d.plasma_mass, 0, 0))) return e;
         } }

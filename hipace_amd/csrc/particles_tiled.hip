@@ -88,13 +88,33 @@ __device__ __forceinline__ void laser_gather_grad_lds (const double* a, int pitc
         }
 }
 
+// What a workgroup of a tile kernel works on: {tile, first particle, end} from the launch records of the sort (heaviest
+// tile first), or -- the first tw.nwg workgroups of the grid -- 256 of the particles appended BEHIND the tile-sorted body
+// (electrons released by an ionisable species since the last sort).  Those take the kernels' path for a particle outside
+// its tile's halo (slab gathers / slab atomics): a few hundred particles whose per-particle kernels were chains of
+// latencies of 10-40 us per launch, three launches per slice, now hidden beside the tiles' work.
+// live_n: the species' particle count on the device (the push of a slice is enqueued before the host knows how many
+// electrons the slice has released).
+__device__ __forceinline__ int4 tile_record (const int* __restrict__ offsets, const TailWork& tw, long n, bool& tail)
+{
+    const int b = (int)blockIdx.x - tw.nwg;
+    tail = b < 0;
+    if (tail) {
+        const long nn = tw.live_n ? (long)*tw.live_n : n;
+        const long first = (long)tw.first + 256L*blockIdx.x;
+        return make_int4(0, (int)min(first, nn), (int)min(first + 256, nn), 0);
+    }
+    return reinterpret_cast<const int4*>(offsets + tile_launch_offset(gridDim.x - tw.nwg))[b];
+}
+constexpr int TAIL_ORIGIN = -(1 << 24);      // "tile origin" of a tail workgroup: no particle is local to it
+
 // (An XCD-chunked tile order -- contiguous tile runs per XCD -- was measured slower here: 916 vs 953 slices/s.)
 // MASK: compile-time set of deposited components (bit c = DepComps entry c), -1 = decide at run time.
 // With a compile-time set the 9x4 accumulations are straight-line ds_add_f64 with immediate offsets.
 template <int ORDER, int TS, int MASK, bool LASER = false>
 __global__ __launch_bounds__(256)
 void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx, DepComps cm,
-                      PartConsts k, int* n_qsa, int* n_fallback, const int* __restrict__ tile_flag)
+                      PartConsts k, int* n_qsa, int* n_fallback, const int* __restrict__ tile_flag, TailWork tw)
 {
     constexpr int R = TS + 2*TILE_HALO;
     // an ionisable species: tiles that hold no charged ion have nothing to deposit (flag written by the species' push)
@@ -109,9 +129,10 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         slot[c] = on ? na++ : -1;
     }
 
-    const int4 lrec = reinterpret_cast<const int4*>(offsets + tile_launch_offset(gridDim.x))[blockIdx.x];     // {tile, first, end}: launch order = heaviest tile first (sort.hip)
+    bool tail;
+    const int4 lrec = tile_record(offsets, tw, pl.n, tail);     // {tile, first, end}: launch order = heaviest tile first (sort.hip)
     const int tile = lrec.x;
-    const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
+    const int ox = tail ? TAIL_ORIGIN : (tile % ntx)*TS - TILE_HALO, oy = tail ? TAIL_ORIGIN : (tile / ntx)*TS - TILE_HALO;
     const int tid = threadIdx.x;
     PT_STAMP(0);
     const int pend = lrec.z;
@@ -198,7 +219,7 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
                 }
             }
         } else {
-            ++nfb;
+            nfb += !tail;
 #pragma unroll
             for (int iy = 0; iy <= ORDER; ++iy) {
 #pragma unroll
@@ -267,7 +288,7 @@ template <int ORDER, int DT, int TS, bool LASER = false, int PAD = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // 128 VGPRs: 4 workgroups per CU
 void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
                        int cBz, int cEz, int cExmBy, int cEypBx, int cSy, int cSx, PartConsts k, int* n_fallback,
-                       const int* __restrict__ tile_flag)
+                       const int* __restrict__ tile_flag, TailWork tw)
 {
     constexpr int R = TS + 2*TILE_HALO;
     constexpr int RP = R + PAD, PL = RP*R;     // row pitch and plane size of the LDS images
@@ -277,9 +298,10 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
     double* img = lds;
     double* acc = lds + 4*PL;
     double* aimg = lds + 6*PL;
-    const int4 lrec = reinterpret_cast<const int4*>(offsets + tile_launch_offset(gridDim.x))[blockIdx.x];     // {tile, first, end} of this workgroup (sort.hip)
+    bool tail;
+    const int4 lrec = tile_record(offsets, tw, pl.n, tail);     // {tile, first, end} of this workgroup (sort.hip)
     const int tile = lrec.x;
-    const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
+    const int ox = tail ? TAIL_ORIGIN : (tile % ntx)*TS - TILE_HALO, oy = tail ? TAIL_ORIGIN : (tile / ntx)*TS - TILE_HALO;
     const int tid = threadIdx.x;
     const int cc[4] = {cBz, cEz, cExmBy, cEypBx};
     // software pipeline over the tile's particles: the next particle's record is in flight while the
@@ -347,7 +369,7 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
         const double b1 = cq*vy, b2 = cqc*vx, b3 = cqc*gx, b4 = -cqc*vxvy, b5 = cc*(gx - 1.0), b6 = -cc*vxvy;
 #pragma unroll
         for (int m = 0; m < NS; ++m) { dsx[m] *= k.dx_inv; dsy[m] *= k.dy_inv; }
-        if (!local) ++nfb;
+        if (!local && !tail) ++nfb;
 #pragma unroll
         for (int iy = 0; iy < NS; ++iy) {
 #pragma unroll
@@ -433,7 +455,7 @@ template <class T> __device__ __forceinline__ void sto (T* base, unsigned o, T v
 template <int ORDER, int TS, bool LASER = false, bool IONIZE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IONIZE ? HPS_PUSH_WAVES_ION : HPS_PUSH_WAVES)))
 void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
-                      int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, int* n_fallback, IonArgs ia, const int* go)
+                      int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, int* n_fallback, IonArgs ia, const int* go, TailWork tw)
 {
     constexpr int R = TS + 2*TILE_HALO;
     constexpr int NS = ORDER + 2;
@@ -443,7 +465,8 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     const int go_now = go ? *go : 1;
     int charged = 0;          // IONIZE: does this thread hold an ion of level > 0 after the slice?
     extern __shared__ __attribute__((aligned(16))) double img[];     // [5][R*R]
-    const int4 lrec = reinterpret_cast<const int4*>(offsets + tile_launch_offset(gridDim.x))[blockIdx.x];     // {tile, first, end} of this workgroup (sort.hip)
+    bool tail;
+    const int4 lrec = tile_record(offsets, tw, pl.n, tail);     // {tile, first, end} of this workgroup (sort.hip)
     const int tile = lrec.x;
     if constexpr (IONIZE) {
         // a tile of neutral atoms at rest (no charged ion so far) in a field below the threshold of the first level:
@@ -453,7 +476,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             return;
         }
     }
-    const int ox = (tile % ntx)*TS - TILE_HALO, oy = (tile / ntx)*TS - TILE_HALO;
+    const int ox = tail ? TAIL_ORIGIN : (tile % ntx)*TS - TILE_HALO, oy = tail ? TAIL_ORIGIN : (tile / ntx)*TS - TILE_HALO;
     const int tid = threadIdx.x;
     const unsigned pend = (unsigned)lrec.z;
     struct PIn { uint64_t id; double xp, yp, uxh, uyh, psih; };
@@ -510,7 +533,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             const int j0 = nodal_weights<ORDER>((yp - k.yoff)*k.dy_inv, sy, dsy);
             const int li = i0 - ox, lj = j0 - oy;
             const bool local = (li >= 0 && li + NS <= R && lj >= 0 && lj + NS <= R);
-            if (!local) ++nfb;
+            if (!local && !tail) ++nfb;
             Fld F{0, 0, 0, 0, 0, 0};
             if (local) {
                 // tensor-product gather: x sums per stencil row, then one y weight per row and component
@@ -828,7 +851,7 @@ static int set_lds (K kernel, size_t bytes)
 
 int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[6], double charge,
                            double mass, int order, double max_qsa, int can_ionize, int* n_qsa, Tiling* T, int* n_fallback,
-                           hipStream_t st, int aabs_comp, const int* tile_flag)
+                           hipStream_t st, int aabs_comp, const int* tile_flag, TailWork tw)
 {
     if (pl.n == 0) return HPS_OK;
     PartConsts k = base_consts(g);
@@ -841,9 +864,9 @@ int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
     SlabView f(slab);
     int mask = 0; for (int c = 0; c < 6; ++c) mask |= (comp[c] >= 0) << c;
 #define CALLM(O, S, M) { if (int e = set_lds(k_deposit_tiled<O, S, M>, lds)) return e; \
-        hipLaunchKernelGGL((k_deposit_tiled<O, S, M>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag); }
+        hipLaunchKernelGGL((k_deposit_tiled<O, S, M>), dim3(T->g.ntiles + tw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag, tw); }
 #define CALLL(O, S, M) { if (int e = set_lds(k_deposit_tiled<O, S, M, true>, lds)) return e; \
-        hipLaunchKernelGGL((k_deposit_tiled<O, S, M, true>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag); }
+        hipLaunchKernelGGL((k_deposit_tiled<O, S, M, true>), dim3(T->g.ntiles + tw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag, tw); }
 #define CALL(O, S) { if (aabs_comp >= 0) { if (mask == 51) CALLL(O, S, 51) else CALLL(O, S, -1) } \
                      else if (mask == 51) CALLM(O, S, 51) else if (mask == 59) CALLM(O, S, 59) else if (mask == 32) CALLM(O, S, 32) \
                      else if (mask == 3) CALLM(O, S, 3) else if (mask == 39) CALLM(O, S, 39) else if (mask == 47) CALLM(O, S, 47) else CALLM(O, S, -1) }
@@ -857,7 +880,7 @@ int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
 
 int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int cache[4], const int depos[2],
                             double charge, double mass, int order, int dtype, int can_ionize, Tiling* T, int* n_fallback,
-                            hipStream_t st, int aabs_comp, const int* tile_flag)
+                            hipStream_t st, int aabs_comp, const int* tile_flag, TailWork tw)
 {
     if (pl.n == 0) return HPS_OK;
     PartConsts k = base_consts(g);
@@ -868,8 +891,8 @@ int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hp
     const size_t lds = (size_t)(aabs_comp >= 0 ? 7 : 6)*R*(R + pad)*sizeof(double);
     SlabView f(slab);
 #define HPS_EXPL_LAUNCH(O, D, S, L, P) { if (int e = set_lds(k_explicit_tiled<O, D, S, L, P>, lds)) return e; \
-        hipLaunchKernelGGL((k_explicit_tiled<O, D, S, L, P>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
-                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback, tile_flag); }
+        hipLaunchKernelGGL((k_explicit_tiled<O, D, S, L, P>), dim3(T->g.ntiles + tw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
+                           cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback, tile_flag, tw); }
 #define HPS_EXPL_PADS(O, D, S, L) { if (pad == 8) HPS_EXPL_LAUNCH(O, D, S, L, 8) else HPS_EXPL_LAUNCH(O, D, S, L, 2) }
     if (dtype == 2) {
 #define CALL(O, S) { if (aabs_comp >= 0) HPS_EXPL_PADS(O, 2, S, true) else HPS_EXPL_PADS(O, 2, S, false) }
@@ -888,7 +911,7 @@ int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hp
 
 int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], double charge,
                           double mass, int order, int temp_slice, int n_subcycles, int can_ionize, Tiling* T,
-                          int* n_fallback, hipStream_t st, int aabs_comp, const IonArgs* ion, const int* go)
+                          int* n_fallback, hipStream_t st, int aabs_comp, const IonArgs* ion, const int* go, TailWork tw)
 {
     if (pl.n == 0) return HPS_OK;
     PartConsts k = base_consts(g);
@@ -900,8 +923,8 @@ int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_
     SlabView f(slab);
     const IonArgs ia = ion ? *ion : IonArgs{};
 #define HPS_ADV(O, S, L, I) { if (int e = set_lds(k_advance_tiled<O, S, L, I>, lds)) return e; \
-        hipLaunchKernelGGL((k_advance_tiled<O, S, L, I>), dim3(T->g.ntiles), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
-                           comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback, ia, go); }
+        hipLaunchKernelGGL((k_advance_tiled<O, S, L, I>), dim3(T->g.ntiles + tw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
+                           comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback, ia, go, tw); }
 #define CALL(O, S) { if (ion) { if (aabs_comp >= 0) HPS_ADV(O, S, true, true) else HPS_ADV(O, S, false, true) } \
                      else     { if (aabs_comp >= 0) HPS_ADV(O, S, true, false) else HPS_ADV(O, S, false, false) } }
     HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
@@ -982,7 +1005,7 @@ extern "C" int hps_deposit_current_tiled (hps_slab slab, hps_plasma pl, hps_geom
     if (int e = check_tiling(tiling, slab, pl, "hps_deposit_current_tiled")) return e;
     for (int c = 0; c < 6; ++c) HPS_REQUIRE(comp[c] >= -1 && comp[c] < slab.ncomp, "hps_deposit_current_tiled: bad component");
     return deposit_current_tiled(slab, pl, g, comp, charge, mass, order, max_qsa, can_ionize, n_qsa,
-                                 static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr);
+                                 static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr, TailWork{});
 }
 
 extern "C" int hps_explicit_deposit_tiled (hps_slab slab, hps_plasma pl, hps_geom g, const int cache[4], const int depos[2],
@@ -994,7 +1017,7 @@ extern "C" int hps_explicit_deposit_tiled (hps_slab slab, hps_plasma pl, hps_geo
     if (int e = check_stencil(slab, (order + 1)/2 + 1, "hps_explicit_deposit_tiled")) return e;
     if (int e = check_tiling(tiling, slab, pl, "hps_explicit_deposit_tiled")) return e;
     return explicit_deposit_tiled(slab, pl, g, cache, depos, charge, mass, order, dtype, can_ionize,
-                                  static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr);
+                                  static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr, TailWork{});
 }
 
 extern "C" int hps_advance_plasma_tiled (hps_slab slab, hps_plasma pl, hps_geom g, const int comp[5], double charge,
@@ -1006,5 +1029,5 @@ extern "C" int hps_advance_plasma_tiled (hps_slab slab, hps_plasma pl, hps_geom 
     if (int e = check_stencil(slab, (order + 1)/2 + 1, "hps_advance_plasma_tiled")) return e;
     if (int e = check_tiling(tiling, slab, pl, "hps_advance_plasma_tiled")) return e;
     return advance_plasma_tiled(slab, pl, g, comp, charge, mass, order, temp_slice, n_subcycles, can_ionize,
-                                static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr, nullptr);
+                                static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr, nullptr, TailWork{});
 }
