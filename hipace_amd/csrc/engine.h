@@ -139,7 +139,9 @@ struct Engine {
     int solve_slice (int islice);
     int solve_slice_begin (int islice);      // ... in two halves: everything up to the Bx/By solve's norm read-back is enqueued,
     int solve_slice_finish (int islice);     // then the host waits for the norms and enqueues the rest
-    int pending_slice = -1; bool pend_fuse = false, pend_gated = false;
+    int pending_slice = -1; bool pend_fuse = false, pend_gated = false, pend_gated_ion = false;
+    bool gate_ion_push = true; IonArgs pend_ia{}; long pend_covered = 0;      // the ionisable species' push + the electrons' push behind the V-cycles (HPS_GATED_ION_PUSH=0: off)
+    int push_with_ionization (int islice, const int comp[5], const int* go, bool first);
     bool lazy_shift = true, shift_pending = false;      // ShiftSlices deferred to the next slice's InitializeSlices pass (HPS_LAZY_SHIFT=0: off)
     void flush_shift ();
     bool fuse_sources = true;       // the Poisson sources formed inside the first transform pass (HPS_FUSE_SOURCES=0: k_rhs_all + staging planes)

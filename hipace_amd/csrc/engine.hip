@@ -519,6 +519,7 @@ int Engine::create (const hps_deck& deck, int device)
     pc = (d.bxby_solver != 0);
     if (const char* v = std::getenv("HPS_GATED_PUSH")) gate_push = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_FOLD_TAIL")) fold_tail = std::atoi(v) != 0;
+    if (const char* v = std::getenv("HPS_GATED_ION_PUSH")) gate_ion_push = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_LAZY_SHIFT")) lazy_shift = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_FUSE_SOURCES")) fuse_sources = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_SORT_FALLBACK_DIV")) { const long q = std::atol(v); if (q >= 1) fallback_div = q; }
@@ -1421,19 +1422,44 @@ int Engine::solve_slice_begin (int islice)
     // V-cycle straight into the push instead of idling until the host has seen the norms and launched it.
     const bool fuse = fuse_push_deposit && tiling && islice > 0 && !moving && c_aabs < 0 && ion.n == 0 && np > 0 && tiling->sorted_n == np;
     const bool gated = gate_push && tiling && !fuse && ion.n == 0 && np > 0 && tiling->sorted_n == np && !diagnostics && !d_fd && !d_insitu;
+    // ... and with an ionisable species on tiles: its field bounds, its push (which takes the ADK decisions and appends the
+    // electrons) and the electrons' push, all behind the speculated V-cycles; the two pushes are gated (HPS_GATED_ION_PUSH=0: off)
+    const bool gated_ion = gate_push && gate_ion_push && tiling && !fuse && ion.n > 0 && ion.tiling && np > 0 && tiling->sorted_n > 0 && fold_tail
+                           && !diagnostics && !d_fd && !d_insitu;
     const int comp_push[5] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ};
     {   int iters = 0, extra = 0;
         if ((e = mg_solve1_begin(mg, slab, HPS_C_BX, HPS_C_SY, HPS_C_CHI, d.mg_tol_rel, d.mg_tol_abs, 200, st))) return e;
+        if (gated_ion) {
+            mark();   // b6
+            mark();   // b7
+            if ((e = push_with_ionization(islice, comp_push, mg_gate_after_enqueued(mg), true))) return e;
+        }
         if (gated) {
             mark();   // b6
             mark();   // b7
             if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st, c_aabs, nullptr, mg_gate_after_enqueued(mg)))) return e;
         }
         if (laser_split && d.laser_solver == 2) { if ((e = laser_advance_slice(*this, islice)) || (e = laser_done())) return e; }
-        pending_slice = islice; pend_fuse = fuse; pend_gated = gated;
+        pending_slice = islice; pend_fuse = fuse; pend_gated = gated; pend_gated_ion = gated_ion;
         HPS_HIP_CHECK(hipGetLastError());
         return HPS_OK;
     }
+}
+
+// DoFieldIonization + the ions' push + the electrons' push (Hipace.cpp:693-701) of a slice on tiles, enqueued without a word from
+// the host in between: the ions' field bounds, the ions' push (ADK decisions on the fields it gathers, electrons appended on the
+// device), the electrons' tile-sorted body with the tail's workgroups reading the live particle count.  `go`: the multigrid
+// solve's gate word (both pushes do nothing unless the solve is over); first = false: the same launches again, ungated, after
+// the host has added V-cycles (same ADK sequence number: the count is posted once).
+int Engine::push_with_ionization (int islice, const int comp[5], const int* go, bool first)
+{
+    int e;
+    if ((e = ion_field_bounds())) return e;
+    if (first) pend_ia = ion_args(islice);
+    if ((e = advance_plasma_tiled(slab, ion.pl, gm, comp, d.ion_charge, d.ion_mass, d.order, 0, d.n_subcycles, 1, ion.tiling, d_nfallback, st, c_aabs, &pend_ia, go))) return e;
+    TailWork tw = fold_tail_of(pl, tiling, 256, &pend_covered);
+    if (tw.nwg) tw.live_n = ion.d_cnt;
+    return advance_plasma_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st, c_aabs, nullptr, go, tw);
 }
 
 int Engine::solve_slice_finish (int islice)
@@ -1446,16 +1472,22 @@ int Engine::solve_slice_finish (int islice)
     const dim3 b256(256);
     const dim3 gplane(ceil_div(plane, 256));
     const CellBox bb{beam_box.ilo, beam_box.ihi, beam_box.jlo, beam_box.jhi};
-    const bool fuse = pend_fuse, gated = pend_gated;
+    const bool fuse = pend_fuse, gated = pend_gated, gated_ion = pend_gated_ion;
     const int comp_push[5] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ};
     int e;
     {   int iters = 0, extra = 0;
         if ((e = mg_solve1_finish(mg, &iters, nullptr, &extra, st))) return e;
         total_vcycles += iters;
         // the speculated V-cycles were not enough (the gated push has not run): the host has added the rest, push now
-        if (gated && extra) { if ((e = species_advance(pl, tiling, comp_push, d.plasma_charge, d.plasma_mass, 0, 0))) return e; } }
+        if (gated && extra) { if ((e = species_advance(pl, tiling, comp_push, d.plasma_charge, d.plasma_mass, 0, 0))) return e; }
+        if (gated_ion) {
+            if (extra) { if ((e = push_with_ionization(islice, comp_push, nullptr, false))) return e; }
+            // the electrons the slice has released beyond the room the body's launch had for them
+            if ((e = ionize_collect())) return e;
+            if (pl.n > pend_covered) { if ((e = hps_advance_plasma_laser(slab, tail_of(pl, pend_covered, pl.n - pend_covered), gm, comp_push, c_aabs, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; }
+        } }
 
-    if (!gated) {
+    if (!gated && !gated_ion) {
     mark();   // b6
     if (diagnostics)
         hipLaunchKernelGGL(k_checksum, dim3(64, ncomp), b256, 0, st, f, ncomp, d_checksum);

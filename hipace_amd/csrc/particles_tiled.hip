@@ -469,6 +469,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     const int4 lrec = tile_record(offsets, tw, pl.n, tail);     // {tile, first, end} of this workgroup (sort.hip)
     const int tile = lrec.x;
     if constexpr (IONIZE) {
+        if (!go_now) return;      // (gated: nothing is posted, the launch is repeated ungated)
         // a tile of neutral atoms at rest (no charged ion so far) in a field below the threshold of the first level:
         // nothing to decide, nothing to push -- most tiles of a slice (the field image is not even loaded)
         if (ia.fbound && ia.tile_flag && ia.tile_flag[tile] == 0 && adk_tile_below_threshold(ia, tile % ntx, tile / ntx)) {

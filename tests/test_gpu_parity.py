@@ -1533,7 +1533,7 @@ def _run_with_env(api, var, value, deck, n_steps, tile_size=16):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["gated_push", "lazy_shift", "fuse_sources", "laser_stream_fft", "laser_stream_mg", "ion_tile_skip", "fold_tail"])
+@pytest.mark.parametrize("case", ["gated_push", "lazy_shift", "fuse_sources", "laser_stream_fft", "laser_stream_mg", "ion_tile_skip", "fold_tail", "gated_ion_push"])
 def test_schedules_do_not_change_results(api, case):
     """The engine's scheduling choices -- the push enqueued behind the multigrid's V-cycles and gated on its stopping rule,
     the envelope solver on a stream of its own, the tiles of atoms that cannot ionise skipped before their image is loaded --
@@ -1551,21 +1551,22 @@ def test_schedules_do_not_change_results(api, case):
         deck.update(nx=64, ny=64, nz=30, lo=(-16.0, -16.0, -4.0), hi=(16.0, 16.0, 4.0), laser_a0=1.5, laser_lambda0=0.4,
                     laser_solver=1 if case.endswith("fft") else 2, dt=5.0, n_steps=3)
     else:      # fold_tail: the electrons released since the last sort ride in the tile kernels' launches (sort_period 7: tails of up to 6 slices)
-        var, steps = ("HPS_ION_TILE_SKIP" if case == "ion_tile_skip" else "HPS_FOLD_TAIL"), 2
+        # gated_ion_push: the ions' push (with its ADK decisions) and the electrons' push enqueued behind the Bx/By V-cycles
+        var, steps = {"ion_tile_skip": "HPS_ION_TILE_SKIP", "fold_tail": "HPS_FOLD_TAIL", "gated_ion_push": "HPS_GATED_ION_PUSH"}[case], 2
         deck = decks.laser_ionization_SI()
         deck.update(nx=128, ny=128, nz=60, laser_solver=1, dt=6.0 * 10.0e-6 / 299792458.0, n_steps=2)
     a = _run_with_env(api, var, "1", deck, steps)
     b = _run_with_env(api, var, "0", deck, steps)
     sa, sb = a.slab(), b.slab()
     # two runs of ONE schedule differ by the order of their LDS atomics; two steps of the ionisation deck have shown 1.2e-12
-    tol = 1e-11 if case in ("ion_tile_skip", "fold_tail") else 1e-12
+    tol = 1e-11 if case in ("ion_tile_skip", "fold_tail", "gated_ion_push") else 1e-12
     for c, nm in enumerate(a.comp_names()):
         sc = max(np.abs(sb[c]).max(), 1e-300)
         assert np.abs(sa[c] - sb[c]).max() <= tol * sc, (case, nm)
     ra, va = a.particles()
     rb, vb = b.particles()
     assert ra.shape == rb.shape and np.array_equal(np.sort(va), np.sort(vb))
-    if case in ("ion_tile_skip", "fold_tail"):      # (released electrons are appended in the order of an atomic counter)
+    if case in ("ion_tile_skip", "fold_tail", "gated_ion_push"):      # (released electrons are appended in the order of an atomic counter)
         (_, _, la, ka), (_, _, lb, kb) = a.ions(), b.ions()
         assert np.array_equal(la[np.argsort(ka)], lb[np.argsort(kb)])
         assert a.ion_stats() == b.ion_stats() and a.ion_stats()[0] > 100
