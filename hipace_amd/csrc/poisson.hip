@@ -41,6 +41,18 @@ __device__ __forceinline__ double odd_ext (int m, int N, G&& get)
     return sgn*get(m - 1);
 }
 
+// ... of both rows of a pair at once (one 16-byte LDS read)
+template <class G>
+__device__ __forceinline__ double2 odd_ext2 (int m, int N, G&& get)
+{
+    double sgn = 1.0;
+    if (m < 0) { m = -m; sgn = -1.0; }
+    if (m > N) { m = 2*N - m; sgn = -sgn; }
+    if (m == 0 || m == N) return make_double2(0.0, 0.0);
+    const double2 v = get(m - 1);
+    return make_double2(sgn*v.x, sgn*v.y);
+}
+
 // post-processing of one C2R output row: r has N = n+1 entries, k in [0, n)
 __device__ __forceinline__ double dst_from_r (const double* r, int k, int N, double isin4)
 {
@@ -164,6 +176,9 @@ __device__ __forceinline__ void load_row_pairs_src (lds_double* cbuf, const DstA
     }
 }
 
+#ifndef HPS_PRE_B128
+#define HPS_PRE_B128 1
+#endif
 // Z entries of both rows of a pair -> W[p] and W[N-p] (registers), rows read from LDS
 template <int T, int N, int PP, int NT = 256>
 __device__ __forceinline__ void pre_to_regs (const lds_double* cbuf, int tid, double (&wr)[T][PP], double (&wi)[T][PP],
@@ -176,10 +191,17 @@ __device__ __forceinline__ void pre_to_regs (const lds_double* cbuf, int tid, do
             const int p = tid + NT*m;
             wr[t][m] = wi[t][m] = vr[t][m] = vi[t][m] = 0.0;
             if (p <= N/2) {
+#if HPS_PRE_B128
+                // three 16-byte reads (lanes 32 B apart: 2-way bank conflicts) instead of six 8-byte ones (4-way)
+                auto gc = [&] (int j) { return ldc(cbuf, t*N + j); };
+                const double2 e1 = odd_ext2(2*p + 1, N, gc), e0 = odd_ext2(2*p - 1, N, gc), e2 = odd_ext2(2*p, N, gc);
+                const double are = e1.x - e0.x, aim = e2.x, bre = e1.y - e0.y, bim = e2.y;
+#else
                 auto ga = [&] (int j) { return (double)cbuf[2*(t*N + j)]; };
                 auto gb = [&] (int j) { return (double)cbuf[2*(t*N + j) + 1]; };
                 const double are = odd_ext(2*p + 1, N, ga) - odd_ext(2*p - 1, N, ga), aim = odd_ext(2*p, N, ga);
                 const double bre = odd_ext(2*p + 1, N, gb) - odd_ext(2*p - 1, N, gb), bim = odd_ext(2*p, N, gb);
+#endif
                 wr[t][m] = are - bim; wi[t][m] = aim + bre;      // W[p]
                 vr[t][m] = are + bim; vi[t][m] = bre - aim;      // W[N-p]
             }
