@@ -477,7 +477,12 @@ def main():
             run_lanes(lane_engines, rank, world, W, dev, slices_per_step=max(2, min(args.warmup, nz)), transport=transport)   # warm every stage
             barrier()
             t0 = time.perf_counter()
+            if os.environ.get("HPS_DRIVE_TRACE"):
+                from hipace_amd import pipeline as _pl
+                del _pl._TRACE[:]
             solvedL = run_lanes(lane_engines, rank, world, W * boxes, dev, transport=transport)
+            if os.environ.get("HPS_DRIVE_TRACE"):
+                _pl.dump_trace()
             barrier()
             dtL = time.perf_counter() - t0
             nL = solvedL // L

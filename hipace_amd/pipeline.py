@@ -26,6 +26,8 @@ Dependencies: solving slice k of step s+1 needs the beam of slices k and k-1 of 
 the explicit source term, Hipace.cpp:639-657), so a rank trails its predecessor by two slices.
 """
 import gc
+import os
+import time
 import ctypes as C
 
 import torch
@@ -351,6 +353,25 @@ def make_transport(rank, world, device):
 _EV_SLICE, _EV_STEP, _EV_LFREE, _EV_LOCAL = 0, 64, 80, 4096
 
 
+_TRACE = [] if os.environ.get("HPS_DRIVE_TRACE") else None      # diagnostic: (seconds, stage, what, slice) per host action
+
+
+def _trace(stage, what, q):
+    if _TRACE is not None:
+        _TRACE.append((time.perf_counter(), stage, what, q))
+
+
+def dump_trace():
+    """HPS_DRIVE_TRACE=<file>: write the host-side timeline of the stages (begin / finish of every slice, waits on local
+    edges) recorded so far and clear it."""
+    if _TRACE:
+        with open(os.environ["HPS_DRIVE_TRACE"], "w") as f:
+            t0 = _TRACE[0][0]
+            for t, st, what, q in _TRACE:
+                f.write(f"{(t - t0)*1e6:12.1f} us  stage {st}  {'      '*st}{what} {q}\n")
+        del _TRACE[:]
+
+
 def _drive(gens, engines=None):
     """One host thread, several stages: every generator runs to its next yield in turn ("work": a slice has been enqueued
     and its norm read-back is pending; "wait": a local edge has nothing for it yet).  With `engines` (HPS_DRIVE_READY=1) a
@@ -594,6 +615,7 @@ def _stage(engine, rank, world, n_steps, device, on_step_end=None, slices_per_st
                     ev = recv_ev.pop((m, imported, 0), None)
                     if ev is not None:
                         while not T.ready(ev[0]):      # (a local edge: the stage ahead has not sent it yet)
+                            _trace(rank, "wait-in", q)
                             yield "wait"
                         T.engine_wait(engine, ev[0])
                         if moving:
@@ -612,9 +634,13 @@ def _stage(engine, rank, world, n_steps, device, on_step_end=None, slices_per_st
                         imported = k
             # the slice in two halves: everything up to the Bx/By solve's norm read-back is enqueued, the other stages of
             # this process (if any) get their turn, then the host waits for the norms and enqueues the rest
+            _trace(rank, "begin", q)
             engine.solve_slice_begin(islice)
+            _trace(rank, "begun", q)
             yield "work"
+            _trace(rank, "finish", q)
             engine.solve_slice_finish(islice)
+            _trace(rank, "finished", q)
             solved += 1
             if step + 1 < n_steps:
                 if not ring:                           # MultiBuffer.cpp:299-308: send to myself
@@ -648,6 +674,7 @@ def _stage(engine, rank, world, n_steps, device, on_step_end=None, slices_per_st
                         ev = engine.record_event(_EV_SLICE + q % 64)  # the slice (its push, the exports) is done
                         for kind, k, t in out:
                             while not T.can_send():    # (a local edge: the stage behind has not posted its receive yet)
+                                _trace(rank, "wait-out", q)
                                 yield "wait"
                             if kind == "b":
                                 spool_done[k] = T.send(t, ev, 4 * nz + k)
