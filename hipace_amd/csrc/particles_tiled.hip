@@ -108,6 +108,13 @@ __device__ __forceinline__ int4 tile_record (const int* __restrict__ offsets, co
 }
 constexpr int TAIL_ORIGIN = -(1 << 24);      // "tile origin" of a tail workgroup: no particle is local to it
 
+// Row pitch of the deposition's LDS accumulators = R + HPS_DEP_PAD doubles.  The lanes of a wave work on particles of 64
+// consecutive cells (four tile rows at the sort's (rank, cell) order): with pitch 20 the four rows fall on the 32 eight-byte
+// bank slots at offsets 0, 20, 8, 28 -- three rows deep on some slots, one on others; with pitch 48 (HPS_DEP_PAD=28) rows
+// alternate between the two halves of the banks.
+#ifndef HPS_DEP_PAD
+#define HPS_DEP_PAD 0
+#endif
 // (An XCD-chunked tile order -- contiguous tile runs per XCD -- was measured slower here: 916 vs 953 slices/s.)
 // MASK: compile-time set of deposited components (bit c = DepComps entry c), -1 = decide at run time.
 // With a compile-time set the 9x4 accumulations are straight-line ds_add_f64 with immediate offsets.
@@ -117,9 +124,10 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
                       PartConsts k, int* n_qsa, int* n_fallback, const int* __restrict__ tile_flag, TailWork tw)
 {
     constexpr int R = TS + 2*TILE_HALO;
+    constexpr int RP = R + HPS_DEP_PAD, PL = RP*R;      // row pitch and plane size of the accumulators (HPS_DEP_PAD, below)
     // an ionisable species: tiles that hold no charged ion have nothing to deposit (flag written by the species' push)
     if (tile_flag && !tile_flag[offsets[gridDim.x + 2 + blockIdx.x]]) return;
-    extern __shared__ __attribute__((aligned(16))) double acc[];     // [active comps][R*R]
+    extern __shared__ __attribute__((aligned(16))) double acc[];     // [active comps][R][RP]
     const int gc[6] = {cm.jx, cm.jy, cm.jz, cm.rho, cm.chi, cm.rhomjz};
     // slot of each component (compacted)
     int slot[6]; int na = 0;
@@ -158,9 +166,9 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     }
     {
         double2* z = (double2*)acc;
-        for (int s = tid; s < na*R*R/2; s += 256) z[s] = make_double2(0.0, 0.0);
+        for (int s = tid; s < na*PL/2; s += 256) z[s] = make_double2(0.0, 0.0);
     }
-    double* aimg = acc + na*R*R;          // LASER: |a|^2 over the tile region
+    double* aimg = acc + na*PL;          // LASER: |a|^2 over the tile region
     if constexpr (LASER) { const int ca[1] = {k.aabs}; load_region<R, R, 256, 1>(aimg, f, ca, 1, ox, oy, tid); }
     __syncthreads();
     PT_STAMP(1);
@@ -213,9 +221,9 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
 #pragma unroll
                 for (int ix = 0; ix <= ORDER; ++ix) {
                     const double cd = q_invvol*sx[ix]*sy[iy];
-                    double* p = acc + (lj + iy)*R + li + ix;
+                    double* p = acc + (lj + iy)*RP + li + ix;
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) if (slot[c] >= 0) lds_add(p + slot[c]*R*R, cd*wv[c]);
+                    for (int c = 0; c < 6; ++c) if (slot[c] >= 0) lds_add(p + slot[c]*PL, cd*wv[c]);
                 }
             }
         } else {
@@ -247,7 +255,7 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             if (slot[c] >= 0) {
-                const double v = acc[slot[c]*R*R + s];
+                const double v = acc[slot[c]*PL + lj*RP + li];
                 if (v != 0.0) atomic_add_f64(p + gc[c]*f.ns, v);
             }
         }
@@ -861,7 +869,7 @@ int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
     DepComps cm{comp[0], comp[1], comp[2], comp[3], comp[4], comp[5]};
     int na = 0; for (int c = 0; c < 6; ++c) na += comp[c] >= 0;
     const int R = T->g.ts + 2*TILE_HALO;
-    const size_t lds = (size_t)(na + (aabs_comp >= 0 ? 1 : 0))*R*R*sizeof(double);
+    const size_t lds = ((size_t)na*R*(R + HPS_DEP_PAD) + (aabs_comp >= 0 ? (size_t)R*R : 0))*sizeof(double);
     SlabView f(slab);
     int mask = 0; for (int c = 0; c < 6; ++c) mask |= (comp[c] >= 0) << c;
 #define CALLM(O, S, M) { if (int e = set_lds(k_deposit_tiled<O, S, M>, lds)) return e; \
