@@ -115,6 +115,12 @@ constexpr int TAIL_ORIGIN = -(1 << 24);      // "tile origin" of a tail workgrou
 #ifndef HPS_DEP_PAD
 #define HPS_DEP_PAD 0
 #endif
+#ifndef HPS_DEP_NB
+#define HPS_DEP_NB 4
+#endif
+#ifndef HPS_DEP_PIPE
+#define HPS_DEP_PIPE 0
+#endif
 // (An XCD-chunked tile order -- contiguous tile runs per XCD -- was measured slower here: 916 vs 953 slices/s.)
 // MASK: compile-time set of deposited components (bit c = DepComps entry c), -1 = decide at run time.
 // With a compile-time set the 9x4 accumulations are straight-line ds_add_f64 with immediate offsets.
@@ -157,8 +163,15 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     // of them is processed: the kernel is bound by memory-level parallelism, not by issue slots.
     // The first batch (the whole tile at nominal density) is requested before the accumulators are
     // zeroed, so its HBM latency hides behind the zeroing.
-    constexpr int NB = 4;
+    // HPS_DEP_PIPE: the next batch is requested while the current one is worked on (the loads of a workgroup then overlap
+    // its own LDS atomics, not only those of the other workgroups of the CU).  Measured with HPS_DEP_NB = 2 and 1 (76 VGPRs,
+    // 6 waves per SIMD instead of 4): 71.0 / 74.8 us against 71.4 -- no gain: on a lattice sheet the kernel moves its 235 MB at
+    // 3.9 TB/s (59.9 us, scripts/diag_deposit.py 0.0; a device copy reaches 5.4), behind the driver at 3.3
+    constexpr int NB = HPS_DEP_NB;
     Rec rec[NB];
+#if HPS_DEP_PIPE
+    Rec nxt[NB];
+#endif
     const int ipb = lrec.y + tid;
     if (ipb < pend) {
 #pragma unroll
@@ -174,10 +187,21 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     PT_STAMP(1);
 
     for (int ip0 = ipb; ip0 < pend; ip0 += 256*NB) {
+#if HPS_DEP_PIPE
+      if (ip0 != ipb) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) rec[u] = nxt[u];
+      }
+      if (ip0 + 256*NB < pend) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) nxt[u] = fetch(min(ip0 + 256*NB + 256*u, pend - 1));
+      }
+#else
       if (ip0 != ipb) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) rec[u] = fetch(min(ip0 + 256*u, pend - 1));
       }
+#endif
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         const int ip = ip0 + 256*u;
