@@ -1,29 +1,40 @@
 """openPMD output of the slice engine's diagnostics (the reference: diagnostics/OpenPMDWriter.cpp:55-450).
 
-One file per output iteration, `<prefix>/openpmd_%06d.npz`, holding the openPMD 1.1 hierarchy the reference writes
-through openPMD-api -- `/data/<iteration>/fields/<name>` (meshes: data order C, axes z y x, gridSpacing,
-gridGlobalOffset, position; OpenPMDWriter.cpp:85-180) and `/data/<iteration>/particles/<beam>/{position, momentum,
-weighting, id, charge, mass, positionOffset}` (:290-450) -- with the same record and attribute names.  The CONTAINER is
-numpy's npz (a zip of .npy arrays + one JSON document of attributes) instead of HDF5 / ADIOS2, because this image has no
-HDF5 library and no openPMD-api; the hierarchy paths are the array names.  With `json_too=True` the same iteration is also
-written as `openpmd_%06d.json` in the layout of openPMD-api's JSON backend (plain text: groups as nested objects, every
-group's attributes under "attributes" as {"datatype", "value"}, datasets as {"attributes", "datatype", "data": nested
-lists}, constant record components as groups with the attributes "value" and "shape", "platform_byte_widths" at the root)
--- the one openPMD container that needs no library to write.  That layout is restated from openPMD-api 0.14/0.15's
-JSONIOHandlerImpl; it could not be opened with openPMD-api here (not installed), `tests/test_abi_and_oracle_ops.py` only
-checks it against itself.  `tests/openpmd_shim.py` offers the
-subset of openPMD-viewer's `OpenPMDTimeSeries` that the reference's checksum backend uses
-(tests/checksum/backend/openpmd_backend.py:17-62), so that backend's reductions run on these files unchanged.
+One file per output iteration holding the openPMD 1.1 hierarchy the reference writes through openPMD-api --
+`/data/<iteration>/fields/<name>` (meshes: data order C, axes z y x, gridSpacing, gridGlobalOffset, position;
+OpenPMDWriter.cpp:85-180) and `/data/<iteration>/particles/<beam>/{position, momentum, weighting, id, charge, mass,
+positionOffset}` (:290-450) -- with the same record and attribute names, in up to three containers:
+
+* `<prefix>/openpmd_%06d.h5`: HDF5, the reference's container and file name (`hipace.file_prefix/openpmd_%06T.h5`), written
+  through the HDF5 C library by ctypes (`hipace_amd/h5lite.py`; the image has libhdf5 1.10 but neither h5py nor openPMD-api)
+  in the layout of openPMD-api's HDF5 backend: groups = hierarchy, contiguous datasets, constant record components as groups
+  with the attributes `value` and `shape`, attribute datatypes as openPMD-api writes them.  Checked here by reading it back
+  (`read_hdf5`, `tests/openpmd_shim.py`) and with the library's own `h5dump`; openPMD-viewer / openPMD-api themselves are
+  not installed, so "the reference's `checksumAPI.py` opens it unmodified" is what the layout is built for, not something
+  this image can run.  Written when the library can be loaded (`hdf5=None`) or on request;
+* `openpmd_%06d.npz`: numpy's npz (a zip of .npy arrays + one JSON document of attributes; the hierarchy paths are the array
+  names) -- always written, needs nothing;
+* with `json_too=True` `openpmd_%06d.json` in the layout of openPMD-api's JSON backend (plain text: groups as nested objects,
+  every group's attributes under "attributes" as {"datatype", "value"}, datasets as {"attributes", "datatype", "data": nested
+  lists}, constant record components as groups with the attributes "value" and "shape", "platform_byte_widths" at the
+  root), restated from openPMD-api 0.14/0.15's JSONIOHandlerImpl.
+
+`tests/openpmd_shim.py` offers the subset of openPMD-viewer's `OpenPMDTimeSeries` that the reference's checksum backend uses
+(tests/checksum/backend/openpmd_backend.py:17-62) on the HDF5 files (or the npz container), so that backend's reductions
+run on these files unchanged.
 """
 import json
 import os
 
 import numpy as np
 
+from . import h5lite
+
 OPENPMD_VERSION = "1.1.0"
 
 
-def write_iteration(prefix, iteration, time, dt, geometry, fields=None, beams=None, normalized=True, constants=None, json_too=False):
+def write_iteration(prefix, iteration, time, dt, geometry, fields=None, beams=None, normalized=True, constants=None, json_too=False,
+                    hdf5=None):
     """Write one openPMD iteration.
 
     geometry: dict(lo=(x, y, z), hi=(x, y, z)) of the (possibly coarsened) diagnostic grid.
@@ -31,7 +42,8 @@ def write_iteration(prefix, iteration, time, dt, geometry, fields=None, beams=No
     beams: {name: dict(x, y, z, ux, uy, uz, w, [id], charge, mass)} -- u = proper velocity / c as the engine keeps it
     (normalised units) or in m/s times gamma (SI), written as the reference does (OpenPMDWriter.cpp:376-385: momentum =
     u * mass * c with unitSI attributes).
-    Returns the file name.
+    hdf5: also write `openpmd_%06d.h5` (None: if the HDF5 C library can be loaded, `h5lite.available()`).
+    Returns the name of the npz file.
     """
     os.makedirs(prefix, exist_ok=True)
     base = f"/data/{iteration}"
@@ -71,7 +83,60 @@ def write_iteration(prefix, iteration, time, dt, geometry, fields=None, beams=No
     if json_too:
         with open(os.path.join(prefix, "openpmd_%06d.json" % iteration), "w") as f:
             json.dump(to_openpmd_json(attrs, arrays), f)
+    if hdf5 is None:
+        hdf5 = h5lite.available()
+    if hdf5:
+        write_hdf5(os.path.join(prefix, "openpmd_%06d.h5" % iteration), attrs, arrays)
     return fn
+
+
+# ---- HDF5 container (the reference's: hipace.file_prefix/openpmd_%06T.h5 through openPMD-api) -----------------------------
+_RECORDS = ("position", "momentum", "weighting", "charge", "mass", "positionOffset", "id")
+_H5_KINDS = dict(UINT="UINT", FLOAT="FLOAT", ARR_DBL_7="DOUBLE", VEC_ULONG="ULONG")
+
+
+def _complete(attrs, arrays):
+    """the attributes the openPMD standard requires at record / record-component level added where the hierarchy above leaves
+    them out (unitDimension, timeOffset; unitSI of every component)"""
+    full = {p: dict(a) for p, a in attrs.items()}
+    for path in list(full) + list(arrays):
+        comp = path.rstrip("/").split("/")
+        if (len(comp) >= 2 and comp[-2] == "fields") or (comp and comp[-1] in _RECORDS):
+            a = full.setdefault(path, {})
+            a.setdefault("unitDimension", [0.0] * 7)      # (the engine's units are the deck's; the reference writes its own table)
+            a.setdefault("timeOffset", 0.0)
+    for path in arrays:
+        full.setdefault(path, {}).setdefault("unitSI", 1.0)
+    return full
+
+
+def write_hdf5(fn, attrs, arrays):
+    """{hierarchy path: attribute dict}, {hierarchy path: array} -> one HDF5 file laid out as openPMD-api's HDF5 backend does
+    (groups = hierarchy, contiguous datasets, constant record components as groups with `value` and `shape`, attribute
+    datatypes as in `hipace_amd/h5lite.py`)."""
+    full = _complete(attrs, arrays)
+    with h5lite.File(fn, "w") as f:
+        for path, arr in arrays.items():
+            f.dataset(path, arr)
+        for path in full:
+            if path not in arrays and path != "/":
+                f.group(path)
+        for path, a in full.items():
+            for k, v in a.items():
+                f.attr(path, k, v, _H5_KINDS.get(_ATTR_TYPES.get(k)))
+    return fn
+
+
+def read_hdf5(fn):
+    """The inverse (tests, tests/openpmd_shim.py): {path: array}, {path: {attribute: value}}."""
+    arrays, attrs = {}, {}
+    with h5lite.File(fn, "r") as f:
+        attrs["/"] = f.attrs("/")
+        for path, is_ds in f.walk("/"):
+            attrs[path] = f.attrs(path)
+            if is_ds:
+                arrays[path] = f.read(path)
+    return arrays, attrs
 
 
 # ---- openPMD-api JSON backend layout -------------------------------------------------------------------------------------
@@ -145,7 +210,7 @@ def read_openpmd_json(fn):
     return arrays, attrs
 
 
-def write_engine_output(engine, prefix, iteration, time=0.0, beam_name="beam", beam=None, json_too=False):
+def write_engine_output(engine, prefix, iteration, time=0.0, beam_name="beam", beam=None, json_too=False, hdf5=None):
     """diagnostic.output of one step of a SliceEngine: the fields of its field diagnostic (set_field_diagnostic before
     the step) and, if given, the beam as (7, n) rows x y z ux uy uz w."""
     d = engine.deck
@@ -155,4 +220,4 @@ def write_engine_output(engine, prefix, iteration, time=0.0, beam_name="beam", b
         beams = {beam_name: dict(x=beam[0], y=beam[1], z=beam[2], ux=beam[3], uy=beam[4], uz=beam[5], w=beam[6],
                                  charge=d["beam_charge"], mass=d.get("beam_mass", 1.0) or 1.0)}
     return write_iteration(prefix, iteration, time, d.get("dt", 0.0), dict(lo=d["lo"], hi=d["hi"]), fields, beams,
-                           normalized=not d.get("si_units", 0), json_too=json_too)
+                           normalized=not d.get("si_units", 0), json_too=json_too, hdf5=hdf5)

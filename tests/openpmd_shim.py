@@ -1,6 +1,7 @@
 """The subset of openPMD-viewer's OpenPMDTimeSeries that the reference's checksum backend uses
-(/root/reference/tests/checksum/backend/openpmd_backend.py:17-62), reading the npz container of
-hipace_amd/openpmd_writer.py, and that backend's two reductions restated on top of it."""
+(/root/reference/tests/checksum/backend/openpmd_backend.py:17-62), reading the HDF5 files of hipace_amd/openpmd_writer.py
+(through hipace_amd/h5lite.py: the HDF5 C library by ctypes; the image has neither h5py nor openPMD-viewer) or its npz
+container, and that backend's two reductions restated on top of it."""
 import glob
 import json
 import os
@@ -9,11 +10,21 @@ import re
 import numpy as np
 
 
+class _Arrays(dict):
+    """{path: array} with numpy's NpzFile interface (`files`)"""
+    @property
+    def files(self):
+        return list(self)
+
+
 class OpenPMDTimeSeries:
-    def __init__(self, path):
-        files = sorted(glob.glob(os.path.join(path, "openpmd_*.npz")))
+    def __init__(self, path, container=None):
+        """container: "h5" | "npz" | None = the HDF5 files if the writer has made them (the reference's container), else npz"""
+        h5 = sorted(glob.glob(os.path.join(path, "openpmd_*.h5")))
+        self.container = container or ("h5" if h5 else "npz")
+        files = h5 if self.container == "h5" else sorted(glob.glob(os.path.join(path, "openpmd_*.npz")))
         assert files, f"no openPMD iterations under {path}"
-        self._files = {int(re.search(r"openpmd_(\d+)\.npz$", f).group(1)): f for f in files}
+        self._files = {int(re.search(r"openpmd_(\d+)\.(npz|h5)$", f).group(1)): f for f in files}
         self.iterations = np.array(sorted(self._files))
         z, attrs = self._open(self.iterations[-1])
         base = f"/data/{self.iterations[-1]}"
@@ -39,6 +50,10 @@ class OpenPMDTimeSeries:
             self.avail_record_components[s] = sorted(comps)
 
     def _open(self, iteration):
+        if self.container == "h5":
+            from hipace_amd import openpmd_writer as W
+            arrays, attrs = W.read_hdf5(self._files[int(iteration)])
+            return _Arrays(arrays), attrs
         z = np.load(self._files[int(iteration)])
         return z, json.loads(bytes(z["__attrs__"]).decode())
 

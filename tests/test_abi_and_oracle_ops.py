@@ -256,3 +256,49 @@ def test_openpmd_json_document(tmp_path):
         if k != "__attrs__":
             assert np.array_equal(arrays[k], z[k]), k
     assert attrs["/data/12/fields/rho"]["gridGlobalOffset"] == [-3.0, -2.0, -1.0]
+
+
+def test_openpmd_hdf5_file(tmp_path):
+    """The reference's container: `openpmd_%06T.h5` written through the HDF5 C library (hipace_amd/h5lite.py: ctypes, the image
+    has libhdf5 but neither h5py nor openPMD-api) in the layout of openPMD-api's HDF5 backend -- the hierarchy as groups,
+    records as contiguous datasets of doubles / uint64, constant components as groups with `value` and `shape`, strings as
+    fixed-length H5T_C_S1, bools as the {FALSE, TRUE} enum.  Read back bit for bit; the structure is also looked at with the
+    library's own `h5dump` when the image has it.  (diagnostics/OpenPMDWriter.cpp:55-450)"""
+    import shutil
+    import subprocess
+    import numpy as np
+    from hipace_amd import h5lite, openpmd_writer as W
+    if not h5lite.available():
+        pytest.skip("no HDF5 C library in this image")
+    rng = np.random.default_rng(4)
+    fields = {"Ez": rng.standard_normal((4, 3, 5)), "rho": rng.standard_normal((4, 3, 5))}
+    beam = dict(x=rng.random(7), y=rng.random(7), z=rng.random(7), ux=rng.random(7), uy=rng.random(7), uz=rng.random(7), w=rng.random(7),
+                charge=-1.0, mass=1.0)
+    fn = W.write_iteration(str(tmp_path), 12, 0.5, 0.1, dict(lo=(-1.0, -2.0, -3.0), hi=(1.0, 2.0, 3.0)), fields, {"beam": beam}, hdf5=True)
+    h5 = fn.replace(".npz", ".h5")
+    assert open(h5, "rb").read(8) == b"\x89HDF\r\n\x1a\n"
+    arrays, attrs = W.read_hdf5(h5)
+    z = np.load(fn)
+    for k in z.files:
+        if k != "__attrs__":
+            assert arrays[k].dtype == z[k].dtype and np.array_equal(arrays[k], z[k]), k
+    assert attrs["/"]["openPMD"] == "1.1.0" and attrs["/"]["basePath"] == "/data/%T/" and attrs["/"]["iterationEncoding"] == "fileBased"
+    assert attrs["/data/12"] == {"time": 0.5, "dt": 0.1, "timeUnitSI": 1.0}
+    ez = attrs["/data/12/fields/Ez"]
+    assert ez["axisLabels"] == ["z", "y", "x"] and ez["geometry"] == "cartesian" and ez["gridGlobalOffset"] == [-3.0, -2.0, -1.0]
+    assert ez["unitDimension"] == [0.0] * 7 and ez["unitSI"] == 1.0 and len(ez["gridSpacing"]) == 3
+    ch = attrs["/data/12/particles/beam/charge"]
+    assert ch["value"] == -1.0 and ch["shape"] == [7] and ch["macroWeighted"] == 0
+    assert attrs["/data/12/particles/beam"]["normalized_units"] is True
+    assert attrs["/data/12/particles/beam/positionOffset/x"]["value"] == 0.0
+    # the same through the shim of the reference's checksum backend
+    from tests import openpmd_shim as S
+    ts = S.OpenPMDTimeSeries(str(tmp_path))
+    assert ts.container == "h5" and ts.avail_fields == ["Ez", "rho"] and ts.avail_species == ["beam"]
+    assert S.checksums(str(tmp_path))["lev=0"]["Ez"] == float(np.sum(np.abs(fields["Ez"])))
+    tool = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if os.path.exists("/opt/conda/bin/h5dump") else None)
+    if tool:
+        out = subprocess.run([tool, "-H", h5], capture_output=True, text=True).stdout
+        for want in ('GROUP "fields"', 'DATASET "Ez"', "H5T_IEEE_F64LE", "SIMPLE { ( 4, 3, 5 ) / ( 4, 3, 5 ) }", 'DATASET "id"', "H5T_STD_U64LE",
+                     'GROUP "charge"', 'ATTRIBUTE "openPMD"', "H5T_STD_U32LE", "H5T_ENUM"):
+            assert want in out, want

@@ -365,8 +365,9 @@ def _beam_soa_from_blocks(eng):
 
 
 def test_openpmd_output_reproduces_the_reference_checksums(oracle, tmp_path):
-    """the diagnostics written in the openPMD hierarchy (hipace_amd/openpmd_writer.py; npz container, no
-    HDF5 in this image) and read back through the subset of openPMD-viewer that the reference's checksum backend uses
+    """the diagnostics written in the openPMD hierarchy (hipace_amd/openpmd_writer.py: HDF5 files through the HDF5
+    C library where the image has it -- it does --, and the npz container) and read back through the subset of openPMD-viewer
+    that the reference's checksum backend uses
     (tests/openpmd_shim.py restating tests/checksum/backend/openpmd_backend.py:40-62) give the numbers of the reference's
     benchmark JSON: 12 of the 16 fields and the whole beam block (charge, id, mass, x, y, z, ux, uy, uz, w)."""
     from hipace_amd import openpmd_writer as W
@@ -395,6 +396,11 @@ def test_openpmd_output_reproduces_the_reference_checksums(oracle, tmp_path):
             if grp == "beam" or k in names:
                 assert abs(cs[grp][k] - v) <= 1e-11 * max(abs(v), 1e-300), (grp, k, cs[grp][k], v)
     ts = S.OpenPMDTimeSeries(str(tmp_path))
+    from hipace_amd import h5lite
+    assert ts.container == ("h5" if h5lite.available() else "npz")
+    if ts.container == "h5":        # the npz container holds the same numbers
+        cn = S.OpenPMDTimeSeries(str(tmp_path), container="npz")
+        assert np.array_equal(cn.get_field("Ez", 1)[0], ts.get_field("Ez", 1)[0])
     assert list(ts.iterations) == [0, 1]
     arr, info = ts.get_field("Ez", 1)
     assert arr.shape == (deck["nz"], deck["ny"], deck["nx"]) and info["axisLabels"] == ["z", "y", "x"] and info["dataOrder"] == "C"
