@@ -37,7 +37,8 @@ def write_iteration(prefix, iteration, time, dt, geometry, fields=None, beams=No
                     hdf5=None):
     """Write one openPMD iteration.
 
-    geometry: dict(lo=(x, y, z), hi=(x, y, z)) of the (possibly coarsened) diagnostic grid.
+    geometry: dict(lo=(x, y, z), hi=(x, y, z)[, cells=(nx, ny, nz) of the simulation grid]) of the (possibly coarsened)
+    diagnostic grid.
     fields: {name: array [nz, ny, nx]} (diag_type xyz, as hps_engine_field_diagnostic returns them).
     beams: {name: dict(x, y, z, ux, uy, uz, w, [id], charge, mass)} -- u = proper velocity / c as the engine keeps it
     (normalised units) or in m/s times gamma (SI), written as the reference does (OpenPMDWriter.cpp:376-385: momentum =
@@ -65,19 +66,43 @@ def write_iteration(prefix, iteration, time, dt, geometry, fields=None, beams=No
     for bname, b in (beams or {}).items():
         p = f"{base}/particles/{bname}"
         n = len(b["x"])
+        # multipliers from the engine's units to SI as the reference writes them (OpenPMDWriter.cpp:344-384): the momentum
+        # datasets hold u as the beam keeps it; their unitSI is mass (SI run) or mass * c (normalised run: openPMD-viewer
+        # divides a momentum by mass * c to show u, the reference's "openpmd_viewer_u_workaround", on by default)
+        m_e, q_e, c_SI, ep0 = 9.1093837015e-31, 1.602176634e-19, 299792458.0, 8.8541878128e-12
+        mass = float(b["mass"])
+        to_si = dict(pos=1.0, w=1.0, mom=mass, charge=1.0, mass=1.0)
+        mom_unit = mass
+        if normalized:
+            kp_inv = c_SI / (q_e * np.sqrt(1.0 / (ep0 * m_e)))          # n_0 = 1 (OpenPMDWriter.cpp:353-357)
+            lo, hi = geometry["lo"], geometry["hi"]
+            cell = 1.0                                                    # dx dy dz of the simulation grid, if the caller gives it
+            for ax, nn in zip(range(3), geometry.get("cells", (0, 0, 0))):
+                cell *= (hi[ax] - lo[ax]) / nn if nn else 1.0
+            to_si = dict(pos=kp_inv, w=cell * kp_inv**3, mom=mass * m_e * c_SI, charge=q_e, mass=m_e)
+            mom_unit = mass * c_SI
+        ref = "HiPACE++_reference_unitSI"
         for comp in "xyz":
             arrays[f"{p}/position/{comp}"] = np.asarray(b[comp], dtype=np.float64)
             arrays[f"{p}/momentum/{comp}"] = np.asarray(b["u" + comp], dtype=np.float64)
-            attrs[f"{p}/positionOffset/{comp}"] = dict(value=0.0, shape=[n], unitSI=1.0)
+            attrs[f"{p}/position/{comp}"] = {"unitSI": 1.0, ref: to_si["pos"]}
+            attrs[f"{p}/momentum/{comp}"] = {"unitSI": mom_unit, ref: to_si["mom"]}
+            attrs[f"{p}/positionOffset/{comp}"] = {"value": 0.0, "shape": [n], "unitSI": 1.0, ref: to_si["pos"]}
         arrays[f"{p}/weighting"] = np.asarray(b["w"], dtype=np.float64)
         arrays[f"{p}/id"] = np.asarray(b.get("id", np.arange(1, n + 1)), dtype=np.uint64)
         # constant record components (one value for all particles, OpenPMDWriter.cpp:340-347)
-        attrs[f"{p}/charge"] = dict(value=float(b["charge"]), shape=[n], unitSI=1.0, macroWeighted=0, weightingPower=1.0)
-        attrs[f"{p}/mass"] = dict(value=float(b["mass"]), shape=[n], unitSI=1.0, macroWeighted=0, weightingPower=1.0)
-        attrs[f"{p}/weighting"] = dict(macroWeighted=1, weightingPower=1.0, unitSI=1.0)
-        attrs[f"{p}/position"] = dict(macroWeighted=0, weightingPower=0.0, unitSI=1.0)
-        attrs[f"{p}/momentum"] = dict(macroWeighted=0, weightingPower=1.0, unitSI=1.0)
+        # unitDimension = powers of (L, M, T, I, theta, N, J) (utils/IOUtil.cpp:105-140)
+        attrs[f"{p}/charge"] = {"value": float(b["charge"]), "shape": [n], "unitSI": 1.0, "macroWeighted": 0, "weightingPower": 1.0,
+                                "unitDimension": [0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0], ref: to_si["charge"]}
+        attrs[f"{p}/mass"] = {"value": mass, "shape": [n], "unitSI": 1.0, "macroWeighted": 0, "weightingPower": 1.0,
+                              "unitDimension": [0.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0], ref: to_si["mass"]}
+        attrs[f"{p}/weighting"] = {"macroWeighted": 1, "weightingPower": 1.0, "unitSI": 1.0, ref: to_si["w"]}
+        attrs[f"{p}/position"] = dict(macroWeighted=0, weightingPower=0.0, unitDimension=[1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+        attrs[f"{p}/positionOffset"] = dict(unitDimension=[1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+        attrs[f"{p}/momentum"] = dict(macroWeighted=0, weightingPower=1.0, unitDimension=[1.0, 1.0, -1.0, 0.0, 0.0, 0.0, 0.0])
         attrs[p] = {"HiPACE++_use_reference_unitSI": True, "normalized_units": bool(normalized)}
+        if normalized:
+            attrs[p]["HiPACE++_Plasma_Density"] = 1.0
     fn = os.path.join(prefix, "openpmd_%06d.npz" % iteration)
     np.savez(fn, __attrs__=np.frombuffer(json.dumps(attrs).encode(), dtype=np.uint8), **{k: v for k, v in arrays.items()})
     if json_too:
@@ -219,5 +244,5 @@ def write_engine_output(engine, prefix, iteration, time=0.0, beam_name="beam", b
     if beam is not None:
         beams = {beam_name: dict(x=beam[0], y=beam[1], z=beam[2], ux=beam[3], uy=beam[4], uz=beam[5], w=beam[6],
                                  charge=d["beam_charge"], mass=d.get("beam_mass", 1.0) or 1.0)}
-    return write_iteration(prefix, iteration, time, d.get("dt", 0.0), dict(lo=d["lo"], hi=d["hi"]), fields, beams,
+    return write_iteration(prefix, iteration, time, d.get("dt", 0.0), dict(lo=d["lo"], hi=d["hi"], cells=(d["nx"], d["ny"], d["nz"])), fields, beams,
                            normalized=not d.get("si_units", 0), json_too=json_too, hdf5=hdf5)

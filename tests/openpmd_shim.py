@@ -96,3 +96,21 @@ def checksums(path):
             c = np.sum(np.abs(Q))
             out[s][a] = int(c) if isinstance(c, (np.int64, np.uint64)) else float(c)
     return out
+
+
+H5PY_PYTHON = os.environ.get("HPS_H5PY_PYTHON", "/opt/conda/bin/python3.9")      # an interpreter that has h5py (the system one has not)
+
+
+def h5py_checksums(path):
+    """The same reductions by h5py itself: tests/h5py_reader.py (openPMD-viewer's sequence of h5py accesses) run with the
+    image's conda interpreter.  None where there is no such interpreter."""
+    import subprocess
+    if not os.path.exists(H5PY_PYTHON):
+        return None
+    probe = subprocess.run([H5PY_PYTHON, "-c", "import h5py"], capture_output=True, cwd="/tmp")
+    if probe.returncode != 0:
+        return None
+    r = subprocess.run([H5PY_PYTHON, os.path.join(os.path.dirname(os.path.abspath(__file__)), "h5py_reader.py"), path],
+                       capture_output=True, text=True, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout)

@@ -296,6 +296,10 @@ def test_openpmd_hdf5_file(tmp_path):
     ts = S.OpenPMDTimeSeries(str(tmp_path))
     assert ts.container == "h5" and ts.avail_fields == ["Ez", "rho"] and ts.avail_species == ["beam"]
     assert S.checksums(str(tmp_path))["lev=0"]["Ez"] == float(np.sum(np.abs(fields["Ez"])))
+    hc = S.h5py_checksums(str(tmp_path))          # h5py 3.3 of the image's conda interpreter, openPMD-viewer's access pattern
+    if hc is not None:
+        assert hc["lev=0"]["rho"] == float(np.sum(np.abs(fields["rho"]))) and hc["meta"]["rho"]["gridGlobalOffset"] == [-3.0, -2.0, -1.0]
+        assert abs(hc["beam"]["ux"] - float(np.sum(np.abs(beam["ux"])))) <= 1e-14 and hc["beam"]["id"] == 28 and hc["beam"]["charge"] == 7.0
     tool = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if os.path.exists("/opt/conda/bin/h5dump") else None)
     if tool:
         out = subprocess.run([tool, "-H", h5], capture_output=True, text=True).stdout

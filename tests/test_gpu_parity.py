@@ -1354,6 +1354,13 @@ def test_openpmd_output_of_the_engine(api, tmp_path):
     for grp in ("lev=0", "beam"):
         for k, v in gold[grp].items():
             assert abs(cs[grp][k] - v) <= 1e-9 * max(abs(v), 1e-300), (grp, k, cs[grp][k], v)
+    # the HDF5 files (openpmd_%06T.h5, the reference's container) read by h5py as openPMD-viewer reads them, where the
+    # image has an interpreter with h5py (tests/h5py_reader.py)
+    hc = S.h5py_checksums(str(tmp_path))
+    if hc is not None:
+        for grp in ("lev=0", "beam"):
+            for k, v in gold[grp].items():
+                assert abs(hc[grp][k] - v) <= 1e-9 * max(abs(v), 1e-300), ("h5py", grp, k, hc[grp][k], v)
 
 
 @pytest.mark.gpu

@@ -402,6 +402,14 @@ def test_openpmd_output_reproduces_the_reference_checksums(oracle, tmp_path):
         cn = S.OpenPMDTimeSeries(str(tmp_path), container="npz")
         assert np.array_equal(cn.get_field("Ez", 1)[0], ts.get_field("Ez", 1)[0])
     assert list(ts.iterations) == [0, 1]
+    # ... and h5py itself, reading the files as openPMD-viewer does (an interpreter with h5py: the image's conda python)
+    hc = S.h5py_checksums(str(tmp_path)) if ts.container == "h5" else None
+    if hc is not None:
+        assert hc["iterations"] == [0, 1] and hc["meta"]["Ez"]["axisLabels"] == ["z", "y", "x"]
+        for grp in ("lev=0", "beam"):
+            for k, v in gold[grp].items():
+                if grp == "beam" or k in names:
+                    assert abs(hc[grp][k] - v) <= 1e-11 * max(abs(v), 1e-300), ("h5py", grp, k, hc[grp][k], v)
     arr, info = ts.get_field("Ez", 1)
     assert arr.shape == (deck["nz"], deck["ny"], deck["nx"]) and info["axisLabels"] == ["z", "y", "x"] and info["dataOrder"] == "C"
     assert abs(info["gridSpacing"][0] - (deck["hi"][2] - deck["lo"][2]) / deck["nz"]) < 1e-15
