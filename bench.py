@@ -70,6 +70,20 @@ def algorithmic_bytes(n, ppc2):
     }
 
 
+def slice_bytes(n, ppc2, n_vcycles):
+    """SURVEY 8(d), last rows of the table: algorithmic bytes of one whole slice (explicit solver, no laser) with the
+    reference's pass structure -- deposition, explicit deposition, gather + push, three Poisson solves of 9 passes,
+    right-hand sides / -grad Psi / Sx, Sy / AddRhoIons, the zero and shift slab operations, hpmg solve1 at the measured
+    number of V-cycles -- and the survey's fused lower bound (ideal 4-pass Poisson solves, no zero / shift traffic, the push
+    of slice k and the deposition of slice k-1 sharing the particle reads: 184 B per particle)."""
+    C = n * n
+    P = ppc2 * C
+    mg = 17 * 8 * C + (4.0 / 3.0) * 23 * 8 * C * n_vcycles
+    reference = (56 * P + 32 * C) + (56 * P + 48 * C) + (128 * P + 40 * C) + 3 * (9 * 16 * C + 8 * C) + 176 * C + 152 * C + mg
+    fused = 184 * P + (32 + 48 + 40) * C + 3 * 4 * 16 * C + 176 * C + mg
+    return reference, fused
+
+
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of `kernel_prefix` from the committed rocprofv3 --pmc summary (two separate
     passes, FETCH_SIZE and WRITE_SIZE, scripts/pmc_traffic.py).  Units are KB; on gfx950 FETCH_SIZE reports
@@ -562,6 +576,20 @@ def main():
                          "duration_source": f"HIP events on the engine's stream around the kernel, {nprof} launches of the timed region, "
                                             "minus the interval between two back-to-back event records measured on the same slices"},
         }
+        if not (args.config5 or args.config2):
+            # the whole slice against the HBM roofline: bytes of the reference's pass structure and of the survey's
+            # fused lower bound at the measured V-cycle count, over the measured time per slice of ONE stage
+            nv = out["vcycles_per_slice"]
+            b_ref, b_fused = slice_bytes(args.n, args.ppc * args.ppc, nv)
+            t_slice = 1.0 / out["value"] * world if out["value"] > 0 else 0.0
+            out["roofline"]["slice"] = {
+                "algorithmic_bytes_reference_passes": b_ref, "algorithmic_bytes_fused_lower_bound": b_fused, "vcycles": nv,
+                "achieved_reference_passes": b_ref / t_slice / 1e9 if t_slice else 0.0,
+                "frac_reference_passes": b_ref / t_slice / 1e9 / HBM_PEAK_GBS if t_slice else 0.0,
+                "slices_per_s_at_peak_fused": HBM_PEAK_GBS * 1e9 / b_fused,
+                "note": "bytes per slice from SURVEY 8(d) (what the algorithm has to move, not counter traffic) / seconds per slice of one "
+                        "stage (1 / value per GPU); the engine's own pass structure moves less than the reference's (fused sources, "
+                        "two-pass y transform, fused level-0 multigrid passes, no staging planes)"}
         if args.cpu_slices > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.n, args.ppc, args.cpu_slices, args.cpu_threads or min(os.cpu_count() or 1, CPU_THREADS_DEFAULT))
         emit(out)
