@@ -875,17 +875,20 @@ def test_bench_line_contract():
     assert c["kind"] == "port" and 1 <= c["cores"] <= c["host_cores"] and c["unit"] == "slices/s" and c["value"] > 0
     assert c["serial_value"] > 0
     assert "workload" in d["config"] and "model" not in d["config"]
-    # a short run is not taken at the (cheap) head of the box, every timed slice carries the event timers, and the
-    # line says where the traffic figure comes from
+    # a short run is not taken at the (cheap) head of the box, every 16th timed slice carries the event timers (every 2nd of
+    # fewer than 64), and the line says where the traffic figure comes from
     t = d["timed_slices"]
-    assert t["first"] >= 400 and t["last"] - t["first"] + 1 == 96 and 13 <= d["profiled_slices"] <= 14
+    assert t["first"] >= 400 and t["last"] - t["first"] + 1 == 96 and 5 <= d["profiled_slices"] <= 7
+    sl = r["slice"]
+    assert sl["algorithmic_bytes_fused_lower_bound"] < sl["algorithmic_bytes_reference_passes"] and 0.2 < sl["frac_reference_passes"] < 1.0
     assert r["traffic"] is None or "profiles/" in r["traffic_source"]
     assert d["vcycles_per_slice"] > 1.0
 
 
 @pytest.mark.gpu
 def test_bench_short_run_times_every_slice():
-    """The driver's `--steps 20 --warmup 5`: 20 slices at the representative window, timers on every one of them."""
+    """The driver's `--steps 20 --warmup 5`: 20 slices at the representative window, the four event records of the roofline's
+    kernel duration on every second one of them (on every one they cost 0.9 % of the rate)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -893,7 +896,7 @@ def test_bench_short_run_times_every_slice():
                           "--cpu-slices", "0"], capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
-    assert d["steps"] == 20 and d["warmup"] == 5 and d["profiled_slices"] == 20
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["profiled_slices"] == 10
     assert d["timed_slices"]["first"] >= 400 and d["vcycles_per_slice"] > 1.0
 
 
