@@ -13,6 +13,7 @@ namespace hps {
 // hps_mg_solve1 in two halves (multigrid.hip): kernels enqueued between them are gated on mg_gate_after_enqueued
 int mg_solve1_begin (void* mg_handle, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, double tol_rel, double tol_abs,
                      int max_iters, hipStream_t st);
+int mg_solve1_prepare (void* mg_handle, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, int max_iters, hipStream_t st);
 const int* mg_gate_after_enqueued (void* mg_handle);
 bool mg_solve1_ready (void* mg_handle);
 int mg_solve1_finish (void* mg_handle, int* iters_out, double* resnorm_out, int* extra, hipStream_t st);
@@ -118,6 +119,11 @@ struct Engine {
     // and the push (HPS_LASER_ASYNC=0: on the engine's stream, in the reference's place, Hipace.cpp:637).
     hipStream_t st_laser = nullptr; hipEvent_t ev_lfork = nullptr, ev_ldone = nullptr;
     bool laser_async = true, laser_pending = false;
+    // Small kernels of a slice that wait for nothing on its critical path run on a stream of their own beside it: the beam's
+    // deposition (needs the zeroed beam planes; wanted by the Sx/Sy initialisation behind the Poisson solves) and the
+    // multigrid's coefficient hierarchy (needs chi; wanted by the Bx/By solve).  Measured: 1453-1458 slices/s against 1452-1470 without -- the two event waits cost what the
+    // 14 us of kernels off the chain save -- so this is off unless HPS_AUX_STREAM=1
+    hipStream_t st_aux = nullptr; hipEvent_t ev_aux[3] = {nullptr, nullptr, nullptr}; bool aux_on = false, aux_pending = false;
     hipStream_t laser_stream () const { return (laser_async && st_laser) ? st_laser : st; }
     int fork_laser ();          // the laser stream may read what the engine's stream has written so far
     int laser_done ();          // mark the end of the laser stream's work of this slice

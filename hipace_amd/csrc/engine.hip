@@ -387,6 +387,8 @@ Engine::~Engine ()
     (void)hipFree(d_fd); (void)hipFree(d_fd_comps); (void)hipFree(d_insitu); (void)hipFree(d_insitu_pl); (void)hipFree(d_insitu_bm);
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto e : hand_ev) if (e) (void)hipEventDestroy(e);
+    if (st_aux) (void)hipStreamDestroy(st_aux);
+    for (hipEvent_t ev : ev_aux) if (ev) (void)hipEventDestroy(ev);
     if (st_laser) (void)hipStreamDestroy(st_laser);
     if (ev_lfork) (void)hipEventDestroy(ev_lfork);
     if (ev_ldone) (void)hipEventDestroy(ev_ldone);
@@ -518,6 +520,11 @@ int Engine::create (const hps_deck& deck, int device)
     if (d.field_bc != 0) { set_error("hps_engine_create: only boundary.field = Dirichlet is built"); return HPS_ERR_UNSUPPORTED; }
     pc = (d.bxby_solver != 0);
     if (const char* v = std::getenv("HPS_GATED_PUSH")) gate_push = std::atoi(v) != 0;
+    if (const char* v = std::getenv("HPS_AUX_STREAM")) aux_on = std::atoi(v) != 0;
+    if (aux_on) {
+        HPS_HIP_CHECK(hipStreamCreateWithFlags(&st_aux, hipStreamNonBlocking));
+        for (hipEvent_t& ev : ev_aux) HPS_HIP_CHECK(hipEventCreateWithFlags(&ev, event_flags(false)));
+    }
     if (const char* v = std::getenv("HPS_FOLD_TAIL")) fold_tail = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_GATED_ION_PUSH")) gate_ion_push = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_LAZY_SHIFT")) lazy_shift = std::atoi(v) != 0;
@@ -1322,6 +1329,9 @@ int Engine::solve_slice_begin (int islice)
         // UpdateLaserAabs (Hipace.cpp:603)
         if ((e = laser_update_aabs(*this, islice, diagnostics ? d_laser_sum : nullptr))) return e;
     }
+    // the auxiliary stream may start on the beam's planes (zeroed above)
+    const bool aux = aux_on && st_aux && !pc && !ahead && !prof_now;
+    if (aux) { HPS_HIP_CHECK(hipEventRecord(ev_aux[0], st)); HPS_HIP_CHECK(hipStreamWaitEvent(st_aux, ev_aux[0], 0)); }
 
     mark();   // b1
     // plasma: jx, jy, [rho], chi, rhomjz (Hipace.cpp:609-610); beam: jz_beam on This (:613-614)
@@ -1352,13 +1362,22 @@ int Engine::solve_slice_begin (int islice)
             const BeamView bB{pb, pb + cB, pb + 2*cB, pb + 3*cB, pb + 4*cB, pb + 5*cB, pb + 6*cB};
             const int nbA = (int)ceil_div(cA, 256), nbB = (int)ceil_div(cB, 256);
             const double csq_inv = 1.0/(gm.c*gm.c);
-#define HPS_PAIR(O) hipLaunchKernelGGL(k_beam_deposit_pair<O>, dim3(nbA + nbB), b256, 0, st, f, bA, cA, nbA, HPS_C_JZB, bB, cB, HPS_C_N_JXB, \
+            // (beside the plasma's deposition and the Poisson solves: nothing ahead of the Sx/Sy initialisation reads the beam's planes)
+            hipStream_t sb = (aux && !d.grid_current_on) ? st_aux : st;
+#define HPS_PAIR(O) hipLaunchKernelGGL(k_beam_deposit_pair<O>, dim3(nbA + nbB), b256, 0, sb, f, bA, cA, nbA, HPS_C_JZB, bB, cB, HPS_C_N_JXB, \
                                        HPS_C_N_JYB, d.beam_charge*(d.si_units ? 1.0/(gm.dx*gm.dy*gm.dz) : 1.0), csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff)
             switch (d.order) { case 0: HPS_PAIR(0); break; case 1: HPS_PAIR(1); break; case 2: HPS_PAIR(2); break; default: HPS_PAIR(3); break; }
 #undef HPS_PAIR
         }
     } else if ((e = deposit_beam_slice(islice, -1, -1, HPS_C_JZB))) return e;
     deposit_grid_current(islice, HPS_C_JZB);
+    if (aux) {
+        // chi is final: the multigrid's coefficient hierarchy on the auxiliary stream, joined ahead of the Sx/Sy initialisation
+        HPS_HIP_CHECK(hipEventRecord(ev_aux[1], st)); HPS_HIP_CHECK(hipStreamWaitEvent(st_aux, ev_aux[1], 0));
+        if ((e = mg_solve1_prepare(mg, slab, HPS_C_BX, HPS_C_SY, HPS_C_CHI, 200, st_aux))) return e;
+        HPS_HIP_CHECK(hipEventRecord(ev_aux[2], st_aux));
+        aux_pending = true;
+    }
 
     // AddRhoIons + Psi, Ez, Bz solves + -grad Psi (fields/Fields.cpp:840-957)
     {   const double fa = 1.0/(gm.ep0*gm.c);
@@ -1394,6 +1413,7 @@ int Engine::solve_slice_begin (int islice)
     if (laser_now && !laser_split) { if ((e = laser_advance_slice(*this, islice))) return e; }
     if (laser_split) { if ((e = fork_laser())) return e; }
     if (laser_split && d.laser_solver == 1) { if ((e = laser_advance_slice(*this, islice)) || (e = laser_done())) return e; }
+    if (aux_pending) { HPS_HIP_CHECK(hipStreamWaitEvent(st, ev_aux[2], 0)); aux_pending = false; }
     if (pair || nbeam == 0) {
         // -grad Psi and the beam part of Sx, Sy (Hipace.cpp:659-660) in one pass (without a beam there is no deposition between them either)
         hipLaunchKernelGGL(k_gradpsi_sxsy, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_PSI, HPS_C_EXMBY, HPS_C_EYPBX,

@@ -1347,6 +1347,7 @@ struct SolveRun { int enq, nspec, nzeroed, max_iters; double tol_rel, tol_abs; b
 
 struct Multigrid {
     bool cc; int nx, ny; double dx, dy;
+    bool hierarchy_ready = false;               // mg_solve1_prepare has enqueued the coefficient hierarchy of the next solve
     std::vector<MGLevelDev> L;
     int lowv_begin = 1;                         // first level handled by k_lower_v
     LowLev* d_low = nullptr; size_t low_lds = 0;
@@ -1625,14 +1626,15 @@ static void enqueue_cycles (Multigrid* M, hipStream_t st)
                        reinterpret_cast<int*>(M->d_buf) + MG_GO_WORD, StopRule{M->d_norms, r.enq, r.tol_rel, r.tol_abs});
 }
 
+// The coefficient hierarchy of a solve (average_down_acoef, HpMultiGrid.cpp:1640-1700; level 0 reads the slab) and the zeroing
+// of its norm slots.  It needs the coefficient (chi) only, not the right-hand side: mg_solve1_prepare lets the caller
+// enqueue it early, on a stream of its own, beside whatever produces the right-hand side.
 template <bool CC>
-static int solve1_begin (Multigrid* M, double tol_rel, double tol_abs, int max_iters, hipStream_t st)
+static int solve1_hierarchy (Multigrid* M, int max_iters, hipStream_t st)
 {
     const int lb = M->lowv_begin;
     max_iters = std::min(max_iters, MG_MAX_VCYCLES);
-    M->cor_in_tmp = false;
     const StopRule always{nullptr, -1, 0.0, 0.0};
-    // coefficient hierarchy (average_down_acoef, HpMultiGrid.cpp:1640-1700); level 0 reads the slab
     // speculate as many V-cycles as the previous solve needed; each one is a no-op once converged
     int nspec = std::min(std::max(M->last_iters, 1), std::max(max_iters, 1));
     int nzeroed = std::min(max_iters, nspec + 8);
@@ -1662,6 +1664,20 @@ static int solve1_begin (Multigrid* M, double tol_rel, double tol_abs, int max_i
         hipLaunchKernelGGL(k_level_cinv, dim3(ceil_div(lnx, 64), lny), dim3(64), 0, st, M->L[lb].acf, M->cinvA, lnx, lny,
                            1.0/(M->dx*lfac*M->dx*lfac), 1.0/(M->dy*lfac*M->dy*lfac));
     }
+    HPS_HIP_CHECK(hipGetLastError());
+    return HPS_OK;
+}
+
+template <bool CC>
+static int solve1_begin (Multigrid* M, double tol_rel, double tol_abs, int max_iters, hipStream_t st)
+{
+    max_iters = std::min(max_iters, MG_MAX_VCYCLES);
+    M->cor_in_tmp = false;
+    const StopRule always{nullptr, -1, 0.0, 0.0};
+    int nspec = std::min(std::max(M->last_iters, 1), std::max(max_iters, 1));
+    int nzeroed = std::min(max_iters, nspec + 8);
+    if (M->hierarchy_ready) M->hierarchy_ready = false;       // (mg_solve1_prepare has enqueued it; the caller has ordered the streams)
+    else if (int e = solve1_hierarchy<CC>(M, max_iters, st)) return e;
     // cor[0] = GSRB^4(sol), residual norm, rhs norm, res[1] = R(residual)  (solve_doit :1319-1346)
     // (optional 64 x 48 tiles: 494 workgroups at 1024^2 instead of 817 -- measured slower, see init_huge)
     if (M->init_huge && M->L[0].cells > M->small_tile_cells)
@@ -1759,6 +1775,16 @@ int mg_solve1_begin (void* handle, hps_slab s, int sol_comp, int rhs_comp, int a
     Multigrid* M = static_cast<Multigrid*>(handle);
     set_views(M, s, sol_comp, rhs_comp, acf_comp);
     return M->cc ? solve1_begin<true>(M, tol_rel, tol_abs, max_iters, st) : solve1_begin<false>(M, tol_rel, tol_abs, max_iters, st);
+}
+// the coefficient hierarchy of the NEXT mg_solve1_begin (same slab, same components, same max_iters) on stream `st`, which
+// the caller orders: behind whatever writes the coefficient, ahead of mg_solve1_begin's stream
+int mg_solve1_prepare (void* handle, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, int max_iters, hipStream_t st)
+{
+    Multigrid* M = static_cast<Multigrid*>(handle);
+    set_views(M, s, sol_comp, rhs_comp, acf_comp);
+    if (int e = M->cc ? solve1_hierarchy<true>(M, max_iters, st) : solve1_hierarchy<false>(M, max_iters, st)) return e;
+    M->hierarchy_ready = true;
+    return HPS_OK;
 }
 const int* mg_gate_after_enqueued (void* handle)
 {
