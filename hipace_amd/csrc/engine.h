@@ -7,6 +7,7 @@
 #include "tiling.h"
 #include "particle_math.h"
 #include "poisson_src.h"
+#include "beam_deposit.h"
 
 void mg_rider (void* mg_handle, int** dev_words, const int** host_words);     // multigrid.hip
 namespace hps {
@@ -23,7 +24,6 @@ namespace hps {
 
 struct LaserState;      // laser.hip
 
-struct BeamView { double *x, *y, *z, *ux, *uy, *uz, *w; };
 struct BeamSoA { double *x, *y, *z, *ux, *uy, *uz, *w; int* nsub;      // moving beam (beam.hip); nsub < 0: absorbed
                  double *sx, *sy, *sz; };                              // spin (do_spin_tracking), null otherwise
 
@@ -61,7 +61,8 @@ struct Engine {
     hps_plasma tail_of (const hps_plasma& p, long first, long n) const;
     bool fold_tail = true;                     // the particles behind the tile-sorted body ride in the tile kernels' launches (HPS_FOLD_TAIL=0: off)
     TailWork fold_tail_of (const hps_plasma& p, const Tiling* T, long margin, long* covered) const;
-    int species_deposit (const hps_plasma& p, Tiling* T, const int comp[6], double charge, double mass, int can_ionize);
+    int species_deposit (const hps_plasma& p, Tiling* T, const int comp[6], double charge, double mass, int can_ionize, const BeamPairWork* beam = nullptr);
+    bool fold_beam = true;                     // the static beam's two deposits of a slice as extra workgroups of the plasma's deposition (HPS_FOLD_BEAM=0: a launch of their own)
     int species_explicit (const hps_plasma& p, Tiling* T, const int cache[4], const int depos[2], double charge, double mass, int can_ionize);
     int species_advance (const hps_plasma& p, Tiling* T, const int comp[5], double charge, double mass, int temp_slice, int can_ionize);
     // tile-sorted sheet (sort.hip): second SoA buffer + tiling state

@@ -14,7 +14,8 @@ namespace hps {
 
 int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[6], double charge,
                            double mass, int order, double max_qsa, int can_ionize, int* n_qsa, Tiling* T, int* n_fallback,
-                           hipStream_t st, int aabs_comp = -1, const int* tile_flag = nullptr, TailWork tw = TailWork{});
+                           hipStream_t st, int aabs_comp = -1, const int* tile_flag = nullptr, TailWork tw = TailWork{},
+                           const BeamPairWork* beam = nullptr);
 int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int cache[4], const int depos[2],
                             double charge, double mass, int order, int dtype, int can_ionize, Tiling* T, int* n_fallback,
                             hipStream_t st, int aabs_comp = -1, const int* tile_flag = nullptr, TailWork tw = TailWork{});
@@ -334,29 +335,9 @@ void k_beam_deposit (SlabView f, BeamView b, long first, long count, int cjx, in
 // [0, nbA)) and jx, jy of the next slice's block (the rest) -- different components, no ordering between them
 template <int ORDER>
 __global__ __launch_bounds__(256)
-void k_beam_deposit_pair (SlabView f, BeamView bA, long countA, int nbA, int cjzA, BeamView bB, long countB, int cjxB, int cjyB,
-                          double q_invvol, double clightsq_inv, double dx_inv, double dy_inv, double xoff, double yoff)
+void k_beam_deposit_pair (SlabView f, BeamPairWork w, double dx_inv, double dy_inv, double xoff, double yoff)
 {
-    const bool second = (int)blockIdx.x >= nbA;
-    const BeamView& b = second ? bB : bA;
-    const long ip = (long)(second ? blockIdx.x - nbA : blockIdx.x)*blockDim.x + threadIdx.x;
-    if (ip >= (second ? countB : countA)) return;
-    const double ux = b.ux[ip], uy = b.uy[ip], uz = b.uz[ip];
-    const double gaminv = 1.0/sqrt(1.0 + ux*ux*clightsq_inv + uy*uy*clightsq_inv + uz*uz*clightsq_inv);
-    const double wq = q_invvol*b.w[ip];
-    double sx[ORDER + 1], sy[ORDER + 1];
-    const int i0 = shape_weights<ORDER>((b.x[ip] - xoff)*dx_inv, sx);
-    const int j0 = shape_weights<ORDER>((b.y[ip] - yoff)*dy_inv, sy);
-#pragma unroll
-    for (int iy = 0; iy <= ORDER; ++iy) {
-#pragma unroll
-        for (int ix = 0; ix <= ORDER; ++ix) {
-            double* p = f.p + f.off(i0 + ix, j0 + iy);
-            const double s = sx[ix]*sy[iy];
-            if (second) { atomic_add_f64(p + cjxB*f.ns, s*(wq*(ux*gaminv))); atomic_add_f64(p + cjyB*f.ns, s*(wq*(uy*gaminv))); }
-            else atomic_add_f64(p + cjzA*f.ns, s*(wq*(uz*gaminv)));
-        }
-    }
+    beam_pair_block<ORDER>(f, w, (int)blockIdx.x, dx_inv, dy_inv, xoff, yoff);
 }
 
 __global__ __launch_bounds__(256)
@@ -526,6 +507,7 @@ int Engine::create (const hps_deck& deck, int device)
         for (hipEvent_t& ev : ev_aux) HPS_HIP_CHECK(hipEventCreateWithFlags(&ev, event_flags(false)));
     }
     if (const char* v = std::getenv("HPS_FOLD_TAIL")) fold_tail = std::atoi(v) != 0;
+    if (const char* v = std::getenv("HPS_FOLD_BEAM")) fold_beam = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_GATED_ION_PUSH")) gate_ion_push = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_LAZY_SHIFT")) lazy_shift = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_FUSE_SOURCES")) fuse_sources = std::atoi(v) != 0;
@@ -811,12 +793,12 @@ TailWork Engine::fold_tail_of (const hps_plasma& p, const Tiling* T, long margin
     *covered = T->sorted_n + 256L*tw.nwg;
     return tw;
 }
-int Engine::species_deposit (const hps_plasma& p, Tiling* T, const int comp[6], double charge, double mass, int can_ionize)
+int Engine::species_deposit (const hps_plasma& p, Tiling* T, const int comp[6], double charge, double mass, int can_ionize, const BeamPairWork* beam)
 {
     if (p.n == 0) return HPS_OK;
     if (!T) return hps_deposit_current_laser(slab, p, gm, comp, c_aabs, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, st);
     long covered; const TailWork tw = fold_tail_of(p, T, 0, &covered);
-    if (T->sorted_n > 0) { if (int e = deposit_current_tiled(slab, p, gm, comp, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, T, d_nfallback, st, c_aabs, T == ion.tiling ? ion.d_tile_flag : nullptr, tw)) return e; }
+    if (T->sorted_n > 0) { if (int e = deposit_current_tiled(slab, p, gm, comp, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, T, d_nfallback, st, c_aabs, T == ion.tiling ? ion.d_tile_flag : nullptr, tw, beam)) return e; }
     if (p.n > covered) return hps_deposit_current_laser(slab, tail_of(p, covered, p.n - covered), gm, comp, c_aabs, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, st);
     return HPS_OK;
 }
@@ -1343,29 +1325,33 @@ int Engine::solve_slice_begin (int islice)
                    (since_sort >= 1 && np - tiling->sorted_n > std::max(np/32, 16384L)))) { if ((e = resort())) return e; }
     ++since_sort;
     mark();   // b1b
-    if (!ahead)
-    {   const int comp[6] = {HPS_C_JX, HPS_C_JY, -1, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_CHI, HPS_C_RHOMJZ};
-        if ((e = species_deposit(pl, tiling, comp, d.plasma_charge, d.plasma_mass, 0))) return e;
-        // MultiPlasma::DepositCurrent: every species in turn (MultiPlasma.cpp:78-87); an ion weighs in with its level
-        if (ion.n > 0) { if ((e = species_deposit(ion.pl, ion.tiling, comp, d.ion_charge, d.ion_mass, 1))) return e; } }
-    mark();   // b2
-    // static beam: jz of this slice and jx, jy of the next one in one launch (Hipace.cpp:613-614, 656-657); a moving
-    // beam keeps the two calls (the next slice's block is only final once this slice's push has handed its slipped
-    // particles on -- it is deposited after the solves below as before)
+    // static beam: jz of this slice and jx, jy of the next one in one go (Hipace.cpp:613-614, 656-657), as extra workgroups of
+    // the plasma's deposition where that runs on tiles; a moving beam keeps the two calls (the next slice's block is only
+    // final once this slice's push has handed its slipped particles on -- it is deposited after the solves below as before)
     const bool pair = !moving && nbeam > 0;
+    BeamPairWork bw;
     if (pair) {
         const long fA = beam_off[d.nz - 1 - islice], cA = beam_off[d.nz - islice] - fA;
         const long fB = islice >= 1 ? beam_off[d.nz - islice] : 0, cB = islice >= 1 ? beam_off[d.nz - islice + 1] - fB : 0;
-        if (cA + cB > 0) {
-            double* pa = beam_cur + 7*fA; double* pb = beam_cur + 7*fB;
-            const BeamView bA{pa, pa + cA, pa + 2*cA, pa + 3*cA, pa + 4*cA, pa + 5*cA, pa + 6*cA};
-            const BeamView bB{pb, pb + cB, pb + 2*cB, pb + 3*cB, pb + 4*cB, pb + 5*cB, pb + 6*cB};
-            const int nbA = (int)ceil_div(cA, 256), nbB = (int)ceil_div(cB, 256);
-            const double csq_inv = 1.0/(gm.c*gm.c);
+        double* pa = beam_cur + 7*fA; double* pb = beam_cur + 7*fB;
+        bw.a = BeamView{pa, pa + cA, pa + 2*cA, pa + 3*cA, pa + 4*cA, pa + 5*cA, pa + 6*cA};
+        bw.b = BeamView{pb, pb + cB, pb + 2*cB, pb + 3*cB, pb + 4*cB, pb + 5*cB, pb + 6*cB};
+        bw.ca = cA; bw.cb = cB; bw.nba = (int)ceil_div(cA, 256); bw.nwg = bw.nba + (int)ceil_div(cB, 256);
+        bw.cjz = HPS_C_JZB; bw.cjxn = HPS_C_N_JXB; bw.cjyn = HPS_C_N_JYB;
+        bw.q_invvol = d.beam_charge*(d.si_units ? 1.0/(gm.dx*gm.dy*gm.dz) : 1.0); bw.csq_inv = 1.0/(gm.c*gm.c);
+    }
+    const bool beam_folded = pair && fold_beam && bw.nwg > 0 && !ahead && np > 0 && tiling && tiling->sorted_n > 0;
+    if (!ahead)
+    {   const int comp[6] = {HPS_C_JX, HPS_C_JY, -1, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_CHI, HPS_C_RHOMJZ};
+        if ((e = species_deposit(pl, tiling, comp, d.plasma_charge, d.plasma_mass, 0, beam_folded ? &bw : nullptr))) return e;
+        // MultiPlasma::DepositCurrent: every species in turn (MultiPlasma.cpp:78-87); an ion weighs in with its level
+        if (ion.n > 0) { if ((e = species_deposit(ion.pl, ion.tiling, comp, d.ion_charge, d.ion_mass, 1))) return e; } }
+    mark();   // b2
+    if (pair) {
+        if (!beam_folded && bw.nwg > 0) {
             // (beside the plasma's deposition and the Poisson solves: nothing ahead of the Sx/Sy initialisation reads the beam's planes)
             hipStream_t sb = (aux && !d.grid_current_on) ? st_aux : st;
-#define HPS_PAIR(O) hipLaunchKernelGGL(k_beam_deposit_pair<O>, dim3(nbA + nbB), b256, 0, sb, f, bA, cA, nbA, HPS_C_JZB, bB, cB, HPS_C_N_JXB, \
-                                       HPS_C_N_JYB, d.beam_charge*(d.si_units ? 1.0/(gm.dx*gm.dy*gm.dz) : 1.0), csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff)
+#define HPS_PAIR(O) hipLaunchKernelGGL(k_beam_deposit_pair<O>, dim3(bw.nwg), b256, 0, sb, f, bw, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff)
             switch (d.order) { case 0: HPS_PAIR(0); break; case 1: HPS_PAIR(1); break; case 2: HPS_PAIR(2); break; default: HPS_PAIR(3); break; }
 #undef HPS_PAIR
         }

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "particle_math.h"
 #include "tiling.h"
+#include "beam_deposit.h"
 
 #include <cstdlib>
 
@@ -104,7 +105,7 @@ __device__ __forceinline__ int4 tile_record (const int* __restrict__ offsets, co
         const long first = (long)tw.first + 256L*blockIdx.x;
         return make_int4(0, (int)min(first, nn), (int)min(first + 256, nn), 0);
     }
-    return reinterpret_cast<const int4*>(offsets + tile_launch_offset(gridDim.x - tw.nwg))[b];
+    return reinterpret_cast<const int4*>(offsets + tile_launch_offset(gridDim.x - tw.nwg - tw.extra))[b];
 }
 constexpr int TAIL_ORIGIN = -(1 << 24);      // "tile origin" of a tail workgroup: no particle is local to it
 
@@ -127,8 +128,14 @@ constexpr int TAIL_ORIGIN = -(1 << 24);      // "tile origin" of a tail workgrou
 template <int ORDER, int TS, int MASK, bool LASER = false>
 __global__ __launch_bounds__(256)
 void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx, DepComps cm,
-                      PartConsts k, int* n_qsa, int* n_fallback, const int* __restrict__ tile_flag, TailWork tw)
+                      PartConsts k, int* n_qsa, int* n_fallback, const int* __restrict__ tile_flag, TailWork tw, BeamPairWork bw)
 {
+    // the last bw.nwg workgroups: the static beam's deposits of this slice (beam_deposit.h) -- a 7.9 us launch of a few
+    // thousand particles that nothing ahead of the Sx/Sy initialisation waits for, off the slice's chain of launches
+    if (bw.nwg > 0 && (int)blockIdx.x >= (int)gridDim.x - bw.nwg) {
+        beam_pair_block<ORDER>(f, bw, (int)blockIdx.x - ((int)gridDim.x - bw.nwg), k.dx_inv, k.dy_inv, k.xoff, k.yoff);
+        return;
+    }
     constexpr int R = TS + 2*TILE_HALO;
     constexpr int RP = R + HPS_DEP_PAD, PL = RP*R;      // row pitch and plane size of the accumulators (HPS_DEP_PAD, below)
     // an ionisable species: tiles that hold no charged ion have nothing to deposit (flag written by the species' push)
@@ -884,9 +891,11 @@ static int set_lds (K kernel, size_t bytes)
 
 int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[6], double charge,
                            double mass, int order, double max_qsa, int can_ionize, int* n_qsa, Tiling* T, int* n_fallback,
-                           hipStream_t st, int aabs_comp, const int* tile_flag, TailWork tw)
+                           hipStream_t st, int aabs_comp, const int* tile_flag, TailWork tw, const BeamPairWork* beam)
 {
     if (pl.n == 0) return HPS_OK;
+    const BeamPairWork bw = beam ? *beam : BeamPairWork{};
+    tw.extra = bw.nwg;
     PartConsts k = base_consts(g);
     k.a = charge*invvol_of(g); k.b = charge*g.mu0/mass; k.max_qsa = max_qsa; k.can_ionize = can_ionize;
     k.aabs = aabs_comp; k.laser_fac = (charge/g.q_e)*(g.m_e/mass)*(charge/g.q_e)*(g.m_e/mass);
@@ -897,9 +906,9 @@ int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
     SlabView f(slab);
     int mask = 0; for (int c = 0; c < 6; ++c) mask |= (comp[c] >= 0) << c;
 #define CALLM(O, S, M) { if (int e = set_lds(k_deposit_tiled<O, S, M>, lds)) return e; \
-        hipLaunchKernelGGL((k_deposit_tiled<O, S, M>), dim3(T->g.ntiles + tw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag, tw); }
+        hipLaunchKernelGGL((k_deposit_tiled<O, S, M>), dim3(T->g.ntiles + tw.nwg + bw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag, tw, bw); }
 #define CALLL(O, S, M) { if (int e = set_lds(k_deposit_tiled<O, S, M, true>, lds)) return e; \
-        hipLaunchKernelGGL((k_deposit_tiled<O, S, M, true>), dim3(T->g.ntiles + tw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag, tw); }
+        hipLaunchKernelGGL((k_deposit_tiled<O, S, M, true>), dim3(T->g.ntiles + tw.nwg + bw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag, tw, bw); }
 #define CALL(O, S) { if (aabs_comp >= 0) { if (mask == 51) CALLL(O, S, 51) else CALLL(O, S, -1) } \
                      else if (mask == 51) CALLM(O, S, 51) else if (mask == 59) CALLM(O, S, 59) else if (mask == 32) CALLM(O, S, 32) \
                      else if (mask == 3) CALLM(O, S, 3) else if (mask == 39) CALLM(O, S, 39) else if (mask == 47) CALLM(O, S, 47) else CALLM(O, S, -1) }
@@ -1038,7 +1047,7 @@ extern "C" int hps_deposit_current_tiled (hps_slab slab, hps_plasma pl, hps_geom
     if (int e = check_tiling(tiling, slab, pl, "hps_deposit_current_tiled")) return e;
     for (int c = 0; c < 6; ++c) HPS_REQUIRE(comp[c] >= -1 && comp[c] < slab.ncomp, "hps_deposit_current_tiled: bad component");
     return deposit_current_tiled(slab, pl, g, comp, charge, mass, order, max_qsa, can_ionize, n_qsa,
-                                 static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr, TailWork{});
+                                 static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr, TailWork{}, nullptr);
 }
 
 extern "C" int hps_explicit_deposit_tiled (hps_slab slab, hps_plasma pl, hps_geom g, const int cache[4], const int depos[2],
