@@ -8,6 +8,7 @@
 #include "particle_math.h"
 #include "poisson_src.h"
 #include "beam_deposit.h"
+#include "slab_ops.h"
 
 void mg_rider (void* mg_handle, int** dev_words, const int** host_words);     // multigrid.hip
 namespace hps {
@@ -15,6 +16,10 @@ namespace hps {
 int mg_solve1_begin (void* mg_handle, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, double tol_rel, double tol_abs,
                      int max_iters, hipStream_t st);
 int mg_solve1_prepare (void* mg_handle, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, int max_iters, hipStream_t st);
+// ... in one launch with the -grad Psi / Sx, Sy pass of the slab (multigrid.hip: k_hierarchy_gradpsi); *done = false if this grid's
+// hierarchy needs more than that launch (then nothing has been enqueued)
+int mg_solve1_prepare_with (void* mg_handle, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, int max_iters, SlabView f, GradPsiSxSy ga,
+                            hipStream_t st, bool* done);
 const int* mg_gate_after_enqueued (void* mg_handle);
 bool mg_solve1_ready (void* mg_handle);
 int mg_solve1_finish (void* mg_handle, int* iters_out, double* resnorm_out, int* extra, hipStream_t st);
@@ -62,6 +67,7 @@ struct Engine {
     bool fold_tail = true;                     // the particles behind the tile-sorted body ride in the tile kernels' launches (HPS_FOLD_TAIL=0: off)
     TailWork fold_tail_of (const hps_plasma& p, const Tiling* T, long margin, long* covered) const;
     int species_deposit (const hps_plasma& p, Tiling* T, const int comp[6], double charge, double mass, int can_ionize, const BeamPairWork* beam = nullptr);
+    bool fold_hierarchy = true;                // the multigrid's coefficient hierarchy in the -grad Psi / Sx, Sy launch (HPS_FOLD_HIERARCHY=0: in mg_solve1_begin)
     bool fold_beam = true;                     // the static beam's two deposits of a slice as extra workgroups of the plasma's deposition (HPS_FOLD_BEAM=0: a launch of their own)
     int species_explicit (const hps_plasma& p, Tiling* T, const int cache[4], const int depos[2], double charge, double mass, int can_ionize);
     int species_advance (const hps_plasma& p, Tiling* T, const int comp[5], double charge, double mass, int temp_slice, int can_ionize);

@@ -35,7 +35,6 @@ void set_error (const std::string& msg) { g_err = msg; }
 // ------------------------------------------------------------------------------------------
 struct CompList { int n; int c[12]; };
 
-struct CellBox { int ilo, ihi, jlo, jhi; };     // padded-array cell range, inclusive
 
 // zero the components of `full` everywhere and those of `boxed` inside the box
 __global__ __launch_bounds__(256)
@@ -217,31 +216,9 @@ void k_sxsy_beam (SlabView f, int cSx, int cSy, int cJzb, int cNx, int cNy, int 
 
 // -grad Psi (k_grad_psi) and the beam part of Sx, Sy (k_sxsy_beam) in one pass over the plane: one launch less per slice
 __global__ __launch_bounds__(256)
-void k_gradpsi_sxsy (SlabView f, int cPsi, int cExmBy, int cEypBx, double hdx_inv, double hdy_inv,
-                     int cSx, int cSy, int cJzb, int cNx, int cNy, int cPx, int cPy,
-                     double mu0, double dx2, double dy2, double dz2, CellBox bb)
+void k_gradpsi_sxsy (SlabView f, GradPsiSxSy a)
 {
-    const int i = blockIdx.x*blockDim.x + threadIdx.x - f.ng;
-    const int j = blockIdx.y - f.ng;
-    if (i >= f.nx + f.ng) return;
-    const long o = f.off(i, j);
-    const int gg = f.ng - 1;
-    if (i >= -gg && i < f.nx + gg && j >= -gg && j < f.ny + gg) {
-        const double* P = f.p + cPsi*f.ns + o;
-        f.p[cExmBy*f.ns + o] = -(P[1] - P[-1])*hdx_inv;
-        f.p[cEypBx*f.ns + o] = -(P[f.js] - P[-f.js])*hdy_inv;
-    }
-    const int ia = i + f.ng, ja = j + f.ng;
-    if (i < 0 || i >= f.nx || j < 0 || j >= f.ny || ia < bb.ilo || ia > bb.ihi || ja < bb.jlo || ja > bb.jhi) {
-        f.p[cSy*f.ns + o] = 0.0; f.p[cSx*f.ns + o] = 0.0; return;
-    }
-    const double* J = f.p + cJzb*f.ns + o;
-    const double dx_jzb = (J[1] - J[-1])/dx2;
-    const double dy_jzb = (J[f.js] - J[-f.js])/dy2;
-    const double dz_jxb = (f.p[cPx*f.ns + o] - f.p[cNx*f.ns + o])/dz2;
-    const double dz_jyb = (f.p[cPy*f.ns + o] - f.p[cNy*f.ns + o])/dz2;
-    f.p[cSy*f.ns + o] =  mu0*(-dy_jzb + dz_jyb);
-    f.p[cSx*f.ns + o] = -mu0*(-dx_jzb + dz_jxb);
+    gradpsi_sxsy_cell(f, a, (int)(blockIdx.x*blockDim.x + threadIdx.x) - f.ng, (int)blockIdx.y - f.ng);
 }
 
 // per-component sum |Q| over the valid cells, accumulated into acc[n]
@@ -508,6 +485,7 @@ int Engine::create (const hps_deck& deck, int device)
     }
     if (const char* v = std::getenv("HPS_FOLD_TAIL")) fold_tail = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_FOLD_BEAM")) fold_beam = std::atoi(v) != 0;
+    if (const char* v = std::getenv("HPS_FOLD_HIERARCHY")) fold_hierarchy = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_GATED_ION_PUSH")) gate_ion_push = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_LAZY_SHIFT")) lazy_shift = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_FUSE_SOURCES")) fuse_sources = std::atoi(v) != 0;
@@ -1402,9 +1380,16 @@ int Engine::solve_slice_begin (int islice)
     if (aux_pending) { HPS_HIP_CHECK(hipStreamWaitEvent(st, ev_aux[2], 0)); aux_pending = false; }
     if (pair || nbeam == 0) {
         // -grad Psi and the beam part of Sx, Sy (Hipace.cpp:659-660) in one pass (without a beam there is no deposition between them either)
-        hipLaunchKernelGGL(k_gradpsi_sxsy, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_PSI, HPS_C_EXMBY, HPS_C_EYPBX,
-                           0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy), HPS_C_SX, HPS_C_SY, HPS_C_JZB, HPS_C_N_JXB, HPS_C_N_JYB, HPS_C_P_JXB, HPS_C_P_JYB,
-                           gm.mu0, 2.0*gm.dx, 2.0*gm.dy, 2.0*gm.dz, bb);
+        const GradPsiSxSy ga{HPS_C_PSI, HPS_C_EXMBY, HPS_C_EYPBX, 0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy), HPS_C_SX, HPS_C_SY, HPS_C_JZB, HPS_C_N_JXB, HPS_C_N_JYB,
+                             HPS_C_P_JXB, HPS_C_P_JYB, gm.mu0, 2.0*gm.dx, 2.0*gm.dy, 2.0*gm.dz, bb};
+        // ... and, in the same launch, the coefficient hierarchy of the Bx/By multigrid solve (it needs chi only): one launch less
+        // on the chain between the explicit deposition and the first smoothing pass
+        bool with_hierarchy = false;
+        if (fold_hierarchy && !pc && !aux) {
+            if ((e = mg_solve1_prepare_with(mg, slab, HPS_C_BX, HPS_C_SY, HPS_C_CHI, 200, f, ga, st, &with_hierarchy))) return e;
+        }
+        if (!with_hierarchy)
+            hipLaunchKernelGGL(k_gradpsi_sxsy, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, ga);
         mark();   // b3
     } else {
         hipLaunchKernelGGL(k_grad_psi, dim3(ceil_div(d.nx + 2*(g - 1), 256), d.ny + 2*(g - 1)), b256, 0, st, f, HPS_C_PSI,

@@ -19,6 +19,7 @@
 //    its arrays in LDS (whole lower V incl. the 16 bottom sweeps), replacing ~4 launches per level.
 #include "common.h"
 #include "mg_gate.h"
+#include "slab_ops.h"
 
 #include <vector>
 #include <algorithm>
@@ -1283,14 +1284,14 @@ void k_lower_v3 (const Low2* __restrict__ dp, const double* __restrict__ acf_g, 
 struct PyrOut { double* p[5]; int nx[5], ny[5];      // levels 1..5, row pitch = nx
                 double* cinv; int cinv_l; double cfx, cfy; };      // inverse diagonals of level 1 + cinv_l (k_lower_v3's level A), or null
 
-__global__ __launch_bounds__(256)
-void k_acf_pyramid (FView acf0, int nx0, int ny0, PyrOut out, int nlev_out, unsigned long long* zero, int nzero)
+__device__ __forceinline__ void acf_pyramid_block (const FView& acf0, int nx0, int ny0, const PyrOut& out, int nlev_out, unsigned long long* zero, int nzero,
+                                                   int bx, int by)
 {
     // the first launch of a solve: it also clears the norm slots (saves a memset launch)
-    if (blockIdx.x == 0 && blockIdx.y == 0) for (int q = threadIdx.x; q < nzero; q += 256) zero[q] = 0ULL;
+    if (bx == 0 && by == 0) for (int q = threadIdx.x; q < nzero; q += 256) zero[q] = 0ULL;
     __shared__ double s_a[2][16*16];
     const int t = threadIdx.x;
-    const int bi = blockIdx.x*32, bj = blockIdx.y*32;       // level-0 origin of the block
+    const int bi = bx*32, bj = by*32;       // level-0 origin of the block
     int li = t & 15, lj = t >> 4;
     double v = 0.0;
     {
@@ -1321,6 +1322,26 @@ void k_acf_pyramid (FView acf0, int nx0, int ny0, PyrOut out, int nlev_out, unsi
         }
         cur ^= 1;
     }
+}
+
+__global__ __launch_bounds__(256)
+void k_acf_pyramid (FView acf0, int nx0, int ny0, PyrOut out, int nlev_out, unsigned long long* zero, int nzero)
+{
+    acf_pyramid_block(acf0, nx0, ny0, out, nlev_out, zero, nzero, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// the pyramid's blocks (the first gx*gy workgroups) and, behind them, a pass of the engine's slab that is due at the same point of
+// a slice: -grad Psi and the Sx / Sy initialisation (slab_ops.h), 256 cells of a padded row per workgroup -- the coefficient
+// hierarchy costs the slice no launch of its own
+__global__ __launch_bounds__(256)
+void k_hierarchy_gradpsi (FView acf0, int nx0, int ny0, PyrOut out, int nlev_out, unsigned long long* zero, int nzero, int gx, int gy,
+                          SlabView f, GradPsiSxSy ga, int nbx)
+{
+    const int b = (int)blockIdx.x;
+    if (b < gx*gy) { acf_pyramid_block(acf0, nx0, ny0, out, nlev_out, zero, nzero, b % gx, b / gx); return; }
+    const int q = b - gx*gy;
+    const int row = q / nbx, bxs = q - row*nbx;
+    gradpsi_sxsy_cell(f, ga, bxs*256 + (int)threadIdx.x - f.ng, row - f.ng);
 }
 
 // inverse diagonals of a cell-centred level (grids whose level A lies below the pyramid kernel's five levels)
@@ -1629,8 +1650,10 @@ static void enqueue_cycles (Multigrid* M, hipStream_t st)
 // The coefficient hierarchy of a solve (average_down_acoef, HpMultiGrid.cpp:1640-1700; level 0 reads the slab) and the zeroing
 // of its norm slots.  It needs the coefficient (chi) only, not the right-hand side: mg_solve1_prepare lets the caller
 // enqueue it early, on a stream of its own, beside whatever produces the right-hand side.
+struct GuestPass { bool on = false; SlabView f{hps_slab{}}; GradPsiSxSy ga{}; };
+
 template <bool CC>
-static int solve1_hierarchy (Multigrid* M, int max_iters, hipStream_t st)
+static int solve1_hierarchy (Multigrid* M, int max_iters, hipStream_t st, const GuestPass* guest = nullptr)
 {
     const int lb = M->lowv_begin;
     max_iters = std::min(max_iters, MG_MAX_VCYCLES);
@@ -1646,6 +1669,13 @@ static int solve1_hierarchy (Multigrid* M, int max_iters, hipStream_t st)
         for (int il = 1; il <= np; ++il) { po.p[il-1] = M->L[il].acf; po.nx[il-1] = M->L[il].b.hix + 1; po.ny[il-1] = M->L[il].b.hiy + 1; }
         const double lfac = (double)(1 << lb), lfx = 1.0/(M->dx*lfac*M->dx*lfac), lfy = 1.0/(M->dy*lfac*M->dy*lfac);
         if (M->use_low3 && lb <= np) { po.cinv = M->cinvA; po.cinv_l = lb - 1; po.cfx = lfx; po.cfy = lfy; }
+        if (guest) {
+            const int gx = ceil_div(M->nx, 32), gy = ceil_div(M->ny, 32);
+            const SlabView& f = guest->f;
+            const int nbx = ceil_div(f.js, 256), rows = f.ny + 2*f.ng;
+            hipLaunchKernelGGL(k_hierarchy_gradpsi, dim3(gx*gy + nbx*rows), dim3(256), 0, st, M->acf0, M->nx, M->ny, po, np, M->d_norms, nzero_words,
+                               gx, gy, f, guest->ga, nbx);
+        } else
         hipLaunchKernelGGL(k_acf_pyramid, dim3(ceil_div(M->nx, 32), ceil_div(M->ny, 32)), dim3(256), 0, st, M->acf0, M->nx, M->ny, po, np,
                            M->d_norms, nzero_words);
         first = np + 1;
@@ -1784,6 +1814,19 @@ int mg_solve1_prepare (void* handle, hps_slab s, int sol_comp, int rhs_comp, int
     set_views(M, s, sol_comp, rhs_comp, acf_comp);
     if (int e = M->cc ? solve1_hierarchy<true>(M, max_iters, st) : solve1_hierarchy<false>(M, max_iters, st)) return e;
     M->hierarchy_ready = true;
+    return HPS_OK;
+}
+int mg_solve1_prepare_with (void* handle, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, int max_iters, SlabView f, GradPsiSxSy ga,
+                            hipStream_t st, bool* done)
+{
+    Multigrid* M = static_cast<Multigrid*>(handle);
+    *done = false;
+    if (!M->cc) return HPS_OK;                       // (the nodal hierarchy has no pyramid kernel)
+    set_views(M, s, sol_comp, rhs_comp, acf_comp);
+    GuestPass g; g.on = true; g.f = f; g.ga = ga;
+    if (int e = solve1_hierarchy<true>(M, max_iters, st, &g)) return e;
+    M->hierarchy_ready = true;
+    *done = true;
     return HPS_OK;
 }
 const int* mg_gate_after_enqueued (void* handle)
