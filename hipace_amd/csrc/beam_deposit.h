@@ -1,6 +1,6 @@
 // beam_deposit.h -- the static beam's two deposits of a slice (jz of this slice's block, jx / jy of the next one's:
 // BeamDepositCurrent.cpp:25-140, Hipace.cpp:613-614, 656-657) as a device function: the kernel of its own in engine.hip
-// and the extra workgroups at the end of the plasma deposition's grid (particles_tiled.hip) both run it.
+// and the extra workgroups at the head of the plasma deposition's grid (particles_tiled.hip) both run it.
 #ifndef HPS_BEAM_DEPOSIT_H_
 #define HPS_BEAM_DEPOSIT_H_
 

@@ -98,11 +98,12 @@ __device__ __forceinline__ void laser_gather_grad_lds (const double* a, int pitc
 // electrons the slice has released).
 __device__ __forceinline__ int4 tile_record (const int* __restrict__ offsets, const TailWork& tw, long n, bool& tail)
 {
-    const int b = (int)blockIdx.x - tw.nwg;
+    const int b0 = (int)blockIdx.x - tw.extra;       // (tw.extra workgroups at the head of the grid are not ours: the beam's deposition)
+    const int b = b0 - tw.nwg;
     tail = b < 0;
     if (tail) {
         const long nn = tw.live_n ? (long)*tw.live_n : n;
-        const long first = (long)tw.first + 256L*blockIdx.x;
+        const long first = (long)tw.first + 256L*b0;
         return make_int4(0, (int)min(first, nn), (int)min(first + 256, nn), 0);
     }
     return reinterpret_cast<const int4*>(offsets + tile_launch_offset(gridDim.x - tw.nwg - tw.extra))[b];
@@ -130,10 +131,11 @@ __global__ __launch_bounds__(256)
 void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx, DepComps cm,
                       PartConsts k, int* n_qsa, int* n_fallback, const int* __restrict__ tile_flag, TailWork tw, BeamPairWork bw)
 {
-    // the last bw.nwg workgroups: the static beam's deposits of this slice (beam_deposit.h) -- a 7.9 us launch of a few
-    // thousand particles that nothing ahead of the Sx/Sy initialisation waits for, off the slice's chain of launches
-    if (bw.nwg > 0 && (int)blockIdx.x >= (int)gridDim.x - bw.nwg) {
-        beam_pair_block<ORDER>(f, bw, (int)blockIdx.x - ((int)gridDim.x - bw.nwg), k.dx_inv, k.dy_inv, k.xoff, k.yoff);
+    // the first bw.nwg workgroups: the static beam's deposits of this slice (beam_deposit.h) -- a 7.9 us launch of a few
+    // thousand particles that nothing ahead of the Sx/Sy initialisation waits for, off the slice's chain of launches.  (At the
+    // head of the grid: at its end they were a tail of 6 us behind the last tile.)
+    if ((int)blockIdx.x < bw.nwg) {
+        beam_pair_block<ORDER>(f, bw, (int)blockIdx.x, k.dx_inv, k.dy_inv, k.xoff, k.yoff);
         return;
     }
     constexpr int R = TS + 2*TILE_HALO;

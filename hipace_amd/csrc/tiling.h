@@ -24,7 +24,7 @@ struct Tiling {
 // particles appended behind the tile-sorted body, worked on by the first `nwg` workgroups of a tile kernel's grid, 256 each
 // (particles_tiled.hip::tile_record); live_n: the species' particle count on the device, or null (= hps_plasma::n)
 struct TailWork { int first = 0, nwg = 0; const unsigned long long* live_n = nullptr;
-                  int extra = 0; };      // extra: workgroups at the END of the grid that are not tiles either (the beam's deposition)
+                  int extra = 0; };      // extra: workgroups at the HEAD of the grid that are neither (the beam's deposition)
 
 // int index of the per-workgroup launch records inside Tiling::offsets
 __host__ __device__ inline int tile_launch_offset (int ntiles) { return (2*ntiles + 2 + 3) & ~3; }
