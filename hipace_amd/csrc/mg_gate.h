@@ -23,12 +23,20 @@ __device__ __forceinline__ double norm_slot (const unsigned long long* norms, in
 // wave-uniform (read-first-lane), so that the `return` behind it is a scalar branch.  (Written as 48 reads per lane the
 // compiler emitted 17 vector loads per wave and batch: every wave of every workgroup pushed them through its CU's
 // address unit at the head of the kernel.)  All lanes of the wave must be active.
+// FRESH: the three reads go to the L2 (device-scope atomic loads): for a workgroup that evaluates the rule on norms that other
+// workgroups of the SAME launch have just added to -- its CU's L1 may hold the slots' lines from the gate at the kernel's head
+template <bool FRESH = false>
 __device__ __forceinline__ bool vcycle_active (const StopRule& sr)
 {
     if (sr.k < 0) return true;
     const int q = threadIdx.x & (MG_NSUB - 1);
     const int pslot = (sr.k == 0) ? 0 : 1 + sr.k;
-    unsigned long long a = sr.norms[q], b = sr.norms[MG_NSUB + q], c = sr.norms[pslot*MG_NSUB + q];
+    unsigned long long a, b, c;
+    if (FRESH) {
+        a = __hip_atomic_load(sr.norms + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b = __hip_atomic_load(sr.norms + MG_NSUB + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c = __hip_atomic_load(sr.norms + pslot*MG_NSUB + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else { a = sr.norms[q]; b = sr.norms[MG_NSUB + q]; c = sr.norms[pslot*MG_NSUB + q]; }
 #pragma unroll
     for (int o = MG_NSUB/2; o > 0; o >>= 1) {
         const unsigned long long a2 = __shfl_xor(a, o), b2 = __shfl_xor(b, o), c2 = __shfl_xor(c, o);

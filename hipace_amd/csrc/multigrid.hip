@@ -356,14 +356,52 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
 
 // NSW red-black half-sweeps per launch: 4 (one GSRB^4 of the reference) or 8 (the two consecutive
 // GSRB^4 that end a V-cycle on level 0, fused: one pass over HBM instead of two)
-template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, int NSW = 4>
+// POST: the launch that ends the last V-cycle enqueued so far also does what k_post_norms does (below): the workgroup that
+// finishes last -- a counter -- evaluates the stopping rule for the kernels gated behind the solve and posts the norms to the
+// host.  One launch (4.7 us between the last V-cycle and the gated push) less on a slice's chain.
+struct PostArgs { const unsigned long long* src; volatile unsigned long long* dst; int nwords; volatile unsigned long long* seq_slot;
+                  unsigned long long seq; int* go_word; StopRule after; unsigned int* counter; };
+
+__device__ __forceinline__ void post_epilogue (const PostArgs& pa)      // every workgroup of the launch, whole, at its end
+{
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // This workgroup's norm atomics (thread 0's, block_max_to) must have been performed before it is counted: wait for
+        // their acknowledgement.  NOT a __threadfence(): a device-scope release on this GPU writes the XCD's L2 back, once per
+        // workgroup -- measured: the launch took 66 us instead of 34.  The norms are device-scope atomics, read back below
+        // by device-scope atomic loads: no cache in between.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // two levels of counters (16 + 1): one counter for all workgroups is a chain of ~500 same-address atomics of ~20 ns each
+        const unsigned nb = gridDim.x, c = blockIdx.x & 15u, want = (nb - c + 15u) >> 4;
+        int last = 0;
+        if (atomicAdd(pa.counter + 1 + c, 1u) == want - 1u) {
+            __hip_atomic_store(pa.counter + 1 + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (atomicAdd(pa.counter, 1u) == (nb < 16u ? nb : 16u) - 1u) ? 1 : 0;
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(pa.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {   const bool act = vcycle_active<true>(pa.after);
+        if (threadIdx.x == 0) *pa.go_word = act ? 0 : 1; }
+    for (int w = threadIdx.x; w < pa.nwords; w += blockDim.x)
+        pa.dst[w] = __hip_atomic_load(pa.src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *pa.seq_slot = pa.seq;
+}
+
+template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, int NSW = 4, bool POST = false>
 __global__ __launch_bounds__(TS::NT, 4)      // at most 128 VGPRs: two 512-thread workgroups per CU (several variants sit at 113-130)
 void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FView phi_in, FView crse, FView res_out,
                FView cres_out, double facx, double facy, int ntx, unsigned long long* resnorm,
-               unsigned long long* rhsnorm, StopRule sr)
+               unsigned long long* rhsnorm, StopRule sr, PostArgs pa)
 {
     static_assert(!FUSE_R || (CC && DO_RES), "fused restriction is cell-centred only");
-    if (NSW != 4 && !vcycle_active(sr)) return;       // (the 4-sweep kernels read the gate behind their loads, see smooth_tile)
+    static_assert(!POST || NSW != 4, "the post rides on the fused level-0 pass");
+    if (NSW != 4 && !vcycle_active(sr)) { if (POST) post_epilogue(pa); return; }       // (the 4-sweep kernels read the gate behind their loads, see smooth_tile)
     constexpr int GT_X = TS::TX, GT_Y = TS::TY;
     __shared__ double s_phi[2][TS::AY*TS::AX];
     __shared__ double s_red[TS::NT/64];
@@ -383,6 +421,7 @@ void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FV
                                                              facx, facy, gi0, gj0, resnorm, rhsnorm, sr);
     else          smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, false, NSW>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
                                                               facx, facy, gi0, gj0, resnorm, rhsnorm, sr);
+    if (POST) post_epilogue(pa);
 }
 
 // coarse = R(fine): 4-average (cell-centred) or 9-point full weighting (nodal)
@@ -1368,6 +1407,7 @@ struct SolveRun { int enq, nspec, nzeroed, max_iters; double tol_rel, tol_abs; b
 
 struct Multigrid {
     bool cc; int nx, ny; double dx, dy;
+    bool post_fold = false; unsigned int* d_post_counter = nullptr;     // k_post_norms' work in the last V-cycle's level-0 launch (HPS_MG_POST_FOLD=1; measured: 1474 against 1481 slices/s, off)
     bool hierarchy_ready = false;               // mg_solve1_prepare has enqueued the coefficient hierarchy of the next solve
     std::vector<MGLevelDev> L;
     int lowv_begin = 1;                         // first level handled by k_lower_v
@@ -1396,7 +1436,7 @@ struct Multigrid {
     ~Multigrid () {
         for (auto& l : L) { (void)hipFree(l.acf); (void)hipFree(l.res); (void)hipFree(l.cor); (void)hipFree(l.rescor); }
         if (getenv("HPS_MG_DEBUG")) fprintf(stderr, "mg: solves %ld trips %ld hist %ld %ld %ld %ld %ld %ld\n", dbg_solves, dbg_trips, dbg_hist[0], dbg_hist[1], dbg_hist[2], dbg_hist[3], dbg_hist[4], dbg_hist[5]);
-        (void)hipFree(d_buf); (void)hipFree(d_low); (void)hipFree(tmp0); (void)hipFree(d_low2); (void)hipFree(d_low3); (void)hipFree(cinvA); (void)hipFree(coef_img);
+        (void)hipFree(d_buf); (void)hipFree(d_post_counter); (void)hipFree(d_low); (void)hipFree(tmp0); (void)hipFree(d_low2); (void)hipFree(d_low3); (void)hipFree(cinvA); (void)hipFree(coef_img);
         if (h_buf) (void)hipHostFree(h_buf);
     }
     FView lv (int il, double* p) const {
@@ -1438,6 +1478,7 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
     if (M->nlev() < 2) { delete M; set_error("hps_mg_create: grid too small to coarsen"); return HPS_ERR_ARG; }
     if (const char* e = getenv("HPS_MG_SMALL_CELLS")) M->small_tile_cells = atol(e);
     if (const char* e = getenv("HPS_MG_INIT_HUGE")) M->init_huge = atoi(e) != 0;
+    if (const char* e = getenv("HPS_MG_POST_FOLD")) M->post_fold = atoi(e) != 0;
     if (const char* e = getenv("HPS_MG_MID_CELLS")) M->mid_tile_cells = atol(e);
     const int nl = M->nlev();
     M->lowv_begin = nl - 1;
@@ -1503,6 +1544,8 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
     HPS_HIP_CHECK(hipMalloc(&M->d_low, low.size()*sizeof(LowLev)));
     HPS_HIP_CHECK(hipMemcpy(M->d_low, low.data(), low.size()*sizeof(LowLev), hipMemcpyHostToDevice));
     HPS_HIP_CHECK(hipMalloc(&M->d_buf, (3 + MG_MAX_VCYCLES)*MG_NSUB*sizeof(unsigned long long)));
+    HPS_HIP_CHECK(hipMalloc(&M->d_post_counter, 17*sizeof(unsigned int)));
+    HPS_HIP_CHECK(hipMemset(M->d_post_counter, 0, 17*sizeof(unsigned int)));
     HPS_HIP_CHECK(hipHostMalloc(&M->h_buf, ((3 + MG_MAX_VCYCLES)*MG_NSUB + 8)*sizeof(unsigned long long), hipHostMallocMapped));
     HPS_HIP_CHECK(hipHostGetDevicePointer((void**)&M->h_buf_dev, M->h_buf, 0));
     M->h_seq = M->h_buf + (3 + MG_MAX_VCYCLES)*MG_NSUB; M->h_seq_dev = M->h_buf_dev + (3 + MG_MAX_VCYCLES)*MG_NSUB;
@@ -1519,7 +1562,7 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
 template <class TS, bool CC, int SRC, bool DO_RES, int NSW = 4>
 static void launch_smooth_ts (Multigrid* M, int il, FView phi_out, FView phi_out2, FView rhs, FView acf, FView phi_in, FView crse,
                               FView res_out, FView cres_out, unsigned long long* resnorm, unsigned long long* rhsnorm,
-                              const StopRule& sr, hipStream_t st)
+                              const StopRule& sr, hipStream_t st, const PostArgs* post = nullptr)
 {
     const LevBox& b = M->L[il].b;
     constexpr int E = DO_RES ? NSW : NSW - 1;
@@ -1529,8 +1572,15 @@ static void launch_smooth_ts (Multigrid* M, int il, FView phi_out, FView phi_out
     const double ldx = M->dx*fac, ldy = M->dy*fac;
     const double facx = 1.0/(ldx*ldx), facy = 1.0/(ldy*ldy);
     constexpr bool FUSE = CC && DO_RES;
+    if constexpr (NSW != 4) {
+        if (post) {
+            hipLaunchKernelGGL((k_smooth<TS, CC, SRC, DO_RES, FUSE, NSW, true>), dim3(ntx*nty), dim3(TS::NT), 0, st, b, phi_out, phi_out2, rhs, acf,
+                               phi_in, crse, res_out, cres_out, facx, facy, ntx, resnorm, rhsnorm, sr, *post);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_smooth<TS, CC, SRC, DO_RES, FUSE, NSW>), dim3(ntx*nty), dim3(TS::NT), 0, st, b, phi_out, phi_out2, rhs, acf,
-                       phi_in, crse, res_out, cres_out, facx, facy, ntx, resnorm, rhsnorm, sr);
+                       phi_in, crse, res_out, cres_out, facx, facy, ntx, resnorm, rhsnorm, sr, PostArgs{});
 }
 
 template <bool CC, int SRC, bool DO_RES>
@@ -1558,7 +1608,7 @@ static void restrict_residual_if_nodal (Multigrid* M, int il, const StopRule& sr
 // V-cycle k (vcycle :1429-1512).  On entry res[1] = R(rhs - L(cor[0])); on exit again, plus
 // tmp0 = smoothed solution, cor[0] = sol = GSRB^4(tmp0) and the residual norm in d_norms[2+k].
 template <bool CC>
-static void vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStream_t st)
+static bool vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStream_t st, const PostArgs* post = nullptr)      // returns: the post has ridden along
 {
     const int nl = M->nlev();
     const int lb = M->lowv_begin;
@@ -1600,8 +1650,10 @@ static void vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
         if (M->fuse_level0) {
             launch_smooth_ts<TileHuge, CC, SRC_PROLONG, true, 8>(M, 0, M->lv(0, out), M->sol, M->rhs, M->acf0, M->lv(0, in), M->lv(1, crse),
                                                                  M->lv(0, M->L[0].rescor), M->lv(1, M->L[1].res), M->d_norms + (2 + k)*MG_NSUB,
-                                                                 nullptr, sr, st);
+                                                                 nullptr, sr, st, CC ? post : nullptr);
             M->cor_in_tmp = !M->cor_in_tmp;
+            restrict_residual_if_nodal<CC>(M, 0, sr, st);
+            return CC && post != nullptr;
         } else {
             launch_smooth<CC, SRC_PROLONG, false>(M, 0, M->lv(0, M->tmp0), none, M->rhs, M->acf0, M->lv(0, M->L[0].cor), M->lv(1, crse),
                                                   none, none, nullptr, nullptr, sr, st);
@@ -1610,6 +1662,7 @@ static void vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
         }
     }
     restrict_residual_if_nodal<CC>(M, 0, sr, st);
+    return false;
 }
 
 // norm slots (and the rider words) -> mapped host memory, sequence number last behind a system-scope fence: the host
@@ -1633,14 +1686,24 @@ template <bool CC>
 static void enqueue_cycles (Multigrid* M, hipStream_t st)
 {
     SolveRun& r = M->run;
+    bool posted = false;
     for (int v = 0; v < r.nspec && r.enq < r.max_iters; ++v, ++r.enq) {
         if (r.enq >= r.nzeroed) {        // more slots than foreseen: zero the next batch (rare)
             const int more = std::min(r.max_iters - r.nzeroed, 64);
             (void)hipMemsetAsync(M->d_norms + (2 + r.nzeroed)*MG_NSUB, 0, more*MG_NSUB*sizeof(unsigned long long), st);
             r.nzeroed += more;
         }
+        const bool last = !(v + 1 < r.nspec && r.enq + 1 < r.max_iters);
+        if (last && M->post_fold) {
+            ++M->seq; ++M->dbg_trips;
+            const PostArgs pa{M->d_buf, (volatile unsigned long long*)M->h_buf_dev, (3 + r.enq + 1)*MG_NSUB, (volatile unsigned long long*)M->h_seq_dev, M->seq,
+                              reinterpret_cast<int*>(M->d_buf) + MG_GO_WORD, StopRule{M->d_norms, r.enq + 1, r.tol_rel, r.tol_abs}, M->d_post_counter};
+            posted = vcycle<CC>(M, r.enq, r.tol_rel, r.tol_abs, st, &pa);
+            if (!posted) { --M->seq; --M->dbg_trips; }
+        } else
         vcycle<CC>(M, r.enq, r.tol_rel, r.tol_abs, st);
     }
+    if (posted) return;
     ++M->seq; ++M->dbg_trips;
     hipLaunchKernelGGL(k_post_norms, dim3(1), dim3(256), 0, st, M->d_buf, (volatile unsigned long long*)M->h_buf_dev,
                        (3 + r.enq)*MG_NSUB, (volatile unsigned long long*)M->h_seq_dev, M->seq,

@@ -1543,7 +1543,7 @@ def _run_with_env(api, var, value, deck, n_steps, tile_size=16):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["gated_push", "lazy_shift", "fuse_sources", "aux_stream", "fold_beam", "fold_hierarchy", "laser_stream_fft", "laser_stream_mg", "ion_tile_skip", "fold_tail", "gated_ion_push"])
+@pytest.mark.parametrize("case", ["gated_push", "lazy_shift", "fuse_sources", "aux_stream", "fold_beam", "fold_hierarchy", "mg_post_fold", "laser_stream_fft", "laser_stream_mg", "ion_tile_skip", "fold_tail", "gated_ion_push"])
 def test_schedules_do_not_change_results(api, case):
     """The engine's scheduling choices -- the push enqueued behind the multigrid's V-cycles and gated on its stopping rule,
     the envelope solver on a stream of its own, the tiles of atoms that cannot ionise skipped before their image is loaded --
@@ -1559,6 +1559,8 @@ def test_schedules_do_not_change_results(api, case):
         var, deck, steps = "HPS_FOLD_BEAM", decks.blowout_wake(), 2
     elif case == "fold_hierarchy":  # the multigrid's coefficient hierarchy in the launch of the -grad Psi / Sx, Sy pass
         var, deck, steps = "HPS_FOLD_HIERARCHY", decks.blowout_wake(), 2
+    elif case == "mg_post_fold":    # the norms' post to the host and the gate of the push by the last workgroup of the last V-cycle's level-0 launch
+        var, deck, steps = "HPS_MG_POST_FOLD", decks.blowout_wake(), 2
     elif case == "aux_stream":      # the beam's deposition and the multigrid's coefficient hierarchy on a stream beside the slice's
         var, deck, steps = "HPS_AUX_STREAM", decks.blowout_wake(), 2
     elif case.startswith("laser_stream"):
