@@ -1050,11 +1050,10 @@ void k_rel_b_error (SlabView f, int cB, int cBit, double* out, volatile double* 
         atomic_add_f64(out, part[0] + part[1] + part[2] + part[3]);
         atomic_add_f64(out + 1, part[4] + part[5] + part[6] + part[7]);
         if (host) {
-            __threadfence();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the two atomics above are acknowledged (no __threadfence(): see adk_post)
             unsigned int* done = reinterpret_cast<unsigned int*>(out + 3);
             if (atomicAdd(done, 1u) == gridDim.x - 1) {
-                *done = 0u;
-                __threadfence();
+                __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 host[0] = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 host[1] = __hip_atomic_load(out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 host[2] = __hip_atomic_load(out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

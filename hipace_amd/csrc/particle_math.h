@@ -261,12 +261,15 @@ __device__ __forceinline__ void adk_emit (const IonArgs& a, bool ionize, double 
 // system-scope fence); call from every workgroup after its last adk_emit
 __device__ __forceinline__ void adk_post (const IonArgs& a)
 {
+    // every wave waits for the acknowledgement of its own counter atomics (adk_emit) before the workgroup is counted as done.
+    // (Not a __threadfence(): a device-scope release fence on this GPU writes the XCD's L2 back -- once per workgroup that
+    // was most of this kernel's time on tiles that have nothing to ionise.  The counters are device-scope atomics, read
+    // back below by device-scope atomic loads; the electrons' arrays are read by the NEXT kernel.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
         if (atomicAdd(a.cnt + 2, 1ULL) == (unsigned long long)gridDim.x - 1ULL) {
-            a.cnt[2] = 0ULL;
-            __threadfence();
+            __hip_atomic_store(a.cnt + 2, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a.host[0] = (long long)__hip_atomic_load(a.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a.host[1] = (long long)__hip_atomic_load(a.cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a.host[2] = (long long)__hip_atomic_load(a.cnt + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
