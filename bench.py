@@ -92,15 +92,14 @@ def pmc_traffic(kernel_prefix):
     Only valid for the default 1024^2 x 4 ppc workload the counters were collected on.  Returns
     (bytes, source) -- NOT measured in this run: the counters need their own rocprofv3 passes."""
     import csv
-    for name in (PMC_SUMMARY, "r01h_pmc_fetch_write_per_kernel.csv"):
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
-            continue
-        with open(path) as f:
-            for r in csv.DictReader(f):
-                if r["kernel"].startswith(kernel_prefix):
-                    b = (2.0 * float(r["FETCH_SIZE_raw_per_launch"]) + float(r["WRITE_SIZE_raw_per_launch"])) * 1024.0
-                    return b, f"committed rocprofv3 --pmc summary profiles/{name} (FETCH_SIZE x2 + WRITE_SIZE, separate passes; not collected in this run)"
+    path = os.path.join(ROOT, "profiles", PMC_SUMMARY)      # no older summary stands in for a missing one: traffic = null then
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["kernel"].startswith(kernel_prefix):
+                b = (2.0 * float(r["FETCH_SIZE_raw_per_launch"]) + float(r["WRITE_SIZE_raw_per_launch"])) * 1024.0
+                return b, f"committed rocprofv3 --pmc summary profiles/{PMC_SUMMARY} (FETCH_SIZE x2 + WRITE_SIZE, separate passes; not collected in this run)"
     return None, None
 
 
@@ -440,6 +439,19 @@ def main():
             phases[k] += ph[k]
         nprof += n
     ring_stats = transport.stats() if transport is not None else None
+    rccl_ranks_seen = None
+    if transport is not None:
+        # evidence that N processes were on RCCL: what the communicators of this rank's two ring edges report about themselves
+        # (ncclCommCount = 2 each on a ring of 2+ ranks) and that messages went both ways; summed over the ranks below
+        inf = transport.info()
+        ring_stats = dict(ring_stats, **inf)
+        on_ring = (inf["comm_in_ranks"] == 2 and inf["comm_out_ranks"] == 2 and ring_stats["sent"] > 0 and ring_stats["received"] > 0) if world > 1 \
+            else (inf["comm_out_ranks"] == 1 and ring_stats["sent"] > 0)
+        rccl_ranks_seen = int(on_ring)
+        if world > 1:
+            t = torch.tensor([rccl_ranks_seen], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t)
+            rccl_ranks_seen = int(t.item())
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -569,6 +581,7 @@ def main():
             "ionization": (dict(zip(("electrons_released", "product_species_particles"), snap["ion"]))
                            if (args.config5 and not args.no_ionization) else None),
             "ring": ring_stats,
+            "rccl_ranks_seen": rccl_ranks_seen,
             "roofline": {"bound": "hbm", "kernel": "k_deposit_tiled<2,%d>" % args.tile if args.tile else "k_deposit_current<2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": kernel_ms,

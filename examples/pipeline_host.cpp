@@ -78,6 +78,13 @@ int main (int argc, char** argv)
     const int sort_period = argc > 8 ? std::atoi(argv[8]) : 128;
     if (deck.dt != 0.0) { std::fprintf(stderr, "pipeline_host hands a static beam on (hipace.dt = 0)\n"); return 2; }
     if (n_steps < 1 || world < 1 || rank < 0 || rank >= world || L < 1) { std::fprintf(stderr, "bad arguments\n"); return 2; }
+    if (world > 1) {
+        // before the first HIP call: the ring's receive and send streams and the engines' streams on hardware queues of their
+        // own (hps_ring_init refuses 2+ ranks otherwise), and two RCCL channels per hand-off (a receive posted ahead is a
+        // kernel that holds its workgroups until the data comes).  Values the launcher exported win.
+        setenv("GPU_MAX_HW_QUEUES", "8", 0);
+        setenv("NCCL_MAX_P2P_NCHANNELS", "2", 0);
+    }
     int ndev = 0;
     HIPCHECK(hipGetDeviceCount(&ndev));
     const int dev = rank % (ndev > 0 ? ndev : 1), nz = deck.nz, W = world*L;

@@ -4,6 +4,34 @@ import ctypes as C
 import os
 import subprocess
 
+
+def _ring_environment():
+    """A ring of 2+ ranks posts its receives ahead as RCCL kernels that wait on the device: the ring's two streams and the
+    engine's stream must each get a hardware queue of their own (hps_ring_init refuses to start otherwise), and the runtime
+    reads GPU_MAX_HW_QUEUES once, when the process first touches HIP.  Any multi-rank launch (torchrun exports WORLD_SIZE)
+    therefore gets the variable HERE, at the import of the binding -- before libhpslice.so is loaded, and before torch
+    initialises the device unless the host has already done so (RcclTransport checks that and says so)."""
+    try:
+        multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    except ValueError:
+        multi = False
+    if multi:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
+def hip_already_started():
+    """True if torch has initialised the device in this process (GPU_MAX_HW_QUEUES set now would come too late)."""
+    import sys
+    t = sys.modules.get("torch")
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:      # noqa: BLE001
+        return False
+
+
+_HWQ_PRESET = "GPU_MAX_HW_QUEUES" in os.environ     # set by the host's environment, before this process started
+_HIP_STARTED_AT_IMPORT = hip_already_started()
+_ring_environment()
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO = os.environ.get("HPS_LIB") or os.path.join(CSRC, "libhpslice.so")      # HPS_LIB: a diagnostic build (make stamps)
@@ -174,6 +202,8 @@ _SIGS = {
     "hps_ring_sync": (C.c_int, [C.c_void_p]),
     "hps_ring_sync_timeout": (C.c_int, [C.c_void_p, C.c_double]),
     "hps_ring_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "hps_engine_tiling": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "hps_ring_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 5),
     "hps_ring_destroy": (C.c_int, [C.c_void_p]),
     "hps_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long]),
     "hps_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long]),

@@ -174,4 +174,16 @@ inline int ceil_div (long a, long b) { return (int)((a + b - 1)/b); }
 
 } // namespace hps
 
+
+// A wave waits until its own outstanding global atomics / stores are acknowledged, ahead of a "this workgroup is done" count.
+// gfx942 / gfx950 (the Makefile's ARCH): no-return atomics and stores are counted in vmcnt and device-scope atomics are
+// performed at the memory side of the XCDs' L2s, so `s_waitcnt vmcnt(0)` + device-scope atomic loads of the counters is
+// enough -- and a __threadfence() there writes the XCD's L2 back, once per workgroup (DESIGN.md section 4 "tried").  Any
+// other target (gfx10+ count stores in vscnt / storecnt) gets the formal device-scope fence.
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(__gfx942__) || defined(__gfx950__))
+#define HPS_OWN_ATOMICS_ACKNOWLEDGED() __threadfence()
+#else
+#define HPS_OWN_ATOMICS_ACKNOWLEDGED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
 #endif

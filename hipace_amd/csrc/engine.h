@@ -15,6 +15,7 @@ namespace hps {
 // hps_mg_solve1 in two halves (multigrid.hip): kernels enqueued between them are gated on mg_gate_after_enqueued
 int mg_solve1_begin (void* mg_handle, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, double tol_rel, double tol_abs,
                      int max_iters, hipStream_t st);
+void mg_solve1_forget_hierarchy (void* mg_handle);
 int mg_solve1_prepare (void* mg_handle, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, int max_iters, hipStream_t st);
 // ... in one launch with the -grad Psi / Sx, Sy pass of the slab (multigrid.hip: k_hierarchy_gradpsi); *done = false if this grid's
 // hierarchy needs more than that launch (then nothing has been enqueued)

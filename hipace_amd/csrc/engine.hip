@@ -1053,7 +1053,7 @@ void k_rel_b_error (SlabView f, int cB, int cBit, double* out, volatile double* 
         atomic_add_f64(out, part[0] + part[1] + part[2] + part[3]);
         atomic_add_f64(out + 1, part[4] + part[5] + part[6] + part[7]);
         if (host) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the two atomics above are acknowledged (no __threadfence(): see adk_post)
+            HPS_OWN_ATOMICS_ACKNOWLEDGED();      // the two atomics above are acknowledged (no __threadfence(): see adk_post)
             unsigned int* done = reinterpret_cast<unsigned int*>(out + 3);
             if (atomicAdd(done, 1u) == gridDim.x - 1) {
                 __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1259,6 +1259,7 @@ int Engine::solve_slice_begin (int islice)
     int e;
 
     prof_now = profiling && (slices_done % prof_stride == 0);
+    mg_solve1_forget_hierarchy(mg);            // (left set only if the previous slice failed between prepare and begin)
     if ((e = join_laser())) return e;          // the envelope solver of the previous slice has read its chi
     mark();   // b0
     if (d_insitu_pl && np > 0)        // m_multi_plasma.InSituComputeDiags (Hipace.cpp:590)
@@ -1606,6 +1607,12 @@ extern "C" int hps_engine_info (void* h, int* ncomp, int* ng, long* np)
 }
 extern "C" hps_slab hps_engine_slab (void* h) { Engine* E = static_cast<Engine*>(h); E->flush_shift(); return E->slab; }
 extern "C" hps_plasma hps_engine_plasma (void* h) { return static_cast<Engine*>(h)->pl; }
+extern "C" int hps_engine_tiling (void* h, void** tiling)
+{
+    HPS_REQUIRE(h && tiling, "hps_engine_tiling: null argument");
+    *tiling = static_cast<Engine*>(h)->tiling;
+    return HPS_OK;
+}
 extern "C" hps_plasma hps_engine_ions (void* h)
 {
     Engine* E = static_cast<Engine*>(h);

@@ -371,7 +371,7 @@ __device__ __forceinline__ void post_epilogue (const PostArgs& pa)      // every
         // their acknowledgement.  NOT a __threadfence(): a device-scope release on this GPU writes the XCD's L2 back, once per
         // workgroup -- measured: the launch took 66 us instead of 34.  The norms are device-scope atomics, read back below
         // by device-scope atomic loads: no cache in between.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        HPS_OWN_ATOMICS_ACKNOWLEDGED();
         // two levels of counters (16 + 1): one counter for all workgroups is a chain of ~500 same-address atomics of ~20 ns each
         const unsigned nb = gridDim.x, c = blockIdx.x & 15u, want = (nb - c + 15u) >> 4;
         int last = 0;
@@ -1892,6 +1892,8 @@ int mg_solve1_prepare_with (void* handle, hps_slab s, int sol_comp, int rhs_comp
     *done = true;
     return HPS_OK;
 }
+// a hierarchy enqueued by mg_solve1_prepare* that no mg_solve1_begin followed (the caller failed in between) is dropped
+void mg_solve1_forget_hierarchy (void* handle) { if (handle) static_cast<Multigrid*>(handle)->hierarchy_ready = false; }
 const int* mg_gate_after_enqueued (void* handle)
 {
     return reinterpret_cast<const int*>(static_cast<Multigrid*>(handle)->d_buf) + MG_GO_WORD;

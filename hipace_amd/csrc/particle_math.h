@@ -265,7 +265,7 @@ __device__ __forceinline__ void adk_post (const IonArgs& a)
     // (Not a __threadfence(): a device-scope release fence on this GPU writes the XCD's L2 back -- once per workgroup that
     // was most of this kernel's time on tiles that have nothing to ionise.  The counters are device-scope atomics, read
     // back below by device-scope atomic loads; the electrons' arrays are read by the NEXT kernel.)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HPS_OWN_ATOMICS_ACKNOWLEDGED();
     __syncthreads();
     if (threadIdx.x == 0) {
         if (atomicAdd(a.cnt + 2, 1ULL) == (unsigned long long)gridDim.x - 1ULL) {

@@ -110,6 +110,9 @@ __device__ __forceinline__ int4 tile_record (const int* __restrict__ offsets, co
 }
 constexpr int TAIL_ORIGIN = -(1 << 24);      // "tile origin" of a tail workgroup: no particle is local to it
 
+template <int R, int RP = R, int NT = 256, int NC = 6>
+__device__ __forceinline__ void load_region (double* img, const SlabView& f, const int* comps, int nc, int ox, int oy, int tid);
+
 // Row pitch of the deposition's LDS accumulators = R + HPS_DEP_PAD doubles.  The lanes of a wave work on particles of 64
 // consecutive cells (four tile rows at the sort's (rank, cell) order): with pitch 20 the four rows fall on the 32 eight-byte
 // bank slots at offsets 0, 20, 8, 28 -- three rows deep on some slots, one on others; with pitch 48 (HPS_DEP_PAD=28) rows
@@ -299,7 +302,7 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
 // image of `nc` slab components over the tile region into LDS (0 outside the slab box).  All loads of a thread are issued
 // before its first LDS store (the loop over the thread's cells is unrolled by hand: its trip count depends on the thread, and
 // left to the compiler every round of loads waited for the one before -- four trips to memory at the head of each tile)
-template <int R, int RP = R, int NT = 256, int NC = 6>
+template <int R, int RP, int NT, int NC>
 __device__ __forceinline__ void load_region (double* img, const SlabView& f, const int* comps, int nc, int ox, int oy, int tid)
 {
     constexpr int NIT = (R*R + NT - 1)/NT;
@@ -479,6 +482,27 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
 // array element at a 32-bit byte offset from a uniform base: global_load / global_store with an SGPR base and one offset VGPR
 template <class T> __device__ __forceinline__ T ldo (const T* base, unsigned o) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + o); }
 template <class T> __device__ __forceinline__ void sto (T* base, unsigned o, T v) { *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + o) = v; }
+// the same with the non-temporal hint (global_load / global_store ... nt): for arrays only this kernel touches -- the
+// half-step momenta -- so that they do not push what the next deposition reads (x, y, w, ux, uy, psi) out of the caches
+#ifndef HPS_PUSH_NT
+#define HPS_PUSH_NT 0
+#endif
+template <class T> __device__ __forceinline__ T ldo_nt (const T* base, unsigned o)
+{
+#if HPS_PUSH_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + o));
+#else
+    return ldo(base, o);
+#endif
+}
+template <class T> __device__ __forceinline__ void sto_nt (T* base, unsigned o, T v)
+{
+#if HPS_PUSH_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<T*>(reinterpret_cast<char*>(base) + o));
+#else
+    sto(base, o, v);
+#endif
+}
 
 // IONIZE: the species can be field-ionised (ADK, ionization.hip).  The decision needs exactly the fields the push gathers,
 // so it is taken here, between the gather and the push (the reference ionises, then pushes: Hipace.cpp:693-701): the ion's
@@ -526,7 +550,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         PIn q;
         const unsigned o = ip*8u;
         q.id = ldo(pl.idcpu, o); q.xp = ldo(pl.x_prev, o); q.yp = ldo(pl.y_prev, o);
-        q.uxh = ldo(pl.ux_half, o); q.uyh = ldo(pl.uy_half, o); q.psih = ldo(pl.psi_half, o);
+        q.uxh = ldo_nt(pl.ux_half, o); q.uyh = ldo_nt(pl.uy_half, o); q.psih = ldo_nt(pl.psi_half, o);
         return q;
     };
     // the thread's first particle is requested ahead of the field image: its six values arrive with the image's
@@ -677,7 +701,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             }
             sto(pl.x, o8, xp); sto(pl.y, o8, yp);
             if (!k.temp_slice) {
-                sto(pl.ux_half, o8, ux); sto(pl.uy_half, o8, uy); sto(pl.psi_half, o8, psi);
+                sto_nt(pl.ux_half, o8, ux); sto_nt(pl.uy_half, o8, uy); sto_nt(pl.psi_half, o8, psi);
                 if (pl.x_prev != pl.x) sto(pl.x_prev, o8, xp);      // (aliased by the engine: already stored)
                 if (pl.y_prev != pl.y) sto(pl.y_prev, o8, yp);
             }
@@ -898,6 +922,9 @@ int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
     if (pl.n == 0) return HPS_OK;
     const BeamPairWork bw = beam ? *beam : BeamPairWork{};
     tw.extra = bw.nwg;
+    // the per-tile skip indexes the launch order by blockIdx: only valid while the grid holds tile workgroups alone
+    HPS_REQUIRE(!(tile_flag && (tw.nwg || bw.nwg)), "deposit_current_tiled: tile flags cannot be combined with tail or beam workgroups");
+    HPS_REQUIRE(pl.n + 256L*tw.nwg < (1L << 28), "deposit_current_tiled: the tile kernels address at most 2^28 particles per sheet");
     PartConsts k = base_consts(g);
     k.a = charge*invvol_of(g); k.b = charge*g.mu0/mass; k.max_qsa = max_qsa; k.can_ionize = can_ionize;
     k.aabs = aabs_comp; k.laser_fac = (charge/g.q_e)*(g.m_e/mass)*(charge/g.q_e)*(g.m_e/mass);
@@ -927,6 +954,8 @@ int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hp
                             hipStream_t st, int aabs_comp, const int* tile_flag, TailWork tw)
 {
     if (pl.n == 0) return HPS_OK;
+    HPS_REQUIRE(!(tile_flag && tw.nwg), "explicit_deposit_tiled: tile flags cannot be combined with tail workgroups");
+    HPS_REQUIRE(pl.n + 256L*tw.nwg < (1L << 28), "explicit_deposit_tiled: the tile kernels address at most 2^28 particles per sheet");
     PartConsts k = base_consts(g);
     k.a = charge*invvol_of(g)*g.mu0; k.b = charge/mass; k.can_ionize = can_ionize;
     k.aabs = aabs_comp; k.laser_fac = (g.m_e/g.q_e)*(g.m_e/g.q_e);
@@ -958,6 +987,10 @@ int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_
                           int* n_fallback, hipStream_t st, int aabs_comp, const IonArgs* ion, const int* go, TailWork tw)
 {
     if (pl.n == 0) return HPS_OK;
+    // 32-bit byte offsets into the SoA arrays (ip*8u, __builtin_assume(ip < 2^28) in the kernel); the tail's live count is
+    // read on the device but bounded by the workgroups it was given
+    HPS_REQUIRE(pl.n + 256L*tw.nwg < (1L << 28), "advance_plasma_tiled: the tile kernels address at most 2^28 particles per sheet");
+    HPS_REQUIRE(!(ion && ion->tile_flag && tw.nwg), "advance_plasma_tiled: an ionisable species' tile flags cannot be combined with tail workgroups");
     PartConsts k = base_consts(g);
     k.a = charge/(mass*g.c); k.dz = g.dz/n_subcycles;
     k.aabs = aabs_comp; k.laser_fac = (charge/g.q_e)*(g.m_e/mass)*(charge/g.q_e)*(g.m_e/mass);

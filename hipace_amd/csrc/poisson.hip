@@ -83,6 +83,9 @@ struct DstArgs {
     // sources of a slice straight from the slab's charge and current planes (no staging planes, no source kernel)
     const double* sp[DST_MAXPLANES][2]; const double* sq[DST_MAXPLANES][2]; double sc[DST_MAXPLANES][2]; int npairs[DST_MAXPLANES];
     long long* dbg;                 // optional: shader-clock stamps of workgroup 0 at the phase boundaries
+    // blocked intermediate planes (k_dst_rows_sym<.., LIN, LOUT>, see "blocked layout" below)
+    int rows_pad;                   // rows per plane rounded up to the workgroup's 2T rows: a workgroup never straddles planes
+    int blk_cols;                   // columns of the blocked planes (= rows per plane of the transposed view)
 };
 #ifdef HPS_POISSON_STAMPS
 // stamps are kept in registers and written by HPS_STAMP_FLUSH at the end of the kernel: a global
@@ -250,6 +253,201 @@ __device__ __forceinline__ void post_store (const lds_double* cbuf, const DstArg
                 if (scale) { ta *= sca[t][m]; tb *= scb[t][m]; }
                 da[k] = ta;
                 if (db) db[k] = tb;
+            }
+        }
+    }
+}
+
+// ---- blocked layout of the intermediate planes: a solve without transposes -------------------------------------------------
+// The x pass works on B = 2T rows per workgroup, the y pass on B columns.  Between the passes a plane is stored in blocks of
+// B rows, element (row r, column k) at ((r / B)*ncols + k)*B + r % B: the x pass writes / reads its B rows as ONE contiguous
+// run of ncols*B doubles ([k][B]: a (row 2t, row 2t+1) pair of a column is an aligned double2), and the y pass -- B columns
+// k0..k0+B-1, all rows -- finds B*B contiguous doubles per row block ([k - k0][r], 288 B for B = 6) and transforms in place.
+// Both k_transpose launches of a solve (a read and a write of every plane each) are gone.  Planes are padded to whole
+// blocks (rows_pad), so a workgroup never straddles two planes.
+struct BlkRow { int plane, j0; };
+__device__ __forceinline__ BlkRow blk_row (const DstArgs& a, int row0)
+{
+    BlkRow r; r.plane = row0 / a.rows_pad; r.j0 = row0 - r.plane*a.rows_pad; return r;
+}
+
+// row-major rows (or rows formed from other planes) with the padded row numbering
+template <int T, int N, int NT, bool SRC>
+__device__ __forceinline__ void load_row_pairs_p (lds_double* cbuf, const DstArgs& a, int row0, int tid)
+{
+    constexpr int n = N - 1, NJ = (n + NT - 1)/NT;
+    const BlkRow br = blk_row(a, row0);
+    const int pl = br.plane;
+    double v[T][2][NJ];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = min(br.j0 + 2*t + h, a.rows_per_plane - 1);
+            const long ro = (long)r*a.src_pitch;
+            if constexpr (SRC) {
+                const int np = a.npairs[pl];
+                const double* p0 = a.sp[pl][0] + ro; const double* q0 = a.sq[pl][0] ? a.sq[pl][0] + ro : nullptr;
+                const double c0 = a.sc[pl][0];
+                if (np == 1) {
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) { const int j = min(tid + NT*m, n - 1); v[t][h][m] = q0 ? c0*(p0[j] - q0[j]) : c0*p0[j]; }
+                } else {
+                    const double* p1 = a.sp[pl][1] + ro; const double* q1 = a.sq[pl][1] + ro;
+                    const double c1 = a.sc[pl][1];
+#pragma unroll
+                    for (int m = 0; m < NJ; ++m) { const int j = min(tid + NT*m, n - 1); v[t][h][m] = c0*(p0[j] - q0[j]) + c1*(p1[j] - q1[j]); }
+                }
+            } else {
+                const double* p0 = a.src[pl] + ro;
+#pragma unroll
+                for (int m = 0; m < NJ; ++m) { const int j = min(tid + NT*m, n - 1); v[t][h][m] = p0[j]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const bool oka = br.j0 + 2*t < a.rows_per_plane, okb = br.j0 + 2*t + 1 < a.rows_per_plane;
+#pragma unroll
+        for (int m = 0; m < NJ; ++m) {
+            const int j = tid + NT*m;
+            if (j < n) stc(cbuf, t*N + j, oka ? v[t][0][m] : 0.0, okb ? v[t][1][m] : 0.0);
+        }
+    }
+}
+
+// the workgroup's B rows from a blocked plane: one contiguous run of n*T double2, item f = k*T + t = rows (2t, 2t+1) at column k
+template <int T, int N, int NT>
+__device__ __forceinline__ void load_blocked_rows (lds_double* cbuf, const DstArgs& a, int row0, int tid)
+{
+    constexpr int n = N - 1, ITEMS = n*T, NI = (ITEMS + NT - 1)/NT;
+    const BlkRow br = blk_row(a, row0);
+    const double2* base = reinterpret_cast<const double2*>(a.src[br.plane] + (long)(br.j0/(2*T))*n*(2*T));
+    double2 v[NI];
+#pragma unroll
+    for (int m = 0; m < NI; ++m) v[m] = base[min(tid + NT*m, ITEMS - 1)];
+#pragma unroll
+    for (int m = 0; m < NI; ++m) {
+        const int f = tid + NT*m;
+        if (f < ITEMS) {
+            const int k = f / T, t = f - k*T;
+            const bool oka = br.j0 + 2*t < a.rows_per_plane, okb = br.j0 + 2*t + 1 < a.rows_per_plane;
+            stc(cbuf, t*N + k, oka ? v[m].x : 0.0, okb ? v[m].y : 0.0);
+        }
+    }
+}
+
+// the workgroup's B columns (its "rows" in the transposed view) from a blocked plane: per row block B*B contiguous doubles
+// [kk][r]; item f = (jb, kk, u) is the double2 (rows jb*B + 2u, + 1) of column k0 + kk
+template <int T, int N, int NT>
+__device__ __forceinline__ void load_blocked_cols (lds_double* cbuf, const DstArgs& a, int row0, int tid)
+{
+    constexpr int n = N - 1, B = 2*T, NJB = (n + B - 1)/B, PER = B*(B/2), ITEMS = NJB*PER, NI = (ITEMS + NT - 1)/NT;
+    const BlkRow br = blk_row(a, row0);
+    const int k0 = br.j0;                                // first column of the workgroup (a multiple of B)
+    const double2* plane = reinterpret_cast<const double2*>(a.src[br.plane]);
+    double2 v[NI];
+#pragma unroll
+    for (int m = 0; m < NI; ++m) {
+        const int f = min(tid + NT*m, ITEMS - 1);
+        const int jb = f / PER, e = f - jb*PER;
+        const int kk = min(e / (B/2), a.rows_per_plane - 1 - k0);        // (columns past the plane's last: clamped, zeroed below)
+        const int u = e - (e / (B/2))*(B/2);
+        v[m] = plane[((long)jb*a.blk_cols + k0 + kk)*(B/2) + u];
+    }
+#pragma unroll
+    for (int m = 0; m < NI; ++m) {
+        const int f = tid + NT*m;
+        if (f < ITEMS) {
+            const int jb = f / PER, e = f - jb*PER;
+            const int kk = e / (B/2), u = e - kk*(B/2);
+            const int t = kk >> 1, h = kk & 1, j = jb*B + 2*u;
+            const bool ok = k0 + kk < a.rows_per_plane;
+            if (j < n) cbuf[2*(t*N + j) + h] = ok ? v[m].x : 0.0;
+            if (j + 1 < n) cbuf[2*(t*N + j + 1) + h] = ok ? v[m].y : 0.0;
+        }
+    }
+}
+
+// T_k of a row pair from the transform's output X (stored at [q % N1][q / N1])
+template <int N1, int N2>
+__device__ __forceinline__ double2 dst_pair (const lds_double* cbuf, int t, int k, double is)
+{
+    constexpr int N = N1*N2;
+    const int q1 = k + 1, q2 = N - 1 - k;
+    const double2 x1 = ldc(cbuf, t*N + (q1 % N1)*N2 + q1/N1);
+    const double2 x2 = ldc(cbuf, t*N + (q2 % N1)*N2 + q2/N1);
+    return make_double2(0.5*(x2.x - x1.x) + (x1.x + x2.x)*is, 0.5*(x2.y - x1.y) + (x1.y + x2.y)*is);
+}
+
+// output rows -> their block of a blocked plane (contiguous double2 run, as load_blocked_rows reads it)
+template <int T, int N1, int N2, int NT>
+__device__ __forceinline__ void store_blocked_rows (const lds_double* cbuf, const DstArgs& a, int row0, int tid)
+{
+    constexpr int N = N1*N2, n = N - 1, ITEMS = n*T, NI = (ITEMS + NT - 1)/NT;
+    const BlkRow br = blk_row(a, row0);
+    double2* base = reinterpret_cast<double2*>(a.dst[br.plane] + (long)(br.j0/(2*T))*n*(2*T));
+    double is[NI];
+#pragma unroll
+    for (int m = 0; m < NI; ++m) is[m] = a.isin4[min(tid + NT*m, ITEMS - 1)/T];
+#pragma unroll
+    for (int m = 0; m < NI; ++m) {
+        const int f = tid + NT*m;
+        if (f < ITEMS) { const int k = f / T, t = f - k*T; base[f] = dst_pair<N1, N2>(cbuf, t, k, is[m]); }
+    }
+}
+
+// output "rows" (columns k0 + 2t, k0 + 2t + 1 of the blocked plane), element j -> ((j / B)*ncols + column)*B + j % B
+template <int T, int N1, int N2, int NT>
+__device__ __forceinline__ void store_blocked_cols (const lds_double* cbuf, const DstArgs& a, int row0, int tid)
+{
+    constexpr int N = N1*N2, n = N - 1, B = 2*T, NK = (n + NT - 1)/NT;
+    const BlkRow br = blk_row(a, row0);
+    const int k0 = br.j0;
+    double* plane = a.dst[br.plane];
+    double is[NK];
+#pragma unroll
+    for (int m = 0; m < NK; ++m) is[m] = a.isin4[min(tid + NT*m, n - 1)];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        if (k0 + 2*t >= a.rows_per_plane) break;
+        const bool okb = k0 + 2*t + 1 < a.rows_per_plane;
+#pragma unroll
+        for (int m = 0; m < NK; ++m) {
+            const int j = tid + NT*m;
+            if (j < n) {
+                const double2 v = dst_pair<N1, N2>(cbuf, t, j, is[m]);
+                const int jb = j / B, r = j - jb*B;
+                double* p = plane + ((long)jb*a.blk_cols + k0 + 2*t)*B + r;
+                p[0] = v.x;
+                if (okb) p[B] = v.y;
+            }
+        }
+    }
+}
+
+// row-major output with the padded row numbering (the last pass of a blocked solve writes the destination planes)
+template <int T, int N1, int N2, int NT>
+__device__ __forceinline__ void post_store_p (const lds_double* cbuf, const DstArgs& a, int row0, int tid)
+{
+    constexpr int N = N1*N2, n = N - 1, NK = (n + NT - 1)/NT;
+    const BlkRow br = blk_row(a, row0);
+    double is[NK];
+#pragma unroll
+    for (int m = 0; m < NK; ++m) is[m] = a.isin4[min(tid + NT*m, n - 1)];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int ja = br.j0 + 2*t;
+        if (ja >= a.rows_per_plane) break;
+        double* da = a.dst[br.plane] + (long)ja*a.dst_pitch;
+        double* db = (ja + 1 < a.rows_per_plane) ? da + a.dst_pitch : nullptr;
+#pragma unroll
+        for (int m = 0; m < NK; ++m) {
+            const int k = tid + NT*m;
+            if (k < n) {
+                const double2 v = dst_pair<N1, N2>(cbuf, t, k, is[m]);
+                da[k] = v.x;
+                if (db) db[k] = v.y;
             }
         }
     }
@@ -462,9 +660,12 @@ __device__ __forceinline__ void sym_stage (lds_double* cbuf, const double2* __re
     __syncthreads();
 }
 
-template <int N1, int N2, bool SRC = false, bool TWICE = false>
+template <int N1, int N2, bool SRC = false, bool TWICE = false, int LIN = 0, int LOUT = 0>
 __global__ __launch_bounds__(DSTS_NT) void k_dst_rows_sym (DstArgs a)
 {
+    // LIN / LOUT: layout of the planes read / written -- 0 row-major, 1 blocked planes seen by rows, 2 blocked planes seen
+    // by columns ("blocked layout" above); any of them non-zero: padded row numbering (a.rows_pad)
+    constexpr bool BLK = (LIN != 0 || LOUT != 0);
     // TWICE: the two y passes of a solve in one kernel -- transform the rows, multiply by a.scale (the inverse eigenvalues),
     // transform them again, all in LDS: one launch, one write and one read of the planes less than two passes
     static_assert(N1 % 2 == 1 && N2 % 2 == 1, "symmetric kernel needs odd factors");
@@ -480,7 +681,10 @@ __global__ __launch_bounds__(DSTS_NT) void k_dst_rows_sym (DstArgs a)
 
     HPS_STAMP_DECL;
     HPS_STAMP(0);
-    if (SRC) load_row_pairs_src<T, N, NT>(cbuf, a, row0, total_rows, tid);
+    if constexpr (LIN == 1) load_blocked_rows<T, N, NT>(cbuf, a, row0, tid);
+    else if constexpr (LIN == 2) load_blocked_cols<T, N, NT>(cbuf, a, row0, tid);
+    else if constexpr (BLK) load_row_pairs_p<T, N, NT, SRC>(cbuf, a, row0, tid);
+    else if (SRC) load_row_pairs_src<T, N, NT>(cbuf, a, row0, total_rows, tid);
     else load_row_pairs<T, N, NT>(cbuf, a, row0, total_rows, tid);
     __syncthreads();
     HPS_STAMP(1);
@@ -517,8 +721,14 @@ __global__ __launch_bounds__(DSTS_NT) void k_dst_rows_sym (DstArgs a)
             double ta[T][NK], tb[T][NK];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                const int ra = min(row0 + 2*t, total_rows - 1), rb = min(row0 + 2*t + 1, total_rows - 1);
-                const int ja = ra - (ra / a.rows_per_plane)*a.rows_per_plane, jb = rb - (rb / a.rows_per_plane)*a.rows_per_plane;
+                int ja, jb;
+                if constexpr (BLK) {
+                    const int j0 = row0 - (row0 / a.rows_pad)*a.rows_pad;
+                    ja = min(j0 + 2*t, a.rows_per_plane - 1); jb = min(j0 + 2*t + 1, a.rows_per_plane - 1);
+                } else {
+                    const int ra = min(row0 + 2*t, total_rows - 1), rb = min(row0 + 2*t + 1, total_rows - 1);
+                    ja = ra - (ra / a.rows_per_plane)*a.rows_per_plane; jb = rb - (rb / a.rows_per_plane)*a.rows_per_plane;
+                }
 #pragma unroll
                 for (int m = 0; m < NK; ++m) {
                     const int k = min(tid + NT*m, n - 1);
@@ -542,7 +752,10 @@ __global__ __launch_bounds__(DSTS_NT) void k_dst_rows_sym (DstArgs a)
             __syncthreads();
         }
     }
-    post_store<T, N1, N2, NT, TWICE>(cbuf, a, row0, total_rows, tid);
+    if constexpr (LOUT == 1) store_blocked_rows<T, N1, N2, NT>(cbuf, a, row0, tid);
+    else if constexpr (LOUT == 2) store_blocked_cols<T, N1, N2, NT>(cbuf, a, row0, tid);
+    else if constexpr (BLK) post_store_p<T, N1, N2, NT>(cbuf, a, row0, tid);
+    else post_store<T, N1, N2, NT, TWICE>(cbuf, a, row0, total_rows, tid);
     HPS_STAMP(5);
     HPS_STAMP_FLUSH;
 }
@@ -886,10 +1099,14 @@ void k_dense_product (GemmArgs g)
 
 typedef void (*dst_kernel_t)(DstArgs);
 typedef void (*dst_cols_kernel_t)(DstArgs, int);
-struct DstImpl { int N, N1, N2; dst_kernel_t kernel; bool sym; int T; int nt; dst_cols_kernel_t cols; dst_kernel_t mfma; dst_kernel_t src; dst_kernel_t twice; };
+struct DstImpl { int N, N1, N2; dst_kernel_t kernel; bool sym; int T; int nt; dst_cols_kernel_t cols; dst_kernel_t mfma; dst_kernel_t src; dst_kernel_t twice;
+                 // the passes of a solve on blocked intermediate planes (no transposes): first pass from row-major rows / from
+                 // rows formed out of other planes, both y passes in place on the blocked planes, last pass to row-major rows
+                 dst_kernel_t b_first, b_first_src, b_twice, b_last; };
 
-#define HPS_DST_IMPL(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows<N1, N2>, false, DST_T, 256, nullptr, nullptr, nullptr, nullptr}
-#define HPS_DST_SYM(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows_sym<N1, N2>, true, DSTS_T, DSTS_NT, k_dst_cols_sym<N1, N2>, k_dst_rows_mfma<N1, N2>, k_dst_rows_sym<N1, N2, true>, k_dst_rows_sym<N1, N2, false, true>}
+#define HPS_DST_IMPL(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows<N1, N2>, false, DST_T, 256, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
+#define HPS_DST_SYM(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows_sym<N1, N2>, true, DSTS_T, DSTS_NT, k_dst_cols_sym<N1, N2>, k_dst_rows_mfma<N1, N2>, k_dst_rows_sym<N1, N2, true>, k_dst_rows_sym<N1, N2, false, true>, \
+                                    k_dst_rows_sym<N1, N2, false, false, 0, 1>, k_dst_rows_sym<N1, N2, true, false, 0, 1>, k_dst_rows_sym<N1, N2, false, true, 2, 2>, k_dst_rows_sym<N1, N2, false, false, 1, 0>}
 static const DstImpl g_dst_impls[] = {
     HPS_DST_SYM(25, 41),    // nx = 1024
     HPS_DST_SYM(19, 27),    // 512
@@ -1004,6 +1221,10 @@ struct Poisson {
     dst_kernel_t kx_src = nullptr;      // the x pass with its rows formed from other planes (sym kernels only)
     dst_kernel_t ky2 = nullptr;         // both y passes (transform, inverse eigenvalues, transform) in one launch (sym kernels; HPS_POISSON_Y2=0: off)
     dst_cols_kernel_t kcols = nullptr; size_t lds_cols = 0;     // y direction on column blocks (symmetric factorisations)
+    // blocked intermediate planes (HPS_POISSON_BLOCKED=0: off): three launches per solve, no transposes
+    dst_kernel_t kb_first = nullptr, kb_first_src = nullptr, kb_twice = nullptr, kb_last = nullptr;
+    long blk_plane = 0;                 // doubles per blocked plane: ny rounded up to whole row blocks, times nx
+    bool blocked () const { return kb_first != nullptr; }
     double2 *tab_x = nullptr, *tab_y = nullptr;        // each: [fa | fb | tw] concatenated
     double *mtab_x = nullptr, *mtab_y = nullptr;       // MFMA operand tables [stage A | stage B] (k_dst_rows_mfma)
     const double *ma_x = nullptr, *mb_x = nullptr, *ma_y = nullptr, *mb_y = nullptr;
@@ -1133,7 +1354,20 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
         if (P->kx_src && P->lds_x > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->kx_src, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_x));
         if (P->lds_y > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->ky, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_y));
         if (P->ky2 && P->lds_y > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->ky2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_y));
-        HPS_HIP_CHECK(hipMalloc(&P->buf_a, (size_t)DST_MAXPLANES*nx*ny*sizeof(double)));
+        size_t plane_doubles = (size_t)nx*ny;
+        {   const char* v = getenv("HPS_POISSON_BLOCKED");
+            const bool want = !(v && atoi(v) == 0);
+            if (want && ix->sym && iy->sym && ix->T == iy->T && P->ky2 && !P->kcols && !P->mtab_x) {
+                const int B = 2*ix->T;
+                P->kb_first = ix->b_first; P->kb_first_src = ix->b_first_src; P->kb_twice = iy->b_twice; P->kb_last = ix->b_last;
+                P->blk_plane = (long)((ny + B - 1)/B)*B*nx;
+                plane_doubles = std::max(plane_doubles, (size_t)P->blk_plane);
+                for (dst_kernel_t kf : {P->kb_first, P->kb_first_src, P->kb_last})
+                    if (P->lds_x > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_x));
+                if (P->lds_y > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->kb_twice, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_y));
+            }
+        }
+        HPS_HIP_CHECK(hipMalloc(&P->buf_a, (DST_MAXPLANES*plane_doubles + 64)*sizeof(double)));
         HPS_HIP_CHECK(hipMalloc(&P->buf_b, (size_t)DST_MAXPLANES*nx*ny*sizeof(double)));
     } else if (allow_own && nx <= 512 && ny <= 512) {
         P->kx = P->ky = nullptr;
@@ -1252,7 +1486,7 @@ int poisson_solve_batch (Poisson* P, int nb, const double* const* src, long src_
 bool poisson_sources_fusable (void* handle)
 {
     Poisson* P = static_cast<Poisson*>(handle);
-    return P->own() && P->kx_src && !P->kcols && !P->dense();
+    return P->own() && (P->kx_src || P->kb_first_src) && !P->kcols && !P->dense();
 }
 int poisson_solve_batch_src (void* handle, int nb, const PoissonSrc* spec, long src_pitch, hps_slab dst, const int* dst_comps, hipStream_t st)
 {
@@ -1300,6 +1534,36 @@ static int poisson_solve_batch_impl (Poisson* P, int nb, const double* const* sr
     auto rows_grid = [] (int rows, int T) { return dim3(ceil_div(rows, 2*T)); };
     DstArgs a{};
     a.dbg = P->dbg;
+    if (P->blocked()) {
+        // three launches, the intermediate planes in blocks of B = 2T rows ("blocked layout", k_dst_rows_sym<.., LIN, LOUT>)
+        const int B = 2*P->tx;
+        const int ypad = ceil_div(ny, B)*B, xpad = ceil_div(nx, B)*B;
+        // 1: DST along x of the sources -> blocked planes
+        for (int b = 0; b < nb; ++b) { a.src[b] = spec ? nullptr : src[b]; a.dst[b] = P->buf_a + b*P->blk_plane; }
+        a.src_pitch = src_pitch; a.dst_pitch = nx; a.scale = nullptr; a.fa = P->fa_x; a.fb = P->fb_x; a.tw = P->tw_x; a.isin4 = P->isin_x;
+        a.rows_per_plane = ny; a.nplanes = nb; a.rows_pad = ypad; a.blk_cols = nx;
+        if (spec) {
+            for (int b = 0; b < nb; ++b) {
+                a.npairs[b] = spec[b].npairs;
+                for (int k = 0; k < 2; ++k) { a.sp[b][k] = spec[b].p[k]; a.sq[b][k] = spec[b].q[k]; a.sc[b][k] = spec[b].c[k]; }
+            }
+            hipLaunchKernelGGL(P->kb_first_src, dim3(nb*ypad/B), dim3(P->ntx), P->lds_x, st, a);
+            for (int b = 0; b < nb; ++b) a.npairs[b] = 0;
+        } else
+        hipLaunchKernelGGL(P->kb_first, dim3(nb*ypad/B), dim3(P->ntx), P->lds_x, st, a);
+        // 2: DST along y, inverse eigenvalues, DST along y -- in place, B columns of the blocked planes per workgroup
+        for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_a + b*P->blk_plane; a.dst[b] = P->buf_a + b*P->blk_plane; }
+        a.scale = P->eig; a.fa = P->fa_y; a.fb = P->fb_y; a.tw = P->tw_y; a.isin4 = P->isin_y;
+        a.rows_per_plane = nx; a.rows_pad = xpad; a.blk_cols = nx;
+        hipLaunchKernelGGL(P->kb_twice, dim3(nb*xpad/B), dim3(P->nty), P->lds_y, st, a);
+        // 3: DST along x -> destination planes
+        for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_a + b*P->blk_plane; a.dst[b] = dst[b]; }
+        a.scale = nullptr; a.dst_pitch = dst_pitch; a.fa = P->fa_x; a.fb = P->fb_x; a.tw = P->tw_x; a.isin4 = P->isin_x;
+        a.rows_per_plane = ny; a.rows_pad = ypad; a.blk_cols = nx;
+        hipLaunchKernelGGL(P->kb_last, dim3(nb*ypad/B), dim3(P->ntx), P->lds_x, st, a);
+        HPS_HIP_CHECK(hipGetLastError());
+        return HPS_OK;
+    }
     // 1: DST along x of the sources -> A
     for (int b = 0; b < nb; ++b) { a.src[b] = spec ? nullptr : src[b]; a.dst[b] = P->buf_a + b*plane; }
     a.src_pitch = src_pitch; a.dst_pitch = nx; a.scale = nullptr; a.fa = P->fa_x; a.fb = P->fb_x; a.tw = P->tw_x; a.isin4 = P->isin_x;

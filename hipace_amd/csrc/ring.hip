@@ -42,6 +42,8 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     const char* (*GetLastError)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
 };
 
 Rccl g_rccl;
@@ -65,6 +67,8 @@ int load_rccl ()
     HPS_SYM(GetErrorString, "ncclGetErrorString")
 #undef HPS_SYM
     *reinterpret_cast<void**>(&g_rccl.GetLastError) = dlsym(so, "ncclGetLastError");      // optional
+    *reinterpret_cast<void**>(&g_rccl.CommCount) = dlsym(so, "ncclCommCount");            // optional (hps_ring_info)
+    *reinterpret_cast<void**>(&g_rccl.CommUserRank) = dlsym(so, "ncclCommUserRank");
     g_rccl.so = so;
     return HPS_OK;
 }
@@ -126,10 +130,15 @@ extern "C" int hps_ring_init (int rank, int world, int device, const char* id_ed
         // ring's receive stream, its send stream and the engine's stream onto one hardware queue, a send queued behind such
         // a receive never runs and the ring waits in a circle.  ROCm's default is 4 hardware queues per process; the ring
         // needs every stream of the process on its own queue: refuse to start with fewer than 8 (set before HIP starts).
+        // The check can only read the environment: whether the value was there BEFORE the runtime started is the host's
+        // business (hipace_amd/_lib.py sets it at import when WORLD_SIZE > 1, examples/pipeline_host.cpp before its first
+        // HIP call).  HPS_RING_ALLOW_SHARED_QUEUES=1 overrides the refusal (a host that knows its queue assignment).
         const char* q = std::getenv("GPU_MAX_HW_QUEUES");
-        if (!q || std::atoi(q) < 8) {
+        const char* ovr = std::getenv("HPS_RING_ALLOW_SHARED_QUEUES");
+        if ((!q || std::atoi(q) < 8) && !(ovr && std::atoi(ovr) != 0)) {
             hps::set_error("hps_ring_init: set GPU_MAX_HW_QUEUES >= 8 in the environment before the process touches HIP (the ring's "
-                           "posted-ahead receives must not share a hardware queue with its sends or the engine's stream)");
+                           "posted-ahead receives must not share a hardware queue with its sends or the engine's stream); "
+                           "HPS_RING_ALLOW_SHARED_QUEUES=1 overrides this check");
             return HPS_ERR_ARG;
         }
     }
@@ -340,6 +349,23 @@ extern "C" int hps_ring_stats (void* handle, long* n_sent, long* n_received, lon
     if (n_received) *n_received = R->n_received;
     if (bytes_sent) *bytes_sent = R->bytes_sent;
     if (bytes_received) *bytes_received = R->bytes_received;
+    return HPS_OK;
+}
+
+// What RCCL itself says about the ring's communicators: ranks of the incoming and outgoing edge's communicator (2 and 2 on
+// a ring of 2+ ranks, 0 and 1 for the one-rank ring's self communicator; -1 where the library has no ncclCommCount) and
+// this rank's place in each (1 on the incoming edge, 0 on the outgoing one).
+extern "C" int hps_ring_info (void* handle, int* world, int* comm_in_ranks, int* comm_out_ranks, int* my_rank_in, int* my_rank_out)
+{
+    Ring* R = static_cast<Ring*>(handle);
+    HPS_REQUIRE(R, "hps_ring_info: null ring");
+    auto count = [](ncclComm_t c) { int n = -1; if (!c) return 0; if (g_rccl.CommCount && g_rccl.CommCount(c, &n) != 0) n = -1; return n; };
+    auto urank = [](ncclComm_t c) { int n = -1; if (!c) return -1; if (g_rccl.CommUserRank && g_rccl.CommUserRank(c, &n) != 0) n = -1; return n; };
+    if (world) *world = R->world;
+    if (comm_in_ranks) *comm_in_ranks = count(R->comm_in);
+    if (comm_out_ranks) *comm_out_ranks = count(R->world == 1 ? R->comm_self : R->comm_out);
+    if (my_rank_in) *my_rank_in = urank(R->comm_in);
+    if (my_rank_out) *my_rank_out = urank(R->world == 1 ? R->comm_self : R->comm_out);
     return HPS_OK;
 }
 

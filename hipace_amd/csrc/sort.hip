@@ -297,6 +297,7 @@ extern "C" int hps_beam_sort_by_box (const double* z_dev, long n, double plo_z, 
 extern "C" int hps_tiling_create (int nx, int ny, int tile_size, long max_particles, void** handle)
 {
     HPS_REQUIRE(nx > 0 && ny > 0 && max_particles >= 0 && handle, "hps_tiling_create: bad argument");
+    HPS_REQUIRE(max_particles < (1L << 28), "hps_tiling_create: at most 2^28 particles per tile-sorted sheet (32-bit offsets in the tile kernels)");
     Tiling* T = nullptr;
     if (int e = tiling_create(nx, ny, tile_size, std::max(max_particles, 1L), &T)) return e;
     *handle = T;

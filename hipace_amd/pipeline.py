@@ -105,6 +105,18 @@ class RcclTransport:
 
     def __init__(self, rank, world, device_index, group=None):
         from . import _lib
+        if world > 1:
+            # hardware queues (see _lib._ring_environment): the variable must have been in the environment before HIP started
+            import os
+            if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8 and os.environ.get("HPS_RING_ALLOW_SHARED_QUEUES", "0") in ("", "0"):
+                if _lib.hip_already_started():
+                    raise RuntimeError("RcclTransport: a ring of %d ranks needs GPU_MAX_HW_QUEUES >= 8 in the environment BEFORE the "
+                                       "process touches the GPU (export it in the launcher, or import hipace_amd._lib under WORLD_SIZE > 1 "
+                                       "before torch.cuda is initialised); HPS_RING_ALLOW_SHARED_QUEUES=1 overrides" % world)
+                os.environ["GPU_MAX_HW_QUEUES"] = "8"
+            elif not _lib._HWQ_PRESET and _lib._HIP_STARTED_AT_IMPORT:
+                raise RuntimeError("RcclTransport: GPU_MAX_HW_QUEUES was set after torch had initialised the device -- the runtime did "
+                                   "not see it; export it in the launcher's environment")
         self._lib, self._check = _lib.lib(), _lib.check
         self.rank, self.world = rank, world
         my = C.create_string_buffer(128)
@@ -166,6 +178,12 @@ class RcclTransport:
         ns, nr, bs, br = C.c_long(), C.c_long(), C.c_longlong(), C.c_longlong()
         self._check(self._lib.hps_ring_stats(self._h, C.byref(ns), C.byref(nr), C.byref(bs), C.byref(br)))
         return dict(sent=ns.value, received=nr.value, bytes_sent=bs.value, bytes_received=br.value)
+
+    def info(self):
+        """What RCCL reports for this rank's two edge communicators (hps_ring_info)."""
+        v = [C.c_int() for _ in range(5)]
+        self._check(self._lib.hps_ring_info(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("world", "comm_in_ranks", "comm_out_ranks", "my_rank_in", "my_rank_out"), (x.value for x in v)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -425,7 +443,9 @@ def run_pipeline(*args, **kwargs):
     driver allocates small objects per slice (views, tuples, events), and with torch imported one full collection over the
     heap takes 30-50 ms -- measured as one stall of that length in the middle of the first step, with the device running dry
     (the whole difference between the ring and the plain slice loop on one GPU).  What exists now is parked in the permanent
-    generation for the run."""
+    generation for the run.
+    Two or more ranks on RCCL: GPU_MAX_HW_QUEUES >= 8 must be in the environment before the process touches the GPU
+    (hipace_amd._lib sets it at import when WORLD_SIZE > 1; RcclTransport refuses a host that initialised the device first)."""
     gc.freeze()                     # (no collection first: that is the 30-50 ms pass this is here to avoid)
     try:
         return _drive([_stage(*args, **kwargs)])[0]
@@ -445,6 +465,7 @@ def run_lanes(engines, rank, world, n_steps, device, on_step_end=None, slices_pe
     ring comes from this thread.
     on_step_end(step, engine), on_slice(stage_in_process, m, q): as `_stage`'s, with the stage's engine / index added.
     slices_per_step: as `_stage`'s; a list has one entry per STAGE of the whole ring (world*L).
+    world > 1: the same requirement on GPU_MAX_HW_QUEUES as `run_pipeline`.
     Returns the number of slices solved by this process."""
     L = len(engines)
     W = world * L

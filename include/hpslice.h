@@ -274,8 +274,16 @@ int hps_engine_slice_ready (void* handle);
 int hps_engine_run_step (void* handle);                   /* begin_step + all slices head->tail   */
 int hps_engine_sync (void* handle);                       /* host waits for the engine's stream (and, through it, the laser stream) */
 int hps_engine_info (void* handle, int* ncomp, int* nguards, long* nparticles);
+/* Deferred ShiftSlices: hps_engine_solve_slice leaves the slab UNSHIFTED (Fields::ShiftSlices, fields/Fields.cpp:588-670, runs
+ * in the next slice's InitializeSlices pass); hps_engine_slab and hps_engine_sync enqueue the pending shift before they
+ * return, hps_engine_record_event / hps_engine_copy_async / the export calls do NOT.  A host that keeps the hps_slab
+ * pointer and reads the Previous / Next planes stream-ordered between two slices without one of those two calls sees
+ * them as they were before the shift; HPS_LAZY_SHIFT=0 in the environment restores the shift at the end of every slice. */
 hps_slab hps_engine_slab (void* handle);
 hps_plasma hps_engine_plasma (void* handle);
+/* the tiling of the first species as the engine holds it now (NULL with tile_size 0): for hps_tiling_info and for calling
+ * the *_tiled operators on the engine's own sheet (diagnostics: scripts/deposit_variants.py); owned by the engine */
+int hps_engine_tiling (void* handle, void** tiling);
 /* species "ion" (hps_deck.ion_on): its sheet, the electrons it has released since hps_engine_create and the size of the
  * first species now (hps_engine_plasma().n follows it); synchronises the stream */
 hps_plasma hps_engine_ions (void* handle);
@@ -452,9 +460,16 @@ int hps_ring_sync (void* ring);                 /* host waits for both streams o
 /* Both waits poll and give up with HPS_ERR_COMM (the rank's message counters in hps_last_error) after HPS_RING_TIMEOUT_S
  * seconds (environment, default 900) -- hps_ring_sync_timeout with the limit as an argument: a ring whose peer is gone, or
  * whose posted-ahead receives share a hardware queue with the sends they wait for, fails loudly instead of hanging.
- * hps_ring_init refuses to start a ring of 2+ ranks unless GPU_MAX_HW_QUEUES >= 8 is set in the environment. */
+ * hps_ring_init refuses to start a ring of 2+ ranks unless GPU_MAX_HW_QUEUES >= 8 is set in the environment -- by the
+ * host, BEFORE its first HIP call (the runtime reads it once; the library can only see the string): examples/pipeline_host.cpp
+ * does it with setenv at the top of main, hipace_amd/_lib.py at import when WORLD_SIZE > 1.  HPS_RING_ALLOW_SHARED_QUEUES=1
+ * turns the refusal off for a host that has arranged its queues some other way. */
 int hps_ring_sync_timeout (void* ring, double seconds);
 int hps_ring_stats (void* ring, long* n_sent, long* n_received, long long* bytes_sent, long long* bytes_received);
+/* what RCCL reports (ncclCommCount / ncclCommUserRank) for the communicators of the incoming and the outgoing edge: 2 and
+ * 2 ranks on a ring of 2+ processes (this rank is 1 on the incoming edge, 0 on the outgoing one), 0 and 1 for the one-rank
+ * ring -- the evidence that N processes are on RCCL (bench.py's `rccl_ranks_seen`) */
+int hps_ring_info (void* ring, int* world, int* comm_in_ranks, int* comm_out_ranks, int* my_rank_in, int* my_rank_out);
 int hps_ring_destroy (void* ring);
 
 /* ---- utilities ---------------------------------------------------------------------------- */

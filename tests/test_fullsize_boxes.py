@@ -1,0 +1,218 @@
+"""Whole boxes at the BASELINE sizes: the HIP engine with its DEFAULT schedule (16 x 16 tiles, adaptive re-sort, every fold
+and gate on -- what bench.py times) sweeps all nz slices of each full-size deck, as the reference does
+(Hipace.cpp:478-480), and is compared with fixtures the pinned CPU oracle wrote for the same deck
+(tests/golden/fullsize_*.json, scripts/make_fullsize_fixtures.py; the deck is stored in the fixture).
+
+What is compared, following the reference's checksum test (tests/checksum/checksum.py:82-160,
+tests/checksum/backend/openpmd_backend.py:40-62): the whole-box sum of |F| of every field at the north-star's 1e-6
+relative, the beam block, and the integer state -- particles still valid (QSA drops / absorbed particles), V-cycle total,
+ionised count, ion-level sum.  The same numbers are checked on every trace slice along the box, so the region bench.py
+times (slices 705-724: blown-out sheath, re-sorts, halo fallbacks) is inside the comparison.
+
+Tolerances, and why they are what they are: the GPU's scatter sums in a different order (atomics), so a slice differs from
+the oracle's by ~1e-13; behind the driver the sheath's trajectories cross and amplify that along the box.  The whole-box
+checksums are held to 1e-6 (north-star bar); per-slice plane sums to 1e-6 of the largest plane sum of that component along
+the box.  The multigrid's stopping rule is a threshold on a norm: a slice whose residual norm lands within rounding of the
+tolerance may take one V-cycle more or less than the oracle's, so the V-cycle TOTAL may differ by a few counts in tens of
+thousands -- the test allows 0.1 % and prints the difference.  Particle counts must be exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+REPORT_DIR = os.environ.get("HPS_FULLSIZE_REPORT")        # directory: write what was measured next to what was expected
+
+
+def _fixture(name):
+    path = os.path.join(GOLD, f"fullsize_{name}.json")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated (scripts/make_fullsize_fixtures.py --only {name})")
+    fx = json.load(open(path))
+    deck = {k: (tuple(v) if isinstance(v, list) else v) for k, v in fx["deck"].items()}
+    return fx, deck
+
+
+def _snapshot(eng, have_ions):
+    slab = eng.slab()
+    names = eng.comp_names()
+    real, valid = eng.particles()
+    live = valid != 0
+    out = dict(slab_sum_abs={names[c]: float(np.abs(slab[c]).sum()) for c in range(len(names))},
+               vcycles=int(eng.stats()["vcycles"]), n_valid=int(live.sum()), n_particles=int(valid.size),
+               sum_w=float(real[2][live].sum()), sum_abs_x=float(np.abs(real[0][live]).sum()))
+    if eng.deck.get("bxby_solver", 0):
+        out["pc_iterations"] = int(eng.pc_stats()[0])
+    if eng.deck.get("laser_solver", 0) == 2:
+        out["laser_vcycles"] = int(eng.laser_vcycles())
+    if have_ions:
+        _, iv, lev, _ = eng.ions()
+        out.update(n_ionized=int(eng.ion_stats()[0]), ion_level_sum=int(lev[iv != 0].sum()))
+    return out
+
+
+def _beam_block(eng):
+    """n, sum w, sum |x|, |y|, |z|, |uz| of the static beam's blocks ([7][count_p] per slice, include/hpslice.h)"""
+    import torch
+    nbeam, off = eng.beam_layout()
+    if nbeam == 0:
+        return dict(n=0.0, w=0.0, x=0.0, y=0.0, z=0.0, uz=0.0)
+    t = torch.empty(7 * nbeam, dtype=torch.float64, device="cuda")
+    eng.initial_beam_into(t)
+    eng.sync()
+    h = t.cpu().numpy()
+    s = np.zeros(7)
+    for p in range(eng.deck["nz"]):
+        c = int(off[p + 1] - off[p])
+        if c:
+            s += np.abs(h[7 * off[p]:7 * off[p] + 7 * c].reshape(7, c)).sum(axis=1)
+    return dict(n=float(nbeam), w=s[6], x=s[0], y=s[1], z=s[2], uz=s[5])
+
+
+def _run_box(api, name, tile_size=16, sort_period=128):
+    fx, deck = _fixture(name)
+    nz = deck["nz"]
+    have_ions = bool(deck.get("ion_on", 0))
+    eng = api.SliceEngine(deck, tile_size=tile_size, sort_period=sort_period)
+    eng.set_diagnostics(True)
+    eng.begin_step()
+    trace = {}
+    for q in range(nz):
+        eng.solve_slice(nz - 1 - q)
+        if str(q) in fx["trace"]:
+            trace[str(q)] = _snapshot(eng, have_ions)
+    got = dict(checksums={k: float(v) for k, v in eng.checksums().items()}, final=_snapshot(eng, have_ions), trace=trace,
+               beam=_beam_block(eng) if fx["beam"] is not None else None,
+               sorts=eng.sorts() if tile_size else 0, fallbacks=eng.fallbacks() if tile_size else 0)
+    if REPORT_DIR:
+        os.makedirs(REPORT_DIR, exist_ok=True)
+        with open(os.path.join(REPORT_DIR, f"fullsize_{name}_gpu.json"), "w") as f:
+            json.dump(got, f, indent=1, sort_keys=True)
+    return fx, got
+
+
+def _compare(fx, got, *, rtol=1e-6, vc_rtol=1e-3, int_keys=("n_valid", "n_particles"), soft_int_keys=("vcycles",),
+             trace_from=0, skip_checksums=()):
+    bad = []
+    worst = 0.0
+    for k, v in fx["checksums"].items():
+        if k in skip_checksums:
+            continue
+        g = got["checksums"][k]
+        if v == 0.0:
+            if g != 0.0:
+                bad.append(("checksum", k, g, v))
+            continue
+        d = abs(g - v) / abs(v)
+        worst = max(worst, d)
+        if d > rtol:
+            bad.append(("checksum", k, g, v, d))
+    # plane sums along the box: relative to the component's largest plane sum
+    names = list(fx["final"]["slab_sum_abs"].keys())
+    scale = {c: max(max(s["slab_sum_abs"][c] for s in fx["trace"].values()), 1e-300) for c in names}
+    worst_trace = 0.0
+    for q, want in sorted(fx["trace"].items(), key=lambda kv: int(kv[0])):
+        if int(q) < trace_from:
+            continue
+        have = got["trace"][q]
+        for c in names:
+            if c in skip_checksums:
+                continue
+            d = abs(have["slab_sum_abs"][c] - want["slab_sum_abs"][c]) / scale[c]
+            worst_trace = max(worst_trace, d)
+            if d > rtol:
+                bad.append(("trace", q, c, have["slab_sum_abs"][c], want["slab_sum_abs"][c], d))
+        for k in int_keys:
+            if k in want and have[k] != want[k]:
+                bad.append(("trace", q, k, have[k], want[k]))
+        for k in soft_int_keys:
+            if k in want and abs(have[k] - want[k]) > max(2, vc_rtol * want[k]):
+                bad.append(("trace", q, k, have[k], want[k]))
+        for k in ("sum_w", "sum_abs_x"):
+            if abs(have[k] - want[k]) > 1e-6 * max(abs(want[k]), 1e-300):
+                bad.append(("trace", q, k, have[k], want[k]))
+    if fx.get("beam") is not None:
+        for k, v in fx["beam"].items():
+            if abs(got["beam"][k] - v) > 1e-9 * max(abs(v), 1e-300):
+                bad.append(("beam", k, got["beam"][k], v))
+    return bad, worst, worst_trace
+
+
+def test_config4_whole_box_vs_oracle_fixture(api):
+    """BASELINE configs[3] = bench.py's headline deck: blowout_wake 1024 x 1024 x 1024, 4 ppc, explicit solver."""
+    fx, got = _run_box(api, "config4")
+    bad, worst, worst_trace = _compare(fx, got)
+    print(f"config4: worst checksum deviation {worst:.2e}, worst plane-sum deviation {worst_trace:.2e}, V-cycles "
+          f"{got['final']['vcycles']} (oracle {fx['final']['vcycles']}), sorts {got['sorts']}, fallbacks {got['fallbacks']}")
+    assert not bad, bad[:10]
+    assert got["fallbacks"] > 0 and got["sorts"] > 1          # the schedule's slow paths were exercised
+
+
+def test_config3_whole_box_vs_oracle_fixture(api):
+    """BASELINE configs[2]: blowout_wake 512 x 512 x 1024, 4 ppc, explicit solver."""
+    fx, got = _run_box(api, "config3")
+    bad, worst, worst_trace = _compare(fx, got)
+    print(f"config3: worst checksum deviation {worst:.2e}, worst plane-sum deviation {worst_trace:.2e}, V-cycles "
+          f"{got['final']['vcycles']} (oracle {fx['final']['vcycles']})")
+    assert not bad, bad[:10]
+
+
+def test_config2_whole_box_vs_oracle_fixture(api):
+    """BASELINE configs[1]: linear_wake.normalized 256 x 256 x 512, 4 ppc, predictor-corrector Bx/By -- with its driver
+    reaching the head of the box, so that the loop takes the same path on both sides (the fixture script's
+    config2_beam_at_head_deck says why): held to 1e-6 with the same number of loop iterations."""
+    fx, got = _run_box(api, "config2_beam_at_head")
+    bad, worst, worst_trace = _compare(fx, got, int_keys=("n_valid", "n_particles", "pc_iterations"), soft_int_keys=())
+    print(f"config2 (beam at the head): worst checksum deviation {worst:.2e}, worst plane-sum deviation {worst_trace:.2e}, PC iterations "
+          f"{got['final']['pc_iterations']} (oracle {fx['final']['pc_iterations']})")
+    assert not bad, bad[:10]
+
+
+def test_config2_baseline_deck_whole_box_vs_oracle_fixture(api):
+    """The BASELINE deck itself (driver 54 slices into the box).  Ahead of the driver the serial CPU path holds exact zeros
+    and its loop leaves after one pass (ComputeRelBFieldError returns 0 for sum|B| = 0, fields/Fields.cpp:1283), also on the
+    first slice with beam; a scatter with atomics leaves 1e-16 residue and the loop iterates on it to max_iterations, as the
+    reference's GPU build must.  At a loop tolerance of 4e-2 and a mixing factor of 0.05 the result depends on that path:
+    the two runs agree to a few per cent where the driver sets in and to ~1e-2 behind it -- checked at 5e-2 on the
+    whole-box checksums of the physical fields, with the iteration counts equal slice by slice once both are behind the
+    transition."""
+    fx, got = _run_box(api, "config2")
+    phys = ("ExmBy", "EypBx", "Ez", "Bx", "By", "Psi", "jx", "jy", "jz", "rhomjz")
+    for k in phys:
+        v, g = fx["checksums"][k], got["checksums"][k]
+        assert abs(g - v) <= 5e-2 * abs(v), (k, g, v)
+    qs = sorted(fx["trace"], key=int)
+    behind = [q for q in qs if int(q) >= 95]
+    for a, b in zip(behind, behind[1:]):
+        d_or = fx["trace"][b]["pc_iterations"] - fx["trace"][a]["pc_iterations"]
+        d_gpu = got["trace"][b]["pc_iterations"] - got["trace"][a]["pc_iterations"]
+        assert abs(d_or - d_gpu) <= max(2, 0.02 * d_or), (a, b, d_or, d_gpu)
+    for q in qs:
+        assert got["trace"][q]["n_valid"] == fx["trace"][q]["n_valid"]
+    print(f"config2 (BASELINE deck): PC iterations {got['final']['pc_iterations']} (oracle {fx['final']['pc_iterations']}: exact zeros "
+          f"ahead of the driver)")
+
+
+@pytest.mark.parametrize("name", ["config5_fft", "config5_mg"])
+def test_config5_whole_box_vs_oracle_fixture(api, name):
+    """BASELINE configs[4] (laser envelope + N dopant with ADK ionisation), at the sizes the oracle's three envelope time
+    levels fit host memory (see the fixture's `what`)."""
+    fx, got = _run_box(api, name)
+    bad, worst, worst_trace = _compare(fx, got, int_keys=("n_valid", "n_particles", "n_ionized", "ion_level_sum"),
+                                       soft_int_keys=("vcycles", "laser_vcycles"))
+    print(f"{name}: worst checksum deviation {worst:.2e}, worst plane-sum deviation {worst_trace:.2e}, ionised "
+          f"{got['final']['n_ionized']} (oracle {fx['final']['n_ionized']})")
+    assert not bad, bad[:10]
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from hipace_amd import _lib, api as A
+    _lib.lib()      # raises if libhpslice.so is missing: no fallback
+    return A
