@@ -103,6 +103,29 @@ def pmc_traffic(kernel_prefix):
     return None, None
 
 
+def pmc_slice_bytes():
+    """HBM bytes per SLICE summed over every kernel of the committed --pmc summary (FETCH_SIZE x2 + WRITE_SIZE, as pmc_traffic):
+    launches x bytes per launch of every kernel / the slices of that run (= the launches of the deposition kernel, one per
+    slice).  Counter traffic of the whole schedule, re-sorts amortised as they fell in the counted window; None without a summary."""
+    import csv
+    path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
+    if not os.path.exists(path):
+        return None
+    tot, nsl = 0.0, 0
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            try:
+                b = (2.0 * float(r["FETCH_SIZE_raw_per_launch"]) + float(r["WRITE_SIZE_raw_per_launch"])) * 1024.0
+            except ValueError:
+                continue
+            if b != b:      # nan: the kernel has no WRITE_SIZE row
+                continue
+            tot += b * int(r["launches"])
+            if r["kernel"].startswith("void hps::k_deposit_tiled<2, 16, 51"):
+                nsl = int(r["launches"])
+    return tot / nsl if nsl else None
+
+
 def cpu_baseline(n, ppc, nslices, threads):
     """Time the CPU oracle (restatement of the reference's CPU path) on the head `nslices` slices of the same deck:
     one thread (the reference's serial build) and `threads` OpenMP threads (4-colour tiles in the scatter kernels, as
@@ -299,9 +322,11 @@ def main():
         args.inflight = 1
     if world > 1 and not args.inflight_ring:
         args.inflight = 1
-    if args.ring_self or args.fuse or args.config2:
-        args.inflight = 1                       # (the predictor-corrector loop holds the host once per iteration: its slice has no
-                                                #  enqueue-only first half for a one-thread driver of several engines to interleave)
+    if args.ring_self or args.fuse:
+        args.inflight = 1
+    if args.config2 and os.environ.get("HPS_PC_SPECULATE", "1") == "0":
+        args.inflight = 1                       # (host-controlled predictor-corrector loop: the host is held once per iteration, the slice
+                                                #  has no enqueue-only first half for a one-thread driver of several engines to interleave)
     eng = api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period)
     lanes = 1                                   # the headline measurement: one engine
     engines = [eng]
@@ -522,6 +547,21 @@ def main():
         inflight = dict(value=W * nL / dtL, stages_per_gpu=L, slices_per_stage=nL, seconds=dtL,
                         window="whole boxes, pipeline fill included" if whole else
                                f"{nL} slices per stage in steady state (device clock: events on the stages' streams)")
+        if not (args.config5 or args.config2):
+            # the GPU's time per slice with L stages sharing it, against the survey's fused lower bound and the counter traffic
+            nvL = sum(e.stats()["vcycles"] for e in lane_engines) / max(sum(e.stats()["slices"] for e in lane_engines), 1)
+            _, b_fusedL = slice_bytes(args.n, args.ppc * args.ppc, nvL)
+            t_gpu = dtL * world / (W * nL)
+            cb = pmc_slice_bytes() if (args.tile == 16 and args.n == 1024 and args.ppc == 2) else None
+            inflight["roofline"] = {
+                "seconds_per_slice_of_the_gpu": t_gpu, "vcycles": nvL,
+                "algorithmic_bytes_fused_lower_bound": b_fusedL, "achieved_fused": b_fusedL / t_gpu / 1e9,
+                "frac_fused_lower_bound": b_fusedL / t_gpu / 1e9 / HBM_PEAK_GBS,
+                "counter_bytes_per_slice": cb, "achieved_counter": cb / t_gpu / 1e9 if cb else None,
+                "frac_counter_bytes": cb / t_gpu / 1e9 / HBM_PEAK_GBS if cb else None,
+                "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "note": "one stage's counter bytes per slice (profiles/" + PMC_SUMMARY + ") over the GPU's time per slice with all stages "
+                        "in flight; the aggregate counter run of the L-stage window is profiles/r04_inflight_pmc.csv"}
         del lane_engines[1:]
 
     if rank == 0:
@@ -595,14 +635,24 @@ def main():
             nv = out["vcycles_per_slice"]
             b_ref, b_fused = slice_bytes(args.n, args.ppc * args.ppc, nv)
             t_slice = 1.0 / out["value"] * world if out["value"] > 0 else 0.0
+            cb = pmc_slice_bytes() if headline else None
             out["roofline"]["slice"] = {
-                "algorithmic_bytes_reference_passes": b_ref, "algorithmic_bytes_fused_lower_bound": b_fused, "vcycles": nv,
-                "achieved_reference_passes": b_ref / t_slice / 1e9 if t_slice else 0.0,
-                "frac_reference_passes": b_ref / t_slice / 1e9 / HBM_PEAK_GBS if t_slice else 0.0,
+                "vcycles": nv,
+                # what the algorithm has to move at least (fused lower bound) and what the counters say the engine
+                # moves, each over the measured time per slice of ONE stage
+                "algorithmic_bytes_fused_lower_bound": b_fused,
+                "achieved_fused": b_fused / t_slice / 1e9 if t_slice else 0.0,
+                "frac_fused_lower_bound": b_fused / t_slice / 1e9 / HBM_PEAK_GBS if t_slice else 0.0,
                 "slices_per_s_at_peak_fused": HBM_PEAK_GBS * 1e9 / b_fused,
-                "note": "bytes per slice from SURVEY 8(d) (what the algorithm has to move, not counter traffic) / seconds per slice of one "
-                        "stage (1 / value per GPU); the engine's own pass structure moves less than the reference's (fused sources, "
-                        "two-pass y transform, fused level-0 multigrid passes, no staging planes)"}
+                "counter_bytes_per_slice": cb,
+                "achieved_counter": cb / t_slice / 1e9 if (cb and t_slice) else None,
+                "frac_counter_bytes": cb / t_slice / 1e9 / HBM_PEAK_GBS if (cb and t_slice) else None,
+                "counter_source": f"profiles/{PMC_SUMMARY}: sum over all kernels of launches x (FETCH_SIZE x2 + WRITE_SIZE) / slices of that run "
+                                  "(committed summary, not collected in this run)" if cb else None,
+                # for reference only: the bytes the REFERENCE's pass structure would move (the engine does not move them)
+                "reference_passes": {"algorithmic_bytes": b_ref, "achieved": b_ref / t_slice / 1e9 if t_slice else 0.0,
+                                     "frac": b_ref / t_slice / 1e9 / HBM_PEAK_GBS if t_slice else 0.0},
+                "note": "seconds per slice of one stage = 1 / value per GPU"}
         if args.cpu_slices > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.n, args.ppc, args.cpu_slices, args.cpu_threads or min(os.cpu_count() or 1, CPU_THREADS_DEFAULT))
         emit(out)

@@ -12,10 +12,15 @@
 
 void mg_rider (void* mg_handle, int** dev_words, const int** host_words);     // multigrid.hip
 namespace hps {
+
+constexpr int PC_MAX_SPEC = 64;      // flags / host slots of the device-controlled predictor-corrector loop: iterations 1 .. 62
+
 // hps_mg_solve1 in two halves (multigrid.hip): kernels enqueued between them are gated on mg_gate_after_enqueued
 int mg_solve1_begin (void* mg_handle, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, double tol_rel, double tol_abs,
                      int max_iters, hipStream_t st);
 void mg_solve1_forget_hierarchy (void* mg_handle);
+bool poisson_gateable (void* poisson_handle);
+void poisson_set_gate (void* poisson_handle, const int* gate);
 int mg_solve1_prepare (void* mg_handle, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, int max_iters, hipStream_t st);
 // ... in one launch with the -grad Psi / Sx, Sy pass of the slab (multigrid.hip: k_hierarchy_gradpsi); *done = false if this grid's
 // hierarchy needs more than that launch (then nothing has been enqueued)
@@ -117,9 +122,11 @@ struct Engine {
     long total_vcycles = 0, slices_done = 0;
     // predictor-corrector Bx/By (hipace.bxby_solver = predictor-corrector): d_pc = {sum |B|, sum |B - B_iter|, halo
     // fallback counter (int), spare}, h_pc its pinned image read back once per iteration
+    // device-side control of the loop (HPS_PC_SPECULATE=0: off): per-iteration flags, iterations enqueued ahead of the host
+    int* d_pc_go = nullptr; bool pc_speculate = false; int pc_spec_iters = 1, pc_enqueued = 0, pc_islice = -1; double pc_base_seq = 0.0, pc_last_err = 0.0;
+    int solve_slice_pc_begin (int islice); int solve_slice_pc_finish (int islice); int pc_enqueue_iteration (int it); int pc_wait_slot (int slot, double seq);
     bool pc = false; double* d_pc = nullptr; double* d_pc_aux = nullptr; double* h_pc = nullptr; double* h_pc_dev = nullptr; double pc_seq = 0.0; long pc_iterations = 0; double pc_err_sum = 0.0;
     double pc_tol = 4e-2, pc_mix = 0.05; int pc_max_iter = 30;
-    int solve_slice_pc (int islice);
     int c_aabs = -1; double* d_laser_sum = nullptr;       // laser: slab component of |a|^2, device sum of |a| (diagnostics)
     LaserState* laser = nullptr;                          // envelope arrays + solver (laser.hip)
     // The envelope's advance of a slice needs chi of the slice and the envelope of the slices before it -- nothing else
@@ -148,7 +155,7 @@ struct Engine {
     int create (const hps_deck& deck, int device);
     int init_beam ();
     int begin_step ();
-    int deposit_beam_slice (int islice, int cjx, int cjy, int cjz);
+    int deposit_beam_slice (int islice, int cjx, int cjy, int cjz, const int* go = nullptr);
     void deposit_grid_current (int islice, int cjz);
     int solve_slice (int islice);
     int solve_slice_begin (int islice);      // ... in two halves: everything up to the Bx/By solve's norm read-back is enqueued,

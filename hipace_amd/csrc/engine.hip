@@ -15,7 +15,7 @@ namespace hps {
 int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[6], double charge,
                            double mass, int order, double max_qsa, int can_ionize, int* n_qsa, Tiling* T, int* n_fallback,
                            hipStream_t st, int aabs_comp = -1, const int* tile_flag = nullptr, TailWork tw = TailWork{},
-                           const BeamPairWork* beam = nullptr);
+                           const BeamPairWork* beam = nullptr, const int* go = nullptr);
 int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int cache[4], const int depos[2],
                             double charge, double mass, int order, int dtype, int can_ionize, Tiling* T, int* n_fallback,
                             hipStream_t st, int aabs_comp = -1, const int* tile_flag = nullptr, TailWork tw = TailWork{});
@@ -285,8 +285,9 @@ void k_init_plasma (hps_plasma pl, long n, int nx, int ny, int ppcx, int ppcy, d
 template <int ORDER>
 __global__ __launch_bounds__(256)
 void k_beam_deposit (SlabView f, BeamView b, long first, long count, int cjx, int cjy, int cjz,
-                     double q_invvol, double clightsq_inv, double dx_inv, double dy_inv, double xoff, double yoff)
+                     double q_invvol, double clightsq_inv, double dx_inv, double dy_inv, double xoff, double yoff, const int* go)
 {
+    if (go && *go == 0) return;      // (an iteration of the predictor-corrector loop enqueued past the loop's end)
     const long t = (long)blockIdx.x*blockDim.x + threadIdx.x;
     if (t >= count) return;
     const long ip = first + t;
@@ -337,7 +338,7 @@ Engine::~Engine ()
     (void)hipFree(staging); (void)hipFree(beam_data); (void)hipFree(beam_init);
     (void)hipFree(bm_store); (void)hipFree(bm_nsub); (void)hipFree(bm_nsub_scr); (void)hipFree(d_B); (void)hipFree(d_nfront);
     (void)hipFree(d_Bimp); (void)hipFree(d_beam_overflow); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
-    (void)hipFree(d_pc); (void)hipFree(d_pc_aux); if (h_pc) (void)hipHostFree(h_pc);
+    (void)hipFree(d_pc); (void)hipFree(d_pc_aux); (void)hipFree(d_pc_go); if (h_pc) (void)hipHostFree(h_pc);
     (void)hipFree(d_laser_sum);
     if (laser) laser_destroy(*this);
     ion_destroy(*this);
@@ -579,9 +580,14 @@ int Engine::create (const hps_deck& deck, int device)
         HPS_HIP_CHECK(hipMemset(d_pc, 0, 4*sizeof(double)));
         HPS_HIP_CHECK(hipMalloc(&d_pc_aux, 4*sizeof(double)));      // error of the last two iterations (k_pc_mix)
         HPS_HIP_CHECK(hipMemset(d_pc_aux, 0, 4*sizeof(double)));
-        HPS_HIP_CHECK(hipHostMalloc(&h_pc, 4*sizeof(double), hipHostMallocMapped));
-        std::memset(h_pc, 0, 4*sizeof(double));
+        HPS_HIP_CHECK(hipHostMalloc(&h_pc, 4*PC_MAX_SPEC*sizeof(double), hipHostMallocMapped));      // slot 0 + one slot per loop iteration
+        std::memset(h_pc, 0, 4*PC_MAX_SPEC*sizeof(double));
         HPS_HIP_CHECK(hipHostGetDevicePointer((void**)&h_pc_dev, h_pc, 0));
+        HPS_HIP_CHECK(hipMalloc(&d_pc_go, PC_MAX_SPEC*sizeof(int)));
+        HPS_HIP_CHECK(hipMemset(d_pc_go, 0, PC_MAX_SPEC*sizeof(int)));
+        // HPS_PC_SPECULATE=0: the host decides after every iteration, as in rounds 1-3
+        {   const char* v = std::getenv("HPS_PC_SPECULATE");
+            pc_speculate = !(v && std::atoi(v) == 0) && pc_max_iter <= PC_MAX_SPEC - 2 && poisson_gateable(ps); }
         d_nfallback = reinterpret_cast<int*>(d_pc + 2); h_nfallback = reinterpret_cast<const int*>(h_pc + 2);
     }
     if (c_aabs >= 0) { if (int e = laser_create(*this)) return e; }
@@ -728,7 +734,7 @@ void Engine::deposit_grid_current (int islice, int cjz)
                        d.grid_current_peak*std::exp(-0.5*(delta_z*delta_z)));
 }
 
-int Engine::deposit_beam_slice (int islice, int cjx, int cjy, int cjz)
+int Engine::deposit_beam_slice (int islice, int cjx, int cjy, int cjz, const int* go)
 {
     if (nbeam == 0 || islice < 0 || islice >= d.nz) return HPS_OK;
     if (moving) return beam_deposit_moving(*this, d.nz - 1 - islice, cjx, cjy, cjz);
@@ -742,10 +748,10 @@ int Engine::deposit_beam_slice (int islice, int cjx, int cjy, int cjz)
     const dim3 grid(ceil_div(count, 256)), block(256);
     SlabView f(slab);
     switch (d.order) {
-        case 0: hipLaunchKernelGGL(k_beam_deposit<0>, grid, block, 0, st, f, beam, first, count, cjx, cjy, cjz, q_invvol, csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff); break;
-        case 1: hipLaunchKernelGGL(k_beam_deposit<1>, grid, block, 0, st, f, beam, first, count, cjx, cjy, cjz, q_invvol, csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff); break;
-        case 2: hipLaunchKernelGGL(k_beam_deposit<2>, grid, block, 0, st, f, beam, first, count, cjx, cjy, cjz, q_invvol, csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff); break;
-        default: hipLaunchKernelGGL(k_beam_deposit<3>, grid, block, 0, st, f, beam, first, count, cjx, cjy, cjz, q_invvol, csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff); break;
+        case 0: hipLaunchKernelGGL(k_beam_deposit<0>, grid, block, 0, st, f, beam, first, count, cjx, cjy, cjz, q_invvol, csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff, go); break;
+        case 1: hipLaunchKernelGGL(k_beam_deposit<1>, grid, block, 0, st, f, beam, first, count, cjx, cjy, cjz, q_invvol, csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff, go); break;
+        case 2: hipLaunchKernelGGL(k_beam_deposit<2>, grid, block, 0, st, f, beam, first, count, cjx, cjy, cjz, q_invvol, csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff, go); break;
+        default: hipLaunchKernelGGL(k_beam_deposit<3>, grid, block, 0, st, f, beam, first, count, cjx, cjy, cjz, q_invvol, csq_inv, 1.0/gm.dx, 1.0/gm.dy, gm.xoff, gm.yoff, go); break;
     }
     return HPS_OK;
 }
@@ -1032,9 +1038,16 @@ int Engine::fill_field_diagnostic (int islice)
 // the valid cells
 // With `host` (mapped pinned memory) the last workgroup to finish posts {sum |B|, sum |B - B_iter|, fallback counter,
 // seq} there, seq last behind a system-scope fence: the host polls seq instead of a copy + stream synchronise.
+// Loop control on the device (speculative iterations): `go` points at the word of iteration `it` in a per-slice array of
+// flags (k_pc_guess: flag[1] = 1, the others 0); every kernel of an iteration does nothing when its word is 0.  The last
+// workgroup here decides whether the loop goes on -- go[1] = (err > tol && it < max_it), the condition of Hipace.cpp:957 --
+// and posts to slot `it` of the host array (4 doubles per slot; the halo-fallback counter also to slot 0, where the
+// engine's re-sort rule reads it).
 __global__ __launch_bounds__(256)
-void k_rel_b_error (SlabView f, int cB, int cBit, double* out, volatile double* host, double seq)
+void k_rel_b_error (SlabView f, int cB, int cBit, double* out, volatile double* host, double seq,
+                    int* go = nullptr, double tol = 0.0, int it = 0, int max_it = 0)
 {
+    if (go && *go == 0) return;
     double sb = 0.0, sd = 0.0;
     const long cells = (long)f.nx*f.ny;
     for (long c = (long)blockIdx.x*blockDim.x + threadIdx.x; c < cells; c += (long)gridDim.x*blockDim.x) {
@@ -1057,9 +1070,16 @@ void k_rel_b_error (SlabView f, int cB, int cBit, double* out, volatile double* 
             unsigned int* done = reinterpret_cast<unsigned int*>(out + 3);
             if (atomicAdd(done, 1u) == gridDim.x - 1) {
                 __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                host[0] = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                host[1] = __hip_atomic_load(out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                host[2] = __hip_atomic_load(out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double tb = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double td = __hip_atomic_load(out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double fbk = __hip_atomic_load(out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (go) {
+                    const double err = tb > 0.0 ? td/tb : 0.0;
+                    __hip_atomic_store(go + 1, (err > tol && it < max_it) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    host[2] = fbk;                 // slot 0: the fallback counter where the host looks for it
+                    host += 4*it;
+                }
+                host[0] = tb; host[1] = td; host[2] = fbk;
                 __threadfence_system();
                 host[3] = seq;
             }
@@ -1071,9 +1091,10 @@ void k_rel_b_error (SlabView f, int cB, int cBit, double* out, volatile double* 
 // - m PCPrevIter with m = exp(-0.5 (err/(2.5 tol))^2), err = sums[1]/sums[0] of (Previous, PCPrevIter);
 // PCIter = 0; PCPrevIter = This.  Whole planes incl. guards, both components.
 __global__ __launch_bounds__(256)
-void k_pc_guess (double* p, long ns, long plane, const double* sums, double tol)
+void k_pc_guess (double* p, long ns, long plane, const double* sums, double tol, int* go)
 {
     const long s = (long)blockIdx.x*blockDim.x + threadIdx.x;
+    if (s < PC_MAX_SPEC && go) go[s] = (s == 1);      // the loop of this slice starts: its first iteration always runs (Hipace.cpp:956)
     if (s >= plane) return;
     const double err = sums[0] > 0.0 ? sums[1]/sums[0] : 0.0;
     const double q = err/(2.5*tol);
@@ -1090,8 +1111,9 @@ void k_pc_guess (double* p, long ns, long plane, const double* sums, double tol)
 // st[1] = mu0 (d_x jz - d_z jx), d_z = (Previous - Next)/(2 dz)
 __global__ __launch_bounds__(256)
 void k_rhs_bxby (SlabView f, double mu0, double hdx_inv, double hdy_inv, double hdz_inv, double* staging, long plane,
-                 double* sums)
+                 double* sums, const int* go)
 {
+    if (go && *go == 0) return;
     const int i = blockIdx.x*blockDim.x + threadIdx.x;
     const int j = blockIdx.y;
     if (i == 0 && j == 0) { sums[0] = 0.0; sums[1] = 0.0; }      // for the k_rel_b_error of this pass
@@ -1104,8 +1126,9 @@ void k_rhs_bxby (SlabView f, double mu0, double hdx_inv, double hdy_inv, double 
 
 // MixAndShiftBfields (fields/Fields.cpp:1175-1231) + the reset of the temporary currents (Hipace.cpp:1000-1003)
 __global__ __launch_bounds__(256)
-void k_pc_mix (double* p, long ns, long plane, const double* sums, double* err_slots, int it, double mix)
+void k_pc_mix (double* p, long ns, long plane, const double* sums, double* err_slots, int it, double mix, const int* go)
 {
+    if (go && *go == 0) return;      // (this iteration's own flag: its k_rel_b_error has written the NEXT one's)
     const long s = (long)blockIdx.x*blockDim.x + threadIdx.x;
     // the weights of Hipace.cpp:1005-1014 from this iteration's error and the previous one's, on the device: the kernel is
     // enqueued before the host has read the error.  err_slots[it & 1] <- err for the next iteration (nobody reads that slot now)
@@ -1127,7 +1150,7 @@ void k_pc_mix (double* p, long ns, long plane, const double* sums, double* err_s
 // SolveOneSlice with hipace.bxby_solver = predictor-corrector (Hipace.cpp:556-728; the explicit branch is
 // Engine::solve_slice below).  Event marks keep the 10 intervals of the explicit schedule: the loop is booked under
 // the Bx/By-solve interval.
-int Engine::solve_slice_pc (int islice)
+int Engine::solve_slice_pc_begin (int islice)
 {
     SlabView f(slab);
     const long plane = slab.nstride;
@@ -1172,41 +1195,113 @@ int Engine::solve_slice_pc (int islice)
     // the loop (Hipace.cpp:935-1031)
     HPS_HIP_CHECK(hipMemsetAsync(d_pc, 0, 2*sizeof(double), st));
     hipLaunchKernelGGL(k_rel_b_error, dim3(128), b256, 0, st, f, HPS_PC_P_BX, HPS_PC_PIT_BX, d_pc, (volatile double*)nullptr, 0.0);
-    hipLaunchKernelGGL(k_pc_guess, gplane, b256, 0, st, slab.p, slab.nstride, plane, d_pc, pc_tol);
+    const bool spec = pc_speculate && tiling && !moving;
+    hipLaunchKernelGGL(k_pc_guess, gplane, b256, 0, st, slab.p, slab.nstride, plane, d_pc, pc_tol, spec ? d_pc_go : (int*)nullptr);
+    pc_islice = islice;
+    if (spec) {
+        // Device-side loop control: as many iterations as the previous slice took are enqueued at once, every kernel of
+        // iteration `it` looking at the flag its predecessor's error kernel has written (k_rel_b_error): the queue never
+        // runs dry while an error travels to the host and the next iteration's ten launches travel back.  The host reads
+        // the slots in solve_slice_pc_finish and adds iterations one by one only if the speculated ones did not suffice.
+        pc_base_seq = pc_seq;
+        pc_enqueued = 0;
+        const int K = std::max(1, std::min(pc_spec_iters, pc_max_iter));
+        for (int it = 1; it <= K; ++it) if ((e = pc_enqueue_iteration(it))) return e;
+        return HPS_OK;
+    }
     double err = 1.0;
     int it = 0;
-    const int comp_push[5] = {HPS_PC_PSI, HPS_PC_EZ, HPS_PC_BX, HPS_PC_BY, HPS_PC_BZ};
-    // The mixing weights of an iteration are computed on the device (k_pc_mix) and the mixing is enqueued before the host
-    // waits for the iteration's error: it runs while the error travels (config 2: +5 % iterations per second).  Enqueuing
-    // the next iteration's push there as well, gated on the loop's condition, was measured and gains nothing more.
+    // (host-controlled loop.)  The mixing weights of an iteration are computed on the device (k_pc_mix) and the mixing is
+    // enqueued before the host waits for the iteration's error: it runs while the error travels (config 2: +5 % iterations
+    // per second).
     while (err > pc_tol && it < pc_max_iter) {
         ++it; ++pc_iterations;
-        // plasma to the temporary next slice, its jx jy (+ the beam's) there
-        if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 1, d.n_subcycles, 0, tiling, d_nfallback, st))) return e; }
-        else        { if ((e = hps_advance_plasma(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 1, d.n_subcycles, 0, st))) return e; }
-        {   const int comp[6] = {HPS_PC_N_JX, HPS_PC_N_JY, -1, -1, -1, -1};
-            if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st))) return e; }
-            else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
-        if ((e = deposit_beam_slice(islice - 1, HPS_PC_N_JX, HPS_PC_N_JY, -1))) return e;
-        hipLaunchKernelGGL(k_rhs_bxby, dim3(ceil_div(d.nx, 256), d.ny), b256, 0, st, f, gm.mu0, 0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy),
-                           0.5*(1.0/gm.dz), staging, nval, d_pc);
-        {   const int comps[2] = {HPS_PC_IT_BX, HPS_PC_IT_BY};
-            if ((e = hps_poisson_solve_batch(ps, 2, staging, slab, comps, st))) return e; }
-        pc_seq += 1.0;
-        hipLaunchKernelGGL(k_rel_b_error, dim3(128), b256, 0, st, f, HPS_PC_BX, HPS_PC_IT_BX, d_pc, (volatile double*)h_pc_dev, pc_seq);
-        hipLaunchKernelGGL(k_pc_mix, gplane, b256, 0, st, slab.p, slab.nstride, plane, d_pc, d_pc_aux, it, pc_mix);
-        {   // wait for the post; fall back to the stream's status every so often so that a failed launch cannot hang us
-            volatile double* hp = h_pc;
-            long spins = 0;
-            while (hp[3] != pc_seq) {
-                if ((++spins & 0xfffff) == 0 && hipStreamQuery(st) != hipErrorNotReady) {
-                    if (hp[3] == pc_seq) break;
-                    HPS_HIP_CHECK(hipStreamSynchronize(st));
-                    if (hp[3] != pc_seq) { set_error("predictor-corrector: the error read-back never arrived"); return HPS_ERR_HIP; }
-                }
-            }
-            __atomic_thread_fence(__ATOMIC_ACQUIRE); }
+        pc_enqueued = it - 1;
+        if ((e = pc_enqueue_iteration(it))) return e;
+        if ((e = pc_wait_slot(0, pc_seq))) return e;
         err = h_pc[0] > 0.0 ? h_pc[1]/h_pc[0] : 0.0;
+    }
+    pc_last_err = err;
+    return HPS_OK;
+}
+
+// one iteration of the loop on the engine's stream (Hipace.cpp:958-1030); with device-side control every launch is gated
+// on the iteration's flag
+int Engine::pc_enqueue_iteration (int it)
+{
+    SlabView f(slab);
+    const long plane = slab.nstride;
+    const dim3 b256(256);
+    const dim3 gplane(ceil_div(plane, 256));
+    const long nval = (long)d.nx*d.ny;
+    const int islice = pc_islice;
+    const bool spec = pc_speculate && tiling && !moving;
+    int* go = spec ? d_pc_go + it : nullptr;
+    const int comp_push[5] = {HPS_PC_PSI, HPS_PC_EZ, HPS_PC_BX, HPS_PC_BY, HPS_PC_BZ};
+    int e;
+    // plasma to the temporary next slice, its jx jy (+ the beam's) there
+    if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 1, d.n_subcycles, 0, tiling, d_nfallback, st, -1, nullptr, go))) return e; }
+    else        { if ((e = hps_advance_plasma(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 1, d.n_subcycles, 0, st))) return e; }
+    {   const int comp[6] = {HPS_PC_N_JX, HPS_PC_N_JY, -1, -1, -1, -1};
+        if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st, -1, nullptr, TailWork{}, nullptr, go))) return e; }
+        else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
+    if ((e = deposit_beam_slice(islice - 1, HPS_PC_N_JX, HPS_PC_N_JY, -1, go))) return e;
+    hipLaunchKernelGGL(k_rhs_bxby, dim3(ceil_div(d.nx, 256), d.ny), b256, 0, st, f, gm.mu0, 0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy),
+                       0.5*(1.0/gm.dz), staging, nval, d_pc, (const int*)go);
+    {   const int comps[2] = {HPS_PC_IT_BX, HPS_PC_IT_BY};
+        poisson_set_gate(ps, go);
+        e = hps_poisson_solve_batch(ps, 2, staging, slab, comps, st);
+        poisson_set_gate(ps, nullptr);
+        if (e) return e; }
+    pc_seq += 1.0;
+    hipLaunchKernelGGL(k_rel_b_error, dim3(128), b256, 0, st, f, HPS_PC_BX, HPS_PC_IT_BX, d_pc, (volatile double*)h_pc_dev, pc_seq,
+                       go, pc_tol, it, pc_max_iter);
+    hipLaunchKernelGGL(k_pc_mix, gplane, b256, 0, st, slab.p, slab.nstride, plane, d_pc, d_pc_aux, it, pc_mix, (const int*)go);
+    pc_enqueued = it;
+    return HPS_OK;
+}
+
+// wait for the post of sequence number `seq` in host slot `slot`; fall back to the stream's status every so often so that a
+// failed launch cannot hang us
+int Engine::pc_wait_slot (int slot, double seq)
+{
+    volatile double* hp = h_pc + 4*slot;
+    long spins = 0;
+    while (hp[3] != seq) {
+        if ((++spins & 0xfffff) == 0 && hipStreamQuery(st) != hipErrorNotReady) {
+            if (hp[3] == seq) break;
+            HPS_HIP_CHECK(hipStreamSynchronize(st));
+            if (hp[3] != seq) { set_error("predictor-corrector: the error read-back never arrived"); return HPS_ERR_HIP; }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return HPS_OK;
+}
+
+// second half of a predictor-corrector slice: the loop's end (device-side control: read the posted errors, add iterations if
+// the speculated ones did not suffice), diagnostics, the committing push, ShiftSlices
+int Engine::solve_slice_pc_finish (int islice)
+{
+    SlabView f(slab);
+    const long plane = slab.nstride;
+    const dim3 b256(256);
+    const dim3 gplane(ceil_div(plane, 256));
+    const int comp_push[5] = {HPS_PC_PSI, HPS_PC_EZ, HPS_PC_BX, HPS_PC_BY, HPS_PC_BZ};
+    int e;
+    double err = pc_last_err;
+    if (pc_speculate && tiling && !moving) {
+        int it = 0;
+        err = 1.0;
+        while (err > pc_tol && it < pc_max_iter) {
+            ++it; ++pc_iterations;
+            if (it > pc_enqueued) { if ((e = pc_enqueue_iteration(it))) return e; }
+            if ((e = pc_wait_slot(it, pc_base_seq + it))) return e;
+            const volatile double* hp = h_pc + 4*it;
+            err = hp[0] > 0.0 ? hp[1]/hp[0] : 0.0;
+        }
+        // (iterations enqueued beyond `it` find their flag at 0 and do nothing; their sequence numbers are never posted)
+        pc_spec_iters = it;
+        pc_seq = pc_base_seq + std::max(it, pc_enqueued);
     }
     pc_err_sum += err;
     mark();   // b6
@@ -1250,7 +1345,7 @@ int Engine::solve_slice (int islice)
 int Engine::solve_slice_begin (int islice)
 {
     HPS_REQUIRE(pending_slice == -1, "hps_engine_solve_slice_begin: the previous slice has not been finished");
-    if (pc) { if (int e = solve_slice_pc(islice)) return e; pending_slice = islice; return HPS_OK; }
+    if (pc) { if (int e = solve_slice_pc_begin(islice)) return e; pending_slice = islice; return HPS_OK; }
     SlabView f(slab);
     const long plane = slab.nstride;
     const dim3 b256(256);
@@ -1421,7 +1516,7 @@ int Engine::solve_slice_begin (int islice)
     const bool gated_ion = gate_push && gate_ion_push && tiling && !fuse && ion.n > 0 && ion.tiling && np > 0 && tiling->sorted_n > 0 && fold_tail
                            && !diagnostics && !d_fd && !d_insitu;
     const int comp_push[5] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ};
-    {   int iters = 0, extra = 0;
+    {
         if ((e = mg_solve1_begin(mg, slab, HPS_C_BX, HPS_C_SY, HPS_C_CHI, d.mg_tol_rel, d.mg_tol_abs, 200, st))) return e;
         if (gated_ion) {
             mark();   // b6
@@ -1460,7 +1555,7 @@ int Engine::solve_slice_finish (int islice)
 {
     HPS_REQUIRE(pending_slice == islice, "hps_engine_solve_slice_finish: not the slice that hps_engine_solve_slice_begin started");
     pending_slice = -1;
-    if (pc) return HPS_OK;
+    if (pc) return solve_slice_pc_finish(islice);
     SlabView f(slab);
     const long plane = slab.nstride;
     const dim3 b256(256);

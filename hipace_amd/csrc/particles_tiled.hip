@@ -132,8 +132,11 @@ __device__ __forceinline__ void load_region (double* img, const SlabView& f, con
 template <int ORDER, int TS, int MASK, bool LASER = false>
 __global__ __launch_bounds__(256)
 void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx, DepComps cm,
-                      PartConsts k, int* n_qsa, int* n_fallback, const int* __restrict__ tile_flag, TailWork tw, BeamPairWork bw)
+                      PartConsts k, int* n_qsa, int* n_fallback, const int* __restrict__ tile_flag, TailWork tw, BeamPairWork bw,
+                      const int* go)
 {
+    // an iteration of the predictor-corrector loop enqueued past the loop's end (engine.hip: pc_enqueue_iteration)
+    if (go && *go == 0) return;
     // the first bw.nwg workgroups: the static beam's deposits of this slice (beam_deposit.h) -- a 7.9 us launch of a few
     // thousand particles that nothing ahead of the Sx/Sy initialisation waits for, off the slice's chain of launches.  (At the
     // head of the grid: at its end they were a tail of 6 us behind the last tile.)
@@ -485,7 +488,7 @@ template <class T> __device__ __forceinline__ void sto (T* base, unsigned o, T v
 // the same with the non-temporal hint (global_load / global_store ... nt): for arrays only this kernel touches -- the
 // half-step momenta -- so that they do not push what the next deposition reads (x, y, w, ux, uy, psi) out of the caches
 #ifndef HPS_PUSH_NT
-#define HPS_PUSH_NT 0
+#define HPS_PUSH_NT 1
 #endif
 template <class T> __device__ __forceinline__ T ldo_nt (const T* base, unsigned o)
 {
@@ -917,7 +920,7 @@ static int set_lds (K kernel, size_t bytes)
 
 int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[6], double charge,
                            double mass, int order, double max_qsa, int can_ionize, int* n_qsa, Tiling* T, int* n_fallback,
-                           hipStream_t st, int aabs_comp, const int* tile_flag, TailWork tw, const BeamPairWork* beam)
+                           hipStream_t st, int aabs_comp, const int* tile_flag, TailWork tw, const BeamPairWork* beam, const int* go)
 {
     if (pl.n == 0) return HPS_OK;
     const BeamPairWork bw = beam ? *beam : BeamPairWork{};
@@ -935,9 +938,9 @@ int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
     SlabView f(slab);
     int mask = 0; for (int c = 0; c < 6; ++c) mask |= (comp[c] >= 0) << c;
 #define CALLM(O, S, M) { if (int e = set_lds(k_deposit_tiled<O, S, M>, lds)) return e; \
-        hipLaunchKernelGGL((k_deposit_tiled<O, S, M>), dim3(T->g.ntiles + tw.nwg + bw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag, tw, bw); }
+        hipLaunchKernelGGL((k_deposit_tiled<O, S, M>), dim3(T->g.ntiles + tw.nwg + bw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag, tw, bw, go); }
 #define CALLL(O, S, M) { if (int e = set_lds(k_deposit_tiled<O, S, M, true>, lds)) return e; \
-        hipLaunchKernelGGL((k_deposit_tiled<O, S, M, true>), dim3(T->g.ntiles + tw.nwg + bw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag, tw, bw); }
+        hipLaunchKernelGGL((k_deposit_tiled<O, S, M, true>), dim3(T->g.ntiles + tw.nwg + bw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag, tw, bw, go); }
 #define CALL(O, S) { if (aabs_comp >= 0) { if (mask == 51) CALLL(O, S, 51) else CALLL(O, S, -1) } \
                      else if (mask == 51) CALLM(O, S, 51) else if (mask == 59) CALLM(O, S, 59) else if (mask == 32) CALLM(O, S, 32) \
                      else if (mask == 3) CALLM(O, S, 3) else if (mask == 39) CALLM(O, S, 39) else if (mask == 47) CALLM(O, S, 47) else CALLM(O, S, -1) }
@@ -1082,7 +1085,7 @@ extern "C" int hps_deposit_current_tiled (hps_slab slab, hps_plasma pl, hps_geom
     if (int e = check_tiling(tiling, slab, pl, "hps_deposit_current_tiled")) return e;
     for (int c = 0; c < 6; ++c) HPS_REQUIRE(comp[c] >= -1 && comp[c] < slab.ncomp, "hps_deposit_current_tiled: bad component");
     return deposit_current_tiled(slab, pl, g, comp, charge, mass, order, max_qsa, can_ionize, n_qsa,
-                                 static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr, TailWork{}, nullptr);
+                                 static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr, TailWork{}, nullptr, nullptr);
 }
 
 extern "C" int hps_explicit_deposit_tiled (hps_slab slab, hps_plasma pl, hps_geom g, const int cache[4], const int depos[2],

@@ -84,6 +84,7 @@ struct DstArgs {
     const double* sp[DST_MAXPLANES][2]; const double* sq[DST_MAXPLANES][2]; double sc[DST_MAXPLANES][2]; int npairs[DST_MAXPLANES];
     long long* dbg;                 // optional: shader-clock stamps of workgroup 0 at the phase boundaries
     // blocked intermediate planes (k_dst_rows_sym<.., LIN, LOUT>, see "blocked layout" below)
+    const int* gate;                // optional device word: the kernel returns at once when *gate == 0 (poisson_set_gate)
     int rows_pad;                   // rows per plane rounded up to the workgroup's 2T rows: a workgroup never straddles planes
     int blk_cols;                   // columns of the blocked planes (= rows per plane of the transposed view)
 };
@@ -457,6 +458,7 @@ template <int N1, int N2>
 __global__ __launch_bounds__(256)
 void k_dst_rows (DstArgs a)
 {
+    if (a.gate && *a.gate == 0) return;
     constexpr int N = N1*N2, T = DST_T;
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_double* cbuf = (lds_double*)lds_raw;          // [T][N] complex working set
@@ -666,6 +668,7 @@ __global__ __launch_bounds__(DSTS_NT) void k_dst_rows_sym (DstArgs a)
     // LIN / LOUT: layout of the planes read / written -- 0 row-major, 1 blocked planes seen by rows, 2 blocked planes seen
     // by columns ("blocked layout" above); any of them non-zero: padded row numbering (a.rows_pad)
     constexpr bool BLK = (LIN != 0 || LOUT != 0);
+    if (a.gate && *a.gate == 0) return;
     // TWICE: the two y passes of a solve in one kernel -- transform the rows, multiply by a.scale (the inverse eigenvalues),
     // transform them again, all in LDS: one launch, one write and one read of the planes less than two passes
     static_assert(N1 % 2 == 1 && N2 % 2 == 1, "symmetric kernel needs odd factors");
@@ -1043,11 +1046,13 @@ struct GemmArgs {
     double* C[DST_MAXPLANES]; long ldc;
     int M, N, K;
     const double* scale; long scale_r, scale_c;      // optional factor scale[r*scale_r + c*scale_c] on the output
+    const int* gate;                                 // optional device word: return at once when *gate == 0
 };
 
 __global__ __launch_bounds__(256)
 void k_dense_product (GemmArgs g)
 {
+    if (g.gate && *g.gate == 0) return;
     // pitches chosen so that the 32 lanes of one LDS pass hit 32 different 8-byte slots: A rows 34 apart, B rows 48
     __shared__ double As[32][34];
     __shared__ double Bs[32][48];
@@ -1221,7 +1226,7 @@ struct Poisson {
     dst_kernel_t kx_src = nullptr;      // the x pass with its rows formed from other planes (sym kernels only)
     dst_kernel_t ky2 = nullptr;         // both y passes (transform, inverse eigenvalues, transform) in one launch (sym kernels; HPS_POISSON_Y2=0: off)
     dst_cols_kernel_t kcols = nullptr; size_t lds_cols = 0;     // y direction on column blocks (symmetric factorisations)
-    // blocked intermediate planes (HPS_POISSON_BLOCKED=0: off): three launches per solve, no transposes
+    // blocked intermediate planes (HPS_POISSON_BLOCKED=1; measured slower than the transposes): three launches per solve
     dst_kernel_t kb_first = nullptr, kb_first_src = nullptr, kb_twice = nullptr, kb_last = nullptr;
     long blk_plane = 0;                 // doubles per blocked plane: ny rounded up to whole row blocks, times nx
     bool blocked () const { return kb_first != nullptr; }
@@ -1232,6 +1237,8 @@ struct Poisson {
     double *buf_a = nullptr, *buf_b = nullptr;         // [DST_MAXPLANES][nx*ny] ping-pong
     double *S_x = nullptr, *S_y = nullptr;             // dense back-end: [n][n] sine matrices (S_y = S_x if nx == ny)
     long long* dbg = nullptr;
+    const int* gate = nullptr;          // poisson_set_gate: the launches of the following solves return at once when *gate == 0
+    bool gate_ok = false;               // every kernel of the own back-end as configured looks at the gate (the transposes only touch scratch)
     size_t lds_x = 0, lds_y = 0; int tx = DST_T, ty = DST_T, ntx = 256, nty = 256;     // LDS bytes, row pairs and threads per workgroup
     // rocFFT back-end
     rocfft_plan plan_x = nullptr, plan_y = nullptr;
@@ -1333,6 +1340,7 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
         P->fa_x = P->tab_x; P->fb_x = P->fa_x + nax; P->tw_x = P->fb_x + nbx;
         P->fa_y = P->tab_y; P->fb_y = P->fa_y + nay; P->tw_y = P->fb_y + nby;
         P->tx = ix->T; P->ty = iy->T; P->ntx = ix->nt; P->nty = iy->nt;
+        P->gate_ok = true;
         // fp64-MFMA form of the small-DFT stages: parity-tested, but not the default -- v_mfma_f64_16x16x4 runs at the
         // vector fp64 rate on gfx950 (71 TFLOP/s measured), the padded tiles do 1.5x the flops, and with two workgroups
         // per CU the MFMA pipes are the bottleneck: 24.5 us per pass against 22 us for the vector kernel (a lone
@@ -1341,10 +1349,10 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
             size_t fx = 0, fy = 0;
             if ((e = upload_mfma_tables(ix->N1, ix->N2, &P->mtab_x, &fx)) || (e = upload_mfma_tables(iy->N1, iy->N2, &P->mtab_y, &fy))) { delete P; return e; }
             P->ma_x = P->mtab_x; P->mb_x = P->mtab_x + fx; P->ma_y = P->mtab_y; P->mb_y = P->mtab_y + fy;
-            P->kx = ix->mfma; P->ky = iy->mfma; P->kx_src = nullptr; P->ky2 = nullptr;
+            P->kx = ix->mfma; P->ky = iy->mfma; P->kx_src = nullptr; P->ky2 = nullptr; P->gate_ok = false;
         }
         if (iy->cols && getenv("HPS_POISSON_COLS")) {      // measured no faster than rows + transposes (0.143 ms both): off by default
-            P->kcols = iy->cols;
+            P->kcols = iy->cols; P->gate_ok = false;
             P->lds_cols = (size_t)DSTC_T*Ny*sizeof(double2);
             if (P->lds_cols > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->kcols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_cols));
         }
@@ -1356,7 +1364,10 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
         if (P->ky2 && P->lds_y > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->ky2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_y));
         size_t plane_doubles = (size_t)nx*ny;
         {   const char* v = getenv("HPS_POISSON_BLOCKED");
-            const bool want = !(v && atoi(v) == 0);
+            // Measured (profiles/r04b_poisson_blocked_vs_transposes.txt): the two transposes cost 18.4 us per slice, the three
+            // passes on blocked planes 23.5 us more than on row-major ones (the y pass 45.9 against 32.1 us: with B = 6 its
+            // 288-byte runs straddle 128-byte lines that other workgroups -- on other XCDs -- complete).  Opt-in.
+            const bool want = (v && atoi(v) != 0);
             if (want && ix->sym && iy->sym && ix->T == iy->T && P->ky2 && !P->kcols && !P->mtab_x) {
                 const int B = 2*ix->T;
                 P->kb_first = ix->b_first; P->kb_first_src = ix->b_first_src; P->kb_twice = iy->b_twice; P->kb_last = ix->b_last;
@@ -1483,6 +1494,15 @@ int poisson_solve_batch (Poisson* P, int nb, const double* const* src, long src_
 {
     return poisson_solve_batch_impl(P, nb, src, src_pitch, dst, dst_pitch, nullptr, st);
 }
+// Device-side control of a caller's loop (the predictor-corrector iterations enqueued ahead of the host's knowledge of
+// their number): every kernel of the solves enqueued from now on looks at *gate first and does nothing when it is 0.
+// Only for back-ends whose every launch honours it (dense products, the symmetric own transform with blocked planes).
+bool poisson_gateable (void* handle)
+{
+    Poisson* P = static_cast<Poisson*>(handle);
+    return P->dense() || (P->own() && P->gate_ok);
+}
+void poisson_set_gate (void* handle, const int* gate) { static_cast<Poisson*>(handle)->gate = gate; }
 bool poisson_sources_fusable (void* handle)
 {
     Poisson* P = static_cast<Poisson*>(handle);
@@ -1505,6 +1525,7 @@ static int poisson_solve_batch_impl (Poisson* P, int nb, const double* const* sr
         const long plane = (long)nx*ny;
         const dim3 grid(ceil_div(nx, 32), ceil_div(ny, 32), nb), block(256);
         GemmArgs g{};
+        g.gate = P->gate;
         g.M = ny; g.N = nx;
         // 1: A = src . S_x
         for (int b = 0; b < nb; ++b) { g.A[b] = src[b]; g.B[b] = P->S_x; g.C[b] = P->buf_a + b*plane; }
@@ -1534,6 +1555,7 @@ static int poisson_solve_batch_impl (Poisson* P, int nb, const double* const* sr
     auto rows_grid = [] (int rows, int T) { return dim3(ceil_div(rows, 2*T)); };
     DstArgs a{};
     a.dbg = P->dbg;
+    a.gate = P->gate;
     if (P->blocked()) {
         // three launches, the intermediate planes in blocks of B = 2T rows ("blocked layout", k_dst_rows_sym<.., LIN, LOUT>)
         const int B = 2*P->tx;

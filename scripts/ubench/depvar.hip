@@ -10,7 +10,9 @@
 //           each), their payload (t_x, t_y, four products) goes to LDS in bin order, then ONE thread per bin sums the
 //           bin's particles into a 3 x 3 x 4 register patch and issues 36 atomics per BIN (lanes = consecutive bins:
 //           conflict-free addresses) instead of 36 per particle
-//   mode 3  mode 0 without its LDS atomics (loads, arithmetic and flush only): what the kernel costs when the LDS pipe is free
+//   mode 3  mode 0 without its LDS atomics and without flush traffic (loads and arithmetic only)
+//   mode 5  mode 0 without the flush (loads, arithmetic, LDS atomics)
+//   mode 6  mode 3 with every cell of the region flushed (loads, arithmetic, 4 x 28 x 28 global atomics per tile)
 //
 // Build: hipcc -O3 --offload-arch=gfx950 -shared -fPIC depvar.hip -o libdepvar.so   (scripts/deposit_variants.py does it)
 #include "../../hipace_amd/csrc/common.h"
@@ -116,7 +118,7 @@ void k_dep_plain (SlabView f, hps_plasma pl, const int* __restrict__ offsets, in
 #pragma unroll
         for (int u = 0; u < NB; ++u) rec[u] = fetch(pl, min(ipb + 256*u, pend - 1));
     }
-    { double2* z = (double2*)acc; for (int s = tid; s < 4*R*R/2; s += 256) z[s] = make_double2(0.0, 0.0); }
+    { double2* z = (double2*)acc; const double z0 = MODE == 6 ? 1.0e-300 : 0.0; for (int s = tid; s < 4*R*R/2; s += 256) z[s] = make_double2(z0, z0); }
     __syncthreads();
     double junk = 0.0;
     const int npad = ((pend - lrec.y + 255)/256)*256;      // MODE 1: every lane of a wave walks the same rounds (DPP needs them all)
@@ -168,15 +170,16 @@ void k_dep_plain (SlabView f, hps_plasma pl, const int* __restrict__ offsets, in
                         const double ss = sx[ix]*sy[iy];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            if constexpr (MODE == 0) lds_add(p0 + iy*R + ix + c*R*R, ss*d.v[c]);
+                            if constexpr (MODE == 0 || MODE == 5) lds_add(p0 + iy*R + ix + c*R*R, ss*d.v[c]);
                             else junk += ss*d.v[c];
                         }
                     }
             }
         }
     }
-    if (MODE == 3 && junk == 1.2345e-300) sink[tid] = junk;
+    if ((MODE == 3 || MODE == 6) && junk == 1.2345e-300) sink[tid] = junk;
     __syncthreads();
+    if (MODE == 5) { if (acc[tid] == 1.2345e-300) sink[tid] = acc[tid]; return; }
     flush(f, cm, acc, ox, oy, tid);
 }
 
@@ -282,6 +285,7 @@ void k_dep_bins (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int
         }
         __syncthreads();
     }
+    __syncthreads();
     flush(f, cm, acc, ox, oy, tid);
 }
 
@@ -302,6 +306,8 @@ extern "C" int depvar_run (int mode, hps_slab slab, hps_plasma pl, hps_geom g, c
         switch (mode) {
         case 0: hipLaunchKernelGGL((k_dep_plain<0>), dim3(ntiles), dim3(256), lds_plain, 0, f, pl, offsets_dev, ntiles, ntx, cm, k, sink); break;
         case 1: hipLaunchKernelGGL((k_dep_plain<1>), dim3(ntiles), dim3(256), lds_plain, 0, f, pl, offsets_dev, ntiles, ntx, cm, k, sink); break;
+        case 5: hipLaunchKernelGGL((k_dep_plain<5>), dim3(ntiles), dim3(256), lds_plain, 0, f, pl, offsets_dev, ntiles, ntx, cm, k, sink); break;
+        case 6: hipLaunchKernelGGL((k_dep_plain<6>), dim3(ntiles), dim3(256), lds_plain, 0, f, pl, offsets_dev, ntiles, ntx, cm, k, sink); break;
         case 3: hipLaunchKernelGGL((k_dep_plain<3>), dim3(ntiles), dim3(256), lds_plain, 0, f, pl, offsets_dev, ntiles, ntx, cm, k, sink); break;
         case 2: { constexpr int NBC = 4; const size_t lds = lds_plain + 3*256*NBC*sizeof(double2) + (R*R + 8)*sizeof(unsigned);
                   (void)hipFuncSetAttribute((const void*)k_dep_bins<NBC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

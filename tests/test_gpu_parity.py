@@ -880,7 +880,11 @@ def test_bench_line_contract():
     t = d["timed_slices"]
     assert t["first"] >= 400 and t["last"] - t["first"] + 1 == 96 and 5 <= d["profiled_slices"] <= 7
     sl = r["slice"]
-    assert sl["algorithmic_bytes_fused_lower_bound"] < sl["algorithmic_bytes_reference_passes"] and 0.2 < sl["frac_reference_passes"] < 1.0
+    assert sl["algorithmic_bytes_fused_lower_bound"] < sl["reference_passes"]["algorithmic_bytes"] and 0.15 < sl["frac_fused_lower_bound"] < 1.0
+    assert sl["counter_bytes_per_slice"] is None or (sl["counter_bytes_per_slice"] > 0.8 * sl["algorithmic_bytes_fused_lower_bound"]
+                                                     and abs(sl["frac_counter_bytes"] - sl["achieved_counter"] / r["peak"]) < 1e-12)
+    fl = d["in_flight"]
+    assert fl is None or 0.15 < fl["roofline"]["frac_fused_lower_bound"] < 1.0
     assert r["traffic"] is None or "profiles/" in r["traffic_source"]
     assert d["vcycles_per_slice"] > 1.0
 
@@ -1543,7 +1547,7 @@ def _run_with_env(api, var, value, deck, n_steps, tile_size=16):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["gated_push", "lazy_shift", "fuse_sources", "aux_stream", "fold_beam", "fold_hierarchy", "mg_post_fold", "laser_stream_fft", "laser_stream_mg", "ion_tile_skip", "fold_tail", "gated_ion_push"])
+@pytest.mark.parametrize("case", ["gated_push", "lazy_shift", "fuse_sources", "aux_stream", "fold_beam", "fold_hierarchy", "mg_post_fold", "laser_stream_fft", "laser_stream_mg", "ion_tile_skip", "fold_tail", "gated_ion_push", "poisson_blocked", "pc_speculate"])
 def test_schedules_do_not_change_results(api, case):
     """The engine's scheduling choices -- the push enqueued behind the multigrid's V-cycles and gated on its stopping rule,
     the envelope solver on a stream of its own, the tiles of atoms that cannot ionise skipped before their image is loaded --
@@ -1563,6 +1567,12 @@ def test_schedules_do_not_change_results(api, case):
         var, deck, steps = "HPS_MG_POST_FOLD", decks.blowout_wake(), 2
     elif case == "aux_stream":      # the beam's deposition and the multigrid's coefficient hierarchy on a stream beside the slice's
         var, deck, steps = "HPS_AUX_STREAM", decks.blowout_wake(), 2
+    elif case == "poisson_blocked":  # the Poisson solves' intermediate planes in blocks of 6 rows: three launches, no transposes
+        var, deck, steps = "HPS_POISSON_BLOCKED", decks.blowout_wake(), 1
+    elif case == "pc_speculate":     # predictor-corrector loop: iterations enqueued ahead, every kernel gated on the loop's condition
+        var, steps = "HPS_PC_SPECULATE", 1
+        deck = decks.predictor_corrector(decks.linear_wake_gaussian(), 4.0e-2, 30, 0.05)
+        deck.update(nx=64, ny=64, nz=60, plasma_ppc=(2, 2), beam_zmin=deck["lo"][2], beam_zmax=deck["hi"][2])      # (beam on every slice: no loop on rounding noise)
     elif case.startswith("laser_stream"):
         var, steps = "HPS_LASER_ASYNC", 3
         deck = decks.laser_blowout_wake()
@@ -1577,7 +1587,9 @@ def test_schedules_do_not_change_results(api, case):
     b = _run_with_env(api, var, "0", deck, steps)
     sa, sb = a.slab(), b.slab()
     # two runs of ONE schedule differ by the order of their LDS atomics; two steps of the ionisation deck have shown 1.2e-12
-    tol = 1e-11 if case in ("ion_tile_skip", "fold_tail", "gated_ion_push") else 1e-12
+    # (the predictor-corrector loop amplifies that order through its ~5 dependent solves per slice: Bz, five orders of magnitude
+    #  below the other fields in this deck, has shown 4e-12)
+    tol = 1e-11 if case in ("ion_tile_skip", "fold_tail", "gated_ion_push") else 1e-10 if case == "pc_speculate" else 1e-12
     for c, nm in enumerate(a.comp_names()):
         sc = max(np.abs(sb[c]).max(), 1e-300)
         assert np.abs(sa[c] - sb[c]).max() <= tol * sc, (case, nm)
@@ -1589,7 +1601,9 @@ def test_schedules_do_not_change_results(api, case):
         assert np.array_equal(la[np.argsort(ka)], lb[np.argsort(kb)])
         assert a.ion_stats() == b.ion_stats() and a.ion_stats()[0] > 100
     else:
-        assert np.abs(ra - rb).max() <= 1e-12 * np.abs(rb).max()
+        assert np.abs(ra - rb).max() <= (1e-10 if case == "pc_speculate" else 1e-12) * np.abs(rb).max()
+    if case == "pc_speculate":
+        assert a.pc_stats()[0] == b.pc_stats()[0] > deck["nz"]         # the same number of loop iterations, more than one per slice
     if case.startswith("laser_stream"):
         ea, eb = a.laser_envelope(), b.laser_envelope()
         assert np.abs(ea - eb).max() <= 1e-13 * np.abs(eb).max()
