@@ -54,7 +54,7 @@ if ROOT not in sys.path:
 CPU_THREADS_DEFAULT = 16  # OpenMP leg of the CPU baseline: fastest on the 256-core host of the GPU box, 9.5x the serial leg; 64 threads
                           # are already slower and 256 slower than one (profiles/r02b_cpu_threads.json)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_SUMMARY = "r03d_pmc_fetch_write_per_kernel.csv"      # profiles/: rocprofv3 --pmc summary of the shipped kernels
+PMC_SUMMARY = "r04c_pmc_fetch_write_per_kernel.csv"      # profiles/: rocprofv3 --pmc summary of the shipped kernels
 START_SLICE_DEFAULT = 700  # short runs start here (from the head); see profiles/r02a_slice_cost_profile.json
 
 
@@ -190,7 +190,7 @@ def main():
     claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1024, help="timed slices (per GPU)")
+    ap.add_argument("--steps", type=int, default=0, help="timed slices (per GPU); 0 = one whole box (1024 slices; --config5: 2048, --config2: 512)")
     ap.add_argument("--warmup", type=int, default=64, help="untimed warm-up slices")
     ap.add_argument("--n", type=int, default=1024, help="transverse cells per side")
     ap.add_argument("--ppc", type=int, default=2, help="plasma particles per cell per direction")
@@ -320,6 +320,8 @@ def main():
             deck["background_density_SI"] = 2.8239587008591567e23
         args.cpu_slices = 0
         args.inflight = 1
+    if args.steps <= 0:
+        args.steps = nz                         # one whole box of the deck that is timed (config 5: all 2048 slices, the pulse included)
     if world > 1 and not args.inflight_ring:
         args.inflight = 1
     if args.ring_self or args.fuse:
@@ -606,7 +608,7 @@ def main():
                               # run of one step per rank would come out at value_including_fill
                               "fill_slices": lag * (world - 1) if world > 1 else 0,
                               "value_including_fill": (total / dt) * nz / (nz + lag * (world - 1)) if world > 1 else None} if short else
-                             {"whole_boxes": max(1, args.steps // nz), "pipeline_prefilled": False}),
+                             {"whole_boxes": max(1, args.steps // nz), "slices_per_box": nz, "pipeline_prefilled": False}),
             "steps_in_flight": inflight["stages_per_gpu"] if inflight else 1,
             "value_steps_in_flight": inflight["value"] if inflight else None,
             "in_flight": inflight,

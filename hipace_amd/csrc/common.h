@@ -186,4 +186,14 @@ inline int ceil_div (long a, long b) { return (int)((a + b - 1)/b); }
 #define HPS_OWN_ATOMICS_ACKNOWLEDGED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 
+// Ahead of the sequence word of a post to mapped HOST memory: the payload's stores (volatile: system-coherent write-through,
+// `sc0 sc1`, never dirty in an L2) have been acknowledged.  A __threadfence_system() there also writes the XCD's L2 back --
+// microseconds on the one chain of launches a slice is (k_post_norms: 4.9 us per slice for 80 words).  Other targets keep
+// the formal fence.
+#if defined(HPS_KEEP_SYSTEM_FENCE) || (defined(__HIP_DEVICE_COMPILE__) && !(defined(__gfx942__) || defined(__gfx950__)))
+#define HPS_HOST_STORES_ACKNOWLEDGED() __threadfence_system()
+#else
+#define HPS_HOST_STORES_ACKNOWLEDGED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
 #endif

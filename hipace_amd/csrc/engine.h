@@ -73,6 +73,7 @@ struct Engine {
     bool fold_tail = true;                     // the particles behind the tile-sorted body ride in the tile kernels' launches (HPS_FOLD_TAIL=0: off)
     TailWork fold_tail_of (const hps_plasma& p, const Tiling* T, long margin, long* covered) const;
     int species_deposit (const hps_plasma& p, Tiling* T, const int comp[6], double charge, double mass, int can_ionize, const BeamPairWork* beam = nullptr);
+    bool valid_by_w = true;                    // the depositions take "weight != 0" for the valid bit of idcpu (PartConsts::valid_by_w; HPS_VALID_BY_W=0: off)
     bool fold_hierarchy = true;                // the multigrid's coefficient hierarchy in the -grad Psi / Sx, Sy launch (HPS_FOLD_HIERARCHY=0: in mg_solve1_begin)
     bool fold_beam = true;                     // the static beam's two deposits of a slice as extra workgroups of the plasma's deposition (HPS_FOLD_BEAM=0: a launch of their own)
     int species_explicit (const hps_plasma& p, Tiling* T, const int cache[4], const int depos[2], double charge, double mass, int can_ionize);
@@ -123,6 +124,7 @@ struct Engine {
     // predictor-corrector Bx/By (hipace.bxby_solver = predictor-corrector): d_pc = {sum |B|, sum |B - B_iter|, halo
     // fallback counter (int), spare}, h_pc its pinned image read back once per iteration
     // device-side control of the loop (HPS_PC_SPECULATE=0: off): per-iteration flags, iterations enqueued ahead of the host
+    double pc_floor = 0.0;     // sum |B| below this is the exact zero of the serial path (Engine::create)
     int* d_pc_go = nullptr; bool pc_speculate = false; int pc_spec_iters = 1, pc_enqueued = 0, pc_islice = -1; double pc_base_seq = 0.0, pc_last_err = 0.0;
     int solve_slice_pc_begin (int islice); int solve_slice_pc_finish (int islice); int pc_enqueue_iteration (int it); int pc_wait_slot (int slot, double seq);
     bool pc = false; double* d_pc = nullptr; double* d_pc_aux = nullptr; double* h_pc = nullptr; double* h_pc_dev = nullptr; double pc_seq = 0.0; long pc_iterations = 0; double pc_err_sum = 0.0;

@@ -15,10 +15,10 @@ namespace hps {
 int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[6], double charge,
                            double mass, int order, double max_qsa, int can_ionize, int* n_qsa, Tiling* T, int* n_fallback,
                            hipStream_t st, int aabs_comp = -1, const int* tile_flag = nullptr, TailWork tw = TailWork{},
-                           const BeamPairWork* beam = nullptr, const int* go = nullptr);
+                           const BeamPairWork* beam = nullptr, const int* go = nullptr, bool valid_by_w = false);
 int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int cache[4], const int depos[2],
                             double charge, double mass, int order, int dtype, int can_ionize, Tiling* T, int* n_fallback,
-                            hipStream_t st, int aabs_comp = -1, const int* tile_flag = nullptr, TailWork tw = TailWork{});
+                            hipStream_t st, int aabs_comp = -1, const int* tile_flag = nullptr, TailWork tw = TailWork{}, bool valid_by_w = false);
 int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], double charge,
                           double mass, int order, int temp_slice, int n_subcycles, int can_ionize, Tiling* T,
                           int* n_fallback, hipStream_t st, int aabs_comp = -1, const IonArgs* ion = nullptr, const int* go = nullptr,
@@ -487,6 +487,7 @@ int Engine::create (const hps_deck& deck, int device)
     if (const char* v = std::getenv("HPS_FOLD_TAIL")) fold_tail = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_FOLD_BEAM")) fold_beam = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_FOLD_HIERARCHY")) fold_hierarchy = std::atoi(v) != 0;
+    if (const char* v = std::getenv("HPS_VALID_BY_W")) valid_by_w = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_GATED_ION_PUSH")) gate_ion_push = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_LAZY_SHIFT")) lazy_shift = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_FUSE_SOURCES")) fuse_sources = std::atoi(v) != 0;
@@ -580,15 +581,25 @@ int Engine::create (const hps_deck& deck, int device)
         HPS_HIP_CHECK(hipMemset(d_pc, 0, 4*sizeof(double)));
         HPS_HIP_CHECK(hipMalloc(&d_pc_aux, 4*sizeof(double)));      // error of the last two iterations (k_pc_mix)
         HPS_HIP_CHECK(hipMemset(d_pc_aux, 0, 4*sizeof(double)));
-        HPS_HIP_CHECK(hipHostMalloc(&h_pc, 4*PC_MAX_SPEC*sizeof(double), hipHostMallocMapped));      // slot 0 + one slot per loop iteration
-        std::memset(h_pc, 0, 4*PC_MAX_SPEC*sizeof(double));
+        HPS_HIP_CHECK(hipHostMalloc(&h_pc, 8*PC_MAX_SPEC*sizeof(double), hipHostMallocMapped));      // slot 0 + one slot per loop iteration
+        std::memset(h_pc, 0, 8*PC_MAX_SPEC*sizeof(double));
         HPS_HIP_CHECK(hipHostGetDevicePointer((void**)&h_pc_dev, h_pc, 0));
         HPS_HIP_CHECK(hipMalloc(&d_pc_go, PC_MAX_SPEC*sizeof(int)));
         HPS_HIP_CHECK(hipMemset(d_pc_go, 0, PC_MAX_SPEC*sizeof(int)));
+        // Rounding floor of sum |B| (k_rel_b_error).  Ahead of the driver the serial CPU path has EXACT zeros -- electron and ion
+        // charge cancel term by term -- so ComputeRelBFieldError returns 0 (fields/Fields.cpp:1283) and the loop leaves after
+        // one pass, also on the first slice that holds beam.  A scatter with atomics leaves 1e-16 residue of the background
+        // charge; without a floor the loop runs to max_iterations on that noise on every slice ahead of the driver (config 2:
+        // 54 slices x 30 iterations = 40 % of the box's time) and enters the driver on a different path, per cent away from
+        // the CPU's.  What can be resolved of B is eps x mu0 c sum|rho_background| L: 1e-12 of that is "zero".
+        // HPS_PC_NOISE_FLOOR=<relative floor>, 0: the literal rule.
+        {   double rel = 1.0e-12;
+            if (const char* v = std::getenv("HPS_PC_NOISE_FLOOR")) rel = std::atof(v);
+            pc_floor = rel*gm.mu0*gm.c*std::fabs(d.plasma_charge*d.plasma_density)*(double)d.nx*d.ny*(d.nx*gm.dx); }
         // HPS_PC_SPECULATE=0: the host decides after every iteration, as in rounds 1-3
         {   const char* v = std::getenv("HPS_PC_SPECULATE");
             pc_speculate = !(v && std::atoi(v) == 0) && pc_max_iter <= PC_MAX_SPEC - 2 && poisson_gateable(ps); }
-        d_nfallback = reinterpret_cast<int*>(d_pc + 2); h_nfallback = reinterpret_cast<const int*>(h_pc + 2);
+        d_nfallback = reinterpret_cast<int*>(d_pc + 2); h_nfallback = reinterpret_cast<const int*>(h_pc + 4);
     }
     if (c_aabs >= 0) { if (int e = laser_create(*this)) return e; }
     return init_beam();
@@ -785,7 +796,7 @@ int Engine::species_deposit (const hps_plasma& p, Tiling* T, const int comp[6], 
     if (p.n == 0) return HPS_OK;
     if (!T) return hps_deposit_current_laser(slab, p, gm, comp, c_aabs, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, st);
     long covered; const TailWork tw = fold_tail_of(p, T, 0, &covered);
-    if (T->sorted_n > 0) { if (int e = deposit_current_tiled(slab, p, gm, comp, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, T, d_nfallback, st, c_aabs, T == ion.tiling ? ion.d_tile_flag : nullptr, tw, beam)) return e; }
+    if (T->sorted_n > 0) { if (int e = deposit_current_tiled(slab, p, gm, comp, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, T, d_nfallback, st, c_aabs, T == ion.tiling ? ion.d_tile_flag : nullptr, tw, beam, nullptr, valid_by_w && !can_ionize)) return e; }
     if (p.n > covered) return hps_deposit_current_laser(slab, tail_of(p, covered, p.n - covered), gm, comp, c_aabs, charge, mass, d.order, d.max_qsa, can_ionize, d_nqsa, st);
     return HPS_OK;
 }
@@ -794,7 +805,7 @@ int Engine::species_explicit (const hps_plasma& p, Tiling* T, const int cache[4]
     if (p.n == 0) return HPS_OK;
     if (!T) return hps_explicit_deposit_laser(slab, p, gm, cache, c_aabs, depos, charge, mass, d.order, d.deriv_type, can_ionize, st);
     long covered; const TailWork tw = fold_tail_of(p, T, 0, &covered);
-    if (T->sorted_n > 0) { if (int e = explicit_deposit_tiled(slab, p, gm, cache, depos, charge, mass, d.order, d.deriv_type, can_ionize, T, d_nfallback, st, c_aabs, T == ion.tiling ? ion.d_tile_flag : nullptr, tw)) return e; }
+    if (T->sorted_n > 0) { if (int e = explicit_deposit_tiled(slab, p, gm, cache, depos, charge, mass, d.order, d.deriv_type, can_ionize, T, d_nfallback, st, c_aabs, T == ion.tiling ? ion.d_tile_flag : nullptr, tw, valid_by_w && !can_ionize)) return e; }
     if (p.n > covered) return hps_explicit_deposit_laser(slab, tail_of(p, covered, p.n - covered), gm, cache, c_aabs, depos, charge, mass, d.order, d.deriv_type, can_ionize, st);
     return HPS_OK;
 }
@@ -1036,8 +1047,8 @@ int Engine::fill_field_diagnostic (int islice)
 
 // Fields::ComputeRelBFieldError (fields/Fields.cpp:1233-1286): out[0] += sum |B|, out[1] += sum |B - B_iter| over
 // the valid cells
-// With `host` (mapped pinned memory) the last workgroup to finish posts {sum |B|, sum |B - B_iter|, fallback counter,
-// seq} there, seq last behind a system-scope fence: the host polls seq instead of a copy + stream synchronise.
+// With `host` (mapped pinned memory) the last workgroup to finish posts {sum |B|, seq} {sum |B - B_iter|, seq} {fallback
+// counter, seq} there as three 16-byte stores: the host polls the tags instead of a copy + stream synchronise.
 // Loop control on the device (speculative iterations): `go` points at the word of iteration `it` in a per-slice array of
 // flags (k_pc_guess: flag[1] = 1, the others 0); every kernel of an iteration does nothing when its word is 0.  The last
 // workgroup here decides whether the loop goes on -- go[1] = (err > tol && it < max_it), the condition of Hipace.cpp:957 --
@@ -1045,7 +1056,7 @@ int Engine::fill_field_diagnostic (int islice)
 // engine's re-sort rule reads it).
 __global__ __launch_bounds__(256)
 void k_rel_b_error (SlabView f, int cB, int cBit, double* out, volatile double* host, double seq,
-                    int* go = nullptr, double tol = 0.0, int it = 0, int max_it = 0)
+                    int* go = nullptr, double tol = 0.0, int it = 0, int max_it = 0, double floor_b = 0.0)
 {
     if (go && *go == 0) return;
     double sb = 0.0, sd = 0.0;
@@ -1070,18 +1081,25 @@ void k_rel_b_error (SlabView f, int cB, int cBit, double* out, volatile double* 
             unsigned int* done = reinterpret_cast<unsigned int*>(out + 3);
             if (atomicAdd(done, 1u) == gridDim.x - 1) {
                 __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const double tb = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                double tb = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const double td = __hip_atomic_load(out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // sum |B| at the rounding floor of a scatter with atomics counts as the exact zero the serial path has there
+                // (Engine::pc_floor): the rule "relative error = 0 when sum |B| = 0" (fields/Fields.cpp:1283) then applies as on
+                // the CPU; k_pc_mix reads the same word
+                if (!(tb > floor_b)) { tb = 0.0; __hip_atomic_store(out, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                 const double fbk = __hip_atomic_load(out + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // The post: three self-validating 16-byte stores {value, seq} -- no fence.  (A system-scope release fence ahead
+                // of a lone sequence word writes the XCD's L2 back: the kernel took 9.4 us with it against 3.4 without the
+                // post, once per loop iteration.)  The host waits until all three tags carry its sequence number.
+                typedef double dbl2 __attribute__((ext_vector_type(2)));
+                volatile dbl2* hs = reinterpret_cast<volatile dbl2*>(const_cast<double*>(host));
                 if (go) {
                     const double err = tb > 0.0 ? td/tb : 0.0;
                     __hip_atomic_store(go + 1, (err > tol && it < max_it) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    host[2] = fbk;                 // slot 0: the fallback counter where the host looks for it
-                    host += 4*it;
+                    hs[2] = dbl2{fbk, seq};       // slot 0: the fallback counter where the host's re-sort rule looks for it
+                    hs += 4*it;
                 }
-                host[0] = tb; host[1] = td; host[2] = fbk;
-                __threadfence_system();
-                host[3] = seq;
+                hs[0] = dbl2{tb, seq}; hs[1] = dbl2{td, seq}; hs[2] = dbl2{fbk, seq};
             }
         }
     }
@@ -1091,12 +1109,12 @@ void k_rel_b_error (SlabView f, int cB, int cBit, double* out, volatile double* 
 // - m PCPrevIter with m = exp(-0.5 (err/(2.5 tol))^2), err = sums[1]/sums[0] of (Previous, PCPrevIter);
 // PCIter = 0; PCPrevIter = This.  Whole planes incl. guards, both components.
 __global__ __launch_bounds__(256)
-void k_pc_guess (double* p, long ns, long plane, const double* sums, double tol, int* go)
+void k_pc_guess (double* p, long ns, long plane, const double* sums, double tol, int* go, double floor_b)
 {
     const long s = (long)blockIdx.x*blockDim.x + threadIdx.x;
     if (s < PC_MAX_SPEC && go) go[s] = (s == 1);      // the loop of this slice starts: its first iteration always runs (Hipace.cpp:956)
     if (s >= plane) return;
-    const double err = sums[0] > 0.0 ? sums[1]/sums[0] : 0.0;
+    const double err = sums[0] > floor_b ? sums[1]/sums[0] : 0.0;
     const double q = err/(2.5*tol);
     const double m = exp(-0.5*(q*q));
     for (int c = 0; c < 2; ++c) {
@@ -1175,7 +1193,7 @@ int Engine::solve_slice_pc_begin (int islice)
     mark();   // b1b
     // plasma: jx jy jz [rho] rhomjz (Hipace.cpp:616-618); beams deposit into the same jx jy jz (:620-623)
     {   const int comp[6] = {HPS_PC_JX, HPS_PC_JY, HPS_PC_JZ, d.deposit_rho ? HPS_PC_RHO : -1, -1, HPS_PC_RHOMJZ};
-        if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st))) return e; }
+        if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st, -1, nullptr, TailWork{}, nullptr, nullptr, valid_by_w))) return e; }
         else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
     mark();   // b2
     if ((e = deposit_beam_slice(islice, HPS_PC_JX, HPS_PC_JY, HPS_PC_JZ))) return e;
@@ -1196,7 +1214,7 @@ int Engine::solve_slice_pc_begin (int islice)
     HPS_HIP_CHECK(hipMemsetAsync(d_pc, 0, 2*sizeof(double), st));
     hipLaunchKernelGGL(k_rel_b_error, dim3(128), b256, 0, st, f, HPS_PC_P_BX, HPS_PC_PIT_BX, d_pc, (volatile double*)nullptr, 0.0);
     const bool spec = pc_speculate && tiling && !moving;
-    hipLaunchKernelGGL(k_pc_guess, gplane, b256, 0, st, slab.p, slab.nstride, plane, d_pc, pc_tol, spec ? d_pc_go : (int*)nullptr);
+    hipLaunchKernelGGL(k_pc_guess, gplane, b256, 0, st, slab.p, slab.nstride, plane, d_pc, pc_tol, spec ? d_pc_go : (int*)nullptr, pc_floor);
     pc_islice = islice;
     if (spec) {
         // Device-side loop control: as many iterations as the previous slice took are enqueued at once, every kernel of
@@ -1219,7 +1237,7 @@ int Engine::solve_slice_pc_begin (int islice)
         pc_enqueued = it - 1;
         if ((e = pc_enqueue_iteration(it))) return e;
         if ((e = pc_wait_slot(0, pc_seq))) return e;
-        err = h_pc[0] > 0.0 ? h_pc[1]/h_pc[0] : 0.0;
+        err = h_pc[0] > 0.0 ? h_pc[2]/h_pc[0] : 0.0;
     }
     pc_last_err = err;
     return HPS_OK;
@@ -1243,7 +1261,7 @@ int Engine::pc_enqueue_iteration (int it)
     if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 1, d.n_subcycles, 0, tiling, d_nfallback, st, -1, nullptr, go))) return e; }
     else        { if ((e = hps_advance_plasma(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 1, d.n_subcycles, 0, st))) return e; }
     {   const int comp[6] = {HPS_PC_N_JX, HPS_PC_N_JY, -1, -1, -1, -1};
-        if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st, -1, nullptr, TailWork{}, nullptr, go))) return e; }
+        if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st, -1, nullptr, TailWork{}, nullptr, go, valid_by_w))) return e; }
         else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
     if ((e = deposit_beam_slice(islice - 1, HPS_PC_N_JX, HPS_PC_N_JY, -1, go))) return e;
     hipLaunchKernelGGL(k_rhs_bxby, dim3(ceil_div(d.nx, 256), d.ny), b256, 0, st, f, gm.mu0, 0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy),
@@ -1255,7 +1273,7 @@ int Engine::pc_enqueue_iteration (int it)
         if (e) return e; }
     pc_seq += 1.0;
     hipLaunchKernelGGL(k_rel_b_error, dim3(128), b256, 0, st, f, HPS_PC_BX, HPS_PC_IT_BX, d_pc, (volatile double*)h_pc_dev, pc_seq,
-                       go, pc_tol, it, pc_max_iter);
+                       go, pc_tol, it, pc_max_iter, pc_floor);
     hipLaunchKernelGGL(k_pc_mix, gplane, b256, 0, st, slab.p, slab.nstride, plane, d_pc, d_pc_aux, it, pc_mix, (const int*)go);
     pc_enqueued = it;
     return HPS_OK;
@@ -1265,13 +1283,14 @@ int Engine::pc_enqueue_iteration (int it)
 // failed launch cannot hang us
 int Engine::pc_wait_slot (int slot, double seq)
 {
-    volatile double* hp = h_pc + 4*slot;
+    volatile double* hp = h_pc + 8*slot;          // {sum |B|, seq} {sum |B - B_iter|, seq} {fallback counter, seq} (k_rel_b_error)
+    auto there = [&] () { return hp[1] == seq && hp[3] == seq && hp[5] == seq; };
     long spins = 0;
-    while (hp[3] != seq) {
+    while (!there()) {
         if ((++spins & 0xfffff) == 0 && hipStreamQuery(st) != hipErrorNotReady) {
-            if (hp[3] == seq) break;
+            if (there()) break;
             HPS_HIP_CHECK(hipStreamSynchronize(st));
-            if (hp[3] != seq) { set_error("predictor-corrector: the error read-back never arrived"); return HPS_ERR_HIP; }
+            if (!there()) { set_error("predictor-corrector: the error read-back never arrived"); return HPS_ERR_HIP; }
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -1296,8 +1315,8 @@ int Engine::solve_slice_pc_finish (int islice)
             ++it; ++pc_iterations;
             if (it > pc_enqueued) { if ((e = pc_enqueue_iteration(it))) return e; }
             if ((e = pc_wait_slot(it, pc_base_seq + it))) return e;
-            const volatile double* hp = h_pc + 4*it;
-            err = hp[0] > 0.0 ? hp[1]/hp[0] : 0.0;
+            const volatile double* hp = h_pc + 8*it;
+            err = hp[0] > 0.0 ? hp[2]/hp[0] : 0.0;
         }
         // (iterations enqueued beyond `it` find their flag at 0 and do nothing; their sequence numbers are never posted)
         pc_spec_iters = it;

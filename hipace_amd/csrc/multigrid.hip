@@ -388,7 +388,7 @@ __device__ __forceinline__ void post_epilogue (const PostArgs& pa)      // every
         if (threadIdx.x == 0) *pa.go_word = act ? 0 : 1; }
     for (int w = threadIdx.x; w < pa.nwords; w += blockDim.x)
         pa.dst[w] = __hip_atomic_load(pa.src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
+    HPS_HOST_STORES_ACKNOWLEDGED();
     __syncthreads();
     if (threadIdx.x == 0) *pa.seq_slot = pa.seq;
 }
@@ -1676,7 +1676,7 @@ void k_post_norms (const unsigned long long* __restrict__ src, volatile unsigned
     {   const bool act = vcycle_active(after);      // (whole waves: the rule is read lane-parallel)
         if (threadIdx.x == 0) *go_word = act ? 0 : 1; }
     for (int w = threadIdx.x; w < nwords; w += blockDim.x) dst[w] = src[w];
-    __threadfence_system();
+    HPS_HOST_STORES_ACKNOWLEDGED();
     __syncthreads();
     if (threadIdx.x == 0) { *seq_slot = seq; }
 }

@@ -147,7 +147,7 @@ __global__ void k2_post_norms (const unsigned long long* __restrict__ src, volat
     unsigned long long a = 0ULL, b = 0ULL;      // non-negative doubles order like their bit patterns
     for (int q = 0; q < MG2_NSUB; ++q) { a = src[q] > a ? src[q] : a; b = src[MG2_NSUB + q] > b ? src[MG2_NSUB + q] : b; }
     dst[0] = a; dst[1] = b;
-    __threadfence_system();
+    HPS_HOST_STORES_ACKNOWLEDGED();
     dst[2] = seq;
 }
 

@@ -15,6 +15,10 @@ struct PartConsts {
     double plo0, plo1, phi0, phi1;
     double dz;
     int bc, can_ionize, temp_slice, n_subcycles;
+    // depositions of the engine's own sheets: a particle is valid iff its weight is not 0 (every path that clears the valid
+    // bit of idcpu -- QSA drop, absorbing boundary, lattice point without density -- also zeroes the weight, and a weight of
+    // 0 deposits nothing): the kernels then do not read idcpu (8 of 56 bytes per particle).  0 for sheets of a caller.
+    int valid_by_w;
     // laser envelope (use_laser of the reference's operators): slab component of |a|^2 (-1 = no laser) and the
     // operator's normalisation of it (laser_norm / laser_fac)
     int aabs; double laser_fac;

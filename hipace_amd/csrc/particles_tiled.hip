@@ -169,8 +169,9 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     struct Rec { double x, y, w, ux, uy, psi; uint64_t id; int ion; };
     auto fetch = [&] (int ip) {
         Rec r;
-        r.id = pl.idcpu[ip]; r.x = pl.x[ip]; r.y = pl.y[ip]; r.w = pl.w[ip];
+        r.x = pl.x[ip]; r.y = pl.y[ip]; r.w = pl.w[ip];
         r.ux = pl.ux[ip]; r.uy = pl.uy[ip]; r.psi = pl.psi[ip];
+        r.id = k.valid_by_w ? (r.w != 0.0 ? HPS_ID_VALID : 0ULL) : pl.idcpu[ip];      // (PartConsts::valid_by_w: idcpu is not read)
         r.ion = k.can_ionize ? pl.ion_lev[ip] : 1;
         return r;
     };
@@ -249,7 +250,7 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         if (gamma_psi < 0.0 || gamma_psi > k.max_qsa || psi_inv < 0.0) {
             if (n_qsa) atomicAdd(n_qsa, 1);
             pl.w[ip] = 0.0;
-            pl.idcpu[ip] = id & ~HPS_ID_VALID;
+            pl.idcpu[ip] = (k.valid_by_w ? pl.idcpu[ip] : id) & ~HPS_ID_VALID;
             continue;
         }
         // per-component weights in DepComps order
@@ -357,8 +358,9 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
     struct Rec { double x, y, w, ux, uy, psi; uint64_t id; int ion; };
     auto fetch = [&] (int ip) {
         Rec r;
-        r.id = pl.idcpu[ip]; r.x = pl.x[ip]; r.y = pl.y[ip]; r.w = pl.w[ip];
+        r.x = pl.x[ip]; r.y = pl.y[ip]; r.w = pl.w[ip];
         r.ux = pl.ux[ip]; r.uy = pl.uy[ip]; r.psi = pl.psi[ip];
+        r.id = k.valid_by_w ? (r.w != 0.0 ? HPS_ID_VALID : 0ULL) : pl.idcpu[ip];      // (PartConsts::valid_by_w: idcpu is not read)
         r.ion = k.can_ionize ? pl.ion_lev[ip] : 1;
         return r;
     };
@@ -920,7 +922,8 @@ static int set_lds (K kernel, size_t bytes)
 
 int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[6], double charge,
                            double mass, int order, double max_qsa, int can_ionize, int* n_qsa, Tiling* T, int* n_fallback,
-                           hipStream_t st, int aabs_comp, const int* tile_flag, TailWork tw, const BeamPairWork* beam, const int* go)
+                           hipStream_t st, int aabs_comp, const int* tile_flag, TailWork tw, const BeamPairWork* beam, const int* go,
+                           bool valid_by_w)
 {
     if (pl.n == 0) return HPS_OK;
     const BeamPairWork bw = beam ? *beam : BeamPairWork{};
@@ -930,6 +933,7 @@ int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
     HPS_REQUIRE(pl.n + 256L*tw.nwg < (1L << 28), "deposit_current_tiled: the tile kernels address at most 2^28 particles per sheet");
     PartConsts k = base_consts(g);
     k.a = charge*invvol_of(g); k.b = charge*g.mu0/mass; k.max_qsa = max_qsa; k.can_ionize = can_ionize;
+    k.valid_by_w = valid_by_w && !tw.nwg;      // (the tail's workgroups would be fine too; kept on idcpu: released electrons are rare)
     k.aabs = aabs_comp; k.laser_fac = (charge/g.q_e)*(g.m_e/mass)*(charge/g.q_e)*(g.m_e/mass);
     DepComps cm{comp[0], comp[1], comp[2], comp[3], comp[4], comp[5]};
     int na = 0; for (int c = 0; c < 6; ++c) na += comp[c] >= 0;
@@ -954,13 +958,14 @@ int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
 
 int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int cache[4], const int depos[2],
                             double charge, double mass, int order, int dtype, int can_ionize, Tiling* T, int* n_fallback,
-                            hipStream_t st, int aabs_comp, const int* tile_flag, TailWork tw)
+                            hipStream_t st, int aabs_comp, const int* tile_flag, TailWork tw, bool valid_by_w)
 {
     if (pl.n == 0) return HPS_OK;
     HPS_REQUIRE(!(tile_flag && tw.nwg), "explicit_deposit_tiled: tile flags cannot be combined with tail workgroups");
     HPS_REQUIRE(pl.n + 256L*tw.nwg < (1L << 28), "explicit_deposit_tiled: the tile kernels address at most 2^28 particles per sheet");
     PartConsts k = base_consts(g);
     k.a = charge*invvol_of(g)*g.mu0; k.b = charge/mass; k.can_ionize = can_ionize;
+    k.valid_by_w = valid_by_w && !tw.nwg;
     k.aabs = aabs_comp; k.laser_fac = (g.m_e/g.q_e)*(g.m_e/g.q_e);
     const int R = T->g.ts + 2*TILE_HALO;
     const int pad = expl_pad();
@@ -1085,7 +1090,7 @@ extern "C" int hps_deposit_current_tiled (hps_slab slab, hps_plasma pl, hps_geom
     if (int e = check_tiling(tiling, slab, pl, "hps_deposit_current_tiled")) return e;
     for (int c = 0; c < 6; ++c) HPS_REQUIRE(comp[c] >= -1 && comp[c] < slab.ncomp, "hps_deposit_current_tiled: bad component");
     return deposit_current_tiled(slab, pl, g, comp, charge, mass, order, max_qsa, can_ionize, n_qsa,
-                                 static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr, TailWork{}, nullptr, nullptr);
+                                 static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr, TailWork{}, nullptr, nullptr, false);
 }
 
 extern "C" int hps_explicit_deposit_tiled (hps_slab slab, hps_plasma pl, hps_geom g, const int cache[4], const int depos[2],
@@ -1097,7 +1102,7 @@ extern "C" int hps_explicit_deposit_tiled (hps_slab slab, hps_plasma pl, hps_geo
     if (int e = check_stencil(slab, (order + 1)/2 + 1, "hps_explicit_deposit_tiled")) return e;
     if (int e = check_tiling(tiling, slab, pl, "hps_explicit_deposit_tiled")) return e;
     return explicit_deposit_tiled(slab, pl, g, cache, depos, charge, mass, order, dtype, can_ionize,
-                                  static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr, TailWork{});
+                                  static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr, TailWork{}, false);
 }
 
 extern "C" int hps_advance_plasma_tiled (hps_slab slab, hps_plasma pl, hps_geom g, const int comp[5], double charge,

@@ -1049,13 +1049,20 @@ struct GemmArgs {
     const int* gate;                                 // optional device word: return at once when *gate == 0
 };
 
+// The operands of DEPTH 32-deep slabs are in flight at once (registers), refilled as slabs are consumed: with one slab
+// ahead (round 1-3) every slab waited for a trip to memory -- eight trips in a 256-deep product that does 0.1 us of MFMA
+// work per slab: 8.3 us per launch.  LDS slabs are double-buffered: one barrier per slab.
+#ifndef HPS_DENSE_DEPTH
+#define HPS_DENSE_DEPTH 8
+#endif
 __global__ __launch_bounds__(256)
 void k_dense_product (GemmArgs g)
 {
     if (g.gate && *g.gate == 0) return;
+    constexpr int D = HPS_DENSE_DEPTH;
     // pitches chosen so that the 32 lanes of one LDS pass hit 32 different 8-byte slots: A rows 34 apart, B rows 48
-    __shared__ double As[32][34];
-    __shared__ double Bs[32][48];
+    __shared__ double As[2][32][34];
+    __shared__ double Bs[2][32][48];
     const int pl = blockIdx.z;
     const double* __restrict__ A = g.A[pl];
     const double* __restrict__ B = g.B[pl];
@@ -1065,37 +1072,45 @@ void k_dense_product (GemmArgs g)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wr = (wave >> 1)*16, wc = (wave & 1)*16;
     const int lm = lane & 15, lk = lane >> 4;
-    mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
-    // the next slab's operands are fetched into registers while this one is multiplied out of LDS
-    double ra[4], rb[4];
-    auto fetch = [&] (int k0) {
+    mfma_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};      // two chains: an MFMA does not wait for the one before it
+    double ra[D][4], rb[D][4];
+    auto fetch = [&] (int d, int k0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = threadIdx.x + 256*q, r = e >> 5, k = e & 31;
-            ra[q] = (r0 + r < g.M && k0 + k < g.K) ? A[(long)(r0 + r)*g.lda + k0 + k] : 0.0;
-            rb[q] = (k0 + r < g.K && c0 + k < g.N) ? B[(long)(k0 + r)*g.ldb + c0 + k] : 0.0;
+            ra[d][q] = (r0 + r < g.M && k0 + k < g.K) ? A[(long)(r0 + r)*g.lda + k0 + k] : 0.0;
+            rb[d][q] = (k0 + r < g.K && c0 + k < g.N) ? B[(long)(k0 + r)*g.ldb + c0 + k] : 0.0;
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < g.K; k0 += 32) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = threadIdx.x + 256*q, r = e >> 5, k = e & 31;
-            As[r][k] = ra[q]; Bs[r][k] = rb[q];
+    for (int d = 0; d < D; ++d) if (32*d < g.K) fetch(d, 32*d);
+    for (int kb = 0; kb < g.K; kb += 32*D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int k0 = kb + 32*d;
+            if (k0 < g.K) {                      // (uniform)
+                const int buf = d & 1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = threadIdx.x + 256*q, r = e >> 5, k = e & 31;
+                    As[buf][r][k] = ra[d][q]; Bs[buf][r][k] = rb[d][q];
+                }
+                __syncthreads();
+                if (k0 + 32*D < g.K) fetch(d, k0 + 32*D);
+#pragma unroll
+                for (int kk = 0; kk < 32; kk += 8) {
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(As[buf][wr + lm][kk + lk], Bs[buf][kk + lk][wc + lm], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(As[buf][wr + lm][kk + 4 + lk], Bs[buf][kk + 4 + lk][wc + lm], acc1, 0, 0, 0);
+                }
+            }
         }
-        __syncthreads();
-        if (k0 + 32 < g.K) fetch(k0 + 32);
-#pragma unroll
-        for (int kk = 0; kk < 32; kk += 4)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[wr + lm][kk + lk], Bs[kk + lk][wc + lm], acc, 0, 0, 0);
-        __syncthreads();
     }
     double* __restrict__ C = g.C[pl];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int r = r0 + wr + 4*q + lk, c = c0 + wc + lm;
         if (r < g.M && c < g.N) {
-            double v = acc[q];
+            double v = acc0[q] + acc1[q];
             if (g.scale) v *= g.scale[(long)r*g.scale_r + (long)c*g.scale_c];
             C[(long)r*g.ldc + c] = v;
         }

@@ -175,26 +175,16 @@ def test_config2_whole_box_vs_oracle_fixture(api):
 def test_config2_baseline_deck_whole_box_vs_oracle_fixture(api):
     """The BASELINE deck itself (driver 54 slices into the box).  Ahead of the driver the serial CPU path holds exact zeros
     and its loop leaves after one pass (ComputeRelBFieldError returns 0 for sum|B| = 0, fields/Fields.cpp:1283), also on the
-    first slice with beam; a scatter with atomics leaves 1e-16 residue and the loop iterates on it to max_iterations, as the
-    reference's GPU build must.  At a loop tolerance of 4e-2 and a mixing factor of 0.05 the result depends on that path:
-    the two runs agree to a few per cent where the driver sets in and to ~1e-2 behind it -- checked at 5e-2 on the
-    whole-box checksums of the physical fields, with the iteration counts equal slice by slice once both are behind the
-    transition."""
+    first slice with beam; a scatter with atomics leaves 1e-16 residue there.  The engine takes sum|B| at that rounding floor
+    for the zero it stands for (Engine::pc_floor, HPS_PC_NOISE_FLOOR), so the loop follows the CPU's path: the same number
+    of iterations and the box to 1e-6.  (With the literal rule the loop iterates on the noise to max_iterations on every
+    slice ahead of the driver -- 2400-2500 iterations instead of 1631 -- and enters the driver on another path: the two runs
+    then agree to per cents only; gpurun_out/r04/fullsize_tests*.log of round 4.)"""
     fx, got = _run_box(api, "config2")
-    phys = ("ExmBy", "EypBx", "Ez", "Bx", "By", "Psi", "jx", "jy", "jz", "rhomjz")
-    for k in phys:
-        v, g = fx["checksums"][k], got["checksums"][k]
-        assert abs(g - v) <= 5e-2 * abs(v), (k, g, v)
-    qs = sorted(fx["trace"], key=int)
-    behind = [q for q in qs if int(q) >= 95]
-    for a, b in zip(behind, behind[1:]):
-        d_or = fx["trace"][b]["pc_iterations"] - fx["trace"][a]["pc_iterations"]
-        d_gpu = got["trace"][b]["pc_iterations"] - got["trace"][a]["pc_iterations"]
-        assert abs(d_or - d_gpu) <= max(2, 0.02 * d_or), (a, b, d_or, d_gpu)
-    for q in qs:
-        assert got["trace"][q]["n_valid"] == fx["trace"][q]["n_valid"]
-    print(f"config2 (BASELINE deck): PC iterations {got['final']['pc_iterations']} (oracle {fx['final']['pc_iterations']}: exact zeros "
-          f"ahead of the driver)")
+    bad, worst, worst_trace = _compare(fx, got, int_keys=("n_valid", "n_particles", "pc_iterations"), soft_int_keys=())
+    print(f"config2 (BASELINE deck): worst checksum deviation {worst:.2e}, worst plane-sum deviation {worst_trace:.2e}, PC iterations "
+          f"{got['final']['pc_iterations']} (oracle {fx['final']['pc_iterations']})")
+    assert not bad, bad[:10]
 
 
 @pytest.mark.parametrize("name", ["config5_fft", "config5_mg"])
@@ -207,6 +197,53 @@ def test_config5_whole_box_vs_oracle_fixture(api, name):
     print(f"{name}: worst checksum deviation {worst:.2e}, worst plane-sum deviation {worst_trace:.2e}, ionised "
           f"{got['final']['n_ionized']} (oracle {fx['final']['n_ionized']})")
     assert not bad, bad[:10]
+
+
+def test_full_size_laser_and_ionization_properties(api):
+    """1024^2 with the LASER / IONIZE kernel variants (BASELINE configs[4]'s deck, 256 slices around the pulse): identities
+    that need no oracle run -- every released electron is one ionisation level of one macro-ion (count and weight), the
+    product species grows by exactly the released electrons, the ions keep their weights, and the laser-variant deposition
+    conserves charge: the sum of rho - jz/c over the plane equals the particles' q w (1 - v_z/c) summed directly."""
+    from hipace_amd import decks
+    n, nz = 1024, 256
+    d = decks.synthetic(n, nz, 2)
+    d.update(beam_profile=-1, lo=(-20.0, -20.0, -2.0), hi=(20.0, 20.0, 2.0), laser_on=1, laser_a0=4.5, laser_w0=4.0, laser_L0=2.0,
+             laser_lambda0=0.08, laser_solver=1, dt=5.0)
+    decks.with_ion_species(d, "N", 0.2, ppc=(1, 1), initial_level=0, seed=5)
+    d["background_density_SI"] = 2.8239587008591567e23
+    eng = api.SliceEngine(d, tile_size=16, sort_period=128)
+    eng.begin_step()
+    real0, valid0 = eng.particles()
+    n0 = int(valid0.size)
+    ireal0, _, _, key0 = eng.ions()
+    for q in range(nz):
+        eng.solve_slice(nz - 1 - q)
+    released, n_product = eng.ion_stats()
+    ireal, ivalid, lev, key = eng.ions()
+    assert released > 1000                                     # the wake does ionise the dopant
+    assert int(lev[ivalid != 0].sum()) == released             # one level per released electron
+    assert n_product == n0 + released                          # the electrons joined the first species
+    real, valid = eng.particles()
+    assert valid.size == n_product
+    # weights: the electrons appended behind the initial sheet carry their ions' weights
+    order = np.argsort(key)
+    w_now = ireal[2][order]
+    assert np.array_equal(np.sort(key0), key[order]) and (w_now == ireal0[2][np.argsort(key0)]).mean() > 0.9999      # (a QSA drop zeroes a weight)
+    sum_w_released = real[2][valid != 0].sum() - real0[2][valid0 != 0].sum()
+    want = float((lev[order] * w_now).sum())
+    # (electrons dropped by the QSA check or pushed out lose their weight: allow the few that were)
+    assert abs(sum_w_released - want) <= 1e-3 * want, (sum_w_released, want)
+    # charge conservation of the LASER / can-ionise deposition variants: the last slice's rho - jz/c plane (both species,
+    # deposited before that slice's push) sums to the particles' charge -- electrons - w, ions + level w; ionisation adds
+    # neutral pairs and the boundary is periodic, so the sums after the slice are those at the deposition
+    slab = eng.slab()
+    names = eng.comp_names()
+    tot = float(slab[names.index("rhomjz")].sum())
+    want_q = -float(real[2][valid != 0].sum()) + want
+    scale = float(real[2][valid != 0].sum())
+    assert abs(tot - want_q) <= 1e-9 * scale, (tot, want_q)
+    # the background (Ion_rhomjz) neutralises the pre-formed plasma: the total charge in the plane is the dopant's bookkeeping only
+    assert abs(tot + float(slab[names.index("Ion_rhomjz")].sum()) - (want - sum_w_released)) <= 1e-9 * scale
 
 
 @pytest.fixture(scope="module")
