@@ -324,7 +324,7 @@ def main():
         args.steps = nz                         # one whole box of the deck that is timed (config 5: all 2048 slices, the pulse included)
     if world > 1 and not args.inflight_ring:
         args.inflight = 1
-    if args.ring_self or args.fuse:
+    if args.fuse:
         args.inflight = 1
     if args.config2 and os.environ.get("HPS_PC_SPECULATE", "1") == "0":
         args.inflight = 1                       # (host-controlled predictor-corrector loop: the host is held once per iteration, the slice

@@ -129,7 +129,8 @@ __device__ __forceinline__ void load_region (double* img, const SlabView& f, con
 // (An XCD-chunked tile order -- contiguous tile runs per XCD -- was measured slower here: 916 vs 953 slices/s.)
 // MASK: compile-time set of deposited components (bit c = DepComps entry c), -1 = decide at run time.
 // With a compile-time set the 9x4 accumulations are straight-line ds_add_f64 with immediate offsets.
-template <int ORDER, int TS, int MASK, bool LASER = false>
+// VBW: PartConsts::valid_by_w at compile time (as a run-time branch in the fetch it split the batch of loads: 76 against 70 us)
+template <int ORDER, int TS, int MASK, bool LASER = false, bool VBW = false>
 __global__ __launch_bounds__(256)
 void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx, DepComps cm,
                       PartConsts k, int* n_qsa, int* n_fallback, const int* __restrict__ tile_flag, TailWork tw, BeamPairWork bw,
@@ -171,7 +172,8 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         Rec r;
         r.x = pl.x[ip]; r.y = pl.y[ip]; r.w = pl.w[ip];
         r.ux = pl.ux[ip]; r.uy = pl.uy[ip]; r.psi = pl.psi[ip];
-        r.id = k.valid_by_w ? (r.w != 0.0 ? HPS_ID_VALID : 0ULL) : pl.idcpu[ip];      // (PartConsts::valid_by_w: idcpu is not read)
+        if constexpr (VBW) r.id = (r.w != 0.0) ? HPS_ID_VALID : 0ULL;      // (PartConsts::valid_by_w: idcpu is not read)
+        else r.id = pl.idcpu[ip];
         r.ion = k.can_ionize ? pl.ion_lev[ip] : 1;
         return r;
     };
@@ -250,7 +252,7 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         if (gamma_psi < 0.0 || gamma_psi > k.max_qsa || psi_inv < 0.0) {
             if (n_qsa) atomicAdd(n_qsa, 1);
             pl.w[ip] = 0.0;
-            pl.idcpu[ip] = (k.valid_by_w ? pl.idcpu[ip] : id) & ~HPS_ID_VALID;
+            pl.idcpu[ip] = (VBW ? pl.idcpu[ip] : id) & ~HPS_ID_VALID;
             continue;
         }
         // per-component weights in DepComps order
@@ -332,7 +334,7 @@ __device__ __forceinline__ void load_region (double* img, const SlabView& f, con
     }
 }
 
-template <int ORDER, int DT, int TS, bool LASER = false, int PAD = 2>
+template <int ORDER, int DT, int TS, bool LASER = false, int PAD = 2, bool VBW = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // 128 VGPRs: 4 workgroups per CU
 void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
                        int cBz, int cEz, int cExmBy, int cEypBx, int cSy, int cSx, PartConsts k, int* n_fallback,
@@ -360,7 +362,8 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
         Rec r;
         r.x = pl.x[ip]; r.y = pl.y[ip]; r.w = pl.w[ip];
         r.ux = pl.ux[ip]; r.uy = pl.uy[ip]; r.psi = pl.psi[ip];
-        r.id = k.valid_by_w ? (r.w != 0.0 ? HPS_ID_VALID : 0ULL) : pl.idcpu[ip];      // (PartConsts::valid_by_w: idcpu is not read)
+        if constexpr (VBW) r.id = (r.w != 0.0) ? HPS_ID_VALID : 0ULL;      // (PartConsts::valid_by_w: idcpu is not read)
+        else r.id = pl.idcpu[ip];
         r.ion = k.can_ionize ? pl.ion_lev[ip] : 1;
         return r;
     };
@@ -933,10 +936,12 @@ int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
     HPS_REQUIRE(pl.n + 256L*tw.nwg < (1L << 28), "deposit_current_tiled: the tile kernels address at most 2^28 particles per sheet");
     PartConsts k = base_consts(g);
     k.a = charge*invvol_of(g); k.b = charge*g.mu0/mass; k.max_qsa = max_qsa; k.can_ionize = can_ionize;
-    k.valid_by_w = valid_by_w && !tw.nwg;      // (the tail's workgroups would be fine too; kept on idcpu: released electrons are rare)
     k.aabs = aabs_comp; k.laser_fac = (charge/g.q_e)*(g.m_e/mass)*(charge/g.q_e)*(g.m_e/mass);
     DepComps cm{comp[0], comp[1], comp[2], comp[3], comp[4], comp[5]};
     int na = 0; for (int c = 0; c < 6; ++c) na += comp[c] >= 0;
+    {   int m = 0; for (int c = 0; c < 6; ++c) m |= (comp[c] >= 0) << c;
+        // (kernel variants exist for the hot component sets without a laser; the tail's released electrons keep idcpu)
+        k.valid_by_w = valid_by_w && !tw.nwg && aabs_comp < 0 && (m == 51 || m == 3); }
     const int R = T->g.ts + 2*TILE_HALO;
     const size_t lds = ((size_t)na*R*(R + HPS_DEP_PAD) + (aabs_comp >= 0 ? (size_t)R*R : 0))*sizeof(double);
     SlabView f(slab);
@@ -945,13 +950,17 @@ int deposit_current_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
         hipLaunchKernelGGL((k_deposit_tiled<O, S, M>), dim3(T->g.ntiles + tw.nwg + bw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag, tw, bw, go); }
 #define CALLL(O, S, M) { if (int e = set_lds(k_deposit_tiled<O, S, M, true>, lds)) return e; \
         hipLaunchKernelGGL((k_deposit_tiled<O, S, M, true>), dim3(T->g.ntiles + tw.nwg + bw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag, tw, bw, go); }
+#define CALLV(O, S, M) { if (int e = set_lds(k_deposit_tiled<O, S, M, false, true>, lds)) return e; \
+        hipLaunchKernelGGL((k_deposit_tiled<O, S, M, false, true>), dim3(T->g.ntiles + tw.nwg + bw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, cm, k, n_qsa, n_fallback, tile_flag, tw, bw, go); }
 #define CALL(O, S) { if (aabs_comp >= 0) { if (mask == 51) CALLL(O, S, 51) else CALLL(O, S, -1) } \
+                     else if (k.valid_by_w && mask == 51) CALLV(O, S, 51) else if (k.valid_by_w && mask == 3) CALLV(O, S, 3) \
                      else if (mask == 51) CALLM(O, S, 51) else if (mask == 59) CALLM(O, S, 59) else if (mask == 32) CALLM(O, S, 32) \
                      else if (mask == 3) CALLM(O, S, 3) else if (mask == 39) CALLM(O, S, 39) else if (mask == 47) CALLM(O, S, 47) else CALLM(O, S, -1) }
     HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
 #undef CALL
 #undef CALLM
 #undef CALLL
+#undef CALLV
     HPS_HIP_CHECK(hipGetLastError());
     return HPS_OK;
 }
@@ -965,16 +974,16 @@ int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hp
     HPS_REQUIRE(pl.n + 256L*tw.nwg < (1L << 28), "explicit_deposit_tiled: the tile kernels address at most 2^28 particles per sheet");
     PartConsts k = base_consts(g);
     k.a = charge*invvol_of(g)*g.mu0; k.b = charge/mass; k.can_ionize = can_ionize;
-    k.valid_by_w = valid_by_w && !tw.nwg;
+    k.valid_by_w = valid_by_w && !tw.nwg && aabs_comp < 0 && dtype == 2;      // (the kernel variant that exists)
     k.aabs = aabs_comp; k.laser_fac = (g.m_e/g.q_e)*(g.m_e/g.q_e);
     const int R = T->g.ts + 2*TILE_HALO;
     const int pad = expl_pad();
     const size_t lds = (size_t)(aabs_comp >= 0 ? 7 : 6)*R*(R + pad)*sizeof(double);
     SlabView f(slab);
-#define HPS_EXPL_LAUNCH(O, D, S, L, P) { if (int e = set_lds(k_explicit_tiled<O, D, S, L, P>, lds)) return e; \
-        hipLaunchKernelGGL((k_explicit_tiled<O, D, S, L, P>), dim3(T->g.ntiles + tw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
+#define HPS_EXPL_LAUNCH(O, D, S, L, P, V) { if (int e = set_lds(k_explicit_tiled<O, D, S, L, P, V>, lds)) return e; \
+        hipLaunchKernelGGL((k_explicit_tiled<O, D, S, L, P, V>), dim3(T->g.ntiles + tw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
                            cache[0], cache[1], cache[2], cache[3], depos[0], depos[1], k, n_fallback, tile_flag, tw); }
-#define HPS_EXPL_PADS(O, D, S, L) { if (pad == 8) HPS_EXPL_LAUNCH(O, D, S, L, 8) else HPS_EXPL_LAUNCH(O, D, S, L, 2) }
+#define HPS_EXPL_PADS(O, D, S, L) { if (pad == 8) HPS_EXPL_LAUNCH(O, D, S, L, 8, false) else if (!L && D == 2 && k.valid_by_w) HPS_EXPL_LAUNCH(O, D, S, false, 2, true) else HPS_EXPL_LAUNCH(O, D, S, L, 2, false) }
     if (dtype == 2) {
 #define CALL(O, S) { if (aabs_comp >= 0) HPS_EXPL_PADS(O, 2, S, true) else HPS_EXPL_PADS(O, 2, S, false) }
         HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)

@@ -473,9 +473,13 @@ def run_lanes(engines, rank, world, n_steps, device, on_step_end=None, slices_pe
     ringT = make_transport(rank, world, device) if own else transport
     edges = [LocalEdge() for _ in range(L)]        # edges[j]: stage j -> stage j + 1 of this process (the last one closes the loop when world == 1)
     gens = []
+    # one process whose closing edge (last stage -> first stage) goes through the RCCL ring all the same (RcclSelfRing): the
+    # configuration of a rank of a multi-rank ring with L stages -- receives of the first stage posted a step ahead as RCCL
+    # kernels, sends of the last stage behind its engine's events -- on the one rank a 1-GPU box has
+    closing = ringT if (world == 1 and getattr(ringT, "self_ring", False) and not isinstance(ringT, StageTransport)) else None
     for j, eng in enumerate(engines):
-        rx = edges[j - 1] if (j > 0 or world == 1) else ringT
-        tx = edges[j] if (j < L - 1 or world == 1) else ringT
+        rx = edges[j - 1] if (j > 0 or (world == 1 and closing is None)) else ringT
+        tx = edges[j] if (j < L - 1 or (world == 1 and closing is None)) else ringT
         T = StageTransport(eng, rx, tx)
         ose = (lambda step, e=eng: on_step_end(step, e)) if on_step_end is not None else None
         osl = (lambda m, q, jj=j: on_slice(jj, m, q)) if on_slice is not None else None

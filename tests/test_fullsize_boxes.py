@@ -233,17 +233,18 @@ def test_full_size_laser_and_ionization_properties(api):
     want = float((lev[order] * w_now).sum())
     # (electrons dropped by the QSA check or pushed out lose their weight: allow the few that were)
     assert abs(sum_w_released - want) <= 1e-3 * want, (sum_w_released, want)
-    # charge conservation of the LASER / can-ionise deposition variants: the last slice's rho - jz/c plane (both species,
-    # deposited before that slice's push) sums to the particles' charge -- electrons - w, ions + level w; ionisation adds
-    # neutral pairs and the boundary is periodic, so the sums after the slice are those at the deposition
+    # charge conservation of the LASER / can-ionise deposition variants: the last slice's rho - jz/c plane holds both species
+    # (deposited before that slice's push) and the neutralising background of the pre-formed plasma (AddRhoIons): it sums to
+    # the particles' charge -- electrons - w, ions + level w -- plus the background's; ionisation adds neutral pairs and the
+    # boundary is periodic, so the sums after the slice are those at the deposition
     slab = eng.slab()
     names = eng.comp_names()
     tot = float(slab[names.index("rhomjz")].sum())
-    want_q = -float(real[2][valid != 0].sum()) + want
+    background = float(slab[names.index("Ion_rhomjz")].sum())
     scale = float(real[2][valid != 0].sum())
+    assert abs(background - float(real0[2][valid0 != 0].sum())) <= 1e-9 * scale          # the background is the initial sheet's charge
+    want_q = -scale + want + background
     assert abs(tot - want_q) <= 1e-9 * scale, (tot, want_q)
-    # the background (Ion_rhomjz) neutralises the pre-formed plasma: the total charge in the plane is the dopant's bookkeeping only
-    assert abs(tot + float(slab[names.index("Ion_rhomjz")].sum()) - (want - sum_w_released)) <= 1e-9 * scale
 
 
 @pytest.fixture(scope="module")

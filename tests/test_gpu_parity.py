@@ -685,6 +685,38 @@ def test_several_steps_in_flight_on_one_gpu(api, lanes, n_steps):
             assert abs(cs[k] - v) <= 1e-9 * abs(v), (step, k, cs[k], v)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes,n_steps", [(2, 5), (3, 7)])
+def test_several_stages_per_rank_with_the_closing_edge_on_rccl(api, lanes, n_steps):
+    """What a rank of a multi-rank ring with several stages does, on the one rank a 1-GPU box has: `lanes` engines are the
+    stages of this process, the edges between them are in-process copies, and the edge that closes the ring -- last stage
+    -> first stage -- goes through RCCL (RcclSelfRing: ncclSend + ncclRecv on the ring's streams, the first stage's
+    receives posted a step ahead, ordered against the engines by events only).  Every step has the reference's checksums."""
+    import torch
+    from hipace_amd.pipeline import RcclSelfRing, run_lanes
+    gold = json.load(open(os.path.join(GOLD, "blowout_wake_explicit.2Rank.json")))["lev=0"]
+    deck = decks.blowout_wake()
+    deck["n_steps"] = 1
+    engs = [api.SliceEngine(deck, tile_size=16, sort_period=16) for _ in range(lanes)]
+    for e in engs:
+        e.set_diagnostics(True)
+    got = {}
+
+    def on_step_end(step, eng):
+        eng.sync()
+        got[step] = eng.checksums()
+
+    T = RcclSelfRing(0)
+    solved = run_lanes(engs, 0, 1, n_steps, torch.device("cuda", 0), on_step_end, transport=T)
+    st = T.stats()
+    T.close()
+    assert solved == n_steps * deck["nz"] and sorted(got) == list(range(n_steps))
+    assert st["sent"] > 0 and st["sent"] == st["received"]                # the closing edge's messages went through RCCL
+    for step, cs in got.items():
+        for k, v in gold.items():
+            assert abs(cs[k] - v) <= 1e-9 * abs(v), (step, k, cs[k], v)
+
+
 # ---- field diagnostics (SURVEY 8f-4: Fields::Copy into the 3-D output array) ------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("coarsening", [(1, 1, 1), (3, 4, 5), (2, 2, 2)])
