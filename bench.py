@@ -54,7 +54,7 @@ if ROOT not in sys.path:
 CPU_THREADS_DEFAULT = 16  # OpenMP leg of the CPU baseline: fastest on the 256-core host of the GPU box, 9.5x the serial leg; 64 threads
                           # are already slower and 256 slower than one (profiles/r02b_cpu_threads.json)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_SUMMARY = "r04c_pmc_fetch_write_per_kernel.csv"      # profiles/: rocprofv3 --pmc summary of the shipped kernels
+PMC_SUMMARY = "r04f_pmc_fetch_write_per_kernel.csv"      # profiles/: rocprofv3 --pmc summary of the shipped kernels
 START_SLICE_DEFAULT = 700  # short runs start here (from the head); see profiles/r02a_slice_cost_profile.json
 
 
@@ -624,6 +624,11 @@ def main():
                            if (args.config5 and not args.no_ionization) else None),
             "ring": ring_stats,
             "rccl_ranks_seen": rccl_ranks_seen,
+            "stages_per_rank_on_the_ring": (max(1, args.inflight) if (world > 1 or args.ring_self) else None),
+            "stages_per_rank_note": ("N > 1 runs ONE stage per rank unless --inflight-ring: with the closing edge of a 3-stage rank through RCCL "
+                                     "(one rank, --ring-self --inflight 3) the three stages made 1552 slices/s against 1986 with all edges in the "
+                                     "process, two stages 1791 against 1813 (profiles/r04_ring_self_stages.txt); results equal either way")
+                                    if world > 1 and not args.inflight_ring else None,
             "roofline": {"bound": "hbm", "kernel": "k_deposit_tiled<2,%d>" % args.tile if args.tile else "k_deposit_current<2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": kernel_ms,

@@ -1049,11 +1049,12 @@ struct GemmArgs {
     const int* gate;                                 // optional device word: return at once when *gate == 0
 };
 
-// The operands of DEPTH 32-deep slabs are in flight at once (registers), refilled as slabs are consumed: with one slab
-// ahead (round 1-3) every slab waited for a trip to memory -- eight trips in a 256-deep product that does 0.1 us of MFMA
-// work per slab: 8.3 us per launch.  LDS slabs are double-buffered: one barrier per slab.
+// The operands of DEPTH 32-deep slabs are in flight at once (registers), refilled as slabs are consumed; LDS slabs are
+// double-buffered (one barrier per slab), two accumulator chains.  Measured on config 2 (bench.py --config2, two runs each):
+// depth 1 2894-2924 slices/s, 2 2999-3016, 4 2943-3010, 8 (all slabs of a 256-deep product, 252 VGPRs) 2970-2973: the
+// product is not waiting for its operands; 2 it is.
 #ifndef HPS_DENSE_DEPTH
-#define HPS_DENSE_DEPTH 8
+#define HPS_DENSE_DEPTH 2
 #endif
 __global__ __launch_bounds__(256)
 void k_dense_product (GemmArgs g)
