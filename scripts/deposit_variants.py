@@ -106,11 +106,13 @@ def main():
              6: "mode 6  mode 3 with every cell of the region flushed (4 x 28 x 28 global atomics per tile)",
              1: "mode 1  neighbouring lanes on the same words merged over DPP",
              2: "mode 2  bins by stencil base, register patch, 36 atomics per BIN (chunks of 1024)",
-             4: "mode 4  the same in chunks of 512 particles (3 workgroups per CU)"}
+             4: "mode 4  the same in chunks of 512 particles (3 workgroups per CU)",
+             7: "mode 7  768 persistent workgroups, the next tile's particles requested ahead of this tile's atomics",
+             8: "mode 8  the same with 1024 workgroups", 9: "mode 9  the same with 512 workgroups"}
     for halo in (6,):
         lib = build(halo)
         print(f"-- harness kernels with a {halo}-cell halo")
-        for mode in (0, 3, 5, 6, 1, 2, 4):
+        for mode in (0, 3, 5, 6, 1, 2, 4, 7, 8, 9):
             scratch.zero_()
             ms = C.c_float()
             rc = lib.depvar_run(mode, sl, pl, geom.c, offs, ntiles.value, ntx, -1.0, 1.0, 0, C.byref(ms))

@@ -13,6 +13,7 @@
 //   mode 3  mode 0 without its LDS atomics and without flush traffic (loads and arithmetic only)
 //   mode 5  mode 0 without the flush (loads, arithmetic, LDS atomics)
 //   mode 6  mode 3 with every cell of the region flushed (loads, arithmetic, 4 x 28 x 28 global atomics per tile)
+//   mode 7/8/9  persistent workgroups (768 / 1024 / 512 of them), the next tile's particles requested ahead of the current tile's atomics
 //
 // Build: hipcc -O3 --offload-arch=gfx950 -shared -fPIC depvar.hip -o libdepvar.so   (scripts/deposit_variants.py does it)
 #include "../../hipace_amd/csrc/common.h"
@@ -289,6 +290,80 @@ void k_dep_bins (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int
     flush(f, cm, acc, ox, oy, tid);
 }
 
+// ---- mode 7: persistent workgroups, the NEXT tile's particles requested while the current tile's atomics and flush run -------
+// (the shipped kernel loads a whole tile in one batch, works on it and leaves: its own prefetch switch has nothing to prefetch,
+// and loads + arithmetic, LDS atomics and flush add up -- 38 + 17 + 10.5 us on a sheath slice)
+__device__ __forceinline__ void persist_fetch (const hps_plasma& pl, const int4 rec, int tid, Rec (&r)[4])
+{
+    const int ipb = rec.y + tid;
+    if (ipb < rec.z) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = fetch(pl, min(ipb + 256*u, rec.z - 1));
+    }
+}
+__device__ __forceinline__ void persist_tile (const SlabView& f, const hps_plasma& pl, const Comps& cm, const Consts& k, double* acc,
+                                              const int4 lrec, int ntx, int tid, Rec (&first)[4])
+{
+    const int tile = lrec.x, pend = lrec.z;
+    const int ox = (tile % ntx)*TS - HALO, oy = (tile / ntx)*TS - HALO;
+    { double2* z = (double2*)acc; for (int s = tid; s < 4*R*R/2; s += 256) z[s] = make_double2(0.0, 0.0); }
+    __syncthreads();
+    const int ipb = lrec.y + tid;
+    for (int ip0 = ipb; ip0 < pend; ip0 += 1024) {
+        Rec rec[4];
+        if (ip0 != ipb) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rec[u] = fetch(pl, min(ip0 + 256*u, pend - 1));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ip = ip0 + 256*u;
+            if (ip >= pend) break;
+            const Dep d = prepare(ip0 == ipb ? first[u] : rec[u], k);
+            if (!d.on) continue;
+            const int li = d.i0 - ox, lj = d.j0 - oy;
+            if (!(li >= 0 && li + 2 < R && lj >= 0 && lj + 2 < R)) { global_path(f, cm, d); continue; }
+            double sx[3], sy[3]; weights(d.tx, sx); weights(d.ty, sy);
+            double* p0 = acc + lj*R + li;
+#pragma unroll
+            for (int iy = 0; iy < 3; ++iy)
+#pragma unroll
+                for (int ix = 0; ix < 3; ++ix) {
+                    const double ss = sx[ix]*sy[iy];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) lds_add(p0 + iy*R + ix + c*R*R, ss*d.v[c]);
+                }
+        }
+    }
+    __syncthreads();
+    flush(f, cm, acc, ox, oy, tid);
+    __syncthreads();
+}
+__global__ __launch_bounds__(256)
+void k_dep_persist (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntiles, int ntx, Comps cm, Consts k)
+{
+    extern __shared__ __attribute__((aligned(16))) double acc[];      // [4][R*R]
+    const int4* recs = reinterpret_cast<const int4*>(offsets + tile_launch_offset(ntiles));
+    const int tid = threadIdx.x, G = gridDim.x;
+    Rec a[4], b[4];
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    int4 ra = recs[t], rb = ra;
+    persist_fetch(pl, ra, tid, a);
+    while (true) {
+        const bool more_b = t + G < ntiles;
+        if (more_b) { rb = recs[t + G]; persist_fetch(pl, rb, tid, b); }
+        persist_tile(f, pl, cm, k, acc, ra, ntx, tid, a);
+        if (!more_b) break;
+        t += G;
+        const bool more_a = t + G < ntiles;
+        if (more_a) { ra = recs[t + G]; persist_fetch(pl, ra, tid, a); }
+        persist_tile(f, pl, cm, k, acc, rb, ntx, tid, b);
+        if (!more_a) break;
+        t += G;
+    }
+}
+
 } // namespace
 
 extern "C" int depvar_run (int mode, hps_slab slab, hps_plasma pl, hps_geom g, const int* offsets_dev, int ntiles, int ntx,
@@ -315,6 +390,9 @@ extern "C" int depvar_run (int mode, hps_slab slab, hps_plasma pl, hps_geom g, c
         case 4: { constexpr int NBC = 2; const size_t lds = lds_plain + 3*256*NBC*sizeof(double2) + (R*R + 8)*sizeof(unsigned);
                   (void)hipFuncSetAttribute((const void*)k_dep_bins<NBC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                   hipLaunchKernelGGL((k_dep_bins<NBC>), dim3(ntiles), dim3(256), lds, 0, f, pl, offsets_dev, ntiles, ntx, cm, k); } break;
+        case 7: hipLaunchKernelGGL(k_dep_persist, dim3(ntiles < 768 ? ntiles : 768), dim3(256), lds_plain, 0, f, pl, offsets_dev, ntiles, ntx, cm, k); break;
+        case 8: hipLaunchKernelGGL(k_dep_persist, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), lds_plain, 0, f, pl, offsets_dev, ntiles, ntx, cm, k); break;
+        case 9: hipLaunchKernelGGL(k_dep_persist, dim3(ntiles < 512 ? ntiles : 512), dim3(256), lds_plain, 0, f, pl, offsets_dev, ntiles, ntx, cm, k); break;
         default: break;
         }
     };
