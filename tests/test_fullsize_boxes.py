@@ -152,6 +152,38 @@ def test_config4_whole_box_vs_oracle_fixture(api):
     assert got["fallbacks"] > 0 and got["sorts"] > 1          # the schedule's slow paths were exercised
 
 
+def test_config4_three_steps_in_flight_vs_oracle_fixture(api):
+    """The second number of the bench line (`value_steps_in_flight`): three engines on three streams run three consecutive
+    time steps of the headline deck at once (hipace_amd/pipeline.py::run_lanes, one host thread, per-slice beam hand-off
+    between the stages).  hipace.dt = 0, so every step is the box of the fixture: each stage's whole-box checksums and
+    V-cycle total against the oracle's."""
+    import torch
+    from hipace_amd.pipeline import run_lanes
+    fx, deck = _fixture("config4")
+    engs = [api.SliceEngine(deck, tile_size=16, sort_period=128) for _ in range(3)]
+    for e in engs:
+        e.set_diagnostics(True)
+    got = {}
+
+    def on_step_end(step, eng):
+        eng.sync()
+        got[step] = (eng.checksums(), eng.stats()["vcycles"])
+
+    solved = run_lanes(engs, 0, 1, 3, torch.device("cuda", 0), on_step_end)
+    assert solved == 3 * deck["nz"] and sorted(got) == [0, 1, 2]
+    worst = 0.0
+    for step, (cs, vc) in got.items():
+        for k, v in fx["checksums"].items():
+            if v == 0.0:
+                assert cs[k] == 0.0, (step, k)
+            else:
+                worst = max(worst, abs(cs[k] - v) / abs(v))
+                assert abs(cs[k] - v) <= 1e-6 * abs(v), (step, k, cs[k], v)
+        assert abs(vc - fx["final"]["vcycles"]) <= max(2, 1e-3 * fx["final"]["vcycles"]), (step, vc)
+    print(f"config4, three steps in flight: worst checksum deviation {worst:.2e}, V-cycles {[got[s][1] for s in sorted(got)]} "
+          f"(oracle {fx['final']['vcycles']})")
+
+
 def test_config3_whole_box_vs_oracle_fixture(api):
     """BASELINE configs[2]: blowout_wake 512 x 512 x 1024, 4 ppc, explicit solver."""
     fx, got = _run_box(api, "config3")
