@@ -3,7 +3,7 @@
 # its own pass next to --kernel-trace only.  usage (GPU box, repo root): bash scripts/collect_mfma.sh <tag>
 set -u
 TAG=${1:-r03}
-OUT=$PWD/gpurun_out; mkdir -p $OUT
+OUT=$PWD/gpurun_out; mkdir -p $(dirname $OUT/${TAG}_x)
 export TMPDIR=/tmp
 R=$PWD
 cd /tmp && rm -rf /tmp/prof_mf

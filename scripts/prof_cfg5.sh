@@ -2,7 +2,7 @@
 # config 5 (laser + ionisable dopant) under rocprofv3 --kernel-trace: usage bash scripts/prof_cfg5.sh <tag> [bench args]
 set -u
 TAG=${1:-c5}; shift || true
-OUT=$PWD/gpurun_out; mkdir -p $OUT
+OUT=$PWD/gpurun_out; mkdir -p $(dirname $OUT/${TAG}_x)
 export TMPDIR=/tmp
 R=$PWD
 cd /tmp && rm -rf /tmp/prof_c5

@@ -3,7 +3,7 @@
 # usage (GPU box, repo root): bash scripts/quick_prof.sh <tag> [extra bench.py arguments]
 set -u
 TAG=${1:-q}; shift || true
-OUT=$PWD/gpurun_out; mkdir -p $OUT
+OUT=$PWD/gpurun_out; mkdir -p $(dirname $OUT/${TAG}_x)
 export TMPDIR=/tmp
 R=$PWD
 cd /tmp && rm -rf /tmp/prof_q
