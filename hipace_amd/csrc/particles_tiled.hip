@@ -379,6 +379,9 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
     __syncthreads();
 
     int nfb = 0;
+#ifdef HPS_DIAG_EXPL_NO_ATOMICS
+    double diag_sink = 0.0;
+#endif
     for (int ip = ipb; ip < pend; ip += 256) {
         const Rec cur = nxt;
         if (ip + 256 < pend) nxt = fetch(ip + 256);
@@ -443,7 +446,11 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
                     sx_add = (xedge ? b5 : b6)*dd;
                 } else {
                     double Bz, Ez, ExmBy, EypBx;
+#ifdef HPS_DIAG_EXPL_NO_READS      // (diagnostic build: what the kernel costs without its field reads; results are wrong)
+                    if (local) { Bz = 1.0 + ls; Ez = 2.0; ExmBy = 3.0; EypBx = 4.0; }
+#else
                     if (local) { Bz = lds_get(img + ls); Ez = lds_get(img + PL + ls); ExmBy = lds_get(img + 2*PL + ls); EypBx = lds_get(img + 3*PL + ls); }
+#endif
                     else       { Bz = gp_[cBz*f.ns]; Ez = gp_[cEz*f.ns]; ExmBy = gp_[cExmBy*f.ns]; EypBx = gp_[cEypBx*f.ns]; }
                     const double ss = sx[ix]*sy[iy];
                     const double dxs = dsx[ix]*sy[iy];
@@ -469,13 +476,24 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
                     sy_add = fma(ss, ty, fma(a5, dxs, a6*sdy));
                     sx_add = fma(ss, tx, fma(b5, dxs, b6*sdy));
                 }
+#ifdef HPS_DIAG_EXPL_NO_ATOMICS    // (diagnostic build: without the LDS atomics; results are wrong)
+                if (local) { diag_sink += sy_add + sx_add; }
+#else
                 if (local) { lds_add(acc + ls, sy_add); lds_add(acc + PL + ls, sx_add); }
+#endif
                 else       { atomic_add_f64(gp_ + cSy*f.ns, sy_add); atomic_add_f64(gp_ + cSx*f.ns, sx_add); }
             }
         }
     }
     if (n_fallback && nfb) atomicAdd(n_fallback, nfb);
+#ifdef HPS_DIAG_EXPL_NO_ATOMICS
+    if (diag_sink == 1.2345e-300 && n_fallback) atomicAdd(n_fallback, 1);
+#endif
     __syncthreads();
+#ifdef HPS_DIAG_EXPL_NO_FLUSH
+    if (acc[tid] == 1.2345e-300 && n_fallback) atomicAdd(n_fallback, 1);
+    return;
+#endif
     for (int s = tid; s < R*R; s += 256) {
         const int lj = s / R, li = s - lj*R;
         const int i = ox + li, j = oy + lj;
