@@ -324,7 +324,7 @@ def main():
         args.steps = nz                         # one whole box of the deck that is timed (config 5: all 2048 slices, the pulse included)
     if world > 1 and not args.inflight_ring:
         args.inflight = 1
-    if args.fuse:
+    if args.fuse and os.environ.get("BENCH_FUSE_INFLIGHT", "0") != "1":
         args.inflight = 1
     if args.config2 and os.environ.get("HPS_PC_SPECULATE", "1") == "0":
         args.inflight = 1                       # (host-controlled predictor-corrector loop: the host is held once per iteration, the slice
@@ -496,6 +496,9 @@ def main():
     if L > 1:
         from hipace_amd.pipeline import run_lanes
         lane_engines = [eng] + [api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period) for _ in range(L - 1)]
+        if args.fuse:
+            for e in lane_engines[1:]:
+                e.set_fusion(True)
         W = world * L
         lagL = 2                                                 # a stage trails the one ahead by the hand-off of two slices
         if args.steps < nz:

@@ -73,8 +73,8 @@ struct Engine {
     bool fold_tail = true;                     // the particles behind the tile-sorted body ride in the tile kernels' launches (HPS_FOLD_TAIL=0: off)
     TailWork fold_tail_of (const hps_plasma& p, const Tiling* T, long margin, long* covered) const;
     int species_deposit (const hps_plasma& p, Tiling* T, const int comp[6], double charge, double mass, int can_ionize, const BeamPairWork* beam = nullptr);
-    bool valid_by_w = false;                   // HPS_VALID_BY_W=1: the depositions take "weight != 0" for the valid bit of idcpu and do not read it (PartConsts::valid_by_w;
-                                               // 33.5 MB less per kernel at 1024^2 x 4 ppc -- measured: no time gained, profiles/r04a_ab_valid_by_w.txt)
+    bool valid_by_w = true;                    // HPS_VALID_BY_W=0: off.  The depositions take "weight != 0" for the valid bit of idcpu and do not read it (PartConsts::valid_by_w:
+                                               // 33.5 MB less per kernel at 1024^2 x 4 ppc -- no time gained with one stage on the GPU, +1 % with three in flight: r04g_ab_inflight_byte_cuts.txt)
     bool fold_hierarchy = true;                // the multigrid's coefficient hierarchy in the -grad Psi / Sx, Sy launch (HPS_FOLD_HIERARCHY=0: in mg_solve1_begin)
     bool fold_beam = true;                     // the static beam's two deposits of a slice as extra workgroups of the plasma's deposition (HPS_FOLD_BEAM=0: a launch of their own)
     int species_explicit (const hps_plasma& p, Tiling* T, const int cache[4], const int depos[2], double charge, double mass, int can_ionize);

@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <atomic>
+#include <algorithm>
 
 namespace hps {
 
@@ -274,7 +276,7 @@ void k_init_plasma (hps_plasma pl, long n, int nx, int ny, int ppcx, int ppcy, d
     pl.x[k] = x; pl.y[k] = y; pl.w[k] = fac > 0.0 ? weight*fac : 0.0;
     pl.ux[k] = 0.0; pl.uy[k] = 0.0; pl.psi[k] = 1.0;
     pl.x_prev[k] = x; pl.y_prev[k] = y;
-    pl.ux_half[k] = 0.0; pl.uy_half[k] = 0.0; pl.psi_half[k] = 1.0;
+    pl.ux_half[k] = 0.0; pl.uy_half[k] = 0.0; pl.psi_half[k] = fac > 0.0 ? 1.0 : 0.0;      // (0: not a particle, Tiling::valid_by_psi)
     // id = 1, cpu (level) = 0.  A species that can ionise carries its lattice index + 1 in the id bits: the key of its
     // random draws (ionization.hip); the reference only ever reads the sign of the id
     pl.idcpu[k] = (fac > 0.0 ? HPS_ID_VALID : 0ULL) | ((keyed ? (unsigned long long)(k + 1) : 1ULL) << 24);
@@ -468,6 +470,29 @@ int Engine::init_beam ()
     return HPS_OK;
 }
 
+// HPS_CU_MASKS="lo-hi[+lo-hi...],..." (diagnostic): the j-th engine created in this process runs its stream on the compute
+// units of entry j % n only (hipExtStreamCreateWithCUMask).  Bit i of a mask is compute unit i / 8 of XCD i % 8 on this GPU (the
+// driver deals the bits round the XCDs first), so ranges that are multiples of 8 wide take the same number of CUs from every XCD.
+static hipError_t create_engine_stream (hipStream_t* s)
+{
+    const char* v = std::getenv("HPS_CU_MASKS");
+    if (!v || !*v) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    static std::atomic<int> created{0};
+    std::vector<std::string> entries;
+    {   std::string cur; for (const char* p = v; ; ++p) { if (*p == ',' || !*p) { entries.push_back(cur); cur.clear(); if (!*p) break; } else cur += *p; } }
+    const std::string& e = entries[created++ % entries.size()];
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t pos = 0;
+    while (pos < e.size()) {
+        size_t end = e.find('+', pos); if (end == std::string::npos) end = e.size();
+        int lo = 0, hi = -1;
+        if (std::sscanf(e.substr(pos, end - pos).c_str(), "%d-%d", &lo, &hi) == 2)
+            for (int b = std::max(lo, 0); b <= std::min(hi, 255); ++b) mask[b >> 5] |= 1u << (b & 31);
+        pos = end + 1;
+    }
+    return hipExtStreamCreateWithCUMask(s, 8, mask);
+}
+
 int Engine::create (const hps_deck& deck, int device)
 {
     d = deck;
@@ -497,7 +522,7 @@ int Engine::create (const hps_deck& deck, int device)
     if (d.predcorr_max_iter > 0) pc_max_iter = d.predcorr_max_iter;
     if (d.predcorr_mix > 0.0) pc_mix = d.predcorr_mix;
     HPS_HIP_CHECK(hipSetDevice(device));
-    HPS_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HPS_HIP_CHECK(create_engine_stream(&st));
     if (const char* v = std::getenv("HPS_LASER_ASYNC")) laser_async = std::atoi(v) != 0;
     if (laser_async && d.laser_on && d.laser_solver >= 1 && d.dt != 0.0) {
         // below the engine's stream: its kernels fill what the slice leaves idle, they are not to win a CU from it
@@ -620,6 +645,8 @@ int Engine::setup_tiling ()
         return HPS_OK;
     };
     if (int e = tiling_create(d.nx, d.ny, tile_size, np_cap, &tiling)) return e;
+    {   const char* v = std::getenv("HPS_VALID_BY_PSI");       // the electrons' push without its idcpu read (tiling.h)
+        tiling->valid_by_psi = (v && std::atoi(v) != 0); }       // (measured: the push takes the same time with and without, off)
     if (int e = second(pl_alt, pl_real_alt, np_cap, !pc)) return e;
     pl_alt.n = np;
     if (ion.n > 0) {

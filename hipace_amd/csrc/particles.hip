@@ -47,6 +47,7 @@ void k_deposit_current (SlabView f, hps_plasma pl, DepComps cm, PartConsts k, in
         if (n_qsa) atomicAdd(n_qsa, 1);
         pl.w[ip] = 0.0;
         pl.idcpu[ip] = id & ~HPS_ID_VALID;
+        pl.psi_half[ip] = 0.0;      // (Tiling::valid_by_psi: the tile push of the engine's sheet reads validity from here)
         return;
     }
 
@@ -234,6 +235,7 @@ void k_advance_plasma (SlabView f, hps_plasma pl, int cPsi, int cEz, int cBx, in
         if (apply_particle_bc(k, xp, yp, ux, uy)) {
             pl.w[ip] = 0.0;
             pl.idcpu[ip] = id & ~HPS_ID_VALID;
+        pl.psi_half[ip] = 0.0;      // (Tiling::valid_by_psi: the tile push of the engine's sheet reads validity from here)
             return;
         }
         pl.x[ip] = xp;

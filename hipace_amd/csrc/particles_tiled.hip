@@ -253,6 +253,7 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             if (n_qsa) atomicAdd(n_qsa, 1);
             pl.w[ip] = 0.0;
             pl.idcpu[ip] = (VBW ? pl.idcpu[ip] : id) & ~HPS_ID_VALID;
+            pl.psi_half[ip] = 0.0;      // (Tiling::valid_by_psi)
             continue;
         }
         // per-component weights in DepComps order
@@ -543,7 +544,10 @@ template <class T> __device__ __forceinline__ void sto_nt (T* base, unsigned o, 
 #ifndef HPS_PUSH_PF_LASER
 #define HPS_PUSH_PF_LASER 1
 #endif
-template <int ORDER, int TS, bool LASER = false, bool IONIZE = false>
+// VBP: the engine's own electron sheet -- a particle is valid iff its psi_half is not 0 (Tiling::valid_by_psi: every path that
+// clears the valid bit of idcpu also zeroes psi_half, which only the push reads): idcpu is not read, 40 instead of 48 B in per
+// particle in the one particle kernel that is bound by its bytes.
+template <int ORDER, int TS, bool LASER = false, bool IONIZE = false, bool VBP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IONIZE ? HPS_PUSH_WAVES_ION : HPS_PUSH_WAVES)))
 void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
                       int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, int* n_fallback, IonArgs ia, const int* go, TailWork tw)
@@ -553,6 +557,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     // enqueued behind a multigrid solve whose norms the host has not seen yet: run only if that solve is over (*go == 1,
     // set by the solve's k_post_norms; else the host adds V-cycles and launches the push again).  The word is loaded
     // here and looked at behind the barrier that waits for the field image anyway.
+    static_assert(!(VBP && IONIZE), "the ADK draw is keyed by the id");
     const int go_now = go ? *go : 1;
     int charged = 0;          // IONIZE: does this thread hold an ion of level > 0 after the slice?
     extern __shared__ __attribute__((aligned(16))) double img[];     // [5][R*R]
@@ -575,8 +580,10 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     auto fetch = [&] (unsigned ip) {
         PIn q;
         const unsigned o = ip*8u;
-        q.id = ldo(pl.idcpu, o); q.xp = ldo(pl.x_prev, o); q.yp = ldo(pl.y_prev, o);
+        if constexpr (!VBP) q.id = ldo(pl.idcpu, o);
+        q.xp = ldo(pl.x_prev, o); q.yp = ldo(pl.y_prev, o);
         q.uxh = ldo_nt(pl.ux_half, o); q.uyh = ldo_nt(pl.uy_half, o); q.psih = ldo_nt(pl.psi_half, o);
+        if constexpr (VBP) q.id = (q.psih != 0.0) ? HPS_ID_VALID : 0ULL;
         return q;
     };
     // the thread's first particle is requested ahead of the field image: its six values arrive with the image's
@@ -721,7 +728,8 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             yp += dz*k.c_inv*(uy*pinv);
             if (apply_particle_bc(k, xp, yp, ux, uy)) {
                 sto(pl.w, o8, 0.0);
-                sto(pl.idcpu, o8, (uint64_t)(id & ~HPS_ID_VALID));
+                sto(pl.idcpu, o8, (uint64_t)((VBP ? ldo(pl.idcpu, o8) : id) & ~HPS_ID_VALID));
+                sto(pl.psi_half, o8, 0.0);      // (Tiling::valid_by_psi)
                 dead = true;
                 break;
             }
@@ -854,6 +862,7 @@ void k_advance_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__
             if (apply_particle_bc(k, xp, yp, ux, uy)) {
                 pl.w[ip] = 0.0;
                 pl.idcpu[ip] = id & ~HPS_ID_VALID;
+                pl.psi_half[ip] = 0.0;
                 dead = true;
                 break;
             }
@@ -877,6 +886,7 @@ void k_advance_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__
             if (n_qsa) atomicAdd(n_qsa, 1);
             pl.w[ip] = 0.0;
             pl.idcpu[ip] = id & ~HPS_ID_VALID;
+            pl.psi_half[ip] = 0.0;
             continue;
         }
         double wx[ORDER + 1], wy[ORDER + 1];
@@ -1034,11 +1044,14 @@ int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_
     const size_t lds = (size_t)(aabs_comp >= 0 ? 6 : 5)*R*R*sizeof(double);
     SlabView f(slab);
     const IonArgs ia = ion ? *ion : IonArgs{};
-#define HPS_ADV(O, S, L, I) { if (int e = set_lds(k_advance_tiled<O, S, L, I>, lds)) return e; \
-        hipLaunchKernelGGL((k_advance_tiled<O, S, L, I>), dim3(T->g.ntiles + tw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
+    // (the variant without the idcpu read exists for order 2 on 16 x 16 tiles, as the depositions' <.., VBW>)
+    const bool vbp = T->valid_by_psi && !ion && !can_ionize && order == 2 && T->g.ts == 16;
+#define HPS_ADV(O, S, L, I, V) { if (int e = set_lds(k_advance_tiled<O, S, L, I, V>, lds)) return e; \
+        hipLaunchKernelGGL((k_advance_tiled<O, S, L, I, V>), dim3(T->g.ntiles + tw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
                            comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback, ia, go, tw); }
-#define CALL(O, S) { if (ion) { if (aabs_comp >= 0) HPS_ADV(O, S, true, true) else HPS_ADV(O, S, false, true) } \
-                     else     { if (aabs_comp >= 0) HPS_ADV(O, S, true, false) else HPS_ADV(O, S, false, false) } }
+#define CALL(O, S) { if (ion) { if (aabs_comp >= 0) HPS_ADV(O, S, true, true, false) else HPS_ADV(O, S, false, true, false) } \
+                     else if (vbp && O == 2 && S == 16) { if (aabs_comp >= 0) HPS_ADV(2, 16, true, false, true) else HPS_ADV(2, 16, false, false, true) } \
+                     else     { if (aabs_comp >= 0) HPS_ADV(O, S, true, false, false) else HPS_ADV(O, S, false, false, false) } }
     HPS_DISPATCH_ORDER_TS(order, T->g.ts, CALL)
 #undef CALL
 #undef HPS_ADV

@@ -1242,7 +1242,7 @@ struct Poisson {
     dst_kernel_t kx_src = nullptr;      // the x pass with its rows formed from other planes (sym kernels only)
     dst_kernel_t ky2 = nullptr;         // both y passes (transform, inverse eigenvalues, transform) in one launch (sym kernels; HPS_POISSON_Y2=0: off)
     dst_cols_kernel_t kcols = nullptr; size_t lds_cols = 0;     // y direction on column blocks (symmetric factorisations)
-    // blocked intermediate planes (HPS_POISSON_BLOCKED=1; measured slower than the transposes): three launches per solve
+    // blocked intermediate planes (HPS_POISSON_BLOCKED, default on; 0: row-major planes and two transposes): three launches per solve
     dst_kernel_t kb_first = nullptr, kb_first_src = nullptr, kb_twice = nullptr, kb_last = nullptr;
     long blk_plane = 0;                 // doubles per blocked plane: ny rounded up to whole row blocks, times nx
     bool blocked () const { return kb_first != nullptr; }
@@ -1380,10 +1380,12 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
         if (P->ky2 && P->lds_y > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->ky2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_y));
         size_t plane_doubles = (size_t)nx*ny;
         {   const char* v = getenv("HPS_POISSON_BLOCKED");
-            // Measured (profiles/r04b_poisson_blocked_vs_transposes.txt): the two transposes cost 18.4 us per slice, the three
-            // passes on blocked planes 23.5 us more than on row-major ones (the y pass 45.9 against 32.1 us: with B = 6 its
-            // 288-byte runs straddle 128-byte lines that other workgroups -- on other XCDs -- complete).  Opt-in.
-            const bool want = (v && atoi(v) != 0);
+            // Measured (profiles/r04b_poisson_blocked_vs_transposes.txt, r04g_ab_inflight_byte_cuts.txt): with ONE stage on the GPU the
+            // two transposes cost 18.4 us per slice and the three passes on blocked planes 23.5 us more than on row-major ones at
+            // 1024^2 (the y pass 45.9 against 32.1 us: with B = 6 its 288-byte runs straddle 128-byte lines that other workgroups
+            // -- on other XCDs -- complete): 0.3 % slower.  With three stages in flight -- where the GPU's bandwidth is what is
+            // shared -- the 100 MB less per slice are +2 % (512^2: +3 % with one stage, +6 % with three).  On by default; 0: off.
+            const bool want = !(v && atoi(v) == 0);
             if (want && ix->sym && iy->sym && ix->T == iy->T && P->ky2 && !P->kcols && !P->mtab_x) {
                 const int B = 2*ix->T;
                 P->kb_first = ix->b_first; P->kb_first_src = ix->b_first_src; P->kb_twice = iy->b_twice; P->kb_last = ix->b_last;

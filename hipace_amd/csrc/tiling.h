@@ -18,6 +18,10 @@ struct Tiling {
     unsigned int *keys_a = nullptr, *keys_b = nullptr, *idx_a = nullptr, *idx_b = nullptr;
     void* temp = nullptr; size_t temp_bytes = 0; int key_bits = 0, key2_bits = 0;
     int* cell_first = nullptr;                    // [ntiles*ts*ts + 2] run starts of the cell keys
+    // the sheet is one whose every invalidation also zeroes psi_half (the engine's own electron sheet: k_init_plasma, the QSA drop of
+    // the depositions, the absorbing boundary of the pushes): the tile push then takes "psi_half != 0" for the valid bit and does
+    // not read idcpu (HPS_VALID_BY_PSI=0: off).  Never set for a caller's sheet (hps_tiling_create).
+    bool valid_by_psi = false;
     ~Tiling ();
 };
 

@@ -1579,7 +1579,7 @@ def _run_with_env(api, var, value, deck, n_steps, tile_size=16):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["gated_push", "lazy_shift", "fuse_sources", "aux_stream", "fold_beam", "fold_hierarchy", "mg_post_fold", "laser_stream_fft", "laser_stream_mg", "ion_tile_skip", "fold_tail", "gated_ion_push", "poisson_blocked", "pc_speculate", "valid_by_w"])
+@pytest.mark.parametrize("case", ["gated_push", "lazy_shift", "fuse_sources", "aux_stream", "fold_beam", "fold_hierarchy", "mg_post_fold", "laser_stream_fft", "laser_stream_mg", "ion_tile_skip", "fold_tail", "gated_ion_push", "poisson_blocked", "pc_speculate", "valid_by_w", "valid_by_psi"])
 def test_schedules_do_not_change_results(api, case):
     """The engine's scheduling choices -- the push enqueued behind the multigrid's V-cycles and gated on its stopping rule,
     the envelope solver on a stream of its own, the tiles of atoms that cannot ionise skipped before their image is loaded --
@@ -1601,6 +1601,8 @@ def test_schedules_do_not_change_results(api, case):
         var, deck, steps = "HPS_AUX_STREAM", decks.blowout_wake(), 2
     elif case == "valid_by_w":       # the depositions read "weight != 0" instead of the valid bit of idcpu
         var, deck, steps = "HPS_VALID_BY_W", decks.blowout_wake(), 2
+    elif case == "valid_by_psi":     # the push reads "psi_half != 0" instead of the valid bit of idcpu (absorbing walls: particles do die)
+        var, deck, steps = "HPS_VALID_BY_PSI", dict(decks.blowout_wake(), bc=2), 2
     elif case == "poisson_blocked":  # the Poisson solves' intermediate planes in blocks of 6 rows: three launches, no transposes
         var, deck, steps = "HPS_POISSON_BLOCKED", decks.blowout_wake(), 1
     elif case == "pc_speculate":     # predictor-corrector loop: iterations enqueued ahead, every kernel gated on the loop's condition
