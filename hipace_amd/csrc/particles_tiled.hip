@@ -535,6 +535,10 @@ template <class T> __device__ __forceinline__ void sto_nt (T* base, unsigned o, 
 // so it is taken here, between the gather and the push (the reference ionises, then pushes: Hipace.cpp:693-701): the ion's
 // level goes up, its electron is appended to the product species, and the push runs with the new charge.  A neutral
 // atom at rest is not pushed at all (zero charge: the push would leave every quantity as it is).
+// the six sub-steps of a particle through taylor2_substep_pre (particle_math.h; 0: taylor2_substep, the dual-number form)
+#ifndef HPS_PUSH_ALGEBRA
+#define HPS_PUSH_ALGEBRA 1
+#endif
 #ifndef HPS_PUSH_WAVES
 #define HPS_PUSH_WAVES 3
 #endif
@@ -716,6 +720,12 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             }
             const double dz = k.dz, sdz = dz*0.25;
             double ux = isc == 0 ? cur.uxh : ldo(pl.ux_half, o8), uy = isc == 0 ? cur.uyh : ldo(pl.uy_half, o8), psi = isc == 0 ? cur.psih : ldo(pl.psi_half, o8);
+#if HPS_PUSH_ALGEBRA
+            const PushForce PFc = push_force(F, Lf, k.c_inv, qmc);
+            const double h2 = 0.5*sdz*sdz;
+#pragma unroll 1
+            for (int s = 0; s < 4; ++s) taylor2_substep_pre<LASER>(ux, uy, psi, PFc, sdz, h2);
+#else
             if constexpr (LASER) {
 #pragma unroll 1
                 for (int s = 0; s < 4; ++s) taylor2_substep_laser(ux, uy, psi, F, Lf, k.c_inv, qmc, sdz);
@@ -723,6 +733,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
 #pragma unroll 1
                 for (int s = 0; s < 4; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
             }
+#endif
             const double pinv = fast_rcp(psi);
             xp += dz*k.c_inv*(ux*pinv);
             yp += dz*k.c_inv*(uy*pinv);
@@ -739,6 +750,10 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
                 if (pl.x_prev != pl.x) sto(pl.x_prev, o8, xp);      // (aliased by the engine: already stored)
                 if (pl.y_prev != pl.y) sto(pl.y_prev, o8, yp);
             }
+#if HPS_PUSH_ALGEBRA
+#pragma unroll 1
+            for (int s = 0; s < 2; ++s) taylor2_substep_pre<LASER>(ux, uy, psi, PFc, sdz, h2);
+#else
             if constexpr (LASER) {
 #pragma unroll 1
                 for (int s = 0; s < 2; ++s) taylor2_substep_laser(ux, uy, psi, F, Lf, k.c_inv, qmc, sdz);
@@ -746,6 +761,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
 #pragma unroll 1
                 for (int s = 0; s < 2; ++s) taylor2_substep(ux, uy, psi, F, k.c_inv, qmc, sdz);
             }
+#endif
             sto(pl.ux, o8, ux); sto(pl.uy, o8, uy); sto(pl.psi, o8, psi);
         }
     }
