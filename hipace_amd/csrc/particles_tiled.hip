@@ -11,6 +11,7 @@
 // path of the same arithmetic, so results never depend on how stale the sort is.
 // Arithmetic identical to particles.hip (reference file:line cited there).
 #include "common.h"
+#include <type_traits>
 #include "particle_math.h"
 #include "tiling.h"
 #include "beam_deposit.h"
@@ -117,6 +118,10 @@ __device__ __forceinline__ void load_region (double* img, const SlabView& f, con
 // consecutive cells (four tile rows at the sort's (rank, cell) order): with pitch 20 the four rows fall on the 32 eight-byte
 // bank slots at offsets 0, 20, 8, 28 -- three rows deep on some slots, one on others; with pitch 48 (HPS_DEP_PAD=28) rows
 // alternate between the two halves of the banks.
+// the explicit deposition in two passes (image particles straight-line, slab particles behind them; 0: one loop with the choice at every stencil cell)
+#ifndef HPS_EXPL_TWO_PASS
+#define HPS_EXPL_TWO_PASS 1
+#endif
 #ifndef HPS_DEP_PAD
 #define HPS_DEP_PAD 0
 #endif
@@ -379,6 +384,109 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
     }
     __syncthreads();
 
+#if HPS_EXPL_TWO_PASS
+    // Two passes over the workgroup's particles.  The first deposits every particle whose stencil lies inside the tile's image --
+    // all but one in ten thousand -- through LDS, as straight-line code: the choice "image or slab" is made once per particle, not
+    // at each of its 21 stencil cells (84 exec-mask branches per particle before; hoisting them was tried in round 2 and spilled,
+    // because the scheduler then pulls all 36 field reads ahead -- here a compiler barrier per stencil row keeps one row of reads
+    // in flight, as in the push).  The second pass, entered only by a workgroup that met such a particle (or a tail workgroup),
+    // fetches the sheet again and deposits the others through the slab.  Per row the products with sy / dsy are formed once:
+    //   Sy += sx (sy ty + a6 dsy) + (a5 sy) dsx     (14 instead of 17 fp64 operations per inner cell, 2 instead of 3 on the ring)
+    int nfb = 0;
+    bool slow = false;
+    auto one = [&] (const Rec& cur, auto LC) __attribute__((always_inline)) -> bool {
+        constexpr bool LOCAL = decltype(LC)::value;
+        if (!(cur.id & HPS_ID_VALID)) return true;
+        if (k.can_ionize && cur.ion == 0) return true;      // a neutral atom deposits nothing (every term carries its level)
+        const double xmid = (cur.x - k.xoff)*k.dx_inv;
+        const double ymid = (cur.y - k.yoff)*k.dy_inv;
+        double sx[NS], dsx[NS], sy[NS], dsy[NS];
+        int i0, j0;
+        if constexpr (DT == 2) { i0 = centred_weights<ORDER>(xmid, sx, dsx); j0 = centred_weights<ORDER>(ymid, sy, dsy); }
+        else                   { i0 = nodal_weights<ORDER>(xmid, sx, dsx);   j0 = nodal_weights<ORDER>(ymid, sy, dsy); }
+        const int li = i0 - ox, lj = j0 - oy;
+        const bool local = LASER ? (li >= 1 && li + NS + 1 <= R && lj >= 1 && lj + NS + 1 <= R)
+                                 : (li >= 0 && li + NS <= R && lj >= 0 && lj + NS <= R);
+        if (local != LOCAL) return false;
+        const double psi_inv = fast_rcp(cur.psi);
+        const double vx = cur.ux*psi_inv*k.c_inv;
+        const double vy = cur.uy*psi_inv*k.c_inv;
+        double q_invvol_mu0 = k.a, q_mass = k.b;
+        if (k.can_ionize) { const double il = (double)cur.ion; q_invvol_mu0 *= il; q_mass *= il; }
+        const double cdm = q_invvol_mu0*cur.w;
+        double gp;
+        if constexpr (LASER) {
+            double lx[ORDER + 1], ly[ORDER + 1];
+            const int ai = shape_weights<ORDER>(xmid, lx), aj = shape_weights<ORDER>(ymid, ly);
+            const double A = (LOCAL ? laser_gather_lds<ORDER>(aimg, RP, ai - ox, aj - oy, lx, ly)
+                                    : laser_gather<ORDER>(f, k.aabs, xmid, ymid))*k.laser_fac*q_mass*q_mass;
+            gp = 0.5*((1.0 + 0.5*A)*psi_inv*psi_inv + vx*vx + vy*vy + 1.0);
+        } else {
+            gp = 0.5*(psi_inv*psi_inv + vx*vx + vy*vy + 1.0);
+        }
+        const double qp = q_mass*psi_inv;
+        const double vxvy = vx*vy, gy = gp - vy*vy, gx = gp - vx*vx;
+        const double cq = cdm*qp, cqc = cq*k.c_inv, cc = cdm*k.c;
+        const double a1 = cq*vx, a2 = -cqc*vy, a3 = cqc*vxvy, a4 = -cqc*gy, a5 = cc*vxvy, a6 = -cc*(gy - 1.0);
+        const double b1 = cq*vy, b2 = cqc*vx, b3 = cqc*gx, b4 = -cqc*vxvy, b5 = cc*(gx - 1.0), b6 = -cc*vxvy;
+#pragma unroll
+        for (int m = 0; m < NS; ++m) { dsx[m] *= k.dx_inv; dsy[m] *= k.dy_inv; }
+#pragma unroll
+        for (int iy = 0; iy < NS; ++iy) {
+            if constexpr (LOCAL) asm volatile("" ::: "memory");      // one stencil row of LDS reads in flight at a time
+            const bool yedge = (DT == 2) && (iy == 0 || iy == NS - 1);
+            const double a5s = a5*sy[iy], b5s = b5*sy[iy], ay = a6*dsy[iy], by = b6*dsy[iy];
+#pragma unroll
+            for (int ix = 0; ix < NS; ++ix) {
+                const bool xedge = (DT == 2) && (ix == 0 || ix == NS - 1);
+                if (xedge && yedge) continue;
+                double* gp_ = nullptr; int ls = 0;
+                if constexpr (LOCAL) ls = (lj + iy)*RP + li + ix;
+                else                 gp_ = f.p + f.off(i0 + ix, j0 + iy);
+                double sy_add, sx_add;
+                if (xedge)      { sy_add = a5s*dsx[ix]; sx_add = b5s*dsx[ix]; }      // sx = 0: only dsx*sy survives
+                else if (yedge) { sy_add = ay*sx[ix];   sx_add = by*sx[ix]; }        // sy = 0: only sx*dsy
+                else {
+                    double Bz, Ez, ExmBy, EypBx;
+                    if constexpr (LOCAL) { Bz = lds_get(img + ls); Ez = lds_get(img + PL + ls); ExmBy = lds_get(img + 2*PL + ls); EypBx = lds_get(img + 3*PL + ls); }
+                    else                 { Bz = gp_[cBz*f.ns]; Ez = gp_[cEz*f.ns]; ExmBy = gp_[cExmBy*f.ns]; EypBx = gp_[cEypBx*f.ns]; }
+                    double ty = fma(a1, Bz, fma(a2, Ez, fma(a3, ExmBy, a4*EypBx)));
+                    double tx = fma(b1, Bz, fma(b2, Ez, fma(b3, ExmBy, b4*EypBx)));
+                    if constexpr (LASER) {
+                        // gradient of |a|^2 at this stencil cell (ExplicitDeposition.cpp:211-226)
+                        if (sx[ix]*sy[iy] != 0.0) {
+                            const double lf = 0.25*cq*qp*k.laser_fac*k.c;
+                            double ady, adx;
+                            if constexpr (LOCAL) {
+                                const double* a = aimg + ls;
+                                ady = lds_get(a + RP) - lds_get(a - RP); adx = lds_get(a + 1) - lds_get(a - 1);
+                            } else {
+                                const double* a = f.p + k.aabs*f.ns + f.off(i0 + ix, j0 + iy);
+                                ady = a[f.js] - a[-f.js]; adx = a[1] - a[-1];
+                            }
+                            ty = fma(lf*0.5*k.dy_inv, ady, ty);
+                            tx = fma(-lf*0.5*k.dx_inv, adx, tx);
+                        }
+                    }
+                    sy_add = fma(sx[ix], fma(sy[iy], ty, ay), a5s*dsx[ix]);
+                    sx_add = fma(sx[ix], fma(sy[iy], tx, by), b5s*dsx[ix]);
+                }
+                if constexpr (LOCAL) { lds_add(acc + ls, sy_add); lds_add(acc + PL + ls, sx_add); }
+                else                 { atomic_add_f64(gp_ + cSy*f.ns, sy_add); atomic_add_f64(gp_ + cSx*f.ns, sx_add); }
+            }
+        }
+        return true;
+    };
+    for (int ip = ipb; ip < pend; ip += 256) {
+        const Rec cur = nxt;
+        if (ip + 256 < pend) nxt = fetch(ip + 256);
+        if (!one(cur, std::true_type{})) { slow = true; nfb += !tail; }
+    }
+    if (slow) {
+#pragma unroll 1
+        for (int ip = ipb; ip < pend; ip += 256) { const Rec cur = fetch(ip); (void)one(cur, std::false_type{}); }
+    }
+#else
     int nfb = 0;
 #ifdef HPS_DIAG_EXPL_NO_ATOMICS
     double diag_sink = 0.0;
@@ -486,6 +594,7 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
             }
         }
     }
+#endif
     if (n_fallback && nfb) atomicAdd(n_fallback, nfb);
 #ifdef HPS_DIAG_EXPL_NO_ATOMICS
     if (diag_sink == 1.2345e-300 && n_fallback) atomicAdd(n_fallback, 1);
@@ -538,6 +647,9 @@ template <class T> __device__ __forceinline__ void sto_nt (T* base, unsigned o, 
 // the six sub-steps of a particle through taylor2_substep_pre (particle_math.h; 0: taylor2_substep, the dual-number form)
 #ifndef HPS_PUSH_ALGEBRA
 #define HPS_PUSH_ALGEBRA 1
+#endif
+#ifndef HPS_PUSH_SPLIT_GATHER
+#define HPS_PUSH_SPLIT_GATHER 1
 #endif
 #ifndef HPS_PUSH_WAVES
 #define HPS_PUSH_WAVES 3
@@ -644,6 +756,47 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
                 // of s[0], s[NS-1] is always exactly 0 -- was measured: 52 instead of 80 LDS reads per particle, but the
                 // lane-dependent base address costs more than the reads save: 171 against 166 us)
                 const double* b = img + lj*R + li;
+#if HPS_PUSH_SPLIT_GATHER
+                // Psi needs all NS x NS cells (its derivative weights are full); Ez, Bx, By, Bz only the (NS-1) x (NS-1) cells on
+                // which the plain weights live: one of s[0], s[NS-1] is exactly 0, which one depends on the particle's half of
+                // its cell -- 16 + 4 x 9 = 52 LDS reads per particle instead of 80 (order 2), 416 instead of 640 B through the LDS
+                // pipe, 88 instead of 120 FMAs; the skipped terms are exact zeros.  (Round 3 measured this slower, 171 against
+                // 166 us, when the kernel still waited for three dependent trips to memory per particle.)
+#pragma unroll
+                for (int iy = 0; iy < NS; ++iy) {
+                    double rp = 0.0, rd = 0.0;
+#pragma unroll
+                    for (int ix = 0; ix < NS; ++ix) {
+                        const double psi_c = lds_get(b + iy*R + ix);
+                        rp = fma(sx[ix], psi_c, rp);
+                        rd = fma(dsx[ix], psi_c, rd);
+                    }
+                    F.ExmBy = fma(sy[iy], rd, F.ExmBy);
+                    F.EypBx = fma(dsy[iy], rp, F.EypBx);
+                }
+                const bool xhi = !(sx[NS - 1] == 0.0), yhi = !(sy[NS - 1] == 0.0);
+                double px[NS - 1], py[NS - 1];
+#pragma unroll
+                for (int m = 0; m < NS - 1; ++m) { px[m] = xhi ? sx[m + 1] : sx[m]; py[m] = yhi ? sy[m + 1] : sy[m]; }
+                const double* bq = b + R*R + (yhi ? R : 0) + (xhi ? 1 : 0);
+#pragma unroll
+                for (int ky = 0; ky < NS - 1; ++ky) {
+                    asm volatile("" ::: "memory");
+                    double rez = 0.0, rbx = 0.0, rby = 0.0, rbz = 0.0;
+#pragma unroll
+                    for (int kx = 0; kx < NS - 1; ++kx) {
+                        const int ls = ky*R + kx;
+                        rez = fma(px[kx], lds_get(bq + ls), rez);
+                        rbx = fma(px[kx], lds_get(bq + R*R + ls), rbx);
+                        rby = fma(px[kx], lds_get(bq + 2*R*R + ls), rby);
+                        rbz = fma(px[kx], lds_get(bq + 3*R*R + ls), rbz);
+                    }
+                    F.Ez  = fma(py[ky], rez, F.Ez);
+                    F.Bxc = fma(py[ky], rbx, F.Bxc);
+                    F.Byc = fma(py[ky], rby, F.Byc);
+                    F.Bz  = fma(py[ky], rbz, F.Bz);
+                }
+#else
 #ifndef HPS_PUSH_ROLLED_ROWS
 #pragma unroll
 #else
@@ -672,6 +825,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
                     F.Byc = fma(sy[iy], rby, F.Byc);
                     F.Bz  = fma(sy[iy], rbz, F.Bz);
                 }
+#endif
                 F.ExmBy *= k.dx_inv;
                 F.EypBx *= k.dy_inv;
             } else {
