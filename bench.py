@@ -54,7 +54,7 @@ if ROOT not in sys.path:
 CPU_THREADS_DEFAULT = 16  # OpenMP leg of the CPU baseline: fastest on the 256-core host of the GPU box, 9.5x the serial leg; 64 threads
                           # are already slower and 256 slower than one (profiles/r02b_cpu_threads.json)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_SUMMARY = "r04f_pmc_fetch_write_per_kernel.csv"      # profiles/: rocprofv3 --pmc summary of the shipped kernels
+PMC_SUMMARY = "r04g_pmc_fetch_write_per_kernel.csv"      # profiles/: rocprofv3 --pmc summary of the shipped kernels
 START_SLICE_DEFAULT = 700  # short runs start here (from the head); see profiles/r02a_slice_cost_profile.json
 
 
@@ -635,6 +635,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_deposit_tiled<2,%d>" % args.tile if args.tile else "k_deposit_current<2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": kernel_ms,
+                         # SURVEY 8(d)'s figure reads idcpu (56 B per particle); this build's kernel takes "weight != 0" for the valid
+                         # bit (HPS_VALID_BY_W, default on) and reads 48: the same kernel time over the bytes it has to move itself
+                         "bytes_this_build_has_to_move": (ab[dom] - 8 * args.ppc * args.ppc * args.n * args.n) if (headline and os.environ.get("HPS_VALID_BY_W", "1") != "0") else ab[dom],
+                         "frac_of_bytes_this_build_has_to_move": ((ab[dom] - 8 * args.ppc * args.ppc * args.n * args.n) if (headline and os.environ.get("HPS_VALID_BY_W", "1") != "0") else ab[dom])
+                                                                 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else 0.0,
                          "event_interval_ms": raw, "empty_event_interval_ms": overhead,
                          "duration_source": f"HIP events on the engine's stream around the kernel, {nprof} launches of the timed region, "
                                             "minus the interval between two back-to-back event records measured on the same slices"},
