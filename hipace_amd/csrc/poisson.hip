@@ -597,8 +597,31 @@ void k_dst_rows (DstArgs a)
 constexpr int DSTS_T = HPS_DSTS_T;
 constexpr int DSTS_NT = HPS_DSTS_NT;        // threads per workgroup of the symmetric kernel
 
-template <int M, int STRIDE, int KSTRIDE, int ITEMS_PER_T, int ITEM_STRIDE, bool TWIDDLE, int T, int NWAVES>
-__device__ __forceinline__ void sym_stage (lds_double* cbuf, const double2* __restrict__ cs, const double2* __restrict__ tw, int wave, int lane)
+#ifndef HPS_SYM_LEFTOVER
+#define HPS_SYM_LEFTOVER 1
+#endif
+constexpr int cmin_i (int a, int b) { return a < b ? a : b; }
+
+// does sym_stage<M, .., ITEMS_PER_T, .., T, NWAVES> take the LEFTOVER scheme (below)?  Its caller then keeps the stage's table in LDS.
+template <int M, int ITEMS_PER_T, int T, int NWAVES>
+constexpr bool sym_stage_leftover ()
+{
+    constexpr int H = (M - 1)/2, ITEMS = T*ITEMS_PER_T, NW = (ITEMS + 63)/64;
+    constexpr int NG0 = (NWAVES/NW) > 0 ? (NWAVES/NW) : 1, NG = NG0 > H ? H : NG0, KB = (H + NG - 1)/NG;
+    constexpr int FULL = ITEMS/64, REM = ITEMS%64;
+    constexpr int NGX0 = (FULL >= 1 && REM > 0) ? cmin_i(cmin_i(64/REM, (NWAVES - 1)/FULL), H) : 0;
+    constexpr int KBX = NGX0 > 0 ? (H + NGX0 - 1)/NGX0 : 1, NGX = (H + KBX - 1)/KBX, NGU = (H + KB - 1)/KB;
+    // Measured (MI355X, profiles/r04g_ab_poisson_leftover.txt): the 19-point stage of 512^2 (81 items, H = 9: 4 wave-tasks of blocks
+    // of 3 instead of 8) -7.7 us per slice (Poisson 64.6 -> 56.9 us, 3331 -> 3407 slices/s); the 41-point stage of 1024^2 (75 items,
+    // H = 20: 6 wave-tasks of blocks of 4 instead of 8 of 5) +4.7 us on row-major planes and +37 us on blocked ones -- the second
+    // loop body costs the kernel 27 VGPRs (76 -> 103; the two-transform kernel 115 -> 132: one workgroup per CU).  Small factors only.
+    return HPS_SYM_LEFTOVER && M <= 27 && NGX0 >= 2 && (FULL*NGX + 1)*(6 + 4*KBX) < NW*NGU*(6 + 4*KB);
+}
+
+// ltab: the stage's (cos, sin) table in LDS ([H][H] complex) for the wave of the remaining items, or null: plain scheme only
+template <int M, int STRIDE, int KSTRIDE, int ITEMS_PER_T, int ITEM_STRIDE, bool TWIDDLE, int T, int NWAVES, bool LEFTOK = false>
+__device__ __forceinline__ void sym_stage (lds_double* cbuf, const double2* __restrict__ cs, const double2* __restrict__ tw, int wave, int lane,
+                                           const lds_double* ltab = nullptr)
 {
     // one item = one DFT of size M over elements base + n*STRIDE; results go to base + k*KSTRIDE
     constexpr int H = (M - 1)/2;
@@ -609,33 +632,68 @@ __device__ __forceinline__ void sym_stage (lds_double* cbuf, const double2* __re
     constexpr int KB = (H + NG - 1)/NG;
     constexpr int NT = M*ITEMS_PER_T;                 // complex elements per transform
     static_assert(NW <= NWAVES, "too many items for one workgroup");
-    const int g = wave / NW;
-    const int item = (wave % NW)*64 + lane;
-    const bool active = (g < NG) && (item < ITEMS);
+    // Who does what.  Plain scheme: NW waves cover the items once, NG groups of such waves share the outputs k = 1..H in blocks
+    // of KB (a wave's block is uniform: its table rows come through the scalar cache).  When the items do not fill their last
+    // wave -- the 41-point stage at 1024^2 has 3 x 25 = 75: the second wave of every group works with 11 of its 64 lanes --
+    // the LEFTOVER scheme gives every full wave of items one k block and packs the remaining items of ALL k blocks into one
+    // more wave (lane -> (item, block); that wave reads its table entries per lane, from a copy of the table in LDS -- per-lane
+    // global loads were a chain of 20 dependent trips to the L2: the stage took 34 us longer): 75 items, H = 20:
+    // 5 waves with blocks of 4 + 1 wave instead of 8 waves with blocks of 5 -- 6 x (6 + 16) instead of 8 x (6 + 20) instructions
+    // per term of the sum.  Taken where it is less work.
+    constexpr int FULL = ITEMS/64, REM = ITEMS%64;
+    constexpr int NGX0 = (FULL >= 1 && REM > 0) ? cmin_i(cmin_i(64/REM, (NWAVES - 1)/FULL), H) : 0;
+    constexpr int KBX = NGX0 > 0 ? (H + NGX0 - 1)/NGX0 : 1;
+    constexpr int NGX = (H + KBX - 1)/KBX;            // blocks of KBX that cover 1..H
+    constexpr int NGU = (H + KB - 1)/KB;              // (plain scheme: groups that have a block at all)
+    constexpr bool LEFT = LEFTOK && sym_stage_leftover<M, ITEMS_PER_T, T, NWAVES>();
+    constexpr int KBE = LEFT ? KBX : KB;
+    const bool lw = LEFT && (wave == FULL*NGX);       // the wave of the remaining items (wave-uniform)
+    const int gs = LEFT ? wave / (FULL > 0 ? FULL : 1) : wave / NW;      // this wave's k block where it is uniform
+    int g = gs, item = LEFT ? (wave - gs*FULL)*64 + lane : (wave % NW)*64 + lane;
+    bool active = LEFT ? (wave < FULL*NGX) : ((gs < NG) && (item < ITEMS));
+    if (lw) { g = lane / (REM > 0 ? REM : 1); item = 64*FULL + (lane - g*REM); active = lane < REM*NGX; }
     const int t = item / ITEMS_PER_T, r = item - t*ITEMS_PER_T;
     const int base = t*NT + r*ITEM_STRIDE;
-    const int k0 = 1 + g*KB;                          // first k of this group's block
-    double pr[KB], pim[KB], qr[KB], qi[KB];
+    const int k0 = 1 + g*KBE;                         // first k of this lane's block
+    double pr[KBE], pim[KBE], qr[KBE], qi[KBE];
 #pragma unroll
-    for (int kk = 0; kk < KB; ++kk) pr[kk] = pim[kk] = qr[kk] = qi[kk] = 0.0;
+    for (int kk = 0; kk < KBE; ++kk) pr[kk] = pim[kk] = qr[kk] = qi[kk] = 0.0;
     double2 x0 = make_double2(0.0, 0.0), ssum = make_double2(0.0, 0.0);
     if (active) {
         x0 = ldc(cbuf, base);
-        // (requesting step n+1's data pair and table row ahead of step n's FMAs by hand was measured slower)
+        if (!lw) {
+            const int k0s = 1 + gs*KBE;
+            // (requesting step n+1's data pair and table row ahead of step n's FMAs by hand was measured slower)
 #pragma unroll HPS_SYM_UNROLL
-        for (int n = 1; n <= H; ++n) {
-            const double2 xa = ldc(cbuf, base + n*STRIDE), xb = ldc(cbuf, base + (M - n)*STRIDE);
-            const double sr = xa.x + xb.x, si = xa.y + xb.y, dr = xa.x - xb.x, di = xa.y - xb.y;
-            ssum.x += sr; ssum.y += si;
-            // wave-uniform address: the table is read through the scalar cache, not the LDS pipe
-            // (through the constant address space: the load stays a scalar one whatever else the kernel does ahead of it --
-            //  a harmless edit at the kernel's head once turned these into vector loads: 74 -> 108 VGPRs, 150 -> 185 us)
-            typedef const __attribute__((address_space(4))) double cdouble;
-            cdouble* row = (cdouble*)(cs + ((n - 1)*H + (k0 - 1)));
+            for (int n = 1; n <= H; ++n) {
+                const double2 xa = ldc(cbuf, base + n*STRIDE), xb = ldc(cbuf, base + (M - n)*STRIDE);
+                const double sr = xa.x + xb.x, si = xa.y + xb.y, dr = xa.x - xb.x, di = xa.y - xb.y;
+                ssum.x += sr; ssum.y += si;
+                // wave-uniform address: the table is read through the scalar cache, not the LDS pipe
+                // (through the constant address space: the load stays a scalar one whatever else the kernel does ahead of it --
+                //  a harmless edit at the kernel's head once turned these into vector loads: 74 -> 108 VGPRs, 150 -> 185 us)
+                typedef const __attribute__((address_space(4))) double cdouble;
+                cdouble* row = (cdouble*)(cs + ((n - 1)*H + (k0s - 1)));
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) {
-                if (k0 + kk <= H) {
-                    const double2 c = make_double2(row[2*kk], row[2*kk + 1]);            // (cos, sin)(2 pi n k / M)
+                for (int kk = 0; kk < KBE; ++kk) {
+                    if (k0s + kk <= H) {
+                        const double2 c = make_double2(row[2*kk], row[2*kk + 1]);            // (cos, sin)(2 pi n k / M)
+                        pr[kk] = fma(sr, c.x, pr[kk]); pim[kk] = fma(si, c.x, pim[kk]);
+                        qr[kk] = fma(dr, c.y, qr[kk]); qi[kk] = fma(di, c.y, qi[kk]);
+                    }
+                }
+            }
+        } else {
+            // the remaining items: the block differs from lane to lane, the table entries are per-lane loads
+#pragma unroll 2
+            for (int n = 1; n <= H; ++n) {
+                const double2 xa = ldc(cbuf, base + n*STRIDE), xb = ldc(cbuf, base + (M - n)*STRIDE);
+                const double sr = xa.x + xb.x, si = xa.y + xb.y, dr = xa.x - xb.x, di = xa.y - xb.y;
+                ssum.x += sr; ssum.y += si;
+                const int row = (n - 1)*H + (k0 - 1);
+#pragma unroll
+                for (int kk = 0; kk < KBE; ++kk) {
+                    const double2 c = ldc(ltab, row + min(kk, H - k0));      // (clamped: a k beyond H is not stored)
                     pr[kk] = fma(sr, c.x, pr[kk]); pim[kk] = fma(si, c.x, pim[kk]);
                     qr[kk] = fma(dr, c.y, qr[kk]); qi[kk] = fma(di, c.y, qi[kk]);
                 }
@@ -650,7 +708,7 @@ __device__ __forceinline__ void sym_stage (lds_double* cbuf, const double2* __re
         };
         if (g == 0) stc(cbuf, base, x0.x + ssum.x, x0.y + ssum.y);      // k = 0, twiddle 1
 #pragma unroll
-        for (int kk = 0; kk < KB; ++kk) {
+        for (int kk = 0; kk < KBE; ++kk) {
             const int k = k0 + kk;
             if (k <= H) {
                 const double ar = x0.x + pr[kk], ai = x0.y + pim[kk];
@@ -684,6 +742,14 @@ __global__ __launch_bounds__(DSTS_NT) void k_dst_rows_sym (DstArgs a)
 
     HPS_STAMP_DECL;
     HPS_STAMP(0);
+    // a stage that packs its remaining items into one wave (sym_stage, LEFTOVER scheme) reads its table per lane: copy in LDS,
+    // behind the working set (the launch's LDS has room for both tables: hps_poisson_create)
+    constexpr int H1 = (N1 - 1)/2, H2 = (N2 - 1)/2;
+    constexpr bool LEFT_A = sym_stage_leftover<N1, N2, T, NT/64>(), LEFT_B = sym_stage_leftover<N2, N1, T, NT/64>();
+    lds_double* ltab_a = cbuf + 2*T*N;
+    lds_double* ltab_b = ltab_a + 2*H1*H1;
+    if constexpr (LEFT_A) { for (int k = tid; k < H1*H1; k += NT) { const double2 w = csa[k]; stc(ltab_a, k, w.x, w.y); } }
+    if constexpr (LEFT_B) { for (int k = tid; k < H2*H2; k += NT) { const double2 w = csb[k]; stc(ltab_b, k, w.x, w.y); } }
     if constexpr (LIN == 1) load_blocked_rows<T, N, NT>(cbuf, a, row0, tid);
     else if constexpr (LIN == 2) load_blocked_cols<T, N, NT>(cbuf, a, row0, tid);
     else if constexpr (BLK) load_row_pairs_p<T, N, NT, SRC>(cbuf, a, row0, tid);
@@ -713,10 +779,10 @@ __global__ __launch_bounds__(DSTS_NT) void k_dst_rows_sym (DstArgs a)
         __syncthreads();
         HPS_STAMP(2);
         // stage A: DFT-N1 over n1 (stride N2) of column n2, twiddle w_N^(n2 k1), result at [k1][n2]
-        sym_stage<N1, N2, N2, N2, 1, true, T, NT/64>(cbuf, csa, a.tw, wave, lane);
+        sym_stage<N1, N2, N2, N2, 1, true, T, NT/64, true>(cbuf, csa, a.tw, wave, lane, ltab_a);
         HPS_STAMP(3);
         // stage B: DFT-N2 over n2 (stride 1) of row k1, result X[k1 + N1 k2] at [k1][k2]
-        sym_stage<N2, 1, 1, N1, N2, false, T, NT/64>(cbuf, csb, nullptr, wave, lane);
+        sym_stage<N2, 1, 1, N1, N2, false, T, NT/64, true>(cbuf, csb, nullptr, wave, lane, ltab_b);
         HPS_STAMP(4);
         if (TWICE && pass == 0) {
             // T_k of both rows of every pair (times the scale) -> registers -> back to [t][k] as the next pass's input
