@@ -152,6 +152,15 @@ def cpu_baseline(n, ppc, nslices, threads):
                sample=f"oracle (C++ restatement of the reference's CPU path, g++ -O2 -fopenmp), head {nslices} slices of the same "
                       f"{n}x{n}x1024 {ppc * ppc}ppc deck: 1 thread {legs[1][1]:.1f} s"
                       + (f", {best} threads {legs[best][1]:.1f} s" if best > 1 else ""))
+    # the head slices are the cheap ones (no sheath yet).  For scale, the same oracle over the WHOLE box of this deck, as timed
+    # when the full-size parity fixture was written (another host: the build container): tests/golden/fullsize_config4.json
+    try:
+        fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_config4.json")))
+        if n == 1024 and ppc == 2:
+            out["whole_box_elsewhere"] = {"value": 1024.0 / fx["oracle_seconds"], "unit": "slices/s", "seconds": fx["oracle_seconds"],
+                                          "what": fx["generated_by"] + ", all 1024 slices of the headline deck, on the build container's cores (not this host)"}
+    except (OSError, KeyError, ValueError):
+        pass
     return out
 
 

@@ -47,7 +47,7 @@ void k_deposit_current (SlabView f, hps_plasma pl, DepComps cm, PartConsts k, in
         if (n_qsa) atomicAdd(n_qsa, 1);
         pl.w[ip] = 0.0;
         pl.idcpu[ip] = id & ~HPS_ID_VALID;
-        pl.psi_half[ip] = 0.0;      // (Tiling::valid_by_psi: the tile push of the engine's sheet reads validity from here)
+        if (pl.psi_half) pl.psi_half[ip] = 0.0;      // (Tiling::valid_by_psi: the tile push of the engine's sheet reads validity from here)
         return;
     }
 

@@ -122,6 +122,9 @@ __device__ __forceinline__ void load_region (double* img, const SlabView& f, con
 #ifndef HPS_EXPL_TWO_PASS
 #define HPS_EXPL_TWO_PASS 1
 #endif
+#ifndef HPS_EXPL_ROW_BARRIER
+#define HPS_EXPL_ROW_BARRIER 1
+#endif
 #ifndef HPS_DEP_PAD
 #define HPS_DEP_PAD 0
 #endif
@@ -258,7 +261,7 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             if (n_qsa) atomicAdd(n_qsa, 1);
             pl.w[ip] = 0.0;
             pl.idcpu[ip] = (VBW ? pl.idcpu[ip] : id) & ~HPS_ID_VALID;
-            pl.psi_half[ip] = 0.0;      // (Tiling::valid_by_psi)
+            if (pl.psi_half) pl.psi_half[ip] = 0.0;      // (Tiling::valid_by_psi)
             continue;
         }
         // per-component weights in DepComps order
@@ -433,7 +436,9 @@ void k_explicit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offset
         for (int m = 0; m < NS; ++m) { dsx[m] *= k.dx_inv; dsy[m] *= k.dy_inv; }
 #pragma unroll
         for (int iy = 0; iy < NS; ++iy) {
+#if HPS_EXPL_ROW_BARRIER
             if constexpr (LOCAL) asm volatile("" ::: "memory");      // one stencil row of LDS reads in flight at a time
+#endif
             const bool yedge = (DT == 2) && (iy == 0 || iy == NS - 1);
             const double a5s = a5*sy[iy], b5s = b5*sy[iy], ay = a6*dsy[iy], by = b6*dsy[iy];
 #pragma unroll
@@ -764,6 +769,9 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
                 // 166 us, when the kernel still waited for three dependent trips to memory per particle.)
 #pragma unroll
                 for (int iy = 0; iy < NS; ++iy) {
+#ifdef HPS_PUSH_PSI_BARRIER
+                    asm volatile("" ::: "memory");
+#endif
                     double rp = 0.0, rd = 0.0;
 #pragma unroll
                     for (int ix = 0; ix < NS; ++ix) {
