@@ -476,7 +476,7 @@ int Engine::init_beam ()
 static hipError_t create_engine_stream (hipStream_t* s)
 {
     const char* v = std::getenv("HPS_CU_MASKS");
-    if (!v || !*v) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    if (!v || !std::strchr(v, '-')) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);      // (unset, or no range in it)
     static std::atomic<int> created{0};
     std::vector<std::string> entries;
     {   std::string cur; for (const char* p = v; ; ++p) { if (*p == ',' || !*p) { entries.push_back(cur); cur.clear(); if (!*p) break; } else cur += *p; } }

@@ -1579,7 +1579,7 @@ def _run_with_env(api, var, value, deck, n_steps, tile_size=16):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["gated_push", "lazy_shift", "fuse_sources", "aux_stream", "fold_beam", "fold_hierarchy", "mg_post_fold", "laser_stream_fft", "laser_stream_mg", "ion_tile_skip", "fold_tail", "gated_ion_push", "poisson_blocked", "pc_speculate", "valid_by_w", "valid_by_psi"])
+@pytest.mark.parametrize("case", ["gated_push", "lazy_shift", "fuse_sources", "aux_stream", "fold_beam", "fold_hierarchy", "mg_post_fold", "laser_stream_fft", "laser_stream_mg", "ion_tile_skip", "fold_tail", "gated_ion_push", "poisson_blocked", "pc_speculate", "valid_by_w", "valid_by_psi", "cu_masks"])
 def test_schedules_do_not_change_results(api, case):
     """The engine's scheduling choices -- the push enqueued behind the multigrid's V-cycles and gated on its stopping rule,
     the envelope solver on a stream of its own, the tiles of atoms that cannot ionise skipped before their image is loaded --
@@ -1614,12 +1614,14 @@ def test_schedules_do_not_change_results(api, case):
         deck = decks.laser_blowout_wake()
         deck.update(nx=64, ny=64, nz=30, lo=(-16.0, -16.0, -4.0), hi=(16.0, 16.0, 4.0), laser_a0=1.5, laser_lambda0=0.4,
                     laser_solver=1 if case.endswith("fft") else 2, dt=5.0, n_steps=3)
+    elif case == "cu_masks":        # (diagnostic: the engine's stream on half of the compute units, hipExtStreamCreateWithCUMask; "0": a plain stream)
+        var, deck, steps = "HPS_CU_MASKS", decks.blowout_wake(), 1
     else:      # fold_tail: the electrons released since the last sort ride in the tile kernels' launches (sort_period 7: tails of up to 6 slices)
         # gated_ion_push: the ions' push (with its ADK decisions) and the electrons' push enqueued behind the Bx/By V-cycles
         var, steps = {"ion_tile_skip": "HPS_ION_TILE_SKIP", "fold_tail": "HPS_FOLD_TAIL", "gated_ion_push": "HPS_GATED_ION_PUSH"}[case], 2
         deck = decks.laser_ionization_SI()
         deck.update(nx=128, ny=128, nz=60, laser_solver=1, dt=6.0 * 10.0e-6 / 299792458.0, n_steps=2)
-    a = _run_with_env(api, var, "1", deck, steps)
+    a = _run_with_env(api, var, "0-127" if case == "cu_masks" else "1", deck, steps)
     b = _run_with_env(api, var, "0", deck, steps)
     sa, sb = a.slab(), b.slab()
     # two runs of ONE schedule differ by the order of their LDS atomics; two steps of the ionisation deck have shown 1.2e-12
