@@ -266,6 +266,15 @@ __device__ __forceinline__ void post_store (const lds_double* cbuf, const DstArg
 // k0..k0+B-1, all rows -- finds B*B contiguous doubles per row block ([k - k0][r], 288 B for B = 6) and transforms in place.
 // Both k_transpose launches of a solve (a read and a write of every plane each) are gone.  Planes are padded to whole
 // blocks (rows_pad), so a workgroup never straddles two planes.
+// Pitch of a (row block, column) entry of a blocked plane, in doubles.  -DHPS_BLK_PAD=1 pads the block's B = 2T rows to whole
+// 64-byte entries (8 for B = 6): the y pass's B columns are then 384 bytes = three whole 128-byte lines instead of 288-byte runs
+// that straddle lines other workgroups complete, and the x pass writes whole lines (the pad as zeros).  Measured (round 4, call
+// 17): Poisson phase 123.4 against 120.7 us per slice, 2127-2129 against 2137 slices/s with three stages in flight -- the
+// straddled lines are not what the blocked y pass costs, and the padded planes are a third larger.  Off.
+#ifndef HPS_BLK_PAD
+#define HPS_BLK_PAD 0
+#endif
+constexpr int blk_pitch (int T) { return HPS_BLK_PAD ? ((2*T + 7) & ~7) : 2*T; }
 struct BlkRow { int plane, j0; };
 __device__ __forceinline__ BlkRow blk_row (const DstArgs& a, int row0)
 {
@@ -321,12 +330,12 @@ __device__ __forceinline__ void load_row_pairs_p (lds_double* cbuf, const DstArg
 template <int T, int N, int NT>
 __device__ __forceinline__ void load_blocked_rows (lds_double* cbuf, const DstArgs& a, int row0, int tid)
 {
-    constexpr int n = N - 1, ITEMS = n*T, NI = (ITEMS + NT - 1)/NT;
+    constexpr int n = N - 1, ITEMS = n*T, NI = (ITEMS + NT - 1)/NT, BP2 = blk_pitch(T)/2;
     const BlkRow br = blk_row(a, row0);
-    const double2* base = reinterpret_cast<const double2*>(a.src[br.plane] + (long)(br.j0/(2*T))*n*(2*T));
+    const double2* base = reinterpret_cast<const double2*>(a.src[br.plane] + (long)(br.j0/(2*T))*n*(2*BP2));
     double2 v[NI];
 #pragma unroll
-    for (int m = 0; m < NI; ++m) v[m] = base[min(tid + NT*m, ITEMS - 1)];
+    for (int m = 0; m < NI; ++m) { const int f = min(tid + NT*m, ITEMS - 1); const int k = f / T, t = f - k*T; v[m] = base[k*BP2 + t]; }
 #pragma unroll
     for (int m = 0; m < NI; ++m) {
         const int f = tid + NT*m;
@@ -354,7 +363,7 @@ __device__ __forceinline__ void load_blocked_cols (lds_double* cbuf, const DstAr
         const int jb = f / PER, e = f - jb*PER;
         const int kk = min(e / (B/2), a.rows_per_plane - 1 - k0);        // (columns past the plane's last: clamped, zeroed below)
         const int u = e - (e / (B/2))*(B/2);
-        v[m] = plane[((long)jb*a.blk_cols + k0 + kk)*(B/2) + u];
+        v[m] = plane[((long)jb*a.blk_cols + k0 + kk)*(blk_pitch(T)/2) + u];
     }
 #pragma unroll
     for (int m = 0; m < NI; ++m) {
@@ -385,16 +394,19 @@ __device__ __forceinline__ double2 dst_pair (const lds_double* cbuf, int t, int 
 template <int T, int N1, int N2, int NT>
 __device__ __forceinline__ void store_blocked_rows (const lds_double* cbuf, const DstArgs& a, int row0, int tid)
 {
-    constexpr int N = N1*N2, n = N - 1, ITEMS = n*T, NI = (ITEMS + NT - 1)/NT;
+    constexpr int N = N1*N2, n = N - 1, BP2 = blk_pitch(T)/2, ITEMS = n*BP2, NI = (ITEMS + NT - 1)/NT;      // (pad slots included: whole 64-byte entries)
     const BlkRow br = blk_row(a, row0);
-    double2* base = reinterpret_cast<double2*>(a.dst[br.plane] + (long)(br.j0/(2*T))*n*(2*T));
+    double2* base = reinterpret_cast<double2*>(a.dst[br.plane] + (long)(br.j0/(2*T))*n*(2*BP2));
     double is[NI];
 #pragma unroll
-    for (int m = 0; m < NI; ++m) is[m] = a.isin4[min(tid + NT*m, ITEMS - 1)/T];
+    for (int m = 0; m < NI; ++m) is[m] = a.isin4[min(tid + NT*m, ITEMS - 1)/BP2];
 #pragma unroll
     for (int m = 0; m < NI; ++m) {
         const int f = tid + NT*m;
-        if (f < ITEMS) { const int k = f / T, t = f - k*T; base[f] = dst_pair<N1, N2>(cbuf, t, k, is[m]); }
+        if (f < ITEMS) {
+            const int k = f / BP2, t = f - k*BP2;
+            base[f] = t < T ? dst_pair<N1, N2>(cbuf, t, k, is[m]) : make_double2(0.0, 0.0);
+        }
     }
 }
 
@@ -419,9 +431,9 @@ __device__ __forceinline__ void store_blocked_cols (const lds_double* cbuf, cons
             if (j < n) {
                 const double2 v = dst_pair<N1, N2>(cbuf, t, j, is[m]);
                 const int jb = j / B, r = j - jb*B;
-                double* p = plane + ((long)jb*a.blk_cols + k0 + 2*t)*B + r;
+                double* p = plane + ((long)jb*a.blk_cols + k0 + 2*t)*blk_pitch(T) + r;
                 p[0] = v.x;
-                if (okb) p[B] = v.y;
+                if (okb) p[blk_pitch(T)] = v.y;
             }
         }
     }
@@ -1455,7 +1467,7 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
             if (want && ix->sym && iy->sym && ix->T == iy->T && P->ky2 && !P->kcols && !P->mtab_x) {
                 const int B = 2*ix->T;
                 P->kb_first = ix->b_first; P->kb_first_src = ix->b_first_src; P->kb_twice = iy->b_twice; P->kb_last = ix->b_last;
-                P->blk_plane = (long)((ny + B - 1)/B)*B*nx;
+                P->blk_plane = (long)((ny + B - 1)/B)*blk_pitch(ix->T)*nx;
                 plane_doubles = std::max(plane_doubles, (size_t)P->blk_plane);
                 for (dst_kernel_t kf : {P->kb_first, P->kb_first_src, P->kb_last})
                     if (P->lds_x > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_x));
