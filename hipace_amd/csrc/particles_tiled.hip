@@ -653,6 +653,9 @@ template <class T> __device__ __forceinline__ void sto_nt (T* base, unsigned o, 
 #ifndef HPS_PUSH_ALGEBRA
 #define HPS_PUSH_ALGEBRA 1
 #endif
+#ifndef HPS_PUSH_GATHER_PIPE
+#define HPS_PUSH_GATHER_PIPE 0
+#endif
 #ifndef HPS_PUSH_SPLIT_GATHER
 #define HPS_PUSH_SPLIT_GATHER 1
 #endif
@@ -767,6 +770,56 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
                 // its cell -- 16 + 4 x 9 = 52 LDS reads per particle instead of 80 (order 2), 416 instead of 640 B through the LDS
                 // pipe, 88 instead of 120 FMAs; the skipped terms are exact zeros.  (Round 3 measured this slower, 171 against
                 // 166 us, when the kernel still waited for three dependent trips to memory per particle.)
+#if HPS_PUSH_GATHER_PIPE
+                // the LDS reads of a row are requested one step ahead of the arithmetic that uses the previous ones: Psi's NS x NS
+                // cells and the first row of the plain fields are in flight together, then row k + 1 while row k is summed.
+                // Measured (round 4, call 18): 20 registers spilled under the 168 cap (11 without the particle prefetch):
+                // 168.6 / 135 against 131.5 us -- the kernel has no registers left for more reads in flight.  Off.
+                const bool xhi = !(sx[NS - 1] == 0.0), yhi = !(sy[NS - 1] == 0.0);
+                const double* bq = b + R*R + (yhi ? R : 0) + (xhi ? 1 : 0);
+                double vp[NS][NS];
+#pragma unroll
+                for (int iy = 0; iy < NS; ++iy)
+#pragma unroll
+                    for (int ix = 0; ix < NS; ++ix) vp[iy][ix] = lds_get(b + iy*R + ix);
+                double vq[2][4][NS - 1];
+                auto req = [&] (int ky, int slot) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int kx = 0; kx < NS - 1; ++kx) vq[slot][c][kx] = lds_get(bq + c*R*R + ky*R + kx);
+                };
+                req(0, 0);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int iy = 0; iy < NS; ++iy) {
+                    double rp = 0.0, rd = 0.0;
+#pragma unroll
+                    for (int ix = 0; ix < NS; ++ix) { rp = fma(sx[ix], vp[iy][ix], rp); rd = fma(dsx[ix], vp[iy][ix], rd); }
+                    F.ExmBy = fma(sy[iy], rd, F.ExmBy);
+                    F.EypBx = fma(dsy[iy], rp, F.EypBx);
+                }
+                double px[NS - 1], py[NS - 1];
+#pragma unroll
+                for (int m = 0; m < NS - 1; ++m) { px[m] = xhi ? sx[m + 1] : sx[m]; py[m] = yhi ? sy[m + 1] : sy[m]; }
+#pragma unroll
+                for (int ky = 0; ky < NS - 1; ++ky) {
+                    if (ky + 1 < NS - 1) req(ky + 1, (ky + 1) & 1);
+                    asm volatile("" ::: "memory");
+                    double rez = 0.0, rbx = 0.0, rby = 0.0, rbz = 0.0;
+#pragma unroll
+                    for (int kx = 0; kx < NS - 1; ++kx) {
+                        rez = fma(px[kx], vq[ky & 1][0][kx], rez);
+                        rbx = fma(px[kx], vq[ky & 1][1][kx], rbx);
+                        rby = fma(px[kx], vq[ky & 1][2][kx], rby);
+                        rbz = fma(px[kx], vq[ky & 1][3][kx], rbz);
+                    }
+                    F.Ez  = fma(py[ky], rez, F.Ez);
+                    F.Bxc = fma(py[ky], rbx, F.Bxc);
+                    F.Byc = fma(py[ky], rby, F.Byc);
+                    F.Bz  = fma(py[ky], rbz, F.Bz);
+                }
+#else
 #pragma unroll
                 for (int iy = 0; iy < NS; ++iy) {
 #ifdef HPS_PUSH_PSI_BARRIER
@@ -804,6 +857,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
                     F.Byc = fma(py[ky], rby, F.Byc);
                     F.Bz  = fma(py[ky], rbz, F.Bz);
                 }
+#endif
 #else
 #ifndef HPS_PUSH_ROLLED_ROWS
 #pragma unroll
