@@ -891,6 +891,9 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
                 F.ExmBy *= k.dx_inv;
                 F.EypBx *= k.dy_inv;
             } else {
+#ifdef HPS_DIAG_PUSH_NO_FALLBACK      // (diagnostic build: what the kernel's registers are without the slab path; results are wrong)
+                F.Ez = 1.0;
+#else
 #pragma unroll 1
                 for (int iy = 0; iy < NS; ++iy) {
 #pragma unroll
@@ -906,6 +909,7 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
                         F.Bz  += ss*p[cBz*f.ns];
                     }
                 }
+#endif
             }
             F.Bxc *= k.c;
             F.Byc *= k.c;
