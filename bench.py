@@ -575,7 +575,7 @@ def main():
                 "frac_counter_bytes": cb / t_gpu / 1e9 / HBM_PEAK_GBS if cb else None,
                 "unit": "GB/s", "peak": HBM_PEAK_GBS,
                 "note": "one stage's counter bytes per slice (profiles/" + PMC_SUMMARY + ") over the GPU's time per slice with all stages "
-                        "in flight; the aggregate counter run of the L-stage window is profiles/r04_inflight_pmc.csv"}
+                        "in flight; the aggregate counter run of the L-stage window is profiles/r04g_inflight_pmc.csv"}
         del lane_engines[1:]
 
     if rank == 0:
