@@ -29,9 +29,22 @@
 namespace hps {
 
 // 2-D multi-component view in level index space: (i,j,n) -> p[(i+oi) + (j+oj)*js + n*ns]
+// (HPS_MG_OFF32: the element's byte offset in 32-bit arithmetic from the view's base -- global_load / global_store with the
+//  base in SGPRs and one offset VGPR instead of a 64-bit address per access: the level-0 passes spend more instructions on
+//  index arithmetic than on fp64; the solver's planes hold at most 2^28 doubles, checked in mg_create)
+#ifndef HPS_MG_OFF32
+#define HPS_MG_OFF32 1
+#endif
 struct FView {
     double* p; long js, ns; int oi, oj;
-    __device__ __forceinline__ double& operator() (int i, int j, int n) const { return p[(long)(i + oi) + (long)(j + oj)*js + (long)n*ns]; }
+    __device__ __forceinline__ double& operator() (int i, int j, int n) const {
+#if HPS_MG_OFF32
+        const unsigned o = (unsigned)((i + oi) + (j + oj)*(int)js + n*(int)ns)*8u;
+        return *reinterpret_cast<double*>(reinterpret_cast<char*>(p) + o);
+#else
+        return p[(long)(i + oi) + (long)(j + oj)*js + (long)n*ns];
+#endif
+    }
 };
 
 struct LevBox { int lox, loy, hix, hiy;      // index bounds of the level box (walls for nodal)
@@ -1450,6 +1463,7 @@ struct Multigrid {
 int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
 {
     if (nx % 2 != ny % 2) { set_error("hps_mg_create: nx and ny must have the same parity"); return HPS_ERR_ARG; }
+    HPS_REQUIRE((long)(nx + 16)*(ny + 16) < (1L << 27), "hps_mg_create: the kernels address a two-component plane pair by 32-bit byte offsets (at most 2^27 cells per plane)");
     Multigrid* M = new Multigrid;
     M->cc = (nx % 2 == 0); M->nx = nx; M->ny = ny; M->dx = dx; M->dy = dy;
     // level boxes (ctor, HpMultiGrid.cpp:1043-1072)
@@ -1957,6 +1971,7 @@ extern "C" int hps_mg_solve1_fabs (void* handle, hps_slab sol2, hps_slab rhs2, h
     }
     HPS_REQUIRE(sol2.ncomp >= 2 && rhs2.ncomp >= 2 && acoef1.ncomp >= 1, "hps_mg_solve1_fabs: sol and rhs need two components, acoef one");
     const int sh = M->cc ? 0 : 1;
+    HPS_REQUIRE(sol2.nstride < (1L << 27) && rhs2.nstride < (1L << 27) && acoef1.nstride < (1L << 27), "hps_mg_solve1_fabs: planes of at most 2^27 doubles (32-bit byte offsets in the kernels)");
     M->sol  = FView{sol2.p, sol2.jstride, sol2.nstride, sol2.ng - sh, sol2.ng - sh};
     M->rhs  = FView{rhs2.p, rhs2.jstride, rhs2.nstride, rhs2.ng - sh, rhs2.ng - sh};
     M->acf0 = FView{acoef1.p, acoef1.jstride, acoef1.nstride, acoef1.ng - sh, acoef1.ng - sh};
