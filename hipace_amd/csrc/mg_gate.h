@@ -2,6 +2,7 @@
 // that are enqueued behind a solve before the host has read its norms back (the plasma push of the slice engine)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace hps {
 
@@ -37,11 +38,20 @@ __device__ __forceinline__ bool vcycle_active (const StopRule& sr)
         b = __hip_atomic_load(sr.norms + MG_NSUB + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c = __hip_atomic_load(sr.norms + pslot*MG_NSUB + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else { a = sr.norms[q]; b = sr.norms[MG_NSUB + q]; c = sr.norms[pslot*MG_NSUB + q]; }
-#pragma unroll
-    for (int o = MG_NSUB/2; o > 0; o >>= 1) {
-        const unsigned long long a2 = __shfl_xor(a, o), b2 = __shfl_xor(b, o), c2 = __shfl_xor(c, o);
-        a = a2 > a ? a2 : a; b = b2 > b ? b2 : b; c = c2 > c ? c2 : c;
-    }
+    // maxima over the 16 lanes of a row by DPP rotations (row_ror 8, 4, 2, 1: every lane ends with the row's maximum) -- as
+    // __shfl_xor butterflies these were 24 ds_bpermute round trips through the LDS crossbar at the head of every kernel of the chain
+    static_assert(MG_NSUB == 16, "the reduction below is over one DPP row");
+    auto ror = [] (unsigned long long v, auto C) __attribute__((always_inline)) {
+        constexpr int ctrl = 0x120 + decltype(C)::value;      // DPP row_ror:n
+        const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)v, ctrl, 0xf, 0xf, false);
+        const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(v >> 32), ctrl, 0xf, 0xf, false);
+        return ((unsigned long long)hi << 32) | lo;
+    };
+#define HPS_GATE_STEP(N) { const unsigned long long a2 = ror(a, std::integral_constant<int, N>{}), b2 = ror(b, std::integral_constant<int, N>{}), \
+                                                     c2 = ror(c, std::integral_constant<int, N>{}); \
+                           a = a2 > a ? a2 : a; b = b2 > b ? b2 : b; c = c2 > c ? c2 : c; }
+    HPS_GATE_STEP(8) HPS_GATE_STEP(4) HPS_GATE_STEP(2) HPS_GATE_STEP(1)
+#undef HPS_GATE_STEP
     const double res0 = __longlong_as_double((long long)a), rhs0 = __longlong_as_double((long long)b), prev = __longlong_as_double((long long)c);
     const double max_norm = (rhs0 >= res0) ? rhs0 : res0;
     const double target = fmax(sr.tol_abs, fmax(sr.tol_rel, 1.e-16)*max_norm);
