@@ -32,6 +32,12 @@ namespace hps {
 // (HPS_MG_OFF32: the element's byte offset in 32-bit arithmetic from the view's base -- global_load / global_store with the
 //  base in SGPRs and one offset VGPR instead of a 64-bit address per access: the level-0 passes spend more instructions on
 //  index arithmetic than on fp64; the solver's planes hold at most 2^28 doubles, checked in mg_create)
+// 1: the fused 8-sweep level-0 pass evaluates its V-cycle's gate behind its tile's loads, as the 4-sweep kernels do (0: first, a
+// dependent trip to memory ahead of the loads).  With the gate behind them all of the tile's operands are live across it: 61
+// registers spilled under the 128 the kernel may use for two workgroups per CU (round 4).  Off.
+#ifndef HPS_MG_GATE8_BEHIND
+#define HPS_MG_GATE8_BEHIND 0
+#endif
 #ifndef HPS_MG_OFF32
 #define HPS_MG_OFF32 1
 #endif
@@ -196,7 +202,7 @@ __device__ __forceinline__ void block_max_to (unsigned long long* slot, double v
 // DO_RES: residual r = rhs - L(phi_out), max|r| (and max|rhs|) -> norms;
 //         FUSE_R (cell-centred): cres = R(r) written straight to the next level; else r -> res_out.
 // INTERIOR tiles (no swept cell on a wall / outside the box) take a path without masks.
-template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, bool INTERIOR, int NSW>
+template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, bool INTERIOR, int NSW, bool GATE_IN = (NSW == 4)>
 __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], double* s_red, const LevBox& b, const FView& phi_out,
                                              const FView& phi_out2, const FView& rhs, const FView& acf, const FView& phi_in, const FView& crse,
                                              const FView& res_out, const FView& cres_out, double facx, double facy,
@@ -264,7 +270,7 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
             // Only the 4-sweep kernels of the coarser levels do this (a handful of workgroups, each a chain of latencies);
             // the 8-sweep pass of level 0 is bound by bandwidth and registers (all its operands live at once would cost
             // it a workgroup per CU) and reads its gate first.
-            if (NSW == 4) {
+            if (GATE_IN) {
                 const bool active = vcycle_active(sr);
 #pragma unroll
                 for (int m = 0; m < GPAIRS; ++m) { HPS_KEEP(r0[m][0]); HPS_KEEP(r0[m][1]); HPS_KEEP(r1[m][0]); HPS_KEEP(r1[m][1]); HPS_KEEP(ac[m][0]); HPS_KEEP(ac[m][1]); }
@@ -414,7 +420,7 @@ void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FV
 {
     static_assert(!FUSE_R || (CC && DO_RES), "fused restriction is cell-centred only");
     static_assert(!POST || NSW != 4, "the post rides on the fused level-0 pass");
-    if (NSW != 4 && !vcycle_active(sr)) { if (POST) post_epilogue(pa); return; }       // (the 4-sweep kernels read the gate behind their loads, see smooth_tile)
+    if (NSW != 4 && !(HPS_MG_GATE8_BEHIND && !POST) && !vcycle_active(sr)) { if (POST) post_epilogue(pa); return; }       // (the 4-sweep kernels read the gate behind their loads, see smooth_tile)
     constexpr int GT_X = TS::TX, GT_Y = TS::TY;
     __shared__ double s_phi[2][TS::AY*TS::AX];
     __shared__ double s_red[TS::NT/64];
@@ -430,9 +436,10 @@ void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FV
     // every swept cell and its ring strictly inside the unknowns' box and off the walls
     const bool interior = (gi0 - 1 >= b.vlx) && (gi0 + GT_X <= b.vhx) && (gj0 - 1 >= b.vly) && (gj0 + GT_Y <= b.vhy)
                        && (gi0 > b.lox) && (gi0 + GT_X - 1 < b.hix) && (gj0 > b.loy) && (gj0 + GT_Y - 1 < b.hiy);
-    if (interior) smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, true, NSW>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
+    constexpr bool GATE_IN = (NSW == 4) || (HPS_MG_GATE8_BEHIND && !POST);
+    if (interior) smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, true, NSW, GATE_IN>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
                                                              facx, facy, gi0, gj0, resnorm, rhsnorm, sr);
-    else          smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, false, NSW>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
+    else          smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, false, NSW, GATE_IN>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
                                                               facx, facy, gi0, gj0, resnorm, rhsnorm, sr);
     if (POST) post_epilogue(pa);
 }
