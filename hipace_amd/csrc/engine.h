@@ -5,6 +5,7 @@
 #include "common.h"
 #include <vector>
 #include "tiling.h"
+#include "mg_gate.h"
 #include "particle_math.h"
 #include "poisson_src.h"
 #include "beam_deposit.h"
@@ -27,6 +28,8 @@ int mg_solve1_prepare (void* mg_handle, hps_slab s, int sol_comp, int rhs_comp, 
 int mg_solve1_prepare_with (void* mg_handle, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, int max_iters, SlabView f, GradPsiSxSy ga,
                             hipStream_t st, bool* done);
 const int* mg_gate_after_enqueued (void* mg_handle);
+void mg_defer_post (void* mg_handle);
+bool mg_take_deferred_post (void* mg_handle, MgPost* out);
 bool mg_solve1_ready (void* mg_handle);
 int mg_solve1_finish (void* mg_handle, int* iters_out, double* resnorm_out, int* extra, hipStream_t st);
 }
@@ -75,6 +78,7 @@ struct Engine {
     int species_deposit (const hps_plasma& p, Tiling* T, const int comp[6], double charge, double mass, int can_ionize, const BeamPairWork* beam = nullptr);
     bool valid_by_w = true;                    // HPS_VALID_BY_W=0: off.  The depositions take "weight != 0" for the valid bit of idcpu and do not read it (PartConsts::valid_by_w:
                                                // 33.5 MB less per kernel at 1024^2 x 4 ppc -- no time gained with one stage on the GPU, +1 % with three in flight: r04g_ab_inflight_byte_cuts.txt)
+    bool post_in_push = true;                  // the gated plasma push posts the Bx/By solve's norms to the host (HPS_POST_IN_PUSH=0: k_post_norms, a launch of its own)
     bool fold_hierarchy = true;                // the multigrid's coefficient hierarchy in the -grad Psi / Sx, Sy launch (HPS_FOLD_HIERARCHY=0: in mg_solve1_begin)
     bool fold_beam = true;                     // the static beam's two deposits of a slice as extra workgroups of the plasma's deposition (HPS_FOLD_BEAM=0: a launch of their own)
     int species_explicit (const hps_plasma& p, Tiling* T, const int cache[4], const int depos[2], double charge, double mass, int can_ionize);

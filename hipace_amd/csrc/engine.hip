@@ -24,7 +24,7 @@ int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hp
 int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], double charge,
                           double mass, int order, int temp_slice, int n_subcycles, int can_ionize, Tiling* T,
                           int* n_fallback, hipStream_t st, int aabs_comp = -1, const IonArgs* ion = nullptr, const int* go = nullptr,
-                          TailWork tw = TailWork{});
+                          TailWork tw = TailWork{}, const MgPost* post = nullptr);
 int advance_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], const int dep_comp[6],
                            double charge, double mass, int order, int n_subcycles, double max_qsa, int* n_qsa, Tiling* T,
                            int* n_fallback, hipStream_t st);
@@ -510,6 +510,7 @@ int Engine::create (const hps_deck& deck, int device)
         for (hipEvent_t& ev : ev_aux) HPS_HIP_CHECK(hipEventCreateWithFlags(&ev, event_flags(false)));
     }
     if (const char* v = std::getenv("HPS_FOLD_TAIL")) fold_tail = std::atoi(v) != 0;
+    if (const char* v = std::getenv("HPS_POST_IN_PUSH")) post_in_push = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_FOLD_BEAM")) fold_beam = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_FOLD_HIERARCHY")) fold_hierarchy = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_VALID_BY_W")) valid_by_w = std::atoi(v) != 0;
@@ -1563,6 +1564,9 @@ int Engine::solve_slice_begin (int islice)
                            && !diagnostics && !d_fd && !d_insitu;
     const int comp_push[5] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ};
     {
+        // the plain gated push also posts the solve's norms to the host (k_advance_tiled's MgPost): no k_post_norms launch between
+        // the last V-cycle and the push (HPS_POST_IN_PUSH=0: the launch of its own)
+        if (gated && post_in_push) mg_defer_post(mg);
         if ((e = mg_solve1_begin(mg, slab, HPS_C_BX, HPS_C_SY, HPS_C_CHI, d.mg_tol_rel, d.mg_tol_abs, 200, st))) return e;
         if (gated_ion) {
             mark();   // b6
@@ -1572,7 +1576,10 @@ int Engine::solve_slice_begin (int islice)
         if (gated) {
             mark();   // b6
             mark();   // b7
-            if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st, c_aabs, nullptr, mg_gate_after_enqueued(mg)))) return e;
+            MgPost mp{};
+            const bool posting = mg_take_deferred_post(mg, &mp);
+            if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st, c_aabs, nullptr,
+                                          posting ? nullptr : mg_gate_after_enqueued(mg), TailWork{}, posting ? &mp : nullptr))) return e;
         }
         if (laser_split && d.laser_solver == 2) { if ((e = laser_advance_slice(*this, islice)) || (e = laser_done())) return e; }
         pending_slice = islice; pend_fuse = fuse; pend_gated = gated; pend_gated_ion = gated_ion;

@@ -9,6 +9,11 @@ namespace hps {
 constexpr int MG_NSUB = 16;       // a norm slot is MG_NSUB words (workgroups spread their atomics: same-address
                                   // L2 atomics serialise at ~20 ns each); its value is the maximum over them
 struct StopRule { const unsigned long long* norms; int k; double tol_rel, tol_abs; };
+// What k_post_norms does behind the V-cycles enqueued so far, handed to the kernel that is enqueued behind them instead (the gated
+// plasma push): evaluate the rule `after` itself -- every workgroup, for its own gate -- and, workgroup 0, copy the solve's
+// `nwords` words to the host's mapped buffer and the sequence number behind them.  src == nullptr: nothing to do.
+struct MgPost { const unsigned long long* src; volatile unsigned long long* dst; int nwords; volatile unsigned long long* seq_slot;
+                unsigned long long seq; StopRule after; };
 
 __device__ __forceinline__ double norm_slot (const unsigned long long* norms, int slot)
 {

@@ -1442,6 +1442,7 @@ struct Multigrid {
     unsigned long long* h_norms = nullptr;      // pinned copy of d_norms (2 + MG_MAX_VCYCLES slots)
     int last_iters = 1;                         // V-cycles of the previous solve = speculation depth
     SolveRun run{};                             // the solve between mg_solve1_begin and mg_solve1_finish
+    bool defer_post = false; bool deferred_valid = false; MgPost deferred{};      // mg_defer_post / mg_take_deferred_post
     bool use_low2 = false; Low2 low2{}; Low2* d_low2 = nullptr; size_t low2_lds = 0;   // cell-centred register/LDS lower V
     bool use_low3 = false; Low2 low3{}; Low2* d_low3 = nullptr; size_t low3_lds = 0;   // ... one component per workgroup (k_lower_v3)
     double* cinvA = nullptr;                    // inverse diagonals of level lowv_begin (written with the coefficient pyramid)
@@ -1726,6 +1727,13 @@ static void enqueue_cycles (Multigrid* M, hipStream_t st)
     }
     if (posted) return;
     ++M->seq; ++M->dbg_trips;
+    if (M->defer_post) {
+        // the caller's next kernel on this stream posts (mg_take_deferred_post): no launch of its own between the last V-cycle and it
+        M->defer_post = false; M->deferred_valid = true;
+        M->deferred = MgPost{M->d_buf, (volatile unsigned long long*)M->h_buf_dev, (3 + r.enq)*MG_NSUB, (volatile unsigned long long*)M->h_seq_dev, M->seq,
+                             StopRule{M->d_norms, r.enq, r.tol_rel, r.tol_abs}};
+        return;
+    }
     hipLaunchKernelGGL(k_post_norms, dim3(1), dim3(256), 0, st, M->d_buf, (volatile unsigned long long*)M->h_buf_dev,
                        (3 + r.enq)*MG_NSUB, (volatile unsigned long long*)M->h_seq_dev, M->seq,
                        reinterpret_cast<int*>(M->d_buf) + MG_GO_WORD, StopRule{M->d_norms, r.enq, r.tol_rel, r.tol_abs});
@@ -1915,6 +1923,19 @@ int mg_solve1_prepare_with (void* handle, hps_slab s, int sol_comp, int rhs_comp
 }
 // a hierarchy enqueued by mg_solve1_prepare* that no mg_solve1_begin followed (the caller failed in between) is dropped
 void mg_solve1_forget_hierarchy (void* handle) { if (handle) static_cast<Multigrid*>(handle)->hierarchy_ready = false; }
+// mg_defer_post ahead of mg_solve1_begin: the post of the first batch's norms is not launched but handed out by
+// mg_take_deferred_post -- the caller MUST then enqueue, next on the same stream, a kernel that performs it (k_advance_tiled's
+// MgPost argument), or the solve's finish never sees its norms.  (With HPS_MG_POST_FOLD the last V-cycle has posted already:
+// mg_take_deferred_post returns false and the caller gates on mg_gate_after_enqueued as before.)
+void mg_defer_post (void* handle) { Multigrid* M = static_cast<Multigrid*>(handle); M->defer_post = true; M->deferred_valid = false; }
+bool mg_take_deferred_post (void* handle, MgPost* out)
+{
+    Multigrid* M = static_cast<Multigrid*>(handle);
+    M->defer_post = false;
+    if (!M->deferred_valid) return false;
+    M->deferred_valid = false; *out = M->deferred;
+    return true;
+}
 const int* mg_gate_after_enqueued (void* handle)
 {
     return reinterpret_cast<const int*>(static_cast<Multigrid*>(handle)->d_buf) + MG_GO_WORD;

@@ -14,6 +14,7 @@
 #include <type_traits>
 #include "particle_math.h"
 #include "tiling.h"
+#include "mg_gate.h"
 #include "beam_deposit.h"
 
 #include <cstdlib>
@@ -674,7 +675,7 @@ template <class T> __device__ __forceinline__ void sto_nt (T* base, unsigned o, 
 template <int ORDER, int TS, bool LASER = false, bool IONIZE = false, bool VBP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IONIZE ? HPS_PUSH_WAVES_ION : HPS_PUSH_WAVES)))
 void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
-                      int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, int* n_fallback, IonArgs ia, const int* go, TailWork tw)
+                      int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, int* n_fallback, IonArgs ia, const int* go, TailWork tw, MgPost mp)
 {
     constexpr int R = TS + 2*TILE_HALO;
     constexpr int NS = ORDER + 2;
@@ -682,7 +683,19 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
     // set by the solve's k_post_norms; else the host adds V-cycles and launches the push again).  The word is loaded
     // here and looked at behind the barrier that waits for the field image anyway.
     static_assert(!(VBP && IONIZE), "the ADK draw is keyed by the id");
-    const int go_now = go ? *go : 1;
+    // mp.src: this launch stands where k_post_norms stood, directly behind the multigrid's V-cycles (mg_defer_post): every
+    // workgroup evaluates the stopping rule for its own gate, workgroup 0 posts the norms to the host first thing -- the host has
+    // the length of this kernel to read them and enqueue the next slice -- and a 4.8 us launch is off the slice's chain
+    int go_now;
+    if (mp.src) {
+        go_now = vcycle_active(mp.after) ? 0 : 1;      // (all lanes active: the kernel's first statement)
+        if (blockIdx.x == 0) {
+            for (int w = threadIdx.x; w < mp.nwords; w += 256) mp.dst[w] = mp.src[w];
+            HPS_HOST_STORES_ACKNOWLEDGED();
+            __syncthreads();
+            if (threadIdx.x == 0) *mp.seq_slot = mp.seq;
+        }
+    } else go_now = go ? *go : 1;
     int charged = 0;          // IONIZE: does this thread hold an ion of level > 0 after the slice?
     extern __shared__ __attribute__((aligned(16))) double img[];     // [5][R*R]
     bool tail;
@@ -1265,7 +1278,7 @@ int explicit_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hp
 
 int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_geom& g, const int comp[5], double charge,
                           double mass, int order, int temp_slice, int n_subcycles, int can_ionize, Tiling* T,
-                          int* n_fallback, hipStream_t st, int aabs_comp, const IonArgs* ion, const int* go, TailWork tw)
+                          int* n_fallback, hipStream_t st, int aabs_comp, const IonArgs* ion, const int* go, TailWork tw, const MgPost* post)
 {
     if (pl.n == 0) return HPS_OK;
     // 32-bit byte offsets into the SoA arrays (ip*8u, __builtin_assume(ip < 2^28) in the kernel); the tail's live count is
@@ -1280,11 +1293,13 @@ int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_
     const size_t lds = (size_t)(aabs_comp >= 0 ? 6 : 5)*R*R*sizeof(double);
     SlabView f(slab);
     const IonArgs ia = ion ? *ion : IonArgs{};
+    HPS_REQUIRE(!(post && (tw.nwg || tw.extra)), "advance_plasma_tiled: the launch that posts the multigrid's norms has tile workgroups only");
+    const MgPost mp = post ? *post : MgPost{};
     // (the variant without the idcpu read exists for order 2 on 16 x 16 tiles, as the depositions' <.., VBW>)
     const bool vbp = T->valid_by_psi && !ion && !can_ionize && order == 2 && T->g.ts == 16;
 #define HPS_ADV(O, S, L, I, V) { if (int e = set_lds(k_advance_tiled<O, S, L, I, V>, lds)) return e; \
         hipLaunchKernelGGL((k_advance_tiled<O, S, L, I, V>), dim3(T->g.ntiles + tw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
-                           comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback, ia, go, tw); }
+                           comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback, ia, go, tw, mp); }
 #define CALL(O, S) { if (ion) { if (aabs_comp >= 0) HPS_ADV(O, S, true, true, false) else HPS_ADV(O, S, false, true, false) } \
                      else if (vbp && O == 2 && S == 16) { if (aabs_comp >= 0) HPS_ADV(2, 16, true, false, true) else HPS_ADV(2, 16, false, false, true) } \
                      else     { if (aabs_comp >= 0) HPS_ADV(O, S, true, false, false) else HPS_ADV(O, S, false, false, false) } }
@@ -1390,5 +1405,5 @@ extern "C" int hps_advance_plasma_tiled (hps_slab slab, hps_plasma pl, hps_geom 
     if (int e = check_stencil(slab, (order + 1)/2 + 1, "hps_advance_plasma_tiled")) return e;
     if (int e = check_tiling(tiling, slab, pl, "hps_advance_plasma_tiled")) return e;
     return advance_plasma_tiled(slab, pl, g, comp, charge, mass, order, temp_slice, n_subcycles, can_ionize,
-                                static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr, nullptr, TailWork{});
+                                static_cast<Tiling*>(tiling), n_fallback, (hipStream_t)stream, -1, nullptr, nullptr, TailWork{}, nullptr);
 }

@@ -1579,7 +1579,7 @@ def _run_with_env(api, var, value, deck, n_steps, tile_size=16):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["gated_push", "lazy_shift", "fuse_sources", "aux_stream", "fold_beam", "fold_hierarchy", "mg_post_fold", "laser_stream_fft", "laser_stream_mg", "ion_tile_skip", "fold_tail", "gated_ion_push", "poisson_blocked", "pc_speculate", "valid_by_w", "valid_by_psi", "cu_masks"])
+@pytest.mark.parametrize("case", ["gated_push", "lazy_shift", "fuse_sources", "aux_stream", "fold_beam", "fold_hierarchy", "mg_post_fold", "laser_stream_fft", "laser_stream_mg", "ion_tile_skip", "fold_tail", "gated_ion_push", "poisson_blocked", "pc_speculate", "valid_by_w", "valid_by_psi", "cu_masks", "post_in_push"])
 def test_schedules_do_not_change_results(api, case):
     """The engine's scheduling choices -- the push enqueued behind the multigrid's V-cycles and gated on its stopping rule,
     the envelope solver on a stream of its own, the tiles of atoms that cannot ionise skipped before their image is loaded --
@@ -1614,6 +1614,8 @@ def test_schedules_do_not_change_results(api, case):
         deck = decks.laser_blowout_wake()
         deck.update(nx=64, ny=64, nz=30, lo=(-16.0, -16.0, -4.0), hi=(16.0, 16.0, 4.0), laser_a0=1.5, laser_lambda0=0.4,
                     laser_solver=1 if case.endswith("fft") else 2, dt=5.0, n_steps=3)
+    elif case == "post_in_push":    # the gated push posts the Bx/By solve's norms to the host itself (no k_post_norms launch ahead of it)
+        var, deck, steps = "HPS_POST_IN_PUSH", decks.blowout_wake(), 2
     elif case == "cu_masks":        # (diagnostic: the engine's stream on half of the compute units, hipExtStreamCreateWithCUMask; "0": a plain stream)
         var, deck, steps = "HPS_CU_MASKS", decks.blowout_wake(), 1
     else:      # fold_tail: the electrons released since the last sort ride in the tile kernels' launches (sort_period 7: tails of up to 6 slices)
