@@ -638,8 +638,8 @@ def main():
             "rccl_ranks_seen": rccl_ranks_seen,
             "stages_per_rank_on_the_ring": (max(1, args.inflight) if (world > 1 or args.ring_self) else None),
             "stages_per_rank_note": ("N > 1 runs ONE stage per rank unless --inflight-ring: with the closing edge of a 3-stage rank through RCCL "
-                                     "(one rank, --ring-self --inflight 3) the three stages made 1552 slices/s against 1986 with all edges in the "
-                                     "process, two stages 1791 against 1813 (profiles/r04_ring_self_stages.txt); results equal either way")
+                                     "(one rank, --ring-self --inflight 3) the three stages made 1710 slices/s against 2110 with all edges in the "
+                                     "process, two stages 1876 against 1995 (profiles/r04_ring_self_stages.txt); results equal either way")
                                     if world > 1 and not args.inflight_ring else None,
             "roofline": {"bound": "hbm", "kernel": "k_deposit_tiled<2,%d>" % args.tile if args.tile else "k_deposit_current<2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
