@@ -41,6 +41,20 @@ namespace hps {
 #ifndef HPS_MG_OFF32
 #define HPS_MG_OFF32 1
 #endif
+// HPS_MG_BLOCKROWS: a thread's GPAIRS cell pairs sit in GPAIRS consecutive rows of the tile (a 2 x GPAIRS block of cells) instead
+// of rows NT/PR apart, and the values it has written last stay in registers: of the four neighbours of a cell it updates, the
+// partner in its pair and the cells above / below inside its block come from registers, not from LDS -- 5 instead of 12 LDS reads
+// per half-sweep and component for GPAIRS = 3.  (The sweeps of the fused level-0 pass ran at 1900 cycles per half-sweep, which is
+// what the LDS pipe carries for two workgroups of 123 KB each.)
+// Measured (round 4): the kernels with GPAIRS = 2 (64 x 32 tiles: the initial level-0 pass 24.4 -> 22.0 us, the level-1 passes
+// 9.1 -> 8.2) gain; the fused 8-sweep level-0 pass (GPAIRS = 3, 128 registers for two workgroups per CU) does not have the 24
+// registers for the values and takes 39.2 instead of 32.2 us: block rows up to HPS_MG_BLOCKROWS_MAXG pairs per thread only.
+#ifndef HPS_MG_BLOCKROWS
+#define HPS_MG_BLOCKROWS 1
+#endif
+#ifndef HPS_MG_BLOCKROWS_MAXG
+#define HPS_MG_BLOCKROWS_MAXG 2
+#endif
 struct FView {
     double* p; long js, ns; int oi, oj;
     __device__ __forceinline__ double& operator() (int i, int j, int n) const {
@@ -198,6 +212,8 @@ __device__ __forceinline__ void block_max_to (unsigned long long* slot, double v
     __syncthreads();
 }
 
+// row (within the tile) and pair index of a thread's m-th cell pair (BR: block rows, see HPS_MG_BLOCKROWS)
+#define MG_ROWPK(m) const int jj = BR ? (tid / PR)*GPAIRS + (m) : (tid + MG_NT*(m)) / PR, pk = BR ? (tid & (PR - 1)) : (tid + MG_NT*(m)) - jj*PR
 // phi_out = GSRB^4(start), start = 0 | phi_in | phi_in + P(crse);
 // DO_RES: residual r = rhs - L(phi_out), max|r| (and max|rhs|) -> norms;
 //         FUSE_R (cell-centred): cres = R(r) written straight to the next level; else r -> res_out.
@@ -211,6 +227,7 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
     constexpr int E = DO_RES ? NSW : NSW - 1;         // rim of the swept tile that is not final
     constexpr int GT_X = TS::TX, GT_Y = TS::TY, GA_X = TS::AX, GA_Y = TS::AY, MG_NT = TS::NT, GPAIRS = TS::GPAIRS, PR = TS::PR;
     constexpr int AXH = GA_X/2, CH = GA_Y*AXH;        // entries per row / per plane of one colour
+    constexpr bool BR = HPS_MG_BLOCKROWS && (GPAIRS <= HPS_MG_BLOCKROWS_MAXG);
     const int tid = threadIdx.x;
     const int cpar = (gi0 + gj0) & 1;                 // colour of ringed cell (0, 0) is (gi0 - 1 + gj0 - 1) & 1
     MG_STAMP(0);
@@ -224,8 +241,7 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
     double rmax = 0.0;
 #pragma unroll
     for (int m = 0; m < GPAIRS; ++m) {
-        const int pi = tid + MG_NT*m;
-        const int jj = pi / PR, pk = pi - jj*PR;
+        MG_ROWPK(m);
         const int j = gj0 + jj;
         hx[m] = (gi0 + 2*pk + j) & 1;                 // colour 0 cell: (i + j) even
         fym[m] = INTERIOR ? facy : wall_mult<CC>(j, b.loy, b.hiy, facy);
@@ -295,75 +311,170 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
     __syncthreads();
     MG_STAMP(2);
 
-#pragma unroll
-    for (int icolor = 0; icolor < NSW; ++icolor) {
-        constexpr int dummy = 0; (void)dummy;
-        const int p = icolor & 1;                     // compile-time after unrolling
+    double l0[GPAIRS][2], l1[GPAIRS][2];              // BR: the thread's own cells, as it wrote them last (pair, sweep parity of the cell)
+    if constexpr (BR) {
+        // the thread's own cells, as it wrote them last (index: pair, sweep parity of the cell)
 #pragma unroll
         for (int m = 0; m < GPAIRS; ++m) {
-            const int pi = tid + MG_NT*m;
-            const int jj = pi / PR, pk = pi - jj*PR;
-            const int j = gj0 + jj;
-            const int h = hx[m] ^ p;
-            (void)j;
-            // self: plane p, entry pk + h; west / east: plane 1-p, entries pk, pk + 1; south / north: pk + h
+            MG_ROWPK(m);
             const int row = (jj + 1)*AXH + pk;
-            const double* nb0 = &s_phi[0][(1 - p)*CH + row];
-            const double* nb1 = &s_phi[1][(1 - p)*CH + row];
-            const double n0 = (r0[m][p] - (fxm[m][p]*(nb0[0] + nb0[1]) + fym[m]*(nb0[h - AXH] + nb0[h + AXH])))*ci[m][p];
-            const double n1 = (r1[m][p] - (fxm[m][p]*(nb1[0] + nb1[1]) + fym[m]*(nb1[h - AXH] + nb1[h + AXH])))*ci[m][p];
-            if (INTERIOR || in[m][p]) { s_phi[0][p*CH + row + h] = n0; s_phi[1][p*CH + row + h] = n1; }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) { const int h = hx[m] ^ p; l0[m][p] = s_phi[0][p*CH + row + h]; l1[m][p] = s_phi[1][p*CH + row + h]; }
         }
-        __syncthreads();
+#pragma unroll
+        for (int icolor = 0; icolor < NSW; ++icolor) {
+            const int p = icolor & 1;                     // compile-time after unrolling
+#pragma unroll
+            for (int m = 0; m < GPAIRS; ++m) {
+                MG_ROWPK(m);
+                const int h = hx[m] ^ p;
+                // self: plane p, entry pk + h.  West / east: the partner (register) and entry pk + h of plane 1-p (the pair's other side);
+                // south / north: the block's own rows (registers) or entry pk + h of the rows below / above it
+                const int row = (jj + 1)*AXH + pk;
+                const double* nb0 = &s_phi[0][(1 - p)*CH + row];
+                const double* nb1 = &s_phi[1][(1 - p)*CH + row];
+                const double we0 = nb0[h] + l0[m][1 - p], we1 = nb1[h] + l1[m][1 - p];      // (west + east: a + b = b + a to the bit)
+                const double s0 = (m > 0) ? l0[m > 0 ? m - 1 : 0][1 - p] : nb0[h - AXH], s1 = (m > 0) ? l1[m > 0 ? m - 1 : 0][1 - p] : nb1[h - AXH];
+                const double t0 = (m + 1 < GPAIRS) ? l0[m + 1 < GPAIRS ? m + 1 : m][1 - p] : nb0[h + AXH], t1 = (m + 1 < GPAIRS) ? l1[m + 1 < GPAIRS ? m + 1 : m][1 - p] : nb1[h + AXH];
+                const double n0 = (r0[m][p] - (fxm[m][p]*we0 + fym[m]*(s0 + t0)))*ci[m][p];
+                const double n1 = (r1[m][p] - (fxm[m][p]*we1 + fym[m]*(s1 + t1)))*ci[m][p];
+                if (INTERIOR || in[m][p]) { s_phi[0][p*CH + row + h] = n0; s_phi[1][p*CH + row + h] = n1; l0[m][p] = n0; l1[m][p] = n1; }
+            }
+            __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int icolor = 0; icolor < NSW; ++icolor) {
+            constexpr int dummy = 0; (void)dummy;
+            const int p = icolor & 1;                     // compile-time after unrolling
+#pragma unroll
+            for (int m = 0; m < GPAIRS; ++m) {
+                MG_ROWPK(m);
+                const int h = hx[m] ^ p;
+                // self: plane p, entry pk + h; west / east: plane 1-p, entries pk, pk + 1; south / north: pk + h
+                const int row = (jj + 1)*AXH + pk;
+                const double* nb0 = &s_phi[0][(1 - p)*CH + row];
+                const double* nb1 = &s_phi[1][(1 - p)*CH + row];
+                const double n0 = (r0[m][p] - (fxm[m][p]*(nb0[0] + nb0[1]) + fym[m]*(nb0[h - AXH] + nb0[h + AXH])))*ci[m][p];
+                const double n1 = (r1[m][p] - (fxm[m][p]*(nb1[0] + nb1[1]) + fym[m]*(nb1[h - AXH] + nb1[h + AXH])))*ci[m][p];
+                if (INTERIOR || in[m][p]) { s_phi[0][p*CH + row + h] = n0; s_phi[1][p*CH + row + h] = n1; }
+            }
+            __syncthreads();
+        }
     }
     MG_STAMP(3);
 
     double resmax = 0.0;
+    if constexpr (BR) {
+        double la0[GPAIRS], ra0[GPAIRS], la1[GPAIRS], ra1[GPAIRS];      // FUSE_R: residual of the left / right cell of a pair, per component
+        bool finr[GPAIRS];
 #pragma unroll
-    for (int m = 0; m < GPAIRS; ++m) {
-        const int pi = tid + MG_NT*m;
-        const int jj = pi / PR, pk = pi - jj*PR;
-        const int j = gj0 + jj;
-        const bool rowok = (jj >= E && jj < GT_Y - E);
-        double q0[2], q1[2];                          // by sweep parity p
-        bool fin[2];
+        for (int m = 0; m < GPAIRS; ++m) {
+            MG_ROWPK(m);
+            const int j = gj0 + jj;
+            const bool rowok = (jj >= E && jj < GT_Y - E);
+            double q0[2], q1[2];                          // by sweep parity p
+            bool fin[2];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int h = hx[m] ^ p;
-            const int ii = 2*pk + h;
-            fin[p] = rowok && ii >= E && ii < GT_X - E && in[m][p];
-            const int i = gi0 + ii;
-            const int row = (jj + 1)*AXH + pk;
-            const double f0 = s_phi[0][p*CH + row + h], f1 = s_phi[1][p*CH + row + h];
-            q0[p] = 0.0; q1[p] = 0.0;
-            if (DO_RES) {
-                const double* nb0 = &s_phi[0][(1 - p)*CH + row];
-                const double* nb1 = &s_phi[1][(1 - p)*CH + row];
-                const double t0 = residual_v<INTERIOR>(f0, nb0[0], nb0[1], nb0[h - AXH], nb0[h + AXH], i, j, b, r0[m][p], ac[m][p], facx, facy);
-                const double t1 = residual_v<INTERIOR>(f1, nb1[0], nb1[1], nb1[h - AXH], nb1[h + AXH], i, j, b, r1[m][p], ac[m][p], facx, facy);
-                q0[p] = fin[p] ? t0 : 0.0; q1[p] = fin[p] ? t1 : 0.0;
-                resmax = fmax(resmax, fmax(fabs(q0[p]), fabs(q1[p])));
+            for (int p = 0; p < 2; ++p) {
+                const int h = hx[m] ^ p;
+                const int ii = 2*pk + h;
+                fin[p] = rowok && ii >= E && ii < GT_X - E && in[m][p];
+                const int i = gi0 + ii;
+                const int row = (jj + 1)*AXH + pk;
+                const double f0 = l0[m][p], f1 = l1[m][p];
+                q0[p] = 0.0; q1[p] = 0.0;
+                if (DO_RES) {
+                    const double* nb0 = &s_phi[0][(1 - p)*CH + row];
+                    const double* nb1 = &s_phi[1][(1 - p)*CH + row];
+                    const double o0 = nb0[h], o1 = nb1[h];                      // the pair's other side; the partner is in a register
+                    const double w0 = h ? l0[m][1 - p] : o0, e0 = h ? o0 : l0[m][1 - p];
+                    const double w1 = h ? l1[m][1 - p] : o1, e1 = h ? o1 : l1[m][1 - p];
+                    const double s0 = (m > 0) ? l0[m > 0 ? m - 1 : 0][1 - p] : nb0[h - AXH], s1 = (m > 0) ? l1[m > 0 ? m - 1 : 0][1 - p] : nb1[h - AXH];
+                    const double n0 = (m + 1 < GPAIRS) ? l0[m + 1 < GPAIRS ? m + 1 : m][1 - p] : nb0[h + AXH], n1 = (m + 1 < GPAIRS) ? l1[m + 1 < GPAIRS ? m + 1 : m][1 - p] : nb1[h + AXH];
+                    const double t0 = residual_v<INTERIOR>(f0, w0, e0, s0, n0, i, j, b, r0[m][p], ac[m][p], facx, facy);
+                    const double t1 = residual_v<INTERIOR>(f1, w1, e1, s1, n1, i, j, b, r1[m][p], ac[m][p], facx, facy);
+                    q0[p] = fin[p] ? t0 : 0.0; q1[p] = fin[p] ? t1 : 0.0;
+                    resmax = fmax(resmax, fmax(fabs(q0[p]), fabs(q1[p])));
+                }
+                if (fin[p]) {
+                    if (DO_RES && !FUSE_R) { res_out(i, j, 0) = q0[p]; res_out(i, j, 1) = q1[p]; }
+                    phi_out(i, j, 0) = f0;
+                    phi_out(i, j, 1) = f1;
+                    if (phi_out2.p) { phi_out2(i, j, 0) = f0; phi_out2(i, j, 1) = f1; }
+                }
             }
-            if (fin[p]) {
-                if (DO_RES && !FUSE_R) { res_out(i, j, 0) = q0[p]; res_out(i, j, 1) = q1[p]; }
-                phi_out(i, j, 0) = f0;
-                phi_out(i, j, 1) = f1;
-                if (phi_out2.p) { phi_out2(i, j, 0) = f0; phi_out2(i, j, 1) = f1; }
-            }
+            const bool sw = (hx[m] != 0);             // the p = 0 cell is the right one
+            la0[m] = sw ? q0[1] : q0[0]; ra0[m] = sw ? q0[0] : q0[1];
+            la1[m] = sw ? q1[1] : q1[0]; ra1[m] = sw ? q1[0] : q1[1];
+            finr[m] = fin[0];
         }
         if (FUSE_R) {
-            // restrict_cc (:29-37): 0.25*(((a+b)+c)+d), a,b = left,right cell of this row (even j),
-            // c,d the row above.  Tile origins are even, so a pair is one coarse cell's x-extent and
-            // lanes l / l+32 of a wave hold rows jj / jj+1.
-            const bool sw = (hx[m] != 0);             // the p = 0 cell is the right one
-            const double la0 = sw ? q0[1] : q0[0], ra0 = sw ? q0[0] : q0[1];
-            const double la1 = sw ? q1[1] : q1[0], ra1 = sw ? q1[0] : q1[1];
-            const double c0 = __shfl_down(la0, PR), d0 = __shfl_down(ra0, PR);
-            const double c1 = __shfl_down(la1, PR), d1 = __shfl_down(ra1, PR);
-            if (fin[0] && ((tid & PR) == 0)) {
-                const int ic = (gi0 + 2*pk) >> 1, jc = j >> 1;
-                cres_out(ic, jc, 0) = 0.25*(la0 + ra0 + c0 + d0);
-                cres_out(ic, jc, 1) = 0.25*(la1 + ra1 + c1 + d1);
+            // restrict_cc (:29-37): 0.25*(((a+b)+c)+d), a,b = left,right cell of an even row, c,d the row above.  Tile origins are
+            // even, so a pair is one coarse cell's x-extent; the row above an even row is the thread's next pair, or -- for the last
+            // row of its block -- the first pair of the thread PR lanes on (a wave holds 64/PR consecutive blocks, an even number of
+            // rows from an even row on: the pairs that straddle two blocks never straddle two waves)
+            const double c0 = __shfl_down(la0[0], PR), d0 = __shfl_down(ra0[0], PR);
+            const double c1 = __shfl_down(la1[0], PR), d1 = __shfl_down(ra1[0], PR);
+#pragma unroll
+            for (int m = 0; m < GPAIRS; ++m) {
+                MG_ROWPK(m);
+                if (finr[m] && ((jj & 1) == 0)) {
+                    const bool own = (m + 1 < GPAIRS);
+                    const int mu = own ? m + 1 : m;
+                    const double ua0 = own ? la0[mu] : c0, ub0 = own ? ra0[mu] : d0, ua1 = own ? la1[mu] : c1, ub1 = own ? ra1[mu] : d1;
+                    const int ic = (gi0 + 2*pk) >> 1, jc = (gj0 + jj) >> 1;
+                    cres_out(ic, jc, 0) = 0.25*(la0[m] + ra0[m] + ua0 + ub0);
+                    cres_out(ic, jc, 1) = 0.25*(la1[m] + ra1[m] + ua1 + ub1);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < GPAIRS; ++m) {
+            MG_ROWPK(m);
+            const int j = gj0 + jj;
+            const bool rowok = (jj >= E && jj < GT_Y - E);
+            double q0[2], q1[2];                          // by sweep parity p
+            bool fin[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int h = hx[m] ^ p;
+                const int ii = 2*pk + h;
+                fin[p] = rowok && ii >= E && ii < GT_X - E && in[m][p];
+                const int i = gi0 + ii;
+                const int row = (jj + 1)*AXH + pk;
+                const double f0 = s_phi[0][p*CH + row + h], f1 = s_phi[1][p*CH + row + h];
+                q0[p] = 0.0; q1[p] = 0.0;
+                if (DO_RES) {
+                    const double* nb0 = &s_phi[0][(1 - p)*CH + row];
+                    const double* nb1 = &s_phi[1][(1 - p)*CH + row];
+                    const double t0 = residual_v<INTERIOR>(f0, nb0[0], nb0[1], nb0[h - AXH], nb0[h + AXH], i, j, b, r0[m][p], ac[m][p], facx, facy);
+                    const double t1 = residual_v<INTERIOR>(f1, nb1[0], nb1[1], nb1[h - AXH], nb1[h + AXH], i, j, b, r1[m][p], ac[m][p], facx, facy);
+                    q0[p] = fin[p] ? t0 : 0.0; q1[p] = fin[p] ? t1 : 0.0;
+                    resmax = fmax(resmax, fmax(fabs(q0[p]), fabs(q1[p])));
+                }
+                if (fin[p]) {
+                    if (DO_RES && !FUSE_R) { res_out(i, j, 0) = q0[p]; res_out(i, j, 1) = q1[p]; }
+                    phi_out(i, j, 0) = f0;
+                    phi_out(i, j, 1) = f1;
+                    if (phi_out2.p) { phi_out2(i, j, 0) = f0; phi_out2(i, j, 1) = f1; }
+                }
+            }
+            if (FUSE_R) {
+                // restrict_cc (:29-37): 0.25*(((a+b)+c)+d), a,b = left,right cell of this row (even j),
+                // c,d the row above.  Tile origins are even, so a pair is one coarse cell's x-extent and
+                // lanes l / l+32 of a wave hold rows jj / jj+1.
+                const bool sw = (hx[m] != 0);             // the p = 0 cell is the right one
+                const double la0 = sw ? q0[1] : q0[0], ra0 = sw ? q0[0] : q0[1];
+                const double la1 = sw ? q1[1] : q1[0], ra1 = sw ? q1[0] : q1[1];
+                const double c0 = __shfl_down(la0, PR), d0 = __shfl_down(ra0, PR);
+                const double c1 = __shfl_down(la1, PR), d1 = __shfl_down(ra1, PR);
+                if (fin[0] && ((tid & PR) == 0)) {
+                    const int ic = (gi0 + 2*pk) >> 1, jc = j >> 1;
+                    cres_out(ic, jc, 0) = 0.25*(la0 + ra0 + c0 + d0);
+                    cres_out(ic, jc, 1) = 0.25*(la1 + ra1 + c1 + d1);
+                }
             }
         }
     }
