@@ -52,6 +52,11 @@ namespace hps {
 #ifndef HPS_MG_BLOCKROWS
 #define HPS_MG_BLOCKROWS 1
 #endif
+// ... and, HPS_MG_BLOCKROWS_INTERIOR, for any number of pairs in the tiles that touch no wall (their path has no wall multipliers
+// and masks in registers)
+#ifndef HPS_MG_BLOCKROWS_INTERIOR
+#define HPS_MG_BLOCKROWS_INTERIOR 1
+#endif
 #ifndef HPS_MG_BLOCKROWS_MAXG
 #define HPS_MG_BLOCKROWS_MAXG 2
 #endif
@@ -227,7 +232,7 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
     constexpr int E = DO_RES ? NSW : NSW - 1;         // rim of the swept tile that is not final
     constexpr int GT_X = TS::TX, GT_Y = TS::TY, GA_X = TS::AX, GA_Y = TS::AY, MG_NT = TS::NT, GPAIRS = TS::GPAIRS, PR = TS::PR;
     constexpr int AXH = GA_X/2, CH = GA_Y*AXH;        // entries per row / per plane of one colour
-    constexpr bool BR = HPS_MG_BLOCKROWS && (GPAIRS <= HPS_MG_BLOCKROWS_MAXG);
+    constexpr bool BR = HPS_MG_BLOCKROWS && (GPAIRS <= HPS_MG_BLOCKROWS_MAXG || (INTERIOR && HPS_MG_BLOCKROWS_INTERIOR));
     const int tid = threadIdx.x;
     const int cpar = (gi0 + gj0) & 1;                 // colour of ringed cell (0, 0) is (gi0 - 1 + gj0 - 1) & 1
     MG_STAMP(0);
