@@ -36,8 +36,13 @@ import subprocess
 import sys
 import time
 
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    # before HIP starts: the engine's stream, the ring's send and receive streams and torch's own streams must not end up
+for _i, _a in enumerate(sys.argv):          # --edge ipc|rccl: the kind of edge between processes (read by the library when the ids are made)
+    if _a == "--edge" and _i + 1 < len(sys.argv):
+        os.environ["HPS_RING_EDGE"] = sys.argv[_i + 1]
+    elif _a.startswith("--edge="):
+        os.environ["HPS_RING_EDGE"] = _a.split("=", 1)[1]
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("HPS_RING_EDGE", "ipc") == "rccl":
+    # RCCL edges only.  Before HIP starts: the engine's stream, the ring's send and receive streams and torch's own streams must not end up
     # sharing a hardware queue (a send queued behind a receive that waits for its data would close a circle around the ring)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if "--config5" not in sys.argv:
@@ -245,6 +250,12 @@ def main():
     ap.add_argument("--watchdog", type=float, default=1500.0,
                     help="N > 1: seconds after which a rank that is still running gives up with exit code 3 (a ring that "
                          "cannot connect must not hold the node)")
+    ap.add_argument("--edge", choices=["ipc", "rccl"], default=None,
+                    help="N > 1 (and --ring-self): kind of edge between processes -- ipc (default): peer copies into the next rank's "
+                         "buffers, ordered through a shared-memory mailbox (hps_ring_*, HPS_RING_EDGE); rccl: ncclSend / ncclRecv")
+    ap.add_argument("--same-device", action="store_true",
+                    help="N > 1: every rank uses device 0 -- N processes, each with its own engine(s), hand over through the ipc "
+                         "edge on ONE GPU (what a one-GPU box can run of the multi-process path; RCCL refuses two ranks per device)")
     ap.add_argument("--spawn-check", action="store_true",
                     help="only check the launch path: every rank joins the process group (gloo, no GPU needed) and rank 0 "
                          "prints how many ranks there are")
@@ -255,6 +266,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.same_device:
+        assert os.environ.get("HPS_RING_EDGE", "ipc") != "rccl", "--same-device needs the ipc edge (RCCL refuses two ranks on one device)"
+        local = 0
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
 
@@ -292,14 +306,18 @@ def main():
         dog = threading.Timer(args.watchdog, give_up)
         dog.daemon = True
         dog.start()
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        # a host-only group for the barrier in the middle of a run: torch's RCCL barrier is a kernel plus a wait that may
-        # synchronise the whole device, and the ring's posted-ahead receives sit on that device until their data comes
+        # torch.distributed is the bootstrap and the clock's barrier only (the ids of the ring's edges, max-over-ranks of
+        # the times): a host-only gloo group -- one node, loopback.  The data path is the C-ABI ring.  (Fallback: torch's RCCL
+        # group, whose barrier is a kernel plus a wait that may synchronise the whole device -- not usable with --same-device.)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         try:
-            ctl = dist.new_group(backend="gloo")
-        except Exception as exc:      # no usable host interface for gloo: meet on torch's RCCL group, waiting for ITS stream only
-            print(f"bench.py: no gloo group for the mid-run barrier ({exc}); using an all-reduce on torch's stream", file=sys.stderr)
+            dist.init_process_group("gloo")
+            ctl = dist.group.WORLD
+        except Exception as exc:      # noqa: BLE001
+            print(f"bench.py: no gloo process group ({exc}); using torch's RCCL group", file=sys.stderr)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
             ctl = None
+    red_dev = "cpu" if ctl is not None else "cuda"
 
     def meet_mid_run():
         """all ranks have arrived -- without a device-wide synchronise (see on_slice below)"""
@@ -309,6 +327,11 @@ def main():
             t = torch.zeros(1, device="cuda")
             dist.all_reduce(t)
             torch.cuda.current_stream().synchronize()
+
+    def reduce_over_ranks(x, op):
+        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=op)
+        return t.item()
 
     nz = 1024
     deck = decks.synthetic(args.n, nz, args.ppc)
@@ -361,14 +384,14 @@ def main():
 
     transport = None
     if world > 1:
-        from hipace_amd.pipeline import RcclTransport
+        from hipace_amd.pipeline import RingTransport
         progress["phase"] = "ring init"
-        transport = RcclTransport(rank, world, local)          # communicators are created before the clock starts
+        transport = RingTransport(rank, world, local)          # the edges are connected before the clock starts
         progress["transport"] = transport
         progress["phase"] = "headline run"
     elif args.ring_self:
-        from hipace_amd.pipeline import RcclSelfRing
-        transport = RcclSelfRing(local)
+        from hipace_amd.pipeline import RcclSelfRing, ring_edge
+        transport = RcclSelfRing(local, edge=ring_edge())
 
     clock = {}
     stats0 = {}
@@ -477,21 +500,19 @@ def main():
     ring_stats = transport.stats() if transport is not None else None
     rccl_ranks_seen = None
     if transport is not None:
-        # evidence that N processes were on RCCL: what the communicators of this rank's two ring edges report about themselves
-        # (ncclCommCount = 2 each on a ring of 2+ ranks) and that messages went both ways; summed over the ranks below
+        # evidence that N processes were on the ring: what this rank's two ring edges report about themselves (RCCL: ncclCommCount
+        # = 2 each on a ring of 2+ ranks; ipc: both ends of the edge's mailbox attached) and that messages went both ways;
+        # summed over the ranks below
         inf = transport.info()
         ring_stats = dict(ring_stats, **inf)
-        on_ring = (inf["comm_in_ranks"] == 2 and inf["comm_out_ranks"] == 2 and ring_stats["sent"] > 0 and ring_stats["received"] > 0) if world > 1 \
+        # (an open ring -- one step per rank, the short run -- has a head rank that only sends and a tail rank that only receives)
+        on_ring = (inf["comm_in_ranks"] == 2 and inf["comm_out_ranks"] == 2 and ring_stats["sent"] + ring_stats["received"] > 0) if world > 1 \
             else (inf["comm_out_ranks"] == 1 and ring_stats["sent"] > 0)
         rccl_ranks_seen = int(on_ring)
         if world > 1:
-            t = torch.tensor([rccl_ranks_seen], dtype=torch.int64, device="cuda")
-            dist.all_reduce(t)
-            rccl_ranks_seen = int(t.item())
+            rccl_ranks_seen = int(round(reduce_over_ranks(rccl_ranks_seen, dist.ReduceOp.SUM)))
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        dt = reduce_over_ranks(dt, dist.ReduceOp.MAX)
     st_headline = eng.stats()
     snap = dict(laser_vc=eng.laser_vcycles() if args.config5 else None, pc=eng.pc_stats()[0] if args.config2 else None,
                 sorts=eng.sorts() if args.tile else 0, fallbacks=eng.fallbacks() if args.tile else 0,
@@ -555,9 +576,7 @@ def main():
             nL = solvedL // L
             whole = True
         if world > 1:
-            t = torch.tensor([dtL], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtL = t.item()
+            dtL = reduce_over_ranks(dtL, dist.ReduceOp.MAX)
         inflight = dict(value=W * nL / dtL, stages_per_gpu=L, slices_per_stage=nL, seconds=dtL,
                         window="whole boxes, pipeline fill included" if whole else
                                f"{nL} slices per stage in steady state (device clock: events on the stages' streams)")
@@ -635,7 +654,10 @@ def main():
             "ionization": (dict(zip(("electrons_released", "product_species_particles"), snap["ion"]))
                            if (args.config5 and not args.no_ionization) else None),
             "ring": ring_stats,
-            "rccl_ranks_seen": rccl_ranks_seen,
+            "ring_edge": (transport.kind if transport is not None else None),
+            "ranks_seen": rccl_ranks_seen,                  # ranks whose two ring edges are connected to a neighbour and carried messages both ways
+            "rccl_ranks_seen": rccl_ranks_seen if (transport is not None and transport.kind == "rccl") else None,
+            "ranks_on_one_device": bool(args.same_device) if world > 1 else None,
             "stages_per_rank_on_the_ring": (max(1, args.inflight) if (world > 1 or args.ring_self) else None),
             "stages_per_rank_note": ("N > 1 runs ONE stage per rank unless --inflight-ring: with the closing edge of a 3-stage rank through RCCL "
                                      "(one rank, --ring-self --inflight 3) the three stages made 1710 slices/s against 2110 with all edges in the "

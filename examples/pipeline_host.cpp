@@ -7,9 +7,11 @@
 // One process per GPU (device = rank), `stages_per_rank` engines per process (several time steps in flight per device: the
 // reference runs several MPI ranks per GPU for that).  The ring has world x stages_per_rank stages; stage v = rank *
 // stages_per_rank + j runs the steps v, v + W, ...  Edges inside a process are device-to-device copies on the sending
-// engine's stream, ordered by events; the edge that leaves the process is the RCCL ring (hps_ring_send_slice /
-// hps_ring_recv_slice), its receives posted a whole step ahead (MultiBuffer's unlimited max_leading_slices), which is what
-// lets the ring close (more steps than stages) without a rank ever waiting for its successor.  ONE host thread drives all
+// engine's stream, ordered by events; the edge that leaves the process is the C-ABI ring (hps_ring_send_slice /
+// hps_ring_recv_slice: peer copies through a shared-memory mailbox by default, RCCL with HPS_RING_EDGE=rccl), its receives
+// posted a whole step ahead (MultiBuffer's unlimited max_leading_slices), which is what lets the ring close (more steps than
+// stages) without a rank ever waiting for its successor.  With fewer devices than ranks the ranks share devices (rank %
+// devices): the ipc edge also connects processes on ONE device.  ONE host thread drives all
 // engines of the process and makes every call into the ring: a slice is enqueued up to its Bx/By norm read-back
 // (hps_engine_solve_slice_begin), then the other stages get their turn, then the read-backs are awaited in the same order.
 // The ids of the ring's edges travel through files in <id_dir> (no MPI in the image): rank r writes edge_<r>.id and reads
@@ -140,9 +142,11 @@ int main (int argc, char** argv)
     std::vector<double> sums((size_t)ncomp);
     long solved = 0, idle_rounds = 0;
     bool all_done = false;
+    auto t_ring_wait = std::chrono::steady_clock::now();
+    const double ring_timeout = std::getenv("HPS_RING_TIMEOUT_S") ? std::atof(std::getenv("HPS_RING_TIMEOUT_S")) : 900.0;
     while (!all_done) {
         all_done = true;
-        bool worked = false;
+        bool worked = false, ring_waits = false;
         // first halves: every stage that can enqueues its next slice up to the norm read-back
         for (int j = 0; j < L; ++j) {
             Stage& s = S[(size_t)j];
@@ -166,9 +170,18 @@ int main (int argc, char** argv)
             // get_data: this slice's beam and the next one's (the source of its jx, jy) must have been handed on
             const int need = s.q + 1 < nz ? s.q + 1 : nz - 1;
             if (fed && (s.have_step[b] != step || s.have[b] < need + 1)) continue;       // (an in-process edge: the stage ahead is not there yet)
+            const bool from_ring = fed && j == 0 && world > 1;
+            if (from_ring) {
+                // an ipc edge has no event the device could wait for: ask whether the messages have landed (an RCCL edge says
+                // yes at once and lets the engine's stream wait) and give the other stages their turn if not
+                bool there = true;
+                for (int k = s.imported + 1; k <= need && there; ++k)
+                    if (void* ev = s.landed[b][(size_t)k]) there = hps_ring_recv_landed(ring, ev) == 1 || hps_ring_edge_kind(ring) == 0;
+                if (!there) { ring_waits = true; continue; }
+            }
             for (; s.imported < need; ++s.imported) {
                 void* ev = s.landed[b][(size_t)s.imported + 1];
-                if (fed && ev) CHECK(hps_engine_wait_event(s.eng, ev));
+                if (fed && ev) { if (from_ring) CHECK(hps_ring_engine_wait(ring, s.eng, ev)); else CHECK(hps_engine_wait_event(s.eng, ev)); }
             }
             CHECK(hps_engine_solve_slice_begin(s.eng, nz - 1 - s.q));
             s.pending = true;
@@ -215,7 +228,11 @@ int main (int argc, char** argv)
                 ++s.m; s.begun = false;
             }
         }
-        idle_rounds = worked ? 0 : idle_rounds + 1;
+        if (worked || !ring_waits) t_ring_wait = std::chrono::steady_clock::now();
+        else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ring_wait).count() > ring_timeout) {
+            std::fprintf(stderr, "rank %d: no message from the previous rank for %.0f s\n", rank, ring_timeout); return 1;
+        }
+        idle_rounds = (worked || ring_waits) ? 0 : idle_rounds + 1;
         if (idle_rounds > 100000) { std::fprintf(stderr, "rank %d: the stages of this process wait for one another\n", rank); return 1; }
     }
     for (auto& s : S) CHECK(hps_engine_sync(s.eng));

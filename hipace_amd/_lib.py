@@ -5,23 +5,34 @@ import os
 import subprocess
 
 
+def launched_ranks():
+    """How many ranks the launcher says there are: torchrun (WORLD_SIZE), Open MPI, PMI / Hydra, Slurm."""
+    n = 1
+    for k in ("WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS"):
+        try:
+            n = max(n, int(os.environ.get(k, "1") or 1))
+        except ValueError:
+            pass
+    return n
+
+
 def _ring_environment():
-    """A ring of 2+ ranks posts its receives ahead as RCCL kernels that wait on the device: the ring's two streams and the
-    engine's stream must each get a hardware queue of their own (hps_ring_init refuses to start otherwise), and the runtime
-    reads GPU_MAX_HW_QUEUES once, when the process first touches HIP.  Any multi-rank launch (torchrun exports WORLD_SIZE)
-    therefore gets the variable HERE, at the import of the binding -- before libhpslice.so is loaded, and before torch
-    initialises the device unless the host has already done so (RcclTransport checks that and says so)."""
-    try:
-        multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
-    except ValueError:
-        multi = False
-    if multi:
+    """RCCL edges only (HPS_RING_EDGE=rccl; the default ipc edge has no device-resident waiter and needs none of this).  A ring
+    of 2+ ranks posts its receives ahead as RCCL kernels that wait on the device: the ring's two streams and the engine's
+    stream must each get a hardware queue of their own (hps_ring_init refuses to start otherwise), and the runtime reads
+    GPU_MAX_HW_QUEUES once, when the process first touches HIP.  Any multi-rank launch therefore gets the variable HERE, at
+    the import of the binding -- before libhpslice.so is loaded, and before torch initialises the device unless the host has
+    already done so (RingTransport checks that and says so)."""
+    if launched_ranks() > 1:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def hip_already_started():
-    """True if torch has initialised the device in this process (GPU_MAX_HW_QUEUES set now would come too late)."""
+    """True if this process has (or may have) touched HIP: torch has initialised the device, or libhpslice.so has been
+    loaded and used (an engine, a solver: hipSetDevice) -- GPU_MAX_HW_QUEUES set now would come too late."""
     import sys
+    if _LIB is not None:
+        return True
     t = sys.modules.get("torch")
     try:
         return bool(t is not None and t.cuda.is_initialized())
@@ -29,13 +40,13 @@ def hip_already_started():
         return False
 
 
+_LIB = None
 _HWQ_PRESET = "GPU_MAX_HW_QUEUES" in os.environ     # set by the host's environment, before this process started
 _HIP_STARTED_AT_IMPORT = hip_already_started()
 _ring_environment()
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO = os.environ.get("HPS_LIB") or os.path.join(CSRC, "libhpslice.so")      # HPS_LIB: a diagnostic build (make stamps)
-_LIB = None
 
 
 class Slab(C.Structure):
@@ -205,6 +216,10 @@ _SIGS = {
     "hps_engine_tiling": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "hps_ring_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 5),
     "hps_ring_destroy": (C.c_int, [C.c_void_p]),
+    "hps_ring_edge_kind": (C.c_int, [C.c_void_p]),
+    "hps_ring_can_send": (C.c_int, [C.c_void_p]),
+    "hps_ring_recv_landed": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hps_ring_engine_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hps_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long]),
     "hps_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long]),
     "hps_device_count": (C.c_int, [C.POINTER(C.c_int)]),

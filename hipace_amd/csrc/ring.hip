@@ -13,7 +13,28 @@
 //
 // RCCL is opened with dlopen so that the library loads (and the rest of the ABI works) in a process that never
 // touches the ring; when torch has already loaded its librccl.so.1 the same object is reused.
+//
+// Second kind of edge under the same entry points (HPS_RING_EDGE=ipc when the ids are made): a PEER COPY ordered through a
+// mailbox in POSIX shared memory -- for processes of one node, on different devices or on the SAME device (RCCL refuses
+// two ranks on one device, so this is also the edge a one-GPU box can run a ring of processes on).  The receiver writes a
+// descriptor per posted receive (which of its allocations, offset, bytes; allocations are exported once with
+// hipIpcGetMemHandle of their BASE -- a handle made from an interior pointer opens at the allocation's base on this
+// runtime, measured: scripts/ubench/ipc_torch_probe.py) and lets its receive stream write "buffer k is free" into the
+// mailbox behind the event that says so (hipStreamWriteValue64 on the registered page); the sender's host enqueues
+// hipMemcpyAsync(peer pointer) + hipStreamWriteValue64("message k has landed") on its send stream once receive k is posted
+// and free; the receiver's host reads that word before it enqueues the slice that needs the message -- no kernel sits on
+// the device waiting for data, nothing depends on how streams map onto hardware queues, and a side that waits gives up
+// after HPS_RING_TIMEOUT_S with the counters in the error text.  The reference's progress engine is of this kind
+// (MultiBuffer::make_progress polls MPI_Test from the host, MultiBuffer.cpp:287-442; comms_buffer.on_gpu :26-40,76-81).
 #include "common.h"
+
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <atomic>
+#include <map>
+#include <memory>
 
 #include <dlfcn.h>
 #include <cstdlib>
@@ -83,8 +104,44 @@ int load_rccl ()
         }                                                                                             \
     } while (0)
 
+// ---- the mailbox of one ipc edge (one POSIX shared-memory segment, mapped and hipHostRegister'ed by both sides) -------
+constexpr uint32_t kBoxMagic = 0x48505342u;     // "HPSB"
+constexpr int kBoxArenas = 64;
+constexpr uint64_t kBoxDescs = 16384;           // receives posted and not yet matched by a send (a whole step ahead: <= 2 per slice)
+struct alignas(64) BoxWord { volatile unsigned long long v; char pad[56]; };
+struct BoxArena { hipIpcMemHandle_t handle; unsigned long long base, size; };
+struct BoxDesc { unsigned long long offset, bytes; unsigned int arena, pad; };
+struct Mailbox {
+    uint32_t magic, version;
+    std::atomic<int> sender_attached, receiver_attached, sender_gone, receiver_gone;
+    char pad0[40];
+    BoxWord posted;        // receiver's host: receive descriptors written so far
+    BoxWord freed;         // receiver's receive STREAM: receives whose buffer may be written (monotonic, <= posted)
+    BoxWord issued;        // sender's host: messages enqueued so far
+    BoxWord landed;        // sender's send STREAM: messages whose payload is in the receiver's buffer
+    std::atomic<int> n_arenas; char pad1[60];
+    BoxArena arenas[kBoxArenas];
+    BoxDesc desc[kBoxDescs];
+};
+constexpr char kIpcTag[] = "HPSIPC1:";
+struct Ticket { unsigned long long magic, seq; };
+constexpr unsigned long long kTicketMagic = 0x4850535449434b54ull;
+
+struct Box {                                    // one side's view of a mailbox
+    Mailbox* m = nullptr; std::string name; bool creator = false, registered = false;
+    unsigned long long* d_freed = nullptr; unsigned long long* d_landed = nullptr;      // device addresses of the two stream-written words
+};
+std::map<std::string, Box> g_pending_boxes;     // made by hps_ring_unique_id, claimed by hps_ring_init
+
 struct Ring {
     int rank = 0, world = 1, device = 0;
+    int kind = 0;                                          // 0 = RCCL, 1 = ipc peer copies
+    Box box_in, box_out;                                   // ipc: edge (rank-1 -> rank): I receive; edge (rank -> rank+1): I send
+    std::vector<void*> peer_arena;                         // ipc, sender: the receiver's allocations as opened here
+    struct Range { unsigned long long base, size; int id; };
+    std::vector<Range> my_arenas;                          // ipc, receiver: my allocations that have been exported
+    std::vector<std::unique_ptr<Ticket>> tickets;
+    unsigned long long n_posted = 0, n_issued = 0;
     ncclComm_t comm_in = nullptr, comm_out = nullptr;      // edge (rank-1 -> rank): I am comm rank 1; edge (rank -> rank+1): comm rank 0
     ncclComm_t comm_self = nullptr;                        // world == 1: one 1-rank communicator ("send to myself")
     hipStream_t st_recv = nullptr, st_send = nullptr;
@@ -106,6 +163,120 @@ int event_of (std::vector<hipEvent_t>& pool, int slot, hipEvent_t* out)
     return HPS_OK;
 }
 
+// ---- ipc edge ------------------------------------------------------------------------------------------------------
+int edge_kind_env ()
+{
+    const char* v = std::getenv("HPS_RING_EDGE");
+    if (!v || !*v) return 1;                    // default: peer copies through the mailbox (no resident waiter, no queue requirement)
+    return std::strcmp(v, "rccl") == 0 ? 0 : 1;
+}
+bool is_ipc_id (const char* id) { return id && std::strncmp(id, kIpcTag, sizeof(kIpcTag) - 1) == 0; }
+
+double timeout_env (const char* name, double dflt)
+{
+    const char* e = std::getenv(name);
+    const double v = e ? std::atof(e) : dflt;
+    return v > 0.0 ? v : dflt;
+}
+
+int box_map (Box& B, const std::string& name, bool create)
+{
+    const int fd = shm_open(name.c_str(), create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
+    if (fd < 0) { hps::set_error("hps_ring: shm_open(" + name + ") failed: " + std::strerror(errno)); return HPS_ERR_COMM; }
+    if (create && ftruncate(fd, (off_t)sizeof(Mailbox)) != 0) { close(fd); shm_unlink(name.c_str()); hps::set_error("hps_ring: cannot size the mailbox " + name); return HPS_ERR_COMM; }
+    void* p = mmap(nullptr, sizeof(Mailbox), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { if (create) shm_unlink(name.c_str()); hps::set_error("hps_ring: cannot map the mailbox " + name); return HPS_ERR_COMM; }
+    B.m = static_cast<Mailbox*>(p); B.name = name; B.creator = create;
+    if (create) { B.m->version = 1; B.m->magic = kBoxMagic; }       // (a fresh segment is zero-filled)
+    return HPS_OK;
+}
+void box_unmap (Box& B)
+{
+    if (!B.m) return;
+    if (B.registered) (void)hipHostUnregister(B.m);
+    munmap(B.m, sizeof(Mailbox));
+    if (B.creator && !B.name.empty()) shm_unlink(B.name.c_str());      // (harmless when already unlinked)
+    B = Box();
+}
+int box_register (Box& B)
+{
+    HPS_HIP_CHECK(hipHostRegister(B.m, sizeof(Mailbox), hipHostRegisterPortable | hipHostRegisterMapped));
+    B.registered = true;
+    HPS_HIP_CHECK(hipHostGetDevicePointer((void**)&B.d_freed, (void*)&B.m->freed.v, 0));
+    HPS_HIP_CHECK(hipHostGetDevicePointer((void**)&B.d_landed, (void*)&B.m->landed.v, 0));
+    return HPS_OK;
+}
+
+// host wait with a deadline: `cond` polled; `gone` = the peer has said goodbye
+template <class F>
+int ipc_wait (Ring* R, F cond, const std::atomic<int>* gone, double seconds, const char* what)
+{
+    if (cond()) return HPS_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (!cond()) {
+        if ((++spins & 0xfff) == 0) {
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const bool left = gone && gone->load() != 0;
+            if (left && cond()) return HPS_OK;          // (what the peer did before it left counts)
+            if (left || dt > seconds) {
+                char buf[448];
+                const Mailbox* i = R->box_in.m; const Mailbox* o = R->box_out.m;
+                std::snprintf(buf, sizeof buf, "%s: rank %d of %d %s after %.1f s; incoming edge: posted %llu freed %llu issued %llu landed %llu; "
+                              "outgoing edge: posted %llu freed %llu issued %llu landed %llu", what, R->rank, R->world,
+                              left ? "-- the peer has left the ring" : "still waiting", dt,
+                              i ? i->posted.v : 0ull, i ? i->freed.v : 0ull, i ? i->issued.v : 0ull, i ? i->landed.v : 0ull,
+                              o ? o->posted.v : 0ull, o ? o->freed.v : 0ull, o ? o->issued.v : 0ull, o ? o->landed.v : 0ull);
+                hps::set_error(buf);
+                return HPS_ERR_COMM;
+            }
+            if (dt > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+    return HPS_OK;
+}
+
+// receiver: which exported allocation holds p?  Exports the allocation (its base) on first sight.
+int ipc_arena_of (Ring* R, const void* p, long bytes, unsigned* id, unsigned long long* offset)
+{
+    const unsigned long long a = (unsigned long long)(uintptr_t)p;
+    for (const auto& r : R->my_arenas)
+        if (a >= r.base && a + (unsigned long long)bytes <= r.base + r.size) { *id = (unsigned)r.id; *offset = a - r.base; return HPS_OK; }
+    void* base = nullptr; size_t size = 0;
+    HPS_HIP_CHECK(hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)const_cast<void*>(p)));
+    HPS_REQUIRE(base && a + (unsigned long long)bytes <= (unsigned long long)(uintptr_t)base + size, "hps_ring_recv_slice: the buffer is not inside one device allocation");
+    Mailbox* m = R->box_in.m;
+    const int n = m->n_arenas.load();
+    HPS_REQUIRE(n < kBoxArenas, "hps_ring_recv_slice: too many distinct allocations hold receive buffers (64)");
+    HPS_HIP_CHECK(hipIpcGetMemHandle(&m->arenas[n].handle, base));
+    m->arenas[n].base = (unsigned long long)(uintptr_t)base; m->arenas[n].size = size;
+    m->n_arenas.store(n + 1, std::memory_order_release);
+    R->my_arenas.push_back({(unsigned long long)(uintptr_t)base, (unsigned long long)size, n});
+    *id = (unsigned)n; *offset = a - (unsigned long long)(uintptr_t)base;
+    return HPS_OK;
+}
+
+// sender: the receiver's allocation `id` as mapped into this process
+int ipc_peer_arena (Ring* R, unsigned id, void** base)
+{
+    Mailbox* m = R->box_out.m;
+    HPS_REQUIRE((int)id < m->n_arenas.load(std::memory_order_acquire), "hps_ring_send_slice: the receive descriptor names an allocation that was never exported");
+    if (R->peer_arena.size() <= id) R->peer_arena.resize(id + 1, nullptr);
+    if (!R->peer_arena[id]) HPS_HIP_CHECK(hipIpcOpenMemHandle(&R->peer_arena[id], m->arenas[id].handle, hipIpcMemLazyEnablePeerAccess));
+    *base = R->peer_arena[id];
+    return HPS_OK;
+}
+
+inline unsigned long long ld_acq (const volatile unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+inline void st_rel (volatile unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+
+bool ipc_can_send (const Ring* R)
+{
+    const Mailbox* m = R->box_out.m;
+    return ld_acq(&m->posted.v) > R->n_issued && ld_acq(&m->freed.v) > R->n_issued;
+}
+
 } // namespace
 
 extern "C" int hps_ring_destroy (void* handle);
@@ -113,6 +284,19 @@ extern "C" int hps_ring_destroy (void* handle);
 extern "C" int hps_ring_unique_id (char* id_out)
 {
     HPS_REQUIRE(id_out, "hps_ring_unique_id: null argument");
+    if (edge_kind_env() == 1) {
+        // ipc edge: the id is the name of the edge's mailbox, made (and mapped) here by the rank that will SEND over the edge
+        static std::atomic<unsigned> counter{0};
+        char name[96];
+        std::snprintf(name, sizeof name, "/hps_ring_%d_%u_%llx", (int)getpid(), counter.fetch_add(1),
+                      (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
+        Box B;
+        if (int e = box_map(B, name, true)) return e;
+        g_pending_boxes[name] = B;
+        std::memset(id_out, 0, HPS_RING_ID_BYTES);
+        std::snprintf(id_out, HPS_RING_ID_BYTES, "%s%s", kIpcTag, name);
+        return HPS_OK;
+    }
     if (int e = load_rccl()) return e;
     NcclId id;
     HPS_NCCL_CHECK(g_rccl.GetUniqueId(&id));
@@ -124,6 +308,37 @@ extern "C" int hps_ring_init (int rank, int world, int device, const char* id_ed
 {
     HPS_REQUIRE(handle && world >= 1 && rank >= 0 && rank < world, "hps_ring_init: bad rank / world");
     HPS_REQUIRE(id_edge_out && (world == 1 || id_edge_in), "hps_ring_init: the ids of both edges are needed");
+    if (is_ipc_id(id_edge_out)) {
+        HPS_REQUIRE(world == 1 || is_ipc_id(id_edge_in), "hps_ring_init: this rank's outgoing edge is an ipc edge and its incoming edge is not (HPS_RING_EDGE differs between ranks)");
+        HPS_HIP_CHECK(hipSetDevice(device));
+        Ring* R = new Ring;
+        R->rank = rank; R->world = world; R->device = device; R->kind = 1;
+        auto fail = [&] (int e) { hps_ring_destroy(R); return e; };
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&R->st_recv, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&R->st_send, hipStreamNonBlocking, hi) != hipSuccess) {
+            hps::set_error("hps_ring_init: cannot create the ring's streams"); return fail(HPS_ERR_HIP);
+        }
+        const std::string out_name = id_edge_out + sizeof(kIpcTag) - 1;
+        auto it = g_pending_boxes.find(out_name);
+        if (it == g_pending_boxes.end()) { hps::set_error("hps_ring_init: id_edge_out was not made by hps_ring_unique_id of this process"); return fail(HPS_ERR_ARG); }
+        R->box_out = it->second; g_pending_boxes.erase(it);
+        if (world == 1) { *handle = R; return HPS_OK; }          // the rank is its own neighbour: plain device copies, no mailbox traffic
+        if (int e = box_map(R->box_in, id_edge_in + sizeof(kIpcTag) - 1, false)) return fail(e);
+        if (R->box_in.m->magic != kBoxMagic || R->box_in.m->version != 1) { hps::set_error("hps_ring_init: the incoming edge's mailbox is not one of this library version"); return fail(HPS_ERR_COMM); }
+        if (int e = box_register(R->box_in)) return fail(e);
+        if (int e = box_register(R->box_out)) return fail(e);
+        R->box_out.m->sender_attached.store(1);
+        R->box_in.m->receiver_attached.store(1);
+        const double tmo = timeout_env("HPS_RING_CONNECT_TIMEOUT_S", 300.0);
+        if (int e = ipc_wait(R, [&] { return R->box_out.m->receiver_attached.load() != 0; }, nullptr, tmo, "hps_ring_init (waiting for the next rank to attach)")) return fail(e);
+        if (int e = ipc_wait(R, [&] { return R->box_in.m->sender_attached.load() != 0; }, nullptr, tmo, "hps_ring_init (waiting for the previous rank to attach)")) return fail(e);
+        shm_unlink(R->box_out.name.c_str());                      // both sides hold the mapping: nothing is left behind if a rank dies
+        *handle = R;
+        return HPS_OK;
+    }
+    HPS_REQUIRE(world == 1 || !is_ipc_id(id_edge_in), "hps_ring_init: this rank's incoming edge is an ipc edge and its outgoing edge is not (HPS_RING_EDGE differs between ranks)");
     if (int e = load_rccl()) return e;
     if (world > 1) {
         // A receive posted ahead is an RCCL kernel that sits on the device until its data comes.  If the runtime maps the
@@ -212,8 +427,32 @@ extern "C" int hps_ring_init (int rank, int world, int device, const char* id_ed
 extern "C" int hps_ring_send_slice (void* handle, const void* msg_dev, long bytes, void* after_event, int slot, void** done_event)
 {
     Ring* R = static_cast<Ring*>(handle);
-    HPS_REQUIRE(R && R->comm_out, "hps_ring_send_slice: the ring has no outgoing edge (world = 1: use hps_ring_sendrecv_self)");
+    HPS_REQUIRE(R && (R->comm_out || (R->kind == 1 && R->world > 1)), "hps_ring_send_slice: the ring has no outgoing edge (world = 1: use hps_ring_sendrecv_self)");
     HPS_REQUIRE(msg_dev && bytes > 0, "hps_ring_send_slice: empty message");
+    if (R->kind == 1) {
+        // the host waits until the matching receive is posted and its buffer free (a host that must not block asks
+        // hps_ring_can_send first); everything else is enqueued
+        Mailbox* m = R->box_out.m;
+        if (int e = ipc_wait(R, [&] { return ipc_can_send(R); }, &m->receiver_gone, timeout_env("HPS_RING_TIMEOUT_S", 900.0), "hps_ring_send_slice")) return e;
+        const BoxDesc d = m->desc[R->n_issued % kBoxDescs];
+        if (d.bytes != (unsigned long long)bytes) {
+            char buf[160]; std::snprintf(buf, sizeof buf, "hps_ring_send_slice: message %llu has %ld bytes, the receive posted for it %llu", R->n_issued, bytes, d.bytes);
+            hps::set_error(buf); return HPS_ERR_COMM;
+        }
+        void* base = nullptr;
+        if (int e = ipc_peer_arena(R, d.arena, &base)) return e;
+        if (after_event) HPS_HIP_CHECK(hipStreamWaitEvent(R->st_send, static_cast<hipEvent_t>(after_event), 0));
+        HPS_HIP_CHECK(hipMemcpyAsync(static_cast<char*>(base) + d.offset, msg_dev, (size_t)bytes, hipMemcpyDeviceToDevice, R->st_send));
+        HPS_HIP_CHECK(hipStreamWriteValue64(R->st_send, R->box_out.d_landed, R->n_issued + 1, 0));
+        ++R->n_issued;
+        st_rel(&m->issued.v, R->n_issued);
+        hipEvent_t ev;
+        if (int e = event_of(R->ev_send, slot, &ev)) return e;
+        HPS_HIP_CHECK(hipEventRecord(ev, R->st_send));
+        if (done_event) *done_event = ev;
+        ++R->n_sent; R->bytes_sent += bytes;
+        return HPS_OK;
+    }
     if (after_event) HPS_HIP_CHECK(hipStreamWaitEvent(R->st_send, static_cast<hipEvent_t>(after_event), 0));
     HPS_NCCL_CHECK(g_rccl.Send(msg_dev, (size_t)bytes, /*ncclChar*/ 0, /*peer*/ 1, R->comm_out, R->st_send));
     hipEvent_t ev;
@@ -230,8 +469,29 @@ extern "C" int hps_ring_send_slice (void* handle, const void* msg_dev, long byte
 extern "C" int hps_ring_recv_slice (void* handle, void* msg_dev, long bytes, void* after_event, int slot, void** done_event)
 {
     Ring* R = static_cast<Ring*>(handle);
-    HPS_REQUIRE(R && R->comm_in, "hps_ring_recv_slice: the ring has no incoming edge (world = 1: use hps_ring_sendrecv_self)");
+    HPS_REQUIRE(R && (R->comm_in || (R->kind == 1 && R->world > 1)), "hps_ring_recv_slice: the ring has no incoming edge (world = 1: use hps_ring_sendrecv_self)");
     HPS_REQUIRE(msg_dev && bytes > 0, "hps_ring_recv_slice: empty message");
+    if (R->kind == 1) {
+        Mailbox* m = R->box_in.m;
+        HPS_REQUIRE(R->n_posted - ld_acq(&m->issued.v) < kBoxDescs, "hps_ring_recv_slice: too many receives posted ahead of their sends (16384)");
+        HPS_REQUIRE(slot >= 0 && slot < (1 << 20), "hps_ring: bad event slot");
+        BoxDesc d{};
+        if (int e = ipc_arena_of(R, msg_dev, bytes, &d.arena, &d.offset)) return e;
+        d.bytes = (unsigned long long)bytes;
+        m->desc[R->n_posted % kBoxDescs] = d;
+        ++R->n_posted;
+        st_rel(&m->posted.v, R->n_posted);
+        // "buffer free" travels in stream order behind the event that says so (and behind every earlier receive's), so the
+        // word stays monotonic
+        if (after_event) HPS_HIP_CHECK(hipStreamWaitEvent(R->st_recv, static_cast<hipEvent_t>(after_event), 0));
+        HPS_HIP_CHECK(hipStreamWriteValue64(R->st_recv, R->box_in.d_freed, R->n_posted, 0));
+        if ((size_t)slot >= R->tickets.size()) R->tickets.resize((size_t)slot + 1);
+        if (!R->tickets[slot]) R->tickets[slot].reset(new Ticket{kTicketMagic, 0});
+        R->tickets[slot]->seq = R->n_posted;
+        if (done_event) *done_event = R->tickets[slot].get();
+        ++R->n_received; R->bytes_received += bytes;
+        return HPS_OK;
+    }
     if (after_event) HPS_HIP_CHECK(hipStreamWaitEvent(R->st_recv, static_cast<hipEvent_t>(after_event), 0));
     HPS_NCCL_CHECK(g_rccl.Recv(msg_dev, (size_t)bytes, /*ncclChar*/ 0, /*peer*/ 0, R->comm_in, R->st_recv));
     hipEvent_t ev;
@@ -248,13 +508,13 @@ extern "C" int hps_ring_sendrecv_self (void* handle, const void* src_dev, void* 
                                        void** done_event)
 {
     Ring* R = static_cast<Ring*>(handle);
-    HPS_REQUIRE(R && R->comm_self, "hps_ring_sendrecv_self: needs a ring of one rank");
+    HPS_REQUIRE(R && (R->comm_self || (R->kind == 1 && R->world == 1)), "hps_ring_sendrecv_self: needs a ring of one rank");
     HPS_REQUIRE(src_dev && dst_dev && bytes > 0, "hps_ring_sendrecv_self: empty message");
     if (after_event) HPS_HIP_CHECK(hipStreamWaitEvent(R->st_send, static_cast<hipEvent_t>(after_event), 0));
     // HPS_RING_SELF_COPY=1 (diagnostic): the same choreography with a device copy in place of the RCCL pair -- what of the
     // ring's cost is the RCCL kernel running beside the engine's, and what is the events and the host calls
     static const bool plain_copy = [] { const char* v = std::getenv("HPS_RING_SELF_COPY"); return v && std::atoi(v) != 0; }();
-    if (plain_copy) {
+    if (plain_copy || R->kind == 1) {     // (ipc edge with one rank: MultiBuffer.cpp:299-308's in-process copy, on the ring's stream)
         HPS_HIP_CHECK(hipMemcpyAsync(dst_dev, src_dev, (size_t)bytes, hipMemcpyDeviceToDevice, R->st_send));
     } else {
         HPS_NCCL_CHECK(g_rccl.GroupStart());
@@ -327,18 +587,78 @@ extern "C" int hps_ring_sync_sends (void* handle)
     return ring_wait(R, true, false, ring_timeout_env(), "hps_ring_sync_sends");
 }
 
+// ipc edge: "the receive stream is done" does not say that the posted receives have their data (no receive sits on the
+// device); the end of a run also waits until every posted receive has landed -- the sender writes into this process's
+// buffers until then
+static int ipc_wait_all_landed (Ring* R, double seconds, const char* what)
+{
+    if (R->kind != 1 || R->world == 1 || !R->box_in.m) return HPS_OK;
+    Mailbox* m = R->box_in.m;
+    return ipc_wait(R, [&] { return ld_acq(&m->landed.v) >= R->n_posted; }, &m->sender_gone, seconds, what);
+}
+
 extern "C" int hps_ring_sync (void* handle)
 {
     Ring* R = static_cast<Ring*>(handle);
     HPS_REQUIRE(R, "hps_ring_sync: null ring");
-    return ring_wait(R, true, true, ring_timeout_env(), "hps_ring_sync");
+    if (int e = ring_wait(R, true, true, ring_timeout_env(), "hps_ring_sync")) return e;
+    return ipc_wait_all_landed(R, ring_timeout_env(), "hps_ring_sync (receives posted and not yet sent by the previous rank)");
 }
 
 extern "C" int hps_ring_sync_timeout (void* handle, double seconds)
 {
     Ring* R = static_cast<Ring*>(handle);
     HPS_REQUIRE(R && seconds > 0.0, "hps_ring_sync_timeout: bad argument");
-    return ring_wait(R, true, true, seconds, "hps_ring_sync_timeout");
+    if (int e = ring_wait(R, true, true, seconds, "hps_ring_sync_timeout")) return e;
+    return ipc_wait_all_landed(R, seconds, "hps_ring_sync_timeout (receives posted and not yet sent by the previous rank)");
+}
+
+// ---- the non-blocking side of the hand-off, and the wait that works for either kind of edge ---------------------------
+extern "C" int hps_engine_wait_event (void* h, void* event);
+
+extern "C" int hps_ring_edge_kind (void* handle)
+{
+    Ring* R = static_cast<Ring*>(handle);
+    return R ? R->kind : -1;
+}
+
+// 1: the next hps_ring_send_slice will not make the host wait (RCCL edge: always -- the wait happens on the device)
+extern "C" int hps_ring_can_send (void* handle)
+{
+    Ring* R = static_cast<Ring*>(handle);
+    if (!R) return -1;
+    if (R->kind != 1 || R->world == 1) return 1;
+    return ipc_can_send(R) ? 1 : 0;
+}
+
+// 1: the message behind this receive (*done_event of hps_ring_recv_slice) has landed; 0: not yet; < 0: bad argument
+extern "C" int hps_ring_recv_landed (void* handle, void* done_event)
+{
+    Ring* R = static_cast<Ring*>(handle);
+    if (!R || !done_event) return -1;
+    if (R->kind != 1) {
+        const hipError_t e = hipEventQuery(static_cast<hipEvent_t>(done_event));
+        return e == hipSuccess ? 1 : (e == hipErrorNotReady ? 0 : -1);
+    }
+    const Ticket* t = static_cast<const Ticket*>(done_event);
+    if (t->magic != kTicketMagic) return -1;
+    return ld_acq(&R->box_in.m->landed.v) >= t->seq ? 1 : 0;
+}
+
+// Order `engine`'s stream behind a received message.  RCCL edge: the stream waits for the receive's event on the device
+// (hps_engine_wait_event).  ipc edge: the HOST waits until the sender's stream has written "landed" (returns at once when it
+// has, which is the steady state of a rank that trails its predecessor by two slices) -- whatever the engine is given
+// afterwards runs after the payload is in place; gives up after HPS_RING_TIMEOUT_S.
+extern "C" int hps_ring_engine_wait (void* handle, void* engine, void* done_event)
+{
+    Ring* R = static_cast<Ring*>(handle);
+    HPS_REQUIRE(R && engine && done_event, "hps_ring_engine_wait: null argument");
+    if (R->kind != 1) return hps_engine_wait_event(engine, done_event);
+    const Ticket* t = static_cast<const Ticket*>(done_event);
+    HPS_REQUIRE(t->magic == kTicketMagic, "hps_ring_engine_wait: not a receive of this ring");
+    Mailbox* m = R->box_in.m;
+    const unsigned long long seq = t->seq;
+    return ipc_wait(R, [&] { return ld_acq(&m->landed.v) >= seq; }, &m->sender_gone, ring_timeout_env(), "hps_ring_engine_wait");
 }
 
 extern "C" int hps_ring_stats (void* handle, long* n_sent, long* n_received, long long* bytes_sent, long long* bytes_received)
@@ -361,6 +681,16 @@ extern "C" int hps_ring_info (void* handle, int* world, int* comm_in_ranks, int*
     HPS_REQUIRE(R, "hps_ring_info: null ring");
     auto count = [](ncclComm_t c) { int n = -1; if (!c) return 0; if (g_rccl.CommCount && g_rccl.CommCount(c, &n) != 0) n = -1; return n; };
     auto urank = [](ncclComm_t c) { int n = -1; if (!c) return -1; if (g_rccl.CommUserRank && g_rccl.CommUserRank(c, &n) != 0) n = -1; return n; };
+    if (R->kind == 1) {
+        // ipc edge: 2 = both ends of the edge's mailbox are attached (0 and 1 for the one-rank ring, as the RCCL self ring)
+        const bool multi = R->world > 1;
+        if (world) *world = R->world;
+        if (comm_in_ranks) *comm_in_ranks = multi ? (R->box_in.m && R->box_in.m->sender_attached.load() && R->box_in.m->receiver_attached.load() ? 2 : 1) : 0;
+        if (comm_out_ranks) *comm_out_ranks = multi ? (R->box_out.m && R->box_out.m->sender_attached.load() && R->box_out.m->receiver_attached.load() ? 2 : 1) : 1;
+        if (my_rank_in) *my_rank_in = multi ? 1 : -1;
+        if (my_rank_out) *my_rank_out = 0;
+        return HPS_OK;
+    }
     if (world) *world = R->world;
     if (comm_in_ranks) *comm_in_ranks = count(R->comm_in);
     if (comm_out_ranks) *comm_out_ranks = count(R->world == 1 ? R->comm_self : R->comm_out);
@@ -376,6 +706,13 @@ extern "C" int hps_ring_destroy (void* handle)
     (void)hipSetDevice(R->device);
     if (R->st_send) (void)hipStreamSynchronize(R->st_send);
     if (R->st_recv) (void)hipStreamSynchronize(R->st_recv);
+    if (R->kind == 1) {
+        if (R->box_out.m && R->world > 1) R->box_out.m->sender_gone.store(1);
+        if (R->box_in.m) R->box_in.m->receiver_gone.store(1);
+        for (void* p : R->peer_arena) if (p) (void)hipIpcCloseMemHandle(p);
+        box_unmap(R->box_in);
+        box_unmap(R->box_out);
+    }
     if (R->comm_out) g_rccl.CommDestroy(R->comm_out);
     if (R->comm_in) g_rccl.CommDestroy(R->comm_in);
     if (R->comm_self) g_rccl.CommDestroy(R->comm_self);

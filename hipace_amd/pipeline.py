@@ -67,6 +67,8 @@ class GlooTransport:
         if ev is not None and not ev.is_completed():
             ev.wait()
 
+    engine_wait_sent = engine_wait      # (a send's request: the message buffer may be reused)
+
     def engine_wait_ordered(self, engine, evs):
         for ev in evs:
             self.engine_wait(engine, ev)
@@ -98,25 +100,37 @@ class GlooTransport:
         pass
 
 
-class RcclTransport:
-    """The C-ABI ring (include/hpslice.h hps_ring_*): RCCL ncclSend / ncclRecv on device buffers, one 2-rank communicator
-    and one stream per ring edge.  Bootstrap: every rank makes the id of its outgoing edge, all ids are exchanged through
-    the torch.distributed group (any backend), hps_ring_init is collective."""
+def ring_edge():
+    """Kind of edge the C-ABI ring makes (HPS_RING_EDGE, read by hps_ring_unique_id): "ipc" (default: peer copies ordered
+    through a shared-memory mailbox; one node, any device assignment -- also several ranks on ONE device) or "rccl"."""
+    return "rccl" if os.environ.get("HPS_RING_EDGE", "") == "rccl" else "ipc"
 
-    def __init__(self, rank, world, device_index, group=None):
+
+class RingTransport:
+    """The C-ABI ring (include/hpslice.h hps_ring_*), one edge object and one stream per ring edge.  Two kinds of edge under
+    the same calls: RCCL ncclSend / ncclRecv on device buffers (one 2-rank communicator per edge), or -- HPS_RING_EDGE=ipc,
+    the default -- a peer copy into the receiver's buffer (hipIpc memory handles) ordered through a mailbox in shared memory.
+    Bootstrap: every rank makes the id of its outgoing edge, all ids are exchanged through the torch.distributed group (any
+    backend), hps_ring_init is collective."""
+
+    def __init__(self, rank, world, device_index, group=None, edge=None):
         from . import _lib
-        if world > 1:
+        if edge is not None:                                    # (the library reads the variable when the edge's id is made)
+            assert edge in ("ipc", "rccl")
+            os.environ["HPS_RING_EDGE"] = edge
+        if world > 1 and ring_edge() == "rccl":
             # hardware queues (see _lib._ring_environment): the variable must have been in the environment before HIP started
-            import os
-            if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8 and os.environ.get("HPS_RING_ALLOW_SHARED_QUEUES", "0") in ("", "0"):
+            override = os.environ.get("HPS_RING_ALLOW_SHARED_QUEUES", "0") not in ("", "0")
+            if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8 and not override:
                 if _lib.hip_already_started():
-                    raise RuntimeError("RcclTransport: a ring of %d ranks needs GPU_MAX_HW_QUEUES >= 8 in the environment BEFORE the "
-                                       "process touches the GPU (export it in the launcher, or import hipace_amd._lib under WORLD_SIZE > 1 "
-                                       "before torch.cuda is initialised); HPS_RING_ALLOW_SHARED_QUEUES=1 overrides" % world)
+                    raise RuntimeError("RingTransport: an RCCL ring of %d ranks needs GPU_MAX_HW_QUEUES >= 8 in the environment BEFORE the "
+                                       "process touches the GPU (export it in the launcher; importing hipace_amd._lib sets it under a "
+                                       "multi-rank launcher, but this process had already created an engine or initialised torch.cuda); "
+                                       "HPS_RING_ALLOW_SHARED_QUEUES=1 overrides, HPS_RING_EDGE=ipc needs none of this" % world)
                 os.environ["GPU_MAX_HW_QUEUES"] = "8"
-            elif not _lib._HWQ_PRESET and _lib._HIP_STARTED_AT_IMPORT:
-                raise RuntimeError("RcclTransport: GPU_MAX_HW_QUEUES was set after torch had initialised the device -- the runtime did "
-                                   "not see it; export it in the launcher's environment")
+            elif not _lib._HWQ_PRESET and _lib._HIP_STARTED_AT_IMPORT and not override:
+                raise RuntimeError("RingTransport: GPU_MAX_HW_QUEUES was set after torch had initialised the device -- the runtime did "
+                                   "not see it; export it in the launcher's environment (HPS_RING_ALLOW_SHARED_QUEUES=1 overrides)")
         self._lib, self._check = _lib.lib(), _lib.check
         self.rank, self.world = rank, world
         my = C.create_string_buffer(128)
@@ -130,6 +144,8 @@ class RcclTransport:
         self._check(self._lib.hps_ring_init(rank, world, int(device_index), ids[(rank - 1) % world] if world > 1 else None,
                                             ids[rank], C.byref(h)))
         self._h = h
+        self.kind = "ipc" if self._lib.hps_ring_edge_kind(h) == 1 else "rccl"
+        self._polls = self.kind == "ipc" and world > 1       # the host asks before it waits (several stages per thread)
 
     def send(self, t, after_event=None, slot=0):
         done = C.c_void_p()
@@ -151,6 +167,13 @@ class RcclTransport:
         return done.value
 
     def engine_wait(self, engine, ev):
+        """order the engine's stream behind a received message (RCCL: a device-side wait for the receive's event; ipc: the
+        host waits -- not at all in steady state -- until the sender's stream has flagged the message as landed)"""
+        if ev:
+            self._check(self._lib.hps_ring_engine_wait(self._h, engine._h, C.c_void_p(ev)))
+
+    def engine_wait_sent(self, engine, ev):
+        """the engine's stream waits for a send's done-event (a device event with either kind of edge): the buffer may be rewritten"""
         engine.wait_event(ev)
 
     def engine_wait_ordered(self, engine, evs):
@@ -159,10 +182,17 @@ class RcclTransport:
             self.engine_wait(engine, evs[-1])
 
     def ready(self, ev):
-        return True
+        """has the message behind this receive landed?  (RCCL edge: the engine's stream waits on the device -- always go on)"""
+        if not self._polls:
+            return True
+        r = self._lib.hps_ring_recv_landed(self._h, C.c_void_p(ev))
+        if r < 0:
+            raise RuntimeError("hps_ring_recv_landed: not a receive of this ring")
+        return r == 1
 
     def can_send(self):
-        return True
+        """would the next send go out without the host waiting for the receiver (its receive posted, the buffer free)?"""
+        return (not self._polls) or self._lib.hps_ring_can_send(self._h) == 1
 
     def recv_after(self, ev):
         if ev:
@@ -194,7 +224,10 @@ class RcclTransport:
         self.close()
 
 
-class RcclSelfRing(RcclTransport):
+RcclTransport = RingTransport          # the name of rounds 2-4
+
+
+class RcclSelfRing(RingTransport):
     """One rank that is its own ring neighbour, with the hand-off going through RCCL all the same (MultiBuffer.cpp:299-308
     with the transport left in): `run_pipeline(..., transport=RcclSelfRing(device))` then runs the multi-rank code path --
     receives posted a step ahead, sends behind the engine's events, the engine waiting for receive events, buffers reused
@@ -203,8 +236,15 @@ class RcclSelfRing(RcclTransport):
     edge between two ranks), and the event the engine later waits for is looked up then."""
     self_ring = True
 
-    def __init__(self, device_index):
-        super().__init__(0, 1, device_index)
+    def __init__(self, device_index, edge="rccl"):
+        old = os.environ.get("HPS_RING_EDGE")
+        try:
+            super().__init__(0, 1, device_index, edge=edge)
+        finally:
+            if old is None:
+                os.environ.pop("HPS_RING_EDGE", None)
+            else:
+                os.environ["HPS_RING_EDGE"] = old
         self._posted, self._done, self._n_posted, self._n_sent = [], {}, 0, 0
 
     def recv(self, t, after_event=None, slot=0):
@@ -317,8 +357,21 @@ class StageTransport:
             self.rx.recv_after(ev)
 
     def ready(self, ev):
-        """has the message behind this receive ticket been sent (a local edge's tickets only; anything else is an event)?"""
-        return not (isinstance(ev, tuple) and ev and ev[0] == "loc") or ev[2] in ev[1].done
+        """has the message behind this receive ticket been sent (a local edge's tickets), has it landed (an ipc edge of the
+        ring)?  Anything else is an event the engine's stream waits for on the device."""
+        if isinstance(ev, tuple) and ev and ev[0] == "loc":
+            return ev[2] in ev[1].done
+        if isinstance(self.rx, LocalEdge) or isinstance(ev, tuple) or ev is None:
+            return True
+        return self.rx.ready(ev)
+
+    @property
+    def wait_in_tag(self):
+        return "wait" if isinstance(self.rx, LocalEdge) else "wait-ring"
+
+    @property
+    def wait_out_tag(self):
+        return "wait" if isinstance(self.tx, LocalEdge) else "wait-ring"
 
     def _resolve(self, ev):
         if isinstance(ev, tuple) and ev and ev[0] == "loc":
@@ -326,11 +379,18 @@ class StageTransport:
         return ev
 
     def engine_wait(self, engine, ev):
-        ev = self._resolve(ev)
-        if isinstance(ev, tuple):                  # a ticket of the ring transport behind rx (RcclSelfRing): only it can resolve it
+        """order the engine behind a RECEIVED message (`ev` = what recv returned)"""
+        if isinstance(self.rx, LocalEdge):
+            _wait_generic(engine, self._resolve(ev))
+        else:                                      # the ring transport behind rx: only it knows what its receive handles are
             self.rx.engine_wait(engine, ev)
-        else:
+
+    def engine_wait_sent(self, engine, ev):
+        """order the engine behind a SEND's completion (`ev` = what send returned): the message buffer may be rewritten"""
+        if isinstance(self.tx, LocalEdge) or self.tx is None:
             _wait_generic(engine, ev)
+        else:
+            self.tx.engine_wait_sent(engine, ev)
 
     def engine_wait_ordered(self, engine, evs):
         if isinstance(self.rx, LocalEdge):
@@ -341,7 +401,7 @@ class StageTransport:
 
     # ---- send side
     def can_send(self):
-        return self.tx.can_send() if isinstance(self.tx, LocalEdge) else True
+        return self.tx.can_send() if self.tx is not None else True
 
     def send(self, t, after_event=None, slot=0):
         if isinstance(self.tx, LocalEdge):
@@ -409,6 +469,8 @@ def _drive(gens, engines=None):
     tags = [None] * len(gens)
     idle_rounds = 0
     spins = 0
+    ring_wait_since = None
+    ring_timeout = float(os.environ.get("HPS_RING_TIMEOUT_S", "900") or 900)
     while live:
         worked = False
         stepped = False
@@ -418,7 +480,7 @@ def _drive(gens, engines=None):
             try:
                 stepped = True
                 tags[k] = next(gens[k])
-                worked = worked or tags[k] != "wait"
+                worked = worked or tags[k] not in ("wait", "wait-ring")
             except StopIteration as stop:
                 results[k] = stop.value
                 live.remove(k)
@@ -439,9 +501,20 @@ def _drive(gens, engines=None):
         spins = 0
         # (a stage whose slice is pending on the device is progress to come: only rounds in which every stage waits for a
         #  local edge count towards the deadlock check)
-        idle_rounds = 0 if (worked or any(tags[k] == "work" for k in live)) else idle_rounds + 1
+        idle_rounds = 0 if (worked or any(tags[k] in ("work", "wait-ring") for k in live)) else idle_rounds + 1
         if idle_rounds > 1000:
             raise RuntimeError("pipeline stages of this process wait for one another (local edges): deadlock")
+        # every stage waits, at least one of them for another process (ipc edge): fine for as long as the neighbour may take,
+        # loud when it takes longer than the ring's timeout
+        if live and not worked and all(tags[k] in ("wait", "wait-ring") for k in live):
+            now = time.perf_counter()
+            if ring_wait_since is None:
+                ring_wait_since = now
+            elif now - ring_wait_since > ring_timeout:
+                raise RuntimeError(f"pipeline stages of this process have waited {now - ring_wait_since:.0f} s for a neighbouring rank "
+                                   "(HPS_RING_TIMEOUT_S): the ring makes no progress")
+        else:
+            ring_wait_since = None
     return results
 
 
@@ -541,6 +614,9 @@ def _stage(engine, rank, world, n_steps, device, on_step_end=None, slices_per_st
     T = make_transport(rank, world, device) if own_transport else transport
     assert world == 1 or T is not None
     ring = world > 1 or bool(getattr(T, "self_ring", False))      # hand-off through the transport (else: in-process copies)
+    # what a stage yields while it waits for a neighbour: "wait" = a stage of this process (local edge; counts towards the
+    # driver's deadlock check), "wait-ring" = another process (ipc edge; bounded by HPS_RING_TIMEOUT_S)
+    tag_in, tag_out = getattr(T, "wait_in_tag", "wait-ring"), getattr(T, "wait_out_tag", "wait-ring")
     closes = n_steps > world
     f64 = dict(dtype=torch.float64, device=device)
 
@@ -639,23 +715,23 @@ def _stage(engine, rank, world, n_steps, device, on_step_end=None, slices_per_st
                     evs = [recv_ev.pop((m, j, 0), None) for j in range(imported + 1, need + 1)]
                     for ev in evs:
                         while ev is not None and not T.ready(ev[0]):
-                            yield "wait"
+                            yield tag_in
                     T.engine_wait_ordered(engine, [ev[0] for ev in evs if ev is not None])
                     imported = need
                 while imported < need:
                     imported += 1
                     ev = recv_ev.pop((m, imported, 0), None)
                     if ev is not None:
-                        while not T.ready(ev[0]):      # (a local edge: the stage ahead has not sent it yet)
+                        while not T.ready(ev[0]):      # (a local edge: the stage ahead has not sent it yet; an ipc edge: not landed)
                             _trace(rank, "wait-in", q)
-                            yield "wait"
+                            yield tag_in
                         T.engine_wait(engine, ev[0])
                         if moving:
                             engine.import_beam_slice(nz - 1 - imported, rpool[m % 2][imported])
                     if ring_laser:
                         ev, k = recv_ev.pop((m, imported, 1))
                         while not T.ready(ev):
-                            yield "wait"
+                            yield tag_in
                         T.engine_wait(engine, ev)
                         engine.import_laser_slice(nz - 1 - imported, lpool[k])
                         lpool_free[k] = engine.record_event(_EV_LFREE + k)
@@ -687,7 +763,7 @@ def _stage(engine, rank, world, n_steps, device, on_step_end=None, slices_per_st
                     if moving:
                         k = state["ns"] % len(spool)
                         state["ns"] += 1
-                        T.engine_wait(engine, spool_done[k])          # the slot's previous message has left
+                        T.engine_wait_sent(engine, spool_done[k])     # the slot's previous message has left
                         engine.export_beam_slice(islice, spool[k])
                         out.append(("b", k, spool[k]))
                     else:
@@ -699,15 +775,15 @@ def _stage(engine, rank, world, n_steps, device, on_step_end=None, slices_per_st
                     if ring_laser:
                         k = state["nls"] % len(lspool)
                         state["nls"] += 1
-                        T.engine_wait(engine, lspool_done[k])
+                        T.engine_wait_sent(engine, lspool_done[k])
                         engine.export_laser_slice(islice, lspool[k])
                         out.append(("l", k, lspool[k]))
                     if out:
                         ev = engine.record_event(_EV_SLICE + q % 64)  # the slice (its push, the exports) is done
                         for kind, k, t in out:
-                            while not T.can_send():    # (a local edge: the stage behind has not posted its receive yet)
+                            while not T.can_send():    # (the stage / rank behind has not posted its receive yet, or its buffer is in use)
                                 _trace(rank, "wait-out", q)
-                                yield "wait"
+                                yield tag_out
                             if kind == "b":
                                 spool_done[k] = T.send(t, ev, 4 * nz + k)
                             elif kind == "l":

@@ -427,7 +427,8 @@ int hps_engine_copy_async (void* handle, void* dst_dev, const void* src_dev, lon
  * One process per GPU; rank r runs time steps r, r+N, ... (Hipace.cpp:400-401) and hands every pushed beam slice (and
  * the laser envelope of the slice) to rank r+1.  The reference does that with MPI_Isend / MPI_Irecv between ring
  * neighbours (MultiBuffer::make_progress :287-442, put_data :444-493, get_data :495-609); here it is RCCL
- * ncclSend / ncclRecv over xGMI on device buffers.  Every edge r -> r+1 of the ring is its own 2-rank communicator
+ * ncclSend / ncclRecv over xGMI on device buffers (HPS_RING_EDGE=rccl), or peer copies through a mailbox (the default,
+ * described behind hps_ring_destroy below).  Every edge r -> r+1 of the ring is its own 2-rank communicator
  * with its own stream, so sends and receives of a rank progress independently; ordering against the engine is by
  * events only (hps_engine_record_event / hps_engine_wait_event), never by a host synchronisation.
  *
@@ -471,6 +472,23 @@ int hps_ring_stats (void* ring, long* n_sent, long* n_received, long long* bytes
  * ring -- the evidence that N processes are on RCCL (bench.py's `rccl_ranks_seen`) */
 int hps_ring_info (void* ring, int* world, int* comm_in_ranks, int* comm_out_ranks, int* my_rank_in, int* my_rank_out);
 int hps_ring_destroy (void* ring);
+/* ---- the second kind of edge: peer copies through a shared-memory mailbox (HPS_RING_EDGE=ipc, the default; =rccl for the
+ * RCCL edge above).  For the processes of one node, on different devices or on the SAME device (RCCL refuses two ranks on
+ * one device).  hps_ring_unique_id makes the edge's mailbox (POSIX shared memory; the id is its name), hps_ring_init maps
+ * the mailboxes of both edges and waits for both neighbours (HPS_RING_CONNECT_TIMEOUT_S, default 300).  A posted receive is
+ * a descriptor in the mailbox (allocation -- exported once with hipIpcGetMemHandle --, offset, bytes) plus "buffer free",
+ * written by the receive stream behind after_event; a send is hipMemcpyAsync into the receiver's buffer plus "landed",
+ * written by the send stream: no kernel waits on the device, no requirement on hardware queues (GPU_MAX_HW_QUEUES).  What
+ * MultiBuffer does with MPI_Test polls (MultiBuffer.cpp:287-442) the host does with the three calls below.  Differences a
+ * host sees: (1) *done_event of hps_ring_recv_slice is a handle of the RING -- order an engine behind it with
+ * hps_ring_engine_wait (works for both kinds of edge), not hps_engine_wait_event; (2) hps_ring_send_slice makes the HOST wait
+ * (up to HPS_RING_TIMEOUT_S) until the matching receive is posted and free -- ask hps_ring_can_send first where the host
+ * must not block; (3) message sizes are checked: a send whose size differs from the posted receive's fails; (4) receive
+ * buffers must stay allocated until hps_ring_destroy (their allocations are mapped into the sending process). */
+int hps_ring_edge_kind (void* ring);                              /* 0 = RCCL, 1 = ipc */
+int hps_ring_can_send (void* ring);                               /* 1: the next hps_ring_send_slice will not wait on the host */
+int hps_ring_recv_landed (void* ring, void* done_event);          /* 1: that receive's message is in the buffer; 0: not yet */
+int hps_ring_engine_wait (void* ring, void* engine, void* done_event);   /* order the engine's stream behind that receive */
 
 /* ---- utilities ---------------------------------------------------------------------------- */
 int hps_memcpy_d2h (void* dst_host, const void* src_dev, long bytes);

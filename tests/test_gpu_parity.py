@@ -686,8 +686,9 @@ def test_several_steps_in_flight_on_one_gpu(api, lanes, n_steps):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("edge", ["rccl", "ipc"])
 @pytest.mark.parametrize("lanes,n_steps", [(2, 5), (3, 7)])
-def test_several_stages_per_rank_with_the_closing_edge_on_rccl(api, lanes, n_steps):
+def test_several_stages_per_rank_with_the_closing_edge_on_rccl(api, lanes, n_steps, edge):
     """What a rank of a multi-rank ring with several stages does, on the one rank a 1-GPU box has: `lanes` engines are the
     stages of this process, the edges between them are in-process copies, and the edge that closes the ring -- last stage
     -> first stage -- goes through RCCL (RcclSelfRing: ncclSend + ncclRecv on the ring's streams, the first stage's
@@ -706,7 +707,8 @@ def test_several_stages_per_rank_with_the_closing_edge_on_rccl(api, lanes, n_ste
         eng.sync()
         got[step] = eng.checksums()
 
-    T = RcclSelfRing(0)
+    T = RcclSelfRing(0, edge=edge)          # (ipc with one rank: the ring's streams and events, a device copy as the message)
+    assert T.kind == edge
     solved = run_lanes(engs, 0, 1, n_steps, torch.device("cuda", 0), on_step_end, transport=T)
     st = T.stats()
     T.close()
