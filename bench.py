@@ -362,6 +362,9 @@ def main():
         args.inflight = 1                       # (host-controlled predictor-corrector loop: the host is held once per iteration, the slice
                                                 #  has no enqueue-only first half for a one-thread driver of several engines to interleave)
     eng = api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period)
+    early_engines = None
+    if os.environ.get("BENCH_ENGINES_FIRST") == "1" and args.inflight > 1:      # (diagnostic: the stages' engines before the transport)
+        early_engines = [api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period) for _ in range(args.inflight - 1)]
     lanes = 1                                   # the headline measurement: one engine
     engines = [eng]
     if args.fuse:
@@ -378,6 +381,8 @@ def main():
             dist.barrier()
 
     def profiling(on):
+        if os.environ.get("BENCH_NO_PROFILING") == "1":             # (diagnostic)
+            return
         # short runs time every 2nd slice: only the 4 event records the roofline needs (11 would cost 4.5 % of a slice)
         for e in engines:
             e.set_profiling(on, stride=stride, light=short)
@@ -476,8 +481,11 @@ def main():
             from hipace_amd.pipeline import run_pipeline
             stamps = []
             tl = (lambda m, q: stamps.append((m, q, time.perf_counter())) if q % 64 == 0 else None) if os.environ.get("BENCH_TIMELINE") else None
-            args.steps = run_pipeline(eng, 0, 1, max(2, args.steps // nz), dev, transport=transport, handoff_batch=args.handoff_batch,
-                                      on_slice=tl)
+            if os.environ.get("BENCH_SKIP_HEADLINE") == "1":      # (diagnostic)
+                run_slices(64)
+            else:
+                args.steps = run_pipeline(eng, 0, 1, max(2, args.steps // nz), dev, transport=transport, handoff_batch=args.handoff_batch,
+                                          on_slice=tl)
             for a, b in zip(stamps, stamps[1:]):
                 print(f"timeline step {a[0]} slice {a[1]:4d}: {1e3 * (b[2] - a[2]) / 64:.4f} ms/slice", file=sys.stderr)
         elif world == 1:
@@ -525,7 +533,11 @@ def main():
     L = max(1, args.inflight)
     if L > 1:
         from hipace_amd.pipeline import run_lanes
-        lane_engines = [eng] + [api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period) for _ in range(L - 1)]
+        lane_engines = [eng] + (early_engines or [api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period) for _ in range(L - 1)])
+        if os.environ.get("BENCH_LANES_FRESH_ENGINES") == "1":      # (diagnostic)
+            lane_engines[0] = api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period)
+        if os.environ.get("BENCH_LANES_FRESH_TRANSPORT") == "1" and args.ring_self:
+            transport = RcclSelfRing(local, edge=ring_edge())
         if args.fuse:
             for e in lane_engines[1:]:
                 e.set_fusion(True)

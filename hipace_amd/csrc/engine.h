@@ -46,6 +46,7 @@ struct Engine {
     hps_geom gm{};
     int g = 0, ncomp = 0;
     hipStream_t st = nullptr;
+    bool st_pooled = false; int st_device = 0;       // the stream came from the per-device pool (engine.hip: create_engine_stream)
     hps_slab slab{};
     hps_plasma pl{};
     double* pl_real = nullptr;

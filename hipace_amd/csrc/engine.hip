@@ -11,6 +11,15 @@
 #include <limits>
 #include <atomic>
 #include <algorithm>
+#include <map>
+#include <mutex>
+
+// the engines' stream pool (see create_engine_stream)
+namespace {
+std::mutex g_pool_mutex;
+std::map<int, std::vector<hipStream_t>> g_stream_pool;      // device -> streams not in use
+std::map<int, bool> g_pool_made;
+}
 
 namespace hps {
 
@@ -353,7 +362,11 @@ Engine::~Engine ()
     if (st_laser) (void)hipStreamDestroy(st_laser);
     if (ev_lfork) (void)hipEventDestroy(ev_lfork);
     if (ev_ldone) (void)hipEventDestroy(ev_ldone);
-    if (st) (void)hipStreamDestroy(st);
+    if (st && st_pooled) {
+        (void)hipStreamSynchronize(st);
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        g_stream_pool[st_device].push_back(st);
+    } else if (st) (void)hipStreamDestroy(st);
 }
 
 static double beam_density_at (const hps_deck& d, double x, double y, double z)
@@ -473,10 +486,44 @@ int Engine::init_beam ()
 // HPS_CU_MASKS="lo-hi[+lo-hi...],..." (diagnostic): the j-th engine created in this process runs its stream on the compute
 // units of entry j % n only (hipExtStreamCreateWithCUMask).  Bit i of a mask is compute unit i / 8 of XCD i % 8 on this GPU (the
 // driver deals the bits round the XCDs first), so ranges that are multiples of 8 wide take the same number of CUs from every XCD.
-static hipError_t create_engine_stream (hipStream_t* s)
+//
+// Default: the engines' streams come from a small per-device POOL whose streams are created back to back the first time an
+// engine is created on the device.  Why: the runtime gives every stream a hardware queue when it is first used, hardware
+// queues go to the 4 pipes of the compute front end in the order they are created (queue k of the PROCESS on pipe k mod 4),
+// and two queues on one pipe do not overlap chains of short dependent kernels (the multigrid's ~30 launches of 5-10 us): two
+// stages whose queues are 4 apart take turns.  Measured on MI355X (scripts/ubench/queue_pairs.hip; profiles/r05_queue_pairs.txt,
+// r05_stage_queues.txt): three stages whose engines were created AFTER the ring's two streams sat on queues 1, 5, 6 and made
+// 1700 slices/s, created before them (queues 1, 3, 4) 2186.  With the pool the stages' queues are consecutive whatever else
+// the host creates in between.  An engine returns its stream to the pool when it is destroyed.  HPS_STREAM_POOL=<n> sets the
+// pool's size (default 4 = the number of pipes; 0 = a fresh stream per engine, as before).
+static hipError_t create_engine_stream (hipStream_t* s, int device, bool* pooled)
 {
+    *pooled = false;
     const char* v = std::getenv("HPS_CU_MASKS");
-    if (!v || !std::strchr(v, '-')) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);      // (unset, or no range in it)
+    if (!v || !std::strchr(v, '-')) {                       // (unset, or no range in it)
+        int want = 4;
+        if (const char* p = std::getenv("HPS_STREAM_POOL")) want = std::atoi(p);
+        if (want <= 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        std::vector<hipStream_t>& pool = g_stream_pool[device];
+        if (!g_pool_made[device]) {
+            g_pool_made[device] = true;
+            void* scratch = nullptr;
+            if (hipMalloc(&scratch, 256) != hipSuccess) scratch = nullptr;
+            for (int k = 0; k < want; ++k) {
+                hipStream_t t = nullptr;
+                if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess) break;
+                // the first command makes the runtime acquire the stream's hardware queue: now, in this order
+                if (scratch) { (void)hipMemsetAsync(scratch, 0, 256, t); (void)hipStreamSynchronize(t); }
+                pool.push_back(t);
+            }
+            if (scratch) (void)hipFree(scratch);
+            std::reverse(pool.begin(), pool.end());          // (handed out from the back: first created first)
+        }
+        if (pool.empty()) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);       // more engines than the pool holds
+        *s = pool.back(); pool.pop_back(); *pooled = true;
+        return hipSuccess;
+    }
     static std::atomic<int> created{0};
     std::vector<std::string> entries;
     {   std::string cur; for (const char* p = v; ; ++p) { if (*p == ',' || !*p) { entries.push_back(cur); cur.clear(); if (!*p) break; } else cur += *p; } }
@@ -523,7 +570,8 @@ int Engine::create (const hps_deck& deck, int device)
     if (d.predcorr_max_iter > 0) pc_max_iter = d.predcorr_max_iter;
     if (d.predcorr_mix > 0.0) pc_mix = d.predcorr_mix;
     HPS_HIP_CHECK(hipSetDevice(device));
-    HPS_HIP_CHECK(create_engine_stream(&st));
+    HPS_HIP_CHECK(create_engine_stream(&st, device, &st_pooled));
+    st_device = device;
     if (const char* v = std::getenv("HPS_LASER_ASYNC")) laser_async = std::atoi(v) != 0;
     if (laser_async && d.laser_on && d.laser_solver >= 1 && d.dt != 0.0) {
         // below the engine's stream: its kernels fill what the slice leaves idle, they are not to win a CU from it
