@@ -41,6 +41,8 @@ for _i, _a in enumerate(sys.argv):          # --edge ipc|rccl: the kind of edge 
         os.environ["HPS_RING_EDGE"] = sys.argv[_i + 1]
     elif _a.startswith("--edge="):
         os.environ["HPS_RING_EDGE"] = _a.split("=", 1)[1]
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("HPS_RING_TIMEOUT_S", "300")      # a ring that stops making progress fails loudly well inside the driver's limit
 if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("HPS_RING_EDGE", "ipc") == "rccl":
     # RCCL edges only.  Before HIP starts: the engine's stream, the ring's send and receive streams and torch's own streams must not end up
     # sharing a hardware queue (a send queued behind a receive that waits for its data would close a circle around the ring)
@@ -129,6 +131,37 @@ def pmc_slice_bytes():
             if r["kernel"].startswith("void hps::k_deposit_tiled<2, 16, 51"):
                 nsl = int(r["launches"])
     return tot / nsl if nsl else None
+
+
+PHASE_OF_KERNEL = (("k_deposit_tiled", "deposit_current"), ("k_explicit_tiled", "explicit_deposit"), ("k_advance", "advance_plasma"),
+                   ("k_dst_", "poisson"), ("k_transpose", "poisson"), ("rocfft", "poisson"), ("k_dense", "poisson"),
+                   ("k_smooth", "mg_solve1"), ("k_lower", "mg_solve1"), ("k_copy2", "mg_solve1"), ("k_post_norms", "mg_solve1"),
+                   ("k_permute", "sort"), ("k_cell_keys", "sort"), ("k_rank_keys", "sort"), ("k_tile_", "sort"), ("k_run_starts", "sort"),
+                   ("rocprim", "sort"))
+
+
+def pmc_phase_bytes():
+    """HBM bytes per slice of every PHASE of the slice (the engine's phase timers: deposit_current, poisson, explicit_deposit,
+    mg_solve1, advance_plasma, sort, other) from the committed --pmc summary: the kernels of a phase by name, launches x
+    (FETCH_SIZE x2 + WRITE_SIZE) / slices of that run, as pmc_slice_bytes.  None without a summary."""
+    import csv
+    path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
+    if not os.path.exists(path):
+        return None
+    tot, nsl = {}, 0
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            try:
+                b = (2.0 * float(r["FETCH_SIZE_raw_per_launch"]) + float(r["WRITE_SIZE_raw_per_launch"])) * 1024.0
+            except ValueError:
+                continue
+            if b != b:
+                continue
+            ph = next((p for key, p in PHASE_OF_KERNEL if key in r["kernel"]), "other")
+            tot[ph] = tot.get(ph, 0.0) + b * int(r["launches"])
+            if r["kernel"].startswith("void hps::k_deposit_tiled<2, 16, 51"):
+                nsl = int(r["launches"])
+    return {k: v / nsl for k, v in tot.items()} if nsl else None
 
 
 def cpu_baseline(n, ppc, nslices, threads):
@@ -222,13 +255,17 @@ def main():
                          "every 7th / 32nd / 128th slice timed).  0 = 16 for whole boxes, 2 "
                          "when fewer than 64 slices are timed (4 event records per timed slice there: 1464 / 1476 / 1485 slices/s with "
                          "every / every 2nd / every 4th of 20 slices timed)")
+    ap.add_argument("--phase-window", type=int, default=32,
+                    help="--steps < nz, N = 1: slices of an extra window behind the timed region that is run with the full phase timers "
+                         "(11 event records per slice) to fill phase_ms_per_slice / roofline.per_kernel; 0 = none")
     ap.add_argument("--inflight", type=int, default=3,
                     help="second measurement: L time steps in flight on the GPU (hipace_amd/pipeline.py::run_lanes: L engines on L "
                          "streams driven by one host thread, step s+1 trails step s by the per-slice beam hand-off) -> "
                          "value_steps_in_flight; `value` is always the one-engine number.  1 = skip.  N > 1: L stages per rank on "
-                         "the ring, only with --inflight-ring")
-    ap.add_argument("--inflight-ring", action="store_true",
-                    help="N > 1: also time --inflight stages per rank on the RCCL ring (world x L stages)")
+                         "the ring (world x L stages)")
+    ap.add_argument("--inflight-ring", action="store_true", help="(default since round 5; kept for old command lines)")
+    ap.add_argument("--one-stage-per-rank", action="store_true",
+                    help="N > 1: skip the second measurement (--inflight stages per rank on the ring, world x L stages)")
     ap.add_argument("--laser-solver", choices=["fft", "multigrid"], default="fft",
                     help="--config5: lasers.solver_type (multigrid = hpmg system type 2, the reference's default)")
     ap.add_argument("--config5", action="store_true",
@@ -354,17 +391,12 @@ def main():
         args.inflight = 1
     if args.steps <= 0:
         args.steps = nz                         # one whole box of the deck that is timed (config 5: all 2048 slices, the pulse included)
-    if world > 1 and not args.inflight_ring:
-        args.inflight = 1
-    if args.fuse and os.environ.get("BENCH_FUSE_INFLIGHT", "0") != "1":
+    if world > 1 and args.one_stage_per_rank:
         args.inflight = 1
     if args.config2 and os.environ.get("HPS_PC_SPECULATE", "1") == "0":
         args.inflight = 1                       # (host-controlled predictor-corrector loop: the host is held once per iteration, the slice
                                                 #  has no enqueue-only first half for a one-thread driver of several engines to interleave)
     eng = api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period)
-    early_engines = None
-    if os.environ.get("BENCH_ENGINES_FIRST") == "1" and args.inflight > 1:      # (diagnostic: the stages' engines before the transport)
-        early_engines = [api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period) for _ in range(args.inflight - 1)]
     lanes = 1                                   # the headline measurement: one engine
     engines = [eng]
     if args.fuse:
@@ -381,8 +413,6 @@ def main():
             dist.barrier()
 
     def profiling(on):
-        if os.environ.get("BENCH_NO_PROFILING") == "1":             # (diagnostic)
-            return
         # short runs time every 2nd slice: only the 4 event records the roofline needs (11 would cost 4.5 % of a slice)
         for e in engines:
             e.set_profiling(on, stride=stride, light=short)
@@ -399,6 +429,7 @@ def main():
         transport = RcclSelfRing(local, edge=ring_edge())
 
     clock = {}
+    phases_timed = phase_window = None
     stats0 = {}
     timed_first = 0
     if short:
@@ -451,6 +482,17 @@ def main():
                          handoff_batch=args.handoff_batch)
         barrier()
         dt = clock["t1"] - clock["t0"]
+        if world == 1 and args.phase_window > 0 and counts[0] + args.phase_window <= nz:
+            # the driver's short run times the slices with the light timers (the deposition only: 4 event records per timed
+            # slice); the split of a slice over its phases comes from one more window AFTER the timed region, every slice of
+            # it with all 11 event records -- not part of `value`
+            phases_timed = eng.phase_times()
+            eng.set_profiling(True, stride=1, light=False)
+            for q in range(counts[0], counts[0] + args.phase_window):
+                eng.solve_slice(nz - 1 - q)
+            eng.sync()
+            phase_window = dict(zip(("ms", "slices"), eng.phase_times()), first=counts[0], last=counts[0] + args.phase_window - 1)
+            eng.set_profiling(True, stride=stride, light=True)       # (cleared: phase_times below reads what is kept here)
     else:
         def run_slices(count):
             done = 0
@@ -481,11 +523,8 @@ def main():
             from hipace_amd.pipeline import run_pipeline
             stamps = []
             tl = (lambda m, q: stamps.append((m, q, time.perf_counter())) if q % 64 == 0 else None) if os.environ.get("BENCH_TIMELINE") else None
-            if os.environ.get("BENCH_SKIP_HEADLINE") == "1":      # (diagnostic)
-                run_slices(64)
-            else:
-                args.steps = run_pipeline(eng, 0, 1, max(2, args.steps // nz), dev, transport=transport, handoff_batch=args.handoff_batch,
-                                          on_slice=tl)
+            args.steps = run_pipeline(eng, 0, 1, max(2, args.steps // nz), dev, transport=transport, handoff_batch=args.handoff_batch,
+                                      on_slice=tl)
             for a, b in zip(stamps, stamps[1:]):
                 print(f"timeline step {a[0]} slice {a[1]:4d}: {1e3 * (b[2] - a[2]) / 64:.4f} ms/slice", file=sys.stderr)
         elif world == 1:
@@ -497,7 +536,7 @@ def main():
             args.steps = run_pipeline(eng, rank, world, world * steps_per_rank, dev, transport=transport, handoff_batch=args.handoff_batch)
         barrier()
         dt = time.perf_counter() - t0
-    phases, nprof = eng.phase_times()
+    phases, nprof = phases_timed if phases_timed is not None else eng.phase_times()
     eng.set_profiling(False)
     for e in engines[1:]:            # phase times: mean over the lanes (intervals overlap in wall time)
         ph, n = e.phase_times()
@@ -531,13 +570,10 @@ def main():
         progress["phase"] = "steps-in-flight run"
     inflight = None
     L = max(1, args.inflight)
-    if L > 1:
+
+    def measure_in_flight():
         from hipace_amd.pipeline import run_lanes
-        lane_engines = [eng] + (early_engines or [api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period) for _ in range(L - 1)])
-        if os.environ.get("BENCH_LANES_FRESH_ENGINES") == "1":      # (diagnostic)
-            lane_engines[0] = api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period)
-        if os.environ.get("BENCH_LANES_FRESH_TRANSPORT") == "1" and args.ring_self:
-            transport = RcclSelfRing(local, edge=ring_edge())
+        lane_engines = [eng] + [api.SliceEngine(deck, device=local, tile_size=args.tile, sort_period=args.sort_period) for _ in range(L - 1)]
         if args.fuse:
             for e in lane_engines[1:]:
                 e.set_fusion(True)
@@ -608,6 +644,18 @@ def main():
                 "note": "one stage's counter bytes per slice (profiles/" + PMC_SUMMARY + ") over the GPU's time per slice with all stages "
                         "in flight; the aggregate counter run of the L-stage window is profiles/r04g_inflight_pmc.csv"}
         del lane_engines[1:]
+        return inflight
+
+    if L > 1:
+        try:
+            inflight = measure_in_flight()
+        except Exception as exc:      # noqa: BLE001
+            # N > 1: the headline number must not be lost with the second measurement (a ring that times out raises here)
+            if world == 1:
+                raise
+            import traceback
+            traceback.print_exc()
+            inflight = dict(value=None, stages_per_gpu=L, error=f"{type(exc).__name__}: {exc}")
 
     if rank == 0:
         total = args.steps * world
@@ -622,8 +670,14 @@ def main():
         overhead = per_kernel.pop("empty_interval", 0.0)
         raw = per_kernel[dom]
         kernel_ms = max(raw - overhead, 0.0) if lanes == 1 else raw
-        if short:       # light timers: only the deposition was timed
+        if short:       # light timers: only the deposition was timed; the rest of the split from the window behind the timed region
             per_kernel = {k: (v if k == dom else None) for k, v in per_kernel.items()}
+            if phase_window is not None:
+                pw = {k: v / max(phase_window["slices"], 1) for k, v in phase_window["ms"].items()}
+                ov_w = pw.pop("empty_interval", 0.0)
+                for k in per_kernel:
+                    if k != dom:
+                        per_kernel[k] = pw.get(k)
         achieved = ab[dom] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         headline = args.tile == 16 and args.n == 1024 and args.ppc == 2 and not args.config5 and not args.config2
         traffic, traffic_source = pmc_traffic("void hps::k_deposit_tiled<2, 16, 51") if headline else (None, None)
@@ -658,6 +712,9 @@ def main():
             "fused_push_deposit": bool(args.fuse),
             "phase_ms_per_slice": per_kernel,
             "profiled_slices": nprof,
+            "phase_window": ({"first": phase_window["first"], "last": phase_window["last"], "slices": phase_window["slices"],
+                              "what": "behind the timed region, full phase timers on every slice; fills phase_ms_per_slice except deposit_current"}
+                             if phase_window is not None else None),
             "vcycles_per_slice": (st1["vcycles"] - stats0.get("vcycles", 0)) / nsl,
             "laser_vcycles_per_slice": (snap["laser_vc"] / max(st1["slices"], 1)) if args.config5 else None,
             "pc_iterations_per_slice": snap["pc"] / max(st1["slices"], 1) if args.config2 else None,
@@ -671,10 +728,6 @@ def main():
             "rccl_ranks_seen": rccl_ranks_seen if (transport is not None and transport.kind == "rccl") else None,
             "ranks_on_one_device": bool(args.same_device) if world > 1 else None,
             "stages_per_rank_on_the_ring": (max(1, args.inflight) if (world > 1 or args.ring_self) else None),
-            "stages_per_rank_note": ("N > 1 runs ONE stage per rank unless --inflight-ring: with the closing edge of a 3-stage rank through RCCL "
-                                     "(one rank, --ring-self --inflight 3) the three stages made 1710 slices/s against 2110 with all edges in the "
-                                     "process, two stages 1876 against 1995 (profiles/r04_ring_self_stages.txt); results equal either way")
-                                    if world > 1 and not args.inflight_ring else None,
             "roofline": {"bound": "hbm", "kernel": "k_deposit_tiled<2,%d>" % args.tile if args.tile else "k_deposit_current<2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": kernel_ms,
@@ -687,6 +740,34 @@ def main():
                          "duration_source": f"HIP events on the engine's stream around the kernel, {nprof} launches of the timed region, "
                                             "minus the interval between two back-to-back event records measured on the same slices"},
         }
+        if not (args.config5 or args.config2) and all(per_kernel.get(k) is not None for k in ("poisson", "explicit_deposit", "mg_solve1", "advance_plasma")):
+            # every phase of the slice against the HBM roofline, not only the deposition: time per slice (HIP events around the
+            # phase, one empty event interval subtracted), SURVEY 8(d)'s algorithmic bytes, the committed counter bytes
+            nv_ = (st1["vcycles"] - stats0.get("vcycles", 0)) / nsl
+            C_ = args.n * args.n
+            alg = dict(ab, mg_solve1=17 * 8 * C_ + (4.0 / 3.0) * 23 * 8 * C_ * nv_)
+            cbp = pmc_phase_bytes() if headline else None
+            ov = overhead if not short else (ov_w if phase_window is not None else 0.0)
+            rows = {}
+            for k, what in (("advance_plasma", "k_advance_tiled (gather + push)"), ("explicit_deposit", "k_explicit_tiled"),
+                            ("deposit_current", "k_deposit_tiled"), ("poisson", "3 DST solves (k_dst_rows*), sources formed in the first pass"),
+                            ("mg_solve1", "hpmg solve1: all k_smooth / k_lower launches of the Bx, By solve")):
+                ms = max(per_kernel[k] - (ov if lanes == 1 else 0.0), 0.0)
+                if k == dom:
+                    ms = kernel_ms
+                cbk = cbp.get(k) if cbp else None
+                rows[k] = {"kernels": what, "us_per_slice": 1e3 * ms, "algorithmic_bytes": alg[k],
+                           "achieved": alg[k] / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                           "frac": alg[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None,
+                           "counter_bytes": cbk, "frac_counter_bytes": cbk / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if (cbk and ms > 0) else None}
+            out["roofline"]["per_kernel"] = rows
+            out["roofline"]["dominant_by_time"] = max(rows, key=lambda k: rows[k]["us_per_slice"])
+            out["roofline"]["furthest_below_the_roofline"] = min((k for k in rows if rows[k]["frac"]), key=lambda k: rows[k]["frac"])
+            out["roofline"]["per_kernel_note"] = ("`frac` (top level) stays the deposition's, the kernel the north star prices; per_kernel has every phase: "
+                                                  "time from HIP events around the phase"
+                                                  + (f" in a window of {phase_window['slices']} slices behind the timed region (slices {phase_window['first']}-{phase_window['last']})"
+                                                     if (short and phase_window is not None) else " on the profiled slices of the timed region")
+                                                  + ", algorithmic bytes of SURVEY 8(d) (multigrid at the measured V-cycle count), counter bytes from profiles/" + PMC_SUMMARY)
         if not (args.config5 or args.config2):
             # the whole slice against the HBM roofline: bytes of the reference's pass structure and of the survey's
             # fused lower bound at the measured V-cycle count, over the measured time per slice of ONE stage

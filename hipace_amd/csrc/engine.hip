@@ -495,13 +495,16 @@ int Engine::init_beam ()
 // r05_stage_queues.txt): three stages whose engines were created AFTER the ring's two streams sat on queues 1, 5, 6 and made
 // 1700 slices/s, created before them (queues 1, 3, 4) 2186.  With the pool the stages' queues are consecutive whatever else
 // the host creates in between.  An engine returns its stream to the pool when it is destroyed.  HPS_STREAM_POOL=<n> sets the
-// pool's size (default 4 = the number of pipes; 0 = a fresh stream per engine, as before).
+// pool's size (0 = a fresh stream per engine, as before).  Default 3: with the process's null stream that is the runtime's
+// default of 4 hardware queues per priority (GPU_MAX_HW_QUEUES) -- a 4th pooled stream has to share one of those queues,
+// and two processes on one device with pools of 4 made 1249 slices/s together against 1916-1928 with pools of 0-3
+// (profiles/r05_stream_pool_two_processes.txt).  Further engines get streams of their own.
 static hipError_t create_engine_stream (hipStream_t* s, int device, bool* pooled)
 {
     *pooled = false;
     const char* v = std::getenv("HPS_CU_MASKS");
     if (!v || !std::strchr(v, '-')) {                       // (unset, or no range in it)
-        int want = 4;
+        int want = 3;
         if (const char* p = std::getenv("HPS_STREAM_POOL")) want = std::atoi(p);
         if (want <= 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
         std::lock_guard<std::mutex> lock(g_pool_mutex);
