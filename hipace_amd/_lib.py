@@ -184,6 +184,7 @@ _SIGS = {
     "hps_advance_plasma_laser": (C.c_int, [Slab, Plasma, Geom, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_void_p]),
     "hps_engine_pc_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_double)]),
+    "hps_engine_pc_zero_b_slices": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
     "hps_engine_set_diagnostics": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_set_tiling": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "hps_engine_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),

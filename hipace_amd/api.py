@@ -557,6 +557,13 @@ class SliceEngine:
         check(_lib.lib().hps_engine_pc_stats(self._h, C.byref(its), C.byref(err)))
         return its.value, err.value
 
+    def pc_zero_b_slices(self):
+        """slices on which the predictor-corrector loop left after one pass because sum |B| was 0 -- exactly or under the
+        engine's rounding floor (HPS_PC_NOISE_FLOOR)"""
+        n = C.c_long()
+        check(_lib.lib().hps_engine_pc_zero_b_slices(self._h, C.byref(n)))
+        return n.value
+
     def stats(self):
         vc, sl = C.c_long(), C.c_long()
         check(_lib.lib().hps_engine_stats(self._h, C.byref(vc), C.byref(sl)))

@@ -133,7 +133,7 @@ struct Engine {
     double pc_floor = 0.0;     // sum |B| below this is the exact zero of the serial path (Engine::create)
     int* d_pc_go = nullptr; bool pc_speculate = false; int pc_spec_iters = 1, pc_enqueued = 0, pc_islice = -1; double pc_base_seq = 0.0, pc_last_err = 0.0;
     int solve_slice_pc_begin (int islice); int solve_slice_pc_finish (int islice); int pc_enqueue_iteration (int it); int pc_wait_slot (int slot, double seq);
-    bool pc = false; double* d_pc = nullptr; double* d_pc_aux = nullptr; double* h_pc = nullptr; double* h_pc_dev = nullptr; double pc_seq = 0.0; long pc_iterations = 0; double pc_err_sum = 0.0;
+    bool pc = false; double* d_pc = nullptr; double* d_pc_aux = nullptr; double* h_pc = nullptr; double* h_pc_dev = nullptr; double pc_seq = 0.0; long pc_iterations = 0; double pc_err_sum = 0.0; long pc_zero_b_slices = 0;
     double pc_tol = 4e-2, pc_mix = 0.05; int pc_max_iter = 30;
     int c_aabs = -1; double* d_laser_sum = nullptr;       // laser: slab component of |a|^2, device sum of |a| (diagnostics)
     LaserState* laser = nullptr;                          // envelope arrays + solver (laser.hip)

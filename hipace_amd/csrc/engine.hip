@@ -1178,6 +1178,10 @@ void k_rel_b_error (SlabView f, int cB, int cBit, double* out, volatile double* 
                     hs[2] = dbl2{fbk, seq};       // slot 0: the fallback counter where the host's re-sort rule looks for it
                     hs += 4*it;
                 }
+                static_assert(sizeof(dbl2) == 16, "the post is one 16-byte store per {value, seq} pair");
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+                __threadfence_system();      // (no claim about single-copy atomicity of a 16-byte store to host memory elsewhere)
+#endif
                 hs[0] = dbl2{tb, seq}; hs[1] = dbl2{td, seq}; hs[2] = dbl2{fbk, seq};
             }
         }
@@ -1303,7 +1307,14 @@ int Engine::solve_slice_pc_begin (int islice)
         pc_base_seq = pc_seq;
         pc_enqueued = 0;
         const int K = std::max(1, std::min(pc_spec_iters, pc_max_iter));
-        for (int it = 1; it <= K; ++it) if ((e = pc_enqueue_iteration(it))) return e;
+        for (int it = 1; it <= K; ++it) {
+            if ((e = pc_enqueue_iteration(it))) {
+                // a failed launch with the go flags armed: nothing of this slice's loop is to be mistaken for the next slice's --
+                // sequence numbers move past whatever the iterations enqueued so far may still post
+                pc_seq = pc_base_seq + pc_max_iter + 2; pc_enqueued = 0; pc_islice = -1;
+                return e;
+            }
+        }
         return HPS_OK;
     }
     double err = 1.0;
@@ -1396,6 +1407,7 @@ int Engine::solve_slice_pc_finish (int islice)
             if ((e = pc_wait_slot(it, pc_base_seq + it))) return e;
             const volatile double* hp = h_pc + 8*it;
             err = hp[0] > 0.0 ? hp[2]/hp[0] : 0.0;
+            if (!(hp[0] > 0.0) && it == 1) ++pc_zero_b_slices;      // sum |B| exactly 0 or under Engine::pc_floor: the loop leaves after this pass
         }
         // (iterations enqueued beyond `it` find their flag at 0 and do nothing; their sequence numbers are never posted)
         pc_spec_iters = it;
@@ -1776,7 +1788,20 @@ extern "C" int hps_engine_solve_slice_begin (void* h, int islice) { return stati
 extern "C" int hps_engine_slice_ready (void* h)
 {
     Engine* E = static_cast<Engine*>(h);
-    if (E->pending_slice < 0 || E->pc) return 1;
+    if (E->pc) {
+        // device-controlled loop: ready when the host's walk over the posted errors (solve_slice_pc_finish) would not wait --
+        // an iteration that met the tolerance has been posted, or every iteration enqueued so far has
+        if (!(E->pc_speculate && E->tiling && !E->moving) || E->pc_islice < 0 || E->pc_enqueued <= 0) return 1;
+        for (int it = 1; it <= E->pc_enqueued; ++it) {
+            const volatile double* hp = E->h_pc + 8*it;
+            const double seq = E->pc_base_seq + it;
+            if (!(hp[1] == seq && hp[3] == seq && hp[5] == seq)) return 0;
+            const double err = hp[0] > 0.0 ? hp[2]/hp[0] : 0.0;
+            if (!(err > E->pc_tol) || it >= E->pc_max_iter) return 1;
+        }
+        return 1;
+    }
+    if (E->pending_slice < 0) return 1;
     return mg_solve1_ready(E->mg) ? 1 : 0;
 }
 extern "C" int hps_engine_solve_slice_finish (void* h, int islice) { return static_cast<Engine*>(h)->solve_slice_finish(islice); }
@@ -2027,6 +2052,15 @@ extern "C" int hps_engine_pc_stats (void* h, long* its, double* err_sum)
     Engine* E = static_cast<Engine*>(h);
     if (its) *its = E->pc_iterations;
     if (err_sum) *err_sum = E->pc_err_sum;
+    return HPS_OK;
+}
+// slices on which the predictor-corrector loop saw sum |B| = 0 in its first pass -- exactly, or below the engine's rounding
+// floor (Engine::pc_floor, HPS_PC_NOISE_FLOOR) -- and left after it (fields/Fields.cpp:1283)
+extern "C" int hps_engine_pc_zero_b_slices (void* h, long* n)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E && n, "hps_engine_pc_zero_b_slices: null argument");
+    *n = E->pc_zero_b_slices;
     return HPS_OK;
 }
 extern "C" int hps_engine_set_profiling (void* h, int on)

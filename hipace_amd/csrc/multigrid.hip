@@ -2011,6 +2011,7 @@ int mg_solve1_begin (void* handle, hps_slab s, int sol_comp, int rhs_comp, int a
                      int max_iters, hipStream_t st)
 {
     Multigrid* M = static_cast<Multigrid*>(handle);
+    HPS_REQUIRE(s.nstride < (1L << 27) && s.ng <= 8, "mg_solve1_begin: planes of at most 2^27 doubles and at most 8 guard cells (32-bit byte offsets in the kernels)");
     set_views(M, s, sol_comp, rhs_comp, acf_comp);
     return M->cc ? solve1_begin<true>(M, tol_rel, tol_abs, max_iters, st) : solve1_begin<false>(M, tol_rel, tol_abs, max_iters, st);
 }
@@ -2097,6 +2098,7 @@ extern "C" int hps_mg_solve1 (void* handle, hps_slab slab, int sol_comp, int rhs
     HPS_REQUIRE(sol_comp >= 0 && sol_comp + 1 < slab.ncomp && rhs_comp >= 0 && rhs_comp + 1 < slab.ncomp &&
                 acoef_comp >= 0 && acoef_comp < slab.ncomp, "hps_mg_solve1: bad component");
     HPS_REQUIRE(M->cc || slab.ng >= 1, "hps_mg_solve1: node-centred solve needs >= 1 guard cell");
+    HPS_REQUIRE(slab.nstride < (1L << 27) && slab.ng <= 8, "hps_mg_solve1: planes of at most 2^27 doubles and at most 8 guard cells (32-bit byte offsets in the kernels)");
     return mg_solve1(M, slab, sol_comp, rhs_comp, acoef_comp, tol_rel, tol_abs, max_iters, iters_host, resnorm_host,
                      (hipStream_t)stream);
 }

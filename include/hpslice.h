@@ -158,6 +158,8 @@ int hps_poisson_destroy (void* handle);
  * solution) and rhs are 2 ADJACENT components starting at sol_comp / rhs_comp; acoef is 1
  * component.  Blocks the host until converged (the stopping rule needs the residual norm);
  * *iters_host receives the number of V-cycles. */
+/* slab.nstride must be below 2^27 doubles (1 GB planes: the kernels address cells by 32-bit byte offsets from uniform
+ * component bases) and slab.ng at most 8: hps_mg_solve1 / hps_mg_solve1_fabs refuse anything else. */
 int hps_mg_create (int nx, int ny, double dx, double dy, void** handle);
 int hps_mg_solve1 (void* handle, hps_slab slab, int sol_comp, int rhs_comp, int acoef_comp,
                    double tol_rel, double tol_abs, int max_iters, int* iters_host,
@@ -280,6 +282,11 @@ int hps_engine_info (void* handle, int* ncomp, int* nguards, long* nparticles);
  * pointer and reads the Previous / Next planes stream-ordered between two slices without one of those two calls sees
  * them as they were before the shift; HPS_LAZY_SHIFT=0 in the environment restores the shift at the end of every slice. */
 hps_slab hps_engine_slab (void* handle);
+/* The engine's sheet: raw device pointers.  CONTRACT for a host that invalidates particles itself: clearing the valid bit of
+ * idcpu is not enough -- also store 0 to the particle's w AND psi_half.  The engine's tiled depositions take "w != 0" for
+ * the valid bit and do not read idcpu (HPS_VALID_BY_W, default on; the push under HPS_VALID_BY_PSI reads psi_half the same
+ * way): every path of the engine that invalidates a particle (QSA drop, absorbing boundary) zeroes both.  HPS_VALID_BY_W=0
+ * in the environment restores the idcpu read. */
 hps_plasma hps_engine_plasma (void* handle);
 /* the tiling of the first species as the engine holds it now (NULL with tile_size 0): for hps_tiling_info and for calling
  * the *_tiled operators on the engine's own sheet (diagnostics: scripts/deposit_variants.py); owned by the engine */
@@ -295,6 +302,13 @@ int hps_engine_stats (void* handle, long* total_vcycles, long* slices_done);
 /* predictor-corrector: iterations so far and the sum over slices of the final relative B-field error
  * (m_predcorr_avg_iterations / m_predcorr_avg_B_error of Hipace.cpp:964,1028 before the division by nz) */
 int hps_engine_pc_stats (void* handle, long* iterations, double* error_sum);
+/* Slices whose loop left after ONE pass because sum |B| was 0: exactly, or below the engine's rounding floor.  The reference's
+ * rule is relative_Bfield_error = norm_B > 0 ? diff/norm_B : 0 (fields/Fields.cpp:1283); on the serial CPU path norm_B IS 0
+ * ahead of the driver (electron and ion charge cancel term by term), a scatter with atomics leaves 1e-16 residue there.  The
+ * engine treats sum |B| <= 1e-12 mu0 c |q n0| nx ny (nx dx) -- built from the first species' deck density, so a deck whose
+ * density is 0 or lives in a profile has floor 0 = the literal rule -- as that zero (HPS_PC_NOISE_FLOOR=<relative floor>, 0 =
+ * literal rule).  This counter says how often that happened. */
+int hps_engine_pc_zero_b_slices (void* handle, long* slices);
 /* laser: index of the slab component "aabs" (-1 without a laser) and sum |a| over the slices solved in this step
  * (the "laserEnvelope" checksum; needs hps_engine_set_diagnostics; synchronises the stream) */
 int hps_engine_laser_info (void* handle, int* aabs_comp, double* envelope_abs_sum_host);

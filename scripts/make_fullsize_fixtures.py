@@ -42,6 +42,19 @@ def config5_deck(n, nz, solver, ionize=True):
     return d
 
 
+def config5_si_deck(n, nz, solver, ionize=True):
+    """BASELINE configs[4] as BASELINE names it: the .SI deck (tests/laser_blowout_wake_explicit.SI.1Rank.sh,
+    examples/blowout_wake/inputs_SI: hipace.normalized_units = 0, kp_inv = 10 um, lengths in metres, charges in C, masses in
+    kg) on n x n x nz cells over the box of config5_deck, with the same pulse, time step (c dt = 5 kp_inv) and dopant."""
+    kp_inv = 10.0e-6
+    d = decks.laser_blowout_wake_SI()
+    d.update(nx=n, ny=n, nz=nz, plasma_ppc=(2, 2), lo=(-20.0 * kp_inv, -20.0 * kp_inv, -15.0 * kp_inv),
+             hi=(20.0 * kp_inv, 20.0 * kp_inv, 6.0 * kp_inv), laser_solver=solver, dt=5.0 * kp_inv / decks.SI["c"])
+    if ionize:
+        decks.with_ion_species(d, "N", 0.2 * d["plasma_density"], ppc=(1, 1), initial_level=0, seed=5)
+    return d
+
+
 def config2_deck():
     d = decks.predictor_corrector(decks.linear_wake(), 4.0e-2, 30, 0.05)
     d.update(nx=256, ny=256, nz=512, plasma_ppc=(2, 2))
@@ -74,6 +87,11 @@ BOXES = {
                     "envelope time levels of the whole box in host memory: 26 GB at 512 slices, 103 GB at 2048): laser + N dopant, fft envelope solver"),
     "config5_mg": (lambda: config5_deck(512, 256, 2), 32,
                    "the config-5 deck on 512x512x256 cells with the multigrid envelope solver (the reference's default)"),
+    "config5_si_mg": (lambda: config5_si_deck(1024, 512, 2), 32,
+                      "BASELINE configs[4] as named -- the .SI deck (hipace.normalized_units = 0) -- at its transverse size, 512 of its "
+                      "2048 slices over the same box, with the multigrid envelope solver (lasers.solver_type default): laser + N dopant"),
+    "config5_si_fft": (lambda: config5_si_deck(512, 256, 1), 32,
+                       "the .SI config-5 deck on 512x512x256 cells with the fft envelope solver"),
 }
 
 

@@ -211,7 +211,8 @@ def test_config2_baseline_deck_whole_box_vs_oracle_fixture(api):
     for the zero it stands for (Engine::pc_floor, HPS_PC_NOISE_FLOOR), so the loop follows the CPU's path: the same number
     of iterations and the box to 1e-6.  (With the literal rule the loop iterates on the noise to max_iterations on every
     slice ahead of the driver -- 2400-2500 iterations instead of 1631 -- and enters the driver on another path: the two runs
-    then agree to per cents only; gpurun_out/r04/fullsize_tests*.log of round 4.)"""
+    then agree to per cents only: profiles/r04_config2_literal_rule.json against r04_config2_noise_floor.json; the measured deviations
+    of the shipped build: profiles/r05_fullsize_config2.json.)"""
     fx, got = _run_box(api, "config2")
     bad, worst, worst_trace = _compare(fx, got, int_keys=("n_valid", "n_particles", "pc_iterations"), soft_int_keys=())
     print(f"config2 (BASELINE deck): worst checksum deviation {worst:.2e}, worst plane-sum deviation {worst_trace:.2e}, PC iterations "
@@ -219,10 +220,14 @@ def test_config2_baseline_deck_whole_box_vs_oracle_fixture(api):
     assert not bad, bad[:10]
 
 
-@pytest.mark.parametrize("name", ["config5_fft", "config5_mg"])
+@pytest.mark.parametrize("name", ["config5_fft", "config5_mg", "config5_si_fft", "config5_si_mg"])
 def test_config5_whole_box_vs_oracle_fixture(api, name):
     """BASELINE configs[4] (laser envelope + N dopant with ADK ionisation), at the sizes the oracle's three envelope time
-    levels fit host memory (see the fixture's `what`)."""
+    levels fit host memory (see the fixture's `what`): in normalised units and -- as BASELINE names the deck -- in SI units
+    (tests/laser_blowout_wake_explicit.SI.1Rank.sh; hipace.normalized_units = 0), the latter at 1024^2 with the multigrid
+    envelope solver (the reference's default, laser/MultiLaser.cpp:430-608)."""
+    if not os.path.exists(os.path.join(GOLD, f"fullsize_{name}.json")):
+        pytest.skip(f"fixture fullsize_{name}.json not generated (scripts/make_fullsize_fixtures.py)")
     fx, got = _run_box(api, name)
     bad, worst, worst_trace = _compare(fx, got, int_keys=("n_valid", "n_particles", "n_ionized", "ion_level_sum"),
                                        soft_int_keys=("vcycles", "laser_vcycles"))

@@ -294,9 +294,11 @@ def test_full_size_properties(api):
     assert res.abs().max().item() <= 1e-8 * R.abs().max().item() * 1.0001
 
 
-@pytest.mark.parametrize("n,nsl", [(512, 6), (1024, 3)])
+@pytest.mark.parametrize("n,nsl", [(512, 6), (1024, 3), (1023, 3)])
 def test_baseline_blowout_configs_head_slices(api, oracle, n, nsl):
-    """BASELINE configs 3 and 4 at their full transverse size (blowout_wake n x n x 1024, 4 ppc, explicit solver):
+    """BASELINE configs 3 and 4 at their full transverse size (blowout_wake n x n x 1024, 4 ppc, explicit solver) -- and the
+    grid the reference recommends, 2^N - 1 = 1023 cells per side (docs/source/run/parameters.rst:313-321: length-1024
+    transforms, node-centred multigrid coarsening) --:
     a few slices through the driver against the oracle -- every slab component and the V-cycle count.  Both engines
     start on a slice one sigma ahead of the beam centre (the static beam blocks are addressed by slice), where the
     fields are strong from the first slice on.  (The whole box would take the oracle 20 min to 1 h; the decks'
