@@ -129,6 +129,9 @@ __device__ __forceinline__ void load_region (double* img, const SlabView& f, con
 #ifndef HPS_DEP_PAD
 #define HPS_DEP_PAD 0
 #endif
+#ifndef HPS_DEP_FAST_RCP
+#define HPS_DEP_FAST_RCP 0
+#endif
 #ifndef HPS_DEP_NB
 #define HPS_DEP_NB 4
 #endif
@@ -237,7 +240,13 @@ void k_deposit_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
         const uint64_t id = cur.id;
         if (!(id & HPS_ID_VALID)) continue;
         if (k.can_ionize && cur.ion == 0) continue;      // a neutral atom deposits nothing (every term carries its level)
+#if HPS_DEP_FAST_RCP
+        // v_rcp_f64 + one Newton step (as the push: particle_math.h fast_rcp) instead of the IEEE division's eleven
+        // instructions; psi = 0 must still give the inf the QSA test below drops the particle on (Newton would make it a NaN)
+        const double psi_inv = cur.psi != 0.0 ? fast_rcp(cur.psi) : __builtin_huge_val();
+#else
         const double psi_inv = 1.0/cur.psi;      // (IEEE: the QSA test below must see inf for psi = 0)
+#endif
         const double vx_c = cur.ux*psi_inv;
         const double vy_c = cur.uy*psi_inv;
         double q_invvol = k.a*cur.w;
