@@ -43,8 +43,8 @@ for _i, _a in enumerate(sys.argv):          # --edge ipc|rccl: the kind of edge 
         os.environ["HPS_RING_EDGE"] = _a.split("=", 1)[1]
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     os.environ.setdefault("HPS_RING_TIMEOUT_S", "300")      # a ring that stops making progress fails loudly well inside the driver's limit
-if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("HPS_RING_EDGE", "ipc") == "rccl":
-    # RCCL edges only.  Before HIP starts: the engine's stream, the ring's send and receive streams and torch's own streams must not end up
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "--same-device" not in sys.argv:
+    # For RCCL edges -- HPS_RING_EDGE=rccl, or the fall-back of a ring whose ipc probe message fails (RingTransport).  Before HIP starts: the engine's stream, the ring's send and receive streams and torch's own streams must not end up
     # sharing a hardware queue (a send queued behind a receive that waits for its data would close a circle around the ring)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if "--config5" not in sys.argv:

@@ -133,6 +133,25 @@ class RingTransport:
                                    "not see it; export it in the launcher's environment (HPS_RING_ALLOW_SHARED_QUEUES=1 overrides)")
         self._lib, self._check = _lib.lib(), _lib.check
         self.rank, self.world = rank, world
+        self._h = None
+        self._connect(rank, world, device_index, group)
+        if world > 1 and self.kind == "ipc" and edge is None and os.environ.get("HPS_RING_NO_PROBE", "0") in ("", "0"):
+            # One small message around the ring before anything is timed: it opens the next rank's allocation in this process
+            # (hipIpcOpenMemHandle + peer access, first use) and proves that a peer copy and its flags arrive.  If any rank
+            # cannot (a node whose devices have no peer access, a runtime without IPC) ALL ranks fall back to the RCCL edge
+            # together -- decided through the torch.distributed group, loudly.
+            ok = self._probe(device_index)
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 0:
+                import sys
+                print(f"hipace_amd.pipeline: rank {rank}: the ipc edge's probe message failed on some rank ({'here: ' + self._probe_error if not ok else 'not here'}); "
+                      "all ranks fall back to HPS_RING_EDGE=rccl", file=sys.stderr, flush=True)
+                self.close()
+                os.environ["HPS_RING_EDGE"] = "rccl"
+                self._connect(rank, world, device_index, group)
+
+    def _connect(self, rank, world, device_index, group):
         my = C.create_string_buffer(128)
         self._check(self._lib.hps_ring_unique_id(my))
         ids = [None] * world
@@ -146,6 +165,38 @@ class RingTransport:
         self._h = h
         self.kind = "ipc" if self._lib.hps_ring_edge_kind(h) == 1 else "rccl"
         self._polls = self.kind == "ipc" and world > 1       # the host asks before it waits (several stages per thread)
+
+    def _probe(self, device_index, seconds=90.0):
+        """one 4 KB message to the next rank and one from the previous rank, checked; False (and self._probe_error) on any failure"""
+        old = os.environ.get("HPS_RING_TIMEOUT_S")
+        os.environ["HPS_RING_TIMEOUT_S"] = str(int(seconds))
+        self._probe_error = ""
+        try:
+            dev = torch.device("cuda", int(device_index))
+            rx = torch.zeros(512, dtype=torch.float64, device=dev)
+            tx = torch.arange(512, dtype=torch.float64, device=dev) + 1000.0 * self.rank
+            torch.cuda.synchronize(dev)
+            ev = self.recv(rx, None, slot=(1 << 19))
+            self.send(tx, None, slot=(1 << 19))
+            t0 = time.perf_counter()
+            while not self.ready(ev):
+                if time.perf_counter() - t0 > seconds:
+                    raise RuntimeError(f"no probe message from rank {(self.rank - 1) % self.world} after {seconds:.0f} s")
+            self.sync_sends()
+            torch.cuda.synchronize(dev)
+            want = torch.arange(512, dtype=torch.float64, device=dev) + 1000.0 * ((self.rank - 1) % self.world)
+            if not bool((rx == want).all()):
+                raise RuntimeError("the probe message arrived with the wrong contents")
+            self._probe_buffers = (rx, tx)        # (the allocation stays mapped in the neighbour until the ring is destroyed)
+            return True
+        except Exception as exc:      # noqa: BLE001
+            self._probe_error = f"{type(exc).__name__}: {exc}"
+            return False
+        finally:
+            if old is None:
+                os.environ.pop("HPS_RING_TIMEOUT_S", None)
+            else:
+                os.environ["HPS_RING_TIMEOUT_S"] = old
 
     def send(self, t, after_event=None, slot=0):
         done = C.c_void_p()
@@ -205,9 +256,12 @@ class RingTransport:
         self._check(self._lib.hps_ring_sync(self._h))
 
     def stats(self):
+        """messages and bytes of the run (the probe message of the constructor, one each way, is not counted)"""
         ns, nr, bs, br = C.c_long(), C.c_long(), C.c_longlong(), C.c_longlong()
         self._check(self._lib.hps_ring_stats(self._h, C.byref(ns), C.byref(nr), C.byref(bs), C.byref(br)))
-        return dict(sent=ns.value, received=nr.value, bytes_sent=bs.value, bytes_received=br.value)
+        p = 1 if getattr(self, "_probe_buffers", None) is not None else 0
+        return dict(sent=ns.value - p, received=nr.value - p, bytes_sent=bs.value - 4096 * p, bytes_received=br.value - 4096 * p,
+                    probe_messages=p)
 
     def info(self):
         """What RCCL reports for this rank's two edge communicators (hps_ring_info)."""
