@@ -592,6 +592,203 @@ void k_dst_rows (DstArgs a)
 }
 
 
+// ---- N a power of two: in-place radix-4 transform ------------------------------------------------
+// The grids the reference recommends have 2^K - 1 cells per side (docs/source/run/parameters.rst:313-321), i.e. N = n + 1 =
+// 2^K: no dense small-DFT stages there -- a decimation-in-frequency radix-4 pass per pair of bits (one radix-2 pass at the
+// end when K is odd), in place in LDS, twiddles from a copy of w_N^k in LDS.  X[k] = sum_n x[n] exp(+2 pi i n k / N) ends up
+// at position pow2_pos(k) (its base-4 digits reversed); the post-processing reads through that map, so there is no
+// reordering pass.  Same pre- and post-processing, same DstArgs, same launch geometry (2T rows per workgroup) as k_dst_rows.
+template <int LOGN>
+__device__ __forceinline__ int pow2_pos (int k)
+{
+    int pos = 0, span = 1 << LOGN;
+#pragma unroll
+    for (int s = 0; s < LOGN/2; ++s) { span >>= 2; pos += (k & 3)*span; k >>= 2; }
+    if (LOGN & 1) pos += (k & 1);
+    return pos;
+}
+
+template <int LOGN, int T, int NT>
+__device__ __forceinline__ void pow2_fft (lds_double* cbuf, const lds_double* twl, int tid)
+{
+    constexpr int N = 1 << LOGN;
+#pragma unroll
+    for (int s = 0; s < LOGN/2; ++s) {
+        const int lq = LOGN - 2*s - 2;                 // log2 of the quarter span
+        const int q = 1 << lq, L = q << 2;
+#pragma unroll
+        for (int b0 = 0; b0 < T*N/4; b0 += NT) {
+            const int b = b0 + tid;
+            if (T*N/4 % NT == 0 || b < T*N/4) {
+                const int t = b >> (LOGN - 2), bb = b & (N/4 - 1);
+                const int g = bb >> lq, j = bb & (q - 1);
+                const int p0 = t*N + g*L + j;
+                const double2 x0 = ldc(cbuf, p0), x1 = ldc(cbuf, p0 + q), x2 = ldc(cbuf, p0 + 2*q), x3 = ldc(cbuf, p0 + 3*q);
+                const double t0r = x0.x + x2.x, t0i = x0.y + x2.y, t1r = x0.x - x2.x, t1i = x0.y - x2.y;
+                const double t2r = x1.x + x3.x, t2i = x1.y + x3.y, dr = x1.x - x3.x, di = x1.y - x3.y;
+                double y1r = t1r - di, y1i = t1i + dr;          // t1 + i d
+                double y2r = t0r - t2r, y2i = t0i - t2i;
+                double y3r = t1r + di, y3i = t1i - dr;          // t1 - i d
+                if (lq > 0) {
+                    const int tj = j << (2*s);                  // exponent of w_N for w_L^j
+                    const double2 w1 = ldc(twl, tj), w2 = ldc(twl, 2*tj), w3 = ldc(twl, 3*tj);
+                    double a_;
+                    a_ = y1r*w1.x - y1i*w1.y; y1i = y1r*w1.y + y1i*w1.x; y1r = a_;
+                    a_ = y2r*w2.x - y2i*w2.y; y2i = y2r*w2.y + y2i*w2.x; y2r = a_;
+                    a_ = y3r*w3.x - y3i*w3.y; y3i = y3r*w3.y + y3i*w3.x; y3r = a_;
+                }
+                stc(cbuf, p0, t0r + t2r, t0i + t2i);
+                stc(cbuf, p0 + q, y1r, y1i);
+                stc(cbuf, p0 + 2*q, y2r, y2i);
+                stc(cbuf, p0 + 3*q, y3r, y3i);
+            }
+        }
+        __syncthreads();
+    }
+    if (LOGN & 1) {
+#pragma unroll
+        for (int b0 = 0; b0 < T*N/2; b0 += NT) {
+            const int b = b0 + tid;
+            if (T*N/2 % NT == 0 || b < T*N/2) {
+                const double2 x0 = ldc(cbuf, 2*b), x1 = ldc(cbuf, 2*b + 1);
+                stc(cbuf, 2*b, x0.x + x1.x, x0.y + x1.y);
+                stc(cbuf, 2*b + 1, x0.x - x1.x, x0.y - x1.y);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// post_store with the transform's output order behind a map (POS::at(q) = where X[q] sits)
+template <int T, int N, int NT, class POS, bool NOSCALE = false>
+__device__ __forceinline__ void post_store_map (const lds_double* cbuf, const DstArgs& a, int row0, int total_rows, int tid)
+{
+    constexpr int n = N - 1, NK = (n + NT - 1)/NT;
+    const double* scale = NOSCALE ? nullptr : a.scale;
+    double is[NK], sca[T][NK], scb[T][NK];
+#pragma unroll
+    for (int m = 0; m < NK; ++m) is[m] = a.isin4[min(tid + NT*m, n - 1)];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int ra = min(row0 + 2*t, total_rows - 1), rb = min(row0 + 2*t + 1, total_rows - 1);
+        const int ja = ra - (ra / a.rows_per_plane)*a.rows_per_plane, jb = rb - (rb / a.rows_per_plane)*a.rows_per_plane;
+#pragma unroll
+        for (int m = 0; m < NK; ++m) {
+            const int k = min(tid + NT*m, n - 1);
+            sca[t][m] = scale ? scale[(long)ja*n + k] : 1.0;
+            scb[t][m] = scale ? scale[(long)jb*n + k] : 1.0;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int ra = row0 + 2*t, rb = ra + 1;
+        if (ra >= total_rows) break;
+        const int pla = ra / a.rows_per_plane, plb = rb / a.rows_per_plane;
+        const int ja = ra - pla*a.rows_per_plane, jb = rb - plb*a.rows_per_plane;
+        double* da = a.dst[pla] + (long)ja*a.dst_pitch;
+        double* db = (rb < total_rows) ? a.dst[plb] + (long)jb*a.dst_pitch : nullptr;
+#pragma unroll
+        for (int m = 0; m < NK; ++m) {
+            const int k = tid + NT*m;
+            if (k < n) {
+                const double2 x1 = ldc(cbuf, t*N + POS::at(k + 1));
+                const double2 x2 = ldc(cbuf, t*N + POS::at(N - 1 - k));
+                double ta = 0.5*(x2.x - x1.x) + (x1.x + x2.x)*is[m];
+                double tb = 0.5*(x2.y - x1.y) + (x1.y + x2.y)*is[m];
+                if (scale) { ta *= sca[t][m]; tb *= scb[t][m]; }
+                da[k] = ta;
+                if (db) db[k] = tb;
+            }
+        }
+    }
+}
+template <int LOGN> struct Pow2Pos { static __device__ __forceinline__ int at (int q) { return pow2_pos<LOGN>(q); } };
+
+#ifndef HPS_DSTP_T
+#define HPS_DSTP_T 2
+#endif
+#ifndef HPS_DSTP_NT
+#define HPS_DSTP_NT 256
+#endif
+constexpr int DSTP_T = HPS_DSTP_T, DSTP_NT = HPS_DSTP_NT;      // row pairs and threads per workgroup of the power-of-two kernel
+// SRC: the rows are formed from other planes while they are loaded (DstArgs::sp / sq / sc, as k_dst_rows_sym<.., true>)
+// TWICE: the two y passes of a solve in one launch -- transform, times a.scale (the inverse eigenvalues), transform again
+template <int LOGN, bool SRC = false, bool TWICE = false>
+__global__ __launch_bounds__(DSTP_NT)
+void k_dst_rows_pow2 (DstArgs a)
+{
+    if (a.gate && *a.gate == 0) return;
+    constexpr int N = 1 << LOGN, n = N - 1, T = DSTP_T, NT = DSTP_NT;
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    lds_double* cbuf = (lds_double*)lds_raw;          // [T][N] complex working set
+    lds_double* twl = cbuf + 2*T*N;                   // [N] w_N^k
+    const int tid = threadIdx.x;
+    const int total_rows = a.rows_per_plane*a.nplanes;
+    const int row0 = blockIdx.x*2*T;
+    {   constexpr int NW = N/NT > 0 ? N/NT : 1;
+        double2 w[NW];
+#pragma unroll
+        for (int m = 0; m < NW; ++m) w[m] = a.tw[min(tid + NT*m, N - 1)];
+        if constexpr (SRC) load_row_pairs_src<T, N, NT>(cbuf, a, row0, total_rows, tid);
+        else load_row_pairs<T, N, NT>(cbuf, a, row0, total_rows, tid);
+#pragma unroll
+        for (int m = 0; m < NW; ++m) { const int k = tid + NT*m; if (k < N) stc(twl, k, w[m].x, w[m].y); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < (TWICE ? 2 : 1); ++pass) {
+        {
+            constexpr int PP = (N/2 + 1 + NT - 1)/NT;
+            double wr[T][PP], wi[T][PP], vr[T][PP], vi[T][PP];
+            pre_to_regs<T, N, PP, NT>(cbuf, tid, wr, wi, vr, vi);
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int m = 0; m < PP; ++m) {
+                    const int p = tid + NT*m;
+                    if (p <= N/2) {
+                        stc(cbuf, t*N + p, wr[t][m], wi[t][m]);
+                        if (p > 0 && 2*p != N) stc(cbuf, t*N + N - p, vr[t][m], vi[t][m]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        pow2_fft<LOGN, T, NT>(cbuf, twl, tid);
+        if (TWICE && pass == 0) {
+            // T_k of both rows of every pair (times the scale) -> registers -> back to [t][k] as the next pass's input
+            constexpr int NK = (n + NT - 1)/NT;
+            double ta[T][NK], tb[T][NK];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int ra = min(row0 + 2*t, total_rows - 1), rb = min(row0 + 2*t + 1, total_rows - 1);
+                const int ja = ra - (ra / a.rows_per_plane)*a.rows_per_plane, jb = rb - (rb / a.rows_per_plane)*a.rows_per_plane;
+#pragma unroll
+                for (int m = 0; m < NK; ++m) {
+                    const int k = min(tid + NT*m, n - 1);
+                    const double2 x1 = ldc(cbuf, t*N + pow2_pos<LOGN>(k + 1));
+                    const double2 x2 = ldc(cbuf, t*N + pow2_pos<LOGN>(N - 1 - k));
+                    const double is = a.isin4[k];
+                    ta[t][m] = (0.5*(x2.x - x1.x) + (x1.x + x2.x)*is)*a.scale[(long)ja*n + k];
+                    tb[t][m] = (0.5*(x2.y - x1.y) + (x1.y + x2.y)*is)*a.scale[(long)jb*n + k];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int m = 0; m < NK; ++m) {
+                    const int k = tid + NT*m;
+                    if (k < n) stc(cbuf, t*N + k, ta[t][m], tb[t][m]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    post_store_map<T, N, NT, Pow2Pos<LOGN>, TWICE>(cbuf, a, row0, total_rows, tid);
+}
+
 // ---- odd factors: conjugate-symmetric small DFTs -------------------------------------------------
 // For odd M and H = (M-1)/2, with s_n = x_n + x_{M-n}, d_n = x_n - x_{M-n}:
 //   X_0 = x_0 + sum_n s_n,   X_k = x_0 + P_k + i Q_k,   X_{M-k} = x_0 + P_k - i Q_k   (k = 1..H)
@@ -1196,13 +1393,18 @@ void k_dense_product (GemmArgs g)
     }
 }
 
+#ifndef HPS_POISSON_POW2
+#define HPS_POISSON_POW2 1
+#endif
 typedef void (*dst_kernel_t)(DstArgs);
 typedef void (*dst_cols_kernel_t)(DstArgs, int);
 struct DstImpl { int N, N1, N2; dst_kernel_t kernel; bool sym; int T; int nt; dst_cols_kernel_t cols; dst_kernel_t mfma; dst_kernel_t src; dst_kernel_t twice;
                  // the passes of a solve on blocked intermediate planes (no transposes): first pass from row-major rows / from
                  // rows formed out of other planes, both y passes in place on the blocked planes, last pass to row-major rows
-                 dst_kernel_t b_first, b_first_src, b_twice, b_last; };
+                 dst_kernel_t b_first, b_first_src, b_twice, b_last;
+                 bool pow2 = false; };           // N a power of two: k_dst_rows_pow2 (tables: w_N^k only)
 
+#define HPS_DST_POW2(LOGN) DstImpl{1 << (LOGN), 1 << (LOGN), 1, k_dst_rows_pow2<LOGN>, false, DSTP_T, DSTP_NT, nullptr, nullptr, k_dst_rows_pow2<LOGN, true>, k_dst_rows_pow2<LOGN, false, true>, nullptr, nullptr, nullptr, nullptr, true}
 #define HPS_DST_IMPL(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows<N1, N2>, false, DST_T, 256, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
 #define HPS_DST_SYM(N1, N2) DstImpl{(N1)*(N2), N1, N2, k_dst_rows_sym<N1, N2>, true, DSTS_T, DSTS_NT, k_dst_cols_sym<N1, N2>, k_dst_rows_mfma<N1, N2>, k_dst_rows_sym<N1, N2, true>, k_dst_rows_sym<N1, N2, false, true>, \
                                     k_dst_rows_sym<N1, N2, false, false, 0, 1>, k_dst_rows_sym<N1, N2, true, false, 0, 1>, k_dst_rows_sym<N1, N2, false, true, 2, 2>, k_dst_rows_sym<N1, N2, false, false, 1, 0>}
@@ -1212,11 +1414,19 @@ static const DstImpl g_dst_impls[] = {
     HPS_DST_SYM(3, 43),     // 128
     HPS_DST_SYM(5, 13),     // 64
     HPS_DST_SYM(3, 11),     // 32
+#if HPS_POISSON_POW2
+    HPS_DST_POW2(10),       // 1023
+    HPS_DST_POW2(9),        // 511
+    HPS_DST_POW2(8),        // 255
+    HPS_DST_POW2(7),        // 127
+    HPS_DST_POW2(6),        // 63
+#else
     HPS_DST_IMPL(32, 32),   // 1023
     HPS_DST_IMPL(16, 32),   // 511
     HPS_DST_IMPL(16, 16),   // 255
     HPS_DST_IMPL(8, 16),    // 127
     HPS_DST_IMPL(8, 8),     // 63
+#endif
     HPS_DST_SYM(9, 11),     // 98
     HPS_DST_SYM(7, 11),     // 76
 };
@@ -1372,9 +1582,18 @@ static int make_plan (rocfft_plan* plan, int N, int batch)
 
 // DFT matrices of both stages and the inter-stage twiddles, concatenated [fa | fb | tw].
 // sym: only the (cos, sin) of n, k = 1..(M-1)/2 are stored.
-static int upload_tables (int N1, int N2, bool sym, double2** out, size_t* na, size_t* nb)
+static int upload_tables (int N1, int N2, bool sym, double2** out, size_t* na, size_t* nb, bool pow2 = false)
 {
     const int N = N1*N2;
+    if (pow2) {                                   // w_N^k, k < N, where the other factorisations keep their [N1][N2] twiddles
+        *na = *nb = 0;
+        std::vector<double2> h((size_t)N);
+        const long double pi2 = 6.283185307179586476925286766559L;
+        for (int k = 0; k < N; ++k) { const long double ang = pi2*k/N; h[(size_t)k] = make_double2((double)cosl(ang), (double)sinl(ang)); }
+        HPS_HIP_CHECK(hipMalloc(out, h.size()*sizeof(double2)));
+        HPS_HIP_CHECK(hipMemcpy(*out, h.data(), h.size()*sizeof(double2), hipMemcpyHostToDevice));
+        return HPS_OK;
+    }
     const int a0 = sym ? 1 : 0, a1 = sym ? (N1 - 1)/2 : N1 - 1, b1 = sym ? (N2 - 1)/2 : N2 - 1;
     *na = (size_t)(a1 - a0 + 1)*(a1 - a0 + 1); *nb = (size_t)(b1 - a0 + 1)*(b1 - a0 + 1);
     std::vector<double2> h(*na + *nb + N);
@@ -1429,8 +1648,8 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
         {   const char* v = getenv("HPS_POISSON_Y2"); P->ky2 = (v && atoi(v) == 0) ? nullptr : iy->twice; }
         int e;
         size_t nax, nbx, nay, nby;
-        if ((e = upload_tables(ix->N1, ix->N2, ix->sym, &P->tab_x, &nax, &nbx)) ||
-            (e = upload_tables(iy->N1, iy->N2, iy->sym, &P->tab_y, &nay, &nby))) { delete P; return e; }
+        if ((e = upload_tables(ix->N1, ix->N2, ix->sym, &P->tab_x, &nax, &nbx, ix->pow2)) ||
+            (e = upload_tables(iy->N1, iy->N2, iy->sym, &P->tab_y, &nay, &nby, iy->pow2))) { delete P; return e; }
         P->fa_x = P->tab_x; P->fb_x = P->fa_x + nax; P->tw_x = P->fb_x + nbx;
         P->fa_y = P->tab_y; P->fb_y = P->fa_y + nay; P->tw_y = P->fb_y + nby;
         P->tx = ix->T; P->ty = iy->T; P->ntx = ix->nt; P->nty = iy->nt;
@@ -1450,8 +1669,8 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
             P->lds_cols = (size_t)DSTC_T*Ny*sizeof(double2);
             if (P->lds_cols > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->kcols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_cols));
         }
-        P->lds_x = ((size_t)ix->T*Nx + nax + nbx)*sizeof(double2);
-        P->lds_y = ((size_t)iy->T*Ny + nay + nby)*sizeof(double2);
+        P->lds_x = ((size_t)ix->T*Nx + nax + nbx + (ix->pow2 ? Nx : 0))*sizeof(double2);
+        P->lds_y = ((size_t)iy->T*Ny + nay + nby + (iy->pow2 ? Ny : 0))*sizeof(double2);
         if (P->lds_x > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->kx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_x));
         if (P->kx_src && P->lds_x > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->kx_src, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_x));
         if (P->lds_y > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)P->ky, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_y));
