@@ -97,6 +97,7 @@ def _worker(rank, world, port, lanes, n_steps, kind, out):
 
 
 CASES = [(2, 1, 2, "static"), (2, 1, 5, "static"), (3, 1, 7, "static"), (2, 2, 4, "static"), (2, 2, 9, "static"), (3, 2, 8, "static"),
+         (4, 1, 6, "static"),
          (2, 1, 4, "moving"), (2, 2, 6, "moving"), (2, 1, 4, "laser"), (2, 2, 5, "laser")]
 
 
