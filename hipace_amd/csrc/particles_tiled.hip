@@ -681,11 +681,20 @@ template <class T> __device__ __forceinline__ void sto_nt (T* base, unsigned o, 
 // VBP: the engine's own electron sheet -- a particle is valid iff its psi_half is not 0 (Tiling::valid_by_psi: every path that
 // clears the valid bit of idcpu also zeroes psi_half, which only the push reads): idcpu is not read, 40 instead of 48 B in per
 // particle in the one particle kernel that is bound by its bytes.
-template <int ORDER, int TS, bool LASER = false, bool IONIZE = false, bool VBP = false>
+// DEP != 0 (mask of DepComps, 51 or 59): the workgroup goes on to DEPOSIT its tile's pushed particles into the next slice's
+// jx jy chi rhomjz [rho] (which the engine has shifted / zeroed ahead of the launch) -- PlasmaDepositCurrent.cpp:155-246 with the
+// arithmetic of k_deposit_tiled -- once all of them are pushed: the accumulators take the place of the field image in LDS (the
+// push's occupancy is unchanged: round 2's fused kernel held both, 56 KB, two workgroups per CU), every thread reads back the
+// six values it has just stored itself (from the L2, not from HBM: the 48 B per particle the stand-alone deposition of the
+// next slice would fetch), and the next slice needs no deposition launch.  Static beam, no laser, no ionisable species.
+struct DepTail { DepComps cm; double a, b, max_qsa; int* n_qsa; };
+template <int ORDER, int TS, bool LASER = false, bool IONIZE = false, bool VBP = false, int DEP = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IONIZE ? HPS_PUSH_WAVES_ION : HPS_PUSH_WAVES)))
 void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets, int ntx,
-                      int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, int* n_fallback, IonArgs ia, const int* go, TailWork tw, MgPost mp)
+                      int cPsi, int cEz, int cBx, int cBy, int cBz, PartConsts k, int* n_fallback, IonArgs ia, const int* go, TailWork tw, MgPost mp,
+                      DepTail dt)
 {
+    static_assert(DEP == 0 || (!LASER && !IONIZE), "the deposition tail exists for the plain push only");
     constexpr int R = TS + 2*TILE_HALO;
     constexpr int NS = ORDER + 2;
     // enqueued behind a multigrid solve whose norms the host has not seen yet: run only if that solve is over (*go == 1,
@@ -1007,6 +1016,82 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             sto(pl.ux, o8, ux); sto(pl.uy, o8, uy); sto(pl.psi, o8, psi);
         }
     }
+    if constexpr (DEP != 0) {
+        // ---- DepositCurrent of the tile's pushed particles into the next slice ----
+        constexpr int RR = R*R;
+        const int gc[6] = {dt.cm.jx, dt.cm.jy, dt.cm.jz, dt.cm.rho, dt.cm.chi, dt.cm.rhomjz};
+        int slot[6]; int na = 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { const bool on = (DEP >> c) & 1; slot[c] = on ? na++ : -1; }
+        __syncthreads();                                  // every wave is done with the field image
+        double* acc = img;                                // [na][R*R], na <= 5
+        {   double2* z = (double2*)acc;
+            for (int s2 = tid; s2 < na*RR/2; s2 += 256) z[s2] = make_double2(0.0, 0.0); }
+        __syncthreads();
+        for (unsigned iq = (unsigned)lrec.y + tid; iq < pend; iq += 256) {
+            const unsigned o = iq*8u;
+            // (agent-scope loads: past the CU's vector cache, which may still hold the lines as they were before this thread's stores)
+            auto ldc2 = [] (const double* base, unsigned off) {
+                return __hip_atomic_load(reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            const double w = ldc2(pl.w, o);
+            const double x = ldc2(pl.x, o), y = ldc2(pl.y, o), ux = ldc2(pl.ux, o), uy = ldc2(pl.uy, o), psi = ldc2(pl.psi, o);
+            if (w == 0.0) continue;                       // (every invalidation zeroes the weight: PartConsts::valid_by_w)
+            const double psi_inv = 1.0/psi;               // (IEEE: the QSA test must see inf for psi = 0)
+            const double vx_c = ux*psi_inv, vy_c = uy*psi_inv;
+            const double q_invvol = dt.a*w;
+            const double gamma_psi = 0.5*(psi_inv*psi_inv + vx_c*vx_c*k.c_inv*k.c_inv + vy_c*vy_c*k.c_inv*k.c_inv + 1.0);
+            if (gamma_psi < 0.0 || gamma_psi > dt.max_qsa || psi_inv < 0.0) {
+                if (dt.n_qsa) atomicAdd(dt.n_qsa, 1);
+                sto(pl.w, o, 0.0);
+                sto(pl.idcpu, o, (uint64_t)(ldo(pl.idcpu, o) & ~HPS_ID_VALID));
+                sto(pl.psi_half, o, 0.0);
+                continue;
+            }
+            double wx[ORDER + 1], wy[ORDER + 1];
+            const int i0 = shape_weights<ORDER>((x - k.xoff)*k.dx_inv, wx);
+            const int j0 = shape_weights<ORDER>((y - k.yoff)*k.dy_inv, wy);
+            const double wv[6] = {vx_c, vy_c, (gamma_psi - 1.0)*k.c, gamma_psi, dt.b*psi_inv, 1.0};
+            const int li = i0 - ox, lj = j0 - oy;
+            if (li >= 0 && li + ORDER < R && lj >= 0 && lj + ORDER < R) {
+#pragma unroll
+                for (int iy = 0; iy <= ORDER; ++iy) {
+#pragma unroll
+                    for (int ix = 0; ix <= ORDER; ++ix) {
+                        const double cd = q_invvol*wx[ix]*wy[iy];
+                        double* p = acc + (lj + iy)*R + li + ix;
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) if (slot[c] >= 0) lds_add(p + slot[c]*RR, cd*wv[c]);
+                    }
+                }
+            } else {
+                nfb += !tail;
+#pragma unroll
+                for (int iy = 0; iy <= ORDER; ++iy) {
+#pragma unroll
+                    for (int ix = 0; ix <= ORDER; ++ix) {
+                        const double cd = q_invvol*wx[ix]*wy[iy];
+                        double* p = f.p + f.off(i0 + ix, j0 + iy);
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) if (slot[c] >= 0) atomic_add_f64(p + gc[c]*f.ns, cd*wv[c]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int s2 = tid; s2 < RR; s2 += 256) {
+            const int lj = s2 / R, li = s2 - lj*R;
+            const int i = ox + li, j = oy + lj;
+            if (i < -f.ng || i >= f.nx + f.ng || j < -f.ng || j >= f.ny + f.ng) continue;
+            double* p = f.p + f.off(i, j);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                if (slot[c] >= 0) {
+                    const double v = acc[slot[c]*RR + s2];
+                    if (v != 0.0) atomic_add_f64(p + gc[c]*f.ns, v);
+                }
+            }
+        }
+    }
     if (n_fallback && nfb) atomicAdd(n_fallback, nfb);
     if constexpr (IONIZE) {
         // tiles without a charged ion are skipped by the species' deposition kernels on the next slice
@@ -1308,7 +1393,7 @@ int advance_plasma_tiled (const hps_slab& slab, const hps_plasma& pl, const hps_
     const bool vbp = T->valid_by_psi && !ion && !can_ionize && order == 2 && T->g.ts == 16;
 #define HPS_ADV(O, S, L, I, V) { if (int e = set_lds(k_advance_tiled<O, S, L, I, V>, lds)) return e; \
         hipLaunchKernelGGL((k_advance_tiled<O, S, L, I, V>), dim3(T->g.ntiles + tw.nwg), dim3(256), lds, st, f, pl, T->offsets, T->g.ntx, \
-                           comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback, ia, go, tw, mp); }
+                           comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback, ia, go, tw, mp, DepTail{}); }
 #define CALL(O, S) { if (ion) { if (aabs_comp >= 0) HPS_ADV(O, S, true, true, false) else HPS_ADV(O, S, false, true, false) } \
                      else if (vbp && O == 2 && S == 16) { if (aabs_comp >= 0) HPS_ADV(2, 16, true, false, true) else HPS_ADV(2, 16, false, false, true) } \
                      else     { if (aabs_comp >= 0) HPS_ADV(O, S, true, false, false) else HPS_ADV(O, S, false, false, false) } }
@@ -1333,8 +1418,24 @@ int advance_deposit_tiled (const hps_slab& slab, const hps_plasma& pl, const hps
     int mask = 0, na = 0; for (int c = 0; c < 6; ++c) { mask |= (dep_comp[c] >= 0) << c; na += dep_comp[c] >= 0; }
     if (mask != 51 && mask != 59) { set_error("advance_deposit_tiled: deposits jx jy chi rhomjz [rho] only"); return HPS_ERR_UNSUPPORTED; }
     const int R = T->g.ts + 2*TILE_HALO;
-    const size_t lds = (size_t)(5 + na)*R*R*sizeof(double);
     SlabView f(slab);
+    // round 5: the push kernel of the separate schedule with the deposition as its tail (k_advance_tiled<.., DEP>); HPS_FUSED_KERNEL=old:
+    // round 2's kernel that holds image and accumulators together
+    static const bool modern = [] { const char* e = std::getenv("HPS_FUSED_KERNEL"); return !(e && std::string(e) == "old"); }();
+    if (modern && (order == 2 && T->g.ts == 16)) {
+        const size_t lds5 = (size_t)5*R*R*sizeof(double);
+        DepTail dt{cm, kd.a, kd.b, max_qsa, n_qsa};
+        const IonArgs ia{}; const TailWork tw0{}; const MgPost mp0{};
+        if (mask == 51) { if (int e = set_lds(k_advance_tiled<2, 16, false, false, false, 51>, lds5)) return e;
+            hipLaunchKernelGGL((k_advance_tiled<2, 16, false, false, false, 51>), dim3(T->g.ntiles), dim3(256), lds5, st, f, pl, T->offsets, T->g.ntx,
+                               comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback, ia, (const int*)nullptr, tw0, mp0, dt); }
+        else            { if (int e = set_lds(k_advance_tiled<2, 16, false, false, false, 59>, lds5)) return e;
+            hipLaunchKernelGGL((k_advance_tiled<2, 16, false, false, false, 59>), dim3(T->g.ntiles), dim3(256), lds5, st, f, pl, T->offsets, T->g.ntx,
+                               comp[0], comp[1], comp[2], comp[3], comp[4], k, n_fallback, ia, (const int*)nullptr, tw0, mp0, dt); }
+        HPS_HIP_CHECK(hipGetLastError());
+        return HPS_OK;
+    }
+    const size_t lds = (size_t)(5 + na)*R*R*sizeof(double);
     static int nt = 0;
     // (measured at 1024^2 x 4 ppc: 256 threads 285 us, 512 threads 316 us -- against 175 + 77 us for the two kernels)
     if (nt == 0) { nt = 256; if (const char* e = std::getenv("HPS_FUSED_THREADS")) { const int v = std::atoi(e); if (v == 256 || v == 512) nt = v; } }
