@@ -206,3 +206,88 @@ def test_cpp_pipeline_host_as_several_processes(api, tmp_path, world, stages, n_
     # every step but the last hands its non-empty blocks on; the hand-offs that cross a process boundary go through the ring
     crossing = sum(1 for s in range(n_steps - 1) if (s % W) % stages == stages - 1)
     assert sent == received == crossing * nonempty, (sent, received, crossing, nonempty)
+
+
+def _fullsize_worker(rank, world, port, lanes, n_steps, deck, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HPS_RING_EDGE"] = "ipc"
+    os.environ["HPS_RING_TIMEOUT_S"] = "180"
+    try:
+        import torch
+        import torch.distributed as dist
+        from hipace_amd import api
+        from hipace_amd.pipeline import RingTransport, run_lanes
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        engs = [api.SliceEngine(deck, device=0, tile_size=16, sort_period=128) for _ in range(lanes)]
+        for e in engs:
+            e.set_diagnostics(True)
+        T = RingTransport(rank, world, 0)
+        res = {}
+
+        def on_step_end(step, eng):
+            eng.sync()
+            res[step] = (eng.checksums(), eng.stats()["vcycles"])
+
+        prev = {id(e): 0 for e in engs}
+        solved = run_lanes(engs, rank, world, n_steps, torch.device("cuda", 0), on_step_end, transport=T)
+        st = T.stats()
+        dist.barrier()
+        T.close()
+        out.put((rank, solved, res, st, None))
+        dist.destroy_process_group()
+    except Exception as exc:      # noqa: BLE001
+        import traceback
+        out.put((rank, -1, {}, None, traceback.format_exc() + str(exc)))
+
+
+@pytest.mark.gpu
+def test_headline_box_through_two_processes_of_two_stages():
+    """The bench's multi-rank configuration at FULL size, checked: the 1024 x 1024 x 1024, 4 ppc box (tests/golden/fullsize_config4.json, the
+    oracle's whole box) run as six time steps by a closed ring of 2 processes x 2 stages on the one device -- every hand-off
+    between the processes a peer copy through the ipc edge, the receives of a whole step posted ahead.  hipace.dt = 0: every step
+    is the box of the fixture -- its checksums to 1e-6 (measured 4e-11) and its V-cycle total."""
+    import torch.multiprocessing as mp
+    path = os.path.join(GOLD, "fullsize_config4.json")
+    if not os.path.exists(path):
+        pytest.skip("fullsize_config4.json not generated")
+    fx = json.load(open(path))
+    deck = {k: (tuple(v) if isinstance(v, list) else v) for k, v in fx["deck"].items()}
+    world, lanes, n_steps = 2, 2, 6
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fullsize_worker, args=(r, world, port, lanes, n_steps, deck, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        results = [out.get(timeout=600) for _ in range(world)]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    for r in results:
+        assert r[4] is None, f"rank {r[0]}: {r[4]}"
+    got = {}
+    for rank, solved, res, st, _ in results:
+        got.update(res)
+        assert st["sent"] > 0 and st["received"] > 0, (rank, st)
+    assert sorted(got) == list(range(n_steps))
+    worst = 0.0
+    per_stage = {}
+    for s in range(n_steps):
+        cs, vc_total = got[s]
+        for k, v in fx["checksums"].items():
+            if v == 0.0:
+                assert cs[k] == 0.0, (s, k)
+            else:
+                worst = max(worst, abs(cs[k] - v) / abs(v))
+                assert abs(cs[k] - v) <= 1e-6 * abs(v), (s, k, cs[k], v)
+        per_stage.setdefault(s % (world * lanes), []).append(vc_total)
+    # an engine's V-cycle counter runs over its steps: every step adds the box's total
+    for stage, totals in per_stage.items():
+        for n, t in enumerate(sorted(totals)):
+            assert abs(t - (n + 1) * fx["final"]["vcycles"]) <= max(2, 2e-3 * t), (stage, totals)
+    print(f"headline box through 2 processes x 2 stages, 6 steps: worst checksum deviation {worst:.2e}")
