@@ -132,6 +132,16 @@ struct Box {                                    // one side's view of a mailbox
     unsigned long long* d_freed = nullptr; unsigned long long* d_landed = nullptr;      // device addresses of the two stream-written words
 };
 std::map<std::string, Box> g_pending_boxes;     // made by hps_ring_unique_id, claimed by hps_ring_init
+// a mailbox whose id was made but never claimed (the host gave up between hps_ring_unique_id and hps_ring_init) must not
+// stay behind in /dev/shm when the process ends
+struct PendingBoxesCleanup {
+    ~PendingBoxesCleanup () {
+        for (auto& kv : g_pending_boxes) {
+            if (kv.second.m) munmap(kv.second.m, sizeof(Mailbox));
+            if (!kv.second.name.empty()) shm_unlink(kv.second.name.c_str());
+        }
+    }
+} g_pending_boxes_cleanup;
 
 struct Ring {
     int rank = 0, world = 1, device = 0;
