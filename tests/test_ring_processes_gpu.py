@@ -291,3 +291,74 @@ def test_headline_box_through_two_processes_of_two_stages():
         for n, t in enumerate(sorted(totals)):
             assert abs(t - (n + 1) * fx["final"]["vcycles"]) <= max(2, 2e-3 * t), (stage, totals)
     print(f"headline box through 2 processes x 2 stages, 6 steps: worst checksum deviation {worst:.2e}")
+
+
+def _failure_worker(rank, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HPS_RING_EDGE"] = "ipc"
+    os.environ["HPS_RING_TIMEOUT_S"] = "8"
+    os.environ["HPS_RING_NO_PROBE"] = "1"
+    try:
+        import torch
+        import torch.distributed as dist
+        from hipace_amd import _lib
+        from hipace_amd.pipeline import RingTransport
+        dist.init_process_group("gloo", rank=rank, world_size=2)
+        torch.cuda.set_device(0)
+        T = RingTransport(rank, 2, 0)
+        msgs = []
+        a = torch.zeros(1024, dtype=torch.float64, device="cuda")
+        b = torch.zeros(512, dtype=torch.float64, device="cuda")
+        if rank == 1:
+            T.recv(b, None, 0)                     # posts 4096 bytes; rank 0 sends 8192
+            dist.barrier()
+            dist.barrier()                         # rank 0 has seen the size mismatch
+            T.close()                              # ... and now this rank leaves with rank 0 about to send again
+            dist.barrier()
+        else:
+            dist.barrier()
+            for what in ("size", "fits", "gone"):
+                try:
+                    T.send(a if what == "size" else b, None, 1)
+                    msgs.append((what, "no error"))
+                except _lib.HpsError as exc:
+                    msgs.append((what, str(exc)))
+                if what == "fits":
+                    T.sync_sends()
+                    dist.barrier()
+                    dist.barrier()                 # rank 1 has closed its ring: nobody will post another receive
+        out.put((rank, msgs, None))
+        if rank == 0:
+            T.close()
+        dist.destroy_process_group()
+    except Exception as exc:      # noqa: BLE001
+        import traceback
+        out.put((rank, [], traceback.format_exc() + str(exc)))
+
+
+@pytest.mark.gpu
+def test_ipc_edge_fails_loudly():
+    """The ipc edge's error behaviour between two processes: a send whose size differs from the posted receive's is an error
+    (RCCL would hang or corrupt), and a send to a rank that has left the ring -- no receive will ever be posted -- gives up
+    with the edge's counters in the message instead of waiting for HPS_RING_TIMEOUT_S."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failure_worker, args=(r, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        results = dict((r[0], r) for r in (out.get(timeout=240) for _ in range(2)))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    for r in results.values():
+        assert r[2] is None, r[2]
+    msgs = dict(results[0][1])
+    assert "8192 bytes" in msgs["size"] and "4096" in msgs["size"], msgs
+    assert msgs["fits"] == "no error", msgs
+    assert "left the ring" in msgs["gone"] or "still waiting" in msgs["gone"], msgs
