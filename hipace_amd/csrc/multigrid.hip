@@ -111,6 +111,15 @@ using TileMid = TileShape<32, 32, 256>;
 #define HPS_MG_HUGE 64, 48, 512
 #endif
 using TileHuge = TileShape<HPS_MG_HUGE>;      // the fused 8-sweep pass of level 0 (rim 8: 48 x 32 of 64 x 48 final)
+// ... of the node-centred hierarchy (2^K - 1 cells per side): on 64 x 48 tiles that pass spills 37 registers under its cap
+// (no fused restriction: the residual planes are stored, the prolongation is bilinear) -- 64 x 32 tiles (two pairs per thread)
+// do not: Bx/By solve at 1023^2 413 -> 391 us per slice (profiles/r05_nodal_multigrid.txt); the cell-centred pass keeps 64 x 48
+#ifndef HPS_MG_HUGE_NODAL
+#define HPS_MG_HUGE_NODAL 64, 32, 512
+#endif
+using TileHugeNodal = TileShape<HPS_MG_HUGE_NODAL>;
+template <bool CC> struct HugeTileOf { using type = TileHuge; };
+template <> struct HugeTileOf<false> { using type = TileHugeNodal; };
 using TileSmall = TileShape<32, 16, 256>;
 
 // diagonal of the operator at (i,j): -(a + 2(fx+fy)) with the wall modification (gs1 :265-292)
@@ -224,7 +233,7 @@ __device__ __forceinline__ void block_max_to (unsigned long long* slot, double v
 //         FUSE_R (cell-centred): cres = R(r) written straight to the next level; else r -> res_out.
 // INTERIOR tiles (no swept cell on a wall / outside the box) take a path without masks.
 template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, bool INTERIOR, int NSW, bool GATE_IN = (NSW == 4)>
-__device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], double* s_red, const LevBox& b, const FView& phi_out,
+__device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], double* s_red, double* s_crs, const LevBox& b, const FView& phi_out,
                                              const FView& phi_out2, const FView& rhs, const FView& acf, const FView& phi_in, const FView& crse,
                                              const FView& res_out, const FView& cres_out, double facx, double facy,
                                              int gi0, int gj0, unsigned long long* resnorm, unsigned long long* rhsnorm, const StopRule& sr)
@@ -271,6 +280,30 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
     {
         constexpr int NF = (GA_X*GA_Y + MG_NT - 1)/MG_NT;
         double v0[NF], v1[NF];
+        // Node-centred prolongation (bilinear: up to four coarse values per fine cell) THROUGH LDS: asked for from global memory
+        // inside the loop below, the 7 cells of a thread had up to 70 loads in flight -- the fused 8-sweep pass of level 0 spilled
+        // 39 registers under its 128-register cap (58 us against 32 for the cell-centred pass, n = 1023).  The coarse cells under
+        // the ringed tile go to LDS once (one load per coarse cell instead of one per fine neighbour), the interpolation reads them there.
+        constexpr bool PLDS = !CC && SRC == SRC_PROLONG;
+        constexpr int CXN = GA_X/2 + 2, CYN = GA_Y/2 + 2;
+        const int cx0 = (INTERIOR ? gi0 - 1 : min(max(gi0 - 1, b.vlx), b.vhx)) >> 1, cy0 = (INTERIOR ? gj0 - 1 : min(max(gj0 - 1, b.vly), b.vhy)) >> 1;
+        if constexpr (PLDS) {
+            const int cxl = b.vlx >> 1, cxh = (b.vhx >> 1) + 1, cyl = b.vly >> 1, cyh = (b.vhy >> 1) + 1;      // the coarse level's box, walls included
+            constexpr int NC = (CXN*CYN + MG_NT - 1)/MG_NT;
+            double c0[NC], c1[NC];
+#pragma unroll
+            for (int m = 0; m < NC; ++m) {
+                const int q = min(tid + MG_NT*m, CXN*CYN - 1);
+                const int ly = q / CXN, lx = q - ly*CXN;
+                const int X = min(max(cx0 + lx, cxl), cxh), Y = min(max(cy0 + ly, cyl), cyh);
+                c0[m] = crse(X, Y, 0); c1[m] = crse(X, Y, 1);
+            }
+#pragma unroll
+            for (int m = 0; m < NC; ++m) {
+                const int q = tid + MG_NT*m;
+                if (q < CXN*CYN) { s_crs[q] = c0[m]; s_crs[CXN*CYN + q] = c1[m]; }
+            }
+        }
 #pragma unroll
         for (int m = 0; m < NF; ++m) {
             const int s = min(tid + MG_NT*m, GA_X*GA_Y - 1);
@@ -280,9 +313,30 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
             if (SRC != SRC_ZERO) {
                 const int ic = INTERIOR ? i : min(max(i, b.vlx), b.vhx), jc = INTERIOR ? j : min(max(j, b.vly), b.vhy);
                 double a0 = phi_in(ic, jc, 0), a1 = phi_in(ic, jc, 1);
-                if (SRC == SRC_PROLONG) { a0 += prolong_at<CC>(crse, ic, jc, 0); a1 += prolong_at<CC>(crse, ic, jc, 1); }
+                if (SRC == SRC_PROLONG && !PLDS) { a0 += prolong_at<CC>(crse, ic, jc, 0); a1 += prolong_at<CC>(crse, ic, jc, 1); }
                 const bool inside = INTERIOR || (ic == i && jc == j);
                 v0[m] = inside ? a0 : 0.0; v1[m] = inside ? a1 : 0.0;
+            }
+        }
+        if constexpr (PLDS) {
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < NF; ++m) {
+                const int s = min(tid + MG_NT*m, GA_X*GA_Y - 1);
+                const int lj = s / GA_X, li = s - lj*GA_X;
+                const int i = gi0 - 1 + li, j = gj0 - 1 + lj;
+                const int ic = INTERIOR ? i : min(max(i, b.vlx), b.vhx), jc = INTERIOR ? j : min(max(j, b.vly), b.vhy);
+                const bool inside = INTERIOR || (ic == i && jc == j);
+                // prolong_at<false>'s four cases with its order of additions, on the LDS copy
+                const int o = ((jc >> 1) - cy0)*CXN + (ic >> 1) - cx0;
+                const bool io = (ic & 1), jo = (jc & 1);
+                double p0, p1;
+                const double* q0 = s_crs + o; const double* q1 = s_crs + CXN*CYN + o;
+                if (io && jo)  { p0 = (q0[0] + q0[1] + q0[CXN] + q0[CXN + 1])*0.25; p1 = (q1[0] + q1[1] + q1[CXN] + q1[CXN + 1])*0.25; }
+                else if (io)   { p0 = (q0[0] + q0[1])*0.5; p1 = (q1[0] + q1[1])*0.5; }
+                else if (jo)   { p0 = (q0[0] + q0[CXN])*0.5; p1 = (q1[0] + q1[CXN])*0.5; }
+                else           { p0 = q0[0]; p1 = q1[0]; }
+                if (inside) { v0[m] += p0; v1[m] += p1; }
             }
         }
         {   // The gate of a speculative V-cycle, read while ALL the tile's loads are in flight (a kernel's first dependent
@@ -529,7 +583,10 @@ __device__ __forceinline__ void post_epilogue (const PostArgs& pa)      // every
 }
 
 template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, int NSW = 4, bool POST = false>
-__global__ __launch_bounds__(TS::NT, 4)      // at most 128 VGPRs: two 512-thread workgroups per CU (several variants sit at 113-130)
+#ifndef HPS_MG_NODAL_WAVES
+#define HPS_MG_NODAL_WAVES 4
+#endif
+__global__ __launch_bounds__(TS::NT, (CC || NSW == 4) ? 4 : HPS_MG_NODAL_WAVES)      // at most 128 VGPRs: two 512-thread workgroups per CU (several variants sit at 113-130)
 void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FView phi_in, FView crse, FView res_out,
                FView cres_out, double facx, double facy, int ntx, unsigned long long* resnorm,
                unsigned long long* rhsnorm, StopRule sr, PostArgs pa)
@@ -540,6 +597,9 @@ void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FV
     constexpr int GT_X = TS::TX, GT_Y = TS::TY;
     __shared__ double s_phi[2][TS::AY*TS::AX];
     __shared__ double s_red[TS::NT/64];
+    // node-centred prolongation goes through LDS (smooth_tile): the coarse cells under the ringed tile, two components
+    constexpr bool PLDS = !CC && SRC == SRC_PROLONG;
+    __shared__ double s_crs[PLDS ? 2*(TS::AX/2 + 2)*(TS::AY/2 + 2) : 1];
     constexpr int E = DO_RES ? NSW : NSW - 1;
     constexpr int FX = GT_X - 2*E, FY = GT_Y - 2*E;   // cells a tile finalises (even numbers)
     // workgroups go round-robin to the 8 XCDs: give each XCD a contiguous run of tiles, so that the
@@ -553,9 +613,9 @@ void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FV
     const bool interior = (gi0 - 1 >= b.vlx) && (gi0 + GT_X <= b.vhx) && (gj0 - 1 >= b.vly) && (gj0 + GT_Y <= b.vhy)
                        && (gi0 > b.lox) && (gi0 + GT_X - 1 < b.hix) && (gj0 > b.loy) && (gj0 + GT_Y - 1 < b.hiy);
     constexpr bool GATE_IN = (NSW == 4) || (HPS_MG_GATE8_BEHIND && !POST);
-    if (interior) smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, true, NSW, GATE_IN>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
+    if (interior) smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, true, NSW, GATE_IN>(s_phi, s_red, s_crs, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
                                                              facx, facy, gi0, gj0, resnorm, rhsnorm, sr);
-    else          smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, false, NSW, GATE_IN>(s_phi, s_red, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
+    else          smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, false, NSW, GATE_IN>(s_phi, s_red, s_crs, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
                                                               facx, facy, gi0, gj0, resnorm, rhsnorm, sr);
     if (POST) post_epilogue(pa);
 }
@@ -1786,7 +1846,7 @@ static bool vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
         double* in = M->cor_in_tmp ? M->tmp0 : M->L[0].cor;
         double* out = M->cor_in_tmp ? M->L[0].cor : M->tmp0;
         if (M->fuse_level0) {
-            launch_smooth_ts<TileHuge, CC, SRC_PROLONG, true, 8>(M, 0, M->lv(0, out), M->sol, M->rhs, M->acf0, M->lv(0, in), M->lv(1, crse),
+            launch_smooth_ts<typename HugeTileOf<CC>::type, CC, SRC_PROLONG, true, 8>(M, 0, M->lv(0, out), M->sol, M->rhs, M->acf0, M->lv(0, in), M->lv(1, crse),
                                                                  M->lv(0, M->L[0].rescor), M->lv(1, M->L[1].res), M->d_norms + (2 + k)*MG_NSUB,
                                                                  nullptr, sr, st, CC ? post : nullptr);
             M->cor_in_tmp = !M->cor_in_tmp;
