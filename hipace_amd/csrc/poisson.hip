@@ -608,6 +608,27 @@ __device__ __forceinline__ int pow2_pos (int k)
     return pos;
 }
 
+// LDS bank swizzle of the transform's working set (N = 4^5 only).  In place, a radix-4 pass with quarter span 4 or 1 walks the
+// array with lanes 16 or 4 complex numbers apart, and the post-processing reads X[k] at its digit-reversed position -- lanes 256
+// apart: 16 lanes of a ds_read_b128 on the same four banks.  With the base-4 digits a0..a4 of the index, the low two digits are
+// stored as (a1 ^ a2 ^ a3, a0 ^ a2 ^ a4): every access pattern of the kernel -- natural order, the five passes, the digit-reversed
+// reads -- then varies the stored low digits over all 16 values within 16 consecutive lanes.
+#ifndef HPS_DSTP_SWIZZLE
+#define HPS_DSTP_SWIZZLE 1
+#endif
+template <int LOGN>
+__device__ __forceinline__ int pow2_swz (int i)
+{
+    if constexpr (LOGN == 10 && HPS_DSTP_SWIZZLE) {
+        const int a2 = (i >> 4) & 3, a3 = (i >> 6) & 3, a4 = (i >> 8) & 3;
+        return i ^ (((a2 ^ a3) << 2) | (a2 ^ a4));
+    } else if constexpr (LOGN == 9 && HPS_DSTP_SWIZZLE) {
+        // N = 4^4 * 2 (quarter spans 128, 32, 8, 2, then the radix-2 pass; digit-reversed reads vary bits 5..8): by bits b4..b8
+        const int b4 = (i >> 4) & 1, b5 = (i >> 5) & 1, b6 = (i >> 6) & 1, b7 = (i >> 7) & 1, b8 = (i >> 8) & 1;
+        return i ^ ((b4 ^ b7) | ((b4 ^ b8) << 1) | (b5 << 2) | ((b5 ^ b6) << 3));
+    } else return i;
+}
+
 template <int LOGN, int T, int NT>
 __device__ __forceinline__ void pow2_fft (lds_double* cbuf, const lds_double* twl, int tid)
 {
@@ -622,8 +643,9 @@ __device__ __forceinline__ void pow2_fft (lds_double* cbuf, const lds_double* tw
             if (T*N/4 % NT == 0 || b < T*N/4) {
                 const int t = b >> (LOGN - 2), bb = b & (N/4 - 1);
                 const int g = bb >> lq, j = bb & (q - 1);
-                const int p0 = t*N + g*L + j;
-                const double2 x0 = ldc(cbuf, p0), x1 = ldc(cbuf, p0 + q), x2 = ldc(cbuf, p0 + 2*q), x3 = ldc(cbuf, p0 + 3*q);
+                const int l0 = g*L + j, tb = t*N;
+                const int p0 = tb + pow2_swz<LOGN>(l0), p1 = tb + pow2_swz<LOGN>(l0 + q), p2 = tb + pow2_swz<LOGN>(l0 + 2*q), p3 = tb + pow2_swz<LOGN>(l0 + 3*q);
+                const double2 x0 = ldc(cbuf, p0), x1 = ldc(cbuf, p1), x2 = ldc(cbuf, p2), x3 = ldc(cbuf, p3);
                 const double t0r = x0.x + x2.x, t0i = x0.y + x2.y, t1r = x0.x - x2.x, t1i = x0.y - x2.y;
                 const double t2r = x1.x + x3.x, t2i = x1.y + x3.y, dr = x1.x - x3.x, di = x1.y - x3.y;
                 double y1r = t1r - di, y1i = t1i + dr;          // t1 + i d
@@ -638,9 +660,9 @@ __device__ __forceinline__ void pow2_fft (lds_double* cbuf, const lds_double* tw
                     a_ = y3r*w3.x - y3i*w3.y; y3i = y3r*w3.y + y3i*w3.x; y3r = a_;
                 }
                 stc(cbuf, p0, t0r + t2r, t0i + t2i);
-                stc(cbuf, p0 + q, y1r, y1i);
-                stc(cbuf, p0 + 2*q, y2r, y2i);
-                stc(cbuf, p0 + 3*q, y3r, y3i);
+                stc(cbuf, p1, y1r, y1i);
+                stc(cbuf, p2, y2r, y2i);
+                stc(cbuf, p3, y3r, y3i);
             }
         }
         __syncthreads();
@@ -650,9 +672,11 @@ __device__ __forceinline__ void pow2_fft (lds_double* cbuf, const lds_double* tw
         for (int b0 = 0; b0 < T*N/2; b0 += NT) {
             const int b = b0 + tid;
             if (T*N/2 % NT == 0 || b < T*N/2) {
-                const double2 x0 = ldc(cbuf, 2*b), x1 = ldc(cbuf, 2*b + 1);
-                stc(cbuf, 2*b, x0.x + x1.x, x0.y + x1.y);
-                stc(cbuf, 2*b + 1, x0.x - x1.x, x0.y - x1.y);
+                const int tb = (2*b) & ~(N - 1), l0 = (2*b) & (N - 1);
+                const int p0 = tb + pow2_swz<LOGN>(l0), p1 = tb + pow2_swz<LOGN>(l0 + 1);
+                const double2 x0 = ldc(cbuf, p0), x1 = ldc(cbuf, p1);
+                stc(cbuf, p0, x0.x + x1.x, x0.y + x1.y);
+                stc(cbuf, p1, x0.x - x1.x, x0.y - x1.y);
             }
         }
         __syncthreads();
@@ -702,7 +726,7 @@ __device__ __forceinline__ void post_store_map (const lds_double* cbuf, const Ds
         }
     }
 }
-template <int LOGN> struct Pow2Pos { static __device__ __forceinline__ int at (int q) { return pow2_pos<LOGN>(q); } };
+template <int LOGN> struct Pow2Pos { static __device__ __forceinline__ int at (int q) { return pow2_swz<LOGN>(pow2_pos<LOGN>(q)); } };
 
 #ifndef HPS_DSTP_T
 #define HPS_DSTP_T 2
@@ -748,8 +772,8 @@ void k_dst_rows_pow2 (DstArgs a)
                 for (int m = 0; m < PP; ++m) {
                     const int p = tid + NT*m;
                     if (p <= N/2) {
-                        stc(cbuf, t*N + p, wr[t][m], wi[t][m]);
-                        if (p > 0 && 2*p != N) stc(cbuf, t*N + N - p, vr[t][m], vi[t][m]);
+                        stc(cbuf, t*N + pow2_swz<LOGN>(p), wr[t][m], wi[t][m]);
+                        if (p > 0 && 2*p != N) stc(cbuf, t*N + pow2_swz<LOGN>(N - p), vr[t][m], vi[t][m]);
                     }
                 }
             }
@@ -767,8 +791,8 @@ void k_dst_rows_pow2 (DstArgs a)
 #pragma unroll
                 for (int m = 0; m < NK; ++m) {
                     const int k = min(tid + NT*m, n - 1);
-                    const double2 x1 = ldc(cbuf, t*N + pow2_pos<LOGN>(k + 1));
-                    const double2 x2 = ldc(cbuf, t*N + pow2_pos<LOGN>(N - 1 - k));
+                    const double2 x1 = ldc(cbuf, t*N + Pow2Pos<LOGN>::at(k + 1));
+                    const double2 x2 = ldc(cbuf, t*N + Pow2Pos<LOGN>::at(N - 1 - k));
                     const double is = a.isin4[k];
                     ta[t][m] = (0.5*(x2.x - x1.x) + (x1.x + x2.x)*is)*a.scale[(long)ja*n + k];
                     tb[t][m] = (0.5*(x2.y - x1.y) + (x1.y + x2.y)*is)*a.scale[(long)jb*n + k];
