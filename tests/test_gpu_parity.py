@@ -113,7 +113,8 @@ def test_advance_plasma(api, oracle, order, bc, nsc):
 
 
 @pytest.mark.parametrize("nx,ny", [(64, 64), (32, 48), (63, 63), (127, 65), (32, 64), (128, 32), (512, 512),
-                                   (1024, 1024), (1023, 1023), (256, 256), (256, 100), (48, 500), (600, 520)])
+                                   (1024, 1024), (1023, 1023), (256, 256), (256, 100), (48, 500), (600, 520),
+                                   (511, 511), (255, 255), (511, 127), (1023, 511)])      # every length of the power-of-two kernel (2^6 .. 2^10)
 def test_poisson(api, oracle, nx, ny):
     import torch
     rng = np.random.default_rng(nx * 1000 + ny)
@@ -153,7 +154,7 @@ def test_poisson_batch(api, oracle):
     assert np.all(out[[0, 3, 5]] == 0)
 
 
-@pytest.mark.parametrize("nx,ny", [(64, 64), (32, 32), (96, 48), (63, 63), (31, 63), (512, 512), (1024, 1024), (1023, 1023)])
+@pytest.mark.parametrize("nx,ny", [(64, 64), (32, 32), (96, 48), (63, 63), (31, 63), (512, 512), (1024, 1024), (1023, 1023), (511, 511), (255, 127)])
 @pytest.mark.parametrize("warm", [False, True])
 def test_multigrid_solve1(api, oracle, nx, ny, warm):
     """Stand-alone hpmg solve1 against the oracle, up to the headline size (every kernel of the V-cycle: LDS-tiled
