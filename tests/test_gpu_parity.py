@@ -295,7 +295,7 @@ def test_full_size_properties(api):
     assert res.abs().max().item() <= 1e-8 * R.abs().max().item() * 1.0001
 
 
-@pytest.mark.parametrize("n,nsl", [(512, 6), (1024, 3), (1023, 3)])
+@pytest.mark.parametrize("n,nsl", [(512, 6), (1024, 3), (1023, 3), (511, 5)])
 def test_baseline_blowout_configs_head_slices(api, oracle, n, nsl):
     """BASELINE configs 3 and 4 at their full transverse size (blowout_wake n x n x 1024, 4 ppc, explicit solver) -- and the
     grid the reference recommends, 2^N - 1 = 1023 cells per side (docs/source/run/parameters.rst:313-321: length-1024
