@@ -176,8 +176,8 @@ class RingTransport:
             rx = torch.zeros(512, dtype=torch.float64, device=dev)
             tx = torch.arange(512, dtype=torch.float64, device=dev) + 1000.0 * self.rank
             torch.cuda.synchronize(dev)
-            ev = self.recv(rx, None, slot=(1 << 19))
-            self.send(tx, None, slot=(1 << 19))
+            ev = self.recv(rx, None, slot=0)
+            self.send(tx, None, slot=0)
             t0 = time.perf_counter()
             while not self.ready(ev):
                 if time.perf_counter() - t0 > seconds:
