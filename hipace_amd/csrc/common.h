@@ -69,6 +69,32 @@ __device__ __forceinline__ int shape_weights (double xmid, double* s)
     }
 }
 
+// Order 2, the same weights computed ONCE: the plain set lives on three of the four cells -- (w0, w1, w2) at cells 0..2 for
+// t < 1/2, the same three polynomials of u = t - 1 at cells 1..3 otherwise (0.5 t^2 - 1.5 t + 1.125 = w0(t - 1), ...) -- where
+// nodal_weights<2> evaluates both polynomials of every cell and selects.  w / hi are what the push's 3 x 3 gather of the plain
+// fields needs (no second selection from s), s the four-cell set for the Psi gather.
+__device__ __forceinline__ int nodal_weights2_w3 (double xmid, double* s, double* d, double* w, bool& hi)
+{
+    const double xf = floor(xmid);
+    const double t = xmid - xf;
+    const double t2 = t*t;
+    const bool lo = t < 0.5;
+    const double u = lo ? t : t - 1.0, u2 = u*u;
+    w[0] = 0.5*u2 - 0.5*u + 0.125;
+    w[1] = 0.75 - u2;
+    w[2] = 0.5*u2 + 0.5*u + 0.125;
+    s[0] = lo ? w[0] : 0.0;
+    s[1] = lo ? w[1] : w[0];
+    s[2] = lo ? w[2] : w[1];
+    s[3] = lo ? 0.0 : w[2];
+    d[0] = -(-0.5*t2 + t - 0.5);
+    d[1] = -(1.5*t2 - 2.0*t);
+    d[2] = -(-1.5*t2 + t + 0.5);
+    d[3] = -(0.5*t2);
+    hi = !lo;
+    return (int)xf - 1;
+}
+
 // Gather stencil: weights of the "nodal derivative" set (derivative_type 1 of
 // ShapeFactors.H:275-367) on ORDER+2 cells: s[k] interpolates the field, d[k] (= -dS/dx in
 // cells) differentiates it on the fly.  Returns left-most cell.

@@ -669,6 +669,9 @@ template <class T> __device__ __forceinline__ void sto_nt (T* base, unsigned o, 
 #ifndef HPS_PUSH_SPLIT_GATHER
 #define HPS_PUSH_SPLIT_GATHER 1
 #endif
+#ifndef HPS_PUSH_W3
+#define HPS_PUSH_W3 1
+#endif
 #ifndef HPS_PUSH_WAVES
 #define HPS_PUSH_WAVES 3
 #endif
@@ -783,8 +786,16 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
             double xp = isc == 0 ? cur.xp : ldo(pl.x_prev, o8);
             double yp = isc == 0 ? cur.yp : ldo(pl.y_prev, o8);
             double sx[NS], dsx[NS], sy[NS], dsy[NS];
-            const int i0 = nodal_weights<ORDER>((xp - k.xoff)*k.dx_inv, sx, dsx);
-            const int j0 = nodal_weights<ORDER>((yp - k.yoff)*k.dy_inv, sy, dsy);
+            constexpr bool W3 = HPS_PUSH_W3 && ORDER == 2 && HPS_PUSH_SPLIT_GATHER && !HPS_PUSH_GATHER_PIPE;
+            double pxw[3] = {0.0, 0.0, 0.0}, pyw[3] = {0.0, 0.0, 0.0}; bool xhw = false, yhw = false;
+            int i0, j0;
+            if constexpr (W3) {      // the three plain weights and their offset straight from the polynomial (common.h)
+                i0 = nodal_weights2_w3((xp - k.xoff)*k.dx_inv, sx, dsx, pxw, xhw);
+                j0 = nodal_weights2_w3((yp - k.yoff)*k.dy_inv, sy, dsy, pyw, yhw);
+            } else {
+                i0 = nodal_weights<ORDER>((xp - k.xoff)*k.dx_inv, sx, dsx);
+                j0 = nodal_weights<ORDER>((yp - k.yoff)*k.dy_inv, sy, dsy);
+            }
             const int li = i0 - ox, lj = j0 - oy;
             const bool local = (li >= 0 && li + NS <= R && lj >= 0 && lj + NS <= R);
             if (!local && !tail) ++nfb;
@@ -866,10 +877,13 @@ void k_advance_tiled (SlabView f, hps_plasma pl, const int* __restrict__ offsets
                     F.ExmBy = fma(sy[iy], rd, F.ExmBy);
                     F.EypBx = fma(dsy[iy], rp, F.EypBx);
                 }
-                const bool xhi = !(sx[NS - 1] == 0.0), yhi = !(sy[NS - 1] == 0.0);
+                const bool xhi = W3 ? xhw : !(sx[NS - 1] == 0.0), yhi = W3 ? yhw : !(sy[NS - 1] == 0.0);
                 double px[NS - 1], py[NS - 1];
 #pragma unroll
-                for (int m = 0; m < NS - 1; ++m) { px[m] = xhi ? sx[m + 1] : sx[m]; py[m] = yhi ? sy[m + 1] : sy[m]; }
+                for (int m = 0; m < NS - 1; ++m) {
+                    if constexpr (W3) { px[m] = pxw[m < 3 ? m : 2]; py[m] = pyw[m < 3 ? m : 2]; }
+                    else { px[m] = xhi ? sx[m + 1] : sx[m]; py[m] = yhi ? sy[m + 1] : sy[m]; }
+                }
                 const double* bq = b + R*R + (yhi ? R : 0) + (xhi ? 1 : 0);
 #pragma unroll
                 for (int ky = 0; ky < NS - 1; ++ky) {
