@@ -1675,11 +1675,13 @@ def test_mobile_ions_match_oracle(api, oracle, tile_size):
 
 
 @pytest.mark.gpu
-def test_cpp_host_runs_the_ring_through_the_c_abi(api, tmp_path):
+@pytest.mark.parametrize("edge", ["rccl", "ipc"])
+def test_cpp_host_runs_the_ring_through_the_c_abi(api, tmp_path, edge):
     """examples/ring_host.cpp: a C++ program above include/hpslice.h (no Python, no torch in the process) that runs three
     time steps of the blowout_wake deck slice by slice and hands every beam block of a step to the next one through the
-    RCCL ring, ordered by events -- the loop a maintainer of the reference would write in Hipace::Evolve.  Every step
-    reproduces the reference's checksums, and 2/3 of all beam bytes went through the ring."""
+    ring (HPS_RING_EDGE: RCCL's ncclSend + ncclRecv, or the ipc edge's copy on the ring's stream), ordered by events -- the loop
+    a maintainer of the reference would write in Hipace::Evolve.  Every step reproduces the reference's checksums, and 2/3 of
+    all beam bytes went through the ring."""
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "ring_host")
     if not os.path.exists(exe):                          # normally built by __graft_entry__.build()
@@ -1693,7 +1695,7 @@ def test_cpp_host_runs_the_ring_through_the_c_abi(api, tmp_path):
     path = tmp_path / "deck.bin"
     path.write_bytes(bytes(eng._dk))                     # the hps_deck the engine was created from
     del eng
-    out = subprocess.run([exe, str(path), "3", "16"], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([exe, str(path), "3", "16"], capture_output=True, text=True, timeout=600, env=dict(os.environ, HPS_RING_EDGE=edge))
     assert out.returncode == 0, out.stderr[-2000:]
     steps = [l.split() for l in out.stdout.splitlines() if l.startswith("step ")]
     assert [int(s[1]) for s in steps] == [0, 1, 2]
