@@ -281,6 +281,9 @@ def main():
     ap.add_argument("--fuse", action="store_true",
                     help="fused schedule: the push of slice k also deposits the currents of slice k-1 (hps_engine_set_fusion)")
     ap.add_argument("--no-ionization", action="store_true", help="--config5 without the ionisable species")
+    ap.add_argument("--si", action="store_true",
+                    help="--config5 in SI units (hipace.normalized_units = 0: the deck of tests/laser_blowout_wake_explicit.SI.1Rank.sh, as "
+                         "BASELINE.json names configs[4]) instead of its normalised twin")
     ap.add_argument("--config2", action="store_true",
                     help="BASELINE config 2 instead of the headline workload: linear_wake 256x256x512, 4 ppc, "
                          "predictor-corrector Bx/By solver (not the judged bench line)")
@@ -379,14 +382,9 @@ def main():
         args.cpu_slices = 0
     if args.config5:
         nz = 2048
-        deck = decks.synthetic(args.n, nz, args.ppc)
-        deck.update(beam_profile=-1, lo=(-20.0, -20.0, -15.0), hi=(20.0, 20.0, 6.0), laser_on=1, laser_a0=4.5, laser_w0=4.0,
-                    laser_L0=2.0, laser_lambda0=0.08, laser_solver=2 if args.laser_solver == "multigrid" else 1, dt=5.0)
-        if not args.no_ionization:
-            # neutral nitrogen, a fifth of the electron density, one macro-atom per cell: ionised by the wake (ADK); the
-            # deck is in normalised units with kp_inv = 10 um (hipace.background_density_SI)
-            decks.with_ion_species(deck, "N", 0.2, ppc=(1, 1), initial_level=0, seed=5)
-            deck["background_density_SI"] = 2.8239587008591567e23
+        # neutral nitrogen, a fifth of the electron density, one macro-atom per cell: ionised by the wake (ADK); --si: the deck in
+        # SI units as BASELINE names it, else its normalised twin with kp_inv = 10 um (hipace.background_density_SI)
+        deck = decks.config5(args.n, nz, 2 if args.laser_solver == "multigrid" else 1, si=args.si, ionize=not args.no_ionization)
         args.cpu_slices = 0
         args.inflight = 1
     if args.steps <= 0:
@@ -691,7 +689,7 @@ def main():
             "particle_pushes_per_s": total / dt * args.ppc * args.ppc * args.n * args.n,
             "config": {"workload": ("linear_wake.normalized 256x256x512, 4 ppc, order 2, predictor-corrector Bx/By solver "
                                     "(tolerance 4e-2, <= 30 iterations, mixing 0.05), dt=0 (BASELINE.json configs[1])") if args.config2 else
-                                   (f"laser_blowout_wake {args.n}x{args.n}x{nz} in NORMALISED units (BASELINE names the .SI twin of the deck: same kernels, other constants), 4 ppc, order 2, Gaussian laser a0=4.5 + {args.laser_solver} envelope "
+                                   (f"laser_blowout_wake_explicit{'.SI' if args.si else ''} {args.n}x{args.n}x{nz} in {'SI units (hipace.normalized_units = 0, kp_inv = 10 um: the deck BASELINE names)' if args.si else 'NORMALISED units (BASELINE names the .SI twin of the deck: same kernels, other constants; --si runs that one)'}, 4 ppc, order 2, Gaussian laser a0=4.5 + {args.laser_solver} envelope "
                                     "solver every slice" + (", no ionisation" if args.no_ionization else ", neutral N (0.2 n_e, 1 macro-atom per cell) "
                                     "field-ionised by the wake (ADK), released electrons join the plasma") + " (BASELINE.json configs[4])") if args.config5 else
                                    (f"blowout_wake synthetic {args.n}x{args.n}x{nz}, {args.ppc * args.ppc} ppc, "

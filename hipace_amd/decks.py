@@ -185,6 +185,29 @@ def laser_blowout_wake_SI():
     return d
 
 
+def config5(n=1024, nz=2048, solver=1, si=False, ionize=True):
+    """BASELINE configs[4]: laser_blowout_wake on n x n x nz cells, 4 ppc, a Gaussian pulse (a0 = 4.5, w0 = 4 kp^-1, L0 = 2 kp^-1,
+    lambda0 = 0.8 um) that drives the wake and is advanced by the envelope solver on every slice (solver 1 = fft, 2 = multigrid),
+    c dt = 5 kp^-1, neutral nitrogen at a fifth of the electron density (one macro-atom per cell) field-ionised by the wake.
+    si = True: the deck as BASELINE names it (tests/laser_blowout_wake_explicit.SI.1Rank.sh, examples/blowout_wake/inputs_SI:
+    hipace.normalized_units = 0, kp_inv = 10 um); si = False: its normalised twin (same kernels, other constants)."""
+    if si:
+        kp_inv = 10.0e-6
+        d = laser_blowout_wake_SI()
+        d.update(nx=n, ny=n, nz=nz, plasma_ppc=(2, 2), lo=(-20.0 * kp_inv, -20.0 * kp_inv, -15.0 * kp_inv),
+                 hi=(20.0 * kp_inv, 20.0 * kp_inv, 6.0 * kp_inv), laser_solver=solver, dt=5.0 * kp_inv / SI["c"])
+        if ionize:
+            with_ion_species(d, "N", 0.2 * d["plasma_density"], ppc=(1, 1), initial_level=0, seed=5)
+        return d
+    d = synthetic(n, nz, 2)
+    d.update(beam_profile=-1, lo=(-20.0, -20.0, -15.0), hi=(20.0, 20.0, 6.0), laser_on=1, laser_a0=4.5, laser_w0=4.0,
+             laser_L0=2.0, laser_lambda0=0.08, laser_solver=solver, dt=5.0)
+    if ionize:
+        with_ion_species(d, "N", 0.2, ppc=(1, 1), initial_level=0, seed=5)
+        d["background_density_SI"] = 2.8239587008591567e23      # kp_inv = 10 um (hipace.background_density_SI)
+    return d
+
+
 def _ne_SI(kp_inv=10.0e-6):
     wp = SI["c"] / kp_inv
     return wp ** 2 * SI["m_e"] * SI["ep0"] / SI["q_e"] ** 2

@@ -33,26 +33,12 @@ from hipace_amd import decks  # noqa: E402
 
 def config5_deck(n, nz, solver, ionize=True):
     """bench.py --config5's deck (BASELINE configs[4] in normalised units) on n x n x nz cells over the same box."""
-    d = decks.synthetic(n, nz, 2)
-    d.update(beam_profile=-1, lo=(-20.0, -20.0, -15.0), hi=(20.0, 20.0, 6.0), laser_on=1, laser_a0=4.5, laser_w0=4.0,
-             laser_L0=2.0, laser_lambda0=0.08, laser_solver=solver, dt=5.0)
-    if ionize:
-        decks.with_ion_species(d, "N", 0.2, ppc=(1, 1), initial_level=0, seed=5)
-        d["background_density_SI"] = 2.8239587008591567e23
-    return d
+    return decks.config5(n, nz, solver, si=False, ionize=ionize)
 
 
 def config5_si_deck(n, nz, solver, ionize=True):
-    """BASELINE configs[4] as BASELINE names it: the .SI deck (tests/laser_blowout_wake_explicit.SI.1Rank.sh,
-    examples/blowout_wake/inputs_SI: hipace.normalized_units = 0, kp_inv = 10 um, lengths in metres, charges in C, masses in
-    kg) on n x n x nz cells over the box of config5_deck, with the same pulse, time step (c dt = 5 kp_inv) and dopant."""
-    kp_inv = 10.0e-6
-    d = decks.laser_blowout_wake_SI()
-    d.update(nx=n, ny=n, nz=nz, plasma_ppc=(2, 2), lo=(-20.0 * kp_inv, -20.0 * kp_inv, -15.0 * kp_inv),
-             hi=(20.0 * kp_inv, 20.0 * kp_inv, 6.0 * kp_inv), laser_solver=solver, dt=5.0 * kp_inv / decks.SI["c"])
-    if ionize:
-        decks.with_ion_species(d, "N", 0.2 * d["plasma_density"], ppc=(1, 1), initial_level=0, seed=5)
-    return d
+    """BASELINE configs[4] as BASELINE names it: the .SI deck (bench.py --config5 --si) on n x n x nz cells over the same box."""
+    return decks.config5(n, nz, solver, si=True, ionize=ionize)
 
 
 def config2_deck():
