@@ -106,8 +106,9 @@ int load_rccl ()
 
 // ---- the mailbox of one ipc edge (one POSIX shared-memory segment, mapped and hipHostRegister'ed by both sides) -------
 constexpr uint32_t kBoxMagic = 0x48505342u;     // "HPSB"
+constexpr uint32_t kBoxVersion = 2;             // layout of Mailbox (2: 65536 descriptors)
 constexpr int kBoxArenas = 64;
-constexpr uint64_t kBoxDescs = 16384;           // receives posted and not yet matched by a send (a whole step ahead: <= 2 per slice)
+constexpr uint64_t kBoxDescs = 65536;           // receives posted and not yet matched by a send (up to two whole steps ahead, <= 2 per slice: boxes of 16 k slices)
 struct alignas(64) BoxWord { volatile unsigned long long v; char pad[56]; };
 struct BoxArena { hipIpcMemHandle_t handle; unsigned long long base, size; };
 struct BoxDesc { unsigned long long offset, bytes; unsigned int arena, pad; };
@@ -198,7 +199,7 @@ int box_map (Box& B, const std::string& name, bool create)
     close(fd);
     if (p == MAP_FAILED) { if (create) shm_unlink(name.c_str()); hps::set_error("hps_ring: cannot map the mailbox " + name); return HPS_ERR_COMM; }
     B.m = static_cast<Mailbox*>(p); B.name = name; B.creator = create;
-    if (create) { B.m->version = 1; B.m->magic = kBoxMagic; }       // (a fresh segment is zero-filled)
+    if (create) { B.m->version = kBoxVersion; B.m->magic = kBoxMagic; }       // (a fresh segment is zero-filled)
     return HPS_OK;
 }
 void box_unmap (Box& B)
@@ -336,7 +337,7 @@ extern "C" int hps_ring_init (int rank, int world, int device, const char* id_ed
         R->box_out = it->second; g_pending_boxes.erase(it);
         if (world == 1) { *handle = R; return HPS_OK; }          // the rank is its own neighbour: plain device copies, no mailbox traffic
         if (int e = box_map(R->box_in, id_edge_in + sizeof(kIpcTag) - 1, false)) return fail(e);
-        if (R->box_in.m->magic != kBoxMagic || R->box_in.m->version != 1) { hps::set_error("hps_ring_init: the incoming edge's mailbox is not one of this library version"); return fail(HPS_ERR_COMM); }
+        if (R->box_in.m->magic != kBoxMagic || R->box_in.m->version != kBoxVersion) { hps::set_error("hps_ring_init: the incoming edge's mailbox is not one of this library version"); return fail(HPS_ERR_COMM); }
         if (int e = box_register(R->box_in)) return fail(e);
         if (int e = box_register(R->box_out)) return fail(e);
         R->box_out.m->sender_attached.store(1);
@@ -483,7 +484,7 @@ extern "C" int hps_ring_recv_slice (void* handle, void* msg_dev, long bytes, voi
     HPS_REQUIRE(msg_dev && bytes > 0, "hps_ring_recv_slice: empty message");
     if (R->kind == 1) {
         Mailbox* m = R->box_in.m;
-        HPS_REQUIRE(R->n_posted - ld_acq(&m->issued.v) < kBoxDescs, "hps_ring_recv_slice: too many receives posted ahead of their sends (16384)");
+        HPS_REQUIRE(R->n_posted - ld_acq(&m->issued.v) < kBoxDescs, "hps_ring_recv_slice: too many receives posted ahead of their sends (65536)");
         HPS_REQUIRE(slot >= 0 && slot < (1 << 20), "hps_ring: bad event slot");
         BoxDesc d{};
         if (int e = ipc_arena_of(R, msg_dev, bytes, &d.arena, &d.offset)) return e;

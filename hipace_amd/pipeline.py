@@ -688,7 +688,9 @@ def _stage(engine, rank, world, n_steps, device, on_step_end=None, slices_per_st
     spool_done = [None] * (len(spool) if spool else 0)
     ring_laser = laser and ring                      # one rank without a transport: the engine rotates its own time levels
     batch = 1 if (moving or ring_laser) else max(1, int(handoff_batch))
-    lookahead = per_prev
+    # receives are posted a whole step ahead; an ipc edge's mailbox holds 65536 descriptors (ring.hip: kBoxDescs), two per
+    # slice with a laser: boxes beyond 16 k slices post 16 k slices ahead
+    lookahead = min(per_prev, 16384)
     lpool, lspool = [], []
     if ring_laser:
         llen = engine.laser_message_doubles()
