@@ -93,7 +93,9 @@ struct DstArgs {
 // store ahead of the DFT-table loads would keep those off the scalar path
 #define HPS_STAMP_DECL long long stamp_[6] = {0, 0, 0, 0, 0, 0}
 #define HPS_STAMP(i) do { stamp_[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#define HPS_STAMP_FLUSH do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) { for (int q_ = 0; q_ < 6; ++q_) a.dbg[q_] = stamp_[q_]; } } while (0)
+#define HPS_STAMP_FLUSH do { if (a.dbg && threadIdx.x == 0) { const int g_ = (int)gridDim.x, b_ = (int)blockIdx.x; \
+        const int s_ = b_ == 0 ? 0 : b_ == g_/3 ? 1 : b_ == 2*g_/3 ? 2 : b_ == g_ - 1 ? 3 : -1; \
+        if (s_ >= 0) { for (int q_ = 0; q_ < 6; ++q_) a.dbg[6*s_ + q_] = stamp_[q_]; } } } while (0)      /* workgroups 0, g/3, 2g/3, g-1 */
 #else
 #define HPS_STAMP_DECL do { } while (0)
 #define HPS_STAMP(i) do { } while (0)
@@ -2022,12 +2024,12 @@ extern "C" int hps_poisson_solve_batch (void* handle, int nbatch, const double* 
     return poisson_solve_batch(P, nbatch, s, P->nx, d, dst.jstride, (hipStream_t)stream);
 }
 
-extern "C" int hps_poisson_debug_stamps (void* handle, long long* stamps6_host)
+extern "C" int hps_poisson_debug_stamps (void* handle, long long* stamps6_host)      // [4 workgroups][6 stamps]
 {
     Poisson* P = static_cast<Poisson*>(handle);
-    if (!P->dbg) { HPS_HIP_CHECK(hipMalloc(&P->dbg, 8*sizeof(long long))); HPS_HIP_CHECK(hipMemset(P->dbg, 0, 8*sizeof(long long))); return HPS_OK; }
+    if (!P->dbg) { HPS_HIP_CHECK(hipMalloc(&P->dbg, 24*sizeof(long long))); HPS_HIP_CHECK(hipMemset(P->dbg, 0, 24*sizeof(long long))); return HPS_OK; }
     HPS_HIP_CHECK(hipDeviceSynchronize());
-    HPS_HIP_CHECK(hipMemcpy(stamps6_host, P->dbg, 6*sizeof(long long), hipMemcpyDeviceToHost));
+    HPS_HIP_CHECK(hipMemcpy(stamps6_host, P->dbg, 24*sizeof(long long), hipMemcpyDeviceToHost));
     return HPS_OK;
 }
 
