@@ -202,6 +202,7 @@ _SIGS = {
     "hps_engine_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_phase_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hps_engine_beam_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.c_void_p]),
+    "hps_engine_set_beam_particles": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.POINTER(C.c_long)]),
     "hps_engine_set_beam_storage": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_initial_beam": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_ring_unique_id": (C.c_int, [C.c_char_p]),

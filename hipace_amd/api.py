@@ -401,6 +401,16 @@ class SliceEngine:
         check(_lib.lib().hps_engine_beam_info(self._h, C.byref(nb), off))
         return nb.value, np.array(off[:], dtype=np.int64)
 
+    def set_beam_particles(self, soa, allow_outside=False):
+        """A host-initialised beam in place of the deck's (any of the reference's injection types): soa = (7, n) array
+        x y z ux uy uz w.  Before the first begin_step.  -> number of particles outside the box in z (left out)."""
+        soa = np.ascontiguousarray(soa, dtype=np.float64)
+        assert soa.ndim == 2 and soa.shape[0] == 7
+        out = C.c_long(0)
+        check(_lib.lib().hps_engine_set_beam_particles(self._h, soa.shape[1], soa.ctypes.data_as(C.c_void_p),
+                                                       C.byref(out) if allow_outside else None))
+        return out.value
+
     def set_beam_storage(self, tensor, injected_beam_support=False):
         """Use `tensor` (float64, 7*nbeam, on this device) as the engine's beam blocks; None = own.
         injected_beam_support: the blocks are the injected beam handed along the ring (dt = 0), so the slab

@@ -162,6 +162,8 @@ struct Engine {
     ~Engine ();
     int create (const hps_deck& deck, int device);
     int init_beam ();
+    int install_beam (std::vector<double> (&h)[7]);
+    int set_beam_particles (long n, const double* soa_host, long* n_outside);
     int begin_step ();
     int deposit_beam_slice (int islice, int cjx, int cjy, int cjz, const int* go = nullptr);
     void deposit_grid_current (int islice, int cjz);

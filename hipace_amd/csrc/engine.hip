@@ -407,6 +407,54 @@ int Engine::init_beam ()
         }
     }
     beam_off[d.nz] = (long)h[0].size();
+    return install_beam(h);
+}
+
+// A beam the HOST has initialised (any of the reference's injection types: fixed_weight, fixed_weight_pdf, from_file --
+// beam/BeamParticleContainerInit.cpp:348-695 -- draw from amrex::Random or read a file; the slice operators do not care):
+// n particles as [7][n] x y z ux uy uz w in the engine's units (u = gamma beta c, w as the deposition takes it), in any
+// order.  They are binned into the box's slices (BoxSorter's rule, sorting/BoxSort.cpp:34-43: slice = int((z - lo_z)/dz)), head slice first, input
+// order kept inside a slice; particles outside the box in z are counted and left out.  Replaces the deck's beam.
+int Engine::set_beam_particles (long n, const double* soa, long* n_outside)
+{
+    HPS_REQUIRE(n >= 0 && (soa || n == 0), "hps_engine_set_beam_particles: null argument");
+    HPS_REQUIRE(steps_begun == 0 && step_index < 0, "hps_engine_set_beam_particles: call before the first hps_engine_begin_step");
+    std::vector<long> count((size_t)d.nz + 1, 0);
+    std::vector<int> where((size_t)n);
+    long outside = 0;
+    const double inv_dz = 1.0/gm.dz;
+    for (long i = 0; i < n; ++i) {
+        const double z = soa[2*n + i];
+        const double t = (z - d.lo[2])*inv_dz;
+        const int q = (t > -1.0e9 && t < 1.0e9) ? static_cast<int>(t) : -1;      // (the reference's cast: truncation)
+        if (q < 0 || q >= d.nz) { where[(size_t)i] = -1; ++outside; continue; }
+        const int p = d.nz - 1 - q;                      // p-th slice from the head
+        where[(size_t)i] = p; ++count[(size_t)p + 1];
+    }
+    if (n_outside) *n_outside = outside;
+    HPS_REQUIRE(outside == 0 || n_outside, "hps_engine_set_beam_particles: particles outside the box in z (pass n_outside to have them counted and left out)");
+    beam_off.assign(d.nz + 1, 0);
+    for (int p = 0; p < d.nz; ++p) beam_off[p + 1] = beam_off[p] + count[(size_t)p + 1];
+    std::vector<long> next(beam_off.begin(), beam_off.end() - 1);
+    std::vector<double> h[7];
+    for (int k = 0; k < 7; ++k) h[k].resize((size_t)(n - outside));
+    for (long i = 0; i < n; ++i) {
+        const int p = where[(size_t)i];
+        if (p < 0) continue;
+        const long j = next[(size_t)p]++;
+        for (int k = 0; k < 7; ++k) h[k][(size_t)j] = soa[(size_t)k*n + i];
+    }
+    HPS_HIP_CHECK(hipStreamSynchronize(st));
+    (void)hipFree(beam_data); (void)hipFree(beam_init); (void)hipFree(bm_store); (void)hipFree(bm_nsub); (void)hipFree(bm_nsub_scr);
+    (void)hipFree(d_B); (void)hipFree(d_nfront); (void)hipFree(d_Bimp); (void)hipFree(d_beam_overflow);
+    beam_data = beam_init = beam_cur = nullptr; bm_store = nullptr; bm_nsub = bm_nsub_scr = nullptr;
+    d_B = nullptr; d_nfront = nullptr; d_Bimp = nullptr; d_beam_overflow = nullptr;
+    return install_beam(h);
+}
+
+// the beam's device storage from the host arrays h[7] (head slice first, beam_off filled in)
+int Engine::install_beam (std::vector<double> (&h)[7])
+{
     nbeam = (long)h[0].size();
     {
         const int js = d.nx + 2*g, jn = d.ny + 2*g;
@@ -2182,6 +2230,11 @@ extern "C" int hps_engine_initial_beam (void* h, double* dst_dev)
     Engine* E = static_cast<Engine*>(h);
     if (E->nbeam > 0) HPS_HIP_CHECK(hipMemcpy(dst_dev, E->beam_init, 7*E->nbeam*sizeof(double), hipMemcpyDeviceToDevice));
     return HPS_OK;
+}
+extern "C" int hps_engine_set_beam_particles (void* h, long n, const double* soa_host, long* n_outside)
+{
+    HPS_REQUIRE(h, "hps_engine_set_beam_particles: null engine");
+    return static_cast<Engine*>(h)->set_beam_particles(n, soa_host, n_outside);
 }
 extern "C" int hps_engine_set_tiling (void* h, int tile_size, int sort_period)
 {

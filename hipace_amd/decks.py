@@ -369,3 +369,69 @@ def laser_ionization_SI():
     carry no net charge, so the pre-formed plasma stays neutralised by its own background."""
     d = laser_blowout_wake_SI()
     return with_ion_species(d, "N", 0.2 * d["plasma_density"], ppc=(1, 1), initial_level=0, seed=5)
+
+
+def transverse_benchmark(nxy=1023, nz=1000):
+    """examples/benchmarks/inputs_transverse_benchmark as tests/transverse_benchmark.1Rank.sh runs it (my_constants.nxy = 1023):
+    the reference's own transverse scaling benchmark -- 2^N - 1 cells per side, 1000 slices, one plasma electron per cell,
+    absorbing particle boundary, explicit solver.  Its driver is a fixed_weight_pdf beam of 10 nxy^2 particles drawn from
+    amrex::Random: the deck carries no beam (beam_profile = -1), the host hands one in with
+    SliceEngine.set_beam_particles(fixed_weight_pdf_beam(deck, **TRANSVERSE_BENCHMARK_BEAM(nxy)))."""
+    d = copy.deepcopy(_DEFAULT)
+    d.update(nx=nxy, ny=nxy, nz=nz, lo=(-6.0, -6.0, -12.0), hi=(6.0, 6.0, 6.0), order=2, plasma_ppc=(1, 1), plasma_density=1.0,
+             beam_profile=-1, bc=2, n_steps=1, dt=0.0)
+    return d
+
+
+def TRANSVERSE_BENCHMARK_BEAM(nxy=1023):
+    import numpy as np
+    return dict(num_particles=nxy * nxy * 10, density=2.0, pdf=lambda z: np.exp(-0.5 * (z / 1.41) ** 2), pos_std=(0.3, 0.3),
+                u_mean=(0.0, 0.0, 2000.0))
+
+
+def fixed_weight_pdf_beam(deck, num_particles, density, pdf, pos_mean=(0.0, 0.0), pos_std=(1.0, 1.0), u_mean=(0.0, 0.0, 0.0),
+                          u_std=(0.0, 0.0, 0.0), seed=0, pdf_ref_ratio=4):
+    """beam.injection_type = fixed_weight_pdf with a peak density (InitBeamFixedWeightPDF3D / ...PDFSlice,
+    particles/beam/BeamParticleContainerInit.cpp:479-695), on the host: the longitudinal profile `pdf(z)` (vectorised
+    callable) is integrated by the trapezoidal rule on nz * pdf_ref_ratio sub-slices (:502-528), the total weight is
+    density * integral / max_density with max_density = max local_weight / (dz_sub * sigma_x * sigma_y * 2 pi) (:514-531), in
+    normalised units over the cell volume (:540-542); every particle carries total / num_particles (:618).  The particle
+    count of a sub-slice is drawn in proportion to its share of the integral (the reference iterates Poisson draws until
+    the total is num_particles, :546-579 -- a multinomial draw here), z inside a sub-slice follows the linear profile
+    between its two ends (:645-652), x, y and u are normal (:663-670).  numpy's generator stands in for amrex::Random: the
+    beam is the reference's in distribution, not particle by particle.
+    -> (7, num_particles) array x y z ux uy uz w in the engine's units (u times c; AddOneBeamParticleSlice, :86-116)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    nz = deck["nz"]
+    lo, hi = deck["lo"], deck["hi"]
+    dx, dy, dz = (hi[0] - lo[0]) / deck["nx"], (hi[1] - lo[1]) / deck["ny"], (hi[2] - lo[2]) / nz
+    c = 299792458.0 if deck.get("si_units", 0) else 1.0
+    ns = nz * pdf_ref_ratio
+    zs = dz / pdf_ref_ratio
+    edges = lo[2] + zs * np.arange(ns + 1)
+    pe = np.asarray(pdf(edges), dtype=np.float64)
+    assert (pe >= 0.0).all(), "PDF must be >= 0 everywhere"
+    lw = 0.5 * (pe[:-1] + pe[1:])
+    integral = lw.sum()
+    max_density = (lw / (zs * pos_std[0] * pos_std[1] * 2.0 * np.pi)).max()
+    total_weight = density * integral / max_density
+    if not deck.get("si_units", 0):
+        total_weight /= dx * dy * dz
+    counts = rng.multinomial(num_particles, lw / integral)
+    sub = np.repeat(np.arange(ns), counts)
+    w01 = rng.random(num_particles)
+    lo_w, hi_w = pe[:-1][sub], pe[1:][sub]
+    taylor = np.minimum(lo_w, hi_w) * 1.1 > np.maximum(lo_w, hi_w)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        z_t = w01 - w01 * (w01 - 1.0) * (hi_w - lo_w) / (hi_w + lo_w)
+        z_s = (np.sqrt(lo_w * lo_w + w01 * (hi_w * hi_w - lo_w * lo_w)) - lo_w) / (hi_w - lo_w)
+    z = edges[:-1][sub] + zs * np.where(taylor, z_t, z_s)
+    out = np.empty((7, num_particles))
+    out[0] = pos_mean[0] + rng.normal(0.0, pos_std[0], num_particles)
+    out[1] = pos_mean[1] + rng.normal(0.0, pos_std[1], num_particles)
+    out[2] = z
+    for k in range(3):
+        out[3 + k] = (u_mean[k] + (rng.normal(0.0, u_std[k], num_particles) if u_std[k] else 0.0)) * c
+    out[6] = abs(total_weight / num_particles)
+    return out

@@ -400,6 +400,16 @@ int hps_engine_phase_times (void* handle, double* ms_host, long* nslices_host);
  * 7*offsets[p].  A pipeline driver can point the engine at its own buffer (the receive buffer of
  * the ring hand-off); hps_engine_initial_beam copies the injected (step 0) beam into one. */
 int hps_engine_beam_info (void* handle, long* nbeam_host, long* offsets_host /* [nz+1] */);
+/* A beam the host has initialised itself -- any of the reference's injection types (fixed_weight, fixed_weight_pdf, from_file:
+ * InitBeamFixedWeight3D / InitBeamFixedWeightPDFSlice / InitBeamFromFile, particles/beam/BeamParticleContainerInit.cpp:348-477,
+ * 479-695, 697-960, which draw from amrex::Random or read an openPMD file) -- in place of the deck's fixed_ppc one
+ * (deck.beam_profile = -1: none).  soa_host = [7][n] doubles x y z ux uy uz w on the host, u = gamma beta c, w as the
+ * deposition takes it (the weight AddOneBeamParticle stores: in normalised units the injection's total weight over the
+ * particle count and the cell volume); any order.  The particles are binned into the box's slices, slice =
+ * int((z - lo_z)/dz) as the reference's BoxSorter does (particles/sorting/BoxSort.cpp:34-43), input order kept inside
+ * a slice.  Particles outside the box in z are left out and counted in *n_outside (NULL: they are an error).  Call after
+ * hps_engine_create and before the first hps_engine_begin_step; works for hipace.dt = 0 and for a moving beam. */
+int hps_engine_set_beam_particles (void* handle, long n, const double* soa_host, long* n_outside);
 int hps_engine_set_beam_storage (void* handle, double* storage_dev /* [7*nbeam] or NULL = own */);
 int hps_engine_initial_beam (void* handle, double* dst_dev);
 /* hipace.dt != 0: the beam lives in one SoA over all particles (head slice first) whose slice boundaries move when

@@ -1115,7 +1115,7 @@ struct Engine {
     double beam_diag[7] = {0, 0, 0, 0, 0, 0, 0};   // n, sum w, |x|, |y|, |z|, |ux|, |uz| before the push (regular particles)
     // optional external beam storage in the product's block layout (pipeline tests):
     // block p (p-th slice from the head) = [7][count_p] at 7*ext_off[p]
-    const double* ext_beam = nullptr; std::vector<long> ext_off;
+    const double* ext_beam = nullptr; std::vector<long> ext_off; std::vector<double> own_beam;      // own_beam: orc_engine_set_beam_particles
     std::vector<double> checksum;      // per comp: sum |Q| over all valid cells and slices
     long total_vcycles; long n_qsa_total;
     long pc_iterations = 0; double pc_err_sum = 0.0;     // Hipace.cpp:964,1028 (m_predcorr_avg_*)
@@ -2072,6 +2072,7 @@ extern "C" {
 // external beam storage in the product's block layout (see include/hpslice.h, hps_engine_beam_info)
 long orc_engine_beam_layout (void* h, long* offsets /* [nz+1] */);
 void orc_engine_set_external_beam (void* h, const double* storage);
+long orc_engine_set_beam_particles (void* h, long n, const double* soa);
 void orc_engine_initial_beam (void* h, double* dst);
 
 int orc_shape_factor (int order, double xmid, double* s_out) { return shape_factor(order, s_out, xmid); }
@@ -2317,6 +2318,35 @@ void orc_engine_set_external_beam (void* h, const double* storage) {
     e->ext_beam = storage;
 }
 void orc_engine_initial_beam (void* h, double* dst) { static_cast<Engine*>(h)->fill_initial_beam(dst); }
+// A host-initialised beam (any injection type of BeamParticleContainerInit.cpp) in place of the deck's, hipace.dt = 0:
+// soa = [7][n] x y z ux uy uz w; binned as BoxSorter does (sorting/BoxSort.cpp:34-43), head slice first, input order kept
+// inside a slice; returns the number of particles outside the box in z (left out).
+long orc_engine_set_beam_particles (void* h, long n, const double* soa) {
+    Engine* e = static_cast<Engine*>(h);
+    const int nz = e->d.nz;
+    std::vector<int> where((size_t)n);
+    std::vector<long> count((size_t)nz + 1, 0);
+    long outside = 0;
+    const double inv_dz = 1.0/e->gm.dz;
+    for (long i = 0; i < n; ++i) {
+        const double t = (soa[2*n + i] - e->d.lo[2])*inv_dz;
+        const int q = (t > -1.0e9 && t < 1.0e9) ? static_cast<int>(t) : -1;
+        if (q < 0 || q >= nz) { where[(size_t)i] = -1; ++outside; continue; }
+        where[(size_t)i] = nz - 1 - q; ++count[(size_t)(nz - 1 - q) + 1];
+    }
+    e->ext_off.assign(nz + 1, 0);
+    for (int p = 0; p < nz; ++p) e->ext_off[p + 1] = e->ext_off[p] + count[(size_t)p + 1];
+    std::vector<long> next(e->ext_off.begin(), e->ext_off.end() - 1);
+    e->own_beam.assign((size_t)7*(n - outside) + 1, 0.0);
+    for (long i = 0; i < n; ++i) {
+        const int p = where[(size_t)i];
+        if (p < 0) continue;
+        const long first = e->ext_off[p], cnt = e->ext_off[p + 1] - first, j = next[(size_t)p]++ - first;
+        for (int k = 0; k < 7; ++k) e->own_beam[(size_t)7*first + (size_t)k*cnt + j] = soa[(size_t)k*n + i];
+    }
+    e->ext_beam = e->own_beam.data();
+    return outside;
+}
 
 // beam statistics of the whole beam (sum over all slices) for the "beam" block of the JSONs
 void orc_engine_beam_stats (void* h, double* out /* n, sum w, sum|x|, sum|y|, sum|z|, sum|uz| */) {

@@ -504,6 +504,19 @@ class Engine:
         n = lib().orc_engine_beam_layout(self._h, _ptr(off))
         return n, off
 
+    def set_beam_particles(self, soa, allow_outside=False):
+        """A host-initialised beam in place of the deck's (hipace.dt = 0): soa = (7, n) x y z ux uy uz w; same binning as
+        hipace_amd.api.SliceEngine.set_beam_particles.  -> particles outside the box in z (left out)."""
+        assert not self.moving, "the oracle takes host-initialised beams with hipace.dt = 0 only"
+        soa = np.ascontiguousarray(soa, dtype=np.float64)
+        assert soa.ndim == 2 and soa.shape[0] == 7
+        L = lib()
+        L.orc_engine_set_beam_particles.restype = C.c_long
+        L.orc_engine_set_beam_particles.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+        out = L.orc_engine_set_beam_particles(self._h, soa.shape[1], _ptr(soa))
+        assert allow_outside or out == 0, "beam particles outside the box in z"
+        return out
+
     # ---- ring hand-off of a moving beam (same interface as hipace_amd.api.SliceEngine) --------------
     @property
     def moving(self):
