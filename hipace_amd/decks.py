@@ -435,3 +435,42 @@ def fixed_weight_pdf_beam(deck, num_particles, density, pdf, pos_mean=(0.0, 0.0)
         out[3 + k] = (u_mean[k] + (rng.normal(0.0, u_std[k], num_particles) if u_std[k] else 0.0)) * c
     out[6] = abs(total_weight / num_particles)
     return out
+
+
+def fixed_weight_beam(deck, num_particles, density, pos_mean, pos_std, u_mean=(0.0, 0.0, 0.0), u_std=(0.0, 0.0, 0.0),
+                      zmin=-float("inf"), zmax=float("inf"), radius=float("inf"), seed=0):
+    """beam.injection_type = fixed_weight, profile = gaussian, with a peak density (BeamParticleContainer.cpp:137-198,
+    InitBeamFixedWeight3D / InitBeamFixedWeightSlice, BeamParticleContainerInit.cpp:350-477), on the host: z is normal about
+    pos_mean[2] (:375-377), x and y are normal about pos_mean[0](z), pos_mean[1](z) -- numbers or vectorised callables of z
+    (:435-454) --, every particle carries density (2 pi)^(3/2) sigma_x sigma_y sigma_z / num_particles, in normalised units
+    over the cell volume (BeamParticleContainer.cpp:179-190, :420).  Particles outside [zmin, zmax] or the radius are invalid
+    in the reference (:443-446): left out here; particles outside the box are left out by set_beam_particles.  numpy's
+    generator stands in for amrex::Random.  -> (7, n <= num_particles) array x y z ux uy uz w, u times c."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    lo, hi = deck["lo"], deck["hi"]
+    dx, dy, dz = (hi[0] - lo[0]) / deck["nx"], (hi[1] - lo[1]) / deck["ny"], (hi[2] - lo[2]) / deck["nz"]
+    c = 299792458.0 if deck.get("si_units", 0) else 1.0
+    weight = density * (2.0 * np.pi) ** 1.5 * pos_std[0] * pos_std[1] * pos_std[2] / num_particles
+    if not deck.get("si_units", 0):
+        weight /= dx * dy * dz
+    z = rng.normal(pos_mean[2], pos_std[2], num_particles)
+    x = rng.normal(0.0, pos_std[0], num_particles)
+    y = rng.normal(0.0, pos_std[1], num_particles)
+    ok = (z >= zmin) & (z <= zmax) & (x * x + y * y <= radius * radius)
+    mx = pos_mean[0](z) if callable(pos_mean[0]) else pos_mean[0]
+    my = pos_mean[1](z) if callable(pos_mean[1]) else pos_mean[1]
+    out = np.empty((7, num_particles))
+    out[0], out[1], out[2] = mx + x, my + y, z
+    for k in range(3):
+        out[3 + k] = (u_mean[k] + (rng.normal(0.0, u_std[k], num_particles) if u_std[k] else 0.0)) * c
+    out[6] = abs(weight)
+    return np.ascontiguousarray(out[:, ok])
+
+
+def ion_motion_SI_reference_beam(deck, seed=1):
+    """the driver of examples/linear_wake/inputs_ion_motion_SI: fixed_weight, 10^6 particles, peak density ne, a Gaussian of
+    (0.4, 0.4, 1.41) kp^-1 about (0.25 kp^-1, 0.2 (z - 2 kp^-1), 2 kp^-1), u = (10, 20, 100)"""
+    kp_inv = 10.0e-6
+    return fixed_weight_beam(deck, 1000000, deck["plasma_density"], (0.25 * kp_inv, lambda z: (z - 2.0 * kp_inv) * 0.2, 2.0 * kp_inv),
+                             (0.4 * kp_inv, 0.4 * kp_inv, 1.41 * kp_inv), u_mean=(10.0, 20.0, 100.0), seed=seed)
