@@ -438,7 +438,7 @@ def fixed_weight_pdf_beam(deck, num_particles, density, pdf, pos_mean=(0.0, 0.0)
 
 
 def fixed_weight_beam(deck, num_particles, density, pos_mean, pos_std, u_mean=(0.0, 0.0, 0.0), u_std=(0.0, 0.0, 0.0),
-                      zmin=-float("inf"), zmax=float("inf"), radius=float("inf"), seed=0):
+                      zmin=-float("inf"), zmax=float("inf"), radius=float("inf"), seed=0, total_charge=None):
     """beam.injection_type = fixed_weight, profile = gaussian, with a peak density (BeamParticleContainer.cpp:137-198,
     InitBeamFixedWeight3D / InitBeamFixedWeightSlice, BeamParticleContainerInit.cpp:350-477), on the host: z is normal about
     pos_mean[2] (:375-377), x and y are normal about pos_mean[0](z), pos_mean[1](z) -- numbers or vectorised callables of z
@@ -451,7 +451,11 @@ def fixed_weight_beam(deck, num_particles, density, pos_mean, pos_std, u_mean=(0
     lo, hi = deck["lo"], deck["hi"]
     dx, dy, dz = (hi[0] - lo[0]) / deck["nx"], (hi[1] - lo[1]) / deck["ny"], (hi[2] - lo[2]) / deck["nz"]
     c = 299792458.0 if deck.get("si_units", 0) else 1.0
-    weight = density * (2.0 * np.pi) ** 1.5 * pos_std[0] * pos_std[1] * pos_std[2] / num_particles
+    if total_charge is not None:          # <beam>.total_charge (SI units only, BeamParticleContainer.cpp:167-172): density is not read
+        assert deck.get("si_units", 0) and density is None
+        weight = abs(total_charge / deck["beam_charge"]) / num_particles
+    else:
+        weight = density * (2.0 * np.pi) ** 1.5 * pos_std[0] * pos_std[1] * pos_std[2] / num_particles
     if not deck.get("si_units", 0):
         weight /= dx * dy * dz
     z = rng.normal(pos_mean[2], pos_std[2], num_particles)
@@ -474,3 +478,52 @@ def ion_motion_SI_reference_beam(deck, seed=1):
     kp_inv = 10.0e-6
     return fixed_weight_beam(deck, 1000000, deck["plasma_density"], (0.25 * kp_inv, lambda z: (z - 2.0 * kp_inv) * 0.2, 2.0 * kp_inv),
                              (0.4 * kp_inv, 0.4 * kp_inv, 1.41 * kp_inv), u_mean=(10.0, 20.0, 100.0), seed=seed)
+
+
+def production_lwfa(n=64, nz=100, max_step=10):
+    """examples/get_started/inputs_lwfa as tests/production.SI.2Rank.sh runs it (amr.n_cell = 64 64 100, max_step = 10): a laser
+    pulse (a0 = 1.9, w0 = 3 kp^-1, L0 = 0.5 kp^-1, multigrid envelope solver, MG_tolerance_rel = 1e-5) enters a parabolic plasma
+    channel of radius 23 kp^-1 through a cosine up-ramp of 6 mm, steps of c dt = 10 kp^-1, SI units, ne = 1.0505e23 m^-3.
+    The density function n_e (1 + 4 r^2 / (kp^2 Rm^4)) ramp(c t) [c t > 0] is the engine's tabulated form f_r(r) f_t(c t):
+    -> (deck, (r, fr, ct, ft)) for SliceEngine.set_density_profile -- the radial table on the lattice's own radii (exact at
+    every particle), cut at the channel's radius, the time table on the steps' own times."""
+    import numpy as np
+    ne = 1.0505e23
+    wp = (ne * SI["q_e"] ** 2 / (SI["m_e"] * SI["ep0"])) ** 0.5
+    kp_inv = SI["c"] / wp
+    kp = wp / SI["c"]
+    Rm, Lramp = 3.0 * kp_inv, 6.0e-3
+    d = copy.deepcopy(_DEFAULT)
+    d.update(nx=n, ny=n, nz=nz, lo=(-18.0 * kp_inv, -18.0 * kp_inv, -7.5 * kp_inv), hi=(18.0 * kp_inv, 18.0 * kp_inv, 1.5 * kp_inv),
+             order=2, si_units=1, plasma_ppc=(1, 1), plasma_density=ne, plasma_charge=-SI["q_e"], plasma_mass=SI["m_e"],
+             beam_profile=-1, bc=1, n_steps=max_step + 1, dt=10.0 * kp_inv / SI["c"],
+             laser_on=1, laser_a0=1.9, laser_w0=3.0 * kp_inv, laser_L0=0.5 * kp_inv, laser_lambda0=800.0e-9, laser_pos=(0.0, 0.0, 0.0),
+             laser_solver=2, laser_mg_tol_rel=1.0e-5)
+    dx = (d["hi"][0] - d["lo"][0]) / n
+    xs = d["lo"][0] + (np.arange(n) + 0.5) * dx
+    r2 = np.unique(np.add.outer(xs * xs, xs * xs).round(decimals=22))
+    r = np.sqrt(r2)
+    rad = 23.0 * kp_inv
+    inside = r <= rad
+    r_tab = np.concatenate([r[inside], [rad * (1.0 + 1e-12)]]) if inside.sum() < r.size else r
+    fr = 1.0 + 4.0 * r_tab ** 2 / (kp ** 2 * Rm ** 4)
+    if inside.sum() < r.size:
+        fr[-1] = 0.0
+    if r_tab[0] > 0.0:
+        r_tab = np.concatenate([[0.0], r_tab]); fr = np.concatenate([[1.0], fr])
+    ct = np.array([SI["c"] * d["dt"] * k for k in range(max_step + 2)])
+    ft = np.where(ct > 0.0, np.where(ct > Lramp, 1.0, 0.5 * (1.0 - np.cos(np.pi * ct / Lramp))), 0.0)
+    return d, (r_tab, fr, ct, ft)
+
+
+def gaussian_weight_SI():
+    """examples/gaussian_weight/inputs_SI as the last run of tests/gaussian_weight.1Rank.sh (the one its checksum file holds): a
+    fixed_weight beam of 10^5 particles and 1 nC, a Gaussian of (30, 40, 50) um about (0, 10, 20) um, in vacuum on 64^3 cells,
+    absorbing particle boundary.  -> (deck without a beam, the beam's parameters for fixed_weight_beam)"""
+    d = copy.deepcopy(_DEFAULT)
+    d.update(nx=64, ny=64, nz=64, lo=(-200.0e-6, -200.0e-6, -200.0e-6), hi=(200.0e-6, 200.0e-6, 200.0e-6), order=2, si_units=1,
+             plasma_ppc=(0, 0), plasma_density=0.0, plasma_charge=-SI["q_e"], plasma_mass=SI["m_e"],
+             beam_profile=-1, beam_charge=-SI["q_e"], beam_mass=SI["m_e"], bc=2, n_steps=1, dt=0.0)
+    beam = dict(num_particles=100000, density=None, total_charge=1.0e-9, pos_mean=(0.0, 10.0e-6, 20.0e-6),
+                pos_std=(30.0e-6, 40.0e-6, 50.0e-6), u_mean=(0.0, 0.0, 1.0e3), zmin=-1.0, zmax=1.0, radius=1.0)
+    return d, beam

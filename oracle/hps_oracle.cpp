@@ -1117,6 +1117,7 @@ struct Engine {
     // block p (p-th slice from the head) = [7][count_p] at 7*ext_off[p]
     const double* ext_beam = nullptr; std::vector<long> ext_off; std::vector<double> own_beam;      // own_beam: orc_engine_set_beam_particles
     std::vector<double> checksum;      // per comp: sum |Q| over all valid cells and slices
+    std::vector<double> checksum_xz;   // ... over the y = 0 line of every slice (diag_type = xz)
     long total_vcycles; long n_qsa_total;
     long pc_iterations = 0; double pc_err_sum = 0.0;     // Hipace.cpp:964,1028 (m_predcorr_avg_*)
     int c_aabs = -1; double laser_envelope_sum = 0.0;    // slab component of |a|^2; sum |a| over the box ("laserEnvelope")
@@ -1148,7 +1149,7 @@ struct Engine {
         init_ionization();
         mg = d.bxby_solver ? nullptr : new MG(d.nx, d.ny, gm.dx, gm.dy);
         staging.assign((size_t)d.nx*d.ny, 0.0);
-        checksum.assign((size_t)ncomp, 0.0);
+        checksum.assign((size_t)ncomp, 0.0); checksum_xz.assign((size_t)ncomp, 0.0);
         total_vcycles = 0; n_qsa_total = 0;
         t_deposit = t_explicit = t_push = t_poisson = t_mg = t_other = 0;
         pl.n = 0;
@@ -1748,6 +1749,12 @@ struct Engine {
                 double s = 0;
                 for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i) s += std::abs(slab(i,j,n));
                 checksum[n] += s;
+                // diag_type = xz: the y = 0 line of the slice -- the centre row, or the mean of the two central ones
+                // (Fields::Copy's linear interpolation onto the trimmed diagnostic box, fields/Fields.cpp:413-533)
+                double sx = 0;
+                const int ja = (d.ny - 1)/2, jb = d.ny/2;
+                for (int i = 0; i < d.nx; ++i) sx += std::abs(0.5*(slab(i,ja,n) + slab(i,jb,n)));
+                checksum_xz[n] += sx;
             }
         }
         double t8 = now(); t_other += t8 - t7;
@@ -1823,6 +1830,12 @@ struct Engine {
                 double s = 0;
                 for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i) s += std::abs(slab(i,j,n));
                 checksum[n] += s;
+                // diag_type = xz: the y = 0 line of the slice -- the centre row, or the mean of the two central ones
+                // (Fields::Copy's linear interpolation onto the trimmed diagnostic box, fields/Fields.cpp:413-533)
+                double sx = 0;
+                const int ja = (d.ny - 1)/2, jb = d.ny/2;
+                for (int i = 0; i < d.nx; ++i) sx += std::abs(0.5*(slab(i,ja,n) + slab(i,jb,n)));
+                checksum_xz[n] += sx;
             }
         }
         double t8 = now(); t_other += t8 - t7;
@@ -2024,7 +2037,7 @@ struct Engine {
         const int comp[6] = {-1, -1, -1, -1, -1, d.bxby_solver ? (int)pIon_rhomjz : (int)Ion_rhomjz};
         if (!d.plasma_no_neutralize)
             deposit_current(slab, pl, gm, comp, -d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0);
-        std::fill(checksum.begin(), checksum.end(), 0.0);
+        std::fill(checksum.begin(), checksum.end(), 0.0); std::fill(checksum_xz.begin(), checksum_xz.end(), 0.0);
         for (double& v : beam_diag) v = 0.0;
         laser_envelope_sum = 0.0;
         if (c_aabs >= 0) {
@@ -2273,6 +2286,7 @@ double orc_ion_uniform (unsigned long long seed, unsigned long long uid, unsigne
 }
 int32_t* orc_engine_valid (void* h) { return static_cast<Engine*>(h)->pvalid.data(); }
 void orc_engine_checksums (void* h, double* out) { Engine* e = static_cast<Engine*>(h); for (int n = 0; n < e->ncomp; ++n) out[n] = e->checksum[n]; }
+void orc_engine_checksums_xz (void* h, double* out) { Engine* e = static_cast<Engine*>(h); for (int n = 0; n < e->ncomp; ++n) out[n] = e->checksum_xz[n]; }
 long orc_engine_vcycles (void* h) { return static_cast<Engine*>(h)->total_vcycles; }
 long orc_engine_pc_iterations (void* h) { return static_cast<Engine*>(h)->pc_iterations; }
 double orc_engine_pc_error_sum (void* h) { return static_cast<Engine*>(h)->pc_err_sum; }

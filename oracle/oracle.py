@@ -626,6 +626,16 @@ class Engine:
     def copy_async(self, dst, src):
         dst.copy_(src)
 
+    def checksums_xz(self):
+        """diag_type = xz: per field the sum of the absolute values on the y = 0 line of every slice of the last step"""
+        out = np.zeros(self.ncomp)
+        L = lib()
+        L.orc_engine_checksums_xz.restype = None
+        L.orc_engine_checksums_xz.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_engine_checksums_xz(self._h, _ptr(out))
+        names = self.comp_names()
+        return {names[i]: out[i] for i in range(self.ncomp)}
+
     def checksums(self):
         out = np.zeros(self.ncomp)
         lib().orc_engine_checksums(self._h, _ptr(out))

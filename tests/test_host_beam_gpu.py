@@ -30,6 +30,44 @@ def api():
     return A
 
 
+def _xz_diagnostic_sums(api, eng, deck, names, index=None):
+    """One time step of `eng`, and what diag_type = xz + checksumAPI make of it: per field the sum over all slices of the
+    absolute values on the y = 0 line -- the centre row for an odd ny, the mean of the two central rows for an even one
+    (Fields::Copy interpolates linearly onto the diagnostic's grid, fields/Fields.cpp:413-533; Diagnostic::TrimIOBox,
+    diagnostics/Diagnostic.cpp:393-410).  FillFieldDiagnostics runs ahead of the push and of ShiftSlices (Hipace.cpp:691, 722):
+    the rows are copied on the engine's stream behind each slice, which does not flush the deferred shift (hps_engine_slab /
+    hps_engine_sync would); the last slice of a step is shifted at once, so the planes the shift rewrites (jx, jy and the
+    beam's transverse currents) are copied between its two halves.  -> {name: sum}"""
+    import torch
+    from hipace_amd import _lib
+    L = _lib.lib()
+    s = L.hps_engine_slab(eng._h)
+    g, nx, ny, nz = s.ng, deck["nx"], deck["ny"], deck["nz"]
+    index = index or _lib.CIDX
+    js = [ny // 2] if ny % 2 else [ny // 2 - 1, ny // 2]
+    rows = torch.zeros((nz, len(names), len(js), nx), dtype=torch.float64, device="cuda")
+    shifted = {"jx", "jy", "jx_beam", "jy_beam"}
+
+    def copy(isl, which):
+        for m, k in enumerate(names):
+            if k in which:
+                for h, j in enumerate(js):
+                    src = s.p + 8 * (index[k] * s.nstride + (j + g) * s.jstride + g)
+                    assert L.hps_engine_copy_async(eng._h, C.c_void_p(rows[isl, m, h].data_ptr()), C.c_void_p(src), 8 * nx) == 0
+
+    eng.begin_step()
+    for isl in range(nz - 1, 0, -1):
+        eng.solve_slice(isl)
+        copy(isl, set(names))
+    eng.solve_slice_begin(0)
+    copy(0, shifted)
+    eng.solve_slice_finish(0)
+    copy(0, set(names) - shifted)
+    eng.sync()
+    tot = rows.mean(dim=2).abs().sum(dim=(0, 2)).cpu().numpy()
+    return {k: float(tot[m]) for m, k in enumerate(names)}
+
+
 def _deck_beam_as_soa(api, deck):
     """the particles of the deck's fixed_ppc beam, head slice first: (7, n)"""
     import torch
@@ -175,23 +213,8 @@ def test_transverse_benchmark_deck_against_the_reference_checksums(api):
         assert abs(np.abs(soa[row]).sum() - gb[k]) <= 2e-3 * gb[k], k
     eng = api.SliceEngine(deck, tile_size=16)
     assert eng.set_beam_particles(soa) == 0
-    import torch
     names = list(gold["lev=0"].keys())
-    L = _lib.lib()
-    s = L.hps_engine_slab(eng._h)
-    g, jc, nx, nz = s.ng, deck["ny"] // 2, deck["nx"], deck["nz"]
-    rows = torch.zeros((nz, len(names), nx), dtype=torch.float64, device="cuda")
-    eng.begin_step()
-    for isl in range(nz - 1, -1, -1):
-        eng.solve_slice(isl)
-        # FillFieldDiagnostics runs ahead of ShiftSlices (Hipace.cpp:691, 722): copies on the engine's stream, which do
-        # not flush the deferred shift (hps_engine_slab / hps_engine_sync would: jx, jy then hold the next slice's start)
-        for m, k in enumerate(names):
-            src = s.p + 8 * (CIDX[k] * s.nstride + (jc + g) * s.jstride + g)
-            assert L.hps_engine_copy_async(eng._h, C.c_void_p(rows[isl, m].data_ptr()), C.c_void_p(src), 8 * nx) == 0
-    eng.sync()
-    tot = rows.abs().sum(dim=(0, 2)).cpu().numpy()
-    sums = {k: float(tot[m]) for m, k in enumerate(names)}
+    sums = _xz_diagnostic_sums(api, eng, deck, names)
     # measured with this seed (profiles/r05_reference_decks_host_beams.txt): By -4.4e-4, ExmBy -6.1e-5, Ez +2.8e-5, Psi +1.9e-4, chi -9.1e-4,
     # jz_beam -2.5e-3; jx -1.9e-2 and rhomjz -1.8e-2 carry the absolute values of the beam's grid-scale noise
     signal = {"By": 3e-3, "ExmBy": 1e-3, "Ez": 5e-4, "Psi": 1e-3, "chi": 3e-3, "jx": 4e-2, "jz_beam": 1e-2, "rhomjz": 4e-2}
@@ -244,3 +267,62 @@ def test_ion_motion_SI_deck_against_the_reference_checksums(api, oracle):
     for k in cs:
         if oc[k] != 0.0:
             assert abs(cs[k] - oc[k]) <= 1e-8 * abs(oc[k]), (k, cs[k], oc[k])
+
+
+def test_production_lwfa_deck_matches_the_reference_checksums(api):
+    """tests/production.SI.2Rank.sh, second half (examples/get_started/inputs_lwfa at 64 x 64 x 100, max_step = 10; the
+    reference's CI accepts rtol 5e-6): a laser pulse enters a parabolic plasma channel through a density up-ramp -- eleven time
+    steps with the multigrid envelope solver, no beam, nothing random: the xz diagnostic of the last step against
+    tests/checksum/benchmarks_json/production.SI.2Rank_lwfa.json.  Bx, Bz, EypBx, Sy and jy vanish on the symmetry line
+    (rounding: 1e-9 of By's scale) and are held to the file's own size."""
+    gold = json.load(open(os.path.join(GOLD, "production.SI.2Rank_lwfa.json")))["lev=0"]
+    deck, prof = decks.production_lwfa()
+    eng = api.SliceEngine(deck, tile_size=16)
+    eng.set_density_profile(*prof)
+    for _ in range(deck["n_steps"] - 1):
+        eng.run_step()
+    names = [k for k in gold if k != "laserEnvelope"]
+    cn = eng.comp_names()
+    sums = _xz_diagnostic_sums(api, eng, deck, names, index={k: cn.index(k) for k in names})
+    a = eng.laser_envelope()
+    ny = deck["ny"]
+    sums["laserEnvelope"] = float(np.abs(0.5 * (a[:, ny // 2 - 1, :] + a[:, ny // 2, :])).sum())
+    for k in ("By", "ExmBy", "Ez", "Psi", "Sx", "aabs", "chi", "jx", "laserEnvelope", "rhomjz"):
+        assert abs(sums[k] - gold[k]) <= 1e-10 * gold[k], (k, sums[k], gold[k])
+    for k in ("Bx", "Bz", "EypBx", "Sy", "jy"):
+        assert abs(sums[k] - gold[k]) <= 1e-5 * gold[k], (k, sums[k], gold[k])
+    for k in ("jx_beam", "jy_beam", "jz_beam"):
+        assert sums[k] == 0.0 == gold[k]
+
+
+def test_gaussian_weight_deck_against_the_reference_checksums(api, oracle):
+    """tests/gaussian_weight.1Rank.sh, the SI run its checksum file holds: a 1 nC fixed_weight beam in vacuum.  The beam's own
+    sums and the fields it makes against the file to the shot noise of 10^5 particles, and against the oracle on the same
+    particles to rounding."""
+    gold = json.load(open(os.path.join(GOLD, "gaussian_weight.1Rank.json")))
+    deck, beam = decks.gaussian_weight_SI()
+    soa = decks.fixed_weight_beam(deck, seed=5, **beam)
+    ge = api.SliceEngine(deck, tile_size=0)
+    n_out = ge.set_beam_particles(soa, allow_outside=True)
+    dz = (deck["hi"][2] - deck["lo"][2]) / deck["nz"]
+    q = ((soa[2] - deck["lo"][2]) * (1.0 / dz)).astype(np.int64)
+    kept = soa[:, (q >= 0) & (q < deck["nz"])]
+    gb = gold["beam"]
+    assert abs(kept[6].sum() - gb["w"]) <= 1e-3 * gb["w"]             # (the file's beam lost 16 of 10^5 particles to the box)
+    for k, r in (("x", 0), ("y", 1), ("z", 2)):
+        assert abs(np.abs(kept[r]).sum() - gb[k]) <= 1e-2 * gb[k], k
+    assert abs(np.abs(kept[5]).sum() / 299792458.0 - gb["uz"]) <= 1e-3 * gb["uz"]
+    ge.set_diagnostics(True)
+    ge.run_step()
+    cs = ge.checksums()
+    for k, tol in (("jz_beam", 2e-3), ("Bx", 1e-2), ("By", 1e-2), ("Sx", 5e-2), ("Sy", 5e-2)):
+        v = gold["lev=0"][k]
+        assert abs(cs[k] - v) <= tol * v, (k, cs[k], v)
+    for k in ("Bz", "ExmBy", "EypBx", "Ez", "Psi", "chi", "jx", "jy", "jx_beam", "jy_beam", "rhomjz"):
+        assert gold["lev=0"][k] == 0.0 and abs(cs[k]) <= 1e-12 * cs["By"], (k, cs[k])
+    oe = oracle.Engine(deck)
+    assert oe.set_beam_particles(soa, allow_outside=True) == n_out
+    oe.run()
+    oc = oe.checksums()
+    for k in ("jz_beam", "Bx", "By", "Sx", "Sy"):
+        assert abs(cs[k] - oc[k]) <= 1e-9 * oc[k], (k, cs[k], oc[k])

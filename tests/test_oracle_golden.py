@@ -448,3 +448,25 @@ def test_spin_tracking_follows_thomas_bmt(oracle):
         assert np.abs(sp[1]).max() <= 1e-3 * angle and np.abs(sp[2] + om_y * T).max() <= 2e-3 * angle
         assert np.abs(sp[0] - 1.0).max() <= angle ** 2
     assert total > 500
+
+
+def test_oracle_reproduces_the_production_lwfa_checksums(oracle):
+    """tests/production.SI.2Rank.sh, second half (examples/get_started/inputs_lwfa at 64 x 64 x 100, max_step = 10, rtol 5e-6 in the
+    reference's CI): a laser pulse entering a parabolic plasma channel through a density up-ramp, eleven time steps with the
+    multigrid envelope solver; nothing in the deck is random.  The xz diagnostic of the last step (the mean of the two central rows
+    of every slice) to 1e-11; the quantities that vanish on the symmetry line (1e-9 of By's scale there) to 1e-5."""
+    gold = json.load(open(os.path.join(GOLD, "production.SI.2Rank_lwfa.json")))["lev=0"]
+    deck, prof = decks.production_lwfa()
+    eng = oracle.Engine(deck)
+    eng.set_density_profile(*prof)
+    eng.run()
+    cs = eng.checksums_xz()
+    a = eng.laser_envelope()
+    ny = deck["ny"]
+    cs["laserEnvelope"] = np.abs(0.5 * (a[:, ny // 2 - 1, :] + a[:, ny // 2, :])).sum()
+    for k in ("By", "ExmBy", "Ez", "Psi", "Sx", "aabs", "chi", "jx", "laserEnvelope", "rhomjz"):
+        assert abs(cs[k] - gold[k]) <= 1e-11 * gold[k], (k, cs[k], gold[k])
+    for k in ("Bx", "Bz", "EypBx", "Sy", "jy"):
+        assert abs(cs[k] - gold[k]) <= 1e-5 * gold[k], (k, cs[k], gold[k])
+    for k in ("jx_beam", "jy_beam", "jz_beam"):
+        assert cs[k] == 0.0 == gold[k]
