@@ -527,3 +527,27 @@ def gaussian_weight_SI():
     beam = dict(num_particles=100000, density=None, total_charge=1.0e-9, pos_mean=(0.0, 10.0e-6, 20.0e-6),
                 pos_std=(30.0e-6, 40.0e-6, 50.0e-6), u_mean=(0.0, 0.0, 1.0e3), zmin=-1.0, zmax=1.0, radius=1.0)
     return d, beam
+
+
+def radiation_reaction_SI():
+    """examples/beam_in_vacuum/inputs_RR as tests/radiation_reaction.1Rank.sh runs it: a matched gamma = 2000 beam sheet
+    (sigma_y = 1e-12 m) of 10^5 fixed_weight particles in the linear focusing field E = (kp E0 / 2)(x, y, 0) of a blowout at
+    n0 = 5e24 m^-3, SI units, 16 x 16 x 4 cells, six steps of 30 / omega_beta with 50 sub-cycles, radiation reaction on, no z push.
+    -> (deck without a beam, the beam's parameters for fixed_weight_beam)"""
+    ne = 5.0e24
+    wp = (ne * SI["q_e"] ** 2 / (SI["ep0"] * SI["m_e"])) ** 0.5
+    E0 = wp * SI["m_e"] * SI["c"] / SI["q_e"]
+    kp = wp / SI["c"]
+    K, gamma0, emit = kp / 2.0 ** 0.5, 2000.0, 313.0e-6
+    sigma_x = (emit / kp / (gamma0 / 2.0) ** 0.5) ** 0.5
+    sigma_ux = emit / sigma_x
+    uz = (gamma0 ** 2 - 1.0 - sigma_ux ** 2) ** 0.5
+    w_beta = K * SI["c"] / gamma0 ** 0.5
+    d = copy.deepcopy(_DEFAULT)
+    d.update(nx=16, ny=16, nz=4, lo=(-30.0e-6, -30.0e-6, -10.0e-6), hi=(30.0e-6, 30.0e-6, 10.0e-6), order=2, si_units=1,
+             plasma_ppc=(0, 0), plasma_density=0.0, plasma_charge=-SI["q_e"], plasma_mass=SI["m_e"],
+             beam_profile=-1, beam_charge=-SI["q_e"], beam_mass=SI["m_e"], bc=1, n_steps=6, dt=30.0 / w_beta,
+             ext_E_slope=(0.5 * kp * E0, 0.5 * kp * E0), beam_n_subcycles=50, beam_radiation_reaction=1, beam_no_z_push=1)
+    beam = dict(num_particles=100000, density=ne / 1.0e10, pos_mean=(0.0, 0.0, 0.0), pos_std=(sigma_x, 1.0e-12, 1.0e-6),
+                u_mean=(0.0, 0.0, uz), u_std=(sigma_ux, 0.0, uz * 0.01))
+    return d, beam
