@@ -246,3 +246,94 @@ def write_engine_output(engine, prefix, iteration, time=0.0, beam_name="beam", b
                                  charge=d["beam_charge"], mass=d.get("beam_mass", 1.0) or 1.0)}
     return write_iteration(prefix, iteration, time, d.get("dt", 0.0), dict(lo=d["lo"], hi=d["hi"], cells=(d["nx"], d["ny"], d["nz"])), fields, beams,
                            normalized=not d.get("si_units", 0), json_too=json_too, hdf5=hdf5)
+
+
+# ---- beam.injection_type = from_file ------------------------------------------------------------------------------------
+def read_beam(container, deck, iteration=0, species=None, plasma_density=0.0):
+    """<beam>.injection_type = from_file (InitBeamFromFile, particles/beam/BeamParticleContainerInit.cpp:768-1090): the beam of
+    one openPMD iteration as the (7, n) array x y z ux uy uz w that SliceEngine.set_beam_particles takes, in `deck`'s units.
+
+    container: an HDF5 file of this writer or of any openPMD writer (`read_hdf5`), or the (arrays, attrs) pair itself.
+    As the reference: the records are found by their unitDimension -- position L, proper velocity L/T or momentum M L/T, and
+    for the weights `weighting`, else a charge (I T), else a mass (M) record (:797-885, :906-927); record components may be
+    datasets or constant (`value` + `shape`); every value is scaled by its unitSI -- or, for a file that carries
+    HiPACE++_use_reference_unitSI (one of the reference's, or this writer's), by HiPACE++_reference_unitSI (:1011-1040) --
+    over the simulation's unit in SI: 1 m, c (or m c for a momentum), one particle (charge: q, mass: m) in an SI run;
+    1/kp, and n0 dx dy dz / kp^3 particles, in a normalised run, n0 = plasma_density or the file's HiPACE++_Plasma_Density
+    (:990-1009).  species None: the first one in the file."""
+    arrays, attrs = read_hdf5(container) if isinstance(container, str) else container
+    base = f"/data/{iteration}/particles"
+    names = sorted({p[len(base) + 1:].split("/")[0] for p in list(arrays) + list(attrs) if p.startswith(base + "/")})
+    if not names:
+        raise ValueError(f"no particle species in iteration {iteration}")
+    if species is None:
+        species = names[0]
+    if species not in names:
+        raise ValueError(f"species {species!r} not in the file (it holds {names})")
+    root = f"{base}/{species}"
+    records = sorted({p[len(root) + 1:].split("/")[0] for p in list(arrays) + list(attrs) if p.startswith(root + "/")})
+
+    def dims(rec):
+        return tuple(float(v) for v in attrs.get(f"{root}/{rec}", {}).get("unitDimension", [0.0] * 7))
+
+    def comps(rec):
+        cs = sorted({p[len(root) + len(rec) + 2:].split("/")[0] for p in list(arrays) + list(attrs) if p.startswith(f"{root}/{rec}/")})
+        return cs or [None]                  # None: the record is its own (scalar) component
+
+    L, V, P = (1.0, 0, 0, 0, 0, 0, 0), (1.0, 0, -1.0, 0, 0, 0, 0), (1.0, 1.0, -1.0, 0, 0, 0, 0)
+    M, Q, none = (0, 1.0, 0, 0, 0, 0, 0), (0, 0, 1.0, 1.0, 0, 0, 0), (0,) * 7
+    name_r = name_u = name_w = None
+    u_is_momentum = False
+    kind = None
+    for rec in records:
+        dm = dims(rec)
+        if dm == L and ("position" not in records or rec == "position"):
+            name_r = rec
+        elif dm == V:
+            name_u, u_is_momentum = rec, False
+        elif dm == P:
+            name_u, u_is_momentum = rec, True
+    for want, dm, k in (("weighting", none, "weighting"), (None, Q, "charge"), (None, M, "mass")):
+        for rec in records:
+            if name_w is None and dims(rec) == dm and (want is None or rec == want):
+                name_w, kind = rec, k
+    if name_r is None or name_u is None or name_w is None:
+        raise ValueError("the file needs a position (L), a velocity or momentum (L/T, M L/T) and a weighting, charge or mass record")
+
+    def component(rec, axis):
+        for c in comps(rec):
+            if c is None or c.lower() == axis or axis is None:
+                path = f"{root}/{rec}" + (f"/{c}" if c is not None else "")
+                a = attrs.get(path, {})
+                if path in arrays:
+                    return np.asarray(arrays[path], dtype=np.float64), a
+                if "value" in a:
+                    return np.full(int(np.atleast_1d(a["shape"])[0]), float(a["value"])), a
+        raise ValueError(f"record {rec!r} has no {axis!r} component")
+
+    si = deck.get("si_units", 0)
+    c_SI, q_SI, m_SI, ep0 = 299792458.0, 1.602176634e-19, 9.1093837015e-31, 8.8541878128e-12
+    mass, charge = deck.get("beam_mass", 1.0) or 1.0, deck["beam_charge"]
+    m_e_sim, q_e_sim, c_sim = (m_SI, q_SI, c_SI) if si else (1.0, 1.0, 1.0)
+    to_pos = 1.0
+    to_mom = mass * (m_SI / m_e_sim) * c_SI if u_is_momentum else c_SI
+    to_w = dict(weighting=1.0, charge=charge * (q_SI / q_e_sim), mass=mass * (m_SI / m_e_sim))[kind]
+    sp_attrs = attrs.get(root, {})
+    if not si:
+        n0 = plasma_density or float(sp_attrs.get("HiPACE++_Plasma_Density", 0.0))
+        if not n0:
+            raise ValueError("a normalised run needs the plasma density of the external beam (plasma_density, or HiPACE++_Plasma_Density in the file)")
+        kp_inv = c_SI / (q_SI * np.sqrt(n0 / (ep0 * m_SI)))
+        cell = np.prod([(deck["hi"][k] - deck["lo"][k]) / deck[("nx", "ny", "nz")[k]] for k in range(3)])
+        to_pos = kp_inv
+        to_w *= n0 * cell * kp_inv ** 3
+    restart = bool(sp_attrs.get("HiPACE++_use_reference_unitSI", False))
+
+    def scaled(rec, axis, unit):
+        v, a = component(rec, axis)
+        return v * (float(a["HiPACE++_reference_unitSI"] if restart else a.get("unitSI", 1.0)) / unit)
+
+    out = np.array([scaled(name_r, "x", to_pos), scaled(name_r, "y", to_pos), scaled(name_r, "z", to_pos),
+                    scaled(name_u, "x", to_mom) * c_sim, scaled(name_u, "y", to_mom) * c_sim, scaled(name_u, "z", to_mom) * c_sim,
+                    np.abs(scaled(name_w, None, to_w))])
+    return out

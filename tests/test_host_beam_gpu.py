@@ -363,3 +363,31 @@ def test_radiation_reaction_deck_against_the_reference_checksums(api):
         assert v / 4.0 <= sums[k] <= 4.0 * v, (k, sums[k], v)
     for k in ("ExmBy", "EypBx", "Psi", "chi", "rhomjz"):
         assert sums[k] == 0.0 == gold["lev=0"][k]
+
+
+def test_restart_from_the_first_runs_beam_output(api, tmp_path):
+    """tests/restart.normalized.1Rank.sh: the beam_in_vacuum deck on 16 x 16 x 32 cells writes its beam; a second run on
+    24 x 24 x 48 cells of the same box takes it from that file (from_file): the same particles with the weights scaled to
+    the new cells, and the same total current on the grid."""
+    from hipace_amd.openpmd_writer import read_beam, write_iteration
+    base = dict(decks.beam_in_vacuum(), lo=(-2.0, -2.0, -12.0), hi=(2.0, 2.0, 12.0), order=2, n_steps=1)
+    d1 = dict(base, nx=16, ny=16, nz=32)
+    d2 = dict(base, nx=24, ny=24, nz=48, beam_profile=-1)
+    soa1, off1 = _deck_beam_as_soa(api, d1)
+    assert soa1.shape[1] > 100
+    e1 = api.SliceEngine(d1, tile_size=0)
+    e1.set_diagnostics(True)
+    e1.run_step()
+    beam = dict(zip(("x", "y", "z", "ux", "uy", "uz", "w"), soa1), charge=d1["beam_charge"], mass=1.0)
+    fn = write_iteration(str(tmp_path / "restart_1"), 0, 0.0, 0.0, dict(lo=d1["lo"], hi=d1["hi"], cells=(16, 16, 32)),
+                         beams={"beam": beam}, normalized=True, hdf5=True)
+    soa2 = read_beam(str(tmp_path / "restart_1" / "openpmd_000000.h5"), d2, species="beam")
+    ratio = (24 * 24 * 48) / (16 * 16 * 32)
+    assert np.abs(soa2[:6] - soa1[:6]).max() <= 1e-12 * np.abs(soa1[:6]).max()
+    assert np.abs(soa2[6] - ratio * soa1[6]).max() <= 1e-12 * ratio * soa1[6].max()
+    e2 = api.SliceEngine(d2, tile_size=0)
+    assert e2.set_beam_particles(soa2) == 0
+    e2.set_diagnostics(True)
+    e2.run_step()
+    c1, c2 = e1.checksums()["jz_beam"], e2.checksums()["jz_beam"]
+    assert c1 > 0 and abs(c2 / ratio - c1) <= 1e-12 * c1          # sum of jz_beam times the cell volume
