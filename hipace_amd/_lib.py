@@ -166,6 +166,8 @@ _SIGS = {
     "hps_engine_insitu_fields": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_set_field_diagnostic": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hps_engine_field_diagnostic": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hps_engine_set_field_diagnostic_box": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "hps_engine_field_diagnostic_geometry": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hps_engine_record_event": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "hps_engine_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_copy_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]),

@@ -423,22 +423,32 @@ class SliceEngine:
         check(_lib.lib().hps_engine_initial_beam(self._h, C.c_void_p(tensor.data_ptr())))
 
     # ---- field diagnostics (Fields::Copy) -----------------------------------------------------------------
-    def set_field_diagnostic(self, names, coarsening=(1, 1, 1)):
-        """diagnostic.field_data = names, diagnostic.coarsening = cx cy cz (diag_type xyz, whole box)."""
+    def set_field_diagnostic(self, names, coarsening=(1, 1, 1), diag_type="xyz", patch_lo=None, patch_hi=None):
+        """diagnostic.field_data = names, diagnostic.coarsening = cx cy cz, diagnostic.diag_type = xyz | xz | yz | xy,
+        diagnostic.patch_lo / patch_hi (hps_engine_set_field_diagnostic_box)."""
         idx = _lib.CIDX_PC if self.deck.get("bxby_solver", 0) else _lib.CIDX
-        comps = (C.c_int * len(names))(*[idx[n] for n in names])
+        cn = self.comp_names()
+        comps = (C.c_int * len(names))(*[idx[n] if n in idx else cn.index(n) for n in names])
         co = (C.c_int * 3)(*coarsening)
-        check(_lib.lib().hps_engine_set_field_diagnostic(self._h, len(names), comps, co))
+        sd = {"xyz": -1, "yz": 0, "xz": 1, "xy": 2}[diag_type]
+        plo = (C.c_double * 3)(*patch_lo) if patch_lo is not None else None
+        phi = (C.c_double * 3)(*patch_hi) if patch_hi is not None else None
+        check(_lib.lib().hps_engine_set_field_diagnostic_box(self._h, len(names), comps, co, sd, plo, phi))
         self._fd = (list(names), tuple(coarsening))
 
+    def field_diagnostic_geometry(self):
+        """-> (cells (nx, ny, nz), lo, hi) of the diagnostic grid"""
+        n, lo, hi = (C.c_int * 3)(), (C.c_double * 3)(), (C.c_double * 3)()
+        check(_lib.lib().hps_engine_field_diagnostic_geometry(self._h, n, lo, hi))
+        return tuple(n), tuple(lo), tuple(hi)
+
     def field_diagnostic(self):
-        """-> dict name -> array [nz/cz, ny/cy, nx/cx] of the step that is being (or has just been) solved."""
-        names, co = self._fd
-        d = self.deck
-        shp = (len(names), d["nz"] // co[2], d["ny"] // co[1], d["nx"] // co[0])
-        out = np.empty(shp)
+        """-> dict name -> array [nz, ny, nx] of the diagnostic grid, of the step that is being (or has just been) solved."""
+        names, _ = self._fd
+        n, _, _ = self.field_diagnostic_geometry()
+        out = np.empty((len(names), n[2], n[1], n[0]))
         check(_lib.lib().hps_engine_field_diagnostic(self._h, out.ctypes.data_as(C.c_void_p)))
-        return {n: out[i] for i, n in enumerate(names)}
+        return {k: out[i] for i, k in enumerate(names)}
 
     INSITU_FIELDS = ["[Ex^2]", "[Ey^2]", "[Ez^2]", "[Bx^2]", "[By^2]", "[Bz^2]", "[ExmBy^2]", "[EypBx^2]", "[jz_beam]",
                      "[Ez*jz_beam]"]

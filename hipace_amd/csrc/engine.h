@@ -153,6 +153,10 @@ struct Engine {
     int join_laser ();          // the engine's stream waits for the laser stream's last slice (no-op if none is pending)
     // field diagnostic (Fields::Copy): components, coarsening, device array [ncomps][nzc][nyc][nxc]
     std::vector<int> fd_comps; int fd_c[3] = {1, 1, 1}; double* d_fd = nullptr; int* d_fd_comps = nullptr;
+    // geometry of the diagnostic grid (Diagnostic::ResizeFDiagFAB + TrimIOBox, diagnostics/Diagnostic.cpp:300-410): cells, cell
+    // size, position of local cell 0 (GetPosOffset of the diagnostic geometry + first index * cell size), real box, slice direction
+    int fd_n[3] = {0, 0, 0}; double fd_h[3] = {0, 0, 0}, fd_pos0[3] = {0, 0, 0}, fd_lo[3] = {0, 0, 0}, fd_hi[3] = {0, 0, 0}; int fd_slice_dir = -1;
+    size_t fd_cells () const { return (size_t)fd_n[0]*fd_n[1]*fd_n[2]; }
     int fill_field_diagnostic (int islice);
     double* d_insitu_bm = nullptr; double insitu_bm_radius = 0.0;     // [23][nz] raw sums of the beam moments
     void insitu_beam (int islice);

@@ -814,7 +814,7 @@ int Engine::begin_step ()
     if (d_insitu_pl) HPS_HIP_CHECK(hipMemsetAsync(d_insitu_pl, 0, (size_t)15*d.nz*sizeof(double), st));
     if (d_insitu_bm) HPS_HIP_CHECK(hipMemsetAsync(d_insitu_bm, 0, (size_t)23*d.nz*sizeof(double), st));
     if (d_insitu) HPS_HIP_CHECK(hipMemsetAsync(d_insitu, 0, (size_t)10*d.nz*sizeof(double), st));
-    if (d_fd) HPS_HIP_CHECK(hipMemsetAsync(d_fd, 0, fd_comps.size()*(size_t)(d.nx/fd_c[0])*(d.ny/fd_c[1])*(d.nz/fd_c[2])*sizeof(double), st));
+    if (d_fd) HPS_HIP_CHECK(hipMemsetAsync(d_fd, 0, fd_comps.size()*fd_cells()*sizeof(double), st));
     step_index = (next_step >= 0) ? next_step : step_index + 1;      // Hipace::m_physical_time (PlasmaParticleContainerInit.cpp:90)
     next_step = -1;
     ahead_for = -2;
@@ -1143,17 +1143,25 @@ void Engine::insitu_beam (int islice)
 int Engine::fill_field_diagnostic (int islice)
 {
     if (fd_comps.empty()) return HPS_OK;
-    const int nxc = d.nx/fd_c[0], nyc = d.ny/fd_c[1], nzc = d.nz/fd_c[2];
-    const double dzc = (d.hi[2] - d.lo[2])/nzc, dxc = (d.hi[0] - d.lo[0])/nxc, dyc = (d.hi[1] - d.lo[1])/nyc;
-    // GetPosOffset (fields/Fields.H:71-77) of the calculation and of the diagnostic geometry
+    const int nxc = fd_n[0], nyc = fd_n[1], nzc = fd_n[2];
+    const double dzc = fd_h[2], dxc = fd_h[0], dyc = fd_h[1];
+    // GetPosOffset (fields/Fields.H:71-77) of the calculation geometry; of the diagnostic one: fd_pos0 (position of its first cell)
     auto poff = [] (double lo, double hi, double h, int n) { return 0.5*(lo + hi - h*(n - 1)); };
-    const double poff_cz = poff(d.lo[2], d.hi[2], gm.dz, d.nz), poff_dz = poff(d.lo[2], d.hi[2], dzc, nzc);
-    const double poff_dx = poff(d.lo[0], d.hi[0], dxc, nxc), poff_dy = poff(d.lo[1], d.hi[1], dyc, nyc);
+    const double poff_cz = poff(d.lo[2], d.hi[2], gm.dz, d.nz), poff_dz = fd_pos0[2];
+    const double poff_dx = fd_pos0[0], poff_dy = fd_pos0[1];
+    SlabView f(slab);
+    const long plane = (long)nxc*nyc, cstride = plane*nzc;
+    if (fd_slice_dir == 2) {
+        // diag_type xy: one plane that takes every slice inside the diagnostic's z range with the weight dz (Fields.cpp:469-479)
+        const double pos_z = islice*gm.dz + poff_cz;
+        if (!(fd_lo[2] <= pos_z && pos_z <= fd_hi[2])) return HPS_OK;
+        hipLaunchKernelGGL(k_diag_copy, dim3(ceil_div(nxc, 256), nyc), dim3(256), 0, st, f, ncomp, d_fd_comps, (int)fd_comps.size(),
+                           d_fd, nxc, nyc, 0L, cstride, gm.dz, dxc, dyc, poff_dx, poff_dy, gm.xoff, gm.yoff, 1.0/gm.dx, 1.0/gm.dy);
+        return HPS_OK;
+    }
     // which diagnostic planes this slice contributes to (order 1 in z, :428-468)
     const double pos_min = (islice - 1)*gm.dz + poff_cz, pos_max = (islice + 1)*gm.dz + poff_cz;
     const int k_min = (int)std::round((pos_min - poff_dz)*(1.0/dzc)), k_max = (int)std::round((pos_max - poff_dz)*(1.0/dzc));
-    SlabView f(slab);
-    const long plane = (long)nxc*nyc, cstride = plane*nzc;
     for (int k = std::max(k_min, 0); k <= std::min(k_max, nzc - 1); ++k) {
         const double pos = k*dzc + poff_dz;
         const double mid = (pos - poff_cz)*(1.0/gm.dz);
@@ -1984,25 +1992,63 @@ extern "C" int hps_engine_insitu_fields (void* h, double* out)
     HPS_HIP_CHECK(hipMemcpy(out, E->d_insitu, (size_t)10*E->d.nz*sizeof(double), hipMemcpyDeviceToHost));
     return HPS_OK;
 }
-extern "C" int hps_engine_set_field_diagnostic (void* h, int ncomps, const int* comps, const int coarsening[3])
+// diagnostic.diag_type (xyz: slice_dir -1, yz: 0, xz: 1, xy: 2), diagnostic.coarsening, diagnostic.patch_lo / patch_hi:
+// the box of Diagnostic::ResizeFDiagFAB (diagnostics/Diagnostic.cpp:300-390) and TrimIOBox (:393-410)
+extern "C" int hps_engine_set_field_diagnostic_box (void* h, int ncomps, const int* comps, const int coarsening[3], int slice_dir,
+                                                    const double* patch_lo, const double* patch_hi)
 {
     Engine* E = static_cast<Engine*>(h);
     HPS_HIP_CHECK(hipStreamSynchronize(E->st));
     (void)hipFree(E->d_fd); (void)hipFree(E->d_fd_comps); E->d_fd = nullptr; E->d_fd_comps = nullptr; E->fd_comps.clear();
     if (ncomps <= 0) return HPS_OK;
     HPS_REQUIRE(comps && coarsening, "hps_engine_set_field_diagnostic: null argument");
+    HPS_REQUIRE(slice_dir >= -1 && slice_dir <= 2, "hps_engine_set_field_diagnostic: slice_dir must be -1 (xyz), 0 (yz), 1 (xz) or 2 (xy)");
     for (int k = 0; k < ncomps; ++k) HPS_REQUIRE(comps[k] >= 0 && comps[k] < E->ncomp, "hps_engine_set_field_diagnostic: bad component");
     const int n3[3] = {E->d.nx, E->d.ny, E->d.nz};
+    const double h3[3] = {E->gm.dx, E->gm.dy, E->gm.dz};
+    auto floor_div = [] (int a, int b) { return a >= 0 ? a/b : -((-a + b - 1)/b); };
     for (int q = 0; q < 3; ++q) {
-        HPS_REQUIRE(coarsening[q] >= 1 && n3[q] % coarsening[q] == 0, "hps_engine_set_field_diagnostic: sizes must be divisible by the coarsening");
-        E->fd_c[q] = coarsening[q];
+        const int c = (q == slice_dir) ? 1 : coarsening[q];               // (the slice direction is never coarsened, Diagnostic.cpp:71-73)
+        HPS_REQUIRE(c >= 1, "hps_engine_set_field_diagnostic: coarsening must be >= 1");
+        if (!patch_lo && !patch_hi && q != slice_dir)
+            HPS_REQUIRE(n3[q] % c == 0, "hps_engine_set_field_diagnostic: sizes must be divisible by the coarsening");
+        E->fd_c[q] = c;
+        const double plo = E->d.lo[q], phi = E->d.hi[q], hh = h3[q];
+        const double poff_sim = 0.5*(plo + phi - hh*(n3[q] - 1));
+        int small = 0, big = n3[q] - 1;
+        if (patch_lo) small = std::max(small, (int)std::round((patch_lo[q] - poff_sim)/hh));
+        if (patch_hi) big = std::min(big, (int)std::round((patch_hi[q] - poff_sim)/hh));
+        HPS_REQUIRE(big >= small, "hps_engine_set_field_diagnostic: the patch does not meet the box");
+        double lo_d = plo + small*hh, hi_d = phi + (big - (n3[q] - 1))*hh;
+        if (q == slice_dir) {
+            const double half = (hi_d - lo_d)/(2.0*(big - small + 1)), mid = 0.5*(lo_d + hi_d);
+            small = big = 0;
+            if (q < 2) { lo_d = mid - half; hi_d = mid + half; }
+        }
+        const int sc = floor_div(small, c), bc = floor_div(big, c);
+        E->fd_n[q] = bc - sc + 1;
+        E->fd_h[q] = (hi_d - lo_d)/E->fd_n[q];
+        E->fd_pos0[q] = 0.5*(lo_d + hi_d - E->fd_h[q]*(sc + bc)) + sc*E->fd_h[q];
+        E->fd_lo[q] = lo_d; E->fd_hi[q] = hi_d;
     }
+    E->fd_slice_dir = slice_dir;
     E->fd_comps.assign(comps, comps + ncomps);
-    const size_t cells = (size_t)(n3[0]/E->fd_c[0])*(n3[1]/E->fd_c[1])*(n3[2]/E->fd_c[2]);
+    const size_t cells = E->fd_cells();
     HPS_HIP_CHECK(hipMalloc(&E->d_fd, ncomps*cells*sizeof(double)));
     HPS_HIP_CHECK(hipMemset(E->d_fd, 0, ncomps*cells*sizeof(double)));
     HPS_HIP_CHECK(hipMalloc(&E->d_fd_comps, ncomps*sizeof(int)));
     HPS_HIP_CHECK(hipMemcpy(E->d_fd_comps, comps, ncomps*sizeof(int), hipMemcpyHostToDevice));
+    return HPS_OK;
+}
+extern "C" int hps_engine_set_field_diagnostic (void* h, int ncomps, const int* comps, const int coarsening[3])
+{
+    return hps_engine_set_field_diagnostic_box(h, ncomps, comps, coarsening, -1, nullptr, nullptr);
+}
+extern "C" int hps_engine_field_diagnostic_geometry (void* h, int* n3, double* lo3, double* hi3)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E->d_fd, "hps_engine_field_diagnostic_geometry: no diagnostic set");
+    for (int q = 0; q < 3; ++q) { if (n3) n3[q] = E->fd_n[q]; if (lo3) lo3[q] = E->fd_lo[q]; if (hi3) hi3[q] = E->fd_hi[q]; }
     return HPS_OK;
 }
 extern "C" int hps_engine_field_diagnostic (void* h, double* out)
@@ -2010,8 +2056,7 @@ extern "C" int hps_engine_field_diagnostic (void* h, double* out)
     Engine* E = static_cast<Engine*>(h);
     HPS_REQUIRE(E->d_fd && out, "hps_engine_field_diagnostic: no diagnostic set");
     HPS_HIP_CHECK(hipStreamSynchronize(E->st));
-    const size_t cells = (size_t)(E->d.nx/E->fd_c[0])*(E->d.ny/E->fd_c[1])*(E->d.nz/E->fd_c[2]);
-    HPS_HIP_CHECK(hipMemcpy(out, E->d_fd, E->fd_comps.size()*cells*sizeof(double), hipMemcpyDeviceToHost));
+    HPS_HIP_CHECK(hipMemcpy(out, E->d_fd, E->fd_comps.size()*E->fd_cells()*sizeof(double), hipMemcpyDeviceToHost));
     return HPS_OK;
 }
 extern "C" int hps_engine_record_event (void* h, int slot, void** out)

@@ -244,7 +244,10 @@ def write_engine_output(engine, prefix, iteration, time=0.0, beam_name="beam", b
     if beam is not None:
         beams = {beam_name: dict(x=beam[0], y=beam[1], z=beam[2], ux=beam[3], uy=beam[4], uz=beam[5], w=beam[6],
                                  charge=d["beam_charge"], mass=d.get("beam_mass", 1.0) or 1.0)}
-    return write_iteration(prefix, iteration, time, d.get("dt", 0.0), dict(lo=d["lo"], hi=d["hi"], cells=(d["nx"], d["ny"], d["nz"])), fields, beams,
+    lo, hi = d["lo"], d["hi"]
+    if hasattr(engine, "field_diagnostic_geometry"):       # (a slice or a patch: the diagnostic grid's own box)
+        _, lo, hi = engine.field_diagnostic_geometry()
+    return write_iteration(prefix, iteration, time, d.get("dt", 0.0), dict(lo=lo, hi=hi, cells=(d["nx"], d["ny"], d["nz"])), fields, beams,
                            normalized=not d.get("si_units", 0), json_too=json_too, hdf5=hdf5)
 
 

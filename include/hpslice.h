@@ -335,6 +335,16 @@ int hps_engine_set_diagnostics (void* handle, int on);
  * Call set before hps_engine_begin_step; ncomps = 0 switches it off. */
 int hps_engine_set_field_diagnostic (void* handle, int ncomps, const int* comps, const int coarsening[3]);
 int hps_engine_field_diagnostic (void* handle, double* out_host);
+/* The other shapes of the reference's field diagnostic (Diagnostic::ResizeFDiagFAB and TrimIOBox,
+ * diagnostics/Diagnostic.cpp:300-410): diagnostic.diag_type -- slice_dir -1 = xyz, 0 = yz, 1 = xz (one cell about the middle
+ * of the box in that direction: the mean of the two central rows for an even cell count, the central row for an odd one),
+ * 2 = xy (one plane that sums the slices of the z range times dz, Fields.cpp:469-479) -- and diagnostic.patch_lo / patch_hi
+ * (NULL: the whole box; the patch is rounded to cells per direction, the slice is cut about the middle of the patch).  The
+ * array of hps_engine_field_diagnostic is then F[ncomps][n[2]][n[1]][n[0]] with n, and the real box of the diagnostic
+ * grid, from hps_engine_field_diagnostic_geometry. */
+int hps_engine_set_field_diagnostic_box (void* handle, int ncomps, const int* comps, const int coarsening[3], int slice_dir,
+                                         const double* patch_lo /* [3] or NULL */, const double* patch_hi /* [3] or NULL */);
+int hps_engine_field_diagnostic_geometry (void* handle, int* n3, double* lo3, double* hi3);
 
 /* In-situ field reductions (Fields::InSituComputeDiags, fields/Fields.cpp:1288-1347; explicit solver only, as the
  * reference): per solved slice, dx dy dz * sum over the valid cells of {Ex^2, Ey^2, Ez^2, Bx^2, By^2, Bz^2, ExmBy^2,

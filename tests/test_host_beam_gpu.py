@@ -30,42 +30,19 @@ def api():
     return A
 
 
-def _xz_diagnostic_sums(api, eng, deck, names, index=None):
-    """One time step of `eng`, and what diag_type = xz + checksumAPI make of it: per field the sum over all slices of the
-    absolute values on the y = 0 line -- the centre row for an odd ny, the mean of the two central rows for an even one
-    (Fields::Copy interpolates linearly onto the diagnostic's grid, fields/Fields.cpp:413-533; Diagnostic::TrimIOBox,
-    diagnostics/Diagnostic.cpp:393-410).  FillFieldDiagnostics runs ahead of the push and of ShiftSlices (Hipace.cpp:691, 722):
-    the rows are copied on the engine's stream behind each slice, which does not flush the deferred shift (hps_engine_slab /
-    hps_engine_sync would); the last slice of a step is shifted at once, so the planes the shift rewrites (jx, jy and the
-    beam's transverse currents) are copied between its two halves.  -> {name: sum}"""
-    import torch
-    from hipace_amd import _lib
-    L = _lib.lib()
-    s = L.hps_engine_slab(eng._h)
-    g, nx, ny, nz = s.ng, deck["nx"], deck["ny"], deck["nz"]
-    index = index or _lib.CIDX
-    js = [ny // 2] if ny % 2 else [ny // 2 - 1, ny // 2]
-    rows = torch.zeros((nz, len(names), len(js), nx), dtype=torch.float64, device="cuda")
-    shifted = {"jx", "jy", "jx_beam", "jy_beam"}
-
-    def copy(isl, which):
-        for m, k in enumerate(names):
-            if k in which:
-                for h, j in enumerate(js):
-                    src = s.p + 8 * (index[k] * s.nstride + (j + g) * s.jstride + g)
-                    assert L.hps_engine_copy_async(eng._h, C.c_void_p(rows[isl, m, h].data_ptr()), C.c_void_p(src), 8 * nx) == 0
-
-    eng.begin_step()
-    for isl in range(nz - 1, 0, -1):
-        eng.solve_slice(isl)
-        copy(isl, set(names))
-    eng.solve_slice_begin(0)
-    copy(0, shifted)
-    eng.solve_slice_finish(0)
-    copy(0, set(names) - shifted)
-    eng.sync()
-    tot = rows.mean(dim=2).abs().sum(dim=(0, 2)).cpu().numpy()
-    return {k: float(tot[m]) for m, k in enumerate(names)}
+def _xz_diagnostic_sums(api, eng, deck, names):
+    """One time step of `eng` with diagnostic.diag_type = xz (the engine's field diagnostic: the y = 0 line of every slice -- the
+    centre row for an odd ny, the mean of the two central rows for an even one, taken ahead of the push and of ShiftSlices as
+    FillFieldDiagnostics is, Hipace.cpp:691), and what checksumAPI makes of the file: per field the sum of the absolute
+    values.  -> {name: sum}"""
+    eng.set_field_diagnostic(names, diag_type="xz")
+    n, lo, hi = eng.field_diagnostic_geometry()
+    assert n == (deck["nx"], 1, deck["nz"])
+    dy = (deck["hi"][1] - deck["lo"][1]) / deck["ny"]
+    assert abs(0.5 * (lo[1] + hi[1])) <= 1e-12 * dy and abs((hi[1] - lo[1]) - dy) <= 1e-12 * dy
+    eng.run_step()
+    fd = eng.field_diagnostic()
+    return {k: float(np.abs(fd[k]).sum()) for k in names}
 
 
 def _deck_beam_as_soa(api, deck):
@@ -282,8 +259,7 @@ def test_production_lwfa_deck_matches_the_reference_checksums(api):
     for _ in range(deck["n_steps"] - 1):
         eng.run_step()
     names = [k for k in gold if k != "laserEnvelope"]
-    cn = eng.comp_names()
-    sums = _xz_diagnostic_sums(api, eng, deck, names, index={k: cn.index(k) for k in names})
+    sums = _xz_diagnostic_sums(api, eng, deck, names)
     a = eng.laser_envelope()
     ny = deck["ny"]
     sums["laserEnvelope"] = float(np.abs(0.5 * (a[:, ny // 2 - 1, :] + a[:, ny // 2, :])).sum())
@@ -391,3 +367,40 @@ def test_restart_from_the_first_runs_beam_output(api, tmp_path):
     e2.run_step()
     c1, c2 = e1.checksums()["jz_beam"], e2.checksums()["jz_beam"]
     assert c1 > 0 and abs(c2 / ratio - c1) <= 1e-12 * c1          # sum of jz_beam times the cell volume
+
+
+def test_slice_and_patch_diagnostics_are_cuts_of_the_full_one(api):
+    """tests/slice_IO.1Rank.sh + examples/blowout_wake/analysis_slice_IO.py: the blowout deck on 64 x 88 x 100 cells written as
+    diag_type xyz, xz, yz, as an xyz patch of one z plane (patch -3 -100 0 / 3 100 0) and as an xz slice of a patch
+    (0 -3 -10 / 4 3 10): every one of them is the cut of the full output the reference's analysis takes -- the mean of the two
+    central planes for the slices, cells 20:45 of plane 50, cells 32:49 between rows 43 and 44 -- for every field, not only Ez.
+    And diag_type xy: the sum of the patch's slices times dz."""
+    deck = dict(decks.blowout_wake(), ny=88, n_steps=1)
+    names = ["Ez", "ExmBy", "By", "jx", "chi", "jz_beam"]
+
+    def run(**kw):
+        e = api.SliceEngine(deck, tile_size=16)
+        e.set_field_diagnostic(names, **kw)
+        e.run_step()
+        return e.field_diagnostic(), e.field_diagnostic_geometry()
+
+    full, gfull = run()
+    assert gfull[0] == (64, 88, 100)
+    xz, gxz = run(diag_type="xz")
+    yz, gyz = run(diag_type="yz")
+    cut_xy, gcxy = run(patch_lo=(-3.0, -100.0, 0.0), patch_hi=(3.0, 100.0, 0.0))
+    cut_xz, gcxz = run(diag_type="xz", patch_lo=(0.0, -3.0, -10.0), patch_hi=(4.0, 3.0, 10.0))
+    xy, gxy = run(diag_type="xy", patch_lo=(-100.0, -100.0, -1.0), patch_hi=(100.0, 100.0, 1.0))
+    assert gxz[0] == (64, 1, 100) and gyz[0] == (1, 88, 100) and gcxy[0] == (25, 88, 1) and gcxz[0] == (17, 1, 100)
+    dz = 12.0 / 100
+    k_lo, k_hi = int(round((-1.0 + 6.0 - dz / 2) / dz)), int(round((1.0 + 6.0 - dz / 2) / dz))
+    assert gxy[0] == (64, 88, 1)
+    for k in names:
+        f = full[k]                                            # [z, y, x]
+        scale = np.abs(f).max()
+        assert scale > 0
+        assert np.abs(xz[k][:, 0, :] - 0.5 * (f[:, 43, :] + f[:, 44, :])).max() <= 1e-13 * scale, k
+        assert np.abs(yz[k][:, :, 0] - 0.5 * (f[:, :, 31] + f[:, :, 32])).max() <= 1e-13 * scale, k
+        assert np.abs(cut_xy[k][0] - f[50, :, 20:45]).max() <= 1e-13 * scale, k
+        assert np.abs(cut_xz[k][:, 0, :] - 0.5 * (f[:, 43, 32:49] + f[:, 44, 32:49])).max() <= 1e-13 * scale, k
+        assert np.abs(xy[k][0] - dz * f[k_lo:k_hi + 1].sum(axis=0)).max() <= 1e-12 * scale * (k_hi - k_lo + 1), k
