@@ -1441,6 +1441,7 @@ static const DstImpl g_dst_impls[] = {
     HPS_DST_SYM(5, 13),     // 64
     HPS_DST_SYM(3, 11),     // 32
 #if HPS_POISSON_POW2
+    HPS_DST_POW2(11),       // 2047
     HPS_DST_POW2(10),       // 1023
     HPS_DST_POW2(9),        // 511
     HPS_DST_POW2(8),        // 255

@@ -114,7 +114,7 @@ def test_advance_plasma(api, oracle, order, bc, nsc):
 
 @pytest.mark.parametrize("nx,ny", [(64, 64), (32, 48), (63, 63), (127, 65), (32, 64), (128, 32), (512, 512),
                                    (1024, 1024), (1023, 1023), (256, 256), (256, 100), (48, 500), (600, 520),
-                                   (511, 511), (255, 255), (511, 127), (1023, 511)])      # every length of the power-of-two kernel (2^6 .. 2^10)
+                                   (511, 511), (255, 255), (511, 127), (1023, 511), (2047, 255)])      # every length of the power-of-two kernel (2^6 .. 2^11)
 def test_poisson(api, oracle, nx, ny):
     import torch
     rng = np.random.default_rng(nx * 1000 + ny)
