@@ -1869,7 +1869,7 @@ struct Engine {
         store.assign((size_t)d.nz, Beam());
         for (int isl = 0; isl < d.nz; ++isl) {
             Beam& b = store[isl];
-            gen_beam_slice(isl, b);
+            init_beam_slice(isl, b);          // (the deck's fixed_ppc beam, or the host's: orc_engine_set_beam_particles)
             b.nsub.assign(b.x.size(), 0); b.valid.assign(b.x.size(), 1); b.nreg = (long)b.x.size();
             if (d.beam_spin_tracking) {      // initial_spin, normalised (BeamParticleContainer.cpp:390-402)
                 const double* s0 = d.beam_initial_spin;
@@ -2332,7 +2332,7 @@ void orc_engine_set_external_beam (void* h, const double* storage) {
     e->ext_beam = storage;
 }
 void orc_engine_initial_beam (void* h, double* dst) { static_cast<Engine*>(h)->fill_initial_beam(dst); }
-// A host-initialised beam (any injection type of BeamParticleContainerInit.cpp) in place of the deck's, hipace.dt = 0:
+// A host-initialised beam (any injection type of BeamParticleContainerInit.cpp) in place of the deck's (before the first step):
 // soa = [7][n] x y z ux uy uz w; binned as BoxSorter does (sorting/BoxSort.cpp:34-43), head slice first, input order kept
 // inside a slice; returns the number of particles outside the box in z (left out).
 long orc_engine_set_beam_particles (void* h, long n, const double* soa) {

@@ -505,9 +505,8 @@ class Engine:
         return n, off
 
     def set_beam_particles(self, soa, allow_outside=False):
-        """A host-initialised beam in place of the deck's (hipace.dt = 0): soa = (7, n) x y z ux uy uz w; same binning as
+        """A host-initialised beam in place of the deck's, before the first step: soa = (7, n) x y z ux uy uz w; same binning as
         hipace_amd.api.SliceEngine.set_beam_particles.  -> particles outside the box in z (left out)."""
-        assert not self.moving, "the oracle takes host-initialised beams with hipace.dt = 0 only"
         soa = np.ascontiguousarray(soa, dtype=np.float64)
         assert soa.ndim == 2 and soa.shape[0] == 7
         L = lib()

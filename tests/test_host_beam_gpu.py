@@ -304,7 +304,7 @@ def test_gaussian_weight_deck_against_the_reference_checksums(api, oracle):
         assert abs(cs[k] - oc[k]) <= 1e-9 * oc[k], (k, cs[k], oc[k])
 
 
-def test_radiation_reaction_deck_against_the_reference_checksums(api):
+def test_radiation_reaction_deck_against_the_reference_checksums(api, oracle):
     """tests/radiation_reaction.1Rank.sh (examples/beam_in_vacuum/inputs_RR): a matched beam sheet of 10^5 fixed_weight particles
     in a blowout's focusing field, six steps of 30 / omega_beta with radiation reaction.  The file holds the beam ahead of the
     sixth step's push and the xz diagnostic of that step.  The energy the beam has radiated after five steps -- what the deck
@@ -318,7 +318,7 @@ def test_radiation_reaction_deck_against_the_reference_checksums(api):
     assert eng.set_beam_particles(soa) == 0
     for _ in range(deck["n_steps"] - 1):
         eng.run_step()
-    _, st = eng.beam_state()
+    bnd5, st = eng.beam_state()
     gb = gold["beam"]
     assert st.shape[1] == n == 100000
     assert abs(st[6].sum() - gb["w"]) <= 1e-6 * gb["w"]
@@ -339,6 +339,26 @@ def test_radiation_reaction_deck_against_the_reference_checksums(api):
         assert v / 4.0 <= sums[k] <= 4.0 * v, (k, sums[k], v)
     for k in ("ExmBy", "EypBx", "Psi", "chi", "rhomjz"):
         assert sums[k] == 0.0 == gold["lev=0"][k]
+    # ... and the oracle on the same particles: every particle's state ahead of the sixth push
+    oe = oracle.Engine(deck)
+    assert oe.set_beam_particles(soa) == 0
+    for _ in range(deck["n_steps"] - 1):
+        oe.begin_step()
+        for isl in range(deck["nz"] - 1, -1, -1):
+            oe.solve_slice(isl)
+    nz, seen = deck["nz"], 0
+    for p in range(nz):
+        want = oe.beam_slice(nz - 1 - p)
+        got = st[:, bnd5[p]:bnd5[p + 1]]
+        assert got.shape == want.shape
+        seen += want.shape[1]
+        if not want.shape[1]:
+            continue
+        ko, kg = np.argsort(want[5]), np.argsort(got[5])            # (u_z is drawn with a spread: a unique key)
+        for r in range(7):
+            sc = max(np.abs(want[r]).max(), 1e-300)
+            assert np.abs(got[r][kg] - want[r][ko]).max() <= 1e-9 * sc, (p, r)
+    assert seen == n
 
 
 def test_restart_from_the_first_runs_beam_output(api, tmp_path):
