@@ -551,3 +551,17 @@ def radiation_reaction_SI():
     beam = dict(num_particles=100000, density=ne / 1.0e10, pos_mean=(0.0, 0.0, 0.0), pos_std=(sigma_x, 1.0e-12, 1.0e-6),
                 u_mean=(0.0, 0.0, uz), u_std=(sigma_ux, 0.0, uz * 0.01))
     return d, beam
+
+
+def hosing():
+    """tests/hosing.2Rank.sh: the blowout deck with hipace.dt = 20, mobile ions (charge 1, mass 1836, one per cell, neither species
+    with a neutralising background) and a tilted fixed_weight driver (beam.dx_per_dzeta = 0.2, density 200, sigma 0.1, 0.1, 1.41) --
+    the deck of the hosing instability.  (Its checksum file predates the explicit solver's field set: parity is with the oracle.)
+    -> (deck without a beam, the beam's parameters for fixed_weight_beam; the reference draws 10^6 particles)"""
+    d = blowout_wake()
+    d.update(n_steps=11, dt=20.0, beam_profile=-1, plasma_no_neutralize=1, background_density_SI=1.0e23)
+    with_ion_species(d, "H", 1.0, ppc=(1, 1), initial_level=1)
+    d["ion_mass"] = 1836.0
+    beam = dict(num_particles=1000000, density=200.0, pos_mean=(lambda z: 0.2 * z, 0.0, 0.0), pos_std=(0.1, 0.1, 1.41),
+                u_mean=(0.0, 0.0, 2000.0))
+    return d, beam

@@ -424,3 +424,47 @@ def test_slice_and_patch_diagnostics_are_cuts_of_the_full_one(api):
         assert np.abs(cut_xy[k][0] - f[50, :, 20:45]).max() <= 1e-13 * scale, k
         assert np.abs(cut_xz[k][:, 0, :] - 0.5 * (f[:, 43, 32:49] + f[:, 44, 32:49])).max() <= 1e-13 * scale, k
         assert np.abs(xy[k][0] - dz * f[k_lo:k_hi + 1].sum(axis=0)).max() <= 1e-12 * scale * (k_hi - k_lo + 1), k
+
+
+def test_hosing_deck_matches_oracle(api, oracle):
+    """tests/hosing.2Rank.sh at a fifth of its particle count, three of its steps: a tilted random driver that moves
+    (hipace.dt = 20: particles slip through the slices), electrons and mobile ions -- beam slices as sets, every slab component
+    and both sheets' checksums against the oracle on the same particles after every step."""
+    deck, beam = decks.hosing()
+    deck["n_steps"] = 3
+    beam["num_particles"] = 200000
+    soa = decks.fixed_weight_beam(deck, seed=7, **beam)
+    ge = api.SliceEngine(deck, tile_size=16)
+    oe = oracle.Engine(deck)
+    n_out = ge.set_beam_particles(soa, allow_outside=True)
+    assert oe.set_beam_particles(soa, allow_outside=True) == n_out and n_out < 100
+    ge.set_diagnostics(True)
+    nz = deck["nz"]
+    for step in range(deck["n_steps"]):
+        ge.begin_step()
+        oe.begin_step()
+        for k in range(nz - 1, -1, -1):
+            ge.solve_slice(k)
+            oe.solve_slice(k)
+        gs, os_ = ge.slab(), oe.slab()
+        for c, name in enumerate(ge.comp_names()):
+            scale = max(np.abs(os_[c]).max(), 1e-300)
+            assert np.abs(gs[c] - os_[c]).max() <= 1e-7 * scale, (step, name, np.abs(gs[c] - os_[c]).max() / scale)
+        gc, oc = ge.checksums(), oe.checksums()
+        for name, v in oc.items():
+            assert abs(gc[name] - v) <= 1e-8 * max(abs(v), 1e-300), (step, name, gc[name], v)
+        bnd, st = ge.beam_state()
+        moved = 0
+        for p in range(nz):
+            want = oe.beam_slice(nz - 1 - p)
+            got = st[:, bnd[p]:bnd[p + 1]]
+            assert got.shape == want.shape, (step, p, got.shape, want.shape)
+            if want.shape[1]:
+                ko, kg = np.lexsort((want[1], want[0])), np.lexsort((got[1], got[0]))
+                for r in range(7):
+                    sc = max(np.abs(want[r]).max(), 1e-300)
+                    assert np.abs(got[r][kg] - want[r][ko]).max() <= 1e-8 * sc, (step, p, r)
+                moved += want.shape[1]
+        assert moved > 0.99 * soa.shape[1]
+    real, valid, lev, _ = ge.ions()
+    assert np.abs(real[3]).max() > 0           # the ions move
