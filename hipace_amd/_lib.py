@@ -196,6 +196,7 @@ _SIGS = {
     "hps_engine_assume_initial_beam_support": (C.c_int, [C.c_void_p]),
     "hps_engine_beam_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hps_engine_beam_capacity": (C.c_int, [C.c_void_p, C.POINTER(C.c_long)]),
+    "hps_engine_set_beam_capacity": (C.c_int, [C.c_void_p, C.c_long]),
     "hps_engine_beam_message_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "hps_engine_beam_spin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hps_engine_set_beam_import": (C.c_int, [C.c_void_p, C.c_int]),

@@ -331,6 +331,10 @@ class SliceEngine:
         check(_lib.lib().hps_engine_beam_capacity(self._h, C.byref(n)))
         return n.value
 
+    def set_beam_capacity(self, cap):
+        """particles a slice's hand-off message has room for (default: twice the fullest injected slice); before the first step"""
+        check(_lib.lib().hps_engine_set_beam_capacity(self._h, int(cap)))
+
     def beam_message_doubles(self):
         """Length of a hand-off message of the moving beam: 1 + rows*capacity (7 rows, 10 with spin tracking)."""
         r = C.c_int()

@@ -2216,6 +2216,15 @@ extern "C" int hps_engine_beam_capacity (void* h, long* cap)
     *cap = E->beam_cap;
     return HPS_OK;
 }
+extern "C" int hps_engine_set_beam_capacity (void* h, long cap)
+{
+    Engine* E = static_cast<Engine*>(h);
+    HPS_REQUIRE(E->moving, "hps_engine_set_beam_capacity: the engine's beam is static (hipace.dt = 0)");
+    HPS_REQUIRE(E->steps_begun == 0, "hps_engine_set_beam_capacity: call before the first hps_engine_begin_step");
+    HPS_REQUIRE(cap >= 1 && cap < (1L << 31), "hps_engine_set_beam_capacity: bad capacity");
+    E->beam_cap = cap;
+    return HPS_OK;
+}
 extern "C" int hps_engine_beam_message_rows (void* h, int* rows)
 {
     *rows = static_cast<Engine*>(h)->beam_rows;

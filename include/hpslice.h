@@ -432,6 +432,11 @@ int hps_engine_beam_state (void* handle, long* boundaries_host, double* soa_host
  * import (import mode on, set before hps_engine_begin_step; slices in head-first order, slice k-1 before slice k is
  * solved): the regular particles of that slice for the step that has begun.  All asynchronous on the engine's stream. */
 int hps_engine_beam_capacity (void* handle, long* cap_host);
+/* A beam whose slices may come to hold more than twice what the fullest one held when it was injected (a hot beam that bunches
+ * as it slips): the particles a slice's hand-off message has room for, set before the first hps_engine_begin_step -- the same
+ * on every engine of a pipeline (the message size is 1 + rows * cap doubles).  A slice that outgrows it is an error at the end
+ * of the step, never a silent loss. */
+int hps_engine_set_beam_capacity (void* handle, long cap);
 /* rows of a hand-off message: 7, or 10 with spin tracking (sx sy sz behind w); a message is 1 + rows*cap doubles */
 int hps_engine_beam_message_rows (void* handle, int* rows_host);
 /* spin tracking: the three spin arrays [3][nbeam] in the order of hps_engine_beam_state; synchronises the stream */

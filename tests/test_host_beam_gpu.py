@@ -468,3 +468,41 @@ def test_hosing_deck_matches_oracle(api, oracle):
         assert moved > 0.99 * soa.shape[1]
     real, valid, lev, _ = ge.ions()
     assert np.abs(real[3]).max() > 0           # the ions move
+
+
+def test_two_hot_beams_serial_and_pipelined_make_the_same_fields(api):
+    """tests/next_deposition_beam.2Rank.sh (examples/beam_in_vacuum/inputs_normalized_transverse + analysis_transverse.py): two
+    hot fixed_weight beams with transverse drift in vacuum, hipace.dt = 1, ten steps -- the By of iteration 8 of a pipelined run
+    (here: three time steps in flight on the device, the per-slice hand-off between them) equals the serial run's,
+    sum (Fp - Fs)^2 / sum Fs^2 < 1e-10 as the reference asks; the beams are drawn on the host and handed in as one species."""
+    import torch
+    from hipace_amd.pipeline import run_lanes
+    deck = dict(decks.beam_in_vacuum(), nx=16, ny=16, nz=100, lo=(-10.0, -10.0, -10.0), hi=(10.0, 10.0, 10.0), order=2,
+                beam_profile=-1, n_steps=10, dt=1.0, bc=1)
+    b1 = decks.fixed_weight_beam(deck, 10000, 200.0, (lambda z: 0.2 * z, 0.0, 0.0), (0.1, 0.1, 1.41), u_mean=(20.0, 10.0, 20.0),
+                                 u_std=(100.0, 100.0, 15.0), seed=4)
+    b2 = decks.fixed_weight_beam(deck, 3000, 200.0, (0.0, 0.0, 0.0), (8.0, 0.3, 1.41), u_mean=(8.0, 23.0, 21.0),
+                                 u_std=(80.0, 120.0, 14.0), seed=5)
+    soa = np.concatenate([b1, b2], axis=1)
+
+    def engine():
+        e = api.SliceEngine(deck, tile_size=0)
+        e.set_beam_particles(soa, allow_outside=True)
+        e.set_beam_capacity(soa.shape[1])          # (a hot beam: slices fill beyond twice their injected count)
+        e.set_field_diagnostic(["By", "jz_beam", "jx_beam"], diag_type="xz")
+        return e
+
+    ser = engine()
+    want = None
+    for step in range(9):
+        ser.run_step()
+    want = ser.field_diagnostic()                      # iteration 8
+    assert np.abs(want["By"]).max() > 0 and np.abs(want["jx_beam"]).max() > 0
+    got = {}
+    lanes = [engine() for _ in range(3)]
+    run_lanes(lanes, 0, 1, 9, torch.device("cuda", 0),
+              on_step_end=lambda step, e: got.__setitem__(step, {k: v.copy() for k, v in e.field_diagnostic().items()}))
+    assert sorted(got) == list(range(9))
+    for k in want:
+        err = ((got[8][k] - want[k]) ** 2).sum() / (want[k] ** 2).sum()
+        assert err < 1e-10, (k, err)
