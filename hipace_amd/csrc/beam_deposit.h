@@ -35,7 +35,10 @@ __device__ __forceinline__ void beam_pair_block (const SlabView& f, const BeamPa
         for (int ix = 0; ix <= ORDER; ++ix) {
             double* p = f.p + f.off(i0 + ix, j0 + iy);
             const double s = sx[ix]*sy[iy];
-            if (second) { atomic_add_f64(p + w.cjxn*f.ns, s*(wq*(ux*gaminv))); atomic_add_f64(p + w.cjyn*f.ns, s*(wq*(uy*gaminv))); }
+            // (a term that is exactly zero leaves the plane as it is: a cold beam's jx, jy -- 18 of a particle's 27 atomics)
+            if (second) { const double vx = s*(wq*(ux*gaminv)), vy = s*(wq*(uy*gaminv));
+                          if (vx != 0.0) atomic_add_f64(p + w.cjxn*f.ns, vx);
+                          if (vy != 0.0) atomic_add_f64(p + w.cjyn*f.ns, vy); }
             else atomic_add_f64(p + w.cjz*f.ns, s*(wq*(uz*gaminv)));
         }
     }
