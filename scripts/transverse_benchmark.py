@@ -31,7 +31,7 @@ def main():
     L = _lib.lib()
     nx, nz, jc = deck["nx"], deck["nz"], deck["ny"] // 2
     for rep in range(2):
-        eng = api.SliceEngine(deck, tile_size=16)
+        eng = api.SliceEngine(deck, tile_size=int(os.environ.get("TILE", "16")))
         eng.set_beam_particles(soa)
         s = L.hps_engine_slab(eng._h)
         rows = torch.zeros((nz, len(names), nx), dtype=torch.float64, device="cuda")
