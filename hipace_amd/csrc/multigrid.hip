@@ -232,7 +232,11 @@ __device__ __forceinline__ void block_max_to (unsigned long long* slot, double v
 // DO_RES: residual r = rhs - L(phi_out), max|r| (and max|rhs|) -> norms;
 //         FUSE_R (cell-centred): cres = R(r) written straight to the next level; else r -> res_out.
 // INTERIOR tiles (no swept cell on a wall / outside the box) take a path without masks.
-template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, bool INTERIOR, int NSW, bool GATE_IN = (NSW == 4)>
+template <bool CC> __device__ __forceinline__ double restrict_at (const FView& fine, int i, int j, int n);
+// RPULL (node-centred down-leg): the tile's right-hand side IS the restriction of the finer level's residual -- `crse` then
+// is that residual (level above, twice the index), formed while the tile loads (9 reads per cell) and written to `rhs` for
+// the up-leg by the tile that finalises the cell: no k_restrict launch between two levels' smoothers
+template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, bool INTERIOR, int NSW, bool GATE_IN = (NSW == 4), bool RPULL = false>
 __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], double* s_red, double* s_crs, const LevBox& b, const FView& phi_out,
                                              const FView& phi_out2, const FView& rhs, const FView& acf, const FView& phi_in, const FView& crse,
                                              const FView& res_out, const FView& cres_out, double facx, double facy,
@@ -266,7 +270,10 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
             const int ic = INTERIOR ? i : min(max(i, b.vlx), b.vhx), jc = INTERIOR ? j : min(max(j, b.vly), b.vhy);
             const bool ok = INTERIOR || (ic == i && jc == j);
             in[m][p] = ok;
-            const double a0 = rhs(ic, jc, 0), a1 = rhs(ic, jc, 1), a2 = acf(ic, jc, 0);
+            double a0, a1;
+            if constexpr (RPULL) { a0 = restrict_at<CC>(crse, ic, jc, 0); a1 = restrict_at<CC>(crse, ic, jc, 1); }
+            else { a0 = rhs(ic, jc, 0); a1 = rhs(ic, jc, 1); }
+            const double a2 = acf(ic, jc, 0);
             r0[m][p] = ok ? a0 : 0.0;
             r1[m][p] = ok ? a1 : 0.0;
             ac[m][p] = ok ? a2 : 0.0;
@@ -457,6 +464,7 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
                     resmax = fmax(resmax, fmax(fabs(q0[p]), fabs(q1[p])));
                 }
                 if (fin[p]) {
+                    if constexpr (RPULL) { rhs(i, j, 0) = r0[m][p]; rhs(i, j, 1) = r1[m][p]; }
                     if (DO_RES && !FUSE_R) { res_out(i, j, 0) = q0[p]; res_out(i, j, 1) = q1[p]; }
                     phi_out(i, j, 0) = f0;
                     phi_out(i, j, 1) = f1;
@@ -514,6 +522,7 @@ __device__ __forceinline__ void smooth_tile (double (&s_phi)[2][TS::AY*TS::AX], 
                     resmax = fmax(resmax, fmax(fabs(q0[p]), fabs(q1[p])));
                 }
                 if (fin[p]) {
+                    if constexpr (RPULL) { rhs(i, j, 0) = r0[m][p]; rhs(i, j, 1) = r1[m][p]; }
                     if (DO_RES && !FUSE_R) { res_out(i, j, 0) = q0[p]; res_out(i, j, 1) = q1[p]; }
                     phi_out(i, j, 0) = f0;
                     phi_out(i, j, 1) = f1;
@@ -582,7 +591,7 @@ __device__ __forceinline__ void post_epilogue (const PostArgs& pa)      // every
     if (threadIdx.x == 0) *pa.seq_slot = pa.seq;
 }
 
-template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, int NSW = 4, bool POST = false>
+template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, int NSW = 4, bool POST = false, bool RPULL = false>
 #ifndef HPS_MG_NODAL_WAVES
 #define HPS_MG_NODAL_WAVES 4
 #endif
@@ -613,9 +622,9 @@ void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FV
     const bool interior = (gi0 - 1 >= b.vlx) && (gi0 + GT_X <= b.vhx) && (gj0 - 1 >= b.vly) && (gj0 + GT_Y <= b.vhy)
                        && (gi0 > b.lox) && (gi0 + GT_X - 1 < b.hix) && (gj0 > b.loy) && (gj0 + GT_Y - 1 < b.hiy);
     constexpr bool GATE_IN = (NSW == 4) || (HPS_MG_GATE8_BEHIND && !POST);
-    if (interior) smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, true, NSW, GATE_IN>(s_phi, s_red, s_crs, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
+    if (interior) smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, true, NSW, GATE_IN, RPULL>(s_phi, s_red, s_crs, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
                                                              facx, facy, gi0, gj0, resnorm, rhsnorm, sr);
-    else          smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, false, NSW, GATE_IN>(s_phi, s_red, s_crs, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
+    else          smooth_tile<TS, CC, SRC, DO_RES, FUSE_R, false, NSW, GATE_IN, RPULL>(s_phi, s_red, s_crs, b, phi_out, phi_out2, rhs, acf, phi_in, crse, res_out, cres_out,
                                                               facx, facy, gi0, gj0, resnorm, rhsnorm, sr);
     if (POST) post_epilogue(pa);
 }
@@ -716,7 +725,7 @@ __device__ void low_zero_cor (lds_double* base, const LowLev& l)
 template <bool CC>
 __global__ __launch_bounds__(1024)
 void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, const double* __restrict__ res_g,
-                double* __restrict__ cor_g, double facx0, double facy0, int nsweeps_bottom, StopRule sr)
+                double* __restrict__ cor_g, double facx0, double facy0, int nsweeps_bottom, StopRule sr, FView fine_res = FView{})
 {
     if (!vcycle_active(sr)) return;
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
@@ -724,6 +733,16 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
     MG_STAMP(8);
     {
         const LowLev l = lv[0];
+        if (fine_res.p) {
+            // the top level's right-hand side = R(residual of the level above), formed here (no k_restrict launch ahead of this
+            // kernel); cells outside the unknowns' box read as 0
+            for (int s = threadIdx.x; s < l.cells; s += blockDim.x) { base[l.off + s] = acf_g[s]; base[l.off + l.cells + s] = 0.0; base[l.off + 2*l.cells + s] = 0.0; }
+            __syncthreads();
+            HPS_LOW_FOR_VALID(l, i, j) {
+                lplane(base, l, 1)(i, j) = restrict_at<CC>(fine_res, i, j, 0);
+                lplane(base, l, 2)(i, j) = restrict_at<CC>(fine_res, i, j, 1);
+            }
+        } else
         for (int s = threadIdx.x; s < l.cells; s += blockDim.x) {
             base[l.off + s] = acf_g[s];
             base[l.off + l.cells + s] = res_g[s];
@@ -1757,7 +1776,7 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
     return HPS_OK;
 }
 
-template <class TS, bool CC, int SRC, bool DO_RES, int NSW = 4>
+template <class TS, bool CC, int SRC, bool DO_RES, int NSW = 4, bool RPULL = false>
 static void launch_smooth_ts (Multigrid* M, int il, FView phi_out, FView phi_out2, FView rhs, FView acf, FView phi_in, FView crse,
                               FView res_out, FView cres_out, unsigned long long* resnorm, unsigned long long* rhsnorm,
                               const StopRule& sr, hipStream_t st, const PostArgs* post = nullptr)
@@ -1777,7 +1796,7 @@ static void launch_smooth_ts (Multigrid* M, int il, FView phi_out, FView phi_out
             return;
         }
     }
-    hipLaunchKernelGGL((k_smooth<TS, CC, SRC, DO_RES, FUSE, NSW>), dim3(ntx*nty), dim3(TS::NT), 0, st, b, phi_out, phi_out2, rhs, acf,
+    hipLaunchKernelGGL((k_smooth<TS, CC, SRC, DO_RES, FUSE, NSW, false, RPULL>), dim3(ntx*nty), dim3(TS::NT), 0, st, b, phi_out, phi_out2, rhs, acf,
                        phi_in, crse, res_out, cres_out, facx, facy, ntx, resnorm, rhsnorm, sr, PostArgs{});
 }
 
@@ -1812,10 +1831,20 @@ static bool vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
     const int lb = M->lowv_begin;
     const FView none{};
     const StopRule sr{M->d_norms, k, tol_rel, tol_abs};
+    // node-centred levels: the smoother of level il >= 2 forms its right-hand side from level il - 1's residual itself (RPULL);
+    // the launch of k_restrict stays where the next consumer is not a smoother (level 0 -> 1 behind the fused pass, the lower V's input)
+    static const bool pull = [] { const char* v = std::getenv("HPS_MG_NODAL_PULL"); return !(v && std::atoi(v) == 0); }();
+    // (levels on 32 x 16 tiles only: with the nine reads per cell in flight the 64 x 32 variant spills 108 registers under its cap)
+    auto pulls = [&] (int il) { return !CC && pull && il >= 2 && ((il < lb && M->L[il].cells <= M->small_tile_cells) ||
+                                                                 (il == lb && !M->use_low3 && !M->use_low2)); };      // (il == lb: k_lower_v's own load)
     for (int il = 1; il < lb; ++il) {
+        if (pulls(il))
+            launch_smooth_ts<TileSmall, CC, SRC_ZERO, true, 4, !CC>(M, il, M->lv(il, M->L[il].cor), none, M->lv(il, M->L[il].res), M->lv(il, M->L[il].acf), none,
+                                                                    M->lv(il-1, M->L[il-1].rescor), M->lv(il, M->L[il].rescor), M->lv(il+1, M->L[il+1].res), nullptr, nullptr, sr, st);
+        else
         launch_smooth<CC, SRC_ZERO, true>(M, il, M->lv(il, M->L[il].cor), none, M->lv(il, M->L[il].res), M->lv(il, M->L[il].acf), none,
                                           none, M->lv(il, M->L[il].rescor), M->lv(il+1, M->L[il+1].res), nullptr, nullptr, sr, st);
-        restrict_residual_if_nodal<CC>(M, il, sr, st);
+        if (!pulls(il + 1)) restrict_residual_if_nodal<CC>(M, il, sr, st);
     }
     {
         const double fac = (double)(1 << lb);
@@ -1830,7 +1859,7 @@ static bool vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
                                1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr);
         else
             hipLaunchKernelGGL(k_lower_v<CC>, dim3(1), dim3(1024), M->low_lds, st, M->d_low, nl - lb, M->L[lb].acf, M->L[lb].res,
-                               M->L[lb].cor, 1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr);
+                               M->L[lb].cor, 1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr, pulls(lb) ? M->lv(lb-1, M->L[lb-1].rescor) : FView{});
     }
     // up-leg: the smoothed correction of level il lands in rescor[il] (out of place)
     for (int il = lb - 1; il >= 1; --il) {
