@@ -61,7 +61,7 @@ if ROOT not in sys.path:
 CPU_THREADS_DEFAULT = 16  # OpenMP leg of the CPU baseline: fastest on the 256-core host of the GPU box, 9.5x the serial leg; 64 threads
                           # are already slower and 256 slower than one (profiles/r02b_cpu_threads.json)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_SUMMARY = "r05c_pmc_fetch_write_per_kernel.csv"      # profiles/: rocprofv3 --pmc summary of the shipped kernels
+PMC_SUMMARY = "r05d_pmc_fetch_write_per_kernel.csv"      # profiles/: rocprofv3 --pmc summary of the shipped kernels
 START_SLICE_DEFAULT = 700  # short runs start here (from the head); see profiles/r02a_slice_cost_profile.json
 
 
