@@ -662,7 +662,9 @@ int Engine::create (const hps_deck& deck, int device)
     np = (d.plasma_density > 0.0) ? (long)nppc*d.nx*d.ny : 0;
     np_init = np; np_cap = np;
     if (d.ion_on) {
-        if (pc) { set_error("hps_engine_create: ionisation needs the explicit solver"); return HPS_ERR_UNSUPPORTED; }
+        // predictor-corrector: a second species that is fully ionised from the start (mobile ions, tests/ion_motion.SI.1Rank.sh's
+        // first half) is pushed and deposited like the first; ADK decisions inside the loop's final push are not built
+        if (pc && d.ion_init_level < d.ion_Z) { set_error("hps_engine_create: ionisation needs the explicit solver (a species at its top level is fine)"); return HPS_ERR_UNSUPPORTED; }
         HPS_REQUIRE(d.ion_ppc[0] >= 1 && d.ion_ppc[1] >= 1 && d.ion_density > 0.0 && d.ion_mass > 0.0 && d.ion_charge != 0.0,
                     "hps_engine_create: the ion species needs ppc, density, mass and charge");
         ion.n = (long)d.ion_ppc[0]*d.ion_ppc[1]*d.nx*d.ny;
@@ -686,7 +688,7 @@ int Engine::create (const hps_deck& deck, int device)
         return HPS_OK;
     };
     if (np_cap > 0) { if (int e = alloc_sheet(pl, pl_real, np_cap, !pc)) return e; }
-    if (ion.n > 0) { ion.pl.n = ion.n; if (int e = alloc_sheet(ion.pl, ion.real, ion.n, true)) return e; }
+    if (ion.n > 0) { ion.pl.n = ion.n; if (int e = alloc_sheet(ion.pl, ion.real, ion.n, !pc)) return e; }
     HPS_HIP_CHECK(hipMalloc(&d_laser_sum, sizeof(double)));
     HPS_HIP_CHECK(hipMemset(d_laser_sum, 0, sizeof(double)));
     HPS_HIP_CHECK(hipMalloc(&d_nqsa, sizeof(int)));
@@ -757,7 +759,7 @@ int Engine::setup_tiling ()
         int ion_ts = tile_size;
         if (const char* v = std::getenv("HPS_ION_TILE")) { const int t = std::atoi(v); if (t == 16 || t == 32) ion_ts = t; }
         if (int e = tiling_create(d.nx, d.ny, ion_ts, ion.n, &ion.tiling)) return e;
-        if (int e = second(ion.pl_alt, ion.real_alt, ion.n, true)) return e;
+        if (int e = second(ion.pl_alt, ion.real_alt, ion.n, !pc)) return e;
         ion.pl_alt.n = ion.n;
         HPS_HIP_CHECK(hipMalloc(&ion.d_tile_flag, (size_t)ion.tiling->g.ntiles*sizeof(int)));
         {   const char* v = std::getenv("HPS_ION_TILE_SKIP");
@@ -1333,7 +1335,9 @@ int Engine::solve_slice_pc_begin (int islice)
     // plasma: jx jy jz [rho] rhomjz (Hipace.cpp:616-618); beams deposit into the same jx jy jz (:620-623)
     {   const int comp[6] = {HPS_PC_JX, HPS_PC_JY, HPS_PC_JZ, d.deposit_rho ? HPS_PC_RHO : -1, -1, HPS_PC_RHOMJZ};
         if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st, -1, nullptr, TailWork{}, nullptr, nullptr, valid_by_w))) return e; }
-        else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
+        else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; }
+        // MultiPlasma::DepositCurrent: every species in turn (MultiPlasma.cpp:78-87)
+        if (ion.n > 0) { if ((e = species_deposit(ion.pl, ion.tiling, comp, d.ion_charge, d.ion_mass, 1))) return e; } }
     mark();   // b2
     if ((e = deposit_beam_slice(islice, HPS_PC_JX, HPS_PC_JY, HPS_PC_JZ))) return e;
     deposit_grid_current(islice, HPS_PC_JZ);
@@ -1352,7 +1356,7 @@ int Engine::solve_slice_pc_begin (int islice)
     // the loop (Hipace.cpp:935-1031)
     HPS_HIP_CHECK(hipMemsetAsync(d_pc, 0, 2*sizeof(double), st));
     hipLaunchKernelGGL(k_rel_b_error, dim3(128), b256, 0, st, f, HPS_PC_P_BX, HPS_PC_PIT_BX, d_pc, (volatile double*)nullptr, 0.0);
-    const bool spec = pc_speculate && tiling && !moving;
+    const bool spec = pc_speculate && tiling && !moving && ion.n == 0;      // (a second species: the host-controlled loop)
     hipLaunchKernelGGL(k_pc_guess, gplane, b256, 0, st, slab.p, slab.nstride, plane, d_pc, pc_tol, spec ? d_pc_go : (int*)nullptr, pc_floor);
     pc_islice = islice;
     if (spec) {
@@ -1399,16 +1403,18 @@ int Engine::pc_enqueue_iteration (int it)
     const dim3 gplane(ceil_div(plane, 256));
     const long nval = (long)d.nx*d.ny;
     const int islice = pc_islice;
-    const bool spec = pc_speculate && tiling && !moving;
+    const bool spec = pc_speculate && tiling && !moving && ion.n == 0;
     int* go = spec ? d_pc_go + it : nullptr;
     const int comp_push[5] = {HPS_PC_PSI, HPS_PC_EZ, HPS_PC_BX, HPS_PC_BY, HPS_PC_BZ};
     int e;
     // plasma to the temporary next slice, its jx jy (+ the beam's) there
     if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 1, d.n_subcycles, 0, tiling, d_nfallback, st, -1, nullptr, go))) return e; }
     else        { if ((e = hps_advance_plasma(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 1, d.n_subcycles, 0, st))) return e; }
+    if (ion.n > 0) { if ((e = species_advance(ion.pl, ion.tiling, comp_push, d.ion_charge, d.ion_mass, 1, 1))) return e; }      // (go == nullptr with a second species)
     {   const int comp[6] = {HPS_PC_N_JX, HPS_PC_N_JY, -1, -1, -1, -1};
         if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st, -1, nullptr, TailWork{}, nullptr, go, valid_by_w))) return e; }
-        else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; } }
+        else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; }
+        if (ion.n > 0) { if ((e = species_deposit(ion.pl, ion.tiling, comp, d.ion_charge, d.ion_mass, 1))) return e; } }
     if ((e = deposit_beam_slice(islice - 1, HPS_PC_N_JX, HPS_PC_N_JY, -1, go))) return e;
     hipLaunchKernelGGL(k_rhs_bxby, dim3(ceil_div(d.nx, 256), d.ny), b256, 0, st, f, gm.mu0, 0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy),
                        0.5*(1.0/gm.dz), staging, nval, d_pc, (const int*)go);
@@ -1454,7 +1460,7 @@ int Engine::solve_slice_pc_finish (int islice)
     const int comp_push[5] = {HPS_PC_PSI, HPS_PC_EZ, HPS_PC_BX, HPS_PC_BY, HPS_PC_BZ};
     int e;
     double err = pc_last_err;
-    if (pc_speculate && tiling && !moving) {
+    if (pc_speculate && tiling && !moving && ion.n == 0) {
         int it = 0;
         err = 1.0;
         while (err > pc_tol && it < pc_max_iter) {
@@ -1477,6 +1483,7 @@ int Engine::solve_slice_pc_finish (int islice)
     mark();   // b7
     if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st))) return e; }
     else        { if ((e = hps_advance_plasma(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; }
+    if (ion.n > 0) { if ((e = species_advance(ion.pl, ion.tiling, comp_push, d.ion_charge, d.ion_mass, 0, 1))) return e; }
     insitu_beam(islice);
     if (moving && nbeam > 0) { if ((e = beam_push_moving(*this, islice))) return e; }
     mark();   // b8
@@ -1847,7 +1854,7 @@ extern "C" int hps_engine_slice_ready (void* h)
     if (E->pc) {
         // device-controlled loop: ready when the host's walk over the posted errors (solve_slice_pc_finish) would not wait --
         // an iteration that met the tolerance has been posted, or every iteration enqueued so far has
-        if (!(E->pc_speculate && E->tiling && !E->moving) || E->pc_islice < 0 || E->pc_enqueued <= 0) return 1;
+        if (!(E->pc_speculate && E->tiling && !E->moving && E->ion.n == 0) || E->pc_islice < 0 || E->pc_enqueued <= 0) return 1;
         for (int it = 1; it <= E->pc_enqueued; ++it) {
             const volatile double* hp = E->h_pc + 8*it;
             const double seq = E->pc_base_seq + it;

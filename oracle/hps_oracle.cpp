@@ -1691,7 +1691,9 @@ struct Engine {
         double t1 = now(); t_other += t1 - t0;
         // plasma deposit jx jy jz [rho] rhomjz (Hipace.cpp:616-618; chi only with a laser)
         { const int comp[6] = {pjx, pjy, pjz, d.deposit_rho ? (int)prho : -1, -1, prhomjz};
-          n_qsa_total += deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0); }
+          n_qsa_total += deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0);
+          // every species in turn (MultiPlasma::DepositCurrent, MultiPlasma.cpp:78-87); a species at its top level: no ADK step in this loop
+          if (d.ion_on) n_qsa_total += deposit_current(slab, ipl, gm, comp, d.ion_charge, d.ion_mass, d.order, d.max_qsa, 1); }
         double t2 = now(); t_deposit += t2 - t1;
         // beam jx jy jz on This, into the shared components (Hipace.cpp:620-623, BeamDepositCurrent.cpp:56-60)
         if (moving) deposit_beam(store[islice], pjx, pjy, pjz, store[islice].nreg);
@@ -1719,10 +1721,12 @@ struct Engine {
             ++it; ++pc_iterations;
             double ta = now();
             { const int comp[5] = {pPsi, pEz, pBx, pBy, pBz};
-              advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 1, d.n_subcycles, 0); }
+              advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 1, d.n_subcycles, 0);
+              if (d.ion_on) advance_plasma(slab, ipl, gm, comp, d.ion_charge, d.ion_mass, d.order, 1, d.n_subcycles, 1); }
             double tb = now(); t_push += tb - ta;
             { const int comp[6] = {pN_jx, pN_jy, -1, -1, -1, -1};
-              n_qsa_total += deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0); }
+              n_qsa_total += deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0);
+              if (d.ion_on) n_qsa_total += deposit_current(slab, ipl, gm, comp, d.ion_charge, d.ion_mass, d.order, d.max_qsa, 1); }
             double tc = now(); t_deposit += tc - tb;
             if (moving) { if (islice - 1 >= 0) deposit_beam(store[islice - 1], pN_jx, pN_jy, -1, store[islice - 1].nreg); }
             else deposit_beam(beam_next, pN_jx, pN_jy, -1);
@@ -1759,7 +1763,8 @@ struct Engine {
         }
         double t8 = now(); t_other += t8 - t7;
         { const int comp[5] = {pPsi, pEz, pBx, pBy, pBz};
-          advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0); }
+          advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0);
+          if (d.ion_on) advance_plasma(slab, ipl, gm, comp, d.ion_charge, d.ion_mass, d.order, 0, d.n_subcycles, 1); }
         insitu_beam_slice(islice);
         if (moving) {
             const Beam& b = store[islice];

@@ -470,3 +470,34 @@ def test_oracle_reproduces_the_production_lwfa_checksums(oracle):
         assert abs(cs[k] - gold[k]) <= 1e-5 * gold[k], (k, cs[k], gold[k])
     for k in ("jx_beam", "jy_beam", "jz_beam"):
         assert cs[k] == 0.0 == gold[k]
+
+
+def test_predictor_corrector_with_mobile_ions_agrees_with_explicit_solver(oracle):
+    """tests/ion_motion.SI.1Rank.sh, first half: electrons + mobile ions of 5 m_e behind the deck's tilted Gaussian driver (drawn on
+    the host, a tenth of its particles: the loop's extrapolated first guess needs a driver that is smooth in zeta), predictor-corrector
+    (mixing 0.0635, 7 iterations, tolerance 1e-4) against explicit: analysis_equal.py's sum (F_pc - F_expl)^2 / sum F_expl^2 < 0.006
+    for Bx, By, Ez, ExmBy, EypBx."""
+    base = dict(decks.ion_motion_SI(200), beam_profile=-1)
+    kp_inv = 10.0e-6
+    soa = decks.fixed_weight_beam(base, 100000, base["plasma_density"], (0.25 * kp_inv, lambda z: (z - 2.0 * kp_inv) * 0.2, 2.0 * kp_inv),
+                                  (0.4 * kp_inv, 0.4 * kp_inv, 1.41 * kp_inv), u_mean=(10.0, 20.0, 100.0), seed=1)
+    ee = oracle.Engine(base)
+    ep = oracle.Engine(decks.predictor_corrector(base, tol=1.0e-4, max_iter=7, mix=0.0635))
+    for e in (ee, ep):
+        e.set_beam_particles(soa, allow_outside=True)
+        e.begin_step()
+    names = ["Bx", "By", "Ez", "ExmBy", "EypBx"]
+    num = dict.fromkeys(names, 0.0)
+    den = dict.fromkeys(names, 0.0)
+    g = ee.g
+    for isl in range(base["nz"] - 1, -1, -1):
+        ee.solve_slice(isl)
+        ep.solve_slice(isl)
+        se, sp = ee.slab(), ep.slab()
+        for k in names:
+            a = se[oracle.CIDX[k]][g:-g, g:-g]
+            b = sp[oracle.CIDX_PC[k]][g:-g, g:-g]
+            num[k] += float(((b - a) ** 2).sum())
+            den[k] += float((a ** 2).sum())
+    for k in names:
+        assert num[k] / den[k] < 0.006, (k, num[k] / den[k])
