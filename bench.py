@@ -233,6 +233,37 @@ def emit(obj):
     print(json.dumps(obj), file=_JSON_OUT or sys.stdout, flush=True)
 
 
+def reference_benchmark(nxy):
+    """examples/benchmarks/inputs_transverse_benchmark on one GPU (tests/transverse_benchmark.1Rank.sh runs it at nxy = 1023 and
+    profiles/r05_reference_decks_host_beams.txt holds its checksums against the reference's file): slices/s of one whole box."""
+    import torch
+    from hipace_amd import api, decks
+    deck = decks.transverse_benchmark(nxy, 1000)
+    soa = decks.fixed_weight_pdf_beam(deck, seed=2024, **decks.TRANSVERSE_BENCHMARK_BEAM(nxy))
+    eng = api.SliceEngine(deck, tile_size=16)
+    eng.set_beam_particles(soa)
+    nz = deck["nz"]
+    times = []
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.begin_step()
+        for isl in range(nz - 1, -1, -1):
+            eng.solve_slice(isl)
+        eng.sync()
+        times.append(time.perf_counter() - t0)
+    st = eng.stats()
+    print(json.dumps({
+        "metric": f"transverse slices/s of the reference's transverse benchmark deck at {nxy}^2 x 1 ppc (explicit solver)", "value": nz / times[1],
+        "unit": "slices/s", "n_gpus": 1, "steps": nz, "warmup": nz, "ms_per_step": 1e3 * times[1] / nz, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"examples/benchmarks/inputs_transverse_benchmark, my_constants.nxy = {nxy}: {nxy} x {nxy} x 1000 cells, 1 plasma "
+                               f"electron per cell, fixed_weight_pdf beam of {soa.shape[1]} particles (drawn on the host by numpy), "
+                               "absorbing particle boundary, hipace.dt = 0; NOT the BASELINE.json configuration (run bench.py without this flag)"},
+        "vcycles_per_slice": st["vcycles"] / max(st["slices"], 1), "first_box_s": times[0], "timed_box_s": times[1]}))
+    return 0
+
+
 def main():
     claim_stdout()
     ap = argparse.ArgumentParser()
@@ -299,7 +330,13 @@ def main():
     ap.add_argument("--spawn-check", action="store_true",
                     help="only check the launch path: every rank joins the process group (gloo, no GPU needed) and rank 0 "
                          "prints how many ranks there are")
+    ap.add_argument("--reference-benchmark", type=int, nargs="?", const=1023, default=0, metavar="NXY",
+                    help="instead of the BASELINE deck: the reference's own transverse scaling benchmark "
+                         "(examples/benchmarks/inputs_transverse_benchmark: NXY^2 x 1000 cells, 1 ppc, a fixed_weight_pdf beam of "
+                         "10 NXY^2 particles drawn on the host; default NXY = 1023, the size its CI runs) -- one untimed box, one timed")
     args = ap.parse_args()
+    if args.reference_benchmark:
+        return reference_benchmark(args.reference_benchmark)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(respawn_under_torchrun(args.gpus))
