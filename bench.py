@@ -253,14 +253,14 @@ def reference_benchmark(nxy):
         eng.sync()
         times.append(time.perf_counter() - t0)
     st = eng.stats()
-    print(json.dumps({
+    emit({
         "metric": f"transverse slices/s of the reference's transverse benchmark deck at {nxy}^2 x 1 ppc (explicit solver)", "value": nz / times[1],
         "unit": "slices/s", "n_gpus": 1, "steps": nz, "warmup": nz, "ms_per_step": 1e3 * times[1] / nz, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"examples/benchmarks/inputs_transverse_benchmark, my_constants.nxy = {nxy}: {nxy} x {nxy} x 1000 cells, 1 plasma "
                                f"electron per cell, fixed_weight_pdf beam of {soa.shape[1]} particles (drawn on the host by numpy), "
                                "absorbing particle boundary, hipace.dt = 0; NOT the BASELINE.json configuration (run bench.py without this flag)"},
-        "vcycles_per_slice": st["vcycles"] / max(st["slices"], 1), "first_box_s": times[0], "timed_box_s": times[1]}))
+        "vcycles_per_slice": st["vcycles"] / max(st["slices"], 1), "first_box_s": times[0], "timed_box_s": times[1]})
     return 0
 
 
