@@ -270,7 +270,7 @@ __host__ __device__ inline double table_value (const double* x, const double* f,
 // consecutive cells (PlasmaParticleContainerInit.cpp:192-313, ParticleUtil.H:72-83)
 __global__ __launch_bounds__(256)
 void k_init_plasma (hps_plasma pl, long n, int nx, int ny, int ppcx, int ppcy, double lox, double loy, double dx, double dy,
-                    double weight, int level, int keyed, const double* __restrict__ prof, int nr, double ft)
+                    double weight, int level, int keyed, const double* __restrict__ prof, int nr, double ft, double radius_sq)
 {
     const long k = (long)blockIdx.x*blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -281,7 +281,8 @@ void k_init_plasma (hps_plasma pl, long n, int nx, int ny, int ppcx, int ppcy, d
     const int ixp = ip % ppcx, iyp = ip / ppcx;
     const double x = lox + (i + (0.5 + ixp)/ppcx)*dx;
     const double y = loy + (j + (0.5 + iyp)/ppcy)*dy;
-    const double fac = ft*table_value(prof, prof + nr, nr, sqrt(x*x + y*y));
+    // <plasma>.radius: no particle beyond it (PlasmaParticleContainerInit.cpp:262-266)
+    const double fac = (x*x + y*y > radius_sq) ? 0.0 : ft*table_value(prof, prof + nr, nr, sqrt(x*x + y*y));
     pl.x[k] = x; pl.y[k] = y; pl.w[k] = fac > 0.0 ? weight*fac : 0.0;
     pl.ux[k] = 0.0; pl.uy[k] = 0.0; pl.psi[k] = 1.0;
     pl.x_prev[k] = x; pl.y_prev[k] = y;
@@ -596,7 +597,6 @@ int Engine::create (const hps_deck& deck, int device)
     d = deck;
     HPS_REQUIRE(d.nx >= 4 && d.ny >= 4 && d.nz >= 1, "hps_engine_create: bad grid");
     HPS_REQUIRE(d.order >= 0 && d.order <= 3, "hps_engine_create: depos_order must be 0..3");
-    HPS_REQUIRE(d.plasma_radius <= 0.0, "hps_engine_create: finite plasma radius not supported yet");
     HPS_REQUIRE(d.n_subcycles >= 0, "hps_engine_create: plasma n_subcycles must be >= 1 (0 = default 1)");
     if (d.n_subcycles == 0) d.n_subcycles = 1;       // <plasma>.n_subcycles default (particles/plasma/PlasmaParticleContainer.H:182)
     if (d.field_bc != 0) { set_error("hps_engine_create: only boundary.field = Dirichlet is built"); return HPS_ERR_UNSUPPORTED; }
@@ -824,12 +824,13 @@ int Engine::begin_step ()
     prof_ft = table_value(prof_t.data(), prof_f_t.data(), (int)prof_t.size(), gm.c*d.dt*step_index);
     if (int e = ionize_collect()) return e;
     np = np_init; pl.n = np; pl_alt.n = np;
+    const double radius_sq = d.plasma_radius > 0.0 ? d.plasma_radius*d.plasma_radius : std::numeric_limits<double>::infinity();
     if (np > 0) {
         const int nppc = d.plasma_ppc[0]*d.plasma_ppc[1];
         hipLaunchKernelGGL(k_init_plasma, dim3(ceil_div(np, 256)), dim3(256), 0, st, pl, np, d.nx, d.ny,
                            d.plasma_ppc[0], d.plasma_ppc[1], d.lo[0], d.lo[1], gm.dx, gm.dy,
                            d.plasma_density*(d.si_units ? gm.dx*gm.dy*gm.dz/nppc : 1.0/nppc), 0, 0,     // scale_fac, PlasmaParticleContainerInit.cpp:40-41
-                           d_prof_r, (int)prof_r.size(), prof_ft);
+                           d_prof_r, (int)prof_r.size(), prof_ft, radius_sq);
     }
     if (tiling) { if (int e = resort()) return e; }
     if (np > 0 && !d.plasma_no_neutralize) {
@@ -848,7 +849,7 @@ int Engine::begin_step ()
         hipLaunchKernelGGL(k_init_plasma, dim3(ceil_div(ion.n, 256)), dim3(256), 0, st, ion.pl, ion.n, d.nx, d.ny,
                            d.ion_ppc[0], d.ion_ppc[1], d.lo[0], d.lo[1], gm.dx, gm.dy,
                            d.ion_density*(d.si_units ? gm.dx*gm.dy*gm.dz/inppc : 1.0/inppc), d.ion_init_level, 1,
-                           d_prof_r, (int)prof_r.size(), prof_ft);
+                           d_prof_r, (int)prof_r.size(), prof_ft, radius_sq);
         if (ion.tiling) {
             ion.pl_alt.n = ion.n;
             if (int e = tiling_sort(ion.tiling, ion.pl, ion.pl_alt, gm, st)) return e;

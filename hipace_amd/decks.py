@@ -485,8 +485,8 @@ def production_lwfa(n=64, nz=100, max_step=10):
     pulse (a0 = 1.9, w0 = 3 kp^-1, L0 = 0.5 kp^-1, multigrid envelope solver, MG_tolerance_rel = 1e-5) enters a parabolic plasma
     channel of radius 23 kp^-1 through a cosine up-ramp of 6 mm, steps of c dt = 10 kp^-1, SI units, ne = 1.0505e23 m^-3.
     The density function n_e (1 + 4 r^2 / (kp^2 Rm^4)) ramp(c t) [c t > 0] is the engine's tabulated form f_r(r) f_t(c t):
-    -> (deck, (r, fr, ct, ft)) for SliceEngine.set_density_profile -- the radial table on the lattice's own radii (exact at
-    every particle), cut at the channel's radius, the time table on the steps' own times."""
+    -> (deck with plasma_radius, (r, fr, ct, ft)) for SliceEngine.set_density_profile -- the radial table on the lattice's own
+    radii (exact at every particle), the time table on the steps' own times."""
     import numpy as np
     ne = 1.0505e23
     wp = (ne * SI["q_e"] ** 2 / (SI["m_e"] * SI["ep0"])) ** 0.5
@@ -503,12 +503,9 @@ def production_lwfa(n=64, nz=100, max_step=10):
     xs = d["lo"][0] + (np.arange(n) + 0.5) * dx
     r2 = np.unique(np.add.outer(xs * xs, xs * xs).round(decimals=22))
     r = np.sqrt(r2)
-    rad = 23.0 * kp_inv
-    inside = r <= rad
-    r_tab = np.concatenate([r[inside], [rad * (1.0 + 1e-12)]]) if inside.sum() < r.size else r
+    d["plasma_radius"] = 23.0 * kp_inv                   # plasma.radius: no particles in the box's corners
+    r_tab = r
     fr = 1.0 + 4.0 * r_tab ** 2 / (kp ** 2 * Rm ** 4)
-    if inside.sum() < r.size:
-        fr[-1] = 0.0
     if r_tab[0] > 0.0:
         r_tab = np.concatenate([[0.0], r_tab]); fr = np.concatenate([[1.0], fr])
     ct = np.array([SI["c"] * d["dt"] * k for k in range(max_step + 2)])
