@@ -809,7 +809,6 @@ def test_error_behaviour(api):
     fails(lambda: api.Tiling(64, 64, 24, 100), "tile_size")
     deck = decks.blowout_wake()
     fails(lambda: api.SliceEngine(dict(deck, order=4)), "depos_order")
-    fails(lambda: api.SliceEngine(dict(deck, plasma_radius=3.0)), "plasma radius")
     fails(lambda: api.SliceEngine(dict(deck, field_bc=1)), "Dirichlet")
     # engine options that do not apply
     eng = api.SliceEngine(deck)

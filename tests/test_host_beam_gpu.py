@@ -595,3 +595,25 @@ def test_ion_motion_predictor_corrector_equals_explicit(api, oracle):
     # a species that still has levels to lose is refused under this solver, loudly
     with pytest.raises(RuntimeError, match="explicit solver"):
         api.SliceEngine(decks.predictor_corrector(decks.ionization_SI()))
+
+
+def test_finite_plasma_radius_matches_oracle(api, oracle):
+    """<plasma>.radius (PlasmaParticleContainerInit.cpp:262-266): no plasma particles beyond it -- the blowout deck with a plasma
+    column of radius 5 in its 16-wide box, the slices through the driver against the oracle; particles do get left out."""
+    from hipace_amd._lib import COMPS
+    deck = dict(decks.blowout_wake(), plasma_radius=5.0, n_steps=1)
+    ge = api.SliceEngine(deck, tile_size=16)
+    oe = oracle.Engine(deck)
+    ge.begin_step()
+    oe.begin_step()
+    nz = deck["nz"]
+    for isl in range(nz - 1, nz - 1 - 60, -1):
+        ge.solve_slice(isl)
+        oe.solve_slice(isl)
+    gs, os_ = ge.slab(), oe.slab()
+    for c in range(ge.ncomp):
+        assert rel_err(gs[c], os_[c]) < 1e-8, (COMPS[c], rel_err(gs[c], os_[c]))
+    assert ge.stats()["vcycles"] == oe.vcycles()
+    gr, gv = ge.particles()
+    orl, ov = oe.particles()
+    assert int((gv != 0).sum()) == orl.shape[1] < gv.size
