@@ -418,7 +418,9 @@ int hps_engine_beam_info (void* handle, long* nbeam_host, long* offsets_host /* 
  * particle count and the cell volume); any order.  The particles are binned into the box's slices, slice =
  * int((z - lo_z)/dz) as the reference's BoxSorter does (particles/sorting/BoxSort.cpp:34-43), input order kept inside
  * a slice.  Particles outside the box in z are left out and counted in *n_outside (NULL: they are an error).  Call after
- * hps_engine_create and before the first hps_engine_begin_step; works for hipace.dt = 0 and for a moving beam. */
+ * hps_engine_create and before the first hps_engine_begin_step; works for hipace.dt = 0 and for a moving beam.  In a pipeline
+ * every stage's engine is given the same particles (the block layout of hps_engine_beam_info and the hand-off capacity derive
+ * from them; only the head stage injects them, MultiBuffer.cpp:809). */
 int hps_engine_set_beam_particles (void* handle, long n, const double* soa_host, long* n_outside);
 int hps_engine_set_beam_storage (void* handle, double* storage_dev /* [7*nbeam] or NULL = own */);
 int hps_engine_initial_beam (void* handle, double* dst_dev);
