@@ -617,3 +617,34 @@ def test_finite_plasma_radius_matches_oracle(api, oracle):
     gr, gv = ge.particles()
     orl, ov = oe.particles()
     assert int((gv != 0).sum()) == orl.shape[1] < gv.size
+
+
+def test_beam_in_vacuum_fields_follow_theory(api):
+    """tests/beam_in_vacuum.normalized.1Rank.sh's second half (examples/beam_in_vacuum/analysis.py): the fields of a uniform
+    cylindrical beam of radius 1 and density 1 in vacuum against Ampere's and Gauss's laws -- B_theta = mu0 jz0 r / 2 inside,
+    mu0 jz0 R^2 / (2 r) outside, E_r likewise -- on the lines through the box's middle; the reference's tolerances
+    (sum (F - F_th)^2 / sum F_th^2 < 0.005 for Bx, Ey and 0.015 for By, Ex)."""
+    deck = decks.beam_in_vacuum()
+    eng = api.SliceEngine(deck, tile_size=0)
+    eng.set_field_diagnostic(["Bx", "By", "ExmBy", "EypBx"])
+    eng.run_step()
+    fd = eng.field_diagnostic()
+    nz, ny, nx = fd["By"].shape
+    iz, jy, ix = nz // 2, ny // 2, nx // 2
+    x = deck["lo"][0] + (np.arange(nx) + 0.5) * (deck["hi"][0] - deck["lo"][0]) / nx
+    y = deck["lo"][1] + (np.arange(ny) + 0.5) * (deck["hi"][1] - deck["lo"][1]) / ny
+    jz0 = rho0 = -1.0
+    R = 1.0
+
+    def th(s, a):
+        out = a * s / 2.0
+        far = np.abs(s) >= R
+        out[far] = a * R ** 2 / (2.0 * s[far])
+        return out
+
+    By, Bx = fd["By"][iz, jy, :], fd["Bx"][iz, :, ix]
+    Ex, Ey = fd["ExmBy"][iz, jy, :] + By, fd["EypBx"][iz, :, ix] - Bx
+    for name, sim, theory, tol in (("Bx", Bx, th(y, -jz0), 0.005), ("By", By, th(x, jz0), 0.015),
+                                   ("Ex", Ex, th(x, rho0), 0.015), ("Ey", Ey, th(y, rho0), 0.005)):
+        err = ((sim - theory) ** 2).sum() / (theory ** 2).sum()
+        assert err < tol, (name, err)

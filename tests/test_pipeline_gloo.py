@@ -42,14 +42,25 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_steps, out, moving=False, pc=False, batch=1):
+def _host_beam(deck):
+    """a warm Gaussian bunch drawn on the host (decks.fixed_weight_beam) for _moving_deck without its own beam"""
+    return decks.fixed_weight_beam(deck, 3000, 1.0e-3, (0.1, lambda z: 0.05 * z, 0.3), (0.3, 0.3, 0.6), u_mean=(0.0, 0.0, 1.2),
+                                   u_std=(0.02, 0.02, 0.05), seed=9)
+
+
+def _worker(rank, world, port, n_steps, out, moving=False, pc=False, batch=1, host_beam=False):
     import torch.distributed as dist
     from hipace_amd.pipeline import run_pipeline
     from oracle import oracle as O
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    eng = O.Engine(_moving_deck() if moving else _deck(pc))
+    deck = _moving_deck() if moving else _deck(pc)
+    if host_beam:
+        deck = dict(deck, beam_profile=-1)
+    eng = O.Engine(deck)
+    if host_beam:      # every rank's engine is given the particles (layout, capacity); only the head rank injects them
+        eng.set_beam_particles(_host_beam(deck), allow_outside=True)
     sums = {}
 
     def on_step_end(step):
@@ -116,6 +127,40 @@ def test_ring_pipeline_hands_a_moving_beam_on(oracle, world, n_steps):
     seen = set()
     for rank, solved, sums in results:
         assert solved == deck["nz"] * len(range(rank, n_steps, world))
+        for step, cs in sums.items():
+            seen.add(step)
+            for k, v in want[step].items():
+                assert cs[k] == v, (rank, step, k, cs[k], v)
+    assert seen == set(range(n_steps))
+
+
+def test_ring_pipeline_hands_a_host_initialised_moving_beam_on(oracle):
+    """the same with a beam the host has drawn (hps_engine_set_beam_particles' twin in the oracle: a random Gaussian bunch in
+    place of the deck's fixed_ppc one): two ranks, three steps, every step's checksums equal one process stepping the same
+    particles"""
+    world, n_steps = 2, 3
+    deck = dict(_moving_deck(), beam_profile=-1)
+    ref = oracle.Engine(deck)
+    ref.set_beam_particles(_host_beam(deck), allow_outside=True)
+    want = {}
+    for s in range(n_steps):
+        ref.begin_step()
+        for k in range(deck["nz"] - 1, -1, -1):
+            ref.solve_slice(k)
+        want[s] = ref.checksums()
+    assert want[0]["jz_beam"] != 0.0 and want[n_steps - 1]["jz_beam"] != want[0]["jz_beam"]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_steps, out, True, False, 1, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seen = set()
+    for rank, solved, sums in results:
         for step, cs in sums.items():
             seen.add(step)
             for k, v in want[step].items():
