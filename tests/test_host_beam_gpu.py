@@ -648,3 +648,20 @@ def test_beam_in_vacuum_fields_follow_theory(api):
                                    ("Ex", Ex, th(x, rho0), 0.015), ("Ey", Ey, th(y, rho0), 0.005)):
         err = ((sim - theory) ** 2).sum() / (theory ** 2).sum()
         assert err < tol, (name, err)
+
+
+def test_beam_width_follows_betatron_theory(api):
+    """tests/beam_evolution.1Rank.sh's first half (examples/beam_in_vacuum/analysis_beam_push.py): a cold gamma = 1000 disc beam in
+    the focusing field E = (x, y) / 2 -- its rms width after 20 steps of dt = 3 is x_std(0) |cos(omega_beta t)|,
+    omega_beta = sqrt(1/2 / gamma), to 2e-3 as the reference asks"""
+    deck = decks.beam_evolution()
+    eng = api.SliceEngine(deck, tile_size=0)
+    for _ in range(20):
+        eng.run_step()
+    _, st = eng.beam_state()
+    w = st[6]
+    t = 20 * deck["dt"]
+    theory = 0.5 * abs(np.cos(np.sqrt(0.5 / 1000.0) * t))
+    for r in (0, 1):
+        std = np.sqrt((st[r] ** 2 * w).sum() / w.sum())
+        assert (std - theory) / theory < 2.0e-3 and abs(std - theory) / theory < 1.0e-2, (r, std, theory)
