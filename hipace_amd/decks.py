@@ -438,14 +438,17 @@ def fixed_weight_pdf_beam(deck, num_particles, density, pdf, pos_mean=(0.0, 0.0)
 
 
 def fixed_weight_beam(deck, num_particles, density, pos_mean, pos_std, u_mean=(0.0, 0.0, 0.0), u_std=(0.0, 0.0, 0.0),
-                      zmin=-float("inf"), zmax=float("inf"), radius=float("inf"), seed=0, total_charge=None):
+                      zmin=-float("inf"), zmax=float("inf"), radius=float("inf"), seed=0, total_charge=None, do_symmetrize=False,
+                      duz_per_uz0_dzeta=0.0):
     """beam.injection_type = fixed_weight, profile = gaussian, with a peak density (BeamParticleContainer.cpp:137-198,
     InitBeamFixedWeight3D / InitBeamFixedWeightSlice, BeamParticleContainerInit.cpp:350-477), on the host: z is normal about
     pos_mean[2] (:375-377), x and y are normal about pos_mean[0](z), pos_mean[1](z) -- numbers or vectorised callables of z
     (:435-454) --, every particle carries density (2 pi)^(3/2) sigma_x sigma_y sigma_z / num_particles, in normalised units
     over the cell volume (BeamParticleContainer.cpp:179-190, :420).  Particles outside [zmin, zmax] or the radius are invalid
     in the reference (:443-446): left out here; particles outside the box are left out by set_beam_particles.  numpy's
-    generator stands in for amrex::Random.  -> (7, n <= num_particles) array x y z ux uy uz w, u times c."""
+    generator stands in for amrex::Random.  -> (7, n <= num_particles) array x y z ux uy uz w, u times c.
+    do_symmetrize: num_particles / 4 draws, each placed four times at (+-x, +-y) about the mean with (+-ux, +-uy) (:457-470);
+    duz_per_uz0_dzeta: uz += (z - z_mean) duz_per_uz0_dzeta u_mean[2] (GetInitialMomentum.H:47)."""
     import numpy as np
     rng = np.random.default_rng(seed)
     lo, hi = deck["lo"], deck["hi"]
@@ -458,18 +461,24 @@ def fixed_weight_beam(deck, num_particles, density, pos_mean, pos_std, u_mean=(0
         weight = density * (2.0 * np.pi) ** 1.5 * pos_std[0] * pos_std[1] * pos_std[2] / num_particles
     if not deck.get("si_units", 0):
         weight /= dx * dy * dz
-    z = rng.normal(pos_mean[2], pos_std[2], num_particles)
-    x = rng.normal(0.0, pos_std[0], num_particles)
-    y = rng.normal(0.0, pos_std[1], num_particles)
+    nd = num_particles // 4 if do_symmetrize else num_particles
+    assert not do_symmetrize or num_particles % 4 == 0, "to symmetrize the beam its particle number must be divisible by 4"
+    z = rng.normal(pos_mean[2], pos_std[2], nd)
+    x = rng.normal(0.0, pos_std[0], nd)
+    y = rng.normal(0.0, pos_std[1], nd)
     ok = (z >= zmin) & (z <= zmax) & (x * x + y * y <= radius * radius)
     mx = pos_mean[0](z) if callable(pos_mean[0]) else pos_mean[0]
     my = pos_mean[1](z) if callable(pos_mean[1]) else pos_mean[1]
-    out = np.empty((7, num_particles))
-    out[0], out[1], out[2] = mx + x, my + y, z
-    for k in range(3):
-        out[3 + k] = (u_mean[k] + (rng.normal(0.0, u_std[k], num_particles) if u_std[k] else 0.0)) * c
-    out[6] = abs(weight)
-    return np.ascontiguousarray(out[:, ok])
+    u = [u_mean[k] + (rng.normal(0.0, u_std[k], nd) if u_std[k] else np.zeros(nd)) for k in range(3)]
+    u[2] = u[2] + (z - pos_mean[2]) * duz_per_uz0_dzeta * u_mean[2]
+    parts = []
+    for sx, sy in (((1, 1), (-1, 1), (1, -1), (-1, -1)) if do_symmetrize else ((1, 1),)):
+        o = np.empty((7, nd))
+        o[0], o[1], o[2] = mx + sx * x, my + sy * y, z
+        o[3], o[4], o[5] = sx * u[0] * c, sy * u[1] * c, u[2] * c
+        o[6] = abs(weight)
+        parts.append(o[:, ok])
+    return np.ascontiguousarray(np.concatenate(parts, axis=1))
 
 
 def ion_motion_SI_reference_beam(deck, seed=1):

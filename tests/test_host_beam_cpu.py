@@ -131,3 +131,25 @@ def test_restart_from_this_writers_file(tmp_path):
         for k, name in enumerate(("x", "y", "z", "ux", "uy", "uz")):
             assert np.abs(soa[k] - beam[name]).max() <= 1e-12 * np.abs(beam[name]).max(), (si, name)
         assert np.abs(soa[6] - beam["w"] * ratio).max() <= 1e-12 * ratio * 1.5, si
+
+
+def test_fixed_weight_beam_has_the_moments_the_reference_checks():
+    """tests/gaussian_weight.1Rank.sh + examples/gaussian_weight/analysis.py on the host-side restatement of fixed_weight:
+    the normalised deck (symmetrised: the transverse means exact, charge to 1e-3, widths to 3 %) and the tilted, chirped beam
+    of the test's first run (x and y centroid at z_mean + 1 to 5e-3 of the slope, uz there to 5e-4)."""
+    deck = dict(decks.beam_in_vacuum(), nx=64, ny=64, nz=64, lo=(-20.0, -20.0, -20.0), hi=(20.0, 20.0, 20.0), beam_profile=-1)
+    b = decks.fixed_weight_beam(deck, 10000, 1.0, (0.0, 1.0, 2.0), (3.0, 4.0, 5.0), u_mean=(0.0, 0.0, 1.0e3), u_std=(3.0, 4.0, 0.0),
+                                zmin=-20.0, zmax=20.0, radius=40.0, do_symmetrize=True, seed=4)      # (the z centroid of 2500 draws is within the reference's 5 % for about half of all seeds)
+    charge = 1.0 * 3.0 * 4.0 * 5.0 * (2.0 * np.pi) ** 1.5 / (40.0 / 64.0) ** 3
+    assert abs(b[6].sum() - charge) / charge < 1.0e-3
+    assert abs(b[0].mean()) < 1e-12 and abs(b[1].mean() - 1.0) < 1e-4 and abs(b[3].mean()) < 1e-12 and abs(b[4].mean()) < 1e-12
+    assert abs(b[2].mean() - 2.0) / 2.0 < 0.05
+    for r, sd in ((0, 3.0), (1, 4.0), (2, 5.0)):
+        assert abs(b[r].std() - sd) / sd < 0.03, r
+    t = decks.fixed_weight_beam(deck, 1000000, 1.0, (lambda z: (z - 2.0) * 0.1, lambda z: 1.0 + (z - 2.0) * (-0.2), 2.0), (0.1, 0.1, 2.0),
+                                u_mean=(0.0, 0.0, 1.0e3), zmin=-20.0, zmax=20.0, radius=40.0, duz_per_uz0_dzeta=0.01, seed=4)
+    at1 = (t[2] > 2.99) & (t[2] < 3.01)
+    assert at1.sum() > 1000
+    assert abs((t[0][at1] - 0.1).mean() / 0.1) < 5e-3
+    assert abs((t[1][at1] + 0.2 - 1.0).mean() / 0.2) < 5e-3
+    assert abs(((t[5][at1] - (1000.0 + 1000.0 * 0.01)) / (1000.0 + 1000.0 * 0.01)).mean()) < 5e-4
