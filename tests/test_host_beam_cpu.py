@@ -147,7 +147,7 @@ def test_fixed_weight_beam_has_the_moments_the_reference_checks():
     for r, sd in ((0, 3.0), (1, 4.0), (2, 5.0)):
         assert abs(b[r].std() - sd) / sd < 0.03, r
     t = decks.fixed_weight_beam(deck, 1000000, 1.0, (lambda z: (z - 2.0) * 0.1, lambda z: 1.0 + (z - 2.0) * (-0.2), 2.0), (0.1, 0.1, 2.0),
-                                u_mean=(0.0, 0.0, 1.0e3), zmin=-20.0, zmax=20.0, radius=40.0, duz_per_uz0_dzeta=0.01, seed=4)
+                                u_mean=(0.0, 0.0, 1.0e3), zmin=-20.0, zmax=20.0, radius=40.0, duz_per_uz0_dzeta=0.01, do_symmetrize=True, seed=4)
     at1 = (t[2] > 2.99) & (t[2] < 3.01)
     assert at1.sum() > 1000
     assert abs((t[0][at1] - 0.1).mean() / 0.1) < 5e-3
