@@ -665,3 +665,32 @@ def test_beam_width_follows_betatron_theory(api):
     for r in (0, 1):
         std = np.sqrt((st[r] ** 2 * w).sum() / w.sum())
         assert (std - theory) / theory < 2.0e-3 and abs(std - theory) / theory < 1.0e-2, (r, std, theory)
+
+
+def test_blowout_wake_SI_normalised_and_fixed_weight_agree(api):
+    """tests/blowout_wake.2Rank.sh's analysis (examples/blowout_wake/analysis.py): the on-axis Ez of the SI deck over E0 equals the
+    normalised deck's, sum (a - b)^2 / sum b^2 < 1e-10, and the SI deck with its beam from fixed_weight (10^6 random particles, drawn
+    on the host) the fixed_ppc one to 1e-2."""
+    dn, ds = dict(decks.blowout_wake(), n_steps=1), dict(decks.blowout_wake_SI(), n_steps=1)
+    kp_inv = ds["hi"][0] / 8.0
+    c, q_e, m_e, ep0 = 299792458.0, 1.602176634e-19, 9.1093837015e-31, 8.8541878128e-12
+    E0 = (c / kp_inv) * m_e * c / q_e
+
+    def on_axis_ez(deck, soa=None):
+        e = api.SliceEngine(dict(deck, beam_profile=-1) if soa is not None else deck, tile_size=16)
+        if soa is not None:
+            e.set_beam_particles(soa, allow_outside=True)
+        e.set_field_diagnostic(["Ez"])
+        e.run_step()
+        f = e.field_diagnostic()["Ez"]
+        nz, ny, nx = f.shape
+        return f[:, ny // 2, nx // 2]
+
+    ez_n, ez_s = on_axis_ez(dn), on_axis_ez(ds)
+    assert np.abs(ez_n).max() > 0.1
+    assert ((ez_s / E0 - ez_n) ** 2).sum() / (ez_n ** 2).sum() < 1e-10
+    # beam.injection_type = fixed_weight with the deck's Gaussian (sigma 0.3, 0.3, 1.41 kp^-1, peak density 3 n0, cut at zmin / zmax / radius)
+    soa = decks.fixed_weight_beam(ds, 1000000, ds["beam_density"], (0.0, 0.0, 0.0), tuple(s * kp_inv for s in (0.3, 0.3, 1.41)),
+                                  u_mean=(0.0, 0.0, 2000.0), zmin=ds["beam_zmin"], zmax=ds["beam_zmax"], radius=ds["beam_radius"], seed=2)
+    ez_w = on_axis_ez(ds, soa)
+    assert ((ez_w - ez_s) ** 2).sum() / (ez_s ** 2).sum() < 1e-2
