@@ -300,7 +300,10 @@ int beam_push_moving (Engine& E, int islice)
     const SlabView f(E.slab);
     const BeamPushConsts k = push_consts(E, islice);
     const dim3 grid((unsigned)std::min<long>(ceil_div(bound, 256), 2048)), block(256);
-#define CALL(O) hipLaunchKernelGGL(k_beam_push<O>, grid, block, 0, E.st, f, E.bm, E.d_B, p, HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, HPS_C_BZ, k)
+    // the fields of This slice sit at other components of the predictor-corrector's slab (fields/Fields.cpp:128-164)
+    const int cP = E.pc ? (int)HPS_PC_PSI : (int)HPS_C_PSI, cE = E.pc ? (int)HPS_PC_EZ : (int)HPS_C_EZ, cX = E.pc ? (int)HPS_PC_BX : (int)HPS_C_BX,
+              cY = E.pc ? (int)HPS_PC_BY : (int)HPS_C_BY, cZ = E.pc ? (int)HPS_PC_BZ : (int)HPS_C_BZ;
+#define CALL(O) hipLaunchKernelGGL(k_beam_push<O>, grid, block, 0, E.st, f, E.bm, E.d_B, p, cP, cE, cX, cY, cZ, k)
     HPS_BEAM_ORDER(E.d.order, CALL)
 #undef CALL
     hipLaunchKernelGGL(k_beam_partition, dim3(1), dim3(1024), 0, E.st, E.bm, E.bm_scr, E.d_B, E.d_nfront, p, k.min_z);

@@ -662,9 +662,8 @@ int Engine::create (const hps_deck& deck, int device)
     np = (d.plasma_density > 0.0) ? (long)nppc*d.nx*d.ny : 0;
     np_init = np; np_cap = np;
     if (d.ion_on) {
-        // predictor-corrector: a second species that is fully ionised from the start (mobile ions, tests/ion_motion.SI.1Rank.sh's
-        // first half) is pushed and deposited like the first; ADK decisions inside the loop's final push are not built
-        if (pc && d.ion_init_level < d.ion_Z) { set_error("hps_engine_create: ionisation needs the explicit solver (a species at its top level is fine)"); return HPS_ERR_UNSUPPORTED; }
+        // (predictor-corrector: every species is pushed to the temporary slice and deposited in turn inside the loop; the ADK
+        //  decisions are taken once per slice, ahead of the committing push, as Hipace.cpp:693-701 has them)
         HPS_REQUIRE(d.ion_ppc[0] >= 1 && d.ion_ppc[1] >= 1 && d.ion_density > 0.0 && d.ion_mass > 0.0 && d.ion_charge != 0.0,
                     "hps_engine_create: the ion species needs ppc, density, mass and charge");
         ion.n = (long)d.ion_ppc[0]*d.ion_ppc[1]*d.nx*d.ny;
@@ -1330,12 +1329,15 @@ int Engine::solve_slice_pc_begin (int islice)
         if (d.deposit_rho) z.c[z.n++] = HPS_PC_RHO;
         hipLaunchKernelGGL(k_zero_comps, gplane, b256, 0, st, slab.p, slab.nstride, plane, (int)slab.jstride, z, zb, CellBox{0, -1, 0, -1}); }
     mark();   // b1
-    if (tiling && (since_sort >= sort_period || (since_sort >= 2 && *h_nfallback - fb_at_sort > np/fallback_div))) { if ((e = resort())) return e; }
+    if (tiling && (since_sort >= sort_period || (since_sort >= 2 && *h_nfallback - fb_at_sort > np/fallback_div) ||
+                   (since_sort >= 1 && np - tiling->sorted_n > std::max(np/32, 16384L)))) { if ((e = resort())) return e; }
     ++since_sort;
     mark();   // b1b
     // plasma: jx jy jz [rho] rhomjz (Hipace.cpp:616-618); beams deposit into the same jx jy jz (:620-623)
     {   const int comp[6] = {HPS_PC_JX, HPS_PC_JY, HPS_PC_JZ, d.deposit_rho ? HPS_PC_RHO : -1, -1, HPS_PC_RHOMJZ};
-        if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st, -1, nullptr, TailWork{}, nullptr, nullptr, valid_by_w))) return e; }
+        // (with an ionisable species the sheet has electrons behind its tile-sorted body: the helper that also covers that tail)
+        if (ion.n > 0) { if ((e = species_deposit(pl, tiling, comp, d.plasma_charge, d.plasma_mass, 0))) return e; }
+        else if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st, -1, nullptr, TailWork{}, nullptr, nullptr, valid_by_w))) return e; }
         else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; }
         // MultiPlasma::DepositCurrent: every species in turn (MultiPlasma.cpp:78-87)
         if (ion.n > 0) { if ((e = species_deposit(ion.pl, ion.tiling, comp, d.ion_charge, d.ion_mass, 1))) return e; } }
@@ -1409,11 +1411,13 @@ int Engine::pc_enqueue_iteration (int it)
     const int comp_push[5] = {HPS_PC_PSI, HPS_PC_EZ, HPS_PC_BX, HPS_PC_BY, HPS_PC_BZ};
     int e;
     // plasma to the temporary next slice, its jx jy (+ the beam's) there
-    if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 1, d.n_subcycles, 0, tiling, d_nfallback, st, -1, nullptr, go))) return e; }
+    if (ion.n > 0) { if ((e = species_advance(pl, tiling, comp_push, d.plasma_charge, d.plasma_mass, 1, 0))) return e; }
+    else if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 1, d.n_subcycles, 0, tiling, d_nfallback, st, -1, nullptr, go))) return e; }
     else        { if ((e = hps_advance_plasma(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 1, d.n_subcycles, 0, st))) return e; }
     if (ion.n > 0) { if ((e = species_advance(ion.pl, ion.tiling, comp_push, d.ion_charge, d.ion_mass, 1, 1))) return e; }      // (go == nullptr with a second species)
     {   const int comp[6] = {HPS_PC_N_JX, HPS_PC_N_JY, -1, -1, -1, -1};
-        if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st, -1, nullptr, TailWork{}, nullptr, go, valid_by_w))) return e; }
+        if (ion.n > 0) { if ((e = species_deposit(pl, tiling, comp, d.plasma_charge, d.plasma_mass, 0))) return e; }
+        else if (tiling) { if ((e = deposit_current_tiled(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, tiling, d_nfallback, st, -1, nullptr, TailWork{}, nullptr, go, valid_by_w))) return e; }
         else        { if ((e = hps_deposit_current(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, d.max_qsa, 0, d_nqsa, st))) return e; }
         if (ion.n > 0) { if ((e = species_deposit(ion.pl, ion.tiling, comp, d.ion_charge, d.ion_mass, 1))) return e; } }
     if ((e = deposit_beam_slice(islice - 1, HPS_PC_N_JX, HPS_PC_N_JY, -1, go))) return e;
@@ -1482,9 +1486,23 @@ int Engine::solve_slice_pc_finish (int islice)
         hipLaunchKernelGGL(k_checksum, dim3(64, ncomp), b256, 0, st, f, ncomp, d_checksum);
     if ((e = fill_field_diagnostic(islice))) return e;
     mark();   // b7
-    if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st))) return e; }
+    if (ion.n > 0) {
+        // DoFieldIonization (Hipace.cpp:693-696) and the committing pushes of both species (:699-701): the decisions on the tiles'
+        // gathered fields inside the ions' push (or k_ionize ahead of the per-particle push), the electron count back on the host,
+        // then every electron -- the ones this slice has released included
+        if (ion.tiling) {
+            if ((e = ion_field_bounds())) return e;
+            const IonArgs ia = ion_args(islice);
+            if ((e = advance_plasma_tiled(slab, ion.pl, gm, comp_push, d.ion_charge, d.ion_mass, d.order, 0, d.n_subcycles, 1, ion.tiling, d_nfallback, st, -1, &ia))) return e;
+        } else {
+            if ((e = ionize_slice(islice))) return e;
+            if ((e = species_advance(ion.pl, ion.tiling, comp_push, d.ion_charge, d.ion_mass, 0, 1))) return e;
+        }
+        if ((e = ionize_collect())) return e;
+        if ((e = species_advance(pl, tiling, comp_push, d.plasma_charge, d.plasma_mass, 0, 0))) return e;
+    }
+    else if (tiling) { if ((e = advance_plasma_tiled(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, tiling, d_nfallback, st))) return e; }
     else        { if ((e = hps_advance_plasma(slab, pl, gm, comp_push, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0, st))) return e; }
-    if (ion.n > 0) { if ((e = species_advance(ion.pl, ion.tiling, comp_push, d.ion_charge, d.ion_mass, 0, 1))) return e; }
     insitu_beam(islice);
     if (moving && nbeam > 0) { if ((e = beam_push_moving(*this, islice))) return e; }
     mark();   // b8

@@ -106,7 +106,8 @@ int Engine::ion_field_bounds ()
 {
     if (!ion.tiling || !ion.d_fbound) return HPS_OK;
     const TileGeom& g = ion.tiling->g;
-    hipLaunchKernelGGL(k_ion_field_bounds, dim3(g.ntiles), dim3(256), 0, st, SlabView(slab), HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, g.ts, g.ntx, g.nty,
+    const int cP = pc ? (int)HPS_PC_PSI : (int)HPS_C_PSI, cE = pc ? (int)HPS_PC_EZ : (int)HPS_C_EZ, cX = pc ? (int)HPS_PC_BX : (int)HPS_C_BX, cY = pc ? (int)HPS_PC_BY : (int)HPS_C_BY;
+    hipLaunchKernelGGL(k_ion_field_bounds, dim3(g.ntiles), dim3(256), 0, st, SlabView(slab), cP, cE, cX, cY, g.ts, g.ntx, g.nty,
                        ion.d_fbound);
     HPS_HIP_CHECK(hipGetLastError());
     return HPS_OK;
@@ -194,7 +195,8 @@ int Engine::ionize_slice (int islice)
     const PartConsts k = base_consts(gm);
     const SlabView f(slab);
     const dim3 grid(ceil_div(ion.n, 256)), block(256);
-#define CALL(O) hipLaunchKernelGGL(k_ionize<O>, grid, block, 0, st, f, ion.pl, HPS_C_PSI, HPS_C_EZ, HPS_C_BX, HPS_C_BY, k, a)
+    const int cP = pc ? (int)HPS_PC_PSI : (int)HPS_C_PSI, cE = pc ? (int)HPS_PC_EZ : (int)HPS_C_EZ, cX = pc ? (int)HPS_PC_BX : (int)HPS_C_BX, cY = pc ? (int)HPS_PC_BY : (int)HPS_C_BY;
+#define CALL(O) hipLaunchKernelGGL(k_ionize<O>, grid, block, 0, st, f, ion.pl, cP, cE, cX, cY, k, a)
     switch (d.order) { case 0: CALL(0); break; case 1: CALL(1); break; case 2: CALL(2); break; default: CALL(3); break; }
 #undef CALL
     HPS_HIP_CHECK(hipGetLastError());

@@ -1267,7 +1267,8 @@ struct Engine {
     // ionise (the reference reads past the end of its ADK tables there).
     void ionization_module (int islice) {
         if (!d.ion_on || adk_prefactor.empty()) return;
-        const int comp[5] = {Psi, Ez, Bx, By, Bz};
+        const bool pcs = d.bxby_solver != 0;      // (the predictor-corrector solver's slab layout)
+        const int comp[5] = {pcs ? (int)pPsi : (int)Psi, pcs ? (int)pEz : (int)Ez, pcs ? (int)pBx : (int)Bx, pcs ? (int)pBy : (int)By, pcs ? (int)pBz : (int)Bz};
         const double cSI = 299792458.0, qeSI = 1.602176634e-19, meSI = 9.1093837015e-31, ep0SI = 8.8541878128e-12;
         const double wp = std::sqrt(d.background_density_SI*qeSI*qeSI/(ep0SI*meSI));
         const double E0 = d.si_units ? 1.0 : wp*meSI*cSI/qeSI;
@@ -1763,6 +1764,7 @@ struct Engine {
         }
         double t8 = now(); t_other += t8 - t7;
         { const int comp[5] = {pPsi, pEz, pBx, pBy, pBz};
+          ionization_module(islice);               // DoFieldIonization (Hipace.cpp:693-696), before the committing pushes
           advance_plasma(slab, pl, gm, comp, d.plasma_charge, d.plasma_mass, d.order, 0, d.n_subcycles, 0);
           if (d.ion_on) advance_plasma(slab, ipl, gm, comp, d.ion_charge, d.ion_mass, d.order, 0, d.n_subcycles, 1); }
         insitu_beam_slice(islice);
@@ -1928,7 +1930,8 @@ struct Engine {
         const Real qm = d.beam_charge/d.beam_mass;
         const Real min_z = d.lo[2] + islice*gm.dz;
         const Real dx_inv = 1.0/gm.dx, dy_inv = 1.0/gm.dy;
-        const int comp[5] = {Psi, Ez, Bx, By, Bz};
+        const bool pcs = d.bxby_solver != 0;      // This slice's fields in the predictor-corrector's component order
+        const int comp[5] = {pcs ? (int)pPsi : (int)Psi, pcs ? (int)pEz : (int)Ez, pcs ? (int)pBx : (int)Bx, pcs ? (int)pBy : (int)By, pcs ? (int)pBz : (int)Bz};
         const bool ext = (d.ext_E_slope[0] != 0.0 || d.ext_E_slope[1] != 0.0);
         for (size_t ip = 0; ip < b.x.size(); ++ip) {          // getNumParticlesIncludingSlipped (:131)
             if (!b.valid[ip]) continue;

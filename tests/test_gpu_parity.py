@@ -1322,8 +1322,6 @@ def test_laser_wake_with_ionization_matches_oracle(api, oracle, tile_size, solve
 def test_ionization_refusals(api):
     deck = decks.ionization_SI()
     with pytest.raises(RuntimeError):
-        api.SliceEngine(dict(deck, bxby_solver=1))                       # explicit solver only
-    with pytest.raises(RuntimeError):
         api.SliceEngine(dict(deck, ion_charge=deck["plasma_charge"]))    # product and ion charges must be opposite
     norm = decks.blowout_wake()
     decks.with_ion_species(norm, "H", 1.0)

@@ -592,9 +592,61 @@ def test_ion_motion_predictor_corrector_equals_explicit(api, oracle):
         if v != 0.0:
             assert abs(c2[k] - v) <= 1e-9 * abs(v), (k, c2[k], v)
     assert g2.pc_stats()[0] == o2.pc_stats()[0]
-    # a species that still has levels to lose is refused under this solver, loudly
-    with pytest.raises(RuntimeError, match="explicit solver"):
-        api.SliceEngine(decks.predictor_corrector(decks.ionization_SI()))
+
+
+@pytest.mark.parametrize("tile_size", [0, 16])
+def test_ionization_under_the_predictor_corrector_matches_oracle(api, oracle, tile_size):
+    """ADK ionisation with hipace.bxby_solver = predictor-corrector: the reference's ionisation deck (neutral hydrogen, a flat-top
+    driver) under the loop -- every species pushed to the temporary slice and deposited in turn, the decisions taken once per
+    slice ahead of the committing pushes (Hipace.cpp:693-701).  Fields, ion levels (by lattice index), the set of released
+    electrons and the counts equal the oracle's: two steps with the beam held (hipace.dt = 0), one with the deck's own
+    hipace.dt = 1e-12 (a second one enters the driver through a slice whose sum |B| sits under the engine's floor, where the
+    two paths leave the loop differently: INTEGRATION.md); atoms do ionise."""
+    from tests.test_gpu_parity import _compare_ion_run
+    deck = decks.predictor_corrector(decks.ionization_SI(), tol=1.0e-3, max_iter=5, mix=0.1)
+    assert deck["dt"] != 0.0
+    n = _compare_ion_run(api, oracle, dict(deck, dt=0.0), tile_size, 2, tol=1e-7)
+    assert n > 500
+    n = _compare_ion_run(api, oracle, deck, tile_size, 1, tol=1e-7)
+    assert n > 250
+
+
+def test_moving_beam_under_the_predictor_corrector(api, oracle):
+    """The beam's push under hipace.bxby_solver = predictor-corrector gathers This slice's fields where that solver's slab keeps
+    them (fields/Fields.cpp:128-164 against :70-122; the reference looks them up by name, BeamParticleAdvance.cpp:60-66).  The
+    blowout deck with hipace.dt = 6 under the loop: after the first step the fields and every beam particle equal the oracle's
+    to rounding; the beam has moved as under the explicit solver within the loop's (loose) convergence; a second step stays
+    with the oracle to 1e-4 (the head slice whose sum |B| sits under the engine's floor: one pass there against the serial
+    path's ten)."""
+    base = dict(decks.blowout_wake(), dt=6.0)
+    deck = decks.predictor_corrector(base, tol=1.0e-4, max_iter=10, mix=0.1)
+    nz = deck["nz"]
+    ge, oe, xe = api.SliceEngine(deck, tile_size=16), oracle.Engine(deck), api.SliceEngine(base, tile_size=16)
+    ge.set_diagnostics(True)
+    _, s0 = ge.beam_state()
+
+    def step():
+        ge.run_step()
+        oe.begin_step()
+        for k in range(nz - 1, -1, -1):
+            oe.solve_slice(k)
+        gc, oc = ge.checksums(), oe.checksums()
+        bg, sg = ge.beam_state()
+        so = np.concatenate([oe.beam_slice(nz - 1 - p) for p in range(nz)], axis=1)
+        assert so.shape == sg.shape                          # nobody slips in this deck
+        ferr = max(abs(gc[k] - v) / abs(v) for k, v in oc.items() if v)
+        berr = max(np.abs(sg[q] - so[q]).max() / np.abs(so[q]).max() for q in range(6))
+        return ferr, berr, sg
+
+    ferr, berr, sg = step()
+    assert ge.pc_stats()[0] == oe.pc_stats()[0]
+    assert ferr < 1e-10 and berr < 1e-10, (ferr, berr)
+    xe.run_step()
+    _, sx = xe.beam_state()
+    moved = np.abs(sx[3] - s0[3]).max()
+    assert moved > 1.0 and np.abs(sg[3] - sx[3]).max() < 0.1 * moved, (moved, np.abs(sg[3] - sx[3]).max())
+    ferr, berr, _ = step()
+    assert ferr < 1e-4 and berr < 1e-3, (ferr, berr)
 
 
 def test_finite_plasma_radius_matches_oracle(api, oracle):
