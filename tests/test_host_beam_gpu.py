@@ -649,6 +649,40 @@ def test_moving_beam_under_the_predictor_corrector(api, oracle):
     assert ferr < 1e-4 and berr < 1e-3, (ferr, berr)
 
 
+def test_moving_beam_under_the_predictor_corrector_serial_and_pipelined(api):
+    """the same deck with three time steps in flight on the device (the per-slice hand-off of the pushed beam between them) against
+    the serial run, five steps: every checksum of every step to 1e-10 (the loop's control is on the host with a moving beam: the
+    same decisions in both runs), the beam after the last step particle by particle"""
+    import torch
+    from hipace_amd.pipeline import run_lanes
+    deck = decks.predictor_corrector(dict(decks.blowout_wake(), dt=6.0), tol=1.0e-4, max_iter=10, mix=0.1)
+
+    def engine():
+        e = api.SliceEngine(deck, tile_size=16)
+        e.set_diagnostics(True)
+        return e
+
+    ser = engine()
+    want = []
+    for step in range(5):
+        ser.run_step()
+        want.append(ser.checksums())
+    bw, sw = ser.beam_state()
+    got, beams = {}, {}
+
+    def on_end(step, e):
+        got[step] = e.checksums()
+        beams[step] = e.beam_state()
+    run_lanes([engine() for _ in range(3)], 0, 1, 5, torch.device("cuda", 0), on_step_end=on_end)
+    assert sorted(got) == list(range(5))
+    for step in range(5):
+        for k, v in want[step].items():
+            assert abs(got[step][k] - v) <= 1e-10 * abs(v), (step, k, got[step][k], v)
+    assert want[4]["Bx"] != want[0]["Bx"]
+    bg, sg = beams[4]
+    assert np.array_equal(bg, bw) and np.abs(sg - sw).max() <= 1e-10 * np.abs(sw).max()
+
+
 def test_finite_plasma_radius_matches_oracle(api, oracle):
     """<plasma>.radius (PlasmaParticleContainerInit.cpp:262-266): no plasma particles beyond it -- the blowout deck with a plasma
     column of radius 5 in its 16-wide box, the slices through the driver against the oracle; particles do get left out."""
