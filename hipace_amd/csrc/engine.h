@@ -95,6 +95,8 @@ struct Engine {
     void* ps = nullptr;            // Poisson solver handle
     void* mg = nullptr;            // multigrid handle
     double* staging = nullptr;
+    double* d_open_mom = nullptr;      // boundary.field = Open: the multipole moments of up to four sources (Engine::open_boundary)
+    int open_boundary (int nbatch, unsigned no_monopole_mask);
     // driver beam: slice-major SoA (head slice first), static because hipace.dt = 0
     // blocks [slice p from the head][7][count_p]; beam_cur = storage in use (own or caller's)
     double* beam_data = nullptr; double* beam_init = nullptr; double* beam_cur = nullptr;

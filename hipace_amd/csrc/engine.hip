@@ -347,7 +347,7 @@ Engine::~Engine ()
     (void)hipFree(slab.p); (void)hipFree(pl_real); (void)hipFree(pl.idcpu); (void)hipFree(pl.ion_lev);
     delete tiling;
     (void)hipFree(pl_real_alt); (void)hipFree(pl_alt.idcpu); (void)hipFree(pl_alt.ion_lev); 
-    (void)hipFree(staging); (void)hipFree(beam_data); (void)hipFree(beam_init);
+    (void)hipFree(staging); (void)hipFree(d_open_mom); (void)hipFree(beam_data); (void)hipFree(beam_init);
     (void)hipFree(bm_store); (void)hipFree(bm_nsub); (void)hipFree(bm_nsub_scr); (void)hipFree(d_B); (void)hipFree(d_nfront);
     (void)hipFree(d_Bimp); (void)hipFree(d_beam_overflow); (void)hipFree(d_nqsa); (void)hipFree(d_checksum);
     (void)hipFree(d_pc); (void)hipFree(d_pc_aux); (void)hipFree(d_pc_go); if (h_pc) (void)hipHostFree(h_pc);
@@ -599,7 +599,13 @@ int Engine::create (const hps_deck& deck, int device)
     HPS_REQUIRE(d.order >= 0 && d.order <= 3, "hps_engine_create: depos_order must be 0..3");
     HPS_REQUIRE(d.n_subcycles >= 0, "hps_engine_create: plasma n_subcycles must be >= 1 (0 = default 1)");
     if (d.n_subcycles == 0) d.n_subcycles = 1;       // <plasma>.n_subcycles default (particles/plasma/PlasmaParticleContainer.H:182)
-    if (d.field_bc != 0) { set_error("hps_engine_create: only boundary.field = Dirichlet is built"); return HPS_ERR_UNSUPPORTED; }
+    if (d.field_bc != 0 && d.field_bc != 1) { set_error("hps_engine_create: boundary.field must be 0 (Dirichlet) or 1 (Open)"); return HPS_ERR_UNSUPPORTED; }
+    if (d.field_bc == 1) {
+        // (the expansion is about x = y = 0, which must lie inside the box: fields/Fields.cpp:703-705)
+        const double radius = std::min(std::min(std::fabs(d.lo[0]), std::fabs(d.hi[0])), std::min(std::fabs(d.lo[1]), std::fabs(d.hi[1])));
+        HPS_REQUIRE(radius > 0.0 && d.lo[0] < 0.0 && d.hi[0] > 0.0 && d.lo[1] < 0.0 && d.hi[1] > 0.0, "hps_engine_create: boundary.field = Open needs x = y = 0 inside the box");
+        HPS_HIP_CHECK(hipMalloc(&d_open_mom, (size_t)4*2*19*sizeof(double)));
+    }
     pc = (d.bxby_solver != 0);
     if (const char* v = std::getenv("HPS_GATED_PUSH")) gate_push = std::atoi(v) != 0;
     if (const char* v = std::getenv("HPS_AUX_STREAM")) aux_on = std::atoi(v) != 0;
@@ -724,7 +730,8 @@ int Engine::create (const hps_deck& deck, int device)
             pc_floor = rel*gm.mu0*gm.c*std::fabs(d.plasma_charge*d.plasma_density)*(double)d.nx*d.ny*(d.nx*gm.dx); }
         // HPS_PC_SPECULATE=0: the host decides after every iteration, as in rounds 1-3
         {   const char* v = std::getenv("HPS_PC_SPECULATE");
-            pc_speculate = !(v && std::atoi(v) == 0) && pc_max_iter <= PC_MAX_SPEC - 2 && poisson_gateable(ps); }
+            pc_speculate = !(v && std::atoi(v) == 0) && pc_max_iter <= PC_MAX_SPEC - 2 && poisson_gateable(ps)
+                           && d.field_bc == 0; }      // (the open boundary's two launches per solve are not gated: host-controlled loop)
         d_nfallback = reinterpret_cast<int*>(d_pc + 2); h_nfallback = reinterpret_cast<const int*>(h_pc + 4);
     }
     if (c_aabs >= 0) { if (int e = laser_create(*this)) return e; }
@@ -1306,6 +1313,89 @@ void k_pc_mix (double* p, long ns, long plane, const double* sums, double* err_s
     p[HPS_PC_N_JX*ns + s] = 0.0; p[HPS_PC_N_JY*ns + s] = 0.0;
 }
 
+// boundary.field = Open (Fields::SetBoundaryCondition, fields/Fields.cpp:678-735): the free-space Green's function
+// ln|r - r'|^2 / (4 pi) expanded to order 18 about the origin (fields/OpenBoundary.H: 37 real moments; here in complex form,
+// z = x + i y:  ln|z - z'|^2 = ln|z|^2 - sum_n (2/n) Re((z'/z)^n), so with M_n = sum_src s z'^n the potential outside the
+// sources is dx dy/(4 pi) [M_0 ln|z|^2 - sum_n (2/n) Re(M_n z^-n)]).  Coordinates scaled by 3/|diagonal|; sources beyond 95 % of
+// the distance to the nearest wall are left out.  k_multipole_moments: mom[b][2 n], mom[b][2 n + 1] += Re, Im M_n of plane b.
+constexpr int OPEN_ORDER = 18;
+__global__ __launch_bounds__(256)
+void k_multipole_moments (const double* __restrict__ staging, long nval, int nx, double dx, double dy, double xoff, double yoff,
+                          double scale, double cutoff_sq, double* mom)
+{
+    const double* s = staging + (long)blockIdx.y*nval;
+    double re[OPEN_ORDER + 1], im[OPEN_ORDER + 1];
+#pragma unroll
+    for (int n = 0; n <= OPEN_ORDER; ++n) { re[n] = 0.0; im[n] = 0.0; }
+    for (long c = (long)blockIdx.x*blockDim.x + threadIdx.x; c < nval; c += (long)gridDim.x*blockDim.x) {
+        const int j = (int)(c / nx), i = (int)(c - (long)j*nx);
+        const double x = (i*dx + xoff)*scale, y = (j*dy + yoff)*scale;
+        if (x*x + y*y > cutoff_sq) continue;
+        const double sv = s[c];
+        double zr = 1.0, zi = 0.0;
+#pragma unroll
+        for (int n = 0; n <= OPEN_ORDER; ++n) {
+            re[n] += sv*zr; im[n] += sv*zi;
+            const double t = zr*x - zi*y; zi = zr*y + zi*x; zr = t;
+        }
+    }
+    __shared__ double part[4][2*(OPEN_ORDER + 1)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n <= OPEN_ORDER; ++n) {
+        double a = re[n], b = im[n];
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
+        if (lane == 0) { part[wave][2*n] = a; part[wave][2*n + 1] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2*(OPEN_ORDER + 1)) {
+        const double v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (v != 0.0) atomic_add_f64(mom + (long)blockIdx.y*2*(OPEN_ORDER + 1) + threadIdx.x, v);
+    }
+}
+
+// SetDirichletBoundaries (fields/Fields.cpp:627-669) with offset = factor = 1: the outermost rows and columns of the source get
+// -phi(one cell outside)/h^2, corners from both sides.  One thread per boundary point: 2 nx + 2 ny of them per plane.
+__global__ __launch_bounds__(256)
+void k_open_boundary_apply (double* staging, long nval, int nx, int ny, double dx, double dy, double xoff, double yoff,
+                            double scale, double pref, const double* __restrict__ mom, unsigned no_monopole_mask)
+{
+    const int b = blockIdx.y;
+    const int t = blockIdx.x*blockDim.x + threadIdx.x;
+    if (t >= 2*nx + 2*ny) return;
+    double xd, yd, hh; long target;
+    if (t < nx)               { xd = t*dx + xoff;            yd = -dy + yoff;              hh = dy*dy; target = t; }
+    else if (t < 2*nx)        { xd = (t - nx)*dx + xoff;     yd = ny*dy + yoff;            hh = dy*dy; target = (long)(ny - 1)*nx + (t - nx); }
+    else if (t < 2*nx + ny)   { xd = -dx + xoff;             yd = (t - 2*nx)*dy + yoff;    hh = dx*dx; target = (long)(t - 2*nx)*nx; }
+    else                      { xd = nx*dx + xoff;           yd = (t - 2*nx - ny)*dy + yoff; hh = dx*dx; target = (long)(t - 2*nx - ny)*nx + (nx - 1); }
+    const double* M = mom + (long)b*2*(OPEN_ORDER + 1);
+    const double zx = xd*scale, zy = yd*scale, nrm = zx*zx + zy*zy;
+    const double ix = zx/nrm, iy = -zy/nrm;                   // 1/z
+    double v = ((no_monopole_mask >> b) & 1u) ? 0.0 : M[0]*log(nrm);
+    double pr = ix, pi_ = iy;
+    for (int n = 1; n <= OPEN_ORDER; ++n) {
+        v -= (2.0/n)*(M[2*n]*pr - M[2*n + 1]*pi_);
+        const double q = pr*ix - pi_*iy; pi_ = pr*iy + pi_*ix; pr = q;
+    }
+    atomic_add_f64(staging + (long)b*nval + target, -(pref*v)/hh);
+}
+
+int Engine::open_boundary (int nbatch, unsigned no_monopole_mask)
+{
+    if (d.field_bc != 1) return HPS_OK;
+    const long nval = (long)d.nx*d.ny;
+    const double Lx = d.hi[0] - d.lo[0], Ly = d.hi[1] - d.lo[1];
+    const double scale = 3.0/std::sqrt(Lx*Lx + Ly*Ly);
+    const double radius = std::min(std::min(std::fabs(d.lo[0]), std::fabs(d.hi[0])), std::min(std::fabs(d.lo[1]), std::fabs(d.hi[1])));
+    const double cutoff_sq = (0.95*radius*scale)*(0.95*radius*scale);
+    HPS_HIP_CHECK(hipMemsetAsync(d_open_mom, 0, (size_t)nbatch*2*(OPEN_ORDER + 1)*sizeof(double), st));
+    hipLaunchKernelGGL(k_multipole_moments, dim3(256, nbatch), dim3(256), 0, st, staging, nval, d.nx, gm.dx, gm.dy, gm.xoff, gm.yoff,
+                       scale, cutoff_sq, d_open_mom);
+    hipLaunchKernelGGL(k_open_boundary_apply, dim3(ceil_div(2*d.nx + 2*d.ny, 256), nbatch), dim3(256), 0, st, staging, nval, d.nx, d.ny,
+                       gm.dx, gm.dy, gm.xoff, gm.yoff, scale, gm.dx*gm.dy/(4.0*3.14159265358979323846), d_open_mom, no_monopole_mask);
+    return HPS_OK;
+}
+
 // SolveOneSlice with hipace.bxby_solver = predictor-corrector (Hipace.cpp:556-728; the explicit branch is
 // Engine::solve_slice below).  Event marks keep the 10 intervals of the explicit schedule: the loop is booked under
 // the Bx/By-solve interval.
@@ -1350,6 +1440,7 @@ int Engine::solve_slice_pc_begin (int islice)
                            fa*0.5*(1.0/gm.dx), fa*0.5*(1.0/gm.dy), gm.mu0*0.5*(1.0/gm.dy), -gm.mu0*0.5*(1.0/gm.dx),
                            staging, nval);
         const int comps[3] = {HPS_PC_PSI, HPS_PC_EZ, HPS_PC_BZ};
+        if ((e = open_boundary(3, 0x6u))) return e;      // (Ez, Bz: no physical monopole, fields/Fields.cpp:727-731)
         if ((e = hps_poisson_solve_batch(ps, 3, staging, slab, comps, st))) return e; }
     hipLaunchKernelGGL(k_grad_psi, dim3(ceil_div(d.nx + 2*(g - 1), 256), d.ny + 2*(g - 1)), b256, 0, st, f, HPS_PC_PSI,
                        HPS_PC_EXMBY, HPS_PC_EYPBX, 0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy));
@@ -1424,6 +1515,7 @@ int Engine::pc_enqueue_iteration (int it)
     hipLaunchKernelGGL(k_rhs_bxby, dim3(ceil_div(d.nx, 256), d.ny), b256, 0, st, f, gm.mu0, 0.5*(1.0/gm.dx), 0.5*(1.0/gm.dy),
                        0.5*(1.0/gm.dz), staging, nval, d_pc, (const int*)go);
     {   const int comps[2] = {HPS_PC_IT_BX, HPS_PC_IT_BY};
+        if ((e = open_boundary(2, 0u))) return e;
         poisson_set_gate(ps, go);
         e = hps_poisson_solve_batch(ps, 2, staging, slab, comps, st);
         poisson_set_gate(ps, nullptr);
@@ -1637,7 +1729,7 @@ int Engine::solve_slice_begin (int islice)
     {   const double fa = 1.0/(gm.ep0*gm.c);
         const double fez_x = fa*0.5*(1.0/gm.dx), fez_y = fa*0.5*(1.0/gm.dy), fbz_y = gm.mu0*0.5*(1.0/gm.dy), fbz_x = -gm.mu0*0.5*(1.0/gm.dx);
         const int comps[3] = {HPS_C_PSI, HPS_C_EZ, HPS_C_BZ};
-        if (fuse_sources && poisson_sources_fusable(ps)) {
+        if (fuse_sources && poisson_sources_fusable(ps) && d.field_bc == 0) {
             // the three sources (fields/Fields.cpp:887-912) are formed by the first transform pass while it loads its rows:
             // -rhomjz/ep0;  (d_x jx + d_y jy)/(ep0 c);  mu0 (d_y jx - d_x jy) -- centred differences, guard cells read as they are
             const long js = slab.jstride;
@@ -1653,6 +1745,7 @@ int Engine::solve_slice_begin (int islice)
             hipLaunchKernelGGL(k_rhs_all, dim3(ceil_div(slab.jstride, 256), d.ny + 2*g), b256, 0, st, f, HPS_C_RHOMJZ,
                                -1 /* AddRhoIons: done by the slice's zeroing pass */, d.deposit_rho ? HPS_C_RHO : -1, HPS_C_JX, HPS_C_JY, 1.0/gm.ep0,
                                fez_x, fez_y, fbz_y, fbz_x, staging, (long)d.nx*d.ny);
+            if ((e = open_boundary(3, 0x6u))) return e;
             if ((e = hps_poisson_solve_batch(ps, 3, staging, slab, comps, st))) return e;
         } }
     // m_multi_laser.AdvanceSlice (Hipace.cpp:637): a_{n+1} of this slice from chi and the neighbouring slices

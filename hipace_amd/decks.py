@@ -42,7 +42,7 @@ _DEFAULT = dict(
     predcorr_tol=4.0e-2,     # hipace.predcorr_B_error_tolerance (Hipace.H:210)
     predcorr_max_iter=30,    # hipace.predcorr_max_iterations (Hipace.H:213)
     predcorr_mix=0.05,       # hipace.predcorr_B_mixing_factor (Hipace.H:222)
-    field_bc=0,              # boundary.field: 0 Dirichlet; 1 Open exists in the CPU oracle only (the engine refuses it)
+    field_bc=0,              # boundary.field: 0 Dirichlet; 1 Open (multipole expansion of the sources to order 18, fields/Fields.cpp:678-735)
     laser_on=0,              # lasers.names != no_laser: a Gaussian envelope (laser/Laser.H:32-45), static (step 0 only)
     laser_a0=0.0, laser_w0=1.0, laser_L0=1.0, laser_lambda0=0.8e-6, laser_pos=(0.0, 0.0, 0.0),
     laser_zfoc=0.0,          # laser.focal_distance

@@ -201,7 +201,9 @@ typedef struct {
     double dt; int beam_n_subcycles; double beam_mass; double ext_E_slope[2];
     /* hipace.bxby_solver: 0 explicit (Hipace.H:244), 1 predictor-corrector (Hipace.cpp:935-1031) with
      * hipace.predcorr_B_error_tolerance (0 -> 4e-2), predcorr_max_iterations (0 -> 30), predcorr_B_mixing_factor
-     * (0 -> 0.05) (Hipace.H:210-222).  field_bc: boundary.field, 0 Dirichlet; anything else is refused. */
+     * (0 -> 0.05) (Hipace.H:210-222).  field_bc: boundary.field, 0 Dirichlet, 1 Open (Fields::SetBoundaryCondition,
+     * fields/Fields.cpp:678-735: Psi, Ez, Bz -- and Bx, By of the predictor-corrector loop -- solved with the free-space potential
+     * of the sources, expanded to order 18 about x = y = 0, as Dirichlet values; x = y = 0 must lie inside the box). */
     int bxby_solver; double predcorr_tol; int predcorr_max_iter; double predcorr_mix; int field_bc;
     /* a Gaussian laser envelope (laser/Laser.H:32-45; CEP 0, no propagation angle) drives the wake:
      * |a|^2 goes into the slab component "aabs" (appended last) and enters the deposition, the explicit source and the
