@@ -718,8 +718,8 @@ def main():
         traffic, traffic_source = pmc_traffic("void hps::k_deposit_tiled<2, 16, 51") if headline else (None, None)
         out = {
             "metric": "transverse slices/s at 256^2 x 4ppc (predictor-corrector solver)" if args.config2 else
-                      f"transverse slices/s at 1024^2 x 4ppc with a laser envelope (explicit solver, {args.laser_solver} envelope solver)" if args.config5 else
-                      "transverse slices/s at 1024^2 x 4ppc (explicit solver)",
+                      f"transverse slices/s at {args.n}^2 x 4ppc with a laser envelope (explicit solver, {args.laser_solver} envelope solver)" if args.config5 else
+                      f"transverse slices/s at {args.n}^2 x {args.ppc * args.ppc}ppc (explicit solver)",
             "value": total / dt, "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
