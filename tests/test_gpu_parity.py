@@ -679,6 +679,32 @@ def test_open_field_boundary_slice_by_slice_vs_oracle(api, oracle, solver, tile_
         assert ge.stats()["vcycles"] == oe.vcycles()
 
 
+@pytest.mark.gpu
+def test_open_field_boundary_serial_and_pipelined(api):
+    """open walls with three time steps in flight on the device (every engine has its own moments buffer and staging planes):
+    the checksums of every step equal the serial run's"""
+    import torch
+    from hipace_amd.pipeline import run_lanes
+    deck = dict(decks.blowout_wake(), nz=40, lo=(-4.0, -4.0, 1.2), hi=(4.0, 4.0, 6.0), beam_pos_mean=(0.6, -0.4, 0.0), field_bc=1, n_steps=4)
+
+    def engine():
+        e = api.SliceEngine(deck, tile_size=16)
+        e.set_diagnostics(True)
+        return e
+
+    ser = engine()
+    want = []
+    for _ in range(4):
+        ser.run_step()
+        want.append(ser.checksums())
+    got = {}
+    run_lanes([engine() for _ in range(3)], 0, 1, 4, torch.device("cuda", 0), on_step_end=lambda step, e: got.__setitem__(step, e.checksums()))
+    assert sorted(got) == [0, 1, 2, 3]
+    for step in range(4):
+        for k, v in want[step].items():
+            assert abs(got[step][k] - v) <= 1e-10 * abs(v), (step, k, got[step][k], v)
+
+
 # ---- beam particles -> slices (SURVEY 8a row a19; integer work: bit-exact) ---------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,num_boxes", [(0, 8), (1, 1), (1000, 7), (200000, 1024), (65537, 100)])
