@@ -604,7 +604,7 @@ int Engine::create (const hps_deck& deck, int device)
         // (the expansion is about x = y = 0, which must lie inside the box: fields/Fields.cpp:703-705)
         const double radius = std::min(std::min(std::fabs(d.lo[0]), std::fabs(d.hi[0])), std::min(std::fabs(d.lo[1]), std::fabs(d.hi[1])));
         HPS_REQUIRE(radius > 0.0 && d.lo[0] < 0.0 && d.hi[0] > 0.0 && d.lo[1] < 0.0 && d.hi[1] > 0.0, "hps_engine_create: boundary.field = Open needs x = y = 0 inside the box");
-        HPS_HIP_CHECK(hipMalloc(&d_open_mom, (size_t)4*2*19*sizeof(double)));
+        HPS_HIP_CHECK(hipMalloc(&d_open_mom, (size_t)4*256*2*19*sizeof(double)));      // [source][OPEN_PARTS][2 (OPEN_ORDER + 1)]
     }
     pc = (d.bxby_solver != 0);
     if (const char* v = std::getenv("HPS_GATED_PUSH")) gate_push = std::atoi(v) != 0;
@@ -1317,8 +1317,9 @@ void k_pc_mix (double* p, long ns, long plane, const double* sums, double* err_s
 // ln|r - r'|^2 / (4 pi) expanded to order 18 about the origin (fields/OpenBoundary.H: 37 real moments; here in complex form,
 // z = x + i y:  ln|z - z'|^2 = ln|z|^2 - sum_n (2/n) Re((z'/z)^n), so with M_n = sum_src s z'^n the potential outside the
 // sources is dx dy/(4 pi) [M_0 ln|z|^2 - sum_n (2/n) Re(M_n z^-n)]).  Coordinates scaled by 3/|diagonal|; sources beyond 95 % of
-// the distance to the nearest wall are left out.  k_multipole_moments: mom[b][2 n], mom[b][2 n + 1] += Re, Im M_n of plane b.
-constexpr int OPEN_ORDER = 18;
+// the distance to the nearest wall are left out.  k_multipole_moments: mom[b][workgroup][2 n], [2 n + 1] = that workgroup's share of
+// Re, Im M_n of plane b.
+constexpr int OPEN_ORDER = 18, OPEN_PARTS = 256;      // order of the expansion; workgroups (= partial sums) per source
 __global__ __launch_bounds__(256)
 void k_multipole_moments (const double* __restrict__ staging, long nval, int nx, double dx, double dy, double xoff, double yoff,
                           double scale, double cutoff_sq, double* mom)
@@ -1327,30 +1328,45 @@ void k_multipole_moments (const double* __restrict__ staging, long nval, int nx,
     double re[OPEN_ORDER + 1], im[OPEN_ORDER + 1];
 #pragma unroll
     for (int n = 0; n <= OPEN_ORDER; ++n) { re[n] = 0.0; im[n] = 0.0; }
-    for (long c = (long)blockIdx.x*blockDim.x + threadIdx.x; c < nval; c += (long)gridDim.x*blockDim.x) {
-        const int j = (int)(c / nx), i = (int)(c - (long)j*nx);
-        const double x = (i*dx + xoff)*scale, y = (j*dy + yoff)*scale;
-        if (x*x + y*y > cutoff_sq) continue;
-        const double sv = s[c];
-        double zr = 1.0, zi = 0.0;
+    // (eight loads in flight per thread: with two or three waves per SIMD one load per trip leaves the memory latency bare)
+    const long stride = (long)gridDim.x*blockDim.x;
+    for (long c0 = (long)blockIdx.x*blockDim.x + threadIdx.x; c0 < nval; c0 += 8*stride) {
+        double sv8[8];
 #pragma unroll
-        for (int n = 0; n <= OPEN_ORDER; ++n) {
-            re[n] += sv*zr; im[n] += sv*zi;
-            const double t = zr*x - zi*y; zi = zr*y + zi*x; zr = t;
+        for (int u = 0; u < 8; ++u) { const long c = c0 + u*stride; sv8[u] = c < nval ? s[c] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long c = c0 + u*stride;
+            if (c >= nval) break;
+            const int j = (int)(c / nx), i = (int)(c - (long)j*nx);
+            const double x = (i*dx + xoff)*scale, y = (j*dy + yoff)*scale;
+            if (x*x + y*y > cutoff_sq) continue;
+            const double sv = sv8[u];
+            double zr = 1.0, zi = 0.0;
+#pragma unroll
+            for (int n = 0; n <= OPEN_ORDER; ++n) {
+                re[n] += sv*zr; im[n] += sv*zi;
+                const double t = zr*x - zi*y; zi = zr*y + zi*x; zr = t;
+            }
         }
     }
-    __shared__ double part[4][2*(OPEN_ORDER + 1)];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the workgroup's sum through LDS (38 values x 256 threads; 38 x 6 wave-shuffle steps of doubles took longer than the pass):
+    // six threads per value add 43 entries each, one of them the six
+    constexpr int NM = 2*(OPEN_ORDER + 1), LD = 257;
+    __shared__ double part[NM*LD];
 #pragma unroll
-    for (int n = 0; n <= OPEN_ORDER; ++n) {
-        double a = re[n], b = im[n];
-        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
-        if (lane == 0) { part[wave][2*n] = a; part[wave][2*n + 1] = b; }
-    }
+    for (int n = 0; n <= OPEN_ORDER; ++n) { part[(2*n)*LD + threadIdx.x] = re[n]; part[(2*n + 1)*LD + threadIdx.x] = im[n]; }
     __syncthreads();
-    if (threadIdx.x < 2*(OPEN_ORDER + 1)) {
-        const double v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-        if (v != 0.0) atomic_add_f64(mom + (long)blockIdx.y*2*(OPEN_ORDER + 1) + threadIdx.x, v);
+    const int v = threadIdx.x / 6, q = threadIdx.x - 6*v;
+    double a = 0.0;
+    if (v < NM) for (int k = q; k < 256; k += 6) a += part[v*LD + k];
+    __syncthreads();
+    if (v < NM) part[v*LD + q] = a;
+    __syncthreads();
+    // (one partial sum per workgroup, added up by the consumer in a fixed order)
+    if (threadIdx.x < NM) {
+        const double* r = part + threadIdx.x*LD;
+        mom[((long)blockIdx.y*gridDim.x + blockIdx.x)*NM + threadIdx.x] = ((r[0] + r[1]) + (r[2] + r[3])) + (r[4] + r[5]);
     }
 }
 
@@ -1358,9 +1374,23 @@ void k_multipole_moments (const double* __restrict__ staging, long nval, int nx,
 // -phi(one cell outside)/h^2, corners from both sides.  One thread per boundary point: 2 nx + 2 ny of them per plane.
 __global__ __launch_bounds__(256)
 void k_open_boundary_apply (double* staging, long nval, int nx, int ny, double dx, double dy, double xoff, double yoff,
-                            double scale, double pref, const double* __restrict__ mom, unsigned no_monopole_mask)
+                            double scale, double pref, const double* __restrict__ mom, int nparts, unsigned no_monopole_mask)
 {
     const int b = blockIdx.y;
+    constexpr int NM = 2*(OPEN_ORDER + 1);
+    __shared__ double Msh[6][NM];
+    {   // the workgroups' partial moments, in a fixed order
+        const int v = threadIdx.x % NM, q = threadIdx.x / NM;
+        if (q < 6) {
+            double a = 0.0;
+            for (int k = q; k < nparts; k += 6) a += mom[((long)b*nparts + k)*NM + v];
+            Msh[q][v] = a;
+        }
+        __syncthreads();
+        if (threadIdx.x < NM) Msh[0][threadIdx.x] = ((Msh[0][threadIdx.x] + Msh[1][threadIdx.x]) + (Msh[2][threadIdx.x] + Msh[3][threadIdx.x]))
+                                                    + (Msh[4][threadIdx.x] + Msh[5][threadIdx.x]);
+        __syncthreads();
+    }
     const int t = blockIdx.x*blockDim.x + threadIdx.x;
     if (t >= 2*nx + 2*ny) return;
     double xd, yd, hh; long target;
@@ -1368,7 +1398,7 @@ void k_open_boundary_apply (double* staging, long nval, int nx, int ny, double d
     else if (t < 2*nx)        { xd = (t - nx)*dx + xoff;     yd = ny*dy + yoff;            hh = dy*dy; target = (long)(ny - 1)*nx + (t - nx); }
     else if (t < 2*nx + ny)   { xd = -dx + xoff;             yd = (t - 2*nx)*dy + yoff;    hh = dx*dx; target = (long)(t - 2*nx)*nx; }
     else                      { xd = nx*dx + xoff;           yd = (t - 2*nx - ny)*dy + yoff; hh = dx*dx; target = (long)(t - 2*nx - ny)*nx + (nx - 1); }
-    const double* M = mom + (long)b*2*(OPEN_ORDER + 1);
+    const double* M = Msh[0];
     const double zx = xd*scale, zy = yd*scale, nrm = zx*zx + zy*zy;
     const double ix = zx/nrm, iy = -zy/nrm;                   // 1/z
     double v = ((no_monopole_mask >> b) & 1u) ? 0.0 : M[0]*log(nrm);
@@ -1388,11 +1418,10 @@ int Engine::open_boundary (int nbatch, unsigned no_monopole_mask)
     const double scale = 3.0/std::sqrt(Lx*Lx + Ly*Ly);
     const double radius = std::min(std::min(std::fabs(d.lo[0]), std::fabs(d.hi[0])), std::min(std::fabs(d.lo[1]), std::fabs(d.hi[1])));
     const double cutoff_sq = (0.95*radius*scale)*(0.95*radius*scale);
-    HPS_HIP_CHECK(hipMemsetAsync(d_open_mom, 0, (size_t)nbatch*2*(OPEN_ORDER + 1)*sizeof(double), st));
-    hipLaunchKernelGGL(k_multipole_moments, dim3(256, nbatch), dim3(256), 0, st, staging, nval, d.nx, gm.dx, gm.dy, gm.xoff, gm.yoff,
+    hipLaunchKernelGGL(k_multipole_moments, dim3(OPEN_PARTS, nbatch), dim3(256), 0, st, staging, nval, d.nx, gm.dx, gm.dy, gm.xoff, gm.yoff,
                        scale, cutoff_sq, d_open_mom);
     hipLaunchKernelGGL(k_open_boundary_apply, dim3(ceil_div(2*d.nx + 2*d.ny, 256), nbatch), dim3(256), 0, st, staging, nval, d.nx, d.ny,
-                       gm.dx, gm.dy, gm.xoff, gm.yoff, scale, gm.dx*gm.dy/(4.0*3.14159265358979323846), d_open_mom, no_monopole_mask);
+                       gm.dx, gm.dy, gm.xoff, gm.yoff, scale, gm.dx*gm.dy/(4.0*3.14159265358979323846), d_open_mom, OPEN_PARTS, no_monopole_mask);
     return HPS_OK;
 }
 
