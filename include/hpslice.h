@@ -232,7 +232,8 @@ typedef struct {
      * the particle's ion_lev), ion_energies: the element's ionisation energies in eV (NIST; the reference tabulates them in
      * utils/IonizationEnergiesTable.H), ion_Z of them.  In normalised units background_density_SI must be set.
      * ion_seed: key of the counter-based random number generator (one draw per ion, slice and step; the reference draws
-     * from amrex::Random, whose sequence is not reproducible).  Explicit solver only. */
+     * from amrex::Random, whose sequence is not reproducible).  Both Bx/By solvers: under the predictor-corrector loop the
+     * decisions are taken once per slice on the loop's final fields, ahead of the committing pushes (Hipace.cpp:693-701). */
     int plasma_no_neutralize;
     int ion_on; int ion_ppc[2]; double ion_density, ion_mass, ion_charge; int ion_init_level, ion_Z;
     double ion_energies[HPS_MAX_ION_LEVELS]; unsigned long long ion_seed;
