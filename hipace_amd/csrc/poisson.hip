@@ -1335,6 +1335,102 @@ void k_transpose (const double* __restrict__ src, double* __restrict__ dst, int 
 }
 
 // =================================================================================================
+// y direction as tridiagonal solves (round 6; HPS_POISSON_TRIDIAG, default on)
+// After the DST along x every x mode k is an independent system along y,
+//        u[j-1] + b_k u[j] + u[j+1] = dy^2 f[j],    b_k = -2 - 4 sin^2(pi (k+1) / (2 (nx+1))) dy^2/dx^2,   u[-1] = u[ny] = 0
+// -- the 5-point operator whose eigenvalues FFTPoissonSolverDirichletDirect.cpp:58-83 divides by, so DST_y . 1/eig . DST_y is
+// exactly this solve, and two of the four transform passes of a solve (and both transposes / the blocked planes) are gone.
+// The matrix is constant, so its LU factors c'_j(k) = 1/(b_k - c'_{j-1}) are a table made once (hps_poisson_create):
+//        forward   d_j = c'_j (alpha f_j - d_{j-1}),     backward   u_j = d_j - c'_j u_{j+1},     alpha = dy^2 / (2 (nx+1))
+// (alpha carries the normalisation of the two x transforms).  Work split: a thread owns M consecutive rows of one column
+// (registers), a workgroup COLS columns x all segments, so for a fixed row the lanes read COLS consecutive doubles of a
+// row-major plane -- whole 128-byte lines for COLS = 16, no LDS staging of the data.  Both sweeps are first-order linear
+// recurrences: a thread runs its segment with zero inflow, the (multiplier, value) pairs of the segments are chained through
+// LDS by one lane per column (nseg <= 64 dependent FMAs), and the inflow's multiple is added back -- |c'| < 1, every
+// multiplier is a product of them, so nothing grows.
+// =================================================================================================
+struct TriArgs {
+    double* plane[DST_MAXPLANES]; long pitch;        // row-major [j][k] planes, solved in place
+    const double* cp;                                // [ny][nx] LU factors c'_j(k)
+    double alpha;
+    int nx, ny, nseg;
+    const int* gate;
+};
+
+template <int M, int COLS>
+__global__ __launch_bounds__(COLS*64)
+void k_tridiag_y (TriArgs a)
+{
+    if (a.gate && *a.gate == 0) return;
+    __shared__ double sA[64][COLS], sB[64][COLS], sD[64][COLS];
+    const int tid = threadIdx.x, kk = tid % COLS, s = tid / COLS;
+    const int k = blockIdx.x*COLS + kk, kc = min(k, a.nx - 1);
+    double* __restrict__ p = a.plane[blockIdx.y];
+    const int j0 = s*M;
+    double e[M], c[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const int jc = min(j0 + i, a.ny - 1);
+        e[i] = p[(long)jc*a.pitch + kc];
+        c[i] = a.cp[(long)jc*a.nx + kc];
+    }
+    // rows past the plane: identity rows (c' = 0, f = 0)
+#pragma unroll
+    for (int i = 0; i < M; ++i) if (j0 + i >= a.ny) { e[i] = 0.0; c[i] = 0.0; }
+    // forward sweep of the segment, zero inflow
+    {
+        double d = 0.0, pm = 1.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) { d = c[i]*fma(a.alpha, e[i], -d); e[i] = d; pm *= -c[i]; }
+        sA[s][kk] = pm; sB[s][kk] = d;
+    }
+    __syncthreads();
+    if (tid < COLS) {
+        double D = 0.0;
+        for (int q = 0; q < a.nseg; ++q) { const double A = sA[q][kk], B = sB[q][kk]; sD[q][kk] = D; D = fma(A, D, B); }
+    }
+    __syncthreads();
+    // true d_j = e_j + (prod_{q <= j} -c'_q) D; backward sweep of the segment, zero inflow
+    {
+        const double D = sD[s][kk];
+        double pm = 1.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) { pm *= -c[i]; e[i] = fma(pm, D, e[i]); }
+        double h = 0.0, qm = 1.0;
+#pragma unroll
+        for (int i = M - 1; i >= 0; --i) { h = fma(-c[i], h, e[i]); e[i] = h; qm *= -c[i]; }
+        sA[s][kk] = qm; sB[s][kk] = h;         // (the forward chain's reads of sA / sB lie behind the barrier above)
+    }
+    __syncthreads();
+    if (tid < COLS) {
+        double U = 0.0;
+        for (int q = a.nseg - 1; q >= 0; --q) { const double A = sA[q][kk], B = sB[q][kk]; sD[q][kk] = U; U = fma(A, U, B); }
+    }
+    __syncthreads();
+    {
+        const double U = sD[s][kk];
+        double qm = 1.0;
+#pragma unroll
+        for (int i = M - 1; i >= 0; --i) { qm *= -c[i]; e[i] = fma(qm, U, e[i]); }
+    }
+    if (k < a.nx) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) if (j0 + i < a.ny) p[(long)(j0 + i)*a.pitch + k] = e[i];
+    }
+}
+typedef void (*tri_kernel_t)(TriArgs);
+struct TriImpl { int M, cols; tri_kernel_t kernel; };
+// rows per thread by plane height: at most 64 segments per column
+static TriImpl find_tri_impl (int ny)
+{
+    if (ny <= 256) return TriImpl{4, 16, k_tridiag_y<4, 16>};
+    if (ny <= 512) return TriImpl{8, 16, k_tridiag_y<8, 16>};
+    if (ny <= 1024) return TriImpl{16, 16, k_tridiag_y<16, 16>};
+    if (ny <= 2048) return TriImpl{32, 8, k_tridiag_y<32, 8>};
+    return TriImpl{0, 0, nullptr};
+}
+
+// =================================================================================================
 // dense back-end: n + 1 without a built factorisation (prime 257 of the 256^2 decks, ...), n <= 512.
 // DST-I as a matrix product with S[j][k] = 2 sin(pi (j+1)(k+1)/(n+1)) (FFTW's RODFT00 scaling, as the row kernels):
 // x direction X.S_x, y direction S_y.X -- four products per solve, no transposes.  One workgroup per 32 x 32 tile of
@@ -1567,6 +1663,9 @@ struct Poisson {
     const double2 *fa_x = nullptr, *fb_x = nullptr, *tw_x = nullptr, *fa_y = nullptr, *fb_y = nullptr, *tw_y = nullptr;
     double *buf_a = nullptr, *buf_b = nullptr;         // [DST_MAXPLANES][nx*ny] ping-pong
     double *S_x = nullptr, *S_y = nullptr;             // dense back-end: [n][n] sine matrices (S_y = S_x if nx == ny)
+    // y direction as tridiagonal solves (k_tridiag_y; HPS_POISSON_TRIDIAG=0: off): needs a transform along x only
+    tri_kernel_t ktri = nullptr; int tri_M = 0, tri_cols = 0; double* tri_cp = nullptr; double tri_alpha = 0.0;
+    bool tri () const { return ktri != nullptr; }
     long long* dbg = nullptr;
     const int* gate = nullptr;          // poisson_set_gate: the launches of the following solves return at once when *gate == 0
     bool gate_ok = false;               // every kernel of the own back-end as configured looks at the gate (the transposes only touch scratch)
@@ -1580,7 +1679,7 @@ struct Poisson {
     // shared
     double* eig = nullptr; double* isin_x = nullptr; double* isin_y = nullptr;
 
-    bool own () const { return kx && ky; }
+    bool own () const { return kx && (ky || ktri); }
     bool dense () const { return S_x != nullptr; }
     ~Poisson () {
         if (plan_x) rocfft_plan_destroy(plan_x);
@@ -1588,7 +1687,7 @@ struct Poisson {
         if (info) rocfft_execution_info_destroy(info);
         (void)hipFree(work); (void)hipFree(zbuf); (void)hipFree(rbuf); (void)hipFree(eig);
         (void)hipFree(isin_x); (void)hipFree(isin_y); (void)hipFree(tab_x); (void)hipFree(tab_y); (void)hipFree(mtab_x); (void)hipFree(mtab_y);
-        (void)hipFree(buf_a); (void)hipFree(buf_b);
+        (void)hipFree(buf_a); (void)hipFree(buf_b); (void)hipFree(tri_cp);
         if (S_y != S_x) (void)hipFree(S_y);
         (void)hipFree(S_x);
     }
@@ -1670,6 +1769,39 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
     const int Nx = nx + 1, Ny = ny + 1;
     const DstImpl* ix = allow_own ? find_dst_impl(Nx) : nullptr;
     const DstImpl* iy = allow_own ? find_dst_impl(Ny) : nullptr;
+    // the y direction as tridiagonal solves wherever a transform along x exists (own kernels or the dense product)
+    const TriImpl ti = find_tri_impl(ny);
+    const bool want_tri = [&] { const char* v = getenv("HPS_POISSON_TRIDIAG");
+                                return allow_own && ti.kernel && !(v && atoi(v) == 0) && !getenv("HPS_POISSON_MFMA") && !getenv("HPS_POISSON_COLS"); }();
+    auto make_tri = [&] () -> int {
+        // LU factors of tridiag(1, b_k, 1) in extended precision, rounded once: c'_0 = 1/b, c'_j = 1/(b - c'_{j-1})
+        std::vector<double> h((size_t)nx*ny);
+        const long double pi = 3.14159265358979323846264338327950288L;
+        for (int k = 0; k < nx; ++k) {
+            const long double sk = sinl(pi*(k + 1)/(2.0L*(nx + 1)));
+            const long double b = -2.0L - 4.0L*sk*sk*((long double)dy*dy)/((long double)dx*dx);
+            long double cprev = 0.0L;
+            for (int j = 0; j < ny; ++j) { cprev = 1.0L/(b - cprev); h[(size_t)j*nx + k] = (double)cprev; }
+        }
+        HPS_HIP_CHECK(hipMalloc(&P->tri_cp, h.size()*sizeof(double)));
+        HPS_HIP_CHECK(hipMemcpy(P->tri_cp, h.data(), h.size()*sizeof(double), hipMemcpyHostToDevice));
+        P->ktri = ti.kernel; P->tri_M = ti.M; P->tri_cols = ti.cols;
+        P->tri_alpha = dy*dy/(2.0*(nx + 1));
+        return HPS_OK;
+    };
+    if (ix && want_tri) {
+        P->kx = ix->kernel; P->kx_src = ix->src;
+        int e;
+        size_t nax, nbx;
+        if ((e = upload_tables(ix->N1, ix->N2, ix->sym, &P->tab_x, &nax, &nbx, ix->pow2)) || (e = make_tri())) { delete P; return e; }
+        P->fa_x = P->tab_x; P->fb_x = P->fa_x + nax; P->tw_x = P->fb_x + nbx;
+        P->tx = ix->T; P->ntx = ix->nt;
+        P->gate_ok = true;
+        P->lds_x = ((size_t)ix->T*Nx + nax + nbx + (ix->pow2 ? Nx : 0))*sizeof(double2);
+        for (dst_kernel_t kf : {P->kx, P->kx_src})
+            if (kf && P->lds_x > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_x));
+        HPS_HIP_CHECK(hipMalloc(&P->buf_a, ((size_t)DST_MAXPLANES*nx*ny + 64)*sizeof(double)));
+    } else
     if (ix && iy) {
         P->kx = ix->kernel; P->ky = iy->kernel; P->kx_src = ix->src;
         {   const char* v = getenv("HPS_POISSON_Y2"); P->ky2 = (v && atoi(v) == 0) ? nullptr : iy->twice; }
@@ -1737,6 +1869,7 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
         else if (int e = sines(ny, &P->S_y)) { delete P; return e; }
         HPS_HIP_CHECK(hipMalloc(&P->buf_a, (size_t)DST_MAXPLANES*nx*ny*sizeof(double)));
         HPS_HIP_CHECK(hipMalloc(&P->buf_b, (size_t)DST_MAXPLANES*nx*ny*sizeof(double)));
+        if (want_tri) { if (int e = make_tri()) { delete P; return e; } }
     } else {
         P->kx = P->ky = nullptr;
         if (!g_rocfft_setup) { rocfft_setup(); g_rocfft_setup = true; }
@@ -1858,6 +1991,14 @@ int poisson_solve_batch_src (void* handle, int nb, const PoissonSrc* spec, long 
     for (int b = 0; b < nb; ++b) d[b] = slab_cell00(dst, dst_comps[b]);
     return poisson_solve_batch_impl(P, nb, nullptr, src_pitch, d, dst.jstride, spec, st);
 }
+static void launch_tri (Poisson* P, int nb, hipStream_t st)
+{
+    TriArgs t{};
+    for (int b = 0; b < nb; ++b) t.plane[b] = P->buf_a + (long)b*P->nx*P->ny;
+    t.pitch = P->nx; t.cp = P->tri_cp; t.alpha = P->tri_alpha; t.nx = P->nx; t.ny = P->ny;
+    t.nseg = ceil_div(P->ny, P->tri_M); t.gate = P->gate;
+    hipLaunchKernelGGL(P->ktri, dim3(ceil_div(P->nx, P->tri_cols), nb), dim3(P->tri_cols*t.nseg), 0, st, t);
+}
 static int poisson_solve_batch_impl (Poisson* P, int nb, const double* const* src, long src_pitch, double* const* dst, long dst_pitch,
                                      const PoissonSrc* spec, hipStream_t st)
 {
@@ -1873,6 +2014,15 @@ static int poisson_solve_batch_impl (Poisson* P, int nb, const double* const* sr
         for (int b = 0; b < nb; ++b) { g.A[b] = src[b]; g.B[b] = P->S_x; g.C[b] = P->buf_a + b*plane; }
         g.lda = src_pitch; g.ldb = nx; g.ldc = nx; g.K = nx; g.scale = nullptr;
         hipLaunchKernelGGL(k_dense_product, grid, block, 0, st, g);
+        if (P->tri()) {
+            // 2: the y direction of every x mode as a tridiagonal solve, in place; 3: dst = A . S_x
+            launch_tri(P, nb, st);
+            for (int b = 0; b < nb; ++b) { g.A[b] = P->buf_a + b*plane; g.B[b] = P->S_x; g.C[b] = dst[b]; }
+            g.lda = nx; g.ldb = nx; g.ldc = dst_pitch; g.K = nx; g.scale = nullptr;
+            hipLaunchKernelGGL(k_dense_product, grid, block, 0, st, g);
+            HPS_HIP_CHECK(hipGetLastError());
+            return HPS_OK;
+        }
         // 2: B = (S_y . A) * inverse eigenvalues (stored x-frequency major)
         for (int b = 0; b < nb; ++b) { g.A[b] = P->S_y; g.B[b] = P->buf_a + b*plane; g.C[b] = P->buf_b + b*plane; }
         g.lda = ny; g.ldb = nx; g.ldc = nx; g.K = ny; g.scale = P->eig; g.scale_r = 1; g.scale_c = ny;
@@ -1942,6 +2092,10 @@ static int poisson_solve_batch_impl (Poisson* P, int nb, const double* const* sr
         for (int b = 0; b < nb; ++b) a.npairs[b] = 0;
     } else
     hipLaunchKernelGGL(P->kx, rows_grid(ny*nb, P->tx), dim3(P->ntx), P->lds_x, st, a);
+    if (P->tri()) {
+        // 2: the y direction of every x mode as a tridiagonal solve, in place on A (no transposes, no y transforms)
+        launch_tri(P, nb, st);
+    } else
     if (P->kcols) {
         // 2-5: DST along y, inverse eigenvalues, DST along y -- in place on column blocks of A
         for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_a + b*plane; a.dst[b] = P->buf_a + b*plane; }
