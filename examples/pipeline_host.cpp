@@ -28,6 +28,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <deque>
 #include <vector>
 
 #define CHECK(call) do { const int e_ = (call); if (e_ != 0) { std::fprintf(stderr, "%s failed (%d): %s\n", #call, e_, hps_last_error()); return 1; } } while (0)
@@ -138,6 +139,23 @@ int main (int argc, char** argv)
         return 0;
     };
 
+    // put_data towards the next process: on an ipc edge hps_ring_send_slice makes the HOST wait until the matching receive is
+    // posted and its buffer free (include/hpslice.h) -- with several stages per thread that would hold up the siblings of the
+    // last stage.  So a block that cannot go out at once waits in an outbox; hps_ring_can_send is asked at the top of every
+    // round (an RCCL edge always says yes: its sends only enqueue).  The engine event a block waits for comes from a pool of 64
+    // slots, so the last stage does not run more than 32 slices ahead of the outbox.
+    struct Outgoing { int q, b; void* pushed; Stage* s; };
+    std::deque<Outgoing> outbox;
+    auto flush_outbox = [&] (bool block) -> int {
+        while (!outbox.empty() && (block || hps_ring_edge_kind(ring) == 0 || hps_ring_can_send(ring) == 1)) {
+            const Outgoing o = outbox.front();
+            void* gone = nullptr;
+            CHECK(hps_ring_send_slice(ring, o.s->buf[o.b] + 7*off[(size_t)o.q], block_bytes(o.q), o.pushed, o.b*nz + o.q, &gone));
+            outbox.pop_front();
+        }
+        return 0;
+    };
+
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<double> sums((size_t)ncomp);
     long solved = 0, idle_rounds = 0;
@@ -147,6 +165,7 @@ int main (int argc, char** argv)
     while (!all_done) {
         all_done = true;
         bool worked = false, ring_waits = false;
+        if (ring) { const size_t before = outbox.size(); if (flush_outbox(false)) return 1; if (outbox.size() < before) worked = true; if (!outbox.empty()) ring_waits = true; }
         // first halves: every stage that can enqueues its next slice up to the norm read-back
         for (int j = 0; j < L; ++j) {
             Stage& s = S[(size_t)j];
@@ -167,6 +186,7 @@ int main (int argc, char** argv)
                 worked = true;
             }
             if (s.pending) continue;
+            if (j == L - 1 && outbox.size() >= 32) { ring_waits = true; continue; }       // (the next process is not taking blocks: do not outrun the event pool)
             // get_data: this slice's beam and the next one's (the source of its jx, jy) must have been handed on
             const int need = s.q + 1 < nz ? s.q + 1 : nz - 1;
             if (fed && (s.have_step[b] != step || s.have[b] < need + 1)) continue;       // (an in-process edge: the stage ahead is not there yet)
@@ -200,9 +220,10 @@ int main (int argc, char** argv)
                 const bool to_ring = (j == L - 1) && world > 1;
                 if (to_ring) {
                     if (block_bytes(q) > 0) {
-                        void* pushed = nullptr; void* gone = nullptr;
+                        void* pushed = nullptr;
                         CHECK(hps_engine_record_event(s.eng, q % 64, &pushed));
-                        CHECK(hps_ring_send_slice(ring, s.buf[b] + 7*off[(size_t)q], block_bytes(q), pushed, b*nz + q, &gone));
+                        outbox.push_back(Outgoing{q, b, pushed, &s});
+                        if (flush_outbox(false)) return 1;
                     }
                 } else {
                     Stage& r = S[(size_t)((j + 1) % L)];
@@ -235,6 +256,7 @@ int main (int argc, char** argv)
         idle_rounds = (worked || ring_waits) ? 0 : idle_rounds + 1;
         if (idle_rounds > 100000) { std::fprintf(stderr, "rank %d: the stages of this process wait for one another\n", rank); return 1; }
     }
+    if (ring && flush_outbox(true)) return 1;
     for (auto& s : S) CHECK(hps_engine_sync(s.eng));
     if (ring) CHECK(hps_ring_sync(ring));
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -170,6 +170,7 @@ _SIGS = {
     "hps_engine_field_diagnostic_geometry": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hps_engine_record_event": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "hps_engine_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hps_stream_pool_shared_pairs": (C.c_int, [C.c_int]),
     "hps_engine_copy_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]),
     "hps_engine_set_profiling_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "hps_engine_set_laser_import": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

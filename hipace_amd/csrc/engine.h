@@ -22,6 +22,7 @@ int mg_solve1_begin (void* mg_handle, hps_slab s, int sol_comp, int rhs_comp, in
 void mg_solve1_forget_hierarchy (void* mg_handle);
 bool poisson_gateable (void* poisson_handle);
 void poisson_set_gate (void* poisson_handle, const int* gate);
+bool ring_is_ticket (const void* p);      // ring.hip: is p the receive handle of an ipc ring edge (not a hipEvent_t)?
 int mg_solve1_prepare (void* mg_handle, hps_slab s, int sol_comp, int rhs_comp, int acf_comp, int max_iters, hipStream_t st);
 // ... in one launch with the -grad Psi / Sx, Sy pass of the slab (multigrid.hip: k_hierarchy_gradpsi); *done = false if this grid's
 // hierarchy needs more than that launch (then nothing has been enqueued)

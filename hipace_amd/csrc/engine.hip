@@ -548,6 +548,55 @@ int Engine::install_beam (std::vector<double> (&h)[7])
 // default of 4 hardware queues per priority (GPU_MAX_HW_QUEUES) -- a 4th pooled stream has to share one of those queues,
 // and two processes on one device with pools of 4 made 1249 slices/s together against 1916-1928 with pools of 0-3
 // (profiles/r05_stream_pool_two_processes.txt).  Further engines get streams of their own.
+// Self-check of the engines' stream pool (HPS_STREAM_POOL_CHECK=0: off).  The pool's size is a property of the runtime read
+// off one box (four front-end pipes per priority less the null stream's: streams created back to back land on different
+// pipes up to 3; a fourth shares one -- profiles/r05_queue_pairs.txt, r05_stream_pool_two_processes.txt).  Another runtime, or
+// a process that had created streams of its own first, may map two pool streams to one pipe, and three stages in flight
+// then take turns without anything saying so.  So once per device, when the pool is made: a one-workgroup kernel that spins
+// for 100 us, R times on both streams of every pair; side by side takes R x 100 us, taking turns 2 R x 100 us.
+__global__ void k_pool_spin (long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+namespace { std::map<int, int> g_pool_shared_pairs; }
+static void check_stream_pool (int device, const std::vector<hipStream_t>& pool)
+{
+    g_pool_shared_pairs[device] = -1;
+    if (const char* v = std::getenv("HPS_STREAM_POOL_CHECK")) if (std::atoi(v) == 0) return;
+    if (pool.size() < 2) { g_pool_shared_pairs[device] = 0; return; }
+    int rate = 0;
+    if (hipDeviceGetAttribute(&rate, hipDeviceAttributeWallClockRate, device) != hipSuccess || rate <= 0) return;
+    const long long ticks = (long long)rate/10;                 // (kHz: 100 us)
+    const int R = 4;
+    int shared = 0;
+    std::string which;
+    for (size_t i = 0; i < pool.size(); ++i) for (size_t j = i + 1; j < pool.size(); ++j) {
+        hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, pool[i], ticks/20);      // (code object loaded, queues awake)
+        hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, pool[j], ticks/20);
+        (void)hipStreamSynchronize(pool[i]); (void)hipStreamSynchronize(pool[j]);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < R; ++r) {
+            hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, pool[i], ticks);
+            hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, pool[j], ticks);
+        }
+        (void)hipStreamSynchronize(pool[i]); (void)hipStreamSynchronize(pool[j]);
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (us > 1.6*R*100.0) { ++shared; which += " (" + std::to_string(i) + "," + std::to_string(j) + "): " + std::to_string((int)us) + " us"; }
+    }
+    g_pool_shared_pairs[device] = shared;
+    if (shared)
+        std::fprintf(stderr, "libhpslice: device %d: %d pair(s) of the %zu engine streams of the pool take turns instead of running side by side "
+                             "(%d x 100 us on both streams of a pair, expected %d us:%s) -- several stages in flight on this device will share a "
+                             "front-end pipe; try HPS_STREAM_POOL=%zu or GPU_MAX_HW_QUEUES\n", device, shared, pool.size(), R, R*100, which.c_str(), pool.size() - 1);
+}
+extern "C" int hps_stream_pool_shared_pairs (int device)      // -1: not checked (no pool yet, or HPS_STREAM_POOL_CHECK=0)
+{
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    auto it = g_pool_shared_pairs.find(device);
+    return it == g_pool_shared_pairs.end() ? -1 : it->second;
+}
+
 static hipError_t create_engine_stream (hipStream_t* s, int device, bool* pooled)
 {
     *pooled = false;
@@ -570,6 +619,7 @@ static hipError_t create_engine_stream (hipStream_t* s, int device, bool* pooled
                 pool.push_back(t);
             }
             if (scratch) (void)hipFree(scratch);
+            check_stream_pool(device, pool);
             std::reverse(pool.begin(), pool.end());          // (handed out from the back: first created first)
         }
         if (pool.empty()) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);       // more engines than the pool holds
@@ -2222,6 +2272,8 @@ extern "C" int hps_engine_wait_event (void* h, void* event)
 {
     Engine* E = static_cast<Engine*>(h);
     HPS_REQUIRE(event, "hps_engine_wait_event: null event");
+    HPS_REQUIRE(!ring_is_ticket(event), "hps_engine_wait_event: this is the receive handle of an ipc ring edge, not a hipEvent_t -- order the engine behind "
+                                        "it with hps_ring_engine_wait(ring, engine, handle), which works for both kinds of edge");
     HPS_HIP_CHECK(hipStreamWaitEvent(E->st, static_cast<hipEvent_t>(event), 0));
     return HPS_OK;
 }

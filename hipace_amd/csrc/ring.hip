@@ -32,8 +32,11 @@
 #include <sys/stat.h>
 #include <fcntl.h>
 #include <unistd.h>
+#include <algorithm>
 #include <atomic>
 #include <map>
+#include <mutex>
+#include <unordered_set>
 #include <memory>
 
 #include <dlfcn.h>
@@ -127,6 +130,10 @@ struct Mailbox {
 constexpr char kIpcTag[] = "HPSIPC1:";
 struct Ticket { unsigned long long magic, seq; };
 constexpr unsigned long long kTicketMagic = 0x4850535449434b54ull;
+// every live receive handle of an ipc edge: hps_engine_wait_event refuses them (a host written against the RCCL edge would
+// hand one to hipStreamWaitEvent as if it were a hipEvent_t)
+std::mutex g_tickets_mu;
+std::unordered_set<const void*> g_tickets;
 
 struct Box {                                    // one side's view of a mailbox
     Mailbox* m = nullptr; std::string name; bool creator = false, registered = false;
@@ -252,10 +259,15 @@ int ipc_wait (Ring* R, F cond, const std::atomic<int>* gone, double seconds, con
 int ipc_arena_of (Ring* R, const void* p, long bytes, unsigned* id, unsigned long long* offset)
 {
     const unsigned long long a = (unsigned long long)(uintptr_t)p;
-    for (const auto& r : R->my_arenas)
-        if (a >= r.base && a + (unsigned long long)bytes <= r.base + r.size) { *id = (unsigned)r.id; *offset = a - r.base; return HPS_OK; }
     void* base = nullptr; size_t size = 0;
     HPS_HIP_CHECK(hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)const_cast<void*>(p)));
+    // a cached range only counts while it is still the SAME allocation (base and size): a freed receive pool whose address
+    // range was handed out again would otherwise be reached through the stale mapping in the sender -- "landed" flagged, the
+    // data nowhere.  (An allocation freed and re-made with the same base AND size cannot be told apart here: receive buffers
+    // must stay allocated until hps_ring_destroy, include/hpslice.h.)
+    for (const auto& r : R->my_arenas)
+        if ((unsigned long long)(uintptr_t)base == r.base && (unsigned long long)size == r.size &&
+            a >= r.base && a + (unsigned long long)bytes <= r.base + r.size) { *id = (unsigned)r.id; *offset = a - r.base; return HPS_OK; }
     HPS_REQUIRE(base && a + (unsigned long long)bytes <= (unsigned long long)(uintptr_t)base + size, "hps_ring_recv_slice: the buffer is not inside one device allocation");
     Mailbox* m = R->box_in.m;
     const int n = m->n_arenas.load();
@@ -291,6 +303,13 @@ bool ipc_can_send (const Ring* R)
 } // namespace
 
 extern "C" int hps_ring_destroy (void* handle);
+namespace hps {
+bool ring_is_ticket (const void* p)
+{
+    std::lock_guard<std::mutex> lk(g_tickets_mu);
+    return g_tickets.count(p) != 0;
+}
+}
 
 extern "C" int hps_ring_unique_id (char* id_out)
 {
@@ -476,7 +495,8 @@ extern "C" int hps_ring_send_slice (void* handle, const void* msg_dev, long byte
 
 // get_data (MultiBuffer.cpp:495-609): post the receive of the next message of the previous rank into msg_dev.  The
 // receive stream first waits for `after_event` (the buffer's previous contents are no longer needed); *done_event
-// fires when the data has landed -- make the engine's stream wait for it (hps_engine_wait_event).
+// fires when the data has landed -- make the engine's stream wait for it (hps_ring_engine_wait; on the RCCL edge it is a
+// hipEvent_t and hps_engine_wait_event does the same).
 extern "C" int hps_ring_recv_slice (void* handle, void* msg_dev, long bytes, void* after_event, int slot, void** done_event)
 {
     Ring* R = static_cast<Ring*>(handle);
@@ -497,7 +517,11 @@ extern "C" int hps_ring_recv_slice (void* handle, void* msg_dev, long bytes, voi
         if (after_event) HPS_HIP_CHECK(hipStreamWaitEvent(R->st_recv, static_cast<hipEvent_t>(after_event), 0));
         HPS_HIP_CHECK(hipStreamWriteValue64(R->st_recv, R->box_in.d_freed, R->n_posted, 0));
         if ((size_t)slot >= R->tickets.size()) R->tickets.resize((size_t)slot + 1);
-        if (!R->tickets[slot]) R->tickets[slot].reset(new Ticket{kTicketMagic, 0});
+        if (!R->tickets[slot]) {
+            R->tickets[slot].reset(new Ticket{kTicketMagic, 0});
+            std::lock_guard<std::mutex> lk(g_tickets_mu);
+            g_tickets.insert(R->tickets[slot].get());
+        }
         R->tickets[slot]->seq = R->n_posted;
         if (done_event) *done_event = R->tickets[slot].get();
         ++R->n_received; R->bytes_received += bytes;
@@ -718,6 +742,21 @@ extern "C" int hps_ring_destroy (void* handle)
     if (R->st_send) (void)hipStreamSynchronize(R->st_send);
     if (R->st_recv) (void)hipStreamSynchronize(R->st_recv);
     if (R->kind == 1) {
+        // receiver: copies the previous rank has already enqueued into my buffers must have landed before the buffers go
+        // (the host may free them right after this call): wait, bounded, for landed >= min(posted, issued) or for the sender
+        // to have left
+        if (R->box_in.m && R->world > 1) {
+            Mailbox* m = R->box_in.m;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (!m->sender_gone.load()) {
+                const unsigned long long want = std::min<unsigned long long>(R->n_posted, ld_acq(&m->issued.v));
+                if (ld_acq(&m->landed.v) >= want) break;
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) break;
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+        }
+        {   std::lock_guard<std::mutex> lk(g_tickets_mu);
+            for (auto& t : R->tickets) if (t) g_tickets.erase(t.get()); }
         if (R->box_out.m && R->world > 1) R->box_out.m->sender_gone.store(1);
         if (R->box_in.m) R->box_in.m->receiver_gone.store(1);
         for (void* p : R->peer_arena) if (p) (void)hipIpcCloseMemHandle(p);

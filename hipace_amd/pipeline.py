@@ -100,6 +100,16 @@ class GlooTransport:
         pass
 
 
+def host_identity():
+    """what tells two ranks that they share a node (and with it /dev/shm and the devices' IPC handles)"""
+    import socket
+    try:
+        boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+    except OSError:
+        boot = ""
+    return f"{socket.gethostname()}|{boot}"
+
+
 def ring_edge():
     """Kind of edge the C-ABI ring makes (HPS_RING_EDGE, read by hps_ring_unique_id): "ipc" (default: peer copies ordered
     through a shared-memory mailbox; one node, any device assignment -- also several ranks on ONE device) or "rccl"."""
@@ -134,22 +144,42 @@ class RingTransport:
         self._lib, self._check = _lib.lib(), _lib.check
         self.rank, self.world = rank, world
         self._h = None
-        self._connect(rank, world, device_index, group)
-        if world > 1 and self.kind == "ipc" and edge is None and os.environ.get("HPS_RING_NO_PROBE", "0") in ("", "0"):
+        self.fell_back = None                   # why a ring that was to be ipc is RCCL (text), else None
+        chosen_here = edge is None and not os.environ.get("HPS_RING_EDGE")
+        if world > 1 and chosen_here:
+            # the default edge is ipc: POSIX shared memory + hipIpc handles, i.e. ONE node.  A ring that spans hosts takes RCCL
+            # (decided by all ranks together, before any rank makes a mailbox its neighbour on another host could never open)
+            ids = [None] * world
+            dist.all_gather_object(ids, host_identity(), group=group)
+            if len(set(ids)) > 1:
+                os.environ["HPS_RING_EDGE"] = "rccl"
+                self.fell_back = f"the ring spans {len(set(ids))} hosts"
+        if world > 1 and ring_edge() == "ipc" and edge is None and os.environ.get("HPS_RING_NO_PROBE", "0") in ("", "0"):
             # One small message around the ring before anything is timed: it opens the next rank's allocation in this process
             # (hipIpcOpenMemHandle + peer access, first use) and proves that a peer copy and its flags arrive.  If any rank
-            # cannot (a node whose devices have no peer access, a runtime without IPC) ALL ranks fall back to the RCCL edge
-            # together -- decided through the torch.distributed group, loudly.
-            ok = self._probe(device_index)
+            # cannot connect or cannot pass the message (a node whose devices have no peer access, a runtime without IPC, a
+            # neighbour whose shared memory is not ours) ALL ranks fall back to the RCCL edge together -- decided through the
+            # torch.distributed group, loudly.
+            ok, why = True, ""
+            try:
+                self._connect(rank, world, device_index, group)
+            except Exception as exc:      # noqa: BLE001
+                ok, why = False, f"hps_ring_init: {type(exc).__name__}: {exc}"
+            if ok:
+                ok = self._probe(device_index)
+                why = self._probe_error
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
             if int(flag.item()) == 0:
                 import sys
-                print(f"hipace_amd.pipeline: rank {rank}: the ipc edge's probe message failed on some rank ({'here: ' + self._probe_error if not ok else 'not here'}); "
+                print(f"hipace_amd.pipeline: rank {rank}: the ipc edge could not be set up on some rank ({'here: ' + why if not ok else 'not here'}); "
                       "all ranks fall back to HPS_RING_EDGE=rccl", file=sys.stderr, flush=True)
                 self.close()
+                self.fell_back = "the ipc edge's connection or probe message failed" + (f" on this rank: {why}" if not ok else " on another rank")
                 os.environ["HPS_RING_EDGE"] = "rccl"
                 self._connect(rank, world, device_index, group)
+        else:
+            self._connect(rank, world, device_index, group)
 
     def _connect(self, rank, world, device_index, group):
         my = C.create_string_buffer(128)

@@ -464,6 +464,11 @@ int hps_engine_assume_initial_beam_support (void* handle);
  * stream included.  It is for streams of the engine's device (another engine, the ring's send stream): it is recorded
  * without the system-scope fence HIP puts behind an event by default (HPS_EVENT_FENCE=0 restores it). */
 int hps_engine_record_event (void* handle, int slot, void** event_out);
+/* The engines of a device take their streams from a pool made with the first engine (HPS_STREAM_POOL, default 3: streams
+ * created back to back land on different pipes of the command front end).  When the pool is made every pair of its streams
+ * runs a 100-us kernel side by side once; pairs that took turns are counted and a warning goes to stderr.  Returns that
+ * count (0 = every pair overlaps), -1 before the first engine of the device or with HPS_STREAM_POOL_CHECK=0. */
+int hps_stream_pool_shared_pairs (int device);
 int hps_engine_wait_event (void* handle, void* event);
 int hps_engine_copy_async (void* handle, void* dst_dev, const void* src_dev, long bytes);
 
@@ -490,11 +495,16 @@ int hps_engine_copy_async (void* handle, void* dst_dev, const void* src_dev, lon
 int hps_ring_unique_id (char* id_out /* [HPS_RING_ID_BYTES] */);
 int hps_ring_init (int rank, int world, int device, const char* id_edge_in, const char* id_edge_out, void** ring);
 /* put_data: `bytes` at msg_dev go to rank+1.  The send waits (on the device) for after_event (hipEvent_t, may be NULL);
- * *done_event (pool slot `slot` of the ring's send events) fires when msg_dev may be overwritten. */
+ * *done_event (pool slot `slot` of the ring's send events; a hipEvent_t on both kinds of edge) fires when msg_dev may be
+ * overwritten.  RCCL edge: only enqueues.  ipc edge (the default): the HOST blocks in this call (up to HPS_RING_TIMEOUT_S)
+ * until the next rank has posted the matching receive and its buffer is free -- a host that drives several stages from one
+ * thread asks hps_ring_can_send first and keeps the block in an outbox meanwhile (examples/pipeline_host.cpp). */
 int hps_ring_send_slice (void* ring, const void* msg_dev, long bytes, void* after_event, int slot, void** done_event);
 /* get_data: post the receive of the next message from rank-1 into msg_dev (messages arrive in the order they were
- * sent).  The receive waits for after_event (may be NULL); *done_event (pool slot `slot` of the receive events) fires
- * when the data has landed: hps_engine_wait_event(engine, *done_event) before the slice that reads it. */
+ * sent).  The receive waits for after_event (may be NULL); *done_event (slot `slot` of the ring's receive handles) stands
+ * for "the data has landed": hps_ring_engine_wait(ring, engine, *done_event) before the slice that reads it.  The handle is
+ * a hipEvent_t on the RCCL edge only; on the ipc edge (the default) it is an object of the ring, and
+ * hps_engine_wait_event refuses it with HPS_ERR_ARG -- hosts written against rounds 2-4 change that one call. */
 int hps_ring_recv_slice (void* ring, void* msg_dev, long bytes, void* after_event, int slot, void** done_event);
 int hps_ring_sendrecv_self (void* ring, const void* src_dev, void* dst_dev, long bytes, void* after_event, int slot,
                             void** done_event);
@@ -532,7 +542,11 @@ int hps_ring_destroy (void* ring);
 int hps_ring_edge_kind (void* ring);                              /* 0 = RCCL, 1 = ipc */
 int hps_ring_can_send (void* ring);                               /* 1: the next hps_ring_send_slice will not wait on the host */
 int hps_ring_recv_landed (void* ring, void* done_event);          /* 1: that receive's message is in the buffer; 0: not yet */
-int hps_ring_engine_wait (void* ring, void* engine, void* done_event);   /* order the engine's stream behind that receive */
+/* order the engine behind that receive.  RCCL edge: the engine's STREAM waits for the receive's event (the call only
+ * enqueues).  ipc edge: the HOST blocks here (up to HPS_RING_TIMEOUT_S) until the sender's stream has flagged the message
+ * as landed -- the engine's later launches are then ordered behind it by program order; a host with several stages per
+ * thread polls hps_ring_recv_landed first and gives its other stages their turn (examples/pipeline_host.cpp). */
+int hps_ring_engine_wait (void* ring, void* engine, void* done_event);
 
 /* ---- utilities ---------------------------------------------------------------------------- */
 int hps_memcpy_d2h (void* dst_host, const void* src_dev, long bytes);

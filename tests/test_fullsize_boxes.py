@@ -31,7 +31,7 @@ REPORT_DIR = os.environ.get("HPS_FULLSIZE_REPORT")        # directory: write wha
 def _fixture(name):
     path = os.path.join(GOLD, f"fullsize_{name}.json")
     if not os.path.exists(path):
-        pytest.skip(f"{path} not generated (scripts/make_fullsize_fixtures.py --only {name})")
+        pytest.fail(f"{path} is missing: a parity fixture must not turn into a skip (scripts/make_fullsize_fixtures.py --only {name} writes it)")
     fx = json.load(open(path))
     deck = {k: (tuple(v) if isinstance(v, list) else v) for k, v in fx["deck"].items()}
     return fx, deck
@@ -227,7 +227,7 @@ def test_config5_whole_box_vs_oracle_fixture(api, name):
     (tests/laser_blowout_wake_explicit.SI.1Rank.sh; hipace.normalized_units = 0), the latter at 1024^2 with the multigrid
     envelope solver (the reference's default, laser/MultiLaser.cpp:430-608)."""
     if not os.path.exists(os.path.join(GOLD, f"fullsize_{name}.json")):
-        pytest.skip(f"fixture fullsize_{name}.json not generated (scripts/make_fullsize_fixtures.py)")
+        pytest.fail(f"fixture fullsize_{name}.json is missing (scripts/make_fullsize_fixtures.py writes it)")
     fx, got = _run_box(api, name)
     bad, worst, worst_trace = _compare(fx, got, int_keys=("n_valid", "n_particles", "n_ionized", "ion_level_sum"),
                                        soft_int_keys=("vcycles", "laser_vcycles"))

@@ -160,7 +160,7 @@ def test_processes_on_one_device_hand_over_through_the_ipc_edge(oracle, world, l
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,stages,n_steps", [(2, 1, 2), (2, 1, 5), (2, 2, 7), (3, 1, 4)])
+@pytest.mark.parametrize("world,stages,n_steps", [(2, 1, 2), (2, 1, 5), (2, 2, 7), (3, 1, 4), (2, 3, 8)])
 def test_cpp_pipeline_host_as_several_processes(api, tmp_path, world, stages, n_steps):
     """examples/pipeline_host.cpp run as `world` PROCESSES on the one device (rank % devices): the between-process branch of
     the C++ host -- edge ids through files, receives of a whole step posted ahead, hps_ring_send_slice behind the engine's
@@ -251,7 +251,7 @@ def test_headline_box_through_two_processes_of_two_stages():
     import torch.multiprocessing as mp
     path = os.path.join(GOLD, "fullsize_config4.json")
     if not os.path.exists(path):
-        pytest.skip("fullsize_config4.json not generated")
+        pytest.fail("tests/golden/fullsize_config4.json is missing (scripts/make_fullsize_fixtures.py --only config4 writes it)")
     fx = json.load(open(path))
     deck = {k: (tuple(v) if isinstance(v, list) else v) for k, v in fx["deck"].items()}
     world, lanes, n_steps = 2, 2, 6
