@@ -61,7 +61,10 @@ if ROOT not in sys.path:
 CPU_THREADS_DEFAULT = 16  # OpenMP leg of the CPU baseline: fastest on the 256-core host of the GPU box, 9.5x the serial leg; 64 threads
                           # are already slower and 256 slower than one (profiles/r02b_cpu_threads.json)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_SUMMARY = "r05d_pmc_fetch_write_per_kernel.csv"      # profiles/: rocprofv3 --pmc summary of the shipped kernels
+PMC_SUMMARY = "r06_pmc_fetch_write_per_kernel.csv"       # profiles/: rocprofv3 --pmc summary of the shipped kernels
+PMC_FP64 = "r06_pmc_fp64_per_kernel.csv"                  # profiles/: SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 per launch (scripts/collect_flops.sh)
+FP64_VALU_PEAK_TFLOPS = 78.6  # vector fp64: half of MI355X_MICROARCH.md's 157.3 TFLOP/s fp32 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop
+                              # x 2.4 GHz, every instruction an FMA); scripts/ubench/mfma64.hip measured 71 on this part
 START_SLICE_DEFAULT = 700  # short runs start here (from the head); see profiles/r02a_slice_cost_profile.json
 
 
@@ -133,8 +136,24 @@ def pmc_slice_bytes():
     return tot / nsl if nsl else None
 
 
+def pmc_fp64(kernel_prefix):
+    """fp64 flops and VALU instructions per launch of `kernel_prefix` from the committed SQ instruction counters (wave-level
+    instruction counts x 64 lanes: ADD + MUL + 2 FMA + TRANS; exec-masked lanes count as if active -- an upper bound of the
+    useful flops).  None without the summary."""
+    import csv
+    path = os.path.join(ROOT, "profiles", PMC_FP64)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["kernel"].startswith(kernel_prefix):
+                f64 = sum(float(r[k]) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+                return dict(flops=float(r["fp64_flops_per_launch"]), fp64_wave_instructions=f64, valu_wave_instructions=float(r["SQ_INSTS_VALU"]))
+    return None
+
+
 PHASE_OF_KERNEL = (("k_deposit_tiled", "deposit_current"), ("k_explicit_tiled", "explicit_deposit"), ("k_advance", "advance_plasma"),
-                   ("k_dst_", "poisson"), ("k_transpose", "poisson"), ("rocfft", "poisson"), ("k_dense", "poisson"),
+                   ("k_dst_", "poisson"), ("k_tridiag", "poisson"), ("k_transpose", "poisson"), ("rocfft", "poisson"), ("k_dense", "poisson"),
                    ("k_smooth", "mg_solve1"), ("k_lower", "mg_solve1"), ("k_copy2", "mg_solve1"), ("k_post_norms", "mg_solve1"),
                    ("k_permute", "sort"), ("k_cell_keys", "sort"), ("k_rank_keys", "sort"), ("k_tile_", "sort"), ("k_run_starts", "sort"),
                    ("rocprim", "sort"))
@@ -264,6 +283,156 @@ def reference_benchmark(nxy):
     return 0
 
 
+def _pci_bus_id(dev):
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    buf = ctypes.create_string_buffer(64)
+    rc = hip.hipDeviceGetPCIBusId(buf, 64, int(dev))
+    return buf.value.decode() if rc == 0 else f"hipDeviceGetPCIBusId={rc}"
+
+
+def dry_leg_worker(args, rank, world):
+    """--dry-legs: what a leg's worker does to the control flow, without a GPU -- join the leg's process group, agree on a
+    number, rank 0 prints a line.  BENCH_DRY_FAIL=<kind>: rank 1 of that leg raises; BENCH_DRY_HANG=<kind>: it never comes back."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", init_method="file://" + os.environ["HPS_BENCH_LEG_RDZV"], rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=max(20.0, args.leg_timeout)))
+    if rank == 1 and os.environ.get("BENCH_DRY_FAIL") == args.leg:
+        raise RuntimeError(f"dry leg {args.leg}: rank 1 fails on purpose")
+    if rank == 1 and os.environ.get("BENCH_DRY_HANG") == args.leg:
+        time.sleep(3600)
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    if rank == 0:
+        v = {"ipc": 2000.0, "rccl": 1900.0}[args.leg] * world
+        emit({"metric": "dry run", "value": v, "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": 1e3 * world / v, "ring_edge": args.leg, "ranks_seen": int(t.item()),
+              "rccl_ranks_seen": int(t.item()) if args.leg == "rccl" else None, "value_steps_in_flight": 1.2 * v})
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
+def supervise_legs(args, rank, world):
+    """N > 1: the process the launcher started for this rank does not touch the GPU.  It runs the measurement once per KIND OF
+    EDGE between the ranks -- `ipc` (peer copies through hipIpc handles, ordered by a shared-memory mailbox) and `rccl`
+    (ncclSend / ncclRecv, what the north star names) -- each as a worker process of its own (`bench.py ... --leg <kind>`), the
+    workers of a leg meeting through a file store of their own.  A leg that fails, hangs or crashes is killed at --leg-timeout
+    and recorded with its error text; the other leg's number is not lost with it, and no state of a failed leg (a stuck
+    stream, a half-connected communicator) is carried into the next.  Rank 0 prints ONE line: the better leg's line, plus
+    `ring_edges` = what every leg measured or why it could not, `rccl_ranks_seen` = the RCCL leg's count whichever leg won."""
+    import signal
+    import tempfile
+    kinds = [args.edge] if args.edge else (["ipc"] if args.same_device else ["ipc", "rccl"])
+    argv, skip = [], False
+    for a in sys.argv[1:]:
+        if skip:
+            skip = False
+            continue
+        if a == "--edge":
+            skip = True
+            continue
+        if a.startswith("--edge="):
+            continue
+        argv.append(a)
+    key = "%s_%s_%d" % (os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("MASTER_PORT", "0"), os.getppid())
+    key = "".join(c if c.isalnum() or c in "_-" else "_" for c in key)
+    rdzv_dir = os.environ.get("HPS_BENCH_RDZV_DIR", tempfile.gettempdir())
+    legs = {}
+    for i, kind in enumerate(kinds):
+        rdzv = os.path.join(rdzv_dir, f"hps_bench_rdzv_{key}_{i}_{kind}")
+        env = dict(os.environ, HPS_RING_EDGE=kind, HPS_BENCH_LEG_RDZV=rdzv)
+        env.setdefault("HPS_RING_TIMEOUT_S", "120")
+        env.setdefault("HPS_RING_CONNECT_TIMEOUT_S", "120")
+        errf = tempfile.TemporaryFile(mode="w+")
+        t0 = time.perf_counter()
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ["--leg", kind, "--watchdog", str(max(30.0, args.leg_timeout - 15.0))],
+                             env=env, stdout=subprocess.PIPE, stderr=errf, text=True, start_new_session=True)
+        timed_out = False
+        try:
+            out, _ = p.communicate(timeout=args.leg_timeout)
+        except subprocess.TimeoutExpired:
+            timed_out = True
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            out, _ = p.communicate()
+        errf.seek(0)
+        err = errf.read()
+        errf.close()
+        if err:
+            sys.stderr.write(f"---- bench.py rank {rank}, {kind} leg, stderr ----\n{err[-6000:]}\n")
+            sys.stderr.flush()
+        line = None
+        for ln in (out or "").splitlines():
+            if ln.startswith("{"):
+                try:
+                    line = json.loads(ln)
+                except ValueError:
+                    pass
+        rec = {"seconds": time.perf_counter() - t0, "returncode": p.returncode}
+        if timed_out:
+            rec["error"] = f"the leg's worker of rank {rank} was still running after {args.leg_timeout:.0f} s and was killed"
+        elif p.returncode != 0:
+            last = [ln for ln in err.strip().splitlines() if ln.strip()][-3:]
+            rec["error"] = f"the leg's worker of rank {rank} exited with code {p.returncode}: " + " | ".join(last)[-600:]
+        legs[kind] = (rec, line)
+        if timed_out or p.returncode != 0:
+            time.sleep(3.0)          # (a killed worker's queues are torn down by the driver before the next leg starts)
+    if rank != 0:
+        # (a rank whose worker failed while rank 0's did not cannot say so through a group -- there is none between the
+        #  supervisors by design; its stderr above holds the text, and rank 0's worker of that leg fails or times out with it)
+        return 0
+    for i, kind in enumerate(kinds):
+        try:
+            os.unlink(os.path.join(rdzv_dir, f"hps_bench_rdzv_{key}_{i}_{kind}"))
+        except OSError:
+            pass
+    edges = {}
+    for kind in ("ipc", "rccl"):
+        if kind not in legs:
+            edges[kind] = {"value": None, "skipped": ("RCCL refuses two ranks on one device (--same-device)" if (args.same_device and kind == "rccl")
+                                                      else f"--edge {args.edge} asked for the other kind only")}
+            continue
+        rec, line = legs[kind]
+        e = {"value": line.get("value") if line else None,
+             "value_steps_in_flight": line.get("value_steps_in_flight") if line else None,
+             "ms_per_step": line.get("ms_per_step") if line else None,
+             "ranks_seen": line.get("ranks_seen") if line else None,
+             "leg_seconds": rec["seconds"]}
+        if kind == "rccl":
+            e["rccl_ranks_seen"] = line.get("rccl_ranks_seen") if line else None
+        if line and line.get("rank_devices"):
+            e["rank_devices"] = line["rank_devices"]
+        if line and isinstance(line.get("in_flight"), dict) and line["in_flight"].get("error"):
+            e["in_flight_error"] = line["in_flight"]["error"]
+        if "error" in rec:
+            e["error"] = rec["error"]
+        elif line is None:
+            e["error"] = "the leg's rank-0 worker ended without a line"
+        edges[kind] = e
+    good = [k for k in kinds if legs[k][1] is not None and legs[k][1].get("value")]
+    if not good:
+        emit({"metric": "transverse slices/s", "value": None, "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "error": "no ring-edge leg produced a number", "ring_edges": edges})
+        return 1
+    best = max(good, key=lambda k: legs[k][1]["value"])
+    out = dict(legs[best][1])
+    out["ring_edge"] = best
+    out["ring_edges"] = edges
+    out["value_is_of_edge"] = best
+    rc = edges.get("rccl", {})
+    out["rccl_ranks_seen"] = rc.get("rccl_ranks_seen")
+    if out["rccl_ranks_seen"] != world:
+        out["rccl_ranks_seen_note"] = rc.get("error") or rc.get("skipped") or "the RCCL leg ran but did not count every rank on its edges"
+    emit(out)
+    return 0
+
+
 def main():
     claim_stdout()
     ap = argparse.ArgumentParser()
@@ -330,6 +499,15 @@ def main():
     ap.add_argument("--spawn-check", action="store_true",
                     help="only check the launch path: every rank joins the process group (gloo, no GPU needed) and rank 0 "
                          "prints how many ranks there are")
+    ap.add_argument("--leg", choices=["ipc", "rccl"], default=None,
+                    help="(internal, N > 1) this process is the worker of one ring-edge leg: bench.py under a launcher starts one "
+                         "worker per rank and edge kind, see supervise_legs")
+    ap.add_argument("--leg-timeout", type=float, default=600.0,
+                    help="N > 1: seconds one edge kind's leg (all its ranks) may take before its workers are killed and the leg is "
+                         "recorded as failed; the other kind's number is not lost with it")
+    ap.add_argument("--dry-legs", action="store_true",
+                    help="N > 1, no GPU: the workers only join their process group and print a made-up line (control flow of the "
+                         "two legs; BENCH_DRY_FAIL=<kind> makes that leg's rank 1 fail, BENCH_DRY_HANG=<kind> makes it hang)")
     ap.add_argument("--reference-benchmark", type=int, nargs="?", const=1023, default=0, metavar="NXY",
                     help="instead of the BASELINE deck: the reference's own transverse scaling benchmark "
                          "(examples/benchmarks/inputs_transverse_benchmark: NXY^2 x 1000 cells, 1 ppc, a fixed_weight_pdf beam of "
@@ -349,6 +527,9 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
 
+    if world > 1 and args.leg is None and not args.spawn_check:
+        return supervise_legs(args, rank, world)
+
     import torch
     import torch.distributed as dist
     if args.spawn_check:
@@ -359,6 +540,9 @@ def main():
             emit({"spawn_check": True, "n_gpus": int(t.item()), "world_size": dist.get_world_size()})
         dist.destroy_process_group()
         return
+
+    if args.dry_legs and args.leg is not None:
+        return dry_leg_worker(args, rank, world)
 
     from hipace_amd import api, decks
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
@@ -388,7 +572,13 @@ def main():
         # group, whose barrier is a kernel plus a wait that may synchronise the whole device -- not usable with --same-device.)
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         try:
-            dist.init_process_group("gloo")
+            import datetime
+            rdzv = os.environ.get("HPS_BENCH_LEG_RDZV")
+            if rdzv:      # a leg's workers meet through a file of their own (the launcher's store belongs to the supervisors)
+                dist.init_process_group("gloo", init_method="file://" + rdzv, rank=rank, world_size=world,
+                                        timeout=datetime.timedelta(seconds=max(60.0, args.leg_timeout)))
+            else:
+                dist.init_process_group("gloo")
             ctl = dist.group.WORLD
         except Exception as exc:      # noqa: BLE001
             print(f"bench.py: no gloo process group ({exc}); using torch's RCCL group", file=sys.stderr)
@@ -456,8 +646,15 @@ def main():
     if world > 1:
         from hipace_amd.pipeline import RingTransport
         progress["phase"] = "ring init"
-        transport = RingTransport(rank, world, local)          # the edges are connected before the clock starts
+        # the edges are connected before the clock starts.  A leg's edge kind is fixed (no fall-back inside a leg: the other
+        # kind has a leg of its own) and proven first: one 4 KB message to the next rank and one from the previous rank, contents
+        # checked -- between two DEVICES this is the first use of the peer mapping (ipc) / the communicators (RCCL)
+        transport = RingTransport(rank, world, local, edge=args.leg)
         progress["transport"] = transport
+        if args.leg is not None:
+            progress["phase"] = "ring probe"
+            if not transport._probe(local, seconds=60.0):
+                raise RuntimeError(f"rank {rank}: the {transport.kind} edge's probe message failed: {transport._probe_error}")
         progress["phase"] = "headline run"
     elif args.ring_self:
         from hipace_amd.pipeline import RcclSelfRing, ring_edge
@@ -593,8 +790,16 @@ def main():
         rccl_ranks_seen = int(on_ring)
         if world > 1:
             rccl_ranks_seen = int(round(reduce_over_ranks(rccl_ranks_seen, dist.ReduceOp.SUM)))
+    rank_devices = None
     if world > 1:
         dt = reduce_over_ranks(dt, dist.ReduceOp.MAX)
+        # which device every rank ran on (PCI bus id as the runtime reports it): the evidence that the edges crossed devices
+        try:
+            mine = f"{local}:{torch.cuda.get_device_properties(local).name}:{_pci_bus_id(local)}"
+        except Exception as exc:      # noqa: BLE001
+            mine = f"{local}:?({exc})"
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, mine)
     st_headline = eng.stats()
     snap = dict(laser_vc=eng.laser_vcycles() if args.config5 else None, pc=eng.pc_stats()[0] if args.config2 else None,
                 sorts=eng.sorts() if args.tile else 0, fallbacks=eng.fallbacks() if args.tile else 0,
@@ -762,6 +967,7 @@ def main():
             "ranks_seen": rccl_ranks_seen,                  # ranks whose two ring edges are connected to a neighbour and carried messages both ways
             "rccl_ranks_seen": rccl_ranks_seen if (transport is not None and transport.kind == "rccl") else None,
             "ranks_on_one_device": bool(args.same_device) if world > 1 else None,
+            "rank_devices": rank_devices,
             "stages_per_rank_on_the_ring": (max(1, args.inflight) if (world > 1 or args.ring_self) else None),
             "roofline": {"bound": "hbm", "kernel": "k_deposit_tiled<2,%d>" % args.tile if args.tile else "k_deposit_current<2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -795,6 +1001,36 @@ def main():
                            "achieved": alg[k] / (ms * 1e-3) / 1e9 if ms > 0 else None,
                            "frac": alg[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None,
                            "counter_bytes": cbk, "frac_counter_bytes": cbk / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if (cbk and ms > 0) else None}
+                if k == "mg_solve1" and ms > 0:
+                    # SURVEY 8(d)'s bytes are those of the REFERENCE's pass structure; the fused smoothers move about half of
+                    # them.  `frac` is what the kernels move (counter bytes) over their time; the survey-bytes figure is kept
+                    # beside it under its own name
+                    rows[k]["frac_reference_passes"] = rows[k]["frac"]
+                    if cbk:
+                        rows[k]["achieved"] = cbk / (ms * 1e-3) / 1e9
+                        rows[k]["frac"] = rows[k]["frac_counter_bytes"]
+                        rows[k]["frac_is_of"] = "counter bytes (what the kernels move); frac_reference_passes: SURVEY 8(d)'s bytes of the reference's passes"
+                if k == "poisson" and ms > 0:
+                    # SURVEY 8(d) prices a solve at 4 transform passes (16 B per cell each); this build makes 3 passes -- DST along
+                    # x, tridiagonal solves along y (k_tridiag_y, + its 8 B per cell table), DST along x
+                    moved = 3 * (3 * 16 + 8) * C_
+                    rows[k]["kernels"] = "3 solves: DST along x (k_dst_rows*, sources formed in the pass), tridiagonal solves along y (k_tridiag_y), DST along x"
+                    rows[k]["bytes_this_build_has_to_move"] = moved
+                    rows[k]["frac_of_bytes_this_build_has_to_move"] = moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                if k == "advance_plasma" and ms > 0:
+                    # the push against BOTH roofs: HBM above, fp64 VALU here
+                    fl = pmc_fp64("void hps::k_advance_tiled<2, 16, false, false, false") if headline else None
+                    if fl:
+                        simd_clk = 256 * 4 * 2.4e9 * (ms * 1e-3)       # SIMD-cycles of the launch
+                        rows[k].update({"flops": fl["flops"], "achieved_tflops": fl["flops"] / (ms * 1e-3) / 1e12,
+                                        "peak_fp64_valu_tflops": FP64_VALU_PEAK_TFLOPS,
+                                        "frac_fp64_valu": fl["flops"] / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                        "flops_per_particle": fl["flops"] / (args.ppc * args.ppc * C_),
+                                        # issue slots: a wave instruction holds its SIMD's 16 lanes for 4 cycles
+                                        "frac_simd_issue_fp64": 4.0 * fl["fp64_wave_instructions"] / simd_clk,
+                                        "frac_simd_issue_all_valu": 4.0 * fl["valu_wave_instructions"] / simd_clk,
+                                        "flops_source": f"profiles/{PMC_FP64}: SQ_INSTS_VALU_ADD/MUL/FMA/TRANS_F64 per launch x 64 lanes, FMA = 2 "
+                                                        "(committed rocprofv3 --pmc summary, not collected in this run)"})
             out["roofline"]["per_kernel"] = rows
             out["roofline"]["dominant_by_time"] = max(rows, key=lambda k: rows[k]["us_per_slice"])
             out["roofline"]["furthest_below_the_roofline"] = min((k for k in rows if rows[k]["frac"]), key=lambda k: rows[k]["frac"])
@@ -838,4 +1074,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -227,6 +227,47 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     assert bad.returncode != 0 and "--gpus 2" in bad.stderr
 
 
+@pytest.mark.parametrize("fault", ["none", "fail_ipc", "hang_rccl", "fail_both"])
+def test_bench_runs_one_leg_per_edge_kind_and_survives_a_failed_leg(fault):
+    """`bench.py --gpus 2` measures once per kind of ring edge (ipc, rccl), each leg in worker processes of its own
+    (bench.py::supervise_legs); a leg whose worker raises, or never comes back, is recorded with its error and does not take
+    the other leg's number with it.  --dry-legs: the control flow only (gloo, no GPU)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if fault == "fail_ipc":
+        env["BENCH_DRY_FAIL"] = "ipc"
+    elif fault == "hang_rccl":
+        env["BENCH_DRY_HANG"] = "rccl"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-legs", "--leg-timeout", "15"]
+    if fault == "fail_both":
+        # both legs fail: one line all the same, value null, exit code 1
+        env["BENCH_DRY_FAIL"] = "ipc"
+        cmd += ["--edge", "ipc"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (out.stdout[-500:], out.stderr[-2000:])
+    d = json.loads(lines[0])
+    e = d["ring_edges"]
+    if fault == "none":
+        assert out.returncode == 0
+        assert d["ring_edge"] == d["value_is_of_edge"] == "ipc" and d["value"] == e["ipc"]["value"] > e["rccl"]["value"] > 0
+        assert d["rccl_ranks_seen"] == 2 and "error" not in e["ipc"] and "error" not in e["rccl"]
+    elif fault == "fail_ipc":
+        assert out.returncode == 0
+        assert d["ring_edge"] == "rccl" and d["value"] == e["rccl"]["value"] > 0 and d["rccl_ranks_seen"] == 2
+        assert e["ipc"]["value"] is None and "exited with code" in e["ipc"]["error"]
+    elif fault == "hang_rccl":
+        assert out.returncode == 0
+        assert d["ring_edge"] == "ipc" and d["value"] == e["ipc"]["value"] > 0
+        assert e["rccl"]["value"] is None and "killed" in e["rccl"]["error"]
+        assert d["rccl_ranks_seen"] is None and "killed" in d["rccl_ranks_seen_note"]
+    else:
+        assert out.returncode != 0 and d["value"] is None and "error" in d
+        assert e["ipc"]["value"] is None and "skipped" in e["rccl"]
+
+
 def test_openpmd_json_document(tmp_path):
     """hipace_amd/openpmd_writer.py with json_too: the iteration in the layout of openPMD-api's JSON backend -- groups as nested
     objects, attributes as {"datatype", "value"}, datasets as {"datatype", "data"}, constant components as value + shape --
