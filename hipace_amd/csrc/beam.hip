@@ -32,7 +32,7 @@ struct BeamPushConsts {
 template <int ORDER>
 __global__ __launch_bounds__(256)
 void k_beam_deposit_dyn (SlabView f, BeamSoA b, const long* __restrict__ B, const int* __restrict__ nfront, int p,
-                         int cjx, int cjy, int cjz, double q_invvol, double clightsq_inv, PartConsts k)
+                         int cjx, int cjy, int cjz, double q_invvol, double clightsq_inv, PartConsts k, int* disturbed)
 {
     const long first = B[p] + nfront[p], count = B[p + 1] - first;
     for (long t = (long)blockIdx.x*blockDim.x + threadIdx.x; t < count; t += (long)gridDim.x*blockDim.x) {
@@ -41,6 +41,9 @@ void k_beam_deposit_dyn (SlabView f, BeamSoA b, const long* __restrict__ B, cons
     const double ux = b.ux[ip], uy = b.uy[ip], uz = b.uz[ip];
     const double gaminv = 1.0/sqrt(1.0 + ux*ux*clightsq_inv + uy*uy*clightsq_inv + uz*uz*clightsq_inv);
     const double wq = q_invvol*b.w[ip];
+    // (predictor-corrector loop: Engine::d_pc_dist, as k_beam_deposit)
+    if (disturbed && ((cjx >= 0 && (wq*(ux*gaminv) != 0.0 || wq*(uy*gaminv) != 0.0)) || (cjz >= 0 && wq*(uz*gaminv) != 0.0)))
+        __hip_atomic_store(disturbed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double sx[ORDER + 1], sy[ORDER + 1];
     const int i0 = shape_weights<ORDER>((b.x[ip] - k.xoff)*k.dx_inv, sx);
     const int j0 = shape_weights<ORDER>((b.y[ip] - k.yoff)*k.dy_inv, sy);
@@ -286,7 +289,7 @@ int beam_deposit_moving (Engine& E, int p, int cjx, int cjy, int cjz)
     const PartConsts k = base_consts(E.gm);
     const double q_invvol = E.d.beam_charge*(E.d.si_units ? 1.0/(E.gm.dx*E.gm.dy*E.gm.dz) : 1.0), csq_inv = 1.0/(E.gm.c*E.gm.c);
     const dim3 grid((unsigned)std::min<long>(ceil_div(bound, 256), 2048)), block(256);
-#define CALL(O) hipLaunchKernelGGL(k_beam_deposit_dyn<O>, grid, block, 0, E.st, f, E.bm, E.d_B, E.d_nfront, p, cjx, cjy, cjz, q_invvol, csq_inv, k)
+#define CALL(O) hipLaunchKernelGGL(k_beam_deposit_dyn<O>, grid, block, 0, E.st, f, E.bm, E.d_B, E.d_nfront, p, cjx, cjy, cjz, q_invvol, csq_inv, k, E.d_pc_dist)
     HPS_BEAM_ORDER(E.d.order, CALL)
 #undef CALL
     return HPS_OK;

@@ -133,6 +133,7 @@ struct Engine {
     // predictor-corrector Bx/By (hipace.bxby_solver = predictor-corrector): d_pc = {sum |B|, sum |B - B_iter|, halo
     // fallback counter (int), spare}, h_pc its pinned image read back once per iteration
     // device-side control of the loop (HPS_PC_SPECULATE=0: off): per-iteration flags, iterations enqueued ahead of the host
+    int* d_pc_dist = nullptr;  // predictor-corrector: device word "something other than rounding residue has been deposited in this sweep" (Engine::create)
     double pc_floor = 0.0;     // sum |B| below this is the exact zero of the serial path (Engine::create)
     int* d_pc_go = nullptr; bool pc_speculate = false; int pc_spec_iters = 1, pc_enqueued = 0, pc_islice = -1; double pc_base_seq = 0.0, pc_last_err = 0.0;
     int solve_slice_pc_begin (int islice); int solve_slice_pc_finish (int islice); int pc_enqueue_iteration (int it); int pc_wait_slot (int slot, double seq);

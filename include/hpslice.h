@@ -305,12 +305,15 @@ int hps_engine_stats (void* handle, long* total_vcycles, long* slices_done);
 /* predictor-corrector: iterations so far and the sum over slices of the final relative B-field error
  * (m_predcorr_avg_iterations / m_predcorr_avg_B_error of Hipace.cpp:964,1028 before the division by nz) */
 int hps_engine_pc_stats (void* handle, long* iterations, double* error_sum);
-/* Slices whose loop left after ONE pass because sum |B| was 0: exactly, or below the engine's rounding floor.  The reference's
- * rule is relative_Bfield_error = norm_B > 0 ? diff/norm_B : 0 (fields/Fields.cpp:1283); on the serial CPU path norm_B IS 0
- * ahead of the driver (electron and ion charge cancel term by term), a scatter with atomics leaves 1e-16 residue there.  The
- * engine treats sum |B| <= 1e-12 mu0 c |q n0| nx ny (nx dx) -- built from the first species' deck density, so a deck whose
- * density is 0 or lives in a profile has floor 0 = the literal rule -- as that zero (HPS_PC_NOISE_FLOOR=<relative floor>, 0 =
- * literal rule).  This counter says how often that happened. */
+/* Slices whose loop left after ONE pass because sum |B| of the guess was 0.  The reference's rule is relative_Bfield_error =
+ * norm_B > 0 ? diff/norm_B : 0 (fields/Fields.cpp:1283), and the engine applies it literally.  On the serial CPU path norm_B IS 0
+ * ahead of the driver (electron and ion charge cancel term by term); a scatter with atomics leaves 1e-16 residue there.  The
+ * engine therefore keeps one device word per sweep, "only the cold plasma's residue has been deposited so far" (cleared by
+ * hps_engine_begin_step; set by the beam's deposition when a term is not exactly zero, and from the first slice on with a grid
+ * current, a second species or no neutralising background), and while it is clear stores the exact zero the serial path holds
+ * into Bx, By at the end of a loop pass -- so norm_B is exactly 0 on the same slices as on the CPU, and a real but tiny norm_B
+ * (a moving beam's head) iterates as it does there.  HPS_PC_EXACT_ZERO=0 turns that off; HPS_PC_NOISE_FLOOR=<relative floor>
+ * (rounds 4-5: 1e-12 of mu0 c |q n0| nx ny (nx dx); now 0) is kept as a diagnostic.  This counter says how often norm_B was 0. */
 int hps_engine_pc_zero_b_slices (void* handle, long* slices);
 /* laser: index of the slab component "aabs" (-1 without a laser) and sum |a| over the slices solved in this step
  * (the "laserEnvelope" checksum; needs hps_engine_set_diagnostics; synchronises the stream) */

@@ -207,12 +207,12 @@ def test_config2_whole_box_vs_oracle_fixture(api):
 def test_config2_baseline_deck_whole_box_vs_oracle_fixture(api):
     """The BASELINE deck itself (driver 54 slices into the box).  Ahead of the driver the serial CPU path holds exact zeros
     and its loop leaves after one pass (ComputeRelBFieldError returns 0 for sum|B| = 0, fields/Fields.cpp:1283), also on the
-    first slice with beam; a scatter with atomics leaves 1e-16 residue there.  The engine takes sum|B| at that rounding floor
-    for the zero it stands for (Engine::pc_floor, HPS_PC_NOISE_FLOOR), so the loop follows the CPU's path: the same number
-    of iterations and the box to 1e-6.  (With the literal rule the loop iterates on the noise to max_iterations on every
-    slice ahead of the driver -- 2400-2500 iterations instead of 1631 -- and enters the driver on another path: the two runs
-    then agree to per cents only: profiles/r04_config2_literal_rule.json against r04_config2_noise_floor.json; the measured deviations
-    of the shipped build: profiles/r05_fullsize_config2.json.)"""
+    first slice with beam; a scatter with atomics leaves 1e-16 residue there.  Round 6: the engine keeps one device word "only
+    the cold plasma's residue has been deposited in this sweep so far" (Engine::d_pc_dist, set by the beam's deposition) and
+    while it is clear stores the serial path's exact zero into Bx, By -- the reference's literal rule then leaves the loop after
+    one pass on the same slices as the CPU, no magnitude floor (HPS_PC_NOISE_FLOOR is 0 now): the same number of iterations
+    and the box to 1e-6.  (HPS_PC_EXACT_ZERO=0: the literal rule on the residue -- 2400-2500 iterations instead of 1631, the
+    driver entered on another path, per cents apart: profiles/r04_config2_literal_rule.json.)"""
     fx, got = _run_box(api, "config2")
     bad, worst, worst_trace = _compare(fx, got, int_keys=("n_valid", "n_particles", "pc_iterations"), soft_int_keys=())
     print(f"config2 (BASELINE deck): worst checksum deviation {worst:.2e}, worst plane-sum deviation {worst_trace:.2e}, PC iterations "
