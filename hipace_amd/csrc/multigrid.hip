@@ -1598,6 +1598,80 @@ void k_hierarchy_gradpsi (FView acf0, int nx0, int ny0, PyrOut out, int nlev_out
     gradpsi_sxsy_cell(f, ga, bxs*256 + (int)threadIdx.x - f.ng, row - f.ng);
 }
 
+// ---- node-centred coefficient hierarchy in one launch (round 6) ------------------------------------------------------------
+// average_down_acoef on the 2^K - 1 grids (HpMultiGrid.cpp:1640-1700 with the 9-point full weighting of the nodal levels) was one
+// k_restrict launch per level: five dependent 5-us launches per solve at 1023^2 (26 us of the slice).  Here a workgroup owns
+// NB x NB nodes of the coarsest level wanted (level np) and everything below them: with s = np - l, level l's nodes
+// [T0 2^s, (T0 + NB) 2^s) are its to write, and it needs [T0 2^s - c_l, (T0 + NB) 2^s) with c_l = 2^s - 1 of them (the 3 x 3
+// stencils of the nodes above reach one node further down-left per level): a (NB 2^np + 2^np - 1)^2 window of level 0 goes to
+// LDS (95^2 for np = 5, NB = 2: 2.2 x the plane's 8 MB, once), every level is formed there with the same expression and
+// operand order as restrict_at<false> -- the nodes outside a level's unknowns are never needed by a coarser unknown -- and
+// the owned unknowns go to their level's plane.  Fine window index of node 2i - 1 is 2 (i - lo_l): no index arithmetic.
+constexpr int NPYR_MAX = 5, NPYR_NB = 2;
+struct NodalPyr { FView lev[NPYR_MAX]; int vhx[NPYR_MAX + 1], vhy[NPYR_MAX + 1]; int np; };      // vh*[l]: last unknown of level l (first: 1)
+
+template <int NP>       // (compile-time level count: the window widths are constants, the index divisions multiplications)
+__global__ __launch_bounds__(256)
+void k_nodal_acf_pyramid (FView f0, NodalPyr o, unsigned long long* zero, int nzero)
+{
+    extern __shared__ double npyr_lds[];
+    constexpr int np = NP;
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && blockIdx.y == 0) for (int w = tid; w < nzero; w += 256) zero[w] = 0ULL;      // the solve's norm slots
+    const int T0x = blockIdx.x*NPYR_NB, T0y = blockIdx.y*NPYR_NB;
+    // level 0 window
+    int w = NPYR_NB*(1 << np) + (1 << np) - 1;
+    int lox = T0x*(1 << np) - ((1 << np) - 1), loy = T0y*(1 << np) - ((1 << np) - 1);
+    double* cur = npyr_lds;
+    // (eight loads of a thread in flight before the first LDS store: one load per trip was 35 dependent round trips per workgroup
+    //  -- the launch took what the five k_restrict launches it replaces had taken)
+    for (int e0 = tid; e0 < w*w; e0 += 8*256) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = min(e0 + 256*u, w*w - 1);
+            const int lj = e / w, li = e - lj*w;
+            const int i = lox + li, j = loy + lj;
+            const bool in = (i >= 1 && i <= o.vhx[0] && j >= 1 && j <= o.vhy[0]);
+            const double x = f0(min(max(i, 1), o.vhx[0]), min(max(j, 1), o.vhy[0]), 0);
+            v[u] = in ? x : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + 256*u; if (e < w*w) cur[e] = v[u]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 1; l <= np; ++l) {
+        const int s = np - l;
+        const int wl = NPYR_NB*(1 << s) + (1 << s) - 1;
+        const int lxl = T0x*(1 << s) - ((1 << s) - 1), lyl = T0y*(1 << s) - ((1 << s) - 1);
+        const int ox = T0x*(1 << s), oy = T0y*(1 << s);          // first owned node
+        double* nxt = cur + w*w;
+        const FView& out = o.lev[l - 1];
+        for (int e = tid; e < wl*wl; e += 256) {
+            const int lj = e / wl, li = e - lj*wl;
+            const int i = lxl + li, j = lyl + lj;
+            double v = 0.0;
+            if (i >= 1 && i <= o.vhx[l] && j >= 1 && j <= o.vhy[l]) {
+                const double* f = cur + (2*lj)*w + 2*li;             // node (2i - 1, 2j - 1) of the finer window
+                v = (1./16.)*(f[0] + 2.*f[1] + f[2]
+                            + 2.*f[w] + 4.*f[w + 1] + 2.*f[w + 2]
+                            + f[2*w] + 2.*f[2*w + 1] + f[2*w + 2]);
+                if (i >= ox && j >= oy) out(i, j, 0) = v;
+            }
+            if (l < np) nxt[e] = v;
+        }
+        __syncthreads();
+        cur = nxt; w = wl;
+    }
+}
+static size_t nodal_pyramid_lds (int np)
+{
+    size_t n = 0;
+    for (int l = 0; l < np; ++l) { const int s = np - l; const size_t w = (size_t)NPYR_NB*(1 << s) + (1 << s) - 1; n += w*w; }
+    return n*sizeof(double);
+}
+
 // inverse diagonals of a cell-centred level (grids whose level A lies below the pyramid kernel's five levels)
 __global__ void k_level_cinv (const double* __restrict__ acf, double* __restrict__ cinv, int nx, int ny, double fx, double fy)
 {
@@ -1624,6 +1698,7 @@ struct Multigrid {
     bool cc; int nx, ny; double dx, dy;
     bool post_fold = false; unsigned int* d_post_counter = nullptr;     // k_post_norms' work in the last V-cycle's level-0 launch (HPS_MG_POST_FOLD=1; measured: 1474 against 1481 slices/s, off)
     bool hierarchy_ready = false;               // mg_solve1_prepare has enqueued the coefficient hierarchy of the next solve
+    bool nodal_pyramid = false;                 // node-centred grids: the coefficient hierarchy in one launch (k_nodal_acf_pyramid; HPS_MG_NODAL_PYRAMID=0: off)
     std::vector<MGLevelDev> L;
     int lowv_begin = 1;                         // first level handled by k_lower_v
     LowLev* d_low = nullptr; size_t low_lds = 0;
@@ -1693,6 +1768,12 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
         if (!ok) break;
     }
     if (M->nlev() < 2) { delete M; set_error("hps_mg_create: grid too small to coarsen"); return HPS_ERR_ARG; }
+    if (!M->cc) {
+        const char* v = getenv("HPS_MG_NODAL_PYRAMID");
+        M->nodal_pyramid = !(v && atoi(v) == 0);
+        if (M->nodal_pyramid)
+            HPS_HIP_CHECK(hipFuncSetAttribute((const void*)k_nodal_acf_pyramid<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nodal_pyramid_lds(NPYR_MAX)));
+    }
     if (const char* e = getenv("HPS_MG_SMALL_CELLS")) M->small_tile_cells = atol(e);
     if (const char* e = getenv("HPS_MG_INIT_HUGE")) M->init_huge = atoi(e) != 0;
     if (const char* e = getenv("HPS_MG_POST_FOLD")) M->post_fold = atoi(e) != 0;
@@ -1975,6 +2056,22 @@ static int solve1_hierarchy (Multigrid* M, int max_iters, hipStream_t st, const 
         } else
         hipLaunchKernelGGL(k_acf_pyramid, dim3(ceil_div(M->nx, 32), ceil_div(M->ny, 32)), dim3(256), 0, st, M->acf0, M->nx, M->ny, po, np,
                            M->d_norms, nzero_words);
+        first = np + 1;
+    } else if (M->nodal_pyramid && lb >= 1) {
+        // node-centred: levels 1..min(lb, 5) in one launch, the norm slots zeroed by it too
+        NodalPyr o{};
+        const int np = std::min(lb, NPYR_MAX);
+        o.np = np;
+        o.vhx[0] = M->L[0].b.vhx; o.vhy[0] = M->L[0].b.vhy;
+        for (int il = 1; il <= np; ++il) { o.lev[il-1] = M->lv(il, M->L[il].acf); o.vhx[il] = M->L[il].b.vhx; o.vhy[il] = M->L[il].b.vhy; }
+        const int tx = ceil_div(M->L[np].b.hix, NPYR_NB), ty = ceil_div(M->L[np].b.hiy, NPYR_NB);      // top-level nodes 0..hi - 1 (0: wall)
+        switch (np) {
+            case 1: hipLaunchKernelGGL(k_nodal_acf_pyramid<1>, dim3(tx, ty), dim3(256), nodal_pyramid_lds(np), st, M->acf0, o, M->d_norms, nzero_words); break;
+            case 2: hipLaunchKernelGGL(k_nodal_acf_pyramid<2>, dim3(tx, ty), dim3(256), nodal_pyramid_lds(np), st, M->acf0, o, M->d_norms, nzero_words); break;
+            case 3: hipLaunchKernelGGL(k_nodal_acf_pyramid<3>, dim3(tx, ty), dim3(256), nodal_pyramid_lds(np), st, M->acf0, o, M->d_norms, nzero_words); break;
+            case 4: hipLaunchKernelGGL(k_nodal_acf_pyramid<4>, dim3(tx, ty), dim3(256), nodal_pyramid_lds(np), st, M->acf0, o, M->d_norms, nzero_words); break;
+            default: hipLaunchKernelGGL(k_nodal_acf_pyramid<5>, dim3(tx, ty), dim3(256), nodal_pyramid_lds(np), st, M->acf0, o, M->d_norms, nzero_words); break;
+        }
         first = np + 1;
     } else {
         HPS_HIP_CHECK(hipMemsetAsync(M->d_norms, 0, nzero_words*sizeof(unsigned long long), st));

@@ -1351,7 +1351,7 @@ void k_transpose (const double* __restrict__ src, double* __restrict__ dst, int 
 // =================================================================================================
 struct TriArgs {
     double* plane[DST_MAXPLANES]; long pitch;        // row-major [j][k] planes, solved in place
-    const double* cp;                                // [ny][nx] LU factors c'_j(k)
+    const double* cp;                                // [ny][pitch] LU factors c'_j(k)
     double alpha;
     int nx, ny, nseg;
     const int* gate;
@@ -1372,7 +1372,7 @@ void k_tridiag_y (TriArgs a)
     for (int i = 0; i < M; ++i) {
         const int jc = min(j0 + i, a.ny - 1);
         e[i] = p[(long)jc*a.pitch + kc];
-        c[i] = a.cp[(long)jc*a.nx + kc];
+        c[i] = a.cp[(long)jc*a.pitch + kc];
     }
     // rows past the plane: identity rows (c' = 0, f = 0)
 #pragma unroll
@@ -1423,6 +1423,14 @@ struct TriImpl { int M, cols; tri_kernel_t kernel; };
 // rows per thread by plane height: at most 64 segments per column
 static TriImpl find_tri_impl (int ny)
 {
+    // (A/B: HPS_TRI_M, HPS_TRI_COLS pick another instantiated shape that still covers the plane with <= 64 segments)
+    {   const char* vm = getenv("HPS_TRI_M"); const char* vc = getenv("HPS_TRI_COLS");
+        if (vm || vc) {
+            const int m = vm ? atoi(vm) : 16, c = vc ? atoi(vc) : 16;
+            static const TriImpl all[] = {{4, 16, k_tridiag_y<4, 16>}, {8, 16, k_tridiag_y<8, 16>}, {16, 16, k_tridiag_y<16, 16>}, {32, 8, k_tridiag_y<32, 8>},
+                                          {16, 8, k_tridiag_y<16, 8>}, {16, 4, k_tridiag_y<16, 4>}, {8, 8, k_tridiag_y<8, 8>}, {32, 4, k_tridiag_y<32, 4>}};
+            for (const TriImpl& t : all) if (t.M == m && t.cols == c && (long)m*64 >= ny) return t;
+        } }
     if (ny <= 256) return TriImpl{4, 16, k_tridiag_y<4, 16>};
     if (ny <= 512) return TriImpl{8, 16, k_tridiag_y<8, 16>};
     if (ny <= 1024) return TriImpl{16, 16, k_tridiag_y<16, 16>};
@@ -1665,6 +1673,7 @@ struct Poisson {
     double *S_x = nullptr, *S_y = nullptr;             // dense back-end: [n][n] sine matrices (S_y = S_x if nx == ny)
     // y direction as tridiagonal solves (k_tridiag_y; HPS_POISSON_TRIDIAG=0: off): needs a transform along x only
     tri_kernel_t ktri = nullptr; int tri_M = 0, tri_cols = 0; double* tri_cp = nullptr; double tri_alpha = 0.0;
+    long pa = 0;                        // row pitch of the intermediate planes between the x passes (own kernels: nx rounded up to whole 128-byte lines; dense: nx)
     bool tri () const { return ktri != nullptr; }
     long long* dbg = nullptr;
     const int* gate = nullptr;          // poisson_set_gate: the launches of the following solves return at once when *gate == 0
@@ -1775,13 +1784,14 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
                                 return allow_own && ti.kernel && !(v && atoi(v) == 0) && !getenv("HPS_POISSON_MFMA") && !getenv("HPS_POISSON_COLS"); }();
     auto make_tri = [&] () -> int {
         // LU factors of tridiag(1, b_k, 1) in extended precision, rounded once: c'_0 = 1/b, c'_j = 1/(b - c'_{j-1})
-        std::vector<double> h((size_t)nx*ny);
+        const long pa = P->pa;            // (the table has the planes' pitch: same addresses modulo a line, pad columns 0)
+        std::vector<double> h((size_t)pa*ny, 0.0);
         const long double pi = 3.14159265358979323846264338327950288L;
         for (int k = 0; k < nx; ++k) {
             const long double sk = sinl(pi*(k + 1)/(2.0L*(nx + 1)));
             const long double b = -2.0L - 4.0L*sk*sk*((long double)dy*dy)/((long double)dx*dx);
             long double cprev = 0.0L;
-            for (int j = 0; j < ny; ++j) { cprev = 1.0L/(b - cprev); h[(size_t)j*nx + k] = (double)cprev; }
+            for (int j = 0; j < ny; ++j) { cprev = 1.0L/(b - cprev); h[(size_t)j*pa + k] = (double)cprev; }
         }
         HPS_HIP_CHECK(hipMalloc(&P->tri_cp, h.size()*sizeof(double)));
         HPS_HIP_CHECK(hipMemcpy(P->tri_cp, h.data(), h.size()*sizeof(double), hipMemcpyHostToDevice));
@@ -1789,7 +1799,9 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
         P->tri_alpha = dy*dy/(2.0*(nx + 1));
         return HPS_OK;
     };
+    P->pa = nx;
     if (ix && want_tri) {
+        P->pa = ((long)nx + 15)/16*16;        // rows of the intermediate planes start on 128-byte lines (nx = 2^K - 1: 24.7 -> 18 us for the y solves)
         P->kx = ix->kernel; P->kx_src = ix->src;
         int e;
         size_t nax, nbx;
@@ -1800,7 +1812,7 @@ int poisson_create (int nx, int ny, double dx, double dy, bool allow_own, Poisso
         P->lds_x = ((size_t)ix->T*Nx + nax + nbx + (ix->pow2 ? Nx : 0))*sizeof(double2);
         for (dst_kernel_t kf : {P->kx, P->kx_src})
             if (kf && P->lds_x > 64*1024) HPS_HIP_CHECK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_x));
-        HPS_HIP_CHECK(hipMalloc(&P->buf_a, ((size_t)DST_MAXPLANES*nx*ny + 64)*sizeof(double)));
+        HPS_HIP_CHECK(hipMalloc(&P->buf_a, ((size_t)DST_MAXPLANES*P->pa*ny + 64)*sizeof(double)));
     } else
     if (ix && iy) {
         P->kx = ix->kernel; P->ky = iy->kernel; P->kx_src = ix->src;
@@ -1994,8 +2006,8 @@ int poisson_solve_batch_src (void* handle, int nb, const PoissonSrc* spec, long 
 static void launch_tri (Poisson* P, int nb, hipStream_t st)
 {
     TriArgs t{};
-    for (int b = 0; b < nb; ++b) t.plane[b] = P->buf_a + (long)b*P->nx*P->ny;
-    t.pitch = P->nx; t.cp = P->tri_cp; t.alpha = P->tri_alpha; t.nx = P->nx; t.ny = P->ny;
+    for (int b = 0; b < nb; ++b) t.plane[b] = P->buf_a + (long)b*P->pa*P->ny;
+    t.pitch = P->pa; t.cp = P->tri_cp; t.alpha = P->tri_alpha; t.nx = P->nx; t.ny = P->ny;
     t.nseg = ceil_div(P->ny, P->tri_M); t.gate = P->gate;
     hipLaunchKernelGGL(P->ktri, dim3(ceil_div(P->nx, P->tri_cols), nb), dim3(P->tri_cols*t.nseg), 0, st, t);
 }
@@ -2079,8 +2091,9 @@ static int poisson_solve_batch_impl (Poisson* P, int nb, const double* const* sr
         return HPS_OK;
     }
     // 1: DST along x of the sources -> A
-    for (int b = 0; b < nb; ++b) { a.src[b] = spec ? nullptr : src[b]; a.dst[b] = P->buf_a + b*plane; }
-    a.src_pitch = src_pitch; a.dst_pitch = nx; a.scale = nullptr; a.fa = P->fa_x; a.fb = P->fb_x; a.tw = P->tw_x; a.isin4 = P->isin_x;
+    const long pa = P->tri() ? P->pa : (long)nx, plane_a = P->tri() ? pa*ny : plane;
+    for (int b = 0; b < nb; ++b) { a.src[b] = spec ? nullptr : src[b]; a.dst[b] = P->buf_a + b*plane_a; }
+    a.src_pitch = src_pitch; a.dst_pitch = pa; a.scale = nullptr; a.fa = P->fa_x; a.fb = P->fb_x; a.tw = P->tw_x; a.isin4 = P->isin_x;
     a.ma = P->ma_x; a.mb = P->mb_x;
     a.rows_per_plane = ny; a.nplanes = nb;
     if (spec) {
@@ -2127,8 +2140,8 @@ static int poisson_solve_batch_impl (Poisson* P, int nb, const double* const* sr
         hipLaunchKernelGGL(k_transpose, dim3(ceil_div(ny, 32), ceil_div(nx, 32), nb), dim3(256), 0, st, P->buf_b, P->buf_a, nx, ny, plane);
     }
     // 6: DST along x -> destination planes
-    for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_a + b*plane; a.dst[b] = dst[b]; }
-    a.src_pitch = nx; a.dst_pitch = dst_pitch; a.fa = P->fa_x; a.fb = P->fb_x; a.tw = P->tw_x; a.isin4 = P->isin_x;
+    for (int b = 0; b < nb; ++b) { a.src[b] = P->buf_a + b*plane_a; a.dst[b] = dst[b]; }
+    a.src_pitch = pa; a.dst_pitch = dst_pitch; a.fa = P->fa_x; a.fb = P->fb_x; a.tw = P->tw_x; a.isin4 = P->isin_x;
     a.ma = P->ma_x; a.mb = P->mb_x;
     a.rows_per_plane = ny;
     hipLaunchKernelGGL(P->kx, rows_grid(ny*nb, P->tx), dim3(P->ntx), P->lds_x, st, a);
