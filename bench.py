@@ -152,6 +152,60 @@ def pmc_fp64(kernel_prefix):
     return None
 
 
+CONFIG5_ROWS = (   # row, what, kernel-name patterns (mangled names of the committed kernel trace), bytes per slice as f(C cells, Pe electrons, Pi ions) or None
+    ("advance_plasma_electrons", "k_advance_tiled<LASER> of the electron sheet (the electrons the dopant has released ride in its tail)",
+     ("k_advance_tiledILi2ELi16ELb1ELb0E",), lambda C, Pe, Pi: 128 * Pe + 6 * 8 * C),
+    ("advance_plasma_ions_adk", "k_advance_tiled<LASER, IONIZE> of the N dopant: gather, ADK decision per macro-atom, push (tiles without field above threshold skip)",
+     ("k_advance_tiledILi2ELi16ELb1ELb1E", "k_ion_field_bounds", "k_ionize"), lambda C, Pe, Pi: 136 * Pi + 6 * 8 * C),
+    ("deposit_current_both_species", "k_deposit_tiled<LASER>, one launch per species and slice",
+     ("k_deposit_tiled",), lambda C, Pe, Pi: 56 * (Pe + Pi) + 2 * 5 * 8 * C),
+    ("explicit_deposit_both_species", "k_explicit_tiled<LASER>, one launch per species and slice",
+     ("k_explicit_tiled",), lambda C, Pe, Pi: 56 * (Pe + Pi) + 2 * 7 * 8 * C),
+    ("envelope_solve", "the slice's envelope advance on the engine's laser stream: right-hand side, phases, the solve (hpmg type 2: k2_*; fft: rocFFT's "
+                       "fft_rtc / transpose_rtc kernels + k_laser_divide), store, |a|^2",
+     ("k2_", "k_laser_", "fft_rtc", "transpose_rtc"), None),
+    ("poisson", "3 solves: DST along x, tridiagonal solves along y, DST along x", ("k_dst_", "k_tridiag", "k_dense"), lambda C, Pe, Pi: 3 * (3 * 16 + 8) * C),
+    ("mg_solve1", "hpmg solve1 of Bx, By", ("k_smooth", "k_lower_v", "k_post_norms", "k_hierarchy_gradpsi"), None),
+    ("sort_slab_other", "re-sorts (both species), slab shift / zero, fills and copies", ("rocprim", "k_permute", "k_cell_keys", "k_shift_zero", "k_tile_", "k_run_starts",
+                                                                                             "k_rank_keys", "fillBuffer", "copyBuffer"), None),
+)
+
+
+def config5_rows(si, solver, n, ppc2):
+    """roofline.per_kernel of a config-5 run from the COMMITTED rocprofv3 --kernel-trace summary of the same command (profiles/
+    r06_config5_<units>_<solver>_kernel_stats.csv: scripts/quick_prof.sh): kernel time per slice of every group of kernels -- the ion
+    species' push with its ADK decisions and the envelope solve as rows of their own; the envelope's kernels run on a second stream
+    beside the slice's chain, so the rows add up to more than a slice takes.  None without the summary."""
+    import csv
+    name = f"r06_config5_{'si' if si else 'norm'}_{'mg' if solver == 'multigrid' else 'fft'}_kernel_stats.csv"
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path) or n != 1024:
+        return None
+    rows_csv = list(csv.DictReader(open(path)))
+    nsl = next((int(r["Calls"]) for r in rows_csv if "k_laser_rhs" in r["Name"]), 0)
+    if not nsl:
+        return None
+    C = n * n
+    Pe, Pi = ppc2 * C, C
+    out, used = {}, set()
+    for key, what, pats, fb in CONFIG5_ROWS:
+        ns = 0.0
+        launches = 0
+        for i, r in enumerate(rows_csv):
+            if i not in used and any(p in r["Name"] for p in pats):
+                used.add(i)
+                ns += float(r["TotalDurationNs"])
+                launches += int(r["Calls"])
+        us = ns / nsl / 1e3
+        b = fb(C, Pe, Pi) if fb else None
+        out[key] = {"kernels": what, "us_per_slice": us, "launches_per_slice": launches / nsl, "algorithmic_bytes": b,
+                    "achieved": b / (us * 1e-6) / 1e9 if (b and us > 0) else None,
+                    "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if (b and us > 0) else None}
+    rest = sum(float(r["TotalDurationNs"]) for i, r in enumerate(rows_csv) if i not in used and "k_laser_init" not in r["Name"] and "k_pool_spin" not in r["Name"])
+    out["unlisted_kernels"] = {"us_per_slice": rest / nsl / 1e3}
+    return out, f"profiles/{name} (rocprofv3 --kernel-trace of `bench.py --config5{' --si' if si else ''}{' --laser-solver multigrid' if solver == 'multigrid' else ''}`, {nsl} slices incl. the warm-up box; committed summary, not collected in this run)"
+
+
 PHASE_OF_KERNEL = (("k_deposit_tiled", "deposit_current"), ("k_explicit_tiled", "explicit_deposit"), ("k_advance", "advance_plasma"),
                    ("k_dst_", "poisson"), ("k_tridiag", "poisson"), ("k_transpose", "poisson"), ("rocfft", "poisson"), ("k_dense", "poisson"),
                    ("k_smooth", "mg_solve1"), ("k_lower", "mg_solve1"), ("k_copy2", "mg_solve1"), ("k_post_norms", "mg_solve1"),
@@ -1039,6 +1093,16 @@ def main():
                                                   + (f" in a window of {phase_window['slices']} slices behind the timed region (slices {phase_window['first']}-{phase_window['last']})"
                                                      if (short and phase_window is not None) else " on the profiled slices of the timed region")
                                                   + ", algorithmic bytes of SURVEY 8(d) (multigrid at the measured V-cycle count), counter bytes from profiles/" + PMC_SUMMARY)
+        if args.config5:
+            c5 = config5_rows(args.si, args.laser_solver, args.n, args.ppc * args.ppc)
+            if c5:
+                rows5, src5 = c5
+                out["roofline"]["per_kernel"] = rows5
+                out["roofline"]["per_kernel_source"] = src5
+                out["roofline"]["dominant_by_time"] = max((k for k in rows5 if k != "unlisted_kernels"), key=lambda k: rows5[k]["us_per_slice"])
+                out["roofline"]["per_kernel_note"] = ("kernel time per slice by group, from the committed kernel trace of this command; the envelope solve runs on its own "
+                                                      "stream beside the slice's chain (HPS_LASER_ASYNC), so the rows sum to more than 1 / value; bytes: SURVEY 8(d)'s "
+                                                      "per-particle figures with the sixth gathered plane (|a|^2), electrons 4 per cell, dopant 1 per cell")
         if not (args.config5 or args.config2):
             # the whole slice against the HBM roofline: bytes of the reference's pass structure and of the survey's
             # fused lower bound at the measured V-cycle count, over the measured time per slice of ONE stage

@@ -1124,6 +1124,34 @@ struct Engine {
     // envelope at time steps n-1, n, n+1 for every slice, valid cells only ([islice][j][i]); what the reference keeps in
     // the 9 slots of its laser slab + the MultiBuffer (utils/MultiBuffer.cpp:840-852, 913-925)
     std::vector<cplx> la_nm1, la_n00, la_np1; int laser_steps = 0;
+    // Rolling window (single-step runs of boxes whose three envelope time levels do not fit host memory: 103 GB at
+    // 1024^2 x 2048).  The first step needs a_n on slices j, j+1, j+2 -- the Gaussian of init_laser_slice, formed when first
+    // asked for -- and a_{n+1} on j+1, j+2, written two and one slice earlier (MultiLaser.cpp:180-213 keeps exactly these
+    // slices of the time levels in its slab); a_{n-1} is not read in step 0.  Three slots per level, slot = slice % 3.  Same
+    // arithmetic on the same values as with whole-box arrays (tests/test_oracle_golden.py compares the two on a small box).
+    bool laser_window = false;
+    std::vector<cplx> win_n00[3], win_np1[3]; int win_n00_sl[3] = {-1, -1, -1}, win_np1_sl[3] = {-1, -1, -1};
+    const cplx* n00_slice (int sl) {
+        const size_t pl2 = (size_t)d.nx*d.ny;
+        if (!laser_window) return la_n00.data() + (size_t)sl*pl2;
+        const int k = sl % 3;
+        if (win_n00_sl[k] != sl) { win_n00[k].resize(pl2); init_laser_slice(sl, win_n00[k].data()); win_n00_sl[k] = sl; }
+        return win_n00[k].data();
+    }
+    const cplx* np1_slice_read (int sl) {
+        const size_t pl2 = (size_t)d.nx*d.ny;
+        if (!laser_window) return la_np1.data() + (size_t)sl*pl2;
+        const int k = sl % 3;
+        if (win_np1_sl[k] != sl) { std::fprintf(stderr, "oracle: envelope window: a_{n+1} of slice %d is not held\n", sl); std::abort(); }
+        return win_np1[k].data();
+    }
+    cplx* np1_slice_write (int sl) {
+        const size_t pl2 = (size_t)d.nx*d.ny;
+        if (!laser_window) return la_np1.data() + (size_t)sl*pl2;
+        const int k = sl % 3;
+        win_np1[k].resize(pl2); win_np1_sl[k] = sl;
+        return win_np1[k].data();
+    }
     MG* laser_mg = nullptr; std::vector<double> laser_mg_guess; long laser_vcycles = 0;      // lasers.solver_type = multigrid
     bool laser_import = false;     // ring pipeline: a_n and a_{n-1} of the coming step arrive slice by slice
     double t_deposit, t_explicit, t_push, t_poisson, t_mg, t_other;
@@ -1523,7 +1551,7 @@ struct Engine {
     // UpdateLaserAabs (:214-291): aabs = |a_n|^2 on the field grid.  Laser grid = field grid and lasers.interp_order = 1,
     // so the interpolation weight is 1 on the cell itself; cells outside the laser box (the guard cells) get 0.
     void update_laser_aabs (int islice, bool accumulate) {
-        const cplx* a = la_n00.data() + (size_t)islice*d.nx*d.ny;
+        const cplx* a = n00_slice(islice);
         zero_comp(c_aabs);
         double sum_abs = 0.0;
         for (int j = 0; j < d.ny; ++j) for (int i = 0; i < d.nx; ++i) {
@@ -1558,11 +1586,14 @@ struct Engine {
         const cplx I(0.0, 1.0);
         static const std::vector<cplx> zeros_dummy;
         std::vector<cplx> zero(pl2, cplx(0.0, 0.0));
-        auto at = [&] (const std::vector<cplx>& v, int sl) -> const cplx* { return (sl < d.nz) ? v.data() + (size_t)sl*pl2 : zero.data(); };
-        const cplx *n00j00 = at(la_n00, islice), *n00jp1 = at(la_n00, islice + 1), *n00jp2 = at(la_n00, islice + 2);
-        const cplx *nm1j00 = at(la_nm1, islice), *nm1jp1 = at(la_nm1, islice + 1), *nm1jp2 = at(la_nm1, islice + 2);
-        const cplx *np1jp1 = at(la_np1, islice + 1), *np1jp2 = at(la_np1, islice + 2);
+        auto at = [&] (const std::vector<cplx>& v, int sl) -> const cplx* { return (sl < d.nz && !laser_window) ? v.data() + (size_t)sl*pl2 : zero.data(); };
+        auto at_n00 = [&] (int sl) -> const cplx* { return sl < d.nz ? n00_slice(sl) : zero.data(); };
+        auto at_np1 = [&] (int sl) -> const cplx* { return sl < d.nz ? np1_slice_read(sl) : zero.data(); };
+        const cplx *n00j00 = at_n00(islice), *n00jp1 = at_n00(islice + 1), *n00jp2 = at_n00(islice + 2);
+        const cplx *nm1j00 = at(la_nm1, islice), *nm1jp1 = at(la_nm1, islice + 1), *nm1jp2 = at(la_nm1, islice + 2);      // (not read in step 0)
+        const cplx *np1jp1 = at_np1(islice + 1), *np1jp2 = at_np1(islice + 2);
         const int step = laser_steps;
+        if (laser_window && step != 0) { std::fprintf(stderr, "oracle: the envelope window holds the first step only\n"); std::abort(); }
         const int imid = (nx + 1)/2, jmid = (ny + 1)/2;
         double tj00 = 0.0, tjp1 = 0.0, tjp2 = 0.0;
         if (d.laser_use_phase) {
@@ -1626,7 +1657,7 @@ struct Engine {
                                             d.laser_mg_tol_rel, d.laser_mg_tol_abs, 200, nullptr);
             if (it < 0) { std::fprintf(stderr, "oracle: laser multigrid solve failed on slice %d\n", islice); std::abort(); }
             laser_vcycles += it;
-            cplx* out = la_np1.data() + (size_t)islice*pl2;
+            cplx* out = np1_slice_write(islice);
             for (size_t o = 0; o < pl2; ++o) out[o] = cplx(sol[o], sol[pl2 + o]);
             return;
         }
@@ -1643,7 +1674,7 @@ struct Engine {
         }
         fft2(rhs, +1);
         const double inv_n = 1.0/((double)nx*ny);
-        cplx* out = la_np1.data() + (size_t)islice*pl2;
+        cplx* out = np1_slice_write(islice);
         for (size_t o = 0; o < pl2; ++o) out[o] = rhs[o]*inv_n;
     }
 
@@ -2050,6 +2081,16 @@ struct Engine {
         laser_envelope_sum = 0.0;
         if (c_aabs >= 0) {
             const size_t tot = (size_t)d.nx*d.ny*d.nz;
+            if (la_n00.empty() && steps_begun == 0 && !laser_import && d.n_steps == 1 && d.laser_solver >= 1 && d.dt != 0.0) {
+                // one step over a box whose time levels would not fit: the rolling window (ORC_LASER_WINDOW=1 / 0 forces it on / off)
+                const char* v = std::getenv("ORC_LASER_WINDOW");
+                laser_window = v ? std::atoi(v) != 0 : (double)tot*48.0 > 24.0e9;
+            }
+            if (laser_window) {
+                if (steps_begun > 0) { std::fprintf(stderr, "oracle: the envelope window holds the first step only\n"); std::abort(); }
+                for (int k = 0; k < 3; ++k) { win_n00_sl[k] = -1; win_np1_sl[k] = -1; }
+                laser_steps = 0;
+            } else
             if (la_n00.empty()) {
                 la_n00.assign(tot, cplx(0.0, 0.0)); la_nm1.assign(tot, cplx(0.0, 0.0)); la_np1.assign(tot, cplx(0.0, 0.0));
                 if (!laser_import) { for (int k = 0; k < d.nz; ++k) init_laser_slice(k, la_n00.data() + (size_t)k*d.nx*d.ny); laser_steps = 0; }
@@ -2305,7 +2346,11 @@ double orc_engine_laser_envelope_sum (void* h) { return static_cast<Engine*>(h)-
 // {a_{n+1}, a_n}, which the next stage stores as its {a_n, a_{n-1}}
 void orc_engine_set_step (void* h, int step) { static_cast<Engine*>(h)->next_step = step; }
 void orc_engine_set_laser_import (void* h, int on, int step) { Engine* e = static_cast<Engine*>(h); e->laser_import = (on != 0); e->laser_steps = step; }
+static void no_window (void* h, const char* what) {
+    if (static_cast<Engine*>(h)->laser_window) { std::fprintf(stderr, "oracle: %s needs the envelope's whole-box time levels (ORC_LASER_WINDOW=0)\n", what); std::abort(); }
+}
 void orc_engine_export_laser_slice (void* h, int islice, double* out /* [2][ny][nx] complex */) {
+    no_window(h, "export_laser_slice");
     Engine* e = static_cast<Engine*>(h); const size_t pl2 = (size_t)e->d.nx*e->d.ny;
     const bool evolve = e->d.laser_solver >= 1 && e->d.dt != 0.0;
     std::memcpy(out, (evolve ? e->la_np1 : e->la_n00).data() + (size_t)islice*pl2, pl2*sizeof(cplx));

@@ -76,6 +76,10 @@ BOXES = {
     "config5_si_mg": (lambda: config5_si_deck(1024, 512, 2), 32,
                       "BASELINE configs[4] as named -- the .SI deck (hipace.normalized_units = 0) -- at its transverse size, 512 of its "
                       "2048 slices over the same box, with the multigrid envelope solver (lasers.solver_type default): laser + N dopant"),
+    "config5_si_mg_full": (lambda: config5_si_deck(1024, 2048, 2), 128,
+                           "BASELINE configs[4] as named AND at its own length: laser_blowout_wake_explicit.SI 1024x1024x2048, 4 ppc, laser + N dopant, "
+                           "multigrid envelope solver; the oracle holds the envelope's time levels in a rolling window (one step: a_n is "
+                           "the Gaussian formed per slice, a_{n+1} is kept for the two slices that read it)"),
     "config5_si_fft": (lambda: config5_si_deck(512, 256, 1), 32,
                        "the .SI config-5 deck on 512x512x256 cells with the fft envelope solver"),
 }

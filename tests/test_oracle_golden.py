@@ -523,3 +523,29 @@ def test_beam_under_the_predictor_corrector_moves_as_under_the_explicit_solver(o
     for q in (3, 4, 5):
         kick = np.abs(bx[q] - s0[q]).max()
         assert kick > 1.0 and np.abs(bp[q] - bx[q]).max() < 0.1 * kick, (q, kick, np.abs(bp[q] - bx[q]).max())
+
+
+@pytest.mark.parametrize("solver", [1, 2])
+def test_envelope_rolling_window_equals_whole_box_time_levels(oracle, solver):
+    """The oracle's rolling window over the envelope's time levels (one step over a box too long to hold three whole-box
+    levels: 103 GB at BASELINE configs[4]'s 1024^2 x 2048) against the whole-box arrays on a small box, both envelope
+    solvers, with the dopant: every checksum, the V-cycle counts and the ionisation bookkeeping bit for bit."""
+    import os
+    from hipace_amd import decks
+    deck = decks.config5(32, 40, solver, si=False, ionize=True)
+    deck.update(lo=(-20.0, -20.0, -6.0), hi=(20.0, 20.0, 6.0), n_steps=1)
+    out = []
+    old = os.environ.get("ORC_LASER_WINDOW")
+    try:
+        for w in ("0", "1"):
+            os.environ["ORC_LASER_WINDOW"] = w
+            oe = oracle.Engine(deck)
+            oe.run()
+            out.append((oe.checksums(), oe.vcycles(), oe.laser_vcycles() if hasattr(oe, "laser_vcycles") else 0, oe.ion_stats() if hasattr(oe, "ion_stats") else 0))
+    finally:
+        if old is None:
+            del os.environ["ORC_LASER_WINDOW"]
+        else:
+            os.environ["ORC_LASER_WINDOW"] = old
+    assert out[0][0]["laserEnvelope"] > 0.0 and out[0][0]["aabs"] > 0.0
+    assert out[0] == out[1]
