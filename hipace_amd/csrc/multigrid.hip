@@ -689,19 +689,18 @@ __device__ __forceinline__ double lprolong (const LView& c, int i, int j)
 
 // 1024 threads as a 32 x 32 patch swept over the level: no integer divisions in the loops
 #define HPS_LOW_FOR_VALID(l, i, j)                                                          \
-    for (int j = (l).b.vly + (int)(threadIdx.x >> 5); j <= (l).b.vhy; j += 32)              \
+    for (int j = (l).b.vly + (int)(threadIdx.x >> 5); j <= (l).b.vhy; j += (int)(blockDim.x >> 5))   \
         for (int i = (l).b.vlx + (int)(threadIdx.x & 31); i <= (l).b.vhx; i += 32)
 
 template <bool CC>
-__device__ void low_sweeps (lds_double* base, const LowLev& l, double facx, double facy, int nsweeps)
+__device__ void low_sweeps (lds_double* base, const LowLev& l, double facx, double facy, int nsweeps, int n0 = 0, int n1 = 2)
 {
     const LView cinv = lplane(base, l, 7);
     for (int is = 0; is < nsweeps; ++is) {
         HPS_LOW_FOR_VALID(l, i, j) {
             if (((i + j + is) & 1) == 0) {
                 const double ci = cinv(i, j);
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
+                for (int n = n0; n < n1; ++n) {
                     const LView rhs = lplane(base, l, 1 + n), phi = lplane(base, l, 3 + n);
                     phi(i, j) = (rhs(i, j) - offdiag<CC, false>((const lds_double*)&phi(i, j), l.nxb, i, j, l.b, facx, facy))*ci;
                 }
@@ -730,6 +729,9 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
     if (!vcycle_active(sr)) return;
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     lds_double* base = (lds_double*)lds_raw;
+    // grid = 2 (HPS_MG_LOWV_SPLIT, round 6): one field component per workgroup -- the components only meet in norms this kernel
+    // does not take, so two CUs need no synchronisation and every barrier-separated phase carries half the LDS traffic
+    const int n0 = gridDim.x == 2 ? (int)blockIdx.x : 0, n1 = gridDim.x == 2 ? n0 + 1 : 2;
     MG_STAMP(8);
     {
         const LowLev l = lv[0];
@@ -739,8 +741,7 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
             for (int s = threadIdx.x; s < l.cells; s += blockDim.x) { base[l.off + s] = acf_g[s]; base[l.off + l.cells + s] = 0.0; base[l.off + 2*l.cells + s] = 0.0; }
             __syncthreads();
             HPS_LOW_FOR_VALID(l, i, j) {
-                lplane(base, l, 1)(i, j) = restrict_at<CC>(fine_res, i, j, 0);
-                lplane(base, l, 2)(i, j) = restrict_at<CC>(fine_res, i, j, 1);
+                for (int n = n0; n < n1; ++n) lplane(base, l, 1 + n)(i, j) = restrict_at<CC>(fine_res, i, j, n);
             }
         } else
         for (int s = threadIdx.x; s < l.cells; s += blockDim.x) {
@@ -776,15 +777,14 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
         const LowLev l = lv[il];
         const LowLev c = lv[il + 1];
         low_zero_cor(base, l);
-        low_sweeps<CC>(base, l, facx, facy, 4);
+        low_sweeps<CC>(base, l, facx, facy, 4, n0, n1);
         {   // residual -> rescor
             const LView acf = lplane(base, l, 0);
             // walls of rescor must read as 0 for the nodal restriction
             if (!CC) { lds_double* r = base + l.off + 5*l.cells; for (int s = threadIdx.x; s < 2*l.cells; s += blockDim.x) r[s] = 0.0; __syncthreads(); }
             HPS_LOW_FOR_VALID(l, i, j) {
                 const double a = acf(i, j);
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
+                for (int n = n0; n < n1; ++n) {
                     const LView rhs = lplane(base, l, 1 + n), phi = lplane(base, l, 3 + n), rc = lplane(base, l, 5 + n);
                     rc(i, j) = residual_at<false>((const lds_double*)&phi(i, j), l.nxb, i, j, l.b, rhs(i, j), a, facx, facy);
                 }
@@ -793,8 +793,7 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
         }
         {   // restriction -> res of the next level
             HPS_LOW_FOR_VALID(c, i, j) {
-#pragma unroll
-                for (int n = 0; n < 2; ++n) lplane(base, c, 1 + n)(i, j) = lrestrict<CC>(lplane(base, l, 5 + n), i, j);
+                for (int n = n0; n < n1; ++n) lplane(base, c, 1 + n)(i, j) = lrestrict<CC>(lplane(base, l, 5 + n), i, j);
             }
             __syncthreads();
         }
@@ -804,7 +803,7 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
     {
         const LowLev l = lv[nl - 1];
         low_zero_cor(base, l);
-        low_sweeps<CC>(base, l, facx, facy, nsweeps_bottom);
+        low_sweeps<CC>(base, l, facx, facy, nsweeps_bottom, n0, n1);
     }
     MG_STAMP(12);
     for (int il = nl - 2; il >= 0; --il) {
@@ -812,19 +811,18 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
         const LowLev c = lv[il + 1];
         facx *= 4.0; facy *= 4.0;
         HPS_LOW_FOR_VALID(l, i, j) {
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = n0; n < n1; ++n) {
                 const LView fine = lplane(base, l, 3 + n);
                 fine(i, j) = fine(i, j) + lprolong<CC>(lplane(base, c, 3 + n), i, j);
             }
         }
         __syncthreads();
-        low_sweeps<CC>(base, l, facx, facy, 4);
+        low_sweeps<CC>(base, l, facx, facy, 4, n0, n1);
     }
     MG_STAMP(13);
     {
         const LowLev l = lv[0];
-        for (int s = threadIdx.x; s < 2*l.cells; s += blockDim.x) cor_g[s] = base[l.off + 3*l.cells + s];
+        for (int s = n0*l.cells + threadIdx.x; s < n1*l.cells; s += blockDim.x) cor_g[s] = base[l.off + 3*l.cells + s];
     }
     MG_STAMP(14);
 }
@@ -1698,6 +1696,7 @@ struct Multigrid {
     bool cc; int nx, ny; double dx, dy;
     bool post_fold = false; unsigned int* d_post_counter = nullptr;     // k_post_norms' work in the last V-cycle's level-0 launch (HPS_MG_POST_FOLD=1; measured: 1474 against 1481 slices/s, off)
     bool hierarchy_ready = false;               // mg_solve1_prepare has enqueued the coefficient hierarchy of the next solve
+    bool lowv_split = false; int lowv_threads = 1024;      // k_lower_v: one component per workgroup / threads per workgroup (HPS_MG_LOWV_SPLIT, HPS_MG_LOWV_THREADS)
     bool nodal_pyramid = false;                 // node-centred grids: the coefficient hierarchy in one launch (k_nodal_acf_pyramid; HPS_MG_NODAL_PYRAMID=0: off)
     std::vector<MGLevelDev> L;
     int lowv_begin = 1;                         // first level handled by k_lower_v
@@ -1768,6 +1767,10 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
         if (!ok) break;
     }
     if (M->nlev() < 2) { delete M; set_error("hps_mg_create: grid too small to coarsen"); return HPS_ERR_ARG; }
+    // (node-centred grids: the split is the default -- Bx/By solve at 1023^2 375 -> 361 us per slice, 512 threads the same, 256 slower:
+    //  profiles/r06_lowv_ab.txt; the cell-centred grids run k_lower_v3, which is built that way)
+    {   const char* v = getenv("HPS_MG_LOWV_SPLIT"); M->lowv_split = v ? atoi(v) != 0 : !M->cc;
+        const char* t = getenv("HPS_MG_LOWV_THREADS"); if (t) { const int n = atoi(t); if (n == 256 || n == 512 || n == 1024) M->lowv_threads = n; } }
     if (!M->cc) {
         const char* v = getenv("HPS_MG_NODAL_PYRAMID");
         M->nodal_pyramid = !(v && atoi(v) == 0);
@@ -1939,7 +1942,7 @@ static bool vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
             hipLaunchKernelGGL(k_lower_v2, dim3(1), dim3(1024), M->low2_lds, st, M->d_low2, M->L[lb].acf, M->L[lb].res, M->L[lb].cor,
                                1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr);
         else
-            hipLaunchKernelGGL(k_lower_v<CC>, dim3(1), dim3(1024), M->low_lds, st, M->d_low, nl - lb, M->L[lb].acf, M->L[lb].res,
+            hipLaunchKernelGGL(k_lower_v<CC>, dim3(M->lowv_split ? 2 : 1), dim3(M->lowv_threads), M->low_lds, st, M->d_low, nl - lb, M->L[lb].acf, M->L[lb].res,
                                M->L[lb].cor, 1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr, pulls(lb) ? M->lv(lb-1, M->L[lb-1].rescor) : FView{});
     }
     // up-leg: the smoothed correction of level il lands in rescor[il] (out of place)

@@ -37,7 +37,7 @@ def write_iteration(prefix, iteration, time, dt, geometry, fields=None, beams=No
                     hdf5=None):
     """Write one openPMD iteration.
 
-    geometry: dict(lo=(x, y, z), hi=(x, y, z)[, cells=(nx, ny, nz) of the simulation grid]) of the (possibly coarsened)
+    geometry: dict(lo=(x, y, z), hi=(x, y, z)[, cells=(nx, ny, nz) of the simulation grid][, cell_volume=dx dy dz of it]) of the (possibly coarsened)
     diagnostic grid.
     fields: {name: array [nz, ny, nx]} (diag_type xyz, as hps_engine_field_diagnostic returns them).
     beams: {name: dict(x, y, z, ux, uy, uz, w, [id], charge, mass)} -- u = proper velocity / c as the engine keeps it
@@ -76,9 +76,13 @@ def write_iteration(prefix, iteration, time, dt, geometry, fields=None, beams=No
         if normalized:
             kp_inv = c_SI / (q_e * np.sqrt(1.0 / (ep0 * m_e)))          # n_0 = 1 (OpenPMDWriter.cpp:353-357)
             lo, hi = geometry["lo"], geometry["hi"]
-            cell = 1.0                                                    # dx dy dz of the simulation grid, if the caller gives it
-            for ax, nn in zip(range(3), geometry.get("cells", (0, 0, 0))):
-                cell *= (hi[ax] - lo[ax]) / nn if nn else 1.0
+            # dx dy dz of the SIMULATION grid: given outright (`cell_volume`: the diagnostic grid may be a slice or a patch of the
+            # box, whose lo / hi are not the simulation's), else from lo, hi and `cells`
+            cell = geometry.get("cell_volume")
+            if cell is None:
+                cell = 1.0
+                for ax, nn in zip(range(3), geometry.get("cells", (0, 0, 0))):
+                    cell *= (hi[ax] - lo[ax]) / nn if nn else 1.0
             to_si = dict(pos=kp_inv, w=cell * kp_inv**3, mom=mass * m_e * c_SI, charge=q_e, mass=m_e)
             mom_unit = mass * c_SI
         ref = "HiPACE++_reference_unitSI"
@@ -247,7 +251,10 @@ def write_engine_output(engine, prefix, iteration, time=0.0, beam_name="beam", b
     lo, hi = d["lo"], d["hi"]
     if hasattr(engine, "field_diagnostic_geometry"):       # (a slice or a patch: the diagnostic grid's own box)
         _, lo, hi = engine.field_diagnostic_geometry()
-    return write_iteration(prefix, iteration, time, d.get("dt", 0.0), dict(lo=lo, hi=hi, cells=(d["nx"], d["ny"], d["nz"])), fields, beams,
+    cell_volume = 1.0
+    for ax, nn in enumerate((d["nx"], d["ny"], d["nz"])):          # the simulation's cells, whatever the diagnostic grid is
+        cell_volume *= (d["hi"][ax] - d["lo"][ax]) / nn
+    return write_iteration(prefix, iteration, time, d.get("dt", 0.0), dict(lo=lo, hi=hi, cells=(d["nx"], d["ny"], d["nz"]), cell_volume=cell_volume), fields, beams,
                            normalized=not d.get("si_units", 0), json_too=json_too, hdf5=hdf5)
 
 
