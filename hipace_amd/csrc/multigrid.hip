@@ -687,17 +687,46 @@ __device__ __forceinline__ double lprolong (const LView& c, int i, int j)
     return c(ic, jc);
 }
 
-// 1024 threads as a 32 x 32 patch swept over the level: no integer divisions in the loops
+// A level is worked either by the whole workgroup -- its threads as a 32-wide patch swept over the level (no integer divisions in
+// the loops), phases separated by __syncthreads -- or, round 6, by WAVE 0 ALONE: levels of at most LOWV_WAVE_CELLS points (15^2
+// unknowns and below) as a 16 x 4 patch of the 64 lanes, phases separated by a fence only.  A phase of the generic lower V costs
+// ~900 clocks whatever the level holds (the barrier of 16 waves + an LDS round trip: shader-clock stamps, scripts/diag_mg.py,
+// 84 k clocks per V-cycle at 1023^2 of which the 16 sweeps of the 3 x 3 bottom level alone 14.8 k); in one wave it is the LDS
+// round trip.  Same per-point expressions, same values: only who computes them changes.
+// MEASURED (round 6, profiles/r06_lowv_wave_ab.txt, 1023^2): Bx/By solve 371.8 us per slice with every level on the whole workgroup,
+// 396.3 with the levels of <= 17^2 points on wave 0 alone, 488 with the 33^2 level there too: one wave has nothing to hide its own
+// LDS round trips behind (a 15^2 level is four dependent trips per phase), sixteen waves overlap theirs.  Kept as a switch
+// (HPS_MG_LOWV_WAVE=1), parity-tested by the same multigrid tests, OFF by default.
+struct LowMap { int ti, tj, si, sj, lin, nlin; };
+template <bool WAVE>
+__device__ __forceinline__ LowMap low_map ()
+{
+    if (WAVE) return LowMap{(int)(threadIdx.x & 15), (int)((threadIdx.x & 63) >> 4), 16, 4, (int)(threadIdx.x & 63), 64};
+    return LowMap{(int)(threadIdx.x & 31), (int)(threadIdx.x >> 5), 32, (int)(blockDim.x >> 5), (int)threadIdx.x, (int)blockDim.x};
+}
+template <bool WAVE>
+__device__ __forceinline__ void low_sync ()
+{
+    if (WAVE) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+}
+#define HPS_LOW_FOR_MAP(mp, l, i, j)                                                        \
+    for (int j = (l).b.vly + (mp).tj; j <= (l).b.vhy; j += (mp).sj)                         \
+        for (int i = (l).b.vlx + (mp).ti; i <= (l).b.vhx; i += (mp).si)
+// (whole workgroup, outside the helpers below)
 #define HPS_LOW_FOR_VALID(l, i, j)                                                          \
     for (int j = (l).b.vly + (int)(threadIdx.x >> 5); j <= (l).b.vhy; j += (int)(blockDim.x >> 5))   \
         for (int i = (l).b.vlx + (int)(threadIdx.x & 31); i <= (l).b.vhx; i += 32)
 
-template <bool CC>
+__device__ __forceinline__ double low_fac (double f0, int l) { for (int k = 0; k < l; ++k) f0 *= 0.25; return f0; }      // (exact: powers of two)
+
+template <bool CC, bool WAVE>
 __device__ void low_sweeps (lds_double* base, const LowLev& l, double facx, double facy, int nsweeps, int n0 = 0, int n1 = 2)
 {
+    const LowMap mp = low_map<WAVE>();
     const LView cinv = lplane(base, l, 7);
     for (int is = 0; is < nsweeps; ++is) {
-        HPS_LOW_FOR_VALID(l, i, j) {
+        HPS_LOW_FOR_MAP(mp, l, i, j) {
             if (((i + j + is) & 1) == 0) {
                 const double ci = cinv(i, j);
                 for (int n = n0; n < n1; ++n) {
@@ -706,16 +735,81 @@ __device__ void low_sweeps (lds_double* base, const LowLev& l, double facx, doub
                 }
             }
         }
-        __syncthreads();
+        low_sync<WAVE>();
     }
 }
 
+template <bool WAVE>
 __device__ void low_zero_cor (lds_double* base, const LowLev& l)
 {
+    const LowMap mp = low_map<WAVE>();
     lds_double* c = base + l.off + 3*l.cells;
-    for (int s = threadIdx.x; s < 2*l.cells; s += blockDim.x) c[s] = 0.0;
-    __syncthreads();
+    for (int s = mp.lin; s < 2*l.cells; s += mp.nlin) c[s] = 0.0;
+    low_sync<WAVE>();
 }
+
+// coefficient of level c from level f (average_down_acoef) and the inverse diagonals of a level
+template <bool CC, bool WAVE>
+__device__ void low_hier_level (lds_double* base, const LowLev& f, const LowLev& c)
+{
+    const LowMap mp = low_map<WAVE>();
+    const LView fine = lplane(base, f, 0), crse = lplane(base, c, 0);
+    for (int s = mp.lin; s < c.cells; s += mp.nlin) base[c.off + s] = 0.0;
+    low_sync<WAVE>();
+    HPS_LOW_FOR_MAP(mp, c, i, j) crse(i, j) = lrestrict<CC>(fine, i, j);
+    low_sync<WAVE>();
+}
+template <bool CC, bool WAVE>
+__device__ void low_cinv_level (lds_double* base, const LowLev& l, double fx, double fy)
+{
+    const LowMap mp = low_map<WAVE>();
+    const LView acf = lplane(base, l, 0), cinv = lplane(base, l, 7);
+    HPS_LOW_FOR_MAP(mp, l, i, j) cinv(i, j) = 1.0/diag_c0<CC>(i, j, l.b, acf(i, j), fx, fy);
+}
+
+// down-leg of level l: cor = 0, four half-sweeps, residual, its restriction = right-hand side of level c
+template <bool CC, bool WAVE>
+__device__ void low_down_level (lds_double* base, const LowLev& l, const LowLev& c, double facx, double facy, int n0, int n1)
+{
+    const LowMap mp = low_map<WAVE>();
+    low_zero_cor<WAVE>(base, l);
+    low_sweeps<CC, WAVE>(base, l, facx, facy, 4, n0, n1);
+    {   // residual -> rescor
+        const LView acf = lplane(base, l, 0);
+        // walls of rescor must read as 0 for the nodal restriction
+        if (!CC) { lds_double* r = base + l.off + 5*l.cells; for (int s = mp.lin; s < 2*l.cells; s += mp.nlin) r[s] = 0.0; low_sync<WAVE>(); }
+        HPS_LOW_FOR_MAP(mp, l, i, j) {
+            const double a = acf(i, j);
+            for (int n = n0; n < n1; ++n) {
+                const LView rhs = lplane(base, l, 1 + n), phi = lplane(base, l, 3 + n), rc = lplane(base, l, 5 + n);
+                rc(i, j) = residual_at<false>((const lds_double*)&phi(i, j), l.nxb, i, j, l.b, rhs(i, j), a, facx, facy);
+            }
+        }
+        low_sync<WAVE>();
+    }
+    {   // restriction -> res of the next level
+        HPS_LOW_FOR_MAP(mp, c, i, j) {
+            for (int n = n0; n < n1; ++n) lplane(base, c, 1 + n)(i, j) = lrestrict<CC>(lplane(base, l, 5 + n), i, j);
+        }
+        low_sync<WAVE>();
+    }
+}
+// up-leg of level l: cor += P(cor of level c), four half-sweeps
+template <bool CC, bool WAVE>
+__device__ void low_up_level (lds_double* base, const LowLev& l, const LowLev& c, double facx, double facy, int n0, int n1)
+{
+    const LowMap mp = low_map<WAVE>();
+    HPS_LOW_FOR_MAP(mp, l, i, j) {
+        for (int n = n0; n < n1; ++n) {
+            const LView fine = lplane(base, l, 3 + n);
+            fine(i, j) = fine(i, j) + lprolong<CC>(lplane(base, c, 3 + n), i, j);
+        }
+    }
+    low_sync<WAVE>();
+    low_sweeps<CC, WAVE>(base, l, facx, facy, 4, n0, n1);
+}
+
+constexpr int LOWV_WAVE_CELLS = 17*17;      // levels of at most this many points (walls included) are wave 0's alone
 
 // levels lv[0..nl-1] (finest first): cor[0] = lower-V(res[0]); mirrors the single-block bottom
 // solver of the reference (HpMultiGrid.cpp:854-1033), 16+ sweeps on the last level.  Level 0's
@@ -724,7 +818,8 @@ __device__ void low_zero_cor (lds_double* base, const LowLev& l)
 template <bool CC>
 __global__ __launch_bounds__(1024)
 void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, const double* __restrict__ res_g,
-                double* __restrict__ cor_g, double facx0, double facy0, int nsweeps_bottom, StopRule sr, FView fine_res = FView{})
+                double* __restrict__ cor_g, double facx0, double facy0, int nsweeps_bottom, StopRule sr, FView fine_res = FView{},
+                int wave_cells = 0)
 {
     if (!vcycle_active(sr)) return;
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
@@ -732,6 +827,9 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
     // grid = 2 (HPS_MG_LOWV_SPLIT, round 6): one field component per workgroup -- the components only meet in norms this kernel
     // does not take, so two CUs need no synchronisation and every barrier-separated phase carries half the LDS traffic
     const int n0 = gridDim.x == 2 ? (int)blockIdx.x : 0, n1 = gridDim.x == 2 ? n0 + 1 : 2;
+    // nw: first level that wave 0 works alone (nl: none)
+    int nw = nl;
+    for (int il = nl - 1; il >= 0; --il) if (lv[il].cells <= wave_cells) nw = il;
     MG_STAMP(8);
     {
         const LowLev l = lv[0];
@@ -751,74 +849,35 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
         }
         __syncthreads();
     }
-    for (int il = 1; il < nl; ++il) {     // coefficient hierarchy
-        const LowLev f = lv[il - 1];
-        const LowLev c = lv[il];
-        const LView fine = lplane(base, f, 0), crse = lplane(base, c, 0);
-        for (int s = threadIdx.x; s < c.cells; s += blockDim.x) base[c.off + s] = 0.0;
-        __syncthreads();
-        HPS_LOW_FOR_VALID(c, i, j) crse(i, j) = lrestrict<CC>(fine, i, j);
-        __syncthreads();
-    }
+    // coefficient hierarchy and inverse diagonals of the levels the whole workgroup works (one division per point and V-cycle)
+    for (int il = 1; il < nw; ++il) low_hier_level<CC, false>(base, lv[il - 1], lv[il]);
     MG_STAMP(9);
-    {   // inverse diagonals of every small level (one division per cell per V-cycle)
-        double fx = facx0, fy = facy0;
-        for (int il = 0; il < nl; ++il) {
-            const LowLev l = lv[il];
-            const LView acf = lplane(base, l, 0), cinv = lplane(base, l, 7);
-            HPS_LOW_FOR_VALID(l, i, j) cinv(i, j) = 1.0/diag_c0<CC>(i, j, l.b, acf(i, j), fx, fy);
-            fx *= 0.25; fy *= 0.25;
+    for (int il = 0; il < nw; ++il) low_cinv_level<CC, false>(base, lv[il], low_fac(facx0, il), low_fac(facy0, il));
+    __syncthreads();
+    MG_STAMP(10);
+    const int nbig_down = nw < nl - 1 ? nw : nl - 1;          // levels 0 .. nbig_down-1 go down (and later up) with the whole workgroup
+    for (int il = 0; il < nbig_down; ++il) low_down_level<CC, false>(base, lv[il], lv[il + 1], low_fac(facx0, il), low_fac(facy0, il), n0, n1);
+    MG_STAMP(11);
+    if (nw >= nl) {
+        const LowLev l = lv[nl - 1];
+        low_zero_cor<false>(base, l);
+        low_sweeps<CC, false>(base, l, low_fac(facx0, nl - 1), low_fac(facy0, nl - 1), nsweeps_bottom, n0, n1);
+    } else {
+        if (threadIdx.x < 64) {
+            // wave 0: what is left of the coefficient hierarchy, the down-legs below the workgroup's levels, the bottom, the up-legs
+            for (int il = nw > 0 ? nw : 1; il < nl; ++il) low_hier_level<CC, true>(base, lv[il - 1], lv[il]);
+            for (int il = nw; il < nl; ++il) low_cinv_level<CC, true>(base, lv[il], low_fac(facx0, il), low_fac(facy0, il));
+            low_sync<true>();
+            for (int il = nw; il < nl - 1; ++il) low_down_level<CC, true>(base, lv[il], lv[il + 1], low_fac(facx0, il), low_fac(facy0, il), n0, n1);
+            {   const LowLev l = lv[nl - 1];
+                low_zero_cor<true>(base, l);
+                low_sweeps<CC, true>(base, l, low_fac(facx0, nl - 1), low_fac(facy0, nl - 1), nsweeps_bottom, n0, n1); }
+            for (int il = nl - 2; il >= nw; --il) low_up_level<CC, true>(base, lv[il], lv[il + 1], low_fac(facx0, il), low_fac(facy0, il), n0, n1);
         }
         __syncthreads();
-    }
-    MG_STAMP(10);
-    double facx = facx0, facy = facy0;
-    for (int il = 0; il < nl - 1; ++il) {
-        const LowLev l = lv[il];
-        const LowLev c = lv[il + 1];
-        low_zero_cor(base, l);
-        low_sweeps<CC>(base, l, facx, facy, 4, n0, n1);
-        {   // residual -> rescor
-            const LView acf = lplane(base, l, 0);
-            // walls of rescor must read as 0 for the nodal restriction
-            if (!CC) { lds_double* r = base + l.off + 5*l.cells; for (int s = threadIdx.x; s < 2*l.cells; s += blockDim.x) r[s] = 0.0; __syncthreads(); }
-            HPS_LOW_FOR_VALID(l, i, j) {
-                const double a = acf(i, j);
-                for (int n = n0; n < n1; ++n) {
-                    const LView rhs = lplane(base, l, 1 + n), phi = lplane(base, l, 3 + n), rc = lplane(base, l, 5 + n);
-                    rc(i, j) = residual_at<false>((const lds_double*)&phi(i, j), l.nxb, i, j, l.b, rhs(i, j), a, facx, facy);
-                }
-            }
-            __syncthreads();
-        }
-        {   // restriction -> res of the next level
-            HPS_LOW_FOR_VALID(c, i, j) {
-                for (int n = n0; n < n1; ++n) lplane(base, c, 1 + n)(i, j) = lrestrict<CC>(lplane(base, l, 5 + n), i, j);
-            }
-            __syncthreads();
-        }
-        facx *= 0.25; facy *= 0.25;
-    }
-    MG_STAMP(11);
-    {
-        const LowLev l = lv[nl - 1];
-        low_zero_cor(base, l);
-        low_sweeps<CC>(base, l, facx, facy, nsweeps_bottom, n0, n1);
     }
     MG_STAMP(12);
-    for (int il = nl - 2; il >= 0; --il) {
-        const LowLev l = lv[il];
-        const LowLev c = lv[il + 1];
-        facx *= 4.0; facy *= 4.0;
-        HPS_LOW_FOR_VALID(l, i, j) {
-            for (int n = n0; n < n1; ++n) {
-                const LView fine = lplane(base, l, 3 + n);
-                fine(i, j) = fine(i, j) + lprolong<CC>(lplane(base, c, 3 + n), i, j);
-            }
-        }
-        __syncthreads();
-        low_sweeps<CC>(base, l, facx, facy, 4, n0, n1);
-    }
+    for (int il = nbig_down - 1; il >= 0; --il) low_up_level<CC, false>(base, lv[il], lv[il + 1], low_fac(facx0, il), low_fac(facy0, il), n0, n1);
     MG_STAMP(13);
     {
         const LowLev l = lv[0];
@@ -1696,6 +1755,7 @@ struct Multigrid {
     bool cc; int nx, ny; double dx, dy;
     bool post_fold = false; unsigned int* d_post_counter = nullptr;     // k_post_norms' work in the last V-cycle's level-0 launch (HPS_MG_POST_FOLD=1; measured: 1474 against 1481 slices/s, off)
     bool hierarchy_ready = false;               // mg_solve1_prepare has enqueued the coefficient hierarchy of the next solve
+    int lowv_wave_cells = 0;                                // k_lower_v: levels of at most so many points are worked by wave 0 alone (HPS_MG_LOWV_WAVE=1: 17^2; measured SLOWER, see low_map: off)
     bool lowv_split = false; int lowv_threads = 1024;      // k_lower_v: one component per workgroup / threads per workgroup (HPS_MG_LOWV_SPLIT, HPS_MG_LOWV_THREADS)
     bool nodal_pyramid = false;                 // node-centred grids: the coefficient hierarchy in one launch (k_nodal_acf_pyramid; HPS_MG_NODAL_PYRAMID=0: off)
     std::vector<MGLevelDev> L;
@@ -1770,6 +1830,7 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
     // (node-centred grids: the split is the default -- Bx/By solve at 1023^2 375 -> 361 us per slice, 512 threads the same, 256 slower:
     //  profiles/r06_lowv_ab.txt; the cell-centred grids run k_lower_v3, which is built that way)
     {   const char* v = getenv("HPS_MG_LOWV_SPLIT"); M->lowv_split = v ? atoi(v) != 0 : !M->cc;
+        if (const char* w = getenv("HPS_MG_LOWV_WAVE")) M->lowv_wave_cells = atoi(w) != 0 ? (atoi(w) == 1 ? LOWV_WAVE_CELLS : atoi(w)) : 0;
         const char* t = getenv("HPS_MG_LOWV_THREADS"); if (t) { const int n = atoi(t); if (n == 256 || n == 512 || n == 1024) M->lowv_threads = n; } }
     if (!M->cc) {
         const char* v = getenv("HPS_MG_NODAL_PYRAMID");
@@ -1943,7 +2004,7 @@ static bool vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
                                1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr);
         else
             hipLaunchKernelGGL(k_lower_v<CC>, dim3(M->lowv_split ? 2 : 1), dim3(M->lowv_threads), M->low_lds, st, M->d_low, nl - lb, M->L[lb].acf, M->L[lb].res,
-                               M->L[lb].cor, 1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr, pulls(lb) ? M->lv(lb-1, M->L[lb-1].rescor) : FView{});
+                               M->L[lb].cor, 1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr, pulls(lb) ? M->lv(lb-1, M->L[lb-1].rescor) : FView{}, M->lowv_wave_cells);
     }
     // up-leg: the smoothed correction of level il lands in rescor[il] (out of place)
     for (int il = lb - 1; il >= 1; --il) {
