@@ -739,23 +739,13 @@ __device__ void low_sweeps (lds_double* base, const LowLev& l, double facx, doub
     }
 }
 
-template <bool WAVE>
-__device__ void low_zero_cor (lds_double* base, const LowLev& l)
-{
-    const LowMap mp = low_map<WAVE>();
-    lds_double* c = base + l.off + 3*l.cells;
-    for (int s = mp.lin; s < 2*l.cells; s += mp.nlin) c[s] = 0.0;
-    low_sync<WAVE>();
-}
-
 // coefficient of level c from level f (average_down_acoef) and the inverse diagonals of a level
 template <bool CC, bool WAVE>
 __device__ void low_hier_level (lds_double* base, const LowLev& f, const LowLev& c)
 {
     const LowMap mp = low_map<WAVE>();
     const LView fine = lplane(base, f, 0), crse = lplane(base, c, 0);
-    for (int s = mp.lin; s < c.cells; s += mp.nlin) base[c.off + s] = 0.0;
-    low_sync<WAVE>();
+    // (the walls of every plane hold the zeros the kernel starts from: only unknowns are ever written)
     HPS_LOW_FOR_MAP(mp, c, i, j) crse(i, j) = lrestrict<CC>(fine, i, j);
     low_sync<WAVE>();
 }
@@ -772,12 +762,12 @@ template <bool CC, bool WAVE>
 __device__ void low_down_level (lds_double* base, const LowLev& l, const LowLev& c, double facx, double facy, int n0, int n1)
 {
     const LowMap mp = low_map<WAVE>();
-    low_zero_cor<WAVE>(base, l);
+    // cor = 0 and the walls of rescor = 0 (the nodal restriction reads them): both still hold the zeros the kernel starts from --
+    // a level is visited once per launch -- so neither costs a phase of its own (round 6: 13 of the ~105 barrier-separated
+    // phases of a V-cycle at 1023^2)
     low_sweeps<CC, WAVE>(base, l, facx, facy, 4, n0, n1);
     {   // residual -> rescor
         const LView acf = lplane(base, l, 0);
-        // walls of rescor must read as 0 for the nodal restriction
-        if (!CC) { lds_double* r = base + l.off + 5*l.cells; for (int s = mp.lin; s < 2*l.cells; s += mp.nlin) r[s] = 0.0; low_sync<WAVE>(); }
         HPS_LOW_FOR_MAP(mp, l, i, j) {
             const double a = acf(i, j);
             for (int n = n0; n < n1; ++n) {
@@ -831,13 +821,18 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
     int nw = nl;
     for (int il = nl - 1; il >= 0; --il) if (lv[il].cells <= wave_cells) nw = il;
     MG_STAMP(8);
+    {   // every plane of every level starts from zero (walls, corrections, the coefficient planes' rims)
+        const LowLev last = lv[nl - 1];
+        const int total = last.off + 8*last.cells;
+        for (int s = threadIdx.x; s < total; s += blockDim.x) base[s] = 0.0;
+        __syncthreads();
+    }
     {
         const LowLev l = lv[0];
         if (fine_res.p) {
             // the top level's right-hand side = R(residual of the level above), formed here (no k_restrict launch ahead of this
             // kernel); cells outside the unknowns' box read as 0
-            for (int s = threadIdx.x; s < l.cells; s += blockDim.x) { base[l.off + s] = acf_g[s]; base[l.off + l.cells + s] = 0.0; base[l.off + 2*l.cells + s] = 0.0; }
-            __syncthreads();
+            for (int s = threadIdx.x; s < l.cells; s += blockDim.x) base[l.off + s] = acf_g[s];
             HPS_LOW_FOR_VALID(l, i, j) {
                 for (int n = n0; n < n1; ++n) lplane(base, l, 1 + n)(i, j) = restrict_at<CC>(fine_res, i, j, n);
             }
@@ -860,7 +855,6 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
     MG_STAMP(11);
     if (nw >= nl) {
         const LowLev l = lv[nl - 1];
-        low_zero_cor<false>(base, l);
         low_sweeps<CC, false>(base, l, low_fac(facx0, nl - 1), low_fac(facy0, nl - 1), nsweeps_bottom, n0, n1);
     } else {
         if (threadIdx.x < 64) {
@@ -870,7 +864,6 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
             low_sync<true>();
             for (int il = nw; il < nl - 1; ++il) low_down_level<CC, true>(base, lv[il], lv[il + 1], low_fac(facx0, il), low_fac(facy0, il), n0, n1);
             {   const LowLev l = lv[nl - 1];
-                low_zero_cor<true>(base, l);
                 low_sweeps<CC, true>(base, l, low_fac(facx0, nl - 1), low_fac(facy0, nl - 1), nsweeps_bottom, n0, n1); }
             for (int il = nl - 2; il >= nw; --il) low_up_level<CC, true>(base, lv[il], lv[il + 1], low_fac(facx0, il), low_fac(facy0, il), n0, n1);
         }
