@@ -723,11 +723,15 @@ __device__ __forceinline__ double low_fac (double f0, int l) { for (int k = 0; k
 template <bool CC, bool WAVE>
 __device__ void low_sweeps (lds_double* base, const LowLev& l, double facx, double facy, int nsweeps, int n0 = 0, int n1 = 2)
 {
-    const LowMap mp = low_map<WAVE>();
+    // A half-sweep touches the points of one colour only: the threads are mapped onto THOSE -- a patch 16 half-columns wide
+    // (8 in a lone wave), so a 31^2 level is one trip of 496 threads (8 waves: two per SIMD) instead of 961 threads of which
+    // every other one sits out (16 waves: four per SIMD, all of them issuing the loop's ~150 instructions)
+    const int ti = WAVE ? (int)(threadIdx.x & 7) : (int)(threadIdx.x & 15), tj = WAVE ? (int)((threadIdx.x & 63) >> 3) : (int)(threadIdx.x >> 4);
+    const int si = WAVE ? 8 : 16, sj = WAVE ? 8 : (int)(blockDim.x >> 4);
     const LView cinv = lplane(base, l, 7);
     for (int is = 0; is < nsweeps; ++is) {
-        HPS_LOW_FOR_MAP(mp, l, i, j) {
-            if (((i + j + is) & 1) == 0) {
+        for (int j = l.b.vly + tj; j <= l.b.vhy; j += sj) {
+            for (int i = l.b.vlx + ((l.b.vlx + j + is) & 1) + 2*ti; i <= l.b.vhx; i += 2*si) {      // (i + j + is) even
                 const double ci = cinv(i, j);
                 for (int n = n0; n < n1; ++n) {
                     const LView rhs = lplane(base, l, 1 + n), phi = lplane(base, l, 3 + n);
@@ -807,7 +811,7 @@ constexpr int LOWV_WAVE_CELLS = 17*17;      // levels of at most this many point
 // coefficients of the lower levels are re-derived in LDS (average_down_acoef).
 template <bool CC>
 __global__ __launch_bounds__(1024)
-void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, const double* __restrict__ res_g,
+void k_lower_v (const LowLev* __restrict__ lv, int nl, const double* __restrict__ acf_g, const double* __restrict__ res_g,
                 double* __restrict__ cor_g, double facx0, double facy0, int nsweeps_bottom, StopRule sr, FView fine_res = FView{},
                 int wave_cells = 0)
 {
@@ -844,14 +848,16 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
         }
         __syncthreads();
     }
+    // (every level's descriptor is copied out of global memory ONCE per use below: handed on as a reference to lv[il] itself, each
+    //  phase behind a barrier began with three to four dependent scalar loads of its fields -- a third of a phase's ~900 clocks)
     // coefficient hierarchy and inverse diagonals of the levels the whole workgroup works (one division per point and V-cycle)
-    for (int il = 1; il < nw; ++il) low_hier_level<CC, false>(base, lv[il - 1], lv[il]);
+    for (int il = 1; il < nw; ++il) { const LowLev f = lv[il - 1], c = lv[il]; low_hier_level<CC, false>(base, f, c); }
     MG_STAMP(9);
-    for (int il = 0; il < nw; ++il) low_cinv_level<CC, false>(base, lv[il], low_fac(facx0, il), low_fac(facy0, il));
+    for (int il = 0; il < nw; ++il) { const LowLev l = lv[il]; low_cinv_level<CC, false>(base, l, low_fac(facx0, il), low_fac(facy0, il)); }
     __syncthreads();
     MG_STAMP(10);
     const int nbig_down = nw < nl - 1 ? nw : nl - 1;          // levels 0 .. nbig_down-1 go down (and later up) with the whole workgroup
-    for (int il = 0; il < nbig_down; ++il) low_down_level<CC, false>(base, lv[il], lv[il + 1], low_fac(facx0, il), low_fac(facy0, il), n0, n1);
+    for (int il = 0; il < nbig_down; ++il) { const LowLev l = lv[il], c = lv[il + 1]; low_down_level<CC, false>(base, l, c, low_fac(facx0, il), low_fac(facy0, il), n0, n1); }
     MG_STAMP(11);
     if (nw >= nl) {
         const LowLev l = lv[nl - 1];
@@ -859,18 +865,18 @@ void k_lower_v (const LowLev* lv, int nl, const double* __restrict__ acf_g, cons
     } else {
         if (threadIdx.x < 64) {
             // wave 0: what is left of the coefficient hierarchy, the down-legs below the workgroup's levels, the bottom, the up-legs
-            for (int il = nw > 0 ? nw : 1; il < nl; ++il) low_hier_level<CC, true>(base, lv[il - 1], lv[il]);
-            for (int il = nw; il < nl; ++il) low_cinv_level<CC, true>(base, lv[il], low_fac(facx0, il), low_fac(facy0, il));
+            for (int il = nw > 0 ? nw : 1; il < nl; ++il) { const LowLev f = lv[il - 1], c = lv[il]; low_hier_level<CC, true>(base, f, c); }
+            for (int il = nw; il < nl; ++il) { const LowLev l = lv[il]; low_cinv_level<CC, true>(base, l, low_fac(facx0, il), low_fac(facy0, il)); }
             low_sync<true>();
-            for (int il = nw; il < nl - 1; ++il) low_down_level<CC, true>(base, lv[il], lv[il + 1], low_fac(facx0, il), low_fac(facy0, il), n0, n1);
+            for (int il = nw; il < nl - 1; ++il) { const LowLev l = lv[il], c = lv[il + 1]; low_down_level<CC, true>(base, l, c, low_fac(facx0, il), low_fac(facy0, il), n0, n1); }
             {   const LowLev l = lv[nl - 1];
                 low_sweeps<CC, true>(base, l, low_fac(facx0, nl - 1), low_fac(facy0, nl - 1), nsweeps_bottom, n0, n1); }
-            for (int il = nl - 2; il >= nw; --il) low_up_level<CC, true>(base, lv[il], lv[il + 1], low_fac(facx0, il), low_fac(facy0, il), n0, n1);
+            for (int il = nl - 2; il >= nw; --il) { const LowLev l = lv[il], c = lv[il + 1]; low_up_level<CC, true>(base, l, c, low_fac(facx0, il), low_fac(facy0, il), n0, n1); }
         }
         __syncthreads();
     }
     MG_STAMP(12);
-    for (int il = nbig_down - 1; il >= 0; --il) low_up_level<CC, false>(base, lv[il], lv[il + 1], low_fac(facx0, il), low_fac(facy0, il), n0, n1);
+    for (int il = nbig_down - 1; il >= 0; --il) { const LowLev l = lv[il], c = lv[il + 1]; low_up_level<CC, false>(base, l, c, low_fac(facx0, il), low_fac(facy0, il), n0, n1); }
     MG_STAMP(13);
     {
         const LowLev l = lv[0];
