@@ -337,6 +337,40 @@ def reference_benchmark(nxy):
     return 0
 
 
+def measure_handoff(transport, dev, rank, world, dist, torch, nbytes=1 << 20, reps=64):
+    """What ONE hand-off costs on this edge, by itself: every rank posts `reps` receives of a 1 MiB block (a beam slice's block
+    of the headline deck is 0.9 MB) and sends as many to the next rank, all ranks at once; seconds per message and the rate per
+    edge -- between devices this is the xGMI link (ipc: a peer copy, rccl: ncclSend / ncclRecv), on one device a local copy.
+    None on any failure (the leg's headline number does not depend on it)."""
+    try:
+        n = nbytes // 8
+        rx = [torch.zeros(n, dtype=torch.float64, device=dev) for _ in range(2)]
+        tx = torch.full((n,), float(rank + 1), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        out = {}
+        for label, count in (("warm", 8), ("timed", reps)):
+            dist.barrier()
+            t0 = time.perf_counter()
+            evs = [transport.recv(rx[r & 1], None, slot=r % 64) for r in range(count)]
+            for r in range(count):
+                transport.send(tx, None, slot=r % 64)
+            t1 = time.perf_counter()
+            while not transport.ready(evs[-1]):
+                if time.perf_counter() - t1 > 60.0:
+                    raise RuntimeError("hand-off messages did not arrive within 60 s")
+            transport.finish()
+            out[label] = (time.perf_counter() - t0) / count
+        transport._handoff_buffers = (rx, tx)      # (receive buffers stay allocated until the ring is destroyed: include/hpslice.h)
+        ok = bool((rx[(reps - 1) & 1] == float((rank - 1) % world + 1)).all())
+        worst = torch.tensor([out["timed"]], dtype=torch.float64)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        return {"bytes_per_message": nbytes, "messages": reps, "seconds_per_message": worst.item(), "GB_per_s_per_edge": nbytes / worst.item() / 1e9,
+                "contents_checked": ok, "what": "every rank receives from its predecessor and sends to its successor at once, back to back (max over ranks)"}
+    except Exception as exc:      # noqa: BLE001
+        print(f"bench.py: rank {rank}: hand-off rate not measured ({type(exc).__name__}: {exc})", file=sys.stderr, flush=True)
+        return None
+
+
 def _pci_bus_id(dev):
     import ctypes
     hip = ctypes.CDLL("libamdhip64.so")
@@ -462,6 +496,8 @@ def supervise_legs(args, rank, world):
             e["rccl_ranks_seen"] = line.get("rccl_ranks_seen") if line else None
         if line and line.get("rank_devices"):
             e["rank_devices"] = line["rank_devices"]
+        if line and line.get("handoff"):
+            e["handoff"] = line["handoff"]
         if line and isinstance(line.get("in_flight"), dict) and line["in_flight"].get("error"):
             e["in_flight_error"] = line["in_flight"]["error"]
         if "error" in rec:
@@ -697,6 +733,7 @@ def main():
             e.set_profiling(on, stride=stride, light=short)
 
     transport = None
+    handoff = None
     if world > 1:
         from hipace_amd.pipeline import RingTransport
         progress["phase"] = "ring init"
@@ -709,6 +746,8 @@ def main():
             progress["phase"] = "ring probe"
             if not transport._probe(local, seconds=60.0):
                 raise RuntimeError(f"rank {rank}: the {transport.kind} edge's probe message failed: {transport._probe_error}")
+            progress["phase"] = "hand-off rate"
+            handoff = measure_handoff(transport, dev, rank, world, dist, torch)
         progress["phase"] = "headline run"
     elif args.ring_self:
         from hipace_amd.pipeline import RcclSelfRing, ring_edge
@@ -1022,6 +1061,7 @@ def main():
             "rccl_ranks_seen": rccl_ranks_seen if (transport is not None and transport.kind == "rccl") else None,
             "ranks_on_one_device": bool(args.same_device) if world > 1 else None,
             "rank_devices": rank_devices,
+            "handoff": handoff,
             "stages_per_rank_on_the_ring": (max(1, args.inflight) if (world > 1 or args.ring_self) else None),
             "roofline": {"bound": "hbm", "kernel": "k_deposit_tiled<2,%d>" % args.tile if args.tile else "k_deposit_current<2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
