@@ -595,7 +595,7 @@ template <class TS, bool CC, int SRC, bool DO_RES, bool FUSE_R, int NSW = 4, boo
 #ifndef HPS_MG_NODAL_WAVES
 #define HPS_MG_NODAL_WAVES 4
 #endif
-__global__ __launch_bounds__(TS::NT, (CC || NSW == 4) ? 4 : HPS_MG_NODAL_WAVES)      // at most 128 VGPRs: two 512-thread workgroups per CU (several variants sit at 113-130)
+__global__ __launch_bounds__(TS::NT, (RPULL && TS::GPAIRS > 1) ? 2 : (CC || NSW == 4) ? 4 : HPS_MG_NODAL_WAVES)      // at most 128 VGPRs: two 512-thread workgroups per CU (several variants sit at 113-130); the pulling smoother with two pairs per thread (36 + 36 loads in flight) gets 256
 void k_smooth (LevBox b, FView phi_out, FView phi_out2, FView rhs, FView acf, FView phi_in, FView crse, FView res_out,
                FView cres_out, double facx, double facy, int ntx, unsigned long long* resnorm,
                unsigned long long* rhsnorm, StopRule sr, PostArgs pa)
@@ -1756,6 +1756,7 @@ struct Multigrid {
     bool hierarchy_ready = false;               // mg_solve1_prepare has enqueued the coefficient hierarchy of the next solve
     int lowv_wave_cells = 0;                                // k_lower_v: levels of at most so many points are worked by wave 0 alone (HPS_MG_LOWV_WAVE=1: 17^2; measured SLOWER, see low_map: off)
     bool lowv_split = false; int lowv_threads = 1024;      // k_lower_v: one component per workgroup / threads per workgroup (HPS_MG_LOWV_SPLIT, HPS_MG_LOWV_THREADS)
+    bool nodal_pull1 = false;                   // node-centred: level 1's down-leg smoother forms its right-hand side from level 0's residual itself (HPS_MG_NODAL_PULL1=0: a k_restrict launch)
     bool nodal_pyramid = false;                 // node-centred grids: the coefficient hierarchy in one launch (k_nodal_acf_pyramid; HPS_MG_NODAL_PYRAMID=0: off)
     std::vector<MGLevelDev> L;
     int lowv_begin = 1;                         // first level handled by k_lower_v
@@ -1890,6 +1891,11 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
             break;
         }
     }
+    if (!M->cc) {
+        // level 1 pulls (vcycle: pulls) when it is a smoother level of its own (not the lower V's top) and the general switch is on
+        const char* g0 = getenv("HPS_MG_NODAL_PULL"); const char* g1 = getenv("HPS_MG_NODAL_PULL1");
+        M->nodal_pull1 = !(g0 && atoi(g0) == 0) && !(g1 && atoi(g1) == 0) && M->lowv_begin > 1;
+    }
     std::vector<LowLev> low;
     int off = 0;
     for (int il = M->lowv_begin; il < nl; ++il) {
@@ -1979,10 +1985,16 @@ static bool vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
     // the launch of k_restrict stays where the next consumer is not a smoother (level 0 -> 1 behind the fused pass, the lower V's input)
     static const bool pull = [] { const char* v = std::getenv("HPS_MG_NODAL_PULL"); return !(v && std::atoi(v) == 0); }();
     // (levels on 32 x 16 tiles only: with the nine reads per cell in flight the 64 x 32 variant spills 108 registers under its cap)
-    auto pulls = [&] (int il) { return !CC && pull && il >= 2 && ((il < lb && M->L[il].cells <= M->small_tile_cells) ||
-                                                                 (il == lb && !M->use_low3 && !M->use_low2)); };      // (il == lb: k_lower_v's own load)
+    // (round 6: level 1 too -- on 32 x 32 tiles of 256 threads where it is too large for the 32 x 16 ones: the 64 x 32 variant's 512
+    //  threads are what capped its registers -- so the level 0 -> 1 restriction launch is gone as well: M->nodal_pull1)
+    auto pulls = [&] (int il) { return !CC && pull && ((il >= 2 && ((il < lb && M->L[il].cells <= M->small_tile_cells) ||
+                                                                   (il == lb && !M->use_low3 && !M->use_low2))) ||      // (il == lb: k_lower_v's own load)
+                                                      (il == 1 && M->nodal_pull1)); };
     for (int il = 1; il < lb; ++il) {
-        if (pulls(il))
+        if (pulls(il) && M->L[il].cells > M->small_tile_cells)
+            launch_smooth_ts<TileMid, CC, SRC_ZERO, true, 4, !CC>(M, il, M->lv(il, M->L[il].cor), none, M->lv(il, M->L[il].res), M->lv(il, M->L[il].acf), none,
+                                                                  M->lv(il-1, M->L[il-1].rescor), M->lv(il, M->L[il].rescor), M->lv(il+1, M->L[il+1].res), nullptr, nullptr, sr, st);
+        else if (pulls(il))
             launch_smooth_ts<TileSmall, CC, SRC_ZERO, true, 4, !CC>(M, il, M->lv(il, M->L[il].cor), none, M->lv(il, M->L[il].res), M->lv(il, M->L[il].acf), none,
                                                                     M->lv(il-1, M->L[il-1].rescor), M->lv(il, M->L[il].rescor), M->lv(il+1, M->L[il+1].res), nullptr, nullptr, sr, st);
         else
@@ -2023,7 +2035,7 @@ static bool vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
                                                                  M->lv(0, M->L[0].rescor), M->lv(1, M->L[1].res), M->d_norms + (2 + k)*MG_NSUB,
                                                                  nullptr, sr, st, CC ? post : nullptr);
             M->cor_in_tmp = !M->cor_in_tmp;
-            restrict_residual_if_nodal<CC>(M, 0, sr, st);
+            if (!M->nodal_pull1) restrict_residual_if_nodal<CC>(M, 0, sr, st);
             return CC && post != nullptr;
         } else {
             launch_smooth<CC, SRC_PROLONG, false>(M, 0, M->lv(0, M->tmp0), none, M->rhs, M->acf0, M->lv(0, M->L[0].cor), M->lv(1, crse),
@@ -2032,7 +2044,7 @@ static bool vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
                                                 M->lv(0, M->L[0].rescor), M->lv(1, M->L[1].res), M->d_norms + (2 + k)*MG_NSUB, nullptr, sr, st);
         }
     }
-    restrict_residual_if_nodal<CC>(M, 0, sr, st);
+    if (!M->nodal_pull1) restrict_residual_if_nodal<CC>(M, 0, sr, st);
     return false;
 }
 
@@ -2173,7 +2185,7 @@ static int solve1_begin (Multigrid* M, double tol_rel, double tol_abs, int max_i
     else
     launch_smooth<CC, SRC_DIRECT, true>(M, 0, M->lv(0, M->L[0].cor), FView{}, M->rhs, M->acf0, M->sol, FView{}, M->lv(0, M->L[0].rescor),
                                         M->lv(1, M->L[1].res), M->d_norms, M->d_norms + MG_NSUB, always, st);
-    restrict_residual_if_nodal<CC>(M, 0, always, st);
+    if (!M->nodal_pull1) restrict_residual_if_nodal<CC>(M, 0, always, st);
     M->run = SolveRun{0, nspec, nzeroed, max_iters, tol_rel, tol_abs, CC};
     enqueue_cycles<CC>(M, st);
     HPS_HIP_CHECK(hipGetLastError());
