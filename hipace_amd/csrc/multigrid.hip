@@ -803,6 +803,56 @@ __device__ void low_up_level (lds_double* base, const LowLev& l, const LowLev& c
     low_sweeps<CC, WAVE>(base, l, facx, facy, 4, n0, n1);
 }
 
+// The bottom level of a 2^K - 1 grid holds 3 x 3 unknowns and takes 16+ half-sweeps (HpMultiGrid.cpp:854-1033): as phases of the
+// whole workgroup that was 16 x ~1100 clocks, a quarter of the kernel, for nine numbers.  One lane per component does them in
+// registers instead: the same expression per point ((rhs - offdiag) * 1/diag, offdiag<CC, false>'s), the same colour order; points
+// of one colour do not read one another, so doing them one after the other changes nothing.
+template <bool CC>
+__device__ void low_bottom_lane (lds_double* base, const LowLev& l, double facx, double facy, int nsweeps, int n0, int n1)
+{
+    const int nvx = l.b.vhx - l.b.vlx + 1, nvy = l.b.vhy - l.b.vly + 1;      // <= 3 each (caller)
+    for (int n = n0 + (int)threadIdx.x; n < n1; n += (int)blockDim.x) {       // (thread 0: component n0; thread 1: the other one without the split)
+        const LView rhs = lplane(base, l, 1 + n), phi = lplane(base, l, 3 + n), cinv = lplane(base, l, 7);
+        double p[5][5], r[3][3], c[3][3];
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int b = 0; b < 5; ++b) p[a][b] = 0.0;                          // ring = walls (0), unknowns start from 0
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const bool ok = a < nvy && b < nvx;
+                r[a][b] = ok ? rhs(l.b.vlx + b, l.b.vly + a) : 0.0;
+                c[a][b] = ok ? cinv(l.b.vlx + b, l.b.vly + a) : 0.0;
+            }
+        for (int is = 0; is < nsweeps; ++is) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const int i = l.b.vlx + b, j = l.b.vly + a;
+                    if (a < nvy && b < nvx && ((i + j + is) & 1) == 0) {
+                        const double w = p[a + 1][b], e = p[a + 1][b + 2], so = p[a][b + 1], no = p[a + 2][b + 1];
+                        double lx = facx*(w + e), ly = facy*(so + no);
+                        if (CC) {
+                            const double fx43 = facx*(4./3.), fy43 = facy*(4./3.);
+                            lx = (i == l.b.lox) ? fx43*e : ((i == l.b.hix) ? fx43*w : lx);
+                            ly = (j == l.b.loy) ? fy43*no : ((j == l.b.hiy) ? fy43*so : ly);
+                        }
+                        p[a + 1][b + 1] = (r[a][b] - (lx + ly))*c[a][b];
+                    }
+                }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                if (a < nvy && b < nvx) phi(l.b.vlx + b, l.b.vly + a) = p[a + 1][b + 1];
+    }
+    __syncthreads();
+}
+
 constexpr int LOWV_WAVE_CELLS = 17*17;      // levels of at most this many points (walls included) are wave 0's alone
 
 // levels lv[0..nl-1] (finest first): cor[0] = lower-V(res[0]); mirrors the single-block bottom
@@ -813,7 +863,7 @@ template <bool CC>
 __global__ __launch_bounds__(1024)
 void k_lower_v (const LowLev* __restrict__ lv, int nl, const double* __restrict__ acf_g, const double* __restrict__ res_g,
                 double* __restrict__ cor_g, double facx0, double facy0, int nsweeps_bottom, StopRule sr, FView fine_res = FView{},
-                int wave_cells = 0)
+                int wave_cells = 0, int bottom_lane = 0)
 {
     if (!vcycle_active(sr)) return;
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
@@ -861,6 +911,9 @@ void k_lower_v (const LowLev* __restrict__ lv, int nl, const double* __restrict_
     MG_STAMP(11);
     if (nw >= nl) {
         const LowLev l = lv[nl - 1];
+        if (bottom_lane && l.b.vhx - l.b.vlx < 3 && l.b.vhy - l.b.vly < 3)
+            low_bottom_lane<CC>(base, l, low_fac(facx0, nl - 1), low_fac(facy0, nl - 1), nsweeps_bottom, n0, n1);
+        else
         low_sweeps<CC, false>(base, l, low_fac(facx0, nl - 1), low_fac(facy0, nl - 1), nsweeps_bottom, n0, n1);
     } else {
         if (threadIdx.x < 64) {
@@ -1754,6 +1807,7 @@ struct Multigrid {
     bool cc; int nx, ny; double dx, dy;
     bool post_fold = false; unsigned int* d_post_counter = nullptr;     // k_post_norms' work in the last V-cycle's level-0 launch (HPS_MG_POST_FOLD=1; measured: 1474 against 1481 slices/s, off)
     bool hierarchy_ready = false;               // mg_solve1_prepare has enqueued the coefficient hierarchy of the next solve
+    bool lowv_bottom_lane = true;                           // k_lower_v: a bottom level of at most 3 x 3 unknowns in one lane's registers (HPS_MG_LOWV_BOTTOM_LANE=0: as phases of the workgroup)
     int lowv_wave_cells = 0;                                // k_lower_v: levels of at most so many points are worked by wave 0 alone (HPS_MG_LOWV_WAVE=1: 17^2; measured SLOWER, see low_map: off)
     bool lowv_split = false; int lowv_threads = 1024;      // k_lower_v: one component per workgroup / threads per workgroup (HPS_MG_LOWV_SPLIT, HPS_MG_LOWV_THREADS)
     bool nodal_pull1 = false;                   // node-centred: level 1's down-leg smoother forms its right-hand side from level 0's residual itself (HPS_MG_NODAL_PULL1=0: a k_restrict launch)
@@ -1830,6 +1884,7 @@ int mg_create (int nx, int ny, double dx, double dy, Multigrid** out)
     // (node-centred grids: the split is the default -- Bx/By solve at 1023^2 375 -> 361 us per slice, 512 threads the same, 256 slower:
     //  profiles/r06_lowv_ab.txt; the cell-centred grids run k_lower_v3, which is built that way)
     {   const char* v = getenv("HPS_MG_LOWV_SPLIT"); M->lowv_split = v ? atoi(v) != 0 : !M->cc;
+        if (const char* b = getenv("HPS_MG_LOWV_BOTTOM_LANE")) M->lowv_bottom_lane = atoi(b) != 0;
         if (const char* w = getenv("HPS_MG_LOWV_WAVE")) M->lowv_wave_cells = atoi(w) != 0 ? (atoi(w) == 1 ? LOWV_WAVE_CELLS : atoi(w)) : 0;
         const char* t = getenv("HPS_MG_LOWV_THREADS"); if (t) { const int n = atoi(t); if (n == 256 || n == 512 || n == 1024) M->lowv_threads = n; } }
     if (!M->cc) {
@@ -2015,7 +2070,7 @@ static bool vcycle (Multigrid* M, int k, double tol_rel, double tol_abs, hipStre
                                1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr);
         else
             hipLaunchKernelGGL(k_lower_v<CC>, dim3(M->lowv_split ? 2 : 1), dim3(M->lowv_threads), M->low_lds, st, M->d_low, nl - lb, M->L[lb].acf, M->L[lb].res,
-                               M->L[lb].cor, 1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr, pulls(lb) ? M->lv(lb-1, M->L[lb-1].rescor) : FView{}, M->lowv_wave_cells);
+                               M->L[lb].cor, 1.0/(ldx*ldx), 1.0/(ldy*ldy), nsweeps, sr, pulls(lb) ? M->lv(lb-1, M->L[lb-1].rescor) : FView{}, M->lowv_wave_cells, M->lowv_bottom_lane ? 1 : 0);
     }
     // up-leg: the smoothed correction of level il lands in rescor[il] (out of place)
     for (int il = lb - 1; il >= 1; --il) {
