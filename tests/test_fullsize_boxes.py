@@ -220,12 +220,14 @@ def test_config2_baseline_deck_whole_box_vs_oracle_fixture(api):
     assert not bad, bad[:10]
 
 
-@pytest.mark.parametrize("name", ["config5_fft", "config5_mg", "config5_si_fft", "config5_si_mg"])
+@pytest.mark.parametrize("name", ["config5_fft", "config5_mg", "config5_si_fft", "config5_si_mg", "config5_si_mg_full"])
 def test_config5_whole_box_vs_oracle_fixture(api, name):
     """BASELINE configs[4] (laser envelope + N dopant with ADK ionisation), at the sizes the oracle's three envelope time
     levels fit host memory (see the fixture's `what`): in normalised units and -- as BASELINE names the deck -- in SI units
     (tests/laser_blowout_wake_explicit.SI.1Rank.sh; hipace.normalized_units = 0), the latter at 1024^2 with the multigrid
-    envelope solver (the reference's default, laser/MultiLaser.cpp:430-608)."""
+    envelope solver (the reference's default, laser/MultiLaser.cpp:430-608).  `config5_si_mg_full` (round 6) is configs[4] EXACTLY as
+    BASELINE names it -- laser_blowout_wake_explicit.SI 1024 x 1024 x 2048 -- over all of its 2048 slices: the oracle holds the envelope's
+    time levels in a rolling window there (tests/test_oracle_golden.py::test_envelope_rolling_window_equals_whole_box_time_levels)."""
     if not os.path.exists(os.path.join(GOLD, f"fullsize_{name}.json")):
         pytest.fail(f"fixture fullsize_{name}.json is missing (scripts/make_fullsize_fixtures.py writes it)")
     fx, got = _run_box(api, name)

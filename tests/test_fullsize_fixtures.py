@@ -18,7 +18,7 @@ def _script():
     return m
 
 
-@pytest.mark.parametrize("name", ["config2", "config2_beam_at_head", "config3", "config4", "config5_fft", "config5_mg", "config5_si_fft", "config5_si_mg"])
+@pytest.mark.parametrize("name", ["config2", "config2_beam_at_head", "config3", "config4", "config5_fft", "config5_mg", "config5_si_fft", "config5_si_mg", "config5_si_mg_full"])
 def test_fixture_is_of_the_deck_the_script_builds(name):
     m = _script()
     if not os.path.exists(os.path.join(GOLD, f"fullsize_{name}.json")):
