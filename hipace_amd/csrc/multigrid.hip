@@ -808,7 +808,7 @@ __device__ void low_up_level (lds_double* base, const LowLev& l, const LowLev& c
 // registers instead: the same expression per point ((rhs - offdiag) * 1/diag, offdiag<CC, false>'s), the same colour order; points
 // of one colour do not read one another, so doing them one after the other changes nothing.
 template <bool CC>
-__device__ void low_bottom_lane (lds_double* base, const LowLev& l, double facx, double facy, int nsweeps, int n0, int n1)
+__device__ void low_bottom_regs (lds_double* base, const LowLev& l, double facx, double facy, int nsweeps, int n0, int n1)
 {
     const int nvx = l.b.vhx - l.b.vlx + 1, nvy = l.b.vhy - l.b.vly + 1;      // <= 3 each (caller)
     for (int n = n0 + (int)threadIdx.x; n < n1; n += (int)blockDim.x) {       // (thread 0: component n0; thread 1: the other one without the split)
@@ -850,8 +850,123 @@ __device__ void low_bottom_lane (lds_double* base, const LowLev& l, double facx,
             for (int b = 0; b < 3; ++b)
                 if (a < nvy && b < nvx) phi(l.b.vlx + b, l.b.vly + a) = p[a + 1][b + 1];
     }
+}
+template <bool CC>
+__device__ void low_bottom_lane (lds_double* base, const LowLev& l, double facx, double facy, int nsweeps, int n0, int n1)
+{
+    low_bottom_regs<CC>(base, l, facx, facy, nsweeps, n0, n1);
     __syncthreads();
 }
+
+// ---- one wave, batched phases -------------------------------------------------------------------------------------------------
+// The lone-wave phases above lose because a phase of several trips is several dependent LDS round trips: the compiler cannot move
+// a trip's reads above the previous trip's writes (it does not know that a phase's outputs and inputs are disjoint planes / colours).
+// Here every phase has a compile-time number of trips (TJ x TI, predicates for the level's real extent), computes ALL of a lane's
+// points into registers first and stores them afterwards: one round trip per phase, as with k_lower_v3's register blocks.
+// Patches: 16 x 4 lanes over all points (TI trips of 16 columns, TJ of 4 rows); 8 x 8 lanes over the half-columns of one colour.
+template <int TJ, int TI, class F>
+__device__ __forceinline__ void wv_all (const LevBox& b, F&& f)            // f(i, j, slot): slot = compile-time-indexable trip number
+{
+    const int lane = (int)(threadIdx.x & 63), ti = lane & 15, tj = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < TJ; ++m)
+#pragma unroll
+        for (int q = 0; q < TI; ++q) {
+            const int j = b.vly + tj + 4*m, i = b.vlx + ti + 16*q;
+            f(i, j, m*TI + q, j <= b.vhy && i <= b.vhx);
+        }
+}
+template <bool CC, int TJ, int TI>          // TJ: trips of 8 rows, TI: trips of 16 columns (8 half-columns)
+__device__ void wv_sweeps (lds_double* base, const LowLev& l, double facx, double facy, int nsweeps, int n0, int n1)
+{
+    const int lane = (int)(threadIdx.x & 63), ti = lane & 7, tj = lane >> 3;
+    const LView cinv = lplane(base, l, 7);
+    const bool two = (n1 - n0) == 2;
+    const LView rhs0 = lplane(base, l, 1 + n0), phi0 = lplane(base, l, 3 + n0), rhs1 = lplane(base, l, n1), phi1 = lplane(base, l, 2 + n1);
+    for (int is = 0; is < nsweeps; ++is) {
+        double o0[TJ*TI], o1[TJ*TI];
+#pragma unroll
+        for (int m = 0; m < TJ; ++m)
+#pragma unroll
+            for (int q = 0; q < TI; ++q) {
+                const int j = l.b.vly + tj + 8*m, i = l.b.vlx + ((l.b.vlx + j + is) & 1) + 2*(ti + 8*q);
+                const bool ok = j <= l.b.vhy && i <= l.b.vhx;
+                const int ic = ok ? i : l.b.vlx, jc = ok ? j : l.b.vly;
+                const double ci = cinv(ic, jc);
+                o0[m*TI + q] = (rhs0(ic, jc) - offdiag<CC, false>((const lds_double*)&phi0(ic, jc), l.nxb, ic, jc, l.b, facx, facy))*ci;
+                o1[m*TI + q] = two ? (rhs1(ic, jc) - offdiag<CC, false>((const lds_double*)&phi1(ic, jc), l.nxb, ic, jc, l.b, facx, facy))*ci : 0.0;
+            }
+#pragma unroll
+        for (int m = 0; m < TJ; ++m)
+#pragma unroll
+            for (int q = 0; q < TI; ++q) {
+                const int j = l.b.vly + tj + 8*m, i = l.b.vlx + ((l.b.vlx + j + is) & 1) + 2*(ti + 8*q);
+                if (j <= l.b.vhy && i <= l.b.vhx) { phi0(i, j) = o0[m*TI + q]; if (two) phi1(i, j) = o1[m*TI + q]; }
+            }
+        low_sync<true>();
+    }
+}
+template <bool CC, int TJ, int TI>
+__device__ void wv_hier_level (lds_double* base, const LowLev& f, const LowLev& c)
+{
+    const LView fine = lplane(base, f, 0), crse = lplane(base, c, 0);
+    double o[TJ*TI];
+    wv_all<TJ, TI>(c.b, [&] (int i, int j, int k, bool ok) { o[k] = lrestrict<CC>(fine, ok ? i : c.b.vlx, ok ? j : c.b.vly); });
+    wv_all<TJ, TI>(c.b, [&] (int i, int j, int k, bool ok) { if (ok) crse(i, j) = o[k]; });
+    low_sync<true>();
+}
+template <bool CC, int TJ, int TI>
+__device__ void wv_cinv_level (lds_double* base, const LowLev& l, double fx, double fy)
+{
+    const LView acf = lplane(base, l, 0), cinv = lplane(base, l, 7);
+    double o[TJ*TI];
+    wv_all<TJ, TI>(l.b, [&] (int i, int j, int k, bool ok) { const int ic = ok ? i : l.b.vlx, jc = ok ? j : l.b.vly; o[k] = 1.0/diag_c0<CC>(ic, jc, l.b, acf(ic, jc), fx, fy); });
+    wv_all<TJ, TI>(l.b, [&] (int i, int j, int k, bool ok) { if (ok) cinv(i, j) = o[k]; });
+}
+template <bool CC, int TJ, int TI, int SJ, int SI>
+__device__ void wv_down_level (lds_double* base, const LowLev& l, const LowLev& c, double facx, double facy, int n0, int n1)
+{
+    wv_sweeps<CC, SJ, SI>(base, l, facx, facy, 4, n0, n1);
+    const bool two = (n1 - n0) == 2;
+    {   // residual -> rescor
+        const LView acf = lplane(base, l, 0);
+        const LView rhs0 = lplane(base, l, 1 + n0), phi0 = lplane(base, l, 3 + n0), rc0 = lplane(base, l, 5 + n0);
+        const LView rhs1 = lplane(base, l, n1), phi1 = lplane(base, l, 2 + n1), rc1 = lplane(base, l, 4 + n1);
+        double o0[TJ*TI], o1[TJ*TI];
+        wv_all<TJ, TI>(l.b, [&] (int i, int j, int k, bool ok) {
+            const int ic = ok ? i : l.b.vlx, jc = ok ? j : l.b.vly;
+            const double a = acf(ic, jc);
+            o0[k] = residual_at<false>((const lds_double*)&phi0(ic, jc), l.nxb, ic, jc, l.b, rhs0(ic, jc), a, facx, facy);
+            o1[k] = two ? residual_at<false>((const lds_double*)&phi1(ic, jc), l.nxb, ic, jc, l.b, rhs1(ic, jc), a, facx, facy) : 0.0; });
+        wv_all<TJ, TI>(l.b, [&] (int i, int j, int k, bool ok) { if (ok) { rc0(i, j) = o0[k]; if (two) rc1(i, j) = o1[k]; } });
+        low_sync<true>();
+    }
+    {   // restriction -> res of the next level
+        const LView rc0 = lplane(base, l, 5 + n0), rc1 = lplane(base, l, 4 + n1), r0 = lplane(base, c, 1 + n0), r1 = lplane(base, c, n1);
+        double o0[TJ*TI], o1[TJ*TI];
+        wv_all<TJ, TI>(c.b, [&] (int i, int j, int k, bool ok) {
+            const int ic = ok ? i : c.b.vlx, jc = ok ? j : c.b.vly;
+            o0[k] = lrestrict<CC>(rc0, ic, jc); o1[k] = two ? lrestrict<CC>(rc1, ic, jc) : 0.0; });
+        wv_all<TJ, TI>(c.b, [&] (int i, int j, int k, bool ok) { if (ok) { r0(i, j) = o0[k]; if (two) r1(i, j) = o1[k]; } });
+        low_sync<true>();
+    }
+}
+template <bool CC, int TJ, int TI, int SJ, int SI>
+__device__ void wv_up_level (lds_double* base, const LowLev& l, const LowLev& c, double facx, double facy, int n0, int n1)
+{
+    const bool two = (n1 - n0) == 2;
+    const LView f0 = lplane(base, l, 3 + n0), f1 = lplane(base, l, 2 + n1), c0 = lplane(base, c, 3 + n0), c1 = lplane(base, c, 2 + n1);
+    double o0[TJ*TI], o1[TJ*TI];
+    wv_all<TJ, TI>(l.b, [&] (int i, int j, int k, bool ok) {
+        const int ic = ok ? i : l.b.vlx, jc = ok ? j : l.b.vly;
+        o0[k] = f0(ic, jc) + lprolong<CC>(c0, ic, jc); o1[k] = two ? f1(ic, jc) + lprolong<CC>(c1, ic, jc) : 0.0; });
+    wv_all<TJ, TI>(l.b, [&] (int i, int j, int k, bool ok) { if (ok) { f0(i, j) = o0[k]; if (two) f1(i, j) = o1[k]; } });
+    low_sync<true>();
+    wv_sweeps<CC, SJ, SI>(base, l, facx, facy, 4, n0, n1);
+}
+// by the level's extent: up to 16 x 16 unknowns batched (trips 4 x 1 over all points, 2 x 1 over a colour); larger ones through the
+// unbatched helpers (batched with 8 x 2 trips the kernel spilled 757 registers under its 1024-thread cap)
+#define HPS_WV_DISPATCH(l, CALL_SMALL, CALL_BIG) do { if ((l).b.vhx - (l).b.vlx < 16 && (l).b.vhy - (l).b.vly < 16) { CALL_SMALL; } else { CALL_BIG; } } while (0)
 
 constexpr int LOWV_WAVE_CELLS = 17*17;      // levels of at most this many points (walls included) are wave 0's alone
 
@@ -918,13 +1033,25 @@ void k_lower_v (const LowLev* __restrict__ lv, int nl, const double* __restrict_
     } else {
         if (threadIdx.x < 64) {
             // wave 0: what is left of the coefficient hierarchy, the down-legs below the workgroup's levels, the bottom, the up-legs
-            for (int il = nw > 0 ? nw : 1; il < nl; ++il) { const LowLev f = lv[il - 1], c = lv[il]; low_hier_level<CC, true>(base, f, c); }
-            for (int il = nw; il < nl; ++il) { const LowLev l = lv[il]; low_cinv_level<CC, true>(base, l, low_fac(facx0, il), low_fac(facy0, il)); }
+            for (int il = nw > 0 ? nw : 1; il < nl; ++il) { const LowLev f = lv[il - 1], c = lv[il];
+                HPS_WV_DISPATCH(c, (wv_hier_level<CC, 4, 1>(base, f, c)), (low_hier_level<CC, true>(base, f, c))); }
+            for (int il = nw; il < nl; ++il) { const LowLev l = lv[il];
+                HPS_WV_DISPATCH(l, (wv_cinv_level<CC, 4, 1>(base, l, low_fac(facx0, il), low_fac(facy0, il))), (low_cinv_level<CC, true>(base, l, low_fac(facx0, il), low_fac(facy0, il)))); }
             low_sync<true>();
-            for (int il = nw; il < nl - 1; ++il) { const LowLev l = lv[il], c = lv[il + 1]; low_down_level<CC, true>(base, l, c, low_fac(facx0, il), low_fac(facy0, il), n0, n1); }
+            for (int il = nw; il < nl - 1; ++il) { const LowLev l = lv[il], c = lv[il + 1];
+                HPS_WV_DISPATCH(l, (wv_down_level<CC, 4, 1, 2, 1>(base, l, c, low_fac(facx0, il), low_fac(facy0, il), n0, n1)),
+                                   (low_down_level<CC, true>(base, l, c, low_fac(facx0, il), low_fac(facy0, il), n0, n1))); }
             {   const LowLev l = lv[nl - 1];
-                low_sweeps<CC, true>(base, l, low_fac(facx0, nl - 1), low_fac(facy0, nl - 1), nsweeps_bottom, n0, n1); }
-            for (int il = nl - 2; il >= nw; --il) { const LowLev l = lv[il], c = lv[il + 1]; low_up_level<CC, true>(base, l, c, low_fac(facx0, il), low_fac(facy0, il), n0, n1); }
+                if (bottom_lane && l.b.vhx - l.b.vlx < 3 && l.b.vhy - l.b.vly < 3) {
+                    // (one lane per component: thread 0, and thread 1 without the split; the helper's barrier is the workgroup's: not here)
+                    low_bottom_regs<CC>(base, l, low_fac(facx0, nl - 1), low_fac(facy0, nl - 1), nsweeps_bottom, n0, n1);
+                    low_sync<true>();
+                } else
+                HPS_WV_DISPATCH(l, (wv_sweeps<CC, 2, 1>(base, l, low_fac(facx0, nl - 1), low_fac(facy0, nl - 1), nsweeps_bottom, n0, n1)),
+                                   (low_sweeps<CC, true>(base, l, low_fac(facx0, nl - 1), low_fac(facy0, nl - 1), nsweeps_bottom, n0, n1))); }
+            for (int il = nl - 2; il >= nw; --il) { const LowLev l = lv[il], c = lv[il + 1];
+                HPS_WV_DISPATCH(l, (wv_up_level<CC, 4, 1, 2, 1>(base, l, c, low_fac(facx0, il), low_fac(facy0, il), n0, n1)),
+                                   (low_up_level<CC, true>(base, l, c, low_fac(facx0, il), low_fac(facy0, il), n0, n1))); }
         }
         __syncthreads();
     }
