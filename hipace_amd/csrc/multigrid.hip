@@ -18,6 +18,7 @@
 //  * k_lower_v: every level with <= 32x32 unknowns runs inside ONE 1024-thread workgroup with all
 //    its arrays in LDS (whole lower V incl. the 16 bottom sweeps), replacing ~4 launches per level.
 #include "common.h"
+#include <type_traits>
 #include "mg_gate.h"
 #include "slab_ops.h"
 
@@ -729,6 +730,48 @@ __device__ void low_sweeps (lds_double* base, const LowLev& l, double facx, doub
     const int ti = WAVE ? (int)(threadIdx.x & 7) : (int)(threadIdx.x & 15), tj = WAVE ? (int)((threadIdx.x & 63) >> 3) : (int)(threadIdx.x >> 4);
     const int si = WAVE ? 8 : 16, sj = WAVE ? 8 : (int)(blockDim.x >> 4);
     const LView cinv = lplane(base, l, 7);
+    if (!WAVE && !CC && l.b.vhy - l.b.vly < sj && l.b.vhx - l.b.vlx < 2*si) {
+        // One trip per thread (every level the node-centred lower V holds): the thread's row is fixed and its point alternates
+        // between two columns with the colour -- both points' offsets, coefficients and right-hand sides are set up ONCE, ahead
+        // of the half-sweeps, whose bodies are then four neighbour reads, six fp64 operations and a store.  (The stamps had
+        // shown the phases bound by their instruction streams: the generic views' index arithmetic and the loops' exec-mask
+        // control were most of a phase's 130-250 instructions.)  No wall variants on node-centred levels: walls hold zeros.
+        const int j = l.b.vly + tj;
+        const bool rowok = j <= l.b.vhy;
+        const int jc = rowok ? j : l.b.vly;
+        int off[2]; bool ok[2]; double ci[2], r0[2], r1[2];
+        const bool two = (n1 - n0) == 2;
+        lds_double* ph0 = base + l.off + (3 + n0)*l.cells;
+        lds_double* ph1 = base + l.off + (2 + n1)*l.cells;
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {            // par = is & 1
+            const int i = l.b.vlx + ((l.b.vlx + jc + par) & 1) + 2*ti;
+            ok[par] = rowok && i <= l.b.vhx;
+            const int ic = ok[par] ? i : l.b.vlx;
+            off[par] = (ic - l.b.lox) + (jc - l.b.loy)*l.nxb;
+            ci[par] = cinv(ic, jc);
+            r0[par] = base[l.off + (1 + n0)*l.cells + off[par]];
+            r1[par] = base[l.off + n1*l.cells + off[par]];
+        }
+        const int sy = l.nxb;
+        for (int is = 0; is < nsweeps; ++is) {
+            const int par = is & 1;
+            const int o = par ? off[1] : off[0];
+            const bool k = par ? ok[1] : ok[0];
+            const double c = par ? ci[1] : ci[0], ra = par ? r0[1] : r0[0], rb = par ? r1[1] : r1[0];
+            if (k) {
+                {   const lds_double* q = ph0 + o;
+                    const double w = q[-1], e = q[1], so = q[-sy], no = q[sy];
+                    ph0[o] = (ra - (facx*(w + e) + facy*(so + no)))*c; }
+                if (two) {
+                    const lds_double* q = ph1 + o;
+                    const double w = q[-1], e = q[1], so = q[-sy], no = q[sy];
+                    ph1[o] = (rb - (facx*(w + e) + facy*(so + no)))*c; }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (int is = 0; is < nsweeps; ++is) {
         for (int j = l.b.vly + tj; j <= l.b.vhy; j += sj) {
             for (int i = l.b.vlx + ((l.b.vlx + j + is) & 1) + 2*ti; i <= l.b.vhx; i += 2*si) {      // (i + j + is) even
@@ -807,13 +850,14 @@ __device__ void low_up_level (lds_double* base, const LowLev& l, const LowLev& c
 // whole workgroup that was 16 x ~1100 clocks, a quarter of the kernel, for nine numbers.  One lane per component does them in
 // registers instead: the same expression per point ((rhs - offdiag) * 1/diag, offdiag<CC, false>'s), the same colour order; points
 // of one colour do not read one another, so doing them one after the other changes nothing.
-template <bool CC>
-__device__ void low_bottom_regs (lds_double* base, const LowLev& l, double facx, double facy, int nsweeps, int n0, int n1)
+template <bool CC, int P0>          // P0 = (vlx + vly) & 1: the colour of the level's first unknown, so that every point's colour is a constant
+__device__ __forceinline__ void low_bottom_regs_p (lds_double* base, const LowLev& l, double facx, double facy, int nsweeps, int n0, int n1)
 {
     const int nvx = l.b.vhx - l.b.vlx + 1, nvy = l.b.vhy - l.b.vly + 1;      // <= 3 each (caller)
     for (int n = n0 + (int)threadIdx.x; n < n1; n += (int)blockDim.x) {       // (thread 0: component n0; thread 1: the other one without the split)
         const LView rhs = lplane(base, l, 1 + n), phi = lplane(base, l, 3 + n), cinv = lplane(base, l, 7);
         double p[5][5], r[3][3], c[3][3];
+        bool ok[3][3];
 #pragma unroll
         for (int a = 0; a < 5; ++a)
 #pragma unroll
@@ -822,34 +866,45 @@ __device__ void low_bottom_regs (lds_double* base, const LowLev& l, double facx,
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
-                const bool ok = a < nvy && b < nvx;
-                r[a][b] = ok ? rhs(l.b.vlx + b, l.b.vly + a) : 0.0;
-                c[a][b] = ok ? cinv(l.b.vlx + b, l.b.vly + a) : 0.0;
+                ok[a][b] = a < nvy && b < nvx;
+                r[a][b] = ok[a][b] ? rhs(l.b.vlx + b, l.b.vly + a) : 0.0;
+                c[a][b] = ok[a][b] ? cinv(l.b.vlx + b, l.b.vly + a) : 0.0;
             }
-        for (int is = 0; is < nsweeps; ++is) {
+        // one half-sweep: the points of colour `col` (compile-time), straight-line
+        auto half = [&] (auto colc) {
+            constexpr int col = decltype(colc)::value;
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int b = 0; b < 3; ++b) {
+                    if (((a + b + P0 + col) & 1) != 0) continue;                // (i + j + is) even  <=>  (a + b + P0 + is) even
                     const int i = l.b.vlx + b, j = l.b.vly + a;
-                    if (a < nvy && b < nvx && ((i + j + is) & 1) == 0) {
-                        const double w = p[a + 1][b], e = p[a + 1][b + 2], so = p[a][b + 1], no = p[a + 2][b + 1];
-                        double lx = facx*(w + e), ly = facy*(so + no);
-                        if (CC) {
-                            const double fx43 = facx*(4./3.), fy43 = facy*(4./3.);
-                            lx = (i == l.b.lox) ? fx43*e : ((i == l.b.hix) ? fx43*w : lx);
-                            ly = (j == l.b.loy) ? fy43*no : ((j == l.b.hiy) ? fy43*so : ly);
-                        }
-                        p[a + 1][b + 1] = (r[a][b] - (lx + ly))*c[a][b];
+                    const double w = p[a + 1][b], e = p[a + 1][b + 2], so = p[a][b + 1], no = p[a + 2][b + 1];
+                    double lx = facx*(w + e), ly = facy*(so + no);
+                    if (CC) {
+                        const double fx43 = facx*(4./3.), fy43 = facy*(4./3.);
+                        lx = (i == l.b.lox) ? fx43*e : ((i == l.b.hix) ? fx43*w : lx);
+                        ly = (j == l.b.loy) ? fy43*no : ((j == l.b.hiy) ? fy43*so : ly);
                     }
+                    const double v = (r[a][b] - (lx + ly))*c[a][b];
+                    p[a + 1][b + 1] = ok[a][b] ? v : p[a + 1][b + 1];
                 }
-        }
+        };
+        int is = 0;
+        for (; is + 1 < nsweeps; is += 2) { half(std::integral_constant<int, 0>{}); half(std::integral_constant<int, 1>{}); }
+        if (is < nsweeps) half(std::integral_constant<int, 0>{});
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b)
-                if (a < nvy && b < nvx) phi(l.b.vlx + b, l.b.vly + a) = p[a + 1][b + 1];
+                if (ok[a][b]) phi(l.b.vlx + b, l.b.vly + a) = p[a + 1][b + 1];
     }
+}
+template <bool CC>
+__device__ void low_bottom_regs (lds_double* base, const LowLev& l, double facx, double facy, int nsweeps, int n0, int n1)
+{
+    if (((l.b.vlx + l.b.vly) & 1) == 0) low_bottom_regs_p<CC, 0>(base, l, facx, facy, nsweeps, n0, n1);
+    else low_bottom_regs_p<CC, 1>(base, l, facx, facy, nsweeps, n0, n1);
 }
 template <bool CC>
 __device__ void low_bottom_lane (lds_double* base, const LowLev& l, double facx, double facy, int nsweeps, int n0, int n1)
