@@ -30,6 +30,7 @@ filled before the clock starts (rank r runs 2r slices behind rank 0, as the hand
 rank times K slices.
 """
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -788,12 +789,18 @@ def main():
                     barrier()
                 stats0.update(eng.stats())
                 profiling(True)
+                # (the host reads the multigrid's norms once per slice: a collection pass of the interpreter inside a 12 ms window
+                #  is a per-cent-level hiccup -- one run in ~40 showed 1283 instead of 1700; no collection while the clock runs)
+                gc.freeze()
+                gc.disable()
                 clock["t0"] = time.perf_counter()
             elif q == first + args.steps:
                 eng.sync()
                 if transport is not None:
                     transport.sync_sends()
                 clock["t1"] = time.perf_counter()
+                gc.enable()
+                gc.unfreeze()
 
         if world == 1:
             eng.begin_step()
@@ -843,6 +850,8 @@ def main():
         barrier()
         stats0.update(eng.stats())
         profiling(True)
+        gc.freeze()
+        gc.disable()
         t0 = time.perf_counter()
         if world == 1 and args.ring_self:
             from hipace_amd.pipeline import run_pipeline
@@ -861,6 +870,8 @@ def main():
             args.steps = run_pipeline(eng, rank, world, world * steps_per_rank, dev, transport=transport, handoff_batch=args.handoff_batch)
         barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
+        gc.unfreeze()
     phases, nprof = phases_timed if phases_timed is not None else eng.phase_times()
     eng.set_profiling(False)
     for e in engines[1:]:            # phase times: mean over the lanes (intervals overlap in wall time)
