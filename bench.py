@@ -415,6 +415,11 @@ def supervise_legs(args, rank, world):
     `ring_edges` = what every leg measured or why it could not, `rccl_ranks_seen` = the RCCL leg's count whichever leg won."""
     import signal
     import tempfile
+    try:      # (and the supervisor goes when the launcher does, taking its worker with it: see die_with_parent)
+        import ctypes
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM, 0, 0, 0)
+    except Exception:      # noqa: BLE001
+        pass
     kinds = [args.edge] if args.edge else (["ipc"] if args.same_device else ["ipc", "rccl"])
     argv, skip = [], False
     for a in sys.argv[1:]:
@@ -438,8 +443,17 @@ def supervise_legs(args, rank, world):
         env.setdefault("HPS_RING_CONNECT_TIMEOUT_S", "120")
         errf = tempfile.TemporaryFile(mode="w+")
         t0 = time.perf_counter()
+        def die_with_parent():
+            # a worker must not outlive its supervisor (a driver that kills the launcher at ITS limit would otherwise leave the
+            # workers, in sessions of their own, on the GPUs until their watchdogs fire): SIGKILL when the parent goes
+            try:
+                import ctypes
+                ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGKILL, 0, 0, 0)      # PR_SET_PDEATHSIG
+            except Exception:      # noqa: BLE001
+                pass
+
         p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ["--leg", kind, "--watchdog", str(max(30.0, args.leg_timeout - 15.0))],
-                             env=env, stdout=subprocess.PIPE, stderr=errf, text=True, start_new_session=True)
+                             env=env, stdout=subprocess.PIPE, stderr=errf, text=True, start_new_session=True, preexec_fn=die_with_parent)
         timed_out = False
         try:
             out, _ = p.communicate(timeout=args.leg_timeout)
