@@ -582,8 +582,8 @@ class SliceEngine:
         return its.value, err.value
 
     def pc_zero_b_slices(self):
-        """slices on which the predictor-corrector loop left after one pass because sum |B| was 0 -- exactly or under the
-        engine's rounding floor (HPS_PC_NOISE_FLOOR)"""
+        """slices on which the predictor-corrector loop left after one pass because sum |B| of its guess was 0 (the serial
+        path's exact zeros ahead of the beam, which the engine reproduces: INTEGRATION.md)"""
         n = C.c_long()
         check(_lib.lib().hps_engine_pc_zero_b_slices(self._h, C.byref(n)))
         return n.value
